@@ -1,0 +1,347 @@
+"""ORACLE -- TEST INFRASTRUCTURE ONLY.  Never imported by the product package (mliis_amd/).
+
+CPU restatement (PyTorch-CPU, float64 by default, autograd supplies every backward) of the reference's
+EfficientLab graph and one inner optimisation step.  Only tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg may import this module.
+
+PARITY STATUS: **parity unpinned** for the numeric graph.  The reference computes this path inside
+tensorflow==1.15.4 (requirements.txt:1), which is neither vendored under /root/reference nor installable here
+(Python 3.10, no network), and the reference ships no tests / golden vectors for it.  This file
+restates the graph from the reference's graph-construction code and TF's documented op semantics; it is anchored by
+hand-derivable known-answer tests (tests/test_oracle_kat.py).  The *host logic* oracle (oracle/host_ref.py) IS pinned
+against values produced by importing the reference's own numpy code (tests/golden/host_logic.json).
+
+Reference lines followed:
+  graph         models/efficientlab.py:111-119 (normalise), :126-177 (decode), :179-231 (RSD), :294-327 (loss/opt)
+  backbone      models/efficientnet/efficientnet_model.py:170-290 (MBConv), :326-371,396-441 (stem/blocks/endpoints)
+  architecture  models/efficientnet/efficientnet_builder.py:29-42,90-109,125-149
+  BN/dropconn   models/efficientnet/utils.py:87-134,157-170
+  L2            models/regularizers.py:4-10
+  init          models/efficientnet/efficientnet_model.py:61-82; TF glorot_uniform default for tf.layers.conv2d
+TF semantics restated from documentation: SAME padding, non-fused BN (biased variance everywhere; moving stats
+`m -= (m - stat) * (1 - 0.99)`), fused BN in the decoder (unbiased variance into the moving average), bilinear
+resize with align_corners=True, tf.losses.softmax_cross_entropy (mean over rows), GradientDescentOptimizer.
+"""
+from __future__ import annotations
+
+import math
+import re
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+MEAN = [0.485 * 255, 0.456 * 255, 0.406 * 255]
+STD = [0.229 * 255, 0.224 * 255, 0.225 * 255]
+EPS = 1e-3
+MOMENTUM = 0.99
+
+_B0_NOTATION = "r1k3s1e1i32o16 r2k3s2e6i16o24 r2k5s2e6i24o40 r3k3s2e6i40o80 r3k5s1e6i80o112 r4k5s2e6i112o192 r1k3s1e6i192o320"
+_SCALE = {"efficientnet-b0": (1.0, 1.0, 10, 112), "efficientnet-b3": (1.2, 1.4, 17, 136)}
+
+
+# ------------------------------------------------------------------------------------------------ architecture
+def _rf(f, w):
+    f2 = f * w
+    n = max(8, int(f2 + 4) // 8 * 8)
+    return int(n + 8 if n < 0.9 * f2 else n)
+
+
+def arch(name="efficientnet-b0", image_size=224, rsd=(2, 4)):
+    w, d, max_block, dec_c = _SCALE[name]
+    blocks, cum = [], 0
+    for tok in _B0_NOTATION.split():
+        r, k, s, e, i, o = map(int, re.match(r"r(\d+)k(\d+)s(\d+)e(\d+)i(\d+)o(\d+)", tok).groups())
+        cum += r
+        if cum > max_block + 1:
+            break
+        i, o, r = _rf(i, w), _rf(o, w), int(math.ceil(d * r))
+        for j in range(r):
+            blocks.append(dict(k=k, s=s if j == 0 else 1, e=e, i=i if j == 0 else o, o=o))
+    n = len(blocks)
+    red, endpoints = 0, {}
+    for j, b in enumerate(blocks):
+        b["idx"] = j
+        b["se"] = max(1, int(b["i"] * 0.25))
+        b["drop"] = 0.2 * j / n
+        if j == n - 1 or blocks[j + 1]["s"] > 1:
+            red += 1
+            endpoints[red] = j
+    return dict(name=name, blocks=blocks, endpoints=endpoints, dec_c=dec_c, rsd=sorted(rsd or [], reverse=True),
+                stem=_rf(32, w), last=endpoints[4], image_size=image_size)
+
+
+def param_specs(a) -> List[Tuple[str, Tuple[int, ...], str]]:
+    """(name, shape, init) of all TRAINABLE variables in creation order, then names of BN layers."""
+    fe = a["name"]
+    out = [(f"{fe}/stem/conv2d/kernel", (3, 3, 3, a["stem"]), "normal")]
+    out += [(f"{fe}/stem/tpu_batch_normalization/gamma", (a["stem"],), "ones"),
+            (f"{fe}/stem/tpu_batch_normalization/beta", (a["stem"],), "zeros")]
+    for b in a["blocks"]:
+        s, ce = f"{fe}/blocks_{b['idx']}", b["i"] * b["e"]
+        bn = ["tpu_batch_normalization", "tpu_batch_normalization_1", "tpu_batch_normalization_2"]
+        cv = ["conv2d", "conv2d_1"]
+        if b["e"] != 1:
+            out += [(f"{s}/{cv.pop(0)}/kernel", (1, 1, b["i"], ce), "normal")]
+            n = bn.pop(0)
+            out += [(f"{s}/{n}/gamma", (ce,), "ones"), (f"{s}/{n}/beta", (ce,), "zeros")]
+        out += [(f"{s}/depthwise_conv2d/depthwise_kernel", (b["k"], b["k"], ce, 1), "normal")]
+        n = bn.pop(0)
+        out += [(f"{s}/{n}/gamma", (ce,), "ones"), (f"{s}/{n}/beta", (ce,), "zeros")]
+        out += [(f"{s}/se/conv2d/kernel", (1, 1, ce, b["se"]), "normal"), (f"{s}/se/conv2d/bias", (b["se"],), "zeros"),
+                (f"{s}/se/conv2d_1/kernel", (1, 1, b["se"], ce), "normal"), (f"{s}/se/conv2d_1/bias", (ce,), "zeros")]
+        out += [(f"{s}/{cv.pop(0)}/kernel", (1, 1, ce, b["o"]), "normal")]
+        n = bn.pop(0)
+        out += [(f"{s}/{n}/gamma", (b["o"],), "ones"), (f"{s}/{n}/beta", (b["o"],), "zeros")]
+    deep = a["blocks"][a["last"]]["o"]
+    for r in a["rsd"]:
+        s = f"decode/decode_skip_connections_{r - 1}"
+        cs = a["blocks"][a["endpoints"][r]]["o"]
+        cc, co = deep + cs, a["dec_c"]
+        assert deep == co, "upsample 1x1 branch not restated (never hit for b0/b3 with rsd 2 4)"
+        for j, (k, ci) in enumerate([(1, cc), (3, cc), (3, 2 * co + cc)]):
+            sfx = "" if j == 0 else f"_{j}"
+            out += [(f"{s}/conv2d{sfx}/kernel", (k, k, ci, co), "glorot"), (f"{s}/conv2d{sfx}/bias", (co,), "zeros"),
+                    (f"{s}/batch_normalization{sfx}/gamma", (co,), "ones"),
+                    (f"{s}/batch_normalization{sfx}/beta", (co,), "zeros")]
+        deep = co
+    out += [("decode/final_layer_weights/kernel", (1, 1, a["dec_c"], 2), "normal"),
+            ("decode/final_layer_weights/bias", (2,), "zeros")]
+    return out
+
+
+def init_state(a, seed=0, dtype=torch.float64):
+    """Returns (params: ordered dict name->tensor, bn: dict bn_prefix->(moving_mean, moving_var))."""
+    g = np.random.default_rng(seed)
+    params, bn = {}, {}
+    for name, shape, init in param_specs(a):
+        if init == "normal":     # conv_kernel_initializer: N(0, sqrt(2 / (kh*kw*out)))
+            v = g.standard_normal(shape) * math.sqrt(2.0 / (shape[0] * shape[1] * shape[3]))
+        elif init == "glorot":   # glorot_uniform: U(-l, l), l = sqrt(6/(fan_in+fan_out)), receptive field included
+            rf = shape[0] * shape[1]
+            lim = math.sqrt(6.0 / (rf * shape[2] + rf * shape[3]))
+            v = g.uniform(-lim, lim, shape)
+        elif init == "ones":
+            v = np.ones(shape)
+        else:
+            v = np.zeros(shape)
+        params[name] = torch.tensor(v, dtype=dtype)
+        if name.endswith("/gamma"):
+            p = name[: -len("/gamma")]
+            bn[p] = (torch.zeros(shape, dtype=dtype), torch.ones(shape, dtype=dtype))
+    return params, bn
+
+
+# ------------------------------------------------------------------------------------------------------ ops
+def same_pad_amounts(size, k, s, d=1):
+    out = -(-size // s)
+    tot = max((out - 1) * s + (k - 1) * d + 1 - size, 0)
+    return tot // 2, tot - tot // 2
+
+
+def conv2d_same(x, w_hwio, stride=1, dilation=1, bias=None, groups=1):
+    """x: NCHW; w: TF HWIO (depthwise: HW,C,1 with groups=C)."""
+    kh, kw = w_hwio.shape[:2]
+    pt, pb = same_pad_amounts(x.shape[2], kh, stride, dilation)
+    pl, pr = same_pad_amounts(x.shape[3], kw, stride, dilation)
+    x = F.pad(x, (pl, pr, pt, pb))
+    if groups == 1:
+        w = w_hwio.permute(3, 2, 0, 1)
+    else:
+        w = w_hwio.permute(2, 3, 0, 1)  # (C,1,kh,kw)
+    return F.conv2d(x, w, bias, stride=stride, dilation=dilation, groups=groups)
+
+
+def swish(x):
+    return x * torch.sigmoid(x)
+
+
+def batch_norm(x, gamma, beta, moving, training, new_moving: Optional[dict], key, fused):
+    """x: NCHW.  training: batch stats (biased var for normalisation).  Records the EMA target in new_moving."""
+    if training:
+        mean = x.mean(dim=(0, 2, 3))
+        var = ((x - mean[None, :, None, None]) ** 2).mean(dim=(0, 2, 3))
+        if new_moving is not None:
+            n = x.numel() // x.shape[1]
+            v_ema = var * (n / (n - 1.0)) if fused else var
+            mm, mv = moving
+            d = 1.0 - MOMENTUM
+            new_moving[key] = ((mm - (mm - mean.detach()) * d), (mv - (mv - v_ema.detach()) * d))
+    else:
+        mean, var = moving
+    inv = torch.rsqrt(var + EPS)
+    return (x - mean[None, :, None, None]) * (inv * gamma)[None, :, None, None] + beta[None, :, None, None]
+
+
+def resize_bilinear_ac(x, size):
+    if tuple(x.shape[2:]) == tuple(size):
+        return x
+    return F.interpolate(x, size=size, mode="bilinear", align_corners=True)
+
+
+# -------------------------------------------------------------------------------------------------- forward
+def forward(a, params, bn, x_nhwc, training=True, dc_scales: Optional[Dict[int, torch.Tensor]] = None,
+            dropout_mask: Optional[torch.Tensor] = None, taps: Optional[dict] = None):
+    """x_nhwc: [N,H,W,3] in 0..255.  dc_scales[block_idx]: [N] tensor of 0 or 1/keep (training only; None -> no
+    drop-connect).  dropout_mask: [N,h,w,C] of 0 or 1/(1-rate) applied before the final 1x1.  Returns
+    (logits NHWC, new_moving dict).  `taps` (optional dict) receives named intermediates in NHWC."""
+    fe = a["name"]
+    P = params
+    new_moving = {} if training else None
+    dt = P[f"{fe}/stem/conv2d/kernel"].dtype
+    x = x_nhwc.to(dt)
+    x = (x - torch.tensor(MEAN, dtype=dt)) / torch.tensor(STD, dtype=dt)
+    x = x.permute(0, 3, 1, 2)
+
+    def BN(t, prefix, fused=False):
+        return batch_norm(t, P[prefix + "/gamma"], P[prefix + "/beta"], bn[prefix], training, new_moving, prefix, fused)
+
+    def tap(name, t):
+        if taps is not None:
+            taps[name] = t.permute(0, 2, 3, 1)
+
+    x = swish(BN(conv2d_same(x, P[f"{fe}/stem/conv2d/kernel"], 2), f"{fe}/stem/tpu_batch_normalization"))
+    tap("stem", x)
+    ends = {}
+    inv_end = {v: k for k, v in a["endpoints"].items()}
+    for b in a["blocks"][: a["last"] + 1]:
+        s = f"{fe}/blocks_{b['idx']}"
+        bns = [f"{s}/tpu_batch_normalization", f"{s}/tpu_batch_normalization_1", f"{s}/tpu_batch_normalization_2"]
+        cvs = [f"{s}/conv2d/kernel", f"{s}/conv2d_1/kernel"]
+        inp = x
+        if b["e"] != 1:
+            x = swish(BN(conv2d_same(x, P[cvs.pop(0)]), bns.pop(0)))
+        ce = x.shape[1]
+        x = swish(BN(conv2d_same(x, P[f"{s}/depthwise_conv2d/depthwise_kernel"], b["s"], groups=ce), bns.pop(0)))
+        sq = x.mean(dim=(2, 3), keepdim=True)
+        sq = swish(conv2d_same(sq, P[f"{s}/se/conv2d/kernel"], bias=P[f"{s}/se/conv2d/bias"]))
+        sq = conv2d_same(sq, P[f"{s}/se/conv2d_1/kernel"], bias=P[f"{s}/se/conv2d_1/bias"])
+        x = torch.sigmoid(sq) * x
+        x = BN(conv2d_same(x, P[cvs.pop(0)]), bns.pop(0))
+        if b["s"] == 1 and b["i"] == b["o"]:
+            if training and b["drop"] and dc_scales is not None and b["idx"] in dc_scales:
+                x = x * dc_scales[b["idx"]].to(dt)[:, None, None, None]
+            x = x + inp
+        tap(f"block_{b['idx']}", x)
+        if b["idx"] in inv_end:
+            ends[inv_end[b["idx"]]] = x
+    dec = ends[4]
+    for r in a["rsd"]:
+        s = f"decode/decode_skip_connections_{r - 1}"
+        skip = ends[r]
+        up = resize_bilinear_ac(dec, skip.shape[2:])
+        cat = torch.cat([up, skip], dim=1)
+
+        def branch(t, j, k, d):
+            sfx = "" if j == 0 else f"_{j}"
+            t = conv2d_same(t, P[f"{s}/conv2d{sfx}/kernel"], 1, d, bias=P[f"{s}/conv2d{sfx}/bias"])
+            return BN(swish(t), f"{s}/batch_normalization{sfx}", fused=True)
+        b0 = branch(cat, 0, 1, 1)
+        b1 = branch(cat, 1, 3, 2)
+        b2 = cat.mean(dim=(2, 3), keepdim=True).expand_as(cat)
+        dec = branch(torch.cat([b0, b1, b2], dim=1), 2, 3, 1) + up
+        tap(f"rsd_{r}", dec)
+    if dropout_mask is not None and training:
+        dec = dec * dropout_mask.to(dt).permute(0, 3, 1, 2)
+    dec = conv2d_same(dec, P["decode/final_layer_weights/kernel"], bias=P["decode/final_layer_weights/bias"])
+    tap("final_small", dec)
+    H = x_nhwc.shape[1]
+    logits = resize_bilinear_ac(dec, (H, x_nhwc.shape[2]))
+    return logits.permute(0, 2, 3, 1), new_moving
+
+
+def loss_fn(a, params, logits, labels, label_smoothing=0.0, dice=False, l2=False):
+    """models/efficientlab.py:294-313.  logits/labels NHWC [N,H,W,2]."""
+    t = labels.to(logits.dtype)
+    if label_smoothing:
+        t = t * (1 - label_smoothing) + label_smoothing / 2
+    logp = F.log_softmax(logits, dim=-1)
+    # tf.losses.softmax_cross_entropy: weights=1, SUM_BY_NONZERO_WEIGHTS -> mean over rows
+    loss = -(t * logp).sum(-1).mean()
+    if dice:
+        p1 = torch.softmax(logits, dim=-1)[..., 1].flatten(1)
+        t1 = labels.to(logits.dtype)[..., 1].flatten(1)
+        inter = (p1 * t1).sum(1)
+        den = p1.sum(1) + t1.sum(1) - inter
+        iou = ((inter + 1e-7) / (den + 1e-7)).mean()
+        loss = loss - torch.log(2 * iou / (iou + 1))
+    if l2:
+        loss = loss + 0.0005 * sum(0.5 * (v ** 2).sum() for k, v in params.items() if "batch_normalization" not in k)
+    return loss
+
+
+def predictions(logits):
+    """(softmax > 0.5) as float, models/efficientlab.py:174-176,291-292."""
+    return (torch.softmax(logits, dim=-1) > 0.5).to(logits.dtype)
+
+
+def inner_step(a, params, bn, x, y, lr, dc_scales=None, dropout_mask=None, label_smoothing=0.0, dice=False, l2=False,
+               weight_decay_rate=1.0):
+    """One `session.run(minimize_op)` (reptile.py:114-121,639-643): fwd + bwd + BN moving update + SGD apply.
+    Mutates params / bn in place; returns (loss, grads dict, logits)."""
+    if weight_decay_rate != 1.0:  # pre_step_op, meta_learners/variables.py:48-55
+        for k in params:
+            params[k] = params[k] * weight_decay_rate
+    leaves = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()}
+    logits, new_moving = forward(a, leaves, bn, x, True, dc_scales, dropout_mask)
+    loss = loss_fn(a, leaves, logits, y, label_smoothing, dice, l2)
+    names = list(leaves)
+    grads = torch.autograd.grad(loss, [leaves[k] for k in names], allow_unused=True)
+    out_g = {}
+    for k, g in zip(names, grads):
+        if g is None:
+            g = torch.zeros_like(params[k])
+        out_g[k] = g
+        params[k] = params[k] - lr * g
+    for k, v in new_moving.items():
+        bn[k] = v
+    return float(loss.detach()), out_g, logits.detach()
+
+
+# ------------------------------------------------------------------------------- Learner protocol (for tests / baseline)
+class OracleLearner:
+    """Implements the same Learner protocol as mliis_amd.learner.Learner on the CPU restatement, so the
+    meta-learner host logic (Gecko/FOMLIS, sharding, all-reduce) can be exercised without a GPU."""
+
+    def __init__(self, name="efficientnet-b0", image_size=224, rsd=(2, 4), seed=0, dtype=torch.float64, lr=1e-3,
+                 l2=False, dice=False, label_smoothing=0.0, drop_connect=True):
+        self.a = arch(name, image_size, rsd)
+        self.params, self.bn = init_state(self.a, seed, dtype)
+        self.dtype, self.lr, self.l2, self.dice, self.ls = dtype, lr, l2, dice, label_smoothing
+        self.drop_connect = drop_connect
+        self.names = list(self.params)
+        self.sizes = [self.params[k].numel() for k in self.names]
+        self.bn_names = list(self.bn)
+        self.n_trainable = sum(self.sizes)
+
+    # -- variable state (meta_learners/variables.py:58-80)
+    def export_trainable(self) -> torch.Tensor:
+        return torch.cat([self.params[k].reshape(-1) for k in self.names]).clone()
+
+    def import_trainable(self, flat: torch.Tensor):
+        off = 0
+        for k, n in zip(self.names, self.sizes):
+            self.params[k] = flat[off:off + n].reshape(self.params[k].shape).to(self.dtype).clone()
+            off += n
+
+    def export_bn(self) -> torch.Tensor:
+        return torch.cat([torch.cat([self.bn[k][0], self.bn[k][1]]) for k in self.bn_names]).clone()
+
+    def import_bn(self, flat: torch.Tensor):
+        off = 0
+        for k in self.bn_names:
+            c = self.bn[k][0].numel()
+            self.bn[k] = (flat[off:off + c].clone().to(self.dtype), flat[off + c:off + 2 * c].clone().to(self.dtype))
+            off += 2 * c
+
+    def inner_step(self, x, y, lr=None, dc_scales=None, dropout_mask=None, weight_decay_rate=1.0):
+        loss, _, _ = inner_step(self.a, self.params, self.bn, x, y, self.lr if lr is None else lr,
+                                dc_scales if self.drop_connect else None, dropout_mask, self.ls, self.dice, self.l2,
+                                weight_decay_rate)
+        return loss
+
+    def predict(self, x, training=False):
+        with torch.no_grad():
+            logits, _ = forward(self.a, self.params, self.bn, x, training)
+        return predictions(logits)
