@@ -1,0 +1,156 @@
+/* libmliis_hip -- C ABI of the MI355X (gfx950) inner-loop kernels for EfficientLab.
+ *
+ * The reference (ml4ai/mliis) has no FFI: its hot path crosses from Python into the TensorFlow 1.15 runtime at
+ * `session.run(model.minimize_op, feed_dict=...)` (meta_learners/supervised_reptile/supervised_reptile/reptile.py:114-121,
+ * 639-643).  Each entry point below replaces the TF op(s) named in its comment (file:line of the graph-construction call
+ * that creates the op).  INTEGRATION.md shows the ctypes binding a maintainer would add.
+ *
+ * Conventions
+ *   - all device buffers are caller-owned fp32, NHWC; a tensor [N,H,W,C] is passed as a 2-D view [rows = N*H*W][C] with a
+ *     row stride `ld*` in floats (so slices of channel-concatenated buffers are passed without copies);
+ *   - pointers 16-byte aligned, channel counts and leading dimensions multiples of 4, unless a comment says otherwise;
+ *   - no allocation, no synchronisation, no global mutable state: every call only enqueues kernels on `stream`;
+ *     scratch comes from a caller-provided workspace whose size the matching *_workspace_floats() returns;
+ *   - returns MLIIS_OK (0) or a negative MLIIS_ERR_*; mliis_last_error() returns a thread-local message;
+ *   - reductions are deterministic (two-stage, no float atomics): identical inputs give bit-identical outputs.
+ */
+#ifndef MLIIS_HIP_H
+#define MLIIS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifndef __HIP__
+typedef struct ihipStream_t* hipStream_t;
+#endif
+
+#define MLIIS_OK 0
+#define MLIIS_ERR_ARG (-1)
+#define MLIIS_ERR_UNSUPPORTED (-2)
+#define MLIIS_ERR_ALIGN (-3)
+#define MLIIS_ERR_LAUNCH (-4)
+#define MLIIS_ERR_WORKSPACE (-5)
+
+int mliis_version(void);
+const char* mliis_last_error(void);
+
+/* ---- stem: (x - MEAN_RGB) / STDDEV_RGB (models/efficientlab.py:113-114) fused into conv 3x3 s2 SAME, 3 -> Co, no bias
+ *      (models/efficientnet/efficientnet_model.py:359-366,411-412).  x: [S,H,W,3] in 0..255; img_idx (nullable, device
+ *      int32[N]) selects the batch images out of the S resident shots.  mean3 / std3 are HOST float[3]. */
+int mliis_stem_conv_fwd(const float* x, const int* img_idx, const float* w, float* z, int N, int H, int W, int Co,
+                        const float* mean3, const float* std3, hipStream_t stream);
+size_t mliis_stem_conv_bwd_filter_workspace_floats(int N, int H, int W, int Co);
+int mliis_stem_conv_bwd_filter(const float* x, const int* img_idx, const float* dz, float* dw, int N, int H, int W, int Co,
+                               const float* mean3, const float* std3, float* ws, size_t ws_floats, hipStream_t stream);
+
+/* ---- depthwise k x k (k 3|5, stride 1|2, TF-SAME, no bias): keras DepthwiseConv2D
+ *      (models/efficientnet/efficientnet_model.py:190-196,271; utils.py:219-222).  H, W are the INPUT size in all three;
+ *      w / dw are [k,k,C] (TF [k,k,C,1]). */
+int mliis_dwconv_fwd(const float* x, const float* w, float* y, int N, int H, int W, int C, int k, int stride, hipStream_t stream);
+int mliis_dwconv_bwd_data(const float* dy, const float* w, float* dx, int N, int H, int W, int C, int k, int stride,
+                          hipStream_t stream);
+size_t mliis_dwconv_bwd_filter_workspace_floats(int N, int H, int W, int C, int k, int stride);
+int mliis_dwconv_bwd_filter(const float* x, const float* dy, float* dw, int N, int H, int W, int C, int k, int stride, float* ws,
+                            size_t ws_floats, hipStream_t stream);
+
+/* ---- dense conv (k 1|3, stride 1, TF-SAME, dilation >= 1, optional bias) on the fp32 matrix cores:
+ *      tf.layers.Conv2D 1x1 expand/project (efficientnet_model.py:175-182,225-232) and tf.layers.conv2d of the RSD decoder /
+ *      ASPP (models/efficientlab.py:185-190,218-224,258-283).  w is TF HWIO [k,k,Cin,Cout].  `accumulate` != 0 adds into the
+ *      destination.  ws may be NULL (disables split-K). */
+size_t mliis_conv2d_workspace_floats(int Nimg, int H, int W, int Cred, int Nout, int ksize);
+int mliis_conv2d_fwd(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int Nimg, int H, int W, int Cin,
+                     int Cout, int ksize, int dil, int accumulate, float* ws, size_t ws_floats, hipStream_t stream);
+/*      gradient w.r.t. input channels [ci_begin, ci_begin+Cin_out) of a conv whose weight has Cin_total input channels */
+int mliis_conv2d_bwd_data(const float* dy, int lddy, const float* w, float* dx, int lddx, int Nimg, int H, int W, int Cin_total,
+                          int ci_begin, int Cin_out, int Cout, int ksize, int dil, int accumulate, float* ws, size_t ws_floats,
+                          hipStream_t stream);
+size_t mliis_conv2d_bwd_filter_workspace_floats(int Nimg, int H, int W, int Cin, int Cout, int ksize);
+int mliis_conv2d_bwd_filter(const float* x, int ldx, const float* dy, int lddy, float* dw, int Nimg, int H, int W, int Cin, int Cout,
+                            int ksize, int dil, int accumulate, float* ws, size_t ws_floats, hipStream_t stream);
+
+/* ---- batch norm, training mode (TpuBatchNormalization, models/efficientnet/utils.py:87-134; tf.layers.batch_normalization,
+ *      models/efficientlab.py:190).  pre_swish: statistics/normalisation act on swish(x) (decoder order conv->swish->BN);
+ *      post_swish: y = swish(bn(x)) (backbone order conv->BN->swish).  bn_stats also applies the moving-average update
+ *      m -= (m - stat) * (1 - momentum) (moving_* nullable); unbiased_moving_var selects the fused-BN rule.
+ *      bn_apply: y = [swish](gamma * xhat + beta) * img_scale[n] + res   (img_scale = drop-connect scale, utils.py:157-170;
+ *      res = identity skip, efficientnet_model.py:281-288 / RSD residual, efficientlab.py:226-229).
+ *      bn_bwd: upstream gradient = dy * img_scale[n] * chan_scale[n,c] + chan_add[n,c]  (SE gate / pooled gradient fused in). */
+size_t mliis_colreduce_workspace_floats(long long rows_per_seg, int C, int nseg, int nv);
+int mliis_bn_stats(const float* x, int ldx, long long rows, int C, int pre_swish, float eps, float momentum, int unbiased_moving_var,
+                   float* mean, float* rstd, float* moving_mean, float* moving_var, float* ws, size_t ws_floats, hipStream_t stream);
+int mliis_bn_apply(const float* x, int ldx, float* y, int ldy, long long rows, int C, int rows_per_img, const float* mean,
+                   const float* rstd, const float* gamma, const float* beta, int pre_swish, int post_swish, const float* img_scale,
+                   const float* res, int ldr, hipStream_t stream);
+/*      workspace: mliis_colreduce_workspace_floats(rows, C, 1, 2) + 2*C + 16 floats */
+int mliis_bn_bwd(const float* x, int ldx, const float* dy, int lddy, float* dx, int lddx, long long rows, int C, int rows_per_img,
+                 const float* mean, const float* rstd, const float* gamma, const float* beta, int pre_swish, int post_swish,
+                 const float* img_scale, const float* chan_scale, const float* chan_add, float* dgamma, float* dbeta, float* ws,
+                 size_t ws_floats, hipStream_t stream);
+
+/* ---- per-image column sums: out[seg,c] (+)= scale * sum_rows a[row,c] * b[row,c]  (b nullable).  Serves tf.reduce_mean over
+ *      H,W of squeeze-excite (efficientnet_model.py:247) and of the RSD pooled branch (efficientlab.py:192-197), their
+ *      gradients, and conv bias gradients.  workspace: mliis_colreduce_workspace_floats(rows_per_seg, C, nseg, 1). */
+int mliis_colsum(const float* a, int lda, const float* b, int ldb, long long rows_per_seg, int nseg, int C, float scale, float* out,
+                 int accumulate, float* ws, size_t ws_floats, hipStream_t stream);
+
+/* ---- squeeze-excite gate (efficientnet_model.py:238-251): hpre = W1.s + b1; gate = sigmoid(W2.swish(hpre) + b2).
+ *      w1 [C,R], w2 [R,C] (TF HWIO 1x1).  R <= 128. */
+int mliis_se_mlp_fwd(const float* s, const float* w1, const float* b1, const float* w2, const float* b2, float* hpre, float* gate,
+                     int N, int C, int R, hipStream_t stream);
+int mliis_se_mlp_bwd(const float* dgate, const float* gate, const float* s, const float* hpre, const float* w1, const float* w2,
+                     float* dpre1, float* dpre2, float* chan_add, float* dw1, float* db1, float* dw2, float* db2, int N, int C, int R,
+                     int HW, hipStream_t stream);
+/*      y[m,c] (+)= x[m,c] * S[n(m),c] + A[n(m),c]  (x, S, A optional): gate apply, tf.tile of pooled vectors, pooled-gradient
+ *      broadcast, strided channel-slice copy (tf.concat, efficientlab.py:208,222). */
+int mliis_chan_affine(const float* x, int ldx, const float* S, const float* A, float* y, int ldy, long long rows, int C,
+                      int rows_per_img, int accumulate, hipStream_t stream);
+
+/* ---- tf.image.resize_images(BILINEAR, align_corners=True) (efficientlab.py:171-172,205-206) and its transpose.
+ *      C % 2 == 0 (the 2-channel logits map uses 8-byte vectors). */
+int mliis_resize_bilinear_fwd(const float* x, int ldx, float* y, int ldy, int N, int Hi, int Wi, int Ho, int Wo, int C,
+                              hipStream_t stream);
+int mliis_resize_bilinear_bwd(const float* dy, int lddy, float* dx, int lddx, int N, int Hi, int Wi, int Ho, int Wo, int C,
+                              int accumulate, hipStream_t stream);
+
+/* ---- final layer: [dropout mask *] 1x1 conv C -> 2 + bias (efficientlab.py:161-167).  w [C,2], y/dy [rows,2] dense.
+ *      mask (nullable) has the layout of x and holds 0 or 1/(1-rate). */
+int mliis_final_conv_fwd(const float* x, int ldx, const float* mask, const float* w, const float* b, float* y, long long rows, int C,
+                         hipStream_t stream);
+int mliis_final_conv_bwd_data(const float* dy, const float* w, const float* mask, float* dx, int lddx, long long rows, int C,
+                              hipStream_t stream);
+/*      workspace: mliis_colreduce_workspace_floats(rows, C, 1, 2) */
+int mliis_final_conv_bwd_filter(const float* x, int ldx, const float* mask, const float* dy, long long rows, int C, float* dw, float* db,
+                                float* ws, size_t ws_floats, hipStream_t stream);
+
+/* ---- loss: mean-over-pixels softmax CE with label smoothing [- ln(2 IoU / (IoU + 1))] (efficientlab.py:294-303,319-396),
+ *      gradient w.r.t. logits, and predictions = (softmax > 0.5) (efficientlab.py:174-176,291-292).
+ *      out (device float[3]) = {loss + extra_loss, ce, iou}. */
+size_t mliis_softmax_ce_workspace_floats(int N, int H, int W);
+int mliis_softmax_ce(const float* logits, const float* labels, const int* img_idx, int N, int H, int W, float label_smoothing, int dice,
+                     float extra_loss, float* dlogits, float* pred, float* out, float* ws, size_t ws_floats, hipStream_t stream);
+
+/* ---- optimizer + arena algebra.  tf.train.GradientDescentOptimizer / AdamOptimizer(beta1=0) apply
+ *      (efficientlab.py:16,301,315-317; meta_learners/args.py:151-154) with the L2 gradient (models/regularizers.py:4-10)
+ *      folded in through a per-quad byte mask; lr_dev (nullable device float) overrides lr so captured graphs can vary it.
+ *      axpby / lincomb implement meta_learners/variables.py:9-55 on the flat arena. */
+int mliis_sgd_fused(float* w, const float* g, const uint8_t* l2_quad_mask, long long n, float lr, const float* lr_dev, float l2,
+                    hipStream_t stream);
+int mliis_adam_b1zero_fused(float* w, const float* g, float* v, const uint8_t* l2_quad_mask, long long n, float lr, const float* lr_dev,
+                            float l2, float beta2, float eps, const float* step_dev, hipStream_t stream);
+int mliis_axpby(float a, const float* x, float b, float* y, long long n, hipStream_t stream);
+int mliis_lincomb(float a, const float* x, float b, const float* y, float* out, long long n, hipStream_t stream);
+
+/* ---- HIP-graph capture of one inner step (replaces the per-op dispatch of session.run) */
+int mliis_graph_begin_capture(hipStream_t stream);
+int mliis_graph_end_capture(hipStream_t stream, void** graph_exec_out);
+int mliis_graph_launch(void* graph_exec, hipStream_t stream);
+int mliis_graph_destroy(void* graph_exec);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MLIIS_HIP_H */

@@ -1,0 +1,98 @@
+"""ctypes binding of libmliis_hip.so (the C ABI declared in include/mliis_hip.h).
+
+The library is built in-tree (mliis_amd/libmliis_hip.so) by `__graft_entry__.build()` / `make -C mliis_amd/csrc`.
+There is NO fallback: if the shared object is missing or a call fails, an exception is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmliis_hip.so")
+
+_f = C.c_float
+_i = C.c_int
+_ll = C.c_longlong
+_p = C.c_void_p
+_sz = C.c_size_t
+
+# name -> (restype, argtypes)
+SIGNATURES = {
+    "mliis_version": (_i, []),
+    "mliis_last_error": (C.c_char_p, []),
+    "mliis_stem_conv_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p]),
+    "mliis_stem_conv_bwd_filter_workspace_floats": (_sz, [_i, _i, _i, _i]),
+    "mliis_stem_conv_bwd_filter": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _sz, _p]),
+    "mliis_dwconv_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "mliis_dwconv_bwd_data": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "mliis_dwconv_bwd_filter_workspace_floats": (_sz, [_i, _i, _i, _i, _i, _i]),
+    "mliis_dwconv_bwd_filter": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _sz, _p]),
+    "mliis_conv2d_workspace_floats": (_sz, [_i, _i, _i, _i, _i, _i]),
+    "mliis_conv2d_fwd": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _p]),
+    "mliis_conv2d_bwd_data": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _p]),
+    "mliis_conv2d_bwd_filter_workspace_floats": (_sz, [_i, _i, _i, _i, _i, _i]),
+    "mliis_conv2d_bwd_filter": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _p]),
+    "mliis_colreduce_workspace_floats": (_sz, [_ll, _i, _i, _i]),
+    "mliis_bn_stats": (_i, [_p, _i, _ll, _i, _i, _f, _f, _i, _p, _p, _p, _p, _p, _sz, _p]),
+    "mliis_bn_apply": (_i, [_p, _i, _p, _i, _ll, _i, _i, _p, _p, _p, _p, _i, _i, _p, _p, _i, _p]),
+    "mliis_bn_bwd": (_i, [_p, _i, _p, _i, _p, _i, _ll, _i, _i, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "mliis_colsum": (_i, [_p, _i, _p, _i, _ll, _i, _i, _f, _p, _i, _p, _sz, _p]),
+    "mliis_se_mlp_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "mliis_se_mlp_bwd": (_i, [_p] * 13 + [_i, _i, _i, _i, _p]),
+    "mliis_chan_affine": (_i, [_p, _i, _p, _p, _p, _i, _ll, _i, _i, _i, _p]),
+    "mliis_resize_bilinear_fwd": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "mliis_resize_bilinear_bwd": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "mliis_final_conv_fwd": (_i, [_p, _i, _p, _p, _p, _p, _ll, _i, _p]),
+    "mliis_final_conv_bwd_data": (_i, [_p, _p, _p, _p, _i, _ll, _i, _p]),
+    "mliis_final_conv_bwd_filter": (_i, [_p, _i, _p, _p, _ll, _i, _p, _p, _p, _sz, _p]),
+    "mliis_softmax_ce_workspace_floats": (_sz, [_i, _i, _i]),
+    "mliis_softmax_ce": (_i, [_p, _p, _p, _i, _i, _i, _f, _i, _f, _p, _p, _p, _p, _sz, _p]),
+    "mliis_sgd_fused": (_i, [_p, _p, _p, _ll, _f, _p, _f, _p]),
+    "mliis_adam_b1zero_fused": (_i, [_p, _p, _p, _p, _ll, _f, _p, _f, _f, _f, _p, _p]),
+    "mliis_axpby": (_i, [_f, _p, _f, _p, _ll, _p]),
+    "mliis_lincomb": (_i, [_f, _p, _f, _p, _p, _ll, _p]),
+    "mliis_graph_begin_capture": (_i, [_p]),
+    "mliis_graph_end_capture": (_i, [_p, C.POINTER(C.c_void_p)]),
+    "mliis_graph_launch": (_i, [_p, _p]),
+    "mliis_graph_destroy": (_i, [_p]),
+}
+
+
+class MliisError(RuntimeError):
+    pass
+
+
+class _Lib:
+    def __init__(self):
+        self._dll = None
+
+    def load(self):
+        if self._dll is None:
+            if not os.path.exists(LIB_PATH):
+                raise MliisError(
+                    "libmliis_hip.so not found at {} -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                    "or `make -C mliis_amd/csrc`.  There is no CPU fallback.".format(LIB_PATH))
+            dll = C.CDLL(LIB_PATH)
+            for name, (res, args) in SIGNATURES.items():
+                fn = getattr(dll, name)
+                fn.restype = res
+                fn.argtypes = args
+            self._dll = dll
+        return self._dll
+
+    def raw(self, name):
+        return getattr(self.load(), name)
+
+    def call(self, name, *args):
+        """Call an int-returning entry point; raise MliisError with the library's message on failure."""
+        rc = getattr(self.load(), name)(*args)
+        if rc != 0:
+            msg = self._dll.mliis_last_error()
+            raise MliisError("{} failed ({}): {}".format(name, rc, msg.decode() if msg else "?"))
+
+    def size(self, name, *args) -> int:
+        return int(getattr(self.load(), name)(*args))
+
+
+lib = _Lib()

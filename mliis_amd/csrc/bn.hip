@@ -1,0 +1,461 @@
+// Batch-norm (training) statistics / apply / backward, and the generic per-channel column reductions that the
+// squeeze-excite, bias-gradient and pooled-branch ops reuse.  All tensors are [rows, C] fp32 views of NHWC
+// activations with a row stride `ld` (floats), C % 4 == 0, 16-byte aligned; lanes run along C in float4 so every
+// wave-instruction touches whole contiguous spans (HBM-bound kernels: SURVEY 2.1 K4/K5/K7/K8).
+//
+// Reductions are two-stage and deterministic: stage 1 writes per-block partial sums, stage 2 (one thread per channel)
+// folds them in double precision.  No float atomics anywhere.
+//
+// Reference semantics: models/efficientnet/utils.py:87-134 (non-fused BN, biased variance),
+// models/efficientlab.py:185-190 (decoder: conv -> swish -> BN, fused BN => unbiased variance into the moving average),
+// models/efficientnet/efficientnet_model.py:266,271,280-288 (BN -> swish, drop-connect + residual).
+#include "common.hpp"
+
+namespace mliis {
+
+constexpr int kColThreads = 256;
+constexpr int kMaxQuadsPerBlock = 64;
+
+struct ColGeom {
+  int Q;        // C / 4
+  int QB;       // quads per block in y (<= 64)
+  int RP;       // rows processed per pass by one block = 256 / QB
+  int rows_per_block;
+  int nblk;     // blocks along rows (per segment)
+};
+
+static inline ColGeom col_geom(long long rows_per_seg, int C, int nseg, int target_blocks = 2048) {
+  ColGeom g;
+  g.Q = C / 4;
+  g.QB = g.Q < kMaxQuadsPerBlock ? g.Q : kMaxQuadsPerBlock;
+  g.RP = kColThreads / g.QB;
+  int ny = ceil_div(g.Q, g.QB);
+  long long want = target_blocks / (ny * (nseg > 0 ? nseg : 1));
+  if (want < 1) want = 1;
+  long long rpb = (rows_per_seg + want - 1) / want;
+  // at least 8 passes per block so the per-block epilogue is amortised, multiple of RP
+  long long minr = (long long)g.RP * 8;
+  if (rpb < minr) rpb = minr;
+  rpb = (rpb + g.RP - 1) / g.RP * g.RP;
+  g.rows_per_block = (int)rpb;
+  g.nblk = ceil_div(rows_per_seg, rpb);
+  return g;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Generic partial column reduction.  Op::NV float4 values per (row, quad).
+// part layout: [seg][blk][v][C]
+// ---------------------------------------------------------------------------------------------------------------
+template <class Op>
+__global__ __launch_bounds__(kColThreads) void colreduce_partial_k(Op op, int rows_per_seg, int C, int QB, int RP,
+                                                                    int rows_per_block, int nblk, float* __restrict__ part) {
+  constexpr int NV = Op::NV;
+  __shared__ float4 sm[kColThreads];
+  const int t = threadIdx.x;
+  const int ql = t % QB, rl = t / QB;
+  const int q = blockIdx.y * QB + ql;
+  const int seg = blockIdx.z;
+  const int Q = C >> 2;
+  const bool active = (rl < RP) && (q < Q);
+  float4 acc[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) acc[v] = f4zero();
+  if (active) {
+    const int r0 = blockIdx.x * rows_per_block;
+    int r1 = r0 + rows_per_block;
+    if (r1 > rows_per_seg) r1 = rows_per_seg;
+    for (int r = r0 + rl; r < r1; r += RP) {
+      float4 vals[NV];
+      op(seg, (long long)seg * rows_per_seg + r, q << 2, vals);
+#pragma unroll
+      for (int v = 0; v < NV; ++v) acc[v] = f4add(acc[v], vals[v]);
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    __syncthreads();
+    sm[t] = acc[v];
+    __syncthreads();
+    if (rl == 0 && q < Q) {
+      float4 s = sm[ql];
+      for (int j = 1; j < RP; ++j) s = f4add(s, sm[j * QB + ql]);
+      st4(part + (((long long)seg * nblk + blockIdx.x) * NV + v) * C + (q << 2), s);
+    }
+  }
+}
+
+template <class Op>
+static int launch_colreduce(Op op, long long rows_per_seg, int C, int nseg, float* part, size_t part_floats,
+                            hipStream_t stream, ColGeom* out_g, const char* name) {
+  ColGeom g = col_geom(rows_per_seg, C, nseg);
+  size_t need = (size_t)nseg * g.nblk * Op::NV * C;
+  MLIIS_REQUIRE(need <= part_floats, MLIIS_ERR_WORKSPACE, "%s: workspace too small (%zu floats needed, %zu given)", name,
+                need, part_floats);
+  dim3 grid(g.nblk, ceil_div(g.Q, g.QB), nseg);
+  hipLaunchKernelGGL((colreduce_partial_k<Op>), grid, dim3(kColThreads), 0, stream, op, (int)rows_per_seg, C, g.QB, g.RP,
+                     g.rows_per_block, g.nblk, part);
+  MLIIS_CHECK_LAUNCH(name);
+  *out_g = g;
+  return MLIIS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// BN statistics
+// ---------------------------------------------------------------------------------------------------------------
+struct StatsOp {
+  static constexpr int NV = 2;
+  const float* x;
+  int ld;
+  int pre_swish;
+  __device__ void operator()(int, long long row, int c, float4* o) const {
+    float4 v = ld4(x + row * ld + c);
+    if (pre_swish) v = make_float4(swish_f(v.x), swish_f(v.y), swish_f(v.z), swish_f(v.w));
+    o[0] = v;
+    o[1] = f4mul(v, v);
+  }
+};
+
+__global__ void bn_stats_finalize_k(const float* __restrict__ part, int nblk, int C, double inv_n, float eps,
+                                    float one_minus_momentum, float ema_var_factor, float* __restrict__ mean,
+                                    float* __restrict__ rstd, float* __restrict__ moving_mean,
+                                    float* __restrict__ moving_var) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, ss = 0.0;
+  for (int b = 0; b < nblk; ++b) {
+    s += (double)part[((long long)b * 2 + 0) * C + c];
+    ss += (double)part[((long long)b * 2 + 1) * C + c];
+  }
+  double m = s * inv_n;
+  double var = ss * inv_n - m * m;
+  if (var < 0.0) var = 0.0;
+  mean[c] = (float)m;
+  rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (moving_mean != nullptr) {
+    float mm = moving_mean[c], mv = moving_var[c];
+    moving_mean[c] = mm - (mm - (float)m) * one_minus_momentum;
+    moving_var[c] = mv - (mv - (float)(var * (double)ema_var_factor)) * one_minus_momentum;
+  }
+}
+
+// y = [post_swish]( gamma * ([pre_swish](x) - mean) * rstd + beta ) * img_scale[n] + res
+__global__ __launch_bounds__(256) void bn_apply_k(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy,
+                                                  long long rows, int C, int rows_per_img,
+                                                  const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                  int pre_swish, int post_swish, const float* __restrict__ img_scale,
+                                                  const float* __restrict__ res, int ldr) {
+  const int Q = C >> 2;
+  const long long total = rows * Q;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / Q;
+    const int c = (int)(i - r * Q) << 2;
+    float4 v = ld4(x + r * ldx + c);
+    if (pre_swish) v = make_float4(swish_f(v.x), swish_f(v.y), swish_f(v.z), swish_f(v.w));
+    const float4 m = ld4(mean + c), rs = ld4(rstd + c), g = ld4(gamma + c), b = ld4(beta + c);
+    float4 o;
+    o.x = fmaf((v.x - m.x) * rs.x, g.x, b.x);
+    o.y = fmaf((v.y - m.y) * rs.y, g.y, b.y);
+    o.z = fmaf((v.z - m.z) * rs.z, g.z, b.z);
+    o.w = fmaf((v.w - m.w) * rs.w, g.w, b.w);
+    if (post_swish) o = make_float4(swish_f(o.x), swish_f(o.y), swish_f(o.z), swish_f(o.w));
+    if (img_scale != nullptr) o = f4scale(o, img_scale[r / rows_per_img]);
+    if (res != nullptr) o = f4add(o, ld4(res + r * ldr + c));
+    st4(y + r * ldy + c, o);
+  }
+}
+
+// upstream gradient seen by the BN output: dy * img_scale[n] * chan_scale[n,c] + chan_add[n,c]
+struct BnBwdCommon {
+  const float* x;   // conv output saved in forward (pre-BN, pre-swish if pre_swish)
+  int ldx;
+  const float* dy;
+  int lddy;
+  int rows_per_img;
+  int C;
+  const float* mean;
+  const float* rstd;
+  const float* gamma;
+  const float* beta;
+  int pre_swish, post_swish;
+  const float* img_scale;   // [N] or null        (drop-connect)
+  const float* chan_scale;  // [N,C] or null      (squeeze-excite gate)
+  const float* chan_add;    // [N,C] or null      (squeeze-excite pooled-gradient / HW)
+  __device__ __forceinline__ void load(long long row, int c, float4& xin, float4& xhat, float4& g) const {
+    xin = ld4(x + row * ldx + c);
+    float4 v = xin;
+    if (pre_swish) v = make_float4(swish_f(v.x), swish_f(v.y), swish_f(v.z), swish_f(v.w));
+    const float4 m = ld4(mean + c), rs = ld4(rstd + c);
+    xhat = make_float4((v.x - m.x) * rs.x, (v.y - m.y) * rs.y, (v.z - m.z) * rs.z, (v.w - m.w) * rs.w);
+    g = ld4(dy + row * lddy + c);
+    const int n = (int)(row / rows_per_img);
+    if (img_scale != nullptr) g = f4scale(g, img_scale[n]);
+    if (chan_scale != nullptr) g = f4mul(g, ld4(chan_scale + (long long)n * C + c));
+    if (chan_add != nullptr) g = f4add(g, ld4(chan_add + (long long)n * C + c));
+    if (post_swish) {
+      const float4 ga = ld4(gamma + c), be = ld4(beta + c);
+      g.x *= swish_grad_f(fmaf(xhat.x, ga.x, be.x));
+      g.y *= swish_grad_f(fmaf(xhat.y, ga.y, be.y));
+      g.z *= swish_grad_f(fmaf(xhat.z, ga.z, be.z));
+      g.w *= swish_grad_f(fmaf(xhat.w, ga.w, be.w));
+    }
+  }
+};
+
+struct BnBwdOp {
+  static constexpr int NV = 2;
+  BnBwdCommon p;
+  __device__ void operator()(int, long long row, int c, float4* o) const {
+    float4 xin, xhat, g;
+    p.load(row, c, xin, xhat, g);
+    o[0] = g;
+    o[1] = f4mul(g, xhat);
+  }
+};
+
+__global__ void bn_bwd_finalize_k(const float* __restrict__ part, int nblk, int C, double inv_n, float* __restrict__ dgamma,
+                                  float* __restrict__ dbeta, float* __restrict__ c1, float* __restrict__ c2) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, sx = 0.0;
+  for (int b = 0; b < nblk; ++b) {
+    s += (double)part[((long long)b * 2 + 0) * C + c];
+    sx += (double)part[((long long)b * 2 + 1) * C + c];
+  }
+  dbeta[c] = (float)s;
+  dgamma[c] = (float)sx;
+  c1[c] = (float)(s * inv_n);
+  c2[c] = (float)(sx * inv_n);
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_k(BnBwdCommon p, long long rows, const float* __restrict__ c1,
+                                                      const float* __restrict__ c2, float* __restrict__ dx, int lddx) {
+  const int Q = p.C >> 2;
+  const long long total = rows * Q;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / Q;
+    const int c = (int)(i - r * Q) << 2;
+    float4 xin, xhat, g;
+    p.load(r, c, xin, xhat, g);
+    const float4 a = ld4(c1 + c), b = ld4(c2 + c), ga = ld4(p.gamma + c), rs = ld4(p.rstd + c);
+    float4 d;
+    d.x = ga.x * rs.x * (g.x - a.x - xhat.x * b.x);
+    d.y = ga.y * rs.y * (g.y - a.y - xhat.y * b.y);
+    d.z = ga.z * rs.z * (g.z - a.z - xhat.z * b.z);
+    d.w = ga.w * rs.w * (g.w - a.w - xhat.w * b.w);
+    if (p.pre_swish) {
+      d.x *= swish_grad_f(xin.x);
+      d.y *= swish_grad_f(xin.y);
+      d.z *= swish_grad_f(xin.z);
+      d.w *= swish_grad_f(xin.w);
+    }
+    st4(dx + r * lddx + c, d);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Generic sums: out[seg][v][c] = scale * sum_rows f(...)
+// ---------------------------------------------------------------------------------------------------------------
+struct SumOp {  // column sum of a (optionally times b)
+  static constexpr int NV = 1;
+  const float* a;
+  int lda;
+  const float* b;  // nullable
+  int ldb;
+  __device__ void operator()(int, long long row, int c, float4* o) const {
+    float4 v = ld4(a + row * lda + c);
+    if (b != nullptr) v = f4mul(v, ld4(b + row * ldb + c));
+    o[0] = v;
+  }
+};
+
+// sum_rows x[row, c] * (mask[row,c]) * dy[row, j], j = 0,1   (final 1x1 conv, Cout = 2: weight gradient)
+struct Outer2Op {
+  static constexpr int NV = 2;
+  const float* x;
+  int ldx;
+  const float* mask;  // nullable, same layout as x
+  const float* dy;    // [rows, 2]
+  __device__ void operator()(int, long long row, int c, float4* o) const {
+    float4 v = ld4(x + row * ldx + c);
+    if (mask != nullptr) v = f4mul(v, ld4(mask + row * ldx + c));
+    const float2 d = *reinterpret_cast<const float2*>(dy + row * 2);
+    o[0] = f4scale(v, d.x);
+    o[1] = f4scale(v, d.y);
+  }
+};
+
+__global__ void sum_finalize_k(const float* __restrict__ part, int nblk, int NV, int C, int nseg, float scale,
+                               float* __restrict__ out, int accumulate) {
+  // out layout [seg][v][C]
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long total = (long long)nseg * NV * C;
+  if (i >= total) return;
+  int c = (int)(i % C);
+  int v = (int)((i / C) % NV);
+  int seg = (int)(i / ((long long)C * NV));
+  double s = 0.0;
+  for (int b = 0; b < nblk; ++b) s += (double)part[(((long long)seg * nblk + b) * NV + v) * C + c];
+  float r = (float)(s * (double)scale);
+  out[i] = accumulate ? out[i] + r : r;
+}
+
+static inline int ew_grid(long long total_quads) {
+  long long b = (total_quads + 255) / 256;
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace mliis
+
+using namespace mliis;
+
+extern "C" {
+
+size_t mliis_colreduce_workspace_floats(long long rows_per_seg, int C, int nseg, int nv) {
+  if (rows_per_seg <= 0 || C <= 0 || (C & 3) || nseg <= 0 || nv <= 0) return 0;
+  ColGeom g = col_geom(rows_per_seg, C, nseg);
+  return (size_t)nseg * g.nblk * nv * C;
+}
+
+int mliis_bn_stats(const float* x, int ldx, long long rows, int C, int pre_swish, float eps, float momentum,
+                   int unbiased_moving_var, float* mean, float* rstd, float* moving_mean, float* moving_var, float* ws,
+                   size_t ws_floats, hipStream_t stream) {
+  MLIIS_REQUIRE(x && mean && rstd && ws, MLIIS_ERR_ARG, "bn_stats: null pointer");
+  MLIIS_REQUIRE(rows > 1 && C > 0 && (C & 3) == 0 && (ldx & 3) == 0 && ldx >= C, MLIIS_ERR_ARG,
+                "bn_stats: bad shape rows=%lld C=%d ld=%d", rows, C, ldx);
+  MLIIS_REQUIRE(aligned16(x) && aligned16(ws), MLIIS_ERR_ALIGN, "bn_stats: pointers must be 16-byte aligned");
+  MLIIS_REQUIRE((moving_mean == nullptr) == (moving_var == nullptr), MLIIS_ERR_ARG, "bn_stats: moving stats must come as a pair");
+  StatsOp op{x, ldx, pre_swish};
+  ColGeom g;
+  int rc = launch_colreduce(op, rows, C, 1, ws, ws_floats, stream, &g, "bn_stats");
+  if (rc) return rc;
+  double n = (double)rows;
+  float factor = unbiased_moving_var ? (float)(n / (n - 1.0)) : 1.0f;
+  hipLaunchKernelGGL(bn_stats_finalize_k, dim3(ceil_div(C, 128)), dim3(128), 0, stream, ws, g.nblk, C, 1.0 / n, eps,
+                     (float)(1.0 - (double)momentum), factor, mean, rstd, moving_mean, moving_var);
+  MLIIS_CHECK_LAUNCH("bn_stats_finalize");
+  return MLIIS_OK;
+}
+
+int mliis_bn_apply(const float* x, int ldx, float* y, int ldy, long long rows, int C, int rows_per_img, const float* mean,
+                   const float* rstd, const float* gamma, const float* beta, int pre_swish, int post_swish,
+                   const float* img_scale, const float* res, int ldr, hipStream_t stream) {
+  MLIIS_REQUIRE(x && y && mean && rstd && gamma && beta, MLIIS_ERR_ARG, "bn_apply: null pointer");
+  MLIIS_REQUIRE(rows > 0 && C > 0 && (C & 3) == 0 && (ldx & 3) == 0 && (ldy & 3) == 0 && ldx >= C && ldy >= C &&
+                    rows_per_img > 0 && (res == nullptr || ((ldr & 3) == 0 && ldr >= C)),
+                MLIIS_ERR_ARG, "bn_apply: bad shape");
+  MLIIS_REQUIRE(aligned16(x) && aligned16(y) && aligned16(mean) && aligned16(rstd) && aligned16(gamma) && aligned16(beta) &&
+                    aligned16(res),
+                MLIIS_ERR_ALIGN, "bn_apply: pointers must be 16-byte aligned");
+  hipLaunchKernelGGL(bn_apply_k, dim3(ew_grid(rows * (C / 4))), dim3(256), 0, stream, x, ldx, y, ldy, rows, C, rows_per_img,
+                     mean, rstd, gamma, beta, pre_swish, post_swish, img_scale, res, ldr);
+  MLIIS_CHECK_LAUNCH("bn_apply");
+  return MLIIS_OK;
+}
+
+int mliis_bn_bwd(const float* x, int ldx, const float* dy, int lddy, float* dx, int lddx, long long rows, int C,
+                 int rows_per_img, const float* mean, const float* rstd, const float* gamma, const float* beta, int pre_swish,
+                 int post_swish, const float* img_scale, const float* chan_scale, const float* chan_add, float* dgamma,
+                 float* dbeta, float* ws, size_t ws_floats, hipStream_t stream) {
+  MLIIS_REQUIRE(x && dy && dx && mean && rstd && gamma && beta && dgamma && dbeta && ws, MLIIS_ERR_ARG, "bn_bwd: null pointer");
+  MLIIS_REQUIRE(rows > 1 && C > 0 && (C & 3) == 0 && (ldx & 3) == 0 && (lddy & 3) == 0 && (lddx & 3) == 0 && ldx >= C &&
+                    lddy >= C && lddx >= C && rows_per_img > 0,
+                MLIIS_ERR_ARG, "bn_bwd: bad shape");
+  MLIIS_REQUIRE(aligned16(x) && aligned16(dy) && aligned16(dx) && aligned16(ws) && aligned16(chan_scale) && aligned16(chan_add) &&
+                    aligned16(mean) && aligned16(rstd) && aligned16(gamma) && aligned16(beta),
+                MLIIS_ERR_ALIGN, "bn_bwd: pointers must be 16-byte aligned");
+  BnBwdCommon p{x, ldx, dy, lddy, rows_per_img, C, mean, rstd, gamma, beta, pre_swish, post_swish, img_scale, chan_scale, chan_add};
+  BnBwdOp op{p};
+  ColGeom g;
+  // the tail of the workspace holds the two per-channel coefficient vectors
+  MLIIS_REQUIRE(ws_floats >= (size_t)2 * C + 16, MLIIS_ERR_WORKSPACE, "bn_bwd: workspace too small");
+  size_t coef_off = (ws_floats - (size_t)2 * C) & ~(size_t)3;
+  int rc = launch_colreduce(op, rows, C, 1, ws, coef_off, stream, &g, "bn_bwd");
+  if (rc) return rc;
+  float* c1 = ws + coef_off;
+  float* c2 = c1 + C;
+  hipLaunchKernelGGL(bn_bwd_finalize_k, dim3(ceil_div(C, 128)), dim3(128), 0, stream, ws, g.nblk, C, 1.0 / (double)rows, dgamma,
+                     dbeta, c1, c2);
+  MLIIS_CHECK_LAUNCH("bn_bwd_finalize");
+  hipLaunchKernelGGL(bn_bwd_apply_k, dim3(ew_grid(rows * (C / 4))), dim3(256), 0, stream, p, rows, c1, c2, dx, lddx);
+  MLIIS_CHECK_LAUNCH("bn_bwd_apply");
+  return MLIIS_OK;
+}
+
+// out[seg, c] (+)= scale * sum_{rows of seg} a[row,c] * (b[row,c] if b)
+int mliis_colsum(const float* a, int lda, const float* b, int ldb, long long rows_per_seg, int nseg, int C, float scale,
+                 float* out, int accumulate, float* ws, size_t ws_floats, hipStream_t stream) {
+  MLIIS_REQUIRE(a && out && ws, MLIIS_ERR_ARG, "colsum: null pointer");
+  MLIIS_REQUIRE(rows_per_seg > 0 && nseg > 0 && C > 0 && (C & 3) == 0 && (lda & 3) == 0 && lda >= C &&
+                    (b == nullptr || ((ldb & 3) == 0 && ldb >= C)),
+                MLIIS_ERR_ARG, "colsum: bad shape");
+  MLIIS_REQUIRE(aligned16(a) && aligned16(b) && aligned16(ws), MLIIS_ERR_ALIGN, "colsum: pointers must be 16-byte aligned");
+  SumOp op{a, lda, b, ldb};
+  ColGeom g;
+  int rc = launch_colreduce(op, rows_per_seg, C, nseg, ws, ws_floats, stream, &g, "colsum");
+  if (rc) return rc;
+  long long total = (long long)nseg * C;
+  hipLaunchKernelGGL(sum_finalize_k, dim3(ceil_div(total, 256)), dim3(256), 0, stream, ws, g.nblk, 1, C, nseg, scale, out,
+                     accumulate);
+  MLIIS_CHECK_LAUNCH("colsum_finalize");
+  return MLIIS_OK;
+}
+
+// dw[c, j] = sum_rows x[row,c]*mask[row,c]*dy[row,j]  (j in {0,1});  dw is [C,2] row-major (TF HWIO of a 1x1 conv)
+int mliis_final_conv_bwd_filter(const float* x, int ldx, const float* mask, const float* dy, long long rows, int C, float* dw,
+                                float* db, float* ws, size_t ws_floats, hipStream_t stream);
+}
+
+namespace mliis {
+__global__ void final_dw_finalize_k(const float* __restrict__ part, int nblk, int C, float* __restrict__ dw) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 2 * C) return;
+  int c = i >> 1, j = i & 1;
+  double s = 0.0;
+  for (int b = 0; b < nblk; ++b) s += (double)part[((long long)b * 2 + j) * C + c];
+  dw[i] = (float)s;
+}
+__global__ __launch_bounds__(256) void sum2_k(const float* __restrict__ dy, long long rows, float* __restrict__ db) {
+  // single block: db[j] = sum_rows dy[row, j]
+  __shared__ double sm[2][256];
+  double a0 = 0.0, a1 = 0.0;
+  for (long long r = threadIdx.x; r < rows; r += 256) {
+    float2 d = *reinterpret_cast<const float2*>(dy + r * 2);
+    a0 += d.x;
+    a1 += d.y;
+  }
+  sm[0][threadIdx.x] = a0;
+  sm[1][threadIdx.x] = a1;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+      sm[0][threadIdx.x] += sm[0][threadIdx.x + s];
+      sm[1][threadIdx.x] += sm[1][threadIdx.x + s];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    db[0] = (float)sm[0][0];
+    db[1] = (float)sm[1][0];
+  }
+}
+}  // namespace mliis
+
+extern "C" int mliis_final_conv_bwd_filter(const float* x, int ldx, const float* mask, const float* dy, long long rows, int C,
+                                           float* dw, float* db, float* ws, size_t ws_floats, hipStream_t stream) {
+  MLIIS_REQUIRE(x && dy && dw && db && ws, MLIIS_ERR_ARG, "final_conv_bwd_filter: null pointer");
+  MLIIS_REQUIRE(rows > 0 && C > 0 && (C & 3) == 0 && (ldx & 3) == 0 && ldx >= C, MLIIS_ERR_ARG, "final_conv_bwd_filter: bad shape");
+  MLIIS_REQUIRE(aligned16(x) && aligned16(mask) && aligned16(ws) && (reinterpret_cast<uintptr_t>(dy) & 7u) == 0, MLIIS_ERR_ALIGN,
+                "final_conv_bwd_filter: alignment");
+  Outer2Op op{x, ldx, mask, dy};
+  ColGeom g;
+  int rc = launch_colreduce(op, rows, C, 1, ws, ws_floats, stream, &g, "final_conv_bwd_filter");
+  if (rc) return rc;
+  hipLaunchKernelGGL(final_dw_finalize_k, dim3(ceil_div(2 * C, 128)), dim3(128), 0, stream, ws, g.nblk, C, dw);
+  MLIIS_CHECK_LAUNCH("final_dw_finalize");
+  hipLaunchKernelGGL(sum2_k, dim3(1), dim3(256), 0, stream, dy, rows, db);
+  MLIIS_CHECK_LAUNCH("final_db");
+  return MLIIS_OK;
+}

@@ -1,0 +1,54 @@
+// Shared device/host helpers for libmliis_hip (gfx950 / CDNA4 only; wave = 64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/mliis_hip.h"
+
+namespace mliis {
+
+int set_error(int code, const char* fmt, ...);
+
+#define MLIIS_REQUIRE(cond, code, ...)                 \
+  do {                                                 \
+    if (!(cond)) return ::mliis::set_error((code), __VA_ARGS__); \
+  } while (0)
+
+#define MLIIS_CHECK_LAUNCH(name)                                                              \
+  do {                                                                                        \
+    hipError_t e__ = hipGetLastError();                                                       \
+    if (e__ != hipSuccess)                                                                    \
+      return ::mliis::set_error(MLIIS_ERR_LAUNCH, "%s: launch failed: %s", (name), hipGetErrorString(e__)); \
+  } while (0)
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+static inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+constexpr int kWave = 64;
+
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float swish_f(float x) { return x * sigmoid_f(x); }
+// d/dx [x * sigmoid(x)] = s * (1 + x * (1 - s))
+__device__ __forceinline__ float swish_grad_f(float x) {
+  float s = sigmoid_f(x);
+  return s * (1.0f + x * (1.0f - s));
+}
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 f4mul(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+__device__ __forceinline__ float4 f4fma(float4 a, float4 b, float4 c) {
+  return make_float4(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w));
+}
+__device__ __forceinline__ float4 f4scale(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+}  // namespace mliis

@@ -1,0 +1,612 @@
+// Dense convolutions as implicit GEMMs on the fp32 matrix cores (v_mfma_f32_16x16x4_f32), NHWC activations,
+// TF HWIO weights.  One kernel family serves
+//   * MBConv 1x1 expand/project convs         (models/efficientnet/efficientnet_model.py:175-182,225-232)
+//   * RSD decoder 1x1 / 3x3 / 3x3-dilated convs (models/efficientlab.py:185-190,218-224) and optional ASPP (:248-289)
+// in forward ("NN": B = W[tap][ci][co]), backward-data ("NK": the same HWIO buffer read as B^T with the tap offset
+// negated -- no weight transpose is ever materialised) and backward-filter (reduction over pixels, split over M,
+// deterministic two-stage fold).
+//
+// Tiling (wave = 64 lanes, 4 waves per workgroup):
+//   forward / bwd-data : block tile (64*TM) x (16*NT) outputs, K step 32; wave w owns rows [16*TM*w, 16*TM*(w+1)).
+//     A tile in LDS as [kq = k/4][row ^ kq][4] : 16-byte fragments, conflict-free ds_write_b128 (8 lanes = 8 rows^kq) and
+//     conflict-free ds_read_b128 (a 16-lane read group covers 16 distinct rows mod 16).  Inside every 16-wide K group the K
+//     order is permuted identically for A and B (lane group g owns k = 4g..4g+3), so one b128 read feeds 4 MFMAs.
+//     B tile: NN -> [k][BN+4] read with ds_read_b32 (two rows 4 apart land on disjoint bank halves);
+//             NK -> same fragment layout as A.
+//   bwd-filter : block tile (64*TMF ci) x (16*NT co) for one tap; streams 32 pixels per step; A = X^T, B = dY, both
+//     read k-major with ds_read_b32 (row stride == 16 mod 32 banks).
+// Global loads are float4 along C (128-byte spans per 8 lanes), software-pipelined through registers (load chunk i+1
+// while chunk i is multiplied).
+#include "common.hpp"
+
+namespace mliis {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct ConvGemmParams {
+  const float* A;
+  int lda;
+  int Nimg, H, W;
+  int C;
+  int ntaps, dil, sign;
+  const float* B;
+  long long b_tap_stride;
+  int ldb;
+  int Nout;
+  float* Cmat;
+  int ldc;
+  const float* bias;
+  int accumulate;
+  float* partial;        // non-null => split-K partial output [z][M][Nout]
+  int chunks_per_split;  // K chunks per blockIdx.z
+};
+
+template <int TM, int NT, bool B_NK>
+__global__ __launch_bounds__(256) void conv_gemm_k(ConvGemmParams p) {
+  constexpr int BM = 64 * TM, BN = 16 * NT, BK = 32;
+  constexpr int LDB_NN = BN + 4;
+  constexpr int A_FLOATS = 8 * BM * 4;
+  constexpr int B_FLOATS = B_NK ? 8 * BN * 4 : BK * LDB_NN;
+  constexpr int A_PER_THREAD = 2 * TM;                    // float4 per thread per chunk
+  constexpr int B_TOTAL = B_NK ? BN * 8 : BK * (BN / 4);  // float4 per chunk
+  constexpr int B_PER_THREAD = (B_TOTAL + 255) / 256;
+  __shared__ __attribute__((aligned(16))) float sm[A_FLOATS + B_FLOATS];
+  float* smA = sm;
+  float* smB = sm + A_FLOATS;
+
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int l15 = lane & 15, g = lane >> 4;
+  const long long M = (long long)p.Nimg * p.H * p.W;
+  const long long m0 = (long long)blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+  const int cpc = (p.C + BK - 1) / BK;  // chunks per tap
+  const int nchunks_total = p.ntaps * cpc;
+  int it0 = blockIdx.z * p.chunks_per_split;
+  int it1 = it0 + p.chunks_per_split;
+  if (it1 > nchunks_total) it1 = nchunks_total;
+
+  // ---- per-thread A rows
+  const int a_kq = t & 7;
+  const int a_r0 = t >> 3;  // 0..31
+  int a_h[A_PER_THREAD], a_w[A_PER_THREAD];
+  long long a_m[A_PER_THREAD];
+#pragma unroll
+  for (int i = 0; i < A_PER_THREAD; ++i) {
+    long long m = m0 + a_r0 + 32 * i;
+    a_m[i] = m;
+    if (m < M) {
+      int rem = (int)(m % ((long long)p.H * p.W));
+      a_h[i] = rem / p.W;
+      a_w[i] = rem - a_h[i] * p.W;
+    } else {
+      a_h[i] = -100000;
+      a_w[i] = -100000;
+    }
+  }
+
+  float4 ra[A_PER_THREAD];
+  float4 rb[B_PER_THREAD];
+
+  auto load_chunk = [&](int it) {
+    const int tap = it / cpc;
+    const int c0 = (it - tap * cpc) * BK;
+    int dh = 0, dw = 0;
+    if (p.ntaps > 1) {
+      dh = (tap / 3 - 1) * p.dil * p.sign;
+      dw = (tap % 3 - 1) * p.dil * p.sign;
+    }
+    const int ca = c0 + a_kq * 4;
+#pragma unroll
+    for (int i = 0; i < A_PER_THREAD; ++i) {
+      const int hh = a_h[i] + dh, ww = a_w[i] + dw;
+      const bool ok = (a_m[i] < M) && (ca < p.C) && (hh >= 0) && (hh < p.H) && (ww >= 0) && (ww < p.W);
+      ra[i] = ok ? ld4(p.A + (a_m[i] + (long long)dh * p.W + dw) * p.lda + ca) : f4zero();
+    }
+    const float* Bt = p.B + (long long)tap * p.b_tap_stride;
+#pragma unroll
+    for (int i = 0; i < B_PER_THREAD; ++i) {
+      const int idx = t + 256 * i;
+      rb[i] = f4zero();
+      if (idx < B_TOTAL) {
+        if (B_NK) {
+          const int n = idx >> 3, kq = idx & 7;
+          const int k = c0 + kq * 4;
+          if (n0 + n < p.Nout && k < p.C) rb[i] = ld4(Bt + (long long)(n0 + n) * p.ldb + k);
+        } else {
+          const int k = idx / (BN / 4), nq = idx - k * (BN / 4);
+          const int n = n0 + nq * 4;
+          if (c0 + k < p.C && n < p.Nout) rb[i] = ld4(Bt + (long long)(c0 + k) * p.ldb + n);
+        }
+      }
+    }
+  };
+
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int i = 0; i < A_PER_THREAD; ++i) {
+      const int row = a_r0 + 32 * i;
+      st4(smA + (a_kq * BM + (row ^ a_kq)) * 4, ra[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < B_PER_THREAD; ++i) {
+      const int idx = t + 256 * i;
+      if (idx < B_TOTAL) {
+        if (B_NK) {
+          const int n = idx >> 3, kq = idx & 7;
+          st4(smB + (kq * BN + (n ^ kq)) * 4, rb[i]);
+        } else {
+          const int k = idx / (BN / 4), nq = idx - k * (BN / 4);
+          st4(smB + k * LDB_NN + nq * 4, rb[i]);
+        }
+      }
+    }
+  };
+
+  f32x4 acc[TM][NT];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  if (it0 < it1) load_chunk(it0);
+  for (int it = it0; it < it1; ++it) {
+    store_chunk();
+    __syncthreads();
+    if (it + 1 < it1) load_chunk(it + 1);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int kq = q * 4 + g;
+      float4 av[TM];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int row = wave * 16 * TM + i * 16 + l15;
+        av[i] = ld4(smA + (kq * BM + (row ^ kq)) * 4);
+      }
+      if (B_NK) {
+        float4 bv[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bv[j] = ld4(smB + (kq * BN + ((j * 16 + l15) ^ kq)) * 4);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            const float a = s == 0 ? av[i].x : s == 1 ? av[i].y : s == 2 ? av[i].z : av[i].w;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+              const float b = s == 0 ? bv[j].x : s == 1 ? bv[j].y : s == 2 ? bv[j].z : bv[j].w;
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i][j], 0, 0, 0);
+            }
+          }
+        }
+      } else {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          float bs[NT];
+#pragma unroll
+          for (int j = 0; j < NT; ++j) bs[j] = smB[(q * 16 + 4 * g + s) * LDB_NN + j * 16 + l15];
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            const float a = s == 0 ? av[i].x : s == 1 ? av[i].y : s == 2 ? av[i].z : av[i].w;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bs[j], acc[i][j], 0, 0, 0);
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue.  C/D layout of 16x16x4: col = lane & 15, row = 4 * (lane >> 4) + reg
+  const bool split = p.partial != nullptr;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const long long m = m0 + wave * 16 * TM + i * 16 + g * 4 + r;
+      if (m >= M) continue;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int n = n0 + j * 16 + l15;
+        if (n >= p.Nout) continue;
+        float v = acc[i][j][r];
+        if (split) {
+          p.partial[((long long)blockIdx.z * M + m) * p.Nout + n] = v;
+        } else {
+          if (p.bias != nullptr) v += p.bias[n];
+          float* dst = p.Cmat + m * p.ldc + n;
+          if (p.accumulate) v += *dst;
+          *dst = v;
+        }
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void splitk_reduce_k(const float* __restrict__ partial, int splits, long long M, int Nout,
+                                                       float* __restrict__ Cmat, int ldc, const float* __restrict__ bias,
+                                                       int accumulate) {
+  const int Q = Nout >> 2;
+  const long long total = M * Q;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long m = i / Q;
+    const int n = (int)(i - m * Q) << 2;
+    float4 s = ld4(partial + m * Nout + n);
+    for (int z = 1; z < splits; ++z) s = f4add(s, ld4(partial + ((long long)z * M + m) * Nout + n));
+    if (bias != nullptr) s = f4add(s, ld4(bias + n));
+    float* dst = Cmat + m * ldc + n;
+    if (accumulate) s = f4add(s, ld4(dst));
+    st4(dst, s);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ backward-filter
+struct FilterGradParams {
+  const float* X;
+  int ldx;
+  int Nimg, H, W;
+  int C;
+  int ntaps, dil;
+  const float* dY;
+  int lddy;
+  int Nout;
+  float* partial;  // [splits][ntaps*C][Nout]
+  int rows_per_split;
+};
+
+template <int TMF, int NT>
+__global__ __launch_bounds__(256) void conv_filter_grad_k(FilterGradParams p) {
+  constexpr int BCI = 64 * TMF, BN = 16 * NT, BKM = 32;
+  constexpr int LDX = BCI + 16;
+  constexpr int LDD = (BN % 32 == 0) ? BN + 16 : BN;
+  constexpr int X_PER_THREAD = (BKM * (BCI / 4)) / 256;  // 2 * TMF
+  constexpr int D_TOTAL = BKM * (BN / 4);
+  constexpr int D_PER_THREAD = (D_TOTAL + 255) / 256;
+  __shared__ __attribute__((aligned(16))) float sm[BKM * LDX + BKM * LDD];
+  float* smX = sm;
+  float* smD = sm + BKM * LDX;
+
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int l15 = lane & 15, g = lane >> 4;
+  const long long M = (long long)p.Nimg * p.H * p.W;
+  const int cblocks = (p.C + BCI - 1) / BCI;
+  const int tap = blockIdx.x / cblocks;
+  const int ci0 = (blockIdx.x - tap * cblocks) * BCI;
+  const int n0 = blockIdx.y * BN;
+  long long mbeg = (long long)blockIdx.z * p.rows_per_split;
+  long long mend = mbeg + p.rows_per_split;
+  if (mend > M) mend = M;
+  int dh = 0, dw = 0;
+  if (p.ntaps > 1) {
+    dh = (tap / 3 - 1) * p.dil;
+    dw = (tap % 3 - 1) * p.dil;
+  }
+  const long long shift = (long long)dh * p.W + dw;
+  const long long HW = (long long)p.H * p.W;
+
+  const int x_cq = t % (BCI / 4);
+  const int x_r0 = t / (BCI / 4);  // rows x_r0 + (256/(BCI/4)) * i
+  constexpr int X_RSTEP = 256 / (BCI / 4);
+
+  float4 rx[X_PER_THREAD];
+  float4 rd[D_PER_THREAD];
+
+  auto load_chunk = [&](long long mc) {
+#pragma unroll
+    for (int i = 0; i < X_PER_THREAD; ++i) {
+      const long long m = mc + x_r0 + X_RSTEP * i;
+      bool ok = (m < mend) && (ci0 + x_cq * 4 < p.C);
+      if (ok && p.ntaps > 1) {
+        const int rem = (int)(m % HW);
+        const int h = rem / p.W, w = rem - h * p.W;
+        const int hh = h + dh, ww = w + dw;
+        ok = (hh >= 0) && (hh < p.H) && (ww >= 0) && (ww < p.W);
+      }
+      rx[i] = ok ? ld4(p.X + (m + shift) * p.ldx + ci0 + x_cq * 4) : f4zero();
+    }
+#pragma unroll
+    for (int i = 0; i < D_PER_THREAD; ++i) {
+      const int idx = t + 256 * i;
+      rd[i] = f4zero();
+      if (idx < D_TOTAL) {
+        const int r = idx / (BN / 4), nq = idx - r * (BN / 4);
+        const long long m = mc + r;
+        const int n = n0 + nq * 4;
+        if (m < mend && n < p.Nout) rd[i] = ld4(p.dY + m * p.lddy + n);
+      }
+    }
+  };
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int i = 0; i < X_PER_THREAD; ++i) st4(smX + (x_r0 + X_RSTEP * i) * LDX + x_cq * 4, rx[i]);
+#pragma unroll
+    for (int i = 0; i < D_PER_THREAD; ++i) {
+      const int idx = t + 256 * i;
+      if (idx < D_TOTAL) {
+        const int r = idx / (BN / 4), nq = idx - r * (BN / 4);
+        st4(smD + r * LDD + nq * 4, rd[i]);
+      }
+    }
+  };
+
+  f32x4 acc[TMF][NT];
+#pragma unroll
+  for (int i = 0; i < TMF; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  if (mbeg < mend) load_chunk(mbeg);
+  for (long long mc = mbeg; mc < mend; mc += BKM) {
+    store_chunk();
+    __syncthreads();
+    if (mc + BKM < mend) load_chunk(mc + BKM);
+#pragma unroll
+    for (int kk = 0; kk < BKM / 4; ++kk) {
+      const int mrow = kk * 4 + g;
+      float a[TMF], b[NT];
+#pragma unroll
+      for (int i = 0; i < TMF; ++i) a[i] = smX[mrow * LDX + (wave * TMF + i) * 16 + l15];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) b[j] = smD[mrow * LDD + j * 16 + l15];
+#pragma unroll
+      for (int i = 0; i < TMF; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  const long long Ktot = (long long)p.ntaps * p.C;
+#pragma unroll
+  for (int i = 0; i < TMF; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ci = ci0 + (wave * TMF + i) * 16 + g * 4 + r;
+      if (ci >= p.C) continue;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int n = n0 + j * 16 + l15;
+        if (n < p.Nout) p.partial[((long long)blockIdx.z * Ktot + (long long)tap * p.C + ci) * p.Nout + n] = acc[i][j][r];
+      }
+    }
+}
+
+__global__ __launch_bounds__(256) void filter_reduce_k(const float* __restrict__ partial, int splits, long long total,
+                                                       float* __restrict__ out, int accumulate) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    float s = partial[i];
+    for (int z = 1; z < splits; ++z) s += partial[(long long)z * total + i];
+    out[i] = accumulate ? out[i] + s : s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ host-side planning
+struct GemmPlan {
+  int tm, nt, gx, gy, gz, chunks_per_split;
+};
+
+static inline int pick_nt(int Nout) {
+  int blocks = (Nout + 127) / 128;
+  int per = (Nout + blocks - 1) / blocks;
+  int nt = (per + 15) / 16;
+  return nt < 1 ? 1 : nt;
+}
+
+static inline GemmPlan plan_gemm(long long M, int Nout, int C, int ntaps, int num_cus, int allow_split) {
+  GemmPlan g;
+  g.nt = pick_nt(Nout);
+  g.gy = (Nout + g.nt * 16 - 1) / (g.nt * 16);
+  long long b128 = (M + 127) / 128 * g.gy;
+  g.tm = (b128 >= num_cus * 3 / 4) ? 2 : 1;
+  g.gx = (int)((M + 64 * g.tm - 1) / (64 * g.tm));
+  int nchunks = ntaps * ((C + 31) / 32);
+  g.gz = 1;
+  if (allow_split) {
+    long long blocks = (long long)g.gx * g.gy;
+    // split K when the grid cannot fill the chip and there is enough K to amortise the extra pass
+    while (blocks * g.gz * 2 <= num_cus && nchunks / (g.gz * 2) >= 8 && g.gz < 16) g.gz *= 2;
+  }
+  g.chunks_per_split = (nchunks + g.gz - 1) / g.gz;
+  g.gz = (nchunks + g.chunks_per_split - 1) / g.chunks_per_split;
+  return g;
+}
+
+template <bool B_NK>
+static void launch_gemm(const GemmPlan& g, const ConvGemmParams& p, hipStream_t stream) {
+  dim3 grid(g.gx, g.gy, g.gz), block(256);
+#define L(TM_, NT_)                                                                               \
+  hipLaunchKernelGGL((conv_gemm_k<TM_, NT_, B_NK>), grid, block, 0, stream, p);                   \
+  break;
+#define ROW(TM_)       \
+  switch (g.nt) {      \
+    case 1: L(TM_, 1)  \
+    case 2: L(TM_, 2)  \
+    case 3: L(TM_, 3)  \
+    case 4: L(TM_, 4)  \
+    case 5: L(TM_, 5)  \
+    case 6: L(TM_, 6)  \
+    case 7: L(TM_, 7)  \
+    default: L(TM_, 8) \
+  }
+  if (g.tm == 2) {
+    ROW(2)
+  } else {
+    ROW(1)
+  }
+#undef ROW
+#undef L
+}
+
+struct FilterPlan {
+  int tmf, nt, gx, gy, gz, rows_per_split;
+};
+static inline FilterPlan plan_filter(long long M, int C, int Nout, int ntaps, int num_cus) {
+  FilterPlan f;
+  f.nt = pick_nt(Nout);
+  f.gy = (Nout + f.nt * 16 - 1) / (f.nt * 16);
+  // 128-wide ci blocks halve the dY re-reads; take them unless they pad more zero rows than 64-wide blocks would
+  const int waste128 = (C + 127) / 128 * 128 - C, waste64 = (C + 63) / 64 * 64 - C;
+  f.tmf = (C >= 128 && waste128 <= waste64) ? 2 : 1;
+  int bci = 64 * f.tmf;
+  f.gx = ntaps * ((C + bci - 1) / bci);
+  long long base = (long long)f.gx * f.gy;
+  long long want = (4LL * num_cus + base - 1) / base;  // ~4 blocks per CU in total
+  if (want < 1) want = 1;
+  long long rps = (M + want - 1) / want;
+  if (rps < 256) rps = 256;
+  rps = (rps + 31) / 32 * 32;
+  f.rows_per_split = (int)rps;
+  f.gz = (int)((M + rps - 1) / rps);
+  return f;
+}
+
+static void launch_filter(const FilterPlan& f, const FilterGradParams& p, hipStream_t stream) {
+  dim3 grid(f.gx, f.gy, f.gz), block(256);
+#define L(T_, NT_)                                                                      \
+  hipLaunchKernelGGL((conv_filter_grad_k<T_, NT_>), grid, block, 0, stream, p);         \
+  break;
+#define ROW(T_)       \
+  switch (f.nt) {     \
+    case 1: L(T_, 1)  \
+    case 2: L(T_, 2)  \
+    case 3: L(T_, 3)  \
+    case 4: L(T_, 4)  \
+    case 5: L(T_, 5)  \
+    case 6: L(T_, 6)  \
+    case 7: L(T_, 7)  \
+    default: L(T_, 8) \
+  }
+  if (f.tmf == 2) {
+    ROW(2)
+  } else {
+    ROW(1)
+  }
+#undef ROW
+#undef L
+}
+
+static int g_num_cus = 0;
+static int num_cus() {
+  if (g_num_cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+      g_num_cus = prop.multiProcessorCount;
+    else
+      g_num_cus = 256;
+  }
+  return g_num_cus;
+}
+
+static int conv_check(const char* name, int Nimg, int H, int W, int Cin, int Cout, int ksize, int dil) {
+  MLIIS_REQUIRE(Nimg > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, MLIIS_ERR_ARG, "%s: bad shape", name);
+  MLIIS_REQUIRE((Cin & 3) == 0 && (Cout & 3) == 0, MLIIS_ERR_ARG, "%s: channel counts must be multiples of 4 (Cin=%d Cout=%d)", name,
+                Cin, Cout);
+  MLIIS_REQUIRE(ksize == 1 || ksize == 3, MLIIS_ERR_UNSUPPORTED, "%s: kernel size %d unsupported (1 or 3)", name, ksize);
+  MLIIS_REQUIRE(dil >= 1, MLIIS_ERR_ARG, "%s: dilation must be >= 1", name);
+  return MLIIS_OK;
+}
+
+}  // namespace mliis
+
+using namespace mliis;
+
+extern "C" {
+
+// Workspace (floats) that conv2d_fwd / conv2d_bwd_data may need for split-K partials.
+size_t mliis_conv2d_workspace_floats(int Nimg, int H, int W, int Cred, int Nout, int ksize) {
+  long long M = (long long)Nimg * H * W;
+  GemmPlan g = plan_gemm(M, Nout, Cred, ksize * ksize, num_cus(), 1);
+  return g.gz > 1 ? (size_t)g.gz * M * Nout : 0;
+}
+
+// y[M, Cout] (ld = ldy) (+)= conv(x[M, Cin] (ld = ldx), w[k,k,Cin,Cout]) + bias ; stride 1, TF-SAME, dilation dil
+int mliis_conv2d_fwd(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int Nimg, int H, int W, int Cin,
+                     int Cout, int ksize, int dil, int accumulate, float* ws, size_t ws_floats, hipStream_t stream) {
+  int rc = conv_check("conv2d_fwd", Nimg, H, W, Cin, Cout, ksize, dil);
+  if (rc) return rc;
+  MLIIS_REQUIRE(x && w && y, MLIIS_ERR_ARG, "conv2d_fwd: null pointer");
+  MLIIS_REQUIRE((ldx & 3) == 0 && ldx >= Cin && ldy >= Cout, MLIIS_ERR_ARG, "conv2d_fwd: bad leading dimensions");
+  MLIIS_REQUIRE(aligned16(x) && aligned16(w) && aligned16(bias), MLIIS_ERR_ALIGN, "conv2d_fwd: pointers must be 16-byte aligned");
+  long long M = (long long)Nimg * H * W;
+  GemmPlan g = plan_gemm(M, Cout, Cin, ksize * ksize, num_cus(), ws != nullptr);
+  ConvGemmParams p{x, ldx, Nimg, H, W, Cin, ksize * ksize, dil, +1, w, (long long)Cin * Cout, Cout, Cout, y, ldy, bias, accumulate,
+                   nullptr, g.chunks_per_split};
+  if (g.gz > 1) {
+    size_t need = (size_t)g.gz * M * Cout;
+    MLIIS_REQUIRE(need <= ws_floats && aligned16(ws) && (ldy & 3) == 0 && aligned16(y), MLIIS_ERR_WORKSPACE,
+                  "conv2d_fwd: split-K workspace too small (%zu needed, %zu given) or unaligned output", need, ws_floats);
+    p.partial = ws;
+  }
+  launch_gemm<false>(g, p, stream);
+  MLIIS_CHECK_LAUNCH("conv2d_fwd");
+  if (g.gz > 1) {
+    long long q = M * (Cout / 4);
+    int blocks = (int)((q + 255) / 256 > 2048 ? 2048 : (q + 255) / 256);
+    hipLaunchKernelGGL(splitk_reduce_k, dim3(blocks), dim3(256), 0, stream, ws, g.gz, M, Cout, y, ldy, bias, accumulate);
+    MLIIS_CHECK_LAUNCH("conv2d_fwd_splitk_reduce");
+  }
+  return MLIIS_OK;
+}
+
+// dx[M, Cin_out] (ld = lddx) (+)= conv_transpose(dy[M, Cout] (ld = lddy), w) restricted to input channels
+// [ci_begin, ci_begin + Cin_out) of a weight tensor w[k,k,Cin_total,Cout].
+int mliis_conv2d_bwd_data(const float* dy, int lddy, const float* w, float* dx, int lddx, int Nimg, int H, int W, int Cin_total,
+                          int ci_begin, int Cin_out, int Cout, int ksize, int dil, int accumulate, float* ws, size_t ws_floats,
+                          hipStream_t stream) {
+  int rc = conv_check("conv2d_bwd_data", Nimg, H, W, Cin_out, Cout, ksize, dil);
+  if (rc) return rc;
+  MLIIS_REQUIRE(dy && w && dx, MLIIS_ERR_ARG, "conv2d_bwd_data: null pointer");
+  MLIIS_REQUIRE(ci_begin >= 0 && ci_begin + Cin_out <= Cin_total, MLIIS_ERR_ARG, "conv2d_bwd_data: channel window out of range");
+  MLIIS_REQUIRE((lddy & 3) == 0 && lddy >= Cout && lddx >= Cin_out, MLIIS_ERR_ARG, "conv2d_bwd_data: bad leading dimensions");
+  MLIIS_REQUIRE(aligned16(dy) && aligned16(w), MLIIS_ERR_ALIGN, "conv2d_bwd_data: pointers must be 16-byte aligned");
+  long long M = (long long)Nimg * H * W;
+  GemmPlan g = plan_gemm(M, Cin_out, Cout, ksize * ksize, num_cus(), ws != nullptr);
+  ConvGemmParams p{dy, lddy, Nimg, H, W, Cout, ksize * ksize, dil, -1, w + (long long)ci_begin * Cout, (long long)Cin_total * Cout,
+                   Cout, Cin_out, dx, lddx, nullptr, accumulate, nullptr, g.chunks_per_split};
+  if (g.gz > 1) {
+    size_t need = (size_t)g.gz * M * Cin_out;
+    MLIIS_REQUIRE(need <= ws_floats && aligned16(ws) && (lddx & 3) == 0 && aligned16(dx), MLIIS_ERR_WORKSPACE,
+                  "conv2d_bwd_data: split-K workspace too small (%zu needed, %zu given) or unaligned output", need, ws_floats);
+    p.partial = ws;
+  }
+  launch_gemm<true>(g, p, stream);
+  MLIIS_CHECK_LAUNCH("conv2d_bwd_data");
+  if (g.gz > 1) {
+    long long q = M * (Cin_out / 4);
+    int blocks = (int)((q + 255) / 256 > 2048 ? 2048 : (q + 255) / 256);
+    hipLaunchKernelGGL(splitk_reduce_k, dim3(blocks), dim3(256), 0, stream, ws, g.gz, M, Cin_out, dx, lddx, nullptr, accumulate);
+    MLIIS_CHECK_LAUNCH("conv2d_bwd_data_splitk_reduce");
+  }
+  return MLIIS_OK;
+}
+
+size_t mliis_conv2d_bwd_filter_workspace_floats(int Nimg, int H, int W, int Cin, int Cout, int ksize) {
+  long long M = (long long)Nimg * H * W;
+  FilterPlan f = plan_filter(M, Cin, Cout, ksize * ksize, num_cus());
+  return (size_t)f.gz * ksize * ksize * Cin * Cout;
+}
+
+// dw[k,k,Cin,Cout] (+)= sum_pixels x[pixel + tap offset, ci] * dy[pixel, co]
+int mliis_conv2d_bwd_filter(const float* x, int ldx, const float* dy, int lddy, float* dw, int Nimg, int H, int W, int Cin, int Cout,
+                            int ksize, int dil, int accumulate, float* ws, size_t ws_floats, hipStream_t stream) {
+  int rc = conv_check("conv2d_bwd_filter", Nimg, H, W, Cin, Cout, ksize, dil);
+  if (rc) return rc;
+  MLIIS_REQUIRE(x && dy && dw && ws, MLIIS_ERR_ARG, "conv2d_bwd_filter: null pointer");
+  MLIIS_REQUIRE((ldx & 3) == 0 && ldx >= Cin && (lddy & 3) == 0 && lddy >= Cout, MLIIS_ERR_ARG, "conv2d_bwd_filter: bad leading dimensions");
+  MLIIS_REQUIRE(aligned16(x) && aligned16(dy) && aligned16(ws), MLIIS_ERR_ALIGN, "conv2d_bwd_filter: pointers must be 16-byte aligned");
+  long long M = (long long)Nimg * H * W;
+  FilterPlan f = plan_filter(M, Cin, Cout, ksize * ksize, num_cus());
+  size_t total = (size_t)ksize * ksize * Cin * Cout;
+  MLIIS_REQUIRE((size_t)f.gz * total <= ws_floats, MLIIS_ERR_WORKSPACE, "conv2d_bwd_filter: workspace too small (%zu needed, %zu given)",
+                (size_t)f.gz * total, ws_floats);
+  FilterGradParams p{x, ldx, Nimg, H, W, Cin, ksize * ksize, dil, dy, lddy, Cout, ws, f.rows_per_split};
+  launch_filter(f, p, stream);
+  MLIIS_CHECK_LAUNCH("conv2d_bwd_filter");
+  int blocks = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+  hipLaunchKernelGGL(filter_reduce_k, dim3(blocks), dim3(256), 0, stream, ws, f.gz, (long long)total, dw, accumulate);
+  MLIIS_CHECK_LAUNCH("conv2d_bwd_filter_reduce");
+  return MLIIS_OK;
+}
+}

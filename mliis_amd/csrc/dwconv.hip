@@ -1,0 +1,295 @@
+// Depthwise k x k convolution (k in {3,5}, stride in {1,2}, TF-SAME padding), NHWC fp32: forward, backward-data,
+// backward-filter.  Reference call sites: models/efficientnet/efficientnet_model.py:190-196,271 and
+// models/efficientnet/utils.py:219-222 (keras DepthwiseConv2D, depth_multiplier 1, no bias).
+//
+// HBM-bound (arithmetic intensity 0.9-6.2 flop/B).  Lanes run along C in float4, so one wave
+// instruction reads whole contiguous channel spans; every thread owns a strip of TW outputs along W and keeps the
+// (TW-1)*S+K input columns of the current filter row in registers (sliding window), so each input element is fetched
+// K (not K*K) times per strip and those re-reads are L1/L2 hits.  Filter taps are wave-uniform-per-quad loads that stay
+// in L1.  Backward-filter is a deterministic two-stage reduction (block partials -> double-precision fold).
+#include "common.hpp"
+
+namespace mliis {
+
+template <int K, int S, int TW>
+__global__ __launch_bounds__(256) void dwconv_fwd_k(const float* __restrict__ x, const float* __restrict__ w,
+                                                    float* __restrict__ y, int N, int Hi, int Wi, int Ho, int Wo, int C, int pt,
+                                                    int pl) {
+  constexpr int IW = (TW - 1) * S + K;
+  const int Q = C >> 2;
+  const int strips = (Wo + TW - 1) / TW;
+  const long long total = (long long)N * Ho * strips * Q;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int cq = (int)(i % Q);
+  long long r = i / Q;
+  const int sx = (int)(r % strips);
+  r /= strips;
+  const int ho = (int)(r % Ho);
+  const int n = (int)(r / Ho);
+  const int c = cq << 2;
+  const int wo0 = sx * TW;
+  const int hi0 = ho * S - pt, wi0 = wo0 * S - pl;
+  float4 acc[TW];
+#pragma unroll
+  for (int t = 0; t < TW; ++t) acc[t] = f4zero();
+#pragma unroll
+  for (int ky = 0; ky < K; ++ky) {
+    const int hi = hi0 + ky;
+    if (hi < 0 || hi >= Hi) continue;
+    const float* xrow = x + ((long long)(n * Hi + hi) * Wi) * C + c;
+    float4 in[IW];
+#pragma unroll
+    for (int j = 0; j < IW; ++j) {
+      const int wi = wi0 + j;
+      in[j] = (wi >= 0 && wi < Wi) ? ld4(xrow + (long long)wi * C) : f4zero();
+    }
+#pragma unroll
+    for (int kx = 0; kx < K; ++kx) {
+      const float4 wv = ld4(w + (ky * K + kx) * C + c);
+#pragma unroll
+      for (int t = 0; t < TW; ++t) acc[t] = f4fma(in[t * S + kx], wv, acc[t]);
+    }
+  }
+  float* yrow = y + ((long long)(n * Ho + ho) * Wo) * C + c;
+#pragma unroll
+  for (int t = 0; t < TW; ++t)
+    if (wo0 + t < Wo) st4(yrow + (long long)(wo0 + t) * C, acc[t]);
+}
+
+// dx[n,hi,wi,c] = sum_{ky,kx : (hi+pt-ky) % S == 0, (wi+pl-kx) % S == 0} dy[n,(hi+pt-ky)/S,(wi+pl-kx)/S,c] * w[ky,kx,c]
+template <int K, int S, int TW>
+__global__ __launch_bounds__(256) void dwconv_bwd_data_k(const float* __restrict__ dy, const float* __restrict__ w,
+                                                         float* __restrict__ dx, int N, int Hi, int Wi, int Ho, int Wo, int C,
+                                                         int pt, int pl) {
+  constexpr int JW = TW + K - 1;
+  const int Q = C >> 2;
+  const int strips = (Wi + TW - 1) / TW;
+  const long long total = (long long)N * Hi * strips * Q;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int cq = (int)(i % Q);
+  long long r = i / Q;
+  const int sx = (int)(r % strips);
+  r /= strips;
+  const int hi = (int)(r % Hi);
+  const int n = (int)(r / Hi);
+  const int c = cq << 2;
+  const int wi0 = sx * TW;
+  const int base = wi0 + pl - (K - 1);  // wx of window slot j is base + j ; tap kx pairs output t with slot t + K-1-kx
+  float4 acc[TW];
+#pragma unroll
+  for (int t = 0; t < TW; ++t) acc[t] = f4zero();
+#pragma unroll
+  for (int ky = 0; ky < K; ++ky) {
+    const int hy = hi + pt - ky;
+    if (hy < 0 || (hy % S) != 0) continue;
+    const int ho = hy / S;
+    if (ho >= Ho) continue;
+    const float* drow = dy + ((long long)(n * Ho + ho) * Wo) * C + c;
+    float4 dv[JW];
+#pragma unroll
+    for (int j = 0; j < JW; ++j) {
+      const int wx = base + j;
+      const bool ok = (wx >= 0) && ((wx % S) == 0) && ((wx / S) < Wo);
+      dv[j] = ok ? ld4(drow + (long long)(wx / S) * C) : f4zero();
+    }
+#pragma unroll
+    for (int kx = 0; kx < K; ++kx) {
+      const float4 wv = ld4(w + (ky * K + kx) * C + c);
+#pragma unroll
+      for (int t = 0; t < TW; ++t) acc[t] = f4fma(dv[t + K - 1 - kx], wv, acc[t]);
+    }
+  }
+  float* xrow = dx + ((long long)(n * Hi + hi) * Wi) * C + c;
+#pragma unroll
+  for (int t = 0; t < TW; ++t)
+    if (wi0 + t < Wi) st4(xrow + (long long)(wi0 + t) * C, acc[t]);
+}
+
+// Stage 1 of dw[ky,kx,c] = sum_{n,ho,wo} x[n,ho*S-pt+ky,wo*S-pl+kx,c] * dy[n,ho,wo,c].
+// Block = QB channel quads x RP strip-lanes; every thread walks strips item = rl, rl+RP, ... of the block's range keeping
+// K*K float4 accumulators, then the RP lanes of each quad are folded through LDS.  part layout [blk][K*K][C].
+template <int K, int S, int TW>
+__global__ __launch_bounds__(256) void dwconv_bwd_filter_k(const float* __restrict__ x, const float* __restrict__ dy,
+                                                           float* __restrict__ part, int N, int Hi, int Wi, int Ho, int Wo,
+                                                           int C, int pt, int pl, int QB, int RP, int items_per_block) {
+  constexpr int IW = (TW - 1) * S + K;
+  __shared__ float4 sm[256];
+  const int t = threadIdx.x;
+  const int ql = t % QB, rl = t / QB;
+  const int Q = C >> 2;
+  const int q = blockIdx.y * QB + ql;
+  const int c = q << 2;
+  const int strips = (Wo + TW - 1) / TW;
+  const long long items = (long long)N * Ho * strips;
+  const bool active = (rl < RP) && (q < Q);
+  float4 acc[K * K];
+#pragma unroll
+  for (int k = 0; k < K * K; ++k) acc[k] = f4zero();
+  if (active) {
+    const long long i0 = (long long)blockIdx.x * items_per_block;
+    long long i1 = i0 + items_per_block;
+    if (i1 > items) i1 = items;
+    for (long long it = i0 + rl; it < i1; it += RP) {
+      const int sx = (int)(it % strips);
+      const long long r = it / strips;
+      const int ho = (int)(r % Ho);
+      const int n = (int)(r / Ho);
+      const int wo0 = sx * TW;
+      const int hi0 = ho * S - pt, wi0 = wo0 * S - pl;
+      const float* drow = dy + ((long long)(n * Ho + ho) * Wo) * C + c;
+      float4 dv[TW];
+#pragma unroll
+      for (int j = 0; j < TW; ++j) dv[j] = (wo0 + j < Wo) ? ld4(drow + (long long)(wo0 + j) * C) : f4zero();
+#pragma unroll
+      for (int ky = 0; ky < K; ++ky) {
+        const int hi = hi0 + ky;
+        if (hi < 0 || hi >= Hi) continue;
+        const float* xrow = x + ((long long)(n * Hi + hi) * Wi) * C + c;
+        float4 in[IW];
+#pragma unroll
+        for (int j = 0; j < IW; ++j) {
+          const int wi = wi0 + j;
+          in[j] = (wi >= 0 && wi < Wi) ? ld4(xrow + (long long)wi * C) : f4zero();
+        }
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) {
+#pragma unroll
+          for (int j = 0; j < TW; ++j) acc[ky * K + kx] = f4fma(in[j * S + kx], dv[j], acc[ky * K + kx]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < K * K; ++k) {
+    __syncthreads();
+    sm[t] = acc[k];
+    __syncthreads();
+    if (rl == 0 && q < Q) {
+      float4 s = sm[ql];
+      for (int j = 1; j < RP; ++j) s = f4add(s, sm[j * QB + ql]);
+      st4(part + ((long long)blockIdx.x * (K * K) + k) * C + c, s);
+    }
+  }
+}
+
+__global__ void dw_filter_finalize_k(const float* __restrict__ part, int nblk, int KK, int C, float* __restrict__ dw) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= KK * C) return;
+  double s = 0.0;
+  for (int b = 0; b < nblk; ++b) s += (double)part[(long long)b * KK * C + i];
+  dw[i] = (float)s;
+}
+
+struct DwGeom {
+  int Ho, Wo, pt, pl;
+};
+static inline DwGeom dw_geom(int Hi, int Wi, int K, int S) {
+  DwGeom g;
+  g.Ho = (Hi + S - 1) / S;
+  g.Wo = (Wi + S - 1) / S;
+  int th = (g.Ho - 1) * S + K - Hi;
+  int tw = (g.Wo - 1) * S + K - Wi;
+  if (th < 0) th = 0;
+  if (tw < 0) tw = 0;
+  g.pt = th / 2;
+  g.pl = tw / 2;
+  return g;
+}
+
+struct DwFilterGeom {
+  int QB, RP, items_per_block, nblk, ny;
+};
+static inline DwFilterGeom dw_filter_geom(int N, int Ho, int Wo, int C, int TW) {
+  DwFilterGeom g;
+  int Q = C / 4;
+  g.QB = Q < 64 ? Q : 64;
+  g.RP = 256 / g.QB;
+  g.ny = ceil_div(Q, g.QB);
+  long long items = (long long)N * Ho * ((Wo + TW - 1) / TW);
+  long long want = 1024 / g.ny;
+  if (want < 1) want = 1;
+  long long ipb = (items + want - 1) / want;
+  long long minr = (long long)g.RP * 4;
+  if (ipb < minr) ipb = minr;
+  ipb = (ipb + g.RP - 1) / g.RP * g.RP;
+  g.items_per_block = (int)ipb;
+  g.nblk = ceil_div(items, ipb);
+  return g;
+}
+
+constexpr int kTW = 4;
+
+}  // namespace mliis
+
+using namespace mliis;
+
+#define DW_DISPATCH(KERNEL, ...)                                                                              \
+  do {                                                                                                        \
+    if (k == 3 && stride == 1) hipLaunchKernelGGL((KERNEL<3, 1, kTW>), grid, dim3(256), 0, stream, __VA_ARGS__);      \
+    else if (k == 3 && stride == 2) hipLaunchKernelGGL((KERNEL<3, 2, kTW>), grid, dim3(256), 0, stream, __VA_ARGS__); \
+    else if (k == 5 && stride == 1) hipLaunchKernelGGL((KERNEL<5, 1, kTW>), grid, dim3(256), 0, stream, __VA_ARGS__); \
+    else hipLaunchKernelGGL((KERNEL<5, 2, kTW>), grid, dim3(256), 0, stream, __VA_ARGS__);                            \
+  } while (0)
+
+static int dw_check(const char* name, const void* a, const void* b, const void* c, int N, int H, int W, int C, int k, int stride) {
+  MLIIS_REQUIRE(a && b && c, MLIIS_ERR_ARG, "%s: null pointer", name);
+  MLIIS_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && (C & 3) == 0, MLIIS_ERR_ARG, "%s: bad shape N=%d H=%d W=%d C=%d (C %% 4 must be 0)",
+                name, N, H, W, C);
+  MLIIS_REQUIRE((k == 3 || k == 5) && (stride == 1 || stride == 2), MLIIS_ERR_UNSUPPORTED, "%s: unsupported k=%d stride=%d", name, k,
+                stride);
+  MLIIS_REQUIRE(aligned16(a) && aligned16(b) && aligned16(c), MLIIS_ERR_ALIGN, "%s: pointers must be 16-byte aligned", name);
+  return MLIIS_OK;
+}
+
+extern "C" {
+
+int mliis_dwconv_fwd(const float* x, const float* w, float* y, int N, int H, int W, int C, int k, int stride, hipStream_t stream) {
+  int rc = dw_check("dwconv_fwd", x, w, y, N, H, W, C, k, stride);
+  if (rc) return rc;
+  DwGeom g = dw_geom(H, W, k, stride);
+  long long total = (long long)N * g.Ho * ((g.Wo + kTW - 1) / kTW) * (C / 4);
+  dim3 grid(ceil_div(total, 256));
+  DW_DISPATCH(dwconv_fwd_k, x, w, y, N, H, W, g.Ho, g.Wo, C, g.pt, g.pl);
+  MLIIS_CHECK_LAUNCH("dwconv_fwd");
+  return MLIIS_OK;
+}
+
+int mliis_dwconv_bwd_data(const float* dy, const float* w, float* dx, int N, int H, int W, int C, int k, int stride,
+                          hipStream_t stream) {
+  int rc = dw_check("dwconv_bwd_data", dy, w, dx, N, H, W, C, k, stride);
+  if (rc) return rc;
+  DwGeom g = dw_geom(H, W, k, stride);
+  long long total = (long long)N * H * ((W + kTW - 1) / kTW) * (C / 4);
+  dim3 grid(ceil_div(total, 256));
+  DW_DISPATCH(dwconv_bwd_data_k, dy, w, dx, N, H, W, g.Ho, g.Wo, C, g.pt, g.pl);
+  MLIIS_CHECK_LAUNCH("dwconv_bwd_data");
+  return MLIIS_OK;
+}
+
+size_t mliis_dwconv_bwd_filter_workspace_floats(int N, int H, int W, int C, int k, int stride) {
+  if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return 0;
+  DwGeom g = dw_geom(H, W, k, stride);
+  DwFilterGeom f = dw_filter_geom(N, g.Ho, g.Wo, C, kTW);
+  return (size_t)f.nblk * k * k * C;
+}
+
+int mliis_dwconv_bwd_filter(const float* x, const float* dy, float* dw, int N, int H, int W, int C, int k, int stride, float* ws,
+                            size_t ws_floats, hipStream_t stream) {
+  int rc = dw_check("dwconv_bwd_filter", x, dy, dw, N, H, W, C, k, stride);
+  if (rc) return rc;
+  MLIIS_REQUIRE(ws && aligned16(ws), MLIIS_ERR_ARG, "dwconv_bwd_filter: workspace null/unaligned");
+  DwGeom g = dw_geom(H, W, k, stride);
+  DwFilterGeom f = dw_filter_geom(N, g.Ho, g.Wo, C, kTW);
+  size_t need = (size_t)f.nblk * k * k * C;
+  MLIIS_REQUIRE(need <= ws_floats, MLIIS_ERR_WORKSPACE, "dwconv_bwd_filter: workspace too small (%zu needed, %zu given)", need,
+                ws_floats);
+  dim3 grid(f.nblk, f.ny);
+  DW_DISPATCH(dwconv_bwd_filter_k, x, dy, ws, N, H, W, g.Ho, g.Wo, C, g.pt, g.pl, f.QB, f.RP, f.items_per_block);
+  MLIIS_CHECK_LAUNCH("dwconv_bwd_filter");
+  hipLaunchKernelGGL(dw_filter_finalize_k, dim3(ceil_div(k * k * C, 256)), dim3(256), 0, stream, ws, f.nblk, k * k, C, dw);
+  MLIIS_CHECK_LAUNCH("dwconv_bwd_filter_finalize");
+  return MLIIS_OK;
+}
+}

@@ -1,0 +1,370 @@
+// Decoder tail: bilinear resize (align_corners=True) forward / backward, final 1x1 conv (Cout = 2, + bias, optional
+// dropout mask) forward / backward-data, and the fused per-pixel softmax cross-entropy (+ label smoothing, + soft-IoU "dice"
+// term) forward/backward with the thresholded prediction mask.
+// Reference: models/efficientlab.py:161-177 (dropout -> 1x1 -> resize -> softmax -> >0.5), :205-206 (RSD upsample),
+// :294-303,319-327,329-396 (loss).  All HBM-bound, all deterministic (gather-form backward, two-stage reductions).
+#include "common.hpp"
+
+namespace mliis {
+
+template <int V>
+struct Vec;
+template <>
+struct Vec<4> {
+  typedef float4 T;
+};
+template <>
+struct Vec<2> {
+  typedef float2 T;
+};
+__device__ __forceinline__ float4 vfma(float s, float4 a, float4 c) {
+  return make_float4(fmaf(s, a.x, c.x), fmaf(s, a.y, c.y), fmaf(s, a.z, c.z), fmaf(s, a.w, c.w));
+}
+__device__ __forceinline__ float2 vfma(float s, float2 a, float2 c) { return make_float2(fmaf(s, a.x, c.x), fmaf(s, a.y, c.y)); }
+template <class T>
+__device__ __forceinline__ T vzero();
+template <>
+__device__ __forceinline__ float4 vzero<float4>() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+template <>
+__device__ __forceinline__ float2 vzero<float2>() { return make_float2(0.f, 0.f); }
+
+__device__ __forceinline__ void src_coord(int o, float scale, int in_size, int& i0, int& i1, float& l) {
+  const float f = (float)o * scale;
+  i0 = (int)floorf(f);
+  if (i0 > in_size - 1) i0 = in_size - 1;
+  i1 = i0 + 1 < in_size ? i0 + 1 : in_size - 1;
+  l = f - (float)i0;
+}
+
+template <int V>
+__global__ __launch_bounds__(256) void resize_fwd_k(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy, int N,
+                                                    int Hi, int Wi, int Ho, int Wo, int C, float sh, float sw) {
+  typedef typename Vec<V>::T T;
+  const int Q = C / V;
+  const long long total = (long long)N * Ho * Wo * Q;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % Q) * V;
+    long long p = i / Q;
+    const int wo = (int)(p % Wo);
+    long long r = p / Wo;
+    const int ho = (int)(r % Ho);
+    const int n = (int)(r / Ho);
+    int y0, y1, x0, x1;
+    float ly, lx;
+    src_coord(ho, sh, Hi, y0, y1, ly);
+    src_coord(wo, sw, Wi, x0, x1, lx);
+    const float* base = x + (long long)n * Hi * Wi * ldx + c;
+    const T tl = *reinterpret_cast<const T*>(base + ((long long)y0 * Wi + x0) * ldx);
+    const T tr = *reinterpret_cast<const T*>(base + ((long long)y0 * Wi + x1) * ldx);
+    const T bl = *reinterpret_cast<const T*>(base + ((long long)y1 * Wi + x0) * ldx);
+    const T br = *reinterpret_cast<const T*>(base + ((long long)y1 * Wi + x1) * ldx);
+    // top = tl + (tr - tl) * lx ; bottom likewise ; out = top + (bottom - top) * ly   (TF ResizeBilinear form)
+    T o = vzero<T>();
+    o = vfma((1.f - ly) * (1.f - lx), tl, o);
+    o = vfma((1.f - ly) * lx, tr, o);
+    o = vfma(ly * (1.f - lx), bl, o);
+    o = vfma(ly * lx, br, o);
+    *reinterpret_cast<T*>(y + p * ldy + c) = o;
+  }
+}
+
+// gather-form transpose: dx[n,hi,wi] = sum_{ho,wo} wy(ho,hi) * wx(wo,wi) * dy[n,ho,wo]
+template <int V>
+__global__ __launch_bounds__(256) void resize_bwd_k(const float* __restrict__ dy, int lddy, float* __restrict__ dx, int lddx, int N,
+                                                    int Hi, int Wi, int Ho, int Wo, int C, float sh, float sw, int accumulate) {
+  typedef typename Vec<V>::T T;
+  const int Q = C / V;
+  const long long total = (long long)N * Hi * Wi * Q;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % Q) * V;
+    long long p = i / Q;
+    const int wi = (int)(p % Wi);
+    long long r = p / Wi;
+    const int hi = (int)(r % Hi);
+    const int n = (int)(r / Hi);
+    // conservative candidate ranges of output rows/cols that can touch (hi, wi)
+    int ho_lo = (int)floorf((float)(hi - 1) / sh) - 1, ho_hi = (int)ceilf((float)(hi + 1) / sh) + 1;
+    int wo_lo = (int)floorf((float)(wi - 1) / sw) - 1, wo_hi = (int)ceilf((float)(wi + 1) / sw) + 1;
+    if (ho_lo < 0) ho_lo = 0;
+    if (wo_lo < 0) wo_lo = 0;
+    if (ho_hi > Ho - 1) ho_hi = Ho - 1;
+    if (wo_hi > Wo - 1) wo_hi = Wo - 1;
+    T acc = vzero<T>();
+    const float* base = dy + (long long)n * Ho * Wo * lddy + c;
+    for (int ho = ho_lo; ho <= ho_hi; ++ho) {
+      int y0, y1;
+      float ly;
+      src_coord(ho, sh, Hi, y0, y1, ly);
+      const float wy = (y0 == hi ? 1.f - ly : 0.f) + (y1 == hi ? ly : 0.f);
+      if (wy == 0.f) continue;
+      for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+        int x0, x1;
+        float lx;
+        src_coord(wo, sw, Wi, x0, x1, lx);
+        const float wx = (x0 == wi ? 1.f - lx : 0.f) + (x1 == wi ? lx : 0.f);
+        if (wx == 0.f) continue;
+        acc = vfma(wy * wx, *reinterpret_cast<const T*>(base + ((long long)ho * Wo + wo) * lddy), acc);
+      }
+    }
+    T* dst = reinterpret_cast<T*>(dx + p * lddx + c);
+    if (accumulate) {
+      T old = *dst;
+      acc = vfma(1.f, old, acc);
+    }
+    *dst = acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ final 1x1 conv, Cout = 2
+// 4 lanes per pixel, lanes interleave the channel quads (64 contiguous bytes per pixel per step), xor-shuffle reduce.
+__global__ __launch_bounds__(256) void final_conv_fwd_k(const float* __restrict__ x, int ldx, const float* __restrict__ mask,
+                                                        const float* __restrict__ w, const float* __restrict__ b,
+                                                        float* __restrict__ y, long long rows, int C) {
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long row = gid >> 2;
+  const int part = (int)(gid & 3);
+  float a0 = 0.f, a1 = 0.f;
+  if (row < rows) {
+    const int Q = C >> 2;
+    for (int q = part; q < Q; q += 4) {
+      float4 v = ld4(x + row * ldx + q * 4);
+      if (mask) v = f4mul(v, ld4(mask + row * ldx + q * 4));
+      const float4 w0 = ld4(w + q * 8), w1 = ld4(w + q * 8 + 4);  // w[c][0..1] for c = 4q..4q+3
+      a0 += v.x * w0.x + v.y * w0.z + v.z * w1.x + v.w * w1.z;
+      a1 += v.x * w0.y + v.y * w0.w + v.z * w1.y + v.w * w1.w;
+    }
+  }
+  a0 += __shfl_xor(a0, 1, 64);
+  a1 += __shfl_xor(a1, 1, 64);
+  a0 += __shfl_xor(a0, 2, 64);
+  a1 += __shfl_xor(a1, 2, 64);
+  if (row < rows && part == 0) *reinterpret_cast<float2*>(y + row * 2) = make_float2(a0 + b[0], a1 + b[1]);
+}
+
+__global__ __launch_bounds__(256) void final_conv_bwd_data_k(const float* __restrict__ dy, const float* __restrict__ w,
+                                                             const float* __restrict__ mask, float* __restrict__ dx, int lddx,
+                                                             long long rows, int C) {
+  const int Q = C >> 2;
+  const long long total = rows * Q;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / Q;
+    const int q = (int)(i - r * Q);
+    const float2 d = *reinterpret_cast<const float2*>(dy + r * 2);
+    const float4 w0 = ld4(w + q * 8), w1 = ld4(w + q * 8 + 4);
+    float4 o = make_float4(d.x * w0.x + d.y * w0.y, d.x * w0.z + d.y * w0.w, d.x * w1.x + d.y * w1.y, d.x * w1.z + d.y * w1.w);
+    if (mask) o = f4mul(o, ld4(mask + r * lddx + q * 4));
+    st4(dx + r * lddx + q * 4, o);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ softmax CE (+dice)
+// part layout [n][blk][4] = {sum CE, sum p1*t1, sum p1, sum t1}
+__global__ __launch_bounds__(256) void ce_partial_k(const float* __restrict__ logits, const float* __restrict__ labels,
+                                                    const int* __restrict__ idx, int HW, float ls, float* __restrict__ part) {
+  __shared__ float sm[4][4];
+  const int n = blockIdx.y;
+  const int src = idx ? idx[n] : n;
+  const float* z = logits + (long long)n * HW * 2;
+  const float* t = labels + (long long)src * HW * 2;
+  float ce = 0.f, I = 0.f, Sp = 0.f, St = 0.f;
+  for (int p = blockIdx.x * 256 + threadIdx.x; p < HW; p += gridDim.x * 256) {
+    const float2 zz = *reinterpret_cast<const float2*>(z + (long long)p * 2);
+    const float2 tt = *reinterpret_cast<const float2*>(t + (long long)p * 2);
+    const float m = fmaxf(zz.x, zz.y);
+    const float e0 = expf(zz.x - m), e1 = expf(zz.y - m);
+    const float lse = m + logf(e0 + e1);
+    const float t0 = tt.x * (1.f - ls) + 0.5f * ls, t1 = tt.y * (1.f - ls) + 0.5f * ls;
+    ce -= t0 * (zz.x - lse) + t1 * (zz.y - lse);
+    const float p1 = e1 / (e0 + e1);
+    I += p1 * tt.y;
+    Sp += p1;
+    St += tt.y;
+  }
+  ce = wave_sum(ce);
+  I = wave_sum(I);
+  Sp = wave_sum(Sp);
+  St = wave_sum(St);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+    sm[wave][0] = ce;
+    sm[wave][1] = I;
+    sm[wave][2] = Sp;
+    sm[wave][3] = St;
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    const float s = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
+    part[((long long)n * gridDim.x + blockIdx.x) * 4 + threadIdx.x] = s;
+  }
+}
+
+// out: [0] loss, [1] ce, [2] iou ; coef[n] = {A_n, B_n} for the dice gradient (0 when dice off)
+__global__ void ce_finalize_k(const float* __restrict__ part, int nblk, int N, int HW, int dice, float extra_loss,
+                              float* __restrict__ out, float* __restrict__ coef) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double ce = 0.0, iou = 0.0;
+  const double eps = 1e-7;
+  for (int n = 0; n < N; ++n) {
+    double c = 0, I = 0, Sp = 0, St = 0;
+    for (int b = 0; b < nblk; ++b) {
+      const float* q = part + ((long long)n * nblk + b) * 4;
+      c += q[0];
+      I += q[1];
+      Sp += q[2];
+      St += q[3];
+    }
+    ce += c;
+    const double U = Sp + St - I;
+    iou += (I + eps) / (U + eps);
+    coef[2 * n + 0] = (float)(1.0 / (U + eps));
+    coef[2 * n + 1] = (float)((I + eps) / ((U + eps) * (U + eps)));
+  }
+  ce /= (double)N * HW;
+  iou /= N;
+  double loss = ce + extra_loss;
+  double dLdiou = 0.0;
+  if (dice) {
+    loss -= log(2.0 * iou / (iou + 1.0));
+    dLdiou = -1.0 / (iou * (iou + 1.0));
+  }
+  for (int n = 0; n < N; ++n) {
+    coef[2 * n + 0] = (float)(coef[2 * n + 0] * dLdiou / N);
+    coef[2 * n + 1] = (float)(coef[2 * n + 1] * dLdiou / N);
+  }
+  out[0] = (float)loss;
+  out[1] = (float)ce;
+  out[2] = (float)iou;
+}
+
+__global__ __launch_bounds__(256) void ce_grad_k(const float* __restrict__ logits, const float* __restrict__ labels,
+                                                 const int* __restrict__ idx, int HW, float ls, float inv_rows,
+                                                 const float* __restrict__ coef, float* __restrict__ dlogits,
+                                                 float* __restrict__ pred) {
+  const int n = blockIdx.y;
+  const int src = idx ? idx[n] : n;
+  const float* z = logits + (long long)n * HW * 2;
+  const float* t = labels + (long long)src * HW * 2;
+  const float An = coef[2 * n], Bn = coef[2 * n + 1];
+  for (int p = blockIdx.x * 256 + threadIdx.x; p < HW; p += gridDim.x * 256) {
+    const float2 zz = *reinterpret_cast<const float2*>(z + (long long)p * 2);
+    const float2 tt = *reinterpret_cast<const float2*>(t + (long long)p * 2);
+    const float m = fmaxf(zz.x, zz.y);
+    const float e0 = expf(zz.x - m), e1 = expf(zz.y - m);
+    const float inv = 1.f / (e0 + e1);
+    const float p0 = e0 * inv, p1 = e1 * inv;
+    const float t0 = tt.x * (1.f - ls) + 0.5f * ls, t1 = tt.y * (1.f - ls) + 0.5f * ls;
+    const float ts = t0 + t1;
+    float d0 = (p0 * ts - t0) * inv_rows, d1 = (p1 * ts - t1) * inv_rows;
+    const float dp1 = (An * tt.y - Bn * (1.f - tt.y)) * p1 * (1.f - p1);
+    d1 += dp1;
+    d0 -= dp1;
+    if (dlogits) *reinterpret_cast<float2*>(dlogits + ((long long)n * HW + p) * 2) = make_float2(d0, d1);
+    if (pred) *reinterpret_cast<float2*>(pred + ((long long)n * HW + p) * 2) = make_float2(p0 > 0.5f ? 1.f : 0.f, p1 > 0.5f ? 1.f : 0.f);
+  }
+}
+
+static inline int ew_blocks(long long q) {
+  long long b = (q + 255) / 256;
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace mliis
+
+using namespace mliis;
+
+extern "C" {
+
+int mliis_resize_bilinear_fwd(const float* x, int ldx, float* y, int ldy, int N, int Hi, int Wi, int Ho, int Wo, int C,
+                              hipStream_t stream) {
+  MLIIS_REQUIRE(x && y, MLIIS_ERR_ARG, "resize_bilinear_fwd: null pointer");
+  MLIIS_REQUIRE(N > 0 && Hi > 0 && Wi > 0 && Ho > 1 && Wo > 1 && C > 0 && (C & 1) == 0 && ldx >= C && ldy >= C, MLIIS_ERR_ARG,
+                "resize_bilinear_fwd: bad shape");
+  const float sh = (float)(Hi - 1) / (float)(Ho - 1), sw = (float)(Wi - 1) / (float)(Wo - 1);
+  if ((C & 3) == 0 && (ldx & 3) == 0 && (ldy & 3) == 0 && aligned16(x) && aligned16(y)) {
+    long long q = (long long)N * Ho * Wo * (C / 4);
+    hipLaunchKernelGGL((resize_fwd_k<4>), dim3(ew_blocks(q)), dim3(256), 0, stream, x, ldx, y, ldy, N, Hi, Wi, Ho, Wo, C, sh, sw);
+  } else {
+    MLIIS_REQUIRE((ldx & 1) == 0 && (ldy & 1) == 0, MLIIS_ERR_ALIGN, "resize_bilinear_fwd: leading dims must be even");
+    long long q = (long long)N * Ho * Wo * (C / 2);
+    hipLaunchKernelGGL((resize_fwd_k<2>), dim3(ew_blocks(q)), dim3(256), 0, stream, x, ldx, y, ldy, N, Hi, Wi, Ho, Wo, C, sh, sw);
+  }
+  MLIIS_CHECK_LAUNCH("resize_bilinear_fwd");
+  return MLIIS_OK;
+}
+
+// dx [N,Hi,Wi,C] (+)= transpose-resize of dy [N,Ho,Wo,C]  (Hi,Wi = forward INPUT size)
+int mliis_resize_bilinear_bwd(const float* dy, int lddy, float* dx, int lddx, int N, int Hi, int Wi, int Ho, int Wo, int C,
+                              int accumulate, hipStream_t stream) {
+  MLIIS_REQUIRE(dy && dx, MLIIS_ERR_ARG, "resize_bilinear_bwd: null pointer");
+  MLIIS_REQUIRE(N > 0 && Hi > 1 && Wi > 1 && Ho > 1 && Wo > 1 && C > 0 && (C & 1) == 0 && lddy >= C && lddx >= C, MLIIS_ERR_ARG,
+                "resize_bilinear_bwd: bad shape (input side must be > 1)");
+  const float sh = (float)(Hi - 1) / (float)(Ho - 1), sw = (float)(Wi - 1) / (float)(Wo - 1);
+  if ((C & 3) == 0 && (lddx & 3) == 0 && (lddy & 3) == 0 && aligned16(dx) && aligned16(dy)) {
+    long long q = (long long)N * Hi * Wi * (C / 4);
+    hipLaunchKernelGGL((resize_bwd_k<4>), dim3(ew_blocks(q)), dim3(256), 0, stream, dy, lddy, dx, lddx, N, Hi, Wi, Ho, Wo, C, sh, sw,
+                       accumulate);
+  } else {
+    MLIIS_REQUIRE((lddx & 1) == 0 && (lddy & 1) == 0, MLIIS_ERR_ALIGN, "resize_bilinear_bwd: leading dims must be even");
+    long long q = (long long)N * Hi * Wi * (C / 2);
+    hipLaunchKernelGGL((resize_bwd_k<2>), dim3(ew_blocks(q)), dim3(256), 0, stream, dy, lddy, dx, lddx, N, Hi, Wi, Ho, Wo, C, sh, sw,
+                       accumulate);
+  }
+  MLIIS_CHECK_LAUNCH("resize_bilinear_bwd");
+  return MLIIS_OK;
+}
+
+int mliis_final_conv_fwd(const float* x, int ldx, const float* mask, const float* w, const float* b, float* y, long long rows, int C,
+                         hipStream_t stream) {
+  MLIIS_REQUIRE(x && w && b && y, MLIIS_ERR_ARG, "final_conv_fwd: null pointer");
+  MLIIS_REQUIRE(rows > 0 && C > 0 && (C & 3) == 0 && (ldx & 3) == 0 && ldx >= C, MLIIS_ERR_ARG, "final_conv_fwd: bad shape");
+  MLIIS_REQUIRE(aligned16(x) && aligned16(mask) && aligned16(w), MLIIS_ERR_ALIGN, "final_conv_fwd: pointers must be 16-byte aligned");
+  hipLaunchKernelGGL(final_conv_fwd_k, dim3(ceil_div(rows * 4, 256)), dim3(256), 0, stream, x, ldx, mask, w, b, y, rows, C);
+  MLIIS_CHECK_LAUNCH("final_conv_fwd");
+  return MLIIS_OK;
+}
+
+int mliis_final_conv_bwd_data(const float* dy, const float* w, const float* mask, float* dx, int lddx, long long rows, int C,
+                              hipStream_t stream) {
+  MLIIS_REQUIRE(dy && w && dx, MLIIS_ERR_ARG, "final_conv_bwd_data: null pointer");
+  MLIIS_REQUIRE(rows > 0 && C > 0 && (C & 3) == 0 && (lddx & 3) == 0 && lddx >= C, MLIIS_ERR_ARG, "final_conv_bwd_data: bad shape");
+  MLIIS_REQUIRE(aligned16(dx) && aligned16(mask) && aligned16(w), MLIIS_ERR_ALIGN, "final_conv_bwd_data: pointers must be 16-byte aligned");
+  hipLaunchKernelGGL(final_conv_bwd_data_k, dim3(ew_blocks(rows * (C / 4))), dim3(256), 0, stream, dy, w, mask, dx, lddx, rows, C);
+  MLIIS_CHECK_LAUNCH("final_conv_bwd_data");
+  return MLIIS_OK;
+}
+
+size_t mliis_softmax_ce_workspace_floats(int N, int H, int W) {
+  if (N <= 0 || H <= 0 || W <= 0) return 0;
+  int nblk = ceil_div((long long)H * W, 256 * 8);
+  if (nblk > 256) nblk = 256;
+  return (size_t)N * nblk * 4 + 2 * (size_t)N + 8;
+}
+
+// logits [N,H,W,2]; labels [S,H,W,2] addressed through img_idx (nullable).  Writes out[0..2] = {loss, ce, iou} (device),
+// dlogits (nullable), pred (nullable; (softmax > 0.5) as float).  extra_loss is added to the reported loss only (L2 term).
+int mliis_softmax_ce(const float* logits, const float* labels, const int* img_idx, int N, int H, int W, float label_smoothing,
+                     int dice, float extra_loss, float* dlogits, float* pred, float* out, float* ws, size_t ws_floats,
+                     hipStream_t stream) {
+  MLIIS_REQUIRE(logits && labels && out && ws, MLIIS_ERR_ARG, "softmax_ce: null pointer");
+  MLIIS_REQUIRE(N > 0 && H > 0 && W > 0, MLIIS_ERR_ARG, "softmax_ce: bad shape");
+  MLIIS_REQUIRE((reinterpret_cast<uintptr_t>(logits) & 7u) == 0 && (reinterpret_cast<uintptr_t>(labels) & 7u) == 0, MLIIS_ERR_ALIGN,
+                "softmax_ce: logits/labels must be 8-byte aligned");
+  const int HW = H * W;
+  int nblk = ceil_div((long long)HW, 256 * 8);
+  if (nblk > 256) nblk = 256;
+  MLIIS_REQUIRE((size_t)N * nblk * 4 + 2 * (size_t)N <= ws_floats, MLIIS_ERR_WORKSPACE, "softmax_ce: workspace too small");
+  float* coef = ws + (size_t)N * nblk * 4;
+  hipLaunchKernelGGL(ce_partial_k, dim3(nblk, N), dim3(256), 0, stream, logits, labels, img_idx, HW, label_smoothing, ws);
+  MLIIS_CHECK_LAUNCH("softmax_ce_partial");
+  hipLaunchKernelGGL(ce_finalize_k, dim3(1), dim3(64), 0, stream, ws, nblk, N, HW, dice, extra_loss, out, coef);
+  MLIIS_CHECK_LAUNCH("softmax_ce_finalize");
+  if (dlogits || pred) {
+    hipLaunchKernelGGL(ce_grad_k, dim3(nblk, N), dim3(256), 0, stream, logits, labels, img_idx, HW, label_smoothing,
+                       1.0f / ((float)N * (float)HW), coef, dlogits, pred);
+    MLIIS_CHECK_LAUNCH("softmax_ce_grad");
+  }
+  return MLIIS_OK;
+}
+}

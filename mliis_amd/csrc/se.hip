@@ -1,0 +1,169 @@
+// Squeeze-excite gate MLP (forward and backward) and the per-image/per-channel affine elementwise op that applies the
+// gate, tiles pooled vectors and distributes pooled gradients.
+// Reference: models/efficientnet/efficientnet_model.py:238-251:  s = mean_hw(x); g = sigmoid(W2 . swish(W1 . s + b1) + b2);
+// y = g * x.  The spatial mean itself is mliis_colsum (bn.hip); the big tensors are touched by chan_affine only.
+// SE weights are TF HWIO 1x1 kernels: w1 [C][R], w2 [R][C].
+#include "common.hpp"
+
+namespace mliis {
+
+constexpr int kMaxR = 128;
+
+// one workgroup per image
+__global__ __launch_bounds__(256) void se_mlp_fwd_k(const float* __restrict__ s, const float* __restrict__ w1,
+                                                    const float* __restrict__ b1, const float* __restrict__ w2,
+                                                    const float* __restrict__ b2, float* __restrict__ hpre,
+                                                    float* __restrict__ gate, int C, int R) {
+  __shared__ float sh[kMaxR];
+  __shared__ float red[256];
+  const int n = blockIdx.x, t = threadIdx.x;
+  const float* sn = s + (long long)n * C;
+  // phase 1: h_j = b1[j] + sum_c s[c] * w1[c][j];  threads laid out (c-lane, j) so w1 reads are contiguous
+  const int CL = 256 / R;
+  const int j = t % R, cl = t / R;
+  float part = 0.f;
+  if (cl < CL)
+    for (int c = cl; c < C; c += CL) part = fmaf(sn[c], w1[(long long)c * R + j], part);
+  red[t] = part;
+  __syncthreads();
+  if (t < R) {
+    float h = b1[t];
+    for (int k = 0; k < CL; ++k) h += red[k * R + t];
+    hpre[(long long)n * R + t] = h;
+    sh[t] = swish_f(h);
+  }
+  __syncthreads();
+  for (int c = t; c < C; c += 256) {
+    float a = b2[c];
+    for (int k = 0; k < R; ++k) a = fmaf(sh[k], w2[(long long)k * C + c], a);
+    gate[(long long)n * C + c] = sigmoid_f(a);
+  }
+}
+
+// one workgroup per image: dgate -> dpre2 [C], dpre1 [R], chan_add = ds / HW [C]
+__global__ __launch_bounds__(256) void se_mlp_bwd_k(const float* __restrict__ dgate, const float* __restrict__ gate,
+                                                    const float* __restrict__ hpre, const float* __restrict__ w1,
+                                                    const float* __restrict__ w2, float* __restrict__ dpre2,
+                                                    float* __restrict__ dpre1, float* __restrict__ chan_add, int C, int R,
+                                                    float inv_hw) {
+  __shared__ float sd1[kMaxR];
+  const int n = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  float* d2 = dpre2 + (long long)n * C;
+  for (int c = t; c < C; c += 256) {
+    const float g = gate[(long long)n * C + c];
+    d2[c] = dgate[(long long)n * C + c] * g * (1.f - g);
+  }
+  __syncthreads();  // d2 written by this block, read below (same workgroup: barrier suffices)
+  for (int jj = wave; jj < R; jj += 4) {
+    float p = 0.f;
+    for (int c = lane; c < C; c += 64) p = fmaf(d2[c], w2[(long long)jj * C + c], p);
+    p = wave_sum(p);
+    if (lane == 0) {
+      const float d = p * swish_grad_f(hpre[(long long)n * R + jj]);
+      sd1[jj] = d;
+      dpre1[(long long)n * R + jj] = d;
+    }
+  }
+  __syncthreads();
+  for (int c = t; c < C; c += 256) {
+    float a = 0.f;
+    for (int k = 0; k < R; ++k) a = fmaf(sd1[k], w1[(long long)c * R + k], a);
+    chan_add[(long long)n * C + c] = a * inv_hw;
+  }
+}
+
+// one thread per weight element, loops over images (deterministic)
+__global__ __launch_bounds__(256) void se_wgrad_k(const float* __restrict__ s, const float* __restrict__ hpre,
+                                                  const float* __restrict__ dpre1, const float* __restrict__ dpre2,
+                                                  float* __restrict__ dw1, float* __restrict__ db1, float* __restrict__ dw2,
+                                                  float* __restrict__ db2, int N, int C, int R) {
+  const int CR = C * R;
+  const int total = 2 * CR + C + R;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  float a = 0.f;
+  if (i < CR) {  // dw1[c][j] = sum_n s[n][c] * dpre1[n][j]
+    const int c = i / R, j = i - c * R;
+    for (int n = 0; n < N; ++n) a = fmaf(s[(long long)n * C + c], dpre1[(long long)n * R + j], a);
+    dw1[i] = a;
+  } else if (i < 2 * CR) {  // dw2[j][c] = sum_n swish(hpre[n][j]) * dpre2[n][c]
+    const int k = i - CR;
+    const int j = k / C, c = k - j * C;
+    for (int n = 0; n < N; ++n) a = fmaf(swish_f(hpre[(long long)n * R + j]), dpre2[(long long)n * C + c], a);
+    dw2[k] = a;
+  } else if (i < 2 * CR + C) {
+    const int c = i - 2 * CR;
+    for (int n = 0; n < N; ++n) a += dpre2[(long long)n * C + c];
+    db2[c] = a;
+  } else {
+    const int j = i - 2 * CR - C;
+    for (int n = 0; n < N; ++n) a += dpre1[(long long)n * R + j];
+    db1[j] = a;
+  }
+}
+
+// y[m, c] (+)= x[m, c] * S[n(m), c] + A[n(m), c]      (x, S, A each optional)
+__global__ __launch_bounds__(256) void chan_affine_k(const float* __restrict__ x, int ldx, const float* __restrict__ S,
+                                                     const float* __restrict__ A, float* __restrict__ y, int ldy, long long rows,
+                                                     int C, int rows_per_img, int accumulate) {
+  const int Q = C >> 2;
+  const long long total = rows * Q;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / Q;
+    const int c = (int)(i - r * Q) << 2;
+    const long long n = r / rows_per_img;
+    float4 v = x ? ld4(x + r * ldx + c) : f4zero();
+    if (S) v = f4mul(v, ld4(S + n * C + c));
+    if (A) v = f4add(v, ld4(A + n * C + c));
+    float* dst = y + r * ldy + c;
+    if (accumulate) v = f4add(v, ld4(dst));
+    st4(dst, v);
+  }
+}
+
+}  // namespace mliis
+
+using namespace mliis;
+
+extern "C" {
+
+int mliis_se_mlp_fwd(const float* s, const float* w1, const float* b1, const float* w2, const float* b2, float* hpre, float* gate,
+                     int N, int C, int R, hipStream_t stream) {
+  MLIIS_REQUIRE(s && w1 && b1 && w2 && b2 && hpre && gate, MLIIS_ERR_ARG, "se_mlp_fwd: null pointer");
+  MLIIS_REQUIRE(N > 0 && C > 0 && R > 0 && R <= kMaxR, MLIIS_ERR_ARG, "se_mlp_fwd: bad shape (R <= %d)", kMaxR);
+  hipLaunchKernelGGL(se_mlp_fwd_k, dim3(N), dim3(256), 0, stream, s, w1, b1, w2, b2, hpre, gate, C, R);
+  MLIIS_CHECK_LAUNCH("se_mlp_fwd");
+  return MLIIS_OK;
+}
+
+// dgate[N,C] = sum_hw dy * x (mliis_colsum).  Produces dpre1 [N,R], dpre2 [N,C] (scratch kept for the weight gradients),
+// chan_add [N,C] = (dL/ds)/HW, and the four weight gradients.
+int mliis_se_mlp_bwd(const float* dgate, const float* gate, const float* s, const float* hpre, const float* w1, const float* w2,
+                     float* dpre1, float* dpre2, float* chan_add, float* dw1, float* db1, float* dw2, float* db2, int N, int C, int R,
+                     int HW, hipStream_t stream) {
+  MLIIS_REQUIRE(dgate && gate && s && hpre && w1 && w2 && dpre1 && dpre2 && chan_add && dw1 && db1 && dw2 && db2, MLIIS_ERR_ARG,
+                "se_mlp_bwd: null pointer");
+  MLIIS_REQUIRE(N > 0 && C > 0 && R > 0 && R <= kMaxR && HW > 0, MLIIS_ERR_ARG, "se_mlp_bwd: bad shape");
+  hipLaunchKernelGGL(se_mlp_bwd_k, dim3(N), dim3(256), 0, stream, dgate, gate, hpre, w1, w2, dpre2, dpre1, chan_add, C, R,
+                     1.0f / (float)HW);
+  MLIIS_CHECK_LAUNCH("se_mlp_bwd");
+  int total = 2 * C * R + C + R;
+  hipLaunchKernelGGL(se_wgrad_k, dim3(ceil_div(total, 256)), dim3(256), 0, stream, s, hpre, dpre1, dpre2, dw1, db1, dw2, db2, N, C, R);
+  MLIIS_CHECK_LAUNCH("se_wgrad");
+  return MLIIS_OK;
+}
+
+int mliis_chan_affine(const float* x, int ldx, const float* S, const float* A, float* y, int ldy, long long rows, int C,
+                      int rows_per_img, int accumulate, hipStream_t stream) {
+  MLIIS_REQUIRE(y && (x || A), MLIIS_ERR_ARG, "chan_affine: need an output and at least one of x / A");
+  MLIIS_REQUIRE(rows > 0 && C > 0 && (C & 3) == 0 && (ldy & 3) == 0 && ldy >= C && rows_per_img > 0 &&
+                    (x == nullptr || ((ldx & 3) == 0 && ldx >= C)),
+                MLIIS_ERR_ARG, "chan_affine: bad shape");
+  MLIIS_REQUIRE(aligned16(x) && aligned16(S) && aligned16(A) && aligned16(y), MLIIS_ERR_ALIGN, "chan_affine: pointers must be 16-byte aligned");
+  long long q = rows * (C / 4);
+  int blocks = (int)((q + 255) / 256 > 4096 ? 4096 : (q + 255) / 256);
+  hipLaunchKernelGGL(chan_affine_k, dim3(blocks), dim3(256), 0, stream, x, ldx, S, A, y, ldy, rows, C, rows_per_img, accumulate);
+  MLIIS_CHECK_LAUNCH("chan_affine");
+  return MLIIS_OK;
+}
+}

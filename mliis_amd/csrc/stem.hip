@@ -1,0 +1,191 @@
+// Stem: input normalisation fused into the 3x3 stride-2 TF-SAME conv 3 -> Co (no bias).
+// Reference: models/efficientlab.py:113-114 ((x - MEAN_RGB) / STDDEV_RGB on 0..255 inputs, zero padding is applied to the
+// NORMALISED image) and models/efficientnet/efficientnet_model.py:359-366,411-412.  K = 27: far too skinny for the matrix
+// cores and HBM-bound, so this is a direct kernel; the batch is addressed through an optional index vector so the inner
+// loop never re-stacks images (meta_learners/metaseg.py:285-302 wrap-around batches are index lists here).
+#include "common.hpp"
+
+namespace mliis {
+
+struct StemGeom {
+  int Ho, Wo, pt, pl;
+};
+static inline StemGeom stem_geom(int H, int W) {
+  StemGeom g;
+  g.Ho = (H + 1) / 2;
+  g.Wo = (W + 1) / 2;
+  int th = (g.Ho - 1) * 2 + 3 - H, tw = (g.Wo - 1) * 2 + 3 - W;
+  if (th < 0) th = 0;
+  if (tw < 0) tw = 0;
+  g.pt = th / 2;
+  g.pl = tw / 2;
+  return g;
+}
+
+struct Norm3 {
+  float m0, m1, m2, i0, i1, i2;  // mean (m*) and std (i*) per channel
+};
+
+__device__ __forceinline__ void load_window(const float* __restrict__ img, int H, int W, int hi0, int wi0, Norm3 nm, float* v) {
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const int hi = hi0 + ky;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int wi = wi0 + kx;
+      const bool ok = hi >= 0 && hi < H && wi >= 0 && wi < W;
+      const float* px = img + ((long long)hi * W + wi) * 3;
+      // TF divides by std; (x - m) / s is restated as a true division to stay within 1 ulp of it
+      v[(ky * 3 + kx) * 3 + 0] = ok ? (px[0] - nm.m0) / nm.i0 : 0.f;
+      v[(ky * 3 + kx) * 3 + 1] = ok ? (px[1] - nm.m1) / nm.i1 : 0.f;
+      v[(ky * 3 + kx) * 3 + 2] = ok ? (px[2] - nm.m2) / nm.i2 : 0.f;
+    }
+  }
+}
+
+// thread = (pixel, channel octet)
+__global__ __launch_bounds__(256) void stem_fwd_k(const float* __restrict__ x, const int* __restrict__ idx,
+                                                  const float* __restrict__ w, float* __restrict__ z, int N, int H, int W, int Ho,
+                                                  int Wo, int Co, int pt, int pl, Norm3 nm) {
+  extern __shared__ float sw[];  // [27][Co]
+  for (int i = threadIdx.x; i < 27 * Co; i += 256) sw[i] = w[i];
+  __syncthreads();
+  const int OPP = Co >> 3;
+  const long long total = (long long)N * Ho * Wo * OPP;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int oct = (int)(i % OPP);
+  long long pix = i / OPP;
+  const int wo = (int)(pix % Wo);
+  long long r = pix / Wo;
+  const int ho = (int)(r % Ho);
+  const int n = (int)(r / Ho);
+  const int src = idx ? idx[n] : n;
+  float v[27];
+  load_window(x + (long long)src * H * W * 3, H, W, ho * 2 - pt, wo * 2 - pl, nm, v);
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+  for (int k = 0; k < 27; ++k) {
+    const float4 w0 = ld4(sw + k * Co + oct * 8), w1 = ld4(sw + k * Co + oct * 8 + 4);
+    acc[0] = fmaf(v[k], w0.x, acc[0]);
+    acc[1] = fmaf(v[k], w0.y, acc[1]);
+    acc[2] = fmaf(v[k], w0.z, acc[2]);
+    acc[3] = fmaf(v[k], w0.w, acc[3]);
+    acc[4] = fmaf(v[k], w1.x, acc[4]);
+    acc[5] = fmaf(v[k], w1.y, acc[5]);
+    acc[6] = fmaf(v[k], w1.z, acc[6]);
+    acc[7] = fmaf(v[k], w1.w, acc[7]);
+  }
+  float* dst = z + pix * Co + oct * 8;
+  st4(dst, make_float4(acc[0], acc[1], acc[2], acc[3]));
+  st4(dst + 4, make_float4(acc[4], acc[5], acc[6], acc[7]));
+}
+
+// thread = (pixel lane, co); part layout [blk][27][Co]
+__global__ __launch_bounds__(256) void stem_bwd_filter_k(const float* __restrict__ x, const int* __restrict__ idx,
+                                                         const float* __restrict__ dz, float* __restrict__ part, int N, int H,
+                                                         int W, int Ho, int Wo, int Co, int pt, int pl, Norm3 nm,
+                                                         int pix_per_block) {
+  extern __shared__ float sred[];  // [PL][Co] per tap, reused
+  const int PL = 256 / Co;
+  const int co = threadIdx.x % Co, pl_ = threadIdx.x / Co;
+  const bool active = pl_ < PL;
+  const long long P = (long long)N * Ho * Wo;
+  float acc[27];
+#pragma unroll
+  for (int k = 0; k < 27; ++k) acc[k] = 0.f;
+  if (active) {
+    const long long p0 = (long long)blockIdx.x * pix_per_block;
+    long long p1 = p0 + pix_per_block;
+    if (p1 > P) p1 = P;
+    for (long long pix = p0 + pl_; pix < p1; pix += PL) {
+      const int wo = (int)(pix % Wo);
+      long long r = pix / Wo;
+      const int ho = (int)(r % Ho);
+      const int n = (int)(r / Ho);
+      const int src = idx ? idx[n] : n;
+      float v[27];
+      load_window(x + (long long)src * H * W * 3, H, W, ho * 2 - pt, wo * 2 - pl, nm, v);
+      const float d = dz[pix * Co + co];
+#pragma unroll
+      for (int k = 0; k < 27; ++k) acc[k] = fmaf(v[k], d, acc[k]);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 27; ++k) {
+    __syncthreads();
+    if (active) sred[pl_ * Co + co] = acc[k];
+    __syncthreads();
+    if (pl_ == 0) {
+      float s = sred[co];
+      for (int j = 1; j < PL; ++j) s += sred[j * Co + co];
+      part[((long long)blockIdx.x * 27 + k) * Co + co] = s;
+    }
+  }
+}
+
+__global__ void stem_filter_finalize_k(const float* __restrict__ part, int nblk, int total, float* __restrict__ dw) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  double s = 0.0;
+  for (int b = 0; b < nblk; ++b) s += (double)part[(long long)b * total + i];
+  dw[i] = (float)s;
+}
+
+static inline void stem_filter_geom(int N, int Ho, int Wo, int Co, int* pix_per_block, int* nblk) {
+  long long P = (long long)N * Ho * Wo;
+  int PL = 256 / Co;
+  long long ppb = (P + 1023) / 1024;
+  if (ppb < PL * 4) ppb = PL * 4;
+  ppb = (ppb + PL - 1) / PL * PL;
+  *pix_per_block = (int)ppb;
+  *nblk = (int)((P + ppb - 1) / ppb);
+}
+
+}  // namespace mliis
+
+using namespace mliis;
+
+extern "C" {
+
+int mliis_stem_conv_fwd(const float* x, const int* img_idx, const float* w, float* z, int N, int H, int W, int Co, const float* mean3,
+                        const float* std3, hipStream_t stream) {
+  MLIIS_REQUIRE(x && w && z && mean3 && std3, MLIIS_ERR_ARG, "stem_conv_fwd: null pointer");
+  MLIIS_REQUIRE(N > 0 && H > 1 && W > 1 && Co > 0 && (Co & 7) == 0 && Co <= 256, MLIIS_ERR_ARG, "stem_conv_fwd: bad shape (Co %% 8 == 0 required)");
+  MLIIS_REQUIRE(aligned16(z), MLIIS_ERR_ALIGN, "stem_conv_fwd: output must be 16-byte aligned");
+  StemGeom g = stem_geom(H, W);
+  Norm3 nm{mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]};
+  long long total = (long long)N * g.Ho * g.Wo * (Co / 8);
+  hipLaunchKernelGGL(stem_fwd_k, dim3(ceil_div(total, 256)), dim3(256), 27 * Co * sizeof(float), stream, x, img_idx, w, z, N, H, W,
+                     g.Ho, g.Wo, Co, g.pt, g.pl, nm);
+  MLIIS_CHECK_LAUNCH("stem_conv_fwd");
+  return MLIIS_OK;
+}
+
+size_t mliis_stem_conv_bwd_filter_workspace_floats(int N, int H, int W, int Co) {
+  if (N <= 0 || H <= 1 || W <= 1 || Co <= 0 || Co > 256) return 0;
+  StemGeom g = stem_geom(H, W);
+  int ppb, nblk;
+  stem_filter_geom(N, g.Ho, g.Wo, Co, &ppb, &nblk);
+  return (size_t)nblk * 27 * Co;
+}
+
+int mliis_stem_conv_bwd_filter(const float* x, const int* img_idx, const float* dz, float* dw, int N, int H, int W, int Co,
+                               const float* mean3, const float* std3, float* ws, size_t ws_floats, hipStream_t stream) {
+  MLIIS_REQUIRE(x && dz && dw && ws && mean3 && std3, MLIIS_ERR_ARG, "stem_conv_bwd_filter: null pointer");
+  MLIIS_REQUIRE(N > 0 && H > 1 && W > 1 && Co > 0 && Co <= 256, MLIIS_ERR_ARG, "stem_conv_bwd_filter: bad shape");
+  StemGeom g = stem_geom(H, W);
+  int ppb, nblk;
+  stem_filter_geom(N, g.Ho, g.Wo, Co, &ppb, &nblk);
+  MLIIS_REQUIRE((size_t)nblk * 27 * Co <= ws_floats, MLIIS_ERR_WORKSPACE, "stem_conv_bwd_filter: workspace too small");
+  Norm3 nm{mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]};
+  hipLaunchKernelGGL(stem_bwd_filter_k, dim3(nblk), dim3(256), 256 * sizeof(float), stream, x, img_idx, dz, ws, N, H, W, g.Ho, g.Wo, Co,
+                     g.pt, g.pl, nm, ppb);
+  MLIIS_CHECK_LAUNCH("stem_conv_bwd_filter");
+  hipLaunchKernelGGL(stem_filter_finalize_k, dim3(ceil_div(27 * Co, 256)), dim3(256), 0, stream, ws, nblk, 27 * Co, dw);
+  MLIIS_CHECK_LAUNCH("stem_conv_bwd_filter_finalize");
+  return MLIIS_OK;
+}
+}

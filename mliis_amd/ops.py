@@ -1,0 +1,338 @@
+"""Thin tensor-level wrappers over the C ABI (one function per entry point family).
+
+PyTorch is used only as the owner of device memory and streams: every function takes fp32 CUDA(HIP) tensors, passes raw
+pointers + leading dimensions to libmliis_hip.so on the current stream and returns preallocated/new output tensors.
+There is no eager/PyTorch fallback -- a missing library or a non-device tensor raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from ._lib import MliisError, lib
+from .spec import BN_EPS, BN_MOMENTUM, MEAN_RGB, STDDEV_RGB
+
+_MEAN3 = (C.c_float * 3)(*MEAN_RGB)
+_STD3 = (C.c_float * 3)(*STDDEV_RGB)
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise MliisError("mliis_amd ops need device tensors (no CPU path)")
+    return t.data_ptr()
+
+
+def _chk(t: torch.Tensor, dtype=torch.float32):
+    if t.dtype != dtype:
+        raise MliisError("expected {} tensor, got {}".format(dtype, t.dtype))
+    return t
+
+
+class Workspace:
+    """Grow-only scratch buffer (floats) shared by all calls on a stream."""
+
+    def __init__(self, device="cuda", floats: int = 1 << 20):
+        self.device = device
+        self.buf = torch.empty(floats, dtype=torch.float32, device=device)
+
+    def get(self, floats: int) -> torch.Tensor:
+        if floats > self.buf.numel():
+            self.buf = torch.empty(int(floats * 1.25) + 1024, dtype=torch.float32, device=self.device)
+        return self.buf
+
+
+_default_ws = None
+
+
+def default_ws() -> Workspace:
+    global _default_ws
+    if _default_ws is None:
+        _default_ws = Workspace()
+    return _default_ws
+
+
+def rows_ld(t: torch.Tensor) -> Tuple[int, int, int]:
+    """[..., C] view whose leading dims are contiguous rows with stride ld: returns (rows, C, ld)."""
+    C_ = t.shape[-1]
+    if t.stride(-1) != 1:
+        raise MliisError("channel dim must be contiguous")
+    ld = t.stride(-2)
+    rows = t.numel() // C_
+    # all outer dims must collapse onto a uniform row stride
+    exp = ld
+    for d in range(t.dim() - 2, -1, -1):
+        if t.shape[d] != 1 and t.stride(d) != exp:
+            raise MliisError("tensor is not a uniform-row-stride view: shape {} strides {}".format(tuple(t.shape), t.stride()))
+        exp *= t.shape[d]
+    return rows, C_, ld
+
+
+# ------------------------------------------------------------------------------------------------ stem
+def stem_conv_fwd(x, w, idx=None, out=None):
+    S, H, W, _ = x.shape
+    N = S if idx is None else idx.numel()
+    Co = w.shape[-1]
+    Ho, Wo = (H + 1) // 2, (W + 1) // 2
+    out = torch.empty((N, Ho, Wo, Co), dtype=torch.float32, device=x.device) if out is None else out
+    lib.call("mliis_stem_conv_fwd", _ptr(_chk(x)), _ptr(idx), _ptr(w), _ptr(out), N, H, W, Co, _MEAN3, _STD3, _stream())
+    return out
+
+
+def stem_conv_bwd_filter(x, dz, idx=None, out=None, ws: Optional[Workspace] = None):
+    S, H, W, _ = x.shape
+    N, _, _, Co = dz.shape
+    ws = ws or default_ws()
+    need = lib.size("mliis_stem_conv_bwd_filter_workspace_floats", N, H, W, Co)
+    buf = ws.get(need)
+    out = torch.empty((3, 3, 3, Co), dtype=torch.float32, device=x.device) if out is None else out
+    lib.call("mliis_stem_conv_bwd_filter", _ptr(x), _ptr(idx), _ptr(dz), _ptr(out), N, H, W, Co, _MEAN3, _STD3, _ptr(buf), buf.numel(),
+             _stream())
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ depthwise
+def dwconv_fwd(x, w, stride, out=None):
+    N, H, W, C_ = x.shape
+    k = w.shape[0]
+    Ho, Wo = -(-H // stride), -(-W // stride)
+    out = torch.empty((N, Ho, Wo, C_), dtype=torch.float32, device=x.device) if out is None else out
+    lib.call("mliis_dwconv_fwd", _ptr(_chk(x)), _ptr(w), _ptr(out), N, H, W, C_, k, stride, _stream())
+    return out
+
+
+def dwconv_bwd_data(dy, w, stride, in_hw, out=None):
+    N, _, _, C_ = dy.shape
+    H, W = in_hw
+    k = w.shape[0]
+    out = torch.empty((N, H, W, C_), dtype=torch.float32, device=dy.device) if out is None else out
+    lib.call("mliis_dwconv_bwd_data", _ptr(_chk(dy)), _ptr(w), _ptr(out), N, H, W, C_, k, stride, _stream())
+    return out
+
+
+def dwconv_bwd_filter(x, dy, k, stride, out=None, ws: Optional[Workspace] = None):
+    N, H, W, C_ = x.shape
+    ws = ws or default_ws()
+    buf = ws.get(lib.size("mliis_dwconv_bwd_filter_workspace_floats", N, H, W, C_, k, stride))
+    out = torch.empty((k, k, C_, 1), dtype=torch.float32, device=x.device) if out is None else out
+    lib.call("mliis_dwconv_bwd_filter", _ptr(x), _ptr(dy), _ptr(out), N, H, W, C_, k, stride, _ptr(buf), buf.numel(), _stream())
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ dense conv
+def conv2d_fwd(x, w, bias=None, dil=1, out=None, accumulate=False, ws: Optional[Workspace] = None, nhw=None):
+    """x: [N,H,W,>=Cin] view (channel slice allowed); w: [k,k,Cin,Cout]."""
+    N, H, W = nhw if nhw is not None else x.shape[:3]
+    k, _, Cin, Cout = w.shape
+    rows, cx, ldx = rows_ld(x)
+    if cx != Cin:
+        raise MliisError("conv2d_fwd: x has {} channels, weight expects {}".format(cx, Cin))
+    out = torch.empty((N, H, W, Cout), dtype=torch.float32, device=x.device) if out is None else out
+    _, co, ldy = rows_ld(out)
+    ws = ws or default_ws()
+    buf = ws.get(lib.size("mliis_conv2d_workspace_floats", N, H, W, Cin, Cout, k))
+    lib.call("mliis_conv2d_fwd", _ptr(x), ldx, _ptr(w), _ptr(bias), _ptr(out), ldy, N, H, W, Cin, Cout, k, dil, int(accumulate), _ptr(buf),
+             buf.numel(), _stream())
+    return out
+
+
+def conv2d_bwd_data(dy, w, dil=1, ci_begin=0, ci_count=None, out=None, accumulate=False, ws: Optional[Workspace] = None):
+    N, H, W = dy.shape[:3]
+    k, _, Cin, Cout = w.shape
+    ci_count = Cin - ci_begin if ci_count is None else ci_count
+    _, cy, lddy = rows_ld(dy)
+    if cy != Cout:
+        raise MliisError("conv2d_bwd_data: dy has {} channels, weight has {}".format(cy, Cout))
+    out = torch.empty((N, H, W, ci_count), dtype=torch.float32, device=dy.device) if out is None else out
+    _, _, lddx = rows_ld(out)
+    ws = ws or default_ws()
+    buf = ws.get(lib.size("mliis_conv2d_workspace_floats", N, H, W, Cout, ci_count, k))
+    lib.call("mliis_conv2d_bwd_data", _ptr(dy), lddy, _ptr(w), _ptr(out), lddx, N, H, W, Cin, ci_begin, ci_count, Cout, k, dil,
+             int(accumulate), _ptr(buf), buf.numel(), _stream())
+    return out
+
+
+def conv2d_bwd_filter(x, dy, k, dil=1, out=None, accumulate=False, ws: Optional[Workspace] = None):
+    N, H, W = dy.shape[:3]
+    _, Cin, ldx = rows_ld(x)
+    _, Cout, lddy = rows_ld(dy)
+    out = torch.empty((k, k, Cin, Cout), dtype=torch.float32, device=x.device) if out is None else out
+    ws = ws or default_ws()
+    buf = ws.get(lib.size("mliis_conv2d_bwd_filter_workspace_floats", N, H, W, Cin, Cout, k))
+    lib.call("mliis_conv2d_bwd_filter", _ptr(x), ldx, _ptr(dy), lddy, _ptr(out), N, H, W, Cin, Cout, k, dil, int(accumulate), _ptr(buf),
+             buf.numel(), _stream())
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ batch norm
+def bn_stats(x, pre_swish=False, moving=None, unbiased_moving_var=False, mean=None, rstd=None, eps=BN_EPS, momentum=BN_MOMENTUM,
+             ws: Optional[Workspace] = None):
+    rows, C_, ldx = rows_ld(x)
+    mean = torch.empty(C_, dtype=torch.float32, device=x.device) if mean is None else mean
+    rstd = torch.empty(C_, dtype=torch.float32, device=x.device) if rstd is None else rstd
+    ws = ws or default_ws()
+    buf = ws.get(lib.size("mliis_colreduce_workspace_floats", rows, C_, 1, 2))
+    mm, mv = (None, None) if moving is None else moving
+    lib.call("mliis_bn_stats", _ptr(x), ldx, rows, C_, int(pre_swish), eps, momentum, int(unbiased_moving_var), _ptr(mean), _ptr(rstd),
+             _ptr(mm), _ptr(mv), _ptr(buf), buf.numel(), _stream())
+    return mean, rstd
+
+
+def bn_apply(x, mean, rstd, gamma, beta, pre_swish=False, post_swish=False, img_scale=None, res=None, out=None, rows_per_img=None):
+    rows, C_, ldx = rows_ld(x)
+    out = torch.empty(x.shape, dtype=torch.float32, device=x.device) if out is None else out
+    _, _, ldy = rows_ld(out)
+    rpi = rows_per_img or (rows // x.shape[0])
+    ldr = rows_ld(res)[2] if res is not None else 0
+    lib.call("mliis_bn_apply", _ptr(x), ldx, _ptr(out), ldy, rows, C_, rpi, _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), int(pre_swish),
+             int(post_swish), _ptr(img_scale), _ptr(res), ldr, _stream())
+    return out
+
+
+def bn_bwd(x, dy, mean, rstd, gamma, beta, pre_swish=False, post_swish=False, img_scale=None, chan_scale=None, chan_add=None, dx=None,
+           dgamma=None, dbeta=None, rows_per_img=None, ws: Optional[Workspace] = None):
+    rows, C_, ldx = rows_ld(x)
+    _, _, lddy = rows_ld(dy)
+    dx = torch.empty(x.shape, dtype=torch.float32, device=x.device) if dx is None else dx
+    _, _, lddx = rows_ld(dx)
+    dgamma = torch.empty(C_, dtype=torch.float32, device=x.device) if dgamma is None else dgamma
+    dbeta = torch.empty(C_, dtype=torch.float32, device=x.device) if dbeta is None else dbeta
+    rpi = rows_per_img or (rows // x.shape[0])
+    ws = ws or default_ws()
+    buf = ws.get(lib.size("mliis_colreduce_workspace_floats", rows, C_, 1, 2) + 2 * C_ + 16)
+    lib.call("mliis_bn_bwd", _ptr(x), ldx, _ptr(dy), lddy, _ptr(dx), lddx, rows, C_, rpi, _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta),
+             int(pre_swish), int(post_swish), _ptr(img_scale), _ptr(chan_scale), _ptr(chan_add), _ptr(dgamma), _ptr(dbeta), _ptr(buf),
+             buf.numel(), _stream())
+    return dx, dgamma, dbeta
+
+
+def colsum(a, b=None, nseg=1, scale=1.0, out=None, accumulate=False, ws: Optional[Workspace] = None):
+    rows, C_, lda = rows_ld(a)
+    ldb = rows_ld(b)[2] if b is not None else 0
+    out = torch.empty((nseg, C_), dtype=torch.float32, device=a.device) if out is None else out
+    ws = ws or default_ws()
+    buf = ws.get(lib.size("mliis_colreduce_workspace_floats", rows // nseg, C_, nseg, 1))
+    lib.call("mliis_colsum", _ptr(a), lda, _ptr(b), ldb, rows // nseg, nseg, C_, float(scale), _ptr(out), int(accumulate), _ptr(buf),
+             buf.numel(), _stream())
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ squeeze-excite
+def se_mlp_fwd(s, w1, b1, w2, b2, hpre=None, gate=None):
+    N, C_ = s.shape
+    R = b1.numel()
+    hpre = torch.empty((N, R), dtype=torch.float32, device=s.device) if hpre is None else hpre
+    gate = torch.empty((N, C_), dtype=torch.float32, device=s.device) if gate is None else gate
+    lib.call("mliis_se_mlp_fwd", _ptr(s), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), _ptr(hpre), _ptr(gate), N, C_, R, _stream())
+    return hpre, gate
+
+
+def se_mlp_bwd(dgate, gate, s, hpre, w1, w2, hw, outs=None):
+    N, C_ = s.shape
+    R = hpre.shape[1]
+    dev = s.device
+    if outs is None:
+        outs = dict(dpre1=torch.empty((N, R), device=dev), dpre2=torch.empty((N, C_), device=dev), chan_add=torch.empty((N, C_), device=dev),
+                    dw1=torch.empty((1, 1, C_, R), device=dev), db1=torch.empty(R, device=dev), dw2=torch.empty((1, 1, R, C_), device=dev),
+                    db2=torch.empty(C_, device=dev))
+    lib.call("mliis_se_mlp_bwd", _ptr(dgate), _ptr(gate), _ptr(s), _ptr(hpre), _ptr(w1), _ptr(w2), _ptr(outs["dpre1"]), _ptr(outs["dpre2"]),
+             _ptr(outs["chan_add"]), _ptr(outs["dw1"]), _ptr(outs["db1"]), _ptr(outs["dw2"]), _ptr(outs["db2"]), N, C_, R, hw, _stream())
+    return outs
+
+
+def chan_affine(x, S=None, A=None, out=None, accumulate=False, rows_per_img=None, like=None):
+    ref = x if x is not None else (out if out is not None else like)
+    rows, C_, _ = rows_ld(ref)
+    ldx = rows_ld(x)[2] if x is not None else 0
+    out = torch.empty(ref.shape, dtype=torch.float32, device=ref.device) if out is None else out
+    _, _, ldy = rows_ld(out)
+    rpi = rows_per_img or (rows // ref.shape[0])
+    lib.call("mliis_chan_affine", _ptr(x), ldx, _ptr(S), _ptr(A), _ptr(out), ldy, rows, C_, rpi, int(accumulate), _stream())
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ resize / head / loss
+def resize_bilinear_fwd(x, out_hw, out=None):
+    N, Hi, Wi = x.shape[:3]
+    _, C_, ldx = rows_ld(x)
+    Ho, Wo = out_hw
+    out = torch.empty((N, Ho, Wo, C_), dtype=torch.float32, device=x.device) if out is None else out
+    _, _, ldy = rows_ld(out)
+    lib.call("mliis_resize_bilinear_fwd", _ptr(x), ldx, _ptr(out), ldy, N, Hi, Wi, Ho, Wo, C_, _stream())
+    return out
+
+
+def resize_bilinear_bwd(dy, in_hw, out=None, accumulate=False):
+    N, Ho, Wo = dy.shape[:3]
+    _, C_, lddy = rows_ld(dy)
+    Hi, Wi = in_hw
+    out = torch.empty((N, Hi, Wi, C_), dtype=torch.float32, device=dy.device) if out is None else out
+    _, _, lddx = rows_ld(out)
+    lib.call("mliis_resize_bilinear_bwd", _ptr(dy), lddy, _ptr(out), lddx, N, Hi, Wi, Ho, Wo, C_, int(accumulate), _stream())
+    return out
+
+
+def final_conv_fwd(x, w, b, mask=None, out=None):
+    rows, C_, ldx = rows_ld(x)
+    out = torch.empty(tuple(x.shape[:-1]) + (2,), dtype=torch.float32, device=x.device) if out is None else out
+    lib.call("mliis_final_conv_fwd", _ptr(x), ldx, _ptr(mask), _ptr(w), _ptr(b), _ptr(out), rows, C_, _stream())
+    return out
+
+
+def final_conv_bwd_data(dy, w, C_, mask=None, out=None):
+    rows = dy.numel() // 2
+    out = torch.empty(tuple(dy.shape[:-1]) + (C_,), dtype=torch.float32, device=dy.device) if out is None else out
+    _, _, lddx = rows_ld(out)
+    lib.call("mliis_final_conv_bwd_data", _ptr(dy), _ptr(w), _ptr(mask), _ptr(out), lddx, rows, C_, _stream())
+    return out
+
+
+def final_conv_bwd_filter(x, dy, mask=None, dw=None, db=None, ws: Optional[Workspace] = None):
+    rows, C_, ldx = rows_ld(x)
+    dw = torch.empty((1, 1, C_, 2), dtype=torch.float32, device=x.device) if dw is None else dw
+    db = torch.empty(2, dtype=torch.float32, device=x.device) if db is None else db
+    ws = ws or default_ws()
+    buf = ws.get(lib.size("mliis_colreduce_workspace_floats", rows, C_, 1, 2))
+    lib.call("mliis_final_conv_bwd_filter", _ptr(x), ldx, _ptr(mask), _ptr(dy), rows, C_, _ptr(dw), _ptr(db), _ptr(buf), buf.numel(), _stream())
+    return dw, db
+
+
+def softmax_ce(logits, labels, idx=None, label_smoothing=0.0, dice=False, extra_loss=0.0, want_grad=True, want_pred=False, dlogits=None,
+               pred=None, out=None, ws: Optional[Workspace] = None):
+    N, H, W, _ = logits.shape
+    dev = logits.device
+    if want_grad and dlogits is None:
+        dlogits = torch.empty_like(logits)
+    if want_pred and pred is None:
+        pred = torch.empty_like(logits)
+    out = torch.empty(4, dtype=torch.float32, device=dev) if out is None else out
+    ws = ws or default_ws()
+    buf = ws.get(lib.size("mliis_softmax_ce_workspace_floats", N, H, W))
+    lib.call("mliis_softmax_ce", _ptr(logits), _ptr(labels), _ptr(idx), N, H, W, float(label_smoothing), int(dice), float(extra_loss),
+             _ptr(dlogits) if want_grad else None, _ptr(pred) if want_pred else None, _ptr(out), _ptr(buf), buf.numel(), _stream())
+    return out, dlogits, pred
+
+
+# ------------------------------------------------------------------------------------------------ optimizer / arena
+def sgd_fused(w, g, lr, l2_quad_mask=None, l2=0.0, lr_dev=None):
+    lib.call("mliis_sgd_fused", _ptr(w), _ptr(g), _ptr(l2_quad_mask), w.numel(), float(lr), _ptr(lr_dev), float(l2), _stream())
+
+
+def adam_b1zero_fused(w, g, v, step_dev, lr, l2_quad_mask=None, l2=0.0, lr_dev=None, beta2=0.999, eps=1e-8):
+    lib.call("mliis_adam_b1zero_fused", _ptr(w), _ptr(g), _ptr(v), _ptr(l2_quad_mask), w.numel(), float(lr), _ptr(lr_dev), float(l2),
+             float(beta2), float(eps), _ptr(step_dev), _stream())
+
+
+def axpby(a, x, b, y):
+    lib.call("mliis_axpby", float(a), _ptr(x), float(b), _ptr(y), y.numel(), _stream())
+
+
+def lincomb(a, x, b, y, out):
+    lib.call("mliis_lincomb", float(a), _ptr(x), float(b), _ptr(y), _ptr(out), out.numel(), _stream())

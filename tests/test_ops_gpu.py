@@ -1,0 +1,323 @@
+"""Per-kernel parity: every C-ABI entry point (called through mliis_amd.ops) against the float64 CPU oracle ops
+(oracle/efficientlab_ref.py + autograd) on the same seeded inputs.  Tolerances: forward rel 2e-5, backward rel 1e-4
+(fp32 kernels vs fp64 oracle), normalised by the tensor's max-abs."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import efficientlab_ref as R  # noqa: E402
+
+
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g, dtype=torch.float64) * scale)
+
+
+def close(got, ref, tol, what=""):
+    got = got.detach().cpu().double()
+    ref = ref.detach().cpu().double()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    den = max(ref.abs().max().item(), 1e-30)
+    err = (got - ref).abs().max().item() / den
+    assert err <= tol, "{}: rel err {:.3e} > {:.1e}".format(what, err, tol)
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2)
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def f32(t, d):
+    return t.float().contiguous().to(d)
+
+
+# ------------------------------------------------------------------------------------------------ depthwise
+@pytest.mark.parametrize("k,s,H,W,C", [(3, 1, 14, 14, 32), (3, 2, 16, 16, 24), (5, 1, 14, 14, 40), (5, 2, 28, 28, 16),
+                                       (3, 2, 15, 17, 8), (5, 2, 9, 11, 8), (3, 1, 5, 3, 4), (5, 1, 7, 30, 144)])
+def test_dwconv_all(k, s, H, W, C):
+    from mliis_amd import ops
+    d = dev()
+    N = 2
+    x = rnd(N, H, W, C, seed=1).requires_grad_(True)
+    w = rnd(k, k, C, 1, seed=2).requires_grad_(True)
+    y = R.conv2d_same(nchw(x), w, s, groups=C)
+    dy = rnd(*y.shape, seed=3)
+    gx, gw = torch.autograd.grad(y, [x, w], dy)
+    yg = ops.dwconv_fwd(f32(x, d), f32(w, d), s)
+    close(yg, nhwc(y), 2e-5, "dw fwd")
+    dyg = f32(nhwc(dy), d)
+    close(ops.dwconv_bwd_data(dyg, f32(w, d), s, (H, W)), gx, 1e-4, "dw bwd data")
+    close(ops.dwconv_bwd_filter(f32(x, d), dyg, k, s), gw, 1e-4, "dw bwd filter")
+
+
+# ------------------------------------------------------------------------------------------------ dense conv
+@pytest.mark.parametrize("k,dil,H,W,Cin,Cout,N", [
+    (1, 1, 8, 8, 16, 96, 2), (1, 1, 7, 9, 96, 24, 3), (1, 1, 14, 14, 40, 240, 2), (1, 1, 4, 4, 672, 112, 2),
+    (3, 1, 14, 14, 24, 112, 2), (3, 2, 14, 14, 136, 112, 2), (3, 1, 9, 11, 360, 112, 1), (3, 6, 14, 14, 112, 112, 1),
+    (1, 1, 56, 56, 24, 144, 4), (3, 2, 6, 5, 8, 8, 1),
+])
+def test_conv2d_all(k, dil, H, W, Cin, Cout, N):
+    from mliis_amd import ops
+    d = dev()
+    x = rnd(N, H, W, Cin, seed=4).requires_grad_(True)
+    w = rnd(k, k, Cin, Cout, seed=5, scale=1.0 / math.sqrt(k * k * Cin)).requires_grad_(True)
+    b = rnd(Cout, seed=6).requires_grad_(True)
+    y = R.conv2d_same(nchw(x), w, 1, dil, bias=b)
+    dy = rnd(*y.shape, seed=7)
+    gx, gw, gb = torch.autograd.grad(y, [x, w, b], dy)
+    xg, wg, bg = f32(x, d), f32(w, d), f32(b, d)
+    close(ops.conv2d_fwd(xg, wg, bg, dil), nhwc(y), 2e-5, "conv fwd")
+    dyg = f32(nhwc(dy), d)
+    close(ops.conv2d_bwd_data(dyg, wg, dil), gx, 1e-4, "conv bwd data")
+    close(ops.conv2d_bwd_filter(xg, dyg, k, dil), gw, 1e-4, "conv bwd filter")
+    close(ops.colsum(dyg), gb[None], 1e-4, "bias grad")
+
+
+def test_conv2d_slices_and_accumulate():
+    """Channel-sliced input/output views of concat buffers, partial-input-channel bwd-data, accumulate flags."""
+    from mliis_amd import ops
+    d = dev()
+    N, H, W = 2, 10, 10
+    cat = rnd(N, H, W, 48, seed=8)
+    w = rnd(3, 3, 24, 16, seed=9, scale=0.1)
+    xs = cat[..., 16:40]
+    y = R.conv2d_same(nchw(xs), w, 1, 2)
+    catg = f32(cat, d)
+    outbuf = torch.zeros(N, H, W, 40, device=d)
+    ops.conv2d_fwd(catg[..., 16:40], f32(w, d), None, 2, out=outbuf[..., 8:24])
+    close(outbuf[..., 8:24], nhwc(y), 2e-5, "sliced fwd")
+    assert outbuf[..., :8].abs().max().item() == 0 and outbuf[..., 24:].abs().max().item() == 0
+    ops.conv2d_fwd(catg[..., 16:40], f32(w, d), None, 2, out=outbuf[..., 8:24], accumulate=True)
+    close(outbuf[..., 8:24], 2 * nhwc(y), 2e-5, "accumulate fwd")
+    # bwd-data for input channels [8, 20) only
+    dy = rnd(N, H, W, 16, seed=10)
+    xr = xs.clone().requires_grad_(True)
+    (gx,) = torch.autograd.grad(R.conv2d_same(nchw(xr), w, 1, 2), [xr], nchw(dy))
+    got = ops.conv2d_bwd_data(f32(dy, d), f32(w, d), 2, ci_begin=8, ci_count=12)
+    close(got, gx[..., 8:20], 1e-4, "partial bwd data")
+
+
+# ------------------------------------------------------------------------------------------------ stem
+@pytest.mark.parametrize("H,W,Co", [(16, 16, 32), (15, 13, 32), (8, 8, 40)])
+def test_stem(H, W, Co):
+    from mliis_amd import ops
+    d = dev()
+    S, idx = 4, [2, 0, 3, 2, 1]
+    g = torch.Generator().manual_seed(11)
+    x = torch.randint(0, 256, (S, H, W, 3), generator=g).double()
+    w = rnd(3, 3, 3, Co, seed=12).requires_grad_(True)
+    xn = (x[idx] - torch.tensor(R.MEAN, dtype=torch.float64)) / torch.tensor(R.STD, dtype=torch.float64)
+    z = R.conv2d_same(nchw(xn), w, 2)
+    dz = rnd(*z.shape, seed=13)
+    (gw,) = torch.autograd.grad(z, [w], dz)
+    ig = torch.tensor(idx, dtype=torch.int32, device=d)
+    close(ops.stem_conv_fwd(f32(x, d), f32(w, d), ig), nhwc(z), 2e-5, "stem fwd")
+    close(ops.stem_conv_bwd_filter(f32(x, d), f32(nhwc(dz), d), ig), gw, 1e-4, "stem bwd filter")
+
+
+# ------------------------------------------------------------------------------------------------ batch norm
+@pytest.mark.parametrize("pre,post,C,rows_hw,N", [(0, 1, 32, 36, 3), (0, 0, 24, 49, 2), (1, 0, 112, 25, 2), (0, 1, 672, 9, 2), (0, 1, 8, 1000, 2)])
+def test_bn_train_fwd_bwd(pre, post, C, rows_hw, N):
+    from mliis_amd import ops
+    d = dev()
+    x = (rnd(N, rows_hw, 1, C, seed=14) * 2 + 0.5).requires_grad_(True)
+    gamma = (rnd(C, seed=15) * 0.5 + 1).requires_grad_(True)
+    beta = rnd(C, seed=16).requires_grad_(True)
+    res = rnd(N, rows_hw, 1, C, seed=17)
+    img_scale = torch.tensor([0.0, 1.25, 1.25][:N], dtype=torch.float64)
+    chan_scale = rnd(N, C, seed=18)
+    chan_add = rnd(N, C, seed=19) * 0.1
+    mm0, mv0 = rnd(C, seed=20), rnd(C, seed=21).abs() + 0.5
+    xin = R.swish(x) if pre else x
+    mean = xin.mean(dim=(0, 1, 2))
+    var = ((xin - mean) ** 2).mean(dim=(0, 1, 2))
+    xhat = (xin - mean) * torch.rsqrt(var + 1e-3)
+    u = xhat * gamma + beta
+    bn_out = R.swish(u) if post else u
+    y = bn_out * img_scale[:, None, None, None] + res
+    dy = rnd(*y.shape, seed=22)
+    # upstream of the BN output inside the kernel: dy*img_scale*chan_scale + chan_add
+    up = dy * img_scale[:, None, None, None] * chan_scale[:, None, None, :] + chan_add[:, None, None, :]
+    gx, gg, gb = torch.autograd.grad(bn_out, [x, gamma, beta], up)
+    xg = f32(x, d)
+    mm, mv = f32(mm0, d), f32(mv0, d)
+    m, r = ops.bn_stats(xg, bool(pre), moving=(mm, mv), unbiased_moving_var=bool(pre))
+    close(m, mean, 1e-5, "mean")
+    close(r, torch.rsqrt(var + 1e-3), 1e-5, "rstd")
+    n = N * rows_hw
+    close(mm, mm0 - (mm0 - mean) * 0.01, 1e-5, "moving mean")
+    close(mv, mv0 - (mv0 - var * (n / (n - 1.0) if pre else 1.0)) * 0.01, 1e-5, "moving var")
+    yg = ops.bn_apply(xg, m, r, f32(gamma, d), f32(beta, d), bool(pre), bool(post), f32(img_scale, d), f32(res, d))
+    close(yg, y, 2e-5, "bn apply")
+    dx, dg, db = ops.bn_bwd(xg, f32(dy, d), m, r, f32(gamma, d), f32(beta, d), bool(pre), bool(post), f32(img_scale, d),
+                            f32(chan_scale, d), f32(chan_add, d))
+    close(dx, gx, 1e-4, "bn dx")
+    close(dg, gg, 1e-4, "bn dgamma")
+    close(db, gb, 1e-4, "bn dbeta")
+
+
+def test_colsum_segments_and_product():
+    from mliis_amd import ops
+    d = dev()
+    a, b = rnd(3, 50, 1, 24, seed=23), rnd(3, 50, 1, 24, seed=24)
+    close(ops.colsum(f32(a, d), f32(b, d), nseg=3, scale=0.5), 0.5 * (a * b).sum(dim=(1, 2)), 1e-5, "colsum prod seg")
+    out = torch.ones(3, 24, device=d)
+    ops.colsum(f32(a, d), None, nseg=3, out=out, accumulate=True)
+    close(out, 1 + a.sum(dim=(1, 2)), 1e-5, "colsum accumulate")
+
+
+# ------------------------------------------------------------------------------------------------ squeeze-excite
+@pytest.mark.parametrize("C,Rr,N,HW", [(32, 8, 3, 16), (96, 4, 2, 9), (672, 28, 2, 4), (144, 6, 5, 49)])
+def test_se(C, Rr, N, HW):
+    from mliis_amd import ops
+    d = dev()
+    x = rnd(N, HW, 1, C, seed=25).requires_grad_(True)
+    w1 = rnd(1, 1, C, Rr, seed=26, scale=0.3).requires_grad_(True)
+    b1 = rnd(Rr, seed=27).requires_grad_(True)
+    w2 = rnd(1, 1, Rr, C, seed=28, scale=0.3).requires_grad_(True)
+    b2 = rnd(C, seed=29).requires_grad_(True)
+    s = x.mean(dim=(1, 2))
+    h = s @ w1[0, 0] + b1
+    gate = torch.sigmoid(R.swish(h) @ w2[0, 0] + b2)
+    y = x * gate[:, None, None, :]
+    dy = rnd(*y.shape, seed=30)
+    gx, gw1, gb1, gw2, gb2 = torch.autograd.grad(y, [x, w1, b1, w2, b2], dy)
+    xg, dyg = f32(x, d), f32(dy, d)
+    sg = ops.colsum(xg, None, nseg=N, scale=1.0 / HW)
+    close(sg, s, 1e-5, "se pool")
+    hp, gg = ops.se_mlp_fwd(sg, f32(w1, d), f32(b1, d), f32(w2, d), f32(b2, d))
+    close(gg, gate, 2e-5, "se gate")
+    close(ops.chan_affine(xg, S=gg), y, 2e-5, "se scale")
+    dgate = ops.colsum(dyg, xg, nseg=N)
+    o = ops.se_mlp_bwd(dgate, gg, sg, hp, f32(w1, d), f32(w2, d), HW)
+    close(o["dw1"], gw1, 1e-4, "dw1")
+    close(o["db1"], gb1, 1e-4, "db1")
+    close(o["dw2"], gw2, 1e-4, "dw2")
+    close(o["db2"], gb2, 1e-4, "db2")
+    dx = ops.chan_affine(dyg, S=gg, A=o["chan_add"])
+    close(dx, gx, 1e-4, "se dx")
+
+
+def test_chan_affine_broadcast_and_copy():
+    from mliis_amd import ops
+    d = dev()
+    v = rnd(2, 12, seed=31)
+    buf = torch.zeros(2, 3, 3, 20, device=d)
+    ops.chan_affine(None, A=f32(v, d), out=buf[..., 4:16])
+    close(buf[..., 4:16], v[:, None, None, :].expand(2, 3, 3, 12), 1e-6, "tile")
+    src = rnd(2, 3, 3, 8, seed=32)
+    ops.chan_affine(f32(src, d), out=buf[..., 12:20])
+    close(buf[..., 12:20], src, 1e-6, "copy")
+    ops.chan_affine(None, A=f32(v, d), out=buf[..., 4:16], accumulate=True)
+    assert buf[..., :4].abs().max().item() == 0
+
+
+# ------------------------------------------------------------------------------------------------ resize
+@pytest.mark.parametrize("Hi,Wi,Ho,Wo,C", [(14, 14, 56, 56, 112), (7, 5, 20, 13, 8), (56, 56, 224, 224, 2), (4, 4, 4, 4, 8), (3, 6, 2, 2, 4)])
+def test_resize(Hi, Wi, Ho, Wo, C):
+    from mliis_amd import ops
+    d = dev()
+    x = rnd(2, Hi, Wi, C, seed=33).requires_grad_(True)
+    y = F.interpolate(nchw(x), size=(Ho, Wo), mode="bilinear", align_corners=True)
+    dy = rnd(*y.shape, seed=34)
+    (gx,) = torch.autograd.grad(y, [x], dy)
+    close(ops.resize_bilinear_fwd(f32(x, d), (Ho, Wo)), nhwc(y), 2e-5, "resize fwd")
+    close(ops.resize_bilinear_bwd(f32(nhwc(dy), d), (Hi, Wi)), gx, 1e-4, "resize bwd")
+
+
+# ------------------------------------------------------------------------------------------------ final conv + loss
+@pytest.mark.parametrize("C,rows,use_mask", [(112, 300, False), (136, 77, True), (8, 5, True)])
+def test_final_conv(C, rows, use_mask):
+    from mliis_amd import ops
+    d = dev()
+    x = rnd(1, rows, 1, C, seed=35).requires_grad_(True)
+    w = rnd(1, 1, C, 2, seed=36).requires_grad_(True)
+    b = rnd(2, seed=37).requires_grad_(True)
+    mask = ((torch.rand(1, rows, 1, C, generator=torch.Generator().manual_seed(38)) > 0.5).double() * 2.0) if use_mask else None
+    xm = x * mask if use_mask else x
+    y = xm @ w[0, 0] + b
+    dy = rnd(*y.shape, seed=39)
+    gx, gw, gb = torch.autograd.grad(y, [x, w, b], dy)
+    mg = f32(mask, d) if use_mask else None
+    close(ops.final_conv_fwd(f32(x, d), f32(w, d), f32(b, d), mg), y, 2e-5, "final fwd")
+    close(ops.final_conv_bwd_data(f32(dy, d), f32(w, d), C, mg), gx, 1e-4, "final dx")
+    dw, db = ops.final_conv_bwd_filter(f32(x, d), f32(dy, d), mg)
+    close(dw, gw, 1e-4, "final dw")
+    close(db, gb, 1e-4, "final db")
+
+
+@pytest.mark.parametrize("dice,ls,H,W", [(False, 0.0, 16, 16), (True, 0.0, 24, 20), (True, 0.1, 9, 7), (False, 0.2, 224, 224)])
+def test_softmax_ce(dice, ls, H, W):
+    from mliis_amd import ops
+    d = dev()
+    S, idx = 3, [1, 1, 0, 2]
+    N = len(idx)
+    z = (rnd(N, H, W, 2, seed=40) * 3).requires_grad_(True)
+    g = torch.Generator().manual_seed(41)
+    m = torch.rand(S, H, W, generator=g).double()
+    m = torch.where(m < 0.6, (m < 0.3).double(), m)  # mostly binary, some fractional labels
+    labels = torch.stack([1 - m, m], -1)
+    a = R.arch()
+    loss = R.loss_fn(a, {}, z, labels[idx], ls, dice, False)
+    (gz,) = torch.autograd.grad(loss, [z])
+    out, dl, pred = ops.softmax_ce(f32(z, d), f32(labels, d), torch.tensor(idx, dtype=torch.int32, device=d), ls, dice, want_pred=True)
+    assert abs(out[0].item() - loss.item()) <= 2e-5 * max(1.0, abs(loss.item()))
+    close(dl, gz, 1e-4, "dlogits")
+    # mask: bit-exact against the oracle rule applied to the same fp32 logits
+    zf = z.detach().float()
+    ref_pred = (torch.softmax(zf.double(), -1) > 0.5).float()
+    margin = (zf[..., 0] - zf[..., 1]).abs() > 1e-6
+    assert torch.equal(pred.cpu()[margin], ref_pred[margin])
+
+
+# ------------------------------------------------------------------------------------------------ optimizer / arena
+def test_sgd_l2_mask_and_arena_algebra():
+    from mliis_amd import ops
+    d = dev()
+    n = 4096 + 8
+    w, g = rnd(n, seed=42), rnd(n, seed=43)
+    mask = (torch.arange(n // 4) % 3 != 0)
+    wg, gg = f32(w, d), f32(g, d)
+    lr_dev = torch.tensor([0.05], device=d)
+    ops.sgd_fused(wg, gg, 123.0, mask.to(torch.uint8).to(d), 5e-4, lr_dev)  # lr_dev overrides the host lr
+    l2m = mask.repeat_interleave(4).double()
+    close(wg, w - 0.05 * (g + 5e-4 * w * l2m), 1e-6, "sgd")
+    x, y = rnd(n, seed=44), rnd(n, seed=45)
+    yg = f32(y, d)
+    ops.axpby(0.3, f32(x, d), -1.5, yg)
+    close(yg, 0.3 * x - 1.5 * y, 1e-6, "axpby")
+    o = torch.empty(n, device=d)
+    ops.lincomb(2.0, f32(x, d), 0.25, f32(y, d), o)
+    close(o, 2 * x + 0.25 * y, 1e-6, "lincomb")
+    # Adam(beta1=0) single step, t = 1
+    v = torch.zeros(n, device=d)
+    w2 = f32(w, d)
+    ops.adam_b1zero_fused(w2, gg, v, torch.tensor([1.0], device=d), 1e-3)
+    vv = 0.001 * g * g
+    close(w2, w - 1e-3 * math.sqrt(1 - 0.999) * g / (vv.sqrt() + 1e-8), 1e-5, "adam b1=0")
+
+
+def test_errors_are_loud():
+    from mliis_amd import ops
+    from mliis_amd._lib import MliisError
+    d = dev()
+    with pytest.raises(MliisError):
+        ops.dwconv_fwd(torch.zeros(1, 4, 4, 6, device=d), torch.zeros(3, 3, 6, 1, device=d), 1)  # C % 4 != 0
+    with pytest.raises(MliisError):
+        ops.dwconv_fwd(torch.zeros(1, 4, 4, 8, device=d), torch.zeros(7, 7, 8, 1, device=d), 1)  # k = 7 unsupported
+    with pytest.raises(MliisError):
+        ops.dwconv_fwd(torch.zeros(1, 4, 4, 8), torch.zeros(3, 3, 8, 1), 1)  # CPU tensors: no fallback

@@ -1,0 +1,92 @@
+"""Per-layer kernel timings on the GPU (EfficientLab-6-3 shapes, N=8): depthwise fwd/bwd vs the HBM roofline and the
+dense convs vs the fp32-MFMA roofline.  Usage: python tools/bench_kernels.py [--n 8] [--iters 20]"""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mliis_amd import ops, spec  # noqa: E402
+
+HBM_PEAK = 8.0e12
+MFMA_F32_PEAK = 157.3e12
+
+
+def timeit(fn, iters, warmup=3):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    s = torch.cuda.Event(enable_timing=True)
+    e = torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) * 1e-3 / iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=8)
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--out", default=None)
+    a = ap.parse_args()
+    d = torch.device("cuda:0")
+    arch = spec.derive()
+    N = a.n
+    res = {"depthwise": [], "dense": []}
+    tot = dict(fwd_t=0, fwd_b=0, bwd_t=0, bwd_b=0)
+    for b in arch.blocks:
+        C, k, s, hi, ho = b.cexp, b.k, b.stride, b.h_in, b.h_out
+        x = torch.randn(N, hi, hi, C, device=d)
+        w = torch.randn(k, k, C, 1, device=d)
+        y = torch.empty(N, ho, ho, C, device=d)
+        dy = torch.randn(N, ho, ho, C, device=d)
+        dx = torch.empty_like(x)
+        dw = torch.empty_like(w)
+        tf = timeit(lambda: ops.dwconv_fwd(x, w, s, out=y), a.iters)
+        tbd = timeit(lambda: ops.dwconv_bwd_data(dy, w, s, (hi, hi), out=dx), a.iters)
+        tbf = timeit(lambda: ops.dwconv_bwd_filter(x, dy, k, s, out=dw), a.iters)
+        fb = 4 * (x.numel() + y.numel() + w.numel())
+        bb = 4 * (2 * x.numel() + y.numel() + 2 * w.numel())
+        res["depthwise"].append(dict(block=b.idx, C=C, k=k, s=s, h=hi, fwd_us=tf * 1e6, bwd_data_us=tbd * 1e6, bwd_filter_us=tbf * 1e6,
+                                     fwd_frac=fb / tf / HBM_PEAK, bwd_frac=bb / (tbd + tbf) / HBM_PEAK))
+        tot["fwd_t"] += tf
+        tot["fwd_b"] += fb
+        tot["bwd_t"] += tbd + tbf
+        tot["bwd_b"] += bb
+        print("dw b%-2d C=%-3d k%d s%d h=%-3d fwd %7.1f us (%4.1f%% HBM)  bwd_data %7.1f  bwd_filter %7.1f (%4.1f%% HBM)" % (
+            b.idx, C, k, s, hi, tf * 1e6, 100 * fb / tf / HBM_PEAK, tbd * 1e6, tbf * 1e6, 100 * bb / (tbd + tbf) / HBM_PEAK), flush=True)
+    res["depthwise_total"] = dict(fwd_us=tot["fwd_t"] * 1e6, bwd_us=tot["bwd_t"] * 1e6, fwd_frac=tot["fwd_b"] / tot["fwd_t"] / HBM_PEAK,
+                                  bwd_frac=tot["bwd_b"] / tot["bwd_t"] / HBM_PEAK)
+    print("dw total fwd %.1f us (%.1f%% of 8 TB/s)  bwd %.1f us (%.1f%%)" % (tot["fwd_t"] * 1e6, 100 * res["depthwise_total"]["fwd_frac"],
+                                                                          tot["bwd_t"] * 1e6, 100 * res["depthwise_total"]["bwd_frac"]), flush=True)
+    dense = [("b1.exp", 1, 1, 112, 16, 96), ("b2.exp", 1, 1, 56, 24, 144), ("b4.exp", 1, 1, 28, 40, 240), ("b6.exp", 1, 1, 14, 80, 480),
+             ("b9.proj", 1, 1, 14, 672, 112), ("rsd4.br1", 3, 2, 14, 224, 112), ("rsd4.fuse", 3, 1, 14, 448, 112),
+             ("rsd2.br0", 1, 1, 56, 136, 112), ("rsd2.br1", 3, 2, 56, 136, 112), ("rsd2.fuse", 3, 1, 56, 360, 112)]
+    for name, k, dil, h, ci, co in dense:
+        x = torch.randn(N, h, h, ci, device=d)
+        w = torch.randn(k, k, ci, co, device=d) * 0.05
+        bias = torch.zeros(co, device=d)
+        y = torch.empty(N, h, h, co, device=d)
+        dy = torch.randn(N, h, h, co, device=d)
+        dx = torch.empty_like(x)
+        dw = torch.empty_like(w)
+        fl = 2.0 * N * h * h * k * k * ci * co
+        tf = timeit(lambda: ops.conv2d_fwd(x, w, bias, dil, out=y), a.iters)
+        tbd = timeit(lambda: ops.conv2d_bwd_data(dy, w, dil, out=dx), a.iters)
+        tbf = timeit(lambda: ops.conv2d_bwd_filter(x, dy, k, dil, out=dw), a.iters)
+        res["dense"].append(dict(name=name, fwd_us=tf * 1e6, bwd_data_us=tbd * 1e6, bwd_filter_us=tbf * 1e6, gflop=fl / 1e9,
+                                 fwd_tf=fl / tf / 1e12, bwd_data_tf=fl / tbd / 1e12, bwd_filter_tf=fl / tbf / 1e12))
+        print("%-10s %7.3f GFLOP  fwd %8.1f us (%5.1f TF, %4.1f%%)  bwd_data %8.1f us (%5.1f TF)  bwd_filter %8.1f us (%5.1f TF)" % (
+            name, fl / 1e9, tf * 1e6, fl / tf / 1e12, 100 * fl / tf / MFMA_F32_PEAK, tbd * 1e6, fl / tbd / 1e12, tbf * 1e6, fl / tbf / 1e12), flush=True)
+    if a.out:
+        os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)
+        json.dump(res, open(a.out, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
