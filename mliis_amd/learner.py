@@ -1,0 +1,494 @@
+"""EfficientLab learner: the MI355X replacement for `session.run(model.minimize_op, feed_dict)`.
+
+Mirrors the handles the reference's meta-learner uses on the model object (models/efficientlab.py:42-61,94-100,108,173-176,
+298-317) as methods:
+
+    reference handle                                   here
+    -------------------------------------------------  ------------------------------------------------
+    sess.run(minimize_op, {X, Y[, lr_ph]})             Learner.inner_step(batch_idx, lr=None)
+    sess.run(predictions, {X, is_training_ph: False})  Learner.predict(images, training=False)
+    VariableState(trainable).export/import             Learner.export_trainable() / import_trainable()
+    VariableState(global).export/import                Learner.export_all() / import_all()
+    model.loss                                         Learner.last_loss (device scalar, read lazily)
+
+One inner step = forward + backward + BN moving-average update + fused SGD/Adam apply, entirely on the device, in a fixed
+sequence of C-ABI kernel launches over preallocated HBM buffers; after the first (eager) step of a given batch size the
+sequence is captured into a HIP graph and replayed, so the host does no per-op work in the hot loop.
+
+Graph semantics restated from: models/efficientlab.py:111-119,126-231,294-317; models/efficientnet/efficientnet_model.py:
+253-290,396-441; models/efficientnet/utils.py:87-170.  Backward formulas: SURVEY.md Appendix B.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import ops, spec
+from ._lib import MliisError, lib
+from .arena import Arena
+
+
+class _Plan:
+    """All activation / gradient buffers of one inner step for a fixed batch size N."""
+
+    def __init__(self, L: "Learner", N: int):
+        a, dev = L.arch, L.device
+        self.N = N
+
+        def buf(*shape):
+            return torch.empty(shape, dtype=torch.float32, device=dev)
+
+        def vec(c):
+            return buf(c), buf(c)
+        self.idx = torch.zeros(N, dtype=torch.int32, device=dev)
+        H = a.image_size
+        hs = a.h_stem
+        self.z_stem, self.a_stem = buf(N, hs, hs, a.stem_out), buf(N, hs, hs, a.stem_out)
+        self.st_stem = vec(a.stem_out)
+        self.blocks = []
+        nskip = sum(1 for b in a.blocks if b.executed and b.skip)
+        self.dc_all = torch.ones(max(nskip, 1), N, dtype=torch.float32, device=dev)
+        si = 0
+        gmax = 0
+        for b in a.blocks:
+            if not b.executed:
+                continue
+            B = {}
+            hi, ho, ce = b.h_in, b.h_out, b.cexp
+            if b.expand != 1:
+                B["z0"], B["a0"], B["st0"] = buf(N, hi, hi, ce), buf(N, hi, hi, ce), vec(ce)
+            B["z1"], B["a1"], B["st1"] = buf(N, ho, ho, ce), buf(N, ho, ho, ce), vec(ce)
+            B["s"], B["hpre"], B["gate"] = buf(N, ce), buf(N, b.se), buf(N, ce)
+            B["a2"] = buf(N, ho, ho, ce)
+            B["z2"], B["st2"], B["out"] = buf(N, ho, ho, b.cout), vec(b.cout), buf(N, ho, ho, b.cout)
+            B["dout"] = buf(N, ho, ho, b.cout)
+            B["dgate"], B["dpre1"], B["dpre2"], B["chan_add"] = buf(N, ce), buf(N, b.se), buf(N, ce), buf(N, ce)
+            if b.skip:
+                B["dc"] = self.dc_all[si]
+                si += 1
+            gmax = max(gmax, N * hi * hi * ce, N * ho * ho * ce)
+            self.blocks.append(B)
+        self.gA, self.gB = buf(gmax), buf(gmax)   # scratch gradients wrt expanded activations
+        self.dstem = buf(N, hs, hs, a.stem_out)
+        self.rsd = []
+        for m in a.rsd:
+            D = {}
+            h = m.h
+            D["cat"] = buf(N, h, h, m.c_cat)
+            D["z0"], D["z1"], D["zf"] = buf(N, h, h, m.c_out), buf(N, h, h, m.c_out), buf(N, h, h, m.c_out)
+            D["st0"], D["st1"], D["stf"] = vec(m.c_out), vec(m.c_out), vec(m.c_out)
+            D["pyr"] = buf(N, h, h, m.c_pyr)
+            D["pool"], D["dpool"] = buf(N, m.c_cat), buf(N, m.c_cat)
+            D["out"], D["dout"] = buf(N, h, h, m.c_out), buf(N, h, h, m.c_out)
+            D["dzf"], D["dpyr"], D["dcat"] = buf(N, h, h, m.c_out), buf(N, h, h, m.c_pyr), buf(N, h, h, m.c_cat)
+            self.rsd.append(D)
+        hd = a.h_dec
+        self.small, self.dsmall = buf(N, hd, hd, 2), buf(N, hd, hd, 2)
+        self.logits, self.dlogits, self.pred = buf(N, H, H, 2), buf(N, H, H, 2), buf(N, H, H, 2)
+        self.drop_mask = buf(N, hd, hd, a.aspp_dimension) if L.final_layer_dropout_rate > 0 else None
+        self.loss_out = torch.zeros(4, dtype=torch.float32, device=dev)
+        self.graph = None           # captured hipGraphExec for the training step
+        self.steps_run = 0
+
+
+class Learner:
+    def __init__(self, feature_extractor_name: str = "efficientnet-b0", image_size: int = 224, rsd: Optional[Sequence[int]] = (2, 4),
+                 learning_rate: float = 1e-3, optimizer: str = "sgd", l2: bool = False, l1: bool = False, darc1: bool = False,
+                 dice: bool = False, label_smoothing: float = 0.0, final_layer_dropout_rate: float = 0.0,
+                 spatial_pyramid_pooling: bool = False, skip_decoding: bool = False, drop_connect: bool = True, seed: int = 0,
+                 device="cuda:0", use_graph: bool = True, max_shots: int = 16):
+        if spatial_pyramid_pooling or skip_decoding:
+            raise NotImplementedError("--spatial_pyramid_pooling / --skip_decoding decoders are not built yet (not part of "
+                                      "EfficientLab-6-3; SURVEY.md 8(a) a18)")
+        if l1 or darc1:
+            raise NotImplementedError("--l1 / --darc1 regularisers are not built (off in run.sh)")
+        if optimizer not in ("sgd", "adam"):
+            raise ValueError("optimizer must be 'sgd' or 'adam' (Adam with beta1=0, the reference default)")
+        if not torch.cuda.is_available():
+            raise MliisError("mliis_amd.Learner needs an MI355X (HIP device); there is no CPU path")
+        lib.load()  # fail loudly if the HIP extension is missing
+        self.device = torch.device(device)
+        torch.cuda.set_device(self.device)
+        self.arch = spec.derive(feature_extractor_name, image_size, list(rsd or []), final_layer_dropout_rate)
+        self.feature_extractor_name = feature_extractor_name
+        self.final_layer_scope = "decode/final_layer_weights"
+        self.lr, self.optimizer = float(learning_rate), optimizer
+        self.l2, self.dice, self.label_smoothing = bool(l2), bool(dice), float(label_smoothing)
+        self.final_layer_dropout_rate = float(final_layer_dropout_rate or 0.0)
+        self.drop_connect = drop_connect
+        self.use_graph = use_graph
+        self.stream = torch.cuda.Stream(device=self.device)
+        self.arena = Arena(self.arch, self.device)
+        self.arena.init_weights(seed)
+        self.variables_initialized = True
+        self.ws = ops.Workspace(self.device, 1 << 22)
+        self.lr_dev = torch.tensor([self.lr], dtype=torch.float32, device=self.device)
+        self.adam_v = torch.zeros_like(self.arena.theta) if optimizer == "adam" else None
+        self.adam_t = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self.plans: Dict[int, _Plan] = {}
+        self.max_shots = max_shots
+        H = image_size
+        self.shots_x = torch.zeros(max_shots, H, H, 3, dtype=torch.float32, device=self.device)
+        self.shots_y = torch.zeros(max_shots, H, H, 2, dtype=torch.float32, device=self.device)
+        self.n_shots = 0
+        self.rng = torch.Generator(device=self.device)
+        self.rng.manual_seed(seed)
+        self._pname()
+        torch.cuda.synchronize(self.device)   # arena was initialised on the default stream; steps run on self.stream
+
+    # ------------------------------------------------------------------------------------------- names
+    def _pname(self):
+        fe = self.arch.name
+        self.n_stem = (f"{fe}/stem/conv2d/kernel", f"{fe}/stem/tpu_batch_normalization")
+        self.n_blocks = []
+        for b in self.arch.blocks:
+            if not b.executed:
+                continue
+            s = f"{fe}/blocks_{b.idx}"
+            bns = [f"{s}/tpu_batch_normalization", f"{s}/tpu_batch_normalization_1", f"{s}/tpu_batch_normalization_2"]
+            cvs = [f"{s}/conv2d/kernel", f"{s}/conv2d_1/kernel"]
+            d = {}
+            if b.expand != 1:
+                d["w_exp"], d["bn0"] = cvs.pop(0), bns.pop(0)
+            d["w_dw"], d["bn1"] = f"{s}/depthwise_conv2d/depthwise_kernel", bns.pop(0)
+            d["se"] = (f"{s}/se/conv2d/kernel", f"{s}/se/conv2d/bias", f"{s}/se/conv2d_1/kernel", f"{s}/se/conv2d_1/bias")
+            d["w_proj"], d["bn2"] = cvs.pop(0), bns.pop(0)
+            self.n_blocks.append(d)
+        self.n_rsd = []
+        for m in self.arch.rsd:
+            s = f"decode/decode_skip_connections_{m.scope_index}"
+            self.n_rsd.append([(f"{s}/conv2d{x}/kernel", f"{s}/conv2d{x}/bias", f"{s}/batch_normalization{x}") for x in ("", "_1", "_2")])
+        self.n_final = ("decode/final_layer_weights/kernel", "decode/final_layer_weights/bias")
+
+    # ------------------------------------------------------------------------------------------- variable state
+    @property
+    def n_trainable(self) -> int:
+        return self.arena.n_trainable
+
+    def export_trainable(self) -> torch.Tensor:
+        """Device clone of the (padded) trainable arena -- VariableState.export_variables (variables.py:70-74)."""
+        with torch.cuda.stream(self.stream):
+            return self.arena.theta.clone()
+
+    def import_trainable(self, flat: torch.Tensor):
+        with torch.cuda.stream(self.stream):
+            self.arena.theta.copy_(flat)
+
+    def export_bn(self) -> torch.Tensor:
+        with torch.cuda.stream(self.stream):
+            return self.arena.bn_moving.clone()
+
+    def import_bn(self, flat: torch.Tensor):
+        with torch.cuda.stream(self.stream):
+            self.arena.bn_moving.copy_(flat)
+
+    def export_all(self):
+        """All global variables (trainable + BN moving [+ Adam slots]) -- Gecko._full_state (reptile.py:35-36,258)."""
+        with torch.cuda.stream(self.stream):
+            st = {"theta": self.arena.theta.clone(), "bn": self.arena.bn_moving.clone()}
+            if self.adam_v is not None:
+                st["adam_v"], st["adam_t"] = self.adam_v.clone(), self.adam_t.clone()
+            return st
+
+    def import_all(self, st):
+        with torch.cuda.stream(self.stream):
+            self.arena.theta.copy_(st["theta"])
+            self.arena.bn_moving.copy_(st["bn"])
+            if self.adam_v is not None and "adam_v" in st:
+                self.adam_v.copy_(st["adam_v"])
+                self.adam_t.copy_(st["adam_t"])
+
+    def synchronize(self):
+        self.stream.synchronize()
+
+    def loss_value(self) -> float:
+        self.stream.synchronize()
+        return float(self.last_loss[0].item())
+
+    def load_named(self, values, **kw) -> int:
+        self.stream.synchronize()
+        n = self.arena.load_named(values, **kw)
+        torch.cuda.synchronize(self.device)
+        return n
+
+    # ------------------------------------------------------------------------------------------- task data
+    def load_task(self, images, labels):
+        """Make a task's shots resident: images [S,H,W,3] f32 0..255, labels [S,H,W,2] (numpy or tensors)."""
+        images = torch.as_tensor(images)
+        labels = torch.as_tensor(labels)
+        S = images.shape[0]
+        if S > self.max_shots:
+            raise ValueError("task has {} shots; Learner was built with max_shots={}".format(S, self.max_shots))
+        H = self.arch.image_size
+        if tuple(images.shape[1:]) != (H, H, 3) or tuple(labels.shape) != (S, H, H, 2):
+            raise ValueError("expected images [S,{0},{0},3] and labels [S,{0},{0},2], got {1} / {2}".format(H, tuple(images.shape),
+                                                                                                    tuple(labels.shape)))
+        with torch.cuda.stream(self.stream):
+            self.shots_x[:S].copy_(images.to(torch.float32), non_blocking=True)
+            self.shots_y[:S].copy_(labels.to(torch.float32), non_blocking=True)
+        self.n_shots = S
+
+    def _plan(self, N: int) -> _Plan:
+        if N not in self.plans:
+            with torch.cuda.stream(self.stream):
+                self.plans[N] = _Plan(self, N)
+        return self.plans[N]
+
+    # ------------------------------------------------------------------------------------------- forward
+    def _forward(self, P: _Plan, x, idx, training: bool):
+        A, a, ws, N = self.arena, self.arch, self.ws, P.N
+        w, mv = A.w, A.mv
+
+        def bn(xin, st, prefix, y, pre=False, post=False, img_scale=None, res=None, fused=False):
+            if training:
+                ops.bn_stats(xin, pre, moving=(mv[prefix + "/moving_mean"], mv[prefix + "/moving_variance"]), unbiased_moving_var=fused,
+                             mean=st[0], rstd=st[1], ws=ws)
+            else:
+                st[0].copy_(mv[prefix + "/moving_mean"])
+                torch.rsqrt(mv[prefix + "/moving_variance"] + spec.BN_EPS, out=st[1])
+            return ops.bn_apply(xin, st[0], st[1], w[prefix + "/gamma"], w[prefix + "/beta"], pre, post, img_scale, res, out=y)
+
+        ops.stem_conv_fwd(x, w[self.n_stem[0]], idx, out=P.z_stem)
+        cur = bn(P.z_stem, P.st_stem, self.n_stem[1], P.a_stem, post=True)
+        ex = [b for b in a.blocks if b.executed]
+        for b, B, nm in zip(ex, P.blocks, self.n_blocks):
+            B["x_in"] = cur
+            t = cur
+            if b.expand != 1:
+                ops.conv2d_fwd(t, w[nm["w_exp"]], out=B["z0"], ws=ws)
+                t = bn(B["z0"], B["st0"], nm["bn0"], B["a0"], post=True)
+            ops.dwconv_fwd(t, w[nm["w_dw"]], b.stride, out=B["z1"])
+            bn(B["z1"], B["st1"], nm["bn1"], B["a1"], post=True)
+            hw = b.h_out * b.h_out
+            ops.colsum(B["a1"], None, nseg=N, scale=1.0 / hw, out=B["s"], ws=ws)
+            se = nm["se"]
+            ops.se_mlp_fwd(B["s"], w[se[0]], w[se[1]], w[se[2]], w[se[3]], B["hpre"], B["gate"])
+            ops.chan_affine(B["a1"], S=B["gate"], out=B["a2"])
+            ops.conv2d_fwd(B["a2"], w[nm["w_proj"]], out=B["z2"], ws=ws)
+            use_dc = training and self.drop_connect and b.skip and b.drop_rate > 0
+            B["use_dc"] = use_dc
+            cur = bn(B["z2"], B["st2"], nm["bn2"], B["out"], img_scale=B["dc"] if use_dc else None, res=B["x_in"] if b.skip else None)
+        ends = {r: P.blocks[bi]["out"] for r, bi in a.reductions.items() if bi < len(P.blocks)}
+        dec = ends[4]
+        for m, D, nm, r in zip(a.rsd, P.rsd, self.n_rsd, sorted([x.scope_index + 1 for x in a.rsd], reverse=True)):
+            skip = ends[r]
+            cat = D["cat"]
+            up = cat[..., :m.c_deep]
+            if m.h_in == m.h:
+                ops.chan_affine(dec, out=up)
+            else:
+                ops.resize_bilinear_fwd(dec, (m.h, m.h), out=up)
+            ops.chan_affine(skip, out=cat[..., m.c_deep:])
+            pyr = D["pyr"]
+            (k0, b0, n0), (k1, b1, n1), (kf, bf, nf) = nm
+            ops.conv2d_fwd(cat, w[k0], w[b0], 1, out=D["z0"], ws=ws)
+            bn(D["z0"], D["st0"], n0, pyr[..., :m.c_out], pre=True, fused=True)
+            ops.conv2d_fwd(cat, w[k1], w[b1], 2, out=D["z1"], ws=ws)
+            bn(D["z1"], D["st1"], n1, pyr[..., m.c_out:2 * m.c_out], pre=True, fused=True)
+            ops.colsum(cat, None, nseg=N, scale=1.0 / (m.h * m.h), out=D["pool"], ws=ws)
+            ops.chan_affine(None, A=D["pool"], out=pyr[..., 2 * m.c_out:])
+            ops.conv2d_fwd(pyr, w[kf], w[bf], 1, out=D["zf"], ws=ws)
+            dec = bn(D["zf"], D["stf"], nf, D["out"], pre=True, res=up, fused=True)
+        mask = P.drop_mask if (training and P.drop_mask is not None) else None
+        P.dec_in = dec
+        ops.final_conv_fwd(dec, w[self.n_final[0]], w[self.n_final[1]], mask, out=P.small)
+        H = a.image_size
+        ops.resize_bilinear_fwd(P.small, (H, H), out=P.logits)
+        return P.logits
+
+    # ------------------------------------------------------------------------------------------- backward
+    def _backward(self, P: _Plan, x, idx):
+        A, a, ws, N = self.arena, self.arch, self.ws, P.N
+        w, g = A.w, A.g
+        hd = a.h_dec
+        ops.resize_bilinear_bwd(P.dlogits, (hd, hd), out=P.dsmall)
+        mask = P.drop_mask
+        ops.final_conv_bwd_filter(P.dec_in, P.dsmall, mask, dw=g[self.n_final[0]], db=g[self.n_final[1]], ws=ws)
+        ex = [b for b in a.blocks if b.executed]
+        has_grad = [False] * len(P.blocks)
+        dtop = P.rsd[-1]["dout"] if P.rsd else P.blocks[-1]["dout"]
+        ops.final_conv_bwd_data(P.dsmall, w[self.n_final[0]], a.aspp_dimension, mask, out=dtop)
+        if not P.rsd:
+            has_grad[-1] = True
+
+        def bn_b(xin, dy, st, prefix, dx, pre=False, post=False, img_scale=None, chan_scale=None, chan_add=None):
+            ops.bn_bwd(xin, dy, st[0], st[1], w[prefix + "/gamma"], w[prefix + "/beta"], pre, post, img_scale, chan_scale, chan_add, dx=dx,
+                       dgamma=g[prefix + "/gamma"], dbeta=g[prefix + "/beta"], ws=ws)
+
+        rs = sorted([x.scope_index + 1 for x in a.rsd], reverse=True)
+        for j in range(len(a.rsd) - 1, -1, -1):
+            m, D, nm, r = a.rsd[j], P.rsd[j], self.n_rsd[j], rs[j]
+            (k0, b0, n0), (k1, b1, n1), (kf, bf, nf) = nm
+            co, hw = m.c_out, m.h * m.h
+            dO, cat, pyr, dpyr, dcat = D["dout"], D["cat"], D["pyr"], D["dpyr"], D["dcat"]
+            bn_b(D["zf"], dO, D["stf"], nf, D["dzf"], pre=True)
+            ops.colsum(D["dzf"], None, out=g[bf].view(1, -1), ws=ws)
+            ops.conv2d_bwd_filter(pyr, D["dzf"], 3, 1, out=g[kf], ws=ws)
+            ops.conv2d_bwd_data(D["dzf"], w[kf], 1, out=dpyr, ws=ws)
+            d0, d1 = dpyr[..., :co], dpyr[..., co:2 * co]
+            bn_b(D["z0"], d0, D["st0"], n0, d0, pre=True)
+            ops.colsum(d0, None, out=g[b0].view(1, -1), ws=ws)
+            ops.conv2d_bwd_filter(cat, d0, 1, 1, out=g[k0], ws=ws)
+            ops.conv2d_bwd_data(d0, w[k0], 1, out=dcat, ws=ws)
+            bn_b(D["z1"], d1, D["st1"], n1, d1, pre=True)
+            ops.colsum(d1, None, out=g[b1].view(1, -1), ws=ws)
+            ops.conv2d_bwd_filter(cat, d1, 3, 2, out=g[k1], ws=ws)
+            ops.conv2d_bwd_data(d1, w[k1], 2, out=dcat, accumulate=True, ws=ws)
+            ops.colsum(dpyr[..., 2 * co:], None, nseg=N, scale=1.0 / hw, out=D["dpool"], ws=ws)
+            ops.chan_affine(None, A=D["dpool"], out=dcat, accumulate=True)
+            # dU = dO + dcat[:, :c_deep] (residual);  dS = dcat[:, c_deep:]
+            ops.chan_affine(dcat[..., :m.c_deep], out=dO, accumulate=True)
+            # gradient w.r.t. the deep input
+            if j > 0:
+                tgt, tgt_has = P.rsd[j - 1]["dout"], False
+            else:
+                bi = a.reductions[4]
+                tgt, tgt_has = P.blocks[bi]["dout"], has_grad[bi]
+            if m.h_in == m.h:
+                ops.chan_affine(dO, out=tgt, accumulate=tgt_has)
+            else:
+                ops.resize_bilinear_bwd(dO, (m.h_in, m.h_in), out=tgt, accumulate=tgt_has)
+            if j == 0:
+                has_grad[a.reductions[4]] = True
+            # gradient w.r.t. the skip endpoint
+            bi = a.reductions[r]
+            ops.chan_affine(dcat[..., m.c_deep:], out=P.blocks[bi]["dout"], accumulate=has_grad[bi])
+            has_grad[bi] = True
+
+        for bi in range(len(P.blocks) - 1, -1, -1):
+            b, B, nm = ex[bi], P.blocks[bi], self.n_blocks[bi]
+            if not has_grad[bi]:
+                raise MliisError("internal: block {} has no upstream gradient".format(bi))
+            dout = B["dout"]
+            ce, hw = b.cexp, b.h_out * b.h_out
+            # gradient for the block input: identity-skip part first (before dout is overwritten in place)
+            tgt = P.blocks[bi - 1]["dout"] if bi > 0 else P.dstem
+            tgt_has = has_grad[bi - 1] if bi > 0 else False
+            if b.skip:
+                ops.chan_affine(dout, out=tgt, accumulate=tgt_has)
+                tgt_has = True
+            bn_b(B["z2"], dout, B["st2"], nm["bn2"], dout, img_scale=B["dc"] if B["use_dc"] else None)
+            ops.conv2d_bwd_filter(B["a2"], dout, 1, 1, out=g[nm["w_proj"]], ws=ws)
+            n2 = N * hw * ce
+            da2 = P.gA[:n2].view(N, b.h_out, b.h_out, ce)
+            ops.conv2d_bwd_data(dout, w[nm["w_proj"]], 1, out=da2, ws=ws)
+            ops.colsum(da2, B["a1"], nseg=N, out=B["dgate"], ws=ws)
+            se = nm["se"]
+            outs = dict(dpre1=B["dpre1"], dpre2=B["dpre2"], chan_add=B["chan_add"], dw1=g[se[0]], db1=g[se[1]], dw2=g[se[2]], db2=g[se[3]])
+            ops.se_mlp_bwd(B["dgate"], B["gate"], B["s"], B["hpre"], w[se[0]], w[se[2]], hw, outs)
+            bn_b(B["z1"], da2, B["st1"], nm["bn1"], da2, post=True, chan_scale=B["gate"], chan_add=B["chan_add"])
+            dw_in = B["a0"] if b.expand != 1 else B["x_in"]
+            ops.dwconv_bwd_filter(dw_in, da2, b.k, b.stride, out=g[nm["w_dw"]], ws=ws)
+            if b.expand != 1:
+                n0 = N * b.h_in * b.h_in * ce
+                da0 = P.gB[:n0].view(N, b.h_in, b.h_in, ce)
+                ops.dwconv_bwd_data(da2, w[nm["w_dw"]], b.stride, (b.h_in, b.h_in), out=da0)
+                bn_b(B["z0"], da0, B["st0"], nm["bn0"], da0, post=True)
+                ops.conv2d_bwd_filter(B["x_in"], da0, 1, 1, out=g[nm["w_exp"]], ws=ws)
+                ops.conv2d_bwd_data(da0, w[nm["w_exp"]], 1, out=tgt, accumulate=tgt_has, ws=ws)
+            else:
+                if tgt_has:  # no-expand block with identity skip (EfficientNet-B3 stage-1 repeats)
+                    n0 = N * b.h_in * b.h_in * ce
+                    tmp = P.gB[:n0].view(N, b.h_in, b.h_in, ce)
+                    ops.dwconv_bwd_data(da2, w[nm["w_dw"]], b.stride, (b.h_in, b.h_in), out=tmp)
+                    ops.chan_affine(tmp, out=tgt, accumulate=True)
+                else:
+                    ops.dwconv_bwd_data(da2, w[nm["w_dw"]], b.stride, (b.h_in, b.h_in), out=tgt)
+            if bi > 0:
+                has_grad[bi - 1] = True
+        bn_b(P.z_stem, P.dstem, P.st_stem, self.n_stem[1], P.dstem, post=True)
+        ops.stem_conv_bwd_filter(x, P.dstem, idx, out=g[self.n_stem[0]], ws=ws)
+
+    # ------------------------------------------------------------------------------------------- one optimisation step
+    def _apply(self):
+        A = self.arena
+        l2 = spec.L2_WEIGHT if self.l2 else 0.0
+        if self.optimizer == "sgd":
+            ops.sgd_fused(A.theta, A.grad, self.lr, A.l2_quad_mask, l2, self.lr_dev)
+        else:
+            self.adam_t.add_(1.0)
+            ops.adam_b1zero_fused(A.theta, A.grad, self.adam_v, self.adam_t, self.lr, A.l2_quad_mask, l2, self.lr_dev)
+
+    def _train_sequence(self, P: _Plan):
+        logits = self._forward(P, self.shots_x, P.idx, True)
+        ops.softmax_ce(logits, self.shots_y, P.idx, self.label_smoothing, self.dice, 0.0, want_grad=True, want_pred=False,
+                       dlogits=P.dlogits, out=P.loss_out, ws=self.ws)
+        self._backward(P, self.shots_x, P.idx)
+        self._apply()
+
+    def inner_step(self, batch_idx: Sequence[int], lr: Optional[float] = None, dc_scales: Optional[Dict[int, torch.Tensor]] = None,
+                   dropout_mask: Optional[torch.Tensor] = None, weight_decay_rate: float = 1.0):
+        """One `session.run(minimize_op)` on images `batch_idx` of the resident task.  Returns the device loss scalar."""
+        N = len(batch_idx)
+        if N == 0:
+            raise ValueError("empty mini-batch")
+        if max(batch_idx) >= self.n_shots or min(batch_idx) < 0:
+            raise ValueError("batch index out of range of the resident task ({} shots)".format(self.n_shots))
+        P = self._plan(N)
+        with torch.cuda.stream(self.stream):
+            P.idx.copy_(torch.tensor(list(batch_idx), dtype=torch.int32), non_blocking=True)
+            self.lr_dev.fill_(self.lr if lr is None else float(lr))
+            if weight_decay_rate != 1.0:  # pre_step_op (variables.py:48-55)
+                ops.axpby(0.0, None, float(weight_decay_rate), self.arena.theta)
+            self._fill_masks(P, dc_scales, dropout_mask)
+            if self.use_graph and P.steps_run >= 1 and self.optimizer == "sgd":
+                if P.graph is None:
+                    gexec = C.c_void_p()
+                    lib.call("mliis_graph_begin_capture", self.stream.cuda_stream)
+                    try:
+                        self._train_sequence(P)
+                    finally:
+                        lib.call("mliis_graph_end_capture", self.stream.cuda_stream, C.byref(gexec))
+                    P.graph = gexec
+                lib.call("mliis_graph_launch", P.graph, self.stream.cuda_stream)
+            else:
+                self._train_sequence(P)
+            P.steps_run += 1
+        self.last_loss = P.loss_out
+        return P.loss_out[0]
+
+    def _fill_masks(self, P: _Plan, dc_scales, dropout_mask):
+        ex = [b for b in self.arch.blocks if b.executed]
+        if self.drop_connect:
+            if dc_scales is not None:
+                for b, B in zip(ex, P.blocks):
+                    if b.skip and "dc" in B:
+                        v = dc_scales.get(b.idx)
+                        if v is None:
+                            B["dc"].fill_(1.0)
+                        else:
+                            B["dc"].copy_(torch.as_tensor(v, dtype=torch.float32))
+            else:
+                keeps = torch.tensor([1.0 - b.drop_rate for b in ex if b.skip], dtype=torch.float32, device=self.device)[:, None]
+                if keeps.numel():
+                    u = torch.rand(P.dc_all.shape, generator=self.rng, device=self.device)
+                    P.dc_all.copy_(torch.floor(keeps + u) / keeps)   # utils.py:159-170
+        if P.drop_mask is not None:
+            if dropout_mask is not None:
+                P.drop_mask.copy_(torch.as_tensor(dropout_mask, dtype=torch.float32))
+            else:
+                keep = 1.0 - self.final_layer_dropout_rate
+                u = torch.rand(P.drop_mask.shape, generator=self.rng, device=self.device)
+                P.drop_mask.copy_((u < keep).to(torch.float32) / keep)
+
+    # ------------------------------------------------------------------------------------------- inference
+    def predict(self, images, training: bool = False, return_logits: bool = False):
+        """predictions tensor of the reference: (softmax(logits) > 0.5) as float, [N,H,W,2]."""
+        images = torch.as_tensor(images)
+        N = images.shape[0]
+        P = self._plan(N)
+        with torch.cuda.stream(self.stream):
+            x = images.to(device=self.device, dtype=torch.float32).contiguous()
+            logits = self._forward(P, x, None, training)
+            dummy = torch.zeros_like(logits)
+            ops.softmax_ce(logits, dummy, None, 0.0, False, 0.0, want_grad=False, want_pred=True, pred=P.pred, out=P.loss_out, ws=self.ws)
+            out = P.pred.clone()
+            lg = logits.clone() if return_logits else None
+        self.stream.synchronize()
+        return (out, lg) if return_logits else out
+
+    def gradients_packed(self) -> torch.Tensor:
+        return self.arena.export_grad_packed()
