@@ -1,0 +1,199 @@
+"""Headline benchmark: inner-loop images/sec of the Reptile/FOMAML adaptation loop over EfficientLab-6-3 (224x224, 5-shot).
+
+    python bench.py --gpus N --steps K --warmup W          (N = 1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = one meta-step: every rank adapts ONE synthetic 5-shot task (BASELINE.json configs[1]: 8 inner SGD steps of batch 8
+= 64 image passes, fp32, drop-connect on), then the outer Reptile update (one RCCL all-reduce of the flat delta when N > 1).
+Meta-batch = N tasks, one per GPU (weak scaling, no data-path collective besides that exchange).  Synthetic data of
+BASELINE.md section 3, resident in HBM before the timed region.  Rank 0 prints ONE JSON line with `roofline` (dominant kernel,
+timed live with HIP events on the launch stream) and `cpu_baseline` (the CPU oracle timed on this box's host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+MFMA_F32_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, dense f32-input MFMA
+HBM_PEAK_GBS = 8000.0          # ibid., HBM3E spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--foml", action="store_true", help="FOMAML with a 5-shot tail batch (BASELINE configs[2] flavour)")
+    ap.add_argument("--inner-iters", type=int, default=8)
+    ap.add_argument("--inner-batch", type=int, default=8)
+    ap.add_argument("--shots", type=int, default=5)
+    ap.add_argument("--image-size", type=int, default=224)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--pool", type=int, default=8, help="number of distinct synthetic tasks resident per GPU")
+    return ap.parse_args()
+
+
+def cpu_baseline(args):
+    """CPU oracle (PyTorch-CPU fp32 restatement of the same graph) on a bounded sample of the same workload."""
+    from oracle import efficientlab_ref as R
+    from mliis_amd.metaseg import synthetic_task, mini_batch_indices
+    import random
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    O = R.OracleLearner(image_size=args.image_size, seed=0, dtype=torch.float32, lr=1e-3)
+    x, y = synthetic_task(args.shots, args.image_size, seed=0)
+    O.load_task(torch.tensor(x), torch.tensor(y))
+    batches = [list(b) for b in mini_batch_indices(args.shots, args.inner_batch, 64, rng=random.Random(0))]
+    t0 = time.time()
+    O.inner_step(batches[0])           # warm-up step (also a cost probe)
+    probe = time.time() - t0
+    n = int(max(2, min(args.inner_iters, 20.0 / max(probe, 1e-3))))
+    t0 = time.time()
+    for b in batches[1:1 + n]:
+        O.inner_step(b)
+    dt = time.time() - t0
+    return {"value": n * args.inner_batch / dt, "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": "%d inner SGD steps (batch %d, %dx%d, fp32) of one synthetic %d-shot task on the PyTorch-CPU oracle, "
+                      "%d threads, after 1 warm-up step" % (n, args.inner_batch, args.image_size, args.image_size, args.shots, cores)}
+
+
+def roofline(L, args):
+    """Per-launch timing (HIP events on the learner's stream) of one eager inner step; reports the dominant kernel."""
+    from mliis_amd import ops
+    idx = [i % args.shots for i in range(args.inner_batch)]
+    reps = 5
+    L.use_graph, saved = False, L.use_graph
+    L.inner_step(idx)
+    ops.PROFILE = []
+    for _ in range(reps):
+        L.inner_step(idx)
+    L.synchronize()
+    recs = ops.profile_resolve(ops.PROFILE)
+    ops.PROFILE = None
+    L.use_graph = saved
+    by = {}
+    for r in recs:
+        if r["op"] in ("conv2d_fwd", "conv2d_bwd_data") and r.get("splits", 1) == 1:
+            k = r["kernel"]
+        elif r["op"] == "conv2d_bwd_filter":
+            k = "conv_filter_grad_k(+reduce)"
+        elif r["op"].startswith("dwconv"):
+            k = r["op"]
+        else:
+            continue
+        d = by.setdefault(k, dict(ms=0.0, n=0, flops=0.0, bytes=0.0))
+        d["ms"] += r["ms"]
+        d["n"] += 1
+        d["flops"] += r.get("flops", 0.0)
+        d["bytes"] += r.get("bytes", 0.0)
+    gemm = {k: v for k, v in by.items() if k.startswith("conv_gemm_k")}
+    dom = max(gemm, key=lambda k: gemm[k]["ms"])
+    d = gemm[dom]
+    ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+    out = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TFLOPS,
+           "traffic": None, "launches_per_step": d["n"] // reps, "avg_launch_us": 1e3 * d["ms"] / d["n"],
+           "algorithmic_flops_per_launch": d["flops"] / d["n"]}
+    dw = {}
+    for k in ("dwconv_fwd", "dwconv_bwd_data", "dwconv_bwd_filter"):
+        if k in by:
+            v = by[k]
+            dw[k] = {"us_per_step": 1e3 * v["ms"] / reps, "algorithmic_MB_per_step": v["bytes"] / reps / 1e6,
+                     "GBps": v["bytes"] / (v["ms"] * 1e-3) / 1e9, "frac_of_8TBps": v["bytes"] / (v["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    families = {k: {"us_per_step": 1e3 * v["ms"] / reps, "launches_per_step": v["n"] // reps,
+                    "TFLOPs": (v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["flops"] else None} for k, v in sorted(by.items())}
+    return out, dw, families
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; there is no CPU path (the CPU oracle is only the reported baseline)")
+    device = torch.device("cuda", local)
+    from mliis_amd.learner import Learner
+    from mliis_amd.metaseg import DeviceTask, synthetic_task
+    from mliis_amd.reptile import FOMLIS, Gecko, Dist
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args)
+
+    shots = 10 if args.foml else args.shots
+    L = Learner(image_size=args.image_size, rsd=(2, 4), learning_rate=1e-3, optimizer="sgd", dice=False, l2=False, seed=0, device=device,
+                use_graph=not args.no_graph, max_shots=max(16, shots))
+    tasks = []
+    for i in range(args.pool):
+        x, y = synthetic_task(shots, args.image_size, seed=1000 * rank + i)
+        tasks.append(DeviceTask("synthetic_%d_%d" % (rank, i), torch.from_numpy(x).to(device), torch.from_numpy(y).to(device)))
+    D = Dist()
+    if args.foml:
+        meta = FOMLIS(L, train_shots=shots, tail_shots=5, dist=D, rng_mode="per_task", seed=0)
+    else:
+        meta = Gecko(L, dist=D, rng_mode="per_task", seed=0)
+
+    def step():
+        meta.train_step(tasks, num_shots=shots, inner_batch_size=args.inner_batch, inner_iters=args.inner_iters, replacement=False,
+                        meta_step_size=0.1, meta_batch_size=world)
+
+    for _ in range(args.warmup):
+        step()
+    D.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    D.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    imgs_per_task = ((args.inner_iters - 1) * args.inner_batch + 5) if args.foml else args.inner_iters * args.inner_batch
+    value = world * imgs_per_task * args.steps / dt
+    loss = L.loss_value()
+
+    roof = dwr = fam = None
+    if rank == 0 and not args.no_roofline:
+        roof, dwr, fam = roofline(L, args)
+    if rank == 0:
+        out = {
+            "metric": "inner-loop images/sec (EfficientLab-6-3, 224x224, 5-shot)", "value": value, "unit": "images/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "EfficientLab-6-3 (EfficientNet-B0 blocks 0-10 + RSD(4)+RSD(2)), %dx%d, meta-batch=%d (1 task/GPU), "
+                                   "%d-shot x %d inner SGD steps of batch %d (%d image fwd+bwd+BN-EMA+SGD per task), %s outer update, fp32, "
+                                   "CE loss, drop-connect on" % (args.image_size, args.image_size, world, shots, args.inner_iters,
+                                                                 args.inner_batch, imgs_per_task, "FOMAML(tail 5)" if args.foml else "Reptile"),
+                       "hip_graph": not args.no_graph, "final_loss": loss},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        if dwr is not None:
+            out["depthwise_hbm"] = dwr
+            out["kernel_families_eager_us"] = fam
+        if cpu is not None:
+            out["gpu_over_cpu"] = value / cpu["value"]
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -62,6 +62,8 @@ int mliis_dwconv_bwd_filter(const float* x, const float* dy, float* dw, int N, i
  *      ASPP (models/efficientlab.py:185-190,218-224,258-283).  w is TF HWIO [k,k,Cin,Cout].  `accumulate` != 0 adds into the
  *      destination.  ws may be NULL (disables split-K). */
 size_t mliis_conv2d_workspace_floats(int Nimg, int H, int W, int Cred, int Nout, int ksize);
+/*      tiling chosen for a fwd / bwd-data call: kernel instantiation conv_gemm_k<tm, nt, .> and split-K factor (profiling aid) */
+int mliis_conv2d_plan(int Nimg, int H, int W, int Cred, int Nout, int ksize, int* tm, int* nt, int* splits);
 int mliis_conv2d_fwd(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int Nimg, int H, int W, int Cin,
                      int Cout, int ksize, int dil, int accumulate, float* ws, size_t ws_floats, hipStream_t stream);
 /*      gradient w.r.t. input channels [ci_begin, ci_begin+Cin_out) of a conv whose weight has Cin_total input channels */

@@ -514,6 +514,17 @@ using namespace mliis;
 
 extern "C" {
 
+// Tiling the planner picks for a conv2d_fwd / conv2d_bwd_data call (profiling aid: identifies the kernel instantiation
+// conv_gemm_k<tm, nt, B_NK> and its split-K factor).
+int mliis_conv2d_plan(int Nimg, int H, int W, int Cred, int Nout, int ksize, int* tm, int* nt, int* splits) {
+  MLIIS_REQUIRE(tm && nt && splits, MLIIS_ERR_ARG, "conv2d_plan: null pointer");
+  GemmPlan g = plan_gemm((long long)Nimg * H * W, Nout, Cred, ksize * ksize, num_cus(), 1);
+  *tm = g.tm;
+  *nt = g.nt;
+  *splits = g.gz;
+  return MLIIS_OK;
+}
+
 // Workspace (floats) that conv2d_fwd / conv2d_bwd_data may need for split-K partials.
 size_t mliis_conv2d_workspace_floats(int Nimg, int H, int W, int Cred, int Nout, int ksize) {
   long long M = (long long)Nimg * H * W;

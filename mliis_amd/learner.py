@@ -168,20 +168,39 @@ class Learner:
     def n_trainable(self) -> int:
         return self.arena.n_trainable
 
+    def _out(self, t):
+        """Hand a tensor produced on the learner stream to the caller's current stream."""
+        cur = torch.cuda.current_stream(self.device)
+        if cur != self.stream:
+            cur.wait_stream(self.stream)
+            if torch.is_tensor(t):
+                t.record_stream(cur)
+        return t
+
+    def _in(self):
+        """Order the learner stream after work the caller queued on its current stream."""
+        cur = torch.cuda.current_stream(self.device)
+        if cur != self.stream:
+            self.stream.wait_stream(cur)
+
     def export_trainable(self) -> torch.Tensor:
         """Device clone of the (padded) trainable arena -- VariableState.export_variables (variables.py:70-74)."""
         with torch.cuda.stream(self.stream):
-            return self.arena.theta.clone()
+            t = self.arena.theta.clone()
+        return self._out(t)
 
     def import_trainable(self, flat: torch.Tensor):
+        self._in()
         with torch.cuda.stream(self.stream):
             self.arena.theta.copy_(flat)
 
     def export_bn(self) -> torch.Tensor:
         with torch.cuda.stream(self.stream):
-            return self.arena.bn_moving.clone()
+            t = self.arena.bn_moving.clone()
+        return self._out(t)
 
     def import_bn(self, flat: torch.Tensor):
+        self._in()
         with torch.cuda.stream(self.stream):
             self.arena.bn_moving.copy_(flat)
 
@@ -191,15 +210,28 @@ class Learner:
             st = {"theta": self.arena.theta.clone(), "bn": self.arena.bn_moving.clone()}
             if self.adam_v is not None:
                 st["adam_v"], st["adam_t"] = self.adam_v.clone(), self.adam_t.clone()
-            return st
+        for v in st.values():
+            self._out(v)
+        return st
 
     def import_all(self, st):
+        self._in()
         with torch.cuda.stream(self.stream):
             self.arena.theta.copy_(st["theta"])
             self.arena.bn_moving.copy_(st["bn"])
             if self.adam_v is not None and "adam_v" in st:
                 self.adam_v.copy_(st["adam_v"])
                 self.adam_t.copy_(st["adam_t"])
+
+    def axpby(self, a: float, x: torch.Tensor, b: float, y: torch.Tensor):
+        """y <- a*x + b*y on flat arena-shaped buffers (meta_learners/variables.py:9-45 on the device)."""
+        self._in()
+        with torch.cuda.stream(self.stream):
+            ops.axpby(a, x, b, y)
+
+    def comm_context(self):
+        """Context in which collectives on arena buffers must be issued (orders them after this learner's stream)."""
+        return torch.cuda.stream(self.stream)
 
     def synchronize(self):
         self.stream.synchronize()
@@ -226,6 +258,7 @@ class Learner:
         if tuple(images.shape[1:]) != (H, H, 3) or tuple(labels.shape) != (S, H, H, 2):
             raise ValueError("expected images [S,{0},{0},3] and labels [S,{0},{0},2], got {1} / {2}".format(H, tuple(images.shape),
                                                                                                     tuple(labels.shape)))
+        self._in()
         with torch.cuda.stream(self.stream):
             self.shots_x[:S].copy_(images.to(torch.float32), non_blocking=True)
             self.shots_y[:S].copy_(labels.to(torch.float32), non_blocking=True)
@@ -448,7 +481,7 @@ class Learner:
                 self._train_sequence(P)
             P.steps_run += 1
         self.last_loss = P.loss_out
-        return P.loss_out[0]
+        return P.loss_out
 
     def _fill_masks(self, P: _Plan, dc_scales, dropout_mask):
         ex = [b for b in self.arch.blocks if b.executed]

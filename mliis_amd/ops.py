@@ -36,6 +36,38 @@ def _chk(t: torch.Tensor, dtype=torch.float32):
     return t
 
 
+# ---- optional per-call timing (bench.py / tools): PROFILE = [] enables it; every wrapped call appends
+#      {"op", "ms", **meta} with HIP events recorded on the stream the kernels are launched on.
+PROFILE = None
+
+
+def _timed(op, meta, fn):
+    if PROFILE is None:
+        return fn()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    st = torch.cuda.current_stream()
+    s.record(st)
+    r = fn()
+    e.record(st)
+    PROFILE.append(dict(op=op, ev=(s, e), **meta))
+    return r
+
+
+def profile_resolve(records):
+    """Turn recorded event pairs into milliseconds (call after a stream/device synchronize)."""
+    for r in records:
+        if "ev" in r:
+            s, e = r.pop("ev")
+            r["ms"] = s.elapsed_time(e)
+    return records
+
+
+def conv2d_plan(N, H, W, cred, nout, k):
+    tm, nt, sp = C.c_int(), C.c_int(), C.c_int()
+    lib.call("mliis_conv2d_plan", N, H, W, cred, nout, k, C.byref(tm), C.byref(nt), C.byref(sp))
+    return tm.value, nt.value, sp.value
+
+
 class Workspace:
     """Grow-only scratch buffer (floats) shared by all calls on a stream."""
 
@@ -104,7 +136,8 @@ def dwconv_fwd(x, w, stride, out=None):
     k = w.shape[0]
     Ho, Wo = -(-H // stride), -(-W // stride)
     out = torch.empty((N, Ho, Wo, C_), dtype=torch.float32, device=x.device) if out is None else out
-    lib.call("mliis_dwconv_fwd", _ptr(_chk(x)), _ptr(w), _ptr(out), N, H, W, C_, k, stride, _stream())
+    meta = dict(bytes=4.0 * (x.numel() + out.numel() + k * k * C_), shape=(N, H, W, C_, k, stride)) if PROFILE is not None else {}
+    _timed("dwconv_fwd", meta, lambda: lib.call("mliis_dwconv_fwd", _ptr(_chk(x)), _ptr(w), _ptr(out), N, H, W, C_, k, stride, _stream()))
     return out
 
 
@@ -113,7 +146,9 @@ def dwconv_bwd_data(dy, w, stride, in_hw, out=None):
     H, W = in_hw
     k = w.shape[0]
     out = torch.empty((N, H, W, C_), dtype=torch.float32, device=dy.device) if out is None else out
-    lib.call("mliis_dwconv_bwd_data", _ptr(_chk(dy)), _ptr(w), _ptr(out), N, H, W, C_, k, stride, _stream())
+    # bwd algorithmic bytes: read dY, read X, write dX, read W, write dW -- split here as data: dY + dX + W
+    meta = dict(bytes=4.0 * (dy.numel() + out.numel() + k * k * C_), shape=(N, H, W, C_, k, stride)) if PROFILE is not None else {}
+    _timed("dwconv_bwd_data", meta, lambda: lib.call("mliis_dwconv_bwd_data", _ptr(_chk(dy)), _ptr(w), _ptr(out), N, H, W, C_, k, stride, _stream()))
     return out
 
 
@@ -122,7 +157,9 @@ def dwconv_bwd_filter(x, dy, k, stride, out=None, ws: Optional[Workspace] = None
     ws = ws or default_ws()
     buf = ws.get(lib.size("mliis_dwconv_bwd_filter_workspace_floats", N, H, W, C_, k, stride))
     out = torch.empty((k, k, C_, 1), dtype=torch.float32, device=x.device) if out is None else out
-    lib.call("mliis_dwconv_bwd_filter", _ptr(x), _ptr(dy), _ptr(out), N, H, W, C_, k, stride, _ptr(buf), buf.numel(), _stream())
+    meta = dict(bytes=4.0 * (x.numel() + k * k * C_), shape=(N, H, W, C_, k, stride)) if PROFILE is not None else {}   # filter: X + dW
+    _timed("dwconv_bwd_filter", meta, lambda: lib.call("mliis_dwconv_bwd_filter", _ptr(x), _ptr(dy), _ptr(out), N, H, W, C_, k, stride, _ptr(buf),
+                                                       buf.numel(), _stream()))
     return out
 
 
@@ -138,8 +175,13 @@ def conv2d_fwd(x, w, bias=None, dil=1, out=None, accumulate=False, ws: Optional[
     _, co, ldy = rows_ld(out)
     ws = ws or default_ws()
     buf = ws.get(lib.size("mliis_conv2d_workspace_floats", N, H, W, Cin, Cout, k))
-    lib.call("mliis_conv2d_fwd", _ptr(x), ldx, _ptr(w), _ptr(bias), _ptr(out), ldy, N, H, W, Cin, Cout, k, dil, int(accumulate), _ptr(buf),
-             buf.numel(), _stream())
+    meta = {}
+    if PROFILE is not None:
+        tm, nt, sp = conv2d_plan(N, H, W, Cin, Cout, k)
+        meta = dict(kernel="conv_gemm_k<%d,%d,false>" % (tm, nt), splits=sp, flops=2.0 * N * H * W * k * k * Cin * Cout,
+                    shape=(N, H, W, Cin, Cout, k, dil))
+    _timed("conv2d_fwd", meta, lambda: lib.call("mliis_conv2d_fwd", _ptr(x), ldx, _ptr(w), _ptr(bias), _ptr(out), ldy, N, H, W, Cin, Cout, k,
+                                                dil, int(accumulate), _ptr(buf), buf.numel(), _stream()))
     return out
 
 
@@ -154,8 +196,13 @@ def conv2d_bwd_data(dy, w, dil=1, ci_begin=0, ci_count=None, out=None, accumulat
     _, _, lddx = rows_ld(out)
     ws = ws or default_ws()
     buf = ws.get(lib.size("mliis_conv2d_workspace_floats", N, H, W, Cout, ci_count, k))
-    lib.call("mliis_conv2d_bwd_data", _ptr(dy), lddy, _ptr(w), _ptr(out), lddx, N, H, W, Cin, ci_begin, ci_count, Cout, k, dil,
-             int(accumulate), _ptr(buf), buf.numel(), _stream())
+    meta = {}
+    if PROFILE is not None:
+        tm, nt, sp = conv2d_plan(N, H, W, Cout, ci_count, k)
+        meta = dict(kernel="conv_gemm_k<%d,%d,true>" % (tm, nt), splits=sp, flops=2.0 * N * H * W * k * k * ci_count * Cout,
+                    shape=(N, H, W, ci_count, Cout, k, dil))
+    _timed("conv2d_bwd_data", meta, lambda: lib.call("mliis_conv2d_bwd_data", _ptr(dy), lddy, _ptr(w), _ptr(out), lddx, N, H, W, Cin, ci_begin,
+                                                     ci_count, Cout, k, dil, int(accumulate), _ptr(buf), buf.numel(), _stream()))
     return out
 
 
@@ -166,8 +213,9 @@ def conv2d_bwd_filter(x, dy, k, dil=1, out=None, accumulate=False, ws: Optional[
     out = torch.empty((k, k, Cin, Cout), dtype=torch.float32, device=x.device) if out is None else out
     ws = ws or default_ws()
     buf = ws.get(lib.size("mliis_conv2d_bwd_filter_workspace_floats", N, H, W, Cin, Cout, k))
-    lib.call("mliis_conv2d_bwd_filter", _ptr(x), ldx, _ptr(dy), lddy, _ptr(out), N, H, W, Cin, Cout, k, dil, int(accumulate), _ptr(buf),
-             buf.numel(), _stream())
+    meta = dict(flops=2.0 * N * H * W * k * k * Cin * Cout, shape=(N, H, W, Cin, Cout, k, dil)) if PROFILE is not None else {}
+    _timed("conv2d_bwd_filter", meta, lambda: lib.call("mliis_conv2d_bwd_filter", _ptr(x), ldx, _ptr(dy), lddy, _ptr(out), N, H, W, Cin, Cout, k,
+                                                       dil, int(accumulate), _ptr(buf), buf.numel(), _stream()))
     return out
 
 

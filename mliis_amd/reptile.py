@@ -1,0 +1,181 @@
+"""Reptile ("Gecko") and first-order MAML ("FOMLIS") meta-learners over a device-resident learner.
+
+Re-statement of meta_learners/supervised_reptile/supervised_reptile/reptile.py:23-125 (Gecko.__init__/train_step) and
+:569-663 (FOMLIS) with the TensorFlow handles (`session`, `input_ph`, `label_ph`, `minimize_op`, `lr_ph`) replaced by one
+`learner` object (mliis_amd.learner.Learner on the GPU; any object with the same methods elsewhere).  What changed, on purpose:
+
+  * parameters never leave the device: `export_variables`/`import_variables` (variables.py:70-80) are arena clones/copies and the
+    outer update `theta <- theta_old + eps * mean_tasks(delta)` (variables.py:9-45; reptile.py:124-125,646-647) is one axpby;
+  * the tasks of a meta-batch are sharded over ranks (task t -> rank t mod P); every rank sums its task deltas and ONE
+    all-reduce(sum) over [delta | BN-moving contribution] combines them (RCCL over xGMI on the GPU node);
+  * BN moving statistics are not reset between tasks in the reference (reptile.py:34 vs :35-36) and therefore follow the
+    SEQUENTIAL exponential moving average over all tasks' steps.  Training-mode statistics never read the moving average, so
+    that sequence is reproduced exactly under sharding: each task accumulates S_t from a zero start and
+    m <- 0.99^(B*T) * m0 + sum_t 0.99^((B-1-t)*T) * S_t   (SURVEY.md 8(e)-1);
+  * randomness: rng_mode="reference" consumes Python's global `random` exactly like the reference (valid on one rank);
+    rng_mode="per_task" derives an independent generator per (meta_iter, task) so results do not depend on the rank count.
+Kept quirks: Gecko.train_step runs TWO optimizer steps per batch when `lr` is given and no scheduler is set
+(reptile.py:114-121); FOMLIS.train_step ignores the lr scheduler (reptile.py:639-643, E9).
+"""
+from __future__ import annotations
+
+import random
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import metaseg
+from .spec import BN_MOMENTUM
+
+
+class Dist:
+    """Thin view of torch.distributed (backend "nccl" == RCCL on ROCm, "gloo" on CPU).  World size 1 when uninitialised."""
+
+    def __init__(self):
+        import torch.distributed as dist
+        self._d = dist if (dist.is_available() and dist.is_initialized()) else None
+        self.rank = self._d.get_rank() if self._d else 0
+        self.world = self._d.get_world_size() if self._d else 1
+
+    def all_reduce_sum(self, t: torch.Tensor):
+        if self._d is not None and self.world > 1:
+            self._d.all_reduce(t, op=self._d.ReduceOp.SUM)
+        return t
+
+    def barrier(self):
+        if self._d is not None and self.world > 1:
+            self._d.barrier()
+
+
+def _task_rng(seed: int, meta_iter: int, task: int) -> random.Random:
+    return random.Random((seed * 1000003 + meta_iter) * 1000003 + task)
+
+
+class Gecko:
+    """A meta-learning session for image segmentation that extends Reptile (reference class of the same name)."""
+
+    meta_fn = "Reptile"
+
+    def __init__(self, learner, variables=None, transductive: bool = False, pre_step_op=None, lr_scheduler=None, augment: bool = False,
+                 aug_rate: Optional[float] = None, dist: Optional[Dist] = None, rng_mode: Optional[str] = None, seed: int = 0):
+        if augment:
+            raise NotImplementedError("--augment (host numpy augmentation, augmenters/np_augmenters.py) is not built yet; "
+                                      "SURVEY.md 8(f)-4")
+        self.learner = learner
+        self._transductive = transductive
+        # pre_step_op: the reference passes a TF op that multiplies all trainables by `weight_decay_rate`
+        # (variables.py:48-55); here it is that rate (float) or None.
+        self._pre_step_rate = 1.0 if pre_step_op is None else float(pre_step_op)
+        self.lr_scheduler = lr_scheduler
+        self.augmenter = None
+        self.aug_rate = aug_rate
+        self.eval_sample_number = 0
+        self.dist = dist or Dist()
+        self.rng_mode = rng_mode or ("reference" if self.dist.world == 1 else "per_task")
+        if self.rng_mode == "reference" and self.dist.world > 1:
+            raise ValueError("rng_mode='reference' consumes the global generator sequentially and is only valid on one rank")
+        self.seed = seed
+        self.meta_iter = 0
+        self._comm = None
+        print("{} meta-learning session instantiated ({} rank(s), rng_mode={}).".format(self.meta_fn, self.dist.world, self.rng_mode))
+
+    # ------------------------------------------------------------------------------------------------ helpers
+    def _rng(self, task_idx: int):
+        return None if self.rng_mode == "reference" else _task_rng(self.seed, self.meta_iter, task_idx)
+
+    def _batches(self, n_shots: int, inner_batch_size: int, inner_iters: int, replacement: bool, rng) -> List[List[int]]:
+        return [list(b) for b in metaseg.mini_batch_indices(n_shots, inner_batch_size, inner_iters, replacement, rng)]
+
+    def _sample(self, dataset, num_shots, rng):
+        (images, labels) = metaseg.sample_task(dataset, num_shots, rng)
+        self.learner.load_task(images, labels)
+        return int(images.shape[0])
+
+    def _run_meta_batch(self, dataset, num_shots, inner_batch_size, inner_iters, replacement, meta_step_size, meta_batch_size, lr,
+                        fomaml: bool):
+        L, D = self.learner, self.dist
+        with L.comm_context():   # every arena-sized temporary is created/used in the learner's stream order
+            old = L.export_trainable()
+            bn0 = L.export_bn()
+            nt, nb = old.numel(), bn0.numel()
+            if self._comm is None or self._comm.numel() != nt + nb:
+                self._comm = torch.zeros(nt + nb, dtype=old.dtype, device=old.device)
+                self._bn_zero = torch.zeros_like(bn0)
+            comm = self._comm
+            comm.zero_()
+            delta, bn_acc = comm[:nt], comm[nt:]
+            decay = BN_MOMENTUM
+            T = inner_iters
+            for t in range(meta_batch_size):
+                rng = self._rng(t)
+                if self.rng_mode != "reference" and t % D.world != D.rank:
+                    continue
+                n_shots = self._sample(dataset, num_shots, rng)
+                batches = self._task_batches(n_shots, inner_batch_size, inner_iters, replacement, rng)
+                L.import_bn(self._bn_zero)
+                last_backup = None
+                for j, idx in enumerate(batches):
+                    if fomaml and j == inner_iters - 1:
+                        last_backup = L.export_trainable()
+                    self._step(idx, j, lr)
+                # delta += theta_task - (theta_before_last_step | theta_old)
+                L.axpby(1.0, L.export_trainable(), 1.0, delta)
+                L.axpby(-1.0, last_backup if fomaml else old, 1.0, delta)
+                L.axpby(decay ** ((meta_batch_size - 1 - t) * T), L.export_bn(), 1.0, bn_acc)
+                L.import_trainable(old)
+            D.all_reduce_sum(comm)
+            # theta <- old + (eps / B) * sum_t delta_t ;  bn <- decay^(B*T) * bn0 + sum_t decay^((B-1-t)T) S_t
+            L.axpby(meta_step_size / meta_batch_size, delta, 1.0, old)
+            L.import_trainable(old)
+            L.axpby(decay ** (meta_batch_size * T), bn0, 1.0, bn_acc)
+            L.import_bn(bn_acc)
+        self.meta_iter += 1
+
+    def _task_batches(self, n_shots, inner_batch_size, inner_iters, replacement, rng):
+        return self._batches(n_shots, inner_batch_size, inner_iters, replacement, rng)
+
+    def _step(self, idx, j, lr):
+        L = self.learner
+        wd = self._pre_step_rate
+        if lr is not None:  # reptile.py:114-116 -- first optimizer step with the given lr
+            L.inner_step(idx, lr=lr, weight_decay_rate=wd)
+            wd = 1.0
+        if self.lr_scheduler is not None:  # :117-119
+            L.inner_step(idx, lr=self.lr_scheduler.cur_lr(cur_step=j), weight_decay_rate=wd)
+        else:  # :120-121 -- runs also when lr was given (quirk E1)
+            L.inner_step(idx, weight_decay_rate=wd)
+
+    # ------------------------------------------------------------------------------------------------ public surface
+    def train_step(self, dataset, num_classes=1, num_shots=5, inner_batch_size=8, inner_iters=8, replacement=False, meta_step_size=0.1,
+                   meta_batch_size=1, lr=None, verbose=False, **_unused_tf_handles):
+        """Perform one Reptile training step (reptile.py:64-125).  `num_classes` is ignored (binary Gecko)."""
+        self._run_meta_batch(dataset, num_shots, inner_batch_size, inner_iters, replacement, meta_step_size, meta_batch_size, lr, False)
+
+
+class FOMLIS(Gecko):
+    """First-order MAML for image segmentation (reference class of the same name, reptile.py:569-663)."""
+
+    meta_fn = "FOMAML"
+
+    def __init__(self, *args, train_shots: Optional[int] = None, tail_shots: Optional[int] = None,
+                 sample_train_val_with_replacement: bool = False, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.train_shots = train_shots - tail_shots if tail_shots is not None else train_shots
+        self.tail_shots = tail_shots
+        if sample_train_val_with_replacement:
+            raise NotImplementedError("--sample_foml_train_val_with_replacement draws from the unseeded numpy generator; not built")
+        self.sample_train_val_with_replacement = False
+
+    def _task_batches(self, n_shots, inner_batch_size, inner_iters, replacement, rng):
+        return metaseg.fomaml_batch_indices(n_shots, self.tail_shots, inner_batch_size, inner_iters, replacement, rng)
+
+    def _step(self, idx, j, lr):
+        wd = self._pre_step_rate
+        if lr is not None:  # reptile.py:639-641
+            self.learner.inner_step(idx, lr=lr, weight_decay_rate=wd)
+        else:  # :642-643 (the scheduler is never consulted: quirk E9)
+            self.learner.inner_step(idx, weight_decay_rate=wd)
+
+    def train_step(self, dataset, num_classes=1, num_shots=5, inner_batch_size=8, inner_iters=8, replacement=False, meta_step_size=0.1,
+                   meta_batch_size=1, verbose=False, lr=None, **_unused_tf_handles):
+        self._run_meta_batch(dataset, num_shots, inner_batch_size, inner_iters, replacement, meta_step_size, meta_batch_size, lr, True)

@@ -335,7 +335,21 @@ class OracleLearner:
             self.bn[k] = (flat[off:off + c].clone().to(self.dtype), flat[off + c:off + 2 * c].clone().to(self.dtype))
             off += 2 * c
 
-    def inner_step(self, x, y, lr=None, dc_scales=None, dropout_mask=None, weight_decay_rate=1.0):
+    def axpby(self, a, x, b, y):
+        y.mul_(b).add_(x, alpha=a)
+
+    def comm_context(self):
+        import contextlib
+        return contextlib.nullcontext()
+
+    def load_task(self, images, labels):
+        self._x, self._y = torch.as_tensor(images), torch.as_tensor(labels)
+
+    def inner_step(self, x, y=None, lr=None, dc_scales=None, dropout_mask=None, weight_decay_rate=1.0):
+        """inner_step(x, y, ...) on explicit tensors, or inner_step(batch_idx, ...) on the task given to load_task()."""
+        if y is None:
+            i = list(x)
+            x, y = self._x[i], self._y[i]
         loss, _, _ = inner_step(self.a, self.params, self.bn, x, y, self.lr if lr is None else lr,
                                 dc_scales if self.drop_connect else None, dropout_mask, self.ls, self.dice, self.l2,
                                 weight_decay_rate)
