@@ -42,12 +42,34 @@ def parse():
     return ap.parse_args()
 
 
+def usable_cores() -> int:
+    """Host cores this process may actually use: affinity mask, further limited by a cgroup CPU quota if one is set."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+        except (OSError, ValueError, IndexError):
+            pass
+    return max(1, n)
+
+
 def cpu_baseline(args):
     """CPU oracle (PyTorch-CPU fp32 restatement of the same graph) on a bounded sample of the same workload."""
     from oracle import efficientlab_ref as R
     from mliis_amd.metaseg import synthetic_task, mini_batch_indices
     import random
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     O = R.OracleLearner(image_size=args.image_size, seed=0, dtype=torch.float32, lr=1e-3)
     x, y = synthetic_task(args.shots, args.image_size, seed=0)
@@ -114,7 +136,15 @@ def roofline(L, args):
 
 
 def main():
+    import contextlib
     args = parse()
+    with contextlib.redirect_stdout(sys.stderr):   # stdout carries exactly ONE JSON line
+        out = _run(args)
+    if out is not None:
+        print(json.dumps(out))
+
+
+def _run(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -189,10 +219,12 @@ def main():
             out["kernel_families_eager_us"] = fam
         if cpu is not None:
             out["gpu_over_cpu"] = value / cpu["value"]
-        print(json.dumps(out))
+    else:
+        out = None
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
+    return out
 
 
 if __name__ == "__main__":

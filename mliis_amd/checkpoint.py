@@ -1,0 +1,66 @@
+"""Checkpoint directory layout of the reference:
+
+    <dir>/checkpoint                 text; first line  model_checkpoint_path: "model.ckpt-<step>"
+    <dir>/model.ckpt-<step>.npz      all global variables under their TF names (trainables + BN moving statistics)
+
+`tf.train.Saver(max_to_keep=2).save(sess, save_dir/model.ckpt, global_step=i)` (train.py:54,129-131) and
+`latest_checkpoint` (utils/util.py:42-50: regex on the first line of `checkpoint`) are mirrored.  The tensor container is
+numpy's .npz, not a TF TensorBundle (a bundle reader/writer is SURVEY 8(f)-3, not built yet) -- variable names and shapes are
+the reference's, so a converter is a pure re-packaging.
+"""
+from __future__ import annotations
+
+import os
+import re
+from typing import Dict, List, Optional
+
+import numpy as np
+
+CKPT_PREFIX = "model.ckpt"
+
+
+def latest_checkpoint(checkpoint_dir: str, ckpt_prefix: str = CKPT_PREFIX) -> str:
+    with open(os.path.join(checkpoint_dir, "checkpoint")) as f:
+        first = f.readline()
+    m = re.findall(re.escape(ckpt_prefix + "-") + r"[0-9]+", first)
+    if not m:
+        raise FileNotFoundError("no {}-<step> entry in {}/checkpoint".format(ckpt_prefix, checkpoint_dir))
+    return os.path.join(checkpoint_dir, m[0])
+
+
+class Saver:
+    def __init__(self, max_to_keep: int = 2):
+        self.max_to_keep = max_to_keep
+        self.kept: List[str] = []
+
+    def save(self, values: Dict[str, np.ndarray], save_dir: str, global_step: int, prefix: str = CKPT_PREFIX) -> str:
+        os.makedirs(save_dir, exist_ok=True)
+        base = "{}-{}".format(prefix, global_step)
+        path = os.path.join(save_dir, base)
+        np.savez(path + ".npz", **{k.replace("/", "|"): v for k, v in values.items()})
+        if base in self.kept:
+            self.kept.remove(base)
+        self.kept.append(base)
+        while self.max_to_keep and len(self.kept) > self.max_to_keep:
+            old = self.kept.pop(0)
+            try:
+                os.remove(os.path.join(save_dir, old + ".npz"))
+            except OSError:
+                pass
+        with open(os.path.join(save_dir, "checkpoint"), "w") as f:
+            f.write('model_checkpoint_path: "{}"\n'.format(base))
+            for b in self.kept:
+                f.write('all_model_checkpoint_paths: "{}"\n'.format(b))
+        return path
+
+
+def load(path: str) -> Dict[str, np.ndarray]:
+    """path: <dir>/model.ckpt-<step> (as returned by latest_checkpoint)."""
+    with np.load(path + ".npz") as z:
+        return {k.replace("|", "/"): z[k] for k in z.files}
+
+
+def save_fine_tuned_checkpoint(values, save_dir: str, task_name: str, eval_sample_num: int, step: int) -> str:
+    """<save_dir>/<task_name>/<eval_sample_num>/model.ckpt-<step>  (utils/util.py:72-81)."""
+    d = os.path.join(save_dir, str(task_name), str(eval_sample_num))
+    return Saver(max_to_keep=1).save(values, d, step)

@@ -523,5 +523,11 @@ class Learner:
         self.stream.synchronize()
         return (out, lg) if return_logits else out
 
+    def predict_resident(self, idx: Sequence[int], training: bool = False):
+        """predict() on images `idx` of the task made resident by load_task()."""
+        with torch.cuda.stream(self.stream):
+            x = self.shots_x[torch.tensor(list(idx), dtype=torch.long, device=self.device)]
+        return self.predict(x, training=training)
+
     def gradients_packed(self) -> torch.Tensor:
         return self.arena.export_grad_packed()

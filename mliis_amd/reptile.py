@@ -152,6 +152,76 @@ class Gecko:
         self._run_meta_batch(dataset, num_shots, inner_batch_size, inner_iters, replacement, meta_step_size, meta_batch_size, lr, False)
 
 
+    # ------------------------------------------------------------------------------------------------ evaluation
+    DEFAULT_NUM_TEST_EXAMPLES = 5
+
+    def evaluate(self, dataset, num_classes=1, num_shots=5, inner_batch_size=8, inner_iters=4, replacement=False, eval_all_tasks=False,
+                 num_tasks_to_sample=1, test_shots=DEFAULT_NUM_TEST_EXAMPLES, verbose=False, save_fine_tuned_checkpoints=False,
+                 save_fine_tuned_checkpoints_dir: Optional[str] = None, eval_sample_num: Optional[int] = None, lr: Optional[float] = None,
+                 drop_rate: Optional[float] = None, aug_rate: Optional[float] = None, **_unused_tf_handles):
+        """One evaluation pass (reptile.py:127-233): fine-tune on `num_shots` examples of each sampled task, predict the held-out
+        `test_shots`, return (mean IoU, {task_name: IoU}).  Shuffles the caller's task list in place like the reference (E18)."""
+        import numpy as np
+        print("Evaluating {} meta-learning.".format(self.meta_fn))
+        if eval_all_tasks:
+            sampled = dataset
+        else:
+            random.shuffle(dataset)
+            sampled = dataset[:num_tasks_to_sample]
+        ious, task_iou_map = [], {}
+        for task in sampled:
+            (images, labels), name = metaseg.sample_task([task], num_shots + test_shots, None, return_task_name=True)
+            n = int(images.shape[0])
+            self.learner.load_task(images, labels)
+            train_idx, test_idx = metaseg.split_indices(n, test_shots)
+            iou = self._evaluate(train_idx, test_idx, labels, inner_batch_size, inner_iters, replacement, lr=lr, task_name=name,
+                                 save_fine_tuned_checkpoints=save_fine_tuned_checkpoints,
+                                 save_fine_tuned_checkpoints_dir=save_fine_tuned_checkpoints_dir, eval_sample_num=eval_sample_num)
+            ious.append(iou)
+            task_iou_map[name] = iou
+        mean_iou = float(np.nanmean(ious))
+        print("Mean IoU from train on {} images and evaluate on {} test images: {}".format(num_shots, test_shots, mean_iou))
+        return mean_iou, task_iou_map
+
+    def _evaluate(self, train_idx, test_idx, labels, inner_batch_size, inner_iters, replacement, lr=None, task_name=None,
+                  save_fine_tuned_checkpoints=False, save_fine_tuned_checkpoints_dir=None, eval_sample_num=None):
+        """Evaluates a single task's train/test split (reptile.py:235-294): ALL global variables are restored afterwards."""
+        import numpy as np
+        from .metrics import iou as _iou
+        L = self.learner
+        old = L.export_all()
+        inner_iter = 0
+        for inner_iter, b in enumerate(metaseg.mini_batch_indices(len(train_idx), inner_batch_size, inner_iters, replacement)):
+            idx = [train_idx[i] for i in b]
+            if lr is not None:
+                L.inner_step(idx, lr=lr, weight_decay_rate=self._pre_step_rate)
+            elif self.lr_scheduler is not None:
+                L.inner_step(idx, lr=self.lr_scheduler.cur_lr(cur_step=inner_iter), weight_decay_rate=self._pre_step_rate)
+            else:
+                L.inner_step(idx, weight_decay_rate=self._pre_step_rate)
+        if save_fine_tuned_checkpoints:
+            from .checkpoint import save_fine_tuned_checkpoint
+            L.synchronize()
+            save_fine_tuned_checkpoint(L.arena.named_numpy(), save_fine_tuned_checkpoints_dir, task_name, eval_sample_num, inner_iter)
+        preds = self._test_predictions(train_idx, test_idx)
+        lab = labels.detach().cpu().numpy() if hasattr(labels, "detach") else np.asarray(labels)
+        class_iou = float(np.nanmean([_iou(preds[j], lab[test_idx[j]]) for j in range(len(test_idx))]))
+        print("Mean task IoU: {}".format(class_iou))
+        L.import_all(old)
+        return class_iou
+
+    def _test_predictions(self, train_idx, test_idx):
+        """reptile.py:482-524: transductive -> all test images in one inference-mode batch; otherwise one call per test image on the
+        batch [train images..., that test image], keeping the last prediction."""
+        L = self.learner
+        if self._transductive:
+            return L.predict_resident(list(test_idx), training=False).cpu().numpy()
+        out = []
+        for t in test_idx:
+            out.append(L.predict_resident(list(train_idx) + [t], training=False)[-1].cpu().numpy())
+        return out
+
+
 class FOMLIS(Gecko):
     """First-order MAML for image segmentation (reference class of the same name, reptile.py:569-663)."""
 

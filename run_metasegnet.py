@@ -1,0 +1,121 @@
+"""Entry point with the reference's command line (run_metasegnet.py:28-210, flags of meta_learners/args.py) on the MI355X
+inner-loop engine.
+
+    python run_metasegnet.py --image_size 224 --rsd 2 4 --sgd --foml --foml-tail 5 --train-shots 10 --meta-batch 8 \
+        --meta-iters 100 --checkpoint ckpt --synthetic-tasks 64
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 run_metasegnet.py ...   (tasks sharded 1/GPU)
+
+Writes the reference's checkpoint directory layout (mliis_amd/checkpoint.py) and `<checkpoint>/meta-test_results.json`.
+Out of scope in this build (clear errors): UHO hyper-parameter search, k-shot learning-curve experiment, host augmentation,
+the FSS-1000 TFRecord reader; use --synthetic-tasks for data.
+"""
+import datetime
+import json
+import os
+import random
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from mliis_amd import checkpoint as ckpt  # noqa: E402
+from mliis_amd.args import argument_parser, evaluate_kwargs, make_lr_scheduler, model_kwargs, train_kwargs  # noqa: E402
+
+
+def _dataset(args, device, rank):
+    from mliis_amd.metaseg import DeviceTask, synthetic_task
+    if not args.synthetic_tasks:
+        raise NotImplementedError("reading FSS-1000 TFRecord-GZIP shards from --data-dir is not built yet (SURVEY.md 8(f)-2); "
+                                  "pass --synthetic-tasks N")
+    n_ex = max(args.train_shots or 0, args.shots + 5)
+    tasks = []
+    for i in range(args.synthetic_tasks):
+        x, y = synthetic_task(n_ex, args.image_size, seed=i)
+        tasks.append(DeviceTask("synthetic_{:04d}".format(i), torch.from_numpy(x).to(device), torch.from_numpy(y).to(device)))
+    n_test = max(1, len(tasks) // 4)
+    return tasks[:-n_test], tasks[-n_test:]
+
+
+def main():
+    start = datetime.datetime.now()
+    print("Experiment started at: {}".format(start))
+    args = argument_parser().parse_args()
+    if args.optimize_update_hyperparms_on_val_set or args.run_k_shot_learning_curves_experiment:
+        raise NotImplementedError("UHO search / k-shot learning curves are experiment harnesses outside the hot path (SURVEY.md 8(f)-4)")
+    random.seed(args.seed)
+    world, rank, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    device = torch.device("cuda", local)
+    from mliis_amd.learner import Learner
+    from mliis_amd.reptile import Dist
+    from mliis_amd.train import train_gecko
+
+    print("Defining model architecture:")
+    print("Using loss {}".format(args.loss_name))
+    learner = Learner(device=device, **model_kwargs(args))
+    lr_scheduler = make_lr_scheduler(args)
+    print("Model contains {} trainable parameters.".format(learner.n_trainable))
+    print("Meta-learning with algorithm:\n{}".format("FOMAML" if args.foml else "Reptile"))
+    train_set, test_set = _dataset(args, device, rank)
+
+    if args.restore_efficient_net_weights_from is not None and not args.pretrained:
+        path = ckpt.latest_checkpoint(args.restore_efficient_net_weights_from)
+        print("Restoring from checkpoint {}".format(path))
+        learner.load_named(ckpt.load(path), strict=False, prefixes=[learner.feature_extractor_name])
+    if not args.pretrained:
+        print("Meta-training...")
+        if args.continue_training_from_checkpoint is not None:
+            path = ckpt.latest_checkpoint(args.continue_training_from_checkpoint)
+            print("Continuing meta-training from checkpoint: {}".format(path))
+            learner.load_named(ckpt.load(path))
+        train_gecko(learner, train_set, test_set, args.checkpoint, lr_scheduler=lr_scheduler, augment=args.augment, dist=Dist(),
+                    seed=args.seed, **train_kwargs(args))
+    else:
+        path = ckpt.latest_checkpoint(args.checkpoint)
+        print("Restoring from checkpoint: {}".format(path))
+        if args.do_not_restore_final_layer_weights:
+            learner.load_named(ckpt.load(path), strict=False, exclude_prefix=learner.final_layer_scope)
+        else:
+            learner.load_named(ckpt.load(path))
+
+    if rank == 0:
+        ek = evaluate_kwargs(args)
+        meta = ek["meta_fn"](learner, transductive=ek["transductive"], pre_step_op=(ek["weight_decay_rate"] if ek["weight_decay_rate"] != 1 else None),
+                             lr_scheduler=lr_scheduler, augment=ek["augment"], aug_rate=ek["aug_rate"], rng_mode="reference",
+                             dist=type("One", (), {"rank": 0, "world": 1, "all_reduce_sum": staticmethod(lambda t: t), "barrier": staticmethod(lambda: None)})())
+        results = {}
+        print("Evaluating {}-shot learning on meta-test tasks.".format(args.shots))
+        ious = []
+        for sample in range(max(1, min(args.eval_samples, 2 if args.serially_eval_all_test_tasks else args.eval_samples))):
+            miou, m = meta.evaluate(test_set, num_shots=ek["num_shots"], inner_batch_size=ek["eval_inner_batch_size"],
+                                    inner_iters=ek["eval_inner_iters"], replacement=ek["replacement"],
+                                    eval_all_tasks=args.serially_eval_all_test_tasks, num_tasks_to_sample=1, eval_sample_num=sample)
+            ious.append(miou)
+            for k, v in m.items():
+                results.setdefault(k, []).append(v)
+            if not args.serially_eval_all_test_tasks and sample + 1 >= args.eval_samples:
+                break
+        # Do NOT change this print (it's used to grep logs):
+        print("Mean IoU over all meta-test tasks: {}".format(float(np.nanmean(ious))))
+        os.makedirs(args.checkpoint, exist_ok=True)
+        out = os.path.join(args.checkpoint, "meta-test_results.json")
+        with open(out, "w") as f:
+            json.dump(results, f)
+        print("Wrote results to {}".format(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+    end = datetime.datetime.now()
+    print("Experiment finished at: {}, taking {}".format(end, end - start))
+
+
+if __name__ == "__main__":
+    main()

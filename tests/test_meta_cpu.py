@@ -1,0 +1,163 @@
+"""Meta-learner host logic on the CPU oracle learner (float64): Reptile / FOMAML outer-update algebra, sequential BN
+moving-average semantics under task sharding, and the world_size-2 gloo path == single-process result."""
+import copy
+import os
+import random
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+from mliis_amd import metaseg
+from mliis_amd.reptile import FOMLIS, Gecko
+from oracle import efficientlab_ref as R
+
+H = 32
+
+
+def _tasks(n, shots):
+    out = []
+    for i in range(n):
+        x, y = metaseg.synthetic_task(shots, H, seed=50 + i, block=4)
+        out.append(metaseg.DeviceTask("t%d" % i, torch.tensor(x), torch.tensor(y)))
+    return out
+
+
+def _learner():
+    return R.OracleLearner(image_size=H, seed=3, dtype=torch.float64, lr=1e-2, drop_connect=False)
+
+
+def _sequential_reference(L, tasks_batches, fomaml, eps):
+    """What the reference does: tasks one after another, BN moving stats never reset, numpy-style averaging."""
+    old = L.export_trainable()
+    ups = []
+    for x, y, batches in tasks_batches:
+        L.load_task(x, y)
+        last = None
+        for j, b in enumerate(batches):
+            if fomaml and j == len(batches) - 1:
+                last = L.export_trainable()
+            L.inner_step(b)
+        ups.append(L.export_trainable() - (last if fomaml else old))
+        L.import_trainable(old)
+    L.import_trainable(old + eps * torch.stack(ups).mean(0))
+
+
+@pytest.mark.parametrize("fomaml", [False, True])
+def test_meta_step_matches_sequential_reference(fomaml):
+    tasks = _tasks(3, 6)
+    B, iters, bs, eps = 3, 3, 4, 0.25
+    A = _learner()
+    ref = copy.deepcopy(A)
+    if fomaml:
+        meta = FOMLIS(A, train_shots=6, tail_shots=2, rng_mode="per_task", seed=1)
+    else:
+        meta = Gecko(A, rng_mode="per_task", seed=1)
+    # replay the same per-task generators to build the reference schedule
+    from mliis_amd.reptile import _task_rng
+    sched = []
+    for t in range(B):
+        rng = _task_rng(1, 0, t)
+        (x, y) = metaseg.sample_task(tasks, 6, rng)
+        batches = metaseg.fomaml_batch_indices(6, 2, bs, iters, False, rng) if fomaml else \
+            [list(b) for b in metaseg.mini_batch_indices(6, bs, iters, False, rng)]
+        sched.append((x, y, batches))
+    meta.train_step(tasks, num_shots=6, inner_batch_size=bs, inner_iters=iters, replacement=False, meta_step_size=eps, meta_batch_size=B)
+    _sequential_reference(ref, sched, fomaml, eps)
+    assert torch.allclose(A.export_trainable(), ref.export_trainable(), rtol=0, atol=1e-12)
+    # BN moving statistics follow the SEQUENTIAL exponential average over all tasks' steps
+    assert torch.allclose(A.export_bn(), ref.export_bn(), rtol=1e-10, atol=1e-12)
+    assert meta.meta_iter == 1
+
+
+def test_reference_rng_mode_consumes_global_random_like_the_reference(golden):
+    """rng_mode='reference': task choice + batch order come from the global `random`, in the reference's order."""
+    tasks = _tasks(2, 5)
+    A = _learner()
+    seen = []
+    orig = A.inner_step
+    A.inner_step = lambda idx, **kw: seen.append(list(idx)) or 0.0
+    meta = Gecko(A, rng_mode="reference")
+    random.seed(0)
+    meta.train_step(tasks, num_shots=5, inner_batch_size=8, inner_iters=3, meta_step_size=0.0, meta_batch_size=1)
+    random.seed(0)
+    random.sample(list(tasks), 1)          # the task draw consumes the generator first (metaseg.py:244)
+    exp = [list(b) for b in metaseg.mini_batch_indices(5, 8, 3)]
+    assert seen == exp
+    A.inner_step = orig
+
+
+def test_gecko_two_steps_per_batch_quirk_and_fomlis_single():
+    tasks = _tasks(1, 5)
+    for cls, kw, expect in ((Gecko, {}, 2), (FOMLIS, dict(train_shots=5, tail_shots=None), 1)):
+        A = _learner()
+        calls = []
+        A.inner_step = lambda idx, **k: calls.append(k.get("lr")) or 0.0
+        m = cls(A, rng_mode="per_task", **kw)
+        m.train_step(tasks, num_shots=5, inner_batch_size=4, inner_iters=2, meta_step_size=0.1, meta_batch_size=1, lr=0.5)
+        assert len(calls) == 2 * expect          # Gecko runs two optimizer steps per batch when lr is given
+        assert calls[0] == 0.5
+
+
+def test_unsupported_features_raise():
+    A = _learner()
+    with pytest.raises(NotImplementedError):
+        Gecko(A, augment=True)
+    with pytest.raises(NotImplementedError):
+        FOMLIS(A, train_shots=5, tail_shots=2, sample_train_val_with_replacement=True)
+    with pytest.raises(ValueError):
+        Gecko(A, rng_mode="reference", dist=type("D", (), {"rank": 0, "world": 2})())
+
+
+# ------------------------------------------------------------------------------------------------ gloo, world size 2
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, fomaml, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        A = _learner()
+        tasks = _tasks(3, 6)
+        meta = FOMLIS(A, train_shots=6, tail_shots=2, seed=1) if fomaml else Gecko(A, seed=1)
+        assert meta.rng_mode == "per_task" and meta.dist.world == world
+        for _ in range(2):
+            meta.train_step(tasks, num_shots=6, inner_batch_size=4, inner_iters=2, replacement=False, meta_step_size=0.3, meta_batch_size=4)
+        q.put((rank, A.export_trainable().numpy(), A.export_bn().numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fomaml", [False, True])
+def test_gloo_world2_equals_single_process(fomaml):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, fomaml, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # every rank ends with the same parameters
+    np.testing.assert_array_equal(res[0][1], res[1][1])
+    np.testing.assert_array_equal(res[0][2], res[1][2])
+    # and they equal the single-process (world 1, per-task rng) run
+    torch.set_num_threads(4)
+    A = _learner()
+    tasks = _tasks(3, 6)
+    meta = FOMLIS(A, train_shots=6, tail_shots=2, seed=1, rng_mode="per_task") if fomaml else Gecko(A, seed=1, rng_mode="per_task")
+    for _ in range(2):
+        meta.train_step(tasks, num_shots=6, inner_batch_size=4, inner_iters=2, replacement=False, meta_step_size=0.3, meta_batch_size=4)
+    np.testing.assert_allclose(res[0][1], A.export_trainable().numpy(), rtol=0, atol=1e-9)  # thread-count dependent fp64 rounding
+    np.testing.assert_allclose(res[0][2], A.export_bn().numpy(), rtol=1e-8, atol=1e-9)
