@@ -24,7 +24,7 @@ struct ColGeom {
   int nblk;     // blocks along rows (per segment)
 };
 
-static inline ColGeom col_geom(long long rows_per_seg, int C, int nseg, int target_blocks = 2048) {
+static inline ColGeom col_geom(long long rows_per_seg, int C, int nseg, int target_blocks = 512) {
   ColGeom g;
   g.Q = C / 4;
   g.QB = g.Q < kMaxQuadsPerBlock ? g.Q : kMaxQuadsPerBlock;
@@ -115,17 +115,16 @@ struct StatsOp {
   }
 };
 
-__global__ void bn_stats_finalize_k(const float* __restrict__ part, int nblk, int C, double inv_n, float eps,
-                                    float one_minus_momentum, float ema_var_factor, float* __restrict__ mean,
-                                    float* __restrict__ rstd, float* __restrict__ moving_mean,
-                                    float* __restrict__ moving_var) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0, ss = 0.0;
-  for (int b = 0; b < nblk; ++b) {
-    s += (double)part[((long long)b * 2 + 0) * C + c];
-    ss += (double)part[((long long)b * 2 + 1) * C + c];
-  }
+__global__ __launch_bounds__(256) void bn_stats_finalize_k(const float* __restrict__ part, int nblk, int C, double inv_n, float eps,
+                                                           float one_minus_momentum, float ema_var_factor,
+                                                           float* __restrict__ mean, float* __restrict__ rstd,
+                                                           float* __restrict__ moving_mean, float* __restrict__ moving_var) {
+  __shared__ double sm[kFoldY * (kFoldX + 1)];
+  const int c = blockIdx.x * kFoldX + threadIdx.x;
+  const bool ok = c < C;
+  const double s = fold_partials(part, nblk, 2LL * C, c, ok, sm);
+  const double ss = fold_partials(part, nblk, 2LL * C, (long long)C + c, ok, sm);
+  if (!ok || threadIdx.y != 0) return;
   double m = s * inv_n;
   double var = ss * inv_n - m * m;
   if (var < 0.0) var = 0.0;
@@ -213,15 +212,15 @@ struct BnBwdOp {
   }
 };
 
-__global__ void bn_bwd_finalize_k(const float* __restrict__ part, int nblk, int C, double inv_n, float* __restrict__ dgamma,
-                                  float* __restrict__ dbeta, float* __restrict__ c1, float* __restrict__ c2) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0, sx = 0.0;
-  for (int b = 0; b < nblk; ++b) {
-    s += (double)part[((long long)b * 2 + 0) * C + c];
-    sx += (double)part[((long long)b * 2 + 1) * C + c];
-  }
+__global__ __launch_bounds__(256) void bn_bwd_finalize_k(const float* __restrict__ part, int nblk, int C, double inv_n,
+                                                         float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ c1,
+                                                         float* __restrict__ c2) {
+  __shared__ double sm[kFoldY * (kFoldX + 1)];
+  const int c = blockIdx.x * kFoldX + threadIdx.x;
+  const bool ok = c < C;
+  const double s = fold_partials(part, nblk, 2LL * C, c, ok, sm);
+  const double sx = fold_partials(part, nblk, 2LL * C, (long long)C + c, ok, sm);
+  if (!ok || threadIdx.y != 0) return;
   dbeta[c] = (float)s;
   dgamma[c] = (float)sx;
   c1[c] = (float)(s * inv_n);
@@ -285,18 +284,28 @@ struct Outer2Op {
   }
 };
 
-__global__ void sum_finalize_k(const float* __restrict__ part, int nblk, int NV, int C, int nseg, float scale,
-                               float* __restrict__ out, int accumulate) {
-  // out layout [seg][v][C]
-  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  long long total = (long long)nseg * NV * C;
-  if (i >= total) return;
-  int c = (int)(i % C);
-  int v = (int)((i / C) % NV);
-  int seg = (int)(i / ((long long)C * NV));
-  double s = 0.0;
-  for (int b = 0; b < nblk; ++b) s += (double)part[(((long long)seg * nblk + b) * NV + v) * C + c];
-  float r = (float)(s * (double)scale);
+// out layout [seg][v][C]; part layout [seg][blk][v][C]; one block column = (seg, v, 16 channels)
+__global__ __launch_bounds__(256) void sum_finalize_k(const float* __restrict__ part, int nblk, int NV, int C, int nseg, float scale,
+                                                      float* __restrict__ out, int accumulate) {
+  __shared__ double sm[kFoldY * (kFoldX + 1)];
+  const int c = blockIdx.x * kFoldX + threadIdx.x;
+  const int v = blockIdx.y, seg = blockIdx.z;
+  const bool ok = c < C;
+  const double s = fold_partials(part + (long long)seg * nblk * NV * C, nblk, (long long)NV * C, (long long)v * C + c, ok, sm);
+  if (!ok || threadIdx.y != 0) return;
+  const long long i = ((long long)seg * NV + v) * C + c;
+  const float r = (float)(s * (double)scale);
+  out[i] = accumulate ? out[i] + r : r;
+}
+
+__global__ __launch_bounds__(256) void fold_flat_k(const float* __restrict__ part, int nblk, long long total, float scale,
+                                                   float* __restrict__ out, int accumulate) {
+  __shared__ double sm[kFoldY * (kFoldX + 1)];
+  const long long i = (long long)blockIdx.x * kFoldX + threadIdx.x;
+  const bool ok = i < total;
+  const double s = fold_partials(part, nblk, total, i, ok, sm);
+  if (!ok || threadIdx.y != 0) return;
+  const float r = (float)(s * (double)scale);
   out[i] = accumulate ? out[i] + r : r;
 }
 
@@ -333,7 +342,7 @@ int mliis_bn_stats(const float* x, int ldx, long long rows, int C, int pre_swish
   if (rc) return rc;
   double n = (double)rows;
   float factor = unbiased_moving_var ? (float)(n / (n - 1.0)) : 1.0f;
-  hipLaunchKernelGGL(bn_stats_finalize_k, dim3(ceil_div(C, 128)), dim3(128), 0, stream, ws, g.nblk, C, 1.0 / n, eps,
+  hipLaunchKernelGGL(bn_stats_finalize_k, dim3(ceil_div(C, kFoldX)), dim3(kFoldX, kFoldY), 0, stream, ws, g.nblk, C, 1.0 / n, eps,
                      (float)(1.0 - (double)momentum), factor, mean, rstd, moving_mean, moving_var);
   MLIIS_CHECK_LAUNCH("bn_stats_finalize");
   return MLIIS_OK;
@@ -376,7 +385,7 @@ int mliis_bn_bwd(const float* x, int ldx, const float* dy, int lddy, float* dx, 
   if (rc) return rc;
   float* c1 = ws + coef_off;
   float* c2 = c1 + C;
-  hipLaunchKernelGGL(bn_bwd_finalize_k, dim3(ceil_div(C, 128)), dim3(128), 0, stream, ws, g.nblk, C, 1.0 / (double)rows, dgamma,
+  hipLaunchKernelGGL(bn_bwd_finalize_k, dim3(ceil_div(C, kFoldX)), dim3(kFoldX, kFoldY), 0, stream, ws, g.nblk, C, 1.0 / (double)rows, dgamma,
                      dbeta, c1, c2);
   MLIIS_CHECK_LAUNCH("bn_bwd_finalize");
   hipLaunchKernelGGL(bn_bwd_apply_k, dim3(ew_grid(rows * (C / 4))), dim3(256), 0, stream, p, rows, c1, c2, dx, lddx);
@@ -396,8 +405,7 @@ int mliis_colsum(const float* a, int lda, const float* b, int ldb, long long row
   ColGeom g;
   int rc = launch_colreduce(op, rows_per_seg, C, nseg, ws, ws_floats, stream, &g, "colsum");
   if (rc) return rc;
-  long long total = (long long)nseg * C;
-  hipLaunchKernelGGL(sum_finalize_k, dim3(ceil_div(total, 256)), dim3(256), 0, stream, ws, g.nblk, 1, C, nseg, scale, out,
+  hipLaunchKernelGGL(sum_finalize_k, dim3(ceil_div(C, kFoldX), 1, nseg), dim3(kFoldX, kFoldY), 0, stream, ws, g.nblk, 1, C, nseg, scale, out,
                      accumulate);
   MLIIS_CHECK_LAUNCH("colsum_finalize");
   return MLIIS_OK;
@@ -409,13 +417,13 @@ int mliis_final_conv_bwd_filter(const float* x, int ldx, const float* mask, cons
 }
 
 namespace mliis {
-__global__ void final_dw_finalize_k(const float* __restrict__ part, int nblk, int C, float* __restrict__ dw) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= 2 * C) return;
-  int c = i >> 1, j = i & 1;
-  double s = 0.0;
-  for (int b = 0; b < nblk; ++b) s += (double)part[((long long)b * 2 + j) * C + c];
-  dw[i] = (float)s;
+__global__ __launch_bounds__(256) void final_dw_finalize_k(const float* __restrict__ part, int nblk, int C, float* __restrict__ dw) {
+  __shared__ double sm[kFoldY * (kFoldX + 1)];
+  const int c = blockIdx.x * kFoldX + threadIdx.x;
+  const int j = blockIdx.y;
+  const bool ok = c < C;
+  const double s = fold_partials(part, nblk, 2LL * C, (long long)j * C + c, ok, sm);
+  if (ok && threadIdx.y == 0) dw[c * 2 + j] = (float)s;
 }
 __global__ __launch_bounds__(256) void sum2_k(const float* __restrict__ dy, long long rows, float* __restrict__ db) {
   // single block: db[j] = sum_rows dy[row, j]
@@ -453,7 +461,7 @@ extern "C" int mliis_final_conv_bwd_filter(const float* x, int ldx, const float*
   ColGeom g;
   int rc = launch_colreduce(op, rows, C, 1, ws, ws_floats, stream, &g, "final_conv_bwd_filter");
   if (rc) return rc;
-  hipLaunchKernelGGL(final_dw_finalize_k, dim3(ceil_div(2 * C, 128)), dim3(128), 0, stream, ws, g.nblk, C, dw);
+  hipLaunchKernelGGL(final_dw_finalize_k, dim3(ceil_div(C, kFoldX), 2), dim3(kFoldX, kFoldY), 0, stream, ws, g.nblk, C, dw);
   MLIIS_CHECK_LAUNCH("final_dw_finalize");
   hipLaunchKernelGGL(sum2_k, dim3(1), dim3(256), 0, stream, dy, rows, db);
   MLIIS_CHECK_LAUNCH("final_db");

@@ -51,4 +51,32 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Second stage of the deterministic two-stage reductions: fold `nblk` partial vectors.  Launch with blockDim = (16, 16):
+// threadIdx.x = column inside the block, threadIdx.y = one of 16 lanes that stride over the partial blocks; the lanes are
+// combined through LDS in double precision in a fixed order, so the result does not depend on scheduling.
+// Returns the column sum in every thread with threadIdx.y == 0 (others return garbage-free partials; ignore them).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kFoldX = 16, kFoldY = 16;
+
+__device__ __forceinline__ double fold_partials(const float* __restrict__ part, int nblk, long long blk_stride, long long col_off,
+                                                bool col_valid, double* __restrict__ sm /* [kFoldY][kFoldX + 1] */) {
+  double s = 0.0;
+  if (col_valid)
+    for (int b = threadIdx.y; b < nblk; b += kFoldY) s += (double)part[(long long)b * blk_stride + col_off];
+  sm[threadIdx.y * (kFoldX + 1) + threadIdx.x] = s;
+  __syncthreads();
+  double r = 0.0;
+  if (threadIdx.y == 0) {
+#pragma unroll
+    for (int j = 0; j < kFoldY; ++j) r += sm[j * (kFoldX + 1) + threadIdx.x];
+  }
+  __syncthreads();
+  return r;
+}
+
+// out[i] (+)= scale * sum_z part[z * total + i]
+__global__ __launch_bounds__(256) void fold_flat_k(const float* __restrict__ part, int nblk, long long total, float scale,
+                                                   float* __restrict__ out, int accumulate);
+
 }  // namespace mliis

@@ -372,15 +372,6 @@ __global__ __launch_bounds__(256) void conv_filter_grad_k(FilterGradParams p) {
     }
 }
 
-__global__ __launch_bounds__(256) void filter_reduce_k(const float* __restrict__ partial, int splits, long long total,
-                                                       float* __restrict__ out, int accumulate) {
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    float s = partial[i];
-    for (int z = 1; z < splits; ++z) s += partial[(long long)z * total + i];
-    out[i] = accumulate ? out[i] + s : s;
-  }
-}
-
 // ------------------------------------------------------------------------------------------------ host-side planning
 struct GemmPlan {
   int tm, nt, gx, gy, gz, chunks_per_split;
@@ -451,7 +442,8 @@ static inline FilterPlan plan_filter(long long M, int C, int Nout, int ntaps, in
   int bci = 64 * f.tmf;
   f.gx = ntaps * ((C + bci - 1) / bci);
   long long base = (long long)f.gx * f.gy;
-  long long want = (4LL * num_cus + base - 1) / base;  // ~4 blocks per CU in total
+  long long want = (3LL * num_cus + base - 1) / base;  // ~3 blocks per CU in total ...
+  if (want > 96) want = 96;                            // ... but bound the number of partial slabs the fold has to read
   if (want < 1) want = 1;
   long long rps = (M + want - 1) / want;
   if (rps < 256) rps = 256;
@@ -615,8 +607,8 @@ int mliis_conv2d_bwd_filter(const float* x, int ldx, const float* dy, int lddy, 
   FilterGradParams p{x, ldx, Nimg, H, W, Cin, ksize * ksize, dil, dy, lddy, Cout, ws, f.rows_per_split};
   launch_filter(f, p, stream);
   MLIIS_CHECK_LAUNCH("conv2d_bwd_filter");
-  int blocks = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
-  hipLaunchKernelGGL(filter_reduce_k, dim3(blocks), dim3(256), 0, stream, ws, f.gz, (long long)total, dw, accumulate);
+  hipLaunchKernelGGL(fold_flat_k, dim3(ceil_div((long long)total, kFoldX)), dim3(kFoldX, kFoldY), 0, stream, ws, f.gz, (long long)total, 1.0f, dw,
+                     accumulate);
   MLIIS_CHECK_LAUNCH("conv2d_bwd_filter_reduce");
   return MLIIS_OK;
 }

@@ -174,14 +174,6 @@ __global__ __launch_bounds__(256) void dwconv_bwd_filter_k(const float* __restri
   }
 }
 
-__global__ void dw_filter_finalize_k(const float* __restrict__ part, int nblk, int KK, int C, float* __restrict__ dw) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= KK * C) return;
-  double s = 0.0;
-  for (int b = 0; b < nblk; ++b) s += (double)part[(long long)b * KK * C + i];
-  dw[i] = (float)s;
-}
-
 struct DwGeom {
   int Ho, Wo, pt, pl;
 };
@@ -208,7 +200,7 @@ static inline DwFilterGeom dw_filter_geom(int N, int Ho, int Wo, int C, int TW) 
   g.RP = 256 / g.QB;
   g.ny = ceil_div(Q, g.QB);
   long long items = (long long)N * Ho * ((Wo + TW - 1) / TW);
-  long long want = 1024 / g.ny;
+  long long want = 512 / g.ny;
   if (want < 1) want = 1;
   long long ipb = (items + want - 1) / want;
   long long minr = (long long)g.RP * 4;
@@ -288,7 +280,8 @@ int mliis_dwconv_bwd_filter(const float* x, const float* dy, float* dw, int N, i
   dim3 grid(f.nblk, f.ny);
   DW_DISPATCH(dwconv_bwd_filter_k, x, dy, ws, N, H, W, g.Ho, g.Wo, C, g.pt, g.pl, f.QB, f.RP, f.items_per_block);
   MLIIS_CHECK_LAUNCH("dwconv_bwd_filter");
-  hipLaunchKernelGGL(dw_filter_finalize_k, dim3(ceil_div(k * k * C, 256)), dim3(256), 0, stream, ws, f.nblk, k * k, C, dw);
+  hipLaunchKernelGGL(fold_flat_k, dim3(ceil_div(k * k * C, kFoldX)), dim3(kFoldX, kFoldY), 0, stream, ws, f.nblk, (long long)k * k * C, 1.0f,
+                     dw, 0);
   MLIIS_CHECK_LAUNCH("dwconv_bwd_filter_finalize");
   return MLIIS_OK;
 }

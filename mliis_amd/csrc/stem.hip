@@ -126,18 +126,10 @@ __global__ __launch_bounds__(256) void stem_bwd_filter_k(const float* __restrict
   }
 }
 
-__global__ void stem_filter_finalize_k(const float* __restrict__ part, int nblk, int total, float* __restrict__ dw) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
-  double s = 0.0;
-  for (int b = 0; b < nblk; ++b) s += (double)part[(long long)b * total + i];
-  dw[i] = (float)s;
-}
-
 static inline void stem_filter_geom(int N, int Ho, int Wo, int Co, int* pix_per_block, int* nblk) {
   long long P = (long long)N * Ho * Wo;
   int PL = 256 / Co;
-  long long ppb = (P + 1023) / 1024;
+  long long ppb = (P + 511) / 512;
   if (ppb < PL * 4) ppb = PL * 4;
   ppb = (ppb + PL - 1) / PL * PL;
   *pix_per_block = (int)ppb;
@@ -184,7 +176,7 @@ int mliis_stem_conv_bwd_filter(const float* x, const int* img_idx, const float* 
   hipLaunchKernelGGL(stem_bwd_filter_k, dim3(nblk), dim3(256), 256 * sizeof(float), stream, x, img_idx, dz, ws, N, H, W, g.Ho, g.Wo, Co,
                      g.pt, g.pl, nm, ppb);
   MLIIS_CHECK_LAUNCH("stem_conv_bwd_filter");
-  hipLaunchKernelGGL(stem_filter_finalize_k, dim3(ceil_div(27 * Co, 256)), dim3(256), 0, stream, ws, nblk, 27 * Co, dw);
+  hipLaunchKernelGGL(fold_flat_k, dim3(ceil_div(27 * Co, kFoldX)), dim3(kFoldX, kFoldY), 0, stream, ws, nblk, (long long)27 * Co, 1.0f, dw, 0);
   MLIIS_CHECK_LAUNCH("stem_conv_bwd_filter_finalize");
   return MLIIS_OK;
 }
