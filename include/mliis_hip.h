@@ -64,8 +64,12 @@ int mliis_dwconv_bwd_filter(const float* x, const float* dy, float* dw, int N, i
 size_t mliis_conv2d_workspace_floats(int Nimg, int H, int W, int Cred, int Nout, int ksize);
 /*      tiling chosen for a fwd / bwd-data call: kernel instantiation conv_gemm_k<tm, nt, .> and split-K factor (profiling aid) */
 int mliis_conv2d_plan(int Nimg, int H, int W, int Cred, int Nout, int ksize, int* tm, int* nt, int* splits);
+/*      stats_part (nullable): the epilogue also emits the following batch norm's stage-1 statistics -- per row-block column sums
+ *      {sum v, sum v^2} (of swish(v) when stats_swish) as [*stats_nblk][2][Cout]; *stats_nblk == 0 means "not produced" (split-K
+ *      plan) and the caller must run mliis_bn_stats_partial instead.  Needs >= ceil(M/64) * 2 * Cout floats. */
 int mliis_conv2d_fwd(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int Nimg, int H, int W, int Cin,
-                     int Cout, int ksize, int dil, int accumulate, float* ws, size_t ws_floats, hipStream_t stream);
+                     int Cout, int ksize, int dil, int accumulate, float* stats_part, int stats_swish, int* stats_nblk, float* ws,
+                     size_t ws_floats, hipStream_t stream);
 /*      gradient w.r.t. input channels [ci_begin, ci_begin+Cin_out) of a conv whose weight has Cin_total input channels */
 int mliis_conv2d_bwd_data(const float* dy, int lddy, const float* w, float* dx, int lddx, int Nimg, int H, int W, int Cin_total,
                           int ci_begin, int Cin_out, int Cout, int ksize, int dil, int accumulate, float* ws, size_t ws_floats,
@@ -87,7 +91,15 @@ int mliis_bn_stats(const float* x, int ldx, long long rows, int C, int pre_swish
 int mliis_bn_apply(const float* x, int ldx, float* y, int ldy, long long rows, int C, int rows_per_img, const float* mean,
                    const float* rstd, const float* gamma, const float* beta, int pre_swish, int post_swish, const float* img_scale,
                    const float* res, int ldr, hipStream_t stream);
-/*      workspace: mliis_colreduce_workspace_floats(rows, C, 1, 2) + 2*C + 16 floats */
+/*      training fast path (3 launches -> 1): stage-1 statistics from the producer's epilogue or mliis_bn_stats_partial
+ *      (part [nblk][2][C], mliis_colreduce_workspace_floats(rows, C, 1, 2) floats), then fold + moving-average update + apply. */
+int mliis_bn_stats_partial(const float* x, int ldx, long long rows, int C, int pre_swish, float* part, size_t part_floats, int* nblk_out,
+                           hipStream_t stream);
+int mliis_bn_apply_fused(const float* x, int ldx, float* y, int ldy, long long rows, int C, int rows_per_img, const float* part, int nblk,
+                         float eps, float momentum, int unbiased_moving_var, float* mean, float* rstd, float* moving_mean,
+                         float* moving_var, const float* gamma, const float* beta, int pre_swish, int post_swish, const float* img_scale,
+                         const float* res, int ldr, hipStream_t stream);
+/*      workspace: mliis_colreduce_workspace_floats(rows, C, 1, 2) floats */
 int mliis_bn_bwd(const float* x, int ldx, const float* dy, int lddy, float* dx, int lddx, long long rows, int C, int rows_per_img,
                  const float* mean, const float* rstd, const float* gamma, const float* beta, int pre_swish, int post_swish,
                  const float* img_scale, const float* chan_scale, const float* chan_add, float* dgamma, float* dbeta, float* ws,

@@ -164,6 +164,109 @@ __global__ __launch_bounds__(256) void bn_apply_k(const float* __restrict__ x, i
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Fused "fold statistics + normalise": grid = (ceil(C/32), row chunks).  Every block folds the stage-1 partial sums of
+// ITS 32 channels (32 channels x 8 fold lanes, double precision, fixed order), keeps mean / rstd in LDS and streams its rows
+// (8 float4 lanes = one 128-byte line per row).  Blocks with blockIdx.y == 0 publish mean / rstd for the backward pass and
+// apply the moving-average update -- so no separate finalize launch exists.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kChanBlock = 32;
+
+struct BnFold {
+  const float* part;  // [nblk][2][C]
+  int nblk;
+  double inv_n;
+  float eps, one_minus_momentum, ema_var_factor;
+  float* mean;        // [C] out
+  float* rstd;        // [C] out
+  float* moving_mean; // nullable
+  float* moving_var;
+};
+
+__device__ __forceinline__ void fold32(const float* __restrict__ part, int nblk, int C, int c0, double* smd /*[2][8][32]*/, double& s,
+                                       double& ss) {
+  const int t = threadIdx.x, ch = t & 31, bl = t >> 5;
+  double a = 0.0, b = 0.0;
+  if (c0 + ch < C)
+    for (int k = bl; k < nblk; k += 8) {
+      a += (double)part[((long long)k * 2 + 0) * C + c0 + ch];
+      b += (double)part[((long long)k * 2 + 1) * C + c0 + ch];
+    }
+  smd[(0 * 8 + bl) * 32 + ch] = a;
+  smd[(1 * 8 + bl) * 32 + ch] = b;
+  __syncthreads();
+  s = ss = 0.0;
+  if (t < 32) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      s += smd[(0 * 8 + k) * 32 + t];
+      ss += smd[(1 * 8 + k) * 32 + t];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_apply_fused_k(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy,
+                                                        long long rows, int C, int rows_per_img, BnFold f,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        int pre_swish, int post_swish, const float* __restrict__ img_scale,
+                                                        const float* __restrict__ res, int ldr, int rows_per_block) {
+  __shared__ double smd[2 * 8 * 32];
+  __shared__ __attribute__((aligned(16))) float s_mean[kChanBlock], s_rstd[kChanBlock];
+  const int t = threadIdx.x;
+  const int c0 = blockIdx.x * kChanBlock;
+  double s, ss;
+  fold32(f.part, f.nblk, C, c0, smd, s, ss);
+  if (t < 32) {
+    double m = s * f.inv_n;
+    double var = ss * f.inv_n - m * m;
+    if (var < 0.0) var = 0.0;
+    const float mf = (float)m, rf = (float)(1.0 / sqrt(var + (double)f.eps));
+    s_mean[t] = mf;
+    s_rstd[t] = rf;
+    const int c = c0 + t;
+    if (blockIdx.y == 0 && c < C) {
+      f.mean[c] = mf;
+      f.rstd[c] = rf;
+      if (f.moving_mean != nullptr) {
+        const float mm = f.moving_mean[c], mv = f.moving_var[c];
+        f.moving_mean[c] = mm - (mm - mf) * f.one_minus_momentum;
+        f.moving_var[c] = mv - (mv - (float)(var * (double)f.ema_var_factor)) * f.one_minus_momentum;
+      }
+    }
+  }
+  __syncthreads();
+  const int q = t & 7, rl = t >> 3;
+  const int c = c0 + q * 4;
+  if (c >= C) return;
+  const float4 m = ld4(s_mean + q * 4), rs = ld4(s_rstd + q * 4), g = ld4(gamma + c), b = ld4(beta + c);
+  long long r1 = (long long)(blockIdx.y + 1) * rows_per_block;
+  if (r1 > rows) r1 = rows;
+  for (long long r = (long long)blockIdx.y * rows_per_block + rl; r < r1; r += 32) {
+    float4 v = ld4(x + r * ldx + c);
+    if (pre_swish) v = make_float4(swish_f(v.x), swish_f(v.y), swish_f(v.z), swish_f(v.w));
+    float4 o;
+    o.x = fmaf((v.x - m.x) * rs.x, g.x, b.x);
+    o.y = fmaf((v.y - m.y) * rs.y, g.y, b.y);
+    o.z = fmaf((v.z - m.z) * rs.z, g.z, b.z);
+    o.w = fmaf((v.w - m.w) * rs.w, g.w, b.w);
+    if (post_swish) o = make_float4(swish_f(o.x), swish_f(o.y), swish_f(o.z), swish_f(o.w));
+    if (img_scale != nullptr) o = f4scale(o, img_scale[r / rows_per_img]);
+    if (res != nullptr) o = f4add(o, ld4(res + r * ldr + c));
+    st4(y + r * ldy + c, o);
+  }
+}
+
+static inline void chan_grid(long long rows, int C, int* gx, int* gy, int* rows_per_block) {
+  *gx = ceil_div(C, kChanBlock);
+  long long want = 768 / *gx;
+  if (want < 1) want = 1;
+  long long rpb = (rows + want - 1) / want;
+  if (rpb < 64) rpb = 64;
+  rpb = (rpb + 31) / 32 * 32;
+  *rows_per_block = (int)rpb;
+  *gy = ceil_div(rows, rpb);
+}
+
 // upstream gradient seen by the BN output: dy * img_scale[n] * chan_scale[n,c] + chan_add[n,c]
 struct BnBwdCommon {
   const float* x;   // conv output saved in forward (pre-BN, pre-swish if pre_swish)
@@ -237,6 +340,50 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_k(BnBwdCommon p, long long r
     float4 xin, xhat, g;
     p.load(r, c, xin, xhat, g);
     const float4 a = ld4(c1 + c), b = ld4(c2 + c), ga = ld4(p.gamma + c), rs = ld4(p.rstd + c);
+    float4 d;
+    d.x = ga.x * rs.x * (g.x - a.x - xhat.x * b.x);
+    d.y = ga.y * rs.y * (g.y - a.y - xhat.y * b.y);
+    d.z = ga.z * rs.z * (g.z - a.z - xhat.z * b.z);
+    d.w = ga.w * rs.w * (g.w - a.w - xhat.w * b.w);
+    if (p.pre_swish) {
+      d.x *= swish_grad_f(xin.x);
+      d.y *= swish_grad_f(xin.y);
+      d.z *= swish_grad_f(xin.z);
+      d.w *= swish_grad_f(xin.w);
+    }
+    st4(dx + r * lddx + c, d);
+  }
+}
+
+// finalize (fold the two gradient sums of this block's 32 channels) + input-gradient pass in one launch
+__global__ __launch_bounds__(256) void bn_bwd_apply_fused_k(BnBwdCommon p, long long rows, const float* __restrict__ part, int nblk,
+                                                            double inv_n, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                            float* __restrict__ dx, int lddx, int rows_per_block) {
+  __shared__ double smd[2 * 8 * 32];
+  __shared__ __attribute__((aligned(16))) float s_c1[kChanBlock], s_c2[kChanBlock];
+  const int t = threadIdx.x;
+  const int c0 = blockIdx.x * kChanBlock;
+  double s, sx;
+  fold32(part, nblk, p.C, c0, smd, s, sx);
+  if (t < 32) {
+    s_c1[t] = (float)(s * inv_n);
+    s_c2[t] = (float)(sx * inv_n);
+    const int c = c0 + t;
+    if (blockIdx.y == 0 && c < p.C) {
+      dbeta[c] = (float)s;
+      dgamma[c] = (float)sx;
+    }
+  }
+  __syncthreads();
+  const int q = t & 7, rl = t >> 3;
+  const int c = c0 + q * 4;
+  if (c >= p.C) return;
+  const float4 a = ld4(s_c1 + q * 4), b = ld4(s_c2 + q * 4), ga = ld4(p.gamma + c), rs = ld4(p.rstd + c);
+  long long r1 = (long long)(blockIdx.y + 1) * rows_per_block;
+  if (r1 > rows) r1 = rows;
+  for (long long r = (long long)blockIdx.y * rows_per_block + rl; r < r1; r += 32) {
+    float4 xin, xhat, g;
+    p.load(r, c, xin, xhat, g);
     float4 d;
     d.x = ga.x * rs.x * (g.x - a.x - xhat.x * b.x);
     d.y = ga.y * rs.y * (g.y - a.y - xhat.y * b.y);
@@ -378,18 +525,53 @@ int mliis_bn_bwd(const float* x, int ldx, const float* dy, int lddy, float* dx, 
   BnBwdCommon p{x, ldx, dy, lddy, rows_per_img, C, mean, rstd, gamma, beta, pre_swish, post_swish, img_scale, chan_scale, chan_add};
   BnBwdOp op{p};
   ColGeom g;
-  // the tail of the workspace holds the two per-channel coefficient vectors
-  MLIIS_REQUIRE(ws_floats >= (size_t)2 * C + 16, MLIIS_ERR_WORKSPACE, "bn_bwd: workspace too small");
-  size_t coef_off = (ws_floats - (size_t)2 * C) & ~(size_t)3;
-  int rc = launch_colreduce(op, rows, C, 1, ws, coef_off, stream, &g, "bn_bwd");
+  int rc = launch_colreduce(op, rows, C, 1, ws, ws_floats, stream, &g, "bn_bwd");
   if (rc) return rc;
-  float* c1 = ws + coef_off;
-  float* c2 = c1 + C;
-  hipLaunchKernelGGL(bn_bwd_finalize_k, dim3(ceil_div(C, kFoldX)), dim3(kFoldX, kFoldY), 0, stream, ws, g.nblk, C, 1.0 / (double)rows, dgamma,
-                     dbeta, c1, c2);
-  MLIIS_CHECK_LAUNCH("bn_bwd_finalize");
-  hipLaunchKernelGGL(bn_bwd_apply_k, dim3(ew_grid(rows * (C / 4))), dim3(256), 0, stream, p, rows, c1, c2, dx, lddx);
-  MLIIS_CHECK_LAUNCH("bn_bwd_apply");
+  int gx, gy, rpb;
+  chan_grid(rows, C, &gx, &gy, &rpb);
+  hipLaunchKernelGGL(bn_bwd_apply_fused_k, dim3(gx, gy), dim3(256), 0, stream, p, rows, ws, g.nblk, 1.0 / (double)rows, dgamma, dbeta, dx,
+                     lddx, rpb);
+  MLIIS_CHECK_LAUNCH("bn_bwd_apply_fused");
+  return MLIIS_OK;
+}
+
+// Stage 1 only: per-block column sums {sum x, sum x^2} (of swish(x) when pre_swish) into part [nblk][2][C]; *nblk_out = nblk.
+// Used when the producer of x could not emit the statistics itself (depthwise / stem outputs).
+int mliis_bn_stats_partial(const float* x, int ldx, long long rows, int C, int pre_swish, float* part, size_t part_floats, int* nblk_out,
+                           hipStream_t stream) {
+  MLIIS_REQUIRE(x && part && nblk_out, MLIIS_ERR_ARG, "bn_stats_partial: null pointer");
+  MLIIS_REQUIRE(rows > 1 && C > 0 && (C & 3) == 0 && (ldx & 3) == 0 && ldx >= C, MLIIS_ERR_ARG, "bn_stats_partial: bad shape");
+  MLIIS_REQUIRE(aligned16(x) && aligned16(part), MLIIS_ERR_ALIGN, "bn_stats_partial: pointers must be 16-byte aligned");
+  StatsOp op{x, ldx, pre_swish};
+  ColGeom g;
+  int rc = launch_colreduce(op, rows, C, 1, part, part_floats, stream, &g, "bn_stats_partial");
+  if (rc) return rc;
+  *nblk_out = g.nblk;
+  return MLIIS_OK;
+}
+
+// Folds partial statistics (part [nblk][2][C], from mliis_bn_stats_partial or from mliis_conv2d_fwd's fused epilogue), writes
+// mean / rstd (kept for the backward pass), updates the moving averages and applies
+// y = [swish](gamma * ([swish](x) - mean) * rstd + beta) * img_scale[n] + res      -- ONE launch.
+int mliis_bn_apply_fused(const float* x, int ldx, float* y, int ldy, long long rows, int C, int rows_per_img, const float* part, int nblk,
+                         float eps, float momentum, int unbiased_moving_var, float* mean, float* rstd, float* moving_mean,
+                         float* moving_var, const float* gamma, const float* beta, int pre_swish, int post_swish, const float* img_scale,
+                         const float* res, int ldr, hipStream_t stream) {
+  MLIIS_REQUIRE(x && y && part && mean && rstd && gamma && beta, MLIIS_ERR_ARG, "bn_apply_fused: null pointer");
+  MLIIS_REQUIRE(rows > 1 && nblk > 0 && C > 0 && (C & 3) == 0 && (ldx & 3) == 0 && (ldy & 3) == 0 && ldx >= C && ldy >= C &&
+                    rows_per_img > 0 && (res == nullptr || ((ldr & 3) == 0 && ldr >= C)),
+                MLIIS_ERR_ARG, "bn_apply_fused: bad shape");
+  MLIIS_REQUIRE(aligned16(x) && aligned16(y) && aligned16(gamma) && aligned16(beta) && aligned16(res), MLIIS_ERR_ALIGN,
+                "bn_apply_fused: pointers must be 16-byte aligned");
+  MLIIS_REQUIRE((moving_mean == nullptr) == (moving_var == nullptr), MLIIS_ERR_ARG, "bn_apply_fused: moving stats must come as a pair");
+  const double n = (double)rows;
+  BnFold f{part, nblk, 1.0 / n, eps, (float)(1.0 - (double)momentum), unbiased_moving_var ? (float)(n / (n - 1.0)) : 1.0f, mean, rstd,
+           moving_mean, moving_var};
+  int gx, gy, rpb;
+  chan_grid(rows, C, &gx, &gy, &rpb);
+  hipLaunchKernelGGL(bn_apply_fused_k, dim3(gx, gy), dim3(256), 0, stream, x, ldx, y, ldy, rows, C, rows_per_img, f, gamma, beta, pre_swish,
+                     post_swish, img_scale, res, ldr, rpb);
+  MLIIS_CHECK_LAUNCH("bn_apply_fused");
   return MLIIS_OK;
 }
 

@@ -39,6 +39,8 @@ struct ConvGemmParams {
   int accumulate;
   float* partial;        // non-null => split-K partial output [z][M][Nout]
   int chunks_per_split;  // K chunks per blockIdx.z
+  float* stats_part;     // non-null => epilogue also writes per-row-block column sums [gridDim.x][2][Nout] of the
+  int stats_swish;       //             stored values (of swish(value) when stats_swish) for the following batch norm
 };
 
 template <int TM, int NT, bool B_NK>
@@ -199,6 +201,10 @@ __global__ __launch_bounds__(256) void conv_gemm_k(ConvGemmParams p) {
 
   // ---- epilogue.  C/D layout of 16x16x4: col = lane & 15, row = 4 * (lane >> 4) + reg
   const bool split = p.partial != nullptr;
+  const bool stats = (p.stats_part != nullptr) && !split;
+  float s1[NT], s2[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) s1[j] = s2[j] = 0.f;
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -217,7 +223,36 @@ __global__ __launch_bounds__(256) void conv_gemm_k(ConvGemmParams p) {
           float* dst = p.Cmat + m * p.ldc + n;
           if (p.accumulate) v += *dst;
           *dst = v;
+          if (stats) {
+            const float u = p.stats_swish ? swish_f(v) : v;
+            s1[j] += u;
+            s2[j] = fmaf(u, u, s2[j]);
+          }
         }
+      }
+    }
+  }
+  if (stats) {  // wave-uniform branch: fold rows over the 4 lane groups, then over the 4 waves through LDS (fixed order)
+    float* red = sm;  // K loop ended with a barrier: LDS is free.  layout [wave][2][BN]
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      float a = s1[j], b = s2[j];
+      a += __shfl_xor(a, 16, 64);
+      b += __shfl_xor(b, 16, 64);
+      a += __shfl_xor(a, 32, 64);
+      b += __shfl_xor(b, 32, 64);
+      if (g == 0) {
+        red[(wave * 2 + 0) * BN + j * 16 + l15] = a;
+        red[(wave * 2 + 1) * BN + j * 16 + l15] = b;
+      }
+    }
+    __syncthreads();
+    for (int idx = t; idx < 2 * BN; idx += 256) {
+      const int v = idx / BN, col = idx - v * BN;
+      const int n = n0 + col;
+      if (n < p.Nout) {
+        const float r0 = red[(0 * 2 + v) * BN + col] + red[(1 * 2 + v) * BN + col] + red[(2 * 2 + v) * BN + col] + red[(3 * 2 + v) * BN + col];
+        p.stats_part[((long long)blockIdx.x * 2 + v) * p.Nout + n] = r0;
       }
     }
   }
@@ -526,7 +561,8 @@ size_t mliis_conv2d_workspace_floats(int Nimg, int H, int W, int Cred, int Nout,
 
 // y[M, Cout] (ld = ldy) (+)= conv(x[M, Cin] (ld = ldx), w[k,k,Cin,Cout]) + bias ; stride 1, TF-SAME, dilation dil
 int mliis_conv2d_fwd(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int Nimg, int H, int W, int Cin,
-                     int Cout, int ksize, int dil, int accumulate, float* ws, size_t ws_floats, hipStream_t stream) {
+                     int Cout, int ksize, int dil, int accumulate, float* stats_part, int stats_swish, int* stats_nblk, float* ws,
+                     size_t ws_floats, hipStream_t stream) {
   int rc = conv_check("conv2d_fwd", Nimg, H, W, Cin, Cout, ksize, dil);
   if (rc) return rc;
   MLIIS_REQUIRE(x && w && y, MLIIS_ERR_ARG, "conv2d_fwd: null pointer");
@@ -535,7 +571,14 @@ int mliis_conv2d_fwd(const float* x, int ldx, const float* w, const float* bias,
   long long M = (long long)Nimg * H * W;
   GemmPlan g = plan_gemm(M, Cout, Cin, ksize * ksize, num_cus(), ws != nullptr);
   ConvGemmParams p{x, ldx, Nimg, H, W, Cin, ksize * ksize, dil, +1, w, (long long)Cin * Cout, Cout, Cout, y, ldy, bias, accumulate,
-                   nullptr, g.chunks_per_split};
+                   nullptr, g.chunks_per_split, nullptr, 0};
+  if (stats_nblk) *stats_nblk = 0;
+  if (stats_part != nullptr && g.gz == 1) {   // fused BN statistics: only when the epilogue sees final values
+    MLIIS_REQUIRE(!accumulate && stats_nblk, MLIIS_ERR_ARG, "conv2d_fwd: fused statistics need accumulate == 0 and a stats_nblk output");
+    p.stats_part = stats_part;
+    p.stats_swish = stats_swish;
+    *stats_nblk = g.gx;
+  }
   if (g.gz > 1) {
     size_t need = (size_t)g.gz * M * Cout;
     MLIIS_REQUIRE(need <= ws_floats && aligned16(ws) && (ldy & 3) == 0 && aligned16(y), MLIIS_ERR_WORKSPACE,
@@ -567,7 +610,7 @@ int mliis_conv2d_bwd_data(const float* dy, int lddy, const float* w, float* dx, 
   long long M = (long long)Nimg * H * W;
   GemmPlan g = plan_gemm(M, Cin_out, Cout, ksize * ksize, num_cus(), ws != nullptr);
   ConvGemmParams p{dy, lddy, Nimg, H, W, Cout, ksize * ksize, dil, -1, w + (long long)ci_begin * Cout, (long long)Cin_total * Cout,
-                   Cout, Cin_out, dx, lddx, nullptr, accumulate, nullptr, g.chunks_per_split};
+                   Cout, Cin_out, dx, lddx, nullptr, accumulate, nullptr, g.chunks_per_split, nullptr, 0};
   if (g.gz > 1) {
     size_t need = (size_t)g.gz * M * Cin_out;
     MLIIS_REQUIRE(need <= ws_floats && aligned16(ws) && (lddx & 3) == 0 && aligned16(dx), MLIIS_ERR_WORKSPACE,

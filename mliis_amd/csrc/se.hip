@@ -8,18 +8,19 @@
 namespace mliis {
 
 constexpr int kMaxR = 128;
+constexpr int kSeThreads = 1024;  // one workgroup per image: all 16 waves of a CU work on the tiny MLP to cut its latency
 
 // one workgroup per image
-__global__ __launch_bounds__(256) void se_mlp_fwd_k(const float* __restrict__ s, const float* __restrict__ w1,
+__global__ __launch_bounds__(kSeThreads) void se_mlp_fwd_k(const float* __restrict__ s, const float* __restrict__ w1,
                                                     const float* __restrict__ b1, const float* __restrict__ w2,
                                                     const float* __restrict__ b2, float* __restrict__ hpre,
                                                     float* __restrict__ gate, int C, int R) {
   __shared__ float sh[kMaxR];
-  __shared__ float red[256];
+  __shared__ float red[kSeThreads];
   const int n = blockIdx.x, t = threadIdx.x;
   const float* sn = s + (long long)n * C;
   // phase 1: h_j = b1[j] + sum_c s[c] * w1[c][j];  threads laid out (c-lane, j) so w1 reads are contiguous
-  const int CL = 256 / R;
+  const int CL = kSeThreads / R;
   const int j = t % R, cl = t / R;
   float part = 0.f;
   if (cl < CL)
@@ -33,7 +34,7 @@ __global__ __launch_bounds__(256) void se_mlp_fwd_k(const float* __restrict__ s,
     sh[t] = swish_f(h);
   }
   __syncthreads();
-  for (int c = t; c < C; c += 256) {
+  for (int c = t; c < C; c += kSeThreads) {
     float a = b2[c];
     for (int k = 0; k < R; ++k) a = fmaf(sh[k], w2[(long long)k * C + c], a);
     gate[(long long)n * C + c] = sigmoid_f(a);
@@ -41,7 +42,7 @@ __global__ __launch_bounds__(256) void se_mlp_fwd_k(const float* __restrict__ s,
 }
 
 // one workgroup per image: dgate -> dpre2 [C], dpre1 [R], chan_add = ds / HW [C]
-__global__ __launch_bounds__(256) void se_mlp_bwd_k(const float* __restrict__ dgate, const float* __restrict__ gate,
+__global__ __launch_bounds__(kSeThreads) void se_mlp_bwd_k(const float* __restrict__ dgate, const float* __restrict__ gate,
                                                     const float* __restrict__ hpre, const float* __restrict__ w1,
                                                     const float* __restrict__ w2, float* __restrict__ dpre2,
                                                     float* __restrict__ dpre1, float* __restrict__ chan_add, int C, int R,
@@ -49,12 +50,12 @@ __global__ __launch_bounds__(256) void se_mlp_bwd_k(const float* __restrict__ dg
   __shared__ float sd1[kMaxR];
   const int n = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
   float* d2 = dpre2 + (long long)n * C;
-  for (int c = t; c < C; c += 256) {
+  for (int c = t; c < C; c += kSeThreads) {
     const float g = gate[(long long)n * C + c];
     d2[c] = dgate[(long long)n * C + c] * g * (1.f - g);
   }
   __syncthreads();  // d2 written by this block, read below (same workgroup: barrier suffices)
-  for (int jj = wave; jj < R; jj += 4) {
+  for (int jj = wave; jj < R; jj += kSeThreads / 64) {
     float p = 0.f;
     for (int c = lane; c < C; c += 64) p = fmaf(d2[c], w2[(long long)jj * C + c], p);
     p = wave_sum(p);
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(256) void se_mlp_bwd_k(const float* __restrict__ dg
     }
   }
   __syncthreads();
-  for (int c = t; c < C; c += 256) {
+  for (int c = t; c < C; c += kSeThreads) {
     float a = 0.f;
     for (int k = 0; k < R; ++k) a = fmaf(sd1[k], w1[(long long)c * R + k], a);
     chan_add[(long long)n * C + c] = a * inv_hw;
@@ -131,7 +132,7 @@ int mliis_se_mlp_fwd(const float* s, const float* w1, const float* b1, const flo
                      int N, int C, int R, hipStream_t stream) {
   MLIIS_REQUIRE(s && w1 && b1 && w2 && b2 && hpre && gate, MLIIS_ERR_ARG, "se_mlp_fwd: null pointer");
   MLIIS_REQUIRE(N > 0 && C > 0 && R > 0 && R <= kMaxR, MLIIS_ERR_ARG, "se_mlp_fwd: bad shape (R <= %d)", kMaxR);
-  hipLaunchKernelGGL(se_mlp_fwd_k, dim3(N), dim3(256), 0, stream, s, w1, b1, w2, b2, hpre, gate, C, R);
+  hipLaunchKernelGGL(se_mlp_fwd_k, dim3(N), dim3(kSeThreads), 0, stream, s, w1, b1, w2, b2, hpre, gate, C, R);
   MLIIS_CHECK_LAUNCH("se_mlp_fwd");
   return MLIIS_OK;
 }
@@ -144,7 +145,7 @@ int mliis_se_mlp_bwd(const float* dgate, const float* gate, const float* s, cons
   MLIIS_REQUIRE(dgate && gate && s && hpre && w1 && w2 && dpre1 && dpre2 && chan_add && dw1 && db1 && dw2 && db2, MLIIS_ERR_ARG,
                 "se_mlp_bwd: null pointer");
   MLIIS_REQUIRE(N > 0 && C > 0 && R > 0 && R <= kMaxR && HW > 0, MLIIS_ERR_ARG, "se_mlp_bwd: bad shape");
-  hipLaunchKernelGGL(se_mlp_bwd_k, dim3(N), dim3(256), 0, stream, dgate, gate, hpre, w1, w2, dpre2, dpre1, chan_add, C, R,
+  hipLaunchKernelGGL(se_mlp_bwd_k, dim3(N), dim3(kSeThreads), 0, stream, dgate, gate, hpre, w1, w2, dpre2, dpre1, chan_add, C, R,
                      1.0f / (float)HW);
   MLIIS_CHECK_LAUNCH("se_mlp_bwd");
   int total = 2 * C * R + C + R;

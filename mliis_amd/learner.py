@@ -90,6 +90,16 @@ class _Plan:
         self.logits, self.dlogits, self.pred = buf(N, H, H, 2), buf(N, H, H, 2), buf(N, H, H, 2)
         self.drop_mask = buf(N, hd, hd, a.aspp_dimension) if L.final_layer_dropout_rate > 0 else None
         self.loss_out = torch.zeros(4, dtype=torch.float32, device=dev)
+        # stage-1 BN statistics handed from a producer (GEMM epilogue / stats kernel) to the fused fold+apply kernel
+        need = 0
+        for b in a.blocks:
+            if b.executed:
+                for rows, c in ((N * b.h_in ** 2, b.cexp), (N * b.h_out ** 2, b.cexp), (N * b.h_out ** 2, b.cout)):
+                    need = max(need, -(-rows // 64) * 2 * c, ops.bn_stats_partial_floats(rows, c))
+        for m in a.rsd:
+            need = max(need, -(-(N * m.h * m.h) // 64) * 2 * m.c_out, ops.bn_stats_partial_floats(N * m.h * m.h, m.c_out))
+        need = max(need, ops.bn_stats_partial_floats(N * hs * hs, a.stem_out))
+        self.stats_part = buf(need + 64)
         self.graph = None           # captured hipGraphExec for the training step
         self.steps_run = 0
 
@@ -275,14 +285,25 @@ class Learner:
         A, a, ws, N = self.arena, self.arch, self.ws, P.N
         w, mv = A.w, A.mv
 
-        def bn(xin, st, prefix, y, pre=False, post=False, img_scale=None, res=None, fused=False):
+        def bn(xin, st, prefix, y, pre=False, post=False, img_scale=None, res=None, fused=False, nblk=0):
+            """nblk > 0: the producing conv already left the stage-1 statistics in P.stats_part."""
             if training:
-                ops.bn_stats(xin, pre, moving=(mv[prefix + "/moving_mean"], mv[prefix + "/moving_variance"]), unbiased_moving_var=fused,
-                             mean=st[0], rstd=st[1], ws=ws)
-            else:
-                st[0].copy_(mv[prefix + "/moving_mean"])
-                torch.rsqrt(mv[prefix + "/moving_variance"] + spec.BN_EPS, out=st[1])
+                if nblk == 0:
+                    nblk = ops.bn_stats_partial(xin, pre, P.stats_part)
+                return ops.bn_apply_fused(xin, P.stats_part, nblk, st[0], st[1], w[prefix + "/gamma"], w[prefix + "/beta"],
+                                          moving=(mv[prefix + "/moving_mean"], mv[prefix + "/moving_variance"]), unbiased_moving_var=fused,
+                                          pre_swish=pre, post_swish=post, img_scale=img_scale, res=res, out=y)
+            st[0].copy_(mv[prefix + "/moving_mean"])
+            torch.rsqrt(mv[prefix + "/moving_variance"] + spec.BN_EPS, out=st[1])
             return ops.bn_apply(xin, st[0], st[1], w[prefix + "/gamma"], w[prefix + "/beta"], pre, post, img_scale, res, out=y)
+
+        def conv(xin, wname, bname, dil, out, swish_stats):
+            """dense conv; in training the epilogue also emits the following BN's statistics (returns their block count)."""
+            if training:
+                return ops.conv2d_fwd(xin, w[wname], w[bname] if bname else None, dil, out=out, ws=ws, stats_part=P.stats_part,
+                                      stats_swish=swish_stats)[1]
+            ops.conv2d_fwd(xin, w[wname], w[bname] if bname else None, dil, out=out, ws=ws)
+            return 0
 
         ops.stem_conv_fwd(x, w[self.n_stem[0]], idx, out=P.z_stem)
         cur = bn(P.z_stem, P.st_stem, self.n_stem[1], P.a_stem, post=True)
@@ -291,8 +312,8 @@ class Learner:
             B["x_in"] = cur
             t = cur
             if b.expand != 1:
-                ops.conv2d_fwd(t, w[nm["w_exp"]], out=B["z0"], ws=ws)
-                t = bn(B["z0"], B["st0"], nm["bn0"], B["a0"], post=True)
+                nb = conv(t, nm["w_exp"], None, 1, B["z0"], False)
+                t = bn(B["z0"], B["st0"], nm["bn0"], B["a0"], post=True, nblk=nb)
             ops.dwconv_fwd(t, w[nm["w_dw"]], b.stride, out=B["z1"])
             bn(B["z1"], B["st1"], nm["bn1"], B["a1"], post=True)
             hw = b.h_out * b.h_out
@@ -300,10 +321,10 @@ class Learner:
             se = nm["se"]
             ops.se_mlp_fwd(B["s"], w[se[0]], w[se[1]], w[se[2]], w[se[3]], B["hpre"], B["gate"])
             ops.chan_affine(B["a1"], S=B["gate"], out=B["a2"])
-            ops.conv2d_fwd(B["a2"], w[nm["w_proj"]], out=B["z2"], ws=ws)
+            nb = conv(B["a2"], nm["w_proj"], None, 1, B["z2"], False)
             use_dc = training and self.drop_connect and b.skip and b.drop_rate > 0
             B["use_dc"] = use_dc
-            cur = bn(B["z2"], B["st2"], nm["bn2"], B["out"], img_scale=B["dc"] if use_dc else None, res=B["x_in"] if b.skip else None)
+            cur = bn(B["z2"], B["st2"], nm["bn2"], B["out"], img_scale=B["dc"] if use_dc else None, res=B["x_in"] if b.skip else None, nblk=nb)
         ends = {r: P.blocks[bi]["out"] for r, bi in a.reductions.items() if bi < len(P.blocks)}
         dec = ends[4]
         for m, D, nm, r in zip(a.rsd, P.rsd, self.n_rsd, sorted([x.scope_index + 1 for x in a.rsd], reverse=True)):
@@ -317,14 +338,14 @@ class Learner:
             ops.chan_affine(skip, out=cat[..., m.c_deep:])
             pyr = D["pyr"]
             (k0, b0, n0), (k1, b1, n1), (kf, bf, nf) = nm
-            ops.conv2d_fwd(cat, w[k0], w[b0], 1, out=D["z0"], ws=ws)
-            bn(D["z0"], D["st0"], n0, pyr[..., :m.c_out], pre=True, fused=True)
-            ops.conv2d_fwd(cat, w[k1], w[b1], 2, out=D["z1"], ws=ws)
-            bn(D["z1"], D["st1"], n1, pyr[..., m.c_out:2 * m.c_out], pre=True, fused=True)
+            nb = conv(cat, k0, b0, 1, D["z0"], True)
+            bn(D["z0"], D["st0"], n0, pyr[..., :m.c_out], pre=True, fused=True, nblk=nb)
+            nb = conv(cat, k1, b1, 2, D["z1"], True)
+            bn(D["z1"], D["st1"], n1, pyr[..., m.c_out:2 * m.c_out], pre=True, fused=True, nblk=nb)
             ops.colsum(cat, None, nseg=N, scale=1.0 / (m.h * m.h), out=D["pool"], ws=ws)
             ops.chan_affine(None, A=D["pool"], out=pyr[..., 2 * m.c_out:])
-            ops.conv2d_fwd(pyr, w[kf], w[bf], 1, out=D["zf"], ws=ws)
-            dec = bn(D["zf"], D["stf"], nf, D["out"], pre=True, res=up, fused=True)
+            nb = conv(pyr, kf, bf, 1, D["zf"], True)
+            dec = bn(D["zf"], D["stf"], nf, D["out"], pre=True, res=up, fused=True, nblk=nb)
         mask = P.drop_mask if (training and P.drop_mask is not None) else None
         P.dec_in = dec
         ops.final_conv_fwd(dec, w[self.n_final[0]], w[self.n_final[1]], mask, out=P.small)

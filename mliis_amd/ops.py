@@ -164,8 +164,10 @@ def dwconv_bwd_filter(x, dy, k, stride, out=None, ws: Optional[Workspace] = None
 
 
 # ------------------------------------------------------------------------------------------------ dense conv
-def conv2d_fwd(x, w, bias=None, dil=1, out=None, accumulate=False, ws: Optional[Workspace] = None, nhw=None):
-    """x: [N,H,W,>=Cin] view (channel slice allowed); w: [k,k,Cin,Cout]."""
+def conv2d_fwd(x, w, bias=None, dil=1, out=None, accumulate=False, ws: Optional[Workspace] = None, nhw=None, stats_part=None,
+               stats_swish=False):
+    """x: [N,H,W,>=Cin] view (channel slice allowed); w: [k,k,Cin,Cout].  With stats_part (a float buffer) the epilogue also emits
+    the next batch norm's stage-1 statistics and the function returns (out, nblk); nblk == 0 means they were not produced."""
     N, H, W = nhw if nhw is not None else x.shape[:3]
     k, _, Cin, Cout = w.shape
     rows, cx, ldx = rows_ld(x)
@@ -180,8 +182,14 @@ def conv2d_fwd(x, w, bias=None, dil=1, out=None, accumulate=False, ws: Optional[
         tm, nt, sp = conv2d_plan(N, H, W, Cin, Cout, k)
         meta = dict(kernel="conv_gemm_k<%d,%d,false>" % (tm, nt), splits=sp, flops=2.0 * N * H * W * k * k * Cin * Cout,
                     shape=(N, H, W, Cin, Cout, k, dil))
+    nblk = C.c_int(0)
+    if stats_part is not None and stats_part.numel() < (-(-N * H * W // 64)) * 2 * Cout:
+        raise MliisError("conv2d_fwd: stats_part too small")
     _timed("conv2d_fwd", meta, lambda: lib.call("mliis_conv2d_fwd", _ptr(x), ldx, _ptr(w), _ptr(bias), _ptr(out), ldy, N, H, W, Cin, Cout, k,
-                                                dil, int(accumulate), _ptr(buf), buf.numel(), _stream()))
+                                                dil, int(accumulate), _ptr(stats_part), int(stats_swish), C.byref(nblk), _ptr(buf),
+                                                buf.numel(), _stream()))
+    if stats_part is not None:
+        return out, nblk.value
     return out
 
 
@@ -233,6 +241,32 @@ def bn_stats(x, pre_swish=False, moving=None, unbiased_moving_var=False, mean=No
     return mean, rstd
 
 
+def bn_stats_partial(x, pre_swish, part):
+    """Stage-1 statistics of x into `part` ([nblk][2][C]); returns nblk."""
+    rows, C_, ldx = rows_ld(x)
+    nblk = C.c_int(0)
+    lib.call("mliis_bn_stats_partial", _ptr(x), ldx, rows, C_, int(pre_swish), _ptr(part), part.numel(), C.byref(nblk), _stream())
+    return nblk.value
+
+
+def bn_stats_partial_floats(rows, C_):
+    return lib.size("mliis_colreduce_workspace_floats", rows, C_, 1, 2)
+
+
+def bn_apply_fused(x, part, nblk, mean, rstd, gamma, beta, moving=None, unbiased_moving_var=False, pre_swish=False, post_swish=False,
+                   img_scale=None, res=None, out=None, rows_per_img=None, eps=BN_EPS, momentum=BN_MOMENTUM):
+    rows, C_, ldx = rows_ld(x)
+    out = torch.empty(x.shape, dtype=torch.float32, device=x.device) if out is None else out
+    _, _, ldy = rows_ld(out)
+    rpi = rows_per_img or (rows // x.shape[0])
+    ldr = rows_ld(res)[2] if res is not None else 0
+    mm, mv = (None, None) if moving is None else moving
+    lib.call("mliis_bn_apply_fused", _ptr(x), ldx, _ptr(out), ldy, rows, C_, rpi, _ptr(part), int(nblk), eps, momentum,
+             int(unbiased_moving_var), _ptr(mean), _ptr(rstd), _ptr(mm), _ptr(mv), _ptr(gamma), _ptr(beta), int(pre_swish), int(post_swish),
+             _ptr(img_scale), _ptr(res), ldr, _stream())
+    return out
+
+
 def bn_apply(x, mean, rstd, gamma, beta, pre_swish=False, post_swish=False, img_scale=None, res=None, out=None, rows_per_img=None):
     rows, C_, ldx = rows_ld(x)
     out = torch.empty(x.shape, dtype=torch.float32, device=x.device) if out is None else out
@@ -254,7 +288,7 @@ def bn_bwd(x, dy, mean, rstd, gamma, beta, pre_swish=False, post_swish=False, im
     dbeta = torch.empty(C_, dtype=torch.float32, device=x.device) if dbeta is None else dbeta
     rpi = rows_per_img or (rows // x.shape[0])
     ws = ws or default_ws()
-    buf = ws.get(lib.size("mliis_colreduce_workspace_floats", rows, C_, 1, 2) + 2 * C_ + 16)
+    buf = ws.get(lib.size("mliis_colreduce_workspace_floats", rows, C_, 1, 2))
     lib.call("mliis_bn_bwd", _ptr(x), ldx, _ptr(dy), lddy, _ptr(dx), lddx, rows, C_, rpi, _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta),
              int(pre_swish), int(post_swish), _ptr(img_scale), _ptr(chan_scale), _ptr(chan_add), _ptr(dgamma), _ptr(dbeta), _ptr(buf),
              buf.numel(), _stream())

@@ -321,3 +321,45 @@ def test_errors_are_loud():
         ops.dwconv_fwd(torch.zeros(1, 4, 4, 8, device=d), torch.zeros(7, 7, 8, 1, device=d), 1)  # k = 7 unsupported
     with pytest.raises(MliisError):
         ops.dwconv_fwd(torch.zeros(1, 4, 4, 8), torch.zeros(3, 3, 8, 1), 1)  # CPU tensors: no fallback
+
+
+# ------------------------------------------------------------------------------------------------ fused BN fast path
+@pytest.mark.parametrize("k,dil,H,W,Cin,Cout,N,swish", [(1, 1, 14, 14, 40, 240, 2, False), (3, 2, 20, 20, 136, 112, 2, True), (1, 1, 56, 56, 24, 144, 4, False),
+                                                        (3, 1, 9, 11, 72, 112, 1, True), (1, 1, 7, 7, 96, 24, 3, False)])
+def test_conv_epilogue_statistics_and_fused_bn(k, dil, H, W, Cin, Cout, N, swish):
+    """conv2d_fwd's fused stage-1 statistics + bn_apply_fused == separate bn_stats + bn_apply == float64 oracle."""
+    from mliis_amd import ops
+    d = dev()
+    x = rnd(N, H, W, Cin, seed=50)
+    w = rnd(k, k, Cin, Cout, seed=51, scale=1.0 / math.sqrt(k * k * Cin))
+    b = rnd(Cout, seed=52)
+    gamma, beta = rnd(Cout, seed=53) * 0.3 + 1, rnd(Cout, seed=54)
+    res = rnd(N, H, W, Cout, seed=55)
+    z = nhwc(R.conv2d_same(nchw(x), w, 1, dil, bias=b))
+    u = R.swish(z) if swish else z
+    mean, var = u.mean(dim=(0, 1, 2)), u.var(dim=(0, 1, 2), unbiased=False)
+    y = (u - mean) * torch.rsqrt(var + 1e-3) * gamma + beta
+    y = (y if swish else R.swish(y)) + res
+    part = torch.empty(1 << 18, device=d)
+    zg, nblk = ops.conv2d_fwd(f32(x, d), f32(w, d), f32(b, d), dil, stats_part=part, stats_swish=swish)
+    close(zg, z, 2e-5, "conv out")
+    if nblk == 0:   # split-K plan: the caller falls back to the stats kernel
+        nblk = ops.bn_stats_partial(zg, swish, part)
+    assert nblk > 0
+    n = N * H * W
+    sums = part[: nblk * 2 * Cout].view(nblk, 2, Cout).double().sum(0).cpu()
+    close(sums[0] / n, mean, 1e-5, "epilogue mean")
+    close(sums[1] / n, var + mean ** 2, 1e-5, "epilogue E[x^2]")
+    mm, mv = torch.zeros(Cout, device=d), torch.ones(Cout, device=d)
+    m_o, r_o = torch.empty(Cout, device=d), torch.empty(Cout, device=d)
+    yg = ops.bn_apply_fused(zg, part, nblk, m_o, r_o, f32(gamma, d), f32(beta, d), moving=(mm, mv), unbiased_moving_var=swish, pre_swish=swish,
+                            post_swish=not swish, res=f32(res, d))
+    close(yg, y, 3e-5, "fused bn apply")
+    close(m_o, mean, 1e-5, "mean out")
+    close(r_o, torch.rsqrt(var + 1e-3), 1e-5, "rstd out")
+    close(mm, 0.01 * mean, 1e-5, "moving mean")
+    close(mv, 0.99 + 0.01 * var * (n / (n - 1.0) if swish else 1.0), 1e-5, "moving var")
+    # stats kernel path gives the same normalisation
+    nb2 = ops.bn_stats_partial(zg, swish, part)
+    y2 = ops.bn_apply_fused(zg, part, nb2, m_o, r_o, f32(gamma, d), f32(beta, d), pre_swish=swish, post_swish=not swish, res=f32(res, d))
+    close(y2, y, 3e-5, "fused bn apply (stats kernel)")
