@@ -52,7 +52,10 @@ __global__ __launch_bounds__(256) void conv_gemm_k(ConvGemmParams p) {
   constexpr int A_PER_THREAD = 2 * TM;                    // float4 per thread per chunk
   constexpr int B_TOTAL = B_NK ? BN * 8 : BK * (BN / 4);  // float4 per chunk
   constexpr int B_PER_THREAD = (B_TOTAL + 255) / 256;
-  __shared__ __attribute__((aligned(16))) float sm[A_FLOATS + B_FLOATS];
+  constexpr int LDS_STAGE = BN + 4;                        // epilogue staging row stride (floats)
+  constexpr int STAGE_FLOATS = 4 * 16 * LDS_STAGE;         // 4 waves x 16 rows
+  constexpr int SM_FLOATS = (A_FLOATS + B_FLOATS) > STAGE_FLOATS ? (A_FLOATS + B_FLOATS) : STAGE_FLOATS;
+  __shared__ __attribute__((aligned(16))) float sm[SM_FLOATS];
   float* smA = sm;
   float* smB = sm + A_FLOATS;
 
@@ -199,37 +202,72 @@ __global__ __launch_bounds__(256) void conv_gemm_k(ConvGemmParams p) {
     __syncthreads();
   }
 
-  // ---- epilogue.  C/D layout of 16x16x4: col = lane & 15, row = 4 * (lane >> 4) + reg
+  // ---- epilogue.  C/D layout of 16x16x4: col = lane & 15, row = 4 * (lane >> 4) + reg.  Final values go through a per-wave
+  // LDS staging tile so that global stores are whole rows (BN*4 contiguous bytes, float4 per lane) instead of 64-byte pieces.
   const bool split = p.partial != nullptr;
   const bool stats = (p.stats_part != nullptr) && !split;
   float s1[NT], s2[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) s1[j] = s2[j] = 0.f;
+  if (split) {
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const long long m = m0 + wave * 16 * TM + i * 16 + g * 4 + r;
-      if (m >= M) continue;
+      for (int r = 0; r < 4; ++r) {
+        const long long m = m0 + wave * 16 * TM + i * 16 + g * 4 + r;
+        if (m >= M) continue;
 #pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const int n = n0 + j * 16 + l15;
-        if (n >= p.Nout) continue;
-        float v = acc[i][j][r];
-        if (split) {
-          p.partial[((long long)blockIdx.z * M + m) * p.Nout + n] = v;
-        } else {
-          if (p.bias != nullptr) v += p.bias[n];
+        for (int j = 0; j < NT; ++j) {
+          const int n = n0 + j * 16 + l15;
+          if (n < p.Nout) p.partial[((long long)blockIdx.z * M + m) * p.Nout + n] = acc[i][j][r];
+        }
+      }
+  } else {
+    float* stage = sm + wave * 16 * LDS_STAGE;
+    float bj[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int n = n0 + j * 16 + l15;
+      bj[j] = (p.bias != nullptr && n < p.Nout) ? p.bias[n] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const long long mbase = m0 + wave * 16 * TM + i * 16;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) stage[(g * 4 + r) * LDS_STAGE + j * 16 + l15] = acc[i][j][r] + bj[j];
+      __syncthreads();
+#pragma unroll
+      for (int it = 0; it < NT; ++it) {
+        const int idx = it * 64 + lane;
+        const int row = idx / (BN / 4), q = idx - row * (BN / 4);
+        const long long m = mbase + row;
+        const int n = n0 + q * 4;
+        if (m < M && n < p.Nout) {
+          float4 v = ld4(stage + row * LDS_STAGE + q * 4);
           float* dst = p.Cmat + m * p.ldc + n;
-          if (p.accumulate) v += *dst;
-          *dst = v;
-          if (stats) {
+          if (p.accumulate) v = f4add(v, ld4(dst));
+          st4(dst, v);
+        }
+      }
+      __syncthreads();
+    }
+    if (stats) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const long long m = m0 + wave * 16 * TM + i * 16 + g * 4 + r;
+          if (m >= M) continue;
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            const float v = acc[i][j][r] + bj[j];
             const float u = p.stats_swish ? swish_f(v) : v;
             s1[j] += u;
             s2[j] = fmaf(u, u, s2[j]);
           }
         }
-      }
     }
   }
   if (stats) {  // wave-uniform branch: fold rows over the 4 lane groups, then over the 4 waves through LDS (fixed order)
@@ -566,8 +604,9 @@ int mliis_conv2d_fwd(const float* x, int ldx, const float* w, const float* bias,
   int rc = conv_check("conv2d_fwd", Nimg, H, W, Cin, Cout, ksize, dil);
   if (rc) return rc;
   MLIIS_REQUIRE(x && w && y, MLIIS_ERR_ARG, "conv2d_fwd: null pointer");
-  MLIIS_REQUIRE((ldx & 3) == 0 && ldx >= Cin && ldy >= Cout, MLIIS_ERR_ARG, "conv2d_fwd: bad leading dimensions");
-  MLIIS_REQUIRE(aligned16(x) && aligned16(w) && aligned16(bias), MLIIS_ERR_ALIGN, "conv2d_fwd: pointers must be 16-byte aligned");
+  MLIIS_REQUIRE((ldx & 3) == 0 && ldx >= Cin && (ldy & 3) == 0 && ldy >= Cout, MLIIS_ERR_ARG, "conv2d_fwd: bad leading dimensions");
+  MLIIS_REQUIRE(aligned16(x) && aligned16(w) && aligned16(bias) && aligned16(y), MLIIS_ERR_ALIGN,
+                "conv2d_fwd: pointers must be 16-byte aligned");
   long long M = (long long)Nimg * H * W;
   GemmPlan g = plan_gemm(M, Cout, Cin, ksize * ksize, num_cus(), ws != nullptr);
   ConvGemmParams p{x, ldx, Nimg, H, W, Cin, ksize * ksize, dil, +1, w, (long long)Cin * Cout, Cout, Cout, y, ldy, bias, accumulate,
@@ -605,8 +644,9 @@ int mliis_conv2d_bwd_data(const float* dy, int lddy, const float* w, float* dx, 
   if (rc) return rc;
   MLIIS_REQUIRE(dy && w && dx, MLIIS_ERR_ARG, "conv2d_bwd_data: null pointer");
   MLIIS_REQUIRE(ci_begin >= 0 && ci_begin + Cin_out <= Cin_total, MLIIS_ERR_ARG, "conv2d_bwd_data: channel window out of range");
-  MLIIS_REQUIRE((lddy & 3) == 0 && lddy >= Cout && lddx >= Cin_out, MLIIS_ERR_ARG, "conv2d_bwd_data: bad leading dimensions");
-  MLIIS_REQUIRE(aligned16(dy) && aligned16(w), MLIIS_ERR_ALIGN, "conv2d_bwd_data: pointers must be 16-byte aligned");
+  MLIIS_REQUIRE((lddy & 3) == 0 && lddy >= Cout && (lddx & 3) == 0 && lddx >= Cin_out && (ci_begin & 3) == 0, MLIIS_ERR_ARG,
+                "conv2d_bwd_data: bad leading dimensions");
+  MLIIS_REQUIRE(aligned16(dy) && aligned16(w) && aligned16(dx), MLIIS_ERR_ALIGN, "conv2d_bwd_data: pointers must be 16-byte aligned");
   long long M = (long long)Nimg * H * W;
   GemmPlan g = plan_gemm(M, Cin_out, Cout, ksize * ksize, num_cus(), ws != nullptr);
   ConvGemmParams p{dy, lddy, Nimg, H, W, Cout, ksize * ksize, dil, -1, w + (long long)ci_begin * Cout, (long long)Cin_total * Cout,
