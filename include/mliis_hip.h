@@ -67,9 +67,14 @@ int mliis_conv2d_plan(int Nimg, int H, int W, int Cred, int Nout, int ksize, int
 /*      stats_part (nullable): the epilogue also emits the following batch norm's stage-1 statistics -- per row-block column sums
  *      {sum v, sum v^2} (of swish(v) when stats_swish) as [*stats_nblk][2][Cout]; *stats_nblk == 0 means "not produced" (split-K
  *      plan) and the caller must run mliis_bn_stats_partial instead.  Needs >= ceil(M/64) * 2 * Cout floats. */
-int mliis_conv2d_fwd(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int Nimg, int H, int W, int Cin,
-                     int Cout, int ksize, int dil, int accumulate, float* stats_part, int stats_swish, int* stats_nblk, float* ws,
-                     size_t ws_floats, hipStream_t stream);
+/*      wt (nullable): K-contiguous shadow copy of w, layout [k,k,Cout,Cin] (mliis_transpose_weights); when given, the forward
+ *      GEMM reads it instead of w (same result, faster B-operand path). */
+int mliis_conv2d_fwd(const float* x, int ldx, const float* w, const float* wt, const float* bias, float* y, int ldy, int Nimg, int H,
+                     int W, int Cin, int Cout, int ksize, int dil, int accumulate, float* stats_part, int stats_swish, int* stats_nblk,
+                     float* ws, size_t ws_floats, hipStream_t stream);
+/*      batched HWIO -> HWOI copy of dense-conv weights between two arenas of identical layout; desc = device int32
+ *      [ndesc][4] {offset, taps, Cin, Cout} */
+int mliis_transpose_weights(const float* src, float* dst, const int* desc, int ndesc, hipStream_t stream);
 /*      gradient w.r.t. input channels [ci_begin, ci_begin+Cin_out) of a conv whose weight has Cin_total input channels */
 int mliis_conv2d_bwd_data(const float* dy, int lddy, const float* w, float* dx, int lddx, int Nimg, int H, int W, int Cin_total,
                           int ci_begin, int Cin_out, int Cout, int ksize, int dil, int accumulate, float* ws, size_t ws_floats,

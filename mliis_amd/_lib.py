@@ -30,7 +30,8 @@ SIGNATURES = {
     "mliis_dwconv_bwd_filter": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _sz, _p]),
     "mliis_conv2d_workspace_floats": (_sz, [_i, _i, _i, _i, _i, _i]),
     "mliis_conv2d_plan": (_i, [_i, _i, _i, _i, _i, _i, _p, _p, _p]),
-    "mliis_conv2d_fwd": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _p, _sz, _p]),
+    "mliis_conv2d_fwd": (_i, [_p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _p, _sz, _p]),
+    "mliis_transpose_weights": (_i, [_p, _p, _p, _i, _p]),
     "mliis_conv2d_bwd_data": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _p]),
     "mliis_conv2d_bwd_filter_workspace_floats": (_sz, [_i, _i, _i, _i, _i, _i]),
     "mliis_conv2d_bwd_filter": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _p]),

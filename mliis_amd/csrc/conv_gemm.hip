@@ -11,12 +11,17 @@
 //     A tile in LDS as [kq = k/4][row ^ kq][4] : 16-byte fragments, conflict-free ds_write_b128 (8 lanes = 8 rows^kq) and
 //     conflict-free ds_read_b128 (a 16-lane read group covers 16 distinct rows mod 16).  Inside every 16-wide K group the K
 //     order is permuted identically for A and B (lane group g owns k = 4g..4g+3), so one b128 read feeds 4 MFMAs.
-//     B tile: NN -> [k][BN+4] read with ds_read_b32 (two rows 4 apart land on disjoint bank halves);
-//             NK -> same fragment layout as A.
+//     B tile: NK (weights K-contiguous: backward-data on the HWIO buffer, forward on the HWOI shadow copy that
+//             mliis_transpose_weights refreshes once per step) -> same 16-byte fragment layout as A (one b128 read per 4 MFMAs);
+//             NN (forward straight from HWIO, kept for callers without a shadow copy) -> [k][BN+4] read with ds_read_b32.
+//   Planner: 64-row blocks (TM = 1) so two workgroups share a CU and hide each other's LDS/barrier latency (measured: rsd2
+//   fuse bwd-data 54 -> 85 TF vs one 128-row block per CU); a K chunk whose second 16-wide group is pure padding skips it.
 //   bwd-filter : block tile (64*TMF ci) x (16*NT co) for one tap; streams 32 pixels per step; A = X^T, B = dY, both
 //     read k-major with ds_read_b32 (row stride == 16 mod 32 banks).
 // Global loads are float4 along C (128-byte spans per 8 lanes), software-pipelined through registers (load chunk i+1
 // while chunk i is multiplied).
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace mliis {
@@ -159,8 +164,12 @@ __global__ __launch_bounds__(256) void conv_gemm_k(ConvGemmParams p) {
     store_chunk();
     __syncthreads();
     if (it + 1 < it1) load_chunk(it + 1);
+    // the second 16-wide k group of a chunk is all zero padding when the channel count ends inside the first one
+    const int c0_cur = (it - (it / cpc) * cpc) * BK;
+    const int qmax = (c0_cur + 16 < p.C) ? 2 : 1;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
+      if (q >= qmax) continue;
       const int kq = q * 4 + g;
       float4 av[TM];
 #pragma unroll
@@ -445,6 +454,39 @@ __global__ __launch_bounds__(256) void conv_filter_grad_k(FilterGradParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ weight shadow (HWIO -> HWOI)
+// dst[off + tap*Ci*Co + co*Ci + ci] = src[off + tap*Ci*Co + ci*Co + co] for every descriptor (off, taps, Ci, Co): one launch per
+// inner step keeps a K-contiguous copy of all dense-conv weights so the FORWARD GEMM can use the same b128-fragment B path as
+// backward-data.  32x32 LDS tiles: coalesced reads along co, coalesced writes along ci.
+__global__ __launch_bounds__(256) void transpose_weights_k(const float* __restrict__ src, float* __restrict__ dst,
+                                                           const int* __restrict__ desc) {
+  __shared__ float tile[32][33];
+  const int d = blockIdx.y;
+  const int off = desc[4 * d + 0], taps = desc[4 * d + 1], Ci = desc[4 * d + 2], Co = desc[4 * d + 3];
+  const int tci = (Ci + 31) / 32, tco = (Co + 31) / 32;
+  const int ntiles = taps * tci * tco;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int tIdx = blockIdx.x; tIdx < ntiles; tIdx += gridDim.x) {
+    const int tap = tIdx / (tci * tco);
+    const int rem = tIdx - tap * tci * tco;
+    const int ci0 = (rem / tco) * 32, co0 = (rem % tco) * 32;
+    const float* s0 = src + off + (long long)tap * Ci * Co;
+    float* d0 = dst + off + (long long)tap * Ci * Co;
+#pragma unroll
+    for (int r = ty; r < 32; r += 8) {
+      const int ci = ci0 + r, co = co0 + tx;
+      tile[r][tx] = (ci < Ci && co < Co) ? s0[(long long)ci * Co + co] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = ty; r < 32; r += 8) {
+      const int co = co0 + r, ci = ci0 + tx;
+      if (co < Co && ci < Ci) d0[(long long)co * Ci + ci] = tile[tx][r];
+    }
+    __syncthreads();
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ host-side planning
 struct GemmPlan {
   int tm, nt, gx, gy, gz, chunks_per_split;
@@ -461,15 +503,22 @@ static inline GemmPlan plan_gemm(long long M, int Nout, int C, int ntaps, int nu
   GemmPlan g;
   g.nt = pick_nt(Nout);
   g.gy = (Nout + g.nt * 16 - 1) / (g.nt * 16);
-  long long b128 = (M + 127) / 128 * g.gy;
-  g.tm = (b128 >= num_cus * 3 / 4) ? 2 : 1;
+  g.tm = 1;  // measured: two co-resident 64-row blocks per CU hide LDS/barrier latency better than one 128-row block
+  {  // tuning override (experiments only): MLIIS_GEMM_TM = 1 | 2
+    static int forced = -1;
+    if (forced < 0) {
+      const char* e = getenv("MLIIS_GEMM_TM");
+      forced = e ? atoi(e) : 0;
+    }
+    if (forced == 1 || forced == 2) g.tm = forced;
+  }
   g.gx = (int)((M + 64 * g.tm - 1) / (64 * g.tm));
   int nchunks = ntaps * ((C + 31) / 32);
   g.gz = 1;
   if (allow_split) {
     long long blocks = (long long)g.gx * g.gy;
     // split K when the grid cannot fill the chip and there is enough K to amortise the extra pass
-    while (blocks * g.gz * 2 <= num_cus && nchunks / (g.gz * 2) >= 8 && g.gz < 16) g.gz *= 2;
+    while (blocks * g.gz * 2 <= num_cus && nchunks / (g.gz * 2) >= 3 && g.gz < 16) g.gz *= 2;
   }
   g.chunks_per_split = (nchunks + g.gz - 1) / g.gz;
   g.gz = (nchunks + g.chunks_per_split - 1) / g.chunks_per_split;
@@ -598,12 +647,13 @@ size_t mliis_conv2d_workspace_floats(int Nimg, int H, int W, int Cred, int Nout,
 }
 
 // y[M, Cout] (ld = ldy) (+)= conv(x[M, Cin] (ld = ldx), w[k,k,Cin,Cout]) + bias ; stride 1, TF-SAME, dilation dil
-int mliis_conv2d_fwd(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int Nimg, int H, int W, int Cin,
-                     int Cout, int ksize, int dil, int accumulate, float* stats_part, int stats_swish, int* stats_nblk, float* ws,
-                     size_t ws_floats, hipStream_t stream) {
+int mliis_conv2d_fwd(const float* x, int ldx, const float* w, const float* wt, const float* bias, float* y, int ldy, int Nimg, int H,
+                     int W, int Cin, int Cout, int ksize, int dil, int accumulate, float* stats_part, int stats_swish, int* stats_nblk,
+                     float* ws, size_t ws_floats, hipStream_t stream) {
   int rc = conv_check("conv2d_fwd", Nimg, H, W, Cin, Cout, ksize, dil);
   if (rc) return rc;
-  MLIIS_REQUIRE(x && w && y, MLIIS_ERR_ARG, "conv2d_fwd: null pointer");
+  MLIIS_REQUIRE(x && (w || wt) && y, MLIIS_ERR_ARG, "conv2d_fwd: null pointer");
+  MLIIS_REQUIRE(aligned16(wt), MLIIS_ERR_ALIGN, "conv2d_fwd: wt must be 16-byte aligned");
   MLIIS_REQUIRE((ldx & 3) == 0 && ldx >= Cin && (ldy & 3) == 0 && ldy >= Cout, MLIIS_ERR_ARG, "conv2d_fwd: bad leading dimensions");
   MLIIS_REQUIRE(aligned16(x) && aligned16(w) && aligned16(bias) && aligned16(y), MLIIS_ERR_ALIGN,
                 "conv2d_fwd: pointers must be 16-byte aligned");
@@ -624,7 +674,13 @@ int mliis_conv2d_fwd(const float* x, int ldx, const float* w, const float* bias,
                   "conv2d_fwd: split-K workspace too small (%zu needed, %zu given) or unaligned output", need, ws_floats);
     p.partial = ws;
   }
-  launch_gemm<false>(g, p, stream);
+  if (wt != nullptr) {  // K-contiguous shadow weights [k,k,Cout,Cin]: forward on the b128-fragment B path
+    p.B = wt;
+    p.ldb = Cin;
+    launch_gemm<true>(g, p, stream);
+  } else {
+    launch_gemm<false>(g, p, stream);
+  }
   MLIIS_CHECK_LAUNCH("conv2d_fwd");
   if (g.gz > 1) {
     long long q = M * (Cout / 4);
@@ -665,6 +721,14 @@ int mliis_conv2d_bwd_data(const float* dy, int lddy, const float* w, float* dx, 
     hipLaunchKernelGGL(splitk_reduce_k, dim3(blocks), dim3(256), 0, stream, ws, g.gz, M, Cin_out, dx, lddx, nullptr, accumulate);
     MLIIS_CHECK_LAUNCH("conv2d_bwd_data_splitk_reduce");
   }
+  return MLIIS_OK;
+}
+
+// desc: device int32 [ndesc][4] = {offset (floats), taps, Cin, Cout}; src/dst: arenas with identical layout.
+int mliis_transpose_weights(const float* src, float* dst, const int* desc, int ndesc, hipStream_t stream) {
+  MLIIS_REQUIRE(src && dst && desc && ndesc > 0, MLIIS_ERR_ARG, "transpose_weights: bad arguments");
+  hipLaunchKernelGGL(transpose_weights_k, dim3(48, ndesc), dim3(256), 0, stream, src, dst, desc);
+  MLIIS_CHECK_LAUNCH("transpose_weights");
   return MLIIS_OK;
 }
 

@@ -135,6 +135,17 @@ class Learner:
         self.arena.init_weights(seed)
         self.variables_initialized = True
         self.ws = ops.Workspace(self.device, 1 << 22)
+        # K-contiguous ("HWOI") shadow of the dense-conv weights, refreshed by ONE batched transpose at the top of every
+        # forward, so the forward GEMMs read their B operand as 16-byte k-fragments like backward-data does
+        A = self.arena
+        self.theta_t = torch.zeros_like(A.theta)
+        fe = self.arch.name
+        desc = []
+        for p in A.trainable:
+            if p.kind == "conv" and p.executed and "/se/" not in p.name and p.name not in (f"{fe}/stem/conv2d/kernel", "decode/final_layer_weights/kernel"):
+                desc.append([A.t_off[p.name], p.shape[0] * p.shape[1], p.shape[2], p.shape[3]])
+        self.wt_desc = torch.tensor(desc, dtype=torch.int32, device=self.device)
+        self.wt = {p.name: self.theta_t[A.t_off[p.name]:A.t_off[p.name] + p.size] for p in A.trainable}
         self.lr_dev = torch.tensor([self.lr], dtype=torch.float32, device=self.device)
         self.adam_v = torch.zeros_like(self.arena.theta) if optimizer == "adam" else None
         self.adam_t = torch.zeros(1, dtype=torch.float32, device=self.device)
@@ -297,12 +308,14 @@ class Learner:
             torch.rsqrt(mv[prefix + "/moving_variance"] + spec.BN_EPS, out=st[1])
             return ops.bn_apply(xin, st[0], st[1], w[prefix + "/gamma"], w[prefix + "/beta"], pre, post, img_scale, res, out=y)
 
+        ops.transpose_weights(A.theta, self.theta_t, self.wt_desc)
+
         def conv(xin, wname, bname, dil, out, swish_stats):
             """dense conv; in training the epilogue also emits the following BN's statistics (returns their block count)."""
             if training:
                 return ops.conv2d_fwd(xin, w[wname], w[bname] if bname else None, dil, out=out, ws=ws, stats_part=P.stats_part,
-                                      stats_swish=swish_stats)[1]
-            ops.conv2d_fwd(xin, w[wname], w[bname] if bname else None, dil, out=out, ws=ws)
+                                      stats_swish=swish_stats, wt=self.wt[wname])[1]
+            ops.conv2d_fwd(xin, w[wname], w[bname] if bname else None, dil, out=out, ws=ws, wt=self.wt[wname])
             return 0
 
         ops.stem_conv_fwd(x, w[self.n_stem[0]], idx, out=P.z_stem)

@@ -164,8 +164,13 @@ def dwconv_bwd_filter(x, dy, k, stride, out=None, ws: Optional[Workspace] = None
 
 
 # ------------------------------------------------------------------------------------------------ dense conv
+def transpose_weights(src, dst, desc):
+    """dst <- HWOI copies of the dense-conv weights listed in desc (device int32 [n,4] = offset, taps, Cin, Cout)."""
+    lib.call("mliis_transpose_weights", _ptr(src), _ptr(dst), _ptr(desc), int(desc.shape[0]), _stream())
+
+
 def conv2d_fwd(x, w, bias=None, dil=1, out=None, accumulate=False, ws: Optional[Workspace] = None, nhw=None, stats_part=None,
-               stats_swish=False):
+               stats_swish=False, wt=None):
     """x: [N,H,W,>=Cin] view (channel slice allowed); w: [k,k,Cin,Cout].  With stats_part (a float buffer) the epilogue also emits
     the next batch norm's stage-1 statistics and the function returns (out, nblk); nblk == 0 means they were not produced."""
     N, H, W = nhw if nhw is not None else x.shape[:3]
@@ -180,12 +185,12 @@ def conv2d_fwd(x, w, bias=None, dil=1, out=None, accumulate=False, ws: Optional[
     meta = {}
     if PROFILE is not None:
         tm, nt, sp = conv2d_plan(N, H, W, Cin, Cout, k)
-        meta = dict(kernel="conv_gemm_k<%d,%d,false>" % (tm, nt), splits=sp, flops=2.0 * N * H * W * k * k * Cin * Cout,
-                    shape=(N, H, W, Cin, Cout, k, dil))
+        meta = dict(kernel="conv_gemm_k<%d,%d,%s>" % (tm, nt, "true" if wt is not None else "false"), splits=sp,
+                    flops=2.0 * N * H * W * k * k * Cin * Cout, shape=(N, H, W, Cin, Cout, k, dil))
     nblk = C.c_int(0)
     if stats_part is not None and stats_part.numel() < (-(-N * H * W // 64)) * 2 * Cout:
         raise MliisError("conv2d_fwd: stats_part too small")
-    _timed("conv2d_fwd", meta, lambda: lib.call("mliis_conv2d_fwd", _ptr(x), ldx, _ptr(w), _ptr(bias), _ptr(out), ldy, N, H, W, Cin, Cout, k,
+    _timed("conv2d_fwd", meta, lambda: lib.call("mliis_conv2d_fwd", _ptr(x), ldx, _ptr(w), _ptr(wt), _ptr(bias), _ptr(out), ldy, N, H, W, Cin, Cout, k,
                                                 dil, int(accumulate), _ptr(stats_part), int(stats_swish), C.byref(nblk), _ptr(buf),
                                                 buf.numel(), _stream()))
     if stats_part is not None:

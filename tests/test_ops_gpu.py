@@ -81,6 +81,15 @@ def test_conv2d_all(k, dil, H, W, Cin, Cout, N):
     gx, gw, gb = torch.autograd.grad(y, [x, w, b], dy)
     xg, wg, bg = f32(x, d), f32(w, d), f32(b, d)
     close(ops.conv2d_fwd(xg, wg, bg, dil), nhwc(y), 2e-5, "conv fwd")
+    # forward through the K-contiguous shadow weights (batched HWIO -> HWOI transpose)
+    wt = torch.full((wg.numel() + 8,), float("nan"), device=d)
+    desc = torch.tensor([[4, k * k, Cin, Cout]], dtype=torch.int32, device=d)
+    src = torch.zeros(wg.numel() + 8, device=d)
+    src[4:4 + wg.numel()] = wg.reshape(-1)
+    ops.transpose_weights(src, wt, desc)
+    assert torch.equal(wt[4:4 + wg.numel()].view(k, k, Cout, Cin), wg.permute(0, 1, 3, 2)), "shadow weights"
+    assert torch.isnan(wt[:4]).all() and torch.isnan(wt[4 + wg.numel():]).all()
+    close(ops.conv2d_fwd(xg, wg, bg, dil, wt=wt[4:4 + wg.numel()]), nhwc(y), 2e-5, "conv fwd (shadow weights)")
     dyg = f32(nhwc(dy), d)
     close(ops.conv2d_bwd_data(dyg, wg, dil), gx, 1e-4, "conv bwd data")
     close(ops.conv2d_bwd_filter(xg, dyg, k, dil), gw, 1e-4, "conv bwd filter")

@@ -33,13 +33,14 @@ def main():
     ap.add_argument("--n", type=int, default=8)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--dense-only", action="store_true")
     a = ap.parse_args()
     d = torch.device("cuda:0")
     arch = spec.derive()
     N = a.n
     res = {"depthwise": [], "dense": []}
     tot = dict(fwd_t=0, fwd_b=0, bwd_t=0, bwd_b=0)
-    for b in arch.blocks:
+    for b in ([] if a.dense_only else arch.blocks):
         C, k, s, hi, ho = b.cexp, b.k, b.stride, b.h_in, b.h_out
         x = torch.randn(N, hi, hi, C, device=d)
         w = torch.randn(k, k, C, 1, device=d)
@@ -60,9 +61,11 @@ def main():
         tot["bwd_b"] += bb
         print("dw b%-2d C=%-3d k%d s%d h=%-3d fwd %7.1f us (%4.1f%% HBM)  bwd_data %7.1f  bwd_filter %7.1f (%4.1f%% HBM)" % (
             b.idx, C, k, s, hi, tf * 1e6, 100 * fb / tf / HBM_PEAK, tbd * 1e6, tbf * 1e6, 100 * bb / (tbd + tbf) / HBM_PEAK), flush=True)
-    res["depthwise_total"] = dict(fwd_us=tot["fwd_t"] * 1e6, bwd_us=tot["bwd_t"] * 1e6, fwd_frac=tot["fwd_b"] / tot["fwd_t"] / HBM_PEAK,
+    if not a.dense_only:
+      res["depthwise_total"] = dict(fwd_us=tot["fwd_t"] * 1e6, bwd_us=tot["bwd_t"] * 1e6, fwd_frac=tot["fwd_b"] / tot["fwd_t"] / HBM_PEAK,
                                   bwd_frac=tot["bwd_b"] / tot["bwd_t"] / HBM_PEAK)
-    print("dw total fwd %.1f us (%.1f%% of 8 TB/s)  bwd %.1f us (%.1f%%)" % (tot["fwd_t"] * 1e6, 100 * res["depthwise_total"]["fwd_frac"],
+    if not a.dense_only:
+      print("dw total fwd %.1f us (%.1f%% of 8 TB/s)  bwd %.1f us (%.1f%%)" % (tot["fwd_t"] * 1e6, 100 * res["depthwise_total"]["fwd_frac"],
                                                                           tot["bwd_t"] * 1e6, 100 * res["depthwise_total"]["bwd_frac"]), flush=True)
     dense = [("b1.exp", 1, 1, 112, 16, 96), ("b2.exp", 1, 1, 56, 24, 144), ("b4.exp", 1, 1, 28, 40, 240), ("b6.exp", 1, 1, 14, 80, 480),
              ("b9.proj", 1, 1, 14, 672, 112), ("rsd4.br1", 3, 2, 14, 224, 112), ("rsd4.fuse", 3, 1, 14, 448, 112),
@@ -76,7 +79,8 @@ def main():
         dx = torch.empty_like(x)
         dw = torch.empty_like(w)
         fl = 2.0 * N * h * h * k * k * ci * co
-        tf = timeit(lambda: ops.conv2d_fwd(x, w, bias, dil, out=y), a.iters)
+        wt = w.permute(0, 1, 3, 2).contiguous().view(-1)
+        tf = timeit(lambda: ops.conv2d_fwd(x, w, bias, dil, out=y, wt=wt), a.iters)
         tbd = timeit(lambda: ops.conv2d_bwd_data(dy, w, dil, out=dx), a.iters)
         tbf = timeit(lambda: ops.conv2d_bwd_filter(x, dy, k, dil, out=dw), a.iters)
         res["dense"].append(dict(name=name, fwd_us=tf * 1e6, bwd_data_us=tbd * 1e6, bwd_filter_us=tbf * 1e6, gflop=fl / 1e9,
