@@ -121,8 +121,14 @@ def roofline(L, args):
     dom = max(gemm, key=lambda k: gemm[k]["ms"])
     d = gemm[dom]
     ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+    traffic, tsrc = None, None
+    tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if os.path.exists(tpath):   # PMC counters cannot be sampled from inside this process: taken from the committed rocprofv3 --pmc passes
+        k = json.load(open(tpath)).get("kernels", {}).get(dom.replace(" ", ""))
+        if k:
+            traffic, tsrc = k["hbm_bytes_per_launch"], "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950-corrected)"
     out = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TFLOPS,
-           "traffic": None, "launches_per_step": d["n"] // reps, "avg_launch_us": 1e3 * d["ms"] / d["n"],
+           "traffic": traffic, "traffic_source": tsrc, "launches_per_step": d["n"] // reps, "avg_launch_us": 1e3 * d["ms"] / d["n"],
            "algorithmic_flops_per_launch": d["flops"] / d["n"]}
     dw = {}
     for k in ("dwconv_fwd", "dwconv_bwd_data", "dwconv_bwd_filter"):
