@@ -69,9 +69,11 @@ int mliis_conv2d_plan(int Nimg, int H, int W, int Cred, int Nout, int ksize, int
  *      plan) and the caller must run mliis_bn_stats_partial instead.  Needs >= ceil(M/64) * 2 * Cout floats. */
 /*      wt (nullable): K-contiguous shadow copy of w, layout [k,k,Cout,Cin] (mliis_transpose_weights); when given, the forward
  *      GEMM reads it instead of w (same result, faster B-operand path). */
-int mliis_conv2d_fwd(const float* x, int ldx, const float* w, const float* wt, const float* bias, float* y, int ldy, int Nimg, int H,
-                     int W, int Cin, int Cout, int ksize, int dil, int accumulate, float* stats_part, int stats_swish, int* stats_nblk,
-                     float* ws, size_t ws_floats, hipStream_t stream);
+/*      x_scale (nullable, [Nimg,Cin], 1x1 convs): x[m,c] is multiplied by x_scale[image(m),c] while it is staged -- the
+ *      squeeze-excite gate (efficientnet_model.py:251) applied on the fly, so the gated tensor is never materialised. */
+int mliis_conv2d_fwd(const float* x, int ldx, const float* x_scale, const float* w, const float* wt, const float* bias, float* y, int ldy,
+                     int Nimg, int H, int W, int Cin, int Cout, int ksize, int dil, int accumulate, float* stats_part, int stats_swish,
+                     int* stats_nblk, float* ws, size_t ws_floats, hipStream_t stream);
 /*      batched HWIO -> HWOI copy of dense-conv weights between two arenas of identical layout; desc = device int32
  *      [ndesc][4] {offset, taps, Cin, Cout} */
 int mliis_transpose_weights(const float* src, float* dst, const int* desc, int ndesc, hipStream_t stream);
@@ -80,8 +82,8 @@ int mliis_conv2d_bwd_data(const float* dy, int lddy, const float* w, float* dx, 
                           int ci_begin, int Cin_out, int Cout, int ksize, int dil, int accumulate, float* ws, size_t ws_floats,
                           hipStream_t stream);
 size_t mliis_conv2d_bwd_filter_workspace_floats(int Nimg, int H, int W, int Cin, int Cout, int ksize);
-int mliis_conv2d_bwd_filter(const float* x, int ldx, const float* dy, int lddy, float* dw, int Nimg, int H, int W, int Cin, int Cout,
-                            int ksize, int dil, int accumulate, float* ws, size_t ws_floats, hipStream_t stream);
+int mliis_conv2d_bwd_filter(const float* x, int ldx, const float* x_scale, const float* dy, int lddy, float* dw, int Nimg, int H, int W,
+                            int Cin, int Cout, int ksize, int dil, int accumulate, float* ws, size_t ws_floats, hipStream_t stream);
 
 /* ---- batch norm, training mode (TpuBatchNormalization, models/efficientnet/utils.py:87-134; tf.layers.batch_normalization,
  *      models/efficientlab.py:190).  pre_swish: statistics/normalisation act on swish(x) (decoder order conv->swish->BN);

@@ -46,6 +46,8 @@ struct ConvGemmParams {
   int chunks_per_split;  // K chunks per blockIdx.z
   float* stats_part;     // non-null => epilogue also writes per-row-block column sums [gridDim.x][2][Nout] of the
   int stats_swish;       //             stored values (of swish(value) when stats_swish) for the following batch norm
+  const float* a_scale;  // non-null => A[m][c] is multiplied by a_scale[image(m)][c] while it is staged (squeeze-excite gate
+                         //             applied on the fly: the gated activation tensor is never materialised)
 };
 
 template <int TM, int NT, bool B_NK>
@@ -79,13 +81,15 @@ __global__ __launch_bounds__(256) void conv_gemm_k(ConvGemmParams p) {
   // ---- per-thread A rows
   const int a_kq = t & 7;
   const int a_r0 = t >> 3;  // 0..31
-  int a_h[A_PER_THREAD], a_w[A_PER_THREAD];
+  int a_h[A_PER_THREAD], a_w[A_PER_THREAD], a_n[A_PER_THREAD];
   long long a_m[A_PER_THREAD];
 #pragma unroll
   for (int i = 0; i < A_PER_THREAD; ++i) {
     long long m = m0 + a_r0 + 32 * i;
     a_m[i] = m;
+    a_n[i] = 0;
     if (m < M) {
+      a_n[i] = (int)(m / ((long long)p.H * p.W));
       int rem = (int)(m % ((long long)p.H * p.W));
       a_h[i] = rem / p.W;
       a_w[i] = rem - a_h[i] * p.W;
@@ -112,6 +116,7 @@ __global__ __launch_bounds__(256) void conv_gemm_k(ConvGemmParams p) {
       const int hh = a_h[i] + dh, ww = a_w[i] + dw;
       const bool ok = (a_m[i] < M) && (ca < p.C) && (hh >= 0) && (hh < p.H) && (ww >= 0) && (ww < p.W);
       ra[i] = ok ? ld4(p.A + (a_m[i] + (long long)dh * p.W + dw) * p.lda + ca) : f4zero();
+      if (p.a_scale != nullptr && ok) ra[i] = f4mul(ra[i], ld4(p.a_scale + (long long)a_n[i] * p.C + ca));
     }
     const float* Bt = p.B + (long long)tap * p.b_tap_stride;
 #pragma unroll
@@ -334,6 +339,7 @@ struct FilterGradParams {
   int Nout;
   float* partial;  // [splits][ntaps*C][Nout]
   int rows_per_split;
+  const float* x_scale;  // nullable [Nimg][C]: X[m][c] *= x_scale[image(m)][c] on load
 };
 
 template <int TMF, int NT>
@@ -386,6 +392,7 @@ __global__ __launch_bounds__(256) void conv_filter_grad_k(FilterGradParams p) {
         ok = (hh >= 0) && (hh < p.H) && (ww >= 0) && (ww < p.W);
       }
       rx[i] = ok ? ld4(p.X + (m + shift) * p.ldx + ci0 + x_cq * 4) : f4zero();
+      if (p.x_scale != nullptr && ok) rx[i] = f4mul(rx[i], ld4(p.x_scale + (m / HW) * p.C + ci0 + x_cq * 4));
     }
 #pragma unroll
     for (int i = 0; i < D_PER_THREAD; ++i) {
@@ -565,7 +572,13 @@ static inline FilterPlan plan_filter(long long M, int C, int Nout, int ntaps, in
   f.gx = ntaps * ((C + bci - 1) / bci);
   long long base = (long long)f.gx * f.gy;
   long long want = (3LL * num_cus + base - 1) / base;  // ~3 blocks per CU in total ...
-  if (want > 96) want = 96;                            // ... but bound the number of partial slabs the fold has to read
+  {                                                    // ... bounded by the slab bytes the fold has to read (<= 8 MB, <= 512 slabs)
+    const long long total = (long long)ntaps * C * Nout;
+    long long cap = (2LL << 20) / (total > 0 ? total : 1);
+    if (cap > 512) cap = 512;
+    if (cap < 8) cap = 8;
+    if (want > cap) want = cap;
+  }
   if (want < 1) want = 1;
   long long rps = (M + want - 1) / want;
   if (rps < 256) rps = 256;
@@ -647,9 +660,9 @@ size_t mliis_conv2d_workspace_floats(int Nimg, int H, int W, int Cred, int Nout,
 }
 
 // y[M, Cout] (ld = ldy) (+)= conv(x[M, Cin] (ld = ldx), w[k,k,Cin,Cout]) + bias ; stride 1, TF-SAME, dilation dil
-int mliis_conv2d_fwd(const float* x, int ldx, const float* w, const float* wt, const float* bias, float* y, int ldy, int Nimg, int H,
-                     int W, int Cin, int Cout, int ksize, int dil, int accumulate, float* stats_part, int stats_swish, int* stats_nblk,
-                     float* ws, size_t ws_floats, hipStream_t stream) {
+int mliis_conv2d_fwd(const float* x, int ldx, const float* x_scale, const float* w, const float* wt, const float* bias, float* y, int ldy,
+                     int Nimg, int H, int W, int Cin, int Cout, int ksize, int dil, int accumulate, float* stats_part, int stats_swish,
+                     int* stats_nblk, float* ws, size_t ws_floats, hipStream_t stream) {
   int rc = conv_check("conv2d_fwd", Nimg, H, W, Cin, Cout, ksize, dil);
   if (rc) return rc;
   MLIIS_REQUIRE(x && (w || wt) && y, MLIIS_ERR_ARG, "conv2d_fwd: null pointer");
@@ -660,7 +673,9 @@ int mliis_conv2d_fwd(const float* x, int ldx, const float* w, const float* wt, c
   long long M = (long long)Nimg * H * W;
   GemmPlan g = plan_gemm(M, Cout, Cin, ksize * ksize, num_cus(), ws != nullptr);
   ConvGemmParams p{x, ldx, Nimg, H, W, Cin, ksize * ksize, dil, +1, w, (long long)Cin * Cout, Cout, Cout, y, ldy, bias, accumulate,
-                   nullptr, g.chunks_per_split, nullptr, 0};
+                   nullptr, g.chunks_per_split, nullptr, 0, x_scale};
+  MLIIS_REQUIRE(aligned16(x_scale) && (x_scale == nullptr || ksize == 1), MLIIS_ERR_ARG,
+                "conv2d_fwd: x_scale must be 16-byte aligned and is only supported for 1x1 convs");
   if (stats_nblk) *stats_nblk = 0;
   if (stats_part != nullptr && g.gz == 1) {   // fused BN statistics: only when the epilogue sees final values
     MLIIS_REQUIRE(!accumulate && stats_nblk, MLIIS_ERR_ARG, "conv2d_fwd: fused statistics need accumulate == 0 and a stats_nblk output");
@@ -706,7 +721,7 @@ int mliis_conv2d_bwd_data(const float* dy, int lddy, const float* w, float* dx, 
   long long M = (long long)Nimg * H * W;
   GemmPlan g = plan_gemm(M, Cin_out, Cout, ksize * ksize, num_cus(), ws != nullptr);
   ConvGemmParams p{dy, lddy, Nimg, H, W, Cout, ksize * ksize, dil, -1, w + (long long)ci_begin * Cout, (long long)Cin_total * Cout,
-                   Cout, Cin_out, dx, lddx, nullptr, accumulate, nullptr, g.chunks_per_split, nullptr, 0};
+                   Cout, Cin_out, dx, lddx, nullptr, accumulate, nullptr, g.chunks_per_split, nullptr, 0, nullptr};
   if (g.gz > 1) {
     size_t need = (size_t)g.gz * M * Cin_out;
     MLIIS_REQUIRE(need <= ws_floats && aligned16(ws) && (lddx & 3) == 0 && aligned16(dx), MLIIS_ERR_WORKSPACE,
@@ -739,8 +754,8 @@ size_t mliis_conv2d_bwd_filter_workspace_floats(int Nimg, int H, int W, int Cin,
 }
 
 // dw[k,k,Cin,Cout] (+)= sum_pixels x[pixel + tap offset, ci] * dy[pixel, co]
-int mliis_conv2d_bwd_filter(const float* x, int ldx, const float* dy, int lddy, float* dw, int Nimg, int H, int W, int Cin, int Cout,
-                            int ksize, int dil, int accumulate, float* ws, size_t ws_floats, hipStream_t stream) {
+int mliis_conv2d_bwd_filter(const float* x, int ldx, const float* x_scale, const float* dy, int lddy, float* dw, int Nimg, int H, int W,
+                            int Cin, int Cout, int ksize, int dil, int accumulate, float* ws, size_t ws_floats, hipStream_t stream) {
   int rc = conv_check("conv2d_bwd_filter", Nimg, H, W, Cin, Cout, ksize, dil);
   if (rc) return rc;
   MLIIS_REQUIRE(x && dy && dw && ws, MLIIS_ERR_ARG, "conv2d_bwd_filter: null pointer");
@@ -751,7 +766,8 @@ int mliis_conv2d_bwd_filter(const float* x, int ldx, const float* dy, int lddy, 
   size_t total = (size_t)ksize * ksize * Cin * Cout;
   MLIIS_REQUIRE((size_t)f.gz * total <= ws_floats, MLIIS_ERR_WORKSPACE, "conv2d_bwd_filter: workspace too small (%zu needed, %zu given)",
                 (size_t)f.gz * total, ws_floats);
-  FilterGradParams p{x, ldx, Nimg, H, W, Cin, ksize * ksize, dil, dy, lddy, Cout, ws, f.rows_per_split};
+  MLIIS_REQUIRE(aligned16(x_scale), MLIIS_ERR_ALIGN, "conv2d_bwd_filter: x_scale must be 16-byte aligned");
+  FilterGradParams p{x, ldx, Nimg, H, W, Cin, ksize * ksize, dil, dy, lddy, Cout, ws, f.rows_per_split, x_scale};
   launch_filter(f, p, stream);
   MLIIS_CHECK_LAUNCH("conv2d_bwd_filter");
   hipLaunchKernelGGL(fold_flat_k, dim3(ceil_div((long long)total, kFoldX)), dim3(kFoldX, kFoldY), 0, stream, ws, f.gz, (long long)total, 1.0f, dw,

@@ -83,19 +83,21 @@ __global__ __launch_bounds__(256) void stem_fwd_k(const float* __restrict__ x, c
   st4(dst + 4, make_float4(acc[4], acc[5], acc[6], acc[7]));
 }
 
-// thread = (pixel lane, co); part layout [blk][27][Co]
+// thread = (pixel lane, channel quad): 27 x float4 accumulators; the 27 normalised inputs of a pixel are shared by the Co/4 quad
+// threads of that pixel (L1 broadcast).  part layout [blk][27][Co].
 __global__ __launch_bounds__(256) void stem_bwd_filter_k(const float* __restrict__ x, const int* __restrict__ idx,
                                                          const float* __restrict__ dz, float* __restrict__ part, int N, int H,
                                                          int W, int Ho, int Wo, int Co, int pt, int pl, Norm3 nm,
                                                          int pix_per_block) {
-  extern __shared__ float sred[];  // [PL][Co] per tap, reused
-  const int PL = 256 / Co;
-  const int co = threadIdx.x % Co, pl_ = threadIdx.x / Co;
+  __shared__ float4 sred[256];
+  const int QC = Co >> 2;            // channel quads
+  const int PL = 256 / QC;           // pixel lanes
+  const int q = threadIdx.x % QC, pl_ = threadIdx.x / QC;
   const bool active = pl_ < PL;
   const long long P = (long long)N * Ho * Wo;
-  float acc[27];
+  float4 acc[27];
 #pragma unroll
-  for (int k = 0; k < 27; ++k) acc[k] = 0.f;
+  for (int k = 0; k < 27; ++k) acc[k] = f4zero();
   if (active) {
     const long long p0 = (long long)blockIdx.x * pix_per_block;
     long long p1 = p0 + pix_per_block;
@@ -108,27 +110,27 @@ __global__ __launch_bounds__(256) void stem_bwd_filter_k(const float* __restrict
       const int src = idx ? idx[n] : n;
       float v[27];
       load_window(x + (long long)src * H * W * 3, H, W, ho * 2 - pt, wo * 2 - pl, nm, v);
-      const float d = dz[pix * Co + co];
+      const float4 d = ld4(dz + pix * Co + q * 4);
 #pragma unroll
-      for (int k = 0; k < 27; ++k) acc[k] = fmaf(v[k], d, acc[k]);
+      for (int k = 0; k < 27; ++k) acc[k] = f4fma(make_float4(v[k], v[k], v[k], v[k]), d, acc[k]);
     }
   }
 #pragma unroll
   for (int k = 0; k < 27; ++k) {
     __syncthreads();
-    if (active) sred[pl_ * Co + co] = acc[k];
+    sred[threadIdx.x] = acc[k];
     __syncthreads();
-    if (pl_ == 0) {
-      float s = sred[co];
-      for (int j = 1; j < PL; ++j) s += sred[j * Co + co];
-      part[((long long)blockIdx.x * 27 + k) * Co + co] = s;
+    if (pl_ == 0 && q < QC) {
+      float4 s4 = sred[q];
+      for (int j = 1; j < PL; ++j) s4 = f4add(s4, sred[j * QC + q]);
+      st4(part + ((long long)blockIdx.x * 27 + k) * Co + q * 4, s4);
     }
   }
 }
 
 static inline void stem_filter_geom(int N, int Ho, int Wo, int Co, int* pix_per_block, int* nblk) {
   long long P = (long long)N * Ho * Wo;
-  int PL = 256 / Co;
+  int PL = 256 / (Co / 4);
   long long ppb = (P + 511) / 512;
   if (ppb < PL * 4) ppb = PL * 4;
   ppb = (ppb + PL - 1) / PL * PL;
@@ -167,13 +169,14 @@ size_t mliis_stem_conv_bwd_filter_workspace_floats(int N, int H, int W, int Co) 
 int mliis_stem_conv_bwd_filter(const float* x, const int* img_idx, const float* dz, float* dw, int N, int H, int W, int Co,
                                const float* mean3, const float* std3, float* ws, size_t ws_floats, hipStream_t stream) {
   MLIIS_REQUIRE(x && dz && dw && ws && mean3 && std3, MLIIS_ERR_ARG, "stem_conv_bwd_filter: null pointer");
-  MLIIS_REQUIRE(N > 0 && H > 1 && W > 1 && Co > 0 && Co <= 256, MLIIS_ERR_ARG, "stem_conv_bwd_filter: bad shape");
+  MLIIS_REQUIRE(N > 0 && H > 1 && W > 1 && Co > 0 && (Co & 3) == 0 && Co <= 256, MLIIS_ERR_ARG, "stem_conv_bwd_filter: bad shape");
+  MLIIS_REQUIRE(aligned16(dz) && aligned16(ws), MLIIS_ERR_ALIGN, "stem_conv_bwd_filter: dz / workspace must be 16-byte aligned");
   StemGeom g = stem_geom(H, W);
   int ppb, nblk;
   stem_filter_geom(N, g.Ho, g.Wo, Co, &ppb, &nblk);
   MLIIS_REQUIRE((size_t)nblk * 27 * Co <= ws_floats, MLIIS_ERR_WORKSPACE, "stem_conv_bwd_filter: workspace too small");
   Norm3 nm{mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]};
-  hipLaunchKernelGGL(stem_bwd_filter_k, dim3(nblk), dim3(256), 256 * sizeof(float), stream, x, img_idx, dz, ws, N, H, W, g.Ho, g.Wo, Co,
+  hipLaunchKernelGGL(stem_bwd_filter_k, dim3(nblk), dim3(256), 0, stream, x, img_idx, dz, ws, N, H, W, g.Ho, g.Wo, Co,
                      g.pt, g.pl, nm, ppb);
   MLIIS_CHECK_LAUNCH("stem_conv_bwd_filter");
   hipLaunchKernelGGL(fold_flat_k, dim3(ceil_div(27 * Co, kFoldX)), dim3(kFoldX, kFoldY), 0, stream, ws, nblk, (long long)27 * Co, 1.0f, dw, 0);

@@ -62,7 +62,6 @@ class _Plan:
                 B["z0"], B["a0"], B["st0"] = buf(N, hi, hi, ce), buf(N, hi, hi, ce), vec(ce)
             B["z1"], B["a1"], B["st1"] = buf(N, ho, ho, ce), buf(N, ho, ho, ce), vec(ce)
             B["s"], B["hpre"], B["gate"] = buf(N, ce), buf(N, b.se), buf(N, ce)
-            B["a2"] = buf(N, ho, ho, ce)
             B["z2"], B["st2"], B["out"] = buf(N, ho, ho, b.cout), vec(b.cout), buf(N, ho, ho, b.cout)
             B["dout"] = buf(N, ho, ho, b.cout)
             B["dgate"], B["dpre1"], B["dpre2"], B["chan_add"] = buf(N, ce), buf(N, b.se), buf(N, ce), buf(N, ce)
@@ -310,12 +309,12 @@ class Learner:
 
         ops.transpose_weights(A.theta, self.theta_t, self.wt_desc)
 
-        def conv(xin, wname, bname, dil, out, swish_stats):
+        def conv(xin, wname, bname, dil, out, swish_stats, x_scale=None):
             """dense conv; in training the epilogue also emits the following BN's statistics (returns their block count)."""
             if training:
                 return ops.conv2d_fwd(xin, w[wname], w[bname] if bname else None, dil, out=out, ws=ws, stats_part=P.stats_part,
-                                      stats_swish=swish_stats, wt=self.wt[wname])[1]
-            ops.conv2d_fwd(xin, w[wname], w[bname] if bname else None, dil, out=out, ws=ws, wt=self.wt[wname])
+                                      stats_swish=swish_stats, wt=self.wt[wname], x_scale=x_scale)[1]
+            ops.conv2d_fwd(xin, w[wname], w[bname] if bname else None, dil, out=out, ws=ws, wt=self.wt[wname], x_scale=x_scale)
             return 0
 
         ops.stem_conv_fwd(x, w[self.n_stem[0]], idx, out=P.z_stem)
@@ -333,8 +332,8 @@ class Learner:
             ops.colsum(B["a1"], None, nseg=N, scale=1.0 / hw, out=B["s"], ws=ws)
             se = nm["se"]
             ops.se_mlp_fwd(B["s"], w[se[0]], w[se[1]], w[se[2]], w[se[3]], B["hpre"], B["gate"])
-            ops.chan_affine(B["a1"], S=B["gate"], out=B["a2"])
-            nb = conv(B["a2"], nm["w_proj"], None, 1, B["z2"], False)
+            # squeeze-excite gate applied inside the project GEMM's A loader (the gated tensor is never written)
+            nb = conv(B["a1"], nm["w_proj"], None, 1, B["z2"], False, x_scale=B["gate"])
             use_dc = training and self.drop_connect and b.skip and b.drop_rate > 0
             B["use_dc"] = use_dc
             cur = bn(B["z2"], B["st2"], nm["bn2"], B["out"], img_scale=B["dc"] if use_dc else None, res=B["x_in"] if b.skip else None, nblk=nb)
@@ -438,7 +437,7 @@ class Learner:
                 ops.chan_affine(dout, out=tgt, accumulate=tgt_has)
                 tgt_has = True
             bn_b(B["z2"], dout, B["st2"], nm["bn2"], dout, img_scale=B["dc"] if B["use_dc"] else None)
-            ops.conv2d_bwd_filter(B["a2"], dout, 1, 1, out=g[nm["w_proj"]], ws=ws)
+            ops.conv2d_bwd_filter(B["a1"], dout, 1, 1, out=g[nm["w_proj"]], ws=ws, x_scale=B["gate"])
             n2 = N * hw * ce
             da2 = P.gA[:n2].view(N, b.h_out, b.h_out, ce)
             ops.conv2d_bwd_data(dout, w[nm["w_proj"]], 1, out=da2, ws=ws)

@@ -170,7 +170,7 @@ def transpose_weights(src, dst, desc):
 
 
 def conv2d_fwd(x, w, bias=None, dil=1, out=None, accumulate=False, ws: Optional[Workspace] = None, nhw=None, stats_part=None,
-               stats_swish=False, wt=None):
+               stats_swish=False, wt=None, x_scale=None):
     """x: [N,H,W,>=Cin] view (channel slice allowed); w: [k,k,Cin,Cout].  With stats_part (a float buffer) the epilogue also emits
     the next batch norm's stage-1 statistics and the function returns (out, nblk); nblk == 0 means they were not produced."""
     N, H, W = nhw if nhw is not None else x.shape[:3]
@@ -190,7 +190,7 @@ def conv2d_fwd(x, w, bias=None, dil=1, out=None, accumulate=False, ws: Optional[
     nblk = C.c_int(0)
     if stats_part is not None and stats_part.numel() < (-(-N * H * W // 64)) * 2 * Cout:
         raise MliisError("conv2d_fwd: stats_part too small")
-    _timed("conv2d_fwd", meta, lambda: lib.call("mliis_conv2d_fwd", _ptr(x), ldx, _ptr(w), _ptr(wt), _ptr(bias), _ptr(out), ldy, N, H, W, Cin, Cout, k,
+    _timed("conv2d_fwd", meta, lambda: lib.call("mliis_conv2d_fwd", _ptr(x), ldx, _ptr(x_scale), _ptr(w), _ptr(wt), _ptr(bias), _ptr(out), ldy, N, H, W, Cin, Cout, k,
                                                 dil, int(accumulate), _ptr(stats_part), int(stats_swish), C.byref(nblk), _ptr(buf),
                                                 buf.numel(), _stream()))
     if stats_part is not None:
@@ -219,7 +219,7 @@ def conv2d_bwd_data(dy, w, dil=1, ci_begin=0, ci_count=None, out=None, accumulat
     return out
 
 
-def conv2d_bwd_filter(x, dy, k, dil=1, out=None, accumulate=False, ws: Optional[Workspace] = None):
+def conv2d_bwd_filter(x, dy, k, dil=1, out=None, accumulate=False, ws: Optional[Workspace] = None, x_scale=None):
     N, H, W = dy.shape[:3]
     _, Cin, ldx = rows_ld(x)
     _, Cout, lddy = rows_ld(dy)
@@ -227,7 +227,7 @@ def conv2d_bwd_filter(x, dy, k, dil=1, out=None, accumulate=False, ws: Optional[
     ws = ws or default_ws()
     buf = ws.get(lib.size("mliis_conv2d_bwd_filter_workspace_floats", N, H, W, Cin, Cout, k))
     meta = dict(flops=2.0 * N * H * W * k * k * Cin * Cout, shape=(N, H, W, Cin, Cout, k, dil)) if PROFILE is not None else {}
-    _timed("conv2d_bwd_filter", meta, lambda: lib.call("mliis_conv2d_bwd_filter", _ptr(x), ldx, _ptr(dy), lddy, _ptr(out), N, H, W, Cin, Cout, k,
+    _timed("conv2d_bwd_filter", meta, lambda: lib.call("mliis_conv2d_bwd_filter", _ptr(x), ldx, _ptr(x_scale), _ptr(dy), lddy, _ptr(out), N, H, W, Cin, Cout, k,
                                                        dil, int(accumulate), _ptr(buf), buf.numel(), _stream()))
     return out
 

@@ -372,3 +372,22 @@ def test_conv_epilogue_statistics_and_fused_bn(k, dil, H, W, Cin, Cout, N, swish
     nb2 = ops.bn_stats_partial(zg, swish, part)
     y2 = ops.bn_apply_fused(zg, part, nb2, m_o, r_o, f32(gamma, d), f32(beta, d), pre_swish=swish, post_swish=not swish, res=f32(res, d))
     close(y2, y, 3e-5, "fused bn apply (stats kernel)")
+
+
+@pytest.mark.parametrize("H,W,Cin,Cout,N", [(14, 14, 240, 40, 3), (7, 9, 96, 24, 2), (28, 28, 144, 40, 2)])
+def test_conv1x1_with_se_gate_on_the_fly(H, W, Cin, Cout, N):
+    """x_scale: the squeeze-excite gate applied inside the GEMM loaders == conv / filter-gradient of the gated tensor."""
+    from mliis_amd import ops
+    d = dev()
+    x = rnd(N, H, W, Cin, seed=60)
+    gate = torch.sigmoid(rnd(N, Cin, seed=61))
+    w = rnd(1, 1, Cin, Cout, seed=62, scale=1.0 / math.sqrt(Cin)).requires_grad_(True)
+    xs = x * gate[:, None, None, :]
+    y = R.conv2d_same(nchw(xs), w, 1, 1)
+    dy = rnd(*y.shape, seed=63)
+    (gw,) = torch.autograd.grad(y, [w], dy)
+    xg, gg, wg = f32(x, d), f32(gate, d), f32(w, d)
+    wt = wg.permute(0, 1, 3, 2).contiguous().view(-1)
+    close(ops.conv2d_fwd(xg, wg, None, 1, x_scale=gg), nhwc(y), 2e-5, "gated conv (HWIO weights)")
+    close(ops.conv2d_fwd(xg, wg, None, 1, x_scale=gg, wt=wt), nhwc(y), 2e-5, "gated conv (shadow weights)")
+    close(ops.conv2d_bwd_filter(xg, f32(nhwc(dy), d), 1, 1, x_scale=gg), gw, 1e-4, "gated filter grad")
