@@ -71,9 +71,13 @@ int mliis_conv2d_plan(int Nimg, int H, int W, int Cred, int Nout, int ksize, int
  *      GEMM reads it instead of w (same result, faster B-operand path). */
 /*      x_scale (nullable, [Nimg,Cin], 1x1 convs): x[m,c] is multiplied by x_scale[image(m),c] while it is staged -- the
  *      squeeze-excite gate (efficientnet_model.py:251) applied on the fly, so the gated tensor is never materialised. */
-int mliis_conv2d_fwd(const float* x, int ldx, const float* x_scale, const float* w, const float* wt, const float* bias, float* y, int ldy,
-                     int Nimg, int H, int W, int Cin, int Cout, int ksize, int dil, int accumulate, float* stats_part, int stats_swish,
-                     int* stats_nblk, float* ws, size_t ws_floats, hipStream_t stream);
+/*      The weight tensor has Cin_total input channels; the conv reads its channels [ci_begin, ci_begin+Cin) against x's Cin
+ *      channels.  border_bias (nullable, [Nimg,9,Cout], 3x3 dilation 1 only): per-pixel bias selected by the pixel's border
+ *      class -- the exact contribution of spatially constant input channels (mliis_rsd_pool_fwd). */
+int mliis_conv2d_fwd(const float* x, int ldx, const float* x_scale, const float* w, const float* wt, const float* bias,
+                     const float* border_bias, float* y, int ldy, int Nimg, int H, int W, int Cin_total, int ci_begin, int Cin, int Cout,
+                     int ksize, int dil, int accumulate, float* stats_part, int stats_swish, int* stats_nblk, float* ws,
+                     size_t ws_floats, hipStream_t stream);
 /*      batched HWIO -> HWOI copy of dense-conv weights between two arenas of identical layout; desc = device int32
  *      [ndesc][4] {offset, taps, Cin, Cout} */
 int mliis_transpose_weights(const float* src, float* dst, const int* desc, int ndesc, hipStream_t stream);
@@ -82,8 +86,21 @@ int mliis_conv2d_bwd_data(const float* dy, int lddy, const float* w, float* dx, 
                           int ci_begin, int Cin_out, int Cout, int ksize, int dil, int accumulate, float* ws, size_t ws_floats,
                           hipStream_t stream);
 size_t mliis_conv2d_bwd_filter_workspace_floats(int Nimg, int H, int W, int Cin, int Cout, int ksize);
+/*      writes rows [ci_begin, ci_begin+Cin) (per tap) of the full [k,k,Cin_total,Cout] gradient tensor dw */
 int mliis_conv2d_bwd_filter(const float* x, int ldx, const float* x_scale, const float* dy, int lddy, float* dw, int Nimg, int H, int W,
-                            int Cin, int Cout, int ksize, int dil, int accumulate, float* ws, size_t ws_floats, hipStream_t stream);
+                            int Cin_total, int ci_begin, int Cin, int Cout, int ksize, int dil, int accumulate, float* ws,
+                            size_t ws_floats, hipStream_t stream);
+
+/* ---- RSD pooled branch (models/efficientlab.py:192-197,220-224) without convolving it: the Cp spatially constant channels
+ *      [c_begin, c_begin+Cp) of the 3x3 fuse conv's input become a per-image, per-border-class bias (forward) and need only
+ *      per-image sums of the output gradient over the map, its border rows/columns and corners (backward).  tot[n][co] =
+ *      per-image column sums of dz (mliis_colsum with nseg = N).  dpool = (dL/dpool) / (H*W). */
+int mliis_rsd_pool_fwd(const float* pool, const float* w, float* border_bias, int N, int Cp, int Cin_total, int c_begin, int Co,
+                       hipStream_t stream);
+size_t mliis_rsd_pool_bwd_workspace_floats(int N, int Co);
+int mliis_rsd_pool_bwd(const float* dz, int lddz, const float* tot, const float* pool, const float* w, float* dw, float* dbias,
+                       float* dpool, int N, int H, int W, int Cp, int Cin_total, int c_begin, int Co, float* ws, size_t ws_floats,
+                       hipStream_t stream);
 
 /* ---- batch norm, training mode (TpuBatchNormalization, models/efficientnet/utils.py:87-134; tf.layers.batch_normalization,
  *      models/efficientlab.py:190).  pre_swish: statistics/normalisation act on swish(x) (decoder order conv->swish->BN);

@@ -446,14 +446,16 @@ __global__ __launch_bounds__(256) void sum_finalize_k(const float* __restrict__ 
 }
 
 __global__ __launch_bounds__(256) void fold_flat_k(const float* __restrict__ part, int nblk, long long total, float scale,
-                                                   float* __restrict__ out, int accumulate) {
+                                                   float* __restrict__ out, int accumulate, long long seg_len, long long seg_stride,
+                                                   long long seg_off) {
   __shared__ double sm[kFoldY * (kFoldX + 1)];
   const long long i = (long long)blockIdx.x * kFoldX + threadIdx.x;
   const bool ok = i < total;
   const double s = fold_partials(part, nblk, total, i, ok, sm);
   if (!ok || threadIdx.y != 0) return;
   const float r = (float)(s * (double)scale);
-  out[i] = accumulate ? out[i] + r : r;
+  const long long o = (i / seg_len) * seg_stride + seg_off + i % seg_len;
+  out[o] = accumulate ? out[o] + r : r;
 }
 
 static inline int ew_grid(long long total_quads) {

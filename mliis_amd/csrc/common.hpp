@@ -75,8 +75,10 @@ __device__ __forceinline__ double fold_partials(const float* __restrict__ part, 
   return r;
 }
 
-// out[i] (+)= scale * sum_z part[z * total + i]
+// out[map(i)] (+)= scale * sum_z part[z * total + i], map(i) = (i / seg_len) * seg_stride + seg_off + i % seg_len
+// (seg_len = total, seg_off = 0 for a dense output; the segmented form writes a channel window of a larger weight tensor)
 __global__ __launch_bounds__(256) void fold_flat_k(const float* __restrict__ part, int nblk, long long total, float scale,
-                                                   float* __restrict__ out, int accumulate);
+                                                   float* __restrict__ out, int accumulate, long long seg_len, long long seg_stride,
+                                                   long long seg_off);
 
 }  // namespace mliis

@@ -48,6 +48,9 @@ struct ConvGemmParams {
   int stats_swish;       //             stored values (of swish(value) when stats_swish) for the following batch norm
   const float* a_scale;  // non-null => A[m][c] is multiplied by a_scale[image(m)][c] while it is staged (squeeze-excite gate
                          //             applied on the fly: the gated activation tensor is never materialised)
+  const float* border_bias;  // non-null => [Nimg][9][Nout] added per output pixel by its border class 3*rowclass + colclass
+                             //             (0 = first, 1 = interior, 2 = last): the contribution of spatially CONSTANT input
+                             //             channels of a 3x3 SAME conv (the RSD pooled branch) without convolving them
 };
 
 template <int TM, int NT, bool B_NK>
@@ -244,13 +247,32 @@ __global__ __launch_bounds__(256) void conv_gemm_k(ConvGemmParams p) {
       const int n = n0 + j * 16 + l15;
       bj[j] = (p.bias != nullptr && n < p.Nout) ? p.bias[n] : 0.f;
     }
+    const long long HWp = (long long)p.H * p.W;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const long long mbase = m0 + wave * 16 * TM + i * 16;
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
+      for (int r = 0; r < 4; ++r) {
+        const float* bb = nullptr;
+        if (p.border_bias != nullptr) {
+          const long long m = mbase + g * 4 + r;
+          if (m < M) {
+            const int ni = (int)(m / HWp);
+            const int rem = (int)(m - (long long)ni * HWp);
+            const int h = rem / p.W, w_ = rem - h * p.W;
+            const int cls = (h == 0 ? 0 : (h == p.H - 1 ? 2 : 1)) * 3 + (w_ == 0 ? 0 : (w_ == p.W - 1 ? 2 : 1));
+            bb = p.border_bias + ((long long)ni * 9 + cls) * p.Nout;
+          }
+        }
 #pragma unroll
-        for (int j = 0; j < NT; ++j) stage[(g * 4 + r) * LDS_STAGE + j * 16 + l15] = acc[i][j][r] + bj[j];
+        for (int j = 0; j < NT; ++j) {
+          const int n = n0 + j * 16 + l15;
+          float v = acc[i][j][r] + bj[j];
+          if (bb != nullptr && n < p.Nout) v += bb[n];
+          acc[i][j][r] = v;   // keep the final value for the statistics below
+          stage[(g * 4 + r) * LDS_STAGE + j * 16 + l15] = v;
+        }
+      }
       __syncthreads();
 #pragma unroll
       for (int it = 0; it < NT; ++it) {
@@ -276,7 +298,7 @@ __global__ __launch_bounds__(256) void conv_gemm_k(ConvGemmParams p) {
           if (m >= M) continue;
 #pragma unroll
           for (int j = 0; j < NT; ++j) {
-            const float v = acc[i][j][r] + bj[j];
+            const float v = acc[i][j][r];
             const float u = p.stats_swish ? swish_f(v) : v;
             s1[j] += u;
             s2[j] = fmaf(u, u, s2[j]);
@@ -572,11 +594,11 @@ static inline FilterPlan plan_filter(long long M, int C, int Nout, int ntaps, in
   f.gx = ntaps * ((C + bci - 1) / bci);
   long long base = (long long)f.gx * f.gy;
   long long want = (3LL * num_cus + base - 1) / base;  // ~3 blocks per CU in total ...
-  {                                                    // ... bounded by the slab bytes the fold has to read (<= 8 MB, <= 512 slabs)
+  {  // ... bounded by the slab count the fold has to read: 96 in general, up to 512 for tiny filters (fold cost ~ slabs * size)
     const long long total = (long long)ntaps * C * Nout;
-    long long cap = (2LL << 20) / (total > 0 ? total : 1);
+    long long cap = (1LL << 19) / (total > 0 ? total : 1);
     if (cap > 512) cap = 512;
-    if (cap < 8) cap = 8;
+    if (cap < 96) cap = 96;
     if (want > cap) want = cap;
   }
   if (want < 1) want = 1;
@@ -660,9 +682,10 @@ size_t mliis_conv2d_workspace_floats(int Nimg, int H, int W, int Cred, int Nout,
 }
 
 // y[M, Cout] (ld = ldy) (+)= conv(x[M, Cin] (ld = ldx), w[k,k,Cin,Cout]) + bias ; stride 1, TF-SAME, dilation dil
-int mliis_conv2d_fwd(const float* x, int ldx, const float* x_scale, const float* w, const float* wt, const float* bias, float* y, int ldy,
-                     int Nimg, int H, int W, int Cin, int Cout, int ksize, int dil, int accumulate, float* stats_part, int stats_swish,
-                     int* stats_nblk, float* ws, size_t ws_floats, hipStream_t stream) {
+int mliis_conv2d_fwd(const float* x, int ldx, const float* x_scale, const float* w, const float* wt, const float* bias,
+                     const float* border_bias, float* y, int ldy, int Nimg, int H, int W, int Cin_total, int ci_begin, int Cin, int Cout,
+                     int ksize, int dil, int accumulate, float* stats_part, int stats_swish, int* stats_nblk, float* ws,
+                     size_t ws_floats, hipStream_t stream) {
   int rc = conv_check("conv2d_fwd", Nimg, H, W, Cin, Cout, ksize, dil);
   if (rc) return rc;
   MLIIS_REQUIRE(x && (w || wt) && y, MLIIS_ERR_ARG, "conv2d_fwd: null pointer");
@@ -671,9 +694,14 @@ int mliis_conv2d_fwd(const float* x, int ldx, const float* x_scale, const float*
   MLIIS_REQUIRE(aligned16(x) && aligned16(w) && aligned16(bias) && aligned16(y), MLIIS_ERR_ALIGN,
                 "conv2d_fwd: pointers must be 16-byte aligned");
   long long M = (long long)Nimg * H * W;
-  GemmPlan g = plan_gemm(M, Cout, Cin, ksize * ksize, num_cus(), ws != nullptr);
-  ConvGemmParams p{x, ldx, Nimg, H, W, Cin, ksize * ksize, dil, +1, w, (long long)Cin * Cout, Cout, Cout, y, ldy, bias, accumulate,
-                   nullptr, g.chunks_per_split, nullptr, 0, x_scale};
+  GemmPlan g = plan_gemm(M, Cout, Cin, ksize * ksize, num_cus(), ws != nullptr && border_bias == nullptr);
+  MLIIS_REQUIRE(ci_begin >= 0 && (ci_begin & 3) == 0 && ci_begin + Cin <= Cin_total, MLIIS_ERR_ARG,
+                "conv2d_fwd: input-channel window out of range");
+  MLIIS_REQUIRE(border_bias == nullptr || (ksize == 3 && dil == 1 && H >= 2 && W >= 2 && aligned16(border_bias)), MLIIS_ERR_ARG,
+                "conv2d_fwd: border_bias needs a 3x3 dilation-1 conv on a map of at least 2x2");
+  ConvGemmParams p{x, ldx, Nimg, H, W, Cin, ksize * ksize, dil, +1, w ? w + (long long)ci_begin * Cout : nullptr,
+                   (long long)Cin_total * Cout, Cout, Cout, y, ldy, bias, accumulate, nullptr, g.chunks_per_split, nullptr, 0, x_scale,
+                   border_bias};
   MLIIS_REQUIRE(aligned16(x_scale) && (x_scale == nullptr || ksize == 1), MLIIS_ERR_ARG,
                 "conv2d_fwd: x_scale must be 16-byte aligned and is only supported for 1x1 convs");
   if (stats_nblk) *stats_nblk = 0;
@@ -690,8 +718,8 @@ int mliis_conv2d_fwd(const float* x, int ldx, const float* x_scale, const float*
     p.partial = ws;
   }
   if (wt != nullptr) {  // K-contiguous shadow weights [k,k,Cout,Cin]: forward on the b128-fragment B path
-    p.B = wt;
-    p.ldb = Cin;
+    p.B = wt + ci_begin;
+    p.ldb = Cin_total;
     launch_gemm<true>(g, p, stream);
   } else {
     launch_gemm<false>(g, p, stream);
@@ -721,7 +749,7 @@ int mliis_conv2d_bwd_data(const float* dy, int lddy, const float* w, float* dx, 
   long long M = (long long)Nimg * H * W;
   GemmPlan g = plan_gemm(M, Cin_out, Cout, ksize * ksize, num_cus(), ws != nullptr);
   ConvGemmParams p{dy, lddy, Nimg, H, W, Cout, ksize * ksize, dil, -1, w + (long long)ci_begin * Cout, (long long)Cin_total * Cout,
-                   Cout, Cin_out, dx, lddx, nullptr, accumulate, nullptr, g.chunks_per_split, nullptr, 0, nullptr};
+                   Cout, Cin_out, dx, lddx, nullptr, accumulate, nullptr, g.chunks_per_split, nullptr, 0, nullptr, nullptr};
   if (g.gz > 1) {
     size_t need = (size_t)g.gz * M * Cin_out;
     MLIIS_REQUIRE(need <= ws_floats && aligned16(ws) && (lddx & 3) == 0 && aligned16(dx), MLIIS_ERR_WORKSPACE,
@@ -755,7 +783,8 @@ size_t mliis_conv2d_bwd_filter_workspace_floats(int Nimg, int H, int W, int Cin,
 
 // dw[k,k,Cin,Cout] (+)= sum_pixels x[pixel + tap offset, ci] * dy[pixel, co]
 int mliis_conv2d_bwd_filter(const float* x, int ldx, const float* x_scale, const float* dy, int lddy, float* dw, int Nimg, int H, int W,
-                            int Cin, int Cout, int ksize, int dil, int accumulate, float* ws, size_t ws_floats, hipStream_t stream) {
+                            int Cin_total, int ci_begin, int Cin, int Cout, int ksize, int dil, int accumulate, float* ws,
+                            size_t ws_floats, hipStream_t stream) {
   int rc = conv_check("conv2d_bwd_filter", Nimg, H, W, Cin, Cout, ksize, dil);
   if (rc) return rc;
   MLIIS_REQUIRE(x && dy && dw && ws, MLIIS_ERR_ARG, "conv2d_bwd_filter: null pointer");
@@ -770,8 +799,9 @@ int mliis_conv2d_bwd_filter(const float* x, int ldx, const float* x_scale, const
   FilterGradParams p{x, ldx, Nimg, H, W, Cin, ksize * ksize, dil, dy, lddy, Cout, ws, f.rows_per_split, x_scale};
   launch_filter(f, p, stream);
   MLIIS_CHECK_LAUNCH("conv2d_bwd_filter");
+  MLIIS_REQUIRE(ci_begin >= 0 && ci_begin + Cin <= Cin_total, MLIIS_ERR_ARG, "conv2d_bwd_filter: input-channel window out of range");
   hipLaunchKernelGGL(fold_flat_k, dim3(ceil_div((long long)total, kFoldX)), dim3(kFoldX, kFoldY), 0, stream, ws, f.gz, (long long)total, 1.0f, dw,
-                     accumulate);
+                     accumulate, (long long)Cin * Cout, (long long)Cin_total * Cout, (long long)ci_begin * Cout);
   MLIIS_CHECK_LAUNCH("conv2d_bwd_filter_reduce");
   return MLIIS_OK;
 }

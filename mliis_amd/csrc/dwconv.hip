@@ -281,7 +281,7 @@ int mliis_dwconv_bwd_filter(const float* x, const float* dy, float* dw, int N, i
   DW_DISPATCH(dwconv_bwd_filter_k, x, dy, ws, N, H, W, g.Ho, g.Wo, C, g.pt, g.pl, f.QB, f.RP, f.items_per_block);
   MLIIS_CHECK_LAUNCH("dwconv_bwd_filter");
   hipLaunchKernelGGL(fold_flat_k, dim3(ceil_div(k * k * C, kFoldX)), dim3(kFoldX, kFoldY), 0, stream, ws, f.nblk, (long long)k * k * C, 1.0f,
-                     dw, 0);
+                     dw, 0, (long long)k * k * C, 0LL, 0LL);
   MLIIS_CHECK_LAUNCH("dwconv_bwd_filter_finalize");
   return MLIIS_OK;
 }

@@ -179,7 +179,7 @@ int mliis_stem_conv_bwd_filter(const float* x, const int* img_idx, const float* 
   hipLaunchKernelGGL(stem_bwd_filter_k, dim3(nblk), dim3(256), 0, stream, x, img_idx, dz, ws, N, H, W, g.Ho, g.Wo, Co,
                      g.pt, g.pl, nm, ppb);
   MLIIS_CHECK_LAUNCH("stem_conv_bwd_filter");
-  hipLaunchKernelGGL(fold_flat_k, dim3(ceil_div(27 * Co, kFoldX)), dim3(kFoldX, kFoldY), 0, stream, ws, nblk, (long long)27 * Co, 1.0f, dw, 0);
+  hipLaunchKernelGGL(fold_flat_k, dim3(ceil_div(27 * Co, kFoldX)), dim3(kFoldX, kFoldY), 0, stream, ws, nblk, (long long)27 * Co, 1.0f, dw, 0, (long long)27 * Co, 0LL, 0LL);
   MLIIS_CHECK_LAUNCH("stem_conv_bwd_filter_finalize");
   return MLIIS_OK;
 }

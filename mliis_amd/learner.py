@@ -79,10 +79,11 @@ class _Plan:
             D["cat"] = buf(N, h, h, m.c_cat)
             D["z0"], D["z1"], D["zf"] = buf(N, h, h, m.c_out), buf(N, h, h, m.c_out), buf(N, h, h, m.c_out)
             D["st0"], D["st1"], D["stf"] = vec(m.c_out), vec(m.c_out), vec(m.c_out)
-            D["pyr"] = buf(N, h, h, m.c_pyr)
+            D["pyr"] = buf(N, h, h, 2 * m.c_out)        # the pooled third of the reference's "pyramid" is never materialised
             D["pool"], D["dpool"] = buf(N, m.c_cat), buf(N, m.c_cat)
+            D["bbias"], D["tot"] = buf(N, 9, m.c_out), buf(N, m.c_out)
             D["out"], D["dout"] = buf(N, h, h, m.c_out), buf(N, h, h, m.c_out)
-            D["dzf"], D["dpyr"], D["dcat"] = buf(N, h, h, m.c_out), buf(N, h, h, m.c_pyr), buf(N, h, h, m.c_cat)
+            D["dzf"], D["dpyr"], D["dcat"] = buf(N, h, h, m.c_out), buf(N, h, h, 2 * m.c_out), buf(N, h, h, m.c_cat)
             self.rsd.append(D)
         hd = a.h_dec
         self.small, self.dsmall = buf(N, hd, hd, 2), buf(N, hd, hd, 2)
@@ -309,12 +310,13 @@ class Learner:
 
         ops.transpose_weights(A.theta, self.theta_t, self.wt_desc)
 
-        def conv(xin, wname, bname, dil, out, swish_stats, x_scale=None):
+        def conv(xin, wname, bname, dil, out, swish_stats, x_scale=None, border_bias=None):
             """dense conv; in training the epilogue also emits the following BN's statistics (returns their block count)."""
             if training:
                 return ops.conv2d_fwd(xin, w[wname], w[bname] if bname else None, dil, out=out, ws=ws, stats_part=P.stats_part,
-                                      stats_swish=swish_stats, wt=self.wt[wname], x_scale=x_scale)[1]
-            ops.conv2d_fwd(xin, w[wname], w[bname] if bname else None, dil, out=out, ws=ws, wt=self.wt[wname], x_scale=x_scale)
+                                      stats_swish=swish_stats, wt=self.wt[wname], x_scale=x_scale, border_bias=border_bias)[1]
+            ops.conv2d_fwd(xin, w[wname], w[bname] if bname else None, dil, out=out, ws=ws, wt=self.wt[wname], x_scale=x_scale,
+                           border_bias=border_bias)
             return 0
 
         ops.stem_conv_fwd(x, w[self.n_stem[0]], idx, out=P.z_stem)
@@ -354,9 +356,10 @@ class Learner:
             bn(D["z0"], D["st0"], n0, pyr[..., :m.c_out], pre=True, fused=True, nblk=nb)
             nb = conv(cat, k1, b1, 2, D["z1"], True)
             bn(D["z1"], D["st1"], n1, pyr[..., m.c_out:2 * m.c_out], pre=True, fused=True, nblk=nb)
+            # pooled branch: per-image mean of `cat`, folded into the fuse conv as a border-class bias (rsd.hip)
             ops.colsum(cat, None, nseg=N, scale=1.0 / (m.h * m.h), out=D["pool"], ws=ws)
-            ops.chan_affine(None, A=D["pool"], out=pyr[..., 2 * m.c_out:])
-            nb = conv(pyr, kf, bf, 1, D["zf"], True)
+            ops.rsd_pool_fwd(D["pool"], w[kf], 2 * m.c_out, out=D["bbias"])
+            nb = conv(pyr, kf, bf, 1, D["zf"], True, border_bias=D["bbias"])
             dec = bn(D["zf"], D["stf"], nf, D["out"], pre=True, res=up, fused=True, nblk=nb)
         mask = P.drop_mask if (training and P.drop_mask is not None) else None
         P.dec_in = dec
@@ -391,9 +394,10 @@ class Learner:
             co, hw = m.c_out, m.h * m.h
             dO, cat, pyr, dpyr, dcat = D["dout"], D["cat"], D["pyr"], D["dpyr"], D["dcat"]
             bn_b(D["zf"], dO, D["stf"], nf, D["dzf"], pre=True)
-            ops.colsum(D["dzf"], None, out=g[bf].view(1, -1), ws=ws)
-            ops.conv2d_bwd_filter(pyr, D["dzf"], 3, 1, out=g[kf], ws=ws)
-            ops.conv2d_bwd_data(D["dzf"], w[kf], 1, out=dpyr, ws=ws)
+            ops.colsum(D["dzf"], None, nseg=N, out=D["tot"], ws=ws)
+            ops.rsd_pool_bwd(D["dzf"], D["tot"], D["pool"], w[kf], 2 * co, dw=g[kf], dbias=g[bf], dpool=D["dpool"], ws=ws)
+            ops.conv2d_bwd_filter(pyr, D["dzf"], 3, 1, out=g[kf], ws=ws)          # rows of the 2*co convolved channels
+            ops.conv2d_bwd_data(D["dzf"], w[kf], 1, ci_begin=0, ci_count=2 * co, out=dpyr, ws=ws)
             d0, d1 = dpyr[..., :co], dpyr[..., co:2 * co]
             bn_b(D["z0"], d0, D["st0"], n0, d0, pre=True)
             ops.colsum(d0, None, out=g[b0].view(1, -1), ws=ws)
@@ -403,8 +407,7 @@ class Learner:
             ops.colsum(d1, None, out=g[b1].view(1, -1), ws=ws)
             ops.conv2d_bwd_filter(cat, d1, 3, 2, out=g[k1], ws=ws)
             ops.conv2d_bwd_data(d1, w[k1], 2, out=dcat, accumulate=True, ws=ws)
-            ops.colsum(dpyr[..., 2 * co:], None, nseg=N, scale=1.0 / hw, out=D["dpool"], ws=ws)
-            ops.chan_affine(None, A=D["dpool"], out=dcat, accumulate=True)
+            ops.chan_affine(None, A=D["dpool"], out=dcat, accumulate=True)   # d(mean)/d(cat) = dpool / (H*W) on every pixel
             # dU = dO + dcat[:, :c_deep] (residual);  dS = dcat[:, c_deep:]
             ops.chan_affine(dcat[..., :m.c_deep], out=dO, accumulate=True)
             # gradient w.r.t. the deep input

@@ -170,14 +170,14 @@ def transpose_weights(src, dst, desc):
 
 
 def conv2d_fwd(x, w, bias=None, dil=1, out=None, accumulate=False, ws: Optional[Workspace] = None, nhw=None, stats_part=None,
-               stats_swish=False, wt=None, x_scale=None):
+               stats_swish=False, wt=None, x_scale=None, border_bias=None, ci_begin=0):
     """x: [N,H,W,>=Cin] view (channel slice allowed); w: [k,k,Cin,Cout].  With stats_part (a float buffer) the epilogue also emits
     the next batch norm's stage-1 statistics and the function returns (out, nblk); nblk == 0 means they were not produced."""
     N, H, W = nhw if nhw is not None else x.shape[:3]
-    k, _, Cin, Cout = w.shape
-    rows, cx, ldx = rows_ld(x)
-    if cx != Cin:
-        raise MliisError("conv2d_fwd: x has {} channels, weight expects {}".format(cx, Cin))
+    k, _, Cin_total, Cout = w.shape
+    rows, Cin, ldx = rows_ld(x)
+    if ci_begin + Cin > Cin_total:
+        raise MliisError("conv2d_fwd: x has {} channels, weight has {} (window starts at {})".format(Cin, Cin_total, ci_begin))
     out = torch.empty((N, H, W, Cout), dtype=torch.float32, device=x.device) if out is None else out
     _, co, ldy = rows_ld(out)
     ws = ws or default_ws()
@@ -190,7 +190,8 @@ def conv2d_fwd(x, w, bias=None, dil=1, out=None, accumulate=False, ws: Optional[
     nblk = C.c_int(0)
     if stats_part is not None and stats_part.numel() < (-(-N * H * W // 64)) * 2 * Cout:
         raise MliisError("conv2d_fwd: stats_part too small")
-    _timed("conv2d_fwd", meta, lambda: lib.call("mliis_conv2d_fwd", _ptr(x), ldx, _ptr(x_scale), _ptr(w), _ptr(wt), _ptr(bias), _ptr(out), ldy, N, H, W, Cin, Cout, k,
+    _timed("conv2d_fwd", meta, lambda: lib.call("mliis_conv2d_fwd", _ptr(x), ldx, _ptr(x_scale), _ptr(w), _ptr(wt), _ptr(bias), _ptr(border_bias), _ptr(out), ldy, N, H, W,
+                                                Cin_total, ci_begin, Cin, Cout, k,
                                                 dil, int(accumulate), _ptr(stats_part), int(stats_swish), C.byref(nblk), _ptr(buf),
                                                 buf.numel(), _stream()))
     if stats_part is not None:
@@ -219,17 +220,42 @@ def conv2d_bwd_data(dy, w, dil=1, ci_begin=0, ci_count=None, out=None, accumulat
     return out
 
 
-def conv2d_bwd_filter(x, dy, k, dil=1, out=None, accumulate=False, ws: Optional[Workspace] = None, x_scale=None):
+def conv2d_bwd_filter(x, dy, k, dil=1, out=None, accumulate=False, ws: Optional[Workspace] = None, x_scale=None, ci_begin=0):
+    """Writes rows [ci_begin, ci_begin + x.channels) of `out` ([k,k,Cin_total,Cout]; Cin_total = x.channels when out is None)."""
     N, H, W = dy.shape[:3]
     _, Cin, ldx = rows_ld(x)
     _, Cout, lddy = rows_ld(dy)
     out = torch.empty((k, k, Cin, Cout), dtype=torch.float32, device=x.device) if out is None else out
+    Cin_total = out.shape[2]
     ws = ws or default_ws()
     buf = ws.get(lib.size("mliis_conv2d_bwd_filter_workspace_floats", N, H, W, Cin, Cout, k))
     meta = dict(flops=2.0 * N * H * W * k * k * Cin * Cout, shape=(N, H, W, Cin, Cout, k, dil)) if PROFILE is not None else {}
-    _timed("conv2d_bwd_filter", meta, lambda: lib.call("mliis_conv2d_bwd_filter", _ptr(x), ldx, _ptr(x_scale), _ptr(dy), lddy, _ptr(out), N, H, W, Cin, Cout, k,
+    _timed("conv2d_bwd_filter", meta, lambda: lib.call("mliis_conv2d_bwd_filter", _ptr(x), ldx, _ptr(x_scale), _ptr(dy), lddy, _ptr(out), N, H, W, Cin_total, ci_begin,
+                                                       Cin, Cout, k,
                                                        dil, int(accumulate), _ptr(buf), buf.numel(), _stream()))
     return out
+
+
+def rsd_pool_fwd(pool, w, c_begin, out=None):
+    """border-class bias [N,9,Cout] of the constant channels [c_begin, c_begin+Cp) of a 3x3 conv with weights w."""
+    N, Cp = pool.shape
+    _, _, Cin_total, Co = w.shape
+    out = torch.empty((N, 9, Co), dtype=torch.float32, device=pool.device) if out is None else out
+    lib.call("mliis_rsd_pool_fwd", _ptr(pool), _ptr(w), _ptr(out), N, Cp, Cin_total, c_begin, Co, _stream())
+    return out
+
+
+def rsd_pool_bwd(dz, tot, pool, w, c_begin, dw, dbias=None, dpool=None, ws: Optional[Workspace] = None):
+    N, H, W = dz.shape[:3]
+    _, Co, lddz = rows_ld(dz)
+    Cp = pool.shape[1]
+    Cin_total = w.shape[2]
+    dpool = torch.empty((N, Cp), dtype=torch.float32, device=dz.device) if dpool is None else dpool
+    ws = ws or default_ws()
+    buf = ws.get(lib.size("mliis_rsd_pool_bwd_workspace_floats", N, Co))
+    lib.call("mliis_rsd_pool_bwd", _ptr(dz), lddz, _ptr(tot), _ptr(pool), _ptr(w), _ptr(dw), _ptr(dbias), _ptr(dpool), N, H, W, Cp, Cin_total,
+             c_begin, Co, _ptr(buf), buf.numel(), _stream())
+    return dpool
 
 
 # ------------------------------------------------------------------------------------------------ batch norm

@@ -391,3 +391,34 @@ def test_conv1x1_with_se_gate_on_the_fly(H, W, Cin, Cout, N):
     close(ops.conv2d_fwd(xg, wg, None, 1, x_scale=gg), nhwc(y), 2e-5, "gated conv (HWIO weights)")
     close(ops.conv2d_fwd(xg, wg, None, 1, x_scale=gg, wt=wt), nhwc(y), 2e-5, "gated conv (shadow weights)")
     close(ops.conv2d_bwd_filter(xg, f32(nhwc(dy), d), 1, 1, x_scale=gg), gw, 1e-4, "gated filter grad")
+
+
+@pytest.mark.parametrize("H,W,Cc,Cp,Co,N", [(14, 14, 224, 224, 112, 2), (9, 12, 48, 24, 16, 3), (56, 56, 224, 136, 112, 2), (2, 2, 16, 8, 16, 2)])
+def test_rsd_pooled_branch_as_border_bias(H, W, Cc, Cp, Co, N):
+    """3x3 conv over [convolved Cc channels | Cp spatially-constant channels] == conv over the Cc channels + per-border-class
+    bias; gradients of the constant channels / their weight rows from per-image border sums (rsd.hip)."""
+    from mliis_amd import ops
+    d = dev()
+    xc = rnd(N, H, W, Cc, seed=70).requires_grad_(True)
+    pool = rnd(N, Cp, seed=71).requires_grad_(True)
+    w = rnd(3, 3, Cc + Cp, Co, seed=72, scale=1.0 / math.sqrt(9 * (Cc + Cp))).requires_grad_(True)
+    b = rnd(Co, seed=73).requires_grad_(True)
+    full = torch.cat([xc, pool[:, None, None, :].expand(N, H, W, Cp)], dim=-1)
+    z = nhwc(R.conv2d_same(nchw(full), w, 1, 1, bias=b))
+    dz = rnd(*z.shape, seed=74)
+    gx, gp, gw, gb = torch.autograd.grad(z, [xc, pool, w, b], dz)
+    xg, pg, wg, bg, dzg = f32(xc, d), f32(pool, d), f32(w, d), f32(b, d), f32(dz, d)
+    wt = wg.permute(0, 1, 3, 2).contiguous().view(-1)
+    E = ops.rsd_pool_fwd(pg, wg, Cc)
+    for kw in (dict(), dict(wt=wt)):
+        close(ops.conv2d_fwd(xg, wg, bg, 1, border_bias=E, **kw), z, 2e-5, "fwd with border bias")
+    dw = torch.full((3, 3, Cc + Cp, Co), float("nan"), device=d)
+    db = torch.empty(Co, device=d)
+    tot = ops.colsum(dzg, None, nseg=N)
+    dpool = ops.rsd_pool_bwd(dzg, tot, pg, wg, Cc, dw=dw, dbias=db)
+    ops.conv2d_bwd_filter(xg, dzg, 3, 1, out=dw)
+    assert not torch.isnan(dw).any()
+    close(dw, gw, 1e-4, "dw (convolved + constant rows)")
+    close(db, gb, 1e-4, "dbias")
+    close(dpool * (H * W), gp, 1e-4, "dpool")
+    close(ops.conv2d_bwd_data(dzg, wg, 1, ci_begin=0, ci_count=Cc), gx, 1e-4, "dx of the convolved channels")
