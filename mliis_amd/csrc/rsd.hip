@@ -15,73 +15,88 @@ __device__ __forceinline__ bool tap_valid(int t3, int cls3) {  // t3: 0,1,2 <-> 
   return !((t3 == 0 && cls3 == 0) || (t3 == 2 && cls3 == 2));
 }
 
-// one workgroup per image
-__global__ __launch_bounds__(256) void rsd_pool_fwd_k(const float* __restrict__ pool, const float* __restrict__ w,
-                                                      float* __restrict__ E, int Cp, int Cin_total, int c_begin, int Co) {
-  extern __shared__ float T[];  // [9][Co]
-  const int n = blockIdx.x;
+constexpr int kRsdThreads = 1024;
+
+// grid (N, 9 border classes); threads = (co, c-lane): E[n][cls][co] = sum_c pool[n][c] * sum_{taps valid in cls} W[tap][c][co]
+__global__ __launch_bounds__(kRsdThreads) void rsd_pool_fwd_k(const float* __restrict__ pool, const float* __restrict__ w,
+                                                              float* __restrict__ E, int Cp, int Cin_total, int c_begin, int Co) {
+  __shared__ float red[kRsdThreads];
+  const int n = blockIdx.x, cls = blockIdx.y;
+  const int rc = cls / 3, cc = cls - rc * 3;
+  const int CL = kRsdThreads / Co;
+  const int co = threadIdx.x % Co, cl = threadIdx.x / Co;
   const float* pn = pool + (long long)n * Cp;
-  for (int idx = threadIdx.x; idx < 9 * Co; idx += 256) {
-    const int tap = idx / Co, co = idx - tap * Co;
-    const float* wp = w + ((long long)tap * Cin_total + c_begin) * Co + co;
-    float a = 0.f;
-    for (int c = 0; c < Cp; ++c) a = fmaf(pn[c], wp[(long long)c * Co], a);
-    T[idx] = a;
-  }
+  float a = 0.f;
+  if (cl < CL)
+    for (int c = cl; c < Cp; c += CL) {
+      float ws = 0.f;
+#pragma unroll
+      for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+        for (int tx = 0; tx < 3; ++tx)
+          if (tap_valid(ty, rc) && tap_valid(tx, cc)) ws += w[((long long)(ty * 3 + tx) * Cin_total + c_begin + c) * Co + co];
+      a = fmaf(pn[c], ws, a);
+    }
+  red[threadIdx.x] = a;
   __syncthreads();
-  for (int idx = threadIdx.x; idx < 9 * Co; idx += 256) {
-    const int cls = idx / Co, co = idx - cls * Co;
-    const int rc = cls / 3, cc = cls - rc * 3;
-    float a = 0.f;
-#pragma unroll
-    for (int ty = 0; ty < 3; ++ty)
-#pragma unroll
-      for (int tx = 0; tx < 3; ++tx)
-        if (tap_valid(ty, rc) && tap_valid(tx, cc)) a += T[(ty * 3 + tx) * Co + co];
-    E[((long long)n * 9 + cls) * Co + co] = a;
+  if (threadIdx.x < Co) {
+    float r = 0.f;
+    for (int k = 0; k < CL; ++k) r += red[k * Co + threadIdx.x];
+    E[((long long)n * 9 + cls) * Co + threadIdx.x] = r;
   }
 }
 
-// G[n][tap][co] = sum of dz over the pixels at which `tap` reads inside the map = Tot - excluded row - excluded column + corner
-__global__ __launch_bounds__(256) void rsd_pool_gsum_k(const float* __restrict__ dz, int ld, const float* __restrict__ tot,
-                                                       float* __restrict__ G, int H, int W, int Co) {
-  const int n = blockIdx.x;
+// grid (N, 4): border sums of dz: part 0 = first row, 1 = last row, 2 = first column, 3 = last column.  B[n][part][co]
+__global__ __launch_bounds__(kRsdThreads) void rsd_border_sums_k(const float* __restrict__ dz, int ld, float* __restrict__ B, int H, int W,
+                                                                 int Co) {
+  __shared__ float red[kRsdThreads];
+  const int n = blockIdx.x, part = blockIdx.y;
+  const int CL = kRsdThreads / Co;
+  const int co = threadIdx.x % Co, cl = threadIdx.x / Co;
   const float* d = dz + (long long)n * H * W * ld;
-  for (int co = threadIdx.x; co < Co; co += 256) {
-    float r0 = 0.f, rh = 0.f, c0 = 0.f, cw = 0.f;
-    for (int x = 0; x < W; ++x) {
-      r0 += d[(long long)x * ld + co];
-      rh += d[((long long)(H - 1) * W + x) * ld + co];
+  const int len = part < 2 ? W : H;
+  float a = 0.f;
+  if (cl < CL)
+    for (int i = cl; i < len; i += CL) {
+      long long pix;
+      if (part == 0) pix = i;
+      else if (part == 1) pix = (long long)(H - 1) * W + i;
+      else if (part == 2) pix = (long long)i * W;
+      else pix = (long long)i * W + W - 1;
+      a += d[pix * ld + co];
     }
-    for (int y = 0; y < H; ++y) {
-      c0 += d[((long long)y * W) * ld + co];
-      cw += d[((long long)y * W + W - 1) * ld + co];
-    }
-    const float k00 = d[co], k0w = d[(long long)(W - 1) * ld + co], kh0 = d[((long long)(H - 1) * W) * ld + co],
-                khw = d[((long long)(H - 1) * W + W - 1) * ld + co];
-    const float t = tot[(long long)n * Co + co];
-#pragma unroll
-    for (int ty = 0; ty < 3; ++ty)
-#pragma unroll
-      for (int tx = 0; tx < 3; ++tx) {
-        // tap offset -1 reads above/left: invalid on the first row/col; offset +1 invalid on the last row/col
-        const float rex = ty == 0 ? r0 : (ty == 2 ? rh : 0.f);
-        const float cex = tx == 0 ? c0 : (tx == 2 ? cw : 0.f);
-        float cor = 0.f;
-        if (ty == 0 && tx == 0) cor = k00;
-        if (ty == 0 && tx == 2) cor = k0w;
-        if (ty == 2 && tx == 0) cor = kh0;
-        if (ty == 2 && tx == 2) cor = khw;
-        G[((long long)n * 9 + ty * 3 + tx) * Co + co] = t - rex - cex + cor;
-      }
+  red[threadIdx.x] = a;
+  __syncthreads();
+  if (threadIdx.x < Co) {
+    float r = 0.f;
+    for (int k = 0; k < CL; ++k) r += red[k * Co + threadIdx.x];
+    B[((long long)n * 4 + part) * Co + threadIdx.x] = r;
   }
 }
 
-// element-parallel: [0, 9*Cp*Co) weight-gradient rows, then N*Cp pooled-input gradients, then Co bias gradients
-__global__ __launch_bounds__(256) void rsd_pool_bwd_k(const float* __restrict__ G, const float* __restrict__ tot,
-                                                      const float* __restrict__ pool, const float* __restrict__ w,
-                                                      float* __restrict__ dw, float* __restrict__ dbias, float* __restrict__ dpool,
-                                                      int N, int Cp, int Cin_total, int c_begin, int Co, float inv_hw) {
+// G[n][tap][co] = Tot - excluded row - excluded column + corner      (one thread per element)
+__global__ __launch_bounds__(256) void rsd_gsum_k(const float* __restrict__ dz, int ld, const float* __restrict__ tot,
+                                                  const float* __restrict__ B, float* __restrict__ G, int N, int H, int W, int Co) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N * 9 * Co) return;
+  const int co = i % Co, tap = (i / Co) % 9, n = i / (9 * Co);
+  const int ty = tap / 3, tx = tap - ty * 3;
+  const float* d = dz + (long long)n * H * W * ld;
+  const float* Bn = B + (long long)n * 4 * Co;
+  const float rex = ty == 0 ? Bn[0 * Co + co] : (ty == 2 ? Bn[1 * Co + co] : 0.f);
+  const float cex = tx == 0 ? Bn[2 * Co + co] : (tx == 2 ? Bn[3 * Co + co] : 0.f);
+  float cor = 0.f;
+  if (ty != 1 && tx != 1) {
+    const long long py = ty == 0 ? 0 : H - 1, px = tx == 0 ? 0 : W - 1;
+    cor = d[(py * W + px) * ld + co];
+  }
+  G[i] = tot[(long long)n * Co + co] - rex - cex + cor;
+}
+
+// weight-gradient rows of the constant channels (one thread per element) and the bias gradient
+__global__ __launch_bounds__(256) void rsd_pool_dw_k(const float* __restrict__ G, const float* __restrict__ tot,
+                                                     const float* __restrict__ pool, float* __restrict__ dw, float* __restrict__ dbias,
+                                                     int N, int Cp, int Cin_total, int c_begin, int Co) {
   const long long nW = 9LL * Cp * Co;
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i < nW) {
@@ -91,22 +106,29 @@ __global__ __launch_bounds__(256) void rsd_pool_bwd_k(const float* __restrict__ 
     float a = 0.f;
     for (int n = 0; n < N; ++n) a = fmaf(pool[(long long)n * Cp + c], G[((long long)n * 9 + tap) * Co + co], a);
     dw[((long long)tap * Cin_total + c_begin + c) * Co + co] = a;
-  } else if (i < nW + (long long)N * Cp) {
-    const long long k = i - nW;
-    const int c = (int)(k % Cp), n = (int)(k / Cp);
-    float a = 0.f;
-    for (int tap = 0; tap < 9; ++tap) {
-      const float* wp = w + ((long long)tap * Cin_total + c_begin + c) * Co;
-      const float* gp = G + ((long long)n * 9 + tap) * Co;
-      for (int co = 0; co < Co; ++co) a = fmaf(gp[co], wp[co], a);
-    }
-    dpool[k] = a * inv_hw;
-  } else if (dbias != nullptr && i < nW + (long long)N * Cp + Co) {
-    const int co = (int)(i - nW - (long long)N * Cp);
+  } else if (dbias != nullptr && i < nW + Co) {
+    const int co = (int)(i - nW);
     float a = 0.f;
     for (int n = 0; n < N; ++n) a += tot[(long long)n * Co + co];
     dbias[co] = a;
   }
+}
+
+// dpool[n][c] = inv_hw * sum_tap sum_co G[n][tap][co] * W[tap][c_begin+c][co]      (one wave per (n, c))
+__global__ __launch_bounds__(256) void rsd_pool_dpool_k(const float* __restrict__ G, const float* __restrict__ w, float* __restrict__ dpool,
+                                                        int N, int Cp, int Cin_total, int c_begin, int Co, float inv_hw) {
+  const int wv = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (wv >= N * Cp) return;
+  const int c = wv % Cp, n = wv / Cp;
+  float a = 0.f;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+    const float* wp = w + ((long long)tap * Cin_total + c_begin + c) * Co;
+    const float* gp = G + ((long long)n * 9 + tap) * Co;
+    for (int co = lane; co < Co; co += 64) a = fmaf(gp[co], wp[co], a);
+  }
+  a = wave_sum(a);
+  if (lane == 0) dpool[wv] = a * inv_hw;
 }
 
 }  // namespace mliis
@@ -121,12 +143,12 @@ int mliis_rsd_pool_fwd(const float* pool, const float* w, float* border_bias, in
                        hipStream_t stream) {
   MLIIS_REQUIRE(pool && w && border_bias, MLIIS_ERR_ARG, "rsd_pool_fwd: null pointer");
   MLIIS_REQUIRE(N > 0 && Cp > 0 && Co > 0 && Co <= 1024 && c_begin >= 0 && c_begin + Cp <= Cin_total, MLIIS_ERR_ARG, "rsd_pool_fwd: bad shape");
-  hipLaunchKernelGGL(rsd_pool_fwd_k, dim3(N), dim3(256), 9 * Co * sizeof(float), stream, pool, w, border_bias, Cp, Cin_total, c_begin, Co);
+  hipLaunchKernelGGL(rsd_pool_fwd_k, dim3(N, 9), dim3(kRsdThreads), 0, stream, pool, w, border_bias, Cp, Cin_total, c_begin, Co);
   MLIIS_CHECK_LAUNCH("rsd_pool_fwd");
   return MLIIS_OK;
 }
 
-size_t mliis_rsd_pool_bwd_workspace_floats(int N, int Co) { return (N > 0 && Co > 0) ? (size_t)N * 9 * Co : 0; }
+size_t mliis_rsd_pool_bwd_workspace_floats(int N, int Co) { return (N > 0 && Co > 0) ? (size_t)N * 13 * Co : 0; }
 
 // dz: gradient of the fuse conv output [N,H,W,Co] (row stride lddz); tot[n][co] = per-image column sums of dz.  Writes the
 // weight-gradient rows of the constant channels into dw (full HWIO gradient tensor), dbias (nullable) = sum_n tot, and
@@ -137,11 +159,17 @@ int mliis_rsd_pool_bwd(const float* dz, int lddz, const float* tot, const float*
   MLIIS_REQUIRE(dz && tot && pool && w && dw && dpool && ws, MLIIS_ERR_ARG, "rsd_pool_bwd: null pointer");
   MLIIS_REQUIRE(N > 0 && H >= 2 && W >= 2 && Cp > 0 && Co > 0 && lddz >= Co && c_begin >= 0 && c_begin + Cp <= Cin_total, MLIIS_ERR_ARG,
                 "rsd_pool_bwd: bad shape");
-  MLIIS_REQUIRE((size_t)N * 9 * Co <= ws_floats, MLIIS_ERR_WORKSPACE, "rsd_pool_bwd: workspace too small");
-  hipLaunchKernelGGL(rsd_pool_gsum_k, dim3(N), dim3(256), 0, stream, dz, lddz, tot, ws, H, W, Co);
-  MLIIS_CHECK_LAUNCH("rsd_pool_gsum");
-  const long long total = 9LL * Cp * Co + (long long)N * Cp + Co;
-  hipLaunchKernelGGL(rsd_pool_bwd_k, dim3(ceil_div(total, 256)), dim3(256), 0, stream, ws, tot, pool, w, dw, dbias, dpool, N, Cp, Cin_total,
+  MLIIS_REQUIRE((size_t)N * 13 * Co <= ws_floats && Co <= 1024, MLIIS_ERR_WORKSPACE, "rsd_pool_bwd: workspace too small");
+  float* G = ws;                          // [N][9][Co]
+  float* B = ws + (size_t)N * 9 * Co;     // [N][4][Co]
+  hipLaunchKernelGGL(rsd_border_sums_k, dim3(N, 4), dim3(kRsdThreads), 0, stream, dz, lddz, B, H, W, Co);
+  MLIIS_CHECK_LAUNCH("rsd_border_sums");
+  hipLaunchKernelGGL(rsd_gsum_k, dim3(ceil_div((long long)N * 9 * Co, 256)), dim3(256), 0, stream, dz, lddz, tot, B, G, N, H, W, Co);
+  MLIIS_CHECK_LAUNCH("rsd_gsum");
+  hipLaunchKernelGGL(rsd_pool_dw_k, dim3(ceil_div(9LL * Cp * Co + Co, 256)), dim3(256), 0, stream, G, tot, pool, dw, dbias, N, Cp, Cin_total,
+                     c_begin, Co);
+  MLIIS_CHECK_LAUNCH("rsd_pool_dw");
+  hipLaunchKernelGGL(rsd_pool_dpool_k, dim3(ceil_div((long long)N * Cp * 64, 256)), dim3(256), 0, stream, G, w, dpool, N, Cp, Cin_total,
                      c_begin, Co, 1.0f / ((float)H * (float)W));
   MLIIS_CHECK_LAUNCH("rsd_pool_bwd");
   return MLIIS_OK;
