@@ -183,24 +183,31 @@ struct BnFold {
   float* moving_var;
 };
 
-__device__ __forceinline__ void fold32(const float* __restrict__ part, int nblk, int C, int c0, double* smd /*[2][8][32]*/, double& s,
+// 256 threads = 8 channel quads x 32 fold lanes; each lane strides over the partial blocks with float4 loads, the 32 lanes
+// are combined through LDS in double precision in a fixed order.  Result (threads 0..31 <-> channels c0..c0+31) in s / ss.
+__device__ __forceinline__ void fold32(const float* __restrict__ part, int nblk, int C, int c0, double* smd /*[2][32][32]*/, double& s,
                                        double& ss) {
-  const int t = threadIdx.x, ch = t & 31, bl = t >> 5;
-  double a = 0.0, b = 0.0;
-  if (c0 + ch < C)
-    for (int k = bl; k < nblk; k += 8) {
-      a += (double)part[((long long)k * 2 + 0) * C + c0 + ch];
-      b += (double)part[((long long)k * 2 + 1) * C + c0 + ch];
+  const int t = threadIdx.x, q = t & 7, bl = t >> 3;
+  double a0 = 0, a1 = 0, a2 = 0, a3 = 0, b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+  const int c = c0 + q * 4;
+  if (c < C)
+    for (int k = bl; k < nblk; k += 32) {
+      const float4 u = ld4(part + ((long long)k * 2 + 0) * C + c);
+      const float4 v = ld4(part + ((long long)k * 2 + 1) * C + c);
+      a0 += u.x; a1 += u.y; a2 += u.z; a3 += u.w;
+      b0 += v.x; b1 += v.y; b2 += v.z; b3 += v.w;
     }
-  smd[(0 * 8 + bl) * 32 + ch] = a;
-  smd[(1 * 8 + bl) * 32 + ch] = b;
+  double* p0 = smd + (0 * 32 + bl) * 32 + q * 4;
+  double* p1 = smd + (1 * 32 + bl) * 32 + q * 4;
+  p0[0] = a0; p0[1] = a1; p0[2] = a2; p0[3] = a3;
+  p1[0] = b0; p1[1] = b1; p1[2] = b2; p1[3] = b3;
   __syncthreads();
   s = ss = 0.0;
   if (t < 32) {
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      s += smd[(0 * 8 + k) * 32 + t];
-      ss += smd[(1 * 8 + k) * 32 + t];
+#pragma unroll 8
+    for (int k = 0; k < 32; ++k) {
+      s += smd[(0 * 32 + k) * 32 + t];
+      ss += smd[(1 * 32 + k) * 32 + t];
     }
   }
 }
@@ -210,7 +217,7 @@ __global__ __launch_bounds__(256) void bn_apply_fused_k(const float* __restrict_
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         int pre_swish, int post_swish, const float* __restrict__ img_scale,
                                                         const float* __restrict__ res, int ldr, int rows_per_block) {
-  __shared__ double smd[2 * 8 * 32];
+  __shared__ double smd[2 * 32 * 32];
   __shared__ __attribute__((aligned(16))) float s_mean[kChanBlock], s_rstd[kChanBlock];
   const int t = threadIdx.x;
   const int c0 = blockIdx.x * kChanBlock;
@@ -359,7 +366,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_k(BnBwdCommon p, long long r
 __global__ __launch_bounds__(256) void bn_bwd_apply_fused_k(BnBwdCommon p, long long rows, const float* __restrict__ part, int nblk,
                                                             double inv_n, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                             float* __restrict__ dx, int lddx, int rows_per_block) {
-  __shared__ double smd[2 * 8 * 32];
+  __shared__ double smd[2 * 32 * 32];
   __shared__ __attribute__((aligned(16))) float s_c1[kChanBlock], s_c2[kChanBlock];
   const int t = threadIdx.x;
   const int c0 = blockIdx.x * kChanBlock;

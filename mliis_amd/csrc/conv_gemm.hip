@@ -73,13 +73,24 @@ __global__ __launch_bounds__(256) void conv_gemm_k(ConvGemmParams p) {
   const int lane = t & 63, wave = t >> 6;
   const int l15 = lane & 15, g = lane >> 4;
   const long long M = (long long)p.Nimg * p.H * p.W;
-  const long long m0 = (long long)blockIdx.x * BM;
   const int n0 = blockIdx.y * BN;
   const int cpc = (p.C + BK - 1) / BK;  // chunks per tap
   const int nchunks_total = p.ntaps * cpc;
   int it0 = blockIdx.z * p.chunks_per_split;
   int it1 = it0 + p.chunks_per_split;
   if (it1 > nchunks_total) it1 = nchunks_total;
+
+  const bool split = p.partial != nullptr;
+  const bool stats = (p.stats_part != nullptr) && !split;
+  float s1[NT], s2[NT];   // BN statistics of this block's columns, accumulated over all its row tiles
+#pragma unroll
+  for (int j = 0; j < NT; ++j) s1[j] = s2[j] = 0.f;
+
+  // persistent over row tiles: a block walks tiles blockIdx.x, +gridDim.x, ... so the number of statistics partials (and
+  // of workgroup prologues) is bounded by the grid, not by M
+  const int ntiles = (int)((M + BM - 1) / BM);
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  const long long m0 = (long long)tile * BM;
 
   // ---- per-thread A rows
   const int a_kq = t & 7;
@@ -221,11 +232,6 @@ __global__ __launch_bounds__(256) void conv_gemm_k(ConvGemmParams p) {
 
   // ---- epilogue.  C/D layout of 16x16x4: col = lane & 15, row = 4 * (lane >> 4) + reg.  Final values go through a per-wave
   // LDS staging tile so that global stores are whole rows (BN*4 contiguous bytes, float4 per lane) instead of 64-byte pieces.
-  const bool split = p.partial != nullptr;
-  const bool stats = (p.stats_part != nullptr) && !split;
-  float s1[NT], s2[NT];
-#pragma unroll
-  for (int j = 0; j < NT; ++j) s1[j] = s2[j] = 0.f;
   if (split) {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -306,6 +312,8 @@ __global__ __launch_bounds__(256) void conv_gemm_k(ConvGemmParams p) {
         }
     }
   }
+  }  // row tiles
+
   if (stats) {  // wave-uniform branch: fold rows over the 4 lane groups, then over the 4 waves through LDS (fixed order)
     float* red = sm;  // K loop ended with a barrier: LDS is free.  layout [wave][2][BN]
 #pragma unroll
@@ -542,6 +550,13 @@ static inline GemmPlan plan_gemm(long long M, int Nout, int C, int ntaps, int nu
     if (forced == 1 || forced == 2) g.tm = forced;
   }
   g.gx = (int)((M + 64 * g.tm - 1) / (64 * g.tm));
+  {  // at most ~4 blocks per CU in x; more row tiles are walked by the same blocks (balanced: every block gets the same count)
+    const int cap = 4 * num_cus;
+    if (g.gx > cap) {
+      const int per = (g.gx + cap - 1) / cap;
+      g.gx = (g.gx + per - 1) / per;
+    }
+  }
   int nchunks = ntaps * ((C + 31) / 32);
   g.gz = 1;
   if (allow_split) {

@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_filter_k(const float* __restri
                                                            float* __restrict__ part, int N, int Hi, int Wi, int Ho, int Wo,
                                                            int C, int pt, int pl, int QB, int RP, int items_per_block) {
   constexpr int IW = (TW - 1) * S + K;
-  __shared__ float4 sm[256];
+  __shared__ float4 sm[8 * 256];
   const int t = threadIdx.x;
   const int ql = t % QB, rl = t / QB;
   const int Q = C >> 2;
@@ -161,15 +161,23 @@ __global__ __launch_bounds__(256) void dwconv_bwd_filter_k(const float* __restri
       }
     }
   }
+  // fold the RP strip lanes of every quad through LDS, TB taps per barrier pair (K*K barriers would dominate small layers)
+  constexpr int TB = 8;
 #pragma unroll
-  for (int k = 0; k < K * K; ++k) {
+  for (int k0 = 0; k0 < K * K; k0 += TB) {
     __syncthreads();
-    sm[t] = acc[k];
+#pragma unroll
+    for (int kk = 0; kk < TB; ++kk)
+      if (k0 + kk < K * K) sm[kk * 256 + t] = acc[k0 + kk];
     __syncthreads();
-    if (rl == 0 && q < Q) {
-      float4 s = sm[ql];
-      for (int j = 1; j < RP; ++j) s = f4add(s, sm[j * QB + ql]);
-      st4(part + ((long long)blockIdx.x * (K * K) + k) * C + c, s);
+    for (int item = t; item < TB * QB; item += 256) {
+      const int kk = item / QB, q2 = item - kk * QB;
+      const int qq = blockIdx.y * QB + q2;
+      if (k0 + kk < K * K && qq < Q) {
+        float4 s4 = sm[kk * 256 + q2];
+        for (int j = 1; j < RP; ++j) s4 = f4add(s4, sm[kk * 256 + j * QB + q2]);
+        st4(part + ((long long)blockIdx.x * (K * K) + k0 + kk) * C + (qq << 2), s4);
+      }
     }
   }
 }
