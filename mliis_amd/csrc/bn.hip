@@ -452,6 +452,35 @@ __global__ __launch_bounds__(256) void sum_finalize_k(const float* __restrict__ 
   out[i] = accumulate ? out[i] + r : r;
 }
 
+// Short segments (<= 1024 rows, e.g. squeeze-excite pools on 28x28 / 14x14 maps): one block per (segment, 32 channels) walks all
+// rows of the segment and finishes the sum itself -- no partials, no second launch.
+__global__ __launch_bounds__(256) void colsum_small_k(const float* __restrict__ a, int lda, const float* __restrict__ b, int ldb,
+                                                      int rows_per_seg, int C, float scale, float* __restrict__ out, int accumulate) {
+  __shared__ float4 sm[256];
+  const int t = threadIdx.x, q = t & 7, rl = t >> 3;
+  const int c = blockIdx.x * 32 + q * 4;
+  const int seg = blockIdx.y;
+  float4 acc = f4zero();
+  if (c < C) {
+    const long long r0 = (long long)seg * rows_per_seg;
+    for (int r = rl; r < rows_per_seg; r += 32) {
+      float4 v = ld4(a + (r0 + r) * lda + c);
+      if (b != nullptr) v = f4mul(v, ld4(b + (r0 + r) * ldb + c));
+      acc = f4add(acc, v);
+    }
+  }
+  sm[t] = acc;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    float4 s4 = sm[q];
+    for (int j = 1; j < 32; ++j) s4 = f4add(s4, sm[j * 8 + q]);
+    s4 = f4scale(s4, scale);
+    float* dst = out + (long long)seg * C + c;
+    if (accumulate) s4 = f4add(s4, ld4(dst));
+    st4(dst, s4);
+  }
+}
+
 __global__ __launch_bounds__(256) void fold_flat_k(const float* __restrict__ part, int nblk, long long total, float scale,
                                                    float* __restrict__ out, int accumulate, long long seg_len, long long seg_stride,
                                                    long long seg_off) {
@@ -592,6 +621,12 @@ int mliis_colsum(const float* a, int lda, const float* b, int ldb, long long row
                     (b == nullptr || ((ldb & 3) == 0 && ldb >= C)),
                 MLIIS_ERR_ARG, "colsum: bad shape");
   MLIIS_REQUIRE(aligned16(a) && aligned16(b) && aligned16(ws), MLIIS_ERR_ALIGN, "colsum: pointers must be 16-byte aligned");
+  if (rows_per_seg <= 1024 && aligned16(out)) {
+    hipLaunchKernelGGL(colsum_small_k, dim3(ceil_div(C, 32), nseg), dim3(256), 0, stream, a, lda, b, ldb, (int)rows_per_seg, C, scale, out,
+                       accumulate);
+    MLIIS_CHECK_LAUNCH("colsum_small");
+    return MLIIS_OK;
+  }
   SumOp op{a, lda, b, ldb};
   ColGeom g;
   int rc = launch_colreduce(op, rows_per_seg, C, nseg, ws, ws_floats, stream, &g, "colsum");
@@ -616,19 +651,24 @@ __global__ __launch_bounds__(256) void final_dw_finalize_k(const float* __restri
   const double s = fold_partials(part, nblk, 2LL * C, (long long)j * C + c, ok, sm);
   if (ok && threadIdx.y == 0) dw[c * 2 + j] = (float)s;
 }
-__global__ __launch_bounds__(256) void sum2_k(const float* __restrict__ dy, long long rows, float* __restrict__ db) {
-  // single block: db[j] = sum_rows dy[row, j]
-  __shared__ double sm[2][256];
+__global__ __launch_bounds__(1024) void sum2_k(const float* __restrict__ dy, long long rows, float* __restrict__ db) {
+  // single block: db[j] = sum_rows dy[row, j]; two rows per float4 load
+  __shared__ double sm[2][1024];
   double a0 = 0.0, a1 = 0.0;
-  for (long long r = threadIdx.x; r < rows; r += 256) {
-    float2 d = *reinterpret_cast<const float2*>(dy + r * 2);
-    a0 += d.x;
-    a1 += d.y;
+  const long long pairs = rows >> 1;
+  for (long long r = threadIdx.x; r < pairs; r += 1024) {
+    const float4 d = ld4(dy + r * 4);
+    a0 += (double)d.x + (double)d.z;
+    a1 += (double)d.y + (double)d.w;
+  }
+  if ((rows & 1) && threadIdx.x == 0) {
+    a0 += dy[(rows - 1) * 2];
+    a1 += dy[(rows - 1) * 2 + 1];
   }
   sm[0][threadIdx.x] = a0;
   sm[1][threadIdx.x] = a1;
   __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
+  for (int s = 512; s > 0; s >>= 1) {
     if ((int)threadIdx.x < s) {
       sm[0][threadIdx.x] += sm[0][threadIdx.x + s];
       sm[1][threadIdx.x] += sm[1][threadIdx.x + s];
@@ -646,15 +686,14 @@ extern "C" int mliis_final_conv_bwd_filter(const float* x, int ldx, const float*
                                            float* dw, float* db, float* ws, size_t ws_floats, hipStream_t stream) {
   MLIIS_REQUIRE(x && dy && dw && db && ws, MLIIS_ERR_ARG, "final_conv_bwd_filter: null pointer");
   MLIIS_REQUIRE(rows > 0 && C > 0 && (C & 3) == 0 && (ldx & 3) == 0 && ldx >= C, MLIIS_ERR_ARG, "final_conv_bwd_filter: bad shape");
-  MLIIS_REQUIRE(aligned16(x) && aligned16(mask) && aligned16(ws) && (reinterpret_cast<uintptr_t>(dy) & 7u) == 0, MLIIS_ERR_ALIGN,
-                "final_conv_bwd_filter: alignment");
+  MLIIS_REQUIRE(aligned16(x) && aligned16(mask) && aligned16(ws) && aligned16(dy), MLIIS_ERR_ALIGN, "final_conv_bwd_filter: alignment");
   Outer2Op op{x, ldx, mask, dy};
   ColGeom g;
   int rc = launch_colreduce(op, rows, C, 1, ws, ws_floats, stream, &g, "final_conv_bwd_filter");
   if (rc) return rc;
   hipLaunchKernelGGL(final_dw_finalize_k, dim3(ceil_div(C, kFoldX), 2), dim3(kFoldX, kFoldY), 0, stream, ws, g.nblk, C, dw);
   MLIIS_CHECK_LAUNCH("final_dw_finalize");
-  hipLaunchKernelGGL(sum2_k, dim3(1), dim3(256), 0, stream, dy, rows, db);
+  hipLaunchKernelGGL(sum2_k, dim3(1), dim3(1024), 0, stream, dy, rows, db);
   MLIIS_CHECK_LAUNCH("final_db");
   return MLIIS_OK;
 }

@@ -198,27 +198,44 @@ __global__ __launch_bounds__(256) void ce_partial_k(const float* __restrict__ lo
   }
 }
 
-// out: [0] loss, [1] ce, [2] iou ; coef[n] = {A_n, B_n} for the dice gradient (0 when dice off)
-__global__ void ce_finalize_k(const float* __restrict__ part, int nblk, int N, int HW, int dice, float extra_loss,
-                              float* __restrict__ out, float* __restrict__ coef) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// out: [0] loss, [1] ce, [2] iou ; coef[n] = {A_n, B_n} for the dice gradient (0 when dice off).  One block; thread t folds
+// the partial blocks b = t, t+256, ... of every image, then thread 0 finishes in double precision (fixed order).
+__global__ __launch_bounds__(256) void ce_finalize_k(const float* __restrict__ part, int nblk, int N, int HW, int dice, float extra_loss,
+                                                     float* __restrict__ out, float* __restrict__ coef) {
+  __shared__ double sm[4][256];
+  __shared__ double tot[4];
   double ce = 0.0, iou = 0.0;
   const double eps = 1e-7;
   for (int n = 0; n < N; ++n) {
-    double c = 0, I = 0, Sp = 0, St = 0;
-    for (int b = 0; b < nblk; ++b) {
-      const float* q = part + ((long long)n * nblk + b) * 4;
-      c += q[0];
-      I += q[1];
-      Sp += q[2];
-      St += q[3];
+    double v[4] = {0, 0, 0, 0};
+    for (int b = threadIdx.x; b < nblk; b += 256) {
+      const float4 q = ld4(part + ((long long)n * nblk + b) * 4);
+      v[0] += q.x;
+      v[1] += q.y;
+      v[2] += q.z;
+      v[3] += q.w;
     }
-    ce += c;
-    const double U = Sp + St - I;
-    iou += (I + eps) / (U + eps);
-    coef[2 * n + 0] = (float)(1.0 / (U + eps));
-    coef[2 * n + 1] = (float)((I + eps) / ((U + eps) * (U + eps)));
+#pragma unroll
+    for (int k = 0; k < 4; ++k) sm[k][threadIdx.x] = v[k];
+    __syncthreads();
+    if (threadIdx.x < 4) {
+      double s = 0.0;
+      const int lim = nblk < 256 ? nblk : 256;
+      for (int j = 0; j < lim; ++j) s += sm[threadIdx.x][j];
+      tot[threadIdx.x] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const double I = tot[1], Sp = tot[2], St = tot[3];
+      ce += tot[0];
+      const double U = Sp + St - I;
+      iou += (I + eps) / (U + eps);
+      coef[2 * n + 0] = (float)(1.0 / (U + eps));
+      coef[2 * n + 1] = (float)((I + eps) / ((U + eps) * (U + eps)));
+    }
+    __syncthreads();
   }
+  if (threadIdx.x != 0) return;
   ce /= (double)N * HW;
   iou /= N;
   double loss = ce + extra_loss;
@@ -354,11 +371,12 @@ int mliis_softmax_ce(const float* logits, const float* labels, const int* img_id
   const int HW = H * W;
   int nblk = ceil_div((long long)HW, 256 * 8);
   if (nblk > 256) nblk = 256;
-  MLIIS_REQUIRE((size_t)N * nblk * 4 + 2 * (size_t)N <= ws_floats, MLIIS_ERR_WORKSPACE, "softmax_ce: workspace too small");
+  MLIIS_REQUIRE((size_t)N * nblk * 4 + 2 * (size_t)N <= ws_floats && aligned16(ws), MLIIS_ERR_WORKSPACE,
+                "softmax_ce: workspace too small or unaligned");
   float* coef = ws + (size_t)N * nblk * 4;
   hipLaunchKernelGGL(ce_partial_k, dim3(nblk, N), dim3(256), 0, stream, logits, labels, img_idx, HW, label_smoothing, ws);
   MLIIS_CHECK_LAUNCH("softmax_ce_partial");
-  hipLaunchKernelGGL(ce_finalize_k, dim3(1), dim3(64), 0, stream, ws, nblk, N, HW, dice, extra_loss, out, coef);
+  hipLaunchKernelGGL(ce_finalize_k, dim3(1), dim3(256), 0, stream, ws, nblk, N, HW, dice, extra_loss, out, coef);
   MLIIS_CHECK_LAUNCH("softmax_ce_finalize");
   if (dlogits || pred) {
     hipLaunchKernelGGL(ce_grad_k, dim3(nblk, N), dim3(256), 0, stream, logits, labels, img_idx, HW, label_smoothing,

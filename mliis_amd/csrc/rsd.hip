@@ -17,16 +17,23 @@ __device__ __forceinline__ bool tap_valid(int t3, int cls3) {  // t3: 0,1,2 <-> 
 
 constexpr int kRsdThreads = 1024;
 
-// grid (N, 9 border classes); threads = (co, c-lane): E[n][cls][co] = sum_c pool[n][c] * sum_{taps valid in cls} W[tap][c][co]
+// grid (9 border classes); threads = (co, c-lane); all images handled inside the block so every weight is read once:
+// E[n][cls][co] = sum_c pool[n][c] * sum_{taps valid in cls} W[tap][c][co]
+constexpr int kRsdMaxN = 16;
 __global__ __launch_bounds__(kRsdThreads) void rsd_pool_fwd_k(const float* __restrict__ pool, const float* __restrict__ w,
-                                                              float* __restrict__ E, int Cp, int Cin_total, int c_begin, int Co) {
-  __shared__ float red[kRsdThreads];
-  const int n = blockIdx.x, cls = blockIdx.y;
+                                                              float* __restrict__ E, int N, int Cp, int Cin_total, int c_begin, int Co) {
+  extern __shared__ float dyn[];          // [N][Cp] pooled vectors, then reused as the [CL][Co] reduction buffer per image
+  float* sp = dyn;
+  float* red = dyn + (size_t)N * Cp;
+  const int cls = blockIdx.x;
   const int rc = cls / 3, cc = cls - rc * 3;
   const int CL = kRsdThreads / Co;
   const int co = threadIdx.x % Co, cl = threadIdx.x / Co;
-  const float* pn = pool + (long long)n * Cp;
-  float a = 0.f;
+  for (int i = threadIdx.x; i < N * Cp; i += kRsdThreads) sp[i] = pool[i];
+  __syncthreads();
+  float a[kRsdMaxN];
+#pragma unroll
+  for (int n = 0; n < kRsdMaxN; ++n) a[n] = 0.f;
   if (cl < CL)
     for (int c = cl; c < Cp; c += CL) {
       float ws = 0.f;
@@ -35,14 +42,21 @@ __global__ __launch_bounds__(kRsdThreads) void rsd_pool_fwd_k(const float* __res
 #pragma unroll
         for (int tx = 0; tx < 3; ++tx)
           if (tap_valid(ty, rc) && tap_valid(tx, cc)) ws += w[((long long)(ty * 3 + tx) * Cin_total + c_begin + c) * Co + co];
-      a = fmaf(pn[c], ws, a);
+#pragma unroll
+      for (int n = 0; n < kRsdMaxN; ++n)
+        if (n < N) a[n] = fmaf(sp[n * Cp + c], ws, a[n]);
     }
-  red[threadIdx.x] = a;
-  __syncthreads();
-  if (threadIdx.x < Co) {
-    float r = 0.f;
-    for (int k = 0; k < CL; ++k) r += red[k * Co + threadIdx.x];
-    E[((long long)n * 9 + cls) * Co + threadIdx.x] = r;
+#pragma unroll
+  for (int n = 0; n < kRsdMaxN; ++n) {
+    if (n >= N) break;
+    __syncthreads();
+    red[threadIdx.x] = a[n];
+    __syncthreads();
+    if (threadIdx.x < Co) {
+      float r = 0.f;
+      for (int k = 0; k < CL; ++k) r += red[k * Co + threadIdx.x];
+      E[((long long)n * 9 + cls) * Co + threadIdx.x] = r;
+    }
   }
 }
 
@@ -142,8 +156,11 @@ extern "C" {
 int mliis_rsd_pool_fwd(const float* pool, const float* w, float* border_bias, int N, int Cp, int Cin_total, int c_begin, int Co,
                        hipStream_t stream) {
   MLIIS_REQUIRE(pool && w && border_bias, MLIIS_ERR_ARG, "rsd_pool_fwd: null pointer");
-  MLIIS_REQUIRE(N > 0 && Cp > 0 && Co > 0 && Co <= 1024 && c_begin >= 0 && c_begin + Cp <= Cin_total, MLIIS_ERR_ARG, "rsd_pool_fwd: bad shape");
-  hipLaunchKernelGGL(rsd_pool_fwd_k, dim3(N, 9), dim3(kRsdThreads), 0, stream, pool, w, border_bias, Cp, Cin_total, c_begin, Co);
+  MLIIS_REQUIRE(N > 0 && N <= kRsdMaxN && Cp > 0 && Co > 0 && Co <= 1024 && c_begin >= 0 && c_begin + Cp <= Cin_total &&
+                    (size_t)N * Cp + kRsdThreads <= 15360,
+                MLIIS_ERR_ARG, "rsd_pool_fwd: bad shape (N <= %d)", kRsdMaxN);
+  hipLaunchKernelGGL(rsd_pool_fwd_k, dim3(9), dim3(kRsdThreads), ((size_t)N * Cp + kRsdThreads) * sizeof(float), stream, pool, w, border_bias,
+                     N, Cp, Cin_total, c_begin, Co);
   MLIIS_CHECK_LAUNCH("rsd_pool_fwd");
   return MLIIS_OK;
 }
