@@ -86,11 +86,7 @@ __global__ __launch_bounds__(256) void conv_gemm_k(ConvGemmParams p) {
 #pragma unroll
   for (int j = 0; j < NT; ++j) s1[j] = s2[j] = 0.f;
 
-  // persistent over row tiles: a block walks tiles blockIdx.x, +gridDim.x, ... so the number of statistics partials (and
-  // of workgroup prologues) is bounded by the grid, not by M
-  const int ntiles = (int)((M + BM - 1) / BM);
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-  const long long m0 = (long long)tile * BM;
+  const long long m0 = (long long)blockIdx.x * BM;
 
   // ---- per-thread A rows
   const int a_kq = t & 7;
@@ -312,8 +308,6 @@ __global__ __launch_bounds__(256) void conv_gemm_k(ConvGemmParams p) {
         }
     }
   }
-  }  // row tiles
-
   if (stats) {  // wave-uniform branch: fold rows over the 4 lane groups, then over the 4 waves through LDS (fixed order)
     float* red = sm;  // K loop ended with a barrier: LDS is free.  layout [wave][2][BN]
 #pragma unroll
@@ -342,7 +336,7 @@ __global__ __launch_bounds__(256) void conv_gemm_k(ConvGemmParams p) {
 
 __global__ __launch_bounds__(256) void splitk_reduce_k(const float* __restrict__ partial, int splits, long long M, int Nout,
                                                        float* __restrict__ Cmat, int ldc, const float* __restrict__ bias,
-                                                       int accumulate) {
+                                                       int accumulate, const float* __restrict__ border_bias, int H, int W) {
   const int Q = Nout >> 2;
   const long long total = M * Q;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -351,6 +345,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_k(const float* __restrict__
     float4 s = ld4(partial + m * Nout + n);
     for (int z = 1; z < splits; ++z) s = f4add(s, ld4(partial + ((long long)z * M + m) * Nout + n));
     if (bias != nullptr) s = f4add(s, ld4(bias + n));
+    if (border_bias != nullptr) {
+      const long long HWp = (long long)H * W;
+      const int ni = (int)(m / HWp);
+      const int rem = (int)(m - (long long)ni * HWp);
+      const int h = rem / W, w_ = rem - h * W;
+      const int cls = (h == 0 ? 0 : (h == H - 1 ? 2 : 1)) * 3 + (w_ == 0 ? 0 : (w_ == W - 1 ? 2 : 1));
+      s = f4add(s, ld4(border_bias + ((long long)ni * 9 + cls) * Nout + n));
+    }
     float* dst = Cmat + m * ldc + n;
     if (accumulate) s = f4add(s, ld4(dst));
     st4(dst, s);
@@ -549,14 +551,9 @@ static inline GemmPlan plan_gemm(long long M, int Nout, int C, int ntaps, int nu
     }
     if (forced == 1 || forced == 2) g.tm = forced;
   }
+  // very tall, HBM-bound layers (112x112 maps): 128-row blocks halve the number of BN-statistics partials the consumer folds
+  if ((M + 63) / 64 > 4LL * num_cus && g.tm == 1) g.tm = 2;
   g.gx = (int)((M + 64 * g.tm - 1) / (64 * g.tm));
-  {  // at most ~4 blocks per CU in x; more row tiles are walked by the same blocks (balanced: every block gets the same count)
-    const int cap = 4 * num_cus;
-    if (g.gx > cap) {
-      const int per = (g.gx + cap - 1) / cap;
-      g.gx = (g.gx + per - 1) / per;
-    }
-  }
   int nchunks = ntaps * ((C + 31) / 32);
   g.gz = 1;
   if (allow_split) {
@@ -709,7 +706,7 @@ int mliis_conv2d_fwd(const float* x, int ldx, const float* x_scale, const float*
   MLIIS_REQUIRE(aligned16(x) && aligned16(w) && aligned16(bias) && aligned16(y), MLIIS_ERR_ALIGN,
                 "conv2d_fwd: pointers must be 16-byte aligned");
   long long M = (long long)Nimg * H * W;
-  GemmPlan g = plan_gemm(M, Cout, Cin, ksize * ksize, num_cus(), ws != nullptr && border_bias == nullptr);
+  GemmPlan g = plan_gemm(M, Cout, Cin, ksize * ksize, num_cus(), ws != nullptr);
   MLIIS_REQUIRE(ci_begin >= 0 && (ci_begin & 3) == 0 && ci_begin + Cin <= Cin_total, MLIIS_ERR_ARG,
                 "conv2d_fwd: input-channel window out of range");
   MLIIS_REQUIRE(border_bias == nullptr || (ksize == 3 && dil == 1 && H >= 2 && W >= 2 && aligned16(border_bias)), MLIIS_ERR_ARG,
@@ -743,7 +740,7 @@ int mliis_conv2d_fwd(const float* x, int ldx, const float* x_scale, const float*
   if (g.gz > 1) {
     long long q = M * (Cout / 4);
     int blocks = (int)((q + 255) / 256 > 2048 ? 2048 : (q + 255) / 256);
-    hipLaunchKernelGGL(splitk_reduce_k, dim3(blocks), dim3(256), 0, stream, ws, g.gz, M, Cout, y, ldy, bias, accumulate);
+    hipLaunchKernelGGL(splitk_reduce_k, dim3(blocks), dim3(256), 0, stream, ws, g.gz, M, Cout, y, ldy, bias, accumulate, border_bias, H, W);
     MLIIS_CHECK_LAUNCH("conv2d_fwd_splitk_reduce");
   }
   return MLIIS_OK;
@@ -776,7 +773,7 @@ int mliis_conv2d_bwd_data(const float* dy, int lddy, const float* w, float* dx, 
   if (g.gz > 1) {
     long long q = M * (Cin_out / 4);
     int blocks = (int)((q + 255) / 256 > 2048 ? 2048 : (q + 255) / 256);
-    hipLaunchKernelGGL(splitk_reduce_k, dim3(blocks), dim3(256), 0, stream, ws, g.gz, M, Cin_out, dx, lddx, nullptr, accumulate);
+    hipLaunchKernelGGL(splitk_reduce_k, dim3(blocks), dim3(256), 0, stream, ws, g.gz, M, Cin_out, dx, lddx, nullptr, accumulate, nullptr, H, W);
     MLIIS_CHECK_LAUNCH("conv2d_bwd_data_splitk_reduce");
   }
   return MLIIS_OK;

@@ -7,7 +7,8 @@ inner-loop engine.
 
 Writes the reference's checkpoint directory layout (mliis_amd/checkpoint.py) and `<checkpoint>/meta-test_results.json`.
 Out of scope in this build (clear errors): UHO hyper-parameter search, k-shot learning-curve experiment, host augmentation,
-the FSS-1000 TFRecord reader; use --synthetic-tasks for data.
+TF TensorBundle checkpoints.  Data: --data-dir with FSS-1000 TFRecord-GZIP shards
+(mliis_amd/tfrecord.py, no TensorFlow needed) or --synthetic-tasks N.
 """
 import datetime
 import json
@@ -29,8 +30,15 @@ from mliis_amd.args import argument_parser, evaluate_kwargs, make_lr_scheduler, 
 def _dataset(args, device, rank):
     from mliis_amd.metaseg import DeviceTask, synthetic_task
     if not args.synthetic_tasks:
-        raise NotImplementedError("reading FSS-1000 TFRecord-GZIP shards from --data-dir is not built yet (SURVEY.md 8(f)-2); "
-                                  "pass --synthetic-tasks N")
+        if not args.data_dir:
+            raise SystemExit("pass --data-dir <FSS-1000 TFRecord-GZIP shards> or --synthetic-tasks N")
+        from mliis_amd import tfrecord
+        ids = tfrecord.fp_k_test_task_ids() if args.fp_k_test_set else "fss"
+        train, val, test, _, _, _ = tfrecord.read_fss_1000_dataset(args.data_dir, num_val_tasks=args.num_val_tasks, test_task_ids=ids,
+                                                                   image_size=args.image_size)
+        if not train or not test:
+            raise ValueError("Train / test set has no tasks to evaluate")          # utils/util.py:124-130
+        return train, (val or test)
     n_ex = max(args.train_shots or 0, args.shots + 5)
     tasks = []
     for i in range(args.synthetic_tasks):
