@@ -142,7 +142,8 @@ def train_kwargs(a) -> dict:
 def evaluate_kwargs(a) -> dict:
     return dict(num_classes=a.classes, num_shots=a.shots, eval_inner_batch_size=a.eval_batch, eval_inner_iters=a.eval_iters,
                 replacement=a.replacement, weight_decay_rate=a.weight_decay, num_samples=a.eval_samples, transductive=a.transductive,
-                meta_fn=_meta_fn(a), augment=a.augment, lr=None, aug_rate=a.aug_rate)
+                meta_fn=_meta_fn(a), augment=a.augment, lr=None, aug_rate=a.aug_rate,
+                save_fine_tuned_checkpoints=a.save_fine_tuned_checkpoints, save_fine_tuned_checkpoints_dir=a.save_fine_tuned_checkpoints_dir)
 
 
 def make_lr_scheduler(a):

@@ -355,6 +355,19 @@ class OracleLearner:
                                 weight_decay_rate)
         return loss
 
+    def export_all(self):
+        return {"params": {k: v.clone() for k, v in self.params.items()}, "bn": {k: (a.clone(), b.clone()) for k, (a, b) in self.bn.items()}}
+
+    def import_all(self, st):
+        self.params = {k: v.clone() for k, v in st["params"].items()}
+        self.bn = {k: (a.clone(), b.clone()) for k, (a, b) in st["bn"].items()}
+
+    def predict_resident(self, idx, training=False):
+        return self.predict(self._x[list(idx)], training)
+
+    def synchronize(self):
+        pass
+
     def predict(self, x, training=False):
         with torch.no_grad():
             logits, _ = forward(self.a, self.params, self.bn, x, training)

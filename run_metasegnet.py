@@ -94,28 +94,19 @@ def main():
             learner.load_named(ckpt.load(path))
 
     if rank == 0:
+        from mliis_amd.eval import evaluate_gecko
         ek = evaluate_kwargs(args)
-        meta = ek["meta_fn"](learner, transductive=ek["transductive"], pre_step_op=(ek["weight_decay_rate"] if ek["weight_decay_rate"] != 1 else None),
-                             lr_scheduler=lr_scheduler, augment=ek["augment"], aug_rate=ek["aug_rate"], rng_mode="reference",
-                             dist=type("One", (), {"rank": 0, "world": 1, "all_reduce_sum": staticmethod(lambda t: t), "barrier": staticmethod(lambda: None)})())
-        results = {}
         print("Evaluating {}-shot learning on meta-test tasks.".format(args.shots))
-        ious = []
-        for sample in range(max(1, min(args.eval_samples, 2 if args.serially_eval_all_test_tasks else args.eval_samples))):
-            miou, m = meta.evaluate(test_set, num_shots=ek["num_shots"], inner_batch_size=ek["eval_inner_batch_size"],
-                                    inner_iters=ek["eval_inner_iters"], replacement=ek["replacement"],
-                                    eval_all_tasks=args.serially_eval_all_test_tasks, num_tasks_to_sample=1, eval_sample_num=sample)
-            ious.append(miou)
-            for k, v in m.items():
-                results.setdefault(k, []).append(v)
-            if not args.serially_eval_all_test_tasks and sample + 1 >= args.eval_samples:
-                break
+        mean_test_iou, task_name_iou_map = evaluate_gecko(learner, test_set, lr_scheduler=lr_scheduler,
+                                                          serially_eval_all_tasks=args.serially_eval_all_test_tasks, **ek)
+        print("Evaluated meta-test tasks:")
+        print(task_name_iou_map)
         # Do NOT change this print (it's used to grep logs):
-        print("Mean IoU over all meta-test tasks: {}".format(float(np.nanmean(ious))))
+        print("Mean IoU over all meta-test tasks: {}".format(mean_test_iou))
         os.makedirs(args.checkpoint, exist_ok=True)
         out = os.path.join(args.checkpoint, "meta-test_results.json")
         with open(out, "w") as f:
-            json.dump(results, f)
+            json.dump(task_name_iou_map, f)
         print("Wrote results to {}".format(out))
     if world > 1:
         import torch.distributed as dist

@@ -155,3 +155,33 @@ def test_full_size_step_config2():
     ll = L.loss_value()
     assert abs(ll - lo) <= 1e-4 * max(1.0, abs(lo)), (ll, lo)
     _compare_state(O, L, gO, "full")
+
+
+def test_evaluate_path_matches_oracle():
+    """Gecko.evaluate (fine-tune on 5 shots, predict 5 held-out images in inference mode, per-image IoU, restore ALL variables)
+    on the HIP learner vs the same host code driving the CPU oracle."""
+    _need_gpu()
+    import random
+    from mliis_amd.learner import Learner
+    from mliis_amd.metaseg import DeviceTask
+    from mliis_amd.reptile import Gecko
+    H = 64
+    O = R.OracleLearner(image_size=H, seed=0, dtype=torch.float64, lr=1e-3, drop_connect=False)
+    L = Learner(image_size=H, seed=5, use_graph=True, drop_connect=False)
+    L.load_named({k: v.numpy() for k, v in O.params.items()}, strict=False)
+    x, y = _task(10, H, 7)
+    res = []
+    for learner, conv in ((O, lambda t: torch.tensor(t).double()), (L, lambda t: torch.tensor(t))):
+        task = DeviceTask("t", conv(x), conv(y))
+        before = learner.export_all()
+        random.seed(3)
+        g = Gecko(learner, rng_mode="reference", transductive=False)
+        res.append(g.evaluate([task], num_shots=5, inner_batch_size=8, inner_iters=3, eval_all_tasks=True))
+        random.seed(3)
+        g2 = Gecko(learner, rng_mode="reference", transductive=True)
+        res.append(g2.evaluate([task], num_shots=5, inner_batch_size=8, inner_iters=3, eval_all_tasks=True))
+        after = learner.export_all()
+        if learner is L:
+            assert torch.equal(before["theta"], after["theta"]) and torch.equal(before["bn"], after["bn"])   # full state restored
+    assert abs(res[0][0] - res[2][0]) <= 5e-3, (res[0][0], res[2][0])      # non-transductive mean IoU
+    assert abs(res[1][0] - res[3][0]) <= 5e-3, (res[1][0], res[3][0])      # transductive mean IoU
