@@ -95,8 +95,9 @@ int mliis_conv2d_bwd_filter(const float* x, int ldx, const float* x_scale, const
  *      [c_begin, c_begin+Cp) of the 3x3 fuse conv's input become a per-image, per-border-class bias (forward) and need only
  *      per-image sums of the output gradient over the map, its border rows/columns and corners (backward).  tot[n][co] =
  *      per-image column sums of dz (mliis_colsum with nseg = N).  dpool = (dL/dpool) / (H*W). */
-int mliis_rsd_pool_fwd(const float* pool, const float* w, float* border_bias, int N, int Cp, int Cin_total, int c_begin, int Co,
-                       hipStream_t stream);
+size_t mliis_rsd_pool_fwd_workspace_floats(int N, int Co);
+int mliis_rsd_pool_fwd(const float* pool, const float* w, float* border_bias, int N, int Cp, int Cin_total, int c_begin, int Co, float* ws,
+                       size_t ws_floats, hipStream_t stream);
 size_t mliis_rsd_pool_bwd_workspace_floats(int N, int Co);
 int mliis_rsd_pool_bwd(const float* dz, int lddz, const float* tot, const float* pool, const float* w, float* dw, float* dbias,
                        float* dpool, int N, int H, int W, int Cp, int Cin_total, int c_begin, int Co, float* ws, size_t ws_floats,
@@ -181,6 +182,12 @@ int mliis_adam_b1zero_fused(float* w, const float* g, float* v, const uint8_t* l
                             float l2, float beta2, float eps, const float* step_dev, hipStream_t stream);
 int mliis_axpby(float a, const float* x, float b, float* y, long long n, hipStream_t stream);
 int mliis_lincomb(float a, const float* x, float b, const float* y, float* out, long long n, hipStream_t stream);
+
+/* ---- weight-gradient producers (conv2d / dwconv / stem *_bwd_filter) called with dw == NULL leave their per-split slabs in
+ *      `ws`; one mliis_fold_batched launch then folds all of them into the gradient arena.  desc: device int64 [ndesc][8] =
+ *      {part_off, out_off, total, seg_len, seg_stride, seg_off, nblk, tile_begin} (offsets in floats; tile = 16 outputs). */
+int mliis_fold_batched(const float* part_base, float* out_base, const long long* desc, int ndesc, long long total_tiles,
+                       hipStream_t stream);
 
 /* ---- HIP-graph capture of one inner step (replaces the per-op dispatch of session.run) */
 int mliis_graph_begin_capture(hipStream_t stream);

@@ -31,7 +31,8 @@ SIGNATURES = {
     "mliis_conv2d_workspace_floats": (_sz, [_i, _i, _i, _i, _i, _i]),
     "mliis_conv2d_plan": (_i, [_i, _i, _i, _i, _i, _i, _p, _p, _p]),
     "mliis_conv2d_fwd": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _p, _sz, _p]),
-    "mliis_rsd_pool_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "mliis_rsd_pool_fwd_workspace_floats": (_sz, [_i, _i]),
+    "mliis_rsd_pool_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _sz, _p]),
     "mliis_rsd_pool_bwd_workspace_floats": (_sz, [_i, _i]),
     "mliis_rsd_pool_bwd": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _p]),
     "mliis_transpose_weights": (_i, [_p, _p, _p, _i, _p]),
@@ -59,6 +60,7 @@ SIGNATURES = {
     "mliis_adam_b1zero_fused": (_i, [_p, _p, _p, _p, _ll, _f, _p, _f, _f, _f, _p, _p]),
     "mliis_axpby": (_i, [_f, _p, _f, _p, _ll, _p]),
     "mliis_lincomb": (_i, [_f, _p, _f, _p, _p, _ll, _p]),
+    "mliis_fold_batched": (_i, [_p, _p, _p, _i, _ll, _p]),
     "mliis_graph_begin_capture": (_i, [_p]),
     "mliis_graph_end_capture": (_i, [_p, C.POINTER(C.c_void_p)]),
     "mliis_graph_launch": (_i, [_p, _p]),

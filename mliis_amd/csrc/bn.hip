@@ -452,6 +452,28 @@ __global__ __launch_bounds__(256) void sum_finalize_k(const float* __restrict__ 
   out[i] = accumulate ? out[i] + r : r;
 }
 
+// All weight-gradient slab folds of a backward pass in ONE launch.  desc (device int64 [ndesc][8]) = {part_off, out_off, total,
+// seg_len, seg_stride, seg_off, nblk, tile_begin}; block b handles 16 consecutive outputs of the descriptor whose tile range
+// contains b (binary search over tile_begin).
+__global__ __launch_bounds__(256) void fold_batched_k(const float* __restrict__ part_base, float* __restrict__ out_base,
+                                                      const long long* __restrict__ desc, int ndesc) {
+  __shared__ double sm[kFoldY * (kFoldX + 1)];
+  const long long tile = blockIdx.x;
+  int lo = 0, hi = ndesc - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (desc[(long long)mid * 8 + 7] <= tile) lo = mid; else hi = mid - 1;
+  }
+  const long long* d = desc + (long long)lo * 8;
+  const long long total = d[2];
+  const long long i = (tile - d[7]) * kFoldX + threadIdx.x;
+  const bool ok = i < total;
+  const double s = fold_partials(part_base + d[0], (int)d[6], total, i, ok, sm);
+  if (!ok || threadIdx.y != 0) return;
+  const long long o = (i / d[3]) * d[4] + d[5] + i % d[3];
+  out_base[d[1] + o] = (float)s;
+}
+
 // Short segments (<= 1024 rows, e.g. squeeze-excite pools on 28x28 / 14x14 maps): one block per (segment, 32 channels) walks all
 // rows of the segment and finishes the sum itself -- no partials, no second launch.
 __global__ __launch_bounds__(256) void colsum_small_k(const float* __restrict__ a, int lda, const float* __restrict__ b, int ldb,
@@ -610,6 +632,14 @@ int mliis_bn_apply_fused(const float* x, int ldx, float* y, int ldy, long long r
   hipLaunchKernelGGL(bn_apply_fused_k, dim3(gx, gy), dim3(256), 0, stream, x, ldx, y, ldy, rows, C, rows_per_img, f, gamma, beta, pre_swish,
                      post_swish, img_scale, res, ldr, rpb);
   MLIIS_CHECK_LAUNCH("bn_apply_fused");
+  return MLIIS_OK;
+}
+
+int mliis_fold_batched(const float* part_base, float* out_base, const long long* desc, int ndesc, long long total_tiles,
+                       hipStream_t stream) {
+  MLIIS_REQUIRE(part_base && out_base && desc && ndesc > 0 && total_tiles > 0, MLIIS_ERR_ARG, "fold_batched: bad arguments");
+  hipLaunchKernelGGL(fold_batched_k, dim3((unsigned)total_tiles), dim3(kFoldX, kFoldY), 0, stream, part_base, out_base, desc, ndesc);
+  MLIIS_CHECK_LAUNCH("fold_batched");
   return MLIIS_OK;
 }
 

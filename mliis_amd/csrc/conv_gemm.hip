@@ -799,7 +799,7 @@ int mliis_conv2d_bwd_filter(const float* x, int ldx, const float* x_scale, const
                             size_t ws_floats, hipStream_t stream) {
   int rc = conv_check("conv2d_bwd_filter", Nimg, H, W, Cin, Cout, ksize, dil);
   if (rc) return rc;
-  MLIIS_REQUIRE(x && dy && dw && ws, MLIIS_ERR_ARG, "conv2d_bwd_filter: null pointer");
+  MLIIS_REQUIRE(x && dy && ws, MLIIS_ERR_ARG, "conv2d_bwd_filter: null pointer");   // dw == NULL: leave the slabs in ws (mliis_fold_batched)
   MLIIS_REQUIRE((ldx & 3) == 0 && ldx >= Cin && (lddy & 3) == 0 && lddy >= Cout, MLIIS_ERR_ARG, "conv2d_bwd_filter: bad leading dimensions");
   MLIIS_REQUIRE(aligned16(x) && aligned16(dy) && aligned16(ws), MLIIS_ERR_ALIGN, "conv2d_bwd_filter: pointers must be 16-byte aligned");
   long long M = (long long)Nimg * H * W;
@@ -812,6 +812,7 @@ int mliis_conv2d_bwd_filter(const float* x, int ldx, const float* x_scale, const
   launch_filter(f, p, stream);
   MLIIS_CHECK_LAUNCH("conv2d_bwd_filter");
   MLIIS_REQUIRE(ci_begin >= 0 && ci_begin + Cin <= Cin_total, MLIIS_ERR_ARG, "conv2d_bwd_filter: input-channel window out of range");
+  if (dw == nullptr) return MLIIS_OK;
   hipLaunchKernelGGL(fold_flat_k, dim3(ceil_div((long long)total, kFoldX)), dim3(kFoldX, kFoldY), 0, stream, ws, f.gz, (long long)total, 1.0f, dw,
                      accumulate, (long long)Cin * Cout, (long long)Cin_total * Cout, (long long)ci_begin * Cout);
   MLIIS_CHECK_LAUNCH("conv2d_bwd_filter_reduce");

@@ -290,7 +290,7 @@ size_t mliis_dwconv_bwd_filter_workspace_floats(int N, int H, int W, int C, int 
 
 int mliis_dwconv_bwd_filter(const float* x, const float* dy, float* dw, int N, int H, int W, int C, int k, int stride, float* ws,
                             size_t ws_floats, hipStream_t stream) {
-  int rc = dw_check("dwconv_bwd_filter", x, dy, dw, N, H, W, C, k, stride);
+  int rc = dw_check("dwconv_bwd_filter", x, dy, dw ? dw : ws, N, H, W, C, k, stride);   // dw == NULL: slabs stay in ws
   if (rc) return rc;
   MLIIS_REQUIRE(ws && aligned16(ws), MLIIS_ERR_ARG, "dwconv_bwd_filter: workspace null/unaligned");
   DwGeom g = dw_geom(H, W, k, stride);
@@ -301,6 +301,7 @@ int mliis_dwconv_bwd_filter(const float* x, const float* dy, float* dw, int N, i
   dim3 grid(f.nblk, f.ny);
   DW_DISPATCH(dwconv_bwd_filter_k, x, dy, ws, N, H, W, g.Ho, g.Wo, C, g.pt, g.pl, f.QB, f.RP, f.items_per_block);
   MLIIS_CHECK_LAUNCH("dwconv_bwd_filter");
+  if (dw == nullptr) return MLIIS_OK;
   hipLaunchKernelGGL(fold_flat_k, dim3(ceil_div(k * k * C, kFoldX)), dim3(kFoldX, kFoldY), 0, stream, ws, f.nblk, (long long)k * k * C, 1.0f,
                      dw, 0, (long long)k * k * C, 0LL, 0LL);
   MLIIS_CHECK_LAUNCH("dwconv_bwd_filter_finalize");

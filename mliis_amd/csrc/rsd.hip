@@ -26,6 +26,11 @@ __global__ __launch_bounds__(kRsdThreads) void rsd_pool_fwd_k(const float* __res
   float* sp = dyn;
   float* red = dyn + (size_t)N * Cp;
   const int cls = blockIdx.x;
+  // blockIdx.y selects a chunk of the constant channels; the chunks' partial results are folded by a second (tiny) launch
+  const int cchunk = (Cp + gridDim.y - 1) / gridDim.y;
+  const int cbeg = blockIdx.y * cchunk;
+  const int cend = (cbeg + cchunk < Cp) ? cbeg + cchunk : Cp;
+  E += (long long)blockIdx.y * N * 9 * Co;
   const int rc = cls / 3, cc = cls - rc * 3;
   const int CL = kRsdThreads / Co;
   const int co = threadIdx.x % Co, cl = threadIdx.x / Co;
@@ -35,7 +40,7 @@ __global__ __launch_bounds__(kRsdThreads) void rsd_pool_fwd_k(const float* __res
 #pragma unroll
   for (int n = 0; n < kRsdMaxN; ++n) a[n] = 0.f;
   if (cl < CL)
-    for (int c = cl; c < Cp; c += CL) {
+    for (int c = cbeg + cl; c < cend; c += CL) {
       float ws = 0.f;
 #pragma unroll
       for (int ty = 0; ty < 3; ++ty)
@@ -153,15 +158,23 @@ extern "C" {
 
 // border_bias[n][class][co] for mliis_conv2d_fwd: contribution of the constant input channels [c_begin, c_begin+Cp) whose
 // per-image values are pool[n][:].  w: HWIO [3,3,Cin_total,Co].
-int mliis_rsd_pool_fwd(const float* pool, const float* w, float* border_bias, int N, int Cp, int Cin_total, int c_begin, int Co,
-                       hipStream_t stream) {
+size_t mliis_rsd_pool_fwd_workspace_floats(int N, int Co) { return (N > 0 && Co > 0) ? (size_t)8 * N * 9 * Co : 0; }
+
+int mliis_rsd_pool_fwd(const float* pool, const float* w, float* border_bias, int N, int Cp, int Cin_total, int c_begin, int Co, float* ws,
+                       size_t ws_floats, hipStream_t stream) {
   MLIIS_REQUIRE(pool && w && border_bias, MLIIS_ERR_ARG, "rsd_pool_fwd: null pointer");
   MLIIS_REQUIRE(N > 0 && N <= kRsdMaxN && Cp > 0 && Co > 0 && Co <= 1024 && c_begin >= 0 && c_begin + Cp <= Cin_total &&
                     (size_t)N * Cp + kRsdThreads <= 15360,
                 MLIIS_ERR_ARG, "rsd_pool_fwd: bad shape (N <= %d)", kRsdMaxN);
-  hipLaunchKernelGGL(rsd_pool_fwd_k, dim3(9), dim3(kRsdThreads), ((size_t)N * Cp + kRsdThreads) * sizeof(float), stream, pool, w, border_bias,
-                     N, Cp, Cin_total, c_begin, Co);
+  const int S = 8;   // channel chunks: 72 workgroups instead of 9, each streaming 1/8 of the weights
+  MLIIS_REQUIRE(ws && (size_t)S * N * 9 * Co <= ws_floats, MLIIS_ERR_WORKSPACE, "rsd_pool_fwd: workspace too small");
+  hipLaunchKernelGGL(rsd_pool_fwd_k, dim3(9, S), dim3(kRsdThreads), ((size_t)N * Cp + kRsdThreads) * sizeof(float), stream, pool, w, ws, N,
+                     Cp, Cin_total, c_begin, Co);
   MLIIS_CHECK_LAUNCH("rsd_pool_fwd");
+  const long long total = (long long)N * 9 * Co;
+  hipLaunchKernelGGL(fold_flat_k, dim3(ceil_div(total, kFoldX)), dim3(kFoldX, kFoldY), 0, stream, ws, S, total, 1.0f, border_bias, 0, total,
+                     0LL, 0LL);
+  MLIIS_CHECK_LAUNCH("rsd_pool_fwd_fold");
   return MLIIS_OK;
 }
 

@@ -168,7 +168,7 @@ size_t mliis_stem_conv_bwd_filter_workspace_floats(int N, int H, int W, int Co) 
 
 int mliis_stem_conv_bwd_filter(const float* x, const int* img_idx, const float* dz, float* dw, int N, int H, int W, int Co,
                                const float* mean3, const float* std3, float* ws, size_t ws_floats, hipStream_t stream) {
-  MLIIS_REQUIRE(x && dz && dw && ws && mean3 && std3, MLIIS_ERR_ARG, "stem_conv_bwd_filter: null pointer");
+  MLIIS_REQUIRE(x && dz && ws && mean3 && std3, MLIIS_ERR_ARG, "stem_conv_bwd_filter: null pointer");   // dw == NULL: slabs stay in ws
   MLIIS_REQUIRE(N > 0 && H > 1 && W > 1 && Co > 0 && (Co & 3) == 0 && Co <= 256, MLIIS_ERR_ARG, "stem_conv_bwd_filter: bad shape");
   MLIIS_REQUIRE(aligned16(dz) && aligned16(ws), MLIIS_ERR_ALIGN, "stem_conv_bwd_filter: dz / workspace must be 16-byte aligned");
   StemGeom g = stem_geom(H, W);
@@ -179,6 +179,7 @@ int mliis_stem_conv_bwd_filter(const float* x, const int* img_idx, const float* 
   hipLaunchKernelGGL(stem_bwd_filter_k, dim3(nblk), dim3(256), 0, stream, x, img_idx, dz, ws, N, H, W, g.Ho, g.Wo, Co,
                      g.pt, g.pl, nm, ppb);
   MLIIS_CHECK_LAUNCH("stem_conv_bwd_filter");
+  if (dw == nullptr) return MLIIS_OK;
   hipLaunchKernelGGL(fold_flat_k, dim3(ceil_div(27 * Co, kFoldX)), dim3(kFoldX, kFoldY), 0, stream, ws, nblk, (long long)27 * Co, 1.0f, dw, 0, (long long)27 * Co, 0LL, 0LL);
   MLIIS_CHECK_LAUNCH("stem_conv_bwd_filter_finalize");
   return MLIIS_OK;

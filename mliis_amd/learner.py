@@ -100,6 +100,37 @@ class _Plan:
             need = max(need, -(-(N * m.h * m.h) // 64) * 2 * m.c_out, ops.bn_stats_partial_floats(N * m.h * m.h, m.c_out))
         need = max(need, ops.bn_stats_partial_floats(N * hs * hs, a.stem_out))
         self.stats_part = buf(need + 64)
+        # ---- deferred weight-gradient folds: every *_bwd_filter leaves its per-split slabs in a region of fold_buf and ONE
+        #      mliis_fold_batched launch at the end of the backward pass reduces them all into the gradient arena
+        A = L.arena
+        regs, rows, off, tile = {}, [], 0, 0
+
+        def add(name, ws_floats, total, seg=None):
+            nonlocal off, tile
+            seg_len, seg_stride, seg_off = seg or (total, 0, 0)
+            regs[name] = (off, ws_floats)
+            rows.append([off, A.t_off[name], total, seg_len, seg_stride, seg_off, ws_floats // total, tile])
+            off += (ws_floats + 3) // 4 * 4
+            tile += -(-total // 16)
+        fe = a.name
+        add(f"{fe}/stem/conv2d/kernel", lib.size("mliis_stem_conv_bwd_filter_workspace_floats", N, H, H, a.stem_out), 27 * a.stem_out)
+        for b, nm in zip([b for b in a.blocks if b.executed], L.n_blocks):
+            ce = b.cexp
+            if b.expand != 1:
+                add(nm["w_exp"], lib.size("mliis_conv2d_bwd_filter_workspace_floats", N, b.h_in, b.h_in, b.cin, ce, 1), b.cin * ce)
+            add(nm["w_dw"], lib.size("mliis_dwconv_bwd_filter_workspace_floats", N, b.h_in, b.h_in, ce, b.k, b.stride), b.k * b.k * ce)
+            add(nm["w_proj"], lib.size("mliis_conv2d_bwd_filter_workspace_floats", N, b.h_out, b.h_out, ce, b.cout, 1), ce * b.cout)
+        for m, nm in zip(a.rsd, L.n_rsd):
+            (k0, _, _), (k1, _, _), (kf, _, _) = nm
+            co = m.c_out
+            add(k0, lib.size("mliis_conv2d_bwd_filter_workspace_floats", N, m.h, m.h, m.c_cat, co, 1), m.c_cat * co)
+            add(k1, lib.size("mliis_conv2d_bwd_filter_workspace_floats", N, m.h, m.h, m.c_cat, co, 3), 9 * m.c_cat * co)
+            add(kf, lib.size("mliis_conv2d_bwd_filter_workspace_floats", N, m.h, m.h, 2 * co, co, 3), 9 * 2 * co * co,
+                seg=(2 * co * co, m.c_pyr * co, 0))
+        self.fold_buf = buf(off + 16)
+        self.fold_part = {k: self.fold_buf[o:o + n] for k, (o, n) in regs.items()}
+        self.fold_desc = torch.tensor(rows, dtype=torch.int64, device=dev)
+        self.fold_tiles = tile
         self.graph = None           # captured hipGraphExec for the training step
         self.steps_run = 0
 
@@ -358,7 +389,7 @@ class Learner:
             bn(D["z1"], D["st1"], n1, pyr[..., m.c_out:2 * m.c_out], pre=True, fused=True, nblk=nb)
             # pooled branch: per-image mean of `cat`, folded into the fuse conv as a border-class bias (rsd.hip)
             ops.colsum(cat, None, nseg=N, scale=1.0 / (m.h * m.h), out=D["pool"], ws=ws)
-            ops.rsd_pool_fwd(D["pool"], w[kf], 2 * m.c_out, out=D["bbias"])
+            ops.rsd_pool_fwd(D["pool"], w[kf], 2 * m.c_out, out=D["bbias"], ws=ws)
             nb = conv(pyr, kf, bf, 1, D["zf"], True, border_bias=D["bbias"])
             dec = bn(D["zf"], D["stf"], nf, D["out"], pre=True, res=up, fused=True, nblk=nb)
         mask = P.drop_mask if (training and P.drop_mask is not None) else None
@@ -396,16 +427,16 @@ class Learner:
             bn_b(D["zf"], dO, D["stf"], nf, D["dzf"], pre=True)
             ops.colsum(D["dzf"], None, nseg=N, out=D["tot"], ws=ws)
             ops.rsd_pool_bwd(D["dzf"], D["tot"], D["pool"], w[kf], 2 * co, dw=g[kf], dbias=g[bf], dpool=D["dpool"], ws=ws)
-            ops.conv2d_bwd_filter(pyr, D["dzf"], 3, 1, out=g[kf], ws=ws)          # rows of the 2*co convolved channels
+            ops.conv2d_bwd_filter(pyr, D["dzf"], 3, 1, partial=P.fold_part[kf])    # rows of the 2*co convolved channels
             ops.conv2d_bwd_data(D["dzf"], w[kf], 1, ci_begin=0, ci_count=2 * co, out=dpyr, ws=ws)
             d0, d1 = dpyr[..., :co], dpyr[..., co:2 * co]
             bn_b(D["z0"], d0, D["st0"], n0, d0, pre=True)
             ops.colsum(d0, None, out=g[b0].view(1, -1), ws=ws)
-            ops.conv2d_bwd_filter(cat, d0, 1, 1, out=g[k0], ws=ws)
+            ops.conv2d_bwd_filter(cat, d0, 1, 1, partial=P.fold_part[k0])
             ops.conv2d_bwd_data(d0, w[k0], 1, out=dcat, ws=ws)
             bn_b(D["z1"], d1, D["st1"], n1, d1, pre=True)
             ops.colsum(d1, None, out=g[b1].view(1, -1), ws=ws)
-            ops.conv2d_bwd_filter(cat, d1, 3, 2, out=g[k1], ws=ws)
+            ops.conv2d_bwd_filter(cat, d1, 3, 2, partial=P.fold_part[k1])
             ops.conv2d_bwd_data(d1, w[k1], 2, out=dcat, accumulate=True, ws=ws)
             ops.chan_affine(None, A=D["dpool"], out=dcat, accumulate=True)   # d(mean)/d(cat) = dpool / (H*W) on every pixel
             # dU = dO + dcat[:, :c_deep] (residual);  dS = dcat[:, c_deep:]
@@ -440,7 +471,7 @@ class Learner:
                 ops.chan_affine(dout, out=tgt, accumulate=tgt_has)
                 tgt_has = True
             bn_b(B["z2"], dout, B["st2"], nm["bn2"], dout, img_scale=B["dc"] if B["use_dc"] else None)
-            ops.conv2d_bwd_filter(B["a1"], dout, 1, 1, out=g[nm["w_proj"]], ws=ws, x_scale=B["gate"])
+            ops.conv2d_bwd_filter(B["a1"], dout, 1, 1, x_scale=B["gate"], partial=P.fold_part[nm["w_proj"]])
             n2 = N * hw * ce
             da2 = P.gA[:n2].view(N, b.h_out, b.h_out, ce)
             ops.conv2d_bwd_data(dout, w[nm["w_proj"]], 1, out=da2, ws=ws)
@@ -450,13 +481,13 @@ class Learner:
             ops.se_mlp_bwd(B["dgate"], B["gate"], B["s"], B["hpre"], w[se[0]], w[se[2]], hw, outs)
             bn_b(B["z1"], da2, B["st1"], nm["bn1"], da2, post=True, chan_scale=B["gate"], chan_add=B["chan_add"])
             dw_in = B["a0"] if b.expand != 1 else B["x_in"]
-            ops.dwconv_bwd_filter(dw_in, da2, b.k, b.stride, out=g[nm["w_dw"]], ws=ws)
+            ops.dwconv_bwd_filter(dw_in, da2, b.k, b.stride, partial=P.fold_part[nm["w_dw"]])
             if b.expand != 1:
                 n0 = N * b.h_in * b.h_in * ce
                 da0 = P.gB[:n0].view(N, b.h_in, b.h_in, ce)
                 ops.dwconv_bwd_data(da2, w[nm["w_dw"]], b.stride, (b.h_in, b.h_in), out=da0)
                 bn_b(B["z0"], da0, B["st0"], nm["bn0"], da0, post=True)
-                ops.conv2d_bwd_filter(B["x_in"], da0, 1, 1, out=g[nm["w_exp"]], ws=ws)
+                ops.conv2d_bwd_filter(B["x_in"], da0, 1, 1, partial=P.fold_part[nm["w_exp"]])
                 ops.conv2d_bwd_data(da0, w[nm["w_exp"]], 1, out=tgt, accumulate=tgt_has, ws=ws)
             else:
                 if tgt_has:  # no-expand block with identity skip (EfficientNet-B3 stage-1 repeats)
@@ -469,7 +500,8 @@ class Learner:
             if bi > 0:
                 has_grad[bi - 1] = True
         bn_b(P.z_stem, P.dstem, P.st_stem, self.n_stem[1], P.dstem, post=True)
-        ops.stem_conv_bwd_filter(x, P.dstem, idx, out=g[self.n_stem[0]], ws=ws)
+        ops.stem_conv_bwd_filter(x, P.dstem, idx, partial=P.fold_part[self.n_stem[0]])
+        ops.fold_batched(P.fold_buf, A.grad, P.fold_desc, P.fold_tiles)
 
     # ------------------------------------------------------------------------------------------- one optimisation step
     def _apply(self):

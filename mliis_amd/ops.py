@@ -118,9 +118,13 @@ def stem_conv_fwd(x, w, idx=None, out=None):
     return out
 
 
-def stem_conv_bwd_filter(x, dz, idx=None, out=None, ws: Optional[Workspace] = None):
+def stem_conv_bwd_filter(x, dz, idx=None, out=None, ws: Optional[Workspace] = None, partial=None):
     S, H, W, _ = x.shape
     N, _, _, Co = dz.shape
+    if partial is not None:
+        lib.call("mliis_stem_conv_bwd_filter", _ptr(x), _ptr(idx), _ptr(dz), None, N, H, W, Co, _MEAN3, _STD3, _ptr(partial), partial.numel(),
+                 _stream())
+        return None
     ws = ws or default_ws()
     need = lib.size("mliis_stem_conv_bwd_filter_workspace_floats", N, H, W, Co)
     buf = ws.get(need)
@@ -152,8 +156,11 @@ def dwconv_bwd_data(dy, w, stride, in_hw, out=None):
     return out
 
 
-def dwconv_bwd_filter(x, dy, k, stride, out=None, ws: Optional[Workspace] = None):
+def dwconv_bwd_filter(x, dy, k, stride, out=None, ws: Optional[Workspace] = None, partial=None):
     N, H, W, C_ = x.shape
+    if partial is not None:
+        lib.call("mliis_dwconv_bwd_filter", _ptr(x), _ptr(dy), None, N, H, W, C_, k, stride, _ptr(partial), partial.numel(), _stream())
+        return None
     ws = ws or default_ws()
     buf = ws.get(lib.size("mliis_dwconv_bwd_filter_workspace_floats", N, H, W, C_, k, stride))
     out = torch.empty((k, k, C_, 1), dtype=torch.float32, device=x.device) if out is None else out
@@ -220,11 +227,17 @@ def conv2d_bwd_data(dy, w, dil=1, ci_begin=0, ci_count=None, out=None, accumulat
     return out
 
 
-def conv2d_bwd_filter(x, dy, k, dil=1, out=None, accumulate=False, ws: Optional[Workspace] = None, x_scale=None, ci_begin=0):
-    """Writes rows [ci_begin, ci_begin + x.channels) of `out` ([k,k,Cin_total,Cout]; Cin_total = x.channels when out is None)."""
+def conv2d_bwd_filter(x, dy, k, dil=1, out=None, accumulate=False, ws: Optional[Workspace] = None, x_scale=None, ci_begin=0, partial=None):
+    """Writes rows [ci_begin, ci_begin + x.channels) of `out` ([k,k,Cin_total,Cout]; Cin_total = x.channels when out is None).
+    With `partial` (float buffer of conv2d_bwd_filter_floats(...) elements) only the per-split slabs are produced there; a later
+    fold_batched() call reduces them."""
     N, H, W = dy.shape[:3]
     _, Cin, ldx = rows_ld(x)
     _, Cout, lddy = rows_ld(dy)
+    if partial is not None:
+        lib.call("mliis_conv2d_bwd_filter", _ptr(x), ldx, _ptr(x_scale), _ptr(dy), lddy, None, N, H, W, Cin, 0, Cin, Cout, k, dil, 0,
+                 _ptr(partial), partial.numel(), _stream())
+        return None
     out = torch.empty((k, k, Cin, Cout), dtype=torch.float32, device=x.device) if out is None else out
     Cin_total = out.shape[2]
     ws = ws or default_ws()
@@ -236,12 +249,14 @@ def conv2d_bwd_filter(x, dy, k, dil=1, out=None, accumulate=False, ws: Optional[
     return out
 
 
-def rsd_pool_fwd(pool, w, c_begin, out=None):
+def rsd_pool_fwd(pool, w, c_begin, out=None, ws: Optional[Workspace] = None):
     """border-class bias [N,9,Cout] of the constant channels [c_begin, c_begin+Cp) of a 3x3 conv with weights w."""
     N, Cp = pool.shape
     _, _, Cin_total, Co = w.shape
     out = torch.empty((N, 9, Co), dtype=torch.float32, device=pool.device) if out is None else out
-    lib.call("mliis_rsd_pool_fwd", _ptr(pool), _ptr(w), _ptr(out), N, Cp, Cin_total, c_begin, Co, _stream())
+    ws = ws or default_ws()
+    buf = ws.get(lib.size("mliis_rsd_pool_fwd_workspace_floats", N, Co))
+    lib.call("mliis_rsd_pool_fwd", _ptr(pool), _ptr(w), _ptr(out), N, Cp, Cin_total, c_begin, Co, _ptr(buf), buf.numel(), _stream())
     return out
 
 
@@ -431,6 +446,11 @@ def softmax_ce(logits, labels, idx=None, label_smoothing=0.0, dice=False, extra_
     lib.call("mliis_softmax_ce", _ptr(logits), _ptr(labels), _ptr(idx), N, H, W, float(label_smoothing), int(dice), float(extra_loss),
              _ptr(dlogits) if want_grad else None, _ptr(pred) if want_pred else None, _ptr(out), _ptr(buf), buf.numel(), _stream())
     return out, dlogits, pred
+
+
+def fold_batched(part_base, out_base, desc, total_tiles):
+    """One launch folding every deferred weight-gradient slab set (desc: device int64 [n,8], see include/mliis_hip.h)."""
+    lib.call("mliis_fold_batched", _ptr(part_base), _ptr(out_base), _ptr(desc), int(desc.shape[0]), int(total_tiles), _stream())
 
 
 # ------------------------------------------------------------------------------------------------ optimizer / arena
