@@ -18,44 +18,37 @@ __global__ __launch_bounds__(256) void dwconv_fwd_k(const float* __restrict__ x,
   constexpr int IW = (TW - 1) * S + K;
   const int Q = C >> 2;
   const int strips = (Wo + TW - 1) / TW;
-  const long long total = (long long)N * Ho * strips * Q;
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  const unsigned total = (unsigned)N * Ho * strips * Q;   // host guarantees < 2^31: 32-bit index math (64-bit div is ~4x dearer)
+  const unsigned i = blockIdx.x * 256u + threadIdx.x;
   if (i >= total) return;
-  const int cq = (int)(i % Q);
-  long long r = i / Q;
-  const int sx = (int)(r % strips);
-  r /= strips;
-  const int ho = (int)(r % Ho);
-  const int n = (int)(r / Ho);
+  const int cq = (int)(i % (unsigned)Q);
+  unsigned r = i / (unsigned)Q;
+  const int sx = (int)(r % (unsigned)strips);
+  r /= (unsigned)strips;
+  const int ho = (int)(r % (unsigned)Ho);
+  const int n = (int)(r / (unsigned)Ho);
   const int c = cq << 2;
   const int wo0 = sx * TW;
   const int hi0 = ho * S - pt, wi0 = wo0 * S - pl;
-  // Phase 1: issue EVERY load of the K x IW window unconditionally (out-of-range taps read a safe dummy address and are
-  // zeroed by a select) so all K*IW requests are in flight together -- one memory round trip per thread instead of K.
-  float4 in[K][IW];
-#pragma unroll
-  for (int ky = 0; ky < K; ++ky) {
-    const int hi = hi0 + ky;
-    const bool rok = (hi >= 0) && (hi < Hi);
-    const float* xrow = x + ((long long)(n * Hi + (rok ? hi : 0)) * Wi) * C + c;
-#pragma unroll
-    for (int j = 0; j < IW; ++j) {
-      const int wi = wi0 + j;
-      const bool ok = rok && (wi >= 0) && (wi < Wi);
-      const float4 v = ld4(ok ? xrow + (long long)wi * C : x + c);
-      in[ky][j] = ok ? v : f4zero();
-    }
-  }
   float4 acc[TW];
 #pragma unroll
   for (int t = 0; t < TW; ++t) acc[t] = f4zero();
 #pragma unroll
   for (int ky = 0; ky < K; ++ky) {
+    const int hi = hi0 + ky;
+    if (hi < 0 || hi >= Hi) continue;
+    const float* xrow = x + ((long long)(n * Hi + hi) * Wi) * C + c;
+    float4 in[IW];
+#pragma unroll
+    for (int j = 0; j < IW; ++j) {
+      const int wi = wi0 + j;
+      in[j] = (wi >= 0 && wi < Wi) ? ld4(xrow + (long long)wi * C) : f4zero();
+    }
 #pragma unroll
     for (int kx = 0; kx < K; ++kx) {
       const float4 wv = ld4(w + (ky * K + kx) * C + c);
 #pragma unroll
-      for (int t = 0; t < TW; ++t) acc[t] = f4fma(in[ky][t * S + kx], wv, acc[t]);
+      for (int t = 0; t < TW; ++t) acc[t] = f4fma(in[t * S + kx], wv, acc[t]);
     }
   }
   float* yrow = y + ((long long)(n * Ho + ho) * Wo) * C + c;
@@ -72,42 +65,40 @@ __global__ __launch_bounds__(256) void dwconv_bwd_data_k(const float* __restrict
   constexpr int JW = TW + K - 1;
   const int Q = C >> 2;
   const int strips = (Wi + TW - 1) / TW;
-  const long long total = (long long)N * Hi * strips * Q;
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  const unsigned total = (unsigned)N * Hi * strips * Q;
+  const unsigned i = blockIdx.x * 256u + threadIdx.x;
   if (i >= total) return;
-  const int cq = (int)(i % Q);
-  long long r = i / Q;
-  const int sx = (int)(r % strips);
-  r /= strips;
-  const int hi = (int)(r % Hi);
-  const int n = (int)(r / Hi);
+  const int cq = (int)(i % (unsigned)Q);
+  unsigned r = i / (unsigned)Q;
+  const int sx = (int)(r % (unsigned)strips);
+  r /= (unsigned)strips;
+  const int hi = (int)(r % (unsigned)Hi);
+  const int n = (int)(r / (unsigned)Hi);
   const int c = cq << 2;
   const int wi0 = sx * TW;
   const int base = wi0 + pl - (K - 1);  // wx of window slot j is base + j ; tap kx pairs output t with slot t + K-1-kx
-  float4 dv[K][JW];   // all loads first (see dwconv_fwd_k)
-#pragma unroll
-  for (int ky = 0; ky < K; ++ky) {
-    const int hy = hi + pt - ky;
-    const bool rok = (hy >= 0) && ((hy % S) == 0) && ((hy / S) < Ho);
-    const float* drow = dy + ((long long)(n * Ho + (rok ? hy / S : 0)) * Wo) * C + c;
-#pragma unroll
-    for (int j = 0; j < JW; ++j) {
-      const int wx = base + j;
-      const bool ok = rok && (wx >= 0) && ((wx % S) == 0) && ((wx / S) < Wo);
-      const float4 v = ld4(ok ? drow + (long long)(wx / S) * C : dy + c);
-      dv[ky][j] = ok ? v : f4zero();
-    }
-  }
   float4 acc[TW];
 #pragma unroll
   for (int t = 0; t < TW; ++t) acc[t] = f4zero();
 #pragma unroll
   for (int ky = 0; ky < K; ++ky) {
+    const int hy = hi + pt - ky;
+    if (hy < 0 || (hy % S) != 0) continue;
+    const int ho = hy / S;
+    if (ho >= Ho) continue;
+    const float* drow = dy + ((long long)(n * Ho + ho) * Wo) * C + c;
+    float4 dv[JW];
+#pragma unroll
+    for (int j = 0; j < JW; ++j) {
+      const int wx = base + j;
+      const bool ok = (wx >= 0) && ((wx % S) == 0) && ((wx / S) < Wo);
+      dv[j] = ok ? ld4(drow + (long long)(wx / S) * C) : f4zero();
+    }
 #pragma unroll
     for (int kx = 0; kx < K; ++kx) {
       const float4 wv = ld4(w + (ky * K + kx) * C + c);
 #pragma unroll
-      for (int t = 0; t < TW; ++t) acc[t] = f4fma(dv[ky][t + K - 1 - kx], wv, acc[t]);
+      for (int t = 0; t < TW; ++t) acc[t] = f4fma(dv[t + K - 1 - kx], wv, acc[t]);
     }
   }
   float* xrow = dx + ((long long)(n * Hi + hi) * Wi) * C + c;
@@ -234,14 +225,12 @@ constexpr int kTW = 4;
 
 using namespace mliis;
 
-// strip width per filter size: the all-loads-first window of k = 5 would not fit the register file with 4 outputs per thread
-static inline int tw_of(int k) { return k == 3 ? 4 : 2; }
 #define DW_DISPATCH(KERNEL, ...)                                                                              \
   do {                                                                                                        \
-    if (k == 3 && stride == 1) hipLaunchKernelGGL((KERNEL<3, 1, 4>), grid, dim3(256), 0, stream, __VA_ARGS__);      \
-    else if (k == 3 && stride == 2) hipLaunchKernelGGL((KERNEL<3, 2, 4>), grid, dim3(256), 0, stream, __VA_ARGS__); \
-    else if (k == 5 && stride == 1) hipLaunchKernelGGL((KERNEL<5, 1, 2>), grid, dim3(256), 0, stream, __VA_ARGS__); \
-    else hipLaunchKernelGGL((KERNEL<5, 2, 2>), grid, dim3(256), 0, stream, __VA_ARGS__);                            \
+    if (k == 3 && stride == 1) hipLaunchKernelGGL((KERNEL<3, 1, kTW>), grid, dim3(256), 0, stream, __VA_ARGS__);      \
+    else if (k == 3 && stride == 2) hipLaunchKernelGGL((KERNEL<3, 2, kTW>), grid, dim3(256), 0, stream, __VA_ARGS__); \
+    else if (k == 5 && stride == 1) hipLaunchKernelGGL((KERNEL<5, 1, kTW>), grid, dim3(256), 0, stream, __VA_ARGS__); \
+    else hipLaunchKernelGGL((KERNEL<5, 2, kTW>), grid, dim3(256), 0, stream, __VA_ARGS__);                            \
   } while (0)
 
 static int dw_check(const char* name, const void* a, const void* b, const void* c, int N, int H, int W, int C, int k, int stride) {
@@ -260,8 +249,8 @@ int mliis_dwconv_fwd(const float* x, const float* w, float* y, int N, int H, int
   int rc = dw_check("dwconv_fwd", x, w, y, N, H, W, C, k, stride);
   if (rc) return rc;
   DwGeom g = dw_geom(H, W, k, stride);
-  const int TWk = tw_of(k);
-  long long total = (long long)N * g.Ho * ((g.Wo + TWk - 1) / TWk) * (C / 4);
+  long long total = (long long)N * g.Ho * ((g.Wo + kTW - 1) / kTW) * (C / 4);
+  MLIIS_REQUIRE(total < (1LL << 31), MLIIS_ERR_UNSUPPORTED, "dwconv_fwd: tensor too large for 32-bit indexing");
   dim3 grid(ceil_div(total, 256));
   DW_DISPATCH(dwconv_fwd_k, x, w, y, N, H, W, g.Ho, g.Wo, C, g.pt, g.pl);
   MLIIS_CHECK_LAUNCH("dwconv_fwd");
@@ -273,8 +262,8 @@ int mliis_dwconv_bwd_data(const float* dy, const float* w, float* dx, int N, int
   int rc = dw_check("dwconv_bwd_data", dy, w, dx, N, H, W, C, k, stride);
   if (rc) return rc;
   DwGeom g = dw_geom(H, W, k, stride);
-  const int TWk = tw_of(k);
-  long long total = (long long)N * H * ((W + TWk - 1) / TWk) * (C / 4);
+  long long total = (long long)N * H * ((W + kTW - 1) / kTW) * (C / 4);
+  MLIIS_REQUIRE(total < (1LL << 31), MLIIS_ERR_UNSUPPORTED, "dwconv_bwd_data: tensor too large for 32-bit indexing");
   dim3 grid(ceil_div(total, 256));
   DW_DISPATCH(dwconv_bwd_data_k, dy, w, dx, N, H, W, g.Ho, g.Wo, C, g.pt, g.pl);
   MLIIS_CHECK_LAUNCH("dwconv_bwd_data");
@@ -284,7 +273,7 @@ int mliis_dwconv_bwd_data(const float* dy, const float* w, float* dx, int N, int
 size_t mliis_dwconv_bwd_filter_workspace_floats(int N, int H, int W, int C, int k, int stride) {
   if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return 0;
   DwGeom g = dw_geom(H, W, k, stride);
-  DwFilterGeom f = dw_filter_geom(N, g.Ho, g.Wo, C, tw_of(k));
+  DwFilterGeom f = dw_filter_geom(N, g.Ho, g.Wo, C, kTW);
   return (size_t)f.nblk * k * k * C;
 }
 
@@ -294,7 +283,7 @@ int mliis_dwconv_bwd_filter(const float* x, const float* dy, float* dw, int N, i
   if (rc) return rc;
   MLIIS_REQUIRE(ws && aligned16(ws), MLIIS_ERR_ARG, "dwconv_bwd_filter: workspace null/unaligned");
   DwGeom g = dw_geom(H, W, k, stride);
-  DwFilterGeom f = dw_filter_geom(N, g.Ho, g.Wo, C, tw_of(k));
+  DwFilterGeom f = dw_filter_geom(N, g.Ho, g.Wo, C, kTW);
   size_t need = (size_t)f.nblk * k * k * C;
   MLIIS_REQUIRE(need <= ws_floats, MLIIS_ERR_WORKSPACE, "dwconv_bwd_filter: workspace too small (%zu needed, %zu given)", need,
                 ws_floats);

@@ -107,12 +107,13 @@ __global__ __launch_bounds__(256) void se_wgrad_k(const float* __restrict__ s, c
 __global__ __launch_bounds__(256) void chan_affine_k(const float* __restrict__ x, int ldx, const float* __restrict__ S,
                                                      const float* __restrict__ A, float* __restrict__ y, int ldy, long long rows,
                                                      int C, int rows_per_img, int accumulate) {
-  const int Q = C >> 2;
-  const long long total = rows * Q;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const long long r = i / Q;
-    const int c = (int)(i - r * Q) << 2;
-    const long long n = r / rows_per_img;
+  const unsigned Q = (unsigned)C >> 2;
+  const unsigned total = (unsigned)rows * Q;   // host guarantees < 2^31 (32-bit index math)
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const unsigned ru = i / Q;
+    const int c = (int)(i - ru * Q) << 2;
+    const long long r = ru;
+    const long long n = ru / (unsigned)rows_per_img;
     float4 v = x ? ld4(x + r * ldx + c) : f4zero();
     if (S) v = f4mul(v, ld4(S + n * C + c));
     if (A) v = f4add(v, ld4(A + n * C + c));
@@ -161,6 +162,7 @@ int mliis_chan_affine(const float* x, int ldx, const float* S, const float* A, f
                     (x == nullptr || ((ldx & 3) == 0 && ldx >= C)),
                 MLIIS_ERR_ARG, "chan_affine: bad shape");
   MLIIS_REQUIRE(aligned16(x) && aligned16(S) && aligned16(A) && aligned16(y), MLIIS_ERR_ALIGN, "chan_affine: pointers must be 16-byte aligned");
+  MLIIS_REQUIRE(rows * (C / 4) < (1LL << 31), MLIIS_ERR_UNSUPPORTED, "chan_affine: tensor too large for 32-bit indexing");
   long long q = rows * (C / 4);
   int blocks = (int)((q + 255) / 256 > 4096 ? 4096 : (q + 255) / 256);
   hipLaunchKernelGGL(chan_affine_k, dim3(blocks), dim3(256), 0, stream, x, ldx, S, A, y, ldy, rows, C, rows_per_img, accumulate);

@@ -277,7 +277,7 @@ def predictions(logits):
 
 
 def inner_step(a, params, bn, x, y, lr, dc_scales=None, dropout_mask=None, label_smoothing=0.0, dice=False, l2=False,
-               weight_decay_rate=1.0):
+               weight_decay_rate=1.0, adam_state=None):
     """One `session.run(minimize_op)` (reptile.py:114-121,639-643): fwd + bwd + BN moving update + SGD apply.
     Mutates params / bn in place; returns (loss, grads dict, logits)."""
     if weight_decay_rate != 1.0:  # pre_step_op, meta_learners/variables.py:48-55
@@ -293,7 +293,19 @@ def inner_step(a, params, bn, x, y, lr, dc_scales=None, dropout_mask=None, label
         if g is None:
             g = torch.zeros_like(params[k])
         out_g[k] = g
-        params[k] = params[k] - lr * g
+        if adam_state is None:
+            params[k] = params[k] - lr * g          # tf.train.GradientDescentOptimizer
+        else:
+            # tf.train.AdamOptimizer(beta1=0, beta2=0.999, epsilon=1e-8) (models/efficientlab.py:16): m = g,
+            # v = b2 v + (1-b2) g^2, w -= lr * sqrt(1 - b2^t) / (1 - b1^t) * m / (sqrt(v) + eps)
+            t = adam_state["t"] + 1
+            v = adam_state["v"].get(k, torch.zeros_like(g)) * 0.999 + 0.001 * g * g
+            adam_state["v"][k] = v
+            params[k] = params[k] - lr * math.sqrt(1.0 - 0.999 ** t) * g / (v.sqrt() + 1e-8)
+    if adam_state is not None:
+        adam_state["t"] += 1
+    for k in []:
+        pass
     for k, v in new_moving.items():
         bn[k] = v
     return float(loss.detach()), out_g, logits.detach()

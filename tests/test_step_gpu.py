@@ -185,3 +185,49 @@ def test_evaluate_path_matches_oracle():
             assert torch.equal(before["theta"], after["theta"]) and torch.equal(before["bn"], after["bn"])   # full state restored
     assert abs(res[0][0] - res[2][0]) <= 5e-3, (res[0][0], res[2][0])      # non-transductive mean IoU
     assert abs(res[1][0] - res[3][0]) <= 5e-3, (res[1][0], res[3][0])      # transductive mean IoU
+
+
+def test_dropout_adam_and_b3_variants():
+    """(a) final-layer dropout with an injected mask (run.sh uses rate 0.5); (b) Adam(beta1=0) -- the reference's default optimizer
+    when --sgd is absent; (c) the EfficientNet-B3 backbone (fp32): 18 executed + 8 never-executed blocks, 136-channel decoder."""
+    _need_gpu()
+    from mliis_amd.learner import Learner
+    H, S, idx = 64, 5, [0, 1, 2, 3, 4, 4, 3, 2]
+    x, y = _task(S, H, 9)
+    xb, yb = torch.tensor(x[idx]).double(), torch.tensor(y[idx]).double()
+    # (a) dropout
+    O, L = _pair(H, final_layer_dropout_rate=0.5)
+    L.load_task(x, y)
+    g = torch.Generator().manual_seed(0)
+    mask = (torch.rand(8, 16, 16, 112, generator=g) < 0.5).double() * 2.0
+    lo, gO, _ = R.inner_step(O.a, O.params, O.bn, xb, yb, 1e-3, None, mask)
+    L.inner_step(idx, dc_scales={}, dropout_mask=mask.float())
+    assert abs(L.loss_value() - lo) <= 1e-4 * max(1.0, abs(lo))
+    _compare_state(O, L, gO, "dropout")
+    # (b) Adam(beta1 = 0), two steps
+    O = R.OracleLearner(image_size=H, seed=0, dtype=torch.float64, lr=1e-3)
+    L = Learner(image_size=H, seed=3, optimizer="adam", use_graph=False, drop_connect=False)
+    L.load_named({k: v.numpy() for k, v in O.params.items()}, strict=False)
+    L.load_task(x, y)
+    st = {"t": 0, "v": {}}
+    for _ in range(2):
+        lo, _, _ = R.inner_step(O.a, O.params, O.bn, xb, yb, 1e-3, None, None, adam_state=st)
+        L.inner_step(idx)
+        assert abs(L.loss_value() - lo) <= 1e-3 * max(1.0, abs(lo))
+    th = L.arena.export_trainable_packed().cpu().double()
+    ref = torch.cat([O.params[p.name].reshape(-1) for p in L.arena.trainable])
+    assert (th - ref).abs().max().item() <= 2e-4      # Adam's g/sqrt(v) amplifies fp32 rounding of tiny gradients
+    # (c) EfficientNet-B3 backbone
+    O = R.OracleLearner(name="efficientnet-b3", image_size=H, seed=0, dtype=torch.float64, lr=1e-3, l2=True)
+    L = Learner(feature_extractor_name="efficientnet-b3", image_size=H, seed=4, use_graph=False, drop_connect=False, l2=True)
+    assert L.n_trainable == 11908874
+    L.load_named({k: v.numpy() for k, v in O.params.items()}, strict=False)
+    L.load_task(x, y)
+    lo = O.inner_step(xb, yb)
+    L.inner_step(idx)
+    th0 = R.init_state(O.a, 0)[0]
+    l2 = 0.0005 * sum(0.5 * (v ** 2).sum().item() for k, v in th0.items() if "batch_normalization" not in k)
+    assert abs(L.loss_value() + l2 - lo) <= 1e-4 * max(1.0, abs(lo))
+    th = L.arena.export_trainable_packed().cpu().double()
+    ref = torch.cat([O.params[p.name].reshape(-1) for p in L.arena.trainable])
+    assert (th - ref).abs().max().item() <= 1e-5      # includes the never-executed blocks, which only receive the L2 gradient
