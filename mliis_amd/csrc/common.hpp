@@ -45,6 +45,15 @@ __device__ __forceinline__ float4 f4fma(float4 a, float4 b, float4 c) {
 }
 __device__ __forceinline__ float4 f4scale(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
 
+// XCD-aware block remap (bijective for any grid size): workgroups are dealt round-robin over the 8 XCDs, each with a private
+// L2, so logical neighbours (adjacent rows / row tiles that share halo data) would land on different L2s.  Logical block
+// xcd_remap(b, n) gives every XCD one contiguous 1/8 of the logical range, turning halo re-reads into same-XCD L2 hits.
+// Placement is only a speed matter: results never depend on it.
+__device__ __forceinline__ unsigned xcd_remap(unsigned b, unsigned n) {
+  const unsigned q = n >> 3, r = n & 7u, x = b & 7u, l = b >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + l;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -86,7 +86,8 @@ __global__ __launch_bounds__(256) void conv_gemm_k(ConvGemmParams p) {
 #pragma unroll
   for (int j = 0; j < NT; ++j) s1[j] = s2[j] = 0.f;
 
-  const long long m0 = (long long)blockIdx.x * BM;
+  const unsigned bx = xcd_remap(blockIdx.x, gridDim.x);   // neighbouring row tiles (shared 3x3 halos) on the same XCD's L2
+  const long long m0 = (long long)bx * BM;
 
   // ---- per-thread A rows
   const int a_kq = t & 7;
@@ -328,7 +329,7 @@ __global__ __launch_bounds__(256) void conv_gemm_k(ConvGemmParams p) {
       const int n = n0 + col;
       if (n < p.Nout) {
         const float r0 = red[(0 * 2 + v) * BN + col] + red[(1 * 2 + v) * BN + col] + red[(2 * 2 + v) * BN + col] + red[(3 * 2 + v) * BN + col];
-        p.stats_part[((long long)blockIdx.x * 2 + v) * p.Nout + n] = r0;
+        p.stats_part[((long long)bx * 2 + v) * p.Nout + n] = r0;
       }
     }
   }

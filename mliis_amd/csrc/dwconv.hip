@@ -19,7 +19,7 @@ __global__ __launch_bounds__(256) void dwconv_fwd_k(const float* __restrict__ x,
   const int Q = C >> 2;
   const int strips = (Wo + TW - 1) / TW;
   const unsigned total = (unsigned)N * Ho * strips * Q;   // host guarantees < 2^31: 32-bit index math (64-bit div is ~4x dearer)
-  const unsigned i = blockIdx.x * 256u + threadIdx.x;
+  const unsigned i = xcd_remap(blockIdx.x, gridDim.x) * 256u + threadIdx.x;
   if (i >= total) return;
   const int cq = (int)(i % (unsigned)Q);
   unsigned r = i / (unsigned)Q;
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_data_k(const float* __restrict
   const int Q = C >> 2;
   const int strips = (Wi + TW - 1) / TW;
   const unsigned total = (unsigned)N * Hi * strips * Q;
-  const unsigned i = blockIdx.x * 256u + threadIdx.x;
+  const unsigned i = xcd_remap(blockIdx.x, gridDim.x) * 256u + threadIdx.x;
   if (i >= total) return;
   const int cq = (int)(i % (unsigned)Q);
   unsigned r = i / (unsigned)Q;
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_filter_k(const float* __restri
 #pragma unroll
   for (int k = 0; k < K * K; ++k) acc[k] = f4zero();
   if (active) {
-    const long long i0 = (long long)blockIdx.x * items_per_block;
+    const long long i0 = (long long)xcd_remap(blockIdx.x, gridDim.x) * items_per_block;
     long long i1 = i0 + items_per_block;
     if (i1 > items) i1 = items;
     for (long long it = i0 + rl; it < i1; it += RP) {

@@ -1,0 +1,97 @@
+"""Summarises a rocprofv3 --kernel-trace --stats run of `bench.py` (csv output) into a markdown report: per-family time per inner
+step, the top kernels, and the per-layer depthwise table against the HBM roofline (algorithmic bytes of SURVEY.md 8(d)).
+
+    python tools/profile_summary.py <dir with *_kernel_stats.csv / *_kernel_trace.csv> <inner steps profiled> <out.md>
+"""
+import collections
+import csv
+import glob
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mliis_amd import spec  # noqa: E402
+
+
+def family(n):
+    n = n.replace("void mliis::", "").replace("mliis::", "").split("(")[0]
+    if n.startswith("conv_gemm"):
+        return "dense conv fwd / bwd-data (MFMA implicit GEMM)"
+    if n.startswith("conv_filter"):
+        return "dense conv bwd-filter (MFMA)"
+    if n.startswith("dwconv"):
+        return "depthwise " + n.split("_k")[0].replace("dwconv_", "")
+    if n.startswith("bn_") or "BnBwdOp" in n or "StatsOp" in n:
+        return "batch norm (+swish, drop-connect, residual, SE gate grads)"
+    if n.startswith("rsd"):
+        return "RSD pooled branch"
+    if "SumOp" in n or n.startswith("sum_fin") or n.startswith("colsum"):
+        return "per-image column sums (SE pool, bias grads)"
+    if n.startswith("se_"):
+        return "squeeze-excite MLP"
+    if n.startswith("fold") or n.startswith("splitk"):
+        return "slab folds (split-K, weight grads)"
+    if n.startswith("at::") or n.startswith("__amd"):
+        return "torch plumbing (mask RNG, arena copies)"
+    return "other (stem, resize, head, loss, SGD, transposes)"
+
+
+def main():
+    d, steps, out = sys.argv[1], int(sys.argv[2]), sys.argv[3]
+    stats = list(csv.DictReader(open(glob.glob(os.path.join(d, "**", "*_kernel_stats.csv"), recursive=True)[0])))
+    trace = list(csv.DictReader(open(glob.glob(os.path.join(d, "**", "*_kernel_trace.csv"), recursive=True)[0])))
+    tot = sum(float(r["TotalDurationNs"]) for r in stats) / 1e3 / steps
+    nl = sum(int(r["Calls"]) for r in stats) / steps
+    fam = collections.defaultdict(lambda: [0.0, 0.0])
+    for r in stats:
+        f = fam[family(r["Name"])]
+        f[0] += int(r["Calls"]) / steps
+        f[1] += float(r["TotalDurationNs"]) / 1e3 / steps
+    L = ["# rocprofv3 --kernel-trace --stats summary (`bench.py`, N = 1, HIP-graph replay)", "",
+         "Kernel time per inner step (8 images fwd+bwd+BN-EMA+SGD): **%.0f us in %.0f launches** (%d inner steps profiled)." % (tot, nl, steps), "",
+         "| family | launches/step | us/step | share |", "|---|---|---|---|"]
+    for k, (c, t) in sorted(fam.items(), key=lambda x: -x[1][1]):
+        L.append("| %s | %.0f | %.0f | %.1f %% |" % (k, c, t, 100 * t / tot))
+    L += ["", "| kernel | launches/step | avg us | us/step |", "|---|---|---|---|"]
+    for r in sorted(stats, key=lambda r: -float(r["TotalDurationNs"]))[:25]:
+        n = r["Name"].replace("void mliis::", "").replace("mliis::", "").split("(")[0]
+        L.append("| `%s` | %.1f | %.1f | %.0f |" % (n, int(r["Calls"]) / steps, float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e3 / steps))
+    # depthwise per layer (identified by kernel instantiation + grid size)
+    a = spec.derive()
+    N = 8
+    per = collections.defaultdict(list)
+    for r in trace:
+        n = r["Kernel_Name"]
+        if "dwconv" in n:
+            per[(n.split("(")[0].replace("void mliis::", ""), int(r["Grid_Size_X"]))].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+
+    def grid(items):
+        return -(-items // 256) * 256
+    L += ["", "## Depthwise layers vs the HBM roofline (8.0 TB/s spec; algorithmic bytes = 4*(in+out+k*k*C) fwd, 4*(dY+dX+k*k*C) bwd-data)", "",
+          "| block | C | k,s | map | fwd us | fwd GB/s (% of 8 TB/s) | bwd-data us | bwd-data GB/s (%) |", "|---|---|---|---|---|---|---|---|"]
+    tf = tb = bf = bb = 0.0
+    for b in a.blocks:
+        q = b.cexp // 4
+        gf = grid(N * b.h_out * (-(-b.h_out // 4)) * q)
+        gb = grid(N * b.h_in * (-(-b.h_in // 4)) * q)
+        kf = [v for (k, g), v in per.items() if k.startswith("dwconv_fwd_k<%d, %d" % (b.k, b.stride)) and g == gf]
+        kb = [v for (k, g), v in per.items() if k.startswith("dwconv_bwd_data_k<%d, %d" % (b.k, b.stride)) and g == gb]
+        if not kf or not kb:
+            continue
+        mf = sorted(kf[0])[len(kf[0]) // 2] / 1e3
+        mb = sorted(kb[0])[len(kb[0]) // 2] / 1e3
+        by = 4.0 * (N * b.h_in ** 2 * b.cexp + N * b.h_out ** 2 * b.cexp + b.k ** 2 * b.cexp)
+        tf += mf
+        tb += mb
+        bf += by
+        bb += by
+        L.append("| %d | %d | %d,%d | %d->%d | %.1f | %.0f (%.0f %%) | %.1f | %.0f (%.0f %%) |" % (
+            b.idx, b.cexp, b.k, b.stride, b.h_in, b.h_out, mf, by / mf / 1e3, by / mf / 1e3 / 80, mb, by / mb / 1e3, by / mb / 1e3 / 80))
+    if tf:
+        L.append("| **all** | | | | %.1f | %.0f (%.0f %%) | %.1f | %.0f (%.0f %%) |" % (tf, bf / tf / 1e3, bf / tf / 1e3 / 80, tb, bb / tb / 1e3, bb / tb / 1e3 / 80))
+    open(out, "w").write("\n".join(L) + "\n")
+    print("wrote", out)
+
+
+if __name__ == "__main__":
+    main()
