@@ -33,6 +33,32 @@ __global__ __launch_bounds__(256) void dwconv_fwd_k(const float* __restrict__ x,
   float4 acc[TW];
 #pragma unroll
   for (int t = 0; t < TW; ++t) acc[t] = f4zero();
+  if constexpr (K == 5) {
+    // 5x5 layers live on small maps (one wave per SIMD): issue the whole 5 x IW window before any FMA so the loads form ONE
+    // memory round trip instead of five (out-of-range taps read a safe address and are zeroed by a select)
+    float4 in[K][IW];
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky) {
+      const int hi = hi0 + ky;
+      const bool rok = (hi >= 0) && (hi < Hi);
+      const float* xrow = x + ((long long)(n * Hi + (rok ? hi : 0)) * Wi) * C + c;
+#pragma unroll
+      for (int j = 0; j < IW; ++j) {
+        const int wi = wi0 + j;
+        const bool ok = rok && (wi >= 0) && (wi < Wi);
+        const float4 v = ld4(ok ? xrow + (long long)wi * C : x + c);
+        in[ky][j] = ok ? v : f4zero();
+      }
+    }
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < K; ++kx) {
+        const float4 wv = ld4(w + (ky * K + kx) * C + c);
+#pragma unroll
+        for (int t = 0; t < TW; ++t) acc[t] = f4fma(in[ky][t * S + kx], wv, acc[t]);
+      }
+  } else {
 #pragma unroll
   for (int ky = 0; ky < K; ++ky) {
     const int hi = hi0 + ky;
@@ -50,6 +76,7 @@ __global__ __launch_bounds__(256) void dwconv_fwd_k(const float* __restrict__ x,
 #pragma unroll
       for (int t = 0; t < TW; ++t) acc[t] = f4fma(in[t * S + kx], wv, acc[t]);
     }
+  }
   }
   float* yrow = y + ((long long)(n * Ho + ho) * Wo) * C + c;
 #pragma unroll
@@ -80,6 +107,30 @@ __global__ __launch_bounds__(256) void dwconv_bwd_data_k(const float* __restrict
   float4 acc[TW];
 #pragma unroll
   for (int t = 0; t < TW; ++t) acc[t] = f4zero();
+  if constexpr (K == 5) {   // all loads of the 5 x JW window first (see dwconv_fwd_k)
+    float4 dv[K][JW];
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky) {
+      const int hy = hi + pt - ky;
+      const bool rok = (hy >= 0) && ((hy % S) == 0) && ((hy / S) < Ho);
+      const float* drow = dy + ((long long)(n * Ho + (rok ? hy / S : 0)) * Wo) * C + c;
+#pragma unroll
+      for (int j = 0; j < JW; ++j) {
+        const int wx = base + j;
+        const bool ok = rok && (wx >= 0) && ((wx % S) == 0) && ((wx / S) < Wo);
+        const float4 v = ld4(ok ? drow + (long long)(wx / S) * C : dy + c);
+        dv[ky][j] = ok ? v : f4zero();
+      }
+    }
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < K; ++kx) {
+        const float4 wv = ld4(w + (ky * K + kx) * C + c);
+#pragma unroll
+        for (int t = 0; t < TW; ++t) acc[t] = f4fma(dv[ky][t + K - 1 - kx], wv, acc[t]);
+      }
+  } else {
 #pragma unroll
   for (int ky = 0; ky < K; ++ky) {
     const int hy = hi + pt - ky;
@@ -100,6 +151,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_data_k(const float* __restrict
 #pragma unroll
       for (int t = 0; t < TW; ++t) acc[t] = f4fma(dv[t + K - 1 - kx], wv, acc[t]);
     }
+  }
   }
   float* xrow = dx + ((long long)(n * Hi + hi) * Wi) * C + c;
 #pragma unroll

@@ -68,9 +68,11 @@ class _Plan:
             if b.skip:
                 B["dc"] = self.dc_all[si]
                 si += 1
-            gmax = max(gmax, N * hi * hi * ce, N * ho * ho * ce)
+            # gradients w.r.t. the expanded activations: one pair PER BLOCK (not a shared scratch) so the weight-gradient kernels of a
+            # block can run on the side stream while the main stream already works on the next block
+            B["da2"] = buf(N, ho, ho, ce)
+            B["da0"] = buf(N, hi, hi, ce)
             self.blocks.append(B)
-        self.gA, self.gB = buf(gmax), buf(gmax)   # scratch gradients wrt expanded activations
         self.dstem = buf(N, hs, hs, a.stem_out)
         self.rsd = []
         for m in a.rsd:
@@ -162,6 +164,7 @@ class Learner:
         self.drop_connect = drop_connect
         self.use_graph = use_graph
         self.stream = torch.cuda.Stream(device=self.device)
+        self.side_stream = torch.cuda.Stream(device=self.device)   # weight-gradient GEMMs overlap the backward-data chain
         self.arena = Arena(self.arch, self.device)
         self.arena.init_weights(seed)
         self.variables_initialized = True
@@ -414,6 +417,16 @@ class Learner:
         if not P.rsd:
             has_grad[-1] = True
 
+        def side(fn):
+            """Run a weight-gradient producer on the side stream, ordered after everything queued on the main stream so far.  These
+            kernels only read activations / finished gradient buffers and write their own slab region, so the main stream can go on
+            with the next layer's backward-data chain meanwhile (small layers leave most CUs idle otherwise)."""
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+            with torch.cuda.stream(self.side_stream):
+                self.side_stream.wait_event(ev)
+                fn()
+
         def bn_b(xin, dy, st, prefix, dx, pre=False, post=False, img_scale=None, chan_scale=None, chan_add=None):
             ops.bn_bwd(xin, dy, st[0], st[1], w[prefix + "/gamma"], w[prefix + "/beta"], pre, post, img_scale, chan_scale, chan_add, dx=dx,
                        dgamma=g[prefix + "/gamma"], dbeta=g[prefix + "/beta"], ws=ws)
@@ -427,16 +440,16 @@ class Learner:
             bn_b(D["zf"], dO, D["stf"], nf, D["dzf"], pre=True)
             ops.colsum(D["dzf"], None, nseg=N, out=D["tot"], ws=ws)
             ops.rsd_pool_bwd(D["dzf"], D["tot"], D["pool"], w[kf], 2 * co, dw=g[kf], dbias=g[bf], dpool=D["dpool"], ws=ws)
-            ops.conv2d_bwd_filter(pyr, D["dzf"], 3, 1, partial=P.fold_part[kf])    # rows of the 2*co convolved channels
+            side(lambda pyr=pyr, dzf=D["dzf"], kf=kf: ops.conv2d_bwd_filter(pyr, dzf, 3, 1, partial=P.fold_part[kf]))   # rows of the 2*co convolved channels
             ops.conv2d_bwd_data(D["dzf"], w[kf], 1, ci_begin=0, ci_count=2 * co, out=dpyr, ws=ws)
             d0, d1 = dpyr[..., :co], dpyr[..., co:2 * co]
             bn_b(D["z0"], d0, D["st0"], n0, d0, pre=True)
             ops.colsum(d0, None, out=g[b0].view(1, -1), ws=ws)
-            ops.conv2d_bwd_filter(cat, d0, 1, 1, partial=P.fold_part[k0])
+            side(lambda cat=cat, d0=d0, k0=k0: ops.conv2d_bwd_filter(cat, d0, 1, 1, partial=P.fold_part[k0]))
             ops.conv2d_bwd_data(d0, w[k0], 1, out=dcat, ws=ws)
             bn_b(D["z1"], d1, D["st1"], n1, d1, pre=True)
             ops.colsum(d1, None, out=g[b1].view(1, -1), ws=ws)
-            ops.conv2d_bwd_filter(cat, d1, 3, 2, partial=P.fold_part[k1])
+            side(lambda cat=cat, d1=d1, k1=k1: ops.conv2d_bwd_filter(cat, d1, 3, 2, partial=P.fold_part[k1]))
             ops.conv2d_bwd_data(d1, w[k1], 2, out=dcat, accumulate=True, ws=ws)
             ops.chan_affine(None, A=D["dpool"], out=dcat, accumulate=True)   # d(mean)/d(cat) = dpool / (H*W) on every pixel
             # dU = dO + dcat[:, :c_deep] (residual);  dS = dcat[:, c_deep:]
@@ -471,9 +484,8 @@ class Learner:
                 ops.chan_affine(dout, out=tgt, accumulate=tgt_has)
                 tgt_has = True
             bn_b(B["z2"], dout, B["st2"], nm["bn2"], dout, img_scale=B["dc"] if B["use_dc"] else None)
-            ops.conv2d_bwd_filter(B["a1"], dout, 1, 1, x_scale=B["gate"], partial=P.fold_part[nm["w_proj"]])
-            n2 = N * hw * ce
-            da2 = P.gA[:n2].view(N, b.h_out, b.h_out, ce)
+            side(lambda B=B, dout=dout, nm=nm: ops.conv2d_bwd_filter(B["a1"], dout, 1, 1, x_scale=B["gate"], partial=P.fold_part[nm["w_proj"]]))
+            da2 = B["da2"]
             ops.conv2d_bwd_data(dout, w[nm["w_proj"]], 1, out=da2, ws=ws)
             ops.colsum(da2, B["a1"], nseg=N, out=B["dgate"], ws=ws)
             se = nm["se"]
@@ -481,18 +493,16 @@ class Learner:
             ops.se_mlp_bwd(B["dgate"], B["gate"], B["s"], B["hpre"], w[se[0]], w[se[2]], hw, outs)
             bn_b(B["z1"], da2, B["st1"], nm["bn1"], da2, post=True, chan_scale=B["gate"], chan_add=B["chan_add"])
             dw_in = B["a0"] if b.expand != 1 else B["x_in"]
-            ops.dwconv_bwd_filter(dw_in, da2, b.k, b.stride, partial=P.fold_part[nm["w_dw"]])
+            side(lambda dw_in=dw_in, da2=da2, b=b, nm=nm: ops.dwconv_bwd_filter(dw_in, da2, b.k, b.stride, partial=P.fold_part[nm["w_dw"]]))
             if b.expand != 1:
-                n0 = N * b.h_in * b.h_in * ce
-                da0 = P.gB[:n0].view(N, b.h_in, b.h_in, ce)
+                da0 = B["da0"]
                 ops.dwconv_bwd_data(da2, w[nm["w_dw"]], b.stride, (b.h_in, b.h_in), out=da0)
                 bn_b(B["z0"], da0, B["st0"], nm["bn0"], da0, post=True)
-                ops.conv2d_bwd_filter(B["x_in"], da0, 1, 1, partial=P.fold_part[nm["w_exp"]])
+                side(lambda B=B, da0=da0, nm=nm: ops.conv2d_bwd_filter(B["x_in"], da0, 1, 1, partial=P.fold_part[nm["w_exp"]]))
                 ops.conv2d_bwd_data(da0, w[nm["w_exp"]], 1, out=tgt, accumulate=tgt_has, ws=ws)
             else:
                 if tgt_has:  # no-expand block with identity skip (EfficientNet-B3 stage-1 repeats)
-                    n0 = N * b.h_in * b.h_in * ce
-                    tmp = P.gB[:n0].view(N, b.h_in, b.h_in, ce)
+                    tmp = B["da0"]
                     ops.dwconv_bwd_data(da2, w[nm["w_dw"]], b.stride, (b.h_in, b.h_in), out=tmp)
                     ops.chan_affine(tmp, out=tgt, accumulate=True)
                 else:
@@ -500,7 +510,10 @@ class Learner:
             if bi > 0:
                 has_grad[bi - 1] = True
         bn_b(P.z_stem, P.dstem, P.st_stem, self.n_stem[1], P.dstem, post=True)
-        ops.stem_conv_bwd_filter(x, P.dstem, idx, partial=P.fold_part[self.n_stem[0]])
+        side(lambda: ops.stem_conv_bwd_filter(x, P.dstem, idx, partial=P.fold_part[self.n_stem[0]]))
+        join = torch.cuda.Event()
+        join.record(self.side_stream)
+        self.stream.wait_event(join)          # all slabs written -> one batched fold into the gradient arena
         ops.fold_batched(P.fold_buf, A.grad, P.fold_desc, P.fold_tiles)
 
     # ------------------------------------------------------------------------------------------- one optimisation step
