@@ -3,8 +3,10 @@
 // activations with a row stride `ld` (floats), C % 4 == 0, 16-byte aligned; lanes run along C in float4 so every
 // wave-instruction touches whole contiguous spans (HBM-bound kernels: SURVEY 2.1 K4/K5/K7/K8).
 //
-// Reductions are two-stage and deterministic: stage 1 writes per-block partial sums, stage 2 (one thread per channel)
-// folds them in double precision.  No float atomics anywhere.
+// Reductions are two-stage and deterministic: stage 1 writes per-block partial sums (from the producing GEMM's epilogue when there
+// is one), stage 2 folds them in double precision in a fixed order INSIDE the consumer kernel (bn_apply_fused_k /
+// bn_bwd_apply_fused_k: every block folds the partials of its own 32 channels), so training-mode BN costs one launch forward
+// and two backward.  No float atomics anywhere.
 //
 // Reference semantics: models/efficientnet/utils.py:87-134 (non-fused BN, biased variance),
 // models/efficientlab.py:185-190 (decoder: conv -> swish -> BN, fused BN => unbiased variance into the moving average),
@@ -321,46 +323,6 @@ struct BnBwdOp {
     o[1] = f4mul(g, xhat);
   }
 };
-
-__global__ __launch_bounds__(256) void bn_bwd_finalize_k(const float* __restrict__ part, int nblk, int C, double inv_n,
-                                                         float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ c1,
-                                                         float* __restrict__ c2) {
-  __shared__ double sm[kFoldY * (kFoldX + 1)];
-  const int c = blockIdx.x * kFoldX + threadIdx.x;
-  const bool ok = c < C;
-  const double s = fold_partials(part, nblk, 2LL * C, c, ok, sm);
-  const double sx = fold_partials(part, nblk, 2LL * C, (long long)C + c, ok, sm);
-  if (!ok || threadIdx.y != 0) return;
-  dbeta[c] = (float)s;
-  dgamma[c] = (float)sx;
-  c1[c] = (float)(s * inv_n);
-  c2[c] = (float)(sx * inv_n);
-}
-
-__global__ __launch_bounds__(256) void bn_bwd_apply_k(BnBwdCommon p, long long rows, const float* __restrict__ c1,
-                                                      const float* __restrict__ c2, float* __restrict__ dx, int lddx) {
-  const int Q = p.C >> 2;
-  const long long total = rows * Q;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const long long r = i / Q;
-    const int c = (int)(i - r * Q) << 2;
-    float4 xin, xhat, g;
-    p.load(r, c, xin, xhat, g);
-    const float4 a = ld4(c1 + c), b = ld4(c2 + c), ga = ld4(p.gamma + c), rs = ld4(p.rstd + c);
-    float4 d;
-    d.x = ga.x * rs.x * (g.x - a.x - xhat.x * b.x);
-    d.y = ga.y * rs.y * (g.y - a.y - xhat.y * b.y);
-    d.z = ga.z * rs.z * (g.z - a.z - xhat.z * b.z);
-    d.w = ga.w * rs.w * (g.w - a.w - xhat.w * b.w);
-    if (p.pre_swish) {
-      d.x *= swish_grad_f(xin.x);
-      d.y *= swish_grad_f(xin.y);
-      d.z *= swish_grad_f(xin.z);
-      d.w *= swish_grad_f(xin.w);
-    }
-    st4(dx + r * lddx + c, d);
-  }
-}
 
 // finalize (fold the two gradient sums of this block's 32 channels) + input-gradient pass in one launch
 __global__ __launch_bounds__(256) void bn_bwd_apply_fused_k(BnBwdCommon p, long long rows, const float* __restrict__ part, int nblk,
