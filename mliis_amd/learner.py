@@ -21,6 +21,7 @@ Graph semantics restated from: models/efficientlab.py:111-119,126-231,294-317; m
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, List, Optional, Sequence
 
 import numpy as np
@@ -164,7 +165,10 @@ class Learner:
         self.drop_connect = drop_connect
         self.use_graph = use_graph
         self.stream = torch.cuda.Stream(device=self.device)
-        self.side_stream = torch.cuda.Stream(device=self.device)   # weight-gradient GEMMs overlap the backward-data chain
+        # Optional: weight-gradient GEMMs on a second stream forked inside the HIP graph.  Measured SLOWER on MI355X (4.95 vs 4.56 ms
+        # per step, profiles/r01_notes.md): the cross-stream edges cost more than the idle CUs they fill, so it is off by default.
+        self.overlap_wgrad = os.environ.get("MLIIS_OVERLAP_WGRAD", "0") == "1"
+        self.side_stream = torch.cuda.Stream(device=self.device)
         self.arena = Arena(self.arch, self.device)
         self.arena.init_weights(seed)
         self.variables_initialized = True
@@ -421,6 +425,8 @@ class Learner:
             """Run a weight-gradient producer on the side stream, ordered after everything queued on the main stream so far.  These
             kernels only read activations / finished gradient buffers and write their own slab region, so the main stream can go on
             with the next layer's backward-data chain meanwhile (small layers leave most CUs idle otherwise)."""
+            if not self.overlap_wgrad:
+                return fn()
             ev = torch.cuda.Event()
             ev.record(self.stream)
             with torch.cuda.stream(self.side_stream):
@@ -511,9 +517,11 @@ class Learner:
                 has_grad[bi - 1] = True
         bn_b(P.z_stem, P.dstem, P.st_stem, self.n_stem[1], P.dstem, post=True)
         side(lambda: ops.stem_conv_bwd_filter(x, P.dstem, idx, partial=P.fold_part[self.n_stem[0]]))
-        join = torch.cuda.Event()
-        join.record(self.side_stream)
-        self.stream.wait_event(join)          # all slabs written -> one batched fold into the gradient arena
+        if self.overlap_wgrad:
+            join = torch.cuda.Event()
+            join.record(self.side_stream)
+            self.stream.wait_event(join)
+        # all slabs written -> one batched fold into the gradient arena
         ops.fold_batched(P.fold_buf, A.grad, P.fold_desc, P.fold_tiles)
 
     # ------------------------------------------------------------------------------------------- one optimisation step
