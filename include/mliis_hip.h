@@ -65,8 +65,9 @@ size_t mliis_conv2d_workspace_floats(int Nimg, int H, int W, int Cred, int Nout,
 /*      tiling chosen for a fwd / bwd-data call: kernel instantiation conv_gemm_k<tm, nt, .> and split-K factor (profiling aid) */
 int mliis_conv2d_plan(int Nimg, int H, int W, int Cred, int Nout, int ksize, int* tm, int* nt, int* splits);
 /*      stats_part (nullable): the epilogue also emits the following batch norm's stage-1 statistics -- per row-block column sums
- *      {sum v, sum v^2} (of swish(v) when stats_swish) as [*stats_nblk][2][Cout]; *stats_nblk == 0 means "not produced" (split-K
- *      plan) and the caller must run mliis_bn_stats_partial instead.  Needs >= ceil(M/64) * 2 * Cout floats. */
+ *      {sum v, sum v^2} (of swish(v) when stats_swish) as [*stats_nblk][2][Cout], written by the GEMM epilogue or, on a split-K
+ *      plan, by the slab fold.  *stats_nblk == 0 means "not produced": the caller must run mliis_bn_stats_partial instead.
+ *      Needs >= ceil(M/64) * 2 * Cout floats; requires accumulate == 0. */
 /*      wt (nullable): K-contiguous shadow copy of w, layout [k,k,Cout,Cin] (mliis_transpose_weights); when given, the forward
  *      GEMM reads it instead of w (same result, faster B-operand path). */
 /*      x_scale (nullable, [Nimg,Cin], 1x1 convs): x[m,c] is multiplied by x_scale[image(m),c] while it is staged -- the
@@ -185,7 +186,9 @@ int mliis_lincomb(float a, const float* x, float b, const float* y, float* out, 
 
 /* ---- weight-gradient producers (conv2d / dwconv / stem *_bwd_filter) called with dw == NULL leave their per-split slabs in
  *      `ws`; one mliis_fold_batched launch then folds all of them into the gradient arena.  desc: device int64 [ndesc][8] =
- *      {part_off, out_off, total, seg_len, seg_stride, seg_off, nblk, tile_begin} (offsets in floats; tile = 16 outputs). */
+ *      {part_off, out_off, total, seg_len, seg_stride, seg_off, nblk, tile_begin} (offsets in floats; one tile =
+ *      mliis_fold_tile_outputs() consecutive outputs of a descriptor, tile_begin = running sum of ceil(total / tile)). */
+int mliis_fold_tile_outputs(void);
 int mliis_fold_batched(const float* part_base, float* out_base, const long long* desc, int ndesc, long long total_tiles,
                        hipStream_t stream);
 

@@ -16,49 +16,47 @@
 namespace mliis {
 
 constexpr int kColThreads = 256;
-constexpr int kMaxQuadsPerBlock = 64;
+constexpr int kChanBlock = 32;   // channels per block: 8 float4 lanes = one 128-byte line per row
+constexpr int kRowLanes = 32;    // rows walked in parallel by one block
+constexpr int kBatch = 4;        // rows per thread whose loads are issued before any of them is consumed
 
+// Streaming geometry shared by the column reductions and the BN apply kernels: grid = (row chunks, ceil(C/32)[, segments]);
+// a block owns 32 channels x rows_per_block rows, its 256 threads = 8 channel quads x 32 row lanes.  Small maps are latency-bound
+// (a handful of waves per CU), so every thread issues the loads of kBatch rows before it touches any of them: the per-launch
+// critical path is one or two memory round trips instead of one per row.
 struct ColGeom {
-  int Q;        // C / 4
-  int QB;       // quads per block in y (<= 64)
-  int RP;       // rows processed per pass by one block = 256 / QB
-  int rows_per_block;
-  int nblk;     // blocks along rows (per segment)
+  int gx;              // channel groups
+  int rows_per_block;  // multiple of kRowLanes * kBatch
+  int nblk;            // blocks along rows (per segment)
 };
 
-static inline ColGeom col_geom(long long rows_per_seg, int C, int nseg, int target_blocks = 512) {
+static inline ColGeom col_geom(long long rows_per_seg, int C, int nseg, int target_blocks = 2048) {
   ColGeom g;
-  g.Q = C / 4;
-  g.QB = g.Q < kMaxQuadsPerBlock ? g.Q : kMaxQuadsPerBlock;
-  g.RP = kColThreads / g.QB;
-  int ny = ceil_div(g.Q, g.QB);
-  long long want = target_blocks / (ny * (nseg > 0 ? nseg : 1));
+  g.gx = ceil_div(C, kChanBlock);
+  long long want = target_blocks / ((long long)g.gx * (nseg > 0 ? nseg : 1));
   if (want < 1) want = 1;
   long long rpb = (rows_per_seg + want - 1) / want;
-  // at least 8 passes per block so the per-block epilogue is amortised, multiple of RP
-  long long minr = (long long)g.RP * 8;
-  if (rpb < minr) rpb = minr;
-  rpb = (rpb + g.RP - 1) / g.RP * g.RP;
+  const long long unit = kRowLanes * kBatch;
+  rpb = (rpb + unit - 1) / unit * unit;
   g.rows_per_block = (int)rpb;
   g.nblk = ceil_div(rows_per_seg, rpb);
   return g;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Generic partial column reduction.  Op::NV float4 values per (row, quad).
+// Generic partial column reduction.  Op: Raw load(seg,row,c) then eval(seg,row,c,raw,out[NV]).
 // part layout: [seg][blk][v][C]
 // ---------------------------------------------------------------------------------------------------------------
 template <class Op>
-__global__ __launch_bounds__(kColThreads) void colreduce_partial_k(Op op, int rows_per_seg, int C, int QB, int RP,
-                                                                    int rows_per_block, int nblk, float* __restrict__ part) {
+__global__ __launch_bounds__(kColThreads) void colreduce_partial_k(Op op, int rows_per_seg, int C, int rows_per_block, int nblk,
+                                                                    float* __restrict__ part) {
   constexpr int NV = Op::NV;
-  __shared__ float4 sm[kColThreads];
+  __shared__ float4 sm[NV][4][8];
   const int t = threadIdx.x;
-  const int ql = t % QB, rl = t / QB;
-  const int q = blockIdx.y * QB + ql;
+  const int q = t & 7, rl = t >> 3;
+  const int c = blockIdx.y * kChanBlock + q * 4;
   const int seg = blockIdx.z;
-  const int Q = C >> 2;
-  const bool active = (rl < RP) && (q < Q);
+  const bool active = c < C;
   float4 acc[NV];
 #pragma unroll
   for (int v = 0; v < NV; ++v) acc[v] = f4zero();
@@ -66,22 +64,48 @@ __global__ __launch_bounds__(kColThreads) void colreduce_partial_k(Op op, int ro
     const int r0 = blockIdx.x * rows_per_block;
     int r1 = r0 + rows_per_block;
     if (r1 > rows_per_seg) r1 = rows_per_seg;
-    for (int r = r0 + rl; r < r1; r += RP) {
+    const long long base = (long long)seg * rows_per_seg;
+    int r = r0 + rl;
+    for (; r + (kBatch - 1) * kRowLanes < r1; r += kBatch * kRowLanes) {
+      typename Op::Raw raw[kBatch];
+#pragma unroll
+      for (int u = 0; u < kBatch; ++u) op.load(seg, base + r + u * kRowLanes, c, raw[u]);
+#pragma unroll
+      for (int u = 0; u < kBatch; ++u) {
+        float4 vals[NV];
+        op.eval(seg, base + r + u * kRowLanes, c, raw[u], vals);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) acc[v] = f4add(acc[v], vals[v]);
+      }
+    }
+    for (; r < r1; r += kRowLanes) {
+      typename Op::Raw raw;
+      op.load(seg, base + r, c, raw);
       float4 vals[NV];
-      op(seg, (long long)seg * rows_per_seg + r, q << 2, vals);
+      op.eval(seg, base + r, c, raw, vals);
 #pragma unroll
       for (int v = 0; v < NV; ++v) acc[v] = f4add(acc[v], vals[v]);
     }
   }
+  // 8 row lanes of a wave share a channel quad: butterfly over lane bits 3..5, then the 4 waves through LDS (fixed order)
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
-    __syncthreads();
-    sm[t] = acc[v];
-    __syncthreads();
-    if (rl == 0 && q < Q) {
-      float4 s = sm[ql];
-      for (int j = 1; j < RP; ++j) s = f4add(s, sm[j * QB + ql]);
-      st4(part + (((long long)seg * nblk + blockIdx.x) * NV + v) * C + (q << 2), s);
+#pragma unroll
+    for (int off = 8; off < 64; off <<= 1) {
+      acc[v].x += __shfl_xor(acc[v].x, off);
+      acc[v].y += __shfl_xor(acc[v].y, off);
+      acc[v].z += __shfl_xor(acc[v].z, off);
+      acc[v].w += __shfl_xor(acc[v].w, off);
+    }
+    if ((t & 63) < 8) sm[v][t >> 6][q] = acc[v];
+  }
+  __syncthreads();
+  if (t < 8 * NV) {
+    const int v = t >> 3, qq = t & 7;
+    const int cc = blockIdx.y * kChanBlock + qq * 4;
+    if (cc < C) {
+      float4 s4 = f4add(f4add(sm[v][0][qq], sm[v][1][qq]), f4add(sm[v][2][qq], sm[v][3][qq]));
+      st4(part + (((long long)seg * nblk + blockIdx.x) * NV + v) * C + cc, s4);
     }
   }
 }
@@ -93,9 +117,9 @@ static int launch_colreduce(Op op, long long rows_per_seg, int C, int nseg, floa
   size_t need = (size_t)nseg * g.nblk * Op::NV * C;
   MLIIS_REQUIRE(need <= part_floats, MLIIS_ERR_WORKSPACE, "%s: workspace too small (%zu floats needed, %zu given)", name,
                 need, part_floats);
-  dim3 grid(g.nblk, ceil_div(g.Q, g.QB), nseg);
-  hipLaunchKernelGGL((colreduce_partial_k<Op>), grid, dim3(kColThreads), 0, stream, op, (int)rows_per_seg, C, g.QB, g.RP,
-                     g.rows_per_block, g.nblk, part);
+  dim3 grid(g.nblk, g.gx, nseg);
+  hipLaunchKernelGGL((colreduce_partial_k<Op>), grid, dim3(kColThreads), 0, stream, op, (int)rows_per_seg, C, g.rows_per_block, g.nblk,
+                     part);
   MLIIS_CHECK_LAUNCH(name);
   *out_g = g;
   return MLIIS_OK;
@@ -109,8 +133,10 @@ struct StatsOp {
   const float* x;
   int ld;
   int pre_swish;
-  __device__ void operator()(int, long long row, int c, float4* o) const {
-    float4 v = ld4(x + row * ld + c);
+  typedef float4 Raw;
+  __device__ __forceinline__ void load(int, long long row, int c, Raw& r) const { r = ld4(x + row * ld + c); }
+  __device__ __forceinline__ void eval(int, long long, int, const Raw& r, float4* o) const {
+    float4 v = r;
     if (pre_swish) v = make_float4(swish_f(v.x), swish_f(v.y), swish_f(v.z), swish_f(v.w));
     o[0] = v;
     o[1] = f4mul(v, v);
@@ -172,8 +198,6 @@ __global__ __launch_bounds__(256) void bn_apply_k(const float* __restrict__ x, i
 // (8 float4 lanes = one 128-byte line per row).  Blocks with blockIdx.y == 0 publish mean / rstd for the backward pass and
 // apply the moving-average update -- so no separate finalize launch exists.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int kChanBlock = 32;
-
 struct BnFold {
   const float* part;  // [nblk][2][C]
   int nblk;
@@ -250,8 +274,7 @@ __global__ __launch_bounds__(256) void bn_apply_fused_k(const float* __restrict_
   const float4 m = ld4(s_mean + q * 4), rs = ld4(s_rstd + q * 4), g = ld4(gamma + c), b = ld4(beta + c);
   long long r1 = (long long)(blockIdx.y + 1) * rows_per_block;
   if (r1 > rows) r1 = rows;
-  for (long long r = (long long)blockIdx.y * rows_per_block + rl; r < r1; r += 32) {
-    float4 v = ld4(x + r * ldx + c);
+  auto finish = [&](long long r, float4 v, float4 rv) {
     if (pre_swish) v = make_float4(swish_f(v.x), swish_f(v.y), swish_f(v.z), swish_f(v.w));
     float4 o;
     o.x = fmaf((v.x - m.x) * rs.x, g.x, b.x);
@@ -259,21 +282,29 @@ __global__ __launch_bounds__(256) void bn_apply_fused_k(const float* __restrict_
     o.z = fmaf((v.z - m.z) * rs.z, g.z, b.z);
     o.w = fmaf((v.w - m.w) * rs.w, g.w, b.w);
     if (post_swish) o = make_float4(swish_f(o.x), swish_f(o.y), swish_f(o.z), swish_f(o.w));
-    if (img_scale != nullptr) o = f4scale(o, img_scale[r / rows_per_img]);
-    if (res != nullptr) o = f4add(o, ld4(res + r * ldr + c));
+    if (img_scale != nullptr) o = f4scale(o, img_scale[(int)r / rows_per_img]);
+    if (res != nullptr) o = f4add(o, rv);
     st4(y + r * ldy + c, o);
+  };
+  long long r = (long long)blockIdx.y * rows_per_block + rl;
+  for (; r + (kBatch - 1) * kRowLanes < r1; r += kBatch * kRowLanes) {
+    float4 v[kBatch], rv[kBatch];
+#pragma unroll
+    for (int u = 0; u < kBatch; ++u) {
+      v[u] = ld4(x + (r + u * kRowLanes) * ldx + c);
+      rv[u] = res != nullptr ? ld4(res + (r + u * kRowLanes) * ldr + c) : f4zero();
+    }
+#pragma unroll
+    for (int u = 0; u < kBatch; ++u) finish(r + u * kRowLanes, v[u], rv[u]);
   }
+  for (; r < r1; r += kRowLanes) finish(r, ld4(x + r * ldx + c), res != nullptr ? ld4(res + r * ldr + c) : f4zero());
 }
 
 static inline void chan_grid(long long rows, int C, int* gx, int* gy, int* rows_per_block) {
-  *gx = ceil_div(C, kChanBlock);
-  long long want = 768 / *gx;
-  if (want < 1) want = 1;
-  long long rpb = (rows + want - 1) / want;
-  if (rpb < 64) rpb = 64;
-  rpb = (rpb + 31) / 32 * 32;
-  *rows_per_block = (int)rpb;
-  *gy = ceil_div(rows, rpb);
+  const ColGeom g = col_geom(rows, C, 1);
+  *gx = g.gx;
+  *gy = g.nblk;
+  *rows_per_block = g.rows_per_block;
 }
 
 // upstream gradient seen by the BN output: dy * img_scale[n] * chan_scale[n,c] + chan_add[n,c]
@@ -292,17 +323,24 @@ struct BnBwdCommon {
   const float* img_scale;   // [N] or null        (drop-connect)
   const float* chan_scale;  // [N,C] or null      (squeeze-excite gate)
   const float* chan_add;    // [N,C] or null      (squeeze-excite pooled-gradient / HW)
-  __device__ __forceinline__ void load(long long row, int c, float4& xin, float4& xhat, float4& g) const {
-    xin = ld4(x + row * ldx + c);
+  struct Raw { float4 x, g; };
+  __device__ __forceinline__ void load_raw(long long row, int c, Raw& r) const {
+    r.x = ld4(x + row * ldx + c);
+    r.g = ld4(dy + row * lddy + c);
+  }
+  __device__ __forceinline__ void finish(long long row, int c, const Raw& r, float4& xin, float4& xhat, float4& g) const {
+    xin = r.x;
     float4 v = xin;
     if (pre_swish) v = make_float4(swish_f(v.x), swish_f(v.y), swish_f(v.z), swish_f(v.w));
     const float4 m = ld4(mean + c), rs = ld4(rstd + c);
     xhat = make_float4((v.x - m.x) * rs.x, (v.y - m.y) * rs.y, (v.z - m.z) * rs.z, (v.w - m.w) * rs.w);
-    g = ld4(dy + row * lddy + c);
-    const int n = (int)(row / rows_per_img);
-    if (img_scale != nullptr) g = f4scale(g, img_scale[n]);
-    if (chan_scale != nullptr) g = f4mul(g, ld4(chan_scale + (long long)n * C + c));
-    if (chan_add != nullptr) g = f4add(g, ld4(chan_add + (long long)n * C + c));
+    g = r.g;
+    if (img_scale != nullptr || chan_scale != nullptr || chan_add != nullptr) {
+      const int n = (int)row / rows_per_img;     // rows < 2^31 (checked on the host)
+      if (img_scale != nullptr) g = f4scale(g, img_scale[n]);
+      if (chan_scale != nullptr) g = f4mul(g, ld4(chan_scale + (long long)n * C + c));
+      if (chan_add != nullptr) g = f4add(g, ld4(chan_add + (long long)n * C + c));
+    }
     if (post_swish) {
       const float4 ga = ld4(gamma + c), be = ld4(beta + c);
       g.x *= swish_grad_f(fmaf(xhat.x, ga.x, be.x));
@@ -316,9 +354,11 @@ struct BnBwdCommon {
 struct BnBwdOp {
   static constexpr int NV = 2;
   BnBwdCommon p;
-  __device__ void operator()(int, long long row, int c, float4* o) const {
+  typedef BnBwdCommon::Raw Raw;
+  __device__ __forceinline__ void load(int, long long row, int c, Raw& r) const { p.load_raw(row, c, r); }
+  __device__ __forceinline__ void eval(int, long long row, int c, const Raw& r, float4* o) const {
     float4 xin, xhat, g;
-    p.load(row, c, xin, xhat, g);
+    p.finish(row, c, r, xin, xhat, g);
     o[0] = g;
     o[1] = f4mul(g, xhat);
   }
@@ -350,9 +390,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fused_k(BnBwdCommon p, long 
   const float4 a = ld4(s_c1 + q * 4), b = ld4(s_c2 + q * 4), ga = ld4(p.gamma + c), rs = ld4(p.rstd + c);
   long long r1 = (long long)(blockIdx.y + 1) * rows_per_block;
   if (r1 > rows) r1 = rows;
-  for (long long r = (long long)blockIdx.y * rows_per_block + rl; r < r1; r += 32) {
+  auto finish = [&](long long r, const BnBwdCommon::Raw& raw) {
     float4 xin, xhat, g;
-    p.load(r, c, xin, xhat, g);
+    p.finish(r, c, raw, xin, xhat, g);
     float4 d;
     d.x = ga.x * rs.x * (g.x - a.x - xhat.x * b.x);
     d.y = ga.y * rs.y * (g.y - a.y - xhat.y * b.y);
@@ -365,6 +405,19 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fused_k(BnBwdCommon p, long 
       d.w *= swish_grad_f(xin.w);
     }
     st4(dx + r * lddx + c, d);
+  };
+  long long r = (long long)blockIdx.y * rows_per_block + rl;
+  for (; r + (kBatch - 1) * kRowLanes < r1; r += kBatch * kRowLanes) {
+    BnBwdCommon::Raw raw[kBatch];
+#pragma unroll
+    for (int u = 0; u < kBatch; ++u) p.load_raw(r + u * kRowLanes, c, raw[u]);
+#pragma unroll
+    for (int u = 0; u < kBatch; ++u) finish(r + u * kRowLanes, raw[u]);
+  }
+  for (; r < r1; r += kRowLanes) {
+    BnBwdCommon::Raw raw;
+    p.load_raw(r, c, raw);
+    finish(r, raw);
   }
 }
 
@@ -377,11 +430,12 @@ struct SumOp {  // column sum of a (optionally times b)
   int lda;
   const float* b;  // nullable
   int ldb;
-  __device__ void operator()(int, long long row, int c, float4* o) const {
-    float4 v = ld4(a + row * lda + c);
-    if (b != nullptr) v = f4mul(v, ld4(b + row * ldb + c));
-    o[0] = v;
+  struct Raw { float4 a, b; };
+  __device__ __forceinline__ void load(int, long long row, int c, Raw& r) const {
+    r.a = ld4(a + row * lda + c);
+    r.b = b != nullptr ? ld4(b + row * ldb + c) : make_float4(1.f, 1.f, 1.f, 1.f);
   }
+  __device__ __forceinline__ void eval(int, long long, int, const Raw& r, float4* o) const { o[0] = f4mul(r.a, r.b); }
 };
 
 // sum_rows x[row, c] * (mask[row,c]) * dy[row, j], j = 0,1   (final 1x1 conv, Cout = 2: weight gradient)
@@ -391,12 +445,16 @@ struct Outer2Op {
   int ldx;
   const float* mask;  // nullable, same layout as x
   const float* dy;    // [rows, 2]
-  __device__ void operator()(int, long long row, int c, float4* o) const {
-    float4 v = ld4(x + row * ldx + c);
-    if (mask != nullptr) v = f4mul(v, ld4(mask + row * ldx + c));
-    const float2 d = *reinterpret_cast<const float2*>(dy + row * 2);
-    o[0] = f4scale(v, d.x);
-    o[1] = f4scale(v, d.y);
+  struct Raw { float4 x, m; float2 d; };
+  __device__ __forceinline__ void load(int, long long row, int c, Raw& r) const {
+    r.x = ld4(x + row * ldx + c);
+    r.m = mask != nullptr ? ld4(mask + row * ldx + c) : make_float4(1.f, 1.f, 1.f, 1.f);
+    r.d = *reinterpret_cast<const float2*>(dy + row * 2);
+  }
+  __device__ __forceinline__ void eval(int, long long, int, const Raw& r, float4* o) const {
+    const float4 v = f4mul(r.x, r.m);
+    o[0] = f4scale(v, r.d.x);
+    o[1] = f4scale(v, r.d.y);
   }
 };
 
@@ -415,11 +473,15 @@ __global__ __launch_bounds__(256) void sum_finalize_k(const float* __restrict__ 
 }
 
 // All weight-gradient slab folds of a backward pass in ONE launch.  desc (device int64 [ndesc][8]) = {part_off, out_off, total,
-// seg_len, seg_stride, seg_off, nblk, tile_begin}; block b handles 16 consecutive outputs of the descriptor whose tile range
-// contains b (binary search over tile_begin).
+// seg_len, seg_stride, seg_off, nblk, tile_begin}; block b handles kFoldTile consecutive outputs of the descriptor whose tile range
+// contains b (binary search over tile_begin).  256 threads = 64 output quads (1 KB contiguous per slab) x 4 slab lanes; each lane
+// strides over the slabs with float4 loads issued four at a time, accumulates in double, and the 4 lanes are combined through LDS
+// in a fixed order.
+constexpr int kFoldTile = 256;
+
 __global__ __launch_bounds__(256) void fold_batched_k(const float* __restrict__ part_base, float* __restrict__ out_base,
                                                       const long long* __restrict__ desc, int ndesc) {
-  __shared__ double sm[kFoldY * (kFoldX + 1)];
+  __shared__ double sm[3][64][4];
   const long long tile = blockIdx.x;
   int lo = 0, hi = ndesc - 1;
   while (lo < hi) {
@@ -428,12 +490,54 @@ __global__ __launch_bounds__(256) void fold_batched_k(const float* __restrict__ 
   }
   const long long* d = desc + (long long)lo * 8;
   const long long total = d[2];
-  const long long i = (tile - d[7]) * kFoldX + threadIdx.x;
-  const bool ok = i < total;
-  const double s = fold_partials(part_base + d[0], (int)d[6], total, i, ok, sm);
-  if (!ok || threadIdx.y != 0) return;
-  const long long o = (i / d[3]) * d[4] + d[5] + i % d[3];
-  out_base[d[1] + o] = (float)s;
+  const int nblk = (int)d[6];
+  const int t = threadIdx.x, ql = t & 63, sl = t >> 6;
+  const long long i = (tile - d[7]) * kFoldTile + ql * 4;
+  const bool vec = ((total | d[0]) & 3) == 0;
+  const float* p = part_base + d[0] + i;
+  double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+  if (i < total) {
+    if (vec) {
+      int k = sl;
+      for (; k + 12 < nblk; k += 16) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = ld4(p + (long long)(k + 4 * u) * total);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { a0 += v[u].x; a1 += v[u].y; a2 += v[u].z; a3 += v[u].w; }
+      }
+      for (; k < nblk; k += 4) {
+        const float4 v = ld4(p + (long long)k * total);
+        a0 += v.x; a1 += v.y; a2 += v.z; a3 += v.w;
+      }
+    } else {
+      for (int k = sl; k < nblk; k += 4) {
+        const float* pk = p + (long long)k * total;
+        a0 += pk[0];
+        if (i + 1 < total) a1 += pk[1];
+        if (i + 2 < total) a2 += pk[2];
+        if (i + 3 < total) a3 += pk[3];
+      }
+    }
+  }
+  if (sl > 0) {
+    double* w = sm[sl - 1][ql];
+    w[0] = a0; w[1] = a1; w[2] = a2; w[3] = a3;
+  }
+  __syncthreads();
+  if (sl != 0 || i >= total) return;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) { a0 += sm[j][ql][0]; a1 += sm[j][ql][1]; a2 += sm[j][ql][2]; a3 += sm[j][ql][3]; }
+  const long long seg_len = d[3], seg_stride = d[4], seg_off = d[5];
+  float* out = out_base + d[1];
+  if (vec && ((seg_len | seg_stride | seg_off | d[1]) & 3) == 0) {
+    st4(out + (i / seg_len) * seg_stride + seg_off + i % seg_len, make_float4((float)a0, (float)a1, (float)a2, (float)a3));
+  } else {
+    const double a[4] = {a0, a1, a2, a3};
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (i + e < total) out[((i + e) / seg_len) * seg_stride + seg_off + (i + e) % seg_len] = (float)a[e];
+  }
 }
 
 // Short segments (<= 1024 rows, e.g. squeeze-excite pools on 28x28 / 14x14 maps): one block per (segment, 32 channels) walks all
@@ -447,7 +551,19 @@ __global__ __launch_bounds__(256) void colsum_small_k(const float* __restrict__ 
   float4 acc = f4zero();
   if (c < C) {
     const long long r0 = (long long)seg * rows_per_seg;
-    for (int r = rl; r < rows_per_seg; r += 32) {
+    constexpr int U = 8;
+    int r = rl;
+    for (; r + (U - 1) * 32 < rows_per_seg; r += U * 32) {
+      float4 va[U], vb[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        va[u] = ld4(a + (r0 + r + u * 32) * lda + c);
+        vb[u] = b != nullptr ? ld4(b + (r0 + r + u * 32) * ldb + c) : make_float4(1.f, 1.f, 1.f, 1.f);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) acc = f4add(acc, f4mul(va[u], vb[u]));
+    }
+    for (; r < rows_per_seg; r += 32) {
       float4 v = ld4(a + (r0 + r) * lda + c);
       if (b != nullptr) v = f4mul(v, ld4(b + (r0 + r) * ldb + c));
       acc = f4add(acc, v);
@@ -538,8 +654,8 @@ int mliis_bn_bwd(const float* x, int ldx, const float* dy, int lddy, float* dx, 
                  int post_swish, const float* img_scale, const float* chan_scale, const float* chan_add, float* dgamma,
                  float* dbeta, float* ws, size_t ws_floats, hipStream_t stream) {
   MLIIS_REQUIRE(x && dy && dx && mean && rstd && gamma && beta && dgamma && dbeta && ws, MLIIS_ERR_ARG, "bn_bwd: null pointer");
-  MLIIS_REQUIRE(rows > 1 && C > 0 && (C & 3) == 0 && (ldx & 3) == 0 && (lddy & 3) == 0 && (lddx & 3) == 0 && ldx >= C &&
-                    lddy >= C && lddx >= C && rows_per_img > 0,
+  MLIIS_REQUIRE(rows > 1 && rows < (1LL << 31) && C > 0 && (C & 3) == 0 && (ldx & 3) == 0 && (lddy & 3) == 0 && (lddx & 3) == 0 &&
+                    ldx >= C && lddy >= C && lddx >= C && rows_per_img > 0,
                 MLIIS_ERR_ARG, "bn_bwd: bad shape");
   MLIIS_REQUIRE(aligned16(x) && aligned16(dy) && aligned16(dx) && aligned16(ws) && aligned16(chan_scale) && aligned16(chan_add) &&
                     aligned16(mean) && aligned16(rstd) && aligned16(gamma) && aligned16(beta),
@@ -580,7 +696,7 @@ int mliis_bn_apply_fused(const float* x, int ldx, float* y, int ldy, long long r
                          float* moving_var, const float* gamma, const float* beta, int pre_swish, int post_swish, const float* img_scale,
                          const float* res, int ldr, hipStream_t stream) {
   MLIIS_REQUIRE(x && y && part && mean && rstd && gamma && beta, MLIIS_ERR_ARG, "bn_apply_fused: null pointer");
-  MLIIS_REQUIRE(rows > 1 && nblk > 0 && C > 0 && (C & 3) == 0 && (ldx & 3) == 0 && (ldy & 3) == 0 && ldx >= C && ldy >= C &&
+  MLIIS_REQUIRE(rows > 1 && rows < (1LL << 31) && nblk > 0 && C > 0 && (C & 3) == 0 && (ldx & 3) == 0 && (ldy & 3) == 0 && ldx >= C && ldy >= C &&
                     rows_per_img > 0 && (res == nullptr || ((ldr & 3) == 0 && ldr >= C)),
                 MLIIS_ERR_ARG, "bn_apply_fused: bad shape");
   MLIIS_REQUIRE(aligned16(x) && aligned16(y) && aligned16(gamma) && aligned16(beta) && aligned16(res), MLIIS_ERR_ALIGN,
@@ -597,10 +713,13 @@ int mliis_bn_apply_fused(const float* x, int ldx, float* y, int ldy, long long r
   return MLIIS_OK;
 }
 
+int mliis_fold_tile_outputs(void) { return kFoldTile; }
+
 int mliis_fold_batched(const float* part_base, float* out_base, const long long* desc, int ndesc, long long total_tiles,
                        hipStream_t stream) {
   MLIIS_REQUIRE(part_base && out_base && desc && ndesc > 0 && total_tiles > 0, MLIIS_ERR_ARG, "fold_batched: bad arguments");
-  hipLaunchKernelGGL(fold_batched_k, dim3((unsigned)total_tiles), dim3(kFoldX, kFoldY), 0, stream, part_base, out_base, desc, ndesc);
+  MLIIS_REQUIRE(aligned16(part_base) && aligned16(out_base), MLIIS_ERR_ALIGN, "fold_batched: bases must be 16-byte aligned");
+  hipLaunchKernelGGL(fold_batched_k, dim3((unsigned)total_tiles), dim3(256), 0, stream, part_base, out_base, desc, ndesc);
   MLIIS_CHECK_LAUNCH("fold_batched");
   return MLIIS_OK;
 }

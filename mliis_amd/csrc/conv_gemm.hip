@@ -360,6 +360,60 @@ __global__ __launch_bounds__(256) void splitk_reduce_k(const float* __restrict__
   }
 }
 
+// Split-K fold that also emits the stage-1 BN statistics of the finished values (what the GEMM epilogue does when gz == 1), so a
+// split-K layer needs no separate statistics launch.  grid = (row chunks, ceil(Nout/32)); 256 threads = 8 channel quads x 32 row
+// lanes; stats_part layout [row chunk][2][Nout] ({sum v, sum v^2}, of swish(v) when stats_swish).
+constexpr int kRedRows = 128;   // rows per block: 4 per thread, all slab loads of a row issued together
+
+__global__ __launch_bounds__(256) void splitk_reduce_stats_k(const float* __restrict__ partial, int splits, int M, int Nout,
+                                                             float* __restrict__ Cmat, int ldc, const float* __restrict__ bias,
+                                                             const float* __restrict__ border_bias, int H, int W,
+                                                             float* __restrict__ stats_part, int stats_swish) {
+  __shared__ float4 sm[2][4][8];
+  const int t = threadIdx.x, q = t & 7, rl = t >> 3;
+  const int n = blockIdx.y * 32 + q * 4;
+  float4 s1 = f4zero(), s2 = f4zero();
+  if (n < Nout) {
+    const float4 bv = bias != nullptr ? ld4(bias + n) : f4zero();
+    const int r0 = blockIdx.x * kRedRows;
+    const int r1 = r0 + kRedRows < M ? r0 + kRedRows : M;
+    for (int m = r0 + rl; m < r1; m += 32) {
+      float4 s = ld4(partial + (long long)m * Nout + n);
+      for (int z = 1; z < splits; ++z) s = f4add(s, ld4(partial + ((long long)z * M + m) * Nout + n));
+      s = f4add(s, bv);
+      if (border_bias != nullptr) {
+        const int HWp = H * W;
+        const int ni = m / HWp;
+        const int rem = m - ni * HWp;
+        const int h = rem / W, w_ = rem - h * W;
+        const int cls = (h == 0 ? 0 : (h == H - 1 ? 2 : 1)) * 3 + (w_ == 0 ? 0 : (w_ == W - 1 ? 2 : 1));
+        s = f4add(s, ld4(border_bias + ((long long)ni * 9 + cls) * Nout + n));
+      }
+      st4(Cmat + (long long)m * ldc + n, s);
+      if (stats_swish) s = make_float4(swish_f(s.x), swish_f(s.y), swish_f(s.z), swish_f(s.w));
+      s1 = f4add(s1, s);
+      s2 = f4add(s2, f4mul(s, s));
+    }
+  }
+#pragma unroll
+  for (int off = 8; off < 64; off <<= 1) {
+    s1.x += __shfl_xor(s1.x, off); s1.y += __shfl_xor(s1.y, off); s1.z += __shfl_xor(s1.z, off); s1.w += __shfl_xor(s1.w, off);
+    s2.x += __shfl_xor(s2.x, off); s2.y += __shfl_xor(s2.y, off); s2.z += __shfl_xor(s2.z, off); s2.w += __shfl_xor(s2.w, off);
+  }
+  if ((t & 63) < 8) {
+    sm[0][t >> 6][q] = s1;
+    sm[1][t >> 6][q] = s2;
+  }
+  __syncthreads();
+  if (t < 16) {
+    const int v = t >> 3, qq = t & 7;
+    const int nn = blockIdx.y * 32 + qq * 4;
+    if (nn < Nout)
+      st4(stats_part + ((long long)blockIdx.x * 2 + v) * Nout + nn,
+          f4add(f4add(sm[v][0][qq], sm[v][1][qq]), f4add(sm[v][2][qq], sm[v][3][qq])));
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ backward-filter
 struct FilterGradParams {
   const float* X;
@@ -718,11 +772,16 @@ int mliis_conv2d_fwd(const float* x, int ldx, const float* x_scale, const float*
   MLIIS_REQUIRE(aligned16(x_scale) && (x_scale == nullptr || ksize == 1), MLIIS_ERR_ARG,
                 "conv2d_fwd: x_scale must be 16-byte aligned and is only supported for 1x1 convs");
   if (stats_nblk) *stats_nblk = 0;
-  if (stats_part != nullptr && g.gz == 1) {   // fused BN statistics: only when the epilogue sees final values
+  if (stats_part != nullptr) {   // fused BN statistics: GEMM epilogue (gz == 1) or the split-K fold (gz > 1)
     MLIIS_REQUIRE(!accumulate && stats_nblk, MLIIS_ERR_ARG, "conv2d_fwd: fused statistics need accumulate == 0 and a stats_nblk output");
-    p.stats_part = stats_part;
-    p.stats_swish = stats_swish;
-    *stats_nblk = g.gx;
+    if (g.gz == 1) {
+      p.stats_part = stats_part;
+      p.stats_swish = stats_swish;
+      *stats_nblk = g.gx;
+    } else {
+      MLIIS_REQUIRE(M < (1LL << 31), MLIIS_ERR_ARG, "conv2d_fwd: too many rows for the split-K statistics fold");
+      *stats_nblk = (int)((M + kRedRows - 1) / kRedRows);
+    }
   }
   if (g.gz > 1) {
     size_t need = (size_t)g.gz * M * Cout;
@@ -738,7 +797,11 @@ int mliis_conv2d_fwd(const float* x, int ldx, const float* x_scale, const float*
     launch_gemm<false>(g, p, stream);
   }
   MLIIS_CHECK_LAUNCH("conv2d_fwd");
-  if (g.gz > 1) {
+  if (g.gz > 1 && stats_part != nullptr) {
+    hipLaunchKernelGGL(splitk_reduce_stats_k, dim3((unsigned)((M + kRedRows - 1) / kRedRows), (Cout + 31) / 32), dim3(256), 0, stream, ws, g.gz,
+                       (int)M, Cout, y, ldy, bias, border_bias, H, W, stats_part, stats_swish);
+    MLIIS_CHECK_LAUNCH("conv2d_fwd_splitk_reduce_stats");
+  } else if (g.gz > 1) {
     long long q = M * (Cout / 4);
     int blocks = (int)((q + 255) / 256 > 2048 ? 2048 : (q + 255) / 256);
     hipLaunchKernelGGL(splitk_reduce_k, dim3(blocks), dim3(256), 0, stream, ws, g.gz, M, Cout, y, ldy, bias, accumulate, border_bias, H, W);

@@ -10,6 +10,26 @@ namespace mliis {
 constexpr int kMaxR = 128;
 constexpr int kSeThreads = 1024;  // one workgroup per image: all 16 waves of a CU work on the tiny MLP to cut its latency
 
+// dot product with a stride, loads issued U at a time (these kernels run one workgroup per image: pure latency, so the number of
+// dependent memory round trips is what matters)
+template <int U>
+__device__ __forceinline__ float dot_strided(const float* __restrict__ a, int sa, const float* __restrict__ b, long long sb, int n) {
+  float acc = 0.f;
+  int i = 0;
+  for (; i + U <= n; i += U) {
+    float x[U], y[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      x[u] = a[(long long)(i + u) * sa];
+      y[u] = b[(long long)(i + u) * sb];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc = fmaf(x[u], y[u], acc);
+  }
+  for (; i < n; ++i) acc = fmaf(a[(long long)i * sa], b[(long long)i * sb], acc);
+  return acc;
+}
+
 // one workgroup per image
 __global__ __launch_bounds__(kSeThreads) void se_mlp_fwd_k(const float* __restrict__ s, const float* __restrict__ w1,
                                                     const float* __restrict__ b1, const float* __restrict__ w2,
@@ -17,26 +37,42 @@ __global__ __launch_bounds__(kSeThreads) void se_mlp_fwd_k(const float* __restri
                                                     float* __restrict__ gate, int C, int R) {
   __shared__ float sh[kMaxR];
   __shared__ float red[kSeThreads];
+  __shared__ float red2[8 * kMaxR];
   const int n = blockIdx.x, t = threadIdx.x;
   const float* sn = s + (long long)n * C;
   // phase 1: h_j = b1[j] + sum_c s[c] * w1[c][j];  threads laid out (c-lane, j) so w1 reads are contiguous
   const int CL = kSeThreads / R;
   const int j = t % R, cl = t / R;
   float part = 0.f;
-  if (cl < CL)
-    for (int c = cl; c < C; c += CL) part = fmaf(sn[c], w1[(long long)c * R + j], part);
+  if (cl < CL && cl < C) part = dot_strided<8>(sn + cl, CL, w1 + (long long)cl * R + j, (long long)CL * R, (C - cl + CL - 1) / CL);
   red[t] = part;
+  __syncthreads();
+  if (t < 8 * R) {   // two-level fold of the CL c-lanes: 8 groups, then 8 values (fixed order)
+    const int g = t / R;
+    float h = 0.f;
+    for (int k = g; k < CL; k += 8) h += red[k * R + j];
+    red2[g * R + j] = h;
+  }
   __syncthreads();
   if (t < R) {
     float h = b1[t];
-    for (int k = 0; k < CL; ++k) h += red[k * R + t];
+#pragma unroll
+    for (int g = 0; g < 8; ++g) h += red2[g * R + t];
     hpre[(long long)n * R + t] = h;
     sh[t] = swish_f(h);
   }
   __syncthreads();
   for (int c = t; c < C; c += kSeThreads) {
     float a = b2[c];
-    for (int k = 0; k < R; ++k) a = fmaf(sh[k], w2[(long long)k * C + c], a);
+    int k = 0;
+    for (; k + 8 <= R; k += 8) {
+      float wv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) wv[u] = w2[(long long)(k + u) * C + c];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a = fmaf(sh[k + u], wv[u], a);
+    }
+    for (; k < R; ++k) a = fmaf(sh[k], w2[(long long)k * C + c], a);
     gate[(long long)n * C + c] = sigmoid_f(a);
   }
 }
@@ -48,16 +84,28 @@ __global__ __launch_bounds__(kSeThreads) void se_mlp_bwd_k(const float* __restri
                                                     float* __restrict__ dpre1, float* __restrict__ chan_add, int C, int R,
                                                     float inv_hw) {
   __shared__ float sd1[kMaxR];
+  extern __shared__ float sd2[];   // [C]
   const int n = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
   float* d2 = dpre2 + (long long)n * C;
   for (int c = t; c < C; c += kSeThreads) {
     const float g = gate[(long long)n * C + c];
-    d2[c] = dgate[(long long)n * C + c] * g * (1.f - g);
+    const float v = dgate[(long long)n * C + c] * g * (1.f - g);
+    d2[c] = v;
+    sd2[c] = v;
   }
-  __syncthreads();  // d2 written by this block, read below (same workgroup: barrier suffices)
+  __syncthreads();
   for (int jj = wave; jj < R; jj += kSeThreads / 64) {
+    const float* wr = w2 + (long long)jj * C;
     float p = 0.f;
-    for (int c = lane; c < C; c += 64) p = fmaf(d2[c], w2[(long long)jj * C + c], p);
+    int c = lane;
+    for (; c + 7 * 64 < C; c += 8 * 64) {
+      float wv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) wv[u] = wr[c + u * 64];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) p = fmaf(sd2[c + u * 64], wv[u], p);
+    }
+    for (; c < C; c += 64) p = fmaf(sd2[c], wr[c], p);
     p = wave_sum(p);
     if (lane == 0) {
       const float d = p * swish_grad_f(hpre[(long long)n * R + jj]);
@@ -67,8 +115,17 @@ __global__ __launch_bounds__(kSeThreads) void se_mlp_bwd_k(const float* __restri
   }
   __syncthreads();
   for (int c = t; c < C; c += kSeThreads) {
+    const float* wr = w1 + (long long)c * R;
     float a = 0.f;
-    for (int k = 0; k < R; ++k) a = fmaf(sd1[k], w1[(long long)c * R + k], a);
+    int k = 0;
+    for (; k + 8 <= R; k += 8) {
+      float wv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) wv[u] = wr[k + u];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a = fmaf(sd1[k + u], wv[u], a);
+    }
+    for (; k < R; ++k) a = fmaf(sd1[k], wr[k], a);
     chan_add[(long long)n * C + c] = a * inv_hw;
   }
 }
@@ -146,7 +203,8 @@ int mliis_se_mlp_bwd(const float* dgate, const float* gate, const float* s, cons
   MLIIS_REQUIRE(dgate && gate && s && hpre && w1 && w2 && dpre1 && dpre2 && chan_add && dw1 && db1 && dw2 && db2, MLIIS_ERR_ARG,
                 "se_mlp_bwd: null pointer");
   MLIIS_REQUIRE(N > 0 && C > 0 && R > 0 && R <= kMaxR && HW > 0, MLIIS_ERR_ARG, "se_mlp_bwd: bad shape");
-  hipLaunchKernelGGL(se_mlp_bwd_k, dim3(N), dim3(kSeThreads), 0, stream, dgate, gate, hpre, w1, w2, dpre2, dpre1, chan_add, C, R,
+  MLIIS_REQUIRE(C <= 8192, MLIIS_ERR_UNSUPPORTED, "se_mlp_bwd: C > 8192");
+  hipLaunchKernelGGL(se_mlp_bwd_k, dim3(N), dim3(kSeThreads), (size_t)C * sizeof(float), stream, dgate, gate, hpre, w1, w2, dpre2, dpre1, chan_add, C, R,
                      1.0f / (float)HW);
   MLIIS_CHECK_LAUNCH("se_mlp_bwd");
   int total = 2 * C * R + C + R;

@@ -84,54 +84,80 @@ __global__ __launch_bounds__(256) void stem_fwd_k(const float* __restrict__ x, c
 }
 
 // thread = (pixel lane, channel quad): 27 x float4 accumulators; the 27 normalised inputs of a pixel are shared by the Co/4 quad
-// threads of that pixel (L1 broadcast).  part layout [blk][27][Co].
+// threads of that pixel (L1 broadcast).  Two pixels per trip (both windows loaded before the FMAs).  Block reduction: butterfly over
+// the pixel lanes that share a wave, then the waves through LDS in a fixed order.  part layout [blk][27][Co].
+// The quad index is padded to a power of two (QP >= Co/4; surplus lanes idle) so the lanes of one quad are a fixed xor pattern.
 __global__ __launch_bounds__(256) void stem_bwd_filter_k(const float* __restrict__ x, const int* __restrict__ idx,
                                                          const float* __restrict__ dz, float* __restrict__ part, int N, int H,
                                                          int W, int Ho, int Wo, int Co, int pt, int pl, Norm3 nm,
-                                                         int pix_per_block) {
-  __shared__ float4 sred[256];
+                                                         int pix_per_block, int QP) {
+  extern __shared__ float4 sred[];   // [4 waves][27][QC]
   const int QC = Co >> 2;            // channel quads
-  const int PL = 256 / QC;           // pixel lanes
-  const int q = threadIdx.x % QC, pl_ = threadIdx.x / QC;
-  const bool active = pl_ < PL;
+  const int PL = 256 / QP;           // pixel lanes
+  const int q = threadIdx.x & (QP - 1), pl_ = threadIdx.x / QP;
+  const bool active = q < QC;
   const long long P = (long long)N * Ho * Wo;
   float4 acc[27];
 #pragma unroll
   for (int k = 0; k < 27; ++k) acc[k] = f4zero();
-  if (active) {
-    const long long p0 = (long long)blockIdx.x * pix_per_block;
-    long long p1 = p0 + pix_per_block;
-    if (p1 > P) p1 = P;
-    for (long long pix = p0 + pl_; pix < p1; pix += PL) {
-      const int wo = (int)(pix % Wo);
-      long long r = pix / Wo;
-      const int ho = (int)(r % Ho);
-      const int n = (int)(r / Ho);
-      const int src = idx ? idx[n] : n;
-      float v[27];
-      load_window(x + (long long)src * H * W * 3, H, W, ho * 2 - pt, wo * 2 - pl, nm, v);
-      const float4 d = ld4(dz + pix * Co + q * 4);
+  const long long p0 = (long long)blockIdx.x * pix_per_block;
+  long long p1 = p0 + pix_per_block;
+  if (p1 > P) p1 = P;
+  auto window = [&](long long pix, float* v) {
+    const int wo = (int)(pix % Wo);
+    const long long r = pix / Wo;
+    const int ho = (int)(r % Ho);
+    const int n = (int)(r / Ho);
+    const int src = idx ? idx[n] : n;
+    load_window(x + (long long)src * H * W * 3, H, W, ho * 2 - pt, wo * 2 - pl, nm, v);
+  };
+  long long pix = active ? p0 + pl_ : p1;
+  for (; pix + PL < p1; pix += 2 * PL) {
+    float v0[27], v1[27];
+    window(pix, v0);
+    window(pix + PL, v1);
+    const float4 d0 = ld4(dz + pix * Co + q * 4), d1 = ld4(dz + (pix + PL) * Co + q * 4);
 #pragma unroll
-      for (int k = 0; k < 27; ++k) acc[k] = f4fma(make_float4(v[k], v[k], v[k], v[k]), d, acc[k]);
+    for (int k = 0; k < 27; ++k) {
+      acc[k] = f4fma(make_float4(v0[k], v0[k], v0[k], v0[k]), d0, acc[k]);
+      acc[k] = f4fma(make_float4(v1[k], v1[k], v1[k], v1[k]), d1, acc[k]);
     }
   }
+  for (; pix < p1; pix += PL) {
+    float v[27];
+    window(pix, v);
+    const float4 d = ld4(dz + pix * Co + q * 4);
+#pragma unroll
+    for (int k = 0; k < 27; ++k) acc[k] = f4fma(make_float4(v[k], v[k], v[k], v[k]), d, acc[k]);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int k = 0; k < 27; ++k) {
-    __syncthreads();
-    sred[threadIdx.x] = acc[k];
-    __syncthreads();
-    if (pl_ == 0 && q < QC) {
-      float4 s4 = sred[q];
-      for (int j = 1; j < PL; ++j) s4 = f4add(s4, sred[j * QC + q]);
-      st4(part + ((long long)blockIdx.x * 27 + k) * Co + q * 4, s4);
+    for (int off = QP; off < 64; off <<= 1) {
+      acc[k].x += __shfl_xor(acc[k].x, off);
+      acc[k].y += __shfl_xor(acc[k].y, off);
+      acc[k].z += __shfl_xor(acc[k].z, off);
+      acc[k].w += __shfl_xor(acc[k].w, off);
     }
+    if (lane < QP && active) sred[(wave * 27 + k) * QC + q] = acc[k];
   }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 27 * QC; i += 256) {
+    const float4 s4 = f4add(f4add(sred[i], sred[27 * QC + i]), f4add(sred[2 * 27 * QC + i], sred[3 * 27 * QC + i]));
+    st4(part + (long long)blockIdx.x * 27 * Co + (long long)i * 4, s4);
+  }
+}
+
+static inline int stem_quad_pad(int Co) {
+  int qp = 1;
+  while (qp < Co / 4) qp <<= 1;
+  return qp;
 }
 
 static inline void stem_filter_geom(int N, int Ho, int Wo, int Co, int* pix_per_block, int* nblk) {
   long long P = (long long)N * Ho * Wo;
-  int PL = 256 / (Co / 4);
-  long long ppb = (P + 511) / 512;
+  int PL = 256 / stem_quad_pad(Co);
+  long long ppb = (P + 1023) / 1024;
   if (ppb < PL * 4) ppb = PL * 4;
   ppb = (ppb + PL - 1) / PL * PL;
   *pix_per_block = (int)ppb;
@@ -176,8 +202,8 @@ int mliis_stem_conv_bwd_filter(const float* x, const int* img_idx, const float* 
   stem_filter_geom(N, g.Ho, g.Wo, Co, &ppb, &nblk);
   MLIIS_REQUIRE((size_t)nblk * 27 * Co <= ws_floats, MLIIS_ERR_WORKSPACE, "stem_conv_bwd_filter: workspace too small");
   Norm3 nm{mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]};
-  hipLaunchKernelGGL(stem_bwd_filter_k, dim3(nblk), dim3(256), 0, stream, x, img_idx, dz, ws, N, H, W, g.Ho, g.Wo, Co,
-                     g.pt, g.pl, nm, ppb);
+  hipLaunchKernelGGL(stem_bwd_filter_k, dim3(nblk), dim3(256), (size_t)4 * 27 * (Co / 4) * sizeof(float4), stream, x, img_idx, dz, ws, N, H, W, g.Ho, g.Wo, Co,
+                     g.pt, g.pl, nm, ppb, stem_quad_pad(Co));
   MLIIS_CHECK_LAUNCH("stem_conv_bwd_filter");
   if (dw == nullptr) return MLIIS_OK;
   hipLaunchKernelGGL(fold_flat_k, dim3(ceil_div(27 * Co, kFoldX)), dim3(kFoldX, kFoldY), 0, stream, ws, nblk, (long long)27 * Co, 1.0f, dw, 0, (long long)27 * Co, 0LL, 0LL);

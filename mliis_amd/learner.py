@@ -107,6 +107,7 @@ class _Plan:
         #      mliis_fold_batched launch at the end of the backward pass reduces them all into the gradient arena
         A = L.arena
         regs, rows, off, tile = {}, [], 0, 0
+        fold_tile = lib.raw("mliis_fold_tile_outputs")()
 
         def add(name, ws_floats, total, seg=None):
             nonlocal off, tile
@@ -114,7 +115,7 @@ class _Plan:
             regs[name] = (off, ws_floats)
             rows.append([off, A.t_off[name], total, seg_len, seg_stride, seg_off, ws_floats // total, tile])
             off += (ws_floats + 3) // 4 * 4
-            tile += -(-total // 16)
+            tile += -(-total // fold_tile)
         fe = a.name
         add(f"{fe}/stem/conv2d/kernel", lib.size("mliis_stem_conv_bwd_filter_workspace_floats", N, H, H, a.stem_out), 27 * a.stem_out)
         for b, nm in zip([b for b in a.blocks if b.executed], L.n_blocks):

@@ -422,3 +422,40 @@ def test_rsd_pooled_branch_as_border_bias(H, W, Cc, Cp, Co, N):
     close(db, gb, 1e-4, "dbias")
     close(dpool * (H * W), gp, 1e-4, "dpool")
     close(ops.conv2d_bwd_data(dzg, wg, 1, ci_begin=0, ci_count=Cc), gx, 1e-4, "dx of the convolved channels")
+
+
+# ------------------------------------------------------------------------------------------------ batched slab fold
+def test_fold_batched_dense_segmented_and_ragged():
+    """mliis_fold_batched: several descriptors in one launch -- a dense vector path, a segmented (channel-window) output, a total that
+    is not a multiple of 4 (scalar path) and slab counts from 1 to 37 -- against a float64 sum."""
+    from mliis_amd import ops
+    from mliis_amd._lib import lib
+    d = dev()
+    tile = lib.raw("mliis_fold_tile_outputs")()
+    g = torch.Generator().manual_seed(7)
+    # (total, nblk, seg_len, seg_stride, seg_off)
+    cases = [(4096, 37, 4096, 0, 0), (9 * 8 * 12, 5, 8 * 12, 20 * 12, 4 * 12), (27 * 5 + 2, 3, 27 * 5 + 2, 0, 0), (520, 1, 520, 0, 0), (260, 16, 52, 100, 8)]
+    parts, rows, outs, poff, ooff, tcount = [], [], [], 0, 0, 0
+    for total, nblk, sl, ss, so in cases:
+        p = torch.randn(nblk, total, generator=g, dtype=torch.float64)
+        parts.append((poff, p))
+        span = (total // sl - 1) * ss + so + sl if ss else total
+        span = (span + 3) // 4 * 4
+        rows.append([poff, ooff, total, sl, ss, so, nblk, tcount])
+        outs.append((ooff, span, total, sl, ss, so, p.sum(0)))
+        poff += (nblk * total + 3) // 4 * 4
+        ooff += span
+        tcount += -(-total // tile)
+    buf = torch.zeros(poff + 16, device=d)
+    for off, p in parts:
+        buf[off:off + p.numel()] = p.float().reshape(-1).to(d)
+    out = torch.full((ooff + 16,), -7.0, device=d)
+    ops.fold_batched(buf, out, torch.tensor(rows, dtype=torch.int64, device=d), tcount)
+    out = out.cpu().double()
+    for off, span, total, sl, ss, so, ref in outs:
+        want = torch.full((span,), -7.0, dtype=torch.float64)
+        i = torch.arange(total)
+        want[(i // sl) * ss + so + i % sl] = ref
+        got = out[off:off + span]
+        assert torch.equal(got == -7.0, want == -7.0), "fold wrote outside its window"
+        close(got, want, 1e-6, "fold_batched total={}".format(total))
