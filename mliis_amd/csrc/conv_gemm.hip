@@ -22,6 +22,8 @@
 // while chunk i is multiplied).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace mliis {
@@ -54,7 +56,7 @@ struct ConvGemmParams {
 };
 
 template <int TM, int NT, bool B_NK>
-__global__ __launch_bounds__(256) void conv_gemm_k(ConvGemmParams p) {
+__global__ __launch_bounds__(256, 2) void conv_gemm_k(ConvGemmParams p) {
   constexpr int BM = 64 * TM, BN = 16 * NT, BK = 32;
   constexpr int LDB_NN = BN + 4;
   constexpr int A_FLOATS = 8 * BM * 4;
@@ -335,6 +337,324 @@ __global__ __launch_bounds__(256) void conv_gemm_k(ConvGemmParams p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------ NK path, second generation
+// Same tiling, LDS fragment layout and epilogue as conv_gemm_k<TM, NT, true>, restructured so the matrix pipe is not starved:
+//  * global loads are raw buffer loads whose offset is forced out of range for padded / out-of-image / out-of-K elements (the
+//    hardware returns zeros) -- no branches, so the address arithmetic of chunk k+1 is scheduled between the MFMAs of chunk k;
+//  * (tap, channel offset) advance incrementally in scalar registers, per-row offsets are computed once;
+//  * LDS is double buffered: one barrier per K chunk, the LDS writes of chunk k+1 overlap the MFMAs of chunk k of the other waves;
+//  * all fragments of a chunk are read from LDS before its first MFMA.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned kOob = 0xFFFFFFF0u;          // beyond any num_records: the load returns 0
+constexpr unsigned kBufRecords = 0x80000000u;   // host guarantees every legal byte offset is below 2 GiB
+
+__device__ __forceinline__ float4 buf_ld4(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
+template <int TM, int NT, int PF, bool SC>
+__global__ __launch_bounds__(256, 2) void conv_gemm_nk_k(ConvGemmParams p) {
+  constexpr int BM = 64 * TM, BN = 16 * NT, BK = 32;
+  constexpr int A_FLOATS = 8 * BM * 4;
+  constexpr int B_FLOATS = 8 * BN * 4;
+  constexpr int BUF_FLOATS = A_FLOATS + B_FLOATS;
+  constexpr int A_PER_THREAD = 2 * TM;          // float4 per thread per chunk
+  constexpr int B_TOTAL = BN * 8;               // float4 per chunk
+  constexpr int B_PER_THREAD = (B_TOTAL + 255) / 256;
+  constexpr int LDS_STAGE = BN + 4;             // epilogue staging row stride (floats)
+  constexpr int STAGE_FLOATS = 4 * 16 * LDS_STAGE;
+  constexpr int SM_FLOATS = (2 * BUF_FLOATS) > STAGE_FLOATS ? (2 * BUF_FLOATS) : STAGE_FLOATS;
+  __shared__ __attribute__((aligned(16))) float sm[SM_FLOATS];
+
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int l15 = lane & 15, g = lane >> 4;
+  const long long M = (long long)p.Nimg * p.H * p.W;
+  const int n0 = blockIdx.y * BN;
+  const int cpc = (p.C + BK - 1) / BK;  // chunks per tap
+  const int nchunks_total = p.ntaps * cpc;
+  const int it0 = blockIdx.z * p.chunks_per_split;
+  int it1 = it0 + p.chunks_per_split;
+  if (it1 > nchunks_total) it1 = nchunks_total;
+
+  const bool split = p.partial != nullptr;
+  const bool stats = (p.stats_part != nullptr) && !split;
+  float s1[NT], s2[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) s1[j] = s2[j] = 0.f;
+
+  const unsigned bx = xcd_remap(blockIdx.x, gridDim.x);
+  const long long m0 = (long long)bx * BM;
+
+  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, kBufRecords, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, kBufRecords, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc((void*)(SC ? p.a_scale : p.A), 0, kBufRecords, 0x00020000);
+
+  // ---- per-thread rows: byte offsets computed once
+  const int kq = t & 7;        // this thread's k quad inside a chunk (same for its A and B elements)
+  const int a_r0 = t >> 3;     // 0..31
+  int a_h[A_PER_THREAD], a_w[A_PER_THREAD];
+  unsigned a_off[A_PER_THREAD], s_off[A_PER_THREAD];
+#pragma unroll
+  for (int i = 0; i < A_PER_THREAD; ++i) {
+    const long long m = m0 + a_r0 + 32 * i;
+    a_h[i] = a_w[i] = -0x40000000;   // row beyond M: never in range
+    a_off[i] = s_off[i] = 0;
+    if (m < M) {
+      const int HWp = p.H * p.W;
+      const int n = (int)(m / HWp);
+      const int rem = (int)(m - (long long)n * HWp);
+      a_h[i] = rem / p.W;
+      a_w[i] = rem - a_h[i] * p.W;
+      a_off[i] = (unsigned)((m * p.lda + kq * 4) * 4);
+      s_off[i] = (unsigned)(((long long)n * p.C + kq * 4) * 4);
+    }
+  }
+  unsigned b_off[B_PER_THREAD];
+  bool b_ok[B_PER_THREAD];
+#pragma unroll
+  for (int i = 0; i < B_PER_THREAD; ++i) {
+    const int idx = t + 256 * i;
+    const int n = idx >> 3;
+    b_ok[i] = (idx < B_TOTAL) && (n0 + n < p.Nout);
+    b_off[i] = (unsigned)(((long long)(n0 + n) * p.ldb + kq * 4) * 4);
+  }
+
+  // ---- uniform state (scalar registers): (tap, c0) of the next chunk to LOAD, c0 of the chunk being COMPUTED
+  int tap = it0 / cpc;
+  int c0 = (it0 - tap * cpc) * BK;
+  int c0_cur = c0;
+  float4 ra[PF][A_PER_THREAD], rs[PF][A_PER_THREAD], rb[PF][B_PER_THREAD];
+
+  // chunk (tap, c0) -> registers, then advance.  Branch-free (live == false turns every offset out of range: no memory traffic,
+  // zeros come back) so the compiler knows exactly how many loads are in flight and waits only for the older chunk.
+  auto load_chunk = [&](float4* ra_, float4* rs_, float4* rb_, bool live) {
+    int dh = 0, dw = 0;
+    if (p.ntaps > 1) {
+      const int th = tap / 3;
+      dh = (th - 1) * p.dil * p.sign;
+      dw = (tap - th * 3 - 1) * p.dil * p.sign;
+    }
+    const bool kok = live & (c0 + kq * 4 < p.C);
+    const unsigned da = (unsigned)(((dh * p.W + dw) * p.lda + c0) * 4);
+#pragma unroll
+    for (int i = 0; i < A_PER_THREAD; ++i) {
+      const bool ok = kok & ((unsigned)(a_h[i] + dh) < (unsigned)p.H) & ((unsigned)(a_w[i] + dw) < (unsigned)p.W);
+      ra_[i] = buf_ld4(rA, ok ? a_off[i] + da : kOob);
+      if (SC) rs_[i] = buf_ld4(rS, ok ? s_off[i] + (unsigned)(c0 * 4) : kOob);
+    }
+    const unsigned db = (unsigned)(((long long)tap * p.b_tap_stride + c0) * 4);
+#pragma unroll
+    for (int i = 0; i < B_PER_THREAD; ++i) rb_[i] = buf_ld4(rB, (kok & b_ok[i]) ? b_off[i] + db : kOob);
+    c0 += BK;
+    if (c0 >= p.C) {
+      c0 = 0;
+      ++tap;
+    }
+  };
+  auto store_chunk = [&](float* buf, const float4* ra_, const float4* rs_, const float4* rb_) {
+    float* smA = buf;
+    float* smB = buf + A_FLOATS;
+#pragma unroll
+    for (int i = 0; i < A_PER_THREAD; ++i) {
+      const int row = a_r0 + 32 * i;
+      float4 v = ra_[i];
+      if (SC) v = f4mul(v, rs_[i]);
+      st4(smA + (kq * BM + (row ^ kq)) * 4, v);
+    }
+#pragma unroll
+    for (int i = 0; i < B_PER_THREAD; ++i) {
+      const int idx = t + 256 * i;
+      if (idx < B_TOTAL) st4(smB + (kq * BN + ((idx >> 3) ^ kq)) * 4, rb_[i]);
+    }
+  };
+
+  f32x4 acc[TM][NT];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // ---- software pipeline: chunk j is computed from LDS buffer (j - it0) & 1 while chunk j+1 waits in registers (loaded one
+  // iteration earlier when PF == 2) and the loads of chunk j+PF are in flight; one barrier per chunk.
+  load_chunk(ra[0], rs[0], rb[0], it0 < it1);
+  store_chunk(sm, ra[0], rs[0], rb[0]);
+#pragma unroll
+  for (int s_ = 1; s_ < PF; ++s_) load_chunk(ra[s_], rs[s_], rb[s_], it0 + s_ < it1);
+  __syncthreads();
+  // One chunk: issue the loads of chunk j + PF into register set U (it held chunk j, already in LDS), multiply chunk j out of
+  // LDS buffer `cur`, then move chunk j + 1 (register set (U + 1) % PF, loaded one step earlier when PF == 2) into the other buffer.
+  int cur = 0;
+  auto step = [&](auto UC, int j) {
+    constexpr int U = decltype(UC)::value;
+    constexpr int NX = (U + 1) % PF;
+    // the second 16-wide k group of a chunk is all zero padding when the channel count ends inside the first one
+    const bool two = c0_cur + 16 < p.C;
+    c0_cur += BK;
+    if (c0_cur >= p.C) c0_cur = 0;
+    load_chunk(ra[U], rs[U], rb[U], j + PF < it1);
+    const float* smA = sm + cur * BUF_FLOATS;
+    const float* smB = smA + A_FLOATS;
+    constexpr bool kAllFirst = TM == 1;   // read the fragments of both k groups before the first MFMA (register budget permitting)
+    float4 av[2][TM], bv[2][NT];
+    auto read_frags = [&](int q) {
+      const int fq = q * 4 + g;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) av[q][i] = ld4(smA + (fq * BM + ((wave * 16 * TM + i * 16 + l15) ^ fq)) * 4);
+#pragma unroll
+      for (int jn = 0; jn < NT; ++jn) bv[q][jn] = ld4(smB + (fq * BN + ((jn * 16 + l15) ^ fq)) * 4);
+    };
+    auto multiply = [&](int q) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const float a = s == 0 ? av[q][i].x : s == 1 ? av[q][i].y : s == 2 ? av[q][i].z : av[q][i].w;
+#pragma unroll
+          for (int jn = 0; jn < NT; ++jn) {
+            const float b = s == 0 ? bv[q][jn].x : s == 1 ? bv[q][jn].y : s == 2 ? bv[q][jn].z : bv[q][jn].w;
+            acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i][jn], 0, 0, 0);
+          }
+        }
+      }
+    };
+    if (kAllFirst) {
+      read_frags(0);
+      if (two) read_frags(1);
+      multiply(0);
+      if (two) multiply(1);
+    } else {
+      read_frags(0);
+      multiply(0);
+      if (two) {
+        read_frags(0 + 1);
+        multiply(1);
+      }
+    }
+    store_chunk(sm + (cur ^ 1) * BUF_FLOATS, ra[NX], rs[NX], rb[NX]);   // zeros after the last chunk: nobody reads them
+    cur ^= 1;
+    __syncthreads();
+  };
+  typedef std::integral_constant<int, 0> U0;
+  typedef std::integral_constant<int, 1 % PF> U1;
+  int it = it0;
+  // Main loop: four chunks per trip.  The compiler flushes the load counter at a loop header (it cannot prove across the back edge
+  // that only the newest chunk is in flight), so the long body keeps that flush to every fourth chunk; the tail is straight-line.
+  for (; it + 4 <= it1; it += 4) {
+    step(U0{}, it);
+    step(U1{}, it + 1);
+    step(U0{}, it + 2);
+    step(U1{}, it + 3);
+  }
+  if (it < it1) step(U0{}, it);
+  if (it + 1 < it1) step(U1{}, it + 1);
+  if (it + 2 < it1) step(U0{}, it + 2);
+
+  // ---- epilogue (identical to conv_gemm_k): C/D layout of 16x16x4: col = lane & 15, row = 4 * (lane >> 4) + reg
+  if (split) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long long m = m0 + wave * 16 * TM + i * 16 + g * 4 + r;
+        if (m >= M) continue;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const int n = n0 + j * 16 + l15;
+          if (n < p.Nout) p.partial[((long long)blockIdx.z * M + m) * p.Nout + n] = acc[i][j][r];
+        }
+      }
+    return;
+  }
+  float* stage = sm + wave * 16 * LDS_STAGE;
+  float bj[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int n = n0 + j * 16 + l15;
+    bj[j] = (p.bias != nullptr && n < p.Nout) ? p.bias[n] : 0.f;
+  }
+  const long long HWp = (long long)p.H * p.W;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const long long mbase = m0 + wave * 16 * TM + i * 16;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float* bb = nullptr;
+      if (p.border_bias != nullptr) {
+        const long long m = mbase + g * 4 + r;
+        if (m < M) {
+          const int ni = (int)(m / HWp);
+          const int rem = (int)(m - (long long)ni * HWp);
+          const int h = rem / p.W, w_ = rem - h * p.W;
+          const int cls = (h == 0 ? 0 : (h == p.H - 1 ? 2 : 1)) * 3 + (w_ == 0 ? 0 : (w_ == p.W - 1 ? 2 : 1));
+          bb = p.border_bias + ((long long)ni * 9 + cls) * p.Nout;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int n = n0 + j * 16 + l15;
+        float v = acc[i][j][r] + bj[j];
+        if (bb != nullptr && n < p.Nout) v += bb[n];
+        acc[i][j][r] = v;
+        stage[(g * 4 + r) * LDS_STAGE + j * 16 + l15] = v;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < NT; ++it) {
+      const int idx = it * 64 + lane;
+      const int row = idx / (BN / 4), q = idx - row * (BN / 4);
+      const long long m = mbase + row;
+      const int n = n0 + q * 4;
+      if (m < M && n < p.Nout) {
+        float4 v = ld4(stage + row * LDS_STAGE + q * 4);
+        float* dst = p.Cmat + m * p.ldc + n;
+        if (p.accumulate) v = f4add(v, ld4(dst));
+        st4(dst, v);
+      }
+    }
+    __syncthreads();
+  }
+  if (!stats) return;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const long long m = m0 + wave * 16 * TM + i * 16 + g * 4 + r;
+      if (m >= M) continue;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const float v = acc[i][j][r];
+        const float u = p.stats_swish ? swish_f(v) : v;
+        s1[j] += u;
+        s2[j] = fmaf(u, u, s2[j]);
+      }
+    }
+  float* red = sm;  // layout [wave][2][BN]
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    float a = s1[j], b = s2[j];
+    a += __shfl_xor(a, 16, 64);
+    b += __shfl_xor(b, 16, 64);
+    a += __shfl_xor(a, 32, 64);
+    b += __shfl_xor(b, 32, 64);
+    if (g == 0) {
+      red[(wave * 2 + 0) * BN + j * 16 + l15] = a;
+      red[(wave * 2 + 1) * BN + j * 16 + l15] = b;
+    }
+  }
+  __syncthreads();
+  for (int idx = t; idx < 2 * BN; idx += 256) {
+    const int v = idx / BN, col = idx - v * BN;
+    const int n = n0 + col;
+    if (n < p.Nout) {
+      const float r0 = red[(0 * 2 + v) * BN + col] + red[(1 * 2 + v) * BN + col] + red[(2 * 2 + v) * BN + col] + red[(3 * 2 + v) * BN + col];
+      p.stats_part[((long long)bx * 2 + v) * p.Nout + n] = r0;
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void splitk_reduce_k(const float* __restrict__ partial, int splits, long long M, int Nout,
                                                        float* __restrict__ Cmat, int ldc, const float* __restrict__ bias,
                                                        int accumulate, const float* __restrict__ border_bias, int H, int W) {
@@ -430,7 +750,7 @@ struct FilterGradParams {
 };
 
 template <int TMF, int NT>
-__global__ __launch_bounds__(256) void conv_filter_grad_k(FilterGradParams p) {
+__global__ __launch_bounds__(256, 2) void conv_filter_grad_k(FilterGradParams p) {
   constexpr int BCI = 64 * TMF, BN = 16 * NT, BKM = 32;
   constexpr int LDX = BCI + 16;
   constexpr int LDD = (BN % 32 == 0) ? BN + 16 : BN;
@@ -621,11 +941,23 @@ static inline GemmPlan plan_gemm(long long M, int Nout, int C, int ntaps, int nu
   return g;
 }
 
+static inline bool gemm_v1() {   // tuning switch (experiments only): MLIIS_GEMM_V1=1 selects the first-generation NK kernel
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("MLIIS_GEMM_V1");
+    v = (e && atoi(e) == 1) ? 1 : 0;
+  }
+  return v == 1;
+}
+
 template <bool B_NK>
 static void launch_gemm(const GemmPlan& g, const ConvGemmParams& p, hipStream_t stream) {
   dim3 grid(g.gx, g.gy, g.gz), block(256);
+  const bool v2 = B_NK && !gemm_v1();
 #define L(TM_, NT_)                                                                               \
-  hipLaunchKernelGGL((conv_gemm_k<TM_, NT_, B_NK>), grid, block, 0, stream, p);                   \
+  if (v2 && p.a_scale) hipLaunchKernelGGL((conv_gemm_nk_k<TM_, NT_, (TM_ == 1 ? 2 : 1), true>), grid, block, 0, stream, p); \
+  else if (v2) hipLaunchKernelGGL((conv_gemm_nk_k<TM_, NT_, (TM_ == 1 ? 2 : 1), false>), grid, block, 0, stream, p); \
+  else hipLaunchKernelGGL((conv_gemm_k<TM_, NT_, B_NK>), grid, block, 0, stream, p);              \
   break;
 #define ROW(TM_)       \
   switch (g.nt) {      \
@@ -761,6 +1093,8 @@ int mliis_conv2d_fwd(const float* x, int ldx, const float* x_scale, const float*
   MLIIS_REQUIRE(aligned16(x) && aligned16(w) && aligned16(bias) && aligned16(y), MLIIS_ERR_ALIGN,
                 "conv2d_fwd: pointers must be 16-byte aligned");
   long long M = (long long)Nimg * H * W;
+  MLIIS_REQUIRE(M * ldx * 4 < (1LL << 31) && (long long)ksize * ksize * Cin_total * Cout * 4 < (1LL << 31), MLIIS_ERR_UNSUPPORTED,
+                "conv2d_fwd: operand larger than 2 GiB (32-bit buffer offsets)");
   GemmPlan g = plan_gemm(M, Cout, Cin, ksize * ksize, num_cus(), ws != nullptr);
   MLIIS_REQUIRE(ci_begin >= 0 && (ci_begin & 3) == 0 && ci_begin + Cin <= Cin_total, MLIIS_ERR_ARG,
                 "conv2d_fwd: input-channel window out of range");
@@ -823,6 +1157,8 @@ int mliis_conv2d_bwd_data(const float* dy, int lddy, const float* w, float* dx, 
                 "conv2d_bwd_data: bad leading dimensions");
   MLIIS_REQUIRE(aligned16(dy) && aligned16(w) && aligned16(dx), MLIIS_ERR_ALIGN, "conv2d_bwd_data: pointers must be 16-byte aligned");
   long long M = (long long)Nimg * H * W;
+  MLIIS_REQUIRE(M * lddy * 4 < (1LL << 31) && (long long)ksize * ksize * Cin_total * Cout * 4 < (1LL << 31), MLIIS_ERR_UNSUPPORTED,
+                "conv2d_bwd_data: operand larger than 2 GiB (32-bit buffer offsets)");
   GemmPlan g = plan_gemm(M, Cin_out, Cout, ksize * ksize, num_cus(), ws != nullptr);
   ConvGemmParams p{dy, lddy, Nimg, H, W, Cout, ksize * ksize, dil, -1, w + (long long)ci_begin * Cout, (long long)Cin_total * Cout,
                    Cout, Cin_out, dx, lddx, nullptr, accumulate, nullptr, g.chunks_per_split, nullptr, 0, nullptr, nullptr};
