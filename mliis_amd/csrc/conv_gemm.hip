@@ -868,6 +868,187 @@ __global__ __launch_bounds__(256, 2) void conv_filter_grad_k(FilterGradParams p)
     }
 }
 
+// ------------------------------------------------------------------------------------------------ backward-filter, 2nd generation
+// Same tiling / LDS layout / slab output as conv_filter_grad_k, with the pipeline of conv_gemm_nk_k: branch-free buffer loads
+// (out-of-range rows and halo pixels return zeros), per-row (h, w) advanced incrementally instead of two integer divisions per row
+// and chunk, double-buffered LDS (one barrier per 32-pixel chunk) and a two-chunk register prefetch.
+template <int TMF, int NT, bool SC>
+__global__ __launch_bounds__(256, 2) void conv_filter_grad2_k(FilterGradParams p) {
+  constexpr int BCI = 64 * TMF, BN = 16 * NT, BKM = 32;
+  constexpr int LDX = BCI + 16;
+  constexpr int LDD = (BN % 32 == 0) ? BN + 16 : BN;
+  constexpr int X_PER_THREAD = (BKM * (BCI / 4)) / 256;  // 2 * TMF
+  constexpr int D_TOTAL = BKM * (BN / 4);
+  constexpr int D_PER_THREAD = (D_TOTAL + 255) / 256;
+  constexpr int X_RSTEP = 256 / (BCI / 4);
+  constexpr int BUF_FLOATS = BKM * LDX + BKM * LDD;
+  constexpr int PF = (TMF == 2 && (SC || NT >= 8)) ? 1 : 2;   // register budget: one staging set for the widest instances
+  __shared__ __attribute__((aligned(16))) float sm[2 * BUF_FLOATS];
+
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int M = p.Nimg * p.H * p.W;            // host guarantees < 2^31
+  const int cblocks = (p.C + BCI - 1) / BCI;
+  const int tap = blockIdx.x / cblocks;
+  const int ci0 = (blockIdx.x - tap * cblocks) * BCI;
+  const int n0 = blockIdx.y * BN;
+  const int mbeg = blockIdx.z * p.rows_per_split;
+  int mend = mbeg + p.rows_per_split;
+  if (mend > M) mend = M;
+  int dh = 0, dw = 0;
+  if (p.ntaps > 1) {
+    dh = (tap / 3 - 1) * p.dil;
+    dw = (tap % 3 - 1) * p.dil;
+  }
+  const int HW = p.H * p.W;
+  const int adv_h = BKM / p.W, adv_w = BKM - adv_h * p.W;   // one chunk = 32 pixels further along the flattened (n, h, w) index
+
+  const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)p.X, 0, kBufRecords, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rD = __builtin_amdgcn_make_buffer_rsrc((void*)p.dY, 0, kBufRecords, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc((void*)(SC ? p.x_scale : p.X), 0, kBufRecords, 0x00020000);
+
+  // ---- per-thread X rows: position of the row the NEXT load will fetch
+  const int x_cq = t % (BCI / 4);
+  const int x_r0 = t / (BCI / 4);
+  const bool x_cok = ci0 + x_cq * 4 < p.C;
+  int x_m[X_PER_THREAD], x_h[X_PER_THREAD], x_w[X_PER_THREAD], x_n[X_PER_THREAD];
+  unsigned x_off[X_PER_THREAD];
+#pragma unroll
+  for (int i = 0; i < X_PER_THREAD; ++i) {
+    const int m = mbeg + x_r0 + X_RSTEP * i;
+    x_m[i] = m;
+    x_n[i] = m / HW;
+    const int rem = m - x_n[i] * HW;
+    x_h[i] = rem / p.W;
+    x_w[i] = rem - x_h[i] * p.W;
+    x_off[i] = (unsigned)((((long long)m + (long long)dh * p.W + dw) * p.ldx + ci0 + x_cq * 4) * 4);
+  }
+  const unsigned x_step = (unsigned)(BKM * p.ldx * 4);
+  // ---- per-thread dY elements
+  int d_m[D_PER_THREAD];
+  unsigned d_off[D_PER_THREAD];
+  bool d_ok[D_PER_THREAD];
+#pragma unroll
+  for (int i = 0; i < D_PER_THREAD; ++i) {
+    const int idx = t + 256 * i;
+    const int r = idx / (BN / 4), nq = idx - r * (BN / 4);
+    d_m[i] = mbeg + r;
+    d_ok[i] = (idx < D_TOTAL) && (n0 + nq * 4 < p.Nout);
+    d_off[i] = (unsigned)((((long long)mbeg + r) * p.lddy + n0 + nq * 4) * 4);
+  }
+  const unsigned d_step = (unsigned)(BKM * p.lddy * 4);
+
+  float4 rx[PF][X_PER_THREAD], rs[PF][X_PER_THREAD], rd[PF][D_PER_THREAD];
+  auto load_chunk = [&](float4* rx_, float4* rs_, float4* rd_) {   // next 32 pixel rows -> registers, then advance
+#pragma unroll
+    for (int i = 0; i < X_PER_THREAD; ++i) {
+      const bool ok = x_cok & (x_m[i] < mend) & ((unsigned)(x_h[i] + dh) < (unsigned)p.H) & ((unsigned)(x_w[i] + dw) < (unsigned)p.W);
+      rx_[i] = buf_ld4(rX, ok ? x_off[i] : kOob);
+      if (SC) rs_[i] = buf_ld4(rS, ok ? (unsigned)((x_n[i] * p.C + ci0 + x_cq * 4) * 4) : kOob);
+      x_m[i] += BKM;
+      x_off[i] += x_step;
+      x_w[i] += adv_w;
+      x_h[i] += adv_h;
+      if (x_w[i] >= p.W) {
+        x_w[i] -= p.W;
+        ++x_h[i];
+      }
+      if (x_h[i] >= p.H) {   // crossed into the next image(s)
+        const int k = x_h[i] / p.H;
+        x_h[i] -= k * p.H;
+        x_n[i] += k;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < D_PER_THREAD; ++i) {
+      rd_[i] = buf_ld4(rD, (d_ok[i] & (d_m[i] < mend)) ? d_off[i] : kOob);
+      d_m[i] += BKM;
+      d_off[i] += d_step;
+    }
+  };
+  auto store_chunk = [&](float* buf, const float4* rx_, const float4* rs_, const float4* rd_) {
+    float* smX = buf;
+    float* smD = buf + BKM * LDX;
+#pragma unroll
+    for (int i = 0; i < X_PER_THREAD; ++i) {
+      float4 v = rx_[i];
+      if (SC) v = f4mul(v, rs_[i]);
+      st4(smX + (x_r0 + X_RSTEP * i) * LDX + x_cq * 4, v);
+    }
+#pragma unroll
+    for (int i = 0; i < D_PER_THREAD; ++i) {
+      const int idx = t + 256 * i;
+      if (idx < D_TOTAL) {
+        const int r = idx / (BN / 4), nq = idx - r * (BN / 4);
+        st4(smD + r * LDD + nq * 4, rd_[i]);
+      }
+    }
+  };
+
+  f32x4 acc[TMF][NT];
+#pragma unroll
+  for (int i = 0; i < TMF; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  load_chunk(rx[0], rs[0], rd[0]);
+  store_chunk(sm, rx[0], rs[0], rd[0]);
+  if (PF == 2) load_chunk(rx[PF - 1], rs[PF - 1], rd[PF - 1]);
+  __syncthreads();
+  int cur = 0;
+  auto step = [&](auto UC) {
+    constexpr int U = decltype(UC)::value;
+    constexpr int NX = (U + 1) % PF;
+    load_chunk(rx[U], rs[U], rd[U]);   // PF chunks ahead (rows beyond mend come back as zeros)
+    const float* smX = sm + cur * BUF_FLOATS;
+    const float* smD = smX + BKM * LDX;
+#pragma unroll
+    for (int kk = 0; kk < BKM / 4; ++kk) {
+      const int mrow = kk * 4 + g;
+      float a[TMF], b[NT];
+#pragma unroll
+      for (int i = 0; i < TMF; ++i) a[i] = smX[mrow * LDX + (wave * TMF + i) * 16 + l15];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) b[j] = smD[mrow * LDD + j * 16 + l15];
+#pragma unroll
+      for (int i = 0; i < TMF; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    store_chunk(sm + (cur ^ 1) * BUF_FLOATS, rx[NX], rs[NX], rd[NX]);
+    cur ^= 1;
+    __syncthreads();
+  };
+  typedef std::integral_constant<int, 0> U0;
+  typedef std::integral_constant<int, 1 % PF> U1;
+  const int nchunks = (mend - mbeg + BKM - 1) / BKM;
+  int it = 0;
+  for (; it + 4 <= nchunks; it += 4) {
+    step(U0{});
+    step(U1{});
+    step(U0{});
+    step(U1{});
+  }
+  if (it < nchunks) step(U0{});
+  if (it + 1 < nchunks) step(U1{});
+  if (it + 2 < nchunks) step(U0{});
+
+  const long long Ktot = (long long)p.ntaps * p.C;
+#pragma unroll
+  for (int i = 0; i < TMF; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ci = ci0 + (wave * TMF + i) * 16 + g * 4 + r;
+      if (ci >= p.C) continue;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int n = n0 + j * 16 + l15;
+        if (n < p.Nout) p.partial[((long long)blockIdx.z * Ktot + (long long)tap * p.C + ci) * p.Nout + n] = acc[i][j][r];
+      }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ weight shadow (HWIO -> HWOI)
 // dst[off + tap*Ci*Co + co*Ci + ci] = src[off + tap*Ci*Co + ci*Co + co] for every descriptor (off, taps, Ci, Co): one launch per
 // inner step keeps a K-contiguous copy of all dense-conv weights so the FORWARD GEMM can use the same b128-fragment B path as
@@ -992,7 +1173,7 @@ static inline FilterPlan plan_filter(long long M, int C, int Nout, int ntaps, in
   int bci = 64 * f.tmf;
   f.gx = ntaps * ((C + bci - 1) / bci);
   long long base = (long long)f.gx * f.gy;
-  long long want = (3LL * num_cus + base - 1) / base;  // ~3 blocks per CU in total ...
+  long long want = (2LL * num_cus) / base;  // one full round of two co-resident blocks per CU (no half-empty second round) ...
   {  // ... bounded by the slab count the fold has to read: 96 in general, up to 512 for tiny filters (fold cost ~ slabs * size)
     const long long total = (long long)ntaps * C * Nout;
     long long cap = (1LL << 19) / (total > 0 ? total : 1);
@@ -1011,8 +1192,10 @@ static inline FilterPlan plan_filter(long long M, int C, int Nout, int ntaps, in
 
 static void launch_filter(const FilterPlan& f, const FilterGradParams& p, hipStream_t stream) {
   dim3 grid(f.gx, f.gy, f.gz), block(256);
-#define L(T_, NT_)                                                                      \
-  hipLaunchKernelGGL((conv_filter_grad_k<T_, NT_>), grid, block, 0, stream, p);         \
+#define L(T_, NT_)                                                                                                   \
+  if (gemm_v1()) hipLaunchKernelGGL((conv_filter_grad_k<T_, NT_>), grid, block, 0, stream, p);                       \
+  else if (p.x_scale) hipLaunchKernelGGL((conv_filter_grad2_k<T_, NT_, true>), grid, block, 0, stream, p);           \
+  else hipLaunchKernelGGL((conv_filter_grad2_k<T_, NT_, false>), grid, block, 0, stream, p);                         \
   break;
 #define ROW(T_)       \
   switch (f.nt) {     \
@@ -1203,6 +1386,8 @@ int mliis_conv2d_bwd_filter(const float* x, int ldx, const float* x_scale, const
   MLIIS_REQUIRE((ldx & 3) == 0 && ldx >= Cin && (lddy & 3) == 0 && lddy >= Cout, MLIIS_ERR_ARG, "conv2d_bwd_filter: bad leading dimensions");
   MLIIS_REQUIRE(aligned16(x) && aligned16(dy) && aligned16(ws), MLIIS_ERR_ALIGN, "conv2d_bwd_filter: pointers must be 16-byte aligned");
   long long M = (long long)Nimg * H * W;
+  MLIIS_REQUIRE((M + 64) * ldx * 4 < (1LL << 31) && (M + 64) * lddy * 4 < (1LL << 31), MLIIS_ERR_UNSUPPORTED,
+                "conv2d_bwd_filter: operand larger than 2 GiB (32-bit buffer offsets)");
   FilterPlan f = plan_filter(M, Cin, Cout, ksize * ksize, num_cus());
   size_t total = (size_t)ksize * ksize * Cin * Cout;
   MLIIS_REQUIRE((size_t)f.gz * total <= ws_floats, MLIIS_ERR_WORKSPACE, "conv2d_bwd_filter: workspace too small (%zu needed, %zu given)",
