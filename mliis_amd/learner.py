@@ -169,6 +169,7 @@ class Learner:
         # Optional: weight-gradient GEMMs on a second stream forked inside the HIP graph.  Measured SLOWER on MI355X (4.95 vs 4.56 ms
         # per step, profiles/r01_notes.md): the cross-stream edges cost more than the idle CUs they fill, so it is off by default.
         self.overlap_wgrad = os.environ.get("MLIIS_OVERLAP_WGRAD", "0") == "1"
+        self.bn_small_rows = ops.bn_small_rows()
         self.side_stream = torch.cuda.Stream(device=self.device)
         self.arena = Arena(self.arch, self.device)
         self.arena.init_weights(seed)
@@ -338,9 +339,13 @@ class Learner:
         def bn(xin, st, prefix, y, pre=False, post=False, img_scale=None, res=None, fused=False, nblk=0):
             """nblk > 0: the producing conv already left the stage-1 statistics in P.stats_part."""
             if training:
+                part = P.stats_part
                 if nblk == 0:
-                    nblk = ops.bn_stats_partial(xin, pre, P.stats_part)
-                return ops.bn_apply_fused(xin, P.stats_part, nblk, st[0], st[1], w[prefix + "/gamma"], w[prefix + "/beta"],
+                    if ops.rows_ld(xin)[0] <= self.bn_small_rows:
+                        part = None          # small map: statistics + apply in one register-resident launch
+                    else:
+                        nblk = ops.bn_stats_partial(xin, pre, P.stats_part)
+                return ops.bn_apply_fused(xin, part, nblk, st[0], st[1], w[prefix + "/gamma"], w[prefix + "/beta"],
                                           moving=(mv[prefix + "/moving_mean"], mv[prefix + "/moving_variance"]), unbiased_moving_var=fused,
                                           pre_swish=pre, post_swish=post, img_scale=img_scale, res=res, out=y)
             st[0].copy_(mv[prefix + "/moving_mean"])
@@ -434,9 +439,10 @@ class Learner:
                 self.side_stream.wait_event(ev)
                 fn()
 
-        def bn_b(xin, dy, st, prefix, dx, pre=False, post=False, img_scale=None, chan_scale=None, chan_add=None):
+        def bn_b(xin, dy, st, prefix, dx, pre=False, post=False, img_scale=None, chan_scale=None, chan_add=None, dskip=None,
+                 dskip_accumulate=False):
             ops.bn_bwd(xin, dy, st[0], st[1], w[prefix + "/gamma"], w[prefix + "/beta"], pre, post, img_scale, chan_scale, chan_add, dx=dx,
-                       dgamma=g[prefix + "/gamma"], dbeta=g[prefix + "/beta"], ws=ws)
+                       dgamma=g[prefix + "/gamma"], dbeta=g[prefix + "/beta"], ws=ws, dskip=dskip, dskip_accumulate=dskip_accumulate)
 
         rs = sorted([x.scope_index + 1 for x in a.rsd], reverse=True)
         for j in range(len(a.rsd) - 1, -1, -1):
@@ -487,10 +493,11 @@ class Learner:
             # gradient for the block input: identity-skip part first (before dout is overwritten in place)
             tgt = P.blocks[bi - 1]["dout"] if bi > 0 else P.dstem
             tgt_has = has_grad[bi - 1] if bi > 0 else False
+            # identity-skip part of the block-input gradient: written by the same pass that turns dout into the bn2 input gradient
+            bn_b(B["z2"], dout, B["st2"], nm["bn2"], dout, img_scale=B["dc"] if B["use_dc"] else None,
+                 dskip=tgt if b.skip else None, dskip_accumulate=tgt_has)
             if b.skip:
-                ops.chan_affine(dout, out=tgt, accumulate=tgt_has)
                 tgt_has = True
-            bn_b(B["z2"], dout, B["st2"], nm["bn2"], dout, img_scale=B["dc"] if B["use_dc"] else None)
             side(lambda B=B, dout=dout, nm=nm: ops.conv2d_bwd_filter(B["a1"], dout, 1, 1, x_scale=B["gate"], partial=P.fold_part[nm["w_proj"]]))
             da2 = B["da2"]
             ops.conv2d_bwd_data(dout, w[nm["w_proj"]], 1, out=da2, ws=ws)

@@ -299,8 +299,13 @@ def bn_stats_partial_floats(rows, C_):
     return lib.size("mliis_colreduce_workspace_floats", rows, C_, 1, 2)
 
 
+def bn_small_rows():
+    return lib.raw("mliis_bn_small_rows")()
+
+
 def bn_apply_fused(x, part, nblk, mean, rstd, gamma, beta, moving=None, unbiased_moving_var=False, pre_swish=False, post_swish=False,
                    img_scale=None, res=None, out=None, rows_per_img=None, eps=BN_EPS, momentum=BN_MOMENTUM):
+    """part=None, nblk=0 (tensors of at most bn_small_rows() rows): statistics are computed in the same launch."""
     rows, C_, ldx = rows_ld(x)
     out = torch.empty(x.shape, dtype=torch.float32, device=x.device) if out is None else out
     _, _, ldy = rows_ld(out)
@@ -325,7 +330,8 @@ def bn_apply(x, mean, rstd, gamma, beta, pre_swish=False, post_swish=False, img_
 
 
 def bn_bwd(x, dy, mean, rstd, gamma, beta, pre_swish=False, post_swish=False, img_scale=None, chan_scale=None, chan_add=None, dx=None,
-           dgamma=None, dbeta=None, rows_per_img=None, ws: Optional[Workspace] = None):
+           dgamma=None, dbeta=None, rows_per_img=None, ws: Optional[Workspace] = None, dskip=None, dskip_accumulate=False):
+    """dskip (optional): the pass also writes dskip (+)= dy, the gradient of an identity skip around the normalised branch."""
     rows, C_, ldx = rows_ld(x)
     _, _, lddy = rows_ld(dy)
     dx = torch.empty(x.shape, dtype=torch.float32, device=x.device) if dx is None else dx
@@ -336,8 +342,8 @@ def bn_bwd(x, dy, mean, rstd, gamma, beta, pre_swish=False, post_swish=False, im
     ws = ws or default_ws()
     buf = ws.get(lib.size("mliis_colreduce_workspace_floats", rows, C_, 1, 2))
     lib.call("mliis_bn_bwd", _ptr(x), ldx, _ptr(dy), lddy, _ptr(dx), lddx, rows, C_, rpi, _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta),
-             int(pre_swish), int(post_swish), _ptr(img_scale), _ptr(chan_scale), _ptr(chan_add), _ptr(dgamma), _ptr(dbeta), _ptr(buf),
-             buf.numel(), _stream())
+             int(pre_swish), int(post_swish), _ptr(img_scale), _ptr(chan_scale), _ptr(chan_add), _ptr(dgamma), _ptr(dbeta), _ptr(dskip),
+             rows_ld(dskip)[2] if dskip is not None else 0, int(dskip_accumulate), _ptr(buf), buf.numel(), _stream())
     return dx, dgamma, dbeta
 
 
