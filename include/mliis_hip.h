@@ -127,9 +127,7 @@ int mliis_bn_apply_fused(const float* x, int ldx, float* y, int ldy, long long r
                          const float* res, int ldr, hipStream_t stream);
 /*      workspace: mliis_colreduce_workspace_floats(rows, C, 1, 2) floats.  dskip (nullable): the same pass also writes the
  *      identity-skip gradient dskip[r,c] (+)= dy[r,c] (MBConv residual, efficientnet_model.py:286-288), so it needs no launch of
- *      its own.  Tensors of at most mliis_bn_small_rows() rows take a single-launch register-resident path (forward: part == NULL,
- *      nblk == 0 in mliis_bn_apply_fused computes the statistics in the same launch). */
-int mliis_bn_small_rows(void);
+ *      its own. */
 int mliis_bn_bwd(const float* x, int ldx, const float* dy, int lddy, float* dx, int lddx, long long rows, int C, int rows_per_img,
                  const float* mean, const float* rstd, const float* gamma, const float* beta, int pre_swish, int post_swish,
                  const float* img_scale, const float* chan_scale, const float* chan_add, float* dgamma, float* dbeta, float* dskip,

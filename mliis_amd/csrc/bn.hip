@@ -435,169 +435,6 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fused_k(BnBwdCommon p, long 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Small maps (rows <= kSmallRows, i.e. 14x14 maps at batch 8): the whole column of a channel group fits in the registers of one
-// 1024-thread workgroup, so batch norm needs ONE launch and ONE pass over the tensor in each direction: load everything (a single
-// memory round trip), reduce through the wave butterfly + LDS in a fixed order, finish from registers, store.
-// Block = 16 channels (4 float4 lanes) x 256 row lanes, up to kSmallPer rows per thread.
-// ---------------------------------------------------------------------------------------------------------------
-constexpr int kSmallThreads = 1024, kSmallPer = 8, kSmallRows = (kSmallThreads / 4) * kSmallPer;
-
-// sums v[0..NV) over the block's row lanes for each of the 4 quads; result broadcast to every thread (of that quad)
-template <int NV>
-__device__ __forceinline__ void small_block_sum(float4* v, float4 (*sm)[4][NV]) {
-  const int t = threadIdx.x, q = t & 3, wave = t >> 6;
-#pragma unroll
-  for (int k = 0; k < NV; ++k) {
-#pragma unroll
-    for (int off = 4; off < 64; off <<= 1) {
-      v[k].x += __shfl_xor(v[k].x, off);
-      v[k].y += __shfl_xor(v[k].y, off);
-      v[k].z += __shfl_xor(v[k].z, off);
-      v[k].w += __shfl_xor(v[k].w, off);
-    }
-    if ((t & 63) < 4) sm[wave][q][k] = v[k];
-  }
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < NV; ++k) {
-    float4 s4 = sm[0][q][k];
-#pragma unroll
-    for (int w_ = 1; w_ < kSmallThreads / 64; ++w_) s4 = f4add(s4, sm[w_][q][k]);
-    v[k] = s4;
-  }
-}
-
-__global__ __launch_bounds__(kSmallThreads) void bn_bwd_small_k(BnBwdCommon p, int rows, float inv_n, float* __restrict__ dgamma,
-                                                                float* __restrict__ dbeta, float* __restrict__ dx, int lddx,
-                                                                SkipOut skip) {
-  __shared__ float4 sm[kSmallThreads / 64][4][2];
-  const int t = threadIdx.x, q = t & 3, rl = t >> 2;
-  const int c = blockIdx.x * 16 + q * 4;
-  const bool cok = c < p.C;
-  BnBwdCommon::Raw raw[kSmallPer];
-#pragma unroll
-  for (int u = 0; u < kSmallPer; ++u) {
-    const int r = rl + u * (kSmallThreads / 4);
-    if (cok && r < rows) p.load_raw(r, c, raw[u]);
-  }
-  float4 v[2] = {f4zero(), f4zero()};
-#pragma unroll
-  for (int u = 0; u < kSmallPer; ++u) {
-    const int r = rl + u * (kSmallThreads / 4);
-    if (cok && r < rows) {
-      float4 xin, xhat, g;
-      p.finish(r, c, raw[u], xin, xhat, g);
-      v[0] = f4add(v[0], g);
-      v[1] = f4add(v[1], f4mul(g, xhat));
-    }
-  }
-  small_block_sum<2>(v, sm);
-  if (!cok) return;
-  if (rl == 0) {
-    st4(dbeta + c, v[0]);
-    st4(dgamma + c, v[1]);
-  }
-  const float4 a = f4scale(v[0], inv_n), b = f4scale(v[1], inv_n), ga = ld4(p.gamma + c), rs = ld4(p.rstd + c);
-#pragma unroll
-  for (int u = 0; u < kSmallPer; ++u) {
-    const int r = rl + u * (kSmallThreads / 4);
-    if (r >= rows) continue;
-    float4 xin, xhat, g;
-    skip.put(r, c, raw[u].g);
-    p.finish(r, c, raw[u], xin, xhat, g);
-    float4 d;
-    d.x = ga.x * rs.x * (g.x - a.x - xhat.x * b.x);
-    d.y = ga.y * rs.y * (g.y - a.y - xhat.y * b.y);
-    d.z = ga.z * rs.z * (g.z - a.z - xhat.z * b.z);
-    d.w = ga.w * rs.w * (g.w - a.w - xhat.w * b.w);
-    if (p.pre_swish) {
-      d.x *= swish_grad_f(xin.x);
-      d.y *= swish_grad_f(xin.y);
-      d.z *= swish_grad_f(xin.z);
-      d.w *= swish_grad_f(xin.w);
-    }
-    st4(dx + (long long)r * lddx + c, d);
-  }
-}
-
-// forward: statistics + moving averages + normalise in one launch (see bn_apply_fused_k for the semantics of the flags)
-__global__ __launch_bounds__(kSmallThreads) void bn_fwd_small_k(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy,
-                                                                int rows, int C, int rows_per_img, BnFold f,
-                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                                int pre_swish, int post_swish, const float* __restrict__ img_scale,
-                                                                const float* __restrict__ res, int ldr) {
-  __shared__ float4 sm[kSmallThreads / 64][4][2];
-  const int t = threadIdx.x, q = t & 3, rl = t >> 2;
-  const int c = blockIdx.x * 16 + q * 4;
-  const bool cok = c < C;
-  float4 xv[kSmallPer], rv[kSmallPer];
-#pragma unroll
-  for (int u = 0; u < kSmallPer; ++u) {
-    const int r = rl + u * (kSmallThreads / 4);
-    xv[u] = rv[u] = f4zero();
-    if (cok && r < rows) {
-      xv[u] = ld4(x + (long long)r * ldx + c);
-      if (res != nullptr) rv[u] = ld4(res + (long long)r * ldr + c);
-    }
-  }
-  float4 v[2] = {f4zero(), f4zero()};
-#pragma unroll
-  for (int u = 0; u < kSmallPer; ++u) {
-    const int r = rl + u * (kSmallThreads / 4);
-    if (pre_swish) xv[u] = make_float4(swish_f(xv[u].x), swish_f(xv[u].y), swish_f(xv[u].z), swish_f(xv[u].w));
-    if (cok && r < rows) {
-      v[0] = f4add(v[0], xv[u]);
-      v[1] = f4add(v[1], f4mul(xv[u], xv[u]));
-    }
-  }
-  small_block_sum<2>(v, sm);
-  if (!cok) return;
-  float4 m, var, rs;
-  {  // E[x^2] - mean^2 in double (cancellation), like the fold of the multi-block path
-    const double s0[4] = {v[0].x, v[0].y, v[0].z, v[0].w}, s1_[4] = {v[1].x, v[1].y, v[1].z, v[1].w};
-    float mo[4], vo[4], ro[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const double md = s0[e] * f.inv_n;
-      double vd = s1_[e] * f.inv_n - md * md;
-      if (vd < 0.0) vd = 0.0;
-      mo[e] = (float)md;
-      vo[e] = (float)vd;
-      ro[e] = (float)(1.0 / sqrt(vd + (double)f.eps));
-    }
-    m = make_float4(mo[0], mo[1], mo[2], mo[3]);
-    var = make_float4(vo[0], vo[1], vo[2], vo[3]);
-    rs = make_float4(ro[0], ro[1], ro[2], ro[3]);
-  }
-  if (rl == 0) {
-    st4(f.mean + c, m);
-    st4(f.rstd + c, rs);
-    if (f.moving_mean != nullptr) {
-      const float4 mm = ld4(f.moving_mean + c), mv = ld4(f.moving_var + c);
-      const float o = f.one_minus_momentum, e = f.ema_var_factor;
-      st4(f.moving_mean + c, make_float4(mm.x - (mm.x - m.x) * o, mm.y - (mm.y - m.y) * o, mm.z - (mm.z - m.z) * o, mm.w - (mm.w - m.w) * o));
-      st4(f.moving_var + c, make_float4(mv.x - (mv.x - var.x * e) * o, mv.y - (mv.y - var.y * e) * o, mv.z - (mv.z - var.z * e) * o,
-                                        mv.w - (mv.w - var.w * e) * o));
-    }
-  }
-  const float4 g = ld4(gamma + c), b = ld4(beta + c);
-#pragma unroll
-  for (int u = 0; u < kSmallPer; ++u) {
-    const int r = rl + u * (kSmallThreads / 4);
-    if (r >= rows) continue;
-    float4 o;
-    o.x = fmaf((xv[u].x - m.x) * rs.x, g.x, b.x);
-    o.y = fmaf((xv[u].y - m.y) * rs.y, g.y, b.y);
-    o.z = fmaf((xv[u].z - m.z) * rs.z, g.z, b.z);
-    o.w = fmaf((xv[u].w - m.w) * rs.w, g.w, b.w);
-    if (post_swish) o = make_float4(swish_f(o.x), swish_f(o.y), swish_f(o.z), swish_f(o.w));
-    if (img_scale != nullptr) o = f4scale(o, img_scale[r / rows_per_img]);
-    if (res != nullptr) o = f4add(o, rv[u]);
-    st4(y + (long long)r * ldy + c, o);
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
 // Generic sums: out[seg][v][c] = scale * sum_rows f(...)
 // ---------------------------------------------------------------------------------------------------------------
 struct SumOp {  // column sum of a (optionally times b)
@@ -841,12 +678,6 @@ int mliis_bn_bwd(const float* x, int ldx, const float* dy, int lddy, float* dx, 
                 MLIIS_ERR_ALIGN, "bn_bwd: pointers must be 16-byte aligned");
   BnBwdCommon p{x, ldx, dy, lddy, rows_per_img, C, mean, rstd, gamma, beta, pre_swish, post_swish, img_scale, chan_scale, chan_add};
   SkipOut skip{dskip, lddskip, dskip_accumulate};
-  if (rows <= kSmallRows) {
-    hipLaunchKernelGGL(bn_bwd_small_k, dim3(ceil_div(C, 16)), dim3(kSmallThreads), 0, stream, p, (int)rows, (float)(1.0 / (double)rows), dgamma,
-                       dbeta, dx, lddx, skip);
-    MLIIS_CHECK_LAUNCH("bn_bwd_small");
-    return MLIIS_OK;
-  }
   BnBwdOp op{p};
   ColGeom g;
   int rc = launch_colreduce(op, rows, C, 1, ws, ws_floats, stream, &g, "bn_bwd");
@@ -881,10 +712,8 @@ int mliis_bn_apply_fused(const float* x, int ldx, float* y, int ldy, long long r
                          float eps, float momentum, int unbiased_moving_var, float* mean, float* rstd, float* moving_mean,
                          float* moving_var, const float* gamma, const float* beta, int pre_swish, int post_swish, const float* img_scale,
                          const float* res, int ldr, hipStream_t stream) {
-  MLIIS_REQUIRE(x && y && mean && rstd && gamma && beta, MLIIS_ERR_ARG, "bn_apply_fused: null pointer");
-  MLIIS_REQUIRE(part != nullptr || (nblk == 0 && rows <= kSmallRows), MLIIS_ERR_ARG,
-                "bn_apply_fused: statistics partials may only be omitted (part == NULL, nblk == 0) for rows <= %d", kSmallRows);
-  MLIIS_REQUIRE(rows > 1 && rows < (1LL << 31) && (nblk > 0 || part == nullptr) && C > 0 && (C & 3) == 0 && (ldx & 3) == 0 && (ldy & 3) == 0 && ldx >= C && ldy >= C &&
+  MLIIS_REQUIRE(x && y && part && mean && rstd && gamma && beta, MLIIS_ERR_ARG, "bn_apply_fused: null pointer");
+  MLIIS_REQUIRE(rows > 1 && rows < (1LL << 31) && nblk > 0 && C > 0 && (C & 3) == 0 && (ldx & 3) == 0 && (ldy & 3) == 0 && ldx >= C && ldy >= C &&
                     rows_per_img > 0 && (res == nullptr || ((ldr & 3) == 0 && ldr >= C)),
                 MLIIS_ERR_ARG, "bn_apply_fused: bad shape");
   MLIIS_REQUIRE(aligned16(x) && aligned16(y) && aligned16(gamma) && aligned16(beta) && aligned16(res), MLIIS_ERR_ALIGN,
@@ -893,14 +722,6 @@ int mliis_bn_apply_fused(const float* x, int ldx, float* y, int ldy, long long r
   const double n = (double)rows;
   BnFold f{part, nblk, 1.0 / n, eps, (float)(1.0 - (double)momentum), unbiased_moving_var ? (float)(n / (n - 1.0)) : 1.0f, mean, rstd,
            moving_mean, moving_var};
-  if (part == nullptr) {
-    MLIIS_REQUIRE(aligned16(mean) && aligned16(rstd) && aligned16(moving_mean) && aligned16(moving_var), MLIIS_ERR_ALIGN,
-                  "bn_apply_fused: statistics buffers must be 16-byte aligned");
-    hipLaunchKernelGGL(bn_fwd_small_k, dim3(ceil_div(C, 16)), dim3(kSmallThreads), 0, stream, x, ldx, y, ldy, (int)rows, C, rows_per_img, f, gamma,
-                       beta, pre_swish, post_swish, img_scale, res, ldr);
-    MLIIS_CHECK_LAUNCH("bn_fwd_small");
-    return MLIIS_OK;
-  }
   int gx, gy, rpb;
   chan_grid(rows, C, &gx, &gy, &rpb);
   hipLaunchKernelGGL(bn_apply_fused_k, dim3(gx, gy), dim3(256), 0, stream, x, ldx, y, ldy, rows, C, rows_per_img, f, gamma, beta, pre_swish,
@@ -910,7 +731,6 @@ int mliis_bn_apply_fused(const float* x, int ldx, float* y, int ldy, long long r
 }
 
 int mliis_fold_tile_outputs(void) { return kFoldTile; }
-int mliis_bn_small_rows(void) { return kSmallRows; }
 
 int mliis_fold_batched(const float* part_base, float* out_base, const long long* desc, int ndesc, long long total_tiles,
                        hipStream_t stream) {

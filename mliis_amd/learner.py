@@ -169,7 +169,6 @@ class Learner:
         # Optional: weight-gradient GEMMs on a second stream forked inside the HIP graph.  Measured SLOWER on MI355X (4.95 vs 4.56 ms
         # per step, profiles/r01_notes.md): the cross-stream edges cost more than the idle CUs they fill, so it is off by default.
         self.overlap_wgrad = os.environ.get("MLIIS_OVERLAP_WGRAD", "0") == "1"
-        self.bn_small_rows = ops.bn_small_rows()
         self.side_stream = torch.cuda.Stream(device=self.device)
         self.arena = Arena(self.arch, self.device)
         self.arena.init_weights(seed)
@@ -339,13 +338,9 @@ class Learner:
         def bn(xin, st, prefix, y, pre=False, post=False, img_scale=None, res=None, fused=False, nblk=0):
             """nblk > 0: the producing conv already left the stage-1 statistics in P.stats_part."""
             if training:
-                part = P.stats_part
                 if nblk == 0:
-                    if ops.rows_ld(xin)[0] <= self.bn_small_rows:
-                        part = None          # small map: statistics + apply in one register-resident launch
-                    else:
-                        nblk = ops.bn_stats_partial(xin, pre, P.stats_part)
-                return ops.bn_apply_fused(xin, part, nblk, st[0], st[1], w[prefix + "/gamma"], w[prefix + "/beta"],
+                    nblk = ops.bn_stats_partial(xin, pre, P.stats_part)
+                return ops.bn_apply_fused(xin, P.stats_part, nblk, st[0], st[1], w[prefix + "/gamma"], w[prefix + "/beta"],
                                           moving=(mv[prefix + "/moving_mean"], mv[prefix + "/moving_variance"]), unbiased_moving_var=fused,
                                           pre_swish=pre, post_swish=post, img_scale=img_scale, res=res, out=y)
             st[0].copy_(mv[prefix + "/moving_mean"])

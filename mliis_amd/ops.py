@@ -299,13 +299,8 @@ def bn_stats_partial_floats(rows, C_):
     return lib.size("mliis_colreduce_workspace_floats", rows, C_, 1, 2)
 
 
-def bn_small_rows():
-    return lib.raw("mliis_bn_small_rows")()
-
-
 def bn_apply_fused(x, part, nblk, mean, rstd, gamma, beta, moving=None, unbiased_moving_var=False, pre_swish=False, post_swish=False,
                    img_scale=None, res=None, out=None, rows_per_img=None, eps=BN_EPS, momentum=BN_MOMENTUM):
-    """part=None, nblk=0 (tensors of at most bn_small_rows() rows): statistics are computed in the same launch."""
     rows, C_, ldx = rows_ld(x)
     out = torch.empty(x.shape, dtype=torch.float32, device=x.device) if out is None else out
     _, _, ldy = rows_ld(out)
