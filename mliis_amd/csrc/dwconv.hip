@@ -260,10 +260,12 @@ static inline DwFilterGeom dw_filter_geom(int N, int Ho, int Wo, int C, int TW) 
   g.RP = 256 / g.QB;
   g.ny = ceil_div(Q, g.QB);
   long long items = (long long)N * Ho * ((Wo + TW - 1) / TW);
-  long long want = 512 / g.ny;
+  // measured (tools/dwf_sweep.py): the kernel is latency-bound on every EfficientLab layer -- as many blocks as there are strips to
+  // hand out (one strip per thread on the small maps) beats longer per-thread walks by 1.4-2x; the extra slabs go to the batched fold
+  long long want = 1024 / g.ny;
   if (want < 1) want = 1;
   long long ipb = (items + want - 1) / want;
-  long long minr = (long long)g.RP * 4;
+  long long minr = (long long)g.RP;
   if (ipb < minr) ipb = minr;
   ipb = (ipb + g.RP - 1) / g.RP * g.RP;
   g.items_per_block = (int)ipb;
