@@ -9,7 +9,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmliis_hip.so")
+# MLIIS_HIP_LIB: path of an alternative build of the library (kernel experiments); the default is the in-tree build
+_DEFAULT_LIB = os.path.join(_HERE, "libmliis_hip.so")
+LIB_PATH = os.environ.get("MLIIS_HIP_LIB", _DEFAULT_LIB)
 
 _f = C.c_float
 _i = C.c_int

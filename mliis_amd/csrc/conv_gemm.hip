@@ -24,6 +24,10 @@
 
 #include <type_traits>
 
+#ifndef MLIIS_GEMM_EXP
+#define MLIIS_GEMM_EXP 0   // timing experiments only (1: no barrier, 2: no global loads, 3: no LDS stores) -- results are wrong
+#endif
+
 #include "common.hpp"
 
 namespace mliis {
@@ -365,15 +369,17 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_nk_k(ConvGemmParams p) {
   constexpr int LDS_STAGE = BN + 4;             // epilogue staging row stride (floats)
   constexpr int STAGE_FLOATS = 4 * 16 * LDS_STAGE;
   constexpr int SM_FLOATS = (2 * BUF_FLOATS) > STAGE_FLOATS ? (2 * BUF_FLOATS) : STAGE_FLOATS;
-  __shared__ __attribute__((aligned(16))) float sm[SM_FLOATS];
+  constexpr int kDummy = SM_FLOATS;   // 16-byte scratch slot behind the buffers
+  __shared__ __attribute__((aligned(16))) float sm[SM_FLOATS + 4];
 
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
   const int l15 = lane & 15, g = lane >> 4;
   const long long M = (long long)p.Nimg * p.H * p.W;
   const int n0 = blockIdx.y * BN;
-  const int cpc = (p.C + BK - 1) / BK;  // chunks per tap
-  const int nchunks_total = p.ntaps * cpc;
+  // K is the flattened (tap, channel) index cut into chunks of 32: chunks may straddle taps (every thread tracks the tap / channel of
+  // ITS k quad), so only the very last chunk carries padding and every chunk is a full 2 x 4 x NT MFMA block -- no per-chunk branch.
+  const int nchunks_total = (p.ntaps * p.C + BK - 1) / BK;
   const int it0 = blockIdx.z * p.chunks_per_split;
   int it1 = it0 + p.chunks_per_split;
   if (it1 > nchunks_total) it1 = nchunks_total;
@@ -407,8 +413,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_nk_k(ConvGemmParams p) {
       const int rem = (int)(m - (long long)n * HWp);
       a_h[i] = rem / p.W;
       a_w[i] = rem - a_h[i] * p.W;
-      a_off[i] = (unsigned)((m * p.lda + kq * 4) * 4);
-      s_off[i] = (unsigned)(((long long)n * p.C + kq * 4) * 4);
+      a_off[i] = (unsigned)(m * p.lda * 4);
+      s_off[i] = (unsigned)((long long)n * p.C * 4);
     }
   }
   unsigned b_off[B_PER_THREAD];
@@ -418,40 +424,45 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_nk_k(ConvGemmParams p) {
     const int idx = t + 256 * i;
     const int n = idx >> 3;
     b_ok[i] = (idx < B_TOTAL) && (n0 + n < p.Nout);
-    b_off[i] = (unsigned)(((long long)(n0 + n) * p.ldb + kq * 4) * 4);
+    b_off[i] = (unsigned)((long long)(n0 + n) * p.ldb * 4);
   }
 
-  // ---- uniform state (scalar registers): (tap, c0) of the next chunk to LOAD, c0 of the chunk being COMPUTED
-  int tap = it0 / cpc;
-  int c0 = (it0 - tap * cpc) * BK;
-  int c0_cur = c0;
+  // ---- (tap, channel) of this thread's k quad in the next chunk to LOAD
+  int k_tap, k_c, k_th = 1, k_tw = 1;   // 1x1 convs: tap row / column stay at the centre (dh = dw = 0) for every in-range chunk
+  {
+    const int kabs = it0 * BK + kq * 4;
+    k_tap = kabs / p.C;
+    k_c = kabs - k_tap * p.C;
+    if (p.ntaps > 1) {
+      k_th = k_tap / 3;
+      k_tw = k_tap - k_th * 3;
+    }
+  }
   float4 ra[PF][A_PER_THREAD], rs[PF][A_PER_THREAD], rb[PF][B_PER_THREAD];
 
-  // chunk (tap, c0) -> registers, then advance.  Branch-free (live == false turns every offset out of range: no memory traffic,
-  // zeros come back) so the compiler knows exactly how many loads are in flight and waits only for the older chunk.
+  // next chunk -> registers, then advance.  Branch-free (live == false turns every offset out of range: no memory traffic, zeros
+  // come back) so the compiler knows exactly how many loads are in flight and waits only for the older chunk.
   auto load_chunk = [&](float4* ra_, float4* rs_, float4* rb_, bool live) {
-    int dh = 0, dw = 0;
-    if (p.ntaps > 1) {
-      const int th = tap / 3;
-      dh = (th - 1) * p.dil * p.sign;
-      dw = (tap - th * 3 - 1) * p.dil * p.sign;
-    }
-    const bool kok = live & (c0 + kq * 4 < p.C);
-    const unsigned da = (unsigned)(((dh * p.W + dw) * p.lda + c0) * 4);
+    const int dh = (k_th - 1) * p.dil * p.sign, dw = (k_tw - 1) * p.dil * p.sign;
+    const bool kok = live & (k_tap < p.ntaps);
+    const unsigned da = (unsigned)(((dh * p.W + dw) * p.lda + k_c) * 4);
 #pragma unroll
     for (int i = 0; i < A_PER_THREAD; ++i) {
       const bool ok = kok & ((unsigned)(a_h[i] + dh) < (unsigned)p.H) & ((unsigned)(a_w[i] + dw) < (unsigned)p.W);
       ra_[i] = buf_ld4(rA, ok ? a_off[i] + da : kOob);
-      if (SC) rs_[i] = buf_ld4(rS, ok ? s_off[i] + (unsigned)(c0 * 4) : kOob);
+      if (SC) rs_[i] = buf_ld4(rS, ok ? s_off[i] + (unsigned)(k_c * 4) : kOob);
     }
-    const unsigned db = (unsigned)(((long long)tap * p.b_tap_stride + c0) * 4);
+    const unsigned db = (unsigned)(((long long)k_tap * p.b_tap_stride + k_c) * 4);
 #pragma unroll
     for (int i = 0; i < B_PER_THREAD; ++i) rb_[i] = buf_ld4(rB, (kok & b_ok[i]) ? b_off[i] + db : kOob);
-    c0 += BK;
-    if (c0 >= p.C) {
-      c0 = 0;
-      ++tap;
-    }
+    k_c += BK;
+    const bool wrap = k_c >= p.C;   // C >= 32 whenever there is more than one tap, so one wrap per chunk at most
+    k_c = wrap ? k_c - p.C : k_c;
+    k_tap += wrap ? 1 : 0;
+    k_tw += wrap ? 1 : 0;   // (a 1x1 conv wraps only into out-of-range taps, where the offsets are ignored)
+    const bool roll = k_tw == 3;
+    k_tw = roll ? 0 : k_tw;
+    k_th += roll ? 1 : 0;
   };
   auto store_chunk = [&](float* buf, const float4* ra_, const float4* rs_, const float4* rb_) {
     float* smA = buf;
@@ -466,7 +477,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_nk_k(ConvGemmParams p) {
 #pragma unroll
     for (int i = 0; i < B_PER_THREAD; ++i) {
       const int idx = t + 256 * i;
-      if (idx < B_TOTAL) st4(smB + (kq * BN + ((idx >> 3) ^ kq)) * 4, rb_[i]);
+      if (256 * (i + 1) <= B_TOTAL) st4(smB + (kq * BN + ((idx >> 3) ^ kq)) * 4, rb_[i]);
+      else st4(idx < B_TOTAL ? smB + (kq * BN + ((idx >> 3) ^ kq)) * 4 : sm + kDummy, rb_[i]);   // surplus lanes: a scratch slot, no branch
     }
   };
 
@@ -489,11 +501,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_nk_k(ConvGemmParams p) {
   auto step = [&](auto UC, int j) {
     constexpr int U = decltype(UC)::value;
     constexpr int NX = (U + 1) % PF;
-    // the second 16-wide k group of a chunk is all zero padding when the channel count ends inside the first one
-    const bool two = c0_cur + 16 < p.C;
-    c0_cur += BK;
-    if (c0_cur >= p.C) c0_cur = 0;
+#if MLIIS_GEMM_EXP != 2
     load_chunk(ra[U], rs[U], rb[U], j + PF < it1);
+#endif
     const float* smA = sm + cur * BUF_FLOATS;
     const float* smB = smA + A_FLOATS;
     constexpr bool kAllFirst = TM == 1;   // read the fragments of both k groups before the first MFMA (register budget permitting)
@@ -521,20 +531,22 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_nk_k(ConvGemmParams p) {
     };
     if (kAllFirst) {
       read_frags(0);
-      if (two) read_frags(1);
+      read_frags(1);
       multiply(0);
-      if (two) multiply(1);
+      multiply(1);
     } else {
       read_frags(0);
       multiply(0);
-      if (two) {
-        read_frags(0 + 1);
-        multiply(1);
-      }
+      read_frags(1);
+      multiply(1);
     }
+#if MLIIS_GEMM_EXP != 3
     store_chunk(sm + (cur ^ 1) * BUF_FLOATS, ra[NX], rs[NX], rb[NX]);   // zeros after the last chunk: nobody reads them
+#endif
     cur ^= 1;
+#if MLIIS_GEMM_EXP != 1
     __syncthreads();
+#endif
   };
   typedef std::integral_constant<int, 0> U0;
   typedef std::integral_constant<int, 1 % PF> U1;
@@ -1094,7 +1106,7 @@ static inline int pick_nt(int Nout) {
   return nt < 1 ? 1 : nt;
 }
 
-static inline GemmPlan plan_gemm(long long M, int Nout, int C, int ntaps, int num_cus, int allow_split) {
+static inline GemmPlan plan_gemm(long long M, int Nout, int C, int ntaps, int num_cus, int allow_split, bool flat_k) {
   GemmPlan g;
   g.nt = pick_nt(Nout);
   g.gy = (Nout + g.nt * 16 - 1) / (g.nt * 16);
@@ -1110,7 +1122,8 @@ static inline GemmPlan plan_gemm(long long M, int Nout, int C, int ntaps, int nu
   // very tall, HBM-bound layers (112x112 maps): 128-row blocks halve the number of BN-statistics partials the consumer folds
   if ((M + 63) / 64 > 4LL * num_cus && g.tm == 1) g.tm = 2;
   g.gx = (int)((M + 64 * g.tm - 1) / (64 * g.tm));
-  int nchunks = ntaps * ((C + 31) / 32);
+  // K chunks of 32: per tap (first-generation kernels) or over the flattened (tap, channel) index (conv_gemm_nk_k)
+  int nchunks = flat_k ? (ntaps * C + 31) / 32 : ntaps * ((C + 31) / 32);
   g.gz = 1;
   if (allow_split) {
     long long blocks = (long long)g.gx * g.gy;
@@ -1131,10 +1144,13 @@ static inline bool gemm_v1() {   // tuning switch (experiments only): MLIIS_GEMM
   return v == 1;
 }
 
+// second-generation kernel (flattened-K chunks): K-contiguous B operand, and at most one tap wrap per 32-channel chunk
+static inline bool use_nk2(bool b_nk, int ntaps, int C) { return b_nk && !gemm_v1() && (ntaps == 1 || C >= 32); }
+
 template <bool B_NK>
 static void launch_gemm(const GemmPlan& g, const ConvGemmParams& p, hipStream_t stream) {
   dim3 grid(g.gx, g.gy, g.gz), block(256);
-  const bool v2 = B_NK && !gemm_v1();
+  const bool v2 = use_nk2(B_NK, p.ntaps, p.C);
 #define L(TM_, NT_)                                                                               \
   if (v2 && p.a_scale) hipLaunchKernelGGL((conv_gemm_nk_k<TM_, NT_, (TM_ == 1 ? 2 : 1), true>), grid, block, 0, stream, p); \
   else if (v2) hipLaunchKernelGGL((conv_gemm_nk_k<TM_, NT_, (TM_ == 1 ? 2 : 1), false>), grid, block, 0, stream, p); \
@@ -1249,7 +1265,7 @@ extern "C" {
 // conv_gemm_k<tm, nt, B_NK> and its split-K factor).
 int mliis_conv2d_plan(int Nimg, int H, int W, int Cred, int Nout, int ksize, int* tm, int* nt, int* splits) {
   MLIIS_REQUIRE(tm && nt && splits, MLIIS_ERR_ARG, "conv2d_plan: null pointer");
-  GemmPlan g = plan_gemm((long long)Nimg * H * W, Nout, Cred, ksize * ksize, num_cus(), 1);
+  GemmPlan g = plan_gemm((long long)Nimg * H * W, Nout, Cred, ksize * ksize, num_cus(), 1, use_nk2(true, ksize * ksize, Cred));
   *tm = g.tm;
   *nt = g.nt;
   *splits = g.gz;
@@ -1259,8 +1275,9 @@ int mliis_conv2d_plan(int Nimg, int H, int W, int Cred, int Nout, int ksize, int
 // Workspace (floats) that conv2d_fwd / conv2d_bwd_data may need for split-K partials.
 size_t mliis_conv2d_workspace_floats(int Nimg, int H, int W, int Cred, int Nout, int ksize) {
   long long M = (long long)Nimg * H * W;
-  GemmPlan g = plan_gemm(M, Nout, Cred, ksize * ksize, num_cus(), 1);
-  return g.gz > 1 ? (size_t)g.gz * M * Nout : 0;
+  const GemmPlan g = plan_gemm(M, Nout, Cred, ksize * ksize, num_cus(), 1, true), h = plan_gemm(M, Nout, Cred, ksize * ksize, num_cus(), 1, false);
+  const int gz = g.gz > h.gz ? g.gz : h.gz;   // either K-chunk counting (second / first generation kernel) must fit
+  return gz > 1 ? (size_t)gz * M * Nout : 0;
 }
 
 // y[M, Cout] (ld = ldy) (+)= conv(x[M, Cin] (ld = ldx), w[k,k,Cin,Cout]) + bias ; stride 1, TF-SAME, dilation dil
@@ -1278,7 +1295,7 @@ int mliis_conv2d_fwd(const float* x, int ldx, const float* x_scale, const float*
   long long M = (long long)Nimg * H * W;
   MLIIS_REQUIRE(M * ldx * 4 < (1LL << 31) && (long long)ksize * ksize * Cin_total * Cout * 4 < (1LL << 31), MLIIS_ERR_UNSUPPORTED,
                 "conv2d_fwd: operand larger than 2 GiB (32-bit buffer offsets)");
-  GemmPlan g = plan_gemm(M, Cout, Cin, ksize * ksize, num_cus(), ws != nullptr);
+  GemmPlan g = plan_gemm(M, Cout, Cin, ksize * ksize, num_cus(), ws != nullptr, use_nk2(wt != nullptr, ksize * ksize, Cin));
   MLIIS_REQUIRE(ci_begin >= 0 && (ci_begin & 3) == 0 && ci_begin + Cin <= Cin_total, MLIIS_ERR_ARG,
                 "conv2d_fwd: input-channel window out of range");
   MLIIS_REQUIRE(border_bias == nullptr || (ksize == 3 && dil == 1 && H >= 2 && W >= 2 && aligned16(border_bias)), MLIIS_ERR_ARG,
@@ -1342,7 +1359,7 @@ int mliis_conv2d_bwd_data(const float* dy, int lddy, const float* w, float* dx, 
   long long M = (long long)Nimg * H * W;
   MLIIS_REQUIRE(M * lddy * 4 < (1LL << 31) && (long long)ksize * ksize * Cin_total * Cout * 4 < (1LL << 31), MLIIS_ERR_UNSUPPORTED,
                 "conv2d_bwd_data: operand larger than 2 GiB (32-bit buffer offsets)");
-  GemmPlan g = plan_gemm(M, Cin_out, Cout, ksize * ksize, num_cus(), ws != nullptr);
+  GemmPlan g = plan_gemm(M, Cin_out, Cout, ksize * ksize, num_cus(), ws != nullptr, use_nk2(true, ksize * ksize, Cout));
   ConvGemmParams p{dy, lddy, Nimg, H, W, Cout, ksize * ksize, dil, -1, w + (long long)ci_begin * Cout, (long long)Cin_total * Cout,
                    Cout, Cin_out, dx, lddx, nullptr, accumulate, nullptr, g.chunks_per_split, nullptr, 0, nullptr, nullptr};
   if (g.gz > 1) {
