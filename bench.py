@@ -117,14 +117,14 @@ def roofline(L, args):
         d["n"] += 1
         d["flops"] += r.get("flops", 0.0)
         d["bytes"] += r.get("bytes", 0.0)
-    gemm = {k: v for k, v in by.items() if k.startswith("conv_gemm_k")}
+    gemm = {k: v for k, v in by.items() if k.startswith("conv_gemm")}
     dom = max(gemm, key=lambda k: gemm[k]["ms"])
     d = gemm[dom]
     ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
     traffic, tsrc = None, None
     tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
     if os.path.exists(tpath):   # PMC counters cannot be sampled from inside this process: taken from the committed rocprofv3 --pmc passes
-        k = json.load(open(tpath)).get("kernels", {}).get(dom.replace(" ", ""))
+        k = json.load(open(tpath)).get("kernels", {}).get(dom.replace(", ", ","))
         if k:
             traffic, tsrc = k["hbm_bytes_per_launch"], "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950-corrected)"
     out = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TFLOPS,

@@ -62,8 +62,11 @@ int mliis_dwconv_bwd_filter(const float* x, const float* dy, float* dw, int N, i
  *      ASPP (models/efficientlab.py:185-190,218-224,258-283).  w is TF HWIO [k,k,Cin,Cout].  `accumulate` != 0 adds into the
  *      destination.  ws may be NULL (disables split-K). */
 size_t mliis_conv2d_workspace_floats(int Nimg, int H, int W, int Cred, int Nout, int ksize);
-/*      tiling chosen for a fwd / bwd-data call: kernel instantiation conv_gemm_k<tm, nt, .> and split-K factor (profiling aid) */
+/*      tiling chosen for a fwd / bwd-data call (row-tile factor, column tiles, split-K factor) and the name of the kernel
+ *      instantiation it launches, as rocprofv3 prints it (profiling aids: bench.py matches its live timings to the trace) */
 int mliis_conv2d_plan(int Nimg, int H, int W, int Cred, int Nout, int ksize, int* tm, int* nt, int* splits);
+int mliis_conv2d_kernel_name(int Nimg, int H, int W, int Cred, int Nout, int ksize, int k_contiguous_b, int has_scale, char* buf,
+                             size_t buf_len);
 /*      stats_part (nullable): the epilogue also emits the following batch norm's stage-1 statistics -- per row-block column sums
  *      {sum v, sum v^2} (of swish(v) when stats_swish) as [*stats_nblk][2][Cout], written by the GEMM epilogue or, on a split-K
  *      plan, by the slab fold.  *stats_nblk == 0 means "not produced": the caller must run mliis_bn_stats_partial instead.

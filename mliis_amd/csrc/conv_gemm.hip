@@ -1272,6 +1272,18 @@ int mliis_conv2d_plan(int Nimg, int H, int W, int Cred, int Nout, int ksize, int
   return MLIIS_OK;
 }
 
+// Name of the kernel instantiation (as rocprofv3 prints it, without the mliis:: prefix and argument list) that a conv2d_fwd
+// (k_contiguous_b = a wt operand is given) / conv2d_bwd_data (k_contiguous_b = 1) call with these shapes launches.
+int mliis_conv2d_kernel_name(int Nimg, int H, int W, int Cred, int Nout, int ksize, int k_contiguous_b, int has_scale, char* buf,
+                             size_t buf_len) {
+  MLIIS_REQUIRE(buf && buf_len >= 48, MLIIS_ERR_ARG, "conv2d_kernel_name: buffer too small");
+  const bool v2 = use_nk2(k_contiguous_b != 0, ksize * ksize, Cred);
+  GemmPlan g = plan_gemm((long long)Nimg * H * W, Nout, Cred, ksize * ksize, num_cus(), 1, v2);
+  if (v2) snprintf(buf, buf_len, "conv_gemm_nk_k<%d, %d, %d, %s>", g.tm, g.nt, g.tm == 1 ? 2 : 1, has_scale ? "true" : "false");
+  else snprintf(buf, buf_len, "conv_gemm_k<%d, %d, %s>", g.tm, g.nt, k_contiguous_b ? "true" : "false");
+  return MLIIS_OK;
+}
+
 // Workspace (floats) that conv2d_fwd / conv2d_bwd_data may need for split-K partials.
 size_t mliis_conv2d_workspace_floats(int Nimg, int H, int W, int Cred, int Nout, int ksize) {
   long long M = (long long)Nimg * H * W;

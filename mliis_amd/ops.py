@@ -62,6 +62,12 @@ def profile_resolve(records):
     return records
 
 
+def conv2d_kernel_name(N, H, W, cred, nout, k, k_contiguous_b=True, has_scale=False):
+    buf = C.create_string_buffer(64)
+    lib.call("mliis_conv2d_kernel_name", N, H, W, cred, nout, k, int(k_contiguous_b), int(has_scale), C.cast(buf, C.c_void_p), 64)
+    return buf.value.decode()
+
+
 def conv2d_plan(N, H, W, cred, nout, k):
     tm, nt, sp = C.c_int(), C.c_int(), C.c_int()
     lib.call("mliis_conv2d_plan", N, H, W, cred, nout, k, C.byref(tm), C.byref(nt), C.byref(sp))
@@ -192,7 +198,7 @@ def conv2d_fwd(x, w, bias=None, dil=1, out=None, accumulate=False, ws: Optional[
     meta = {}
     if PROFILE is not None:
         tm, nt, sp = conv2d_plan(N, H, W, Cin, Cout, k)
-        meta = dict(kernel="conv_gemm_k<%d,%d,%s>" % (tm, nt, "true" if wt is not None else "false"), splits=sp,
+        meta = dict(kernel=conv2d_kernel_name(N, H, W, Cin, Cout, k, wt is not None, x_scale is not None), splits=sp,
                     flops=2.0 * N * H * W * k * k * Cin * Cout, shape=(N, H, W, Cin, Cout, k, dil))
     nblk = C.c_int(0)
     if stats_part is not None and stats_part.numel() < (-(-N * H * W // 64)) * 2 * Cout:
@@ -220,7 +226,7 @@ def conv2d_bwd_data(dy, w, dil=1, ci_begin=0, ci_count=None, out=None, accumulat
     meta = {}
     if PROFILE is not None:
         tm, nt, sp = conv2d_plan(N, H, W, Cout, ci_count, k)
-        meta = dict(kernel="conv_gemm_k<%d,%d,true>" % (tm, nt), splits=sp, flops=2.0 * N * H * W * k * k * ci_count * Cout,
+        meta = dict(kernel=conv2d_kernel_name(N, H, W, Cout, ci_count, k), splits=sp, flops=2.0 * N * H * W * k * k * ci_count * Cout,
                     shape=(N, H, W, ci_count, Cout, k, dil))
     _timed("conv2d_bwd_data", meta, lambda: lib.call("mliis_conv2d_bwd_data", _ptr(dy), lddy, _ptr(w), _ptr(out), lddx, N, H, W, Cin, ci_begin,
                                                      ci_count, Cout, k, dil, int(accumulate), _ptr(buf), buf.numel(), _stream()))
