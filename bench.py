@@ -105,7 +105,7 @@ def roofline(L, args):
     by = {}
     for r in recs:
         if r["op"] in ("conv2d_fwd", "conv2d_bwd_data") and r.get("splits", 1) == 1:
-            k = r["kernel"]
+            k = r["kernel"]      # exact instantiation name; split-K launches are a different instantiation (their op time includes the fold)
         elif r["op"] == "conv2d_bwd_filter":
             k = "conv_filter_grad_k(+reduce)"
         elif r["op"].startswith("dwconv"):

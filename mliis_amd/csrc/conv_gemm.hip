@@ -357,7 +357,7 @@ __device__ __forceinline__ float4 buf_ld4(__amdgpu_buffer_rsrc_t r, unsigned byt
   return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 
-template <int TM, int NT, int PF, bool SC>
+template <int TM, int NT, int PF, bool SC, bool SPLIT>
 __global__ __launch_bounds__(256, 2) void conv_gemm_nk_k(ConvGemmParams p) {
   constexpr int BM = 64 * TM, BN = 16 * NT, BK = 32;
   constexpr int A_FLOATS = 8 * BM * 4;
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_nk_k(ConvGemmParams p) {
   int it1 = it0 + p.chunks_per_split;
   if (it1 > nchunks_total) it1 = nchunks_total;
 
-  const bool split = p.partial != nullptr;
+  constexpr bool split = SPLIT;   // split-K instance: raw partial tiles [z][M][Nout], the fold kernel finishes them
   const bool stats = (p.stats_part != nullptr) && !split;
   float s1[NT], s2[NT];
 #pragma unroll
@@ -1125,7 +1125,7 @@ static inline GemmPlan plan_gemm(long long M, int Nout, int C, int ntaps, int nu
   // K chunks of 32: per tap (first-generation kernels) or over the flattened (tap, channel) index (conv_gemm_nk_k)
   int nchunks = flat_k ? (ntaps * C + 31) / 32 : ntaps * ((C + 31) / 32);
   g.gz = 1;
-  if (allow_split) {
+  if (allow_split && g.tm == 1) {   // (128-row tiles are only chosen for grids that fill the chip many times over)
     long long blocks = (long long)g.gx * g.gy;
     // split K when the grid cannot fill the chip and there is enough K to amortise the extra pass
     while (blocks * g.gz * 2 <= num_cus && nchunks / (g.gz * 2) >= 3 && g.gz < 16) g.gz *= 2;
@@ -1151,10 +1151,16 @@ template <bool B_NK>
 static void launch_gemm(const GemmPlan& g, const ConvGemmParams& p, hipStream_t stream) {
   dim3 grid(g.gx, g.gy, g.gz), block(256);
   const bool v2 = use_nk2(B_NK, p.ntaps, p.C);
+#define NK(TM_, NT_, SC_, SP_) hipLaunchKernelGGL((conv_gemm_nk_k<TM_, NT_, (TM_ == 1 ? 2 : 1), SC_, SP_>), grid, block, 0, stream, p)
 #define L(TM_, NT_)                                                                               \
-  if (v2 && p.a_scale) hipLaunchKernelGGL((conv_gemm_nk_k<TM_, NT_, (TM_ == 1 ? 2 : 1), true>), grid, block, 0, stream, p); \
-  else if (v2) hipLaunchKernelGGL((conv_gemm_nk_k<TM_, NT_, (TM_ == 1 ? 2 : 1), false>), grid, block, 0, stream, p); \
-  else hipLaunchKernelGGL((conv_gemm_k<TM_, NT_, B_NK>), grid, block, 0, stream, p);              \
+  if (v2) {                                                                                       \
+    const bool sp = p.partial != nullptr;                                                         \
+    if (TM_ == 1 && sp) {                                                                         \
+      if (p.a_scale) NK(1, NT_, true, true);                                                      \
+      else NK(1, NT_, false, true);                                                               \
+    } else if (p.a_scale) NK(TM_, NT_, true, false);                                              \
+    else NK(TM_, NT_, false, false);                                                              \
+  } else hipLaunchKernelGGL((conv_gemm_k<TM_, NT_, B_NK>), grid, block, 0, stream, p);            \
   break;
 #define ROW(TM_)       \
   switch (g.nt) {      \
@@ -1174,6 +1180,7 @@ static void launch_gemm(const GemmPlan& g, const ConvGemmParams& p, hipStream_t 
   }
 #undef ROW
 #undef L
+#undef NK
 }
 
 struct FilterPlan {
@@ -1279,7 +1286,9 @@ int mliis_conv2d_kernel_name(int Nimg, int H, int W, int Cred, int Nout, int ksi
   MLIIS_REQUIRE(buf && buf_len >= 48, MLIIS_ERR_ARG, "conv2d_kernel_name: buffer too small");
   const bool v2 = use_nk2(k_contiguous_b != 0, ksize * ksize, Cred);
   GemmPlan g = plan_gemm((long long)Nimg * H * W, Nout, Cred, ksize * ksize, num_cus(), 1, v2);
-  if (v2) snprintf(buf, buf_len, "conv_gemm_nk_k<%d, %d, %d, %s>", g.tm, g.nt, g.tm == 1 ? 2 : 1, has_scale ? "true" : "false");
+  if (v2)
+    snprintf(buf, buf_len, "conv_gemm_nk_k<%d, %d, %d, %s, %s>", g.tm, g.nt, g.tm == 1 ? 2 : 1, has_scale ? "true" : "false",
+             g.gz > 1 ? "true" : "false");
   else snprintf(buf, buf_len, "conv_gemm_k<%d, %d, %s>", g.tm, g.nt, k_contiguous_b ? "true" : "false");
   return MLIIS_OK;
 }

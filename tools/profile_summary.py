@@ -1,7 +1,7 @@
 """Summarises a rocprofv3 --kernel-trace --stats run of `bench.py` (csv output) into a markdown report: per-family time per inner
 step, the top kernels, and the per-layer depthwise table against the HBM roofline (algorithmic bytes of SURVEY.md 8(d)).
 
-    python tools/profile_summary.py <dir with *_kernel_stats.csv / *_kernel_trace.csv> <inner steps profiled> <out.md>
+    python tools/profile_summary.py <dir with *_kernel_stats.csv / *_kernel_trace.csv> <inner steps profiled, 0 = count them> <out.md>
 """
 import collections
 import csv
@@ -39,6 +39,8 @@ def family(n):
 def main():
     d, steps, out = sys.argv[1], int(sys.argv[2]), sys.argv[3]
     stats = list(csv.DictReader(open(glob.glob(os.path.join(d, "**", "*_kernel_stats.csv"), recursive=True)[0])))
+    if steps <= 0:   # one optimizer launch per inner step
+        steps = sum(int(r["Calls"]) for r in stats if "sgd_k" in r["Name"] or "adam_b1zero_k" in r["Name"])
     trace = list(csv.DictReader(open(glob.glob(os.path.join(d, "**", "*_kernel_trace.csv"), recursive=True)[0])))
     tot = sum(float(r["TotalDurationNs"]) for r in stats) / 1e3 / steps
     nl = sum(int(r["Calls"]) for r in stats) / steps
