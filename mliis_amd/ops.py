@@ -37,7 +37,7 @@ def _chk(t: torch.Tensor, dtype=torch.float32):
 
 
 # ---- optional per-call timing (bench.py / tools): PROFILE = [] enables it; every wrapped call appends
-#      {"op", "ms", **meta} with HIP events recorded on the stream the kernels are launched on.
+#      {"op", "ms", "fn", **meta} with HIP events recorded on the stream the kernels are launched on ("fn" re-issues the launch).
 PROFILE = None
 
 
@@ -49,7 +49,7 @@ def _timed(op, meta, fn):
     s.record(st)
     r = fn()
     e.record(st)
-    PROFILE.append(dict(op=op, ev=(s, e), **meta))
+    PROFILE.append(dict(op=op, ev=(s, e), fn=fn, **meta))
     return r
 
 
