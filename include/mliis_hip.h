@@ -50,7 +50,10 @@ int mliis_stem_conv_bwd_filter(const float* x, const int* img_idx, const float* 
 /* ---- depthwise k x k (k 3|5, stride 1|2, TF-SAME, no bias): keras DepthwiseConv2D
  *      (models/efficientnet/efficientnet_model.py:190-196,271; utils.py:219-222).  H, W are the INPUT size in all three;
  *      w / dw are [k,k,C] (TF [k,k,C,1]). */
-int mliis_dwconv_fwd(const float* x, const float* w, float* y, int N, int H, int W, int C, int k, int stride, hipStream_t stream);
+/*      stats_part (nullable): also emit the following batch norm's stage-1 statistics {sum y, sum y^2} as [*stats_nblk][2][C]
+ *      (same contract as mliis_conv2d_fwd; needs ceil(N*Ho*ceil(Wo/4) / 32) * 2 * C floats) */
+int mliis_dwconv_fwd(const float* x, const float* w, float* y, int N, int H, int W, int C, int k, int stride, float* stats_part,
+                     size_t stats_floats, int* stats_nblk, hipStream_t stream);
 int mliis_dwconv_bwd_data(const float* dy, const float* w, float* dx, int N, int H, int W, int C, int k, int stride,
                           hipStream_t stream);
 size_t mliis_dwconv_bwd_filter_workspace_floats(int N, int H, int W, int C, int k, int stride);

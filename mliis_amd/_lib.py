@@ -26,7 +26,7 @@ SIGNATURES = {
     "mliis_stem_conv_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p]),
     "mliis_stem_conv_bwd_filter_workspace_floats": (_sz, [_i, _i, _i, _i]),
     "mliis_stem_conv_bwd_filter": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _sz, _p]),
-    "mliis_dwconv_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "mliis_dwconv_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _sz, _p, _p]),
     "mliis_dwconv_bwd_data": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "mliis_dwconv_bwd_filter_workspace_floats": (_sz, [_i, _i, _i, _i, _i, _i]),
     "mliis_dwconv_bwd_filter": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _sz, _p]),

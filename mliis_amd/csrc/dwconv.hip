@@ -84,6 +84,104 @@ __global__ __launch_bounds__(256) void dwconv_fwd_k(const float* __restrict__ x,
     if (wo0 + t < Wo) st4(yrow + (long long)(wo0 + t) * C, acc[t]);
 }
 
+// Forward + the following batch norm's stage-1 statistics (training): grid = (strip blocks, channel groups of 32), 256 threads =
+// 8 channel quads x 32 strips, so the strips of a block share their 32 channels and their {sum y, sum y^2} are folded in the block
+// (lane butterfly, then the 4 waves through LDS in a fixed order) into stats_part [strip block][2][C] -- the statistics pass over
+// the depthwise output and its launch disappear.
+template <int K, int S, int TW>
+__global__ __launch_bounds__(256) void dwconv_fwd_stats_k(const float* __restrict__ x, const float* __restrict__ w,
+                                                          float* __restrict__ y, int N, int Hi, int Wi, int Ho, int Wo, int C, int pt,
+                                                          int pl, float* __restrict__ stats_part) {
+  constexpr int IW = (TW - 1) * S + K;
+  __shared__ float4 sm[2][4][8];
+  const int t = threadIdx.x, q = t & 7, sl = t >> 3;
+  const int strips = (Wo + TW - 1) / TW;
+  const unsigned total = (unsigned)N * Ho * strips;
+  const unsigned bx = xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned item = bx * 32u + sl;
+  const int c = blockIdx.y * 32 + q * 4;
+  const bool active = (item < total) && (c < C);
+  float4 s1 = f4zero(), s2 = f4zero();
+  if (active) {
+    const int sx = (int)(item % (unsigned)strips);
+    const unsigned r = item / (unsigned)strips;
+    const int ho = (int)(r % (unsigned)Ho);
+    const int n = (int)(r / (unsigned)Ho);
+    const int wo0 = sx * TW;
+    const int hi0 = ho * S - pt, wi0 = wo0 * S - pl;
+    float4 acc[TW];
+#pragma unroll
+    for (int j = 0; j < TW; ++j) acc[j] = f4zero();
+    if constexpr (K == 5) {   // whole window first: one memory round trip (see dwconv_fwd_k)
+      float4 in[K][IW];
+#pragma unroll
+      for (int ky = 0; ky < K; ++ky) {
+        const int hi = hi0 + ky;
+        const bool rok = (hi >= 0) && (hi < Hi);
+        const float* xrow = x + ((long long)(n * Hi + (rok ? hi : 0)) * Wi) * C + c;
+#pragma unroll
+        for (int j = 0; j < IW; ++j) {
+          const int wi = wi0 + j;
+          const bool ok = rok && (wi >= 0) && (wi < Wi);
+          const float4 v = ld4(ok ? xrow + (long long)wi * C : x + c);
+          in[ky][j] = ok ? v : f4zero();
+        }
+      }
+#pragma unroll
+      for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) {
+          const float4 wv = ld4(w + (ky * K + kx) * C + c);
+#pragma unroll
+          for (int j = 0; j < TW; ++j) acc[j] = f4fma(in[ky][j * S + kx], wv, acc[j]);
+        }
+    } else {
+#pragma unroll
+      for (int ky = 0; ky < K; ++ky) {
+        const int hi = hi0 + ky;
+        if (hi < 0 || hi >= Hi) continue;
+        const float* xrow = x + ((long long)(n * Hi + hi) * Wi) * C + c;
+        float4 in[IW];
+#pragma unroll
+        for (int j = 0; j < IW; ++j) {
+          const int wi = wi0 + j;
+          in[j] = (wi >= 0 && wi < Wi) ? ld4(xrow + (long long)wi * C) : f4zero();
+        }
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) {
+          const float4 wv = ld4(w + (ky * K + kx) * C + c);
+#pragma unroll
+          for (int j = 0; j < TW; ++j) acc[j] = f4fma(in[j * S + kx], wv, acc[j]);
+        }
+      }
+    }
+    float* yrow = y + ((long long)(n * Ho + ho) * Wo) * C + c;
+#pragma unroll
+    for (int j = 0; j < TW; ++j)
+      if (wo0 + j < Wo) {
+        st4(yrow + (long long)(wo0 + j) * C, acc[j]);
+        s1 = f4add(s1, acc[j]);
+        s2 = f4fma(acc[j], acc[j], s2);
+      }
+  }
+#pragma unroll
+  for (int off = 8; off < 64; off <<= 1) {
+    s1.x += __shfl_xor(s1.x, off); s1.y += __shfl_xor(s1.y, off); s1.z += __shfl_xor(s1.z, off); s1.w += __shfl_xor(s1.w, off);
+    s2.x += __shfl_xor(s2.x, off); s2.y += __shfl_xor(s2.y, off); s2.z += __shfl_xor(s2.z, off); s2.w += __shfl_xor(s2.w, off);
+  }
+  if ((t & 63) < 8) {
+    sm[0][t >> 6][q] = s1;
+    sm[1][t >> 6][q] = s2;
+  }
+  __syncthreads();
+  if (t < 16) {
+    const int v = t >> 3, qq = t & 7;
+    const int cc = blockIdx.y * 32 + qq * 4;
+    if (cc < C)
+      st4(stats_part + ((long long)bx * 2 + v) * C + cc, f4add(f4add(sm[v][0][qq], sm[v][1][qq]), f4add(sm[v][2][qq], sm[v][3][qq])));
+  }
+}
+
 // dx[n,hi,wi,c] = sum_{ky,kx : (hi+pt-ky) % S == 0, (wi+pl-kx) % S == 0} dy[n,(hi+pt-ky)/S,(wi+pl-kx)/S,c] * w[ky,kx,c]
 template <int K, int S, int TW>
 __global__ __launch_bounds__(256) void dwconv_bwd_data_k(const float* __restrict__ dy, const float* __restrict__ w,
@@ -299,12 +397,26 @@ static int dw_check(const char* name, const void* a, const void* b, const void* 
 
 extern "C" {
 
-int mliis_dwconv_fwd(const float* x, const float* w, float* y, int N, int H, int W, int C, int k, int stride, hipStream_t stream) {
+int mliis_dwconv_fwd(const float* x, const float* w, float* y, int N, int H, int W, int C, int k, int stride, float* stats_part,
+                     size_t stats_floats, int* stats_nblk, hipStream_t stream) {
   int rc = dw_check("dwconv_fwd", x, w, y, N, H, W, C, k, stride);
   if (rc) return rc;
   DwGeom g = dw_geom(H, W, k, stride);
-  long long total = (long long)N * g.Ho * ((g.Wo + kTW - 1) / kTW) * (C / 4);
+  const long long strips = (long long)N * g.Ho * ((g.Wo + kTW - 1) / kTW);
+  long long total = strips * (C / 4);
   MLIIS_REQUIRE(total < (1LL << 31), MLIIS_ERR_UNSUPPORTED, "dwconv_fwd: tensor too large for 32-bit indexing");
+  if (stats_part != nullptr) {   // training: the following batch norm's stage-1 statistics come out of the same launch
+    MLIIS_REQUIRE(stats_nblk && aligned16(stats_part), MLIIS_ERR_ARG, "dwconv_fwd: statistics need a 16-byte aligned buffer and a stats_nblk output");
+    const int nblk = (int)((strips + 31) / 32);
+    MLIIS_REQUIRE((size_t)nblk * 2 * C <= stats_floats, MLIIS_ERR_WORKSPACE, "dwconv_fwd: statistics buffer too small (%zu floats needed, %zu given)",
+                  (size_t)nblk * 2 * C, stats_floats);
+    dim3 grid(nblk, ceil_div(C, 32));
+    DW_DISPATCH(dwconv_fwd_stats_k, x, w, y, N, H, W, g.Ho, g.Wo, C, g.pt, g.pl, stats_part);
+    MLIIS_CHECK_LAUNCH("dwconv_fwd_stats");
+    *stats_nblk = nblk;
+    return MLIIS_OK;
+  }
+  if (stats_nblk) *stats_nblk = 0;
   dim3 grid(ceil_div(total, 256));
   DW_DISPATCH(dwconv_fwd_k, x, w, y, N, H, W, g.Ho, g.Wo, C, g.pt, g.pl);
   MLIIS_CHECK_LAUNCH("dwconv_fwd");

@@ -367,8 +367,12 @@ class Learner:
             if b.expand != 1:
                 nb = conv(t, nm["w_exp"], None, 1, B["z0"], False)
                 t = bn(B["z0"], B["st0"], nm["bn0"], B["a0"], post=True, nblk=nb)
-            ops.dwconv_fwd(t, w[nm["w_dw"]], b.stride, out=B["z1"])
-            bn(B["z1"], B["st1"], nm["bn1"], B["a1"], post=True)
+            if training:   # the depthwise launch also leaves bn1's stage-1 statistics in P.stats_part
+                nb = ops.dwconv_fwd(t, w[nm["w_dw"]], b.stride, out=B["z1"], stats_part=P.stats_part)[1]
+            else:
+                ops.dwconv_fwd(t, w[nm["w_dw"]], b.stride, out=B["z1"])
+                nb = 0
+            bn(B["z1"], B["st1"], nm["bn1"], B["a1"], post=True, nblk=nb)
             hw = b.h_out * b.h_out
             ops.colsum(B["a1"], None, nseg=N, scale=1.0 / hw, out=B["s"], ws=ws)
             se = nm["se"]

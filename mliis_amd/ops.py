@@ -141,13 +141,18 @@ def stem_conv_bwd_filter(x, dz, idx=None, out=None, ws: Optional[Workspace] = No
 
 
 # ------------------------------------------------------------------------------------------------ depthwise
-def dwconv_fwd(x, w, stride, out=None):
+def dwconv_fwd(x, w, stride, out=None, stats_part=None):
+    """With stats_part (a float buffer) the launch also emits the next batch norm's stage-1 statistics; returns (out, nblk)."""
     N, H, W, C_ = x.shape
     k = w.shape[0]
     Ho, Wo = -(-H // stride), -(-W // stride)
     out = torch.empty((N, Ho, Wo, C_), dtype=torch.float32, device=x.device) if out is None else out
     meta = dict(bytes=4.0 * (x.numel() + out.numel() + k * k * C_), shape=(N, H, W, C_, k, stride)) if PROFILE is not None else {}
-    _timed("dwconv_fwd", meta, lambda: lib.call("mliis_dwconv_fwd", _ptr(_chk(x)), _ptr(w), _ptr(out), N, H, W, C_, k, stride, _stream()))
+    nblk = C.c_int(0)
+    _timed("dwconv_fwd", meta, lambda: lib.call("mliis_dwconv_fwd", _ptr(_chk(x)), _ptr(w), _ptr(out), N, H, W, C_, k, stride, _ptr(stats_part),
+                                                stats_part.numel() if stats_part is not None else 0, C.byref(nblk), _stream()))
+    if stats_part is not None:
+        return out, nblk.value
     return out
 
 

@@ -59,6 +59,14 @@ def test_dwconv_all(k, s, H, W, C):
     gx, gw = torch.autograd.grad(y, [x, w], dy)
     yg = ops.dwconv_fwd(f32(x, d), f32(w, d), s)
     close(yg, nhwc(y), 2e-5, "dw fwd")
+    # training variant: same output plus the next batch norm's stage-1 statistics
+    part = torch.full((1 << 16,), 7.0, device=d)
+    ys, nblk = ops.dwconv_fwd(f32(x, d), f32(w, d), s, stats_part=part)
+    assert torch.equal(ys, yg) and nblk > 0
+    sums = part[: nblk * 2 * C].view(nblk, 2, C).double().sum(0).cpu()
+    yr = nhwc(y).detach()
+    close(sums[0], yr.sum(dim=(0, 1, 2)), 1e-5, "dw fused sum")
+    close(sums[1], (yr * yr).sum(dim=(0, 1, 2)), 1e-5, "dw fused sum of squares")
     dyg = f32(nhwc(dy), d)
     close(ops.dwconv_bwd_data(dyg, f32(w, d), s, (H, W)), gx, 1e-4, "dw bwd data")
     close(ops.dwconv_bwd_filter(f32(x, d), dyg, k, s), gw, 1e-4, "dw bwd filter")
