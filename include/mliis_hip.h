@@ -127,10 +127,13 @@ int mliis_bn_apply(const float* x, int ldx, float* y, int ldy, long long rows, i
  *      (part [nblk][2][C], mliis_colreduce_workspace_floats(rows, C, 1, 2) floats), then fold + moving-average update + apply. */
 int mliis_bn_stats_partial(const float* x, int ldx, long long rows, int C, int pre_swish, float* part, size_t part_floats, int* nblk_out,
                            hipStream_t stream);
+/*      pool_part (nullable, training): the pass also leaves per-image partial sums of its OUTPUT, [rows/rows_per_img][*pool_chunks][C]
+ *      (needs ceil(rows_per_img/256) * images * C floats) -- the squeeze-excite pooling (efficientnet_model.py:247) without a pass of
+ *      its own; mliis_se_mlp_fwd folds the chunks. */
 int mliis_bn_apply_fused(const float* x, int ldx, float* y, int ldy, long long rows, int C, int rows_per_img, const float* part, int nblk,
                          float eps, float momentum, int unbiased_moving_var, float* mean, float* rstd, float* moving_mean,
                          float* moving_var, const float* gamma, const float* beta, int pre_swish, int post_swish, const float* img_scale,
-                         const float* res, int ldr, hipStream_t stream);
+                         const float* res, int ldr, float* pool_part, size_t pool_floats, int* pool_chunks, hipStream_t stream);
 /*      workspace: mliis_colreduce_workspace_floats(rows, C, 1, 2) floats.  dskip (nullable): the same pass also writes the
  *      identity-skip gradient dskip[r,c] (+)= dy[r,c] (MBConv residual, efficientnet_model.py:286-288), so it needs no launch of
  *      its own. */
@@ -147,8 +150,10 @@ int mliis_colsum(const float* a, int lda, const float* b, int ldb, long long row
 
 /* ---- squeeze-excite gate (efficientnet_model.py:238-251): hpre = W1.s + b1; gate = sigmoid(W2.swish(hpre) + b2).
  *      w1 [C,R], w2 [R,C] (TF HWIO 1x1).  R <= 128. */
-int mliis_se_mlp_fwd(const float* s, const float* w1, const float* b1, const float* w2, const float* b2, float* hpre, float* gate,
-                     int N, int C, int R, hipStream_t stream);
+/*      s_part [N][chunks][C]: pooled sums in `chunks` partials per image (mliis_bn_apply_fused's pool_part, or chunks = 1 for a
+ *      finished vector); s = scale * sum_chunks is what the MLP sees and, if s_out is given, what is kept for the backward pass. */
+int mliis_se_mlp_fwd(const float* s_part, int chunks, float scale, float* s_out, const float* w1, const float* b1, const float* w2,
+                     const float* b2, float* hpre, float* gate, int N, int C, int R, hipStream_t stream);
 int mliis_se_mlp_bwd(const float* dgate, const float* gate, const float* s, const float* hpre, const float* w1, const float* w2,
                      float* dpre1, float* dpre2, float* chan_add, float* dw1, float* db1, float* dw2, float* db2, int N, int C, int R,
                      int HW, hipStream_t stream);

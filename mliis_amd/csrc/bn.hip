@@ -242,7 +242,8 @@ __global__ __launch_bounds__(256) void bn_apply_fused_k(const float* __restrict_
                                                         long long rows, int C, int rows_per_img, BnFold f,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         int pre_swish, int post_swish, const float* __restrict__ img_scale,
-                                                        const float* __restrict__ res, int ldr, int rows_per_block) {
+                                                        const float* __restrict__ res, int ldr, int rows_per_block,
+                                                        float* __restrict__ pool_part, int pool_chunks) {
   __shared__ double smd[2 * 32 * 32];
   __shared__ __attribute__((aligned(16))) float s_mean[kChanBlock], s_rstd[kChanBlock];
   const int t = threadIdx.x;
@@ -269,11 +270,21 @@ __global__ __launch_bounds__(256) void bn_apply_fused_k(const float* __restrict_
   }
   __syncthreads();
   const int q = t & 7, rl = t >> 3;
-  const int c = c0 + q * 4;
-  if (c >= C) return;
+  const bool cok = c0 + q * 4 < C;
+  if (!cok && pool_part == nullptr) return;
+  const int c = cok ? c0 + q * 4 : 0;   // (pooling: surplus lanes stay for the reduction, with an empty row range)
   const float4 m = ld4(s_mean + q * 4), rs = ld4(s_rstd + q * 4), g = ld4(gamma + c), b = ld4(beta + c);
-  long long r1 = (long long)(blockIdx.y + 1) * rows_per_block;
+  // row range: plain chunks of rows_per_block, or (pooling) chunk (blockIdx.y % pool_chunks) of image (blockIdx.y / pool_chunks)
+  long long r0 = (long long)blockIdx.y * rows_per_block, r1 = r0 + rows_per_block;
+  if (pool_part != nullptr) {
+    const int img = blockIdx.y / pool_chunks, ch = blockIdx.y - img * pool_chunks;
+    r0 = (long long)img * rows_per_img + (long long)ch * rows_per_block;
+    r1 = r0 + rows_per_block;
+    if (r1 > (long long)(img + 1) * rows_per_img) r1 = (long long)(img + 1) * rows_per_img;
+  }
   if (r1 > rows) r1 = rows;
+  if (!cok) r1 = r0;
+  float4 pool = f4zero();   // sum of this thread's outputs (squeeze-excite pooling, training)
   auto finish = [&](long long r, float4 v, float4 rv) {
     if (pre_swish) v = make_float4(swish_f(v.x), swish_f(v.y), swish_f(v.z), swish_f(v.w));
     float4 o;
@@ -284,9 +295,10 @@ __global__ __launch_bounds__(256) void bn_apply_fused_k(const float* __restrict_
     if (post_swish) o = make_float4(swish_f(o.x), swish_f(o.y), swish_f(o.z), swish_f(o.w));
     if (img_scale != nullptr) o = f4scale(o, img_scale[(int)r / rows_per_img]);
     if (res != nullptr) o = f4add(o, rv);
+    pool = f4add(pool, o);
     st4(y + r * ldy + c, o);
   };
-  long long r = (long long)blockIdx.y * rows_per_block + rl;
+  long long r = r0 + rl;
   for (; r + (kBatch - 1) * kRowLanes < r1; r += kBatch * kRowLanes) {
     float4 v[kBatch], rv[kBatch];
 #pragma unroll
@@ -298,6 +310,21 @@ __global__ __launch_bounds__(256) void bn_apply_fused_k(const float* __restrict_
     for (int u = 0; u < kBatch; ++u) finish(r + u * kRowLanes, v[u], rv[u]);
   }
   for (; r < r1; r += kRowLanes) finish(r, ld4(x + r * ldx + c), res != nullptr ? ld4(res + r * ldr + c) : f4zero());
+  if (pool_part == nullptr) return;   // (uniform)
+  // pooled partial of this block: butterfly over the 8 row lanes of a wave that share a quad, then the 4 waves through LDS
+#pragma unroll
+  for (int off = 8; off < 64; off <<= 1) {
+    pool.x += __shfl_xor(pool.x, off);
+    pool.y += __shfl_xor(pool.y, off);
+    pool.z += __shfl_xor(pool.z, off);
+    pool.w += __shfl_xor(pool.w, off);
+  }
+  float4* smp = reinterpret_cast<float4*>(smd);   // the statistics fold is done with it
+  __syncthreads();
+  if ((t & 63) < 8) smp[(t >> 6) * 8 + q] = pool;
+  __syncthreads();
+  if (t < 8 && c0 + t * 4 < C)
+    st4(pool_part + (long long)blockIdx.y * C + c0 + t * 4, f4add(f4add(smp[t], smp[8 + t]), f4add(smp[16 + t], smp[24 + t])));
 }
 
 static inline void chan_grid(long long rows, int C, int* gx, int* gy, int* rows_per_block) {
@@ -711,7 +738,7 @@ int mliis_bn_stats_partial(const float* x, int ldx, long long rows, int C, int p
 int mliis_bn_apply_fused(const float* x, int ldx, float* y, int ldy, long long rows, int C, int rows_per_img, const float* part, int nblk,
                          float eps, float momentum, int unbiased_moving_var, float* mean, float* rstd, float* moving_mean,
                          float* moving_var, const float* gamma, const float* beta, int pre_swish, int post_swish, const float* img_scale,
-                         const float* res, int ldr, hipStream_t stream) {
+                         const float* res, int ldr, float* pool_part, size_t pool_floats, int* pool_chunks, hipStream_t stream) {
   MLIIS_REQUIRE(x && y && part && mean && rstd && gamma && beta, MLIIS_ERR_ARG, "bn_apply_fused: null pointer");
   MLIIS_REQUIRE(rows > 1 && rows < (1LL << 31) && nblk > 0 && C > 0 && (C & 3) == 0 && (ldx & 3) == 0 && (ldy & 3) == 0 && ldx >= C && ldy >= C &&
                     rows_per_img > 0 && (res == nullptr || ((ldr & 3) == 0 && ldr >= C)),
@@ -722,10 +749,21 @@ int mliis_bn_apply_fused(const float* x, int ldx, float* y, int ldy, long long r
   const double n = (double)rows;
   BnFold f{part, nblk, 1.0 / n, eps, (float)(1.0 - (double)momentum), unbiased_moving_var ? (float)(n / (n - 1.0)) : 1.0f, mean, rstd,
            moving_mean, moving_var};
-  int gx, gy, rpb;
+  int gx, gy, rpb, cpi = 0;
   chan_grid(rows, C, &gx, &gy, &rpb);
+  if (pool_part != nullptr) {   // per-image pooling of the output: row chunks are cut per image (about 256 rows each)
+    MLIIS_REQUIRE(pool_chunks && aligned16(pool_part) && rows % rows_per_img == 0, MLIIS_ERR_ARG,
+                  "bn_apply_fused: pooling needs an aligned buffer, a pool_chunks output and whole images");
+    const long long nimg = rows / rows_per_img;
+    cpi = (rows_per_img + 255) / 256;
+    rpb = (rows_per_img + cpi - 1) / cpi;
+    gy = (int)(nimg * cpi);
+    MLIIS_REQUIRE((size_t)gy * C <= pool_floats, MLIIS_ERR_WORKSPACE, "bn_apply_fused: pool buffer too small (%zu floats needed, %zu given)",
+                  (size_t)gy * C, pool_floats);
+    *pool_chunks = cpi;
+  }
   hipLaunchKernelGGL(bn_apply_fused_k, dim3(gx, gy), dim3(256), 0, stream, x, ldx, y, ldy, rows, C, rows_per_img, f, gamma, beta, pre_swish,
-                     post_swish, img_scale, res, ldr, rpb);
+                     post_swish, img_scale, res, ldr, rpb, pool_part, cpi);
   MLIIS_CHECK_LAUNCH("bn_apply_fused");
   return MLIIS_OK;
 }

@@ -30,16 +30,36 @@ __device__ __forceinline__ float dot_strided(const float* __restrict__ a, int sa
   return acc;
 }
 
-// one workgroup per image
-__global__ __launch_bounds__(kSeThreads) void se_mlp_fwd_k(const float* __restrict__ s, const float* __restrict__ w1,
+// one workgroup per image.  The pooled vector arrives as `chunks` partial sums per image (s_part [N][chunks][C], from the epilogue
+// of the batch-norm apply that produced the activation, or chunks = 1 for a finished vector); phase 0 folds them (x scale) into LDS
+// and publishes s [N][C] for the backward pass.
+__global__ __launch_bounds__(kSeThreads) void se_mlp_fwd_k(const float* __restrict__ s_part, int chunks, float scale,
+                                                    float* __restrict__ s_out, const float* __restrict__ w1,
                                                     const float* __restrict__ b1, const float* __restrict__ w2,
                                                     const float* __restrict__ b2, float* __restrict__ hpre,
                                                     float* __restrict__ gate, int C, int R) {
   __shared__ float sh[kMaxR];
   __shared__ float red[kSeThreads];
   __shared__ float red2[8 * kMaxR];
+  extern __shared__ float sn[];   // [C]
   const int n = blockIdx.x, t = threadIdx.x;
-  const float* sn = s + (long long)n * C;
+  for (int c = t; c < C; c += kSeThreads) {
+    const float* pp = s_part + ((long long)n * chunks) * C + c;
+    float a = 0.f;
+    int k = 0;
+    for (; k + 8 <= chunks; k += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = pp[(long long)(k + u) * C];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a += v[u];
+    }
+    for (; k < chunks; ++k) a += pp[(long long)k * C];
+    a *= scale;
+    sn[c] = a;
+    if (s_out != nullptr) s_out[(long long)n * C + c] = a;
+  }
+  __syncthreads();
   // phase 1: h_j = b1[j] + sum_c s[c] * w1[c][j];  threads laid out (c-lane, j) so w1 reads are contiguous
   const int CL = kSeThreads / R;
   const int j = t % R, cl = t / R;
@@ -186,11 +206,13 @@ using namespace mliis;
 
 extern "C" {
 
-int mliis_se_mlp_fwd(const float* s, const float* w1, const float* b1, const float* w2, const float* b2, float* hpre, float* gate,
-                     int N, int C, int R, hipStream_t stream) {
-  MLIIS_REQUIRE(s && w1 && b1 && w2 && b2 && hpre && gate, MLIIS_ERR_ARG, "se_mlp_fwd: null pointer");
-  MLIIS_REQUIRE(N > 0 && C > 0 && R > 0 && R <= kMaxR, MLIIS_ERR_ARG, "se_mlp_fwd: bad shape (R <= %d)", kMaxR);
-  hipLaunchKernelGGL(se_mlp_fwd_k, dim3(N), dim3(kSeThreads), 0, stream, s, w1, b1, w2, b2, hpre, gate, C, R);
+int mliis_se_mlp_fwd(const float* s_part, int chunks, float scale, float* s_out, const float* w1, const float* b1, const float* w2,
+                     const float* b2, float* hpre, float* gate, int N, int C, int R, hipStream_t stream) {
+  MLIIS_REQUIRE(s_part && w1 && b1 && w2 && b2 && hpre && gate, MLIIS_ERR_ARG, "se_mlp_fwd: null pointer");
+  MLIIS_REQUIRE(N > 0 && C > 0 && C <= 8192 && R > 0 && R <= kMaxR && chunks > 0, MLIIS_ERR_ARG, "se_mlp_fwd: bad shape (R <= %d, C <= 8192)",
+                kMaxR);
+  hipLaunchKernelGGL(se_mlp_fwd_k, dim3(N), dim3(kSeThreads), (size_t)C * sizeof(float), stream, s_part, chunks, scale, s_out, w1, b1, w2, b2,
+                     hpre, gate, C, R);
   MLIIS_CHECK_LAUNCH("se_mlp_fwd");
   return MLIIS_OK;
 }

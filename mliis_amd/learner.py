@@ -103,6 +103,8 @@ class _Plan:
             need = max(need, -(-(N * m.h * m.h) // 64) * 2 * m.c_out, ops.bn_stats_partial_floats(N * m.h * m.h, m.c_out))
         need = max(need, ops.bn_stats_partial_floats(N * hs * hs, a.stem_out))
         self.stats_part = buf(need + 64)
+        # squeeze-excite pooling partials of the bn1 apply pass: [N][ceil(rows_per_img / 256)][C]
+        self.pool_part = buf(max(N * (-(-(b.h_out * b.h_out) // 256)) * b.cexp for b in a.blocks if b.executed) + 64)
         # ---- deferred weight-gradient folds: every *_bwd_filter leaves its per-split slabs in a region of fold_buf and ONE
         #      mliis_fold_batched launch at the end of the backward pass reduces them all into the gradient arena
         A = L.arena
@@ -335,14 +337,14 @@ class Learner:
         A, a, ws, N = self.arena, self.arch, self.ws, P.N
         w, mv = A.w, A.mv
 
-        def bn(xin, st, prefix, y, pre=False, post=False, img_scale=None, res=None, fused=False, nblk=0):
+        def bn(xin, st, prefix, y, pre=False, post=False, img_scale=None, res=None, fused=False, nblk=0, pool_part=None):
             """nblk > 0: the producing conv already left the stage-1 statistics in P.stats_part."""
             if training:
                 if nblk == 0:
                     nblk = ops.bn_stats_partial(xin, pre, P.stats_part)
                 return ops.bn_apply_fused(xin, P.stats_part, nblk, st[0], st[1], w[prefix + "/gamma"], w[prefix + "/beta"],
                                           moving=(mv[prefix + "/moving_mean"], mv[prefix + "/moving_variance"]), unbiased_moving_var=fused,
-                                          pre_swish=pre, post_swish=post, img_scale=img_scale, res=res, out=y)
+                                          pre_swish=pre, post_swish=post, img_scale=img_scale, res=res, out=y, pool_part=pool_part)
             st[0].copy_(mv[prefix + "/moving_mean"])
             torch.rsqrt(mv[prefix + "/moving_variance"] + spec.BN_EPS, out=st[1])
             return ops.bn_apply(xin, st[0], st[1], w[prefix + "/gamma"], w[prefix + "/beta"], pre, post, img_scale, res, out=y)
@@ -372,11 +374,16 @@ class Learner:
             else:
                 ops.dwconv_fwd(t, w[nm["w_dw"]], b.stride, out=B["z1"])
                 nb = 0
-            bn(B["z1"], B["st1"], nm["bn1"], B["a1"], post=True, nblk=nb)
             hw = b.h_out * b.h_out
-            ops.colsum(B["a1"], None, nseg=N, scale=1.0 / hw, out=B["s"], ws=ws)
             se = nm["se"]
-            ops.se_mlp_fwd(B["s"], w[se[0]], w[se[1]], w[se[2]], w[se[3]], B["hpre"], B["gate"])
+            if training:   # bn1's apply pass also pools its output per image (partial sums); the SE kernel folds them
+                chunks = bn(B["z1"], B["st1"], nm["bn1"], B["a1"], post=True, nblk=nb, pool_part=P.pool_part)[1]
+                ops.se_mlp_fwd(P.pool_part, w[se[0]], w[se[1]], w[se[2]], w[se[3]], B["hpre"], B["gate"], chunks=chunks, scale=1.0 / hw,
+                               s_out=B["s"])
+            else:
+                bn(B["z1"], B["st1"], nm["bn1"], B["a1"], post=True, nblk=nb)
+                ops.colsum(B["a1"], None, nseg=N, scale=1.0 / hw, out=B["s"], ws=ws)
+                ops.se_mlp_fwd(B["s"], w[se[0]], w[se[1]], w[se[2]], w[se[3]], B["hpre"], B["gate"])
             # squeeze-excite gate applied inside the project GEMM's A loader (the gated tensor is never written)
             nb = conv(B["a1"], nm["w_proj"], None, 1, B["z2"], False, x_scale=B["gate"])
             use_dc = training and self.drop_connect and b.skip and b.drop_rate > 0

@@ -311,16 +311,21 @@ def bn_stats_partial_floats(rows, C_):
 
 
 def bn_apply_fused(x, part, nblk, mean, rstd, gamma, beta, moving=None, unbiased_moving_var=False, pre_swish=False, post_swish=False,
-                   img_scale=None, res=None, out=None, rows_per_img=None, eps=BN_EPS, momentum=BN_MOMENTUM):
+                   img_scale=None, res=None, out=None, rows_per_img=None, eps=BN_EPS, momentum=BN_MOMENTUM, pool_part=None):
+    """pool_part (a float buffer): the pass also leaves per-image partial sums of its output there and the function returns
+    (out, chunks_per_image) -- feed both to se_mlp_fwd."""
     rows, C_, ldx = rows_ld(x)
     out = torch.empty(x.shape, dtype=torch.float32, device=x.device) if out is None else out
     _, _, ldy = rows_ld(out)
     rpi = rows_per_img or (rows // x.shape[0])
     ldr = rows_ld(res)[2] if res is not None else 0
     mm, mv = (None, None) if moving is None else moving
+    chunks = C.c_int(0)
     lib.call("mliis_bn_apply_fused", _ptr(x), ldx, _ptr(out), ldy, rows, C_, rpi, _ptr(part), int(nblk), eps, momentum,
              int(unbiased_moving_var), _ptr(mean), _ptr(rstd), _ptr(mm), _ptr(mv), _ptr(gamma), _ptr(beta), int(pre_swish), int(post_swish),
-             _ptr(img_scale), _ptr(res), ldr, _stream())
+             _ptr(img_scale), _ptr(res), ldr, _ptr(pool_part), pool_part.numel() if pool_part is not None else 0, C.byref(chunks), _stream())
+    if pool_part is not None:
+        return out, chunks.value
     return out
 
 
@@ -365,12 +370,17 @@ def colsum(a, b=None, nseg=1, scale=1.0, out=None, accumulate=False, ws: Optiona
 
 
 # ------------------------------------------------------------------------------------------------ squeeze-excite
-def se_mlp_fwd(s, w1, b1, w2, b2, hpre=None, gate=None):
-    N, C_ = s.shape
+def se_mlp_fwd(s, w1, b1, w2, b2, hpre=None, gate=None, chunks=0, scale=1.0, s_out=None):
+    """s: the pooled vector [N, C]; or, with chunks > 0, per-image partial sums [N, chunks, C] (bn_apply_fused's pool_part) that the
+    kernel folds and scales (s_out [N, C] receives the finished vector for the backward pass)."""
+    if chunks > 0 and s_out is None:
+        raise MliisError("se_mlp_fwd: partial sums need an s_out [N, C] tensor")
+    N, C_ = s.shape if chunks == 0 else s_out.shape
     R = b1.numel()
     hpre = torch.empty((N, R), dtype=torch.float32, device=s.device) if hpre is None else hpre
     gate = torch.empty((N, C_), dtype=torch.float32, device=s.device) if gate is None else gate
-    lib.call("mliis_se_mlp_fwd", _ptr(s), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), _ptr(hpre), _ptr(gate), N, C_, R, _stream())
+    lib.call("mliis_se_mlp_fwd", _ptr(s), max(1, int(chunks)), float(scale), _ptr(s_out), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), _ptr(hpre),
+             _ptr(gate), N, C_, R, _stream())
     return hpre, gate
 
 

@@ -251,6 +251,38 @@ def test_se(C, Rr, N, HW):
     close(dx, gx, 1e-4, "se dx")
 
 
+@pytest.mark.parametrize("C,Rr,N,HW", [(40, 10, 3, 196), (672, 28, 2, 49), (24, 6, 2, 784), (144, 6, 8, 300)])
+def test_bn_apply_pools_for_squeeze_excite(C, Rr, N, HW):
+    """bn_apply_fused(pool_part=...) leaves per-image partial sums of its output; se_mlp_fwd(chunks, scale) folds them: the pooled
+    vector and the gate equal the separate colsum + MLP path and the float64 oracle."""
+    from mliis_amd import ops
+    d = dev()
+    x = rnd(N, HW, 1, C, seed=60) * 1.5 + 0.2
+    gamma, beta = rnd(C, seed=61) * 0.3 + 1, rnd(C, seed=62)
+    w1, b1 = rnd(1, 1, C, Rr, seed=63, scale=0.3), rnd(Rr, seed=64)
+    w2, b2 = rnd(1, 1, Rr, C, seed=65, scale=0.3), rnd(C, seed=66)
+    mean, var = x.mean(dim=(0, 1, 2)), x.var(dim=(0, 1, 2), unbiased=False)
+    a = R.swish((x - mean) * torch.rsqrt(var + 1e-3) * gamma + beta)
+    s = a.mean(dim=(1, 2))
+    gate = torch.sigmoid(R.swish(s @ w1[0, 0] + b1) @ w2[0, 0] + b2)
+    xg = f32(x, d)
+    part = torch.empty(ops.bn_stats_partial_floats(N * HW, C) + 16, device=d)
+    nblk = ops.bn_stats_partial(xg, False, part)
+    m_o, r_o = torch.empty(C, device=d), torch.empty(C, device=d)
+    pool = torch.full((N * (-(-HW // 256)) * C + 16,), 3.0, device=d)
+    ag, chunks = ops.bn_apply_fused(xg, part, nblk, m_o, r_o, f32(gamma, d), f32(beta, d), post_swish=True, pool_part=pool)
+    assert chunks == -(-HW // 256)
+    close(ag, a, 3e-5, "bn apply (pooling variant)")
+    sg = torch.empty(N, C, device=d)
+    hp, gg = ops.se_mlp_fwd(pool, f32(w1, d), f32(b1, d), f32(w2, d), f32(b2, d), chunks=chunks, scale=1.0 / HW, s_out=sg)
+    close(sg, s, 1e-5, "pooled vector from the apply pass")
+    close(gg, gate, 3e-5, "gate from pooled partials")
+    assert pool[N * chunks * C:].eq(3.0).all(), "pool partials written out of range"
+    s2 = ops.colsum(ag, None, nseg=N, scale=1.0 / HW)
+    hp2, g2 = ops.se_mlp_fwd(s2, f32(w1, d), f32(b1, d), f32(w2, d), f32(b2, d))
+    close(g2, gg, 1e-5, "same gate as the separate pooling pass")
+
+
 def test_chan_affine_broadcast_and_copy():
     from mliis_amd import ops
     d = dev()
