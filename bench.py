@@ -249,6 +249,7 @@ def _run(args):
         out = None
     if world > 1:
         import torch.distributed as dist
+        dist.barrier()                      # rank 0 may still be in its roofline pass
         dist.destroy_process_group()
     return out
 
