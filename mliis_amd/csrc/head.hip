@@ -68,51 +68,72 @@ __global__ __launch_bounds__(256) void resize_fwd_k(const float* __restrict__ x,
   }
 }
 
-// gather-form transpose: dx[n,hi,wi] = sum_{ho,wo} wy(ho,hi) * wx(wo,wi) * dy[n,ho,wo]
+// gather-form transpose: dx[n,hi,wi] = sum_{ho,wo} wy(ho,hi) * wx(wo,wi) * dy[n,ho,wo]   (atomic-free, deterministic)
+// 8 lanes per output element: lane l takes the candidate output rows ho_lo + l, ho_lo + l + 8, ... and walks their candidate columns
+// four loads at a time; the lanes are combined with a fixed xor butterfly.  (A 4x upsample touches ~11 x 11 candidates per element:
+// one thread walking them serially made this kernel pure latency.)
 template <int V>
 __global__ __launch_bounds__(256) void resize_bwd_k(const float* __restrict__ dy, int lddy, float* __restrict__ dx, int lddx, int N,
-                                                    int Hi, int Wi, int Ho, int Wo, int C, float sh, float sw, int accumulate) {
+                                                    int Hi, int Wi, int Ho, int Wo, int C, float sh, float sw, int accumulate,
+                                                    long long total) {
   typedef typename Vec<V>::T T;
   const int Q = C / V;
-  const long long total = (long long)N * Hi * Wi * Q;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % Q) * V;
-    long long p = i / Q;
-    const int wi = (int)(p % Wi);
-    long long r = p / Wi;
-    const int hi = (int)(r % Hi);
-    const int n = (int)(r / Hi);
-    // conservative candidate ranges of output rows/cols that can touch (hi, wi)
-    int ho_lo = (int)floorf((float)(hi - 1) / sh) - 1, ho_hi = (int)ceilf((float)(hi + 1) / sh) + 1;
-    int wo_lo = (int)floorf((float)(wi - 1) / sw) - 1, wo_hi = (int)ceilf((float)(wi + 1) / sw) + 1;
-    if (ho_lo < 0) ho_lo = 0;
-    if (wo_lo < 0) wo_lo = 0;
-    if (ho_hi > Ho - 1) ho_hi = Ho - 1;
-    if (wo_hi > Wo - 1) wo_hi = Wo - 1;
-    T acc = vzero<T>();
-    const float* base = dy + (long long)n * Ho * Wo * lddy + c;
-    for (int ho = ho_lo; ho <= ho_hi; ++ho) {
-      int y0, y1;
-      float ly;
-      src_coord(ho, sh, Hi, y0, y1, ly);
-      const float wy = (y0 == hi ? 1.f - ly : 0.f) + (y1 == hi ? ly : 0.f);
-      if (wy == 0.f) continue;
-      for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int rl = (int)(gid & 7);
+  const long long i_ = gid >> 3;
+  const bool live = i_ < total;
+  const long long i = live ? i_ : 0;   // surplus lanes shadow element 0 (they take part in the shuffles, never store)
+  const int c = (int)(i % Q) * V;
+  const long long p = i / Q;
+  const int wi = (int)(p % Wi);
+  const long long r = p / Wi;
+  const int hi = (int)(r % Hi);
+  const int n = (int)(r / Hi);
+  // conservative candidate ranges of output rows/cols that can touch (hi, wi)
+  int ho_lo = (int)floorf((float)(hi - 1) / sh) - 1, ho_hi = (int)ceilf((float)(hi + 1) / sh) + 1;
+  int wo_lo = (int)floorf((float)(wi - 1) / sw) - 1, wo_hi = (int)ceilf((float)(wi + 1) / sw) + 1;
+  if (ho_lo < 0) ho_lo = 0;
+  if (wo_lo < 0) wo_lo = 0;
+  if (ho_hi > Ho - 1) ho_hi = Ho - 1;
+  if (wo_hi > Wo - 1) wo_hi = Wo - 1;
+  T acc = vzero<T>();
+  const float* base = dy + (long long)n * Ho * Wo * lddy + c;
+  for (int ho = ho_lo + rl; ho <= ho_hi; ho += 8) {
+    int y0, y1;
+    float ly;
+    src_coord(ho, sh, Hi, y0, y1, ly);
+    const float wy = (y0 == hi ? 1.f - ly : 0.f) + (y1 == hi ? ly : 0.f);
+    if (wy == 0.f) continue;
+    const float* row = base + (long long)ho * Wo * lddy;
+    for (int wo = wo_lo; wo <= wo_hi; wo += 4) {
+      T v[4];
+      float wgt[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int w_ = wo + u <= wo_hi ? wo + u : wo_hi;
         int x0, x1;
         float lx;
-        src_coord(wo, sw, Wi, x0, x1, lx);
+        src_coord(w_, sw, Wi, x0, x1, lx);
         const float wx = (x0 == wi ? 1.f - lx : 0.f) + (x1 == wi ? lx : 0.f);
-        if (wx == 0.f) continue;
-        acc = vfma(wy * wx, *reinterpret_cast<const T*>(base + ((long long)ho * Wo + wo) * lddy), acc);
+        wgt[u] = wo + u <= wo_hi ? wy * wx : 0.f;
+        v[u] = *reinterpret_cast<const T*>(row + (long long)w_ * lddy);
       }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc = vfma(wgt[u], v[u], acc);
     }
-    T* dst = reinterpret_cast<T*>(dx + p * lddx + c);
-    if (accumulate) {
-      T old = *dst;
-      acc = vfma(1.f, old, acc);
-    }
-    *dst = acc;
   }
+  float* a = reinterpret_cast<float*>(&acc);
+#pragma unroll
+  for (int off = 1; off < 8; off <<= 1)
+#pragma unroll
+    for (int e = 0; e < V; ++e) a[e] += __shfl_xor(a[e], off);
+  if (!live || rl != 0) return;
+  T* dst = reinterpret_cast<T*>(dx + p * lddx + c);
+  if (accumulate) {
+    T old = *dst;
+    acc = vfma(1.f, old, acc);
+  }
+  *dst = acc;
 }
 
 // ------------------------------------------------------------------------------------------------ final 1x1 conv, Cout = 2
@@ -320,13 +341,13 @@ int mliis_resize_bilinear_bwd(const float* dy, int lddy, float* dx, int lddx, in
   const float sh = (float)(Hi - 1) / (float)(Ho - 1), sw = (float)(Wi - 1) / (float)(Wo - 1);
   if ((C & 3) == 0 && (lddx & 3) == 0 && (lddy & 3) == 0 && aligned16(dx) && aligned16(dy)) {
     long long q = (long long)N * Hi * Wi * (C / 4);
-    hipLaunchKernelGGL((resize_bwd_k<4>), dim3(ew_blocks(q)), dim3(256), 0, stream, dy, lddy, dx, lddx, N, Hi, Wi, Ho, Wo, C, sh, sw,
-                       accumulate);
+    hipLaunchKernelGGL((resize_bwd_k<4>), dim3((unsigned)((q * 8 + 255) / 256)), dim3(256), 0, stream, dy, lddy, dx, lddx, N, Hi, Wi, Ho, Wo, C, sh,
+                       sw, accumulate, q);
   } else {
     MLIIS_REQUIRE((lddx & 1) == 0 && (lddy & 1) == 0, MLIIS_ERR_ALIGN, "resize_bilinear_bwd: leading dims must be even");
     long long q = (long long)N * Hi * Wi * (C / 2);
-    hipLaunchKernelGGL((resize_bwd_k<2>), dim3(ew_blocks(q)), dim3(256), 0, stream, dy, lddy, dx, lddx, N, Hi, Wi, Ho, Wo, C, sh, sw,
-                       accumulate);
+    hipLaunchKernelGGL((resize_bwd_k<2>), dim3((unsigned)((q * 8 + 255) / 256)), dim3(256), 0, stream, dy, lddy, dx, lddx, N, Hi, Wi, Ho, Wo, C, sh,
+                       sw, accumulate, q);
   }
   MLIIS_CHECK_LAUNCH("resize_bilinear_bwd");
   return MLIIS_OK;

@@ -83,17 +83,19 @@ __global__ __launch_bounds__(256) void stem_fwd_k(const float* __restrict__ x, c
   st4(dst + 4, make_float4(acc[4], acc[5], acc[6], acc[7]));
 }
 
-// thread = (pixel lane, channel quad): 27 x float4 accumulators; the 27 normalised inputs of a pixel are shared by the Co/4 quad
-// threads of that pixel (L1 broadcast).  Two pixels per trip (both windows loaded before the FMAs).  Block reduction: butterfly over
-// the pixel lanes that share a wave, then the waves through LDS in a fixed order.  part layout [blk][27][Co].
+// thread = (pixel lane, channel quad): 27 x float4 accumulators.  The block walks its pixels PL at a time: the 27 normalised window
+// values of those PL pixels are fetched ONCE, cooperatively, into LDS (instead of once per channel-quad thread) and every thread
+// reads its pixel's window from there (8-way broadcast, conflict-free stride 27).  Block reduction: butterfly over the pixel lanes
+// that share a wave, then the waves through LDS in a fixed order.  part layout [blk][27][Co].
 // The quad index is padded to a power of two (QP >= Co/4; surplus lanes idle) so the lanes of one quad are a fixed xor pattern.
 __global__ __launch_bounds__(256) void stem_bwd_filter_k(const float* __restrict__ x, const int* __restrict__ idx,
                                                          const float* __restrict__ dz, float* __restrict__ part, int N, int H,
                                                          int W, int Ho, int Wo, int Co, int pt, int pl, Norm3 nm,
                                                          int pix_per_block, int QP) {
-  extern __shared__ float4 sred[];   // [4 waves][27][QC]
+  extern __shared__ float4 sred[];   // [4 waves][27][QC], then the window stage [PL][27] floats
   const int QC = Co >> 2;            // channel quads
   const int PL = 256 / QP;           // pixel lanes
+  float* swin = reinterpret_cast<float*>(sred + 4 * 27 * QC);
   const int q = threadIdx.x & (QP - 1), pl_ = threadIdx.x / QP;
   const bool active = q < QC;
   const long long P = (long long)N * Ho * Wo;
@@ -103,32 +105,37 @@ __global__ __launch_bounds__(256) void stem_bwd_filter_k(const float* __restrict
   const long long p0 = (long long)blockIdx.x * pix_per_block;
   long long p1 = p0 + pix_per_block;
   if (p1 > P) p1 = P;
-  auto window = [&](long long pix, float* v) {
-    const int wo = (int)(pix % Wo);
-    const long long r = pix / Wo;
-    const int ho = (int)(r % Ho);
-    const int n = (int)(r / Ho);
-    const int src = idx ? idx[n] : n;
-    load_window(x + (long long)src * H * W * 3, H, W, ho * 2 - pt, wo * 2 - pl, nm, v);
-  };
-  long long pix = active ? p0 + pl_ : p1;
-  for (; pix + PL < p1; pix += 2 * PL) {
-    float v0[27], v1[27];
-    window(pix, v0);
-    window(pix + PL, v1);
-    const float4 d0 = ld4(dz + pix * Co + q * 4), d1 = ld4(dz + (pix + PL) * Co + q * 4);
-#pragma unroll
-    for (int k = 0; k < 27; ++k) {
-      acc[k] = f4fma(make_float4(v0[k], v0[k], v0[k], v0[k]), d0, acc[k]);
-      acc[k] = f4fma(make_float4(v1[k], v1[k], v1[k], v1[k]), d1, acc[k]);
+  const float mean[3] = {nm.m0, nm.m1, nm.m2}, sd[3] = {nm.i0, nm.i1, nm.i2};
+  for (long long pg = p0; pg < p1; pg += PL) {
+    for (int e = threadIdx.x; e < PL * 27; e += 256) {
+      const int pp = e / 27, tap = e - pp * 27;
+      const long long pix = pg + pp;
+      float v = 0.f;
+      if (pix < p1) {
+        const int wo = (int)(pix % Wo);
+        const long long r = pix / Wo;
+        const int ho = (int)(r % Ho);
+        const int n = (int)(r / Ho);
+        const int src = idx ? idx[n] : n;
+        const int ky = tap / 9, rem = tap - ky * 9, kx = rem / 3, ci = rem - kx * 3;
+        const int hi = ho * 2 - pt + ky, wi = wo * 2 - pl + kx;
+        // TF divides by std; (x - m) / s is restated as a true division to stay within 1 ulp of it
+        if (hi >= 0 && hi < H && wi >= 0 && wi < W) v = (x[(((long long)src * H + hi) * W + wi) * 3 + ci] - mean[ci]) / sd[ci];
+      }
+      swin[e] = v;
     }
-  }
-  for (; pix < p1; pix += PL) {
-    float v[27];
-    window(pix, v);
-    const float4 d = ld4(dz + pix * Co + q * 4);
+    __syncthreads();
+    const long long pix = pg + pl_;
+    if (active && pix < p1) {
+      const float4 d = ld4(dz + pix * Co + q * 4);
+      const float* wv = swin + pl_ * 27;
 #pragma unroll
-    for (int k = 0; k < 27; ++k) acc[k] = f4fma(make_float4(v[k], v[k], v[k], v[k]), d, acc[k]);
+      for (int k = 0; k < 27; ++k) {
+        const float v = wv[k];
+        acc[k] = f4fma(make_float4(v, v, v, v), d, acc[k]);
+      }
+    }
+    __syncthreads();
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -202,7 +209,8 @@ int mliis_stem_conv_bwd_filter(const float* x, const int* img_idx, const float* 
   stem_filter_geom(N, g.Ho, g.Wo, Co, &ppb, &nblk);
   MLIIS_REQUIRE((size_t)nblk * 27 * Co <= ws_floats, MLIIS_ERR_WORKSPACE, "stem_conv_bwd_filter: workspace too small");
   Norm3 nm{mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]};
-  hipLaunchKernelGGL(stem_bwd_filter_k, dim3(nblk), dim3(256), (size_t)4 * 27 * (Co / 4) * sizeof(float4), stream, x, img_idx, dz, ws, N, H, W, g.Ho, g.Wo, Co,
+  const size_t lds = (size_t)4 * 27 * (Co / 4) * sizeof(float4) + (size_t)(256 / stem_quad_pad(Co)) * 27 * sizeof(float);
+  hipLaunchKernelGGL(stem_bwd_filter_k, dim3(nblk), dim3(256), lds, stream, x, img_idx, dz, ws, N, H, W, g.Ho, g.Wo, Co,
                      g.pt, g.pl, nm, ppb, stem_quad_pad(Co));
   MLIIS_CHECK_LAUNCH("stem_conv_bwd_filter");
   if (dw == nullptr) return MLIIS_OK;
