@@ -248,32 +248,9 @@ __global__ __launch_bounds__(256) void bn_apply_fused_k(const float* __restrict_
   __shared__ __attribute__((aligned(16))) float s_mean[kChanBlock], s_rstd[kChanBlock];
   const int t = threadIdx.x;
   const int c0 = blockIdx.x * kChanBlock;
-  double s, ss;
-  fold32(f.part, f.nblk, C, c0, smd, s, ss);
-  if (t < 32) {
-    double m = s * f.inv_n;
-    double var = ss * f.inv_n - m * m;
-    if (var < 0.0) var = 0.0;
-    const float mf = (float)m, rf = (float)(1.0 / sqrt(var + (double)f.eps));
-    s_mean[t] = mf;
-    s_rstd[t] = rf;
-    const int c = c0 + t;
-    if (blockIdx.y == 0 && c < C) {
-      f.mean[c] = mf;
-      f.rstd[c] = rf;
-      if (f.moving_mean != nullptr) {
-        const float mm = f.moving_mean[c], mv = f.moving_var[c];
-        f.moving_mean[c] = mm - (mm - mf) * f.one_minus_momentum;
-        f.moving_var[c] = mv - (mv - (float)(var * (double)f.ema_var_factor)) * f.one_minus_momentum;
-      }
-    }
-  }
-  __syncthreads();
   const int q = t & 7, rl = t >> 3;
   const bool cok = c0 + q * 4 < C;
-  if (!cok && pool_part == nullptr) return;
-  const int c = cok ? c0 + q * 4 : 0;   // (pooling: surplus lanes stay for the reduction, with an empty row range)
-  const float4 m = ld4(s_mean + q * 4), rs = ld4(s_rstd + q * 4), g = ld4(gamma + c), b = ld4(beta + c);
+  const int c = cok ? c0 + q * 4 : 0;   // surplus lanes shadow channel 0 with an empty row range (they stay for the reductions)
   // row range: plain chunks of rows_per_block, or (pooling) chunk (blockIdx.y % pool_chunks) of image (blockIdx.y / pool_chunks)
   long long r0 = (long long)blockIdx.y * rows_per_block, r1 = r0 + rows_per_block;
   if (pool_part != nullptr) {
@@ -284,8 +261,41 @@ __global__ __launch_bounds__(256) void bn_apply_fused_k(const float* __restrict_
   }
   if (r1 > rows) r1 = rows;
   if (!cok) r1 = r0;
+  // The first batch of rows does not depend on the statistics: fetch it BEFORE folding them, so the small-map launches (one batch
+  // per thread) pay one memory round trip instead of two.
+  long long r = r0 + rl;
+  float4 v0[kBatch], rv0[kBatch];
+#pragma unroll
+  for (int u = 0; u < kBatch; ++u) {
+    const long long ru = r + u * kRowLanes;
+    const long long rr = ru < r1 ? ru : 0;
+    v0[u] = ld4(x + rr * ldx + c);
+    rv0[u] = res != nullptr ? ld4(res + rr * ldr + c) : f4zero();
+  }
+  double s, ss;
+  fold32(f.part, f.nblk, C, c0, smd, s, ss);
+  if (t < 32) {
+    double m = s * f.inv_n;
+    double var = ss * f.inv_n - m * m;
+    if (var < 0.0) var = 0.0;
+    const float mf = (float)m, rf = (float)(1.0 / sqrt(var + (double)f.eps));
+    s_mean[t] = mf;
+    s_rstd[t] = rf;
+    const int cc = c0 + t;
+    if (blockIdx.y == 0 && cc < C) {
+      f.mean[cc] = mf;
+      f.rstd[cc] = rf;
+      if (f.moving_mean != nullptr) {
+        const float mm = f.moving_mean[cc], mv = f.moving_var[cc];
+        f.moving_mean[cc] = mm - (mm - mf) * f.one_minus_momentum;
+        f.moving_var[cc] = mv - (mv - (float)(var * (double)f.ema_var_factor)) * f.one_minus_momentum;
+      }
+    }
+  }
+  __syncthreads();
+  const float4 m = ld4(s_mean + q * 4), rs = ld4(s_rstd + q * 4), g = ld4(gamma + c), b = ld4(beta + c);
   float4 pool = f4zero();   // sum of this thread's outputs (squeeze-excite pooling, training)
-  auto finish = [&](long long r, float4 v, float4 rv) {
+  auto finish = [&](long long rw, float4 v, float4 rv) {
     if (pre_swish) v = make_float4(swish_f(v.x), swish_f(v.y), swish_f(v.z), swish_f(v.w));
     float4 o;
     o.x = fmaf((v.x - m.x) * rs.x, g.x, b.x);
@@ -293,12 +303,15 @@ __global__ __launch_bounds__(256) void bn_apply_fused_k(const float* __restrict_
     o.z = fmaf((v.z - m.z) * rs.z, g.z, b.z);
     o.w = fmaf((v.w - m.w) * rs.w, g.w, b.w);
     if (post_swish) o = make_float4(swish_f(o.x), swish_f(o.y), swish_f(o.z), swish_f(o.w));
-    if (img_scale != nullptr) o = f4scale(o, img_scale[(int)r / rows_per_img]);
+    if (img_scale != nullptr) o = f4scale(o, img_scale[(int)rw / rows_per_img]);
     if (res != nullptr) o = f4add(o, rv);
     pool = f4add(pool, o);
-    st4(y + r * ldy + c, o);
+    st4(y + rw * ldy + c, o);
   };
-  long long r = r0 + rl;
+#pragma unroll
+  for (int u = 0; u < kBatch; ++u)
+    if (r + u * kRowLanes < r1) finish(r + u * kRowLanes, v0[u], rv0[u]);
+  r += kBatch * kRowLanes;
   for (; r + (kBatch - 1) * kRowLanes < r1; r += kBatch * kRowLanes) {
     float4 v[kBatch], rv[kBatch];
 #pragma unroll
@@ -411,28 +424,38 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fused_k(BnBwdCommon p, long 
   __shared__ __attribute__((aligned(16))) float s_c1[kChanBlock], s_c2[kChanBlock];
   const int t = threadIdx.x;
   const int c0 = blockIdx.x * kChanBlock;
+  const int q = t & 7, rl = t >> 3;
+  const bool cok = c0 + q * 4 < p.C;
+  const int c = cok ? c0 + q * 4 : 0;
+  long long r1 = (long long)(blockIdx.y + 1) * rows_per_block;
+  if (r1 > rows) r1 = rows;
+  long long r = (long long)blockIdx.y * rows_per_block + rl;
+  if (!cok) r1 = r;
+  // first batch of rows fetched BEFORE the fold of the gradient sums (it does not depend on them): one round trip on small maps
+  BnBwdCommon::Raw raw0[kBatch];
+#pragma unroll
+  for (int u = 0; u < kBatch; ++u) {
+    const long long ru = r + u * kRowLanes;
+    p.load_raw(ru < r1 ? ru : 0, c, raw0[u]);
+  }
   double s, sx;
   fold32(part, nblk, p.C, c0, smd, s, sx);
   if (t < 32) {
     s_c1[t] = (float)(s * inv_n);
     s_c2[t] = (float)(sx * inv_n);
-    const int c = c0 + t;
-    if (blockIdx.y == 0 && c < p.C) {
-      dbeta[c] = (float)s;
-      dgamma[c] = (float)sx;
+    const int cc = c0 + t;
+    if (blockIdx.y == 0 && cc < p.C) {
+      dbeta[cc] = (float)s;
+      dgamma[cc] = (float)sx;
     }
   }
   __syncthreads();
-  const int q = t & 7, rl = t >> 3;
-  const int c = c0 + q * 4;
-  if (c >= p.C) return;
+  if (!cok) return;
   const float4 a = ld4(s_c1 + q * 4), b = ld4(s_c2 + q * 4), ga = ld4(p.gamma + c), rs = ld4(p.rstd + c);
-  long long r1 = (long long)(blockIdx.y + 1) * rows_per_block;
-  if (r1 > rows) r1 = rows;
-  auto finish = [&](long long r, const BnBwdCommon::Raw& raw) {
+  auto finish = [&](long long rw, const BnBwdCommon::Raw& raw) {
     float4 xin, xhat, g;
-    skip.put(r, c, raw.g);
-    p.finish(r, c, raw, xin, xhat, g);
+    skip.put(rw, c, raw.g);
+    p.finish(rw, c, raw, xin, xhat, g);
     float4 d;
     d.x = ga.x * rs.x * (g.x - a.x - xhat.x * b.x);
     d.y = ga.y * rs.y * (g.y - a.y - xhat.y * b.y);
@@ -444,9 +467,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fused_k(BnBwdCommon p, long 
       d.z *= swish_grad_f(xin.z);
       d.w *= swish_grad_f(xin.w);
     }
-    st4(dx + r * lddx + c, d);
+    st4(dx + rw * lddx + c, d);
   };
-  long long r = (long long)blockIdx.y * rows_per_block + rl;
+#pragma unroll
+  for (int u = 0; u < kBatch; ++u)
+    if (r + u * kRowLanes < r1) finish(r + u * kRowLanes, raw0[u]);
+  r += kBatch * kRowLanes;
   for (; r + (kBatch - 1) * kRowLanes < r1; r += kBatch * kRowLanes) {
     BnBwdCommon::Raw raw[kBatch];
 #pragma unroll
