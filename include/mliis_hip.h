@@ -154,9 +154,13 @@ int mliis_colsum(const float* a, int lda, const float* b, int ldb, long long row
  *      finished vector); s = scale * sum_chunks is what the MLP sees and, if s_out is given, what is kept for the backward pass. */
 int mliis_se_mlp_fwd(const float* s_part, int chunks, float scale, float* s_out, const float* w1, const float* b1, const float* w2,
                      const float* b2, float* hpre, float* gate, int N, int C, int R, hipStream_t stream);
+/*      dw1 .. db2 all NULL: the weight gradients are left to mliis_se_wgrad_batched (one launch for every block of a backward pass;
+ *      desc = device int64 [ndesc][12] {s, hpre, dpre1, dpre2, dw1, db1, dw2, db2 as device addresses, N, C, R, tile_begin}, a tile =
+ *      256 of the 2*C*R + C + R gradient elements of a block, tile_begin = running sum of ceil(elements / 256)). */
 int mliis_se_mlp_bwd(const float* dgate, const float* gate, const float* s, const float* hpre, const float* w1, const float* w2,
                      float* dpre1, float* dpre2, float* chan_add, float* dw1, float* db1, float* dw2, float* db2, int N, int C, int R,
                      int HW, hipStream_t stream);
+int mliis_se_wgrad_batched(const long long* desc, int ndesc, long long total_tiles, hipStream_t stream);
 /*      y[m,c] (+)= x[m,c] * S[n(m),c] + A[n(m),c]  (x, S, A optional): gate apply, tf.tile of pooled vectors, pooled-gradient
  *      broadcast, strided channel-slice copy (tf.concat, efficientlab.py:208,222). */
 int mliis_chan_affine(const float* x, int ldx, const float* S, const float* A, float* y, int ldy, long long rows, int C,

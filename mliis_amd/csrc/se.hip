@@ -151,13 +151,12 @@ __global__ __launch_bounds__(kSeThreads) void se_mlp_bwd_k(const float* __restri
 }
 
 // one thread per weight element, loops over images (deterministic)
-__global__ __launch_bounds__(256) void se_wgrad_k(const float* __restrict__ s, const float* __restrict__ hpre,
-                                                  const float* __restrict__ dpre1, const float* __restrict__ dpre2,
-                                                  float* __restrict__ dw1, float* __restrict__ db1, float* __restrict__ dw2,
-                                                  float* __restrict__ db2, int N, int C, int R) {
+__device__ __forceinline__ void se_wgrad_elem(int i, const float* __restrict__ s, const float* __restrict__ hpre,
+                                              const float* __restrict__ dpre1, const float* __restrict__ dpre2,
+                                              float* __restrict__ dw1, float* __restrict__ db1, float* __restrict__ dw2,
+                                              float* __restrict__ db2, int N, int C, int R) {
   const int CR = C * R;
   const int total = 2 * CR + C + R;
-  const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
   float a = 0.f;
   if (i < CR) {  // dw1[c][j] = sum_n s[n][c] * dpre1[n][j]
@@ -178,6 +177,30 @@ __global__ __launch_bounds__(256) void se_wgrad_k(const float* __restrict__ s, c
     for (int n = 0; n < N; ++n) a += dpre1[(long long)n * R + j];
     db1[j] = a;
   }
+}
+
+__global__ __launch_bounds__(256) void se_wgrad_k(const float* __restrict__ s, const float* __restrict__ hpre,
+                                                  const float* __restrict__ dpre1, const float* __restrict__ dpre2,
+                                                  float* __restrict__ dw1, float* __restrict__ db1, float* __restrict__ dw2,
+                                                  float* __restrict__ db2, int N, int C, int R) {
+  se_wgrad_elem(blockIdx.x * 256 + threadIdx.x, s, hpre, dpre1, dpre2, dw1, db1, dw2, db2, N, C, R);
+}
+
+// The squeeze-excite weight gradients of ALL blocks of a backward pass in one launch (nothing downstream needs them before the
+// optimizer).  desc: device int64 [ndesc][12] = {s, hpre, dpre1, dpre2, dw1, db1, dw2, db2 (device addresses), N, C, R, tile_begin};
+// block b handles 256 consecutive elements of the descriptor whose tile range contains b.
+__global__ __launch_bounds__(256) void se_wgrad_batched_k(const long long* __restrict__ desc, int ndesc) {
+  const long long tile = blockIdx.x;
+  int lo = 0, hi = ndesc - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (desc[(long long)mid * 12 + 11] <= tile) lo = mid; else hi = mid - 1;
+  }
+  const long long* d = desc + (long long)lo * 12;
+  se_wgrad_elem((int)(tile - d[11]) * 256 + threadIdx.x, reinterpret_cast<const float*>(d[0]), reinterpret_cast<const float*>(d[1]),
+                reinterpret_cast<const float*>(d[2]), reinterpret_cast<const float*>(d[3]), reinterpret_cast<float*>(d[4]),
+                reinterpret_cast<float*>(d[5]), reinterpret_cast<float*>(d[6]), reinterpret_cast<float*>(d[7]), (int)d[8], (int)d[9],
+                (int)d[10]);
 }
 
 // y[m, c] (+)= x[m, c] * S[n(m), c] + A[n(m), c]      (x, S, A each optional)
@@ -222,16 +245,25 @@ int mliis_se_mlp_fwd(const float* s_part, int chunks, float scale, float* s_out,
 int mliis_se_mlp_bwd(const float* dgate, const float* gate, const float* s, const float* hpre, const float* w1, const float* w2,
                      float* dpre1, float* dpre2, float* chan_add, float* dw1, float* db1, float* dw2, float* db2, int N, int C, int R,
                      int HW, hipStream_t stream) {
-  MLIIS_REQUIRE(dgate && gate && s && hpre && w1 && w2 && dpre1 && dpre2 && chan_add && dw1 && db1 && dw2 && db2, MLIIS_ERR_ARG,
-                "se_mlp_bwd: null pointer");
+  MLIIS_REQUIRE(dgate && gate && s && hpre && w1 && w2 && dpre1 && dpre2 && chan_add, MLIIS_ERR_ARG, "se_mlp_bwd: null pointer");
+  MLIIS_REQUIRE((dw1 && db1 && dw2 && db2) || (!dw1 && !db1 && !dw2 && !db2), MLIIS_ERR_ARG,
+                "se_mlp_bwd: the four weight-gradient outputs come together (all NULL = deferred to mliis_se_wgrad_batched)");
   MLIIS_REQUIRE(N > 0 && C > 0 && R > 0 && R <= kMaxR && HW > 0, MLIIS_ERR_ARG, "se_mlp_bwd: bad shape");
   MLIIS_REQUIRE(C <= 8192, MLIIS_ERR_UNSUPPORTED, "se_mlp_bwd: C > 8192");
   hipLaunchKernelGGL(se_mlp_bwd_k, dim3(N), dim3(kSeThreads), (size_t)C * sizeof(float), stream, dgate, gate, hpre, w1, w2, dpre2, dpre1, chan_add, C, R,
                      1.0f / (float)HW);
   MLIIS_CHECK_LAUNCH("se_mlp_bwd");
+  if (dw1 == nullptr) return MLIIS_OK;
   int total = 2 * C * R + C + R;
   hipLaunchKernelGGL(se_wgrad_k, dim3(ceil_div(total, 256)), dim3(256), 0, stream, s, hpre, dpre1, dpre2, dw1, db1, dw2, db2, N, C, R);
   MLIIS_CHECK_LAUNCH("se_wgrad");
+  return MLIIS_OK;
+}
+
+int mliis_se_wgrad_batched(const long long* desc, int ndesc, long long total_tiles, hipStream_t stream) {
+  MLIIS_REQUIRE(desc && ndesc > 0 && total_tiles > 0, MLIIS_ERR_ARG, "se_wgrad_batched: bad arguments");
+  hipLaunchKernelGGL(se_wgrad_batched_k, dim3((unsigned)total_tiles), dim3(256), 0, stream, desc, ndesc);
+  MLIIS_CHECK_LAUNCH("se_wgrad_batched");
   return MLIIS_OK;
 }
 

@@ -133,6 +133,15 @@ class _Plan:
             add(k1, lib.size("mliis_conv2d_bwd_filter_workspace_floats", N, m.h, m.h, m.c_cat, co, 3), 9 * m.c_cat * co)
             add(kf, lib.size("mliis_conv2d_bwd_filter_workspace_floats", N, m.h, m.h, 2 * co, co, 3), 9 * 2 * co * co,
                 seg=(2 * co * co, m.c_pyr * co, 0))
+        # squeeze-excite weight gradients of all blocks: one launch (descriptor table of device addresses)
+        rows_se, se_tile = [], 0
+        for b, B, nm in zip([b for b in a.blocks if b.executed], self.blocks, L.n_blocks):
+            se = nm["se"]
+            rows_se.append([B["s"].data_ptr(), B["hpre"].data_ptr(), B["dpre1"].data_ptr(), B["dpre2"].data_ptr()] +
+                           [A.g[k].data_ptr() for k in se] + [N, b.cexp, b.se, se_tile])
+            se_tile += -(-(2 * b.cexp * b.se + b.cexp + b.se) // 256)
+        self.se_desc = torch.tensor(rows_se, dtype=torch.int64, device=dev)
+        self.se_tiles = se_tile
         self.fold_buf = buf(off + 16)
         self.fold_part = {k: self.fold_buf[o:o + n] for k, (o, n) in regs.items()}
         self.fold_desc = torch.tensor(rows, dtype=torch.int64, device=dev)
@@ -509,8 +518,9 @@ class Learner:
             ops.conv2d_bwd_data(dout, w[nm["w_proj"]], 1, out=da2, ws=ws)
             ops.colsum(da2, B["a1"], nseg=N, out=B["dgate"], ws=ws)
             se = nm["se"]
-            outs = dict(dpre1=B["dpre1"], dpre2=B["dpre2"], chan_add=B["chan_add"], dw1=g[se[0]], db1=g[se[1]], dw2=g[se[2]], db2=g[se[3]])
-            ops.se_mlp_bwd(B["dgate"], B["gate"], B["s"], B["hpre"], w[se[0]], w[se[2]], hw, outs)
+            # (the SE weight gradients of all blocks are computed by one batched launch after the loop: P.se_desc)
+            ops.se_mlp_bwd(B["dgate"], B["gate"], B["s"], B["hpre"], w[se[0]], w[se[2]], hw,
+                           dict(dpre1=B["dpre1"], dpre2=B["dpre2"], chan_add=B["chan_add"]))
             bn_b(B["z1"], da2, B["st1"], nm["bn1"], da2, post=True, chan_scale=B["gate"], chan_add=B["chan_add"])
             dw_in = B["a0"] if b.expand != 1 else B["x_in"]
             side(lambda dw_in=dw_in, da2=da2, b=b, nm=nm: ops.dwconv_bwd_filter(dw_in, da2, b.k, b.stride, partial=P.fold_part[nm["w_dw"]]))
@@ -535,6 +545,7 @@ class Learner:
             join = torch.cuda.Event()
             join.record(self.side_stream)
             self.stream.wait_event(join)
+        ops.se_wgrad_batched(P.se_desc, P.se_tiles)
         # all slabs written -> one batched fold into the gradient arena
         ops.fold_batched(P.fold_buf, A.grad, P.fold_desc, P.fold_tiles)
 

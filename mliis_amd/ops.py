@@ -384,7 +384,13 @@ def se_mlp_fwd(s, w1, b1, w2, b2, hpre=None, gate=None, chunks=0, scale=1.0, s_o
     return hpre, gate
 
 
+def se_wgrad_batched(desc, total_tiles):
+    """Deferred squeeze-excite weight gradients of every block in one launch (desc: device int64 [n,12], include/mliis_hip.h)."""
+    lib.call("mliis_se_wgrad_batched", _ptr(desc), int(desc.shape[0]), int(total_tiles), _stream())
+
+
 def se_mlp_bwd(dgate, gate, s, hpre, w1, w2, hw, outs=None):
+    """outs without "dw1".."db2": the weight gradients are deferred to se_wgrad_batched."""
     N, C_ = s.shape
     R = hpre.shape[1]
     dev = s.device
@@ -393,7 +399,8 @@ def se_mlp_bwd(dgate, gate, s, hpre, w1, w2, hw, outs=None):
                     dw1=torch.empty((1, 1, C_, R), device=dev), db1=torch.empty(R, device=dev), dw2=torch.empty((1, 1, R, C_), device=dev),
                     db2=torch.empty(C_, device=dev))
     lib.call("mliis_se_mlp_bwd", _ptr(dgate), _ptr(gate), _ptr(s), _ptr(hpre), _ptr(w1), _ptr(w2), _ptr(outs["dpre1"]), _ptr(outs["dpre2"]),
-             _ptr(outs["chan_add"]), _ptr(outs["dw1"]), _ptr(outs["db1"]), _ptr(outs["dw2"]), _ptr(outs["db2"]), N, C_, R, hw, _stream())
+             _ptr(outs["chan_add"]), _ptr(outs.get("dw1")), _ptr(outs.get("db1")), _ptr(outs.get("dw2")), _ptr(outs.get("db2")), N, C_, R, hw,
+             _stream())
     return outs
 
 
