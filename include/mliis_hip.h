@@ -136,11 +136,15 @@ int mliis_bn_apply_fused(const float* x, int ldx, float* y, int ldy, long long r
                          const float* res, int ldr, float* pool_part, size_t pool_floats, int* pool_chunks, hipStream_t stream);
 /*      workspace: mliis_colreduce_workspace_floats(rows, C, 1, 2) floats.  dskip (nullable): the same pass also writes the
  *      identity-skip gradient dskip[r,c] (+)= dy[r,c] (MBConv residual, efficientnet_model.py:286-288), so it needs no launch of
+ *      its own.  dxsum_part (nullable): per-row-chunk column sums of dx, [chunks][C] with chunks * C = mliis_bn_bwd_dxsum_floats(rows, C) --
+ *      slabs for mliis_fold_batched: the bias gradient of a conv -> swish -> BN stack (efficientlab.py:185-190) without a pass of
  *      its own. */
+size_t mliis_bn_bwd_dxsum_floats(long long rows, int C);
 int mliis_bn_bwd(const float* x, int ldx, const float* dy, int lddy, float* dx, int lddx, long long rows, int C, int rows_per_img,
                  const float* mean, const float* rstd, const float* gamma, const float* beta, int pre_swish, int post_swish,
                  const float* img_scale, const float* chan_scale, const float* chan_add, float* dgamma, float* dbeta, float* dskip,
-                 int lddskip, int dskip_accumulate, float* ws, size_t ws_floats, hipStream_t stream);
+                 int lddskip, int dskip_accumulate, float* dxsum_part, size_t dxsum_floats, float* ws, size_t ws_floats,
+                 hipStream_t stream);
 
 /* ---- per-image column sums: out[seg,c] (+)= scale * sum_rows a[row,c] * b[row,c]  (b nullable).  Serves tf.reduce_mean over
  *      H,W of squeeze-excite (efficientnet_model.py:247) and of the RSD pooled branch (efficientlab.py:192-197), their

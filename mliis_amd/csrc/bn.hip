@@ -419,7 +419,8 @@ struct SkipOut {
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_fused_k(BnBwdCommon p, long long rows, const float* __restrict__ part, int nblk,
                                                             double inv_n, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                            float* __restrict__ dx, int lddx, int rows_per_block, SkipOut skip) {
+                                                            float* __restrict__ dx, int lddx, int rows_per_block, SkipOut skip,
+                                                            float* __restrict__ dxsum_part) {
   __shared__ double smd[2 * 32 * 32];
   __shared__ __attribute__((aligned(16))) float s_c1[kChanBlock], s_c2[kChanBlock];
   const int t = threadIdx.x;
@@ -450,8 +451,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fused_k(BnBwdCommon p, long 
     }
   }
   __syncthreads();
-  if (!cok) return;
+  if (!cok && dxsum_part == nullptr) return;   // (surplus lanes stay for the column-sum reduction, with an empty row range)
   const float4 a = ld4(s_c1 + q * 4), b = ld4(s_c2 + q * 4), ga = ld4(p.gamma + c), rs = ld4(p.rstd + c);
+  float4 dsum = f4zero();   // column sum of this thread's dx rows (bias gradient of a conv -> swish -> BN stack)
   auto finish = [&](long long rw, const BnBwdCommon::Raw& raw) {
     float4 xin, xhat, g;
     skip.put(rw, c, raw.g);
@@ -467,6 +469,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fused_k(BnBwdCommon p, long 
       d.z *= swish_grad_f(xin.z);
       d.w *= swish_grad_f(xin.w);
     }
+    dsum = f4add(dsum, d);
     st4(dx + rw * lddx + c, d);
   };
 #pragma unroll
@@ -485,6 +488,20 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fused_k(BnBwdCommon p, long 
     p.load_raw(r, c, raw);
     finish(r, raw);
   }
+  if (dxsum_part == nullptr) return;   // (uniform)
+#pragma unroll
+  for (int off = 8; off < 64; off <<= 1) {
+    dsum.x += __shfl_xor(dsum.x, off);
+    dsum.y += __shfl_xor(dsum.y, off);
+    dsum.z += __shfl_xor(dsum.z, off);
+    dsum.w += __shfl_xor(dsum.w, off);
+  }
+  float4* smp = reinterpret_cast<float4*>(smd);   // the fold is done with it
+  __syncthreads();
+  if ((t & 63) < 8) smp[(t >> 6) * 8 + q] = dsum;
+  __syncthreads();
+  if (t < 8 && c0 + t * 4 < p.C)
+    st4(dxsum_part + (long long)blockIdx.y * p.C + c0 + t * 4, f4add(f4add(smp[t], smp[8 + t]), f4add(smp[16 + t], smp[24 + t])));
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -718,7 +735,8 @@ int mliis_bn_apply(const float* x, int ldx, float* y, int ldy, long long rows, i
 int mliis_bn_bwd(const float* x, int ldx, const float* dy, int lddy, float* dx, int lddx, long long rows, int C,
                  int rows_per_img, const float* mean, const float* rstd, const float* gamma, const float* beta, int pre_swish,
                  int post_swish, const float* img_scale, const float* chan_scale, const float* chan_add, float* dgamma,
-                 float* dbeta, float* dskip, int lddskip, int dskip_accumulate, float* ws, size_t ws_floats, hipStream_t stream) {
+                 float* dbeta, float* dskip, int lddskip, int dskip_accumulate, float* dxsum_part, size_t dxsum_floats, float* ws,
+                 size_t ws_floats, hipStream_t stream) {
   MLIIS_REQUIRE(x && dy && dx && mean && rstd && gamma && beta && dgamma && dbeta && ws, MLIIS_ERR_ARG, "bn_bwd: null pointer");
   MLIIS_REQUIRE(dskip == nullptr || (aligned16(dskip) && (lddskip & 3) == 0 && lddskip >= C && dskip != dx), MLIIS_ERR_ARG,
                 "bn_bwd: bad skip-gradient output");
@@ -737,8 +755,10 @@ int mliis_bn_bwd(const float* x, int ldx, const float* dy, int lddy, float* dx, 
   if (rc) return rc;
   int gx, gy, rpb;
   chan_grid(rows, C, &gx, &gy, &rpb);
+  MLIIS_REQUIRE(dxsum_part == nullptr || (aligned16(dxsum_part) && (size_t)gy * C <= dxsum_floats), MLIIS_ERR_WORKSPACE,
+                "bn_bwd: column-sum buffer unaligned or too small (%zu floats needed)", (size_t)gy * C);
   hipLaunchKernelGGL(bn_bwd_apply_fused_k, dim3(gx, gy), dim3(256), 0, stream, p, rows, ws, g.nblk, 1.0 / (double)rows, dgamma, dbeta, dx,
-                     lddx, rpb, skip);
+                     lddx, rpb, skip, dxsum_part);
   MLIIS_CHECK_LAUNCH("bn_bwd_apply_fused");
   return MLIIS_OK;
 }
@@ -795,6 +815,14 @@ int mliis_bn_apply_fused(const float* x, int ldx, float* y, int ldy, long long r
 }
 
 int mliis_fold_tile_outputs(void) { return kFoldTile; }
+
+// floats of the dxsum_part output of mliis_bn_bwd: [row chunks][C] (the number of row chunks is its slab count for mliis_fold_batched)
+size_t mliis_bn_bwd_dxsum_floats(long long rows, int C) {
+  if (rows <= 0 || C <= 0 || (C & 3)) return 0;
+  int gx, gy, rpb;
+  chan_grid(rows, C, &gx, &gy, &rpb);
+  return (size_t)gy * C;
+}
 
 int mliis_fold_batched(const float* part_base, float* out_base, const long long* desc, int ndesc, long long total_tiles,
                        hipStream_t stream) {

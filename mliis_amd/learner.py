@@ -127,8 +127,10 @@ class _Plan:
             add(nm["w_dw"], lib.size("mliis_dwconv_bwd_filter_workspace_floats", N, b.h_in, b.h_in, ce, b.k, b.stride), b.k * b.k * ce)
             add(nm["w_proj"], lib.size("mliis_conv2d_bwd_filter_workspace_floats", N, b.h_out, b.h_out, ce, b.cout, 1), ce * b.cout)
         for m, nm in zip(a.rsd, L.n_rsd):
-            (k0, _, _), (k1, _, _), (kf, _, _) = nm
+            (k0, b0_, _), (k1, b1_, _), (kf, _, _) = nm
             co = m.c_out
+            for bias in (b0_, b1_):   # conv-bias gradients: column sums of dz leave the BN backward pass as slabs
+                add(bias, ops.bn_bwd_dxsum_floats(N * m.h * m.h, co), co)
             add(k0, lib.size("mliis_conv2d_bwd_filter_workspace_floats", N, m.h, m.h, m.c_cat, co, 1), m.c_cat * co)
             add(k1, lib.size("mliis_conv2d_bwd_filter_workspace_floats", N, m.h, m.h, m.c_cat, co, 3), 9 * m.c_cat * co)
             add(kf, lib.size("mliis_conv2d_bwd_filter_workspace_floats", N, m.h, m.h, 2 * co, co, 3), 9 * 2 * co * co,
@@ -455,9 +457,10 @@ class Learner:
                 fn()
 
         def bn_b(xin, dy, st, prefix, dx, pre=False, post=False, img_scale=None, chan_scale=None, chan_add=None, dskip=None,
-                 dskip_accumulate=False):
+                 dskip_accumulate=False, dxsum_part=None):
             ops.bn_bwd(xin, dy, st[0], st[1], w[prefix + "/gamma"], w[prefix + "/beta"], pre, post, img_scale, chan_scale, chan_add, dx=dx,
-                       dgamma=g[prefix + "/gamma"], dbeta=g[prefix + "/beta"], ws=ws, dskip=dskip, dskip_accumulate=dskip_accumulate)
+                       dgamma=g[prefix + "/gamma"], dbeta=g[prefix + "/beta"], ws=ws, dskip=dskip, dskip_accumulate=dskip_accumulate,
+                       dxsum_part=dxsum_part)
 
         rs = sorted([x.scope_index + 1 for x in a.rsd], reverse=True)
         for j in range(len(a.rsd) - 1, -1, -1):
@@ -471,12 +474,10 @@ class Learner:
             side(lambda pyr=pyr, dzf=D["dzf"], kf=kf: ops.conv2d_bwd_filter(pyr, dzf, 3, 1, partial=P.fold_part[kf]))   # rows of the 2*co convolved channels
             ops.conv2d_bwd_data(D["dzf"], w[kf], 1, ci_begin=0, ci_count=2 * co, out=dpyr, ws=ws)
             d0, d1 = dpyr[..., :co], dpyr[..., co:2 * co]
-            bn_b(D["z0"], d0, D["st0"], n0, d0, pre=True)
-            ops.colsum(d0, None, out=g[b0].view(1, -1), ws=ws)
+            bn_b(D["z0"], d0, D["st0"], n0, d0, pre=True, dxsum_part=P.fold_part[b0])   # + conv-bias gradient slabs (batched fold)
             side(lambda cat=cat, d0=d0, k0=k0: ops.conv2d_bwd_filter(cat, d0, 1, 1, partial=P.fold_part[k0]))
             ops.conv2d_bwd_data(d0, w[k0], 1, out=dcat, ws=ws)
-            bn_b(D["z1"], d1, D["st1"], n1, d1, pre=True)
-            ops.colsum(d1, None, out=g[b1].view(1, -1), ws=ws)
+            bn_b(D["z1"], d1, D["st1"], n1, d1, pre=True, dxsum_part=P.fold_part[b1])
             side(lambda cat=cat, d1=d1, k1=k1: ops.conv2d_bwd_filter(cat, d1, 3, 2, partial=P.fold_part[k1]))
             ops.conv2d_bwd_data(d1, w[k1], 2, out=dcat, accumulate=True, ws=ws)
             ops.chan_affine(None, A=D["dpool"], out=dcat, accumulate=True)   # d(mean)/d(cat) = dpool / (H*W) on every pixel

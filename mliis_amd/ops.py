@@ -341,8 +341,9 @@ def bn_apply(x, mean, rstd, gamma, beta, pre_swish=False, post_swish=False, img_
 
 
 def bn_bwd(x, dy, mean, rstd, gamma, beta, pre_swish=False, post_swish=False, img_scale=None, chan_scale=None, chan_add=None, dx=None,
-           dgamma=None, dbeta=None, rows_per_img=None, ws: Optional[Workspace] = None, dskip=None, dskip_accumulate=False):
-    """dskip (optional): the pass also writes dskip (+)= dy, the gradient of an identity skip around the normalised branch."""
+           dgamma=None, dbeta=None, rows_per_img=None, ws: Optional[Workspace] = None, dskip=None, dskip_accumulate=False, dxsum_part=None):
+    """dskip (optional): the pass also writes dskip (+)= dy, the gradient of an identity skip around the normalised branch.
+    dxsum_part (optional, bn_bwd_dxsum_floats(rows, C) floats): per-row-chunk column sums of dx (slabs for fold_batched)."""
     rows, C_, ldx = rows_ld(x)
     _, _, lddy = rows_ld(dy)
     dx = torch.empty(x.shape, dtype=torch.float32, device=x.device) if dx is None else dx
@@ -354,8 +355,13 @@ def bn_bwd(x, dy, mean, rstd, gamma, beta, pre_swish=False, post_swish=False, im
     buf = ws.get(lib.size("mliis_colreduce_workspace_floats", rows, C_, 1, 2))
     lib.call("mliis_bn_bwd", _ptr(x), ldx, _ptr(dy), lddy, _ptr(dx), lddx, rows, C_, rpi, _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta),
              int(pre_swish), int(post_swish), _ptr(img_scale), _ptr(chan_scale), _ptr(chan_add), _ptr(dgamma), _ptr(dbeta), _ptr(dskip),
-             rows_ld(dskip)[2] if dskip is not None else 0, int(dskip_accumulate), _ptr(buf), buf.numel(), _stream())
+             rows_ld(dskip)[2] if dskip is not None else 0, int(dskip_accumulate), _ptr(dxsum_part),
+             dxsum_part.numel() if dxsum_part is not None else 0, _ptr(buf), buf.numel(), _stream())
     return dx, dgamma, dbeta
+
+
+def bn_bwd_dxsum_floats(rows, C_):
+    return lib.size("mliis_bn_bwd_dxsum_floats", rows, C_)
 
 
 def colsum(a, b=None, nseg=1, scale=1.0, out=None, accumulate=False, ws: Optional[Workspace] = None):

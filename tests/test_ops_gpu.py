@@ -194,6 +194,15 @@ def test_bn_train_fwd_bwd(pre, post, C, rows_hw, N):
                                f32(chan_scale, d), f32(chan_add, d), dskip=sk, dskip_accumulate=acc)
         assert torch.equal(dx2, dx)
         close(sk, dy + skip0 if acc else dy, 1e-6, "skip gradient acc={}".format(acc))
+    # column sums of dx as per-row-chunk slabs (conv-bias gradient of a conv -> swish -> BN stack)
+    nfl = ops.bn_bwd_dxsum_floats(n, C)
+    slab = torch.full((nfl + 8,), 5.0, device=d)
+    dx3, _, _ = ops.bn_bwd(xg, f32(dy, d), m, r, f32(gamma, d), f32(beta, d), bool(pre), bool(post), f32(img_scale, d),
+                           f32(chan_scale, d), f32(chan_add, d), dxsum_part=slab)
+    assert torch.equal(dx3, dx) and slab[nfl:].eq(5.0).all()
+    got = slab[:nfl].view(-1, C).double().sum(0).cpu()
+    scale = gx.abs().sum(dim=(0, 1, 2)).max().item()          # (without pre-swish the true column sums are ~0: compare on the sum's scale)
+    assert (got - gx.sum(dim=(0, 1, 2))).abs().max().item() <= 1e-5 * scale, "dx column sums"
     # fused forward: statistics from bn_stats_partial folded inside the apply launch
     for _ in range(1):
         mm2, mv2 = f32(mm0, d), f32(mv0, d)
