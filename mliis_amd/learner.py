@@ -179,9 +179,11 @@ class Learner:
         self.drop_connect = drop_connect
         self.use_graph = use_graph
         self.stream = torch.cuda.Stream(device=self.device)
-        # Optional: weight-gradient GEMMs on a second stream forked inside the HIP graph.  Measured SLOWER on MI355X (4.95 vs 4.56 ms
-        # per step, profiles/r01_notes.md): the cross-stream edges cost more than the idle CUs they fill, so it is off by default.
-        self.overlap_wgrad = os.environ.get("MLIIS_OVERLAP_WGRAD", "0") == "1"
+        # Optional (MLIIS_OVERLAP_WGRAD = 1 | 2): weight-gradient GEMMs on a second stream forked inside the HIP graph, one by one (1) or
+        # handed over at a few points of the backward pass (2, MLIIS_WGRAD_FLUSH = block indices).  Neither beats the single stream
+        # on MI355X (profiles/r01_notes.md), so it is off by default.
+        self.overlap_wgrad = int(os.environ.get("MLIIS_OVERLAP_WGRAD", "0"))
+        self.wgrad_flush_before = set(int(v) for v in os.environ.get("MLIIS_WGRAD_FLUSH", "5").split(",") if v.strip().isdigit())
         self.side_stream = torch.cuda.Stream(device=self.device)
         self.arena = Arena(self.arch, self.device)
         self.arena.init_weights(seed)
@@ -444,17 +446,31 @@ class Learner:
         if not P.rsd:
             has_grad[-1] = True
 
-        def side(fn):
-            """Run a weight-gradient producer on the side stream, ordered after everything queued on the main stream so far.  These
-            kernels only read activations / finished gradient buffers and write their own slab region, so the main stream can go on
-            with the next layer's backward-data chain meanwhile (small layers leave most CUs idle otherwise)."""
-            if not self.overlap_wgrad:
-                return fn()
+        pending = []
+
+        def flush():
+            """(phased overlap) hand the collected weight-gradient producers to the side stream, ordered after everything queued on the
+            main stream so far."""
+            if not pending:
+                return
             ev = torch.cuda.Event()
             ev.record(self.stream)
             with torch.cuda.stream(self.side_stream):
                 self.side_stream.wait_event(ev)
-                fn()
+                for f_ in pending:
+                    f_()
+            pending.clear()
+
+        def side(fn):
+            """A weight-gradient producer.  These kernels only read activations / finished per-layer gradient buffers and write their own
+            slab region, so they may run any time before the batched fold: inline (overlap_wgrad = 0), forked one by one onto the side
+            stream (1), or collected and handed over at a few points of the backward pass (2: the decoder's large MFMA-bound
+            weight-gradient GEMMs then overlap the latency-bound chain of the 14x14 blocks)."""
+            if not self.overlap_wgrad:
+                return fn()
+            pending.append(fn)
+            if self.overlap_wgrad == 1:
+                flush()
 
         def bn_b(xin, dy, st, prefix, dx, pre=False, post=False, img_scale=None, chan_scale=None, chan_add=None, dskip=None,
                  dskip_accumulate=False, dxsum_part=None):
@@ -500,8 +516,11 @@ class Learner:
             ops.chan_affine(dcat[..., m.c_deep:], out=P.blocks[bi]["dout"], accumulate=has_grad[bi])
             has_grad[bi] = True
 
+        flush()
         for bi in range(len(P.blocks) - 1, -1, -1):
             b, B, nm = ex[bi], P.blocks[bi], self.n_blocks[bi]
+            if bi in self.wgrad_flush_before:
+                flush()
             if not has_grad[bi]:
                 raise MliisError("internal: block {} has no upstream gradient".format(bi))
             dout = B["dout"]
@@ -542,6 +561,7 @@ class Learner:
                 has_grad[bi - 1] = True
         bn_b(P.z_stem, P.dstem, P.st_stem, self.n_stem[1], P.dstem, post=True)
         side(lambda: ops.stem_conv_bwd_filter(x, P.dstem, idx, partial=P.fold_part[self.n_stem[0]]))
+        flush()
         if self.overlap_wgrad:
             join = torch.cuda.Event()
             join.record(self.side_stream)
