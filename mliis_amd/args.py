@@ -97,6 +97,8 @@ _FLAGS = [
 _EXT = [
     ("--synthetic-tasks", dict(type=int, default=0, help="use N synthetic tasks instead of --data-dir (no dataset needed)")),
     ("--no-hip-graph", dict(action="store_true", help="launch inner steps eagerly instead of replaying a captured HIP graph")),
+    ("--checkpoint-format", dict(choices=["npz", "tf"], default="npz",
+                                 help="tensor container of written checkpoints: numpy .npz or a TensorFlow TensorBundle (.index/.data)")),
 ]
 
 

@@ -4,9 +4,9 @@
     <dir>/model.ckpt-<step>.npz      all global variables under their TF names (trainables + BN moving statistics)
 
 `tf.train.Saver(max_to_keep=2).save(sess, save_dir/model.ckpt, global_step=i)` (train.py:54,129-131) and
-`latest_checkpoint` (utils/util.py:42-50: regex on the first line of `checkpoint`) are mirrored.  The tensor container is
-numpy's .npz, not a TF TensorBundle (a bundle reader/writer is SURVEY 8(f)-3, not built yet) -- variable names and shapes are
-the reference's, so a converter is a pure re-packaging.
+`latest_checkpoint` (utils/util.py:42-50: regex on the first line of `checkpoint`) are mirrored.  Two tensor containers under the
+same names and shapes: numpy's .npz (default) and the TensorFlow TensorBundle (`fmt="tf"`: model.ckpt-<step>.index +
+.data-00000-of-00001, mliis_amd/tfbundle.py) that tf.train.Saver itself writes; `load` takes whichever is there.
 """
 from __future__ import annotations
 
@@ -28,25 +28,40 @@ def latest_checkpoint(checkpoint_dir: str, ckpt_prefix: str = CKPT_PREFIX) -> st
     return os.path.join(checkpoint_dir, m[0])
 
 
+FORMATS = ("npz", "tf")
+
+
+def _files_of(path: str) -> List[str]:
+    return [path + ".npz", path + ".index", path + ".data-00000-of-00001"]
+
+
 class Saver:
-    def __init__(self, max_to_keep: int = 2):
+    def __init__(self, max_to_keep: int = 2, fmt: str = "npz"):
+        if fmt not in FORMATS:
+            raise ValueError("checkpoint format must be one of {} but is {}".format(FORMATS, fmt))
         self.max_to_keep = max_to_keep
+        self.fmt = fmt
         self.kept: List[str] = []
 
     def save(self, values: Dict[str, np.ndarray], save_dir: str, global_step: int, prefix: str = CKPT_PREFIX) -> str:
         os.makedirs(save_dir, exist_ok=True)
         base = "{}-{}".format(prefix, global_step)
         path = os.path.join(save_dir, base)
-        np.savez(path + ".npz", **{k.replace("/", "|"): v for k, v in values.items()})
+        if self.fmt == "tf":
+            from . import tfbundle
+            tfbundle.write_bundle(path, values)
+        else:
+            np.savez(path + ".npz", **{k.replace("/", "|"): v for k, v in values.items()})
         if base in self.kept:
             self.kept.remove(base)
         self.kept.append(base)
         while self.max_to_keep and len(self.kept) > self.max_to_keep:
             old = self.kept.pop(0)
-            try:
-                os.remove(os.path.join(save_dir, old + ".npz"))
-            except OSError:
-                pass
+            for f in _files_of(os.path.join(save_dir, old)):
+                try:
+                    os.remove(f)
+                except OSError:
+                    pass
         with open(os.path.join(save_dir, "checkpoint"), "w") as f:
             f.write('model_checkpoint_path: "{}"\n'.format(base))
             for b in self.kept:
@@ -55,12 +70,15 @@ class Saver:
 
 
 def load(path: str) -> Dict[str, np.ndarray]:
-    """path: <dir>/model.ckpt-<step> (as returned by latest_checkpoint)."""
+    """path: <dir>/model.ckpt-<step> (as returned by latest_checkpoint); a TensorBundle (.index) or the .npz container."""
+    from . import tfbundle
+    if tfbundle.is_bundle(path):
+        return tfbundle.read_bundle(path)
     with np.load(path + ".npz") as z:
         return {k.replace("|", "/"): z[k] for k in z.files}
 
 
-def save_fine_tuned_checkpoint(values, save_dir: str, task_name: str, eval_sample_num: int, step: int) -> str:
+def save_fine_tuned_checkpoint(values, save_dir: str, task_name: str, eval_sample_num: int, step: int, fmt: str = "npz") -> str:
     """<save_dir>/<task_name>/<eval_sample_num>/model.ckpt-<step>  (utils/util.py:72-81)."""
     d = os.path.join(save_dir, str(task_name), str(eval_sample_num))
-    return Saver(max_to_keep=1).save(values, d, step)
+    return Saver(max_to_keep=1, fmt=fmt).save(values, d, step)

@@ -6,8 +6,8 @@ inner-loop engine.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 run_metasegnet.py ...   (tasks sharded 1/GPU)
 
 Writes the reference's checkpoint directory layout (mliis_amd/checkpoint.py) and `<checkpoint>/meta-test_results.json`.
-Out of scope in this build (clear errors): UHO hyper-parameter search, k-shot learning-curve experiment, host augmentation,
-TF TensorBundle checkpoints.  Data: --data-dir with FSS-1000 TFRecord-GZIP shards
+Out of scope in this build (clear errors): UHO hyper-parameter search, k-shot learning-curve experiment, host augmentation
+(SURVEY.md 8(f)).  Checkpoints: numpy .npz or TensorFlow TensorBundle files (--checkpoint-format tf; restoring takes either).  Data: --data-dir with FSS-1000 TFRecord-GZIP shards
 (mliis_amd/tfrecord.py, no TensorFlow needed) or --synthetic-tasks N.
 """
 import datetime
@@ -84,7 +84,7 @@ def main():
             print("Continuing meta-training from checkpoint: {}".format(path))
             learner.load_named(ckpt.load(path))
         train_gecko(learner, train_set, test_set, args.checkpoint, lr_scheduler=lr_scheduler, augment=args.augment, dist=Dist(),
-                    seed=args.seed, **train_kwargs(args))
+                    seed=args.seed, checkpoint_format=args.checkpoint_format, **train_kwargs(args))
     else:
         path = ckpt.latest_checkpoint(args.checkpoint)
         print("Restoring from checkpoint: {}".format(path))
