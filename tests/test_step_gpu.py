@@ -157,6 +157,21 @@ def test_full_size_step_config2():
     _compare_state(O, L, gO, "full")
 
 
+def test_step_at_384_config5_shapes():
+    """BASELINE config 5 input size (384x384: maps 192/96/48/24, other tile / split plans than 224x224), fp32, N = 2: one step."""
+    _need_gpu()
+    H, S, idx = 384, 2, [1, 0]
+    O, L = _pair(H)
+    x, y = _task(S, H, 2)
+    L.load_task(x, y)
+    dc = _dc(O, 2, 4)
+    lo, gO, _ = R.inner_step(O.a, O.params, O.bn, torch.tensor(x[idx]).double(), torch.tensor(y[idx]).double(), 1e-3, dc)
+    L.inner_step(idx, dc_scales=dc)
+    ll = L.loss_value()
+    assert abs(ll - lo) <= 1e-4 * max(1.0, abs(lo)), (ll, lo)
+    _compare_state(O, L, gO, "384")
+
+
 def test_evaluate_path_matches_oracle():
     """Gecko.evaluate (fine-tune on 5 shots, predict 5 held-out images in inference mode, per-image IoU, restore ALL variables)
     on the HIP learner vs the same host code driving the CPU oracle."""
