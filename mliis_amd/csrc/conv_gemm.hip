@@ -1099,11 +1099,21 @@ struct GemmPlan {
   int tm, nt, gx, gy, gz, chunks_per_split;
 };
 
+// Column tiles per block (16 columns each, at most 8): the widest tile that does not pad the output width by much -- padded
+// columns are wasted MFMAs (N = 136: 3 x 48 columns instead of 2 x 80), narrower tiles re-read the A tile more often.
 static inline int pick_nt(int Nout) {
-  int blocks = (Nout + 127) / 128;
-  int per = (Nout + blocks - 1) / blocks;
-  int nt = (per + 15) / 16;
-  return nt < 1 ? 1 : nt;
+  int best = 1;
+  double best_cost = 1e30;
+  const int tiles = (Nout + 15) / 16;
+  for (int nt = 1; nt <= 8; ++nt) {
+    const int blocks = (tiles + nt - 1) / nt;
+    const double cost = (double)(blocks * nt * 16) / (double)Nout * (1.0 + 0.03 * (8 - nt));
+    if (cost < best_cost - 1e-9 || (cost < best_cost + 1e-9 && nt > best)) {
+      best_cost = cost;
+      best = nt;
+    }
+  }
+  return best;
 }
 
 static inline GemmPlan plan_gemm(long long M, int Nout, int C, int ntaps, int num_cus, int allow_split, bool flat_k) {
@@ -1122,13 +1132,28 @@ static inline GemmPlan plan_gemm(long long M, int Nout, int C, int ntaps, int nu
   // very tall, HBM-bound layers (112x112 maps): 128-row blocks halve the number of BN-statistics partials the consumer folds
   if ((M + 63) / 64 > 4LL * num_cus && g.tm == 1) g.tm = 2;
   g.gx = (int)((M + 64 * g.tm - 1) / (64 * g.tm));
+  {  // small grids (14x14 / 28x28 maps) are latency-bound: narrower column tiles -> more blocks, a shorter MFMA chain per block and
+     // often no split-K pass at all (measured +3 % on the whole step; MLIIS_GEMM_FILL = 0 restores the widest tiles)
+    static int fill = -1, min_nt = 2;
+    if (fill < 0) {
+      const char* e = getenv("MLIIS_GEMM_FILL");
+      fill = e ? atoi(e) : 4;
+      const char* m = getenv("MLIIS_GEMM_MIN_NT");
+      if (m) min_nt = atoi(m) < 1 ? 1 : atoi(m);
+    }
+    if (g.tm == 1 && g.gx < num_cus)
+      while (g.nt > min_nt && (long long)g.gx * g.gy < (long long)fill * num_cus) {
+        g.nt = (g.nt + 1) / 2;
+        g.gy = (Nout + g.nt * 16 - 1) / (g.nt * 16);
+      }
+  }
   // K chunks of 32: per tap (first-generation kernels) or over the flattened (tap, channel) index (conv_gemm_nk_k)
   int nchunks = flat_k ? (ntaps * C + 31) / 32 : ntaps * ((C + 31) / 32);
   g.gz = 1;
   if (allow_split && g.tm == 1) {   // (128-row tiles are only chosen for grids that fill the chip many times over)
     long long blocks = (long long)g.gx * g.gy;
     // split K when the grid cannot fill the chip and there is enough K to amortise the extra pass
-    while (blocks * g.gz * 2 <= num_cus && nchunks / (g.gz * 2) >= 3 && g.gz < 16) g.gz *= 2;
+    while (blocks * g.gz * 2 <= num_cus && nchunks / (g.gz * 2) >= 3 && g.gz < 16) g.gz *= 2;   // (a looser bound measured slower)
   }
   g.chunks_per_split = (nchunks + g.gz - 1) / g.gz;
   g.gz = (nchunks + g.chunks_per_split - 1) / g.chunks_per_split;
