@@ -33,10 +33,11 @@ struct ColGeom {
 static inline ColGeom col_geom(long long rows_per_seg, int C, int nseg, int target_blocks = 2048) {
   ColGeom g;
   g.gx = ceil_div(C, kChanBlock);
+  // (measured: 512 .. 8192 target blocks are within noise of each other on the whole step)
   long long want = target_blocks / ((long long)g.gx * (nseg > 0 ? nseg : 1));
   if (want < 1) want = 1;
   long long rpb = (rows_per_seg + want - 1) / want;
-  const long long unit = kRowLanes * kBatch;
+  const long long unit = kRowLanes * kBatch;   // (measured: 32 / 64 / 256 rows are 3-4 % slower on the whole step)
   rpb = (rpb + unit - 1) / unit * unit;
   g.rows_per_block = (int)rpb;
   g.nblk = ceil_div(rows_per_seg, rpb);

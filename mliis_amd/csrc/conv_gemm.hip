@@ -1211,14 +1211,9 @@ static void launch_gemm(const GemmPlan& g, const ConvGemmParams& p, hipStream_t 
 struct FilterPlan {
   int tmf, nt, gx, gy, gz, rows_per_split;
 };
-static inline FilterPlan plan_filter(long long M, int C, int Nout, int ntaps, int num_cus) {
-  FilterPlan f;
-  f.nt = pick_nt(Nout);
+static inline void plan_filter_split(FilterPlan& f, long long M, int C, int Nout, int ntaps, int num_cus) {
+  const int bci = 64 * f.tmf;
   f.gy = (Nout + f.nt * 16 - 1) / (f.nt * 16);
-  // 128-wide ci blocks halve the dY re-reads; take them unless they pad more zero rows than 64-wide blocks would
-  const int waste128 = (C + 127) / 128 * 128 - C, waste64 = (C + 63) / 64 * 64 - C;
-  f.tmf = (C >= 128 && waste128 <= waste64) ? 2 : 1;
-  int bci = 64 * f.tmf;
   f.gx = ntaps * ((C + bci - 1) / bci);
   long long base = (long long)f.gx * f.gy;
   long long want = (2LL * num_cus) / base;  // one full round of two co-resident blocks per CU (no half-empty second round) ...
@@ -1235,6 +1230,26 @@ static inline FilterPlan plan_filter(long long M, int C, int Nout, int ntaps, in
   rps = (rps + 31) / 32 * 32;
   f.rows_per_split = (int)rps;
   f.gz = (int)((M + rps - 1) / rps);
+}
+
+static inline FilterPlan plan_filter(long long M, int C, int Nout, int ntaps, int num_cus) {
+  FilterPlan f;
+  f.nt = pick_nt(Nout);
+  // 128-wide ci blocks halve the dY re-reads; take them unless they pad more zero rows than 64-wide blocks would
+  const int waste128 = (C + 127) / 128 * 128 - C, waste64 = (C + 63) / 64 * 64 - C;
+  f.tmf = (C >= 128 && waste128 <= waste64) ? 2 : 1;
+  plan_filter_split(f, M, C, Nout, ntaps, num_cus);
+  // small maps cannot be split further along the pixels (64 rows per slab): narrower tiles instead (latency-bound, see plan_gemm)
+  static int fill = -1;
+  if (fill < 0) {
+    const char* e = getenv("MLIIS_FILTER_FILL");
+    fill = e ? atoi(e) : 1;
+  }
+  while ((long long)f.gx * f.gy * f.gz < (long long)fill * num_cus && (f.tmf == 2 || f.nt > 2)) {
+    if (f.tmf == 2) f.tmf = 1;
+    else f.nt = (f.nt + 1) / 2;
+    plan_filter_split(f, M, C, Nout, ntaps, num_cus);
+  }
   return f;
 }
 
