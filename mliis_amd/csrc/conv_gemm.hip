@@ -1443,7 +1443,7 @@ int mliis_conv2d_bwd_data(const float* dy, int lddy, const float* w, float* dx, 
 // desc: device int32 [ndesc][4] = {offset (floats), taps, Cin, Cout}; src/dst: arenas with identical layout.
 int mliis_transpose_weights(const float* src, float* dst, const int* desc, int ndesc, hipStream_t stream) {
   MLIIS_REQUIRE(src && dst && desc && ndesc > 0, MLIIS_ERR_ARG, "transpose_weights: bad arguments");
-  hipLaunchKernelGGL(transpose_weights_k, dim3(48, ndesc), dim3(256), 0, stream, src, dst, desc);
+  hipLaunchKernelGGL(transpose_weights_k, dim3(224, ndesc), dim3(256), 0, stream, src, dst, desc);   // (the largest tensor has ~2000 tiles)
   MLIIS_CHECK_LAUNCH("transpose_weights");
   return MLIIS_OK;
 }

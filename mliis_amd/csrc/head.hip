@@ -219,41 +219,44 @@ __global__ __launch_bounds__(256) void ce_partial_k(const float* __restrict__ lo
   }
 }
 
-// out: [0] loss, [1] ce, [2] iou ; coef[n] = {A_n, B_n} for the dice gradient (0 when dice off).  One block; thread t folds
-// the partial blocks b = t, t+256, ... of every image, then thread 0 finishes in double precision (fixed order).
+// out: [0] loss, [1] ce, [2] iou ; coef[n] = {A_n, B_n} for the dice gradient (0 when dice off).  One block: 8 images at a time,
+// 32 lanes per image fold that image's partial blocks (double precision), a lane butterfly finishes the image, thread 0 adds the
+// images up in index order (fixed order: deterministic).
 __global__ __launch_bounds__(256) void ce_finalize_k(const float* __restrict__ part, int nblk, int N, int HW, int dice, float extra_loss,
                                                      float* __restrict__ out, float* __restrict__ coef) {
-  __shared__ double sm[4][256];
-  __shared__ double tot[4];
+  __shared__ double s_ce[8], s_iou[8];
   double ce = 0.0, iou = 0.0;
   const double eps = 1e-7;
-  for (int n = 0; n < N; ++n) {
+  const int g = threadIdx.x >> 5, lane = threadIdx.x & 31;
+  for (int n0 = 0; n0 < N; n0 += 8) {
+    const int n = n0 + g;
     double v[4] = {0, 0, 0, 0};
-    for (int b = threadIdx.x; b < nblk; b += 256) {
-      const float4 q = ld4(part + ((long long)n * nblk + b) * 4);
-      v[0] += q.x;
-      v[1] += q.y;
-      v[2] += q.z;
-      v[3] += q.w;
-    }
+    if (n < N)
+      for (int b = lane; b < nblk; b += 32) {
+        const float4 q = ld4(part + ((long long)n * nblk + b) * 4);
+        v[0] += q.x;
+        v[1] += q.y;
+        v[2] += q.z;
+        v[3] += q.w;
+      }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) sm[k][threadIdx.x] = v[k];
-    __syncthreads();
-    if (threadIdx.x < 4) {
-      double s = 0.0;
-      const int lim = nblk < 256 ? nblk : 256;
-      for (int j = 0; j < lim; ++j) s += sm[threadIdx.x][j];
-      tot[threadIdx.x] = s;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      const double I = tot[1], Sp = tot[2], St = tot[3];
-      ce += tot[0];
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int off = 1; off < 32; off <<= 1) v[k] += __shfl_xor(v[k], off);
+    if (lane == 0 && n < N) {
+      const double I = v[1], Sp = v[2], St = v[3];
       const double U = Sp + St - I;
-      iou += (I + eps) / (U + eps);
+      s_ce[g] = v[0];
+      s_iou[g] = (I + eps) / (U + eps);
       coef[2 * n + 0] = (float)(1.0 / (U + eps));
       coef[2 * n + 1] = (float)((I + eps) / ((U + eps) * (U + eps)));
     }
+    __syncthreads();
+    if (threadIdx.x == 0)
+      for (int j = 0; j < 8 && n0 + j < N; ++j) {
+        ce += s_ce[j];
+        iou += s_iou[j];
+      }
     __syncthreads();
   }
   if (threadIdx.x != 0) return;
