@@ -65,7 +65,8 @@ def main():
     for r in trace:
         n = r["Kernel_Name"]
         if "dwconv" in n:
-            per[(n.split("(")[0].replace("void mliis::", ""), int(r["Grid_Size_X"]))].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+            per[(n.split("(")[0].replace("void mliis::", ""), int(r["Grid_Size_X"]), int(r["Grid_Size_Y"]))].append(
+                int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 
     def grid(items):
         return -(-items // 256) * 256
@@ -76,8 +77,11 @@ def main():
         q = b.cexp // 4
         gf = grid(N * b.h_out * (-(-b.h_out // 4)) * q)
         gb = grid(N * b.h_in * (-(-b.h_in // 4)) * q)
-        kf = [v for (k, g), v in per.items() if k.startswith("dwconv_fwd_k<%d, %d" % (b.k, b.stride)) and g == gf]
-        kb = [v for (k, g), v in per.items() if k.startswith("dwconv_bwd_data_k<%d, %d" % (b.k, b.stride)) and g == gb]
+        # training forward: dwconv_fwd_stats_k, grid (ceil(strips / 32) blocks of 256 threads, ceil(C / 32))
+        gs = -(-(N * b.h_out * (-(-b.h_out // 4))) // 32) * 256
+        kf = [v for (k, g, gy), v in per.items() if (k.startswith("dwconv_fwd_k<%d, %d" % (b.k, b.stride)) and g == gf) or
+              (k.startswith("dwconv_fwd_stats_k<%d, %d" % (b.k, b.stride)) and g == gs and gy == -(-b.cexp // 32))]
+        kb = [v for (k, g, gy), v in per.items() if k.startswith("dwconv_bwd_data_k<%d, %d" % (b.k, b.stride)) and g == gb]
         if not kf or not kb:
             continue
         mf = sorted(kf[0])[len(kf[0]) // 2] / 1e3
