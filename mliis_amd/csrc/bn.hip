@@ -67,6 +67,23 @@ __global__ __launch_bounds__(kColThreads) void colreduce_partial_k(Op op, int ro
     if (r1 > rows_per_seg) r1 = rows_per_seg;
     const long long base = (long long)seg * rows_per_seg;
     int r = r0 + rl;
+    // first batch: its loads are issued before the per-channel constants are fetched (one memory round trip on small maps)
+    typename Op::Raw first[kBatch];
+#pragma unroll
+    for (int u = 0; u < kBatch; ++u) {
+      const int ru = r + u * kRowLanes;
+      op.load(seg, base + (ru < r1 ? ru : r0), c, first[u]);
+    }
+    const typename Op::Ctx ctx = op.ctx(c);   // per-channel constants, loaded once per thread
+#pragma unroll
+    for (int u = 0; u < kBatch; ++u)
+      if (r + u * kRowLanes < r1) {
+        float4 vals[NV];
+        op.eval(ctx, first[u], vals);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) acc[v] = f4add(acc[v], vals[v]);
+      }
+    r += kBatch * kRowLanes;
     for (; r + (kBatch - 1) * kRowLanes < r1; r += kBatch * kRowLanes) {
       typename Op::Raw raw[kBatch];
 #pragma unroll
@@ -74,7 +91,7 @@ __global__ __launch_bounds__(kColThreads) void colreduce_partial_k(Op op, int ro
 #pragma unroll
       for (int u = 0; u < kBatch; ++u) {
         float4 vals[NV];
-        op.eval(seg, base + r + u * kRowLanes, c, raw[u], vals);
+        op.eval(ctx, raw[u], vals);
 #pragma unroll
         for (int v = 0; v < NV; ++v) acc[v] = f4add(acc[v], vals[v]);
       }
@@ -83,7 +100,7 @@ __global__ __launch_bounds__(kColThreads) void colreduce_partial_k(Op op, int ro
       typename Op::Raw raw;
       op.load(seg, base + r, c, raw);
       float4 vals[NV];
-      op.eval(seg, base + r, c, raw, vals);
+      op.eval(ctx, raw, vals);
 #pragma unroll
       for (int v = 0; v < NV; ++v) acc[v] = f4add(acc[v], vals[v]);
     }
@@ -135,8 +152,10 @@ struct StatsOp {
   int ld;
   int pre_swish;
   typedef float4 Raw;
+  struct Ctx {};
+  __device__ __forceinline__ Ctx ctx(int) const { return Ctx(); }
   __device__ __forceinline__ void load(int, long long row, int c, Raw& r) const { r = ld4(x + row * ld + c); }
-  __device__ __forceinline__ void eval(int, long long, int, const Raw& r, float4* o) const {
+  __device__ __forceinline__ void eval(const Ctx&, const Raw& r, float4* o) const {
     float4 v = r;
     if (pre_swish) v = make_float4(swish_f(v.x), swish_f(v.y), swish_f(v.z), swish_f(v.w));
     o[0] = v;
@@ -265,13 +284,15 @@ __global__ __launch_bounds__(256) void bn_apply_fused_k(const float* __restrict_
   // The first batch of rows does not depend on the statistics: fetch it BEFORE folding them, so the small-map launches (one batch
   // per thread) pay one memory round trip instead of two.
   long long r = r0 + rl;
+  const float* rbase = res != nullptr ? res : x;   // no residual: the loads shadow x (ignored later) -- no branch around them
+  const int rld = res != nullptr ? ldr : ldx;
   float4 v0[kBatch], rv0[kBatch];
 #pragma unroll
   for (int u = 0; u < kBatch; ++u) {
     const long long ru = r + u * kRowLanes;
     const long long rr = ru < r1 ? ru : 0;
     v0[u] = ld4(x + rr * ldx + c);
-    rv0[u] = res != nullptr ? ld4(res + rr * ldr + c) : f4zero();
+    rv0[u] = ld4(rbase + rr * rld + c);
   }
   double s, ss;
   fold32(f.part, f.nblk, C, c0, smd, s, ss);
@@ -318,12 +339,12 @@ __global__ __launch_bounds__(256) void bn_apply_fused_k(const float* __restrict_
 #pragma unroll
     for (int u = 0; u < kBatch; ++u) {
       v[u] = ld4(x + (r + u * kRowLanes) * ldx + c);
-      rv[u] = res != nullptr ? ld4(res + (r + u * kRowLanes) * ldr + c) : f4zero();
+      rv[u] = ld4(rbase + (r + u * kRowLanes) * rld + c);
     }
 #pragma unroll
     for (int u = 0; u < kBatch; ++u) finish(r + u * kRowLanes, v[u], rv[u]);
   }
-  for (; r < r1; r += kRowLanes) finish(r, ld4(x + r * ldx + c), res != nullptr ? ld4(res + r * ldr + c) : f4zero());
+  for (; r < r1; r += kRowLanes) finish(r, ld4(x + r * ldx + c), ld4(rbase + r * rld + c));
   if (pool_part == nullptr) return;   // (uniform)
   // pooled partial of this block: butterfly over the 8 row lanes of a wave that share a quad, then the 4 waves through LDS
 #pragma unroll
@@ -349,6 +370,7 @@ static inline void chan_grid(long long rows, int C, int* gx, int* gy, int* rows_
 }
 
 // upstream gradient seen by the BN output: dy * img_scale[n] * chan_scale[n,c] + chan_add[n,c]
+template <bool SE>   // SE: per-image vectors (drop-connect scale, squeeze-excite gate / pooled gradient) are present
 struct BnBwdCommon {
   const float* x;   // conv output saved in forward (pre-BN, pre-swish if pre_swish)
   int ldx;
@@ -364,26 +386,36 @@ struct BnBwdCommon {
   const float* img_scale;   // [N] or null        (drop-connect)
   const float* chan_scale;  // [N,C] or null      (squeeze-excite gate)
   const float* chan_add;    // [N,C] or null      (squeeze-excite pooled-gradient / HW)
-  struct Raw { float4 x, g; };
+  // everything a row needs from memory, fetched together (no load is left inside finish(): the per-image vectors used to cost
+  // one dependent round trip per row)
+  struct Raw { float4 x, g, cs, ca; float is; };
   __device__ __forceinline__ void load_raw(long long row, int c, Raw& r) const {
     r.x = ld4(x + row * ldx + c);
     r.g = ld4(dy + row * lddy + c);
+    if (SE) {
+      const long long n = (int)row / rows_per_img;     // rows < 2^31 (checked on the host)
+      // absent vectors read a valid dummy (the mean vector) and are ignored in finish(): no branch around the loads
+      r.cs = ld4((chan_scale != nullptr ? chan_scale + n * C : mean) + c);
+      r.ca = ld4((chan_add != nullptr ? chan_add + n * C : mean) + c);
+      r.is = (img_scale != nullptr ? img_scale : mean)[img_scale != nullptr ? n : 0];
+    }
   }
-  __device__ __forceinline__ void finish(long long row, int c, const Raw& r, float4& xin, float4& xhat, float4& g) const {
+  struct Ctx { float4 m, rs, ga, be; };   // per-channel constants of this thread's quad, loaded once
+  __device__ __forceinline__ Ctx ctx(int c) const { return Ctx{ld4(mean + c), ld4(rstd + c), ld4(gamma + c), ld4(beta + c)}; }
+  __device__ __forceinline__ void finish(const Ctx& k, const Raw& r, float4& xin, float4& xhat, float4& g) const {
     xin = r.x;
     float4 v = xin;
     if (pre_swish) v = make_float4(swish_f(v.x), swish_f(v.y), swish_f(v.z), swish_f(v.w));
-    const float4 m = ld4(mean + c), rs = ld4(rstd + c);
+    const float4 m = k.m, rs = k.rs;
     xhat = make_float4((v.x - m.x) * rs.x, (v.y - m.y) * rs.y, (v.z - m.z) * rs.z, (v.w - m.w) * rs.w);
     g = r.g;
-    if (img_scale != nullptr || chan_scale != nullptr || chan_add != nullptr) {
-      const int n = (int)row / rows_per_img;     // rows < 2^31 (checked on the host)
-      if (img_scale != nullptr) g = f4scale(g, img_scale[n]);
-      if (chan_scale != nullptr) g = f4mul(g, ld4(chan_scale + (long long)n * C + c));
-      if (chan_add != nullptr) g = f4add(g, ld4(chan_add + (long long)n * C + c));
+    if (SE) {
+      if (img_scale != nullptr) g = f4scale(g, r.is);
+      if (chan_scale != nullptr) g = f4mul(g, r.cs);
+      if (chan_add != nullptr) g = f4add(g, r.ca);
     }
     if (post_swish) {
-      const float4 ga = ld4(gamma + c), be = ld4(beta + c);
+      const float4 ga = k.ga, be = k.be;
       g.x *= swish_grad_f(fmaf(xhat.x, ga.x, be.x));
       g.y *= swish_grad_f(fmaf(xhat.y, ga.y, be.y));
       g.z *= swish_grad_f(fmaf(xhat.z, ga.z, be.z));
@@ -392,14 +424,17 @@ struct BnBwdCommon {
   }
 };
 
+template <bool SE>
 struct BnBwdOp {
   static constexpr int NV = 2;
-  BnBwdCommon p;
-  typedef BnBwdCommon::Raw Raw;
+  BnBwdCommon<SE> p;
+  typedef typename BnBwdCommon<SE>::Raw Raw;
+  typedef typename BnBwdCommon<SE>::Ctx Ctx;
+  __device__ __forceinline__ Ctx ctx(int c) const { return p.ctx(c); }
   __device__ __forceinline__ void load(int, long long row, int c, Raw& r) const { p.load_raw(row, c, r); }
-  __device__ __forceinline__ void eval(int, long long row, int c, const Raw& r, float4* o) const {
+  __device__ __forceinline__ void eval(const Ctx& k, const Raw& r, float4* o) const {
     float4 xin, xhat, g;
-    p.finish(row, c, r, xin, xhat, g);
+    p.finish(k, r, xin, xhat, g);
     o[0] = g;
     o[1] = f4mul(g, xhat);
   }
@@ -418,7 +453,8 @@ struct SkipOut {
   }
 };
 
-__global__ __launch_bounds__(256) void bn_bwd_apply_fused_k(BnBwdCommon p, long long rows, const float* __restrict__ part, int nblk,
+template <bool SE>
+__global__ __launch_bounds__(256) void bn_bwd_apply_fused_k(BnBwdCommon<SE> p, long long rows, const float* __restrict__ part, int nblk,
                                                             double inv_n, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                             float* __restrict__ dx, int lddx, int rows_per_block, SkipOut skip,
                                                             float* __restrict__ dxsum_part) {
@@ -434,12 +470,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fused_k(BnBwdCommon p, long 
   long long r = (long long)blockIdx.y * rows_per_block + rl;
   if (!cok) r1 = r;
   // first batch of rows fetched BEFORE the fold of the gradient sums (it does not depend on them): one round trip on small maps
-  BnBwdCommon::Raw raw0[kBatch];
+  typename BnBwdCommon<SE>::Raw raw0[kBatch];
 #pragma unroll
   for (int u = 0; u < kBatch; ++u) {
     const long long ru = r + u * kRowLanes;
     p.load_raw(ru < r1 ? ru : 0, c, raw0[u]);
   }
+  const typename BnBwdCommon<SE>::Ctx kc = p.ctx(c);
   double s, sx;
   fold32(part, nblk, p.C, c0, smd, s, sx);
   if (t < 32) {
@@ -453,12 +490,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fused_k(BnBwdCommon p, long 
   }
   __syncthreads();
   if (!cok && dxsum_part == nullptr) return;   // (surplus lanes stay for the column-sum reduction, with an empty row range)
-  const float4 a = ld4(s_c1 + q * 4), b = ld4(s_c2 + q * 4), ga = ld4(p.gamma + c), rs = ld4(p.rstd + c);
+  const float4 a = ld4(s_c1 + q * 4), b = ld4(s_c2 + q * 4), ga = kc.ga, rs = kc.rs;
   float4 dsum = f4zero();   // column sum of this thread's dx rows (bias gradient of a conv -> swish -> BN stack)
-  auto finish = [&](long long rw, const BnBwdCommon::Raw& raw) {
+  auto finish = [&](long long rw, const typename BnBwdCommon<SE>::Raw& raw) {
     float4 xin, xhat, g;
     skip.put(rw, c, raw.g);
-    p.finish(rw, c, raw, xin, xhat, g);
+    p.finish(kc, raw, xin, xhat, g);
     float4 d;
     d.x = ga.x * rs.x * (g.x - a.x - xhat.x * b.x);
     d.y = ga.y * rs.y * (g.y - a.y - xhat.y * b.y);
@@ -478,14 +515,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fused_k(BnBwdCommon p, long 
     if (r + u * kRowLanes < r1) finish(r + u * kRowLanes, raw0[u]);
   r += kBatch * kRowLanes;
   for (; r + (kBatch - 1) * kRowLanes < r1; r += kBatch * kRowLanes) {
-    BnBwdCommon::Raw raw[kBatch];
+    typename BnBwdCommon<SE>::Raw raw[kBatch];
 #pragma unroll
     for (int u = 0; u < kBatch; ++u) p.load_raw(r + u * kRowLanes, c, raw[u]);
 #pragma unroll
     for (int u = 0; u < kBatch; ++u) finish(r + u * kRowLanes, raw[u]);
   }
   for (; r < r1; r += kRowLanes) {
-    BnBwdCommon::Raw raw;
+    typename BnBwdCommon<SE>::Raw raw;
     p.load_raw(r, c, raw);
     finish(r, raw);
   }
@@ -515,11 +552,13 @@ struct SumOp {  // column sum of a (optionally times b)
   const float* b;  // nullable
   int ldb;
   struct Raw { float4 a, b; };
+  struct Ctx {};
+  __device__ __forceinline__ Ctx ctx(int) const { return Ctx(); }
   __device__ __forceinline__ void load(int, long long row, int c, Raw& r) const {
     r.a = ld4(a + row * lda + c);
     r.b = b != nullptr ? ld4(b + row * ldb + c) : make_float4(1.f, 1.f, 1.f, 1.f);
   }
-  __device__ __forceinline__ void eval(int, long long, int, const Raw& r, float4* o) const { o[0] = f4mul(r.a, r.b); }
+  __device__ __forceinline__ void eval(const Ctx&, const Raw& r, float4* o) const { o[0] = f4mul(r.a, r.b); }
 };
 
 // sum_rows x[row, c] * (mask[row,c]) * dy[row, j], j = 0,1   (final 1x1 conv, Cout = 2: weight gradient)
@@ -530,12 +569,14 @@ struct Outer2Op {
   const float* mask;  // nullable, same layout as x
   const float* dy;    // [rows, 2]
   struct Raw { float4 x, m; float2 d; };
+  struct Ctx {};
+  __device__ __forceinline__ Ctx ctx(int) const { return Ctx(); }
   __device__ __forceinline__ void load(int, long long row, int c, Raw& r) const {
     r.x = ld4(x + row * ldx + c);
     r.m = mask != nullptr ? ld4(mask + row * ldx + c) : make_float4(1.f, 1.f, 1.f, 1.f);
     r.d = *reinterpret_cast<const float2*>(dy + row * 2);
   }
-  __device__ __forceinline__ void eval(int, long long, int, const Raw& r, float4* o) const {
+  __device__ __forceinline__ void eval(const Ctx&, const Raw& r, float4* o) const {
     const float4 v = f4mul(r.x, r.m);
     o[0] = f4scale(v, r.d.x);
     o[1] = f4scale(v, r.d.y);
@@ -748,18 +789,26 @@ int mliis_bn_bwd(const float* x, int ldx, const float* dy, int lddy, float* dx, 
   MLIIS_REQUIRE(aligned16(x) && aligned16(dy) && aligned16(dx) && aligned16(ws) && aligned16(chan_scale) && aligned16(chan_add) &&
                     aligned16(mean) && aligned16(rstd) && aligned16(gamma) && aligned16(beta),
                 MLIIS_ERR_ALIGN, "bn_bwd: pointers must be 16-byte aligned");
-  BnBwdCommon p{x, ldx, dy, lddy, rows_per_img, C, mean, rstd, gamma, beta, pre_swish, post_swish, img_scale, chan_scale, chan_add};
   SkipOut skip{dskip, lddskip, dskip_accumulate};
-  BnBwdOp op{p};
-  ColGeom g;
-  int rc = launch_colreduce(op, rows, C, 1, ws, ws_floats, stream, &g, "bn_bwd");
-  if (rc) return rc;
   int gx, gy, rpb;
   chan_grid(rows, C, &gx, &gy, &rpb);
   MLIIS_REQUIRE(dxsum_part == nullptr || (aligned16(dxsum_part) && (size_t)gy * C <= dxsum_floats), MLIIS_ERR_WORKSPACE,
                 "bn_bwd: column-sum buffer unaligned or too small (%zu floats needed)", (size_t)gy * C);
-  hipLaunchKernelGGL(bn_bwd_apply_fused_k, dim3(gx, gy), dim3(256), 0, stream, p, rows, ws, g.nblk, 1.0 / (double)rows, dgamma, dbeta, dx,
-                     lddx, rpb, skip, dxsum_part);
+  ColGeom g;
+  int rc;
+  if (img_scale != nullptr || chan_scale != nullptr || chan_add != nullptr) {
+    BnBwdCommon<true> p{x, ldx, dy, lddy, rows_per_img, C, mean, rstd, gamma, beta, pre_swish, post_swish, img_scale, chan_scale, chan_add};
+    rc = launch_colreduce(BnBwdOp<true>{p}, rows, C, 1, ws, ws_floats, stream, &g, "bn_bwd");
+    if (rc) return rc;
+    hipLaunchKernelGGL(bn_bwd_apply_fused_k<true>, dim3(gx, gy), dim3(256), 0, stream, p, rows, ws, g.nblk, 1.0 / (double)rows, dgamma, dbeta,
+                       dx, lddx, rpb, skip, dxsum_part);
+  } else {
+    BnBwdCommon<false> p{x, ldx, dy, lddy, rows_per_img, C, mean, rstd, gamma, beta, pre_swish, post_swish, nullptr, nullptr, nullptr};
+    rc = launch_colreduce(BnBwdOp<false>{p}, rows, C, 1, ws, ws_floats, stream, &g, "bn_bwd");
+    if (rc) return rc;
+    hipLaunchKernelGGL(bn_bwd_apply_fused_k<false>, dim3(gx, gy), dim3(256), 0, stream, p, rows, ws, g.nblk, 1.0 / (double)rows, dgamma, dbeta,
+                       dx, lddx, rpb, skip, dxsum_part);
+  }
   MLIIS_CHECK_LAUNCH("bn_bwd_apply_fused");
   return MLIIS_OK;
 }
