@@ -403,7 +403,8 @@ int mliis_softmax_ce(const float* logits, const float* labels, const int* img_id
   hipLaunchKernelGGL(ce_finalize_k, dim3(1), dim3(256), 0, stream, ws, nblk, N, HW, dice, extra_loss, out, coef);
   MLIIS_CHECK_LAUNCH("softmax_ce_finalize");
   if (dlogits || pred) {
-    hipLaunchKernelGGL(ce_grad_k, dim3(nblk, N), dim3(256), 0, stream, logits, labels, img_idx, HW, label_smoothing,
+    // one pixel per thread (the partial-sum pass above keeps its coarser grid: its block count is the finalize kernel's work)
+    hipLaunchKernelGGL(ce_grad_k, dim3(ceil_div(HW, 256), N), dim3(256), 0, stream, logits, labels, img_idx, HW, label_smoothing,
                        1.0f / ((float)N * (float)HW), coef, dlogits, pred);
     MLIIS_CHECK_LAUNCH("softmax_ce_grad");
   }

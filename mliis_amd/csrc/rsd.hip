@@ -41,12 +41,13 @@ __global__ __launch_bounds__(kRsdThreads) void rsd_pool_fwd_k(const float* __res
   for (int n = 0; n < kRsdMaxN; ++n) a[n] = 0.f;
   if (cl < CL)
     for (int c = cbeg + cl; c < cend; c += CL) {
-      float ws = 0.f;
+      float wt[9], ws = 0.f;   // all nine taps fetched together (valid addresses either way), the excluded ones weighted by zero
+#pragma unroll
+      for (int tp = 0; tp < 9; ++tp) wt[tp] = w[((long long)tp * Cin_total + c_begin + c) * Co + co];
 #pragma unroll
       for (int ty = 0; ty < 3; ++ty)
 #pragma unroll
-        for (int tx = 0; tx < 3; ++tx)
-          if (tap_valid(ty, rc) && tap_valid(tx, cc)) ws += w[((long long)(ty * 3 + tx) * Cin_total + c_begin + c) * Co + co];
+        for (int tx = 0; tx < 3; ++tx) ws += (tap_valid(ty, rc) && tap_valid(tx, cc)) ? wt[ty * 3 + tx] : 0.f;
 #pragma unroll
       for (int n = 0; n < kRsdMaxN; ++n)
         if (n < N) a[n] = fmaf(sp[n * Cp + c], ws, a[n]);
@@ -75,15 +76,20 @@ __global__ __launch_bounds__(kRsdThreads) void rsd_border_sums_k(const float* __
   const float* d = dz + (long long)n * H * W * ld;
   const int len = part < 2 ? W : H;
   float a = 0.f;
-  if (cl < CL)
-    for (int i = cl; i < len; i += CL) {
-      long long pix;
-      if (part == 0) pix = i;
-      else if (part == 1) pix = (long long)(H - 1) * W + i;
-      else if (part == 2) pix = (long long)i * W;
-      else pix = (long long)i * W + W - 1;
-      a += d[pix * ld + co];
+  if (cl < CL) {
+    const long long p0 = part == 0 ? 0 : part == 1 ? (long long)(H - 1) * W : part == 2 ? 0 : W - 1;
+    const long long ps = part < 2 ? 1 : W;   // pixel index = p0 + i * ps
+    for (int i = cl; i < len; i += 8 * CL) {   // eight loads per trip (clamped, zero-weighted past the end)
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int k = i + u * CL < len ? i + u * CL : cl;
+        v[u] = d[(p0 + k * ps) * ld + co];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a += i + u * CL < len ? v[u] : 0.f;
     }
+  }
   red[threadIdx.x] = a;
   __syncthreads();
   if (threadIdx.x < Co) {
@@ -123,7 +129,17 @@ __global__ __launch_bounds__(256) void rsd_pool_dw_k(const float* __restrict__ G
     const long long r = i / Co;
     const int c = (int)(r % Cp), tap = (int)(r / Cp);
     float a = 0.f;
-    for (int n = 0; n < N; ++n) a = fmaf(pool[(long long)n * Cp + c], G[((long long)n * 9 + tap) * Co + co], a);
+    for (int n0 = 0; n0 < N; n0 += 8) {   // all loads of eight images first
+      float pv[8], gv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int n = n0 + u < N ? n0 + u : N - 1;
+        pv[u] = pool[(long long)n * Cp + c];
+        gv[u] = G[((long long)n * 9 + tap) * Co + co];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a = fmaf(n0 + u < N ? pv[u] : 0.f, gv[u], a);
+    }
     dw[((long long)tap * Cin_total + c_begin + c) * Co + co] = a;
   } else if (dbias != nullptr && i < nW + Co) {
     const int co = (int)(i - nW);
@@ -140,11 +156,15 @@ __global__ __launch_bounds__(256) void rsd_pool_dpool_k(const float* __restrict_
   if (wv >= N * Cp) return;
   const int c = wv % Cp, n = wv / Cp;
   float a = 0.f;
+  for (int co = lane; co < Co; co += 64) {   // the nine taps' loads of a column first (one round trip per 64 columns)
+    float gv[9], wv[9];
 #pragma unroll
-  for (int tap = 0; tap < 9; ++tap) {
-    const float* wp = w + ((long long)tap * Cin_total + c_begin + c) * Co;
-    const float* gp = G + ((long long)n * 9 + tap) * Co;
-    for (int co = lane; co < Co; co += 64) a = fmaf(gp[co], wp[co], a);
+    for (int tap = 0; tap < 9; ++tap) {
+      wv[tap] = w[((long long)tap * Cin_total + c_begin + c) * Co + co];
+      gv[tap] = G[((long long)n * 9 + tap) * Co + co];
+    }
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) a = fmaf(gv[tap], wv[tap], a);
   }
   a = wave_sum(a);
   if (lane == 0) dpool[wv] = a * inv_hw;

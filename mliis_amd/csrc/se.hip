@@ -15,18 +15,17 @@ constexpr int kSeThreads = 1024;  // one workgroup per image: all 16 waves of a 
 template <int U>
 __device__ __forceinline__ float dot_strided(const float* __restrict__ a, int sa, const float* __restrict__ b, long long sb, int n) {
   float acc = 0.f;
-  int i = 0;
-  for (; i + U <= n; i += U) {
+  for (int i = 0; i < n; i += U) {   // the last batch is padded with clamped, zero-weighted elements: no serial tail
     float x[U], y[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      x[u] = a[(long long)(i + u) * sa];
-      y[u] = b[(long long)(i + u) * sb];
+      const int k = i + u < n ? i + u : n - 1;
+      x[u] = a[(long long)k * sa];
+      y[u] = b[(long long)k * sb];
     }
 #pragma unroll
-    for (int u = 0; u < U; ++u) acc = fmaf(x[u], y[u], acc);
+    for (int u = 0; u < U; ++u) acc = fmaf(i + u < n ? x[u] : 0.f, y[u], acc);
   }
-  for (; i < n; ++i) acc = fmaf(a[(long long)i * sa], b[(long long)i * sb], acc);
   return acc;
 }
 
@@ -46,15 +45,13 @@ __global__ __launch_bounds__(kSeThreads) void se_mlp_fwd_k(const float* __restri
   for (int c = t; c < C; c += kSeThreads) {
     const float* pp = s_part + ((long long)n * chunks) * C + c;
     float a = 0.f;
-    int k = 0;
-    for (; k + 8 <= chunks; k += 8) {
+    for (int k = 0; k < chunks; k += 8) {
       float v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = pp[(long long)(k + u) * C];
+      for (int u = 0; u < 8; ++u) v[u] = pp[(long long)(k + u < chunks ? k + u : chunks - 1) * C];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) a += v[u];
+      for (int u = 0; u < 8; ++u) a += k + u < chunks ? v[u] : 0.f;
     }
-    for (; k < chunks; ++k) a += pp[(long long)k * C];
     a *= scale;
     sn[c] = a;
     if (s_out != nullptr) s_out[(long long)n * C + c] = a;
@@ -84,15 +81,13 @@ __global__ __launch_bounds__(kSeThreads) void se_mlp_fwd_k(const float* __restri
   __syncthreads();
   for (int c = t; c < C; c += kSeThreads) {
     float a = b2[c];
-    int k = 0;
-    for (; k + 8 <= R; k += 8) {
+    for (int k = 0; k < R; k += 8) {
       float wv[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) wv[u] = w2[(long long)(k + u) * C + c];
+      for (int u = 0; u < 8; ++u) wv[u] = w2[(long long)(k + u < R ? k + u : R - 1) * C + c];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) a = fmaf(sh[k + u], wv[u], a);
+      for (int u = 0; u < 8; ++u) a = fmaf(k + u < R ? sh[k + u] : 0.f, wv[u], a);
     }
-    for (; k < R; ++k) a = fmaf(sh[k], w2[(long long)k * C + c], a);
     gate[(long long)n * C + c] = sigmoid_f(a);
   }
 }
@@ -117,15 +112,13 @@ __global__ __launch_bounds__(kSeThreads) void se_mlp_bwd_k(const float* __restri
   for (int jj = wave; jj < R; jj += kSeThreads / 64) {
     const float* wr = w2 + (long long)jj * C;
     float p = 0.f;
-    int c = lane;
-    for (; c + 7 * 64 < C; c += 8 * 64) {
+    for (int c = lane; c < C; c += 8 * 64) {
       float wv[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) wv[u] = wr[c + u * 64];
+      for (int u = 0; u < 8; ++u) wv[u] = wr[c + u * 64 < C ? c + u * 64 : lane];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) p = fmaf(sd2[c + u * 64], wv[u], p);
+      for (int u = 0; u < 8; ++u) p = fmaf(c + u * 64 < C ? sd2[c + u * 64] : 0.f, wv[u], p);
     }
-    for (; c < C; c += 64) p = fmaf(sd2[c], wr[c], p);
     p = wave_sum(p);
     if (lane == 0) {
       const float d = p * swish_grad_f(hpre[(long long)n * R + jj]);
@@ -137,15 +130,13 @@ __global__ __launch_bounds__(kSeThreads) void se_mlp_bwd_k(const float* __restri
   for (int c = t; c < C; c += kSeThreads) {
     const float* wr = w1 + (long long)c * R;
     float a = 0.f;
-    int k = 0;
-    for (; k + 8 <= R; k += 8) {
+    for (int k = 0; k < R; k += 8) {
       float wv[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) wv[u] = wr[k + u];
+      for (int u = 0; u < 8; ++u) wv[u] = wr[k + u < R ? k + u : R - 1];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) a = fmaf(sd1[k + u], wv[u], a);
+      for (int u = 0; u < 8; ++u) a = fmaf(k + u < R ? sd1[k + u] : 0.f, wv[u], a);
     }
-    for (; k < R; ++k) a = fmaf(sd1[k], wr[k], a);
     chan_add[(long long)n * C + c] = a * inv_hw;
   }
 }
@@ -158,24 +149,35 @@ __device__ __forceinline__ void se_wgrad_elem(int i, const float* __restrict__ s
   const int CR = C * R;
   const int total = 2 * CR + C + R;
   if (i >= total) return;
-  float a = 0.f;
+  // sums over the images, eight at a time with every load of a batch issued first (fixed order: deterministic)
+  auto dot_n = [&](const float* __restrict__ pa, long long sa, const float* __restrict__ pb, long long sb, bool swish_a) {
+    float a = 0.f;
+    for (int n0 = 0; n0 < N; n0 += 8) {
+      float x[8], y[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int n = n0 + u < N ? n0 + u : N - 1;
+        x[u] = pa[n * sa];
+        y[u] = pb != nullptr ? pb[n * sb] : 1.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a = fmaf(n0 + u < N ? (swish_a ? swish_f(x[u]) : x[u]) : 0.f, y[u], a);
+    }
+    return a;
+  };
   if (i < CR) {  // dw1[c][j] = sum_n s[n][c] * dpre1[n][j]
     const int c = i / R, j = i - c * R;
-    for (int n = 0; n < N; ++n) a = fmaf(s[(long long)n * C + c], dpre1[(long long)n * R + j], a);
-    dw1[i] = a;
+    dw1[i] = dot_n(s + c, C, dpre1 + j, R, false);
   } else if (i < 2 * CR) {  // dw2[j][c] = sum_n swish(hpre[n][j]) * dpre2[n][c]
     const int k = i - CR;
     const int j = k / C, c = k - j * C;
-    for (int n = 0; n < N; ++n) a = fmaf(swish_f(hpre[(long long)n * R + j]), dpre2[(long long)n * C + c], a);
-    dw2[k] = a;
+    dw2[k] = dot_n(hpre + j, R, dpre2 + c, C, true);
   } else if (i < 2 * CR + C) {
     const int c = i - 2 * CR;
-    for (int n = 0; n < N; ++n) a += dpre2[(long long)n * C + c];
-    db2[c] = a;
+    db2[c] = dot_n(dpre2 + c, C, nullptr, 0, false);
   } else {
     const int j = i - 2 * CR - C;
-    for (int n = 0; n < N; ++n) a += dpre1[(long long)n * R + j];
-    db1[j] = a;
+    db1[j] = dot_n(dpre1 + j, R, nullptr, 0, false);
   }
 }
 
@@ -214,11 +216,16 @@ __global__ __launch_bounds__(256) void chan_affine_k(const float* __restrict__ x
     const int c = (int)(i - ru * Q) << 2;
     const long long r = ru;
     const long long n = ru / (unsigned)rows_per_img;
-    float4 v = x ? ld4(x + r * ldx + c) : f4zero();
-    if (S) v = f4mul(v, ld4(S + n * C + c));
-    if (A) v = f4add(v, ld4(A + n * C + c));
+    // every operand is fetched before any is used (absent ones shadow the output row: valid, ignored) -- one memory round trip
     float* dst = y + r * ldy + c;
-    if (accumulate) v = f4add(v, ld4(dst));
+    const float4 vx = ld4(x ? x + r * ldx + c : dst);
+    const float4 vs = ld4(S ? S + n * C + c : dst);
+    const float4 va = ld4(A ? A + n * C + c : dst);
+    const float4 vo = ld4(dst);
+    float4 v = x ? vx : f4zero();
+    if (S) v = f4mul(v, vs);
+    if (A) v = f4add(v, va);
+    if (accumulate) v = f4add(v, vo);
     st4(dst, v);
   }
 }

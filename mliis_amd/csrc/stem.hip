@@ -26,20 +26,30 @@ struct Norm3 {
   float m0, m1, m2, i0, i1, i2;  // mean (m*) and std (i*) per channel
 };
 
+// the 27 raw values of a 3x3x3 window, fetched together without branches (out-of-image taps read a clamped, valid pixel and are
+// zeroed afterwards: the padding applies to the NORMALISED image), then normalised
 __device__ __forceinline__ void load_window(const float* __restrict__ img, int H, int W, int hi0, int wi0, Norm3 nm, float* v) {
+  bool ok[9];
 #pragma unroll
   for (int ky = 0; ky < 3; ++ky) {
     const int hi = hi0 + ky;
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
       const int wi = wi0 + kx;
-      const bool ok = hi >= 0 && hi < H && wi >= 0 && wi < W;
-      const float* px = img + ((long long)hi * W + wi) * 3;
-      // TF divides by std; (x - m) / s is restated as a true division to stay within 1 ulp of it
-      v[(ky * 3 + kx) * 3 + 0] = ok ? (px[0] - nm.m0) / nm.i0 : 0.f;
-      v[(ky * 3 + kx) * 3 + 1] = ok ? (px[1] - nm.m1) / nm.i1 : 0.f;
-      v[(ky * 3 + kx) * 3 + 2] = ok ? (px[2] - nm.m2) / nm.i2 : 0.f;
+      ok[ky * 3 + kx] = hi >= 0 && hi < H && wi >= 0 && wi < W;
+      const int hc = hi < 0 ? 0 : (hi >= H ? H - 1 : hi), wc = wi < 0 ? 0 : (wi >= W ? W - 1 : wi);
+      const float* px = img + ((long long)hc * W + wc) * 3;
+      v[(ky * 3 + kx) * 3 + 0] = px[0];
+      v[(ky * 3 + kx) * 3 + 1] = px[1];
+      v[(ky * 3 + kx) * 3 + 2] = px[2];
     }
+  }
+  // TF divides by std; (x - m) / s is restated as a true division to stay within 1 ulp of it
+#pragma unroll
+  for (int tp = 0; tp < 9; ++tp) {
+    v[tp * 3 + 0] = ok[tp] ? (v[tp * 3 + 0] - nm.m0) / nm.i0 : 0.f;
+    v[tp * 3 + 1] = ok[tp] ? (v[tp * 3 + 1] - nm.m1) / nm.i1 : 0.f;
+    v[tp * 3 + 2] = ok[tp] ? (v[tp * 3 + 2] - nm.m2) / nm.i2 : 0.f;
   }
 }
 
