@@ -286,14 +286,18 @@ __global__ __launch_bounds__(256) void bn_apply_fused_k(const float* __restrict_
   long long r = r0 + rl;
   const float* rbase = res != nullptr ? res : x;   // no residual: the loads shadow x (ignored later) -- no branch around them
   const int rld = res != nullptr ? ldr : ldx;
+  const float* isb = img_scale != nullptr ? img_scale : gamma;   // (absent: shadows gamma, ignored)
   float4 v0[kBatch], rv0[kBatch];
+  float is0[kBatch];
 #pragma unroll
   for (int u = 0; u < kBatch; ++u) {
     const long long ru = r + u * kRowLanes;
     const long long rr = ru < r1 ? ru : 0;
     v0[u] = ld4(x + rr * ldx + c);
     rv0[u] = ld4(rbase + rr * rld + c);
+    is0[u] = isb[img_scale != nullptr ? (int)rr / rows_per_img : 0];
   }
+  const float4 g = ld4(gamma + c), b = ld4(beta + c);   // (before the fold: they do not depend on it)
   double s, ss;
   fold32(f.part, f.nblk, C, c0, smd, s, ss);
   if (t < 32) {
@@ -315,9 +319,9 @@ __global__ __launch_bounds__(256) void bn_apply_fused_k(const float* __restrict_
     }
   }
   __syncthreads();
-  const float4 m = ld4(s_mean + q * 4), rs = ld4(s_rstd + q * 4), g = ld4(gamma + c), b = ld4(beta + c);
+  const float4 m = ld4(s_mean + q * 4), rs = ld4(s_rstd + q * 4);
   float4 pool = f4zero();   // sum of this thread's outputs (squeeze-excite pooling, training)
-  auto finish = [&](long long rw, float4 v, float4 rv) {
+  auto finish = [&](long long rw, float4 v, float4 rv, float isc) {
     if (pre_swish) v = make_float4(swish_f(v.x), swish_f(v.y), swish_f(v.z), swish_f(v.w));
     float4 o;
     o.x = fmaf((v.x - m.x) * rs.x, g.x, b.x);
@@ -325,26 +329,29 @@ __global__ __launch_bounds__(256) void bn_apply_fused_k(const float* __restrict_
     o.z = fmaf((v.z - m.z) * rs.z, g.z, b.z);
     o.w = fmaf((v.w - m.w) * rs.w, g.w, b.w);
     if (post_swish) o = make_float4(swish_f(o.x), swish_f(o.y), swish_f(o.z), swish_f(o.w));
-    if (img_scale != nullptr) o = f4scale(o, img_scale[(int)rw / rows_per_img]);
+    if (img_scale != nullptr) o = f4scale(o, isc);
     if (res != nullptr) o = f4add(o, rv);
     pool = f4add(pool, o);
     st4(y + rw * ldy + c, o);
   };
 #pragma unroll
   for (int u = 0; u < kBatch; ++u)
-    if (r + u * kRowLanes < r1) finish(r + u * kRowLanes, v0[u], rv0[u]);
+    if (r + u * kRowLanes < r1) finish(r + u * kRowLanes, v0[u], rv0[u], is0[u]);
   r += kBatch * kRowLanes;
   for (; r + (kBatch - 1) * kRowLanes < r1; r += kBatch * kRowLanes) {
     float4 v[kBatch], rv[kBatch];
+    float is[kBatch];
 #pragma unroll
     for (int u = 0; u < kBatch; ++u) {
       v[u] = ld4(x + (r + u * kRowLanes) * ldx + c);
       rv[u] = ld4(rbase + (r + u * kRowLanes) * rld + c);
+      is[u] = isb[img_scale != nullptr ? (int)(r + u * kRowLanes) / rows_per_img : 0];
     }
 #pragma unroll
-    for (int u = 0; u < kBatch; ++u) finish(r + u * kRowLanes, v[u], rv[u]);
+    for (int u = 0; u < kBatch; ++u) finish(r + u * kRowLanes, v[u], rv[u], is[u]);
   }
-  for (; r < r1; r += kRowLanes) finish(r, ld4(x + r * ldx + c), ld4(rbase + r * rld + c));
+  for (; r < r1; r += kRowLanes)
+    finish(r, ld4(x + r * ldx + c), ld4(rbase + r * rld + c), isb[img_scale != nullptr ? (int)r / rows_per_img : 0]);
   if (pool_part == nullptr) return;   // (uniform)
   // pooled partial of this block: butterfly over the 8 row lanes of a wave that share a quad, then the 4 waves through LDS
 #pragma unroll
