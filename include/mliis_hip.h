@@ -128,7 +128,7 @@ int mliis_bn_apply(const float* x, int ldx, float* y, int ldy, long long rows, i
 int mliis_bn_stats_partial(const float* x, int ldx, long long rows, int C, int pre_swish, float* part, size_t part_floats, int* nblk_out,
                            hipStream_t stream);
 /*      pool_part (nullable, training): the pass also leaves per-image partial sums of its OUTPUT, [rows/rows_per_img][*pool_chunks][C]
- *      (needs ceil(rows_per_img/256) * images * C floats) -- the squeeze-excite pooling (efficientnet_model.py:247) without a pass of
+ *      (needs ceil(rows_per_img/128) * images * C floats) -- the squeeze-excite pooling (efficientnet_model.py:247) without a pass of
  *      its own; mliis_se_mlp_fwd folds the chunks. */
 int mliis_bn_apply_fused(const float* x, int ldx, float* y, int ldy, long long rows, int C, int rows_per_img, const float* part, int nblk,
                          float eps, float momentum, int unbiased_moving_var, float* mean, float* rstd, float* moving_mean,

@@ -19,6 +19,7 @@ constexpr int kColThreads = 256;
 constexpr int kChanBlock = 32;   // channels per block: 8 float4 lanes = one 128-byte line per row
 constexpr int kRowLanes = 32;    // rows walked in parallel by one block
 constexpr int kBatch = 4;        // rows per thread whose loads are issued before any of them is consumed
+constexpr int kPoolRows = 128;   // rows per pooling chunk of bn_apply_fused (one batch per thread)
 
 // Streaming geometry shared by the column reductions and the BN apply kernels: grid = (row chunks, ceil(C/32)[, segments]);
 // a block owns 32 channels x rows_per_block rows, its 256 threads = 8 channel quads x 32 row lanes.  Small maps are latency-bound
@@ -854,11 +855,13 @@ int mliis_bn_apply_fused(const float* x, int ldx, float* y, int ldy, long long r
            moving_mean, moving_var};
   int gx, gy, rpb, cpi = 0;
   chan_grid(rows, C, &gx, &gy, &rpb);
-  if (pool_part != nullptr) {   // per-image pooling of the output: row chunks are cut per image (about 256 rows each)
+  // (every block folds all nblk statistics partials of its channels; taller row chunks would cut that redundant traffic but measured
+  //  the same on the whole step: profiles/r01_notes.md)
+  if (pool_part != nullptr) {   // per-image pooling of the output: row chunks are cut per image (about 128 rows each)
     MLIIS_REQUIRE(pool_chunks && aligned16(pool_part) && rows % rows_per_img == 0, MLIIS_ERR_ARG,
                   "bn_apply_fused: pooling needs an aligned buffer, a pool_chunks output and whole images");
     const long long nimg = rows / rows_per_img;
-    cpi = (rows_per_img + 255) / 256;
+    cpi = (rows_per_img + kPoolRows - 1) / kPoolRows;
     rpb = (rows_per_img + cpi - 1) / cpi;
     gy = (int)(nimg * cpi);
     MLIIS_REQUIRE((size_t)gy * C <= pool_floats, MLIIS_ERR_WORKSPACE, "bn_apply_fused: pool buffer too small (%zu floats needed, %zu given)",

@@ -103,8 +103,8 @@ class _Plan:
             need = max(need, -(-(N * m.h * m.h) // 64) * 2 * m.c_out, ops.bn_stats_partial_floats(N * m.h * m.h, m.c_out))
         need = max(need, ops.bn_stats_partial_floats(N * hs * hs, a.stem_out))
         self.stats_part = buf(need + 64)
-        # squeeze-excite pooling partials of the bn1 apply pass: [N][ceil(rows_per_img / 256)][C]
-        self.pool_part = buf(max(N * (-(-(b.h_out * b.h_out) // 256)) * b.cexp for b in a.blocks if b.executed) + 64)
+        # squeeze-excite pooling partials of the bn1 apply pass: [N][ceil(rows_per_img / 128)][C]
+        self.pool_part = buf(max(N * (-(-(b.h_out * b.h_out) // 128)) * b.cexp for b in a.blocks if b.executed) + 64)
         # ---- deferred weight-gradient folds: every *_bwd_filter leaves its per-split slabs in a region of fold_buf and ONE
         #      mliis_fold_batched launch at the end of the backward pass reduces them all into the gradient arena
         A = L.arena

@@ -278,9 +278,9 @@ def test_bn_apply_pools_for_squeeze_excite(C, Rr, N, HW):
     part = torch.empty(ops.bn_stats_partial_floats(N * HW, C) + 16, device=d)
     nblk = ops.bn_stats_partial(xg, False, part)
     m_o, r_o = torch.empty(C, device=d), torch.empty(C, device=d)
-    pool = torch.full((N * (-(-HW // 256)) * C + 16,), 3.0, device=d)
+    pool = torch.full((N * (-(-HW // 128)) * C + 16,), 3.0, device=d)
     ag, chunks = ops.bn_apply_fused(xg, part, nblk, m_o, r_o, f32(gamma, d), f32(beta, d), post_swish=True, pool_part=pool)
-    assert chunks == -(-HW // 256)
+    assert chunks == -(-HW // 128)
     close(ag, a, 3e-5, "bn apply (pooling variant)")
     sg = torch.empty(N, C, device=d)
     hp, gg = ops.se_mlp_fwd(pool, f32(w1, d), f32(b1, d), f32(w2, d), f32(b2, d), chunks=chunks, scale=1.0 / HW, s_out=sg)
