@@ -51,6 +51,11 @@ def _task_rng(seed: int, meta_iter: int, task: int) -> random.Random:
     return random.Random((seed * 1000003 + meta_iter) * 1000003 + task)
 
 
+def _to_numpy(a):
+    import numpy as np
+    return a.detach().cpu().numpy() if hasattr(a, "detach") else np.asarray(a)
+
+
 class Gecko:
     """A meta-learning session for image segmentation that extends Reptile (reference class of the same name)."""
 
@@ -58,20 +63,23 @@ class Gecko:
 
     def __init__(self, learner, variables=None, transductive: bool = False, pre_step_op=None, lr_scheduler=None, augment: bool = False,
                  aug_rate: Optional[float] = None, dist: Optional[Dist] = None, rng_mode: Optional[str] = None, seed: int = 0):
-        if augment:
-            raise NotImplementedError("--augment (host numpy augmentation, augmenters/np_augmenters.py) is not built yet; "
-                                      "SURVEY.md 8(f)-4")
         self.learner = learner
         self._transductive = transductive
         # pre_step_op: the reference passes a TF op that multiplies all trainables by `weight_decay_rate`
         # (variables.py:48-55); here it is that rate (float) or None.
         self._pre_step_rate = 1.0 if pre_step_op is None else float(pre_step_op)
         self.lr_scheduler = lr_scheduler
-        self.augmenter = None
         self.aug_rate = aug_rate
         self.eval_sample_number = 0
         self.dist = dist or Dist()
         self.rng_mode = rng_mode or ("reference" if self.dist.world == 1 else "per_task")
+        # host augmentation of the inner-loop batches (reptile.py:44-49, augmenters/np_augmenters.py).  rng_mode "reference": the
+        # global `random` / `numpy.random` streams, like the reference; "per_task": private streams re-seeded per (meta-iter, task).
+        self.augmenter = None
+        if augment:
+            from .augment import Augmenter
+            self.augmenter = Augmenter()
+        print("Augmentation rate {}".format(self.aug_rate))
         if self.rng_mode == "reference" and self.dist.world > 1:
             raise ValueError("rng_mode='reference' consumes the global generator sequentially and is only valid on one rank")
         self.seed = seed
@@ -88,8 +96,23 @@ class Gecko:
 
     def _sample(self, dataset, num_shots, rng):
         (images, labels) = metaseg.sample_task(dataset, num_shots, rng)
-        self.learner.load_task(images, labels)
+        if self.augmenter is None:
+            self.learner.load_task(images, labels)
+        else:   # augmented batches are built on the host from these arrays and uploaded one inner step at a time
+            self._host_task = (_to_numpy(images), _to_numpy(labels))
         return int(images.shape[0])
+
+    _train_aug_rate_from_self = False   # Reptile's train_step does not forward aug_rate to _mini_batches (reptile.py:108); FOMAML does
+
+    def _augmented_task_batches(self, inner_batch_size, inner_iters, replacement, rng, task_idx):
+        if rng is not None:   # per-task mode: private, reproducible streams for the augmenter as well
+            import numpy as np
+            self.augmenter.py = rng
+            self.augmenter.npr = np.random.RandomState(_task_rng(self.seed, self.meta_iter, task_idx).getrandbits(32))
+        x, y = self._host_task
+        return metaseg.augmented_batches(x, y, inner_batch_size, inner_iters, replacement, self.augmenter,
+                                         self.aug_rate if self._train_aug_rate_from_self else None, rng,
+                                         tail_shots=getattr(self, "tail_shots", None), fomaml=self._train_aug_rate_from_self)
 
     def _run_meta_batch(self, dataset, num_shots, inner_batch_size, inner_iters, replacement, meta_step_size, meta_batch_size, lr,
                         fomaml: bool):
@@ -111,12 +134,18 @@ class Gecko:
                 if self.rng_mode != "reference" and t % D.world != D.rank:
                     continue
                 n_shots = self._sample(dataset, num_shots, rng)
-                batches = self._task_batches(n_shots, inner_batch_size, inner_iters, replacement, rng)
+                if self.augmenter is None:
+                    batches = self._task_batches(n_shots, inner_batch_size, inner_iters, replacement, rng)
+                else:
+                    batches = self._augmented_task_batches(inner_batch_size, inner_iters, replacement, rng, t)
                 L.import_bn(self._bn_zero)
                 last_backup = None
                 for j, idx in enumerate(batches):
                     if fomaml and j == inner_iters - 1:
                         last_backup = L.export_trainable()
+                    if self.augmenter is not None:   # idx is an augmented (images, labels) batch: make it the resident "task"
+                        L.load_task(idx[0], idx[1])
+                        idx = list(range(int(idx[0].shape[0])))
                     self._step(idx, j, lr)
                 # delta += theta_task - (theta_before_last_step | theta_old)
                 L.axpby(1.0, L.export_trainable(), 1.0, delta)
@@ -176,7 +205,8 @@ class Gecko:
             train_idx, test_idx = metaseg.split_indices(n, test_shots)
             iou = self._evaluate(train_idx, test_idx, labels, inner_batch_size, inner_iters, replacement, lr=lr, task_name=name,
                                  save_fine_tuned_checkpoints=save_fine_tuned_checkpoints,
-                                 save_fine_tuned_checkpoints_dir=save_fine_tuned_checkpoints_dir, eval_sample_num=eval_sample_num)
+                                 save_fine_tuned_checkpoints_dir=save_fine_tuned_checkpoints_dir, eval_sample_num=eval_sample_num,
+                                 aug_rate=self.aug_rate if aug_rate is None else aug_rate, images=images)
             ious.append(iou)
             task_iou_map[name] = iou
         mean_iou = float(np.nanmean(ious))
@@ -184,15 +214,28 @@ class Gecko:
         return mean_iou, task_iou_map
 
     def _evaluate(self, train_idx, test_idx, labels, inner_batch_size, inner_iters, replacement, lr=None, task_name=None,
-                  save_fine_tuned_checkpoints=False, save_fine_tuned_checkpoints_dir=None, eval_sample_num=None):
+                  save_fine_tuned_checkpoints=False, save_fine_tuned_checkpoints_dir=None, eval_sample_num=None, aug_rate=None,
+                  images=None):
         """Evaluates a single task's train/test split (reptile.py:235-294): ALL global variables are restored afterwards."""
         import numpy as np
         from .metrics import iou as _iou
         L = self.learner
         old = L.export_all()
         inner_iter = 0
-        for inner_iter, b in enumerate(metaseg.mini_batch_indices(len(train_idx), inner_batch_size, inner_iters, replacement)):
-            idx = [train_idx[i] for i in b]
+        if self.augmenter is None:
+            schedule = metaseg.mini_batch_indices(len(train_idx), inner_batch_size, inner_iters, replacement)
+        else:   # fine-tune on augmented copies of the support examples (reptile.py:261-262), built on the host
+            if images is None:
+                raise ValueError("_evaluate with augmentation needs the task's images")
+            x, y = _to_numpy(images), _to_numpy(labels)
+            schedule = metaseg.augmented_batches(x[train_idx], y[train_idx], inner_batch_size, inner_iters, replacement, self.augmenter,
+                                                 aug_rate)
+        for inner_iter, b in enumerate(schedule):
+            if self.augmenter is None:
+                idx = [train_idx[i] for i in b]
+            else:
+                L.load_task(b[0], b[1])
+                idx = list(range(int(b[0].shape[0])))
             if lr is not None:
                 L.inner_step(idx, lr=lr, weight_decay_rate=self._pre_step_rate)
             elif self.lr_scheduler is not None:
@@ -203,6 +246,8 @@ class Gecko:
             from .checkpoint import save_fine_tuned_checkpoint
             L.synchronize()
             save_fine_tuned_checkpoint(L.arena.named_numpy(), save_fine_tuned_checkpoints_dir, task_name, eval_sample_num, inner_iter)
+        if self.augmenter is not None:
+            L.load_task(images, labels)   # the augmented batches replaced the resident task
         preds = self._test_predictions(train_idx, test_idx)
         lab = labels.detach().cpu().numpy() if hasattr(labels, "detach") else np.asarray(labels)
         class_iou = float(np.nanmean([_iou(preds[j], lab[test_idx[j]]) for j in range(len(test_idx))]))
@@ -226,6 +271,7 @@ class FOMLIS(Gecko):
     """First-order MAML for image segmentation (reference class of the same name, reptile.py:569-663)."""
 
     meta_fn = "FOMAML"
+    _train_aug_rate_from_self = True   # reptile.py:654,661 pass aug_rate=self.aug_rate
 
     def __init__(self, *args, train_shots: Optional[int] = None, tail_shots: Optional[int] = None,
                  sample_train_val_with_replacement: bool = False, **kwargs):

@@ -6,8 +6,8 @@ inner-loop engine.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 run_metasegnet.py ...   (tasks sharded 1/GPU)
 
 Writes the reference's checkpoint directory layout (mliis_amd/checkpoint.py) and `<checkpoint>/meta-test_results.json`.
-Out of scope in this build (clear errors): UHO hyper-parameter search, k-shot learning-curve experiment, host augmentation
-(SURVEY.md 8(f)).  Checkpoints: numpy .npz or TensorFlow TensorBundle files (--checkpoint-format tf; restoring takes either).  Data: --data-dir with FSS-1000 TFRecord-GZIP shards
+Out of scope in this build (clear errors): UHO hyper-parameter search, k-shot learning-curve experiment.
+--augment / --aug_rate: the reference's host numpy augmentation of the inner-loop batches (mliis_amd/augment.py, same draws).  Checkpoints: numpy .npz or TensorFlow TensorBundle files (--checkpoint-format tf; restoring takes either).  Data: --data-dir with FSS-1000 TFRecord-GZIP shards
 (mliis_amd/tfrecord.py, no TensorFlow needed) or --synthetic-tasks N.
 """
 import datetime

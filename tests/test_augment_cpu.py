@@ -1,0 +1,111 @@
+"""mliis_amd.augment vs the reference augmenter's own outputs (tests/golden/augment.npz, made by importing
+/root/reference/augmenters/np_augmenters.py): bit-exact for the same seeds, same generator consumption."""
+import os
+import random
+
+import numpy as np
+import pytest
+
+from mliis_amd import augment
+from mliis_amd.augment import Augmenter
+
+
+@pytest.fixture(autouse=True)
+def _pristine_order():
+    augment._SHARED_ORDER[:] = augment.PRISTINE_ORDER   # the operation order is process-wide state (like the reference's)
+    yield
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SIZE = 24
+
+
+def _inputs(n, seed=123):
+    g = np.random.RandomState(seed)
+    out = []
+    for _ in range(n):
+        img = (g.rand(SIZE, SIZE, 3) * 255).astype(np.float32)
+        fg = (g.rand(SIZE, SIZE) < 0.35).astype(np.float32)
+        out.append((img, np.stack([1 - fg, fg], axis=2)))
+    return out
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(os.path.join(HERE, "golden", "augment.npz"))
+
+
+def _same(a, b, what):
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape and a.dtype == b.dtype, (what, a.shape, b.shape, a.dtype, b.dtype)
+    assert np.array_equal(a, b), what
+
+
+def test_each_operation_bit_exact(gold):
+    names = ["erase", "translate", "flip", "noise", "exposure", "rotate"]
+    data = _inputs(3 * len(names))
+    k = 0
+    for name in names:
+        for s in range(3):
+            random.seed(100 + s)
+            np.random.seed(200 + s)
+            img, msk = data[k]
+            k += 1
+            a, b = getattr(Augmenter(verbose=False), name)(img.copy(), msk.copy())
+            _same(a, gold["op_%s_%d_image" % (name, s)], "%s image seed %d" % (name, s))
+            _same(b, gold["op_%s_%d_mask" % (name, s)], "%s mask seed %d" % (name, s))
+
+
+def test_driver_sequence_and_generator_consumption(gold):
+    random.seed(7)
+    np.random.seed(11)
+    aug = Augmenter(verbose=False)
+    probs = [None, 0.0, 0.5]
+    for i, (img, msk) in enumerate(_inputs(36, seed=321)):
+        keep_img = img.copy()
+        res = aug.apply_augmentations(img, msk, probs[i % 3])
+        assert isinstance(res, list) == bool(gold["seq_%02d_islist" % i]), i
+        _same(res[0], gold["seq_%02d_image" % i], "call %d image" % i)
+        _same(res[1], gold["seq_%02d_mask" % i], "call %d mask" % i)
+        assert np.array_equal(img, keep_img), "inputs must not be modified"
+    assert random.random() == float(gold["final_py_random"]) and np.random.rand() == float(gold["final_np_random"])
+
+
+def test_private_generators_do_not_touch_the_global_ones():
+    random.seed(1)
+    np.random.seed(1)
+    a0, b0 = random.random(), np.random.rand()
+    random.seed(1)
+    np.random.seed(1)
+    aug = Augmenter(py=random.Random(5), npr=np.random.RandomState(6), verbose=False)
+    img, msk = _inputs(1)[0]
+    for _ in range(5):
+        aug.apply_augmentations(img, msk, 0.0)
+    assert (random.random(), np.random.rand()) == (a0, b0)
+    aug2 = Augmenter(py=random.Random(5), npr=np.random.RandomState(6), verbose=False)
+    aug3 = Augmenter(py=random.Random(5), npr=np.random.RandomState(6), verbose=False)
+    r2, r3 = aug2.apply_augmentations(img, msk, 0.0), aug3.apply_augmentations(img, msk, 0.0)
+    assert np.array_equal(r2[0], r3[0]) and np.array_equal(r2[1], r3[1])
+
+
+@pytest.mark.parametrize("tag,repl", [("wrap", False), ("repl", True)])
+def test_mini_batches_with_augmentation_match_the_reference_schedule(gold, tag, repl):
+    """metaseg._mini_batches / augmented_batches with an augmenter == the reference's _mini_batches (5 samples, batches of 4 with
+    wrap-around or with replacement): same batches bit for bit and the same generator states afterwards."""
+    from mliis_amd import metaseg
+    samples = _inputs(5, seed=555)
+    random.seed(31)
+    np.random.seed(32)
+    got = list(metaseg._mini_batches(samples, 4, 4, replacement=repl, augmenter=Augmenter(verbose=False), aug_rate=0.5))
+    assert len(got) == 4
+    for bi, batch in enumerate(got):
+        _same(np.stack([np.asarray(b[0], dtype=np.float32) for b in batch]), gold["mb_%s_%d_images" % (tag, bi)], "batch %d images" % bi)
+        _same(np.stack([np.asarray(b[1], dtype=np.float32) for b in batch]), gold["mb_%s_%d_masks" % (tag, bi)], "batch %d masks" % bi)
+    assert random.random() == float(gold["mb_%s_final_py" % tag]) and np.random.rand() == float(gold["mb_%s_final_np" % tag])
+    # the array form used by the device learner draws identically (from the same starting state of the shared operation order)
+    augment._SHARED_ORDER[:] = augment.PRISTINE_ORDER
+    random.seed(31)
+    np.random.seed(32)
+    x, y = np.stack([s[0] for s in samples]), np.stack([s[1] for s in samples])
+    for bi, (xb, yb) in enumerate(metaseg.augmented_batches(x, y, 4, 4, repl, Augmenter(verbose=False), 0.5)):
+        _same(xb, gold["mb_%s_%d_images" % (tag, bi)], "array form batch %d" % bi)
+        _same(yb, gold["mb_%s_%d_masks" % (tag, bi)], "array form batch %d masks" % bi)
