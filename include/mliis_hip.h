@@ -62,26 +62,24 @@ int mliis_dwconv_bwd_filter(const float* x, const float* dy, float* dw, int N, i
 
 /* ---- dense conv (k 1|3, stride 1, TF-SAME, dilation >= 1, optional bias) on the fp32 matrix cores:
  *      tf.layers.Conv2D 1x1 expand/project (efficientnet_model.py:175-182,225-232) and tf.layers.conv2d of the RSD decoder /
- *      ASPP (models/efficientlab.py:185-190,218-224,258-283).  w is TF HWIO [k,k,Cin,Cout].  `accumulate` != 0 adds into the
- *      destination.  ws may be NULL (disables split-K). */
+ *      ASPP (models/efficientlab.py:185-190,218-224,258-283).  w is TF HWIO [k,k,Cin,Cout]; the forward reads its K-contiguous
+ *      copy wt [k,k,Cout,Cin] (mliis_transpose_weights, once per weight update), backward-data reads w itself.  `accumulate` != 0
+ *      adds into the destination.  ws may be NULL (disables split-K). */
 size_t mliis_conv2d_workspace_floats(int Nimg, int H, int W, int Cred, int Nout, int ksize);
 /*      tiling chosen for a fwd / bwd-data call (row-tile factor, column tiles, split-K factor) and the name of the kernel
  *      instantiation it launches, as rocprofv3 prints it (profiling aids: bench.py matches its live timings to the trace) */
 int mliis_conv2d_plan(int Nimg, int H, int W, int Cred, int Nout, int ksize, int* tm, int* nt, int* splits);
-int mliis_conv2d_kernel_name(int Nimg, int H, int W, int Cred, int Nout, int ksize, int k_contiguous_b, int has_scale, char* buf,
-                             size_t buf_len);
+int mliis_conv2d_kernel_name(int Nimg, int H, int W, int Cred, int Nout, int ksize, int has_scale, char* buf, size_t buf_len);
 /*      stats_part (nullable): the epilogue also emits the following batch norm's stage-1 statistics -- per row-block column sums
  *      {sum v, sum v^2} (of swish(v) when stats_swish) as [*stats_nblk][2][Cout], written by the GEMM epilogue or, on a split-K
  *      plan, by the slab fold.  *stats_nblk == 0 means "not produced": the caller must run mliis_bn_stats_partial instead.
  *      Needs >= ceil(M/64) * 2 * Cout floats; requires accumulate == 0. */
-/*      wt (nullable): K-contiguous shadow copy of w, layout [k,k,Cout,Cin] (mliis_transpose_weights); when given, the forward
- *      GEMM reads it instead of w (same result, faster B-operand path). */
 /*      x_scale (nullable, [Nimg,Cin], 1x1 convs): x[m,c] is multiplied by x_scale[image(m),c] while it is staged -- the
  *      squeeze-excite gate (efficientnet_model.py:251) applied on the fly, so the gated tensor is never materialised. */
 /*      The weight tensor has Cin_total input channels; the conv reads its channels [ci_begin, ci_begin+Cin) against x's Cin
  *      channels.  border_bias (nullable, [Nimg,9,Cout], 3x3 dilation 1 only): per-pixel bias selected by the pixel's border
  *      class -- the exact contribution of spatially constant input channels (mliis_rsd_pool_fwd). */
-int mliis_conv2d_fwd(const float* x, int ldx, const float* x_scale, const float* w, const float* wt, const float* bias,
+int mliis_conv2d_fwd(const float* x, int ldx, const float* x_scale, const float* wt, const float* bias,
                      const float* border_bias, float* y, int ldy, int Nimg, int H, int W, int Cin_total, int ci_begin, int Cin, int Cout,
                      int ksize, int dil, int accumulate, float* stats_part, int stats_swish, int* stats_nblk, float* ws,
                      size_t ws_floats, hipStream_t stream);

@@ -1,32 +1,26 @@
-// Dense convolutions as implicit GEMMs on the fp32 matrix cores (v_mfma_f32_16x16x4_f32), NHWC activations,
-// TF HWIO weights.  One kernel family serves
-//   * MBConv 1x1 expand/project convs         (models/efficientnet/efficientnet_model.py:175-182,225-232)
+// Dense convolutions as implicit GEMMs on the fp32 matrix cores (v_mfma_f32_16x16x4_f32), NHWC activations, TF HWIO weights.
+// One kernel family serves
+//   * MBConv 1x1 expand/project convs           (models/efficientnet/efficientnet_model.py:175-182,225-232)
 //   * RSD decoder 1x1 / 3x3 / 3x3-dilated convs (models/efficientlab.py:185-190,218-224) and optional ASPP (:248-289)
-// in forward ("NN": B = W[tap][ci][co]), backward-data ("NK": the same HWIO buffer read as B^T with the tap offset
-// negated -- no weight transpose is ever materialised) and backward-filter (reduction over pixels, split over M,
-// deterministic two-stage fold).
+// in forward, backward-data and backward-filter.  Both GEMM operands are always K-contiguous ("NK"): backward-data reads the
+// HWIO buffer itself as B^T with the tap offset negated; forward reads the HWOI shadow copy that mliis_transpose_weights
+// refreshes once per inner step (2 % of a step, and it buys the 16-byte fragment path for B).
 //
 // Tiling (wave = 64 lanes, 4 waves per workgroup):
-//   forward / bwd-data : block tile (64*TM) x (16*NT) outputs, K step 32; wave w owns rows [16*TM*w, 16*TM*(w+1)).
-//     A tile in LDS as [kq = k/4][row ^ kq][4] : 16-byte fragments, conflict-free ds_write_b128 (8 lanes = 8 rows^kq) and
-//     conflict-free ds_read_b128 (a 16-lane read group covers 16 distinct rows mod 16).  Inside every 16-wide K group the K
-//     order is permuted identically for A and B (lane group g owns k = 4g..4g+3), so one b128 read feeds 4 MFMAs.
-//     B tile: NK (weights K-contiguous: backward-data on the HWIO buffer, forward on the HWOI shadow copy that
-//             mliis_transpose_weights refreshes once per step) -> same 16-byte fragment layout as A (one b128 read per 4 MFMAs);
-//             NN (forward straight from HWIO, kept for callers without a shadow copy) -> [k][BN+4] read with ds_read_b32.
+//   forward / bwd-data (conv_gemm_nk_k): block tile (64*TM) x (16*NT) outputs; wave w owns rows [16*TM*w, 16*TM*(w+1)).
+//     K is the flattened (tap, channel) index cut into chunks of 32.  A and B tiles sit in LDS as [kq = k/4][row ^ kq][4]:
+//     16-byte fragments, conflict-free ds_write_b128 (8 lanes = 8 rows ^ kq) and conflict-free ds_read_b128 (a 16-lane read group
+//     covers 16 distinct rows mod 16).  Inside every 16-wide K group the K order is permuted identically for A and B (lane group g
+//     owns k = 4g..4g+3), so one b128 read feeds 4 MFMAs.
 //   Planner: 64-row blocks (TM = 1) so two workgroups share a CU and hide each other's LDS/barrier latency (measured: rsd2
-//   fuse bwd-data 54 -> 85 TF vs one 128-row block per CU); a K chunk whose second 16-wide group is pure padding skips it.
-//   bwd-filter : block tile (64*TMF ci) x (16*NT co) for one tap; streams 32 pixels per step; A = X^T, B = dY, both
-//     read k-major with ds_read_b32 (row stride == 16 mod 32 banks).
-// Global loads are float4 along C (128-byte spans per 8 lanes), software-pipelined through registers (load chunk i+1
-// while chunk i is multiplied).
+//     fuse bwd-data 54 -> 85 TF vs one 128-row block per CU); narrower column tiles / split-K for grids smaller than the chip.
+//   bwd-filter (conv_filter_grad2_k): block tile (64*TMF ci) x (16*NT co) for one tap; streams 32 pixels per step; A = X^T,
+//     B = dY, both read k-major with ds_read_b32 (row stride == 16 mod 32 banks); per-split slabs, deterministic fold.
+// Global loads are raw 16-byte buffer loads along C (128-byte spans per 8 lanes) whose offset is pushed out of range for padding
+// (the hardware returns zeros: no branches), software-pipelined two chunks deep through registers into double-buffered LDS.
 #include <stdlib.h>
 
 #include <type_traits>
-
-#ifndef MLIIS_GEMM_EXP
-#define MLIIS_GEMM_EXP 0   // timing experiments only (1: no barrier, 2: no global loads, 3: no LDS stores) -- results are wrong
-#endif
 
 #include "common.hpp"
 
@@ -59,293 +53,11 @@ struct ConvGemmParams {
                              //             channels of a 3x3 SAME conv (the RSD pooled branch) without convolving them
 };
 
-template <int TM, int NT, bool B_NK>
-__global__ __launch_bounds__(256, 2) void conv_gemm_k(ConvGemmParams p) {
-  constexpr int BM = 64 * TM, BN = 16 * NT, BK = 32;
-  constexpr int LDB_NN = BN + 4;
-  constexpr int A_FLOATS = 8 * BM * 4;
-  constexpr int B_FLOATS = B_NK ? 8 * BN * 4 : BK * LDB_NN;
-  constexpr int A_PER_THREAD = 2 * TM;                    // float4 per thread per chunk
-  constexpr int B_TOTAL = B_NK ? BN * 8 : BK * (BN / 4);  // float4 per chunk
-  constexpr int B_PER_THREAD = (B_TOTAL + 255) / 256;
-  constexpr int LDS_STAGE = BN + 4;                        // epilogue staging row stride (floats)
-  constexpr int STAGE_FLOATS = 4 * 16 * LDS_STAGE;         // 4 waves x 16 rows
-  constexpr int SM_FLOATS = (A_FLOATS + B_FLOATS) > STAGE_FLOATS ? (A_FLOATS + B_FLOATS) : STAGE_FLOATS;
-  __shared__ __attribute__((aligned(16))) float sm[SM_FLOATS];
-  float* smA = sm;
-  float* smB = sm + A_FLOATS;
-
-  const int t = threadIdx.x;
-  const int lane = t & 63, wave = t >> 6;
-  const int l15 = lane & 15, g = lane >> 4;
-  const long long M = (long long)p.Nimg * p.H * p.W;
-  const int n0 = blockIdx.y * BN;
-  const int cpc = (p.C + BK - 1) / BK;  // chunks per tap
-  const int nchunks_total = p.ntaps * cpc;
-  int it0 = blockIdx.z * p.chunks_per_split;
-  int it1 = it0 + p.chunks_per_split;
-  if (it1 > nchunks_total) it1 = nchunks_total;
-
-  const bool split = p.partial != nullptr;
-  const bool stats = (p.stats_part != nullptr) && !split;
-  float s1[NT], s2[NT];   // BN statistics of this block's columns, accumulated over all its row tiles
-#pragma unroll
-  for (int j = 0; j < NT; ++j) s1[j] = s2[j] = 0.f;
-
-  const unsigned bx = xcd_remap(blockIdx.x, gridDim.x);   // neighbouring row tiles (shared 3x3 halos) on the same XCD's L2
-  const long long m0 = (long long)bx * BM;
-
-  // ---- per-thread A rows
-  const int a_kq = t & 7;
-  const int a_r0 = t >> 3;  // 0..31
-  int a_h[A_PER_THREAD], a_w[A_PER_THREAD], a_n[A_PER_THREAD];
-  long long a_m[A_PER_THREAD];
-#pragma unroll
-  for (int i = 0; i < A_PER_THREAD; ++i) {
-    long long m = m0 + a_r0 + 32 * i;
-    a_m[i] = m;
-    a_n[i] = 0;
-    if (m < M) {
-      a_n[i] = (int)(m / ((long long)p.H * p.W));
-      int rem = (int)(m % ((long long)p.H * p.W));
-      a_h[i] = rem / p.W;
-      a_w[i] = rem - a_h[i] * p.W;
-    } else {
-      a_h[i] = -100000;
-      a_w[i] = -100000;
-    }
-  }
-
-  float4 ra[A_PER_THREAD];
-  float4 rb[B_PER_THREAD];
-
-  auto load_chunk = [&](int it) {
-    const int tap = it / cpc;
-    const int c0 = (it - tap * cpc) * BK;
-    int dh = 0, dw = 0;
-    if (p.ntaps > 1) {
-      dh = (tap / 3 - 1) * p.dil * p.sign;
-      dw = (tap % 3 - 1) * p.dil * p.sign;
-    }
-    const int ca = c0 + a_kq * 4;
-#pragma unroll
-    for (int i = 0; i < A_PER_THREAD; ++i) {
-      const int hh = a_h[i] + dh, ww = a_w[i] + dw;
-      const bool ok = (a_m[i] < M) && (ca < p.C) && (hh >= 0) && (hh < p.H) && (ww >= 0) && (ww < p.W);
-      ra[i] = ok ? ld4(p.A + (a_m[i] + (long long)dh * p.W + dw) * p.lda + ca) : f4zero();
-      if (p.a_scale != nullptr && ok) ra[i] = f4mul(ra[i], ld4(p.a_scale + (long long)a_n[i] * p.C + ca));
-    }
-    const float* Bt = p.B + (long long)tap * p.b_tap_stride;
-#pragma unroll
-    for (int i = 0; i < B_PER_THREAD; ++i) {
-      const int idx = t + 256 * i;
-      rb[i] = f4zero();
-      if (idx < B_TOTAL) {
-        if (B_NK) {
-          const int n = idx >> 3, kq = idx & 7;
-          const int k = c0 + kq * 4;
-          if (n0 + n < p.Nout && k < p.C) rb[i] = ld4(Bt + (long long)(n0 + n) * p.ldb + k);
-        } else {
-          const int k = idx / (BN / 4), nq = idx - k * (BN / 4);
-          const int n = n0 + nq * 4;
-          if (c0 + k < p.C && n < p.Nout) rb[i] = ld4(Bt + (long long)(c0 + k) * p.ldb + n);
-        }
-      }
-    }
-  };
-
-  auto store_chunk = [&]() {
-#pragma unroll
-    for (int i = 0; i < A_PER_THREAD; ++i) {
-      const int row = a_r0 + 32 * i;
-      st4(smA + (a_kq * BM + (row ^ a_kq)) * 4, ra[i]);
-    }
-#pragma unroll
-    for (int i = 0; i < B_PER_THREAD; ++i) {
-      const int idx = t + 256 * i;
-      if (idx < B_TOTAL) {
-        if (B_NK) {
-          const int n = idx >> 3, kq = idx & 7;
-          st4(smB + (kq * BN + (n ^ kq)) * 4, rb[i]);
-        } else {
-          const int k = idx / (BN / 4), nq = idx - k * (BN / 4);
-          st4(smB + k * LDB_NN + nq * 4, rb[i]);
-        }
-      }
-    }
-  };
-
-  f32x4 acc[TM][NT];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  if (it0 < it1) load_chunk(it0);
-  for (int it = it0; it < it1; ++it) {
-    store_chunk();
-    __syncthreads();
-    if (it + 1 < it1) load_chunk(it + 1);
-    // the second 16-wide k group of a chunk is all zero padding when the channel count ends inside the first one
-    const int c0_cur = (it - (it / cpc) * cpc) * BK;
-    const int qmax = (c0_cur + 16 < p.C) ? 2 : 1;
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      if (q >= qmax) continue;
-      const int kq = q * 4 + g;
-      float4 av[TM];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int row = wave * 16 * TM + i * 16 + l15;
-        av[i] = ld4(smA + (kq * BM + (row ^ kq)) * 4);
-      }
-      if (B_NK) {
-        float4 bv[NT];
-#pragma unroll
-        for (int j = 0; j < NT; ++j) bv[j] = ld4(smB + (kq * BN + ((j * 16 + l15) ^ kq)) * 4);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-#pragma unroll
-          for (int i = 0; i < TM; ++i) {
-            const float a = s == 0 ? av[i].x : s == 1 ? av[i].y : s == 2 ? av[i].z : av[i].w;
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-              const float b = s == 0 ? bv[j].x : s == 1 ? bv[j].y : s == 2 ? bv[j].z : bv[j].w;
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i][j], 0, 0, 0);
-            }
-          }
-        }
-      } else {
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          float bs[NT];
-#pragma unroll
-          for (int j = 0; j < NT; ++j) bs[j] = smB[(q * 16 + 4 * g + s) * LDB_NN + j * 16 + l15];
-#pragma unroll
-          for (int i = 0; i < TM; ++i) {
-            const float a = s == 0 ? av[i].x : s == 1 ? av[i].y : s == 2 ? av[i].z : av[i].w;
-#pragma unroll
-            for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bs[j], acc[i][j], 0, 0, 0);
-          }
-        }
-      }
-    }
-    __syncthreads();
-  }
-
-  // ---- epilogue.  C/D layout of 16x16x4: col = lane & 15, row = 4 * (lane >> 4) + reg.  Final values go through a per-wave
-  // LDS staging tile so that global stores are whole rows (BN*4 contiguous bytes, float4 per lane) instead of 64-byte pieces.
-  if (split) {
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const long long m = m0 + wave * 16 * TM + i * 16 + g * 4 + r;
-        if (m >= M) continue;
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          const int n = n0 + j * 16 + l15;
-          if (n < p.Nout) p.partial[((long long)blockIdx.z * M + m) * p.Nout + n] = acc[i][j][r];
-        }
-      }
-  } else {
-    float* stage = sm + wave * 16 * LDS_STAGE;
-    float bj[NT];
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int n = n0 + j * 16 + l15;
-      bj[j] = (p.bias != nullptr && n < p.Nout) ? p.bias[n] : 0.f;
-    }
-    const long long HWp = (long long)p.H * p.W;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const long long mbase = m0 + wave * 16 * TM + i * 16;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float* bb = nullptr;
-        if (p.border_bias != nullptr) {
-          const long long m = mbase + g * 4 + r;
-          if (m < M) {
-            const int ni = (int)(m / HWp);
-            const int rem = (int)(m - (long long)ni * HWp);
-            const int h = rem / p.W, w_ = rem - h * p.W;
-            const int cls = (h == 0 ? 0 : (h == p.H - 1 ? 2 : 1)) * 3 + (w_ == 0 ? 0 : (w_ == p.W - 1 ? 2 : 1));
-            bb = p.border_bias + ((long long)ni * 9 + cls) * p.Nout;
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          const int n = n0 + j * 16 + l15;
-          float v = acc[i][j][r] + bj[j];
-          if (bb != nullptr && n < p.Nout) v += bb[n];
-          acc[i][j][r] = v;   // keep the final value for the statistics below
-          stage[(g * 4 + r) * LDS_STAGE + j * 16 + l15] = v;
-        }
-      }
-      __syncthreads();
-#pragma unroll
-      for (int it = 0; it < NT; ++it) {
-        const int idx = it * 64 + lane;
-        const int row = idx / (BN / 4), q = idx - row * (BN / 4);
-        const long long m = mbase + row;
-        const int n = n0 + q * 4;
-        if (m < M && n < p.Nout) {
-          float4 v = ld4(stage + row * LDS_STAGE + q * 4);
-          float* dst = p.Cmat + m * p.ldc + n;
-          if (p.accumulate) v = f4add(v, ld4(dst));
-          st4(dst, v);
-        }
-      }
-      __syncthreads();
-    }
-    if (stats) {
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const long long m = m0 + wave * 16 * TM + i * 16 + g * 4 + r;
-          if (m >= M) continue;
-#pragma unroll
-          for (int j = 0; j < NT; ++j) {
-            const float v = acc[i][j][r];
-            const float u = p.stats_swish ? swish_f(v) : v;
-            s1[j] += u;
-            s2[j] = fmaf(u, u, s2[j]);
-          }
-        }
-    }
-  }
-  if (stats) {  // wave-uniform branch: fold rows over the 4 lane groups, then over the 4 waves through LDS (fixed order)
-    float* red = sm;  // K loop ended with a barrier: LDS is free.  layout [wave][2][BN]
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      float a = s1[j], b = s2[j];
-      a += __shfl_xor(a, 16, 64);
-      b += __shfl_xor(b, 16, 64);
-      a += __shfl_xor(a, 32, 64);
-      b += __shfl_xor(b, 32, 64);
-      if (g == 0) {
-        red[(wave * 2 + 0) * BN + j * 16 + l15] = a;
-        red[(wave * 2 + 1) * BN + j * 16 + l15] = b;
-      }
-    }
-    __syncthreads();
-    for (int idx = t; idx < 2 * BN; idx += 256) {
-      const int v = idx / BN, col = idx - v * BN;
-      const int n = n0 + col;
-      if (n < p.Nout) {
-        const float r0 = red[(0 * 2 + v) * BN + col] + red[(1 * 2 + v) * BN + col] + red[(2 * 2 + v) * BN + col] + red[(3 * 2 + v) * BN + col];
-        p.stats_part[((long long)bx * 2 + v) * p.Nout + n] = r0;
-      }
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------ NK path, second generation
-// Same tiling, LDS fragment layout and epilogue as conv_gemm_k<TM, NT, true>, restructured so the matrix pipe is not starved:
+// ------------------------------------------------------------------------------------------------ forward / backward-data
+// Built so that the matrix pipe is not starved:
 //  * global loads are raw buffer loads whose offset is forced out of range for padded / out-of-image / out-of-K elements (the
 //    hardware returns zeros) -- no branches, so the address arithmetic of chunk k+1 is scheduled between the MFMAs of chunk k;
-//  * (tap, channel offset) advance incrementally in scalar registers, per-row offsets are computed once;
+//  * every thread advances the (tap, channel) position of its own k quad incrementally, per-row offsets are computed once;
 //  * LDS is double buffered: one barrier per K chunk, the LDS writes of chunk k+1 overlap the MFMAs of chunk k of the other waves;
 //  * all fragments of a chunk are read from LDS before its first MFMA.
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -357,7 +69,7 @@ __device__ __forceinline__ float4 buf_ld4(__amdgpu_buffer_rsrc_t r, unsigned byt
   return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 
-template <int TM, int NT, int PF, bool SC, bool SPLIT>
+template <int TM, int NT, int PF, bool SC, bool SPLIT, bool NARROW>
 __global__ __launch_bounds__(256, 2) void conv_gemm_nk_k(ConvGemmParams p) {
   constexpr int BM = 64 * TM, BN = 16 * NT, BK = 32;
   constexpr int A_FLOATS = 8 * BM * 4;
@@ -427,17 +139,16 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_nk_k(ConvGemmParams p) {
     b_off[i] = (unsigned)((long long)(n0 + n) * p.ldb * 4);
   }
 
-  // ---- (tap, channel) of this thread's k quad in the next chunk to LOAD
-  int k_tap, k_c, k_th = 1, k_tw = 1;   // 1x1 convs: tap row / column stay at the centre (dh = dw = 0) for every in-range chunk
-  {
-    const int kabs = it0 * BK + kq * 4;
+  // ---- (tap, channel) of this thread's k quad in the next chunk to LOAD: channel k_c inside tap k_tap = 3 * k_th + k_tw
+  int k_tap, k_c, k_th, k_tw;
+  auto seek = [&](int kabs) {   // from scratch: integer divisions (start of the K range; every chunk of a NARROW instance)
     k_tap = kabs / p.C;
     k_c = kabs - k_tap * p.C;
-    if (p.ntaps > 1) {
-      k_th = k_tap / 3;
-      k_tw = k_tap - k_th * 3;
-    }
-  }
+    k_th = p.ntaps > 1 ? k_tap / 3 : 1;   // 1x1 convs sit on the centre tap (dh = dw = 0)
+    k_tw = p.ntaps > 1 ? k_tap - k_th * 3 : 1;
+  };
+  int kabs = it0 * BK + kq * 4;
+  seek(kabs);
   float4 ra[PF][A_PER_THREAD], rs[PF][A_PER_THREAD], rb[PF][B_PER_THREAD];
 
   // next chunk -> registers, then advance.  Branch-free (live == false turns every offset out of range: no memory traffic, zeros
@@ -445,6 +156,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_nk_k(ConvGemmParams p) {
   auto load_chunk = [&](float4* ra_, float4* rs_, float4* rb_, bool live) {
     const int dh = (k_th - 1) * p.dil * p.sign, dw = (k_tw - 1) * p.dil * p.sign;
     const bool kok = live & (k_tap < p.ntaps);
+    // (recomputed from (k_th, k_tw, k_c) every chunk: carrying the two byte offsets and (dh, dw) incrementally instead removes every
+    // integer multiply from the K loop but measured 4 % SLOWER on the 3x3 decoder convs -- three more live registers per thread)
     const unsigned da = (unsigned)(((dh * p.W + dw) * p.lda + k_c) * 4);
 #pragma unroll
     for (int i = 0; i < A_PER_THREAD; ++i) {
@@ -455,14 +168,19 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_nk_k(ConvGemmParams p) {
     const unsigned db = (unsigned)(((long long)k_tap * p.b_tap_stride + k_c) * 4);
 #pragma unroll
     for (int i = 0; i < B_PER_THREAD; ++i) rb_[i] = buf_ld4(rB, (kok & b_ok[i]) ? b_off[i] + db : kOob);
-    k_c += BK;
-    const bool wrap = k_c >= p.C;   // C >= 32 whenever there is more than one tap, so one wrap per chunk at most
-    k_c = wrap ? k_c - p.C : k_c;
-    k_tap += wrap ? 1 : 0;
-    k_tw += wrap ? 1 : 0;   // (a 1x1 conv wraps only into out-of-range taps, where the offsets are ignored)
-    const bool roll = k_tw == 3;
-    k_tw = roll ? 0 : k_tw;
-    k_th += roll ? 1 : 0;
+    if (NARROW) {   // 3x3 convs over fewer than 32 channels: a chunk spans several taps
+      kabs += BK;
+      seek(kabs);
+    } else {        // C >= 32 (or a 1x1 conv): at most one tap boundary per chunk
+      k_c += BK;
+      const bool wrap = k_c >= p.C;
+      k_c = wrap ? k_c - p.C : k_c;
+      k_tap += wrap ? 1 : 0;
+      k_tw += wrap ? 1 : 0;   // (a 1x1 conv wraps only into out-of-range taps, where the offsets are ignored)
+      const bool roll = k_tw == 3;
+      k_tw = roll ? 0 : k_tw;
+      k_th += roll ? 1 : 0;
+    }
   };
   auto store_chunk = [&](float* buf, const float4* ra_, const float4* rs_, const float4* rb_) {
     float* smA = buf;
@@ -501,9 +219,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_nk_k(ConvGemmParams p) {
   auto step = [&](auto UC, int j) {
     constexpr int U = decltype(UC)::value;
     constexpr int NX = (U + 1) % PF;
-#if MLIIS_GEMM_EXP != 2
     load_chunk(ra[U], rs[U], rb[U], j + PF < it1);
-#endif
     const float* smA = sm + cur * BUF_FLOATS;
     const float* smB = smA + A_FLOATS;
     constexpr bool kAllFirst = TM == 1;   // read the fragments of both k groups before the first MFMA (register budget permitting)
@@ -540,13 +256,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_nk_k(ConvGemmParams p) {
       read_frags(1);
       multiply(1);
     }
-#if MLIIS_GEMM_EXP != 3
     store_chunk(sm + (cur ^ 1) * BUF_FLOATS, ra[NX], rs[NX], rb[NX]);   // zeros after the last chunk: nobody reads them
-#endif
     cur ^= 1;
-#if MLIIS_GEMM_EXP != 1
     __syncthreads();
-#endif
   };
   typedef std::integral_constant<int, 0> U0;
   typedef std::integral_constant<int, 1 % PF> U1;
@@ -563,7 +275,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_nk_k(ConvGemmParams p) {
   if (it + 1 < it1) step(U1{}, it + 1);
   if (it + 2 < it1) step(U0{}, it + 2);
 
-  // ---- epilogue (identical to conv_gemm_k): C/D layout of 16x16x4: col = lane & 15, row = 4 * (lane >> 4) + reg
+  // ---- epilogue: C/D layout of 16x16x4: col = lane & 15, row = 4 * (lane >> 4) + reg
   if (split) {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -761,127 +473,8 @@ struct FilterGradParams {
   const float* x_scale;  // nullable [Nimg][C]: X[m][c] *= x_scale[image(m)][c] on load
 };
 
-template <int TMF, int NT>
-__global__ __launch_bounds__(256, 2) void conv_filter_grad_k(FilterGradParams p) {
-  constexpr int BCI = 64 * TMF, BN = 16 * NT, BKM = 32;
-  constexpr int LDX = BCI + 16;
-  constexpr int LDD = (BN % 32 == 0) ? BN + 16 : BN;
-  constexpr int X_PER_THREAD = (BKM * (BCI / 4)) / 256;  // 2 * TMF
-  constexpr int D_TOTAL = BKM * (BN / 4);
-  constexpr int D_PER_THREAD = (D_TOTAL + 255) / 256;
-  __shared__ __attribute__((aligned(16))) float sm[BKM * LDX + BKM * LDD];
-  float* smX = sm;
-  float* smD = sm + BKM * LDX;
-
-  const int t = threadIdx.x;
-  const int lane = t & 63, wave = t >> 6;
-  const int l15 = lane & 15, g = lane >> 4;
-  const long long M = (long long)p.Nimg * p.H * p.W;
-  const int cblocks = (p.C + BCI - 1) / BCI;
-  const int tap = blockIdx.x / cblocks;
-  const int ci0 = (blockIdx.x - tap * cblocks) * BCI;
-  const int n0 = blockIdx.y * BN;
-  long long mbeg = (long long)blockIdx.z * p.rows_per_split;
-  long long mend = mbeg + p.rows_per_split;
-  if (mend > M) mend = M;
-  int dh = 0, dw = 0;
-  if (p.ntaps > 1) {
-    dh = (tap / 3 - 1) * p.dil;
-    dw = (tap % 3 - 1) * p.dil;
-  }
-  const long long shift = (long long)dh * p.W + dw;
-  const long long HW = (long long)p.H * p.W;
-
-  const int x_cq = t % (BCI / 4);
-  const int x_r0 = t / (BCI / 4);  // rows x_r0 + (256/(BCI/4)) * i
-  constexpr int X_RSTEP = 256 / (BCI / 4);
-
-  float4 rx[X_PER_THREAD];
-  float4 rd[D_PER_THREAD];
-
-  auto load_chunk = [&](long long mc) {
-#pragma unroll
-    for (int i = 0; i < X_PER_THREAD; ++i) {
-      const long long m = mc + x_r0 + X_RSTEP * i;
-      bool ok = (m < mend) && (ci0 + x_cq * 4 < p.C);
-      if (ok && p.ntaps > 1) {
-        const int rem = (int)(m % HW);
-        const int h = rem / p.W, w = rem - h * p.W;
-        const int hh = h + dh, ww = w + dw;
-        ok = (hh >= 0) && (hh < p.H) && (ww >= 0) && (ww < p.W);
-      }
-      rx[i] = ok ? ld4(p.X + (m + shift) * p.ldx + ci0 + x_cq * 4) : f4zero();
-      if (p.x_scale != nullptr && ok) rx[i] = f4mul(rx[i], ld4(p.x_scale + (m / HW) * p.C + ci0 + x_cq * 4));
-    }
-#pragma unroll
-    for (int i = 0; i < D_PER_THREAD; ++i) {
-      const int idx = t + 256 * i;
-      rd[i] = f4zero();
-      if (idx < D_TOTAL) {
-        const int r = idx / (BN / 4), nq = idx - r * (BN / 4);
-        const long long m = mc + r;
-        const int n = n0 + nq * 4;
-        if (m < mend && n < p.Nout) rd[i] = ld4(p.dY + m * p.lddy + n);
-      }
-    }
-  };
-  auto store_chunk = [&]() {
-#pragma unroll
-    for (int i = 0; i < X_PER_THREAD; ++i) st4(smX + (x_r0 + X_RSTEP * i) * LDX + x_cq * 4, rx[i]);
-#pragma unroll
-    for (int i = 0; i < D_PER_THREAD; ++i) {
-      const int idx = t + 256 * i;
-      if (idx < D_TOTAL) {
-        const int r = idx / (BN / 4), nq = idx - r * (BN / 4);
-        st4(smD + r * LDD + nq * 4, rd[i]);
-      }
-    }
-  };
-
-  f32x4 acc[TMF][NT];
-#pragma unroll
-  for (int i = 0; i < TMF; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  if (mbeg < mend) load_chunk(mbeg);
-  for (long long mc = mbeg; mc < mend; mc += BKM) {
-    store_chunk();
-    __syncthreads();
-    if (mc + BKM < mend) load_chunk(mc + BKM);
-#pragma unroll
-    for (int kk = 0; kk < BKM / 4; ++kk) {
-      const int mrow = kk * 4 + g;
-      float a[TMF], b[NT];
-#pragma unroll
-      for (int i = 0; i < TMF; ++i) a[i] = smX[mrow * LDX + (wave * TMF + i) * 16 + l15];
-#pragma unroll
-      for (int j = 0; j < NT; ++j) b[j] = smD[mrow * LDD + j * 16 + l15];
-#pragma unroll
-      for (int i = 0; i < TMF; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
-    }
-    __syncthreads();
-  }
-
-  const long long Ktot = (long long)p.ntaps * p.C;
-#pragma unroll
-  for (int i = 0; i < TMF; ++i)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int ci = ci0 + (wave * TMF + i) * 16 + g * 4 + r;
-      if (ci >= p.C) continue;
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const int n = n0 + j * 16 + l15;
-        if (n < p.Nout) p.partial[((long long)blockIdx.z * Ktot + (long long)tap * p.C + ci) * p.Nout + n] = acc[i][j][r];
-      }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------ backward-filter, 2nd generation
-// Same tiling / LDS layout / slab output as conv_filter_grad_k, with the pipeline of conv_gemm_nk_k: branch-free buffer loads
+// ------------------------------------------------------------------------------------------------ backward-filter kernel
+// The pipeline of conv_gemm_nk_k applied to the pixel reduction: branch-free buffer loads
 // (out-of-range rows and halo pixels return zeros), per-row (h, w) advanced incrementally instead of two integer divisions per row
 // and chunk, double-buffered LDS (one barrier per 32-pixel chunk) and a two-chunk register prefetch.
 template <int TMF, int NT, bool SC>
@@ -1116,39 +709,32 @@ static inline int pick_nt(int Nout) {
   return best;
 }
 
-static inline GemmPlan plan_gemm(long long M, int Nout, int C, int ntaps, int num_cus, int allow_split, bool flat_k) {
+constexpr int kGemmFill = 4;     // fwd / bwd-data: narrow the column tiles of sub-chip grids until there are this many blocks per CU
+constexpr int kFilterFill = 1;   // bwd-filter: same idea, one block per CU is enough (its slabs already split the pixel axis)
+
+// 3x3 convs over fewer than 32 channels: a 32-wide K chunk spans several taps (conv_gemm_nk_k<..., NARROW = true>)
+static inline bool gemm_narrow(int ntaps, int C) { return ntaps > 1 && C < 32; }
+
+static inline GemmPlan plan_gemm(long long M, int Nout, int C, int ntaps, int num_cus, int allow_split) {
   GemmPlan g;
   g.nt = pick_nt(Nout);
   g.gy = (Nout + g.nt * 16 - 1) / (g.nt * 16);
-  g.tm = 1;  // measured: two co-resident 64-row blocks per CU hide LDS/barrier latency better than one 128-row block
-  {  // tuning override (experiments only): MLIIS_GEMM_TM = 1 | 2
-    static int forced = -1;
-    if (forced < 0) {
-      const char* e = getenv("MLIIS_GEMM_TM");
-      forced = e ? atoi(e) : 0;
-    }
-    if (forced == 1 || forced == 2) g.tm = forced;
+  // measured: two co-resident 64-row blocks per CU hide LDS/barrier latency better than one 128-row block; only very tall, HBM-bound
+  // layers (112x112 maps) take 128-row blocks, which halve the number of BN-statistics partials the consumer folds
+  g.tm = (M + 63) / 64 > 4LL * num_cus ? 2 : 1;
+  if (gemm_narrow(ntaps, C)) {   // (not a hot-path shape: one plain instance per column-tile width)
+    g.tm = 1;
+    allow_split = 0;
   }
-  // very tall, HBM-bound layers (112x112 maps): 128-row blocks halve the number of BN-statistics partials the consumer folds
-  if ((M + 63) / 64 > 4LL * num_cus && g.tm == 1) g.tm = 2;
   g.gx = (int)((M + 64 * g.tm - 1) / (64 * g.tm));
-  {  // small grids (14x14 / 28x28 maps) are latency-bound: narrower column tiles -> more blocks, a shorter MFMA chain per block and
-     // often no split-K pass at all (measured +3 % on the whole step; MLIIS_GEMM_FILL = 0 restores the widest tiles)
-    static int fill = -1, min_nt = 2;
-    if (fill < 0) {
-      const char* e = getenv("MLIIS_GEMM_FILL");
-      fill = e ? atoi(e) : 4;
-      const char* m = getenv("MLIIS_GEMM_MIN_NT");
-      if (m) min_nt = atoi(m) < 1 ? 1 : atoi(m);
+  // small grids (14x14 / 28x28 maps) are latency-bound: narrower column tiles (down to 32 columns) until the grid holds
+  // kGemmFill blocks per CU -> a shorter MFMA chain per block and often no split-K pass at all (measured +3 % on the whole step)
+  if (g.tm == 1 && g.gx < num_cus)
+    while (g.nt > 2 && (long long)g.gx * g.gy < (long long)kGemmFill * num_cus) {
+      g.nt = (g.nt + 1) / 2;
+      g.gy = (Nout + g.nt * 16 - 1) / (g.nt * 16);
     }
-    if (g.tm == 1 && g.gx < num_cus)
-      while (g.nt > min_nt && (long long)g.gx * g.gy < (long long)fill * num_cus) {
-        g.nt = (g.nt + 1) / 2;
-        g.gy = (Nout + g.nt * 16 - 1) / (g.nt * 16);
-      }
-  }
-  // K chunks of 32: per tap (first-generation kernels) or over the flattened (tap, channel) index (conv_gemm_nk_k)
-  int nchunks = flat_k ? (ntaps * C + 31) / 32 : ntaps * ((C + 31) / 32);
+  const int nchunks = (ntaps * C + 31) / 32;   // K chunks over the flattened (tap, channel) index
   g.gz = 1;
   if (allow_split && g.tm == 1) {   // (128-row tiles are only chosen for grids that fill the chip many times over)
     long long blocks = (long long)g.gx * g.gy;
@@ -1160,32 +746,18 @@ static inline GemmPlan plan_gemm(long long M, int Nout, int C, int ntaps, int nu
   return g;
 }
 
-static inline bool gemm_v1() {   // tuning switch (experiments only): MLIIS_GEMM_V1=1 selects the first-generation NK kernel
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("MLIIS_GEMM_V1");
-    v = (e && atoi(e) == 1) ? 1 : 0;
-  }
-  return v == 1;
-}
-
-// second-generation kernel (flattened-K chunks): K-contiguous B operand, and at most one tap wrap per 32-channel chunk
-static inline bool use_nk2(bool b_nk, int ntaps, int C) { return b_nk && !gemm_v1() && (ntaps == 1 || C >= 32); }
-
-template <bool B_NK>
 static void launch_gemm(const GemmPlan& g, const ConvGemmParams& p, hipStream_t stream) {
   dim3 grid(g.gx, g.gy, g.gz), block(256);
-  const bool v2 = use_nk2(B_NK, p.ntaps, p.C);
-#define NK(TM_, NT_, SC_, SP_) hipLaunchKernelGGL((conv_gemm_nk_k<TM_, NT_, (TM_ == 1 ? 2 : 1), SC_, SP_>), grid, block, 0, stream, p)
-#define L(TM_, NT_)                                                                               \
-  if (v2) {                                                                                       \
-    const bool sp = p.partial != nullptr;                                                         \
-    if (TM_ == 1 && sp) {                                                                         \
-      if (p.a_scale) NK(1, NT_, true, true);                                                      \
-      else NK(1, NT_, false, true);                                                               \
-    } else if (p.a_scale) NK(TM_, NT_, true, false);                                              \
-    else NK(TM_, NT_, false, false);                                                              \
-  } else hipLaunchKernelGGL((conv_gemm_k<TM_, NT_, B_NK>), grid, block, 0, stream, p);            \
+  const bool sp = p.partial != nullptr, sc = p.a_scale != nullptr, narrow = gemm_narrow(p.ntaps, p.C);
+#define NK(TM_, NT_, SC_, SP_) hipLaunchKernelGGL((conv_gemm_nk_k<TM_, NT_, (TM_ == 1 ? 2 : 1), SC_, SP_, false>), grid, block, 0, stream, p)
+#define L(TM_, NT_)                                  \
+  if (TM_ == 1 && narrow) {                          \
+    hipLaunchKernelGGL((conv_gemm_nk_k<1, NT_, 2, false, false, true>), grid, block, 0, stream, p); \
+  } else if (TM_ == 1 && sp) {                       \
+    if (sc) NK(1, NT_, true, true);                  \
+    else NK(1, NT_, false, true);                    \
+  } else if (sc) NK(TM_, NT_, true, false);          \
+  else NK(TM_, NT_, false, false);                   \
   break;
 #define ROW(TM_)       \
   switch (g.nt) {      \
@@ -1240,12 +812,7 @@ static inline FilterPlan plan_filter(long long M, int C, int Nout, int ntaps, in
   f.tmf = (C >= 128 && waste128 <= waste64) ? 2 : 1;
   plan_filter_split(f, M, C, Nout, ntaps, num_cus);
   // small maps cannot be split further along the pixels (64 rows per slab): narrower tiles instead (latency-bound, see plan_gemm)
-  static int fill = -1;
-  if (fill < 0) {
-    const char* e = getenv("MLIIS_FILTER_FILL");
-    fill = e ? atoi(e) : 1;
-  }
-  while ((long long)f.gx * f.gy * f.gz < (long long)fill * num_cus && (f.tmf == 2 || f.nt > 2)) {
+  while ((long long)f.gx * f.gy * f.gz < (long long)kFilterFill * num_cus && (f.tmf == 2 || f.nt > 2)) {
     if (f.tmf == 2) f.tmf = 1;
     else f.nt = (f.nt + 1) / 2;
     plan_filter_split(f, M, C, Nout, ntaps, num_cus);
@@ -1256,8 +823,7 @@ static inline FilterPlan plan_filter(long long M, int C, int Nout, int ntaps, in
 static void launch_filter(const FilterPlan& f, const FilterGradParams& p, hipStream_t stream) {
   dim3 grid(f.gx, f.gy, f.gz), block(256);
 #define L(T_, NT_)                                                                                                   \
-  if (gemm_v1()) hipLaunchKernelGGL((conv_filter_grad_k<T_, NT_>), grid, block, 0, stream, p);                       \
-  else if (p.x_scale) hipLaunchKernelGGL((conv_filter_grad2_k<T_, NT_, true>), grid, block, 0, stream, p);           \
+  if (p.x_scale) hipLaunchKernelGGL((conv_filter_grad2_k<T_, NT_, true>), grid, block, 0, stream, p);           \
   else hipLaunchKernelGGL((conv_filter_grad2_k<T_, NT_, false>), grid, block, 0, stream, p);                         \
   break;
 #define ROW(T_)       \
@@ -1308,62 +874,55 @@ using namespace mliis;
 
 extern "C" {
 
-// Tiling the planner picks for a conv2d_fwd / conv2d_bwd_data call (profiling aid: identifies the kernel instantiation
-// conv_gemm_k<tm, nt, B_NK> and its split-K factor).
+// Tiling the planner picks for a conv2d_fwd / conv2d_bwd_data call (profiling aid: row-tile factor, column tiles, split-K factor).
 int mliis_conv2d_plan(int Nimg, int H, int W, int Cred, int Nout, int ksize, int* tm, int* nt, int* splits) {
   MLIIS_REQUIRE(tm && nt && splits, MLIIS_ERR_ARG, "conv2d_plan: null pointer");
-  GemmPlan g = plan_gemm((long long)Nimg * H * W, Nout, Cred, ksize * ksize, num_cus(), 1, use_nk2(true, ksize * ksize, Cred));
+  GemmPlan g = plan_gemm((long long)Nimg * H * W, Nout, Cred, ksize * ksize, num_cus(), 1);
   *tm = g.tm;
   *nt = g.nt;
   *splits = g.gz;
   return MLIIS_OK;
 }
 
-// Name of the kernel instantiation (as rocprofv3 prints it, without the mliis:: prefix and argument list) that a conv2d_fwd
-// (k_contiguous_b = a wt operand is given) / conv2d_bwd_data (k_contiguous_b = 1) call with these shapes launches.
-int mliis_conv2d_kernel_name(int Nimg, int H, int W, int Cred, int Nout, int ksize, int k_contiguous_b, int has_scale, char* buf,
-                             size_t buf_len) {
-  MLIIS_REQUIRE(buf && buf_len >= 48, MLIIS_ERR_ARG, "conv2d_kernel_name: buffer too small");
-  const bool v2 = use_nk2(k_contiguous_b != 0, ksize * ksize, Cred);
-  GemmPlan g = plan_gemm((long long)Nimg * H * W, Nout, Cred, ksize * ksize, num_cus(), 1, v2);
-  if (v2)
-    snprintf(buf, buf_len, "conv_gemm_nk_k<%d, %d, %d, %s, %s>", g.tm, g.nt, g.tm == 1 ? 2 : 1, has_scale ? "true" : "false",
-             g.gz > 1 ? "true" : "false");
-  else snprintf(buf, buf_len, "conv_gemm_k<%d, %d, %s>", g.tm, g.nt, k_contiguous_b ? "true" : "false");
+// Name of the kernel instantiation (as rocprofv3 prints it, without the mliis:: prefix and argument list) that a conv2d_fwd /
+// conv2d_bwd_data call with these shapes launches (has_scale: an x_scale operand is given).
+int mliis_conv2d_kernel_name(int Nimg, int H, int W, int Cred, int Nout, int ksize, int has_scale, char* buf, size_t buf_len) {
+  MLIIS_REQUIRE(buf && buf_len >= 56, MLIIS_ERR_ARG, "conv2d_kernel_name: buffer too small");
+  GemmPlan g = plan_gemm((long long)Nimg * H * W, Nout, Cred, ksize * ksize, num_cus(), 1);
+  snprintf(buf, buf_len, "conv_gemm_nk_k<%d, %d, %d, %s, %s, %s>", g.tm, g.nt, g.tm == 1 ? 2 : 1, has_scale ? "true" : "false",
+           g.gz > 1 ? "true" : "false", gemm_narrow(ksize * ksize, Cred) ? "true" : "false");
   return MLIIS_OK;
 }
 
 // Workspace (floats) that conv2d_fwd / conv2d_bwd_data may need for split-K partials.
 size_t mliis_conv2d_workspace_floats(int Nimg, int H, int W, int Cred, int Nout, int ksize) {
   long long M = (long long)Nimg * H * W;
-  const GemmPlan g = plan_gemm(M, Nout, Cred, ksize * ksize, num_cus(), 1, true), h = plan_gemm(M, Nout, Cred, ksize * ksize, num_cus(), 1, false);
-  const int gz = g.gz > h.gz ? g.gz : h.gz;   // either K-chunk counting (second / first generation kernel) must fit
-  return gz > 1 ? (size_t)gz * M * Nout : 0;
+  const GemmPlan g = plan_gemm(M, Nout, Cred, ksize * ksize, num_cus(), 1);
+  return g.gz > 1 ? (size_t)g.gz * M * Nout : 0;
 }
 
-// y[M, Cout] (ld = ldy) (+)= conv(x[M, Cin] (ld = ldx), w[k,k,Cin,Cout]) + bias ; stride 1, TF-SAME, dilation dil
-int mliis_conv2d_fwd(const float* x, int ldx, const float* x_scale, const float* w, const float* wt, const float* bias,
+// y[M, Cout] (ld = ldy) (+)= conv(x[M, Cin] (ld = ldx), w) + bias ; stride 1, TF-SAME, dilation dil; the weights come as the
+// K-contiguous copy wt[k,k,Cout,Cin_total] of the HWIO tensor (mliis_transpose_weights)
+int mliis_conv2d_fwd(const float* x, int ldx, const float* x_scale, const float* wt, const float* bias,
                      const float* border_bias, float* y, int ldy, int Nimg, int H, int W, int Cin_total, int ci_begin, int Cin, int Cout,
                      int ksize, int dil, int accumulate, float* stats_part, int stats_swish, int* stats_nblk, float* ws,
                      size_t ws_floats, hipStream_t stream) {
   int rc = conv_check("conv2d_fwd", Nimg, H, W, Cin, Cout, ksize, dil);
   if (rc) return rc;
-  MLIIS_REQUIRE(x && (w || wt) && y, MLIIS_ERR_ARG, "conv2d_fwd: null pointer");
-  MLIIS_REQUIRE(aligned16(wt), MLIIS_ERR_ALIGN, "conv2d_fwd: wt must be 16-byte aligned");
+  MLIIS_REQUIRE(x && wt && y, MLIIS_ERR_ARG, "conv2d_fwd: null pointer");
   MLIIS_REQUIRE((ldx & 3) == 0 && ldx >= Cin && (ldy & 3) == 0 && ldy >= Cout, MLIIS_ERR_ARG, "conv2d_fwd: bad leading dimensions");
-  MLIIS_REQUIRE(aligned16(x) && aligned16(w) && aligned16(bias) && aligned16(y), MLIIS_ERR_ALIGN,
+  MLIIS_REQUIRE(aligned16(x) && aligned16(wt) && aligned16(bias) && aligned16(y), MLIIS_ERR_ALIGN,
                 "conv2d_fwd: pointers must be 16-byte aligned");
   long long M = (long long)Nimg * H * W;
   MLIIS_REQUIRE(M * ldx * 4 < (1LL << 31) && (long long)ksize * ksize * Cin_total * Cout * 4 < (1LL << 31), MLIIS_ERR_UNSUPPORTED,
                 "conv2d_fwd: operand larger than 2 GiB (32-bit buffer offsets)");
-  GemmPlan g = plan_gemm(M, Cout, Cin, ksize * ksize, num_cus(), ws != nullptr, use_nk2(wt != nullptr, ksize * ksize, Cin));
+  GemmPlan g = plan_gemm(M, Cout, Cin, ksize * ksize, num_cus(), ws != nullptr);
   MLIIS_REQUIRE(ci_begin >= 0 && (ci_begin & 3) == 0 && ci_begin + Cin <= Cin_total, MLIIS_ERR_ARG,
                 "conv2d_fwd: input-channel window out of range");
   MLIIS_REQUIRE(border_bias == nullptr || (ksize == 3 && dil == 1 && H >= 2 && W >= 2 && aligned16(border_bias)), MLIIS_ERR_ARG,
                 "conv2d_fwd: border_bias needs a 3x3 dilation-1 conv on a map of at least 2x2");
-  ConvGemmParams p{x, ldx, Nimg, H, W, Cin, ksize * ksize, dil, +1, w ? w + (long long)ci_begin * Cout : nullptr,
-                   (long long)Cin_total * Cout, Cout, Cout, y, ldy, bias, accumulate, nullptr, g.chunks_per_split, nullptr, 0, x_scale,
-                   border_bias};
+  ConvGemmParams p{x, ldx, Nimg, H, W, Cin, ksize * ksize, dil, +1, wt + ci_begin, (long long)Cin_total * Cout, Cin_total, Cout, y, ldy,
+                   bias, accumulate, nullptr, g.chunks_per_split, nullptr, 0, x_scale, border_bias};
   MLIIS_REQUIRE(aligned16(x_scale) && (x_scale == nullptr || ksize == 1), MLIIS_ERR_ARG,
                 "conv2d_fwd: x_scale must be 16-byte aligned and is only supported for 1x1 convs");
   if (stats_nblk) *stats_nblk = 0;
@@ -1384,13 +943,7 @@ int mliis_conv2d_fwd(const float* x, int ldx, const float* x_scale, const float*
                   "conv2d_fwd: split-K workspace too small (%zu needed, %zu given) or unaligned output", need, ws_floats);
     p.partial = ws;
   }
-  if (wt != nullptr) {  // K-contiguous shadow weights [k,k,Cout,Cin]: forward on the b128-fragment B path
-    p.B = wt + ci_begin;
-    p.ldb = Cin_total;
-    launch_gemm<true>(g, p, stream);
-  } else {
-    launch_gemm<false>(g, p, stream);
-  }
+  launch_gemm(g, p, stream);
   MLIIS_CHECK_LAUNCH("conv2d_fwd");
   if (g.gz > 1 && stats_part != nullptr) {
     hipLaunchKernelGGL(splitk_reduce_stats_k, dim3((unsigned)((M + kRedRows - 1) / kRedRows), (Cout + 31) / 32), dim3(256), 0, stream, ws, g.gz,
@@ -1420,7 +973,7 @@ int mliis_conv2d_bwd_data(const float* dy, int lddy, const float* w, float* dx, 
   long long M = (long long)Nimg * H * W;
   MLIIS_REQUIRE(M * lddy * 4 < (1LL << 31) && (long long)ksize * ksize * Cin_total * Cout * 4 < (1LL << 31), MLIIS_ERR_UNSUPPORTED,
                 "conv2d_bwd_data: operand larger than 2 GiB (32-bit buffer offsets)");
-  GemmPlan g = plan_gemm(M, Cin_out, Cout, ksize * ksize, num_cus(), ws != nullptr, use_nk2(true, ksize * ksize, Cout));
+  GemmPlan g = plan_gemm(M, Cin_out, Cout, ksize * ksize, num_cus(), ws != nullptr);
   ConvGemmParams p{dy, lddy, Nimg, H, W, Cout, ksize * ksize, dil, -1, w + (long long)ci_begin * Cout, (long long)Cin_total * Cout,
                    Cout, Cin_out, dx, lddx, nullptr, accumulate, nullptr, g.chunks_per_split, nullptr, 0, nullptr, nullptr};
   if (g.gz > 1) {
@@ -1429,7 +982,7 @@ int mliis_conv2d_bwd_data(const float* dy, int lddy, const float* w, float* dx, 
                   "conv2d_bwd_data: split-K workspace too small (%zu needed, %zu given) or unaligned output", need, ws_floats);
     p.partial = ws;
   }
-  launch_gemm<true>(g, p, stream);
+  launch_gemm(g, p, stream);
   MLIIS_CHECK_LAUNCH("conv2d_bwd_data");
   if (g.gz > 1) {
     long long q = M * (Cin_out / 4);

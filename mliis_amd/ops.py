@@ -62,9 +62,9 @@ def profile_resolve(records):
     return records
 
 
-def conv2d_kernel_name(N, H, W, cred, nout, k, k_contiguous_b=True, has_scale=False):
+def conv2d_kernel_name(N, H, W, cred, nout, k, has_scale=False):
     buf = C.create_string_buffer(64)
-    lib.call("mliis_conv2d_kernel_name", N, H, W, cred, nout, k, int(k_contiguous_b), int(has_scale), C.cast(buf, C.c_void_p), 64)
+    lib.call("mliis_conv2d_kernel_name", N, H, W, cred, nout, k, int(has_scale), C.cast(buf, C.c_void_p), 64)
     return buf.value.decode()
 
 
@@ -187,12 +187,22 @@ def transpose_weights(src, dst, desc):
     lib.call("mliis_transpose_weights", _ptr(src), _ptr(dst), _ptr(desc), int(desc.shape[0]), _stream())
 
 
+def hwoi(w):
+    """K-contiguous copy [k,k,Cout,Cin] of one HWIO weight tensor (what the learner keeps for its whole arena, refreshed per step)."""
+    k, _, cin, cout = w.shape
+    dst = torch.empty((k, k, cout, cin), dtype=torch.float32, device=w.device)
+    transpose_weights(w.contiguous(), dst, torch.tensor([[0, k * k, cin, cout]], dtype=torch.int32, device=w.device))
+    return dst
+
+
 def conv2d_fwd(x, w, bias=None, dil=1, out=None, accumulate=False, ws: Optional[Workspace] = None, nhw=None, stats_part=None,
                stats_swish=False, wt=None, x_scale=None, border_bias=None, ci_begin=0):
-    """x: [N,H,W,>=Cin] view (channel slice allowed); w: [k,k,Cin,Cout].  With stats_part (a float buffer) the epilogue also emits
-    the next batch norm's stage-1 statistics and the function returns (out, nblk); nblk == 0 means they were not produced."""
+    """x: [N,H,W,>=Cin] view (channel slice allowed); w: [k,k,Cin,Cout]; wt: its K-contiguous copy (built here when not given --
+    the kernels only read wt).  With stats_part (a float buffer) the epilogue also emits the next batch norm's stage-1 statistics
+    and the function returns (out, nblk); nblk == 0 means they were not produced."""
     N, H, W = nhw if nhw is not None else x.shape[:3]
     k, _, Cin_total, Cout = w.shape
+    wt = hwoi(w) if wt is None else wt
     rows, Cin, ldx = rows_ld(x)
     if ci_begin + Cin > Cin_total:
         raise MliisError("conv2d_fwd: x has {} channels, weight has {} (window starts at {})".format(Cin, Cin_total, ci_begin))
@@ -203,12 +213,12 @@ def conv2d_fwd(x, w, bias=None, dil=1, out=None, accumulate=False, ws: Optional[
     meta = {}
     if PROFILE is not None:
         tm, nt, sp = conv2d_plan(N, H, W, Cin, Cout, k)
-        meta = dict(kernel=conv2d_kernel_name(N, H, W, Cin, Cout, k, wt is not None, x_scale is not None), splits=sp,
+        meta = dict(kernel=conv2d_kernel_name(N, H, W, Cin, Cout, k, x_scale is not None), splits=sp,
                     flops=2.0 * N * H * W * k * k * Cin * Cout, shape=(N, H, W, Cin, Cout, k, dil))
     nblk = C.c_int(0)
     if stats_part is not None and stats_part.numel() < (-(-N * H * W // 64)) * 2 * Cout:
         raise MliisError("conv2d_fwd: stats_part too small")
-    _timed("conv2d_fwd", meta, lambda: lib.call("mliis_conv2d_fwd", _ptr(x), ldx, _ptr(x_scale), _ptr(w), _ptr(wt), _ptr(bias), _ptr(border_bias), _ptr(out), ldy, N, H, W,
+    _timed("conv2d_fwd", meta, lambda: lib.call("mliis_conv2d_fwd", _ptr(x), ldx, _ptr(x_scale), _ptr(wt), _ptr(bias), _ptr(border_bias), _ptr(out), ldy, N, H, W,
                                                 Cin_total, ci_begin, Cin, Cout, k,
                                                 dil, int(accumulate), _ptr(stats_part), int(stats_swish), C.byref(nblk), _ptr(buf),
                                                 buf.numel(), _stream()))

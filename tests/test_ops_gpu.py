@@ -77,6 +77,8 @@ def test_dwconv_all(k, s, H, W, C):
     (1, 1, 8, 8, 16, 96, 2), (1, 1, 7, 9, 96, 24, 3), (1, 1, 14, 14, 40, 240, 2), (1, 1, 4, 4, 672, 112, 2),
     (3, 1, 14, 14, 24, 112, 2), (3, 2, 14, 14, 136, 112, 2), (3, 1, 9, 11, 360, 112, 1), (3, 6, 14, 14, 112, 112, 1),
     (1, 1, 56, 56, 24, 144, 4), (3, 2, 6, 5, 8, 8, 1),
+    # narrow 3x3 convs: a 32-wide K chunk of the flattened (tap, channel) index crosses up to 8 taps
+    (3, 1, 10, 10, 4, 8, 2), (3, 2, 9, 9, 12, 20, 1), (3, 1, 8, 8, 20, 4, 2), (3, 3, 8, 8, 28, 16, 1),
 ])
 def test_conv2d_all(k, dil, H, W, Cin, Cout, N):
     from mliis_amd import ops
@@ -88,8 +90,8 @@ def test_conv2d_all(k, dil, H, W, Cin, Cout, N):
     dy = rnd(*y.shape, seed=7)
     gx, gw, gb = torch.autograd.grad(y, [x, w, b], dy)
     xg, wg, bg = f32(x, d), f32(w, d), f32(b, d)
-    close(ops.conv2d_fwd(xg, wg, bg, dil), nhwc(y), 2e-5, "conv fwd")
-    # forward through the K-contiguous shadow weights (batched HWIO -> HWOI transpose)
+    close(ops.conv2d_fwd(xg, wg, bg, dil), nhwc(y), 2e-5, "conv fwd")   # (builds the K-contiguous weight copy itself)
+    # forward through a slot of a K-contiguous shadow arena (batched HWIO -> HWOI transpose)
     wt = torch.full((wg.numel() + 8,), float("nan"), device=d)
     desc = torch.tensor([[4, k * k, Cin, Cout]], dtype=torch.int32, device=d)
     src = torch.zeros(wg.numel() + 8, device=d)
@@ -459,8 +461,7 @@ def test_conv1x1_with_se_gate_on_the_fly(H, W, Cin, Cout, N):
     (gw,) = torch.autograd.grad(y, [w], dy)
     xg, gg, wg = f32(x, d), f32(gate, d), f32(w, d)
     wt = wg.permute(0, 1, 3, 2).contiguous().view(-1)
-    close(ops.conv2d_fwd(xg, wg, None, 1, x_scale=gg), nhwc(y), 2e-5, "gated conv (HWIO weights)")
-    close(ops.conv2d_fwd(xg, wg, None, 1, x_scale=gg, wt=wt), nhwc(y), 2e-5, "gated conv (shadow weights)")
+    close(ops.conv2d_fwd(xg, wg, None, 1, x_scale=gg, wt=wt), nhwc(y), 2e-5, "gated conv")
     close(ops.conv2d_bwd_filter(xg, f32(nhwc(dy), d), 1, 1, x_scale=gg), gw, 1e-4, "gated filter grad")
 
 
