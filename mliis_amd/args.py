@@ -97,6 +97,11 @@ _FLAGS = [
 _EXT = [
     ("--synthetic-tasks", dict(type=int, default=0, help="use N synthetic tasks instead of --data-dir (no dataset needed)")),
     ("--no-hip-graph", dict(action="store_true", help="launch inner steps eagerly instead of replaying a captured HIP graph")),
+    ("--k-shot-range", dict(nargs="+", type=int, default=None,
+                            help="ks of --run_k_shot_learning_curves_experiment (default: the reference's 1 5 10 50 100 200 400)")),
+    ("--k-shot-test-samples", dict(type=int, default=20, help="held-out examples per task in the k-shot experiment (reference: 20)")),
+    ("--skip-train-task-eval", dict(action="store_true",
+                                    help="skip the evaluation pass over the meta-TRAIN tasks that the reference always runs before the test tasks")),
     ("--checkpoint-format", dict(choices=["npz", "tf"], default="npz",
                                  help="tensor container of written checkpoints: numpy .npz or a TensorFlow TensorBundle (.index/.data)")),
 ]
@@ -109,6 +114,14 @@ def argument_parser(extensions: bool = True) -> argparse.ArgumentParser:
     return p
 
 
+def _max_shots(a) -> int:
+    """Examples a task can make resident at once: training / evaluation shots, or the whole k-shot pool."""
+    n = max(16, a.train_shots or 0, a.shots + 5)
+    if getattr(a, "run_k_shot_learning_curves_experiment", False):
+        n = max(n, max(getattr(a, "k_shot_range", None) or [400]) + getattr(a, "k_shot_test_samples", 20))
+    return n
+
+
 def model_kwargs(a) -> dict:
     """Keyword arguments of mliis_amd.learner.Learner from parsed flags (reference: args.py:121-160)."""
     a.model_name = a.model_name.lower()
@@ -118,7 +131,7 @@ def model_kwargs(a) -> dict:
                 learning_rate=a.learning_rate, optimizer="sgd" if a.sgd else "adam", l2=a.l2, l1=a.l1, darc1=a.darc1,
                 dice=("dice" in a.loss_name), label_smoothing=a.label_smoothing, final_layer_dropout_rate=a.final_layer_dropout_rate,
                 spatial_pyramid_pooling=a.spatial_pyramid_pooling, skip_decoding=a.skip_decoding, seed=a.seed,
-                use_graph=not getattr(a, "no_hip_graph", False), max_shots=max(16, a.train_shots or 0, a.shots + 5))
+                use_graph=not getattr(a, "no_hip_graph", False), max_shots=_max_shots(a))
     # --disable_rsd_residual_connections is a no-op in the reference too (kwarg name mismatch)
 
 
@@ -145,7 +158,19 @@ def evaluate_kwargs(a) -> dict:
     return dict(num_classes=a.classes, num_shots=a.shots, eval_inner_batch_size=a.eval_batch, eval_inner_iters=a.eval_iters,
                 replacement=a.replacement, weight_decay_rate=a.weight_decay, num_samples=a.eval_samples, transductive=a.transductive,
                 meta_fn=_meta_fn(a), augment=a.augment, lr=None, aug_rate=a.aug_rate,
+                eval_tasks_with_median_early_stopping_iterations=a.eval_tasks_with_median_early_stopping_iterations,
                 save_fine_tuned_checkpoints=a.save_fine_tuned_checkpoints, save_fine_tuned_checkpoints_dir=a.save_fine_tuned_checkpoints_dir)
+
+
+def hyper_search_kwargs(a) -> dict:
+    """args.py:163-176."""
+    from .hyperparam_search import SUPPORTED_SEARCH_ALGS
+    assert a.uho_estimator in SUPPORTED_SEARCH_ALGS, "{} not in supported hyperparam search algs {}".format(a.uho_estimator, SUPPORTED_SEARCH_ALGS)
+    return dict(lr_search_range_low=a.lr_search_range_low, lr_search_range_high=a.lr_search_range_high,
+                drop_rate_search_range_low=a.drop_rate_search_range_low, drop_rate_search_range_high=a.drop_rate_search_range_high,
+                aug_rate_search_range_low=a.aug_rate_search_range_low, aug_rate_search_range_high=a.aug_rate_search_range_high,
+                batch_size_search_range_low=a.batch_size_search_range_low, batch_size_search_range_high=a.batch_size_search_range_high,
+                estimator=a.uho_estimator)
 
 
 def make_lr_scheduler(a):

@@ -588,8 +588,10 @@ class Learner:
         self._apply()
 
     def inner_step(self, batch_idx: Sequence[int], lr: Optional[float] = None, dc_scales: Optional[Dict[int, torch.Tensor]] = None,
-                   dropout_mask: Optional[torch.Tensor] = None, weight_decay_rate: float = 1.0):
-        """One `session.run(minimize_op)` on images `batch_idx` of the resident task.  Returns the device loss scalar."""
+                   dropout_mask: Optional[torch.Tensor] = None, weight_decay_rate: float = 1.0, drop_rate: Optional[float] = None):
+        """One `session.run(minimize_op)` on images `batch_idx` of the resident task.  Returns the device loss scalar.
+        `drop_rate` overrides the final-layer dropout rate for this step (the reference feeds `final_layer_dropout_rate_ph`, a
+        placeholder that only exists when the model was built with dropout, models/efficientlab.py:94-100)."""
         N = len(batch_idx)
         if N == 0:
             raise ValueError("empty mini-batch")
@@ -601,7 +603,7 @@ class Learner:
             self.lr_dev.fill_(self.lr if lr is None else float(lr))
             if weight_decay_rate != 1.0:  # pre_step_op (variables.py:48-55)
                 ops.axpby(0.0, None, float(weight_decay_rate), self.arena.theta)
-            self._fill_masks(P, dc_scales, dropout_mask)
+            self._fill_masks(P, dc_scales, dropout_mask, drop_rate)
             if self.use_graph and P.steps_run >= 1 and self.optimizer == "sgd":
                 if P.graph is None:
                     gexec = C.c_void_p()
@@ -618,7 +620,11 @@ class Learner:
         self.last_loss = P.loss_out
         return P.loss_out
 
-    def _fill_masks(self, P: _Plan, dc_scales, dropout_mask):
+    def _fill_masks(self, P: _Plan, dc_scales, dropout_mask, drop_rate=None):
+        if drop_rate is not None and P.drop_mask is None:
+            raise ValueError("drop_rate given but the model was built without final-layer dropout (final_layer_dropout_rate = 0)")
+        if drop_rate is not None and not 0.0 <= float(drop_rate) < 1.0:
+            raise ValueError("drop_rate must be in [0, 1), got {}".format(drop_rate))
         ex = [b for b in self.arch.blocks if b.executed]
         if self.drop_connect:
             if dc_scales is not None:
@@ -638,7 +644,7 @@ class Learner:
             if dropout_mask is not None:
                 P.drop_mask.copy_(torch.as_tensor(dropout_mask, dtype=torch.float32))
             else:
-                keep = 1.0 - self.final_layer_dropout_rate
+                keep = 1.0 - (self.final_layer_dropout_rate if drop_rate is None else float(drop_rate))
                 u = torch.rand(P.drop_mask.shape, generator=self.rng, device=self.device)
                 P.drop_mask.copy_((u < keep).to(torch.float32) / keep)
 

@@ -47,6 +47,9 @@ class Dist:
             self._d.barrier()
 
 
+DEFAULT_ITER_RANGE = [1, 5, 10, 25, 50, 100, 200]   # reptile.py:21
+
+
 def _task_rng(seed: int, meta_iter: int, task: int) -> random.Random:
     return random.Random((seed * 1000003 + meta_iter) * 1000003 + task)
 
@@ -206,16 +209,29 @@ class Gecko:
             iou = self._evaluate(train_idx, test_idx, labels, inner_batch_size, inner_iters, replacement, lr=lr, task_name=name,
                                  save_fine_tuned_checkpoints=save_fine_tuned_checkpoints,
                                  save_fine_tuned_checkpoints_dir=save_fine_tuned_checkpoints_dir, eval_sample_num=eval_sample_num,
-                                 aug_rate=self.aug_rate if aug_rate is None else aug_rate, images=images)
+                                 aug_rate=self.aug_rate if aug_rate is None else aug_rate, images=images, drop_rate=drop_rate)
             ious.append(iou)
             task_iou_map[name] = iou
         mean_iou = float(np.nanmean(ious))
         print("Mean IoU from train on {} images and evaluate on {} test images: {}".format(num_shots, test_shots, mean_iou))
         return mean_iou, task_iou_map
 
+    def _fine_tune_step(self, idx, inner_iter, lr, lr_scheduler, drop_rate):
+        """One fine-tuning step with the reference's feed precedence (reptile.py:265-276,459-469): (lr, drop_rate) together, else lr,
+        else the scheduler's lr, else the model defaults."""
+        L, wd = self.learner, self._pre_step_rate
+        if lr is not None and drop_rate is not None:
+            L.inner_step(idx, lr=lr, weight_decay_rate=wd, drop_rate=drop_rate)
+        elif lr is not None:
+            L.inner_step(idx, lr=lr, weight_decay_rate=wd)
+        elif lr_scheduler is not None:
+            L.inner_step(idx, lr=lr_scheduler.cur_lr(cur_step=inner_iter), weight_decay_rate=wd)
+        else:
+            L.inner_step(idx, weight_decay_rate=wd)
+
     def _evaluate(self, train_idx, test_idx, labels, inner_batch_size, inner_iters, replacement, lr=None, task_name=None,
                   save_fine_tuned_checkpoints=False, save_fine_tuned_checkpoints_dir=None, eval_sample_num=None, aug_rate=None,
-                  images=None):
+                  images=None, drop_rate=None):
         """Evaluates a single task's train/test split (reptile.py:235-294): ALL global variables are restored afterwards."""
         import numpy as np
         from .metrics import iou as _iou
@@ -236,12 +252,7 @@ class Gecko:
             else:
                 L.load_task(b[0], b[1])
                 idx = list(range(int(b[0].shape[0])))
-            if lr is not None:
-                L.inner_step(idx, lr=lr, weight_decay_rate=self._pre_step_rate)
-            elif self.lr_scheduler is not None:
-                L.inner_step(idx, lr=self.lr_scheduler.cur_lr(cur_step=inner_iter), weight_decay_rate=self._pre_step_rate)
-            else:
-                L.inner_step(idx, weight_decay_rate=self._pre_step_rate)
+            self._fine_tune_step(idx, inner_iter, lr, self.lr_scheduler, drop_rate)
         if save_fine_tuned_checkpoints:
             from .checkpoint import save_fine_tuned_checkpoint
             L.synchronize()
@@ -254,6 +265,140 @@ class Gecko:
         print("Mean task IoU: {}".format(class_iou))
         L.import_all(old)
         return class_iou
+
+    # ------------------------------------------------------------------------------------------------ early stopping / k-shot curves
+    ES_PATIENCE = 50          # _early_stopping_learn's default patience (reptile.py:444)
+    K_SHOT_ES_MAX_STEPS = 500   # evaluate_k_shot_range's early-stopping horizon (reptile.py:429)
+
+    def _early_stopping_learn(self, train_idx, val_idx, labels, inner_batch_size, min_steps, max_steps, replacement, lr_scheduler=None,
+                              lr=None, drop_rate=None, patience=None, inner_iters=None, aug_rate=None, images=None):
+        """Estimates the number of fine-tuning steps for a task (reptile.py:442-480): after EVERY step the validation examples are
+        predicted and their mean IoU is shown to an EarlyStopper; all variables are restored.  Returns (best step count, best mIoU)."""
+        import numpy as np
+        from .hyperparam_search import EarlyStopper
+        from .metrics import iou as _iou
+        del inner_iters
+        L = self.learner
+        old = L.export_all()
+        if lr_scheduler is not None and lr is not None:
+            raise ValueError("Only lr_scheduler or lr should be speced. Not both.")
+        stopper = EarlyStopper(self.ES_PATIENCE if patience is None else patience, min_steps=min_steps)
+        lab = _to_numpy(labels)
+        if self.augmenter is None:
+            schedule = metaseg.mini_batch_indices(len(train_idx), inner_batch_size, max_steps, replacement)
+        else:
+            if images is None:
+                raise ValueError("_early_stopping_learn with augmentation needs the task's images")
+            x = _to_numpy(images)
+            schedule = metaseg.augmented_batches(x[train_idx], lab[train_idx], inner_batch_size, max_steps, replacement, self.augmenter,
+                                                 aug_rate)
+        for inner_iter, b in enumerate(schedule):
+            if self.augmenter is None:
+                idx = [train_idx[i] for i in b]
+            else:
+                L.load_task(b[0], b[1])
+                idx = list(range(int(b[0].shape[0])))
+            self._fine_tune_step(idx, inner_iter, lr, lr_scheduler, drop_rate)
+            if self.augmenter is not None:
+                L.load_task(images, labels)   # predictions read the ORIGINAL examples
+            preds = self._test_predictions(train_idx, val_idx)
+            miou = np.nanmean([_iou(preds[j], lab[val_idx[j]]) for j in range(len(val_idx))])
+            if not stopper.continue_training(miou, inner_iter + 1):
+                break
+        best_num_steps, best_iou = stopper.best_num_steps(), stopper.best_metric()
+        print("Best iteration found: {}, with mean-IoU {}".format(best_num_steps, best_iou))
+        L.import_all(old)
+        return best_num_steps, best_iou
+
+    def evaluate_with_early_stopping(self, dataset, num_classes=1, num_shots=5, inner_batch_size=8, min_steps=0, max_steps=80,
+                                     replacement=False, eval_all_tasks=False, num_tasks_to_sample=20,
+                                     test_shots=DEFAULT_NUM_TEST_EXAMPLES, lr: Optional[float] = None, drop_rate: Optional[float] = None,
+                                     aug_rate: Optional[float] = None, eval_tasks_with_median_early_stopping_iterations: bool = False,
+                                     **_unused_tf_handles):
+        """reptile.py:296-391: per sampled task, split off `test_shots` validation examples and early-stop on them; optionally
+        re-evaluate every task with the median step count.  Returns (task names, best step counts, IoUs)."""
+        import numpy as np
+        print("Evaluating {} meta-learning.".format(self.meta_fn))
+        if eval_all_tasks:
+            sampled = dataset
+        else:
+            random.shuffle(dataset)
+            sampled = dataset[:num_tasks_to_sample]
+        print("Evaluating {} {}-shot tasks.".format(len(sampled), num_shots))
+        task_names, ious = [], []
+        if min_steps != max_steps:
+            num_steps = []
+            for task in sampled:
+                (images, labels), name = metaseg.sample_task([task], num_shots + test_shots, None, return_task_name=True)
+                task_names.append(name)
+                self.learner.load_task(images, labels)
+                train_idx, test_idx = metaseg.split_indices(int(images.shape[0]), test_shots)
+                steps, miou = self._early_stopping_learn(train_idx, test_idx, labels, inner_batch_size, min_steps=min_steps,
+                                                         max_steps=max_steps, replacement=replacement, lr_scheduler=self.lr_scheduler,
+                                                         lr=lr, drop_rate=drop_rate, aug_rate=aug_rate, images=images)
+                ious.append(miou)
+                num_steps.append(steps)
+            estimated = int(np.median(num_steps))
+        else:
+            estimated = min_steps
+            num_steps = [estimated] * len(sampled)
+        if eval_tasks_with_median_early_stopping_iterations or min_steps == max_steps:
+            print("Estimated best number of steps {}".format(estimated))
+            mean_iou, task_iou_map = self.evaluate(sampled, num_classes=num_classes, num_shots=num_shots, inner_batch_size=inner_batch_size,
+                                                   inner_iters=estimated, replacement=replacement, eval_all_tasks=eval_all_tasks,
+                                                   num_tasks_to_sample=num_tasks_to_sample, test_shots=test_shots, lr=lr,
+                                                   drop_rate=drop_rate, aug_rate=aug_rate)
+            task_names, ious = list(task_iou_map.keys()), list(task_iou_map.values())
+        else:
+            mean_iou = np.nanmean(ious)
+        print("Evaluated {} task/s".format(len(sampled)))
+        print("Mean IoU from train on {} images and evaluate on {} test images: {}".format(num_shots, test_shots, mean_iou))
+        return task_names, num_steps, ious
+
+    def evaluate_k_shot_range(self, task, k_range, iter_range=None, test_samples=20, early_stopping_min_val_samples=5,
+                              esimate_inner_iters_with_early_stoppping: bool = True, **params):
+        """k-shot learning results of one task over a range of k (reptile.py:411-440): the first max(k)+test_samples examples are
+        shuffled and split once; for each k the first k training examples are used -- with at least 10 of them, 20 % are held out to
+        early-stop the step count (which then STAYS in `params` for the following, smaller-than-10 ks too: reference behaviour)."""
+        iter_range = DEFAULT_ITER_RANGE if iter_range is None else iter_range
+        (images, labels), name = metaseg.sample_task([task], max(k_range) + test_samples, None, return_task_name=True)
+        self.learner.load_task(images, labels)
+        training, test_idx = metaseg.split_indices(int(images.shape[0]), test_samples)
+        mious = []
+        for i, k in enumerate(k_range):
+            print("Evaluating {}-shot learning".format(k))
+            train_idx = training[:k]
+            if esimate_inner_iters_with_early_stoppping:
+                if k >= early_stopping_min_val_samples * 2:
+                    val_shots = int(0.2 * k)
+                    print("Split training dataset into {} train shots and {} val shots for early stopping to estimate number of "
+                          "steps.".format(k - val_shots, val_shots))
+                    order = list(train_idx)
+                    random.shuffle(order)
+                    d_tr, d_val = order[:-val_shots], order[-val_shots:]
+                    steps, _ = self._early_stopping_learn(d_tr, d_val, labels, min_steps=1, max_steps=self.K_SHOT_ES_MAX_STEPS,
+                                                          images=images, **params)
+                    params["inner_iters"] = steps
+            else:
+                params["inner_iters"] = iter_range[i]
+            mious.append(self._evaluate(train_idx, test_idx, labels, images=images, **params))
+        print("Evaluated task {} over k-range {}".format(name, k_range))
+        return mious
+
+    def evaluate_m_k_shot_ranges_all_tasks(self, tasks, k_range, m, inner_batch_size, inner_iters, replacement, lr=None, test_samples=20,
+                                           iter_range=None, aug_rate: float = 0.5, **_unused_tf_handles):
+        """reptile.py:393-409: m repetitions of evaluate_k_shot_range per task -> (flat list of ks, flat list of IoUs)."""
+        iter_range = DEFAULT_ITER_RANGE if iter_range is None else iter_range
+        assert len(iter_range) == len(k_range)
+        params = {"inner_batch_size": inner_batch_size, "inner_iters": inner_iters, "replacement": replacement, "lr": lr, "aug_rate": aug_rate}
+        ks, results = [], []
+        for task in tasks:
+            for _ in range(m):
+                res = self.evaluate_k_shot_range(task, k_range=k_range, iter_range=iter_range, test_samples=test_samples, **params)
+                print("k-shot results {}".format({k: r for k, r in zip(k_range, res)}))
+                results.extend(res)
+                ks.extend(k_range)
+        return ks, results
 
     def _test_predictions(self, train_idx, test_idx):
         """reptile.py:482-524: transductive -> all test images in one inference-mode batch; otherwise one call per test image on the

@@ -188,16 +188,18 @@ def parse_example(example: bytes, image_width: int = 224) -> Tuple[np.ndarray, n
 class ShardTask:
     """One binary segmentation task = one shard (meta_learners/metaseg.py:181-230).  Examples are decoded once, lazily."""
 
-    def __init__(self, path: str, image_size: int = 224, name: Optional[str] = None):
+    def __init__(self, path, image_size: int = 224, name: Optional[str] = None):
+        """`path`: one shard, or a list of shards read one after another (the FP-k tasks pool the shards of several synonyms)."""
         self.tfrecord_paths = path
-        self.name = name or os.path.basename(path)
+        self._paths = [path] if isinstance(path, str) else list(path)
+        self.name = name or os.path.basename(self._paths[0])
         self.image_size = image_size
         self._images = self._labels = None
-        self.batch_size = sum(1 for _ in read_records(path))   # count_examples_in_tfrecords
+        self.batch_size = sum(1 for p in self._paths for _ in read_records(p))   # count_examples_in_tfrecords
 
     def _load(self):
         if self._images is None:
-            pairs = [parse_example(r, self.image_size) for r in read_records(self.tfrecord_paths)]
+            pairs = [parse_example(r, self.image_size) for p in self._paths for r in read_records(p)]
             self._images = np.stack([p[0] for p in pairs])
             self._labels = np.stack([p[1] for p in pairs])
 
@@ -250,3 +252,32 @@ def read_fss_1000_dataset(data_dir: str, num_val_tasks: int = 0, num_test_tasks:
     mk = lambda ps: [ShardTask(p, image_size) for p in ps]  # noqa: E731
     tr, va, te = mk(train_shards), mk(val_shards), mk(test_shards)
     return tr, va, te, [t.name for t in tr], [t.name for t in va], [t.name for t in te]
+
+
+DEFAULT_K_SHOT_SET = [{"airliner", "aeroplane"}, {"bus"}, {"motorbike"}, {"potted_plant", "potted plant"}, {"television", "tvmonitor"}]
+
+
+def read_fp_k_shot_dataset(data_dir: str, all_task_names=DEFAULT_K_SHOT_SET, image_size: int = 224):
+    """(tasks, task names) of the FP-k-shot set -- meta_learners/metaseg.py:124-179: one task per synonym set, pooling every shard
+    whose file name contains one of the synonyms (blanks removed); the task is named after the first synonym the set iterates to
+    (Python set order, as in the reference).  Shards are read in sorted-path order (the reference hands TensorFlow a list of globs)."""
+    all_tasks = glob.glob(os.path.join(data_dir, "*.tfrecord*"))
+    print("{} tasks found.".format(len(all_tasks)))
+    print("Building k-shot-FSS-1000 test task samplers...")
+    tasks, names = [], []
+    for synonyms in all_task_names:
+        shards, task_name = [], None
+        for i, synonym in enumerate(synonyms):
+            synonym = synonym.replace(" ", "")
+            if i == 0:
+                task_name = synonym
+                print("Processing task: {}".format(task_name))
+            shards.extend(sorted(x for x in all_tasks if synonym in os.path.basename(x) and x not in shards))
+        print("task shards: {}".format(shards))
+        if not shards:
+            raise ValueError("no shards for task {} under {}".format(task_name, data_dir))
+        t = ShardTask(shards, image_size, name=task_name)
+        print("{} examples in task {}".format(t.batch_size, task_name))
+        tasks.append(t)
+        names.append(task_name)
+    return tasks, names

@@ -357,8 +357,9 @@ class OracleLearner:
     def load_task(self, images, labels):
         self._x, self._y = torch.as_tensor(images), torch.as_tensor(labels)
 
-    def inner_step(self, x, y=None, lr=None, dc_scales=None, dropout_mask=None, weight_decay_rate=1.0):
-        """inner_step(x, y, ...) on explicit tensors, or inner_step(batch_idx, ...) on the task given to load_task()."""
+    def inner_step(self, x, y=None, lr=None, dc_scales=None, dropout_mask=None, weight_decay_rate=1.0, drop_rate=None):
+        """inner_step(x, y, ...) on explicit tensors, or inner_step(batch_idx, ...) on the task given to load_task().
+        (drop_rate is accepted for protocol compatibility; the oracle applies dropout only through an explicit dropout_mask.)"""
         if y is None:
             i = list(x)
             x, y = self._x[i], self._y[i]

@@ -6,7 +6,9 @@ inner-loop engine.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 run_metasegnet.py ...   (tasks sharded 1/GPU)
 
 Writes the reference's checkpoint directory layout (mliis_amd/checkpoint.py) and `<checkpoint>/meta-test_results.json`.
-Out of scope in this build (clear errors): UHO hyper-parameter search, k-shot learning-curve experiment.
+--optimize_update_hyperparms_on_val_set: update-hyperparameter search on the validation tasks (mliis_amd/hyperparam_search.py: the
+early-stopping harness of the reference + a built-in GP / expected-improvement optimiser in place of scikit-optimize);
+--run_k_shot_learning_curves_experiment: k-shot learning curves on the FP-k tasks (or on synthetic tasks with --k-shot-range).
 --augment / --aug_rate: the reference's host numpy augmentation of the inner-loop batches (mliis_amd/augment.py, same draws).  Checkpoints: numpy .npz or TensorFlow TensorBundle files (--checkpoint-format tf; restoring takes either).  Data: --data-dir with FSS-1000 TFRecord-GZIP shards
 (mliis_amd/tfrecord.py, no TensorFlow needed) or --synthetic-tasks N.
 """
@@ -24,36 +26,114 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 from mliis_amd import checkpoint as ckpt  # noqa: E402
-from mliis_amd.args import argument_parser, evaluate_kwargs, make_lr_scheduler, model_kwargs, train_kwargs  # noqa: E402
+from mliis_amd.args import argument_parser, evaluate_kwargs, hyper_search_kwargs, make_lr_scheduler, model_kwargs, train_kwargs  # noqa: E402
 
 
 def _dataset(args, device, rank):
+    """(train, val, test) task lists (run_metasegnet.py:79-98); val is None when empty."""
     from mliis_amd.metaseg import DeviceTask, synthetic_task
     if not args.synthetic_tasks:
         if not args.data_dir:
             raise SystemExit("pass --data-dir <FSS-1000 TFRecord-GZIP shards> or --synthetic-tasks N")
         from mliis_amd import tfrecord
+        if args.run_k_shot_learning_curves_experiment:
+            test, _ = tfrecord.read_fp_k_shot_dataset(args.data_dir, image_size=args.image_size)
+            return None, None, test
         ids = tfrecord.fp_k_test_task_ids() if args.fp_k_test_set else "fss"
         train, val, test, _, _, _ = tfrecord.read_fss_1000_dataset(args.data_dir, num_val_tasks=args.num_val_tasks, test_task_ids=ids,
                                                                    image_size=args.image_size)
-        if not train or not test:
-            raise ValueError("Train / test set has no tasks to evaluate")          # utils/util.py:124-130
-        return train, (val or test)
+        return train, (val or None), test
     n_ex = max(args.train_shots or 0, args.shots + 5)
+    if args.run_k_shot_learning_curves_experiment:
+        n_ex = max(n_ex, max(args.k_shot_range or [400]) + args.k_shot_test_samples)
     tasks = []
     for i in range(args.synthetic_tasks):
         x, y = synthetic_task(n_ex, args.image_size, seed=i)
         tasks.append(DeviceTask("synthetic_{:04d}".format(i), torch.from_numpy(x).to(device), torch.from_numpy(y).to(device)))
     n_test = max(1, len(tasks) // 4)
-    return tasks[:-n_test], tasks[-n_test:]
+    n_val = min(args.num_val_tasks, max(0, len(tasks) - n_test - 1))
+    train, val, test = tasks[:len(tasks) - n_test - n_val], tasks[len(tasks) - n_test - n_val:len(tasks) - n_test], tasks[-n_test:]
+    return train, (val or None), test
+
+
+def _validate_datasets(args, train_set, val_set, test_set):
+    """utils/util.py:124-130."""
+    if not args.pretrained and not args.run_k_shot_learning_curves_experiment:
+        assert train_set is not None and len(train_set) > 0, "Training set must have examples."
+    assert len(test_set) > 0, "Test set must have examples."
+    if args.eval_val_tasks and val_set is not None and len(val_set) == 0:
+        raise ValueError("Val set has no tasks to evaluate")
+
+
+def _evaluate(args, learner, lr_scheduler, train_set, val_set, test_set):
+    """The evaluation half of the reference's main (run_metasegnet.py:135-206), on rank 0."""
+    import copy
+    from mliis_amd.eval import evaluate_gecko, optimize_update_hyperparams, run_k_shot_learning_curves_experiment
+    from mliis_amd.reptile import Dist
+    from mliis_amd.train import train_gecko
+    ek = evaluate_kwargs(args)
+    os.makedirs(args.checkpoint, exist_ok=True)
+    if args.optimize_update_hyperparms_on_val_set:
+        print("Optimizing the update routine hyperparams on the val set")
+        assert val_set is not None and len(val_set) > 0, "Dev set has no tasks"
+        keep = ek["save_fine_tuned_checkpoints"]
+        ek["save_fine_tuned_checkpoints"] = False
+        splits = 1 if args.fss_1000 else 4
+        estimated_lr, estimated_steps = optimize_update_hyperparams(
+            learner, val_set, lr_scheduler=lr_scheduler, serially_eval_all_tasks=args.serially_eval_all_test_tasks,
+            num_configs_to_sample=args.num_configs_to_sample, save_dir=args.checkpoint, results_csv_name=args.uho_results_csv_name,
+            num_train_val_data_splits_to_sample_per_config=splits, max_steps=args.max_steps, min_steps=args.min_steps, **ek,
+            **hyper_search_kwargs(args))
+        ek["save_fine_tuned_checkpoints"] = keep
+        ek["eval_inner_iters"] = estimated_steps
+        ek["lr"] = estimated_lr
+        if args.meta_fine_tune_steps_on_train_val > 0:   # NB (as in the reference): train_kwargs' meta_iters is NOT replaced by that count
+            print("Fine-tuning meta-learned init for {} meta-steps with optimized hyperparameters.".format(args.meta_fine_tune_steps_on_train_val))
+            tp = train_kwargs(args)
+            tp["inner_iters"] = estimated_steps
+            tp["lr"] = estimated_lr
+            tp["meta_step_size"] = tp["meta_step_size_final"]
+            train_gecko(learner, list(train_set) + list(val_set), test_set,
+                        os.path.join(args.checkpoint, "fine-tuned_on_train_val_with_optimized_update_hyperparams"), lr_scheduler=lr_scheduler,
+                        augment=args.augment, dist=Dist(), seed=args.seed, checkpoint_format=args.checkpoint_format, **tp)
+    del ek["eval_tasks_with_median_early_stopping_iterations"]
+    if args.run_k_shot_learning_curves_experiment:
+        kk = copy.copy(ek)
+        del kk["save_fine_tuned_checkpoints"]
+        del kk["save_fine_tuned_checkpoints_dir"]
+        run_k_shot_learning_curves_experiment(learner, test_set, lr_scheduler=lr_scheduler, iter_range=args.k_shot_iter_range,
+                                              k_range=args.k_shot_range, test_samples=args.k_shot_test_samples,
+                                              csv_outpath=os.path.join(args.checkpoint, "k-shot-results.csv"), **kk)
+        return
+    mean_train_iou = None
+    if train_set and not args.skip_train_task_eval:
+        print("Evaluating {}-shot learning on training tasks.".format(args.shots))
+        keep = ek["save_fine_tuned_checkpoints"]
+        ek["save_fine_tuned_checkpoints"] = args.save_fine_tuned_checkpoints_train
+        mean_train_iou, _ = evaluate_gecko(learner, train_set, lr_scheduler=lr_scheduler, serially_eval_all_tasks=False, **ek)
+        ek["save_fine_tuned_checkpoints"] = keep
+    name = "test"
+    if args.eval_val_tasks:
+        test_set, name = val_set, "val"
+    print("Evaluating {}-shot learning on meta-{} tasks.".format(args.shots, name))
+    mean_test_iou, task_name_iou_map = evaluate_gecko(learner, test_set, lr_scheduler=lr_scheduler,
+                                                      serially_eval_all_tasks=args.serially_eval_all_test_tasks, **ek)
+    print("Evaluated meta-{} tasks:".format(name))
+    print(task_name_iou_map)
+    if mean_train_iou is not None:
+        print("Mean meta-train IoU: {}".format(mean_train_iou))
+    # Do NOT change this print (it's used to grep logs):
+    print("Mean IoU over all meta-test tasks: {}".format(mean_test_iou))
+    out = os.path.join(args.checkpoint, "meta-test_results.json")
+    with open(out, "w") as f:
+        json.dump(task_name_iou_map, f)
+    print("Wrote results to {}".format(out))
 
 
 def main():
     start = datetime.datetime.now()
     print("Experiment started at: {}".format(start))
     args = argument_parser().parse_args()
-    if args.optimize_update_hyperparms_on_val_set or args.run_k_shot_learning_curves_experiment:
-        raise NotImplementedError("UHO search / k-shot learning curves are experiment harnesses outside the hot path (SURVEY.md 8(f)-4)")
     random.seed(args.seed)
     world, rank, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
@@ -71,7 +151,8 @@ def main():
     lr_scheduler = make_lr_scheduler(args)
     print("Model contains {} trainable parameters.".format(learner.n_trainable))
     print("Meta-learning with algorithm:\n{}".format("FOMAML" if args.foml else "Reptile"))
-    train_set, test_set = _dataset(args, device, rank)
+    train_set, val_set, test_set = _dataset(args, device, rank)
+    _validate_datasets(args, train_set, val_set, test_set)
 
     if args.restore_efficient_net_weights_from is not None and not args.pretrained:
         path = ckpt.latest_checkpoint(args.restore_efficient_net_weights_from)
@@ -83,7 +164,7 @@ def main():
             path = ckpt.latest_checkpoint(args.continue_training_from_checkpoint)
             print("Continuing meta-training from checkpoint: {}".format(path))
             learner.load_named(ckpt.load(path))
-        train_gecko(learner, train_set, test_set, args.checkpoint, lr_scheduler=lr_scheduler, augment=args.augment, dist=Dist(),
+        train_gecko(learner, train_set, val_set or test_set, args.checkpoint, lr_scheduler=lr_scheduler, augment=args.augment, dist=Dist(),
                     seed=args.seed, checkpoint_format=args.checkpoint_format, **train_kwargs(args))
     else:
         path = ckpt.latest_checkpoint(args.checkpoint)
@@ -94,20 +175,7 @@ def main():
             learner.load_named(ckpt.load(path))
 
     if rank == 0:
-        from mliis_amd.eval import evaluate_gecko
-        ek = evaluate_kwargs(args)
-        print("Evaluating {}-shot learning on meta-test tasks.".format(args.shots))
-        mean_test_iou, task_name_iou_map = evaluate_gecko(learner, test_set, lr_scheduler=lr_scheduler,
-                                                          serially_eval_all_tasks=args.serially_eval_all_test_tasks, **ek)
-        print("Evaluated meta-test tasks:")
-        print(task_name_iou_map)
-        # Do NOT change this print (it's used to grep logs):
-        print("Mean IoU over all meta-test tasks: {}".format(mean_test_iou))
-        os.makedirs(args.checkpoint, exist_ok=True)
-        out = os.path.join(args.checkpoint, "meta-test_results.json")
-        with open(out, "w") as f:
-            json.dump(task_name_iou_map, f)
-        print("Wrote results to {}".format(out))
+        _evaluate(args, learner, lr_scheduler, train_set, val_set, test_set)
     if world > 1:
         import torch.distributed as dist
         dist.barrier()

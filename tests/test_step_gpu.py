@@ -251,3 +251,65 @@ def test_dropout_adam_and_b3_variants():
     th = L.arena.export_trainable_packed().cpu().double()
     ref = torch.cat([O.params[p.name].reshape(-1) for p in L.arena.trainable])
     assert (th - ref).abs().max().item() <= 1e-5      # includes the never-executed blocks, which only receive the L2 gradient
+
+
+def test_early_stopping_harness_and_drop_rate_override():
+    """SURVEY 8(f)-4 on the HIP learner: the early-stopping loop (a prediction pass after every fine-tuning step, HIP-graph replay
+    in between) against an independent replay on the same learner, full state restore, and the per-step drop-rate feed."""
+    _need_gpu()
+    import contextlib
+    import io
+    import random
+    from mliis_amd import hyperparam_search as hs
+    from mliis_amd import metaseg
+    from mliis_amd.learner import Learner
+    from mliis_amd.metrics import iou
+    from mliis_amd.reptile import Gecko
+    H = 64
+    L = Learner(image_size=H, seed=5, use_graph=True, drop_connect=False, final_layer_dropout_rate=0.5, learning_rate=5e-3)
+    x, y = _task(9, H, 21)
+    task = metaseg.DeviceTask("t", torch.tensor(x), torch.tensor(y))
+    L.load_task(task.images, task.labels)
+    tr, va = [0, 1, 2, 3, 4], [5, 6, 7, 8]
+    # drop-rate feed: the mask of the step follows the fed rate, not the rate the model was built with
+    L.inner_step(tr[:4], drop_rate=0.0)
+    L.synchronize()
+    m = L.plans[4].drop_mask
+    assert torch.equal(m, torch.ones_like(m))
+    L.inner_step(tr[:4], drop_rate=0.75)
+    L.synchronize()
+    frac = (L.plans[4].drop_mask == 0).float().mean().item()
+    assert abs(frac - 0.75) < 0.02 and abs(L.plans[4].drop_mask.max().item() - 4.0) < 1e-6
+    with pytest.raises(ValueError):
+        L.inner_step(tr[:4], drop_rate=1.0)
+    L0 = Learner(image_size=H, seed=5, use_graph=False)          # built without dropout: there is nothing to feed (TF: no placeholder)
+    L0.load_task(task.images, task.labels)
+    with pytest.raises(ValueError):
+        L0.inner_step([0, 1], drop_rate=0.2)
+    # early stopping == independent replay of (step, predict, stopper) on the same learner; drop_rate 0 keeps it deterministic
+    g = Gecko(L, transductive=True, rng_mode="reference")
+    before = L.export_all()
+    random.seed(4)
+    with contextlib.redirect_stdout(io.StringIO()):
+        steps, best = g._early_stopping_learn(tr, va, task.labels, 4, min_steps=1, max_steps=8, replacement=False, lr=5e-3, drop_rate=0.0,
+                                              patience=2)
+    after = L.export_all()
+    assert torch.equal(before["theta"], after["theta"]) and torch.equal(before["bn"], after["bn"])
+    random.seed(4)
+    st = hs.EarlyStopper(2, min_steps=1)
+    for it, b in enumerate(metaseg.mini_batch_indices(5, 4, 8, False)):
+        L.inner_step([tr[i] for i in b], lr=5e-3, drop_rate=0.0)
+        preds = L.predict_resident(va, training=False).cpu().numpy()
+        miou = np.nanmean([iou(preds[j], y[va[j]]) for j in range(4)])
+        if not st.continue_training(miou, it + 1):
+            break
+    L.import_all(before)
+    assert (steps, best) == (st.best_num_steps(), st.best_metric()) and 1 <= steps <= 8
+    # evaluate_with_early_stopping end to end (two tasks, median re-evaluation on)
+    tasks = [task, metaseg.DeviceTask("u", torch.tensor(_task(9, H, 22)[0]), torch.tensor(_task(9, H, 22)[1]))]
+    g.ES_PATIENCE = 1
+    with contextlib.redirect_stdout(io.StringIO()):
+        names, nsteps, ious = g.evaluate_with_early_stopping(list(tasks), num_shots=5, inner_batch_size=4, min_steps=0, max_steps=4,
+                                                             eval_all_tasks=True, test_shots=4, lr=5e-3, drop_rate=0.1,
+                                                             eval_tasks_with_median_early_stopping_iterations=True)
+    assert sorted(names) == ["t", "u"] and len(nsteps) == 2 and all(0.0 <= v <= 1.0 for v in ious)
