@@ -35,6 +35,7 @@ def parse():
     ap.add_argument("--inner-batch", type=int, default=8)
     ap.add_argument("--shots", type=int, default=5)
     ap.add_argument("--image-size", type=int, default=224)
+    ap.add_argument("--aspp", action="store_true", help="variant: ASPP decoder in front of the RSD modules (--spatial_pyramid_pooling)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -71,7 +72,7 @@ def cpu_baseline(args):
     import random
     cores = usable_cores()
     torch.set_num_threads(cores)
-    O = R.OracleLearner(image_size=args.image_size, seed=0, dtype=torch.float32, lr=1e-3)
+    O = R.OracleLearner(image_size=args.image_size, seed=0, dtype=torch.float32, lr=1e-3, aspp=args.aspp)
     x, y = synthetic_task(args.shots, args.image_size, seed=0)
     O.load_task(torch.tensor(x), torch.tensor(y))
     batches = [list(b) for b in mini_batch_indices(args.shots, args.inner_batch, 64, rng=random.Random(0))]
@@ -124,20 +125,23 @@ def roofline(L, args):
     # of its launches of an inner step `burst` times back to back between two HIP events on the learner's stream, so that the
     # figure is the kernel's own duration (what rocprofv3 --kernel-trace reports, profiles/r01_final_kernel_stats.csv).
     import torch
+
+    def burst_ms(sites, burst=20):
+        total = 0.0
+        with torch.cuda.stream(L.stream):
+            for r in sites:
+                r["fn"]()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(L.stream)
+                for _ in range(burst):
+                    r["fn"]()
+                e1.record(L.stream)
+                e1.synchronize()
+                total += e0.elapsed_time(e1) / burst
+        return total
     per_step = d["n"] // reps
     sites = [r for r in recs if r.get("kernel") == dom and r["op"] in ("conv2d_fwd", "conv2d_bwd_data")][-per_step:]
-    burst, ms, fl = 20, 0.0, 0.0
-    with torch.cuda.stream(L.stream):
-        for r in sites:
-            r["fn"]()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(L.stream)
-            for _ in range(burst):
-                r["fn"]()
-            e1.record(L.stream)
-            e1.synchronize()
-            ms += e0.elapsed_time(e1) / burst
-            fl += r["flops"]
+    ms, fl = burst_ms(sites), sum(r["flops"] for r in sites)
     d = dict(d, ms=ms, n=len(sites), flops=fl)
     reps_dom = 1
     ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
@@ -150,12 +154,13 @@ def roofline(L, args):
     out = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TFLOPS,
            "traffic": traffic, "traffic_source": tsrc, "launches_per_step": d["n"] // reps_dom, "avg_launch_us": 1e3 * d["ms"] / d["n"],
            "algorithmic_flops_per_launch": d["flops"] / d["n"]}
-    dw = {}
+    dw = {}   # depthwise families against the HBM roofline: algorithmic bytes / the kernels' own durations (burst-timed)
     for k in ("dwconv_fwd", "dwconv_bwd_data", "dwconv_bwd_filter"):
         if k in by:
-            v = by[k]
-            dw[k] = {"us_per_step": 1e3 * v["ms"] / reps, "algorithmic_MB_per_step": v["bytes"] / reps / 1e6,
-                     "GBps": v["bytes"] / (v["ms"] * 1e-3) / 1e9, "frac_of_8TBps": v["bytes"] / (v["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            ksites = [r for r in recs if r["op"] == k][-(by[k]["n"] // reps):]
+            kms, kbytes = burst_ms(ksites), sum(r.get("bytes", 0.0) for r in ksites)
+            dw[k] = {"us_per_step": 1e3 * kms, "launches_per_step": len(ksites), "algorithmic_MB_per_step": kbytes / 1e6,
+                     "GBps": kbytes / (kms * 1e-3) / 1e9, "frac_of_8TBps": kbytes / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS}
     families = {k: {"us_per_step": 1e3 * v["ms"] / reps, "launches_per_step": v["n"] // reps,
                     "TFLOPs": (v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["flops"] else None} for k, v in sorted(by.items())}
     return out, dw, families
@@ -191,7 +196,7 @@ def _run(args):
 
     shots = 10 if args.foml else args.shots
     L = Learner(image_size=args.image_size, rsd=(2, 4), learning_rate=1e-3, optimizer="sgd", dice=False, l2=False, seed=0, device=device,
-                use_graph=not args.no_graph, max_shots=max(16, shots))
+                use_graph=not args.no_graph, max_shots=max(16, shots), spatial_pyramid_pooling=args.aspp)
     tasks = []
     for i in range(args.pool):
         x, y = synthetic_task(shots, args.image_size, seed=1000 * rank + i)
@@ -233,9 +238,10 @@ def _run(args):
             "metric": "inner-loop images/sec (EfficientLab-6-3, 224x224, 5-shot)", "value": value, "unit": "images/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "EfficientLab-6-3 (EfficientNet-B0 blocks 0-10 + RSD(4)+RSD(2)), %dx%d, meta-batch=%d (1 task/GPU), "
+            "config": {"workload": "EfficientLab-6-3 (EfficientNet-B0 blocks 0-10 + %sRSD(4)+RSD(2)), %dx%d, meta-batch=%d (1 task/GPU), "
                                    "%d-shot x %d inner SGD steps of batch %d (%d image fwd+bwd+BN-EMA+SGD per task), %s outer update, fp32, "
-                                   "CE loss, drop-connect on" % (args.image_size, args.image_size, world, shots, args.inner_iters,
+                                   "CE loss, drop-connect on" % ("ASPP + " if args.aspp else "", args.image_size, args.image_size, world, shots,
+                                                                 args.inner_iters,
                                                                  args.inner_batch, imgs_per_task, "FOMAML(tail 5)" if args.foml else "Reptile"),
                        "hip_graph": not args.no_graph, "final_loss": loss},
             "roofline": roof, "cpu_baseline": cpu,

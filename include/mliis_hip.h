@@ -168,6 +168,14 @@ int mliis_se_wgrad_batched(const long long* desc, int ndesc, long long total_til
 int mliis_chan_affine(const float* x, int ldx, const float* S, const float* A, float* y, int ldy, long long rows, int C,
                       int rows_per_img, int accumulate, hipStream_t stream);
 
+/* ---- ASPP activation sites (models/efficientlab.py:258-286, --spatial_pyramid_pooling): y = swish(z) * mask (conv -> swish ->
+ *      tf.layers.dropout; mask = 0 or 1/keep per element, NULL = inference) or, pre_mask != 0, y = swish(z * mask) (the pooled branch
+ *      drops BEFORE the swish); backward dz = dy * mask * swish'(z)  |  dy * swish'(z * mask) * mask.  Row-strided operands. */
+int mliis_swish_mask_fwd(const float* z, int ldz, const float* mask, int ldm, float* y, int ldy, long long rows, int C, int pre_mask,
+                         hipStream_t stream);
+int mliis_swish_mask_bwd(const float* dy, int lddy, const float* z, int ldz, const float* mask, int ldm, float* dz, int lddz, long long rows,
+                         int C, int pre_mask, hipStream_t stream);
+
 /* ---- tf.image.resize_images(BILINEAR, align_corners=True) (efficientlab.py:171-172,205-206) and its transpose.
  *      C % 2 == 0 (the 2-channel logits map uses 8-byte vectors). */
 int mliis_resize_bilinear_fwd(const float* x, int ldx, float* y, int ldy, int N, int Hi, int Wi, int Ho, int Wo, int C,

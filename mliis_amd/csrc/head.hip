@@ -311,6 +311,50 @@ static inline int ew_blocks(long long q) {
   return (int)b;
 }
 
+// ASPP activation sites (models/efficientlab.py:258-286): y = swish(z) * mask (conv -> swish -> dropout; branches 0, 1 and the
+// output conv) or, with pre_mask, y = swish(z * mask) (the pooled branch applies dropout BEFORE the swish).  mask: dropout scale per
+// element (0 or 1/keep), NULL = inference.  backward: dz = dy * mask * swish'(z)   |   dz = dy * swish'(z * mask) * mask.
+// Row-strided operands (channel slices of the concat buffer).  One memory round trip: all operands are fetched first.
+__global__ __launch_bounds__(256) void swish_mask_fwd_k(const float* __restrict__ z, int ldz, const float* __restrict__ mask, int ldm,
+                                                        float* __restrict__ y, int ldy, long long rows, int C, int pre_mask) {
+  const unsigned Q = (unsigned)C >> 2;
+  const unsigned total = (unsigned)rows * Q;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const unsigned r = i / Q;
+    const int c = (int)(i - r * Q) << 2;
+    const float4 vz = ld4(z + (long long)r * ldz + c);
+    const float4 vm = mask ? ld4(mask + (long long)r * ldm + c) : make_float4(1.f, 1.f, 1.f, 1.f);
+    float4 v;
+    if (pre_mask) {
+      v = make_float4(swish_f(vz.x * vm.x), swish_f(vz.y * vm.y), swish_f(vz.z * vm.z), swish_f(vz.w * vm.w));
+    } else {
+      v = make_float4(swish_f(vz.x) * vm.x, swish_f(vz.y) * vm.y, swish_f(vz.z) * vm.z, swish_f(vz.w) * vm.w);
+    }
+    st4(y + (long long)r * ldy + c, v);
+  }
+}
+
+__global__ __launch_bounds__(256) void swish_mask_bwd_k(const float* __restrict__ dy, int lddy, const float* __restrict__ z, int ldz,
+                                                        const float* __restrict__ mask, int ldm, float* __restrict__ dz, int lddz,
+                                                        long long rows, int C, int pre_mask) {
+  const unsigned Q = (unsigned)C >> 2;
+  const unsigned total = (unsigned)rows * Q;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const unsigned r = i / Q;
+    const int c = (int)(i - r * Q) << 2;
+    const float4 vd = ld4(dy + (long long)r * lddy + c);
+    const float4 vz = ld4(z + (long long)r * ldz + c);
+    const float4 vm = mask ? ld4(mask + (long long)r * ldm + c) : make_float4(1.f, 1.f, 1.f, 1.f);
+    float4 g;
+    if (pre_mask) {
+      g = make_float4(swish_grad_f(vz.x * vm.x), swish_grad_f(vz.y * vm.y), swish_grad_f(vz.z * vm.z), swish_grad_f(vz.w * vm.w));
+    } else {
+      g = make_float4(swish_grad_f(vz.x), swish_grad_f(vz.y), swish_grad_f(vz.z), swish_grad_f(vz.w));
+    }
+    st4(dz + (long long)r * lddz + c, make_float4(vd.x * vm.x * g.x, vd.y * vm.y * g.y, vd.z * vm.z * g.z, vd.w * vm.w * g.w));
+  }
+}
+
 }  // namespace mliis
 
 using namespace mliis;
@@ -408,6 +452,38 @@ int mliis_softmax_ce(const float* logits, const float* labels, const int* img_id
                        1.0f / ((float)N * (float)HW), coef, dlogits, pred);
     MLIIS_CHECK_LAUNCH("softmax_ce_grad");
   }
+  return MLIIS_OK;
+}
+static int swish_mask_check(const char* name, const void* a, int lda, const void* b, int ldb, const void* m, int ldm, const void* o, int ldo,
+                            long long rows, int C) {
+  MLIIS_REQUIRE(a && b && o, MLIIS_ERR_ARG, "%s: null pointer", name);
+  MLIIS_REQUIRE(rows > 0 && C > 0 && (C & 3) == 0 && (lda & 3) == 0 && lda >= C && (ldb & 3) == 0 && ldb >= C && (ldo & 3) == 0 && ldo >= C &&
+                    (m == nullptr || ((ldm & 3) == 0 && ldm >= C)),
+                MLIIS_ERR_ARG, "%s: bad shape", name);
+  MLIIS_REQUIRE(aligned16(a) && aligned16(b) && aligned16(m) && aligned16(o), MLIIS_ERR_ALIGN, "%s: pointers must be 16-byte aligned", name);
+  MLIIS_REQUIRE(rows * (C / 4) < (1LL << 31), MLIIS_ERR_UNSUPPORTED, "%s: tensor too large for 32-bit indexing", name);
+  return MLIIS_OK;
+}
+
+int mliis_swish_mask_fwd(const float* z, int ldz, const float* mask, int ldm, float* y, int ldy, long long rows, int C, int pre_mask,
+                         hipStream_t stream) {
+  int rc = swish_mask_check("swish_mask_fwd", z, ldz, z, ldz, mask, ldm, y, ldy, rows, C);
+  if (rc) return rc;
+  const long long q = rows * (C / 4);
+  hipLaunchKernelGGL(swish_mask_fwd_k, dim3((unsigned)((q + 255) / 256 > 4096 ? 4096 : (q + 255) / 256)), dim3(256), 0, stream, z, ldz, mask, ldm, y,
+                     ldy, rows, C, pre_mask);
+  MLIIS_CHECK_LAUNCH("swish_mask_fwd");
+  return MLIIS_OK;
+}
+
+int mliis_swish_mask_bwd(const float* dy, int lddy, const float* z, int ldz, const float* mask, int ldm, float* dz, int lddz, long long rows,
+                         int C, int pre_mask, hipStream_t stream) {
+  int rc = swish_mask_check("swish_mask_bwd", dy, lddy, z, ldz, mask, ldm, dz, lddz, rows, C);
+  if (rc) return rc;
+  const long long q = rows * (C / 4);
+  hipLaunchKernelGGL(swish_mask_bwd_k, dim3((unsigned)((q + 255) / 256 > 4096 ? 4096 : (q + 255) / 256)), dim3(256), 0, stream, dy, lddy, z, ldz, mask,
+                     ldm, dz, lddz, rows, C, pre_mask);
+  MLIIS_CHECK_LAUNCH("swish_mask_bwd");
   return MLIIS_OK;
 }
 }

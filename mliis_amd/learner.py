@@ -88,6 +88,13 @@ class _Plan:
             D["out"], D["dout"] = buf(N, h, h, m.c_out), buf(N, h, h, m.c_out)
             D["dzf"], D["dpyr"], D["dcat"] = buf(N, h, h, m.c_out), buf(N, h, h, 2 * m.c_out), buf(N, h, h, m.c_cat)
             self.rsd.append(D)
+        self.aspp = None
+        if a.aspp:   # --spatial_pyramid_pooling (models/efficientlab.py:248-289)
+            h, ci, d = a.aspp_h, a.aspp_cin, a.aspp_dimension
+            self.aspp = dict(z0=buf(N, h, h, d), z1=buf(N, h, h, d), cat=buf(N, h, h, 3 * d), dcat=buf(N, h, h, 3 * d), zo=buf(N, h, h, d),
+                             out=buf(N, h, h, d), dout=buf(N, h, h, d), dzo=buf(N, h, h, d), pool=buf(N, ci), dpool=buf(N, ci),
+                             z2=buf(N, d), b2=buf(N, d), db2=buf(N, d),
+                             masks=[buf(N, h, h, d), buf(N, h, h, d), buf(N, d), buf(N, h, h, d)])
         hd = a.h_dec
         self.small, self.dsmall = buf(N, hd, hd, 2), buf(N, hd, hd, 2)
         self.logits, self.dlogits, self.pred = buf(N, H, H, 2), buf(N, H, H, 2), buf(N, H, H, 2)
@@ -158,9 +165,8 @@ class Learner:
                  dice: bool = False, label_smoothing: float = 0.0, final_layer_dropout_rate: float = 0.0,
                  spatial_pyramid_pooling: bool = False, skip_decoding: bool = False, drop_connect: bool = True, seed: int = 0,
                  device="cuda:0", use_graph: bool = True, max_shots: int = 16):
-        if spatial_pyramid_pooling or skip_decoding:
-            raise NotImplementedError("--spatial_pyramid_pooling / --skip_decoding decoders are not built yet (not part of "
-                                      "EfficientLab-6-3; SURVEY.md 8(a) a18)")
+        if skip_decoding:
+            raise NotImplementedError("the DeepLabv3+ --skip_decoding decoder is not built (not part of EfficientLab-6-3; SURVEY.md 8(a) a18)")
         if l1 or darc1:
             raise NotImplementedError("--l1 / --darc1 regularisers are not built (off in run.sh)")
         if optimizer not in ("sgd", "adam"):
@@ -170,7 +176,7 @@ class Learner:
         lib.load()  # fail loudly if the HIP extension is missing
         self.device = torch.device(device)
         torch.cuda.set_device(self.device)
-        self.arch = spec.derive(feature_extractor_name, image_size, list(rsd or []), final_layer_dropout_rate)
+        self.arch = spec.derive(feature_extractor_name, image_size, list(rsd or []), final_layer_dropout_rate, spatial_pyramid_pooling)
         self.feature_extractor_name = feature_extractor_name
         self.final_layer_scope = "decode/final_layer_weights"
         self.lr, self.optimizer = float(learning_rate), optimizer
@@ -237,6 +243,8 @@ class Learner:
             s = f"decode/decode_skip_connections_{m.scope_index}"
             self.n_rsd.append([(f"{s}/conv2d{x}/kernel", f"{s}/conv2d{x}/bias", f"{s}/batch_normalization{x}") for x in ("", "_1", "_2")])
         self.n_final = ("decode/final_layer_weights/kernel", "decode/final_layer_weights/bias")
+        s = "decode/spatial_pyramid_pooling"
+        self.n_aspp = [(f"{sc}/conv2d/kernel", f"{sc}/conv2d/bias") for sc in (f"{s}/branch_0", f"{s}/branch_1", f"{s}/branch_2", s)]
 
     # ------------------------------------------------------------------------------------------- variable state
     @property
@@ -404,6 +412,8 @@ class Learner:
             cur = bn(B["z2"], B["st2"], nm["bn2"], B["out"], img_scale=B["dc"] if use_dc else None, res=B["x_in"] if b.skip else None, nblk=nb)
         ends = {r: P.blocks[bi]["out"] for r, bi in a.reductions.items() if bi < len(P.blocks)}
         dec = ends[4]
+        if a.aspp:
+            dec = self._aspp_forward(P, dec, training)
         for m, D, nm, r in zip(a.rsd, P.rsd, self.n_rsd, sorted([x.scope_index + 1 for x in a.rsd], reverse=True)):
             skip = ends[r]
             cat = D["cat"]
@@ -431,6 +441,61 @@ class Learner:
         ops.resize_bilinear_fwd(P.small, (H, H), out=P.logits)
         return P.logits
 
+    # ------------------------------------------------------------------------------------------- ASPP (--spatial_pyramid_pooling)
+    def _aspp_forward(self, P: _Plan, x, training: bool):
+        """models/efficientlab.py:248-289 on the encoder output x [N,h,h,Cin]: 1x1 / 3x3-dilation-6 / image-pooling branches written
+        straight into channel slices of the concat buffer ([pooled | 3x3 | 1x1], the reference's order), then 1x1 conv + swish +
+        dropout.  The dense convs are the MFMA implicit GEMM, the activations mliis_swish_mask_*."""
+        a, w, ws, T, N = self.arch, self.arena.w, self.ws, P.aspp, P.N
+        d, hw = a.aspp_dimension, a.aspp_h * a.aspp_h
+        (k0, c0), (k1, c1), (k2, c2), (ko, co) = self.n_aspp
+        m = T["masks"] if training else [None] * 4
+        cat = T["cat"]
+        ops.conv2d_fwd(x, w[k0], w[c0], 1, out=T["z0"], ws=ws, wt=self.wt[k0])
+        ops.swish_mask_fwd(T["z0"], m[0], out=cat[..., 2 * d:])
+        ops.conv2d_fwd(x, w[k1], w[c1], spec.ASPP_DILATION, out=T["z1"], ws=ws, wt=self.wt[k1])
+        ops.swish_mask_fwd(T["z1"], m[1], out=cat[..., d:2 * d])
+        ops.colsum(x, None, nseg=N, scale=1.0 / hw, out=T["pool"], ws=ws)
+        ops.conv2d_fwd(T["pool"].view(N, 1, 1, -1), w[k2], w[c2], 1, out=T["z2"].view(N, 1, 1, d), ws=ws, wt=self.wt[k2])
+        ops.swish_mask_fwd(T["z2"], m[2], out=T["b2"], pre_mask=True)
+        ops.chan_affine(None, A=T["b2"], out=cat[..., :d])      # bilinear resize of the 1x1 pooled map = broadcast
+        ops.conv2d_fwd(cat, w[ko], w[co], 1, out=T["zo"], ws=ws, wt=self.wt[ko])
+        ops.swish_mask_fwd(T["zo"], m[3], out=T["out"])
+        T["trained"] = training
+        return T["out"]
+
+    def _aspp_backward(self, P: _Plan, x, dx, dx_has: bool):
+        """Gradients of the ASPP parameters (straight into the gradient arena) and of its input (accumulated into dx when dx_has)."""
+        a, A, ws, T, N = self.arch, self.arena, self.ws, P.aspp, P.N
+        w, g = A.w, A.g
+        d, hw = a.aspp_dimension, a.aspp_h * a.aspp_h
+        (k0, c0), (k1, c1), (k2, c2), (ko, co) = self.n_aspp
+        m = T["masks"]
+        cat, dcat = T["cat"], T["dcat"]
+        dzo = ops.swish_mask_bwd(T["dout"], T["zo"], m[3], out=T["dzo"])
+        ops.conv2d_bwd_filter(cat, dzo, 1, 1, out=g[ko], ws=ws)
+        ops.colsum(dzo, out=g[co], ws=ws)
+        ops.conv2d_bwd_data(dzo, w[ko], 1, out=dcat, ws=ws)
+        # 1x1 branch (the pre-activation gradient overwrites its slice of dcat)
+        d0 = ops.swish_mask_bwd(dcat[..., 2 * d:], T["z0"], m[0], out=dcat[..., 2 * d:])
+        ops.conv2d_bwd_filter(x, d0, 1, 1, out=g[k0], ws=ws)
+        ops.colsum(d0, out=g[c0], ws=ws)
+        ops.conv2d_bwd_data(d0, w[k0], 1, out=dx, accumulate=dx_has, ws=ws)
+        # 3x3 dilation-6 branch
+        d1 = ops.swish_mask_bwd(dcat[..., d:2 * d], T["z1"], m[1], out=dcat[..., d:2 * d])
+        ops.conv2d_bwd_filter(x, d1, 3, spec.ASPP_DILATION, out=g[k1], ws=ws)
+        ops.colsum(d1, out=g[c1], ws=ws)
+        ops.conv2d_bwd_data(d1, w[k1], spec.ASPP_DILATION, out=dx, accumulate=True, ws=ws)
+        # image-pooling branch: per-image sums of the broadcast slice -> [N, d] chain -> mean's gradient on every pixel
+        ops.colsum(dcat[..., :d], None, nseg=N, out=T["db2"], ws=ws)
+        d2 = ops.swish_mask_bwd(T["db2"], T["z2"], m[2], out=T["db2"], pre_mask=True)
+        pool4, d24 = T["pool"].view(N, 1, 1, -1), d2.view(N, 1, 1, d)
+        ops.conv2d_bwd_filter(pool4, d24, 1, 1, out=g[k2], ws=ws)
+        ops.colsum(d2, out=g[c2], ws=ws)
+        ops.conv2d_bwd_data(d24, w[k2], 1, out=T["dpool"].view(N, 1, 1, -1), ws=ws)
+        ops.axpby(0.0, None, 1.0 / hw, T["dpool"])                       # d(mean)/dx = 1 / (h*w) on every pixel
+        ops.chan_affine(None, A=T["dpool"], out=dx, accumulate=True)
+
     # ------------------------------------------------------------------------------------------- backward
     def _backward(self, P: _Plan, x, idx):
         A, a, ws, N = self.arena, self.arch, self.ws, P.N
@@ -441,9 +506,9 @@ class Learner:
         ops.final_conv_bwd_filter(P.dec_in, P.dsmall, mask, dw=g[self.n_final[0]], db=g[self.n_final[1]], ws=ws)
         ex = [b for b in a.blocks if b.executed]
         has_grad = [False] * len(P.blocks)
-        dtop = P.rsd[-1]["dout"] if P.rsd else P.blocks[-1]["dout"]
+        dtop = P.rsd[-1]["dout"] if P.rsd else (P.aspp["dout"] if a.aspp else P.blocks[-1]["dout"])
         ops.final_conv_bwd_data(P.dsmall, w[self.n_final[0]], a.aspp_dimension, mask, out=dtop)
-        if not P.rsd:
+        if not P.rsd and not a.aspp:
             has_grad[-1] = True
 
         pending = []
@@ -502,6 +567,8 @@ class Learner:
             # gradient w.r.t. the deep input
             if j > 0:
                 tgt, tgt_has = P.rsd[j - 1]["dout"], False
+            elif a.aspp:
+                tgt, tgt_has = P.aspp["dout"], False
             else:
                 bi = a.reductions[4]
                 tgt, tgt_has = P.blocks[bi]["dout"], has_grad[bi]
@@ -509,13 +576,17 @@ class Learner:
                 ops.chan_affine(dO, out=tgt, accumulate=tgt_has)
             else:
                 ops.resize_bilinear_bwd(dO, (m.h_in, m.h_in), out=tgt, accumulate=tgt_has)
-            if j == 0:
+            if j == 0 and not a.aspp:
                 has_grad[a.reductions[4]] = True
             # gradient w.r.t. the skip endpoint
             bi = a.reductions[r]
             ops.chan_affine(dcat[..., m.c_deep:], out=P.blocks[bi]["dout"], accumulate=has_grad[bi])
             has_grad[bi] = True
 
+        if a.aspp:
+            bi = a.reductions[4]
+            self._aspp_backward(P, P.blocks[bi]["out"], P.blocks[bi]["dout"], has_grad[bi])
+            has_grad[bi] = True
         flush()
         for bi in range(len(P.blocks) - 1, -1, -1):
             b, B, nm = ex[bi], P.blocks[bi], self.n_blocks[bi]
@@ -588,7 +659,8 @@ class Learner:
         self._apply()
 
     def inner_step(self, batch_idx: Sequence[int], lr: Optional[float] = None, dc_scales: Optional[Dict[int, torch.Tensor]] = None,
-                   dropout_mask: Optional[torch.Tensor] = None, weight_decay_rate: float = 1.0, drop_rate: Optional[float] = None):
+                   dropout_mask: Optional[torch.Tensor] = None, weight_decay_rate: float = 1.0, drop_rate: Optional[float] = None,
+                   aspp_masks: Optional[Sequence[torch.Tensor]] = None):
         """One `session.run(minimize_op)` on images `batch_idx` of the resident task.  Returns the device loss scalar.
         `drop_rate` overrides the final-layer dropout rate for this step (the reference feeds `final_layer_dropout_rate_ph`, a
         placeholder that only exists when the model was built with dropout, models/efficientlab.py:94-100)."""
@@ -603,7 +675,7 @@ class Learner:
             self.lr_dev.fill_(self.lr if lr is None else float(lr))
             if weight_decay_rate != 1.0:  # pre_step_op (variables.py:48-55)
                 ops.axpby(0.0, None, float(weight_decay_rate), self.arena.theta)
-            self._fill_masks(P, dc_scales, dropout_mask, drop_rate)
+            self._fill_masks(P, dc_scales, dropout_mask, drop_rate, aspp_masks)
             if self.use_graph and P.steps_run >= 1 and self.optimizer == "sgd":
                 if P.graph is None:
                     gexec = C.c_void_p()
@@ -620,7 +692,14 @@ class Learner:
         self.last_loss = P.loss_out
         return P.loss_out
 
-    def _fill_masks(self, P: _Plan, dc_scales, dropout_mask, drop_rate=None):
+    def _fill_masks(self, P: _Plan, dc_scales, dropout_mask, drop_rate=None, aspp_masks=None):
+        if P.aspp is not None:   # four tf.layers.dropout(rate=0.5) sites: scale 0 or 1/keep (injectable for parity tests)
+            keep = 1.0 - spec.ASPP_DROPOUT
+            for i, mbuf in enumerate(P.aspp["masks"]):
+                if aspp_masks is not None:
+                    mbuf.copy_(torch.as_tensor(aspp_masks[i], dtype=torch.float32).reshape(mbuf.shape))
+                else:
+                    mbuf.copy_((torch.rand(mbuf.shape, generator=self.rng, device=self.device) < keep).to(torch.float32) / keep)
         if drop_rate is not None and P.drop_mask is None:
             raise ValueError("drop_rate given but the model was built without final-layer dropout (final_layer_dropout_rate = 0)")
         if drop_rate is not None and not 0.0 <= float(drop_rate) < 1.0:

@@ -431,6 +431,24 @@ def chan_affine(x, S=None, A=None, out=None, accumulate=False, rows_per_img=None
     return out
 
 
+def swish_mask_fwd(z, mask=None, out=None, pre_mask=False):
+    """ASPP activation: out = swish(z) * mask, or swish(z * mask) with pre_mask (mask None = inference).  Channel-slice views allowed."""
+    rows, C_, ldz = rows_ld(z)
+    out = torch.empty(z.shape, dtype=torch.float32, device=z.device) if out is None else out
+    ldm = rows_ld(mask)[2] if mask is not None else 0
+    lib.call("mliis_swish_mask_fwd", _ptr(z), ldz, _ptr(mask), ldm, _ptr(out), rows_ld(out)[2], rows, C_, int(pre_mask), _stream())
+    return out
+
+
+def swish_mask_bwd(dy, z, mask=None, out=None, pre_mask=False):
+    rows, C_, lddy = rows_ld(dy)
+    out = torch.empty(z.shape, dtype=torch.float32, device=z.device) if out is None else out
+    ldm = rows_ld(mask)[2] if mask is not None else 0
+    lib.call("mliis_swish_mask_bwd", _ptr(dy), lddy, _ptr(z), rows_ld(z)[2], _ptr(mask), ldm, _ptr(out), rows_ld(out)[2], rows, C_,
+             int(pre_mask), _stream())
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ resize / head / loss
 def resize_bilinear_fwd(x, out_hw, out=None):
     N, Hi, Wi = x.shape[:3]

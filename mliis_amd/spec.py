@@ -130,10 +130,17 @@ class Arch:
     h_stem: int = 0
     executed_blocks: int = 0
     h_dec: int = 0                  # side of the final decoded map (input of final 1x1)
+    aspp: bool = False              # --spatial_pyramid_pooling: ASPP between the encoder output and the RSD modules
+    aspp_cin: int = 0               # channels / map side of the encoder output it reads (reduction_4)
+    aspp_h: int = 0
+
+
+ASPP_DILATION = 6        # models/efficientlab.py:265-267 (96 / downsample factor 16)
+ASPP_DROPOUT = 0.5       # models/efficientlab.py:248
 
 
 def derive(name: str = "efficientnet-b0", image_size: int = 224, rsd: Optional[List[int]] = (2, 4),
-           final_layer_dropout_rate: float = 0.0) -> Arch:
+           final_layer_dropout_rate: float = 0.0, spatial_pyramid_pooling: bool = False) -> Arch:
     if name not in _COEFFS:
         raise ValueError("feature_extractor_name must be in {} but is: {}".format(sorted(_COEFFS), name))
     width, depth = _COEFFS[name]
@@ -177,6 +184,9 @@ def derive(name: str = "efficientnet-b0", image_size: int = 224, rsd: Optional[L
         b.executed = b.idx <= last
     mods: List[RSD] = []
     deep_c, deep_h = blocks[last].cout, blocks[last].h_out
+    aspp_cin, aspp_h = deep_c, deep_h
+    if spatial_pyramid_pooling:   # the ASPP output (aspp_dimension channels, same map) replaces the embedded image (efficientlab.py:129-131)
+        deep_c = dec["aspp_dimension"]
     for i in sorted(rsd or [], reverse=True):
         if not 1 <= i <= 4:
             raise ValueError("rsd entries must be reduction indices 1..4, got {}".format(i))
@@ -188,7 +198,8 @@ def derive(name: str = "efficientnet-b0", image_size: int = 224, rsd: Optional[L
     return Arch(name=name, image_size=image_size, stem_out=stem_out, blocks=blocks, reductions=reductions,
                 rsd=mods, aspp_dimension=dec["aspp_dimension"],
                 final_dropout=bool(final_layer_dropout_rate and final_layer_dropout_rate > 0),
-                h_stem=h_stem, executed_blocks=last + 1, h_dec=deep_h)
+                h_stem=h_stem, executed_blocks=last + 1, h_dec=deep_h, aspp=bool(spatial_pyramid_pooling), aspp_cin=aspp_cin,
+                aspp_h=aspp_h)
 
 
 # ----------------------------------------------------------------------------------------------------------
@@ -254,6 +265,12 @@ def param_table(arch: Arch) -> List[Param]:
         P.append(Param(f"{s}/se/conv2d_1/bias", (b.cexp,), "bias", True, True, "zeros", executed=ex))
         P.append(Param(f"{s}/{conv_name()}/kernel", (1, 1, b.cexp, b.cout), "conv", True, True, "normal_fanout", executed=ex))
         _bn(f"{s}/{bn_name()}", b.cout, P, ex)
+    if arch.aspp:   # tf.layers.conv2d defaults: glorot-uniform kernels, zero biases (efficientlab.py:258-283)
+        s, d = "decode/spatial_pyramid_pooling", arch.aspp_dimension
+        for scope, k, ci in ((f"{s}/branch_0", 1, arch.aspp_cin), (f"{s}/branch_1", 3, arch.aspp_cin), (f"{s}/branch_2", 1, arch.aspp_cin),
+                             (s, 1, 3 * d)):
+            P.append(Param(f"{scope}/conv2d/kernel", (k, k, ci, d), "conv", True, True, "glorot_uniform"))
+            P.append(Param(f"{scope}/conv2d/bias", (d,), "bias", True, True, "zeros"))
     for m in arch.rsd:
         s = f"decode/decode_skip_connections_{m.scope_index}"
         convs = []
@@ -292,6 +309,9 @@ def forward_macs_per_image(arch: Arch) -> Dict[str, int]:
         out["depthwise"] += b.h_out ** 2 * b.k ** 2 * b.cexp
         out["se"] += 2 * b.cexp * b.se
         out["pointwise"] += b.h_out ** 2 * b.cexp * b.cout
+    if arch.aspp:
+        d = arch.aspp_dimension
+        out["decoder"] += arch.aspp_h ** 2 * (10 * arch.aspp_cin * d + 3 * d * d) + arch.aspp_cin * d
     for m in arch.rsd:
         px = m.h ** 2
         out["decoder"] += px * (m.c_cat * m.c_out + 9 * m.c_cat * m.c_out + 9 * m.c_pyr * m.c_out)

@@ -48,7 +48,7 @@ def _rf(f, w):
     return int(n + 8 if n < 0.9 * f2 else n)
 
 
-def arch(name="efficientnet-b0", image_size=224, rsd=(2, 4)):
+def arch(name="efficientnet-b0", image_size=224, rsd=(2, 4), aspp=False):
     w, d, max_block, dec_c = _SCALE[name]
     blocks, cum = [], 0
     for tok in _B0_NOTATION.split():
@@ -69,7 +69,7 @@ def arch(name="efficientnet-b0", image_size=224, rsd=(2, 4)):
             red += 1
             endpoints[red] = j
     return dict(name=name, blocks=blocks, endpoints=endpoints, dec_c=dec_c, rsd=sorted(rsd or [], reverse=True),
-                stem=_rf(32, w), last=endpoints[4], image_size=image_size)
+                stem=_rf(32, w), last=endpoints[4], image_size=image_size, aspp=bool(aspp))
 
 
 def param_specs(a) -> List[Tuple[str, Tuple[int, ...], str]]:
@@ -95,6 +95,11 @@ def param_specs(a) -> List[Tuple[str, Tuple[int, ...], str]]:
         n = bn.pop(0)
         out += [(f"{s}/{n}/gamma", (b["o"],), "ones"), (f"{s}/{n}/beta", (b["o"],), "zeros")]
     deep = a["blocks"][a["last"]]["o"]
+    if a.get("aspp"):   # models/efficientlab.py:248-289 (tf.layers.conv2d defaults: glorot-uniform kernel, zero bias)
+        s, d = "decode/spatial_pyramid_pooling", a["dec_c"]
+        for scope, k, ci in ((f"{s}/branch_0", 1, deep), (f"{s}/branch_1", 3, deep), (f"{s}/branch_2", 1, deep), (s, 1, 3 * d)):
+            out += [(f"{scope}/conv2d/kernel", (k, k, ci, d), "glorot"), (f"{scope}/conv2d/bias", (d,), "zeros")]
+        deep = d
     for r in a["rsd"]:
         s = f"decode/decode_skip_connections_{r - 1}"
         cs = a["blocks"][a["endpoints"][r]]["o"]
@@ -182,7 +187,7 @@ def resize_bilinear_ac(x, size):
 
 # -------------------------------------------------------------------------------------------------- forward
 def forward(a, params, bn, x_nhwc, training=True, dc_scales: Optional[Dict[int, torch.Tensor]] = None,
-            dropout_mask: Optional[torch.Tensor] = None, taps: Optional[dict] = None):
+            dropout_mask: Optional[torch.Tensor] = None, taps: Optional[dict] = None, aspp_masks=None):
     """x_nhwc: [N,H,W,3] in 0..255.  dc_scales[block_idx]: [N] tensor of 0 or 1/keep (training only; None -> no
     drop-connect).  dropout_mask: [N,h,w,C] of 0 or 1/(1-rate) applied before the final 1x1.  Returns
     (logits NHWC, new_moving dict).  `taps` (optional dict) receives named intermediates in NHWC."""
@@ -227,6 +232,22 @@ def forward(a, params, bn, x_nhwc, training=True, dc_scales: Optional[Dict[int, 
         if b["idx"] in inv_end:
             ends[inv_end[b["idx"]]] = x
     dec = ends[4]
+    if a.get("aspp"):
+        # Atrous spatial pyramid pooling, models/efficientlab.py:248-289: 1x1 / 3x3-dilation-6 / image-pooling branches (swish, dropout
+        # 0.5 -- the pooled branch drops BEFORE its swish), concat [pooled, 3x3, 1x1] -> 1x1 conv -> swish -> dropout.  aspp_masks: the
+        # four dropout scale tensors (0 or 2) in NHWC for branch_0, branch_1, branch_2 ([N,1,1,C]) and the output (training only).
+        s = "decode/spatial_pyramid_pooling"
+        mk = [None] * 4 if (aspp_masks is None or not training) else [m.to(dt).permute(0, 3, 1, 2) for m in aspp_masks]
+
+        def drop(t, m):
+            return t if m is None else t * m
+        cv = lambda t, scope, d=1: conv2d_same(t, P[f"{scope}/conv2d/kernel"], 1, d, bias=P[f"{scope}/conv2d/bias"])  # noqa: E731
+        b0 = drop(swish(cv(dec, f"{s}/branch_0")), mk[0])
+        b1 = drop(swish(cv(dec, f"{s}/branch_1", 6)), mk[1])
+        b2 = swish(drop(cv(dec.mean(dim=(2, 3), keepdim=True), f"{s}/branch_2"), mk[2]))
+        b2 = b2.expand(-1, -1, dec.shape[2], dec.shape[3])     # bilinear align_corners resize of a 1x1 map = broadcast
+        dec = drop(swish(cv(torch.cat([b2, b1, b0], dim=1), s)), mk[3])
+        tap("aspp", dec)
     for r in a["rsd"]:
         s = f"decode/decode_skip_connections_{r - 1}"
         skip = ends[r]
@@ -277,14 +298,14 @@ def predictions(logits):
 
 
 def inner_step(a, params, bn, x, y, lr, dc_scales=None, dropout_mask=None, label_smoothing=0.0, dice=False, l2=False,
-               weight_decay_rate=1.0, adam_state=None):
+               weight_decay_rate=1.0, adam_state=None, aspp_masks=None):
     """One `session.run(minimize_op)` (reptile.py:114-121,639-643): fwd + bwd + BN moving update + SGD apply.
     Mutates params / bn in place; returns (loss, grads dict, logits)."""
     if weight_decay_rate != 1.0:  # pre_step_op, meta_learners/variables.py:48-55
         for k in params:
             params[k] = params[k] * weight_decay_rate
     leaves = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()}
-    logits, new_moving = forward(a, leaves, bn, x, True, dc_scales, dropout_mask)
+    logits, new_moving = forward(a, leaves, bn, x, True, dc_scales, dropout_mask, aspp_masks=aspp_masks)
     loss = loss_fn(a, leaves, logits, y, label_smoothing, dice, l2)
     names = list(leaves)
     grads = torch.autograd.grad(loss, [leaves[k] for k in names], allow_unused=True)
@@ -317,8 +338,8 @@ class OracleLearner:
     meta-learner host logic (Gecko/FOMLIS, sharding, all-reduce) can be exercised without a GPU."""
 
     def __init__(self, name="efficientnet-b0", image_size=224, rsd=(2, 4), seed=0, dtype=torch.float64, lr=1e-3,
-                 l2=False, dice=False, label_smoothing=0.0, drop_connect=True):
-        self.a = arch(name, image_size, rsd)
+                 l2=False, dice=False, label_smoothing=0.0, drop_connect=True, aspp=False):
+        self.a = arch(name, image_size, rsd, aspp)
         self.params, self.bn = init_state(self.a, seed, dtype)
         self.dtype, self.lr, self.l2, self.dice, self.ls = dtype, lr, l2, dice, label_smoothing
         self.drop_connect = drop_connect
@@ -357,7 +378,7 @@ class OracleLearner:
     def load_task(self, images, labels):
         self._x, self._y = torch.as_tensor(images), torch.as_tensor(labels)
 
-    def inner_step(self, x, y=None, lr=None, dc_scales=None, dropout_mask=None, weight_decay_rate=1.0, drop_rate=None):
+    def inner_step(self, x, y=None, lr=None, dc_scales=None, dropout_mask=None, weight_decay_rate=1.0, drop_rate=None, aspp_masks=None):
         """inner_step(x, y, ...) on explicit tensors, or inner_step(batch_idx, ...) on the task given to load_task().
         (drop_rate is accepted for protocol compatibility; the oracle applies dropout only through an explicit dropout_mask.)"""
         if y is None:
@@ -365,7 +386,7 @@ class OracleLearner:
             x, y = self._x[i], self._y[i]
         loss, _, _ = inner_step(self.a, self.params, self.bn, x, y, self.lr if lr is None else lr,
                                 dc_scales if self.drop_connect else None, dropout_mask, self.ls, self.dice, self.l2,
-                                weight_decay_rate)
+                                weight_decay_rate, aspp_masks=aspp_masks)
         return loss
 
     def export_all(self):

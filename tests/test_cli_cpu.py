@@ -92,3 +92,35 @@ def test_spec_agrees_with_oracle_param_table():
     for name in ("efficientnet-b0", "efficientnet-b3"):
         pt = [(p.name, p.shape) for p in spec.param_table(spec.derive(name)) if p.trainable]
         assert pt == [(n, s) for n, s, _ in R.param_specs(R.arch(name))]
+        # --spatial_pyramid_pooling: four conv kernels + biases between the backbone and the RSD modules (efficientlab.py:248-289)
+        pa = [(p.name, p.shape) for p in spec.param_table(spec.derive(name, spatial_pyramid_pooling=True)) if p.trainable]
+        assert pa == [(n, s) for n, s, _ in R.param_specs(R.arch(name, aspp=True))] and len(pa) == len(pt) + 8
+        i = [n for n, _ in pa].index("decode/spatial_pyramid_pooling/branch_0/conv2d/kernel")
+        assert pa[i - 1][0].startswith(name) and pa[i + 8][0].startswith("decode/decode_skip_connections_3")
+        d = spec.derive(name).aspp_dimension
+        assert dict(pa)["decode/spatial_pyramid_pooling/branch_1/conv2d/kernel"][:2] == (3, 3)
+        assert dict(pa)["decode/spatial_pyramid_pooling/conv2d/kernel"] == (1, 1, 3 * d, d)
+
+
+def test_oracle_aspp_dropout_sites_and_inference():
+    """The oracle's ASPP restatement: masks act at the four dropout sites in training only (the pooled branch before its swish), and an
+    all-ones mask equals no mask."""
+    import torch
+    from oracle import efficientlab_ref as R
+    a = R.arch(image_size=32, aspp=True)
+    P, bn = R.init_state(a, 1)
+    x = torch.rand(2, 32, 32, 3, dtype=torch.float64) * 255
+    d, h = a["dec_c"], 2
+    ones = [torch.ones(2, h, h, d), torch.ones(2, h, h, d), torch.ones(2, 1, 1, d), torch.ones(2, h, h, d)]
+    with torch.no_grad():
+        base, _ = R.forward(a, P, bn, x, True)
+        assert torch.equal(R.forward(a, P, bn, x, True, aspp_masks=ones)[0], base)
+        for site in range(4):
+            m = [t.clone() for t in ones]
+            m[site][:, ..., : d // 2] = 0.0
+            assert not torch.equal(R.forward(a, P, bn, x, True, aspp_masks=m)[0], base)
+            assert torch.equal(R.forward(a, P, bn, x, False, aspp_masks=m)[0], R.forward(a, P, bn, x, False)[0])     # inference ignores them
+        taps = {}
+        zero_out = [ones[0], ones[1], ones[2], torch.zeros(2, h, h, d)]
+        R.forward(a, P, bn, x, True, aspp_masks=zero_out, taps=taps)
+        assert taps["aspp"].abs().max().item() == 0.0

@@ -531,3 +531,25 @@ def test_fold_batched_dense_segmented_and_ragged():
         got = out[off:off + span]
         assert torch.equal(got == -7.0, want == -7.0), "fold wrote outside its window"
         close(got, want, 1e-6, "fold_batched total={}".format(total))
+
+
+@pytest.mark.parametrize("pre_mask", [False, True])
+def test_swish_mask_fwd_bwd(pre_mask):
+    """ASPP activation sites: swish(z) * mask and swish(z * mask), forward and backward, on channel-slice views, vs autograd."""
+    from mliis_amd import ops
+    d = dev()
+    z = rnd(3, 5, 7, 24, seed=70, scale=2.0).requires_grad_(True)
+    mask = torch.tensor(2.0 * (np.random.default_rng(1).random((3, 5, 7, 24)) < 0.5))
+    y = R.swish(z * mask) if pre_mask else R.swish(z) * mask
+    dy = rnd(3, 5, 7, 24, seed=71)
+    (gz,) = torch.autograd.grad(y, [z], dy)
+    cat = torch.full((3, 5, 7, 56), 9.0, device=d)
+    ops.swish_mask_fwd(f32(z, d), f32(mask, d), out=cat[..., 8:32], pre_mask=pre_mask)
+    close(cat[..., 8:32], y, 2e-6, "swish-mask fwd")
+    assert (cat[..., :8] == 9).all() and (cat[..., 32:] == 9).all()
+    dcat = torch.zeros(3, 5, 7, 56, device=d)
+    dcat[..., 8:32] = f32(dy, d)
+    ops.swish_mask_bwd(dcat[..., 8:32], f32(z, d), f32(mask, d), out=dcat[..., 8:32], pre_mask=pre_mask)     # in place on the slice
+    close(dcat[..., 8:32], gz, 1e-5, "swish-mask bwd")
+    # inference: no mask
+    close(ops.swish_mask_fwd(f32(z, d), None, pre_mask=pre_mask), R.swish(z), 2e-6, "swish fwd, no mask")

@@ -313,3 +313,46 @@ def test_early_stopping_harness_and_drop_rate_override():
                                                              eval_all_tasks=True, test_shots=4, lr=5e-3, drop_rate=0.1,
                                                              eval_tasks_with_median_early_stopping_iterations=True)
     assert sorted(names) == ["t", "u"] and len(nsteps) == 2 and all(0.0 <= v <= 1.0 for v in ious)
+
+
+@pytest.mark.parametrize("rsd", [(2, 4), ()])
+def test_aspp_decoder_step_and_inference(rsd):
+    """--spatial_pyramid_pooling (models/efficientlab.py:248-289): one training step with injected dropout masks at
+    the four ASPP sites vs the float64 oracle (loss, every gradient, post-step parameters, BN moving stats), a graph-replayed second
+    step, and inference-mode logits / masks -- with the RSD modules behind it and as the only decoder."""
+    _need_gpu()
+    from mliis_amd.learner import Learner
+    H, S, idx = 64, 5, [3, 1, 4, 0, 2, 3]
+    O = R.OracleLearner(image_size=H, seed=0, dtype=torch.float64, lr=1e-3, rsd=rsd, aspp=True)
+    L = Learner(image_size=H, seed=100, use_graph=True, rsd=rsd, spatial_pyramid_pooling=True)
+    L.load_named({k: v.numpy() for k, v in O.params.items()}, strict=False)
+    assert [p.name for p in L.arena.trainable] == list(O.params)              # same variables, same (creation) order
+    x, y = _task(S, H, 3)
+    L.load_task(x, y)
+    N, d, h = len(idx), O.a["dec_c"], H // 16
+    g = np.random.default_rng(9)
+    for step in range(3):     # step 0 eager, step 1 captures the HIP graph, step 2 replays it
+        dc = _dc(O, N, 20 + step)
+        masks = [torch.tensor(2.0 * (g.random(s) < 0.5)) for s in ((N, h, h, d), (N, h, h, d), (N, 1, 1, d), (N, h, h, d))]
+        lo, gO, _ = R.inner_step(O.a, O.params, O.bn, torch.tensor(x[idx]).double(), torch.tensor(y[idx]).double(), 1e-3, dc,
+                                 aspp_masks=masks)
+        L.inner_step(idx, dc_scales=dc, aspp_masks=masks)
+        ll = L.loss_value()
+        assert abs(ll - lo) <= (1e-4 if step == 0 else 1e-3) * max(1.0, abs(lo)), (step, ll, lo)
+        if step == 0:
+            _compare_state(O, L, gO, "aspp")
+    th = L.arena.export_trainable_packed().cpu().double()
+    ref = torch.cat([O.params[p.name].reshape(-1) for p in L.arena.trainable])
+    assert (th - ref).abs().max().item() <= 3e-5
+    with torch.no_grad():
+        lgO, _ = R.forward(O.a, O.params, O.bn, torch.tensor(x).double(), False)
+    pL, lgL = L.predict(x, training=False, return_logits=True)
+    scale = lgO.abs().max().item()
+    assert (lgL.cpu().double() - lgO).abs().max().item() <= 2e-3 * scale
+    margin = (lgO[..., 0] - lgO[..., 1]).abs() > 1e-3 * scale
+    assert torch.equal(pL.cpu()[margin].double(), R.predictions(lgO)[margin])
+    # random masks: half the activations of a site are dropped, the rest doubled
+    L.inner_step(idx)
+    L.synchronize()
+    for mbuf in L.plans[N].aspp["masks"]:
+        assert set(mbuf.unique().tolist()) <= {0.0, 2.0} and abs((mbuf == 0).float().mean().item() - 0.5) < 0.1
