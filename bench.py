@@ -22,6 +22,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 MFMA_F32_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, dense f32-input MFMA
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA (the --precision bf16 variant only)
 HBM_PEAK_GBS = 8000.0          # ibid., HBM3E spec
 
 
@@ -36,6 +37,8 @@ def parse():
     ap.add_argument("--shots", type=int, default=5)
     ap.add_argument("--image-size", type=int, default=224)
     ap.add_argument("--aspp", action="store_true", help="variant: ASPP decoder in front of the RSD modules (--spatial_pyramid_pooling)")
+    ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32",
+                    help="variant: bf16 operands on the matrix cores (fp32 accumulation, fp32 tensors); the headline metric is fp32")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -151,7 +154,8 @@ def roofline(L, args):
         k = json.load(open(tpath)).get("kernels", {}).get(dom.replace(", ", ","))
         if k:
             traffic, tsrc = k["hbm_bytes_per_launch"], "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950-corrected)"
-    out = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TFLOPS,
+    peak = MFMA_F32_PEAK_TFLOPS if args.precision == "fp32" else MFMA_BF16_PEAK_TFLOPS
+    out = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
            "traffic": traffic, "traffic_source": tsrc, "launches_per_step": d["n"] // reps_dom, "avg_launch_us": 1e3 * d["ms"] / d["n"],
            "algorithmic_flops_per_launch": d["flops"] / d["n"]}
     dw = {}   # depthwise families against the HBM roofline: algorithmic bytes / the kernels' own durations (burst-timed)
@@ -196,7 +200,7 @@ def _run(args):
 
     shots = 10 if args.foml else args.shots
     L = Learner(image_size=args.image_size, rsd=(2, 4), learning_rate=1e-3, optimizer="sgd", dice=False, l2=False, seed=0, device=device,
-                use_graph=not args.no_graph, max_shots=max(16, shots), spatial_pyramid_pooling=args.aspp)
+                use_graph=not args.no_graph, max_shots=max(16, shots), spatial_pyramid_pooling=args.aspp, matmul_precision=args.precision)
     tasks = []
     for i in range(args.pool):
         x, y = synthetic_task(shots, args.image_size, seed=1000 * rank + i)
@@ -237,12 +241,13 @@ def _run(args):
         out = {
             "metric": "inner-loop images/sec (EfficientLab-6-3, 224x224, 5-shot)", "value": value, "unit": "images/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "bf16 matrix-core operands, f32 accumulate / tensors", "data": "synthetic",
             "config": {"workload": "EfficientLab-6-3 (EfficientNet-B0 blocks 0-10 + %sRSD(4)+RSD(2)), %dx%d, meta-batch=%d (1 task/GPU), "
-                                   "%d-shot x %d inner SGD steps of batch %d (%d image fwd+bwd+BN-EMA+SGD per task), %s outer update, fp32, "
-                                   "CE loss, drop-connect on" % ("ASPP + " if args.aspp else "", args.image_size, args.image_size, world, shots,
+                                   "%d-shot x %d inner SGD steps of batch %d (%d image fwd+bwd+BN-EMA+SGD per task), %s outer update, fp32 tensors, "
+                                   "CE loss, drop-connect on%s" % ("ASPP + " if args.aspp else "", args.image_size, args.image_size, world, shots,
                                                                  args.inner_iters,
-                                                                 args.inner_batch, imgs_per_task, "FOMAML(tail 5)" if args.foml else "Reptile"),
+                                                                 args.inner_batch, imgs_per_task, "FOMAML(tail 5)" if args.foml else "Reptile",
+                                                                 "" if args.precision == "fp32" else ", bf16 matrix-core operands"),
                        "hip_graph": not args.no_graph, "final_loss": loss},
             "roofline": roof, "cpu_baseline": cpu,
         }

@@ -66,6 +66,11 @@ int mliis_dwconv_bwd_filter(const float* x, const float* dy, float* dw, int N, i
  *      copy wt [k,k,Cout,Cin] (mliis_transpose_weights, once per weight update), backward-data reads w itself.  `accumulate` != 0
  *      adds into the destination.  ws may be NULL (disables split-K). */
 size_t mliis_conv2d_workspace_floats(int Nimg, int H, int W, int Cred, int Nout, int ksize);
+/*      operand precision of the matrix cores for every later dense-conv call (process-wide): 0 = fp32 operands (default; BASELINE
+ *      configs 1-3), 1 = bf16 operands converted on the fly from the fp32 tensors with fp32 accumulation (configs 4-5 flavour:
+ *      tensors, BN, depthwise and the optimiser stay fp32) */
+int mliis_set_matmul_precision(int bf16);
+int mliis_get_matmul_precision(void);
 /*      tiling chosen for a fwd / bwd-data call (row-tile factor, column tiles, split-K factor) and the name of the kernel
  *      instantiation it launches, as rocprofv3 prints it (profiling aids: bench.py matches its live timings to the trace) */
 int mliis_conv2d_plan(int Nimg, int H, int W, int Cred, int Nout, int ksize, int* tm, int* nt, int* splits);

@@ -31,6 +31,8 @@ SIGNATURES = {
     "mliis_dwconv_bwd_filter_workspace_floats": (_sz, [_i, _i, _i, _i, _i, _i]),
     "mliis_dwconv_bwd_filter": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _sz, _p]),
     "mliis_conv2d_workspace_floats": (_sz, [_i, _i, _i, _i, _i, _i]),
+    "mliis_set_matmul_precision": (_i, [_i]),
+    "mliis_get_matmul_precision": (_i, []),
     "mliis_conv2d_plan": (_i, [_i, _i, _i, _i, _i, _i, _p, _p, _p]),
     "mliis_conv2d_kernel_name": (_i, [_i, _i, _i, _i, _i, _i, _i, _p, _sz]),
     "mliis_conv2d_fwd": (_i, [_p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _p, _sz, _p]),
@@ -101,8 +103,12 @@ class _Lib:
     def raw(self, name):
         return getattr(self.load(), name)
 
+    trace = None   # profiling aid (tools/site_times.py): a list that receives (entry point, args) of every call while it is set
+
     def call(self, name, *args):
         """Call an int-returning entry point; raise MliisError with the library's message on failure."""
+        if self.trace is not None:
+            self.trace.append((name, args))
         rc = getattr(self.load(), name)(*args)
         if rc != 0:
             msg = self._dll.mliis_last_error()

@@ -102,6 +102,8 @@ _EXT = [
     ("--k-shot-test-samples", dict(type=int, default=20, help="held-out examples per task in the k-shot experiment (reference: 20)")),
     ("--skip-train-task-eval", dict(action="store_true",
                                     help="skip the evaluation pass over the meta-TRAIN tasks that the reference always runs before the test tasks")),
+    ("--matmul-precision", dict(choices=["fp32", "bf16"], default="fp32",
+                                help="operand precision of the matrix cores in the dense convs (bf16: fp32 tensors rounded on the fly, fp32 accumulation)")),
     ("--checkpoint-format", dict(choices=["npz", "tf"], default="npz",
                                  help="tensor container of written checkpoints: numpy .npz or a TensorFlow TensorBundle (.index/.data)")),
 ]
@@ -131,7 +133,8 @@ def model_kwargs(a) -> dict:
                 learning_rate=a.learning_rate, optimizer="sgd" if a.sgd else "adam", l2=a.l2, l1=a.l1, darc1=a.darc1,
                 dice=("dice" in a.loss_name), label_smoothing=a.label_smoothing, final_layer_dropout_rate=a.final_layer_dropout_rate,
                 spatial_pyramid_pooling=a.spatial_pyramid_pooling, skip_decoding=a.skip_decoding, seed=a.seed,
-                use_graph=not getattr(a, "no_hip_graph", False), max_shots=_max_shots(a))
+                use_graph=not getattr(a, "no_hip_graph", False), max_shots=_max_shots(a),
+                matmul_precision=getattr(a, "matmul_precision", "fp32"))
     # --disable_rsd_residual_connections is a no-op in the reference too (kwarg name mismatch)
 
 

@@ -18,366 +18,9 @@
 //     B = dY, both read k-major with ds_read_b32 (row stride == 16 mod 32 banks); per-split slabs, deterministic fold.
 // Global loads are raw 16-byte buffer loads along C (128-byte spans per 8 lanes) whose offset is pushed out of range for padding
 // (the hardware returns zeros: no branches), software-pipelined two chunks deep through registers into double-buffered LDS.
-#include <stdlib.h>
-
-#include <type_traits>
-
-#include "common.hpp"
+#include "conv_gemm_kernels.hpp"
 
 namespace mliis {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-struct ConvGemmParams {
-  const float* A;
-  int lda;
-  int Nimg, H, W;
-  int C;
-  int ntaps, dil, sign;
-  const float* B;
-  long long b_tap_stride;
-  int ldb;
-  int Nout;
-  float* Cmat;
-  int ldc;
-  const float* bias;
-  int accumulate;
-  float* partial;        // non-null => split-K partial output [z][M][Nout]
-  int chunks_per_split;  // K chunks per blockIdx.z
-  float* stats_part;     // non-null => epilogue also writes per-row-block column sums [gridDim.x][2][Nout] of the
-  int stats_swish;       //             stored values (of swish(value) when stats_swish) for the following batch norm
-  const float* a_scale;  // non-null => A[m][c] is multiplied by a_scale[image(m)][c] while it is staged (squeeze-excite gate
-                         //             applied on the fly: the gated activation tensor is never materialised)
-  const float* border_bias;  // non-null => [Nimg][9][Nout] added per output pixel by its border class 3*rowclass + colclass
-                             //             (0 = first, 1 = interior, 2 = last): the contribution of spatially CONSTANT input
-                             //             channels of a 3x3 SAME conv (the RSD pooled branch) without convolving them
-};
-
-// ------------------------------------------------------------------------------------------------ forward / backward-data
-// Built so that the matrix pipe is not starved:
-//  * global loads are raw buffer loads whose offset is forced out of range for padded / out-of-image / out-of-K elements (the
-//    hardware returns zeros) -- no branches, so the address arithmetic of chunk k+1 is scheduled between the MFMAs of chunk k;
-//  * every thread advances the (tap, channel) position of its own k quad incrementally, per-row offsets are computed once;
-//  * LDS is double buffered: one barrier per K chunk, the LDS writes of chunk k+1 overlap the MFMAs of chunk k of the other waves;
-//  * all fragments of a chunk are read from LDS before its first MFMA.
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-constexpr unsigned kOob = 0xFFFFFFF0u;          // beyond any num_records: the load returns 0
-constexpr unsigned kBufRecords = 0x80000000u;   // host guarantees every legal byte offset is below 2 GiB
-
-__device__ __forceinline__ float4 buf_ld4(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
-  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);
-  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
-}
-
-template <int TM, int NT, int PF, bool SC, bool SPLIT, bool NARROW>
-__global__ __launch_bounds__(256, 2) void conv_gemm_nk_k(ConvGemmParams p) {
-  constexpr int BM = 64 * TM, BN = 16 * NT, BK = 32;
-  constexpr int A_FLOATS = 8 * BM * 4;
-  constexpr int B_FLOATS = 8 * BN * 4;
-  constexpr int BUF_FLOATS = A_FLOATS + B_FLOATS;
-  constexpr int A_PER_THREAD = 2 * TM;          // float4 per thread per chunk
-  constexpr int B_TOTAL = BN * 8;               // float4 per chunk
-  constexpr int B_PER_THREAD = (B_TOTAL + 255) / 256;
-  constexpr int LDS_STAGE = BN + 4;             // epilogue staging row stride (floats)
-  constexpr int STAGE_FLOATS = 4 * 16 * LDS_STAGE;
-  constexpr int SM_FLOATS = (2 * BUF_FLOATS) > STAGE_FLOATS ? (2 * BUF_FLOATS) : STAGE_FLOATS;
-  constexpr int kDummy = SM_FLOATS;   // 16-byte scratch slot behind the buffers
-  __shared__ __attribute__((aligned(16))) float sm[SM_FLOATS + 4];
-
-  const int t = threadIdx.x;
-  const int lane = t & 63, wave = t >> 6;
-  const int l15 = lane & 15, g = lane >> 4;
-  const long long M = (long long)p.Nimg * p.H * p.W;
-  const int n0 = blockIdx.y * BN;
-  // K is the flattened (tap, channel) index cut into chunks of 32: chunks may straddle taps (every thread tracks the tap / channel of
-  // ITS k quad), so only the very last chunk carries padding and every chunk is a full 2 x 4 x NT MFMA block -- no per-chunk branch.
-  const int nchunks_total = (p.ntaps * p.C + BK - 1) / BK;
-  const int it0 = blockIdx.z * p.chunks_per_split;
-  int it1 = it0 + p.chunks_per_split;
-  if (it1 > nchunks_total) it1 = nchunks_total;
-
-  constexpr bool split = SPLIT;   // split-K instance: raw partial tiles [z][M][Nout], the fold kernel finishes them
-  const bool stats = (p.stats_part != nullptr) && !split;
-  float s1[NT], s2[NT];
-#pragma unroll
-  for (int j = 0; j < NT; ++j) s1[j] = s2[j] = 0.f;
-
-  const unsigned bx = xcd_remap(blockIdx.x, gridDim.x);
-  const long long m0 = (long long)bx * BM;
-
-  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, kBufRecords, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, kBufRecords, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc((void*)(SC ? p.a_scale : p.A), 0, kBufRecords, 0x00020000);
-
-  // ---- per-thread rows: byte offsets computed once
-  const int kq = t & 7;        // this thread's k quad inside a chunk (same for its A and B elements)
-  const int a_r0 = t >> 3;     // 0..31
-  int a_h[A_PER_THREAD], a_w[A_PER_THREAD];
-  unsigned a_off[A_PER_THREAD], s_off[A_PER_THREAD];
-#pragma unroll
-  for (int i = 0; i < A_PER_THREAD; ++i) {
-    const long long m = m0 + a_r0 + 32 * i;
-    a_h[i] = a_w[i] = -0x40000000;   // row beyond M: never in range
-    a_off[i] = s_off[i] = 0;
-    if (m < M) {
-      const int HWp = p.H * p.W;
-      const int n = (int)(m / HWp);
-      const int rem = (int)(m - (long long)n * HWp);
-      a_h[i] = rem / p.W;
-      a_w[i] = rem - a_h[i] * p.W;
-      a_off[i] = (unsigned)(m * p.lda * 4);
-      s_off[i] = (unsigned)((long long)n * p.C * 4);
-    }
-  }
-  unsigned b_off[B_PER_THREAD];
-  bool b_ok[B_PER_THREAD];
-#pragma unroll
-  for (int i = 0; i < B_PER_THREAD; ++i) {
-    const int idx = t + 256 * i;
-    const int n = idx >> 3;
-    b_ok[i] = (idx < B_TOTAL) && (n0 + n < p.Nout);
-    b_off[i] = (unsigned)((long long)(n0 + n) * p.ldb * 4);
-  }
-
-  // ---- (tap, channel) of this thread's k quad in the next chunk to LOAD: channel k_c inside tap k_tap = 3 * k_th + k_tw
-  int k_tap, k_c, k_th, k_tw;
-  auto seek = [&](int kabs) {   // from scratch: integer divisions (start of the K range; every chunk of a NARROW instance)
-    k_tap = kabs / p.C;
-    k_c = kabs - k_tap * p.C;
-    k_th = p.ntaps > 1 ? k_tap / 3 : 1;   // 1x1 convs sit on the centre tap (dh = dw = 0)
-    k_tw = p.ntaps > 1 ? k_tap - k_th * 3 : 1;
-  };
-  int kabs = it0 * BK + kq * 4;
-  seek(kabs);
-  float4 ra[PF][A_PER_THREAD], rs[PF][A_PER_THREAD], rb[PF][B_PER_THREAD];
-
-  // next chunk -> registers, then advance.  Branch-free (live == false turns every offset out of range: no memory traffic, zeros
-  // come back) so the compiler knows exactly how many loads are in flight and waits only for the older chunk.
-  auto load_chunk = [&](float4* ra_, float4* rs_, float4* rb_, bool live) {
-    const int dh = (k_th - 1) * p.dil * p.sign, dw = (k_tw - 1) * p.dil * p.sign;
-    const bool kok = live & (k_tap < p.ntaps);
-    // (recomputed from (k_th, k_tw, k_c) every chunk: carrying the two byte offsets and (dh, dw) incrementally instead removes every
-    // integer multiply from the K loop but measured 4 % SLOWER on the 3x3 decoder convs -- three more live registers per thread)
-    const unsigned da = (unsigned)(((dh * p.W + dw) * p.lda + k_c) * 4);
-#pragma unroll
-    for (int i = 0; i < A_PER_THREAD; ++i) {
-      const bool ok = kok & ((unsigned)(a_h[i] + dh) < (unsigned)p.H) & ((unsigned)(a_w[i] + dw) < (unsigned)p.W);
-      ra_[i] = buf_ld4(rA, ok ? a_off[i] + da : kOob);
-      if (SC) rs_[i] = buf_ld4(rS, ok ? s_off[i] + (unsigned)(k_c * 4) : kOob);
-    }
-    const unsigned db = (unsigned)(((long long)k_tap * p.b_tap_stride + k_c) * 4);
-#pragma unroll
-    for (int i = 0; i < B_PER_THREAD; ++i) rb_[i] = buf_ld4(rB, (kok & b_ok[i]) ? b_off[i] + db : kOob);
-    if (NARROW) {   // 3x3 convs over fewer than 32 channels: a chunk spans several taps
-      kabs += BK;
-      seek(kabs);
-    } else {        // C >= 32 (or a 1x1 conv): at most one tap boundary per chunk
-      k_c += BK;
-      const bool wrap = k_c >= p.C;
-      k_c = wrap ? k_c - p.C : k_c;
-      k_tap += wrap ? 1 : 0;
-      k_tw += wrap ? 1 : 0;   // (a 1x1 conv wraps only into out-of-range taps, where the offsets are ignored)
-      const bool roll = k_tw == 3;
-      k_tw = roll ? 0 : k_tw;
-      k_th += roll ? 1 : 0;
-    }
-  };
-  auto store_chunk = [&](float* buf, const float4* ra_, const float4* rs_, const float4* rb_) {
-    float* smA = buf;
-    float* smB = buf + A_FLOATS;
-#pragma unroll
-    for (int i = 0; i < A_PER_THREAD; ++i) {
-      const int row = a_r0 + 32 * i;
-      float4 v = ra_[i];
-      if (SC) v = f4mul(v, rs_[i]);
-      st4(smA + (kq * BM + (row ^ kq)) * 4, v);
-    }
-#pragma unroll
-    for (int i = 0; i < B_PER_THREAD; ++i) {
-      const int idx = t + 256 * i;
-      if (256 * (i + 1) <= B_TOTAL) st4(smB + (kq * BN + ((idx >> 3) ^ kq)) * 4, rb_[i]);
-      else st4(idx < B_TOTAL ? smB + (kq * BN + ((idx >> 3) ^ kq)) * 4 : sm + kDummy, rb_[i]);   // surplus lanes: a scratch slot, no branch
-    }
-  };
-
-  f32x4 acc[TM][NT];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  // ---- software pipeline: chunk j is computed from LDS buffer (j - it0) & 1 while chunk j+1 waits in registers (loaded one
-  // iteration earlier when PF == 2) and the loads of chunk j+PF are in flight; one barrier per chunk.
-  load_chunk(ra[0], rs[0], rb[0], it0 < it1);
-  store_chunk(sm, ra[0], rs[0], rb[0]);
-#pragma unroll
-  for (int s_ = 1; s_ < PF; ++s_) load_chunk(ra[s_], rs[s_], rb[s_], it0 + s_ < it1);
-  __syncthreads();
-  // One chunk: issue the loads of chunk j + PF into register set U (it held chunk j, already in LDS), multiply chunk j out of
-  // LDS buffer `cur`, then move chunk j + 1 (register set (U + 1) % PF, loaded one step earlier when PF == 2) into the other buffer.
-  int cur = 0;
-  auto step = [&](auto UC, int j) {
-    constexpr int U = decltype(UC)::value;
-    constexpr int NX = (U + 1) % PF;
-    load_chunk(ra[U], rs[U], rb[U], j + PF < it1);
-    const float* smA = sm + cur * BUF_FLOATS;
-    const float* smB = smA + A_FLOATS;
-    constexpr bool kAllFirst = TM == 1;   // read the fragments of both k groups before the first MFMA (register budget permitting)
-    float4 av[2][TM], bv[2][NT];
-    auto read_frags = [&](int q) {
-      const int fq = q * 4 + g;
-#pragma unroll
-      for (int i = 0; i < TM; ++i) av[q][i] = ld4(smA + (fq * BM + ((wave * 16 * TM + i * 16 + l15) ^ fq)) * 4);
-#pragma unroll
-      for (int jn = 0; jn < NT; ++jn) bv[q][jn] = ld4(smB + (fq * BN + ((jn * 16 + l15) ^ fq)) * 4);
-    };
-    auto multiply = [&](int q) {
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-          const float a = s == 0 ? av[q][i].x : s == 1 ? av[q][i].y : s == 2 ? av[q][i].z : av[q][i].w;
-#pragma unroll
-          for (int jn = 0; jn < NT; ++jn) {
-            const float b = s == 0 ? bv[q][jn].x : s == 1 ? bv[q][jn].y : s == 2 ? bv[q][jn].z : bv[q][jn].w;
-            acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i][jn], 0, 0, 0);
-          }
-        }
-      }
-    };
-    if (kAllFirst) {
-      read_frags(0);
-      read_frags(1);
-      multiply(0);
-      multiply(1);
-    } else {
-      read_frags(0);
-      multiply(0);
-      read_frags(1);
-      multiply(1);
-    }
-    store_chunk(sm + (cur ^ 1) * BUF_FLOATS, ra[NX], rs[NX], rb[NX]);   // zeros after the last chunk: nobody reads them
-    cur ^= 1;
-    __syncthreads();
-  };
-  typedef std::integral_constant<int, 0> U0;
-  typedef std::integral_constant<int, 1 % PF> U1;
-  int it = it0;
-  // Main loop: four chunks per trip.  The compiler flushes the load counter at a loop header (it cannot prove across the back edge
-  // that only the newest chunk is in flight), so the long body keeps that flush to every fourth chunk; the tail is straight-line.
-  for (; it + 4 <= it1; it += 4) {
-    step(U0{}, it);
-    step(U1{}, it + 1);
-    step(U0{}, it + 2);
-    step(U1{}, it + 3);
-  }
-  if (it < it1) step(U0{}, it);
-  if (it + 1 < it1) step(U1{}, it + 1);
-  if (it + 2 < it1) step(U0{}, it + 2);
-
-  // ---- epilogue: C/D layout of 16x16x4: col = lane & 15, row = 4 * (lane >> 4) + reg
-  if (split) {
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const long long m = m0 + wave * 16 * TM + i * 16 + g * 4 + r;
-        if (m >= M) continue;
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          const int n = n0 + j * 16 + l15;
-          if (n < p.Nout) p.partial[((long long)blockIdx.z * M + m) * p.Nout + n] = acc[i][j][r];
-        }
-      }
-    return;
-  }
-  float* stage = sm + wave * 16 * LDS_STAGE;
-  float bj[NT];
-#pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int n = n0 + j * 16 + l15;
-    bj[j] = (p.bias != nullptr && n < p.Nout) ? p.bias[n] : 0.f;
-  }
-  const long long HWp = (long long)p.H * p.W;
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    const long long mbase = m0 + wave * 16 * TM + i * 16;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float* bb = nullptr;
-      if (p.border_bias != nullptr) {
-        const long long m = mbase + g * 4 + r;
-        if (m < M) {
-          const int ni = (int)(m / HWp);
-          const int rem = (int)(m - (long long)ni * HWp);
-          const int h = rem / p.W, w_ = rem - h * p.W;
-          const int cls = (h == 0 ? 0 : (h == p.H - 1 ? 2 : 1)) * 3 + (w_ == 0 ? 0 : (w_ == p.W - 1 ? 2 : 1));
-          bb = p.border_bias + ((long long)ni * 9 + cls) * p.Nout;
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const int n = n0 + j * 16 + l15;
-        float v = acc[i][j][r] + bj[j];
-        if (bb != nullptr && n < p.Nout) v += bb[n];
-        acc[i][j][r] = v;
-        stage[(g * 4 + r) * LDS_STAGE + j * 16 + l15] = v;
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < NT; ++it) {
-      const int idx = it * 64 + lane;
-      const int row = idx / (BN / 4), q = idx - row * (BN / 4);
-      const long long m = mbase + row;
-      const int n = n0 + q * 4;
-      if (m < M && n < p.Nout) {
-        float4 v = ld4(stage + row * LDS_STAGE + q * 4);
-        float* dst = p.Cmat + m * p.ldc + n;
-        if (p.accumulate) v = f4add(v, ld4(dst));
-        st4(dst, v);
-      }
-    }
-    __syncthreads();
-  }
-  if (!stats) return;
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const long long m = m0 + wave * 16 * TM + i * 16 + g * 4 + r;
-      if (m >= M) continue;
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const float v = acc[i][j][r];
-        const float u = p.stats_swish ? swish_f(v) : v;
-        s1[j] += u;
-        s2[j] = fmaf(u, u, s2[j]);
-      }
-    }
-  float* red = sm;  // layout [wave][2][BN]
-#pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    float a = s1[j], b = s2[j];
-    a += __shfl_xor(a, 16, 64);
-    b += __shfl_xor(b, 16, 64);
-    a += __shfl_xor(a, 32, 64);
-    b += __shfl_xor(b, 32, 64);
-    if (g == 0) {
-      red[(wave * 2 + 0) * BN + j * 16 + l15] = a;
-      red[(wave * 2 + 1) * BN + j * 16 + l15] = b;
-    }
-  }
-  __syncthreads();
-  for (int idx = t; idx < 2 * BN; idx += 256) {
-    const int v = idx / BN, col = idx - v * BN;
-    const int n = n0 + col;
-    if (n < p.Nout) {
-      const float r0 = red[(0 * 2 + v) * BN + col] + red[(1 * 2 + v) * BN + col] + red[(2 * 2 + v) * BN + col] + red[(3 * 2 + v) * BN + col];
-      p.stats_part[((long long)bx * 2 + v) * p.Nout + n] = r0;
-    }
-  }
-}
 
 __global__ __launch_bounds__(256) void splitk_reduce_k(const float* __restrict__ partial, int splits, long long M, int Nout,
                                                        float* __restrict__ Cmat, int ldc, const float* __restrict__ bias,
@@ -458,202 +101,6 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats_k(const float* __rest
   }
 }
 
-// ------------------------------------------------------------------------------------------------ backward-filter
-struct FilterGradParams {
-  const float* X;
-  int ldx;
-  int Nimg, H, W;
-  int C;
-  int ntaps, dil;
-  const float* dY;
-  int lddy;
-  int Nout;
-  float* partial;  // [splits][ntaps*C][Nout]
-  int rows_per_split;
-  const float* x_scale;  // nullable [Nimg][C]: X[m][c] *= x_scale[image(m)][c] on load
-};
-
-// ------------------------------------------------------------------------------------------------ backward-filter kernel
-// The pipeline of conv_gemm_nk_k applied to the pixel reduction: branch-free buffer loads
-// (out-of-range rows and halo pixels return zeros), per-row (h, w) advanced incrementally instead of two integer divisions per row
-// and chunk, double-buffered LDS (one barrier per 32-pixel chunk) and a two-chunk register prefetch.
-template <int TMF, int NT, bool SC>
-__global__ __launch_bounds__(256, 2) void conv_filter_grad2_k(FilterGradParams p) {
-  constexpr int BCI = 64 * TMF, BN = 16 * NT, BKM = 32;
-  constexpr int LDX = BCI + 16;
-  constexpr int LDD = (BN % 32 == 0) ? BN + 16 : BN;
-  constexpr int X_PER_THREAD = (BKM * (BCI / 4)) / 256;  // 2 * TMF
-  constexpr int D_TOTAL = BKM * (BN / 4);
-  constexpr int D_PER_THREAD = (D_TOTAL + 255) / 256;
-  constexpr int X_RSTEP = 256 / (BCI / 4);
-  constexpr int BUF_FLOATS = BKM * LDX + BKM * LDD;
-  constexpr int PF = (TMF == 2 && (SC || NT >= 8)) ? 1 : 2;   // register budget: one staging set for the widest instances
-  __shared__ __attribute__((aligned(16))) float sm[2 * BUF_FLOATS];
-
-  const int t = threadIdx.x;
-  const int lane = t & 63, wave = t >> 6;
-  const int l15 = lane & 15, g = lane >> 4;
-  const int M = p.Nimg * p.H * p.W;            // host guarantees < 2^31
-  const int cblocks = (p.C + BCI - 1) / BCI;
-  const int tap = blockIdx.x / cblocks;
-  const int ci0 = (blockIdx.x - tap * cblocks) * BCI;
-  const int n0 = blockIdx.y * BN;
-  const int mbeg = blockIdx.z * p.rows_per_split;
-  int mend = mbeg + p.rows_per_split;
-  if (mend > M) mend = M;
-  int dh = 0, dw = 0;
-  if (p.ntaps > 1) {
-    dh = (tap / 3 - 1) * p.dil;
-    dw = (tap % 3 - 1) * p.dil;
-  }
-  const int HW = p.H * p.W;
-  const int adv_h = BKM / p.W, adv_w = BKM - adv_h * p.W;   // one chunk = 32 pixels further along the flattened (n, h, w) index
-
-  const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)p.X, 0, kBufRecords, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rD = __builtin_amdgcn_make_buffer_rsrc((void*)p.dY, 0, kBufRecords, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc((void*)(SC ? p.x_scale : p.X), 0, kBufRecords, 0x00020000);
-
-  // ---- per-thread X rows: position of the row the NEXT load will fetch
-  const int x_cq = t % (BCI / 4);
-  const int x_r0 = t / (BCI / 4);
-  const bool x_cok = ci0 + x_cq * 4 < p.C;
-  int x_m[X_PER_THREAD], x_h[X_PER_THREAD], x_w[X_PER_THREAD], x_n[X_PER_THREAD];
-  unsigned x_off[X_PER_THREAD];
-#pragma unroll
-  for (int i = 0; i < X_PER_THREAD; ++i) {
-    const int m = mbeg + x_r0 + X_RSTEP * i;
-    x_m[i] = m;
-    x_n[i] = m / HW;
-    const int rem = m - x_n[i] * HW;
-    x_h[i] = rem / p.W;
-    x_w[i] = rem - x_h[i] * p.W;
-    x_off[i] = (unsigned)((((long long)m + (long long)dh * p.W + dw) * p.ldx + ci0 + x_cq * 4) * 4);
-  }
-  const unsigned x_step = (unsigned)(BKM * p.ldx * 4);
-  // ---- per-thread dY elements
-  int d_m[D_PER_THREAD];
-  unsigned d_off[D_PER_THREAD];
-  bool d_ok[D_PER_THREAD];
-#pragma unroll
-  for (int i = 0; i < D_PER_THREAD; ++i) {
-    const int idx = t + 256 * i;
-    const int r = idx / (BN / 4), nq = idx - r * (BN / 4);
-    d_m[i] = mbeg + r;
-    d_ok[i] = (idx < D_TOTAL) && (n0 + nq * 4 < p.Nout);
-    d_off[i] = (unsigned)((((long long)mbeg + r) * p.lddy + n0 + nq * 4) * 4);
-  }
-  const unsigned d_step = (unsigned)(BKM * p.lddy * 4);
-
-  float4 rx[PF][X_PER_THREAD], rs[PF][X_PER_THREAD], rd[PF][D_PER_THREAD];
-  auto load_chunk = [&](float4* rx_, float4* rs_, float4* rd_) {   // next 32 pixel rows -> registers, then advance
-#pragma unroll
-    for (int i = 0; i < X_PER_THREAD; ++i) {
-      const bool ok = x_cok & (x_m[i] < mend) & ((unsigned)(x_h[i] + dh) < (unsigned)p.H) & ((unsigned)(x_w[i] + dw) < (unsigned)p.W);
-      rx_[i] = buf_ld4(rX, ok ? x_off[i] : kOob);
-      if (SC) rs_[i] = buf_ld4(rS, ok ? (unsigned)((x_n[i] * p.C + ci0 + x_cq * 4) * 4) : kOob);
-      x_m[i] += BKM;
-      x_off[i] += x_step;
-      x_w[i] += adv_w;
-      x_h[i] += adv_h;
-      if (x_w[i] >= p.W) {
-        x_w[i] -= p.W;
-        ++x_h[i];
-      }
-      if (x_h[i] >= p.H) {   // crossed into the next image(s)
-        const int k = x_h[i] / p.H;
-        x_h[i] -= k * p.H;
-        x_n[i] += k;
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < D_PER_THREAD; ++i) {
-      rd_[i] = buf_ld4(rD, (d_ok[i] & (d_m[i] < mend)) ? d_off[i] : kOob);
-      d_m[i] += BKM;
-      d_off[i] += d_step;
-    }
-  };
-  auto store_chunk = [&](float* buf, const float4* rx_, const float4* rs_, const float4* rd_) {
-    float* smX = buf;
-    float* smD = buf + BKM * LDX;
-#pragma unroll
-    for (int i = 0; i < X_PER_THREAD; ++i) {
-      float4 v = rx_[i];
-      if (SC) v = f4mul(v, rs_[i]);
-      st4(smX + (x_r0 + X_RSTEP * i) * LDX + x_cq * 4, v);
-    }
-#pragma unroll
-    for (int i = 0; i < D_PER_THREAD; ++i) {
-      const int idx = t + 256 * i;
-      if (idx < D_TOTAL) {
-        const int r = idx / (BN / 4), nq = idx - r * (BN / 4);
-        st4(smD + r * LDD + nq * 4, rd_[i]);
-      }
-    }
-  };
-
-  f32x4 acc[TMF][NT];
-#pragma unroll
-  for (int i = 0; i < TMF; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  load_chunk(rx[0], rs[0], rd[0]);
-  store_chunk(sm, rx[0], rs[0], rd[0]);
-  if (PF == 2) load_chunk(rx[PF - 1], rs[PF - 1], rd[PF - 1]);
-  __syncthreads();
-  int cur = 0;
-  auto step = [&](auto UC) {
-    constexpr int U = decltype(UC)::value;
-    constexpr int NX = (U + 1) % PF;
-    load_chunk(rx[U], rs[U], rd[U]);   // PF chunks ahead (rows beyond mend come back as zeros)
-    const float* smX = sm + cur * BUF_FLOATS;
-    const float* smD = smX + BKM * LDX;
-#pragma unroll
-    for (int kk = 0; kk < BKM / 4; ++kk) {
-      const int mrow = kk * 4 + g;
-      float a[TMF], b[NT];
-#pragma unroll
-      for (int i = 0; i < TMF; ++i) a[i] = smX[mrow * LDX + (wave * TMF + i) * 16 + l15];
-#pragma unroll
-      for (int j = 0; j < NT; ++j) b[j] = smD[mrow * LDD + j * 16 + l15];
-#pragma unroll
-      for (int i = 0; i < TMF; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
-    }
-    store_chunk(sm + (cur ^ 1) * BUF_FLOATS, rx[NX], rs[NX], rd[NX]);
-    cur ^= 1;
-    __syncthreads();
-  };
-  typedef std::integral_constant<int, 0> U0;
-  typedef std::integral_constant<int, 1 % PF> U1;
-  const int nchunks = (mend - mbeg + BKM - 1) / BKM;
-  int it = 0;
-  for (; it + 4 <= nchunks; it += 4) {
-    step(U0{});
-    step(U1{});
-    step(U0{});
-    step(U1{});
-  }
-  if (it < nchunks) step(U0{});
-  if (it + 1 < nchunks) step(U1{});
-  if (it + 2 < nchunks) step(U0{});
-
-  const long long Ktot = (long long)p.ntaps * p.C;
-#pragma unroll
-  for (int i = 0; i < TMF; ++i)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int ci = ci0 + (wave * TMF + i) * 16 + g * 4 + r;
-      if (ci >= p.C) continue;
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const int n = n0 + j * 16 + l15;
-        if (n < p.Nout) p.partial[((long long)blockIdx.z * Ktot + (long long)tap * p.C + ci) * p.Nout + n] = acc[i][j][r];
-      }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------ weight shadow (HWIO -> HWOI)
 // dst[off + tap*Ci*Co + co*Ci + ci] = src[off + tap*Ci*Co + ci*Co + co] for every descriptor (off, taps, Ci, Co): one launch per
 // inner step keeps a K-contiguous copy of all dense-conv weights so the FORWARD GEMM can use the same b128-fragment B path as
@@ -688,10 +135,6 @@ __global__ __launch_bounds__(256) void transpose_weights_k(const float* __restri
 }
 
 // ------------------------------------------------------------------------------------------------ host-side planning
-struct GemmPlan {
-  int tm, nt, gx, gy, gz, chunks_per_split;
-};
-
 // Column tiles per block (16 columns each, at most 8): the widest tile that does not pad the output width by much -- padded
 // columns are wasted MFMAs (N = 136: 3 x 48 columns instead of 2 x 80), narrower tiles re-read the A tile more often.
 static inline int pick_nt(int Nout) {
@@ -711,9 +154,6 @@ static inline int pick_nt(int Nout) {
 
 constexpr int kGemmFill = 4;     // fwd / bwd-data: narrow the column tiles of sub-chip grids until there are this many blocks per CU
 constexpr int kFilterFill = 1;   // bwd-filter: same idea, one block per CU is enough (its slabs already split the pixel axis)
-
-// 3x3 convs over fewer than 32 channels: a 32-wide K chunk spans several taps (conv_gemm_nk_k<..., NARROW = true>)
-static inline bool gemm_narrow(int ntaps, int C) { return ntaps > 1 && C < 32; }
 
 static inline GemmPlan plan_gemm(long long M, int Nout, int C, int ntaps, int num_cus, int allow_split) {
   GemmPlan g;
@@ -746,43 +186,6 @@ static inline GemmPlan plan_gemm(long long M, int Nout, int C, int ntaps, int nu
   return g;
 }
 
-static void launch_gemm(const GemmPlan& g, const ConvGemmParams& p, hipStream_t stream) {
-  dim3 grid(g.gx, g.gy, g.gz), block(256);
-  const bool sp = p.partial != nullptr, sc = p.a_scale != nullptr, narrow = gemm_narrow(p.ntaps, p.C);
-#define NK(TM_, NT_, SC_, SP_) hipLaunchKernelGGL((conv_gemm_nk_k<TM_, NT_, (TM_ == 1 ? 2 : 1), SC_, SP_, false>), grid, block, 0, stream, p)
-#define L(TM_, NT_)                                  \
-  if (TM_ == 1 && narrow) {                          \
-    hipLaunchKernelGGL((conv_gemm_nk_k<1, NT_, 2, false, false, true>), grid, block, 0, stream, p); \
-  } else if (TM_ == 1 && sp) {                       \
-    if (sc) NK(1, NT_, true, true);                  \
-    else NK(1, NT_, false, true);                    \
-  } else if (sc) NK(TM_, NT_, true, false);          \
-  else NK(TM_, NT_, false, false);                   \
-  break;
-#define ROW(TM_)       \
-  switch (g.nt) {      \
-    case 1: L(TM_, 1)  \
-    case 2: L(TM_, 2)  \
-    case 3: L(TM_, 3)  \
-    case 4: L(TM_, 4)  \
-    case 5: L(TM_, 5)  \
-    case 6: L(TM_, 6)  \
-    case 7: L(TM_, 7)  \
-    default: L(TM_, 8) \
-  }
-  if (g.tm == 2) {
-    ROW(2)
-  } else {
-    ROW(1)
-  }
-#undef ROW
-#undef L
-#undef NK
-}
-
-struct FilterPlan {
-  int tmf, nt, gx, gy, gz, rows_per_split;
-};
 static inline void plan_filter_split(FilterPlan& f, long long M, int C, int Nout, int ntaps, int num_cus) {
   const int bci = 64 * f.tmf;
   f.gy = (Nout + f.nt * 16 - 1) / (f.nt * 16);
@@ -820,30 +223,16 @@ static inline FilterPlan plan_filter(long long M, int C, int Nout, int ntaps, in
   return f;
 }
 
+// Matrix-core operand precision of the dense convs (mliis_set_matmul_precision): 0 = fp32 (default), 1 = bf16 operands with fp32
+// accumulation.  Process-wide; read when a call is issued (a captured HIP graph keeps what it was captured with).
+static int g_matmul_bf16 = 0;
+static void launch_gemm(const GemmPlan& g, const ConvGemmParams& p, hipStream_t stream) {
+  if (g_matmul_bf16) launch_gemm_bf16(g, p, stream);
+  else launch_gemm_t<false>(g, p, stream);
+}
 static void launch_filter(const FilterPlan& f, const FilterGradParams& p, hipStream_t stream) {
-  dim3 grid(f.gx, f.gy, f.gz), block(256);
-#define L(T_, NT_)                                                                                                   \
-  if (p.x_scale) hipLaunchKernelGGL((conv_filter_grad2_k<T_, NT_, true>), grid, block, 0, stream, p);           \
-  else hipLaunchKernelGGL((conv_filter_grad2_k<T_, NT_, false>), grid, block, 0, stream, p);                         \
-  break;
-#define ROW(T_)       \
-  switch (f.nt) {     \
-    case 1: L(T_, 1)  \
-    case 2: L(T_, 2)  \
-    case 3: L(T_, 3)  \
-    case 4: L(T_, 4)  \
-    case 5: L(T_, 5)  \
-    case 6: L(T_, 6)  \
-    case 7: L(T_, 7)  \
-    default: L(T_, 8) \
-  }
-  if (f.tmf == 2) {
-    ROW(2)
-  } else {
-    ROW(1)
-  }
-#undef ROW
-#undef L
+  if (g_matmul_bf16) launch_filter_bf16(f, p, stream);
+  else launch_filter_t<false>(f, p, stream);
 }
 
 static int g_num_cus = 0;
@@ -874,6 +263,15 @@ using namespace mliis;
 
 extern "C" {
 
+// Operand precision of the matrix cores for every later conv2d_fwd / _bwd_data / _bwd_filter call: 0 = fp32 (v_mfma_f32_16x16x4_f32),
+// 1 = bf16 operands converted on the fly from the fp32 tensors, fp32 accumulation (v_mfma_f32_16x16x32_bf16).
+int mliis_set_matmul_precision(int bf16) {
+  MLIIS_REQUIRE(bf16 == 0 || bf16 == 1, MLIIS_ERR_ARG, "set_matmul_precision: 0 (fp32) or 1 (bf16 operands)");
+  g_matmul_bf16 = bf16;
+  return MLIIS_OK;
+}
+int mliis_get_matmul_precision(void) { return g_matmul_bf16; }
+
 // Tiling the planner picks for a conv2d_fwd / conv2d_bwd_data call (profiling aid: row-tile factor, column tiles, split-K factor).
 int mliis_conv2d_plan(int Nimg, int H, int W, int Cred, int Nout, int ksize, int* tm, int* nt, int* splits) {
   MLIIS_REQUIRE(tm && nt && splits, MLIIS_ERR_ARG, "conv2d_plan: null pointer");
@@ -887,10 +285,10 @@ int mliis_conv2d_plan(int Nimg, int H, int W, int Cred, int Nout, int ksize, int
 // Name of the kernel instantiation (as rocprofv3 prints it, without the mliis:: prefix and argument list) that a conv2d_fwd /
 // conv2d_bwd_data call with these shapes launches (has_scale: an x_scale operand is given).
 int mliis_conv2d_kernel_name(int Nimg, int H, int W, int Cred, int Nout, int ksize, int has_scale, char* buf, size_t buf_len) {
-  MLIIS_REQUIRE(buf && buf_len >= 56, MLIIS_ERR_ARG, "conv2d_kernel_name: buffer too small");
+  MLIIS_REQUIRE(buf && buf_len >= 64, MLIIS_ERR_ARG, "conv2d_kernel_name: buffer too small");
   GemmPlan g = plan_gemm((long long)Nimg * H * W, Nout, Cred, ksize * ksize, num_cus(), 1);
-  snprintf(buf, buf_len, "conv_gemm_nk_k<%d, %d, %d, %s, %s, %s>", g.tm, g.nt, g.tm == 1 ? 2 : 1, has_scale ? "true" : "false",
-           g.gz > 1 ? "true" : "false", gemm_narrow(ksize * ksize, Cred) ? "true" : "false");
+  snprintf(buf, buf_len, "conv_gemm_nk_k<%d, %d, %d, %s, %s, %s, %s>", g.tm, g.nt, g.tm == 1 ? 2 : 1, has_scale ? "true" : "false",
+           g.gz > 1 ? "true" : "false", gemm_narrow(ksize * ksize, Cred) ? "true" : "false", g_matmul_bf16 ? "true" : "false");
   return MLIIS_OK;
 }
 

@@ -1,0 +1,9 @@
+// bf16-operand instances of the dense-conv GEMM kernels (v_mfma_f32_16x16x32_bf16, fp32 accumulation); see conv_gemm_kernels.hpp.
+#include "conv_gemm_kernels.hpp"
+
+namespace mliis {
+
+void launch_gemm_bf16(const GemmPlan& g, const ConvGemmParams& p, hipStream_t stream) { launch_gemm_t<true>(g, p, stream); }
+void launch_filter_bf16(const FilterPlan& f, const FilterGradParams& p, hipStream_t stream) { launch_filter_t<true>(f, p, stream); }
+
+}  // namespace mliis

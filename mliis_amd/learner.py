@@ -164,7 +164,7 @@ class Learner:
                  learning_rate: float = 1e-3, optimizer: str = "sgd", l2: bool = False, l1: bool = False, darc1: bool = False,
                  dice: bool = False, label_smoothing: float = 0.0, final_layer_dropout_rate: float = 0.0,
                  spatial_pyramid_pooling: bool = False, skip_decoding: bool = False, drop_connect: bool = True, seed: int = 0,
-                 device="cuda:0", use_graph: bool = True, max_shots: int = 16):
+                 device="cuda:0", use_graph: bool = True, max_shots: int = 16, matmul_precision: str = "fp32"):
         if skip_decoding:
             raise NotImplementedError("the DeepLabv3+ --skip_decoding decoder is not built (not part of EfficientLab-6-3; SURVEY.md 8(a) a18)")
         if l1 or darc1:
@@ -174,6 +174,10 @@ class Learner:
         if not torch.cuda.is_available():
             raise MliisError("mliis_amd.Learner needs an MI355X (HIP device); there is no CPU path")
         lib.load()  # fail loudly if the HIP extension is missing
+        # operand precision of the matrix cores in the dense convs: "fp32" (BASELINE configs 1-3) or "bf16" (operands rounded to bf16 on
+        # the fly, fp32 accumulation; everything else stays fp32).  Process-wide switch of the library.
+        ops.set_matmul_precision(matmul_precision)
+        self.matmul_precision = matmul_precision
         self.device = torch.device(device)
         torch.cuda.set_device(self.device)
         self.arch = spec.derive(feature_extractor_name, image_size, list(rsd or []), final_layer_dropout_rate, spatial_pyramid_pooling)

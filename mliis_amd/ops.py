@@ -62,9 +62,20 @@ def profile_resolve(records):
     return records
 
 
+def set_matmul_precision(precision: str):
+    """'fp32' (default) or 'bf16': operand precision of the matrix cores in the dense convs (process-wide; fp32 accumulation)."""
+    if precision not in ("fp32", "bf16"):
+        raise MliisError("matmul precision must be 'fp32' or 'bf16', got {!r}".format(precision))
+    lib.call("mliis_set_matmul_precision", int(precision == "bf16"))
+
+
+def get_matmul_precision() -> str:
+    return "bf16" if lib.raw("mliis_get_matmul_precision")() else "fp32"
+
+
 def conv2d_kernel_name(N, H, W, cred, nout, k, has_scale=False):
-    buf = C.create_string_buffer(64)
-    lib.call("mliis_conv2d_kernel_name", N, H, W, cred, nout, k, int(has_scale), C.cast(buf, C.c_void_p), 64)
+    buf = C.create_string_buffer(80)
+    lib.call("mliis_conv2d_kernel_name", N, H, W, cred, nout, k, int(has_scale), C.cast(buf, C.c_void_p), 80)
     return buf.value.decode()
 
 

@@ -553,3 +553,32 @@ def test_swish_mask_fwd_bwd(pre_mask):
     close(dcat[..., 8:32], gz, 1e-5, "swish-mask bwd")
     # inference: no mask
     close(ops.swish_mask_fwd(f32(z, d), None, pre_mask=pre_mask), R.swish(z), 2e-6, "swish fwd, no mask")
+
+
+@pytest.mark.parametrize("k,dil,H,W,Cin,Cout,N", [(1, 1, 14, 14, 40, 240, 2), (3, 2, 14, 14, 136, 112, 2), (1, 1, 56, 56, 24, 144, 4), (3, 1, 8, 8, 20, 16, 2)])
+def test_conv2d_bf16_operands(k, dil, H, W, Cin, Cout, N):
+    """mliis_set_matmul_precision(1): bf16 operands on the matrix cores (v_mfma_f32_16x16x32_bf16), fp32 accumulation.  Exactly the fp32
+    result of the bf16-ROUNDED operands up to accumulation order (tolerance 2e-5), i.e. within bf16 rounding (2^-9 relative per operand)
+    of the full-precision result."""
+    from mliis_amd import ops
+    d = dev()
+    bf = lambda t: t.to(torch.bfloat16).to(torch.float64)   # noqa: E731  round to nearest even, like v_cvt_pk_bf16_f32
+    x32, w32, dy32 = rnd(N, H, W, Cin, seed=80).float(), rnd(k, k, Cin, Cout, seed=81, scale=1.0 / math.sqrt(k * k * Cin)).float(), None
+    x, w = bf(x32).requires_grad_(True), bf(w32).requires_grad_(True)
+    b = rnd(Cout, seed=82)
+    y = R.conv2d_same(nchw(x), w, 1, dil, bias=b)
+    dy32 = rnd(*y.shape, seed=83).float()
+    dy = bf(dy32)
+    gx, gw = torch.autograd.grad(y, [x, w], dy)
+    try:
+        ops.set_matmul_precision("bf16")
+        assert ops.get_matmul_precision() == "bf16"
+        xg, wg, dyg = x32.to(d), w32.to(d), nhwc(dy32).contiguous().to(d)
+        close(ops.conv2d_fwd(xg, wg, f32(b, d), dil), nhwc(y), 2e-5, "bf16 conv fwd")
+        close(ops.conv2d_bwd_data(dyg, wg, dil), gx, 1e-4, "bf16 conv bwd data")
+        close(ops.conv2d_bwd_filter(xg, dyg, k, dil), gw, 1e-4, "bf16 conv bwd filter")
+    finally:
+        ops.set_matmul_precision("fp32")
+    assert ops.get_matmul_precision() == "fp32"
+    with pytest.raises(Exception):
+        ops.set_matmul_precision("fp8")

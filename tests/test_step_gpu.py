@@ -356,3 +356,37 @@ def test_aspp_decoder_step_and_inference(rsd):
     L.synchronize()
     for mbuf in L.plans[N].aspp["masks"]:
         assert set(mbuf.unique().tolist()) <= {0.0, 2.0} and abs((mbuf == 0).float().mean().item() - 0.5) < 0.1
+
+
+def test_bf16_matrix_core_operands_track_the_fp32_trajectory():
+    """BASELINE configs 4-5 flavour (`--matmul-precision bf16`): dense convs with bf16 operands / fp32 accumulation, everything else
+    fp32.  Tolerance stated here: per-step loss within 2 % of the float64 oracle over 4 steps (operands carry 2^-9 relative rounding;
+    the fp32 path holds 1e-4 / 1e-3), inference masks equal to the oracle's wherever its logit margin exceeds 5 % of the logit range."""
+    _need_gpu()
+    from mliis_amd import ops
+    from mliis_amd.learner import Learner
+    H, S = 64, 5
+    try:
+        O = R.OracleLearner(image_size=H, seed=0, dtype=torch.float64, lr=1e-3, drop_connect=False)
+        L = Learner(image_size=H, seed=100, use_graph=True, drop_connect=False, matmul_precision="bf16")
+        assert ops.get_matmul_precision() == "bf16"
+        L.load_named({k: v.numpy() for k, v in O.params.items()}, strict=False)
+        x, y = _task(S, H, 4)
+        L.load_task(x, y)
+        idx = [0, 1, 2, 3, 4, 0, 1, 2]
+        for step in range(4):
+            lo = O.inner_step(torch.tensor(x[idx]).double(), torch.tensor(y[idx]).double())
+            L.inner_step(idx)
+            ll = L.loss_value()
+            assert abs(ll - lo) <= 2e-2 * max(1.0, abs(lo)), (step, ll, lo)
+        with torch.no_grad():
+            lgO, _ = R.forward(O.a, O.params, O.bn, torch.tensor(x).double(), False)
+        pL, lgL = L.predict(x, training=False, return_logits=True)
+        scale = lgO.abs().max().item()
+        assert (lgL.cpu().double() - lgO).abs().max().item() <= 5e-2 * scale
+        margin = (lgO[..., 0] - lgO[..., 1]).abs() > 5e-2 * scale
+        assert torch.equal(pL.cpu()[margin].double(), R.predictions(lgO)[margin])
+    finally:
+        ops.set_matmul_precision("fp32")
+    L2 = Learner(image_size=H, seed=1, use_graph=False)        # the default puts the library back to fp32 operands
+    assert ops.get_matmul_precision() == "fp32" and L2.matmul_precision == "fp32"
