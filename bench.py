@@ -37,6 +37,9 @@ def parse():
     ap.add_argument("--shots", type=int, default=5)
     ap.add_argument("--image-size", type=int, default=224)
     ap.add_argument("--aspp", action="store_true", help="variant: ASPP decoder in front of the RSD modules (--spatial_pyramid_pooling)")
+    ap.add_argument("--augment", action="store_true", help="variant: host augmentation of every inner-loop batch (the reference's run.sh setting)")
+    ap.add_argument("--augment-workers", type=int, default=-1, help="worker processes for the augmentation pixel work (0 = inline, -1 = cores - 1)")
+    ap.add_argument("--tasks-per-gpu", type=int, default=1, help="variant: tasks per GPU and meta-step (the metric's config has 1)")
     ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32",
                     help="variant: bf16 operands on the matrix cores (fp32 accumulation, fp32 tensors); the headline metric is fp32")
     ap.add_argument("--no-graph", action="store_true")
@@ -180,6 +183,10 @@ def main():
 
 
 def _run(args):
+    aug_pool = None
+    if args.augment and args.augment_workers != 0:   # forked workers: before anything initialises the GPU
+        from mliis_amd.augment import AugmentPool
+        aug_pool = AugmentPool(None if args.augment_workers < 0 else args.augment_workers)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -207,13 +214,13 @@ def _run(args):
         tasks.append(DeviceTask("synthetic_%d_%d" % (rank, i), torch.from_numpy(x).to(device), torch.from_numpy(y).to(device)))
     D = Dist()
     if args.foml:
-        meta = FOMLIS(L, train_shots=shots, tail_shots=5, dist=D, rng_mode="per_task", seed=0)
+        meta = FOMLIS(L, train_shots=shots, tail_shots=5, dist=D, rng_mode="per_task", seed=0, augment=args.augment, aug_rate=0.5, aug_pool=aug_pool)
     else:
-        meta = Gecko(L, dist=D, rng_mode="per_task", seed=0)
+        meta = Gecko(L, dist=D, rng_mode="per_task", seed=0, augment=args.augment, aug_rate=0.5, aug_pool=aug_pool)
 
     def step():
         meta.train_step(tasks, num_shots=shots, inner_batch_size=args.inner_batch, inner_iters=args.inner_iters, replacement=False,
-                        meta_step_size=0.1, meta_batch_size=world)
+                        meta_step_size=0.1, meta_batch_size=world * args.tasks_per_gpu)
 
     for _ in range(args.warmup):
         step()
@@ -231,7 +238,7 @@ def _run(args):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     imgs_per_task = ((args.inner_iters - 1) * args.inner_batch + 5) if args.foml else args.inner_iters * args.inner_batch
-    value = world * imgs_per_task * args.steps / dt
+    value = world * args.tasks_per_gpu * imgs_per_task * args.steps / dt
     loss = L.loss_value()
 
     roof = dwr = fam = None
@@ -247,7 +254,10 @@ def _run(args):
                                    "CE loss, drop-connect on%s" % ("ASPP + " if args.aspp else "", args.image_size, args.image_size, world, shots,
                                                                  args.inner_iters,
                                                                  args.inner_batch, imgs_per_task, "FOMAML(tail 5)" if args.foml else "Reptile",
-                                                                 "" if args.precision == "fp32" else ", bf16 matrix-core operands"),
+                                                                 ("" if args.precision == "fp32" else ", bf16 matrix-core operands") +
+                                                                 ((", host augmentation (aug_rate 0.5, %s)" % ("%d worker processes" % aug_pool.workers if aug_pool else "inline"))
+                                                                  if args.augment else "") +
+                                                                 (", %d tasks per GPU and meta-step" % args.tasks_per_gpu if args.tasks_per_gpu != 1 else "")),
                        "hip_graph": not args.no_graph, "final_loss": loss},
             "roofline": roof, "cpu_baseline": cpu,
         }
@@ -262,6 +272,8 @@ def _run(args):
         import torch.distributed as dist
         dist.barrier()                      # rank 0 may still be in its roofline pass
         dist.destroy_process_group()
+    if aug_pool is not None:
+        aug_pool.close()
     return out
 
 

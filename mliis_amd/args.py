@@ -102,6 +102,8 @@ _EXT = [
     ("--k-shot-test-samples", dict(type=int, default=20, help="held-out examples per task in the k-shot experiment (reference: 20)")),
     ("--skip-train-task-eval", dict(action="store_true",
                                     help="skip the evaluation pass over the meta-TRAIN tasks that the reference always runs before the test tasks")),
+    ("--augment-workers", dict(type=int, default=-1,
+                               help="worker processes for the pixel half of --augment (-1: host cores - 1, 0: inline like the reference)")),
     ("--matmul-precision", dict(choices=["fp32", "bf16"], default="fp32",
                                 help="operand precision of the matrix cores in the dense convs (bf16: fp32 tensors rounded on the fly, fp32 accumulation)")),
     ("--checkpoint-format", dict(choices=["npz", "tf"], default="npz",

@@ -18,11 +18,15 @@ The six operations and their draws (np = numpy generator, py = Python generator)
 leading operations to run with np.randint (:146-160).  Quirk kept: "left/right" translation rolls the ROW axis and paints COLUMNS,
 "up/down" rolls the column axis and paints rows (:48-81).
 
-Runs on the host (scipy rotation, a few ms per image): it throttles the GPU loop exactly as SURVEY.md 8(f)-4 predicts; an
-on-device version is future work.
+Every operation is split into a DRAW half (`plan_*`: consumes the generators, touches no pixel -- none of the reference's draws
+depends on pixel values) and a pure PIXEL half (`apply_recipe`).  `apply_augmentations` = plan + apply, so single calls behave like
+the reference's; the split is what lets a whole task's schedule be drawn sequentially (bit-identical generator consumption) while
+the pixel work -- scipy's cubic rotation is 27 ms and the noise field 7 ms per 224x224 image, 134 images/s on one core against
+2 300 images/s of the device loop -- runs on a pool of worker processes (`AugmentPool`) and overlaps the device.
 """
 from __future__ import annotations
 
+import os
 import random as _py_random
 from typing import List, Optional, Sequence, Tuple
 
@@ -35,6 +39,96 @@ BACKGROUND = (1, 0)   # one-hot mask value painted where an operation uncovers p
 # (np_augmenters.py:134,139-141): the training and the evaluation meta-learner of a process therefore share it.  Same here.
 _SHARED_ORDER = ["erase", "translate", "flip", "noise", "exposure", "rotate"]
 PRISTINE_ORDER = tuple(_SHARED_ORDER)
+
+
+# ---------------------------------------------------------------------------------------------------- pixel halves (pure functions)
+def _shift(a, shift: int, wrap, positive, along_rows: bool, colour):
+    """along_rows: roll axis 0 and paint a band of COLUMNS (the reference's 'lr'); else roll axis 1 and paint ROWS ('ud')."""
+    a = np.roll(a, shift if positive else -shift, 0 if along_rows else 1)
+    if not wrap:
+        if along_rows:
+            if positive:
+                a[:, :shift] = colour
+            else:
+                a[:, -shift:] = colour
+        else:
+            if positive:
+                a[-shift:, :] = colour
+            else:
+                a[:shift, :] = colour
+    return a
+
+
+def _apply_one(step, image, mask):
+    op = step[0]
+    if op == "noise":
+        return np.clip(image + step[1], 0.0, 255.0).astype(np.float32), mask.astype(np.float32)
+    if op == "exposure":
+        return np.clip(image + step[1], 0.0, 255.0).astype(np.float32), mask.astype(np.float32)
+    if op == "erase":
+        _, y0, x0, bh, bw, value = step
+        image[y0:y0 + bh, x0:x0 + bw, :] = value
+        mask[y0:y0 + bh, x0:x0 + bw, :] = BACKGROUND
+        return image.astype(np.float32), mask.astype(np.float32)
+    if op == "flip":
+        return np.fliplr(image).astype(np.float32), np.fliplr(mask).astype(np.float32)
+    if op == "translate":
+        _, ud, positive, shift, wrap, colour = step
+        image = _shift(image, shift, wrap, positive, not ud, colour)
+        mask = _shift(mask, shift, wrap, positive, not ud, list(BACKGROUND))
+        return image.astype(np.float32), mask.astype(np.float32)
+    if op == "rotate":
+        _, angle, mode, cval, fill = step
+        image = ndimage.rotate(image, angle=angle, reshape=False, mode=mode, cval=cval)
+        if fill is not None:
+            hole = image == -256
+            image[hole] = fill[hole]
+        mask = ndimage.rotate(mask, angle=angle, reshape=False, mode=mode, cval=-256, order=0)
+        if mode == "constant":
+            mask[mask[:, :, 0] == -256] = BACKGROUND
+        return image, mask
+    raise ValueError("unknown augmentation step {!r}".format(op))
+
+
+def apply_recipe(recipe, image, mask, as_list: bool = True):
+    """Pixel half of apply_augmentations: recipe None -> the inputs untouched (a tuple), else the steps on copies ([image, mask])."""
+    if recipe is None:
+        return image, mask
+    image, mask = image.copy(), mask.copy()
+    for step in recipe:
+        image, mask = _apply_one(step, image, mask)
+    return [image, mask] if as_list else (image, mask)
+
+
+def _apply_job(job):
+    recipe, image, mask = job
+    out = apply_recipe(recipe, image, mask)
+    return np.asarray(out[0], dtype=np.float32), np.asarray(out[1], dtype=np.float32)
+
+
+class AugmentPool:
+    """Worker processes for the pixel halves.  Forked, so create it BEFORE the process initialises the GPU (run_metasegnet.py and
+    bench.py do); the workers only ever run numpy / scipy."""
+
+    def __init__(self, workers: Optional[int] = None):
+        import multiprocessing as mp
+        if workers is None:
+            try:
+                workers = len(os.sched_getaffinity(0))
+            except AttributeError:
+                workers = os.cpu_count() or 1
+            workers = max(1, min(32, workers - 1))
+        self.workers = workers
+        self._pool = mp.get_context("fork").Pool(workers)
+
+    def map_async(self, jobs: Sequence[Tuple]):
+        """jobs: (recipe, image, mask) triples -> handle whose .get() returns the (image, mask) float32 pairs in order."""
+        jobs = list(jobs)
+        return self._pool.map_async(_apply_job, jobs, chunksize=max(1, len(jobs) // (4 * self.workers)))
+
+    def close(self):
+        self._pool.terminate()
+        self._pool.join()
 
 
 class Augmenter:
@@ -51,87 +145,79 @@ class Augmenter:
         if verbose:
             print("Initialized image segmentation augmenter.")
 
-    # ------------------------------------------------------------------------------------------------ operations
-    def noise(self, image, mask, mean_sd: float = 5.1):
+    # ------------------------------------------------------------------------------------------------ draw halves
+    def plan_noise(self, shape, mean_sd: float = 5.1):
         sd = np.abs(self.npr.normal(mean_sd, 1, 1))
-        field = self.npr.normal(0, sd, image.shape)
-        return np.clip(image + field, 0.0, 255.0).astype(np.float32), mask.astype(np.float32)
+        return ("noise", self.npr.normal(0, sd, shape))
 
-    def exposure(self, image, mask, mean_sd: float = 12.75):
+    def plan_exposure(self, shape, mean_sd: float = 12.75):
         sd = np.abs(self.npr.normal(mean_sd, 1, 1))
-        offset = self.npr.normal(0, sd, 1)
-        return np.clip(image + offset, 0.0, 255.0).astype(np.float32), mask.astype(np.float32)
+        return ("exposure", self.npr.normal(0, sd, 1))
 
-    def erase(self, image, mask, area=(0.02, 0.10), aspect=(0.3, 1 / 0.3), grey=(0, 255)):
-        rows, cols = image.shape[:2]
+    def plan_erase(self, shape, area=(0.02, 0.10), aspect=(0.3, 1 / 0.3), grey=(0, 255)):
+        rows, cols = shape[:2]
         a = self.npr.uniform(area[0], area[1]) * rows * cols
         r = self.npr.uniform(aspect[0], aspect[1])
         bw, bh = int(np.sqrt(a / r)), int(np.sqrt(a * r))
         y0 = self.npr.randint(0, rows)
         x0 = self.npr.randint(0, cols)
-        value = self.npr.uniform(grey[0], grey[1])
-        image[y0:y0 + bh, x0:x0 + bw, :] = value
-        mask[y0:y0 + bh, x0:x0 + bw, :] = BACKGROUND
-        return image.astype(np.float32), mask.astype(np.float32)
+        return ("erase", y0, x0, bh, bw, self.npr.uniform(grey[0], grey[1]))
 
-    @staticmethod
-    def flip(image, mask):
-        return np.fliplr(image).astype(np.float32), np.fliplr(mask).astype(np.float32)
+    def plan_flip(self, shape):
+        return ("flip",)
 
-    def _shift(self, a, shift: int, wrap, positive, along_rows: bool, fill: Optional[Sequence[float]]):
-        """along_rows: roll axis 0 and paint a band of COLUMNS (the reference's 'lr'); else roll axis 1 and paint ROWS ('ud')."""
-        a = np.roll(a, shift if positive else -shift, 0 if along_rows else 1)
-        if not wrap:
-            colour = fill if fill is not None else self.npr.uniform(0, 255, a.shape[2])
-            if along_rows:
-                if positive:
-                    a[:, :shift] = colour
-                else:
-                    a[:, -shift:] = colour
-            else:
-                if positive:
-                    a[-shift:, :] = colour
-                else:
-                    a[:shift, :] = colour
-        return a
-
-    def translate(self, image, mask, max_shift: int = 23):
+    def plan_translate(self, shape, max_shift: int = 23):
         ud = self.py.getrandbits(1)
         positive = self.py.getrandbits(1)
         shift = self.npr.randint(1, max_shift + 1, 1)[0]
         wrap = self.py.getrandbits(1)
-        image = self._shift(image, shift, wrap, positive, not ud, None)
-        mask = self._shift(mask, shift, wrap, positive, not ud, list(BACKGROUND))
-        return image.astype(np.float32), mask.astype(np.float32)
+        colour = None if wrap else self.npr.uniform(0, 255, shape[2])
+        return ("translate", ud, positive, shift, wrap, colour)
 
-    def rotate(self, image, mask, max_angle: int = 45):
+    def plan_rotate(self, shape, max_angle: int = 45):
         angle = self.npr.randint(-max_angle, max_angle)
         mode = self.py.sample(["reflect", "constant", "mirror", "wrap"], 1)[0]
-        noise_fill, cval = False, 0
+        cval, fill = 0, None
         if mode == "constant":
             if self.py.getrandbits(1):
-                cval, noise_fill = -256, True
+                cval, fill = -256, self.npr.randint(0, 256, size=shape)
             else:
                 cval = self.npr.randint(0, 256)
-        image = ndimage.rotate(image, angle=angle, reshape=False, mode=mode, cval=cval)
-        if noise_fill:
-            hole = image == -256
-            image[hole] = self.npr.randint(0, 256, size=image.shape)[hole]
-        mask = ndimage.rotate(mask, angle=angle, reshape=False, mode=mode, cval=-256, order=0)
-        if mode == "constant":
-            mask[mask[:, :, 0] == -256] = BACKGROUND
-        return image, mask
+        return ("rotate", angle, mode, cval, fill)
 
-    # ------------------------------------------------------------------------------------------------ driver
+    def plan(self, shape, prob_to_return_original: Optional[float] = 0.0):
+        """Draw half of apply_augmentations for an image of `shape`: None (keep the original) or the list of steps."""
+        keep = self.default_keep_probability if prob_to_return_original is None else prob_to_return_original
+        if self.npr.rand() <= keep:
+            return None
+        self.py.shuffle(self.order)
+        count = self.npr.randint(1, len(self.order) + 1)
+        return [getattr(self, "plan_" + name)(shape) for name in self.order[:count]]
+
+    # ------------------------------------------------------------------------------------------------ reference call surface
+    def _single(self, name, image, mask):
+        return _apply_one(getattr(self, "plan_" + name)(image.shape), image, mask)
+
+    def noise(self, image, mask):
+        return self._single("noise", image, mask)
+
+    def exposure(self, image, mask):
+        return self._single("exposure", image, mask)
+
+    def erase(self, image, mask):
+        return self._single("erase", image, mask)
+
+    @staticmethod
+    def flip(image, mask):
+        return _apply_one(("flip",), image, mask)
+
+    def translate(self, image, mask):
+        return self._single("translate", image, mask)
+
+    def rotate(self, image, mask):
+        return self._single("rotate", image, mask)
+
     def apply_augmentations(self, image, mask, prob_to_return_original: Optional[float] = 0.0, return_image_mask_in_list: bool = True):
         """With probability `prob_to_return_original` (None -> 1/7) the inputs come back untouched (as a tuple); otherwise a random
         number of the shuffled operations is applied to copies and [image, mask] (a list, like the reference) is returned."""
-        keep = self.default_keep_probability if prob_to_return_original is None else prob_to_return_original
-        if self.npr.rand() <= keep:
-            return image, mask
-        image, mask = image.copy(), mask.copy()
-        self.py.shuffle(self.order)
-        count = self.npr.randint(1, len(self.order) + 1)
-        for name in self.order[:count]:
-            image, mask = getattr(self, name)(image, mask)
-        return [image, mask] if return_image_mask_in_list else (image, mask)
+        return apply_recipe(self.plan(image.shape, prob_to_return_original), image, mask, return_image_mask_in_list)

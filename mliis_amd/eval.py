@@ -17,13 +17,13 @@ from .reptile import Gecko
 def evaluate_gecko(learner, dataset, num_classes=1, num_shots=5, eval_inner_batch_size=5, eval_inner_iters=50, replacement=False,
                    num_samples=100, transductive=False, weight_decay_rate=1, meta_fn=Gecko, visualize_predicted_segmentations=False,
                    save_fine_tuned_checkpoints=False, save_fine_tuned_checkpoints_dir: Optional[str] = None, lr_scheduler=None, lr=None,
-                   augment=False, serially_eval_all_tasks: bool = False, aug_rate: Optional[float] = None,
+                   augment=False, serially_eval_all_tasks: bool = False, aug_rate: Optional[float] = None, aug_pool=None,
                    **_ignored) -> Tuple[float, Dict[str, List[float]]]:
     print("Evaluating with eval_inner_iters: {}".format(eval_inner_iters))
     print("Evaluating with lr: {}".format(lr))
     pre_step_op = weight_decay_rate if weight_decay_rate != 1 else None
     gecko = meta_fn(learner, transductive=transductive, pre_step_op=pre_step_op, lr_scheduler=lr_scheduler, augment=augment,
-                    aug_rate=aug_rate, rng_mode="reference", dist=_Single())
+                    aug_rate=aug_rate, rng_mode="reference", dist=_Single(), aug_pool=aug_pool)
     mean_ious, task_iou_map = [], {}
     for i in range(num_samples):
         mean_iou, m = gecko.evaluate(dataset, num_classes=num_classes, num_shots=num_shots, inner_batch_size=eval_inner_batch_size,
@@ -66,7 +66,8 @@ def optimize_update_hyperparams(learner, dataset, num_classes=1, num_shots=5, ev
                                 serially_eval_all_tasks: bool = True, min_steps: int = 0, max_steps: int = 80, num_configs_to_sample=100,
                                 num_train_val_data_splits_to_sample_per_config=1, save_dir: Optional[str] = None,
                                 results_csv_name: str = "GP_val-set_hyper_param_search_results.csv",
-                                eval_tasks_with_median_early_stopping_iterations: bool = False, estimator: str = "GP", **_ignored):
+                                eval_tasks_with_median_early_stopping_iterations: bool = False, estimator: str = "GP", aug_pool=None,
+                                **_ignored):
     """Update-hyperparameter optimisation on a set of (validation) tasks -- eval.py:93-182: every sampled configuration
     (lr, drop rate, aug rate, inner batch size) is scored by Gecko.evaluate_with_early_stopping over the tasks; returns
     (best lr, expected best number of fine-tuning steps) and writes `<save_dir>/<results_csv_name>_<shots>-shot.csv`.
@@ -80,7 +81,7 @@ def optimize_update_hyperparams(learner, dataset, num_classes=1, num_shots=5, ev
         print("Saving fine-tuned checkpoints to {}".format(save_fine_tuned_checkpoints_dir))
     pre_step_op = weight_decay_rate if weight_decay_rate != 1 else None
     gecko = meta_fn(learner, transductive=transductive, pre_step_op=pre_step_op, lr_scheduler=lr_scheduler, augment=augment,
-                    rng_mode="reference", dist=_Single())
+                    rng_mode="reference", dist=_Single(), aug_pool=aug_pool)
     params = {"dataset": dataset, "num_classes": num_classes, "num_shots": num_shots, "inner_batch_size": eval_inner_batch_size,
               "replacement": replacement, "eval_all_tasks": serially_eval_all_tasks, hs.LEARNING_RATE_NAME: lr, hs.DROPOUT_RATE_NAME: drop_rate,
               hs.AUG_RATE_NAME: aug_rate, "eval_tasks_with_median_early_stopping_iterations": eval_tasks_with_median_early_stopping_iterations,
@@ -108,7 +109,7 @@ def run_k_shot_learning_curves_experiment(learner, dataset, num_classes=1, num_s
                                           replacement=False, num_samples=100, transductive=True, weight_decay_rate=1, meta_fn=Gecko,
                                           lr_scheduler=None, lr=None, augment=True, aug_rate: float = 0.5,
                                           csv_outpath: Optional[str] = "k-shot-results.csv", iter_range=None, k_range=None,
-                                          test_samples: int = 20, **_ignored):
+                                          test_samples: int = 20, aug_pool=None, **_ignored):
     """k-shot learning curves (eval.py:187-241): `num_samples` repetitions per task of Gecko.evaluate_k_shot_range over
     k = 1, 5, 10, 50, 100, 200, 400; the (k, mIoU) table goes to `csv_outpath` (the reference ends by rewriting the file with the
     current table only, so that is what is written).  `k_range` / `test_samples` are extensions for smaller tasks."""
@@ -119,7 +120,7 @@ def run_k_shot_learning_curves_experiment(learner, dataset, num_classes=1, num_s
         iter_range = DEFAULT_ITER_RANGE[:len(k_range)]
     print("Using iter range {}".format(iter_range))
     gecko = meta_fn(learner, transductive=transductive, pre_step_op=weight_decay_rate, lr_scheduler=lr_scheduler, augment=augment,
-                    aug_rate=aug_rate, rng_mode="reference", dist=_Single())
+                    aug_rate=aug_rate, rng_mode="reference", dist=_Single(), aug_pool=aug_pool)
     ks, results = gecko.evaluate_m_k_shot_ranges_all_tasks(tasks=dataset, k_range=k_range, m=num_samples, inner_batch_size=eval_inner_batch_size,
                                                            inner_iters=eval_inner_iters, replacement=replacement, lr=lr, test_samples=test_samples,
                                                            iter_range=iter_range, aug_rate=aug_rate)

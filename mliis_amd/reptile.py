@@ -65,7 +65,8 @@ class Gecko:
     meta_fn = "Reptile"
 
     def __init__(self, learner, variables=None, transductive: bool = False, pre_step_op=None, lr_scheduler=None, augment: bool = False,
-                 aug_rate: Optional[float] = None, dist: Optional[Dist] = None, rng_mode: Optional[str] = None, seed: int = 0):
+                 aug_rate: Optional[float] = None, dist: Optional[Dist] = None, rng_mode: Optional[str] = None, seed: int = 0,
+                 aug_pool=None):
         self.learner = learner
         self._transductive = transductive
         # pre_step_op: the reference passes a TF op that multiplies all trainables by `weight_decay_rate`
@@ -78,7 +79,9 @@ class Gecko:
         self.rng_mode = rng_mode or ("reference" if self.dist.world == 1 else "per_task")
         # host augmentation of the inner-loop batches (reptile.py:44-49, augmenters/np_augmenters.py).  rng_mode "reference": the
         # global `random` / `numpy.random` streams, like the reference; "per_task": private streams re-seeded per (meta-iter, task).
+        # aug_pool (augment.AugmentPool, optional): worker processes for the pixel half of the augmentation; the draws stay here.
         self.augmenter = None
+        self.aug_pool = aug_pool
         if augment:
             from .augment import Augmenter
             self.augmenter = Augmenter()
@@ -107,15 +110,18 @@ class Gecko:
 
     _train_aug_rate_from_self = False   # Reptile's train_step does not forward aug_rate to _mini_batches (reptile.py:108); FOMAML does
 
-    def _augmented_task_batches(self, inner_batch_size, inner_iters, replacement, rng, task_idx):
+    def _augmented_task_schedule(self, inner_batch_size, inner_iters, replacement, rng, task_idx):
+        """Draws one task's augmented inner-loop schedule (all generator consumption happens here, in the reference's order) and hands
+        the pixel work to the pool, if there is one."""
         if rng is not None:   # per-task mode: private, reproducible streams for the augmenter as well
             import numpy as np
             self.augmenter.py = rng
             self.augmenter.npr = np.random.RandomState(_task_rng(self.seed, self.meta_iter, task_idx).getrandbits(32))
         x, y = self._host_task
-        return metaseg.augmented_batches(x, y, inner_batch_size, inner_iters, replacement, self.augmenter,
-                                         self.aug_rate if self._train_aug_rate_from_self else None, rng,
-                                         tail_shots=getattr(self, "tail_shots", None), fomaml=self._train_aug_rate_from_self)
+        sched = metaseg.AugmentedSchedule(x, y, inner_batch_size, inner_iters, replacement, self.augmenter,
+                                          self.aug_rate if self._train_aug_rate_from_self else None, rng,
+                                          tail_shots=getattr(self, "tail_shots", None), fomaml=self._train_aug_rate_from_self)
+        return sched.submit(self.aug_pool) if self.aug_pool is not None else sched
 
     def _run_meta_batch(self, dataset, num_shots, inner_batch_size, inner_iters, replacement, meta_step_size, meta_batch_size, lr,
                         fomaml: bool):
@@ -132,15 +138,23 @@ class Gecko:
             delta, bn_acc = comm[:nt], comm[nt:]
             decay = BN_MOMENTUM
             T = inner_iters
-            for t in range(meta_batch_size):
-                rng = self._rng(t)
-                if self.rng_mode != "reference" and t % D.world != D.rank:
-                    continue
-                n_shots = self._sample(dataset, num_shots, rng)
+            # With augmentation every task of the meta-batch is sampled and its schedule DRAWN up front (same generator order as
+            # task-by-task, since the inner steps consume no host randomness); the pixel work of later tasks then runs on the worker
+            # pool while the device trains on the earlier ones.
+            mine = [t for t in range(meta_batch_size) if self.rng_mode == "reference" or t % D.world == D.rank]
+            ahead = {}
+            if self.augmenter is not None:
+                for t in mine:
+                    rng = self._rng(t)
+                    self._sample(dataset, num_shots, rng)
+                    ahead[t] = self._augmented_task_schedule(inner_batch_size, inner_iters, replacement, rng, t)
+            for t in mine:
                 if self.augmenter is None:
+                    rng = self._rng(t)
+                    n_shots = self._sample(dataset, num_shots, rng)
                     batches = self._task_batches(n_shots, inner_batch_size, inner_iters, replacement, rng)
                 else:
-                    batches = self._augmented_task_batches(inner_batch_size, inner_iters, replacement, rng, t)
+                    batches = ahead.pop(t).batches()
                 L.import_bn(self._bn_zero)
                 last_backup = None
                 for j, idx in enumerate(batches):
@@ -245,7 +259,7 @@ class Gecko:
                 raise ValueError("_evaluate with augmentation needs the task's images")
             x, y = _to_numpy(images), _to_numpy(labels)
             schedule = metaseg.augmented_batches(x[train_idx], y[train_idx], inner_batch_size, inner_iters, replacement, self.augmenter,
-                                                 aug_rate)
+                                                 aug_rate, pool=self.aug_pool)
         for inner_iter, b in enumerate(schedule):
             if self.augmenter is None:
                 idx = [train_idx[i] for i in b]
@@ -290,8 +304,8 @@ class Gecko:
             if images is None:
                 raise ValueError("_early_stopping_learn with augmentation needs the task's images")
             x = _to_numpy(images)
-            schedule = metaseg.augmented_batches(x[train_idx], lab[train_idx], inner_batch_size, max_steps, replacement, self.augmenter,
-                                                 aug_rate)
+            schedule = metaseg.lazy_augmented_batches(x[train_idx], lab[train_idx], inner_batch_size, max_steps, replacement,
+                                                      self.augmenter, aug_rate)   # lazy: the loop may stop early
         for inner_iter, b in enumerate(schedule):
             if self.augmenter is None:
                 idx = [train_idx[i] for i in b]

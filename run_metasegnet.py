@@ -65,13 +65,14 @@ def _validate_datasets(args, train_set, val_set, test_set):
         raise ValueError("Val set has no tasks to evaluate")
 
 
-def _evaluate(args, learner, lr_scheduler, train_set, val_set, test_set):
+def _evaluate(args, learner, lr_scheduler, train_set, val_set, test_set, aug_pool=None):
     """The evaluation half of the reference's main (run_metasegnet.py:135-206), on rank 0."""
     import copy
     from mliis_amd.eval import evaluate_gecko, optimize_update_hyperparams, run_k_shot_learning_curves_experiment
     from mliis_amd.reptile import Dist
     from mliis_amd.train import train_gecko
     ek = evaluate_kwargs(args)
+    ek["aug_pool"] = aug_pool
     os.makedirs(args.checkpoint, exist_ok=True)
     if args.optimize_update_hyperparms_on_val_set:
         print("Optimizing the update routine hyperparams on the val set")
@@ -95,7 +96,7 @@ def _evaluate(args, learner, lr_scheduler, train_set, val_set, test_set):
             tp["meta_step_size"] = tp["meta_step_size_final"]
             train_gecko(learner, list(train_set) + list(val_set), test_set,
                         os.path.join(args.checkpoint, "fine-tuned_on_train_val_with_optimized_update_hyperparams"), lr_scheduler=lr_scheduler,
-                        augment=args.augment, dist=Dist(), seed=args.seed, checkpoint_format=args.checkpoint_format, **tp)
+                        augment=args.augment, dist=Dist(), seed=args.seed, checkpoint_format=args.checkpoint_format, aug_pool=aug_pool, **tp)
     del ek["eval_tasks_with_median_early_stopping_iterations"]
     if args.run_k_shot_learning_curves_experiment:
         kk = copy.copy(ek)
@@ -135,6 +136,11 @@ def main():
     print("Experiment started at: {}".format(start))
     args = argument_parser().parse_args()
     random.seed(args.seed)
+    aug_pool = None
+    if args.augment and args.augment_workers != 0:   # forked workers: created before anything initialises the GPU
+        from mliis_amd.augment import AugmentPool
+        aug_pool = AugmentPool(None if args.augment_workers < 0 else args.augment_workers)
+        print("Augmentation pixel work on {} worker processes.".format(aug_pool.workers))
     world, rank, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         import torch.distributed as dist
@@ -165,7 +171,7 @@ def main():
             print("Continuing meta-training from checkpoint: {}".format(path))
             learner.load_named(ckpt.load(path))
         train_gecko(learner, train_set, val_set or test_set, args.checkpoint, lr_scheduler=lr_scheduler, augment=args.augment, dist=Dist(),
-                    seed=args.seed, checkpoint_format=args.checkpoint_format, **train_kwargs(args))
+                    seed=args.seed, checkpoint_format=args.checkpoint_format, aug_pool=aug_pool, **train_kwargs(args))
     else:
         path = ckpt.latest_checkpoint(args.checkpoint)
         print("Restoring from checkpoint: {}".format(path))
@@ -175,7 +181,9 @@ def main():
             learner.load_named(ckpt.load(path))
 
     if rank == 0:
-        _evaluate(args, learner, lr_scheduler, train_set, val_set, test_set)
+        _evaluate(args, learner, lr_scheduler, train_set, val_set, test_set, aug_pool)
+    if aug_pool is not None:
+        aug_pool.close()
     if world > 1:
         import torch.distributed as dist
         dist.barrier()

@@ -109,3 +109,38 @@ def test_mini_batches_with_augmentation_match_the_reference_schedule(gold, tag, 
     for bi, (xb, yb) in enumerate(metaseg.augmented_batches(x, y, 4, 4, repl, Augmenter(verbose=False), 0.5)):
         _same(xb, gold["mb_%s_%d_images" % (tag, bi)], "array form batch %d" % bi)
         _same(yb, gold["mb_%s_%d_masks" % (tag, bi)], "array form batch %d masks" % bi)
+
+
+def test_pooled_schedule_is_bit_identical_to_the_inline_one():
+    """AugmentedSchedule draws first and defers the pixels: on an AugmentPool (forked workers) the batches -- Reptile and FOMAML
+    flavours -- equal the inline ones bit for bit, and the lazy generator (early-stopping loops) produces the same batches too."""
+    import random
+    from mliis_amd import augment, metaseg
+    x, y = metaseg.synthetic_task(6, 48, seed=3, block=4)
+    pool = augment.AugmentPool(2)
+    try:
+        for fomaml in (False, True):
+            outs = []
+            for mode in ("inline", "pool", "lazy"):
+                augment._SHARED_ORDER[:] = augment.PRISTINE_ORDER
+                random.seed(11)
+                np.random.seed(12)
+                A = augment.Augmenter(verbose=False)
+                if mode == "lazy":
+                    if fomaml:
+                        continue
+                    outs.append(list(metaseg.lazy_augmented_batches(x, y, 4, 5, False, A, 0.5)))
+                else:
+                    outs.append(list(metaseg.augmented_batches(x, y, 4, 5, False, A, 0.5, tail_shots=2 if fomaml else None, fomaml=fomaml,
+                                                               pool=pool if mode == "pool" else None)))
+                tail_state = (random.getstate(), np.random.get_state()[1][:8].tolist())
+                outs[-1] = (outs[-1], tail_state)
+            ref = outs[0]
+            for other in outs[1:]:
+                assert len(other[0]) == len(ref[0]) == 5
+                for (ax, ay), (bx, by) in zip(ref[0], other[0]):
+                    assert ax.dtype == bx.dtype == np.float32 and np.array_equal(ax, bx) and np.array_equal(ay, by)
+                assert other[1] == ref[1]                       # the generators end in the same state
+            assert any(not np.array_equal(b[0][i], x[j]) for b in ref[0][:4] for i in range(len(b[0])) for j in range(6))   # something was augmented
+    finally:
+        pool.close()
