@@ -21,7 +21,6 @@ Graph semantics restated from: models/efficientlab.py:111-119,126-231,294-317; m
 from __future__ import annotations
 
 import ctypes as C
-import os
 from typing import Dict, List, Optional, Sequence
 
 import numpy as np
@@ -164,7 +163,8 @@ class Learner:
                  learning_rate: float = 1e-3, optimizer: str = "sgd", l2: bool = False, l1: bool = False, darc1: bool = False,
                  dice: bool = False, label_smoothing: float = 0.0, final_layer_dropout_rate: float = 0.0,
                  spatial_pyramid_pooling: bool = False, skip_decoding: bool = False, drop_connect: bool = True, seed: int = 0,
-                 device="cuda:0", use_graph: bool = True, max_shots: int = 16, matmul_precision: str = "fp32"):
+                 device="cuda:0", use_graph: bool = True, max_shots: int = 16, matmul_precision: str = "fp32",
+                 overlap_wgrad: int = 0, wgrad_flush_before: Sequence[int] = (5,)):
         if skip_decoding:
             raise NotImplementedError("the DeepLabv3+ --skip_decoding decoder is not built (not part of EfficientLab-6-3; SURVEY.md 8(a) a18)")
         if l1 or darc1:
@@ -189,11 +189,11 @@ class Learner:
         self.drop_connect = drop_connect
         self.use_graph = use_graph
         self.stream = torch.cuda.Stream(device=self.device)
-        # Optional (MLIIS_OVERLAP_WGRAD = 1 | 2): weight-gradient GEMMs on a second stream forked inside the HIP graph, one by one (1) or
-        # handed over at a few points of the backward pass (2, MLIIS_WGRAD_FLUSH = block indices).  Neither beats the single stream
+        # Optional (overlap_wgrad = 1 | 2): weight-gradient GEMMs on a second stream forked inside the HIP graph, one by one (1) or
+        # handed over at a few points of the backward pass (2, wgrad_flush_before = block indices).  Neither beats the single stream
         # on MI355X (profiles/r01_notes.md), so it is off by default.
-        self.overlap_wgrad = int(os.environ.get("MLIIS_OVERLAP_WGRAD", "0"))
-        self.wgrad_flush_before = set(int(v) for v in os.environ.get("MLIIS_WGRAD_FLUSH", "5").split(",") if v.strip().isdigit())
+        self.overlap_wgrad = int(overlap_wgrad)
+        self.wgrad_flush_before = set(int(v) for v in wgrad_flush_before)
         self.side_stream = torch.cuda.Stream(device=self.device)
         self.arena = Arena(self.arch, self.device)
         self.arena.init_weights(seed)
