@@ -674,6 +674,7 @@ class Learner:
         if max(batch_idx) >= self.n_shots or min(batch_idx) < 0:
             raise ValueError("batch index out of range of the resident task ({} shots)".format(self.n_shots))
         P = self._plan(N)
+        ops.set_matmul_precision(self.matmul_precision)   # the library switch is process-wide: re-assert this learner's choice
         with torch.cuda.stream(self.stream):
             P.idx.copy_(torch.tensor(list(batch_idx), dtype=torch.int32), non_blocking=True)
             self.lr_dev.fill_(self.lr if lr is None else float(lr))
@@ -737,6 +738,7 @@ class Learner:
         images = torch.as_tensor(images)
         N = images.shape[0]
         P = self._plan(N)
+        ops.set_matmul_precision(self.matmul_precision)
         with torch.cuda.stream(self.stream):
             x = images.to(device=self.device, dtype=torch.float32).contiguous()
             logits = self._forward(P, x, None, training)
