@@ -182,6 +182,114 @@ __global__ __launch_bounds__(256) void dwconv_fwd_stats_k(const float* __restric
   }
 }
 
+// 5x5 layers through an LDS tile.  The sliding-window kernels above fetch every input element K times per strip (10 window loads per
+// output for K = 5: 23-42 % of the HBM roofline even on large launches); here a block stages the (TOH*S + K - S) x (TOW*S + K - S)
+// input window of TOH x TOW outputs for 32 channels in LDS once (raw buffer loads, out-of-image pixels come back as zeros) and every
+// output reads its K*K taps from there (ds_read_b128, 8 channel quads x 8 pixels per wave = contiguous 1 KB, conflict-free) against
+// filter taps.  256 threads = 8 channel quads x 32 pixel lanes.  FLIP: taps reversed = backward-data (a stride-1 correlation with the
+// rotated filter); DIL with it: over the zero-interleaved gradient of a stride-2 layer (75 % of the taps then multiply zeros, which
+// is still 2.4x faster than the gather kernel: the launch is latency-bound, not FMA-bound).  STATS: also emits the following batch norm's stage-1 statistics [block][2][C].
+typedef unsigned dw_u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned kDwOob = 0xFFFFFFF0u;
+
+template <int K, int S, int TOH, int TOW, int TS, bool FLIP, bool STATS, bool DIL>
+__global__ __launch_bounds__(256) void dwconv_tile_k(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y,
+                                                     int Hi, int Wi, int Ho, int Wo, int C, int pt, int pl, int tiles_y, int tiles_x,
+                                                     float* __restrict__ stats_part) {
+  // every thread produces a strip of TS outputs along W from a sliding (TS-1)*S+K wide register window: K*((TS-1)*S+K)/TS LDS reads per
+  // output instead of K*K (10 instead of 25 for K = 5, TS = 4 at stride 1 -- the LDS port is the bottleneck otherwise)
+  constexpr int IH = (TOH - 1) * S + K, IW = (TOW - 1) * S + K, NPIX = IH * IW;
+  constexpr int SPR = TOW / TS, NITEM = TOH * SPR;            // strips per row, strips per tile
+  constexpr int LD_PER = (NPIX + 31) / 32, IT_PER = (NITEM + 31) / 32, WW = (TS - 1) * S + K;
+  static_assert(TOW % TS == 0, "tile width must be a multiple of the strip");
+  __shared__ float4 sm[NPIX * 8];
+  __shared__ float4 red[2][4][8];
+  const int t = threadIdx.x, q = t & 7, lane_p = t >> 3;
+  const unsigned bx = blockIdx.x;
+  const int tx = (int)(bx % (unsigned)tiles_x);
+  const unsigned r = bx / (unsigned)tiles_x;
+  const int ty = (int)(r % (unsigned)tiles_y), n = (int)(r / (unsigned)tiles_y);
+  const int c = blockIdx.y * 32 + q * 4;
+  const bool cok = c < C;
+  const int oy0 = ty * TOH, ox0 = tx * TOW;
+  const int hi0 = oy0 * S - pt, wi0 = ox0 * S - pl;
+  const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, 0x80000000u, 0x00020000);
+  float4 v[LD_PER];
+#pragma unroll
+  for (int i = 0; i < LD_PER; ++i) {
+    const int idx = lane_p + 32 * i;
+    const int iy = idx / IW, ix = idx - iy * IW;
+    int hi = hi0 + iy, wi = wi0 + ix;
+    bool ok = cok & (idx < NPIX);
+    if (DIL) {   // the input is read as if a zero row / column stood between its pixels (backward-data of a stride-2 layer)
+      ok &= ((hi | wi) & 1) == 0;
+      hi >>= 1;
+      wi >>= 1;
+    }
+    ok &= ((unsigned)hi < (unsigned)Hi) & ((unsigned)wi < (unsigned)Wi);
+    const unsigned off = (unsigned)((((n * Hi + hi) * Wi + wi) * C + c) * 4);   // host guarantees the tensor is below 2 GiB
+    const dw_u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(rX, (int)(ok ? off : kDwOob), 0, 0);
+    v[i] = make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
+  }
+  const float* wc = w + (cok ? c : 0);
+#pragma unroll
+  for (int i = 0; i < LD_PER; ++i) {
+    const int idx = lane_p + 32 * i;
+    if (idx < NPIX) sm[idx * 8 + q] = v[i];
+  }
+  __syncthreads();
+  float4 s1 = f4zero(), s2 = f4zero();
+#pragma unroll
+  for (int i = 0; i < IT_PER; ++i) {
+    const int item = lane_p + 32 * i;
+    const int it = item < NITEM ? item : 0;
+    const int oy = it / SPR, ox = (it - oy * SPR) * TS;
+    const float4* base = sm + ((oy * S) * IW + ox * S) * 8 + q;
+    float4 acc[TS];
+#pragma unroll
+    for (int j = 0; j < TS; ++j) acc[j] = f4zero();
+#pragma unroll 1   // (fully unrolled the compiler hoists all K*WW window reads: 260 VGPRs, one wave per SIMD)
+    for (int ky = 0; ky < K; ++ky) {
+      float4 in[WW], wr[K];   // one filter row at a time (L1-resident): all K*K taps in registers cost 100 VGPRs and the occupancy
+#pragma unroll
+      for (int kx = 0; kx < K; ++kx) wr[kx] = ld4(wc + (FLIP ? K * K - 1 - (ky * K + kx) : ky * K + kx) * C);
+#pragma unroll
+      for (int j = 0; j < WW; ++j) in[j] = base[(ky * IW + j) * 8];
+#pragma unroll
+      for (int kx = 0; kx < K; ++kx)
+#pragma unroll
+        for (int j = 0; j < TS; ++j) acc[j] = f4fma(in[j * S + kx], wr[kx], acc[j]);
+    }
+    const bool rok = cok && item < NITEM && oy0 + oy < Ho;
+#pragma unroll
+    for (int j = 0; j < TS; ++j)
+      if (rok && ox0 + ox + j < Wo) {
+        st4(y + ((long long)((n * Ho + oy0 + oy) * Wo + ox0 + ox + j)) * C + c, acc[j]);
+        if (STATS) {
+          s1 = f4add(s1, acc[j]);
+          s2 = f4fma(acc[j], acc[j], s2);
+        }
+      }
+  }
+  if (!STATS) return;
+#pragma unroll
+  for (int off = 8; off < 64; off <<= 1) {
+    s1.x += __shfl_xor(s1.x, off); s1.y += __shfl_xor(s1.y, off); s1.z += __shfl_xor(s1.z, off); s1.w += __shfl_xor(s1.w, off);
+    s2.x += __shfl_xor(s2.x, off); s2.y += __shfl_xor(s2.y, off); s2.z += __shfl_xor(s2.z, off); s2.w += __shfl_xor(s2.w, off);
+  }
+  if ((t & 63) < 8) {
+    red[0][t >> 6][q] = s1;
+    red[1][t >> 6][q] = s2;
+  }
+  __syncthreads();
+  if (t < 16) {
+    const int vv = t >> 3, qq = t & 7;
+    const int cc = blockIdx.y * 32 + qq * 4;
+    if (cc < C)
+      st4(stats_part + ((long long)bx * 2 + vv) * C + cc, f4add(f4add(red[vv][0][qq], red[vv][1][qq]), f4add(red[vv][2][qq], red[vv][3][qq])));
+  }
+}
+
 // dx[n,hi,wi,c] = sum_{ky,kx : (hi+pt-ky) % S == 0, (wi+pl-kx) % S == 0} dy[n,(hi+pt-ky)/S,(wi+pl-kx)/S,c] * w[ky,kx,c]
 template <int K, int S, int TW>
 __global__ __launch_bounds__(256) void dwconv_bwd_data_k(const float* __restrict__ dy, const float* __restrict__ w,
@@ -371,6 +479,32 @@ static inline DwFilterGeom dw_filter_geom(int N, int Ho, int Wo, int C, int TW) 
   return g;
 }
 
+// LDS-tile kernel geometry for the 5x5 layers (dwconv_tile_k): 7 x 16 output tiles in strips of 4 at stride 1, 7 x 7 singles at stride 2
+struct DwTile {
+  int toh, tow, tiles_y, tiles_x;
+  long long blocks;
+};
+static inline DwTile dw_tile(int N, int Ho, int Wo, int stride) {
+  DwTile d;
+  d.toh = 7;
+  d.tow = stride == 1 ? 16 : 7;
+  d.tiles_y = ceil_div(Ho, d.toh);
+  d.tiles_x = ceil_div(Wo, d.tow);
+  d.blocks = (long long)N * d.tiles_y * d.tiles_x;
+  return d;
+}
+template <bool FLIP, bool STATS, bool DIL = false>
+static void launch_dw_tile(const DwTile& d, int stride, int C, const float* x, const float* w, float* y, int Hi, int Wi, int Ho, int Wo, int pt,
+                           int pl, float* stats_part, hipStream_t stream) {
+  dim3 grid((unsigned)d.blocks, ceil_div(C, 32));
+  if (stride == 1)
+    hipLaunchKernelGGL((dwconv_tile_k<5, 1, 7, 16, 4, FLIP, STATS, DIL>), grid, dim3(256), 0, stream, x, w, y, Hi, Wi, Ho, Wo, C, pt, pl, d.tiles_y,
+                       d.tiles_x, stats_part);
+  else
+    hipLaunchKernelGGL((dwconv_tile_k<5, 2, 7, 7, 1, FLIP, STATS, false>), grid, dim3(256), 0, stream, x, w, y, Hi, Wi, Ho, Wo, C, pt, pl, d.tiles_y,
+                       d.tiles_x, stats_part);
+}
+
 constexpr int kTW = 4;
 
 }  // namespace mliis
@@ -405,11 +539,21 @@ int mliis_dwconv_fwd(const float* x, const float* w, float* y, int N, int H, int
   const long long strips = (long long)N * g.Ho * ((g.Wo + kTW - 1) / kTW);
   long long total = strips * (C / 4);
   MLIIS_REQUIRE(total < (1LL << 31), MLIIS_ERR_UNSUPPORTED, "dwconv_fwd: tensor too large for 32-bit indexing");
+  // 5x5 layers: LDS-tile kernel (tensors below 2 GiB: 32-bit buffer offsets; with statistics only while its block count fits the
+  // documented statistics buffer)
+  const DwTile tile = dw_tile(N, g.Ho, g.Wo, stride);
+  const bool tiled = k == 5 && (long long)N * H * W * C * 4 < (1LL << 31) && tile.blocks < (1LL << 31);
   if (stats_part != nullptr) {   // training: the following batch norm's stage-1 statistics come out of the same launch
     MLIIS_REQUIRE(stats_nblk && aligned16(stats_part), MLIIS_ERR_ARG, "dwconv_fwd: statistics need a 16-byte aligned buffer and a stats_nblk output");
     const int nblk = (int)((strips + 31) / 32);
     MLIIS_REQUIRE((size_t)nblk * 2 * C <= stats_floats, MLIIS_ERR_WORKSPACE, "dwconv_fwd: statistics buffer too small (%zu floats needed, %zu given)",
                   (size_t)nblk * 2 * C, stats_floats);
+    if (tiled && (size_t)tile.blocks * 2 * C <= stats_floats) {
+      launch_dw_tile<false, true>(tile, stride, C, x, w, y, H, W, g.Ho, g.Wo, g.pt, g.pl, stats_part, stream);
+      MLIIS_CHECK_LAUNCH("dwconv_fwd_tile_stats");
+      *stats_nblk = (int)tile.blocks;
+      return MLIIS_OK;
+    }
     dim3 grid(nblk, ceil_div(C, 32));
     DW_DISPATCH(dwconv_fwd_stats_k, x, w, y, N, H, W, g.Ho, g.Wo, C, g.pt, g.pl, stats_part);
     MLIIS_CHECK_LAUNCH("dwconv_fwd_stats");
@@ -417,6 +561,11 @@ int mliis_dwconv_fwd(const float* x, const float* w, float* y, int N, int H, int
     return MLIIS_OK;
   }
   if (stats_nblk) *stats_nblk = 0;
+  if (tiled) {
+    launch_dw_tile<false, false>(tile, stride, C, x, w, y, H, W, g.Ho, g.Wo, g.pt, g.pl, nullptr, stream);
+    MLIIS_CHECK_LAUNCH("dwconv_fwd_tile");
+    return MLIIS_OK;
+  }
   dim3 grid(ceil_div(total, 256));
   DW_DISPATCH(dwconv_fwd_k, x, w, y, N, H, W, g.Ho, g.Wo, C, g.pt, g.pl);
   MLIIS_CHECK_LAUNCH("dwconv_fwd");
@@ -430,6 +579,15 @@ int mliis_dwconv_bwd_data(const float* dy, const float* w, float* dx, int N, int
   DwGeom g = dw_geom(H, W, k, stride);
   long long total = (long long)N * H * ((W + kTW - 1) / kTW) * (C / 4);
   MLIIS_REQUIRE(total < (1LL << 31), MLIIS_ERR_UNSUPPORTED, "dwconv_bwd_data: tensor too large for 32-bit indexing");
+  if (k == 5 && (long long)N * H * W * C * 4 < (1LL << 31)) {
+    // dx = dy (zero-interleaved when the layer has stride 2) correlated with the rotated filter, padding K-1-pt / K-1-pl: the
+    // LDS-tile kernel with FLIP (and DIL)
+    const DwTile tile = dw_tile(N, H, W, 1);
+    if (stride == 1) launch_dw_tile<true, false, false>(tile, 1, C, dy, w, dx, g.Ho, g.Wo, H, W, k - 1 - g.pt, k - 1 - g.pl, nullptr, stream);
+    else launch_dw_tile<true, false, true>(tile, 1, C, dy, w, dx, g.Ho, g.Wo, H, W, k - 1 - g.pt, k - 1 - g.pl, nullptr, stream);
+    MLIIS_CHECK_LAUNCH("dwconv_bwd_data_tile");
+    return MLIIS_OK;
+  }
   dim3 grid(ceil_div(total, 256));
   DW_DISPATCH(dwconv_bwd_data_k, dy, w, dx, N, H, W, g.Ho, g.Wo, C, g.pt, g.pl);
   MLIIS_CHECK_LAUNCH("dwconv_bwd_data");
