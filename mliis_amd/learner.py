@@ -755,5 +755,13 @@ class Learner:
             x = self.shots_x[torch.tensor(list(idx), dtype=torch.long, device=self.device)]
         return self.predict(x, training=training)
 
+    def close(self):
+        """Destroy the captured HIP graphs (the buffers themselves are torch tensors and go with the object)."""
+        self.synchronize()
+        for P in self.plans.values():
+            if P.graph is not None:
+                lib.call("mliis_graph_destroy", P.graph)
+                P.graph = None
+
     def gradients_packed(self) -> torch.Tensor:
         return self.arena.export_grad_packed()

@@ -138,6 +138,11 @@ def test_graph_replay_equals_eager_and_variable_batch():
             L.inner_step(idx)
             losses.append(L.loss_value())
         runs.append((losses, L.export_trainable().cpu(), L.export_bn().cpu()))
+        L.close()                                   # destroys the captured graphs; the next step captures again
+        assert all(P.graph is None for P in L.plans.values())
+        L.inner_step([0, 1, 2, 3, 4, 5, 6, 7])
+        L.inner_step([0, 1, 2, 3, 4, 5, 6, 7])
+        assert (L.plans[8].graph is not None) == use_graph
     assert runs[0][0] == runs[1][0]
     assert torch.equal(runs[0][1], runs[1][1]) and torch.equal(runs[0][2], runs[1][2])
 
