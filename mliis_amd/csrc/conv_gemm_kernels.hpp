@@ -531,13 +531,17 @@ __global__ __launch_bounds__(256, 2) void conv_filter_grad2_k(FilterGradParams p
   if (PF == 2) load_chunk(rx[PF - 1], rs[PF - 1], rd[PF - 1]);
   __syncthreads();
   int cur = 0;
+  const bool wave_live = ci0 + wave * TMF * 16 < p.C;
   auto step = [&](auto UC) {
     constexpr int U = decltype(UC)::value;
     constexpr int NX = (U + 1) % PF;
     load_chunk(rx[U], rs[U], rd[U]);   // PF chunks ahead (rows beyond mend come back as zeros)
     const float* smX = sm + cur * BUF_FLOATS;
     const float* smD = smX + BKM * LDX;
-    if constexpr (BF) {   // bf16 operands: lane group g feeds pixels g, 4 + g, ..., 28 + g of the chunk to one 16x16x32 MFMA per tile
+    // a wave whose 16 * TMF input channels all lie beyond C (the tail block of Cin = 136 = 2 * 64 + 8 keeps one wave in four busy; the
+    // 16..40-channel expand convs one or two) skips the fragment reads and MFMAs and leaves the matrix pipe to the co-resident block
+    if (!wave_live) {
+    } else if constexpr (BF) {   // bf16 operands: lane group g feeds pixels g, 4 + g, ..., 28 + g of the chunk to one 16x16x32 MFMA per tile
       bf16x8 a8[TMF], b8[NT];
 #pragma unroll
       for (int kk = 0; kk < BKM / 4; ++kk) {
