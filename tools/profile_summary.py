@@ -82,6 +82,14 @@ def main():
         kf = [v for (k, g, gy), v in per.items() if (k.startswith("dwconv_fwd_k<%d, %d" % (b.k, b.stride)) and g == gf) or
               (k.startswith("dwconv_fwd_stats_k<%d, %d" % (b.k, b.stride)) and g == gs and gy == -(-b.cexp // 32))]
         kb = [v for (k, g, gy), v in per.items() if k.startswith("dwconv_bwd_data_k<%d, %d" % (b.k, b.stride)) and g == gb]
+        if b.k == 5:   # LDS-tile kernel: 7 x 16 output tiles (7 x 7 for the stride-2 forward); backward-data tiles the INPUT map
+            def tiles(h, tow):
+                return N * (-(-h // 7)) * (-(-h // tow)) * 256
+            cy = -(-b.cexp // 32)
+            kf += [v for (k, g, gy), v in per.items() if k.startswith("dwconv_tile_k<5, %d," % b.stride) and ", false, true, false>" in k and
+                   g == tiles(b.h_out, 16 if b.stride == 1 else 7) and gy == cy]
+            kb += [v for (k, g, gy), v in per.items() if k.startswith("dwconv_tile_k<5, 1,") and ", true, false, %s>" % ("true" if b.stride == 2 else "false") in k and
+                   g == tiles(b.h_in, 16) and gy == cy]
         if not kf or not kb:
             continue
         mf = sorted(kf[0])[len(kf[0]) // 2] / 1e3
