@@ -237,13 +237,27 @@ __device__ __forceinline__ void fold32(const float* __restrict__ part, int nblk,
   const int t = threadIdx.x, q = t & 7, bl = t >> 3;
   double a0 = 0, a1 = 0, a2 = 0, a3 = 0, b0 = 0, b1 = 0, b2 = 0, b3 = 0;
   const int c = c0 + q * 4;
-  if (c < C)
-    for (int k = bl; k < nblk; k += 32) {
-      const float4 u = ld4(part + ((long long)k * 2 + 0) * C + c);
-      const float4 v = ld4(part + ((long long)k * 2 + 1) * C + c);
-      a0 += u.x; a1 += u.y; a2 += u.z; a3 += u.w;
-      b0 += v.x; b1 += v.y; b2 += v.z; b3 += v.w;
+  if (c < C) {
+    // kFoldBatch partial blocks per round trip: the big maps hand over 400-1600 partials (25-50 per lane), and one block per
+    // iteration -- load, wait, add -- cost 15 us of pure latency in every apply kernel of a 112x112 layer
+    constexpr int kFoldBatch = 8;
+    for (int k = bl; k < nblk; k += 32 * kFoldBatch) {
+      float4 u[kFoldBatch], v[kFoldBatch];
+#pragma unroll
+      for (int j = 0; j < kFoldBatch; ++j) {
+        const int kk = k + 32 * j;
+        const long long kr = kk < nblk ? kk : bl;   // surplus slots re-read this lane's first block (valid address) and are masked below
+        u[j] = ld4(part + (kr * 2 + 0) * C + c);
+        v[j] = ld4(part + (kr * 2 + 1) * C + c);
+      }
+#pragma unroll
+      for (int j = 0; j < kFoldBatch; ++j)
+        if (k + 32 * j < nblk) {
+          a0 += u[j].x; a1 += u[j].y; a2 += u[j].z; a3 += u[j].w;
+          b0 += v[j].x; b1 += v[j].y; b2 += v[j].z; b3 += v[j].w;
+        }
     }
+  }
   double* p0 = smd + (0 * 32 + bl) * 32 + q * 4;
   double* p1 = smd + (1 * 32 + bl) * 32 + q * 4;
   p0[0] = a0; p0[1] = a1; p0[2] = a2; p0[3] = a3;
