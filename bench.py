@@ -36,6 +36,8 @@ def parse():
     ap.add_argument("--inner-batch", type=int, default=8)
     ap.add_argument("--shots", type=int, default=5)
     ap.add_argument("--image-size", type=int, default=224)
+    ap.add_argument("--backbone", default="efficientnet-b0", choices=["efficientnet-b0", "efficientnet-b3"],
+                    help="variant: EfficientNet-B3 encoder (BASELINE configs[3]); the metric's config is B0")
     ap.add_argument("--aspp", action="store_true", help="variant: ASPP decoder in front of the RSD modules (--spatial_pyramid_pooling)")
     ap.add_argument("--augment", action="store_true", help="variant: host augmentation of every inner-loop batch (the reference's run.sh setting)")
     ap.add_argument("--augment-workers", type=int, default=-1, help="worker processes for the augmentation pixel work (0 = inline, -1 = cores - 1)")
@@ -78,7 +80,7 @@ def cpu_baseline(args):
     import random
     cores = usable_cores()
     torch.set_num_threads(cores)
-    O = R.OracleLearner(image_size=args.image_size, seed=0, dtype=torch.float32, lr=1e-3, aspp=args.aspp)
+    O = R.OracleLearner(name=args.backbone, image_size=args.image_size, seed=0, dtype=torch.float32, lr=1e-3, aspp=args.aspp)
     x, y = synthetic_task(args.shots, args.image_size, seed=0)
     O.load_task(torch.tensor(x), torch.tensor(y))
     batches = [list(b) for b in mini_batch_indices(args.shots, args.inner_batch, 64, rng=random.Random(0))]
@@ -234,7 +236,7 @@ def _run(args):
         cpu = cpu_baseline(args)
 
     shots = 10 if args.foml else args.shots
-    L = Learner(image_size=args.image_size, rsd=(2, 4), learning_rate=1e-3, optimizer="sgd", dice=False, l2=False, seed=0, device=device,
+    L = Learner(feature_extractor_name=args.backbone, image_size=args.image_size, rsd=(2, 4), learning_rate=1e-3, optimizer="sgd", dice=False, l2=False, seed=0, device=device,
                 use_graph=not args.no_graph, max_shots=max(16, shots), spatial_pyramid_pooling=args.aspp, matmul_precision=args.precision)
     tasks = []
     for i in range(args.pool):
@@ -277,9 +279,11 @@ def _run(args):
             "metric": "inner-loop images/sec (EfficientLab-6-3, 224x224, 5-shot)", "value": value, "unit": "images/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "bf16 matrix-core operands, f32 accumulate / tensors", "data": "synthetic",
-            "config": {"workload": "EfficientLab-6-3 (EfficientNet-B0 blocks 0-10 + %sRSD(4)+RSD(2)), %dx%d, meta-batch=%d (1 task/GPU), "
+            "config": {"workload": "%s + %sRSD(4)+RSD(2)), %dx%d, meta-batch=%d (1 task/GPU), "
                                    "%d-shot x %d inner SGD steps of batch %d (%d image fwd+bwd+BN-EMA+SGD per task), %s outer update, fp32 tensors, "
-                                   "CE loss, drop-connect on%s" % ("ASPP + " if args.aspp else "", args.image_size, args.image_size, world, shots,
+                                   "CE loss, drop-connect on%s" % ("EfficientLab-6-3 (EfficientNet-B0 blocks 0-10" if args.backbone == "efficientnet-b0" else
+                                                                 "EfficientLab with the EfficientNet-B3 encoder (blocks 0-17",
+                                                                 "ASPP + " if args.aspp else "", args.image_size, args.image_size, world, shots,
                                                                  args.inner_iters,
                                                                  args.inner_batch, imgs_per_task, "FOMAML(tail 5)" if args.foml else "Reptile",
                                                                  ("" if args.precision == "fp32" else ", bf16 matrix-core operands") +
