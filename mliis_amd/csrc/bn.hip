@@ -131,8 +131,8 @@ __global__ __launch_bounds__(kColThreads) void colreduce_partial_k(Op op, int ro
 
 template <class Op>
 static int launch_colreduce(Op op, long long rows_per_seg, int C, int nseg, float* part, size_t part_floats,
-                            hipStream_t stream, ColGeom* out_g, const char* name) {
-  ColGeom g = col_geom(rows_per_seg, C, nseg);
+                            hipStream_t stream, ColGeom* out_g, const char* name, int target_blocks = 2048) {
+  ColGeom g = col_geom(rows_per_seg, C, nseg, target_blocks);
   size_t need = (size_t)nseg * g.nblk * Op::NV * C;
   MLIIS_REQUIRE(need <= part_floats, MLIIS_ERR_WORKSPACE, "%s: workspace too small (%zu floats needed, %zu given)", name,
                 need, part_floats);
@@ -386,6 +386,18 @@ __global__ __launch_bounds__(256) void bn_apply_fused_k(const float* __restrict_
 
 static inline void chan_grid(long long rows, int C, int* gx, int* gy, int* rows_per_block) {
   const ColGeom g = col_geom(rows, C, 1);
+  *gx = g.gx;
+  *gy = g.nblk;
+  *rows_per_block = g.rows_per_block;
+}
+
+// Geometry of the BN backward pair (reduce pass + apply pass share it: the apply blocks fold the reduce pass's partials).  On large
+// tensors the default 128-row blocks mean 400-800 partials re-folded by as many apply blocks -- more L2 traffic than payload -- so the
+// pair then runs on four times fewer, taller blocks (same rule as mliis_bn_apply_fused).
+constexpr int kManyPartials = 128;   // (whole step, one box: off 2290, 256 -> 2322, 128 -> 2330, 64 -> 2323 images/s)
+static inline int bn_bwd_target(long long rows, int C) { return col_geom(rows, C, 1).nblk >= kManyPartials ? 512 : 2048; }
+static inline void bn_bwd_grid(long long rows, int C, int* gx, int* gy, int* rows_per_block) {
+  const ColGeom g = col_geom(rows, C, 1, bn_bwd_target(rows, C));
   *gx = g.gx;
   *gy = g.nblk;
   *rows_per_block = g.rows_per_block;
@@ -813,20 +825,21 @@ int mliis_bn_bwd(const float* x, int ldx, const float* dy, int lddy, float* dx, 
                 MLIIS_ERR_ALIGN, "bn_bwd: pointers must be 16-byte aligned");
   SkipOut skip{dskip, lddskip, dskip_accumulate};
   int gx, gy, rpb;
-  chan_grid(rows, C, &gx, &gy, &rpb);
+  bn_bwd_grid(rows, C, &gx, &gy, &rpb);
+  const int target = bn_bwd_target(rows, C);
   MLIIS_REQUIRE(dxsum_part == nullptr || (aligned16(dxsum_part) && (size_t)gy * C <= dxsum_floats), MLIIS_ERR_WORKSPACE,
                 "bn_bwd: column-sum buffer unaligned or too small (%zu floats needed)", (size_t)gy * C);
   ColGeom g;
   int rc;
   if (img_scale != nullptr || chan_scale != nullptr || chan_add != nullptr) {
     BnBwdCommon<true> p{x, ldx, dy, lddy, rows_per_img, C, mean, rstd, gamma, beta, pre_swish, post_swish, img_scale, chan_scale, chan_add};
-    rc = launch_colreduce(BnBwdOp<true>{p}, rows, C, 1, ws, ws_floats, stream, &g, "bn_bwd");
+    rc = launch_colreduce(BnBwdOp<true>{p}, rows, C, 1, ws, ws_floats, stream, &g, "bn_bwd", target);
     if (rc) return rc;
     hipLaunchKernelGGL(bn_bwd_apply_fused_k<true>, dim3(gx, gy), dim3(256), 0, stream, p, rows, ws, g.nblk, 1.0 / (double)rows, dgamma, dbeta,
                        dx, lddx, rpb, skip, dxsum_part);
   } else {
     BnBwdCommon<false> p{x, ldx, dy, lddy, rows_per_img, C, mean, rstd, gamma, beta, pre_swish, post_swish, nullptr, nullptr, nullptr};
-    rc = launch_colreduce(BnBwdOp<false>{p}, rows, C, 1, ws, ws_floats, stream, &g, "bn_bwd");
+    rc = launch_colreduce(BnBwdOp<false>{p}, rows, C, 1, ws, ws_floats, stream, &g, "bn_bwd", target);
     if (rc) return rc;
     hipLaunchKernelGGL(bn_bwd_apply_fused_k<false>, dim3(gx, gy), dim3(256), 0, stream, p, rows, ws, g.nblk, 1.0 / (double)rows, dgamma, dbeta,
                        dx, lddx, rpb, skip, dxsum_part);
@@ -869,13 +882,22 @@ int mliis_bn_apply_fused(const float* x, int ldx, float* y, int ldy, long long r
            moving_mean, moving_var};
   int gx, gy, rpb, cpi = 0;
   chan_grid(rows, C, &gx, &gy, &rpb);
-  // (every block folds all nblk statistics partials of its channels; taller row chunks would cut that redundant traffic but measured
-  //  the same on the whole step: profiles/r01_notes.md)
+  // Every block folds all nblk statistics partials of its channels (the price of one launch instead of three).  With many partials
+  // (the 112x112 / 56x56 producers hand over 196-1568) that redundant L2 traffic outweighs the payload at 128 rows per block:
+  // four times taller row chunks then (tools/bn_probe.py, 784 partials: 28.9 -> 23.7 us on 77 MB, 21.8 -> 17.0 us on 28 MB).
+  const bool many_partials = nblk >= kManyPartials;
+  if (many_partials) {
+    const ColGeom g2 = col_geom(rows, C, 1, 512);
+    gx = g2.gx;
+    gy = g2.nblk;
+    rpb = g2.rows_per_block;
+  }
   if (pool_part != nullptr) {   // per-image pooling of the output: row chunks are cut per image (about 128 rows each)
     MLIIS_REQUIRE(pool_chunks && aligned16(pool_part) && rows % rows_per_img == 0, MLIIS_ERR_ARG,
                   "bn_apply_fused: pooling needs an aligned buffer, a pool_chunks output and whole images");
     const long long nimg = rows / rows_per_img;
-    cpi = (rows_per_img + kPoolRows - 1) / kPoolRows;
+    const int pool_rows = many_partials ? 4 * kPoolRows : kPoolRows;
+    cpi = (rows_per_img + pool_rows - 1) / pool_rows;
     rpb = (rows_per_img + cpi - 1) / cpi;
     gy = (int)(nimg * cpi);
     MLIIS_REQUIRE((size_t)gy * C <= pool_floats, MLIIS_ERR_WORKSPACE, "bn_apply_fused: pool buffer too small (%zu floats needed, %zu given)",
@@ -894,7 +916,7 @@ int mliis_fold_tile_outputs(void) { return kFoldTile; }
 size_t mliis_bn_bwd_dxsum_floats(long long rows, int C) {
   if (rows <= 0 || C <= 0 || (C & 3)) return 0;
   int gx, gy, rpb;
-  chan_grid(rows, C, &gx, &gy, &rpb);
+  bn_bwd_grid(rows, C, &gx, &gy, &rpb);
   return (size_t)gy * C;
 }
 
