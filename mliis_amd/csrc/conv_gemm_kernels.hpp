@@ -113,13 +113,18 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_nk_k(ConvGemmParams p) {
     a_h[i] = a_w[i] = -0x40000000;   // row beyond M: never in range
     a_off[i] = s_off[i] = 0;
     if (m < M) {
-      const int HWp = p.H * p.W;
-      const int n = (int)(m / HWp);
-      const int rem = (int)(m - (long long)n * HWp);
-      a_h[i] = rem / p.W;
-      a_w[i] = rem - a_h[i] * p.W;
+      a_h[i] = a_w[i] = 0;   // 1x1 convs never leave the pixel: no (h, w) needed -- and no integer divisions in the prologue
       a_off[i] = (unsigned)(m * p.lda * 4);
-      s_off[i] = (unsigned)((long long)n * p.C * 4);
+      if (p.ntaps > 1 || SC) {
+        const int HWp = p.H * p.W;
+        const int n = (int)(m / HWp);
+        const int rem = (int)(m - (long long)n * HWp);
+        if (p.ntaps > 1) {
+          a_h[i] = rem / p.W;
+          a_w[i] = rem - a_h[i] * p.W;
+        }
+        s_off[i] = (unsigned)((long long)n * p.C * 4);
+      }
     }
   }
   unsigned b_off[B_PER_THREAD];
