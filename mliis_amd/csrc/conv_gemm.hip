@@ -235,6 +235,46 @@ static void launch_filter(const FilterPlan& f, const FilterGradParams& p, hipStr
   else launch_filter_t<false>(f, p, stream);
 }
 
+// ------------------------------------------------------------------------------------------------ short-K 1x1 convs (conv1x1_stream_k)
+// KC = 16-wide K groups (K <= 112), NT = column tiles per wave, KC * NT <= 24 (the B fragments live in registers)
+struct StreamPlan {
+  int kc, nt, gx, gy, row_groups;
+};
+static inline bool stream_plan(long long M, int K, int Nout, int num_cus, StreamPlan* sp) {
+  // (whole step, one box: off 2335, K <= 96 / M >= 2048: 2352, K <= 112 / M >= 1024: 2359 images/s; the 14x14 layers have M = 1568)
+  if (K > 112 || M < 1024 || M >= (1LL << 27)) return false;
+  sp->kc = (K + 15) / 16;
+  int nt = 24 / sp->kc;
+  if (nt > 8) nt = 8;
+  const int tiles = (Nout + 15) / 16;
+  if (nt > tiles) nt = tiles;
+  const int gy = (tiles + nt - 1) / nt;   // balanced column tiles: Nout = 144 -> 9 tiles -> 2 x NT 5 rather than NT 8 + a sliver
+  sp->nt = (tiles + gy - 1) / gy;
+  sp->gy = gy;
+  sp->row_groups = (int)((M + 15) / 16);
+  long long gx = (4LL * num_cus) / gy;     // about 16 waves per CU in flight
+  if (gx < 1) gx = 1;
+  if (gx > (sp->row_groups + 3) / 4) gx = (sp->row_groups + 3) / 4;
+  sp->gx = (int)gx;
+  return true;
+}
+static bool launch_stream(const StreamPlan& sp, const ConvGemmParams& p, hipStream_t stream) {
+  dim3 grid(sp.gx, sp.gy), block(256);
+#define S(KC_, NT_) hipLaunchKernelGGL((conv1x1_stream_k<KC_, NT_>), grid, block, 0, stream, p, sp.row_groups); break;
+  switch (sp.kc) {
+    case 1: switch (sp.nt) { case 1: S(1, 1) case 2: S(1, 2) case 3: S(1, 3) case 4: S(1, 4) case 5: S(1, 5) case 6: S(1, 6) case 7: S(1, 7) case 8: S(1, 8) default: return false; } break;
+    case 2: switch (sp.nt) { case 1: S(2, 1) case 2: S(2, 2) case 3: S(2, 3) case 4: S(2, 4) case 5: S(2, 5) case 6: S(2, 6) case 7: S(2, 7) case 8: S(2, 8) default: return false; } break;
+    case 3: switch (sp.nt) { case 1: S(3, 1) case 2: S(3, 2) case 3: S(3, 3) case 4: S(3, 4) case 5: S(3, 5) case 6: S(3, 6) case 7: S(3, 7) case 8: S(3, 8) default: return false; } break;
+    case 4: switch (sp.nt) { case 1: S(4, 1) case 2: S(4, 2) case 3: S(4, 3) case 4: S(4, 4) case 5: S(4, 5) case 6: S(4, 6) default: return false; } break;
+    case 5: switch (sp.nt) { case 1: S(5, 1) case 2: S(5, 2) case 3: S(5, 3) case 4: S(5, 4) default: return false; } break;
+    case 6: switch (sp.nt) { case 1: S(6, 1) case 2: S(6, 2) case 3: S(6, 3) case 4: S(6, 4) default: return false; } break;
+    case 7: switch (sp.nt) { case 1: S(7, 1) case 2: S(7, 2) case 3: S(7, 3) default: return false; } break;
+    default: return false;
+  }
+#undef S
+  return true;
+}
+
 static int g_num_cus = 0;
 static int num_cus() {
   if (g_num_cus == 0) {
@@ -286,6 +326,11 @@ int mliis_conv2d_plan(int Nimg, int H, int W, int Cred, int Nout, int ksize, int
 // conv2d_bwd_data call with these shapes launches (has_scale: an x_scale operand is given).
 int mliis_conv2d_kernel_name(int Nimg, int H, int W, int Cred, int Nout, int ksize, int has_scale, char* buf, size_t buf_len) {
   MLIIS_REQUIRE(buf && buf_len >= 64, MLIIS_ERR_ARG, "conv2d_kernel_name: buffer too small");
+  StreamPlan sp;
+  if (ksize == 1 && !g_matmul_bf16 && !has_scale && stream_plan((long long)Nimg * H * W, Cred, Nout, num_cus(), &sp)) {
+    snprintf(buf, buf_len, "conv1x1_stream_k<%d, %d>", sp.kc, sp.nt);   // (a call without accumulate / border bias)
+    return MLIIS_OK;
+  }
   GemmPlan g = plan_gemm((long long)Nimg * H * W, Nout, Cred, ksize * ksize, num_cus(), 1);
   snprintf(buf, buf_len, "conv_gemm_nk_k<%d, %d, %d, %s, %s, %s, %s>", g.tm, g.nt, g.tm == 1 ? 2 : 1, has_scale ? "true" : "false",
            g.gz > 1 ? "true" : "false", gemm_narrow(ksize * ksize, Cred) ? "true" : "false", g_matmul_bf16 ? "true" : "false");
@@ -324,6 +369,21 @@ int mliis_conv2d_fwd(const float* x, int ldx, const float* x_scale, const float*
   MLIIS_REQUIRE(aligned16(x_scale) && (x_scale == nullptr || ksize == 1), MLIIS_ERR_ARG,
                 "conv2d_fwd: x_scale must be 16-byte aligned and is only supported for 1x1 convs");
   if (stats_nblk) *stats_nblk = 0;
+  {  // short-K 1x1 convs (the MBConv expand convs): barrier-free streaming kernel
+    StreamPlan sp;
+    if (ksize == 1 && !g_matmul_bf16 && x_scale == nullptr && border_bias == nullptr && !accumulate && M * ldx * 4 < (1LL << 31) &&
+        M * ldy * 4 < (1LL << 31) && stream_plan(M, Cin, Cout, num_cus(), &sp)) {
+      MLIIS_REQUIRE(stats_part == nullptr || stats_nblk, MLIIS_ERR_ARG, "conv2d_fwd: fused statistics need a stats_nblk output");
+      p.stats_part = stats_part;
+      p.stats_swish = stats_swish;
+      if (launch_stream(sp, p, stream)) {
+        MLIIS_CHECK_LAUNCH("conv2d_fwd_stream");
+        if (stats_part != nullptr) *stats_nblk = sp.gx;
+        return MLIIS_OK;
+      }
+      p.stats_part = nullptr;
+    }
+  }
   if (stats_part != nullptr) {   // fused BN statistics: GEMM epilogue (gz == 1) or the split-K fold (gz > 1)
     MLIIS_REQUIRE(!accumulate && stats_nblk, MLIIS_ERR_ARG, "conv2d_fwd: fused statistics need accumulate == 0 and a stats_nblk output");
     if (g.gz == 1) {
@@ -374,6 +434,14 @@ int mliis_conv2d_bwd_data(const float* dy, int lddy, const float* w, float* dx, 
   GemmPlan g = plan_gemm(M, Cin_out, Cout, ksize * ksize, num_cus(), ws != nullptr);
   ConvGemmParams p{dy, lddy, Nimg, H, W, Cout, ksize * ksize, dil, -1, w + (long long)ci_begin * Cout, (long long)Cin_total * Cout,
                    Cout, Cin_out, dx, lddx, nullptr, accumulate, nullptr, g.chunks_per_split, nullptr, 0, nullptr, nullptr};
+  {  // short-K 1x1 convs (backward-data of the MBConv project convs): barrier-free streaming kernel
+    StreamPlan sp;
+    if (ksize == 1 && !g_matmul_bf16 && !accumulate && M * lddx * 4 < (1LL << 31) && stream_plan(M, Cout, Cin_out, num_cus(), &sp) &&
+        launch_stream(sp, p, stream)) {
+      MLIIS_CHECK_LAUNCH("conv2d_bwd_data_stream");
+      return MLIIS_OK;
+    }
+  }
   if (g.gz > 1) {
     size_t need = (size_t)g.gz * M * Cin_out;
     MLIIS_REQUIRE(need <= ws_floats && aligned16(ws) && (lddx & 3) == 0 && aligned16(dx), MLIIS_ERR_WORKSPACE,

@@ -392,6 +392,113 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_nk_k(ConvGemmParams p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------ short-K 1x1 convs, streamed
+// The MBConv expand convs (K = 16..112 input channels) and the backward-data of the project convs (K = 16..112 output channels) are
+// memory-bound GEMMs with one to four K chunks: in conv_gemm_nk_k they spend their time in the fixed chain load -> LDS -> barrier
+// -> a handful of MFMAs -> staged store -> statistics (9-11 us per launch for 3-4 us of traffic).  Here nothing goes through LDS and
+// no wave waits for another: every wave keeps the B fragments of its 16*NT output columns (all of K) in registers, streams 16-row
+// groups of A straight from memory in MFMA operand layout (lane (row, g) loads k = 16*kg + 4g..4g+3 as one 16-byte word), multiplies,
+// adds the bias, stores its accumulators and accumulates the batch-norm statistics; the next row group is in flight meanwhile.
+// One barrier at the very end folds the four waves' statistics.  grid = (row-group blocks, column tiles).
+template <int KC, int NT>
+__global__ __launch_bounds__(256) void conv1x1_stream_k(ConvGemmParams p, int row_groups) {
+  __shared__ float red[4][2][16 * NT];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int M = p.Nimg * p.H * p.W;                  // host guarantees < 2^31 and 32-bit byte offsets
+  const int n0 = blockIdx.y * (16 * NT);
+  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, kBufRecords, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, kBufRecords, 0x00020000);
+  // B fragments: column n0 + 16 j + l15, k = 16 kg + 4 g .. + 3 (zero beyond K / Nout)
+  float4 bv[KC][NT];
+#pragma unroll
+  for (int kg = 0; kg < KC; ++kg)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int n = n0 + j * 16 + l15, k = kg * 16 + g * 4;
+      bv[kg][j] = buf_ld4(rB, (n < p.Nout && k < p.C) ? (unsigned)((n * p.ldb + k) * 4) : kOob);
+    }
+  float bj[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int n = n0 + j * 16 + l15;
+    bj[j] = (p.bias != nullptr && n < p.Nout) ? p.bias[n] : 0.f;
+  }
+  float s1[NT], s2[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) s1[j] = s2[j] = 0.f;
+  const bool stats = p.stats_part != nullptr;
+  const int stride = gridDim.x * 4;
+  auto load_a = [&](int rg, float4* a) {
+    const int m = rg * 16 + l15;
+#pragma unroll
+    for (int kg = 0; kg < KC; ++kg) {
+      const int k = kg * 16 + g * 4;
+      a[kg] = buf_ld4(rA, (rg < row_groups && m < M && k < p.C) ? (unsigned)((m * p.lda + k) * 4) : kOob);
+    }
+  };
+  int rg = blockIdx.x * 4 + wave;
+  float4 a_cur[KC], a_nxt[KC];
+  load_a(rg, a_cur);
+  for (; rg < row_groups; rg += stride) {
+    load_a(rg + stride, a_nxt);
+    f32x4 acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kg = 0; kg < KC; ++kg)
+#pragma unroll
+      for (int sI = 0; sI < 4; ++sI) {
+        const float a = sI == 0 ? a_cur[kg].x : sI == 1 ? a_cur[kg].y : sI == 2 ? a_cur[kg].z : a_cur[kg].w;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const float b = sI == 0 ? bv[kg][j].x : sI == 1 ? bv[kg][j].y : sI == 2 ? bv[kg][j].z : bv[kg][j].w;
+          acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[j], 0, 0, 0);
+        }
+      }
+    // C/D layout: column l15 of tile j, rows 4 g + r
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = rg * 16 + g * 4 + r;
+      if (m < M) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const int n = n0 + j * 16 + l15;
+          const float v = acc[j][r] + bj[j];
+          if (n < p.Nout) p.Cmat[(long long)m * p.ldc + n] = v;
+          if (stats) {
+            const float u = p.stats_swish ? swish_f(v) : v;
+            s1[j] += u;
+            s2[j] = fmaf(u, u, s2[j]);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int kg = 0; kg < KC; ++kg) a_cur[kg] = a_nxt[kg];
+  }
+  if (!stats) return;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    float a = s1[j], b = s2[j];
+    a += __shfl_xor(a, 16, 64);
+    b += __shfl_xor(b, 16, 64);
+    a += __shfl_xor(a, 32, 64);
+    b += __shfl_xor(b, 32, 64);
+    if (g == 0) {
+      red[wave][0][j * 16 + l15] = a;
+      red[wave][1][j * 16 + l15] = b;
+    }
+  }
+  __syncthreads();
+  for (int idx = t; idx < 2 * 16 * NT; idx += 256) {
+    const int v = idx / (16 * NT), col = idx - v * (16 * NT);
+    const int n = n0 + col;
+    if (n < p.Nout)
+      p.stats_part[((long long)blockIdx.x * 2 + v) * p.Nout + n] = red[0][v][col] + red[1][v][col] + red[2][v][col] + red[3][v][col];
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ backward-filter
 struct FilterGradParams {
   const float* X;

@@ -582,3 +582,40 @@ def test_conv2d_bf16_operands(k, dil, H, W, Cin, Cout, N):
     assert ops.get_matmul_precision() == "fp32"
     with pytest.raises(Exception):
         ops.set_matmul_precision("fp8")
+
+
+@pytest.mark.parametrize("H,Cin,Cout,swish", [(32, 24, 144, False), (32, 112, 40, True), (32, 16, 20, False), (40, 96, 672, True), (23, 40, 8, False)])
+def test_conv1x1_short_k_streaming_kernel(H, Cin, Cout, swish):
+    """1x1 convs with K <= 112 and >= 1024 pixels take conv1x1_stream_k (no LDS, no barriers): forward with bias and fused BN
+    statistics into a channel slice of a wider buffer, from a channel slice of a wider input; backward-data likewise -- K tails
+    (24, 40), column tails (20, 40, 8), every KC 1..7."""
+    from mliis_amd import ops
+    d = dev()
+    N = 2
+    assert "conv1x1_stream_k" in ops.conv2d_kernel_name(N, H, H, Cin, Cout, 1)
+    xw = rnd(N, H, H, Cin + 8, seed=90)
+    x = xw[..., 4:4 + Cin].clone().requires_grad_(True)
+    w = rnd(1, 1, Cin, Cout, seed=91, scale=1.0 / math.sqrt(Cin)).requires_grad_(True)
+    b = rnd(Cout, seed=92)
+    y = R.conv2d_same(nchw(x), w, 1, 1, bias=b)
+    dy = rnd(*y.shape, seed=93)
+    (gx,) = torch.autograd.grad(y, [x], dy)
+    xg = f32(xw, d)
+    out = torch.full((N, H, H, Cout + 12), 5.0, device=d)
+    part = torch.full((1 << 18,), 7.0, device=d)
+    _, nblk = ops.conv2d_fwd(xg[..., 4:4 + Cin], f32(w, d), f32(b, d), 1, out=out[..., 8:8 + Cout], stats_part=part, stats_swish=swish)
+    close(out[..., 8:8 + Cout], nhwc(y), 2e-5, "stream fwd")
+    assert (out[..., :8] == 5).all() and (out[..., 8 + Cout:] == 5).all() and nblk > 0
+    v = nhwc(y).detach()
+    v = R.swish(v) if swish else v
+    sums = part[: nblk * 2 * Cout].view(nblk, 2, Cout).double().sum(0).cpu()
+    close(sums[0], v.sum(dim=(0, 1, 2)), 2e-5, "stream fused sum")
+    close(sums[1], (v * v).sum(dim=(0, 1, 2)), 2e-5, "stream fused sum of squares")
+    assert (part[nblk * 2 * Cout:] == 7).all()
+    # backward-data of a conv whose OUTPUT has few channels: K = Cout of the forward
+    if Cout <= 112:
+        assert "conv1x1_stream_k" in ops.conv2d_kernel_name(N, H, H, Cout, Cin, 1)
+        dxw = torch.full((N, H, H, Cin + 4), -3.0, device=d)
+        ops.conv2d_bwd_data(f32(nhwc(dy), d), f32(w, d), 1, out=dxw[..., :Cin])
+        close(dxw[..., :Cin], gx, 1e-4, "stream bwd data")
+        assert (dxw[..., Cin:] == -3).all()
