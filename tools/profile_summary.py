@@ -15,7 +15,7 @@ from mliis_amd import spec  # noqa: E402
 
 def family(n):
     n = n.replace("void mliis::", "").replace("mliis::", "").split("(")[0]
-    if n.startswith("conv_gemm"):
+    if n.startswith("conv_gemm") or n.startswith("conv1x1_stream"):
         return "dense conv fwd / bwd-data (MFMA implicit GEMM)"
     if n.startswith("conv_filter"):
         return "dense conv bwd-filter (MFMA)"
