@@ -117,10 +117,10 @@ class _Plan:
         regs, rows, off, tile = {}, [], 0, 0
         fold_tile = lib.raw("mliis_fold_tile_outputs")()
 
-        def add(name, ws_floats, total, seg=None):
+        def add(name, ws_floats, total, seg=None, key=None):
             nonlocal off, tile
             seg_len, seg_stride, seg_off = seg or (total, 0, 0)
-            regs[name] = (off, ws_floats)
+            regs[key or name] = (off, ws_floats)
             rows.append([off, A.t_off[name], total, seg_len, seg_stride, seg_off, ws_floats // total, tile])
             off += (ws_floats + 3) // 4 * 4
             tile += -(-total // fold_tile)
@@ -132,13 +132,24 @@ class _Plan:
                 add(nm["w_exp"], lib.size("mliis_conv2d_bwd_filter_workspace_floats", N, b.h_in, b.h_in, b.cin, ce, 1), b.cin * ce)
             add(nm["w_dw"], lib.size("mliis_dwconv_bwd_filter_workspace_floats", N, b.h_in, b.h_in, ce, b.k, b.stride), b.k * b.k * ce)
             add(nm["w_proj"], lib.size("mliis_conv2d_bwd_filter_workspace_floats", N, b.h_out, b.h_out, ce, b.cout, 1), ce * b.cout)
-        for m, nm in zip(a.rsd, L.n_rsd):
+        self.filter_tail = {}
+        for j_rsd, (m, nm) in enumerate(zip(a.rsd, L.n_rsd)):
             (k0, b0_, _), (k1, b1_, _), (kf, _, _) = nm
             co = m.c_out
             for bias in (b0_, b1_):   # conv-bias gradients: column sums of dz leave the BN backward pass as slabs
                 add(bias, ops.bn_bwd_dxsum_floats(N * m.h * m.h, co), co)
-            add(k0, lib.size("mliis_conv2d_bwd_filter_workspace_floats", N, m.h, m.h, m.c_cat, co, 1), m.c_cat * co)
-            add(k1, lib.size("mliis_conv2d_bwd_filter_workspace_floats", N, m.h, m.h, m.c_cat, co, 3), 9 * m.c_cat * co)
+            # filter gradients over the concatenated [deep | skip] channels.  A channel count like 136 = 2 * 64 + 8 leaves a third of
+            # the 64-channel blocks of the filter-gradient kernel nearly empty while they still occupy a CU slot each: the sliver
+            # (c_cat mod 64 <= 16 channels) gets its own small launch and fold region instead (profiles/r01_notes.md).
+            tail = m.c_cat % 64 if (m.c_cat > 64 and 0 < m.c_cat % 64 <= 16) else 0
+            self.filter_tail[j_rsd] = tail
+            for kk, kname in ((1, k0), (3, k1)):
+                main_c = m.c_cat - tail
+                add(kname, lib.size("mliis_conv2d_bwd_filter_workspace_floats", N, m.h, m.h, main_c, co, kk), kk * kk * main_c * co,
+                    seg=(main_c * co, m.c_cat * co, 0) if tail else None)
+                if tail:
+                    add(kname, lib.size("mliis_conv2d_bwd_filter_workspace_floats", N, m.h, m.h, tail, co, kk), kk * kk * tail * co,
+                        seg=(tail * co, m.c_cat * co, main_c * co), key=kname + "#tail")
             add(kf, lib.size("mliis_conv2d_bwd_filter_workspace_floats", N, m.h, m.h, 2 * co, co, 3), 9 * 2 * co * co,
                 seg=(2 * co * co, m.c_pyr * co, 0))
         # squeeze-excite weight gradients of all blocks: one launch (descriptor table of device addresses)
@@ -560,10 +571,17 @@ class Learner:
             ops.conv2d_bwd_data(D["dzf"], w[kf], 1, ci_begin=0, ci_count=2 * co, out=dpyr, ws=ws)
             d0, d1 = dpyr[..., :co], dpyr[..., co:2 * co]
             bn_b(D["z0"], d0, D["st0"], n0, d0, pre=True, dxsum_part=P.fold_part[b0])   # + conv-bias gradient slabs (batched fold)
-            side(lambda cat=cat, d0=d0, k0=k0: ops.conv2d_bwd_filter(cat, d0, 1, 1, partial=P.fold_part[k0]))
+            tail = P.filter_tail[j]
+            cmain = cat[..., :m.c_cat - tail] if tail else cat
+
+            def wgrad(dz, kname, kk, dil, cmain=cmain, ctail=cat[..., m.c_cat - tail:] if tail else None):
+                ops.conv2d_bwd_filter(cmain, dz, kk, dil, partial=P.fold_part[kname])
+                if ctail is not None:   # the <= 16-channel sliver of the concat (see _Plan)
+                    ops.conv2d_bwd_filter(ctail, dz, kk, dil, partial=P.fold_part[kname + "#tail"])
+            side(lambda d0=d0, k0=k0, wgrad=wgrad: wgrad(d0, k0, 1, 1))
             ops.conv2d_bwd_data(d0, w[k0], 1, out=dcat, ws=ws)
             bn_b(D["z1"], d1, D["st1"], n1, d1, pre=True, dxsum_part=P.fold_part[b1])
-            side(lambda cat=cat, d1=d1, k1=k1: ops.conv2d_bwd_filter(cat, d1, 3, 2, partial=P.fold_part[k1]))
+            side(lambda d1=d1, k1=k1, wgrad=wgrad: wgrad(d1, k1, 3, 2))
             ops.conv2d_bwd_data(d1, w[k1], 2, out=dcat, accumulate=True, ws=ws)
             ops.chan_affine(None, A=D["dpool"], out=dcat, accumulate=True)   # d(mean)/d(cat) = dpool / (H*W) on every pixel
             # dU = dO + dcat[:, :c_deep] (residual);  dS = dcat[:, c_deep:]
