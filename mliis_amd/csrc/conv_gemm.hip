@@ -189,12 +189,12 @@ static inline GemmPlan plan_gemm(long long M, int Nout, int C, int ntaps, int nu
 static inline void plan_filter_split(FilterPlan& f, long long M, int C, int Nout, int ntaps, int num_cus) {
   const int bci = 64 * f.tmf;
   f.gy = (Nout + f.nt * 16 - 1) / (f.nt * 16);
-  f.gx = ntaps * ((C + bci - 1) / bci);
+  f.gx = f.multitap ? 1 : ntaps * ((C + bci - 1) / bci);
   long long base = (long long)f.gx * f.gy;
   long long want = (2LL * num_cus) / base;  // one full round of two co-resident blocks per CU (no half-empty second round) ...
   {  // ... bounded by the slab count the fold has to read: 96 in general, up to 512 for tiny filters (fold cost ~ slabs * size)
     const long long total = (long long)ntaps * C * Nout;
-    long long cap = (1LL << 19) / (total > 0 ? total : 1);
+    long long cap = (1LL << 21) / (total > 0 ? total : 1);
     if (cap > 512) cap = 512;
     if (cap < 96) cap = 96;
     if (want > cap) want = cap;
@@ -213,10 +213,13 @@ static inline FilterPlan plan_filter(long long M, int C, int Nout, int ntaps, in
   // 128-wide ci blocks halve the dY re-reads; take them unless they pad more zero rows than 64-wide blocks would
   const int waste128 = (C + 127) / 128 * 128 - C, waste64 = (C + 63) / 64 * 64 - C;
   f.tmf = (C >= 128 && waste128 <= waste64) ? 2 : 1;
+  // a 3x3 conv over very few channels (the 8-channel sliver of the RSD concat): all taps in one channel block, dY read once
+  f.multitap = (ntaps > 1 && ntaps * C <= 128) ? 1 : 0;
+  if (f.multitap) f.tmf = ntaps * C > 64 ? 2 : 1;
   plan_filter_split(f, M, C, Nout, ntaps, num_cus);
   // small maps cannot be split further along the pixels (64 rows per slab): narrower tiles instead (latency-bound, see plan_gemm)
-  while ((long long)f.gx * f.gy * f.gz < (long long)kFilterFill * num_cus && (f.tmf == 2 || f.nt > 2)) {
-    if (f.tmf == 2) f.tmf = 1;
+  while ((long long)f.gx * f.gy * f.gz < (long long)kFilterFill * num_cus && ((f.tmf == 2 && !f.multitap) || f.nt > 2)) {
+    if (f.tmf == 2 && !f.multitap) f.tmf = 1;
     else f.nt = (f.nt + 1) / 2;
     plan_filter_split(f, M, C, Nout, ntaps, num_cus);
   }
@@ -490,7 +493,7 @@ int mliis_conv2d_bwd_filter(const float* x, int ldx, const float* x_scale, const
   MLIIS_REQUIRE((size_t)f.gz * total <= ws_floats, MLIIS_ERR_WORKSPACE, "conv2d_bwd_filter: workspace too small (%zu needed, %zu given)",
                 (size_t)f.gz * total, ws_floats);
   MLIIS_REQUIRE(aligned16(x_scale), MLIIS_ERR_ALIGN, "conv2d_bwd_filter: x_scale must be 16-byte aligned");
-  FilterGradParams p{x, ldx, Nimg, H, W, Cin, ksize * ksize, dil, dy, lddy, Cout, ws, f.rows_per_split, x_scale};
+  FilterGradParams p{x, ldx, Nimg, H, W, Cin, ksize * ksize, dil, dy, lddy, Cout, ws, f.rows_per_split, x_scale, f.multitap};
   launch_filter(f, p, stream);
   MLIIS_CHECK_LAUNCH("conv2d_bwd_filter");
   MLIIS_REQUIRE(ci_begin >= 0 && ci_begin + Cin <= Cin_total, MLIIS_ERR_ARG, "conv2d_bwd_filter: input-channel window out of range");

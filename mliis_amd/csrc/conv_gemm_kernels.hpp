@@ -512,6 +512,8 @@ struct FilterGradParams {
   float* partial;  // [splits][ntaps*C][Nout]
   int rows_per_split;
   const float* x_scale;  // nullable [Nimg][C]: X[m][c] *= x_scale[image(m)][c] on load
+  int multitap;          // != 0: ntaps * C <= 64 * TMF -- ONE channel block holds all taps (its rows are the flattened (tap, channel)
+                         //       index), so dY is read once instead of once per tap (the 8-channel sliver of the RSD concat)
 };
 
 // ------------------------------------------------------------------------------------------------ backward-filter kernel
@@ -535,18 +537,14 @@ __global__ __launch_bounds__(256, 2) void conv_filter_grad2_k(FilterGradParams p
   const int lane = t & 63, wave = t >> 6;
   const int l15 = lane & 15, g = lane >> 4;
   const int M = p.Nimg * p.H * p.W;            // host guarantees < 2^31
-  const int cblocks = (p.C + BCI - 1) / BCI;
-  const int tap = blockIdx.x / cblocks;
-  const int ci0 = (blockIdx.x - tap * cblocks) * BCI;
+  const bool mt = p.multitap != 0;
+  const int cblocks = mt ? 1 : (p.C + BCI - 1) / BCI;
+  const int tap = mt ? 0 : blockIdx.x / cblocks;
+  const int ci0 = mt ? 0 : (blockIdx.x - tap * cblocks) * BCI;
   const int n0 = blockIdx.y * BN;
   const int mbeg = blockIdx.z * p.rows_per_split;
   int mend = mbeg + p.rows_per_split;
   if (mend > M) mend = M;
-  int dh = 0, dw = 0;
-  if (p.ntaps > 1) {
-    dh = (tap / 3 - 1) * p.dil;
-    dw = (tap % 3 - 1) * p.dil;
-  }
   const int HW = p.H * p.W;
   const int adv_h = BKM / p.W, adv_w = BKM - adv_h * p.W;   // one chunk = 32 pixels further along the flattened (n, h, w) index
 
@@ -557,7 +555,18 @@ __global__ __launch_bounds__(256, 2) void conv_filter_grad2_k(FilterGradParams p
   // ---- per-thread X rows: position of the row the NEXT load will fetch
   const int x_cq = t % (BCI / 4);
   const int x_r0 = t / (BCI / 4);
-  const bool x_cok = ci0 + x_cq * 4 < p.C;
+  // tap / first channel of the quad this thread loads (block-uniform tap, or per thread in multitap mode)
+  int l_tap = tap, l_c = ci0 + x_cq * 4;
+  if (mt) {
+    l_tap = (x_cq * 4) / p.C;
+    l_c = x_cq * 4 - l_tap * p.C;
+  }
+  const bool x_cok = mt ? l_tap < p.ntaps : l_c < p.C;
+  int dh = 0, dw = 0;
+  if (p.ntaps > 1) {
+    dh = (l_tap / 3 - 1) * p.dil;
+    dw = (l_tap % 3 - 1) * p.dil;
+  }
   int x_m[X_PER_THREAD], x_h[X_PER_THREAD], x_w[X_PER_THREAD], x_n[X_PER_THREAD];
   unsigned x_off[X_PER_THREAD];
 #pragma unroll
@@ -568,7 +577,7 @@ __global__ __launch_bounds__(256, 2) void conv_filter_grad2_k(FilterGradParams p
     const int rem = m - x_n[i] * HW;
     x_h[i] = rem / p.W;
     x_w[i] = rem - x_h[i] * p.W;
-    x_off[i] = (unsigned)((((long long)m + (long long)dh * p.W + dw) * p.ldx + ci0 + x_cq * 4) * 4);
+    x_off[i] = (unsigned)((((long long)m + (long long)dh * p.W + dw) * p.ldx + l_c) * 4);
   }
   const unsigned x_step = (unsigned)(BKM * p.ldx * 4);
   // ---- per-thread dY elements
@@ -591,7 +600,7 @@ __global__ __launch_bounds__(256, 2) void conv_filter_grad2_k(FilterGradParams p
     for (int i = 0; i < X_PER_THREAD; ++i) {
       const bool ok = x_cok & (x_m[i] < mend) & ((unsigned)(x_h[i] + dh) < (unsigned)p.H) & ((unsigned)(x_w[i] + dw) < (unsigned)p.W);
       rx_[i] = buf_ld4(rX, ok ? x_off[i] : kOob);
-      if (SC) rs_[i] = buf_ld4(rS, ok ? (unsigned)((x_n[i] * p.C + ci0 + x_cq * 4) * 4) : kOob);
+      if (SC) rs_[i] = buf_ld4(rS, ok ? (unsigned)((x_n[i] * p.C + l_c) * 4) : kOob);
       x_m[i] += BKM;
       x_off[i] += x_step;
       x_w[i] += adv_w;
@@ -643,7 +652,7 @@ __global__ __launch_bounds__(256, 2) void conv_filter_grad2_k(FilterGradParams p
   if (PF == 2) load_chunk(rx[PF - 1], rs[PF - 1], rd[PF - 1]);
   __syncthreads();
   int cur = 0;
-  const bool wave_live = ci0 + wave * TMF * 16 < p.C;
+  const bool wave_live = mt ? wave * TMF * 16 < p.ntaps * p.C : ci0 + wave * TMF * 16 < p.C;
   auto step = [&](auto UC) {
     constexpr int U = decltype(UC)::value;
     constexpr int NX = (U + 1) % PF;
@@ -704,8 +713,8 @@ __global__ __launch_bounds__(256, 2) void conv_filter_grad2_k(FilterGradParams p
   for (int i = 0; i < TMF; ++i)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int ci = ci0 + (wave * TMF + i) * 16 + g * 4 + r;
-      if (ci >= p.C) continue;
+      const int ci = ci0 + (wave * TMF + i) * 16 + g * 4 + r;   // multitap: the flattened (tap, channel) row, tap == 0 in the index below
+      if (ci >= (mt ? p.ntaps * p.C : p.C)) continue;
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         const int n = n0 + j * 16 + l15;
@@ -758,7 +767,7 @@ static void launch_gemm_t(const GemmPlan& g, const ConvGemmParams& p, hipStream_
 }
 
 struct FilterPlan {
-  int tmf, nt, gx, gy, gz, rows_per_split;
+  int tmf, nt, gx, gy, gz, rows_per_split, multitap;
 };
 
 template <bool BF>
