@@ -56,6 +56,13 @@ int mliis_dwconv_fwd(const float* x, const float* w, float* y, int N, int H, int
                      size_t stats_floats, int* stats_nblk, hipStream_t stream);
 int mliis_dwconv_bwd_data(const float* dy, const float* w, float* dx, int N, int H, int W, int C, int k, int stride,
                           hipStream_t stream);
+/*      same, when dx is the gradient w.r.t. swish(bn(bn_z)) (the expand branch of an MBConv block, efficientnet_model.py:175-182):
+ *      the launch also emits stage 1 of that batch norm's backward -- per-block column sums {sum g, sum g*xhat}, g = dx *
+ *      swish'(gamma*xhat + beta) -- into part [*nblk][2][C] for mliis_bn_bwd(stage1_part, stage1_nblk).  *nblk == 0: not produced
+ *      (part too small: needs N * ceil(H/7) * ceil(W/16) * 2 * C floats); run mliis_bn_bwd without stage-1 partials then. */
+int mliis_dwconv_bwd_data_bn(const float* dy, const float* w, float* dx, int N, int H, int W, int C, int k, int stride, const float* bn_z,
+                             const float* bn_mean, const float* bn_rstd, const float* bn_gamma, const float* bn_beta, float* part,
+                             size_t part_floats, int* nblk, hipStream_t stream);
 size_t mliis_dwconv_bwd_filter_workspace_floats(int N, int H, int W, int C, int k, int stride);
 int mliis_dwconv_bwd_filter(const float* x, const float* dy, float* dw, int N, int H, int W, int C, int k, int stride, float* ws,
                             size_t ws_floats, hipStream_t stream);
@@ -147,7 +154,9 @@ int mliis_bn_bwd(const float* x, int ldx, const float* dy, int lddy, float* dx, 
                  const float* mean, const float* rstd, const float* gamma, const float* beta, int pre_swish, int post_swish,
                  const float* img_scale, const float* chan_scale, const float* chan_add, float* dgamma, float* dbeta, float* dskip,
                  int lddskip, int dskip_accumulate, float* dxsum_part, size_t dxsum_floats, float* ws, size_t ws_floats,
-                 hipStream_t stream);
+                 const float* stage1_part, int stage1_nblk, hipStream_t stream);
+/*      stage1_part (nullable, [stage1_nblk][2][C]): the reduce pass's partial sums {sum g, sum g*xhat} already produced by the kernel
+ *      that wrote dy (mliis_dwconv_bwd_data_bn); mliis_bn_bwd then runs its apply pass only (plain batch norms: no per-image vectors) */
 
 /* ---- per-image column sums: out[seg,c] (+)= scale * sum_rows a[row,c] * b[row,c]  (b nullable).  Serves tf.reduce_mean over
  *      H,W of squeeze-excite (efficientnet_model.py:247) and of the RSD pooled branch (efficientlab.py:192-197), their

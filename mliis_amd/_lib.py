@@ -28,6 +28,7 @@ SIGNATURES = {
     "mliis_stem_conv_bwd_filter": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _sz, _p]),
     "mliis_dwconv_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _sz, _p, _p]),
     "mliis_dwconv_bwd_data": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "mliis_dwconv_bwd_data_bn": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _sz, _p, _p]),
     "mliis_dwconv_bwd_filter_workspace_floats": (_sz, [_i, _i, _i, _i, _i, _i]),
     "mliis_dwconv_bwd_filter": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _sz, _p]),
     "mliis_conv2d_workspace_floats": (_sz, [_i, _i, _i, _i, _i, _i]),
@@ -49,7 +50,7 @@ SIGNATURES = {
     "mliis_bn_apply": (_i, [_p, _i, _p, _i, _ll, _i, _i, _p, _p, _p, _p, _i, _i, _p, _p, _i, _p]),
     "mliis_bn_stats_partial": (_i, [_p, _i, _ll, _i, _i, _p, _sz, _p, _p]),
     "mliis_bn_apply_fused": (_i, [_p, _i, _p, _i, _ll, _i, _i, _p, _i, _f, _f, _i, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _i, _p, _sz, _p, _p]),
-    "mliis_bn_bwd": (_i, [_p, _i, _p, _i, _p, _i, _ll, _i, _i, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _i, _i, _p, _sz, _p, _sz, _p]),
+    "mliis_bn_bwd": (_i, [_p, _i, _p, _i, _p, _i, _ll, _i, _i, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _i, _i, _p, _sz, _p, _sz, _p, _i, _p]),
     "mliis_bn_bwd_dxsum_floats": (_sz, [_ll, _i]),
     "mliis_colsum": (_i, [_p, _i, _p, _i, _ll, _i, _i, _f, _p, _i, _p, _sz, _p]),
     "mliis_se_mlp_fwd": (_i, [_p, _i, _f, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),

@@ -812,7 +812,7 @@ int mliis_bn_bwd(const float* x, int ldx, const float* dy, int lddy, float* dx, 
                  int rows_per_img, const float* mean, const float* rstd, const float* gamma, const float* beta, int pre_swish,
                  int post_swish, const float* img_scale, const float* chan_scale, const float* chan_add, float* dgamma,
                  float* dbeta, float* dskip, int lddskip, int dskip_accumulate, float* dxsum_part, size_t dxsum_floats, float* ws,
-                 size_t ws_floats, hipStream_t stream) {
+                 size_t ws_floats, const float* stage1_part, int stage1_nblk, hipStream_t stream) {
   MLIIS_REQUIRE(x && dy && dx && mean && rstd && gamma && beta && dgamma && dbeta && ws, MLIIS_ERR_ARG, "bn_bwd: null pointer");
   MLIIS_REQUIRE(dskip == nullptr || (aligned16(dskip) && (lddskip & 3) == 0 && lddskip >= C && dskip != dx), MLIIS_ERR_ARG,
                 "bn_bwd: bad skip-gradient output");
@@ -831,6 +831,15 @@ int mliis_bn_bwd(const float* x, int ldx, const float* dy, int lddy, float* dx, 
                 "bn_bwd: column-sum buffer unaligned or too small (%zu floats needed)", (size_t)gy * C);
   ColGeom g;
   int rc;
+  if (stage1_part != nullptr) {   // stage 1 ({sum g, sum g * xhat} partials [stage1_nblk][2][C]) came from the producer of dy
+    MLIIS_REQUIRE(stage1_nblk > 0 && aligned16(stage1_part) && img_scale == nullptr && chan_scale == nullptr && chan_add == nullptr,
+                  MLIIS_ERR_ARG, "bn_bwd: external stage-1 partials need a plain (no per-image vectors) batch norm");
+    BnBwdCommon<false> p{x, ldx, dy, lddy, rows_per_img, C, mean, rstd, gamma, beta, pre_swish, post_swish, nullptr, nullptr, nullptr};
+    hipLaunchKernelGGL(bn_bwd_apply_fused_k<false>, dim3(gx, gy), dim3(256), 0, stream, p, rows, stage1_part, stage1_nblk, 1.0 / (double)rows,
+                       dgamma, dbeta, dx, lddx, rpb, skip, dxsum_part);
+    MLIIS_CHECK_LAUNCH("bn_bwd_apply_fused");
+    return MLIIS_OK;
+  }
   if (img_scale != nullptr || chan_scale != nullptr || chan_add != nullptr) {
     BnBwdCommon<true> p{x, ldx, dy, lddy, rows_per_img, C, mean, rstd, gamma, beta, pre_swish, post_swish, img_scale, chan_scale, chan_add};
     rc = launch_colreduce(BnBwdOp<true>{p}, rows, C, 1, ws, ws_floats, stream, &g, "bn_bwd", target);

@@ -192,10 +192,18 @@ __global__ __launch_bounds__(256) void dwconv_fwd_stats_k(const float* __restric
 typedef unsigned dw_u32x4 __attribute__((ext_vector_type(4)));
 constexpr unsigned kDwOob = 0xFFFFFFF0u;
 
-template <int K, int S, int TOH, int TOW, int TS, bool FLIP, bool STATS, bool DIL>
+// BNB (backward-data launches): the output is the gradient w.r.t. a = swish(bn(z)); the launch then also emits stage 1 of that batch
+// norm's backward -- per-block column sums {sum g, sum g * xhat}, g = dx * swish'(gamma * xhat + beta), xhat = (z - mean) * rstd -- into
+// stats_part [block][2][C], so mliis_bn_bwd needs no reduce pass of its own over (z, dx).
+struct DwBn {
+  const float* z;       // [N, Ho, Wo, C] the batch norm's input (same shape as this launch's output)
+  const float *mean, *rstd, *gamma, *beta;
+};
+
+template <int K, int S, int TOH, int TOW, int TS, bool FLIP, bool STATS, bool DIL, bool BNB>
 __global__ __launch_bounds__(256) void dwconv_tile_k(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y,
                                                      int Hi, int Wi, int Ho, int Wo, int C, int pt, int pl, int tiles_y, int tiles_x,
-                                                     float* __restrict__ stats_part) {
+                                                     float* __restrict__ stats_part, DwBn bn) {
   // every thread produces a strip of TS outputs along W from a sliding (TS-1)*S+K wide register window: K*((TS-1)*S+K)/TS LDS reads per
   // output instead of K*K (10 instead of 25 for K = 5, TS = 4 at stride 1 -- the LDS port is the bottleneck otherwise)
   constexpr int IH = (TOH - 1) * S + K, IW = (TOW - 1) * S + K, NPIX = IH * IW;
@@ -239,6 +247,11 @@ __global__ __launch_bounds__(256) void dwconv_tile_k(const float* __restrict__ x
   }
   __syncthreads();
   float4 s1 = f4zero(), s2 = f4zero();
+  float4 bm = f4zero(), br = f4zero(), bg = f4zero(), bb = f4zero();
+  if (BNB) {
+    const int cc = cok ? c : 0;
+    bm = ld4(bn.mean + cc); br = ld4(bn.rstd + cc); bg = ld4(bn.gamma + cc); bb = ld4(bn.beta + cc);
+  }
 #pragma unroll
   for (int i = 0; i < IT_PER; ++i) {
     const int item = lane_p + 32 * i;
@@ -264,14 +277,26 @@ __global__ __launch_bounds__(256) void dwconv_tile_k(const float* __restrict__ x
 #pragma unroll
     for (int j = 0; j < TS; ++j)
       if (rok && ox0 + ox + j < Wo) {
-        st4(y + ((long long)((n * Ho + oy0 + oy) * Wo + ox0 + ox + j)) * C + c, acc[j]);
+        const long long o4 = ((long long)((n * Ho + oy0 + oy) * Wo + ox0 + ox + j)) * C + c;
+        st4(y + o4, acc[j]);
         if (STATS) {
           s1 = f4add(s1, acc[j]);
           s2 = f4fma(acc[j], acc[j], s2);
         }
+        if (BNB) {
+          const float4 zv = ld4(bn.z + o4);
+          const float4 xh = make_float4((zv.x - bm.x) * br.x, (zv.y - bm.y) * br.y, (zv.z - bm.z) * br.z, (zv.w - bm.w) * br.w);
+          float4 gg = acc[j];
+          gg.x *= swish_grad_f(fmaf(xh.x, bg.x, bb.x));
+          gg.y *= swish_grad_f(fmaf(xh.y, bg.y, bb.y));
+          gg.z *= swish_grad_f(fmaf(xh.z, bg.z, bb.z));
+          gg.w *= swish_grad_f(fmaf(xh.w, bg.w, bb.w));
+          s1 = f4add(s1, gg);
+          s2 = f4fma(gg, xh, s2);
+        }
       }
   }
-  if (!STATS) return;
+  if (!STATS && !BNB) return;
 #pragma unroll
   for (int off = 8; off < 64; off <<= 1) {
     s1.x += __shfl_xor(s1.x, off); s1.y += __shfl_xor(s1.y, off); s1.z += __shfl_xor(s1.z, off); s1.w += __shfl_xor(s1.w, off);
@@ -493,16 +518,21 @@ static inline DwTile dw_tile(int N, int Ho, int Wo, int stride) {
   d.blocks = (long long)N * d.tiles_y * d.tiles_x;
   return d;
 }
-template <bool FLIP, bool STATS, bool DIL = false>
+template <bool FLIP, bool STATS, bool DIL = false, bool BNB = false>
 static void launch_dw_tile(const DwTile& d, int stride, int C, const float* x, const float* w, float* y, int Hi, int Wi, int Ho, int Wo, int pt,
-                           int pl, float* stats_part, hipStream_t stream) {
+                           int pl, float* stats_part, hipStream_t stream, int k = 5, DwBn bn = DwBn{nullptr, nullptr, nullptr, nullptr, nullptr}) {
   dim3 grid((unsigned)d.blocks, ceil_div(C, 32));
+  if (k == 3) {   // (stride-1 geometry: backward-data launches only)
+    hipLaunchKernelGGL((dwconv_tile_k<3, 1, 7, 16, 4, FLIP, STATS, DIL, BNB>), grid, dim3(256), 0, stream, x, w, y, Hi, Wi, Ho, Wo, C, pt, pl,
+                       d.tiles_y, d.tiles_x, stats_part, bn);
+    return;
+  }
   if (stride == 1)
-    hipLaunchKernelGGL((dwconv_tile_k<5, 1, 7, 16, 4, FLIP, STATS, DIL>), grid, dim3(256), 0, stream, x, w, y, Hi, Wi, Ho, Wo, C, pt, pl, d.tiles_y,
-                       d.tiles_x, stats_part);
+    hipLaunchKernelGGL((dwconv_tile_k<5, 1, 7, 16, 4, FLIP, STATS, DIL, BNB>), grid, dim3(256), 0, stream, x, w, y, Hi, Wi, Ho, Wo, C, pt, pl,
+                       d.tiles_y, d.tiles_x, stats_part, bn);
   else
-    hipLaunchKernelGGL((dwconv_tile_k<5, 2, 7, 7, 1, FLIP, STATS, false>), grid, dim3(256), 0, stream, x, w, y, Hi, Wi, Ho, Wo, C, pt, pl, d.tiles_y,
-                       d.tiles_x, stats_part);
+    hipLaunchKernelGGL((dwconv_tile_k<5, 2, 7, 7, 1, FLIP, STATS, false, false>), grid, dim3(256), 0, stream, x, w, y, Hi, Wi, Ho, Wo, C, pt, pl,
+                       d.tiles_y, d.tiles_x, stats_part, bn);
 }
 
 constexpr int kTW = 4;
@@ -550,7 +580,7 @@ int mliis_dwconv_fwd(const float* x, const float* w, float* y, int N, int H, int
     MLIIS_REQUIRE((size_t)nblk * 2 * C <= stats_floats, MLIIS_ERR_WORKSPACE, "dwconv_fwd: statistics buffer too small (%zu floats needed, %zu given)",
                   (size_t)nblk * 2 * C, stats_floats);
     if (tiled && (size_t)tile.blocks * 2 * C <= stats_floats) {
-      launch_dw_tile<false, true>(tile, stride, C, x, w, y, H, W, g.Ho, g.Wo, g.pt, g.pl, stats_part, stream);
+      launch_dw_tile<false, true>(tile, stride, C, x, w, y, H, W, g.Ho, g.Wo, g.pt, g.pl, stats_part, stream, k);
       MLIIS_CHECK_LAUNCH("dwconv_fwd_tile_stats");
       *stats_nblk = (int)tile.blocks;
       return MLIIS_OK;
@@ -563,7 +593,7 @@ int mliis_dwconv_fwd(const float* x, const float* w, float* y, int N, int H, int
   }
   if (stats_nblk) *stats_nblk = 0;
   if (tiled) {
-    launch_dw_tile<false, false>(tile, stride, C, x, w, y, H, W, g.Ho, g.Wo, g.pt, g.pl, nullptr, stream);
+    launch_dw_tile<false, false>(tile, stride, C, x, w, y, H, W, g.Ho, g.Wo, g.pt, g.pl, nullptr, stream, k);
     MLIIS_CHECK_LAUNCH("dwconv_fwd_tile");
     return MLIIS_OK;
   }
@@ -573,19 +603,33 @@ int mliis_dwconv_fwd(const float* x, const float* w, float* y, int N, int H, int
   return MLIIS_OK;
 }
 
-int mliis_dwconv_bwd_data(const float* dy, const float* w, float* dx, int N, int H, int W, int C, int k, int stride,
-                          hipStream_t stream) {
+// bn_z != NULL: dx is the gradient w.r.t. swish(bn(bn_z)) (the expand branch of an MBConv block): the launch also emits stage 1 of that
+// batch norm's backward into part [*nblk][2][C] (see DwBn); *nblk == 0 means "not produced" (no LDS-tile path for this call or part
+// too small) and the caller lets mliis_bn_bwd run its own reduce pass.
+static int dw_bwd_data(const float* dy, const float* w, float* dx, int N, int H, int W, int C, int k, int stride, const DwBn* bn, float* part,
+                       size_t part_floats, int* nblk, hipStream_t stream) {
   int rc = dw_check("dwconv_bwd_data", dy, w, dx, N, H, W, C, k, stride);
   if (rc) return rc;
   DwGeom g = dw_geom(H, W, k, stride);
   long long total = (long long)N * H * ((W + kTW - 1) / kTW) * (C / 4);
   MLIIS_REQUIRE(total < (1LL << 31), MLIIS_ERR_UNSUPPORTED, "dwconv_bwd_data: tensor too large for 32-bit indexing");
-  if (k == 5 && (long long)N * H * W * C * 4 < (1LL << 31)) {
-    // dx = dy (zero-interleaved when the layer has stride 2) correlated with the rotated filter, padding K-1-pt / K-1-pl: the
-    // LDS-tile kernel with FLIP (and DIL)
-    const DwTile tile = dw_tile(N, H, W, 1);
-    if (stride == 1) launch_dw_tile<true, false, false>(tile, 1, C, dy, w, dx, g.Ho, g.Wo, H, W, k - 1 - g.pt, k - 1 - g.pl, nullptr, stream);
-    else launch_dw_tile<true, false, true>(tile, 1, C, dy, w, dx, g.Ho, g.Wo, H, W, k - 1 - g.pt, k - 1 - g.pl, nullptr, stream);
+  if (nblk) *nblk = 0;
+  const DwTile tile = dw_tile(N, H, W, 1);
+  const bool small = (long long)N * H * W * C * 4 < (1LL << 31) && tile.blocks < (1LL << 31);
+  const bool fuse = bn != nullptr && small && nblk != nullptr && part != nullptr && aligned16(part) && (size_t)tile.blocks * 2 * C <= part_floats;
+  // dx = dy (zero-interleaved when the layer has stride 2) correlated with the rotated filter, padding K-1-pt / K-1-pl: the LDS-tile
+  // kernel with FLIP (and DIL) -- for the 5x5 layers always, for the 3x3 layers (where it merely matches the sliding-window kernel)
+  // when the BN-backward statistics ride along
+  if (small && (k == 5 || fuse)) {
+    const int qt = k - 1 - g.pt, ql = k - 1 - g.pl;
+    if (fuse) {
+      if (stride == 1) launch_dw_tile<true, false, false, true>(tile, 1, C, dy, w, dx, g.Ho, g.Wo, H, W, qt, ql, part, stream, k, *bn);
+      else launch_dw_tile<true, false, true, true>(tile, 1, C, dy, w, dx, g.Ho, g.Wo, H, W, qt, ql, part, stream, k, *bn);
+      *nblk = (int)tile.blocks;
+    } else {
+      if (stride == 1) launch_dw_tile<true, false, false>(tile, 1, C, dy, w, dx, g.Ho, g.Wo, H, W, qt, ql, nullptr, stream, k);
+      else launch_dw_tile<true, false, true>(tile, 1, C, dy, w, dx, g.Ho, g.Wo, H, W, qt, ql, nullptr, stream, k);
+    }
     MLIIS_CHECK_LAUNCH("dwconv_bwd_data_tile");
     return MLIIS_OK;
   }
@@ -593,6 +637,21 @@ int mliis_dwconv_bwd_data(const float* dy, const float* w, float* dx, int N, int
   DW_DISPATCH(dwconv_bwd_data_k, dy, w, dx, N, H, W, g.Ho, g.Wo, C, g.pt, g.pl);
   MLIIS_CHECK_LAUNCH("dwconv_bwd_data");
   return MLIIS_OK;
+}
+
+int mliis_dwconv_bwd_data(const float* dy, const float* w, float* dx, int N, int H, int W, int C, int k, int stride,
+                          hipStream_t stream) {
+  return dw_bwd_data(dy, w, dx, N, H, W, C, k, stride, nullptr, nullptr, 0, nullptr, stream);
+}
+
+int mliis_dwconv_bwd_data_bn(const float* dy, const float* w, float* dx, int N, int H, int W, int C, int k, int stride, const float* bn_z,
+                             const float* bn_mean, const float* bn_rstd, const float* bn_gamma, const float* bn_beta, float* part,
+                             size_t part_floats, int* nblk, hipStream_t stream) {
+  MLIIS_REQUIRE(bn_z && bn_mean && bn_rstd && bn_gamma && bn_beta && part && nblk, MLIIS_ERR_ARG, "dwconv_bwd_data_bn: null pointer");
+  MLIIS_REQUIRE(aligned16(bn_z) && aligned16(bn_mean) && aligned16(bn_rstd) && aligned16(bn_gamma) && aligned16(bn_beta), MLIIS_ERR_ALIGN,
+                "dwconv_bwd_data_bn: pointers must be 16-byte aligned");
+  const DwBn bn{bn_z, bn_mean, bn_rstd, bn_gamma, bn_beta};
+  return dw_bwd_data(dy, w, dx, N, H, W, C, k, stride, &bn, part, part_floats, nblk, stream);
 }
 
 size_t mliis_dwconv_bwd_filter_workspace_floats(int N, int H, int W, int C, int k, int stride) {

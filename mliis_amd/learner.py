@@ -553,10 +553,10 @@ class Learner:
                 flush()
 
         def bn_b(xin, dy, st, prefix, dx, pre=False, post=False, img_scale=None, chan_scale=None, chan_add=None, dskip=None,
-                 dskip_accumulate=False, dxsum_part=None):
+                 dskip_accumulate=False, dxsum_part=None, stage1=None):
             ops.bn_bwd(xin, dy, st[0], st[1], w[prefix + "/gamma"], w[prefix + "/beta"], pre, post, img_scale, chan_scale, chan_add, dx=dx,
                        dgamma=g[prefix + "/gamma"], dbeta=g[prefix + "/beta"], ws=ws, dskip=dskip, dskip_accumulate=dskip_accumulate,
-                       dxsum_part=dxsum_part)
+                       dxsum_part=dxsum_part, stage1=stage1)
 
         rs = sorted([x.scope_index + 1 for x in a.rsd], reverse=True)
         for j in range(len(a.rsd) - 1, -1, -1):
@@ -639,8 +639,11 @@ class Learner:
             side(lambda dw_in=dw_in, da2=da2, b=b, nm=nm: ops.dwconv_bwd_filter(dw_in, da2, b.k, b.stride, partial=P.fold_part[nm["w_dw"]]))
             if b.expand != 1:
                 da0 = B["da0"]
-                ops.dwconv_bwd_data(da2, w[nm["w_dw"]], b.stride, (b.h_in, b.h_in), out=da0)
-                bn_b(B["z0"], da0, B["st0"], nm["bn0"], da0, post=True)
+                # the depthwise backward-data launch also emits stage 1 of bn0's backward (sums over (z0, da0)): no reduce pass
+                st0 = B["st0"]
+                _, nb1 = ops.dwconv_bwd_data(da2, w[nm["w_dw"]], b.stride, (b.h_in, b.h_in), out=da0, part=P.stats_part,
+                                             bn=(B["z0"], st0[0], st0[1], w[nm["bn0"] + "/gamma"], w[nm["bn0"] + "/beta"]))
+                bn_b(B["z0"], da0, st0, nm["bn0"], da0, post=True, stage1=(P.stats_part, nb1) if nb1 else None)
                 side(lambda B=B, da0=da0, nm=nm: ops.conv2d_bwd_filter(B["x_in"], da0, 1, 1, partial=P.fold_part[nm["w_exp"]]))
                 ops.conv2d_bwd_data(da0, w[nm["w_exp"]], 1, out=tgt, accumulate=tgt_has, ws=ws)
             else:

@@ -167,11 +167,21 @@ def dwconv_fwd(x, w, stride, out=None, stats_part=None):
     return out
 
 
-def dwconv_bwd_data(dy, w, stride, in_hw, out=None):
+def dwconv_bwd_data(dy, w, stride, in_hw, out=None, bn=None, part=None):
+    """bn = (z, mean, rstd, gamma, beta) with a float buffer `part`: the result is the gradient w.r.t. swish(bn(z)) and the launch also
+    leaves stage 1 of that batch norm's backward in `part`; returns (out, nblk) -- pass (part, nblk) to bn_bwd(stage1=...) when
+    nblk > 0."""
     N, _, _, C_ = dy.shape
     H, W = in_hw
     k = w.shape[0]
     out = torch.empty((N, H, W, C_), dtype=torch.float32, device=dy.device) if out is None else out
+    if bn is not None:
+        z, mean, rstd, gamma, beta = bn
+        nblk = C.c_int(0)
+        _chk(z)
+        lib.call("mliis_dwconv_bwd_data_bn", _ptr(_chk(dy)), _ptr(w), _ptr(out), N, H, W, C_, k, stride, _ptr(z), _ptr(mean), _ptr(rstd),
+                 _ptr(gamma), _ptr(beta), _ptr(part), part.numel(), C.byref(nblk), _stream())
+        return out, nblk.value
     # bwd algorithmic bytes (SURVEY 8(d)): read dY, read X, write dX, read W, write dW -- split here as data: dY + dX + W
     meta = dict(bytes=4.0 * (dy.numel() + out.numel() + k * k * C_), shape=(N, H, W, C_, k, stride)) if PROFILE is not None else {}
     _timed("dwconv_bwd_data", meta, lambda: lib.call("mliis_dwconv_bwd_data", _ptr(_chk(dy)), _ptr(w), _ptr(out), N, H, W, C_, k, stride, _stream()))
@@ -362,7 +372,8 @@ def bn_apply(x, mean, rstd, gamma, beta, pre_swish=False, post_swish=False, img_
 
 
 def bn_bwd(x, dy, mean, rstd, gamma, beta, pre_swish=False, post_swish=False, img_scale=None, chan_scale=None, chan_add=None, dx=None,
-           dgamma=None, dbeta=None, rows_per_img=None, ws: Optional[Workspace] = None, dskip=None, dskip_accumulate=False, dxsum_part=None):
+           dgamma=None, dbeta=None, rows_per_img=None, ws: Optional[Workspace] = None, dskip=None, dskip_accumulate=False, dxsum_part=None,
+           stage1=None):
     """dskip (optional): the pass also writes dskip (+)= dy, the gradient of an identity skip around the normalised branch.
     dxsum_part (optional, bn_bwd_dxsum_floats(rows, C) floats): per-row-chunk column sums of dx (slabs for fold_batched)."""
     rows, C_, ldx = rows_ld(x)
@@ -377,7 +388,8 @@ def bn_bwd(x, dy, mean, rstd, gamma, beta, pre_swish=False, post_swish=False, im
     lib.call("mliis_bn_bwd", _ptr(x), ldx, _ptr(dy), lddy, _ptr(dx), lddx, rows, C_, rpi, _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta),
              int(pre_swish), int(post_swish), _ptr(img_scale), _ptr(chan_scale), _ptr(chan_add), _ptr(dgamma), _ptr(dbeta), _ptr(dskip),
              rows_ld(dskip)[2] if dskip is not None else 0, int(dskip_accumulate), _ptr(dxsum_part),
-             dxsum_part.numel() if dxsum_part is not None else 0, _ptr(buf), buf.numel(), _stream())
+             dxsum_part.numel() if dxsum_part is not None else 0, _ptr(buf), buf.numel(),
+             _ptr(stage1[0]) if stage1 else None, int(stage1[1]) if stage1 else 0, _stream())
     return dx, dgamma, dbeta
 
 

@@ -619,3 +619,38 @@ def test_conv1x1_short_k_streaming_kernel(H, Cin, Cout, swish):
         ops.conv2d_bwd_data(f32(nhwc(dy), d), f32(w, d), 1, out=dxw[..., :Cin])
         close(dxw[..., :Cin], gx, 1e-4, "stream bwd data")
         assert (dxw[..., Cin:] == -3).all()
+
+
+@pytest.mark.parametrize("k,s,H,W,C", [(3, 1, 14, 14, 32), (3, 2, 16, 16, 24), (5, 1, 14, 14, 40), (5, 2, 28, 28, 16), (3, 2, 15, 17, 8), (5, 1, 7, 30, 144)])
+def test_dwconv_bwd_data_emits_bn_backward_stage1(k, s, H, W, C):
+    """mliis_dwconv_bwd_data_bn: same dx as the plain call, plus {sum g, sum g * xhat} partials that make mliis_bn_bwd skip its reduce
+    pass -- dx / dgamma / dbeta of the batch norm then equal the two-pass path and the float64 oracle."""
+    from mliis_amd import ops
+    d = dev()
+    N = 2
+    z = rnd(N, H, W, C, seed=100).requires_grad_(True)                    # expand conv output (the BN input)
+    gamma, beta = (rnd(C, seed=101) * 0.3 + 1.0).requires_grad_(True), (rnd(C, seed=102) * 0.2).requires_grad_(True)
+    wdw = rnd(k, k, C, 1, seed=103, scale=0.3)
+    mean = z.mean(dim=(0, 1, 2)).detach()
+    var = z.var(dim=(0, 1, 2), unbiased=False).detach()
+    rstd = 1.0 / torch.sqrt(var + 1e-3)
+    zh = (z - z.mean(dim=(0, 1, 2))) / torch.sqrt(z.var(dim=(0, 1, 2), unbiased=False) + 1e-3)
+    a = R.swish(zh * gamma + beta)                                        # batch-statistics BN + swish, as in training
+    y = R.conv2d_same(nchw(a), wdw, s, 1, groups=C)
+    dy = rnd(*y.shape, seed=104)
+    gz, gg, gb = torch.autograd.grad(y, [z, gamma, beta], dy)
+    dyg, wg = f32(nhwc(dy), d), f32(wdw, d)
+    part = torch.full((1 << 16,), 3.0, device=d)
+    ref_da = ops.dwconv_bwd_data(dyg, wg, s, (H, W))
+    da, nblk = ops.dwconv_bwd_data(dyg, wg, s, (H, W), bn=(f32(z, d), f32(mean, d), f32(rstd, d), f32(gamma, d), f32(beta, d)), part=part)
+    assert nblk > 0
+    close(da, ref_da, 1e-6, "dx with statistics == dx without")
+    args = (f32(z, d), da, f32(mean, d), f32(rstd, d), f32(gamma, d), f32(beta, d), False, True)
+    dx1, dg1, db1 = ops.bn_bwd(*args, stage1=(part, nblk))
+    dx2, dg2, db2 = ops.bn_bwd(*args)
+    close(dx1, dx2, 1e-5, "fused stage 1 == reduce pass (dx)")
+    close(dg1, dg2, 1e-5, "dgamma")
+    close(db1, db2, 1e-5, "dbeta")
+    close(dx1, gz, 2e-4, "dx vs oracle")
+    close(dg1, gg, 2e-4, "dgamma vs oracle")
+    close(db1, gb, 2e-4, "dbeta vs oracle")
