@@ -177,7 +177,7 @@ def roofline(L, args):
     dll = _lib.load()
     dw = {}
     for k in ("dwconv_fwd", "dwconv_bwd_data", "dwconv_bwd_filter"):
-        ksites = [(n, a) for n, a in calls if n == "mliis_" + k]
+        ksites = [(n, a) for n, a in calls if n == "mliis_" + k or (k == "dwconv_bwd_data" and n == "mliis_dwconv_bwd_data_bn")]
         if not ksites:
             continue
         kms, kbytes = 0.0, 0.0
@@ -196,6 +196,8 @@ def roofline(L, args):
                 ho, wo = same_pad(h, kk, st)[0], same_pad(w_, kk, st)[0]
                 i_el, o_el, w_el = nb * h * w_ * c, nb * ho * wo * c, kk * kk * c
                 kbytes += 4.0 * (i_el + o_el + w_el)   # fwd: X + Y + W; bwd-data: dY + dX + W; bwd-filter: X + dY + dW
+                if n.endswith("_bn"):
+                    kbytes += 4.0 * i_el               # ... + z0: the launch also produces the expand BN's backward statistics
         dw[k] = {"us_per_step": 1e3 * kms, "launches_per_step": len(ksites), "algorithmic_MB_per_step": kbytes / 1e6,
                  "GBps": kbytes / (kms * 1e-3) / 1e9, "frac_of_8TBps": kbytes / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS}
     families = {k: {"us_per_step": 1e3 * v["ms"] / reps, "launches_per_step": v["n"] // reps,

@@ -70,7 +70,7 @@ def main():
 
     def grid(items):
         return -(-items // 256) * 256
-    L += ["", "## Depthwise layers vs the HBM roofline (8.0 TB/s spec; algorithmic bytes = 4*(in+out+k*k*C) fwd, 4*(dY+dX+k*k*C) bwd-data)", "",
+    L += ["", "## Depthwise layers vs the HBM roofline (8.0 TB/s spec; algorithmic bytes = 4*(in+out+k*k*C) fwd, 4*(dY+dX+k*k*C) bwd-data, + 4*z0 for blocks 1-10 whose backward-data launch also reads z0 and emits the expand BN's backward statistics)", "",
           "| block | C | k,s | map | fwd us | fwd GB/s (% of 8 TB/s) | bwd-data us | bwd-data GB/s (%) |", "|---|---|---|---|---|---|---|---|"]
     tf = tb = bf = bb = 0.0
     for b in a.blocks:
@@ -82,25 +82,29 @@ def main():
         kf = [v for (k, g, gy), v in per.items() if (k.startswith("dwconv_fwd_k<%d, %d" % (b.k, b.stride)) and g == gf) or
               (k.startswith("dwconv_fwd_stats_k<%d, %d" % (b.k, b.stride)) and g == gs and gy == -(-b.cexp // 32))]
         kb = [v for (k, g, gy), v in per.items() if k.startswith("dwconv_bwd_data_k<%d, %d" % (b.k, b.stride)) and g == gb]
-        if b.k == 5:   # LDS-tile kernel: 7 x 16 output tiles (7 x 7 for the stride-2 forward); backward-data tiles the INPUT map
-            def tiles(h, tow):
-                return N * (-(-h // 7)) * (-(-h // tow)) * 256
-            cy = -(-b.cexp // 32)
-            kf += [v for (k, g, gy), v in per.items() if k.startswith("dwconv_tile_k<5, %d," % b.stride) and ", false, true, false>" in k and
-                   g == tiles(b.h_out, 16 if b.stride == 1 else 7) and gy == cy]
-            kb += [v for (k, g, gy), v in per.items() if k.startswith("dwconv_tile_k<5, 1,") and ", true, false, %s>" % ("true" if b.stride == 2 else "false") in k and
-                   g == tiles(b.h_in, 16) and gy == cy]
+        # LDS-tile kernel dwconv_tile_k<K, S, TOH, TOW, TS, FLIP, STATS, DIL, BNB>: 7 x 16 output tiles; forward of the stride-1 5x5
+        # layers, backward-data (tiles the INPUT map; DIL for stride-2 layers; BNB = with the expand BN's backward statistics)
+        def tiles(h, tow):
+            return N * (-(-h // 7)) * (-(-h // tow)) * 256
+        cy = -(-b.cexp // 32)
+        if b.k == 5 and b.stride == 1:
+            kf += [v for (k, g, gy), v in per.items() if k.startswith("dwconv_tile_k<5, 1,") and ", false, true, false, false>" in k and
+                   g == tiles(b.h_out, 16) and gy == cy]
+        dil = "true" if b.stride == 2 else "false"
+        kb += [v for (k, g, gy), v in per.items() if k.startswith("dwconv_tile_k<%d, 1," % b.k) and (", true, false, %s, " % dil) in k and
+               g == tiles(b.h_in, 16) and gy == cy]
         if not kf or not kb:
             continue
         mf = sorted(kf[0])[len(kf[0]) // 2] / 1e3
         mb = sorted(kb[0])[len(kb[0]) // 2] / 1e3
         by = 4.0 * (N * b.h_in ** 2 * b.cexp + N * b.h_out ** 2 * b.cexp + b.k ** 2 * b.cexp)
+        byb = by + (4.0 * N * b.h_in ** 2 * b.cexp if b.expand != 1 else 0.0)   # + z0 where the launch also does the BN statistics
         tf += mf
         tb += mb
         bf += by
-        bb += by
+        bb += byb
         L.append("| %d | %d | %d,%d | %d->%d | %.1f | %.0f (%.0f %%) | %.1f | %.0f (%.0f %%) |" % (
-            b.idx, b.cexp, b.k, b.stride, b.h_in, b.h_out, mf, by / mf / 1e3, by / mf / 1e3 / 80, mb, by / mb / 1e3, by / mb / 1e3 / 80))
+            b.idx, b.cexp, b.k, b.stride, b.h_in, b.h_out, mf, by / mf / 1e3, by / mf / 1e3 / 80, mb, byb / mb / 1e3, byb / mb / 1e3 / 80))
     if tf:
         L.append("| **all** | | | | %.1f | %.0f (%.0f %%) | %.1f | %.0f (%.0f %%) |" % (tf, bf / tf / 1e3, bf / tf / 1e3 / 80, tb, bb / tb / 1e3, bb / tb / 1e3 / 80))
     open(out, "w").write("\n".join(L) + "\n")
