@@ -165,6 +165,99 @@ __global__ __launch_bounds__(256) void stem_bwd_filter_k(const float* __restrict
   }
 }
 
+// Matrix-core version for Co <= 64 (EfficientNet-B0 / B3 stems: 32 / 40 channels): dW[tap][co] = sum_pixels win[pixel][tap] * dz[pixel][co]
+// is a [32 x pixels] x [pixels x Co] product (27 taps padded to 32).  A block stages the normalised windows of ALL its pixels in LDS in
+// one round (pixel coordinates first, so the 27 loads per pixel need no integer division), then every wave multiplies a quarter of the
+// pixels with v_mfma_f32_16x16x4_f32 -- lane (l15, g) feeds tap l15 (+16) of pixel p + g and channel l15 (+16 j) of the same pixel,
+// dz straight from memory -- and the four waves' tiles are added through LDS in a fixed order.  part layout [blk][27][Co].
+constexpr int kStemPix = 256;   // pixels per block (upper bound of pix_per_block)
+typedef float stem_f32x4 __attribute__((ext_vector_type(4)));
+
+template <int NTC>
+__global__ __launch_bounds__(256) void stem_bwd_filter_mfma_k(const float* __restrict__ x, const int* __restrict__ idx,
+                                                              const float* __restrict__ dz, float* __restrict__ part, int N, int H, int W,
+                                                              int Ho, int Wo, int Co, int pt, int pl, Norm3 nm, int pix_per_block) {
+  __shared__ int s_base[kStemPix], s_h0[kStemPix], s_w0[kStemPix];
+  __shared__ float swin[kStemPix * 32];
+  __shared__ float red[4][32][16 * NTC + 1];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l15 = lane & 15, g = lane >> 4;
+  const long long P = (long long)N * Ho * Wo;
+  const long long p0 = (long long)blockIdx.x * pix_per_block;
+  const int npix = (int)((p0 + pix_per_block > P ? P : p0 + pix_per_block) - p0);
+  if (t < npix) {
+    const long long pix = p0 + t;
+    const int wo = (int)(pix % Wo);
+    const long long r = pix / Wo;
+    const int ho = (int)(r % Ho), n = (int)(r / Ho);
+    s_base[t] = (idx ? idx[n] : n) * H * W * 3;     // host guarantees the image tensor is below 2^31 floats
+    s_h0[t] = ho * 2 - pt;
+    s_w0[t] = wo * 2 - pl;
+  }
+  __syncthreads();
+  // window staging: thread = (tap = t & 31, pixel row t >> 5); eight pixels per thread and round trip, loads issued together
+  {
+    const int tap = t & 31, prow = t >> 5;
+    const int ky = tap / 9, rem = tap - ky * 9, kx = rem / 3, ci = rem - kx * 3;
+    const float mu = ci == 0 ? nm.m0 : (ci == 1 ? nm.m1 : nm.m2), sg = ci == 0 ? nm.i0 : (ci == 1 ? nm.i1 : nm.i2);
+    constexpr int U = 8;
+    for (int i0 = 0; i0 < npix; i0 += 8 * U) {
+      float v[U];
+      bool ok[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int pp = i0 + prow + 8 * u;
+        const int ps = pp < npix ? pp : 0;
+        const int hi = s_h0[ps] + ky, wi = s_w0[ps] + kx;
+        ok[u] = pp < npix && tap < 27 && hi >= 0 && hi < H && wi >= 0 && wi < W;
+        v[u] = x[ok[u] ? (long long)s_base[ps] + ((long long)hi * W + wi) * 3 + ci : 0];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int pp = i0 + prow + 8 * u;
+        // TF divides by std; (x - m) / s is restated as a true division to stay within 1 ulp of it
+        if (pp < npix) swin[pp * 32 + tap] = ok[u] ? (v[u] - mu) / sg : 0.f;
+      }
+    }
+  }
+  __syncthreads();
+  stem_f32x4 acc[2][NTC];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NTC; ++j) acc[i][j] = (stem_f32x4){0.f, 0.f, 0.f, 0.f};
+  const int per_wave = (npix + 3) / 4;
+  const int w0 = wave * per_wave, w1 = w0 + per_wave < npix ? w0 + per_wave : npix;
+  for (int pb = w0; pb < w1; pb += 4) {
+    const int pp = pb + g;
+    const bool ok = pp < w1;
+    const int ps = ok ? pp : w0;
+    const float a0 = ok ? swin[ps * 32 + l15] : 0.f, a1 = ok ? swin[ps * 32 + 16 + l15] : 0.f;
+    float b[NTC];
+#pragma unroll
+    for (int j = 0; j < NTC; ++j) {
+      const int co = j * 16 + l15;
+      b[j] = (ok && co < Co) ? dz[(p0 + ps) * Co + co] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < NTC; ++j) {
+      acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b[j], acc[0][j], 0, 0, 0);
+      acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b[j], acc[1][j], 0, 0, 0);
+    }
+  }
+  // C/D layout: column l15, rows 4 g + r
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NTC; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[wave][i * 16 + g * 4 + r][j * 16 + l15] = acc[i][j][r];
+  __syncthreads();
+  for (int e = t; e < 27 * Co; e += 256) {
+    const int tap = e / Co, co = e - tap * Co;
+    part[(long long)blockIdx.x * 27 * Co + e] = (red[0][tap][co] + red[1][tap][co]) + (red[2][tap][co] + red[3][tap][co]);
+  }
+}
+
 static inline int stem_quad_pad(int Co) {
   int qp = 1;
   while (qp < Co / 4) qp <<= 1;
@@ -220,6 +313,16 @@ int mliis_stem_conv_bwd_filter(const float* x, const int* img_idx, const float* 
   stem_filter_geom(N, g.Ho, g.Wo, Co, &ppb, &nblk);
   MLIIS_REQUIRE((size_t)nblk * 27 * Co <= ws_floats, MLIIS_ERR_WORKSPACE, "stem_conv_bwd_filter: workspace too small");
   Norm3 nm{mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]};
+  if (Co <= 64 && ppb <= kStemPix && (long long)N * H * W * 3 < (1LL << 31)) {   // matrix-core kernel (same slab layout)
+    if (Co <= 32) hipLaunchKernelGGL(stem_bwd_filter_mfma_k<2>, dim3(nblk), dim3(256), 0, stream, x, img_idx, dz, ws, N, H, W, g.Ho, g.Wo, Co, g.pt, g.pl, nm, ppb);
+    else if (Co <= 48) hipLaunchKernelGGL(stem_bwd_filter_mfma_k<3>, dim3(nblk), dim3(256), 0, stream, x, img_idx, dz, ws, N, H, W, g.Ho, g.Wo, Co, g.pt, g.pl, nm, ppb);
+    else hipLaunchKernelGGL(stem_bwd_filter_mfma_k<4>, dim3(nblk), dim3(256), 0, stream, x, img_idx, dz, ws, N, H, W, g.Ho, g.Wo, Co, g.pt, g.pl, nm, ppb);
+    MLIIS_CHECK_LAUNCH("stem_conv_bwd_filter_mfma");
+    if (dw == nullptr) return MLIIS_OK;
+    hipLaunchKernelGGL(fold_flat_k, dim3(ceil_div(27 * Co, kFoldX)), dim3(kFoldX, kFoldY), 0, stream, ws, nblk, (long long)27 * Co, 1.0f, dw, 0, (long long)27 * Co, 0LL, 0LL);
+    MLIIS_CHECK_LAUNCH("stem_conv_bwd_filter_finalize");
+    return MLIIS_OK;
+  }
   const size_t lds = (size_t)4 * 27 * (Co / 4) * sizeof(float4) + (size_t)(256 / stem_quad_pad(Co)) * 27 * sizeof(float);
   hipLaunchKernelGGL(stem_bwd_filter_k, dim3(nblk), dim3(256), lds, stream, x, img_idx, dz, ws, N, H, W, g.Ho, g.Wo, Co,
                      g.pt, g.pl, nm, ppb, stem_quad_pad(Co));
