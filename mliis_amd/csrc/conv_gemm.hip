@@ -201,7 +201,8 @@ static inline void plan_filter_split(FilterPlan& f, long long M, int C, int Nout
   }
   if (want < 1) want = 1;
   long long rps = (M + want - 1) / want;
-  if (rps < 64) rps = 64;   // at least two 32-row steps per slab (measured: 32 is no faster, 128+ slower -- the kernel is latency-bound)
+  if (rps < 128) rps = 128;   // (whole step on one box: 32 -> 2395, 64 -> 2404, 96 -> 2409, 128 -> 2416, 192 -> 2408, 256 -> 2406 images/s:
+                               //  fewer, longer slabs on the 14x14 layers also halve what the batched fold has to read)
   rps = (rps + 31) / 32 * 32;
   f.rows_per_split = (int)rps;
   f.gz = (int)((M + rps - 1) / rps);
