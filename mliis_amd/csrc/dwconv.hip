@@ -493,7 +493,8 @@ static inline DwFilterGeom dw_filter_geom(int N, int Ho, int Wo, int C, int TW) 
   long long items = (long long)N * Ho * ((Wo + TW - 1) / TW);
   // measured (tools/dwf_sweep.py): the kernel is latency-bound on every EfficientLab layer -- as many blocks as there are strips to
   // hand out (one strip per thread on the small maps) beats longer per-thread walks by 1.4-2x; the extra slabs go to the batched fold
-  long long want = 1024 / g.ny;
+  long long want = 512 / g.ny;   // (whole step on one box: 128 -> 2395, 256 -> 2418, 384 -> 2414, 512 -> 2429, 768 -> 2417, 1024 -> 2407,
+                                 //  2048 -> 2411 images/s: the slabs are read again by the batched fold)
   if (want < 1) want = 1;
   long long ipb = (items + want - 1) / want;
   long long minr = (long long)g.RP;
