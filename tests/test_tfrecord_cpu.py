@@ -84,3 +84,31 @@ def test_task_semantics_and_split(tmp_path, golden):
         t.sample(9)
     assert len(T.fss_test_task_ids()) == 240 and T.fp_k_test_task_ids() == golden["fp_k_test_tasks"]
     assert T.fss_test_task_ids() == golden["fss_test_tasks"]
+
+
+def test_fp_k_shot_reader_pools_the_shards_of_a_task(tmp_path):
+    """read_fp_k_shot_dataset (metaseg.py:124-179): one task per synonym set, pooling every shard whose name contains a synonym."""
+    sizes = {"aeroplane": 3, "airliner": 2, "bus": 4, "motorbike": 1, "potted_plant": 2, "television": 3, "tvmonitor": 1, "zebra": 5}
+    for i, (n, k) in enumerate(sizes.items()):
+        _shard(str(tmp_path / (n + ".tfrecord.gzip")), k, 8, 30 + i)
+    tasks, names = T.read_fp_k_shot_dataset(str(tmp_path), image_size=8)
+    assert len(tasks) == len(names) == 5
+    by = {frozenset(s): t for s, t in zip(T.DEFAULT_K_SHOT_SET, tasks)}
+    assert by[frozenset({"airliner", "aeroplane"})].batch_size == 5 and by[frozenset({"bus"})].batch_size == 4
+    assert by[frozenset({"television", "tvmonitor"})].batch_size == 4 and by[frozenset({"potted_plant", "potted plant"})].batch_size == 2
+    t = by[frozenset({"airliner", "aeroplane"})]
+    assert t.name in ("airliner", "aeroplane")
+    x, y = t.sample(5)
+    assert x.shape == (5, 8, 8, 3) and y.shape == (5, 8, 8, 2)
+    with pytest.raises(ValueError):
+        t.sample(6)
+    with pytest.raises(ValueError):
+        T.read_fp_k_shot_dataset(str(tmp_path), all_task_names=[{"unicorn"}], image_size=8)
+
+
+def test_k_shot_experiment_sizes_the_resident_task():
+    from mliis_amd.args import argument_parser, model_kwargs
+    a = argument_parser().parse_args(["--run_k_shot_learning_curves_experiment", "--checkpoint", "c"])
+    assert model_kwargs(a)["max_shots"] == 420                      # 400-shot pool + 20 held-out examples
+    a = argument_parser().parse_args(["--run_k_shot_learning_curves_experiment", "--k-shot-range", "1", "5", "--k-shot-test-samples", "4", "--checkpoint", "c"])
+    assert model_kwargs(a)["max_shots"] == 16 and model_kwargs(a)["matmul_precision"] == "fp32"
