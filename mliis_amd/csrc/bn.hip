@@ -658,6 +658,15 @@ __global__ __launch_bounds__(256) void fold_batched_k(const float* __restrict__ 
   if (i < total) {
     if (vec) {
       int k = sl;
+      // many slabs, few outputs (stem: 448 slabs of 864 floats; 32-channel depthwise filters: 512 slabs of 288): sixteen loads in
+      // flight per lane, or the handful of blocks that fold them are a 30-round-trip critical path of the whole launch
+      for (; k + 60 < nblk; k += 64) {
+        float4 v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = ld4(p + (long long)(k + 4 * u) * total);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { a0 += v[u].x; a1 += v[u].y; a2 += v[u].z; a3 += v[u].w; }
+      }
       for (; k + 12 < nblk; k += 16) {
         float4 v[4];
 #pragma unroll
