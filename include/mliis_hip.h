@@ -75,7 +75,7 @@ int mliis_dwconv_bwd_filter(const float* x, const float* dy, float* dw, int N, i
 size_t mliis_conv2d_workspace_floats(int Nimg, int H, int W, int Cred, int Nout, int ksize);
 /*      operand precision of the matrix cores for every later dense-conv call (process-wide): 0 = fp32 operands (default; BASELINE
  *      configs 1-3), 1 = bf16 operands converted on the fly from the fp32 tensors with fp32 accumulation (configs 4-5 flavour:
- *      tensors, BN, depthwise and the optimiser stay fp32) */
+ *      tensors, BN, depthwise, the optimiser and the memory-bound short-K 1x1 convs (K <= 112) stay fp32) */
 int mliis_set_matmul_precision(int bf16);
 int mliis_get_matmul_precision(void);
 /*      tiling chosen for a fwd / bwd-data call (row-tile factor, column tiles, split-K factor) and the name of the kernel

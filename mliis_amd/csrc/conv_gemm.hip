@@ -331,7 +331,7 @@ int mliis_conv2d_plan(int Nimg, int H, int W, int Cred, int Nout, int ksize, int
 int mliis_conv2d_kernel_name(int Nimg, int H, int W, int Cred, int Nout, int ksize, int has_scale, char* buf, size_t buf_len) {
   MLIIS_REQUIRE(buf && buf_len >= 64, MLIIS_ERR_ARG, "conv2d_kernel_name: buffer too small");
   StreamPlan sp;
-  if (ksize == 1 && !g_matmul_bf16 && !has_scale && stream_plan((long long)Nimg * H * W, Cred, Nout, num_cus(), &sp)) {
+  if (ksize == 1 && !has_scale && stream_plan((long long)Nimg * H * W, Cred, Nout, num_cus(), &sp)) {
     snprintf(buf, buf_len, "conv1x1_stream_k<%d, %d>", sp.kc, sp.nt);   // (a call without accumulate / border bias)
     return MLIIS_OK;
   }
@@ -375,7 +375,8 @@ int mliis_conv2d_fwd(const float* x, int ldx, const float* x_scale, const float*
   if (stats_nblk) *stats_nblk = 0;
   {  // short-K 1x1 convs (the MBConv expand convs): barrier-free streaming kernel
     StreamPlan sp;
-    if (ksize == 1 && !g_matmul_bf16 && x_scale == nullptr && border_bias == nullptr && !accumulate && M * ldx * 4 < (1LL << 31) &&
+    // (also under bf16 matrix-core operands: these launches are memory-bound, fp32 operands cost nothing there and are more accurate)
+    if (ksize == 1 && x_scale == nullptr && border_bias == nullptr && !accumulate && M * ldx * 4 < (1LL << 31) &&
         M * ldy * 4 < (1LL << 31) && stream_plan(M, Cin, Cout, num_cus(), &sp)) {
       MLIIS_REQUIRE(stats_part == nullptr || stats_nblk, MLIIS_ERR_ARG, "conv2d_fwd: fused statistics need a stats_nblk output");
       p.stats_part = stats_part;
@@ -440,7 +441,7 @@ int mliis_conv2d_bwd_data(const float* dy, int lddy, const float* w, float* dx, 
                    Cout, Cin_out, dx, lddx, nullptr, accumulate, nullptr, g.chunks_per_split, nullptr, 0, nullptr, nullptr};
   {  // short-K 1x1 convs (backward-data of the MBConv project convs): barrier-free streaming kernel
     StreamPlan sp;
-    if (ksize == 1 && !g_matmul_bf16 && !accumulate && M * lddx * 4 < (1LL << 31) && stream_plan(M, Cout, Cin_out, num_cus(), &sp) &&
+    if (ksize == 1 && !accumulate && M * lddx * 4 < (1LL << 31) && stream_plan(M, Cout, Cin_out, num_cus(), &sp) &&
         launch_stream(sp, p, stream)) {
       MLIIS_CHECK_LAUNCH("conv2d_bwd_data_stream");
       return MLIIS_OK;
