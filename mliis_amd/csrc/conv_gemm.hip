@@ -240,7 +240,7 @@ static void launch_filter(const FilterPlan& f, const FilterGradParams& p, hipStr
 }
 
 // ------------------------------------------------------------------------------------------------ short-K 1x1 convs (conv1x1_stream_k)
-// KC = 16-wide K groups (K <= 112), NT = column tiles per wave, KC * NT <= 24 (the B fragments live in registers)
+// KC = 16-wide K groups (K <= 112), NT = column tiles per wave, KC * NT <= 8 (the B fragments live in registers)
 struct StreamPlan {
   int kc, nt, gx, gy, row_groups;
 };
@@ -248,7 +248,10 @@ static inline bool stream_plan(long long M, int K, int Nout, int num_cus, Stream
   // (whole step, one box: off 2335, K <= 96 / M >= 2048: 2352, K <= 112 / M >= 1024: 2359 images/s; the 14x14 layers have M = 1568)
   if (K > 112 || M < 1024 || M >= (1LL << 27)) return false;
   sp->kc = (K + 15) / 16;
-  int nt = 24 / sp->kc;
+  // column tiles per wave: KC * NT <= 8 B-fragment quads in registers.  (Whole step on one box: cap 24 -> 2426, 16 -> 2440, 8 -> 2443,
+  // 4 -> 2447, 2 -> 2439 images/s: more column blocks = more waves in flight beats fewer re-reads of A.)
+  int nt = 8 / sp->kc;
+  if (nt < 1) nt = 1;
   if (nt > 8) nt = 8;
   const int tiles = (Nout + 15) / 16;
   if (nt > tiles) nt = tiles;
@@ -267,12 +270,12 @@ static bool launch_stream(const StreamPlan& sp, const ConvGemmParams& p, hipStre
 #define S(KC_, NT_) hipLaunchKernelGGL((conv1x1_stream_k<KC_, NT_>), grid, block, 0, stream, p, sp.row_groups); break;
   switch (sp.kc) {
     case 1: switch (sp.nt) { case 1: S(1, 1) case 2: S(1, 2) case 3: S(1, 3) case 4: S(1, 4) case 5: S(1, 5) case 6: S(1, 6) case 7: S(1, 7) case 8: S(1, 8) default: return false; } break;
-    case 2: switch (sp.nt) { case 1: S(2, 1) case 2: S(2, 2) case 3: S(2, 3) case 4: S(2, 4) case 5: S(2, 5) case 6: S(2, 6) case 7: S(2, 7) case 8: S(2, 8) default: return false; } break;
-    case 3: switch (sp.nt) { case 1: S(3, 1) case 2: S(3, 2) case 3: S(3, 3) case 4: S(3, 4) case 5: S(3, 5) case 6: S(3, 6) case 7: S(3, 7) case 8: S(3, 8) default: return false; } break;
-    case 4: switch (sp.nt) { case 1: S(4, 1) case 2: S(4, 2) case 3: S(4, 3) case 4: S(4, 4) case 5: S(4, 5) case 6: S(4, 6) default: return false; } break;
-    case 5: switch (sp.nt) { case 1: S(5, 1) case 2: S(5, 2) case 3: S(5, 3) case 4: S(5, 4) default: return false; } break;
-    case 6: switch (sp.nt) { case 1: S(6, 1) case 2: S(6, 2) case 3: S(6, 3) case 4: S(6, 4) default: return false; } break;
-    case 7: switch (sp.nt) { case 1: S(7, 1) case 2: S(7, 2) case 3: S(7, 3) default: return false; } break;
+    case 2: switch (sp.nt) { case 1: S(2, 1) case 2: S(2, 2) case 3: S(2, 3) case 4: S(2, 4) default: return false; } break;
+    case 3: switch (sp.nt) { case 1: S(3, 1) case 2: S(3, 2) default: return false; } break;
+    case 4: switch (sp.nt) { case 1: S(4, 1) case 2: S(4, 2) default: return false; } break;
+    case 5: switch (sp.nt) { case 1: S(5, 1) default: return false; } break;
+    case 6: switch (sp.nt) { case 1: S(6, 1) default: return false; } break;
+    case 7: switch (sp.nt) { case 1: S(7, 1) default: return false; } break;
     default: return false;
   }
 #undef S
