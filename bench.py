@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--aspp", action="store_true", help="variant: ASPP decoder in front of the RSD modules (--spatial_pyramid_pooling)")
     ap.add_argument("--augment", action="store_true", help="variant: host augmentation of every inner-loop batch (the reference's run.sh setting)")
     ap.add_argument("--augment-workers", type=int, default=-1, help="worker processes for the augmentation pixel work (0 = inline, -1 = cores - 1)")
+    ap.add_argument("--concurrent-tasks", type=int, default=1,
+                    help="variant (with --tasks-per-gpu > 1): adapt this many tasks of the meta-batch at once on separate learners / streams")
     ap.add_argument("--tasks-per-gpu", type=int, default=1, help="variant: tasks per GPU and meta-step (the metric's config has 1)")
     ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32",
                     help="variant: bf16 operands on the matrix cores (fp32 accumulation, fp32 tensors); the headline metric is fp32")
@@ -240,15 +242,19 @@ def _run(args):
     shots = 10 if args.foml else args.shots
     L = Learner(feature_extractor_name=args.backbone, image_size=args.image_size, rsd=(2, 4), learning_rate=1e-3, optimizer="sgd", dice=False, l2=False, seed=0, device=device,
                 use_graph=not args.no_graph, max_shots=max(16, shots), spatial_pyramid_pooling=args.aspp, matmul_precision=args.precision)
+    lanes = [Learner(feature_extractor_name=args.backbone, image_size=args.image_size, rsd=(2, 4), learning_rate=1e-3, optimizer="sgd", dice=False,
+                     l2=False, seed=k, device=device, use_graph=not args.no_graph, max_shots=max(16, shots),
+                     spatial_pyramid_pooling=args.aspp, matmul_precision=args.precision) for k in range(1, args.concurrent_tasks)]
     tasks = []
     for i in range(args.pool):
         x, y = synthetic_task(shots, args.image_size, seed=1000 * rank + i)
         tasks.append(DeviceTask("synthetic_%d_%d" % (rank, i), torch.from_numpy(x).to(device), torch.from_numpy(y).to(device)))
     D = Dist()
     if args.foml:
-        meta = FOMLIS(L, train_shots=shots, tail_shots=5, dist=D, rng_mode="per_task", seed=0, augment=args.augment, aug_rate=0.5, aug_pool=aug_pool)
+        meta = FOMLIS(L, train_shots=shots, tail_shots=5, dist=D, rng_mode="per_task", seed=0, augment=args.augment, aug_rate=0.5, aug_pool=aug_pool,
+                      lanes=lanes)
     else:
-        meta = Gecko(L, dist=D, rng_mode="per_task", seed=0, augment=args.augment, aug_rate=0.5, aug_pool=aug_pool)
+        meta = Gecko(L, dist=D, rng_mode="per_task", seed=0, augment=args.augment, aug_rate=0.5, aug_pool=aug_pool, lanes=lanes)
 
     def step():
         meta.train_step(tasks, num_shots=shots, inner_batch_size=args.inner_batch, inner_iters=args.inner_iters, replacement=False,
@@ -291,7 +297,8 @@ def _run(args):
                                                                  ("" if args.precision == "fp32" else ", bf16 matrix-core operands") +
                                                                  ((", host augmentation (aug_rate 0.5, %s)" % ("%d worker processes" % aug_pool.workers if aug_pool else "inline"))
                                                                   if args.augment else "") +
-                                                                 (", %d tasks per GPU and meta-step" % args.tasks_per_gpu if args.tasks_per_gpu != 1 else "")),
+                                                                 (", %d tasks per GPU and meta-step" % args.tasks_per_gpu if args.tasks_per_gpu != 1 else "") +
+                                                                 (", %d adapted concurrently" % args.concurrent_tasks if args.concurrent_tasks != 1 else "")),
                        "hip_graph": not args.no_graph, "final_loss": loss},
             "roofline": roof, "cpu_baseline": cpu,
         }

@@ -200,6 +200,7 @@ class Learner:
         self.drop_connect = drop_connect
         self.use_graph = use_graph
         self.stream = torch.cuda.Stream(device=self.device)
+        self._dc_keeps = None
         # Optional (overlap_wgrad = 1 | 2): weight-gradient GEMMs on a second stream forked inside the HIP graph, one by one (1) or
         # handed over at a few points of the backward pass (2, wgrad_flush_before = block indices).  Neither beats the single stream
         # on MI355X (profiles/r01_notes.md), so it is off by default.
@@ -741,7 +742,10 @@ class Learner:
                         else:
                             B["dc"].copy_(torch.as_tensor(v, dtype=torch.float32))
             else:
-                keeps = torch.tensor([1.0 - b.drop_rate for b in ex if b.skip], dtype=torch.float32, device=self.device)[:, None]
+                if self._dc_keeps is None:   # constant of the architecture: uploaded once (an upload per step would make the host
+                    # wait for the previous step of this stream before it can queue the next one)
+                    self._dc_keeps = torch.tensor([1.0 - b.drop_rate for b in ex if b.skip], dtype=torch.float32, device=self.device)[:, None]
+                keeps = self._dc_keeps
                 if keeps.numel():
                     u = torch.rand(P.dc_all.shape, generator=self.rng, device=self.device)
                     P.dc_all.copy_(torch.floor(keeps + u) / keeps)   # utils.py:159-170

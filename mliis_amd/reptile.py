@@ -66,8 +66,17 @@ class Gecko:
 
     def __init__(self, learner, variables=None, transductive: bool = False, pre_step_op=None, lr_scheduler=None, augment: bool = False,
                  aug_rate: Optional[float] = None, dist: Optional[Dist] = None, rng_mode: Optional[str] = None, seed: int = 0,
-                 aug_pool=None):
+                 aug_pool=None, lanes: Sequence = ()):
         self.learner = learner
+        # lanes: further Learners of the same architecture (own arenas, own streams).  The tasks of a meta-batch that fall on this
+        # rank are then adapted len(lanes)+1 at a time, their inner steps issued round-robin so the launches of one task fill the
+        # compute units the other leaves idle (one 8-image step alone does not fill 256 CUs: profiles/r01_notes.md).  Same update as
+        # task-by-task -- the tasks are independent and the deltas are accumulated in task order -- except that every lane draws its
+        # drop-connect masks from its own generator.
+        self.lanes = list(lanes)
+        for ln in self.lanes:
+            if ln.n_trainable != learner.n_trainable or ln.optimizer != "sgd" or learner.optimizer != "sgd":
+                raise ValueError("lanes must share the learner's architecture and use the SGD inner optimizer (Adam keeps per-learner state)")
         self._transductive = transductive
         # pre_step_op: the reference passes a TF op that multiplies all trainables by `weight_decay_rate`
         # (variables.py:48-55); here it is that rate (float) or None.
@@ -148,6 +157,10 @@ class Gecko:
                     rng = self._rng(t)
                     self._sample(dataset, num_shots, rng)
                     ahead[t] = self._augmented_task_schedule(inner_batch_size, inner_iters, replacement, rng, t)
+            if self.lanes and self.augmenter is None:
+                self._adapt_concurrently(mine, dataset, num_shots, inner_batch_size, inner_iters, replacement, meta_batch_size, lr, fomaml,
+                                         old, delta, bn_acc)
+                mine = []
             for t in mine:
                 if self.augmenter is None:
                     rng = self._rng(t)
@@ -177,11 +190,46 @@ class Gecko:
             L.import_bn(bn_acc)
         self.meta_iter += 1
 
+    def _adapt_concurrently(self, mine, dataset, num_shots, inner_batch_size, inner_iters, replacement, meta_batch_size, lr, fomaml,
+                            old, delta, bn_acc):
+        """The task loop of _run_meta_batch over several learners at once (called inside the main learner's comm_context, so the
+        export_* / import_* / axpby calls below order the lanes' streams against the main learner's)."""
+        L = self.learner
+        lanes = [L] + self.lanes
+        decay, T = BN_MOMENTUM, inner_iters
+        for g0 in range(0, len(mine), len(lanes)):
+            group = []
+            for lane, t in zip(lanes, mine[g0:g0 + len(lanes)]):   # host draws in task order, like the sequential loop
+                rng = self._rng(t)
+                images, labels = metaseg.sample_task(dataset, num_shots, rng)
+                if lane is not L:   # sampled on the main learner's stream, consumed on the lane's
+                    for a in (images, labels):
+                        if torch.is_tensor(a) and a.is_cuda:
+                            a.record_stream(lane.stream)
+                lane.load_task(images, labels)
+                batches = self._task_batches(int(images.shape[0]), inner_batch_size, inner_iters, replacement, rng)
+                if lane is not L:
+                    lane.import_trainable(old)
+                lane.import_bn(self._bn_zero)
+                group.append([lane, t, list(batches), None])
+            for j in range(max(len(g[2]) for g in group)):
+                for g in group:
+                    lane, _, batches, _ = g
+                    if j < len(batches):
+                        if fomaml and j == inner_iters - 1:
+                            g[3] = lane.export_trainable()
+                        self._step(batches[j], j, lr, lane)
+            for lane, t, _, last_backup in group:
+                L.axpby(1.0, lane.export_trainable(), 1.0, delta)
+                L.axpby(-1.0, last_backup if fomaml else old, 1.0, delta)
+                L.axpby(decay ** ((meta_batch_size - 1 - t) * T), lane.export_bn(), 1.0, bn_acc)
+            L.import_trainable(old)
+
     def _task_batches(self, n_shots, inner_batch_size, inner_iters, replacement, rng):
         return self._batches(n_shots, inner_batch_size, inner_iters, replacement, rng)
 
-    def _step(self, idx, j, lr):
-        L = self.learner
+    def _step(self, idx, j, lr, L=None):
+        L = L or self.learner
         wd = self._pre_step_rate
         if lr is not None:  # reptile.py:114-116 -- first optimizer step with the given lr
             L.inner_step(idx, lr=lr, weight_decay_rate=wd)
@@ -444,12 +492,13 @@ class FOMLIS(Gecko):
     def _task_batches(self, n_shots, inner_batch_size, inner_iters, replacement, rng):
         return metaseg.fomaml_batch_indices(n_shots, self.tail_shots, inner_batch_size, inner_iters, replacement, rng)
 
-    def _step(self, idx, j, lr):
+    def _step(self, idx, j, lr, L=None):
+        L = L or self.learner
         wd = self._pre_step_rate
         if lr is not None:  # reptile.py:639-641
-            self.learner.inner_step(idx, lr=lr, weight_decay_rate=wd)
+            L.inner_step(idx, lr=lr, weight_decay_rate=wd)
         else:  # :642-643 (the scheduler is never consulted: quirk E9)
-            self.learner.inner_step(idx, weight_decay_rate=wd)
+            L.inner_step(idx, weight_decay_rate=wd)
 
     def train_step(self, dataset, num_classes=1, num_shots=5, inner_batch_size=8, inner_iters=8, replacement=False, meta_step_size=0.1,
                    meta_batch_size=1, verbose=False, lr=None, **_unused_tf_handles):
