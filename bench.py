@@ -15,6 +15,10 @@ import os
 import sys
 import time
 
+# HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); concurrent task lanes (--concurrent-tasks)
+# want one queue each next to torch's own streams.  Read when the HIP runtime loads, so set before `import torch`.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

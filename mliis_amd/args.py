@@ -104,6 +104,9 @@ _EXT = [
                                     help="skip the evaluation pass over the meta-TRAIN tasks that the reference always runs before the test tasks")),
     ("--augment-workers", dict(type=int, default=-1,
                                help="worker processes for the pixel half of --augment (-1: host cores - 1, 0: inline like the reference)")),
+    ("--concurrent-tasks", dict(type=int, default=1,
+                                help="adapt this many tasks of a meta-batch at once on separate learners / streams (same meta-update; "
+                                     "4 is the optimum on MI355X, needs meta_batch_size / ranks >= 2 to matter)")),
     ("--matmul-precision", dict(choices=["fp32", "bf16"], default="fp32",
                                 help="operand precision of the matrix cores in the dense convs (bf16: fp32 tensors rounded on the fly, fp32 accumulation)")),
     ("--checkpoint-format", dict(choices=["npz", "tf"], default="npz",

@@ -206,7 +206,13 @@ class Learner:
         # on MI355X (profiles/r01_notes.md), so it is off by default.
         self.overlap_wgrad = int(overlap_wgrad)
         self.wgrad_flush_before = set(int(v) for v in wgrad_flush_before)
-        self.side_stream = torch.cuda.Stream(device=self.device)
+        # created only when used: HIP multiplexes a process's streams onto a few hardware queues, and the lanes of a concurrent
+        # meta-batch (reptile.Gecko lanes) want one each
+        self.side_stream = torch.cuda.Stream(device=self.device) if self.overlap_wgrad else None
+        # batch indices go up through a ring of pinned slots: an upload from pageable memory makes the host wait for this stream
+        self._idx_pin = torch.empty((16, 64), dtype=torch.int32).pin_memory()
+        self._idx_ev = [None] * 16
+        self._idx_n = 0
         self.arena = Arena(self.arch, self.device)
         self.arena.init_weights(seed)
         self.variables_initialized = True
@@ -698,7 +704,19 @@ class Learner:
         P = self._plan(N)
         ops.set_matmul_precision(self.matmul_precision)   # the library switch is process-wide: re-assert this learner's choice
         with torch.cuda.stream(self.stream):
-            P.idx.copy_(torch.tensor(list(batch_idx), dtype=torch.int32), non_blocking=True)
+            if N <= self._idx_pin.shape[1]:
+                slot = self._idx_n % len(self._idx_ev)
+                self._idx_n += 1
+                if self._idx_ev[slot] is not None:
+                    self._idx_ev[slot].synchronize()   # the upload that last used this slot (16 steps ago) has been consumed
+                else:
+                    self._idx_ev[slot] = torch.cuda.Event()
+                src = self._idx_pin[slot, :N]
+                src.copy_(torch.tensor(list(batch_idx), dtype=torch.int32))
+                P.idx.copy_(src, non_blocking=True)
+                self._idx_ev[slot].record(self.stream)
+            else:
+                P.idx.copy_(torch.tensor(list(batch_idx), dtype=torch.int32), non_blocking=True)
             self.lr_dev.fill_(self.lr if lr is None else float(lr))
             if weight_decay_rate != 1.0:  # pre_step_op (variables.py:48-55)
                 ops.axpby(0.0, None, float(weight_decay_rate), self.arena.theta)

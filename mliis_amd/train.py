@@ -44,14 +44,14 @@ def train_gecko(learner, train_set, test_set, save_dir, num_classes=5, num_shots
                 eval_inner_iters=50, eval_interval=10, weight_decay_rate=1, time_deadline=None, train_shots=None, transductive=False,
                 meta_fn=Gecko, log_fn=print, save_checkpoint_every_n_meta_iters=100, max_checkpoints_to_keep=2, augment=False,
                 lr_scheduler=None, lr=None, save_best_seen=False, num_tasks_to_eval=100, aug_rate: Optional[float] = None, dist=None,
-                seed: int = 0, verbose: bool = True, checkpoint_format: str = "npz", aug_pool=None):
+                seed: int = 0, verbose: bool = True, checkpoint_format: str = "npz", aug_pool=None, lanes=()):
     os.makedirs(save_dir, exist_ok=True)
     saver = Saver(max_to_keep=max_checkpoints_to_keep, fmt=checkpoint_format)
     best_saver = Saver(max_to_keep=1, fmt=checkpoint_format) if save_best_seen else None
     best_eval_iou = -np.inf
     pre_step_op = weight_decay_rate if weight_decay_rate != 1 else None
     reptile = meta_fn(learner, transductive=transductive, pre_step_op=pre_step_op, lr_scheduler=lr_scheduler, augment=augment,
-                      aug_rate=aug_rate, dist=dist, seed=seed, aug_pool=aug_pool)
+                      aug_rate=aug_rate, dist=dist, seed=seed, aug_pool=aug_pool, lanes=lanes)
     rank0 = reptile.dist.rank == 0
     writers = {"train": _ScalarWriter(os.path.join(save_dir, "train")), "test": _ScalarWriter(os.path.join(save_dir, "test"))} if rank0 else {}
     for i in range(meta_iters):

@@ -18,6 +18,10 @@ import os
 import random
 import sys
 
+# HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); concurrent task lanes (--concurrent-tasks)
+# want one queue each next to torch's own streams.  Read when the HIP runtime loads, so set before `import torch`.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 import torch
 
@@ -170,8 +174,13 @@ def main():
             path = ckpt.latest_checkpoint(args.continue_training_from_checkpoint)
             print("Continuing meta-training from checkpoint: {}".format(path))
             learner.load_named(ckpt.load(path))
+        lanes = []
+        if args.concurrent_tasks > 1 and not args.augment:   # the augmented path uploads host batches step by step: one lane
+            lanes = [Learner(device=device, **dict(model_kwargs(args), seed=args.seed + 1000 * k)) for k in range(1, args.concurrent_tasks)]
         train_gecko(learner, train_set, val_set or test_set, args.checkpoint, lr_scheduler=lr_scheduler, augment=args.augment, dist=Dist(),
-                    seed=args.seed, checkpoint_format=args.checkpoint_format, aug_pool=aug_pool, **train_kwargs(args))
+                    seed=args.seed, checkpoint_format=args.checkpoint_format, aug_pool=aug_pool, lanes=lanes, **train_kwargs(args))
+        for ln in lanes:
+            ln.close()
     else:
         path = ckpt.latest_checkpoint(args.checkpoint)
         print("Restoring from checkpoint: {}".format(path))
