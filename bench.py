@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--aspp", action="store_true", help="variant: ASPP decoder in front of the RSD modules (--spatial_pyramid_pooling)")
     ap.add_argument("--augment", action="store_true", help="variant: host augmentation of every inner-loop batch (the reference's run.sh setting)")
     ap.add_argument("--augment-workers", type=int, default=-1, help="worker processes for the augmentation pixel work (0 = inline, -1 = cores - 1)")
+    ap.add_argument("--overlap-wgrad", type=int, default=0, help="variant: weight-gradient kernels on a second stream inside the graph (1 | 2)")
     ap.add_argument("--concurrent-tasks", type=int, default=1,
                     help="variant (with --tasks-per-gpu > 1): adapt this many tasks of the meta-batch at once on separate learners / streams")
     ap.add_argument("--tasks-per-gpu", type=int, default=1, help="variant: tasks per GPU and meta-step (the metric's config has 1)")
@@ -245,7 +246,8 @@ def _run(args):
 
     shots = 10 if args.foml else args.shots
     L = Learner(feature_extractor_name=args.backbone, image_size=args.image_size, rsd=(2, 4), learning_rate=1e-3, optimizer="sgd", dice=False, l2=False, seed=0, device=device,
-                use_graph=not args.no_graph, max_shots=max(16, shots), spatial_pyramid_pooling=args.aspp, matmul_precision=args.precision)
+                use_graph=not args.no_graph, max_shots=max(16, shots), spatial_pyramid_pooling=args.aspp, matmul_precision=args.precision,
+                overlap_wgrad=args.overlap_wgrad)
     lanes = [Learner(feature_extractor_name=args.backbone, image_size=args.image_size, rsd=(2, 4), learning_rate=1e-3, optimizer="sgd", dice=False,
                      l2=False, seed=k, device=device, use_graph=not args.no_graph, max_shots=max(16, shots),
                      spatial_pyramid_pooling=args.aspp, matmul_precision=args.precision) for k in range(1, args.concurrent_tasks)]
