@@ -18,12 +18,12 @@ def evaluate_gecko(learner, dataset, num_classes=1, num_shots=5, eval_inner_batc
                    num_samples=100, transductive=False, weight_decay_rate=1, meta_fn=Gecko, visualize_predicted_segmentations=False,
                    save_fine_tuned_checkpoints=False, save_fine_tuned_checkpoints_dir: Optional[str] = None, lr_scheduler=None, lr=None,
                    augment=False, serially_eval_all_tasks: bool = False, aug_rate: Optional[float] = None, aug_pool=None,
-                   **_ignored) -> Tuple[float, Dict[str, List[float]]]:
+                   lanes=(), **_ignored) -> Tuple[float, Dict[str, List[float]]]:
     print("Evaluating with eval_inner_iters: {}".format(eval_inner_iters))
     print("Evaluating with lr: {}".format(lr))
     pre_step_op = weight_decay_rate if weight_decay_rate != 1 else None
     gecko = meta_fn(learner, transductive=transductive, pre_step_op=pre_step_op, lr_scheduler=lr_scheduler, augment=augment,
-                    aug_rate=aug_rate, rng_mode="reference", dist=_Single(), aug_pool=aug_pool)
+                    aug_rate=aug_rate, rng_mode="reference", dist=_Single(), aug_pool=aug_pool, lanes=lanes)
     mean_ious, task_iou_map = [], {}
     for i in range(num_samples):
         mean_iou, m = gecko.evaluate(dataset, num_classes=num_classes, num_shots=num_shots, inner_batch_size=eval_inner_batch_size,

@@ -263,6 +263,12 @@ class Gecko:
             random.shuffle(dataset)
             sampled = dataset[:num_tasks_to_sample]
         ious, task_iou_map = [], {}
+        if self.lanes and self.augmenter is None and not save_fine_tuned_checkpoints:
+            for name, iou in self._evaluate_concurrently(sampled, num_shots, test_shots, inner_batch_size, inner_iters, replacement, lr,
+                                                         drop_rate):
+                ious.append(iou)
+                task_iou_map[name] = iou
+            sampled = []
         for task in sampled:
             (images, labels), name = metaseg.sample_task([task], num_shots + test_shots, None, return_task_name=True)
             n = int(images.shape[0])
@@ -278,10 +284,43 @@ class Gecko:
         print("Mean IoU from train on {} images and evaluate on {} test images: {}".format(num_shots, test_shots, mean_iou))
         return mean_iou, task_iou_map
 
-    def _fine_tune_step(self, idx, inner_iter, lr, lr_scheduler, drop_rate):
+    def _evaluate_concurrently(self, sampled, num_shots, test_shots, inner_batch_size, inner_iters, replacement, lr, drop_rate):
+        """evaluate's task loop over the lanes: every task of a group is fine-tuned from the same restored state on a learner of
+        its own, the steps issued round-robin; host draws (example sampling, mini-batch schedule) stay in task order and the
+        predictions / IoUs are taken task by task afterwards, so the result equals the sequential loop's."""
+        import numpy as np
+        from .metrics import iou as _iou
+        L = self.learner
+        lanes = [L] + self.lanes
+        state = L.export_all()
+        out = []
+        for g0 in range(0, len(sampled), len(lanes)):
+            group = []
+            for lane, task in zip(lanes, sampled[g0:g0 + len(lanes)]):
+                (images, labels), name = metaseg.sample_task([task], num_shots + test_shots, None, return_task_name=True)
+                train_idx, test_idx = metaseg.split_indices(int(images.shape[0]), test_shots)
+                schedule = [list(b) for b in metaseg.mini_batch_indices(len(train_idx), inner_batch_size, inner_iters, replacement)]
+                if lane is not L:
+                    lane.import_all(state)
+                lane.load_task(images, labels)
+                group.append((lane, name, images, labels, train_idx, test_idx, schedule))
+            for j in range(max(len(g[6]) for g in group)):
+                for lane, _, _, _, train_idx, _, schedule in group:
+                    if j < len(schedule):
+                        self._fine_tune_step([train_idx[i] for i in schedule[j]], j, lr, self.lr_scheduler, drop_rate, lane)
+            for lane, name, _, labels, train_idx, test_idx, _ in group:
+                preds = self._test_predictions(train_idx, test_idx, lane)
+                lab = labels.detach().cpu().numpy() if hasattr(labels, "detach") else np.asarray(labels)
+                class_iou = float(np.nanmean([_iou(preds[j], lab[test_idx[j]]) for j in range(len(test_idx))]))
+                print("Mean task IoU: {}".format(class_iou))
+                out.append((name, class_iou))
+            L.import_all(state)
+        return out
+
+    def _fine_tune_step(self, idx, inner_iter, lr, lr_scheduler, drop_rate, L=None):
         """One fine-tuning step with the reference's feed precedence (reptile.py:265-276,459-469): (lr, drop_rate) together, else lr,
         else the scheduler's lr, else the model defaults."""
-        L, wd = self.learner, self._pre_step_rate
+        L, wd = L or self.learner, self._pre_step_rate
         if lr is not None and drop_rate is not None:
             L.inner_step(idx, lr=lr, weight_decay_rate=wd, drop_rate=drop_rate)
         elif lr is not None:
@@ -462,10 +501,10 @@ class Gecko:
                 ks.extend(k_range)
         return ks, results
 
-    def _test_predictions(self, train_idx, test_idx):
+    def _test_predictions(self, train_idx, test_idx, L=None):
         """reptile.py:482-524: transductive -> all test images in one inference-mode batch; otherwise one call per test image on the
         batch [train images..., that test image], keeping the last prediction."""
-        L = self.learner
+        L = L or self.learner
         if self._transductive:
             return L.predict_resident(list(test_idx), training=False).cpu().numpy()
         out = []

@@ -69,7 +69,7 @@ def _validate_datasets(args, train_set, val_set, test_set):
         raise ValueError("Val set has no tasks to evaluate")
 
 
-def _evaluate(args, learner, lr_scheduler, train_set, val_set, test_set, aug_pool=None):
+def _evaluate(args, learner, lr_scheduler, train_set, val_set, test_set, aug_pool=None, lanes=()):
     """The evaluation half of the reference's main (run_metasegnet.py:135-206), on rank 0."""
     import copy
     from mliis_amd.eval import evaluate_gecko, optimize_update_hyperparams, run_k_shot_learning_curves_experiment
@@ -115,13 +115,13 @@ def _evaluate(args, learner, lr_scheduler, train_set, val_set, test_set, aug_poo
         print("Evaluating {}-shot learning on training tasks.".format(args.shots))
         keep = ek["save_fine_tuned_checkpoints"]
         ek["save_fine_tuned_checkpoints"] = args.save_fine_tuned_checkpoints_train
-        mean_train_iou, _ = evaluate_gecko(learner, train_set, lr_scheduler=lr_scheduler, serially_eval_all_tasks=False, **ek)
+        mean_train_iou, _ = evaluate_gecko(learner, train_set, lr_scheduler=lr_scheduler, serially_eval_all_tasks=False, lanes=lanes, **ek)
         ek["save_fine_tuned_checkpoints"] = keep
     name = "test"
     if args.eval_val_tasks:
         test_set, name = val_set, "val"
     print("Evaluating {}-shot learning on meta-{} tasks.".format(args.shots, name))
-    mean_test_iou, task_name_iou_map = evaluate_gecko(learner, test_set, lr_scheduler=lr_scheduler,
+    mean_test_iou, task_name_iou_map = evaluate_gecko(learner, test_set, lr_scheduler=lr_scheduler, lanes=lanes,
                                                       serially_eval_all_tasks=args.serially_eval_all_test_tasks, **ek)
     print("Evaluated meta-{} tasks:".format(name))
     print(task_name_iou_map)
@@ -164,6 +164,10 @@ def main():
     train_set, val_set, test_set = _dataset(args, device, rank)
     _validate_datasets(args, train_set, val_set, test_set)
 
+    lanes = []
+    if args.concurrent_tasks > 1 and not args.augment:   # the augmented path uploads host batches step by step: one lane
+        lanes = [Learner(device=device, **dict(model_kwargs(args), seed=args.seed + 1000 * k)) for k in range(1, args.concurrent_tasks)]
+
     if args.restore_efficient_net_weights_from is not None and not args.pretrained:
         path = ckpt.latest_checkpoint(args.restore_efficient_net_weights_from)
         print("Restoring from checkpoint {}".format(path))
@@ -174,13 +178,8 @@ def main():
             path = ckpt.latest_checkpoint(args.continue_training_from_checkpoint)
             print("Continuing meta-training from checkpoint: {}".format(path))
             learner.load_named(ckpt.load(path))
-        lanes = []
-        if args.concurrent_tasks > 1 and not args.augment:   # the augmented path uploads host batches step by step: one lane
-            lanes = [Learner(device=device, **dict(model_kwargs(args), seed=args.seed + 1000 * k)) for k in range(1, args.concurrent_tasks)]
         train_gecko(learner, train_set, val_set or test_set, args.checkpoint, lr_scheduler=lr_scheduler, augment=args.augment, dist=Dist(),
                     seed=args.seed, checkpoint_format=args.checkpoint_format, aug_pool=aug_pool, lanes=lanes, **train_kwargs(args))
-        for ln in lanes:
-            ln.close()
     else:
         path = ckpt.latest_checkpoint(args.checkpoint)
         print("Restoring from checkpoint: {}".format(path))
@@ -190,7 +189,9 @@ def main():
             learner.load_named(ckpt.load(path))
 
     if rank == 0:
-        _evaluate(args, learner, lr_scheduler, train_set, val_set, test_set, aug_pool)
+        _evaluate(args, learner, lr_scheduler, train_set, val_set, test_set, aug_pool, lanes)
+    for ln in lanes:
+        ln.close()
     if aug_pool is not None:
         aug_pool.close()
     if world > 1:

@@ -432,3 +432,37 @@ def test_concurrent_task_lanes_equal_the_sequential_meta_step(fomaml):
     a, b = run(0), run(1)
     assert torch.equal(a[0], b[0]), float((a[0] - b[0]).abs().max())
     assert torch.equal(a[1], b[1]), float((a[1] - b[1]).abs().max())
+
+
+@pytest.mark.parametrize("transductive", [False, True])
+def test_concurrent_task_lanes_equal_the_sequential_evaluation(transductive):
+    """Gecko.evaluate over 3 tasks with a second learner as a lane == the task-by-task loop: same per-task IoUs, same draws from the
+    global generator, the main learner's full state restored."""
+    _need_gpu()
+    import random
+    from mliis_amd.learner import Learner
+    from mliis_amd.metaseg import DeviceTask
+    from mliis_amd.reptile import Gecko
+    H = 64
+    dev = torch.device("cuda", 0)
+    tasks = []
+    for i in range(3):
+        x, y = _task(10, H, 40 + i)
+        tasks.append(DeviceTask("t%d" % i, torch.tensor(x).to(dev), torch.tensor(y).to(dev)))
+    L = Learner(image_size=H, seed=2, use_graph=True, drop_connect=False, learning_rate=5e-3)
+    lane = Learner(image_size=H, seed=77, use_graph=True, drop_connect=False, learning_rate=5e-3)
+    before = L.export_all()
+    res = []
+    for lanes in ((), (lane,)):
+        random.seed(11)
+        np.random.seed(11)
+        g = Gecko(L, rng_mode="reference", transductive=transductive, lanes=lanes)
+        res.append(g.evaluate(list(tasks), num_shots=5, inner_batch_size=4, inner_iters=3, eval_all_tasks=True))
+        res.append(random.random())
+    after = L.export_all()
+    assert res[0][1] == res[2][1] and res[0][0] == res[2][0], (res[0], res[2])
+    assert res[1] == res[3]                      # the same number of draws was taken from the global generator
+    assert len(res[0][1]) == 3
+    assert torch.equal(before["theta"], after["theta"]) and torch.equal(before["bn"], after["bn"])
+    L.close()
+    lane.close()
