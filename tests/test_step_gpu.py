@@ -401,7 +401,7 @@ def test_bf16_matrix_core_operands_track_the_fp32_trajectory():
 
 @pytest.mark.parametrize("fomaml", [False, True])
 def test_concurrent_task_lanes_equal_the_sequential_meta_step(fomaml):
-    """A meta-batch of 3 tasks adapted on 2 learners at once (lanes: own arenas and streams, inner steps issued round-robin) gives the
+    """A meta-batch of 3 tasks adapted on 2 learners at once (lanes: own arenas and streams, inner steps issued round-robin; then on 4) gives the
     same meta-update, bit for bit, as the task-by-task loop on one learner (drop-connect off: its masks are the only per-learner
     randomness) -- over two meta-steps, so the second starts from the first one's imported state; 3 tasks on 2 lanes also covers the
     ragged last group."""
@@ -429,9 +429,11 @@ def test_concurrent_task_lanes_equal_the_sequential_meta_step(fomaml):
             ln.close()
         return out
 
-    a, b = run(0), run(1)
-    assert torch.equal(a[0], b[0]), float((a[0] - b[0]).abs().max())
-    assert torch.equal(a[1], b[1]), float((a[1] - b[1]).abs().max())
+    a = run(0)
+    for n_lanes in (1, 3):    # 3 tasks on 2 learners (ragged last group) and on 4 (all at once)
+        b = run(n_lanes)
+        assert torch.equal(a[0], b[0]), (n_lanes, float((a[0] - b[0]).abs().max()))
+        assert torch.equal(a[1], b[1]), (n_lanes, float((a[1] - b[1]).abs().max()))
 
 
 @pytest.mark.parametrize("transductive", [False, True])
