@@ -399,8 +399,8 @@ def test_bf16_matrix_core_operands_track_the_fp32_trajectory():
     assert ops.get_matmul_precision() == "fp32" and L2.matmul_precision == "fp32"
 
 
-@pytest.mark.parametrize("fomaml", [False, True])
-def test_concurrent_task_lanes_equal_the_sequential_meta_step(fomaml):
+@pytest.mark.parametrize("fomaml,H,bs", [(False, 64, 4), (True, 64, 4), (False, 224, 8)])
+def test_concurrent_task_lanes_equal_the_sequential_meta_step(fomaml, H, bs):
     """A meta-batch of 3 tasks adapted on 2 learners at once (lanes: own arenas and streams, inner steps issued round-robin; then on 4) gives the
     same meta-update, bit for bit, as the task-by-task loop on one learner (drop-connect off: its masks are the only per-learner
     randomness) -- over two meta-steps, so the second starts from the first one's imported state; 3 tasks on 2 lanes also covers the
@@ -409,7 +409,6 @@ def test_concurrent_task_lanes_equal_the_sequential_meta_step(fomaml):
     from mliis_amd.learner import Learner
     from mliis_amd.metaseg import DeviceTask
     from mliis_amd.reptile import FOMLIS, Gecko
-    H = 64
     dev = torch.device("cuda", 0)
     tasks = []
     for i in range(4):
@@ -422,7 +421,7 @@ def test_concurrent_task_lanes_equal_the_sequential_meta_step(fomaml):
         kw = dict(rng_mode="per_task", seed=9, lanes=lanes)
         meta = FOMLIS(L, train_shots=10, tail_shots=5, **kw) if fomaml else Gecko(L, **kw)
         for _ in range(2):
-            meta.train_step(tasks, num_shots=10 if fomaml else 5, inner_batch_size=4, inner_iters=3, meta_step_size=0.5, meta_batch_size=3)
+            meta.train_step(tasks, num_shots=10 if fomaml else 5, inner_batch_size=bs, inner_iters=3, meta_step_size=0.5, meta_batch_size=3)
         st = L.export_all()
         out = (st["theta"].cpu().clone(), st["bn"].cpu().clone())
         for ln in [L] + lanes:
