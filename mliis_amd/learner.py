@@ -51,6 +51,7 @@ class _Plan:
         self.blocks = []
         nskip = sum(1 for b in a.blocks if b.executed and b.skip)
         self.dc_all = torch.ones(max(nskip, 1), N, dtype=torch.float32, device=dev)
+        self.dc_pool, self.dc_pool_i = None, 0   # drop-connect masks drawn 16 steps at a time (Learner._fill_masks)
         si = 0
         gmax = 0
         for b in a.blocks:
@@ -229,6 +230,7 @@ class Learner:
         self.wt_desc = torch.tensor(desc, dtype=torch.int32, device=self.device)
         self.wt = {p.name: self.theta_t[A.t_off[p.name]:A.t_off[p.name] + p.size] for p in A.trainable}
         self.lr_dev = torch.tensor([self.lr], dtype=torch.float32, device=self.device)
+        self._lr_dev_val = float(self.lr)
         self.adam_v = torch.zeros_like(self.arena.theta) if optimizer == "adam" else None
         self.adam_t = torch.zeros(1, dtype=torch.float32, device=self.device)
         self.plans: Dict[int, _Plan] = {}
@@ -717,7 +719,10 @@ class Learner:
                 self._idx_ev[slot].record(self.stream)
             else:
                 P.idx.copy_(torch.tensor(list(batch_idx), dtype=torch.int32), non_blocking=True)
-            self.lr_dev.fill_(self.lr if lr is None else float(lr))
+            lr_now = self.lr if lr is None else float(lr)
+            if lr_now != self._lr_dev_val:   # the fused optimizer kernels read the rate from device memory (graph-replay safe)
+                self.lr_dev.fill_(lr_now)
+                self._lr_dev_val = lr_now
             if weight_decay_rate != 1.0:  # pre_step_op (variables.py:48-55)
                 ops.axpby(0.0, None, float(weight_decay_rate), self.arena.theta)
             self._fill_masks(P, dc_scales, dropout_mask, drop_rate, aspp_masks)
@@ -765,8 +770,11 @@ class Learner:
                     self._dc_keeps = torch.tensor([1.0 - b.drop_rate for b in ex if b.skip], dtype=torch.float32, device=self.device)[:, None]
                 keeps = self._dc_keeps
                 if keeps.numel():
-                    u = torch.rand(P.dc_all.shape, generator=self.rng, device=self.device)
-                    P.dc_all.copy_(torch.floor(keeps + u) / keeps)   # utils.py:159-170
+                    if P.dc_pool is None or P.dc_pool_i >= P.dc_pool.shape[0]:   # one draw per 16 steps: 1 small launch per step, not 4
+                        u = torch.rand((16,) + tuple(P.dc_all.shape), generator=self.rng, device=self.device)
+                        P.dc_pool, P.dc_pool_i = torch.floor(keeps + u) / keeps, 0   # utils.py:159-170
+                    P.dc_all.copy_(P.dc_pool[P.dc_pool_i])
+                    P.dc_pool_i += 1
         if P.drop_mask is not None:
             if dropout_mask is not None:
                 P.drop_mask.copy_(torch.as_tensor(dropout_mask, dtype=torch.float32))
