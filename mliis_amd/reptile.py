@@ -75,7 +75,7 @@ class Gecko:
         # drop-connect masks from its own generator.
         self.lanes = list(lanes)
         for ln in self.lanes:
-            if ln.n_trainable != learner.n_trainable or ln.optimizer != "sgd" or learner.optimizer != "sgd":
+            if ln.n_trainable != learner.n_trainable or getattr(ln, "optimizer", "sgd") != "sgd" or getattr(learner, "optimizer", "sgd") != "sgd":
                 raise ValueError("lanes must share the learner's architecture and use the SGD inner optimizer (Adam keeps per-learner state)")
         self._transductive = transductive
         # pre_step_op: the reference passes a TF op that multiplies all trainables by `weight_decay_rate`

@@ -199,3 +199,23 @@ def test_gloo_world2_equals_single_process(fomaml):
         meta.train_step(tasks, num_shots=6, inner_batch_size=4, inner_iters=2, replacement=False, meta_step_size=0.3, meta_batch_size=4)
     np.testing.assert_allclose(res[0][1], A.export_trainable().numpy(), rtol=0, atol=1e-9)  # thread-count dependent fp64 rounding
     np.testing.assert_allclose(res[0][2], A.export_bn().numpy(), rtol=1e-8, atol=1e-9)
+
+
+@pytest.mark.parametrize("fomaml", [False, True])
+def test_concurrent_lanes_host_logic_equals_task_by_task(fomaml):
+    """Gecko(lanes=...) -- tasks adapted several at a time on learners of their own (on the GPU: own streams) -- gives the update of
+    the task-by-task loop exactly, for training (5 tasks on 1 + 2 learners: a full group and a ragged one) and for evaluate()."""
+    tasks = _tasks(4, 6)
+    res = []
+    for n_lanes in (0, 2):
+        A = _learner()
+        lanes = [R.OracleLearner(image_size=H, seed=90 + k, dtype=torch.float64, lr=1e-2, drop_connect=False) for k in range(n_lanes)]
+        kw = dict(rng_mode="per_task", seed=4, lanes=lanes)
+        meta = FOMLIS(A, train_shots=6, tail_shots=2, **kw) if fomaml else Gecko(A, **kw)
+        for _ in range(2):
+            meta.train_step(tasks, num_shots=6, inner_batch_size=4, inner_iters=3, meta_step_size=0.5, meta_batch_size=5)
+        random.seed(5)
+        ev = meta.evaluate(list(tasks), num_shots=3, test_shots=3, inner_batch_size=2, inner_iters=2, eval_all_tasks=True)
+        res.append((A.export_trainable().clone(), A.export_bn().clone(), ev, random.random()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert res[0][2] == res[1][2] and res[0][3] == res[1][3]
