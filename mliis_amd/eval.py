@@ -11,7 +11,7 @@ from typing import Dict, List, Optional, Tuple
 import numpy as np
 
 from .metrics import ci95
-from .reptile import Gecko
+from .reptile import Gecko, SingleRank
 
 
 def evaluate_gecko(learner, dataset, num_classes=1, num_shots=5, eval_inner_batch_size=5, eval_inner_iters=50, replacement=False,
@@ -43,17 +43,7 @@ def evaluate_gecko(learner, dataset, num_classes=1, num_shots=5, eval_inner_batc
     return mean_iou, task_iou_map
 
 
-class _Single:
-    """Evaluation always runs on one rank (the reference has no distributed evaluation)."""
-    rank, world = 0, 1
-
-    @staticmethod
-    def all_reduce_sum(t):
-        return t
-
-    @staticmethod
-    def barrier():
-        return None
+_Single = SingleRank   # evaluation always runs on one rank (the reference has no distributed evaluation)
 
 
 def optimize_update_hyperparams(learner, dataset, num_classes=1, num_shots=5, eval_inner_batch_size=5, eval_inner_iters=5, replacement=False,

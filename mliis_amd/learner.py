@@ -21,6 +21,7 @@ Graph semantics restated from: models/efficientlab.py:111-119,126-231,294-317; m
 from __future__ import annotations
 
 import ctypes as C
+import math
 from typing import Dict, List, Optional, Sequence
 
 import numpy as np
@@ -217,7 +218,8 @@ class Learner:
         self.arena = Arena(self.arch, self.device)
         self.arena.init_weights(seed)
         self.variables_initialized = True
-        self.ws = ops.Workspace(self.device, 1 << 22)
+        self._capturing = False
+        self.ws = ops.Workspace(self.device, 1 << 22, on_grow=self._on_workspace_grow)
         # K-contiguous ("HWOI") shadow of the dense-conv weights, refreshed by ONE batched transpose at the top of every
         # forward, so the forward GEMMs read their B operand as 16-byte k-fragments like backward-data does
         A = self.arena
@@ -347,11 +349,54 @@ class Learner:
         self.stream.synchronize()
         return float(self.last_loss[0].item())
 
+    ADAM_BETA2 = 0.999
+
+    def named_numpy(self) -> Dict[str, np.ndarray]:
+        """All global variables under their TF names, read after everything queued on the learner's stream has finished: what
+        `tf.train.Saver()` stores (train.py:54,131) -- trainables, BN moving statistics and, for the Adam inner optimizer
+        (--sgd absent), its persistent slots: `<var>/Adam_1` (second moment), `beta1_power` / `beta2_power` in TF's convention
+        (beta^(t+1) after t steps; beta1 = 0).  The first-moment slot `<var>/Adam` equals the last gradient when beta1 = 0 and is
+        not stored."""
+        self.stream.synchronize()
+        torch.cuda.synchronize(self.device)
+        out = self.arena.named_numpy()
+        if self.adam_v is not None:
+            A = self.arena
+            v = self.adam_v.detach().cpu().numpy()
+            for p in A.trainable:
+                o = A.t_off[p.name]
+                out[p.name + "/Adam_1"] = v[o:o + p.size].reshape(p.shape).copy()
+            t = float(self.adam_t.item())
+            out["beta1_power"] = np.float32(0.0)
+            out["beta2_power"] = np.float32(self.ADAM_BETA2 ** (t + 1.0))
+        return out
+
     def load_named(self, values, **kw) -> int:
         self.stream.synchronize()
         n = self.arena.load_named(values, **kw)
+        if self.adam_v is not None and "beta2_power" in values:   # Adam slots of a checkpoint written by named_numpy()
+            A = self.arena
+            for p in A.trainable:
+                key = p.name + "/Adam_1"
+                if key in values:
+                    o = A.t_off[p.name]
+                    self.adam_v[o:o + p.size].copy_(torch.from_numpy(np.asarray(values[key], dtype=np.float32).reshape(-1)))
+            t = round(math.log(float(values["beta2_power"])) / math.log(self.ADAM_BETA2)) - 1
+            self.adam_t.fill_(float(max(t, 0)))
         torch.cuda.synchronize(self.device)
         return n
+
+    def _on_workspace_grow(self, floats: int):
+        """The shared scratch buffer is about to be replaced by a larger one (a plan with more images than any before).  Captured
+        HIP graphs hold the old address: finish the queued work and drop them (the next step of each plan captures again)."""
+        if self._capturing:
+            raise MliisError("workspace would grow to {} floats during HIP-graph capture (the eager first step of a plan sizes it)".format(floats))
+        self.stream.synchronize()
+        for P in self.plans.values():
+            if P.graph is not None:
+                lib.call("mliis_graph_destroy", P.graph)
+                P.graph = None
+                P.steps_run = 0   # next step eager (re-sizes), the one after captures
 
     # ------------------------------------------------------------------------------------------- task data
     def load_task(self, images, labels):
@@ -730,9 +775,11 @@ class Learner:
                 if P.graph is None:
                     gexec = C.c_void_p()
                     lib.call("mliis_graph_begin_capture", self.stream.cuda_stream)
+                    self._capturing = True
                     try:
                         self._train_sequence(P)
                     finally:
+                        self._capturing = False
                         lib.call("mliis_graph_end_capture", self.stream.cuda_stream, C.byref(gexec))
                     P.graph = gexec
                 lib.call("mliis_graph_launch", P.graph, self.stream.cuda_stream)

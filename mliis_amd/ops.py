@@ -86,14 +86,18 @@ def conv2d_plan(N, H, W, cred, nout, k):
 
 
 class Workspace:
-    """Grow-only scratch buffer (floats) shared by all calls on a stream."""
+    """Grow-only scratch buffer (floats) shared by all calls on a stream.  `on_grow` (optional) is called BEFORE the buffer is
+    replaced: an owner whose captured HIP graphs have the old address baked in must drop them there (Learner does)."""
 
-    def __init__(self, device="cuda", floats: int = 1 << 20):
+    def __init__(self, device="cuda", floats: int = 1 << 20, on_grow=None):
         self.device = device
+        self.on_grow = on_grow
         self.buf = torch.empty(floats, dtype=torch.float32, device=device)
 
     def get(self, floats: int) -> torch.Tensor:
         if floats > self.buf.numel():
+            if self.on_grow is not None:
+                self.on_grow(floats)
             self.buf = torch.empty(int(floats * 1.25) + 1024, dtype=torch.float32, device=self.device)
         return self.buf
 

@@ -46,6 +46,41 @@ class Dist:
         if self._d is not None and self.world > 1:
             self._d.barrier()
 
+    def any_true(self, flag: bool, device=None) -> bool:
+        """Collective OR of a per-rank decision (loop exits must be taken by all ranks in the same iteration, or the next
+        all-reduce hangs): one 4-byte all-reduce(MAX)."""
+        if self._d is None or self.world == 1:
+            return bool(flag)
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=device if self._d.get_backend() == "nccl" else "cpu")
+        self._d.all_reduce(t, op=self._d.ReduceOp.MAX)
+        return bool(int(t.item()))
+
+    def broadcast_floats(self, values, device=None, src: int = 0):
+        """Rank `src`'s list of floats on every rank (evaluation results computed on one rank only)."""
+        if self._d is None or self.world == 1:
+            return [float(v) for v in values]
+        t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device if self._d.get_backend() == "nccl" else "cpu")
+        self._d.broadcast(t, src=src)
+        return [float(v) for v in t.tolist()]
+
+
+class SingleRank:
+    """A Dist that is always world size 1: for work one rank does alone while a process group exists (rank-0 evaluation-time
+    fine-tuning), so it neither shards its tasks nor issues collectives the other ranks never join."""
+    rank, world = 0, 1
+
+    def all_reduce_sum(self, t):
+        return t
+
+    def barrier(self):
+        pass
+
+    def any_true(self, flag, device=None):
+        return bool(flag)
+
+    def broadcast_floats(self, values, device=None, src=0):
+        return [float(v) for v in values]
+
 
 DEFAULT_ITER_RANGE = [1, 5, 10, 25, 50, 100, 200]   # reptile.py:21
 
@@ -127,9 +162,12 @@ class Gecko:
             self.augmenter.py = rng
             self.augmenter.npr = np.random.RandomState(_task_rng(self.seed, self.meta_iter, task_idx).getrandbits(32))
         x, y = self._host_task
+        wr = getattr(self, "sample_train_val_with_replacement", False)
         sched = metaseg.AugmentedSchedule(x, y, inner_batch_size, inner_iters, replacement, self.augmenter,
                                           self.aug_rate if self._train_aug_rate_from_self else None, rng,
-                                          tail_shots=getattr(self, "tail_shots", None), fomaml=self._train_aug_rate_from_self)
+                                          tail_shots=getattr(self, "tail_shots", None), fomaml=self._train_aug_rate_from_self,
+                                          with_replacement_train_shots=self.train_shots if wr else None,
+                                          npr=self._npr(rng) if wr else None)
         return sched.submit(self.aug_pool) if self.aug_pool is not None else sched
 
     def _run_meta_batch(self, dataset, num_shots, inner_batch_size, inner_iters, replacement, meta_step_size, meta_batch_size, lr,
@@ -146,7 +184,9 @@ class Gecko:
             comm.zero_()
             delta, bn_acc = comm[:nt], comm[nt:]
             decay = BN_MOMENTUM
-            T = inner_iters
+            # moving-average updates one task issues: one per optimizer step, and Gecko runs TWO steps per batch when `lr` is given
+            # (quirk E1, _steps_per_batch) -- the sequential-average weights below count updates, not batches
+            T = inner_iters * self._steps_per_batch(lr)
             # With augmentation every task of the meta-batch is sampled and its schedule DRAWN up front (same generator order as
             # task-by-task, since the inner steps consume no host randomness); the pixel work of later tasks then runs on the worker
             # pool while the device trains on the earlier ones.
@@ -196,7 +236,7 @@ class Gecko:
         export_* / import_* / axpby calls below order the lanes' streams against the main learner's)."""
         L = self.learner
         lanes = [L] + self.lanes
-        decay, T = BN_MOMENTUM, inner_iters
+        decay, T = BN_MOMENTUM, inner_iters * self._steps_per_batch(lr)
         for g0 in range(0, len(mine), len(lanes)):
             group = []
             for lane, t in zip(lanes, mine[g0:g0 + len(lanes)]):   # host draws in task order, like the sequential loop
@@ -227,6 +267,10 @@ class Gecko:
 
     def _task_batches(self, n_shots, inner_batch_size, inner_iters, replacement, rng):
         return self._batches(n_shots, inner_batch_size, inner_iters, replacement, rng)
+
+    def _steps_per_batch(self, lr) -> int:
+        """Optimizer steps (= BN moving-average updates) `_step` issues per mini-batch."""
+        return 2 if lr is not None else 1
 
     def _step(self, idx, j, lr, L=None):
         L = L or self.learner
@@ -357,7 +401,7 @@ class Gecko:
         if save_fine_tuned_checkpoints:
             from .checkpoint import save_fine_tuned_checkpoint
             L.synchronize()
-            save_fine_tuned_checkpoint(L.arena.named_numpy(), save_fine_tuned_checkpoints_dir, task_name, eval_sample_num, inner_iter)
+            save_fine_tuned_checkpoint(L.named_numpy(), save_fine_tuned_checkpoints_dir, task_name, eval_sample_num, inner_iter)
         if self.augmenter is not None:
             L.load_task(images, labels)   # the augmented batches replaced the resident task
         preds = self._test_predictions(train_idx, test_idx)
@@ -524,12 +568,27 @@ class FOMLIS(Gecko):
         super().__init__(*args, **kwargs)
         self.train_shots = train_shots - tail_shots if tail_shots is not None else train_shots
         self.tail_shots = tail_shots
-        if sample_train_val_with_replacement:
-            raise NotImplementedError("--sample_foml_train_val_with_replacement draws from the unseeded numpy generator; not built")
-        self.sample_train_val_with_replacement = False
+        self.sample_train_val_with_replacement = bool(sample_train_val_with_replacement)
+        if self.sample_train_val_with_replacement:
+            if tail_shots is None or train_shots is None:
+                raise ValueError("sample_train_val_with_replacement needs train_shots and tail_shots (reptile.py:657-658)")
+            print("Sampling train val with replacement.")
+        print("Specializing meta-learner to FOMAML.")
+
+    def _npr(self, rng):
+        """numpy generator of the with-replacement draws: the global `np.random` in reference mode (metaseg.py:313-318), a private
+        stream derived from the task's generator in per-task mode."""
+        import numpy as np
+        return None if rng is None else np.random.RandomState(rng.getrandbits(32))
 
     def _task_batches(self, n_shots, inner_batch_size, inner_iters, replacement, rng):
+        if self.sample_train_val_with_replacement:
+            return metaseg.fomaml_batch_indices(n_shots, self.tail_shots, inner_batch_size, inner_iters, replacement, rng,
+                                                with_replacement_train_shots=self.train_shots, npr=self._npr(rng))
         return metaseg.fomaml_batch_indices(n_shots, self.tail_shots, inner_batch_size, inner_iters, replacement, rng)
+
+    def _steps_per_batch(self, lr) -> int:
+        return 1
 
     def _step(self, idx, j, lr, L=None):
         L = L or self.learner

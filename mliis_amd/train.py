@@ -52,7 +52,8 @@ def train_gecko(learner, train_set, test_set, save_dir, num_classes=5, num_shots
     pre_step_op = weight_decay_rate if weight_decay_rate != 1 else None
     reptile = meta_fn(learner, transductive=transductive, pre_step_op=pre_step_op, lr_scheduler=lr_scheduler, augment=augment,
                       aug_rate=aug_rate, dist=dist, seed=seed, aug_pool=aug_pool, lanes=lanes)
-    rank0 = reptile.dist.rank == 0
+    D = reptile.dist
+    rank0 = D.rank == 0
     writers = {"train": _ScalarWriter(os.path.join(save_dir, "train")), "test": _ScalarWriter(os.path.join(save_dir, "test"))} if rank0 else {}
     for i in range(meta_iters):
         begin = time.time()
@@ -62,22 +63,31 @@ def train_gecko(learner, train_set, test_set, save_dir, num_classes=5, num_shots
             print("Current meta-step size: {}".format(cur))
         reptile.train_step(train_set, num_classes=num_classes, num_shots=(train_shots or num_shots), inner_batch_size=inner_batch_size,
                            inner_iters=inner_iters, replacement=replacement, meta_step_size=cur, meta_batch_size=meta_batch_size, lr=lr)
-        if eval_interval and i % eval_interval == 0 and hasattr(reptile, "evaluate") and rank0:
+        if eval_interval and i % eval_interval == 0 and hasattr(reptile, "evaluate"):
+            # Multi-rank: EVERY rank runs the evaluation (same parameters after the all-reduce, same task lists, same draws from the
+            # global generator), so the ranks stay in lock-step: nobody waits in the next all-reduce for a rank that is still
+            # evaluating (RCCL watchdog), and the host generators stay identical on all ranks.  Rank 0 records the result.
             ious = []
             for name, dataset in (("train", train_set), ("test", test_set)):
                 mean_iou, _ = reptile.evaluate(dataset, num_classes=num_classes, num_shots=num_shots, inner_batch_size=eval_inner_batch_size,
                                                inner_iters=eval_inner_iters, replacement=replacement, eval_all_tasks=False,
                                                num_tasks_to_sample=num_tasks_to_eval)
-                writers[name].add(i, IoU=float(mean_iou), meta_step_size=float(cur))
+                if rank0:
+                    writers[name].add(i, IoU=float(mean_iou), meta_step_size=float(cur))
                 ious.append(mean_iou)
-            log_fn("Train step %d: train=%f test=%f" % (i, ious[0], ious[1]))
+            if rank0:
+                log_fn("Train step %d: train=%f test=%f" % (i, ious[0], ious[1]))
             if save_best_seen and ious[1] > best_eval_iou:
                 best_eval_iou = ious[1]
-                best_saver.save(learner.arena.named_numpy(), os.path.join(save_dir, "best_eval"), i)
+                if rank0:
+                    learner.synchronize()   # evaluate() restores the variables asynchronously on the learner's stream
+                    best_saver.save(learner.named_numpy(), os.path.join(save_dir, "best_eval"), i)
         if rank0 and (i % save_checkpoint_every_n_meta_iters == 0 or i == meta_iters - 1):
             learner.synchronize()
-            saver.save(learner.arena.named_numpy(), save_dir, i)
-        if time_deadline is not None and time.time() > time_deadline:
+            saver.save(learner.named_numpy(), save_dir, i)
+        # the deadline is a per-rank wall clock: the exit is taken by ALL ranks in the same iteration (collective OR), otherwise
+        # the ranks that go on would hang in the next all-reduce
+        if time_deadline is not None and D.any_true(time.time() > time_deadline, device=getattr(learner, "device", None)):
             break
         if verbose and rank0:
             log_estimated_time_remaining(begin, i, meta_iters)

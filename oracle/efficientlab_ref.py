@@ -347,6 +347,41 @@ class OracleLearner:
         self.sizes = [self.params[k].numel() for k in self.names]
         self.bn_names = list(self.bn)
         self.n_trainable = sum(self.sizes)
+        self.feature_extractor_name = name
+        self.final_layer_scope = "decode/final_layer_weights"
+        self.optimizer = "sgd"
+
+    # -- checkpoint surface (all global variables under their TF names)
+    def named_numpy(self):
+        out = {k: v.detach().numpy().astype("float32") for k, v in self.params.items()}
+        for k, (mm, mv) in self.bn.items():
+            out[k + "/moving_mean"], out[k + "/moving_variance"] = mm.numpy().astype("float32"), mv.numpy().astype("float32")
+        return out
+
+    def load_named(self, values, strict=True, prefixes=None, exclude_prefix=None):
+        n = 0
+        names = list(self.params) + [k + s for k in self.bn for s in ("/moving_mean", "/moving_variance")]
+        for name in names:
+            if prefixes is not None and not any(name.startswith(x) for x in prefixes):
+                continue
+            if exclude_prefix is not None and name.startswith(exclude_prefix):
+                continue
+            if name not in values:
+                if strict:
+                    raise KeyError("variable {} missing from checkpoint".format(name))
+                continue
+            v = torch.as_tensor(values[name]).to(self.dtype)
+            if name in self.params:
+                self.params[name] = v.reshape(self.params[name].shape).clone()
+            else:
+                k, which = name.rsplit("/", 1)
+                mm, mv = self.bn[k]
+                self.bn[k] = (v.clone(), mv) if which == "moving_mean" else (mm, v.clone())
+            n += 1
+        return n
+
+    def close(self):
+        pass
 
     # -- variable state (meta_learners/variables.py:58-80)
     def export_trainable(self) -> torch.Tensor:

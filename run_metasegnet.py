@@ -73,7 +73,7 @@ def _evaluate(args, learner, lr_scheduler, train_set, val_set, test_set, aug_poo
     """The evaluation half of the reference's main (run_metasegnet.py:135-206), on rank 0."""
     import copy
     from mliis_amd.eval import evaluate_gecko, optimize_update_hyperparams, run_k_shot_learning_curves_experiment
-    from mliis_amd.reptile import Dist
+    from mliis_amd.reptile import SingleRank
     from mliis_amd.train import train_gecko
     ek = evaluate_kwargs(args)
     ek["aug_pool"] = aug_pool
@@ -100,7 +100,8 @@ def _evaluate(args, learner, lr_scheduler, train_set, val_set, test_set, aug_poo
             tp["meta_step_size"] = tp["meta_step_size_final"]
             train_gecko(learner, list(train_set) + list(val_set), test_set,
                         os.path.join(args.checkpoint, "fine-tuned_on_train_val_with_optimized_update_hyperparams"), lr_scheduler=lr_scheduler,
-                        augment=args.augment, dist=Dist(), seed=args.seed, checkpoint_format=args.checkpoint_format, aug_pool=aug_pool, **tp)
+                        augment=args.augment, dist=SingleRank(), seed=args.seed, checkpoint_format=args.checkpoint_format, aug_pool=aug_pool,
+                        **tp)   # this rank alone (the process group is gone by now): all tasks, no collective
     del ek["eval_tasks_with_median_early_stopping_iterations"]
     if args.run_k_shot_learning_curves_experiment:
         kk = copy.copy(ek)
@@ -135,10 +136,12 @@ def _evaluate(args, learner, lr_scheduler, train_set, val_set, test_set, aug_poo
     print("Wrote results to {}".format(out))
 
 
-def main():
+def main(argv=None, learner_factory=None, device=None):
+    """argv: command line (default sys.argv[1:]).  learner_factory / device: test seam -- any object with the Learner protocol
+    (tests drive the whole program on the CPU oracle learner); the product path always builds mliis_amd.learner.Learner on the GPU."""
     start = datetime.datetime.now()
     print("Experiment started at: {}".format(start))
-    args = argument_parser().parse_args()
+    args = argument_parser().parse_args(argv)
     random.seed(args.seed)
     aug_pool = None
     if args.augment and args.augment_workers != 0:   # forked workers: created before anything initialises the GPU
@@ -148,10 +151,14 @@ def main():
     world, rank, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    device = torch.device("cuda", local)
-    from mliis_amd.learner import Learner
+        if not dist.is_initialized():
+            torch.cuda.set_device(local)   # (device_count() does not initialise the GPU; this and everything after it does)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    device = torch.device("cuda", local) if device is None else torch.device(device)
+    if learner_factory is None:
+        from mliis_amd.learner import Learner
+    else:
+        Learner = learner_factory
     from mliis_amd.reptile import Dist
     from mliis_amd.train import train_gecko
 
@@ -188,16 +195,19 @@ def main():
         else:
             learner.load_named(ckpt.load(path))
 
+    if world > 1:
+        # Meta-training is the only multi-rank phase.  The process group ends HERE, on every rank, before rank 0 evaluates alone:
+        # the other ranks then simply exit instead of sitting in an RCCL barrier whose watchdog a long evaluation would trip.
+        import torch.distributed as dist
+        learner.synchronize()
+        dist.barrier()
+        dist.destroy_process_group()
     if rank == 0:
         _evaluate(args, learner, lr_scheduler, train_set, val_set, test_set, aug_pool, lanes)
     for ln in lanes:
         ln.close()
     if aug_pool is not None:
         aug_pool.close()
-    if world > 1:
-        import torch.distributed as dist
-        dist.barrier()
-        dist.destroy_process_group()
     end = datetime.datetime.now()
     print("Experiment finished at: {}, taking {}".format(end, end - start))
 

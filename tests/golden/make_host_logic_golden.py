@@ -105,6 +105,17 @@ def main():
         bt.append([s[0] for s in te])
         foml.append({"n": n, "tail": tail, "batch": bs, "inner_iters": iters, "seed": seed, "batches": bt})
     G["foml_batches"] = foml
+    # --sample_foml_train_val_with_replacement (reptile.py:657-658; metaseg.py:313-318): numpy draws, then the head schedule, then the tail
+    wr = []
+    for (n, train, tail, bs, iters, seed) in [(10, 5, 5, 8, 8, 0), (10, 5, 5, 8, 3, 4), (6, 4, 2, 4, 4, 7)]:
+        random.seed(seed)
+        np.random.seed(seed + 100)
+        tr, te = MS._sample_train_test_segmentation_with_replacement([(i, i) for i in range(n)], train_shots=train, test_shots=tail)
+        bt = [[s[0] for s in b] for b in MS._mini_batches(tr, bs, iters - 1, False)]
+        bt.append([s[0] for s in te])
+        wr.append({"n": n, "train": train, "tail": tail, "batch": bs, "inner_iters": iters, "seed": seed, "np_seed": seed + 100,
+                   "head": [s[0] for s in tr], "batches": bt})
+    G["foml_with_replacement"] = wr
 
     R = importlib.import_module("meta_learners.supervised_reptile.supervised_reptile.reptile")
     rng = np.random.default_rng(3)

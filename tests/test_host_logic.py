@@ -65,6 +65,24 @@ def test_fomaml_schedule(golden):
         assert len(got) == c["inner_iters"] and len(got[-1]) == c["tail"]
 
 
+def test_fomaml_schedule_with_replacement(golden):
+    """--sample_foml_train_val_with_replacement: head / tail are numpy draws with replacement (metaseg.py:313-318), bit-exact against
+    the reference's own function for seeded `random` + `np.random`."""
+    for c in golden["foml_with_replacement"]:
+        random.seed(c["seed"])
+        np.random.seed(c["np_seed"])
+        got = MS.fomaml_batch_indices(c["n"], c["tail"], c["batch"], c["inner_iters"], with_replacement_train_shots=c["train"])
+        assert got == c["batches"], c
+        np.random.seed(c["np_seed"])
+        tr, te = MS._sample_train_test_segmentation_with_replacement(list(range(c["n"])), c["train"], c["tail"])
+        assert tr == c["head"] and te == c["batches"][-1]
+        # a private RandomState with the same seed gives the same draws (per-task mode)
+        random.seed(c["seed"])
+        got2 = MS.fomaml_batch_indices(c["n"], c["tail"], c["batch"], c["inner_iters"], with_replacement_train_shots=c["train"],
+                                       npr=np.random.RandomState(c["np_seed"]))
+        assert got2 == c["batches"]
+
+
 def test_iou_measure_ci95_earlystopper(golden):
     for c in golden["iou"]:
         assert MT.iou(np.array(c["pred"], np.float32), np.array(c["label"], np.float32)) == pytest.approx(c["iou"], rel=1e-12)

@@ -28,7 +28,7 @@ def _learner():
     return R.OracleLearner(image_size=H, seed=3, dtype=torch.float64, lr=1e-2, drop_connect=False)
 
 
-def _sequential_reference(L, tasks_batches, fomaml, eps):
+def _sequential_reference(L, tasks_batches, fomaml, eps, lr=None):
     """What the reference does: tasks one after another, BN moving stats never reset, numpy-style averaging."""
     old = L.export_trainable()
     ups = []
@@ -38,14 +38,20 @@ def _sequential_reference(L, tasks_batches, fomaml, eps):
         for j, b in enumerate(batches):
             if fomaml and j == len(batches) - 1:
                 last = L.export_trainable()
-            L.inner_step(b)
+            if lr is not None:      # reptile.py:114-116 / :639-641
+                L.inner_step(b, lr=lr)
+                if fomaml:
+                    continue
+            L.inner_step(b)         # :120-121 runs also when lr was given (Gecko only: quirk E1)
         ups.append(L.export_trainable() - (last if fomaml else old))
         L.import_trainable(old)
     L.import_trainable(old + eps * torch.stack(ups).mean(0))
 
 
-@pytest.mark.parametrize("fomaml", [False, True])
-def test_meta_step_matches_sequential_reference(fomaml):
+@pytest.mark.parametrize("fomaml,lr", [(False, None), (True, None), (False, 5e-3), (True, 5e-3)])
+def test_meta_step_matches_sequential_reference(fomaml, lr):
+    """lr given: Gecko runs two optimizer steps (= two BN moving-average updates) per batch, FOMLIS one; the BN recombination
+    weights count updates, not batches."""
     tasks = _tasks(3, 6)
     B, iters, bs, eps = 3, 3, 4, 0.25
     A = _learner()
@@ -63,8 +69,9 @@ def test_meta_step_matches_sequential_reference(fomaml):
         batches = metaseg.fomaml_batch_indices(6, 2, bs, iters, False, rng) if fomaml else \
             [list(b) for b in metaseg.mini_batch_indices(6, bs, iters, False, rng)]
         sched.append((x, y, batches))
-    meta.train_step(tasks, num_shots=6, inner_batch_size=bs, inner_iters=iters, replacement=False, meta_step_size=eps, meta_batch_size=B)
-    _sequential_reference(ref, sched, fomaml, eps)
+    meta.train_step(tasks, num_shots=6, inner_batch_size=bs, inner_iters=iters, replacement=False, meta_step_size=eps, meta_batch_size=B,
+                    lr=lr)
+    _sequential_reference(ref, sched, fomaml, eps, lr)
     assert torch.allclose(A.export_trainable(), ref.export_trainable(), rtol=0, atol=1e-12)
     # BN moving statistics follow the SEQUENTIAL exponential average over all tasks' steps
     assert torch.allclose(A.export_bn(), ref.export_bn(), rtol=1e-10, atol=1e-12)
@@ -140,10 +147,36 @@ def test_augmented_inner_loop_feeds_the_reference_schedule_and_restores_state():
     assert torch.equal(A.export_trainable(), before[0]) and torch.equal(A.export_bn(), before[1])
 
 
+def test_fomlis_sample_train_val_with_replacement():
+    """--sample_foml_train_val_with_replacement (reptile.py:657-658): in reference mode the head / tail come from the global numpy
+    generator right after the task draw; in per-task mode from a private stream (rank-count independent, reproducible)."""
+    tasks = _tasks(2, 6)
+    A = _learner()
+    seen = []
+    A.inner_step = lambda idx, **kw: seen.append(list(idx)) or 0.0
+    meta = FOMLIS(A, train_shots=6, tail_shots=2, sample_train_val_with_replacement=True, rng_mode="reference")
+    assert meta.train_shots == 4
+    random.seed(2)
+    np.random.seed(3)
+    meta.train_step(tasks, num_shots=6, inner_batch_size=3, inner_iters=3, meta_step_size=0.0, meta_batch_size=1)
+    random.seed(2)
+    np.random.seed(3)
+    random.sample(list(tasks), 1)
+    exp = metaseg.fomaml_batch_indices(6, 2, 3, 3, with_replacement_train_shots=4)
+    assert seen == exp and len(seen[-1]) == 2
+    runs = []
+    for _ in range(2):
+        seen.clear()
+        m = FOMLIS(A, train_shots=6, tail_shots=2, sample_train_val_with_replacement=True, rng_mode="per_task", seed=8)
+        m.train_step(tasks, num_shots=6, inner_batch_size=3, inner_iters=3, meta_step_size=0.0, meta_batch_size=2)
+        runs.append([list(b) for b in seen])
+    assert runs[0] == runs[1] and len(runs[0]) == 6
+    with pytest.raises(ValueError):
+        FOMLIS(A, train_shots=5, tail_shots=None, sample_train_val_with_replacement=True)
+
+
 def test_unsupported_features_raise():
     A = _learner()
-    with pytest.raises(NotImplementedError):
-        FOMLIS(A, train_shots=5, tail_shots=2, sample_train_val_with_replacement=True)
     with pytest.raises(ValueError):
         Gecko(A, rng_mode="reference", dist=type("D", (), {"rank": 0, "world": 2})())
 
