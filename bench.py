@@ -3,6 +3,9 @@
     python bench.py --gpus N --steps K --warmup W          (N = 1)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
+Launch contract: for N > 1 the launcher (torch.distributed.run) exports RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*; this process
+binds cuda:LOCAL_RANK and joins the nccl (= RCCL) group BEFORE its first GPU call; nothing here re-executes the program.
+
 One "step" = one meta-step: every rank adapts ONE synthetic 5-shot task (BASELINE.json configs[1]: 8 inner SGD steps of batch 8
 = 64 image passes, fp32, drop-connect on), then the outer Reptile update (one RCCL all-reduce of the flat delta when N > 1).
 Meta-batch = N tasks, one per GPU (weak scaling, no data-path collective besides that exchange).  Synthetic data of
@@ -56,6 +59,14 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--pool", type=int, default=8, help="number of distinct synthetic tasks resident per GPU")
     return ap.parse_args()
+
+
+def _rccl_version():
+    try:
+        v = torch.cuda.nccl.version()
+        return ".".join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v)
+    except Exception:   # noqa: BLE001  (reporting only)
+        return None
 
 
 def usable_cores() -> int:
@@ -170,9 +181,12 @@ def roofline(L, args):
     out = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
            "traffic": traffic, "traffic_source": tsrc, "launches_per_step": d["n"] // reps_dom, "avg_launch_us": 1e3 * d["ms"] / d["n"],
            "algorithmic_flops_per_launch": d["flops"] / d["n"]}
-    # depthwise families against the HBM roofline: algorithmic bytes / the kernels' own durations.  The launches of one
-    # eager step are recorded at the C ABI and re-issued back to back straight through ctypes (a Python-level wrapper call costs
-    # about as much as one of the 5 us kernels and would be what is timed).
+    # depthwise families against the HBM roofline: algorithmic bytes / the kernels' own durations, measured COLD: the
+    # launches of one eager step are recorded at the C ABI and re-issued straight through ctypes (a Python-level wrapper call costs
+    # about as much as one of these kernels) over ROTATING copies of their activation operands -- enough copies that a tensor is
+    # only touched again after > 320 MB of other traffic, i.e. after the 256 MiB Infinity Cache has been flushed.  (Re-issuing one
+    # launch back to back on the same <= 39 MB tensors, as round 1 did, times the cache, not HBM.)  Inside a real step the operands are
+    # partly cache-resident (the producer ran just before), so the in-step durations of profiles/r02_*_kernel_stats.csv are shorter.
     from mliis_amd._lib import lib as _lib
     from mliis_amd.spec import same_pad
     L.use_graph = False
@@ -182,31 +196,67 @@ def roofline(L, args):
     calls, _lib.trace = _lib.trace, None
     L.use_graph = saved
     dll = _lib.load()
-    dw = {}
-    for k in ("dwconv_fwd", "dwconv_bwd_data", "dwconv_bwd_filter"):
-        ksites = [(n, a) for n, a in calls if n == "mliis_" + k or (k == "dwconv_bwd_data" and n == "mliis_dwconv_bwd_data_bn")]
-        if not ksites:
-            continue
-        kms, kbytes = 0.0, 0.0
-        with torch.cuda.stream(L.stream):
-            for n, a in ksites:
-                fn = getattr(dll, n)
-                fn(*a)
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(L.stream)
-                for _ in range(20):
-                    fn(*a)
-                e1.record(L.stream)
-                e1.synchronize()
-                kms += e0.elapsed_time(e1) / 20
-                nb, h, w_, c, kk, st = a[3:9]
-                ho, wo = same_pad(h, kk, st)[0], same_pad(w_, kk, st)[0]
-                i_el, o_el, w_el = nb * h * w_ * c, nb * ho * wo * c, kk * kk * c
-                kbytes += 4.0 * (i_el + o_el + w_el)   # fwd: X + Y + W; bwd-data: dY + dX + W; bwd-filter: X + dY + dW
-                if n.endswith("_bn"):
-                    kbytes += 4.0 * i_el               # ... + z0: the launch also produces the expand BN's backward statistics
-        dw[k] = {"us_per_step": 1e3 * kms, "launches_per_step": len(ksites), "algorithmic_MB_per_step": kbytes / 1e6,
-                 "GBps": kbytes / (kms * 1e-3) / 1e9, "frac_of_8TBps": kbytes / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    # entry point -> (family, index of N in the argument list, {pointer argument: "i" input-resolution | "o" output-resolution tensor},
+    #                 pointer arguments nulled in the re-issues (moving averages: the learner's own state must not be advanced))
+    DW = {"mliis_dwconv_fwd": ("dwconv_fwd", 3, {0: "i", 2: "o"}, ()),
+          "mliis_dwconv_bwd_data": ("dwconv_bwd_data", 3, {0: "o", 2: "i"}, ()),
+          "mliis_dwconv_bwd_data_bn": ("dwconv_bwd_data", 3, {0: "o", 2: "i", 9: "i"}, ()),
+          "mliis_dwconv_bwd_filter": ("dwconv_bwd_filter", 3, {0: "i", 1: "o"}, ()),
+          "mliis_mbconv_dw_fwd_small": ("mbconv_small_fwd", 20, {0: "i", 17: "o", 18: "o"}, (7, 8, 14, 15)),
+          "mliis_mbconv_dw_bwd_small": ("mbconv_small_bwd", 20, {0: "o", 3: "o", 9: "i", 19: "i"}, ())}
+    FLUSH = 320e6
+    dw, layers = {}, []
+    with torch.cuda.stream(L.stream):
+        for n, a in calls:
+            if n not in DW:
+                continue
+            fam_name, iN, rot, nulled = DW[n]
+            nb, h, w_, c, kk = a[iN:iN + 5]
+            st = a[iN + 5] if fam_name.startswith("dwconv") else 1
+            ho, wo = same_pad(h, kk, st)[0], same_pad(w_, kk, st)[0]
+            el = {"i": nb * h * w_ * c, "o": nb * ho * wo * c}
+            w_el = kk * kk * c
+            if fam_name == "mbconv_small_bwd":   # backward-data + backward-filter of the depthwise op: dY, X read, dX written, W, dW
+                nbytes = 4.0 * (2 * el["i"] + el["o"] + 2 * w_el)
+            else:                                # fwd: X + Y + W; bwd-data: dY + dX + W (+ z0 when the BN sums ride along); bwd-filter: X + dY + dW
+                nbytes = 4.0 * (el["i"] + el["o"] + w_el) + (4.0 * el["i"] if n.endswith("_bn") else 0.0)
+            copies = max(2, int(FLUSH / nbytes) + 1)
+            bufs, variants = [], []
+            for r in range(copies):
+                args_r = list(a)
+                for ix, which in rot.items():
+                    buf = torch.empty(int(el[which]), dtype=torch.float32, device=L.device).normal_()
+                    bufs.append(buf)
+                    args_r[ix] = buf.data_ptr()
+                for ix in nulled:
+                    args_r[ix] = None
+                variants.append(tuple(args_r))
+            fn = getattr(dll, n)
+            for v in variants:          # first touch of every copy (page mapping) outside the timed region
+                fn(*v)
+            reps_k = max(20, 2 * copies)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(L.stream)
+            for r in range(reps_k):
+                fn(*variants[r % copies])
+            e1.record(L.stream)
+            e1.synchronize()
+            us = 1e3 * e0.elapsed_time(e1) / reps_k
+            del variants, bufs
+            layers.append({"entry": n[6:], "N,H,W,C,k,s": [nb, h, w_, c, kk, st], "us": round(us, 2), "algorithmic_MB": round(nbytes / 1e6, 2),
+                           "frac_of_8TBps": round(nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 3), "rotating_copies": copies})
+            d_ = dw.setdefault(fam_name, {"us_per_step": 0.0, "launches_per_step": 0, "algorithmic_MB_per_step": 0.0})
+            d_["us_per_step"] += us
+            d_["launches_per_step"] += 1
+            d_["algorithmic_MB_per_step"] += nbytes / 1e6
+    for d_ in dw.values():
+        d_["GBps"] = d_["algorithmic_MB_per_step"] * 1e6 / (d_["us_per_step"] * 1e-6) / 1e9
+        d_["frac_of_8TBps"] = d_["GBps"] / HBM_PEAK_GBS
+    tot_us = sum(d_["us_per_step"] for d_ in dw.values())
+    tot_mb = sum(d_["algorithmic_MB_per_step"] for d_ in dw.values())
+    dw["all_depthwise_fwd_bwd"] = {"us_per_step": tot_us, "algorithmic_MB_per_step": tot_mb, "frac_of_8TBps": tot_mb * 1e6 / (tot_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                   "method": "cold operands: rotating copies, > 320 MB between two touches of a tensor (Infinity Cache flushed)"}
+    dw["per_layer"] = layers
     families = {k: {"us_per_step": 1e3 * v["ms"] / reps, "launches_per_step": v["n"] // reps,
                     "TFLOPs": (v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["flops"] else None} for k, v in sorted(by.items())}
     return out, dw, families
@@ -307,6 +357,11 @@ def _run(args):
                                                                  (", %d adapted concurrently" % args.concurrent_tasks if args.concurrent_tasks != 1 else "")),
                        "hip_graph": not args.no_graph, "final_loss": loss},
             "roofline": roof, "cpu_baseline": cpu,
+            # what the first real multi-GPU run can be checked against: ranks, collective library, bytes of the ONE all-reduce(sum) per
+            # meta-step (flat task delta + BN moving-average contributions, fp32)
+            "dist": {"world": world, "backend": "nccl (RCCL)" if world > 1 else None, "rccl_version": _rccl_version(),
+                     "allreduce_bytes_per_meta_step": int(meta._comm.numel() * 4) if meta._comm is not None else None,
+                     "tasks_per_meta_step": world * args.tasks_per_gpu},
         }
         if dwr is not None:
             out["depthwise_hbm"] = dwr

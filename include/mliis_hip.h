@@ -67,21 +67,42 @@ size_t mliis_dwconv_bwd_filter_workspace_floats(int N, int H, int W, int C, int 
 int mliis_dwconv_bwd_filter(const float* x, const float* dy, float* dw, int N, int H, int W, int C, int k, int stride, float* ws,
                             size_t ws_floats, hipStream_t stream);
 
+/* ---- the depthwise half of an MBConv block on SMALL maps in ONE launch per direction (mbconv_small.hip): expand BN -> swish ->
+ *      depthwise k x k (stride 1) -> BN -> swish -> squeeze-excite mean (efficientnet_model.py:183-200,266-271,247; utils.py:87-134)
+ *      and the whole backward of that chain.  Every op in it is per channel, so a workgroup that owns 8 channels over all of
+ *      [N,H,W] needs no grid-wide dependency.  Eligible shapes (else MLIIS_ERR_UNSUPPORTED, nothing launched; use the op-by-op
+ *      entry points): stride 1, k 3|5, C % 8 == 0, N*H*W <= 2048, N*ceil(H/4)*W <= 512, N <= 32.
+ *      forward: z0 = expand conv output with its stage-1 statistics part0 [nblk0][2][C] (mliis_conv2d_fwd's stats_part); writes the
+ *      batch statistics of both batch norms (mean / rstd, for the backward pass), updates both pairs of moving averages (nullable),
+ *      z1 = depthwise output, a1 = swish(bn1(z1)), s [N,C] = per-image mean of a1, and (nullable) a0 = swish(bn0(z0)).
+ *      backward: da2 = gradient w.r.t. a1 * gate (the project conv's backward-data), gate / chan_add [N,C] as in mliis_bn_bwd's
+ *      chan_scale / chan_add (nullable); writes both BN parameter gradients, the COMPLETE depthwise filter gradient dw [k,k,C] (no
+ *      slabs) and dz0 = gradient w.r.t. the expand conv's output. */
+int mliis_mbconv_dw_small_supported(int N, int H, int W, int C, int k, int stride);
+int mliis_mbconv_dw_fwd_small(const float* z0, const float* part0, int nblk0, const float* gamma0, const float* beta0, float* mean0,
+                              float* rstd0, float* moving_mean0, float* moving_var0, const float* w, const float* gamma1, const float* beta1,
+                              float* mean1, float* rstd1, float* moving_mean1, float* moving_var1, float* a0, float* z1, float* a1, float* s,
+                              int N, int H, int W, int C, int k, float eps, float momentum, hipStream_t stream);
+int mliis_mbconv_dw_bwd_small(const float* da2, const float* gate, const float* chan_add, const float* z1, const float* mean1,
+                              const float* rstd1, const float* gamma1, const float* beta1, const float* w, const float* z0, const float* mean0,
+                              const float* rstd0, const float* gamma0, const float* beta0, float* dgamma1, float* dbeta1, float* dw,
+                              float* dgamma0, float* dbeta0, float* dz0, int N, int H, int W, int C, int k, hipStream_t stream);
+
 /* ---- dense conv (k 1|3, stride 1, TF-SAME, dilation >= 1, optional bias) on the fp32 matrix cores:
  *      tf.layers.Conv2D 1x1 expand/project (efficientnet_model.py:175-182,225-232) and tf.layers.conv2d of the RSD decoder /
  *      ASPP (models/efficientlab.py:185-190,218-224,258-283).  w is TF HWIO [k,k,Cin,Cout]; the forward reads its K-contiguous
  *      copy wt [k,k,Cout,Cin] (mliis_transpose_weights, once per weight update), backward-data reads w itself.  `accumulate` != 0
  *      adds into the destination.  ws may be NULL (disables split-K). */
 size_t mliis_conv2d_workspace_floats(int Nimg, int H, int W, int Cred, int Nout, int ksize);
-/*      operand precision of the matrix cores for every later dense-conv call (process-wide): 0 = fp32 operands (default; BASELINE
- *      configs 1-3), 1 = bf16 operands converted on the fly from the fp32 tensors with fp32 accumulation (configs 4-5 flavour:
- *      tensors, BN, depthwise, the optimiser and the memory-bound short-K 1x1 convs (K <= 112) stay fp32) */
-int mliis_set_matmul_precision(int bf16);
-int mliis_get_matmul_precision(void);
+/*      `precision` (per call; nothing process-wide): operand precision of the matrix cores.  MLIIS_PREC_FP32 = fp32 operands
+ *      (BASELINE configs 1-3), MLIIS_PREC_BF16 = operands rounded to bf16 in registers with fp32 accumulation (configs 4-5 flavour:
+ *      tensors, BN, depthwise and the optimiser stay fp32). */
+#define MLIIS_PREC_FP32 0
+#define MLIIS_PREC_BF16 1
 /*      tiling chosen for a fwd / bwd-data call (row-tile factor, column tiles, split-K factor) and the name of the kernel
  *      instantiation it launches, as rocprofv3 prints it (profiling aids: bench.py matches its live timings to the trace) */
 int mliis_conv2d_plan(int Nimg, int H, int W, int Cred, int Nout, int ksize, int* tm, int* nt, int* splits);
-int mliis_conv2d_kernel_name(int Nimg, int H, int W, int Cred, int Nout, int ksize, int has_scale, char* buf, size_t buf_len);
+int mliis_conv2d_kernel_name(int Nimg, int H, int W, int Cred, int Nout, int ksize, int has_scale, int precision, char* buf, size_t buf_len);
 /*      stats_part (nullable): the epilogue also emits the following batch norm's stage-1 statistics -- per row-block column sums
  *      {sum v, sum v^2} (of swish(v) when stats_swish) as [*stats_nblk][2][Cout], written by the GEMM epilogue or, on a split-K
  *      plan, by the slab fold.  *stats_nblk == 0 means "not produced": the caller must run mliis_bn_stats_partial instead.
@@ -94,19 +115,19 @@ int mliis_conv2d_kernel_name(int Nimg, int H, int W, int Cred, int Nout, int ksi
 int mliis_conv2d_fwd(const float* x, int ldx, const float* x_scale, const float* wt, const float* bias,
                      const float* border_bias, float* y, int ldy, int Nimg, int H, int W, int Cin_total, int ci_begin, int Cin, int Cout,
                      int ksize, int dil, int accumulate, float* stats_part, int stats_swish, int* stats_nblk, float* ws,
-                     size_t ws_floats, hipStream_t stream);
+                     size_t ws_floats, int precision, hipStream_t stream);
 /*      batched HWIO -> HWOI copy of dense-conv weights between two arenas of identical layout; desc = device int32
  *      [ndesc][4] {offset, taps, Cin, Cout} */
 int mliis_transpose_weights(const float* src, float* dst, const int* desc, int ndesc, hipStream_t stream);
 /*      gradient w.r.t. input channels [ci_begin, ci_begin+Cin_out) of a conv whose weight has Cin_total input channels */
 int mliis_conv2d_bwd_data(const float* dy, int lddy, const float* w, float* dx, int lddx, int Nimg, int H, int W, int Cin_total,
                           int ci_begin, int Cin_out, int Cout, int ksize, int dil, int accumulate, float* ws, size_t ws_floats,
-                          hipStream_t stream);
+                          int precision, hipStream_t stream);
 size_t mliis_conv2d_bwd_filter_workspace_floats(int Nimg, int H, int W, int Cin, int Cout, int ksize);
 /*      writes rows [ci_begin, ci_begin+Cin) (per tap) of the full [k,k,Cin_total,Cout] gradient tensor dw */
 int mliis_conv2d_bwd_filter(const float* x, int ldx, const float* x_scale, const float* dy, int lddy, float* dw, int Nimg, int H, int W,
                             int Cin_total, int ci_begin, int Cin, int Cout, int ksize, int dil, int accumulate, float* ws,
-                            size_t ws_floats, hipStream_t stream);
+                            size_t ws_floats, int precision, hipStream_t stream);
 
 /* ---- RSD pooled branch (models/efficientlab.py:192-197,220-224) without convolving it: the Cp spatially constant channels
  *      [c_begin, c_begin+Cp) of the 3x3 fuse conv's input become a per-image, per-border-class bias (forward) and need only

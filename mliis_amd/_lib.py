@@ -31,20 +31,21 @@ SIGNATURES = {
     "mliis_dwconv_bwd_data_bn": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _sz, _p, _p]),
     "mliis_dwconv_bwd_filter_workspace_floats": (_sz, [_i, _i, _i, _i, _i, _i]),
     "mliis_dwconv_bwd_filter": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _sz, _p]),
+    "mliis_mbconv_dw_small_supported": (_i, [_i, _i, _i, _i, _i, _i]),
+    "mliis_mbconv_dw_fwd_small": (_i, [_p, _p, _i] + [_p] * 17 + [_i, _i, _i, _i, _i, _f, _f, _p]),
+    "mliis_mbconv_dw_bwd_small": (_i, [_p] * 20 + [_i, _i, _i, _i, _i, _p]),
     "mliis_conv2d_workspace_floats": (_sz, [_i, _i, _i, _i, _i, _i]),
-    "mliis_set_matmul_precision": (_i, [_i]),
-    "mliis_get_matmul_precision": (_i, []),
     "mliis_conv2d_plan": (_i, [_i, _i, _i, _i, _i, _i, _p, _p, _p]),
-    "mliis_conv2d_kernel_name": (_i, [_i, _i, _i, _i, _i, _i, _i, _p, _sz]),
-    "mliis_conv2d_fwd": (_i, [_p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _p, _sz, _p]),
+    "mliis_conv2d_kernel_name": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _p, _sz]),
+    "mliis_conv2d_fwd": (_i, [_p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _p, _sz, _i, _p]),
     "mliis_rsd_pool_fwd_workspace_floats": (_sz, [_i, _i]),
     "mliis_rsd_pool_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _sz, _p]),
     "mliis_rsd_pool_bwd_workspace_floats": (_sz, [_i, _i]),
     "mliis_rsd_pool_bwd": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _p]),
     "mliis_transpose_weights": (_i, [_p, _p, _p, _i, _p]),
-    "mliis_conv2d_bwd_data": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _p]),
+    "mliis_conv2d_bwd_data": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _i, _p]),
     "mliis_conv2d_bwd_filter_workspace_floats": (_sz, [_i, _i, _i, _i, _i, _i]),
-    "mliis_conv2d_bwd_filter": (_i, [_p, _i, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _p]),
+    "mliis_conv2d_bwd_filter": (_i, [_p, _i, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _i, _p]),
     "mliis_colreduce_workspace_floats": (_sz, [_ll, _i, _i, _i]),
     "mliis_bn_stats": (_i, [_p, _i, _ll, _i, _i, _f, _f, _i, _p, _p, _p, _p, _p, _sz, _p]),
     "mliis_bn_apply": (_i, [_p, _i, _p, _i, _ll, _i, _i, _p, _p, _p, _p, _i, _i, _p, _p, _i, _p]),

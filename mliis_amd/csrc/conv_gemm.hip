@@ -227,16 +227,21 @@ static inline FilterPlan plan_filter(long long M, int C, int Nout, int ntaps, in
   return f;
 }
 
-// Matrix-core operand precision of the dense convs (mliis_set_matmul_precision): 0 = fp32 (default), 1 = bf16 operands with fp32
-// accumulation.  Process-wide; read when a call is issued (a captured HIP graph keeps what it was captured with).
-static int g_matmul_bf16 = 0;
-static void launch_gemm(const GemmPlan& g, const ConvGemmParams& p, hipStream_t stream) {
-  if (g_matmul_bf16) launch_gemm_bf16(g, p, stream);
+// Matrix-core operand precision of a dense-conv call (the `precision` argument of the three entry points): MLIIS_PREC_FP32 = fp32
+// operands (v_mfma_f32_16x16x4_f32), MLIIS_PREC_BF16 = operands rounded to bf16 in registers, fp32 accumulation
+// (v_mfma_f32_16x16x32_bf16).  Per call: nothing process-wide, a captured HIP graph keeps what each launch was issued with.
+static void launch_gemm(const GemmPlan& g, const ConvGemmParams& p, int precision, hipStream_t stream) {
+  if (precision == MLIIS_PREC_BF16) launch_gemm_bf16(g, p, stream);
   else launch_gemm_t<false>(g, p, stream);
 }
-static void launch_filter(const FilterPlan& f, const FilterGradParams& p, hipStream_t stream) {
-  if (g_matmul_bf16) launch_filter_bf16(f, p, stream);
+static void launch_filter(const FilterPlan& f, const FilterGradParams& p, int precision, hipStream_t stream) {
+  if (precision == MLIIS_PREC_BF16) launch_filter_bf16(f, p, stream);
   else launch_filter_t<false>(f, p, stream);
+}
+static int prec_check(const char* name, int precision) {
+  MLIIS_REQUIRE(precision == MLIIS_PREC_FP32 || precision == MLIIS_PREC_BF16, MLIIS_ERR_ARG,
+                "%s: precision must be MLIIS_PREC_FP32 (0) or MLIIS_PREC_BF16 (1), got %d", name, precision);
+  return MLIIS_OK;
 }
 
 // ------------------------------------------------------------------------------------------------ short-K 1x1 convs (conv1x1_stream_k)
@@ -310,15 +315,6 @@ using namespace mliis;
 
 extern "C" {
 
-// Operand precision of the matrix cores for every later conv2d_fwd / _bwd_data / _bwd_filter call: 0 = fp32 (v_mfma_f32_16x16x4_f32),
-// 1 = bf16 operands converted on the fly from the fp32 tensors, fp32 accumulation (v_mfma_f32_16x16x32_bf16).
-int mliis_set_matmul_precision(int bf16) {
-  MLIIS_REQUIRE(bf16 == 0 || bf16 == 1, MLIIS_ERR_ARG, "set_matmul_precision: 0 (fp32) or 1 (bf16 operands)");
-  g_matmul_bf16 = bf16;
-  return MLIIS_OK;
-}
-int mliis_get_matmul_precision(void) { return g_matmul_bf16; }
-
 // Tiling the planner picks for a conv2d_fwd / conv2d_bwd_data call (profiling aid: row-tile factor, column tiles, split-K factor).
 int mliis_conv2d_plan(int Nimg, int H, int W, int Cred, int Nout, int ksize, int* tm, int* nt, int* splits) {
   MLIIS_REQUIRE(tm && nt && splits, MLIIS_ERR_ARG, "conv2d_plan: null pointer");
@@ -331,7 +327,7 @@ int mliis_conv2d_plan(int Nimg, int H, int W, int Cred, int Nout, int ksize, int
 
 // Name of the kernel instantiation (as rocprofv3 prints it, without the mliis:: prefix and argument list) that a conv2d_fwd /
 // conv2d_bwd_data call with these shapes launches (has_scale: an x_scale operand is given).
-int mliis_conv2d_kernel_name(int Nimg, int H, int W, int Cred, int Nout, int ksize, int has_scale, char* buf, size_t buf_len) {
+int mliis_conv2d_kernel_name(int Nimg, int H, int W, int Cred, int Nout, int ksize, int has_scale, int precision, char* buf, size_t buf_len) {
   MLIIS_REQUIRE(buf && buf_len >= 64, MLIIS_ERR_ARG, "conv2d_kernel_name: buffer too small");
   StreamPlan sp;
   if (ksize == 1 && !has_scale && stream_plan((long long)Nimg * H * W, Cred, Nout, num_cus(), &sp)) {
@@ -340,7 +336,7 @@ int mliis_conv2d_kernel_name(int Nimg, int H, int W, int Cred, int Nout, int ksi
   }
   GemmPlan g = plan_gemm((long long)Nimg * H * W, Nout, Cred, ksize * ksize, num_cus(), 1);
   snprintf(buf, buf_len, "conv_gemm_nk_k<%d, %d, %d, %s, %s, %s, %s>", g.tm, g.nt, g.tm == 1 ? 2 : 1, has_scale ? "true" : "false",
-           g.gz > 1 ? "true" : "false", gemm_narrow(ksize * ksize, Cred) ? "true" : "false", g_matmul_bf16 ? "true" : "false");
+           g.gz > 1 ? "true" : "false", gemm_narrow(ksize * ksize, Cred) ? "true" : "false", precision == MLIIS_PREC_BF16 ? "true" : "false");
   return MLIIS_OK;
 }
 
@@ -356,9 +352,10 @@ size_t mliis_conv2d_workspace_floats(int Nimg, int H, int W, int Cred, int Nout,
 int mliis_conv2d_fwd(const float* x, int ldx, const float* x_scale, const float* wt, const float* bias,
                      const float* border_bias, float* y, int ldy, int Nimg, int H, int W, int Cin_total, int ci_begin, int Cin, int Cout,
                      int ksize, int dil, int accumulate, float* stats_part, int stats_swish, int* stats_nblk, float* ws,
-                     size_t ws_floats, hipStream_t stream) {
+                     size_t ws_floats, int precision, hipStream_t stream) {
   int rc = conv_check("conv2d_fwd", Nimg, H, W, Cin, Cout, ksize, dil);
   if (rc) return rc;
+  if ((rc = prec_check("conv2d_fwd", precision))) return rc;
   MLIIS_REQUIRE(x && wt && y, MLIIS_ERR_ARG, "conv2d_fwd: null pointer");
   MLIIS_REQUIRE((ldx & 3) == 0 && ldx >= Cin && (ldy & 3) == 0 && ldy >= Cout, MLIIS_ERR_ARG, "conv2d_fwd: bad leading dimensions");
   MLIIS_REQUIRE(aligned16(x) && aligned16(wt) && aligned16(bias) && aligned16(y), MLIIS_ERR_ALIGN,
@@ -409,7 +406,7 @@ int mliis_conv2d_fwd(const float* x, int ldx, const float* x_scale, const float*
                   "conv2d_fwd: split-K workspace too small (%zu needed, %zu given) or unaligned output", need, ws_floats);
     p.partial = ws;
   }
-  launch_gemm(g, p, stream);
+  launch_gemm(g, p, precision, stream);
   MLIIS_CHECK_LAUNCH("conv2d_fwd");
   if (g.gz > 1 && stats_part != nullptr) {
     hipLaunchKernelGGL(splitk_reduce_stats_k, dim3((unsigned)((M + kRedRows - 1) / kRedRows), (Cout + 31) / 32), dim3(256), 0, stream, ws, g.gz,
@@ -428,9 +425,10 @@ int mliis_conv2d_fwd(const float* x, int ldx, const float* x_scale, const float*
 // [ci_begin, ci_begin + Cin_out) of a weight tensor w[k,k,Cin_total,Cout].
 int mliis_conv2d_bwd_data(const float* dy, int lddy, const float* w, float* dx, int lddx, int Nimg, int H, int W, int Cin_total,
                           int ci_begin, int Cin_out, int Cout, int ksize, int dil, int accumulate, float* ws, size_t ws_floats,
-                          hipStream_t stream) {
+                          int precision, hipStream_t stream) {
   int rc = conv_check("conv2d_bwd_data", Nimg, H, W, Cin_out, Cout, ksize, dil);
   if (rc) return rc;
+  if ((rc = prec_check("conv2d_bwd_data", precision))) return rc;
   MLIIS_REQUIRE(dy && w && dx, MLIIS_ERR_ARG, "conv2d_bwd_data: null pointer");
   MLIIS_REQUIRE(ci_begin >= 0 && ci_begin + Cin_out <= Cin_total, MLIIS_ERR_ARG, "conv2d_bwd_data: channel window out of range");
   MLIIS_REQUIRE((lddy & 3) == 0 && lddy >= Cout && (lddx & 3) == 0 && lddx >= Cin_out && (ci_begin & 3) == 0, MLIIS_ERR_ARG,
@@ -456,7 +454,7 @@ int mliis_conv2d_bwd_data(const float* dy, int lddy, const float* w, float* dx, 
                   "conv2d_bwd_data: split-K workspace too small (%zu needed, %zu given) or unaligned output", need, ws_floats);
     p.partial = ws;
   }
-  launch_gemm(g, p, stream);
+  launch_gemm(g, p, precision, stream);
   MLIIS_CHECK_LAUNCH("conv2d_bwd_data");
   if (g.gz > 1) {
     long long q = M * (Cin_out / 4);
@@ -484,9 +482,10 @@ size_t mliis_conv2d_bwd_filter_workspace_floats(int Nimg, int H, int W, int Cin,
 // dw[k,k,Cin,Cout] (+)= sum_pixels x[pixel + tap offset, ci] * dy[pixel, co]
 int mliis_conv2d_bwd_filter(const float* x, int ldx, const float* x_scale, const float* dy, int lddy, float* dw, int Nimg, int H, int W,
                             int Cin_total, int ci_begin, int Cin, int Cout, int ksize, int dil, int accumulate, float* ws,
-                            size_t ws_floats, hipStream_t stream) {
+                            size_t ws_floats, int precision, hipStream_t stream) {
   int rc = conv_check("conv2d_bwd_filter", Nimg, H, W, Cin, Cout, ksize, dil);
   if (rc) return rc;
+  if ((rc = prec_check("conv2d_bwd_filter", precision))) return rc;
   MLIIS_REQUIRE(x && dy && ws, MLIIS_ERR_ARG, "conv2d_bwd_filter: null pointer");   // dw == NULL: leave the slabs in ws (mliis_fold_batched)
   MLIIS_REQUIRE((ldx & 3) == 0 && ldx >= Cin && (lddy & 3) == 0 && lddy >= Cout, MLIIS_ERR_ARG, "conv2d_bwd_filter: bad leading dimensions");
   MLIIS_REQUIRE(aligned16(x) && aligned16(dy) && aligned16(ws), MLIIS_ERR_ALIGN, "conv2d_bwd_filter: pointers must be 16-byte aligned");
@@ -499,7 +498,7 @@ int mliis_conv2d_bwd_filter(const float* x, int ldx, const float* x_scale, const
                 (size_t)f.gz * total, ws_floats);
   MLIIS_REQUIRE(aligned16(x_scale), MLIIS_ERR_ALIGN, "conv2d_bwd_filter: x_scale must be 16-byte aligned");
   FilterGradParams p{x, ldx, Nimg, H, W, Cin, ksize * ksize, dil, dy, lddy, Cout, ws, f.rows_per_split, x_scale, f.multitap};
-  launch_filter(f, p, stream);
+  launch_filter(f, p, precision, stream);
   MLIIS_CHECK_LAUNCH("conv2d_bwd_filter");
   MLIIS_REQUIRE(ci_begin >= 0 && ci_begin + Cin <= Cin_total, MLIIS_ERR_ARG, "conv2d_bwd_filter: input-channel window out of range");
   if (dw == nullptr) return MLIIS_OK;

@@ -21,7 +21,9 @@ Graph semantics restated from: models/efficientlab.py:111-119,126-231,294-317; m
 from __future__ import annotations
 
 import ctypes as C
+import functools
 import math
+import os
 from typing import Dict, List, Optional, Sequence
 
 import numpy as np
@@ -60,6 +62,8 @@ class _Plan:
                 continue
             B = {}
             hi, ho, ce = b.h_in, b.h_out, b.cexp
+            # small maps (14x14 at 224x224 inputs): the depthwise half of the block runs as ONE launch per direction (mbconv_small.hip)
+            B["small"] = bool(L.small_fused and b.expand != 1 and ops.mbconv_dw_small_supported(N, hi, hi, ce, b.k, b.stride))
             if b.expand != 1:
                 B["z0"], B["a0"], B["st0"] = buf(N, hi, hi, ce), buf(N, hi, hi, ce), vec(ce)
             B["z1"], B["a1"], B["st1"] = buf(N, ho, ho, ce), buf(N, ho, ho, ce), vec(ce)
@@ -128,11 +132,12 @@ class _Plan:
             tile += -(-total // fold_tile)
         fe = a.name
         add(f"{fe}/stem/conv2d/kernel", lib.size("mliis_stem_conv_bwd_filter_workspace_floats", N, H, H, a.stem_out), 27 * a.stem_out)
-        for b, nm in zip([b for b in a.blocks if b.executed], L.n_blocks):
+        for b, nm, B in zip([b for b in a.blocks if b.executed], L.n_blocks, self.blocks):
             ce = b.cexp
             if b.expand != 1:
                 add(nm["w_exp"], lib.size("mliis_conv2d_bwd_filter_workspace_floats", N, b.h_in, b.h_in, b.cin, ce, 1), b.cin * ce)
-            add(nm["w_dw"], lib.size("mliis_dwconv_bwd_filter_workspace_floats", N, b.h_in, b.h_in, ce, b.k, b.stride), b.k * b.k * ce)
+            if not B["small"]:   # (the small-map backward kernel writes the complete depthwise filter gradient itself: no slabs)
+                add(nm["w_dw"], lib.size("mliis_dwconv_bwd_filter_workspace_floats", N, b.h_in, b.h_in, ce, b.k, b.stride), b.k * b.k * ce)
             add(nm["w_proj"], lib.size("mliis_conv2d_bwd_filter_workspace_floats", N, b.h_out, b.h_out, ce, b.cout, 1), ce * b.cout)
         self.filter_tail = {}
         for j_rsd, (m, nm) in enumerate(zip(a.rsd, L.n_rsd)):
@@ -177,7 +182,7 @@ class Learner:
                  dice: bool = False, label_smoothing: float = 0.0, final_layer_dropout_rate: float = 0.0,
                  spatial_pyramid_pooling: bool = False, skip_decoding: bool = False, drop_connect: bool = True, seed: int = 0,
                  device="cuda:0", use_graph: bool = True, max_shots: int = 16, matmul_precision: str = "fp32",
-                 overlap_wgrad: int = 0, wgrad_flush_before: Sequence[int] = (5,)):
+                 overlap_wgrad: int = 0, wgrad_flush_before: Sequence[int] = (5,), small_fused: Optional[bool] = None):
         if skip_decoding:
             raise NotImplementedError("the DeepLabv3+ --skip_decoding decoder is not built (not part of EfficientLab-6-3; SURVEY.md 8(a) a18)")
         if l1 or darc1:
@@ -188,9 +193,13 @@ class Learner:
             raise MliisError("mliis_amd.Learner needs an MI355X (HIP device); there is no CPU path")
         lib.load()  # fail loudly if the HIP extension is missing
         # operand precision of the matrix cores in the dense convs: "fp32" (BASELINE configs 1-3) or "bf16" (operands rounded to bf16 on
-        # the fly, fp32 accumulation; everything else stays fp32).  Process-wide switch of the library.
-        ops.set_matmul_precision(matmul_precision)
+        # the fly, fp32 accumulation; everything else stays fp32).  Passed with every dense-conv call (nothing process-wide).
+        if matmul_precision not in ops.PRECISIONS:
+            raise ValueError("matmul_precision must be one of {}, got {!r}".format(sorted(ops.PRECISIONS), matmul_precision))
         self.matmul_precision = matmul_precision
+        self._conv_fwd = functools.partial(ops.conv2d_fwd, precision=matmul_precision)
+        self._conv_bwd_data = functools.partial(ops.conv2d_bwd_data, precision=matmul_precision)
+        self._conv_bwd_filter = functools.partial(ops.conv2d_bwd_filter, precision=matmul_precision)
         self.device = torch.device(device)
         torch.cuda.set_device(self.device)
         self.arch = spec.derive(feature_extractor_name, image_size, list(rsd or []), final_layer_dropout_rate, spatial_pyramid_pooling)
@@ -200,6 +209,8 @@ class Learner:
         self.l2, self.dice, self.label_smoothing = bool(l2), bool(dice), float(label_smoothing)
         self.final_layer_dropout_rate = float(final_layer_dropout_rate or 0.0)
         self.drop_connect = drop_connect
+        # small-map blocks through the one-launch-per-direction kernels of mbconv_small.hip (MLIIS_SMALL_FUSED=0: op by op, for A/B runs)
+        self.small_fused = (os.environ.get("MLIIS_SMALL_FUSED", "1") != "0") if small_fused is None else bool(small_fused)
         self.use_graph = use_graph
         self.stream = torch.cuda.Stream(device=self.device)
         self._dc_keeps = None
@@ -444,9 +455,9 @@ class Learner:
         def conv(xin, wname, bname, dil, out, swish_stats, x_scale=None, border_bias=None):
             """dense conv; in training the epilogue also emits the following BN's statistics (returns their block count)."""
             if training:
-                return ops.conv2d_fwd(xin, w[wname], w[bname] if bname else None, dil, out=out, ws=ws, stats_part=P.stats_part,
+                return self._conv_fwd(xin, w[wname], w[bname] if bname else None, dil, out=out, ws=ws, stats_part=P.stats_part,
                                       stats_swish=swish_stats, wt=self.wt[wname], x_scale=x_scale, border_bias=border_bias)[1]
-            ops.conv2d_fwd(xin, w[wname], w[bname] if bname else None, dil, out=out, ws=ws, wt=self.wt[wname], x_scale=x_scale,
+            self._conv_fwd(xin, w[wname], w[bname] if bname else None, dil, out=out, ws=ws, wt=self.wt[wname], x_scale=x_scale,
                            border_bias=border_bias)
             return 0
 
@@ -456,6 +467,25 @@ class Learner:
         for b, B, nm in zip(ex, P.blocks, self.n_blocks):
             B["x_in"] = cur
             t = cur
+            if training and B["small"]:
+                # expand GEMM (+ stage-1 statistics) -> ONE launch: bn0 fold + apply + swish, depthwise, bn1 statistics + apply + swish,
+                # squeeze-excite means, both moving averages -> SE MLP -> project GEMM
+                nb = conv(t, nm["w_exp"], None, 1, B["z0"], False)
+                if nb == 0:
+                    nb = ops.bn_stats_partial(B["z0"], False, P.stats_part)
+                p0, p1 = nm["bn0"], nm["bn1"]
+                ops.mbconv_dw_fwd_small(B["z0"], P.stats_part, nb,
+                                        (w[p0 + "/gamma"], w[p0 + "/beta"], B["st0"][0], B["st0"][1], mv[p0 + "/moving_mean"], mv[p0 + "/moving_variance"]),
+                                        w[nm["w_dw"]],
+                                        (w[p1 + "/gamma"], w[p1 + "/beta"], B["st1"][0], B["st1"][1], mv[p1 + "/moving_mean"], mv[p1 + "/moving_variance"]),
+                                        B["z1"], B["a1"], B["s"])
+                se = nm["se"]
+                ops.se_mlp_fwd(B["s"], w[se[0]], w[se[1]], w[se[2]], w[se[3]], B["hpre"], B["gate"])
+                nb = conv(B["a1"], nm["w_proj"], None, 1, B["z2"], False, x_scale=B["gate"])
+                use_dc = self.drop_connect and b.skip and b.drop_rate > 0
+                B["use_dc"] = use_dc
+                cur = bn(B["z2"], B["st2"], nm["bn2"], B["out"], img_scale=B["dc"] if use_dc else None, res=B["x_in"] if b.skip else None, nblk=nb)
+                continue
             if b.expand != 1:
                 nb = conv(t, nm["w_exp"], None, 1, B["z0"], False)
                 t = bn(B["z0"], B["st0"], nm["bn0"], B["a0"], post=True, nblk=nb)
@@ -520,15 +550,15 @@ class Learner:
         (k0, c0), (k1, c1), (k2, c2), (ko, co) = self.n_aspp
         m = T["masks"] if training else [None] * 4
         cat = T["cat"]
-        ops.conv2d_fwd(x, w[k0], w[c0], 1, out=T["z0"], ws=ws, wt=self.wt[k0])
+        self._conv_fwd(x, w[k0], w[c0], 1, out=T["z0"], ws=ws, wt=self.wt[k0])
         ops.swish_mask_fwd(T["z0"], m[0], out=cat[..., 2 * d:])
-        ops.conv2d_fwd(x, w[k1], w[c1], spec.ASPP_DILATION, out=T["z1"], ws=ws, wt=self.wt[k1])
+        self._conv_fwd(x, w[k1], w[c1], spec.ASPP_DILATION, out=T["z1"], ws=ws, wt=self.wt[k1])
         ops.swish_mask_fwd(T["z1"], m[1], out=cat[..., d:2 * d])
         ops.colsum(x, None, nseg=N, scale=1.0 / hw, out=T["pool"], ws=ws)
-        ops.conv2d_fwd(T["pool"].view(N, 1, 1, -1), w[k2], w[c2], 1, out=T["z2"].view(N, 1, 1, d), ws=ws, wt=self.wt[k2])
+        self._conv_fwd(T["pool"].view(N, 1, 1, -1), w[k2], w[c2], 1, out=T["z2"].view(N, 1, 1, d), ws=ws, wt=self.wt[k2])
         ops.swish_mask_fwd(T["z2"], m[2], out=T["b2"], pre_mask=True)
         ops.chan_affine(None, A=T["b2"], out=cat[..., :d])      # bilinear resize of the 1x1 pooled map = broadcast
-        ops.conv2d_fwd(cat, w[ko], w[co], 1, out=T["zo"], ws=ws, wt=self.wt[ko])
+        self._conv_fwd(cat, w[ko], w[co], 1, out=T["zo"], ws=ws, wt=self.wt[ko])
         ops.swish_mask_fwd(T["zo"], m[3], out=T["out"])
         T["trained"] = training
         return T["out"]
@@ -542,26 +572,26 @@ class Learner:
         m = T["masks"]
         cat, dcat = T["cat"], T["dcat"]
         dzo = ops.swish_mask_bwd(T["dout"], T["zo"], m[3], out=T["dzo"])
-        ops.conv2d_bwd_filter(cat, dzo, 1, 1, out=g[ko], ws=ws)
+        self._conv_bwd_filter(cat, dzo, 1, 1, out=g[ko], ws=ws)
         ops.colsum(dzo, out=g[co], ws=ws)
-        ops.conv2d_bwd_data(dzo, w[ko], 1, out=dcat, ws=ws)
+        self._conv_bwd_data(dzo, w[ko], 1, out=dcat, ws=ws)
         # 1x1 branch (the pre-activation gradient overwrites its slice of dcat)
         d0 = ops.swish_mask_bwd(dcat[..., 2 * d:], T["z0"], m[0], out=dcat[..., 2 * d:])
-        ops.conv2d_bwd_filter(x, d0, 1, 1, out=g[k0], ws=ws)
+        self._conv_bwd_filter(x, d0, 1, 1, out=g[k0], ws=ws)
         ops.colsum(d0, out=g[c0], ws=ws)
-        ops.conv2d_bwd_data(d0, w[k0], 1, out=dx, accumulate=dx_has, ws=ws)
+        self._conv_bwd_data(d0, w[k0], 1, out=dx, accumulate=dx_has, ws=ws)
         # 3x3 dilation-6 branch
         d1 = ops.swish_mask_bwd(dcat[..., d:2 * d], T["z1"], m[1], out=dcat[..., d:2 * d])
-        ops.conv2d_bwd_filter(x, d1, 3, spec.ASPP_DILATION, out=g[k1], ws=ws)
+        self._conv_bwd_filter(x, d1, 3, spec.ASPP_DILATION, out=g[k1], ws=ws)
         ops.colsum(d1, out=g[c1], ws=ws)
-        ops.conv2d_bwd_data(d1, w[k1], spec.ASPP_DILATION, out=dx, accumulate=True, ws=ws)
+        self._conv_bwd_data(d1, w[k1], spec.ASPP_DILATION, out=dx, accumulate=True, ws=ws)
         # image-pooling branch: per-image sums of the broadcast slice -> [N, d] chain -> mean's gradient on every pixel
         ops.colsum(dcat[..., :d], None, nseg=N, out=T["db2"], ws=ws)
         d2 = ops.swish_mask_bwd(T["db2"], T["z2"], m[2], out=T["db2"], pre_mask=True)
         pool4, d24 = T["pool"].view(N, 1, 1, -1), d2.view(N, 1, 1, d)
-        ops.conv2d_bwd_filter(pool4, d24, 1, 1, out=g[k2], ws=ws)
+        self._conv_bwd_filter(pool4, d24, 1, 1, out=g[k2], ws=ws)
         ops.colsum(d2, out=g[c2], ws=ws)
-        ops.conv2d_bwd_data(d24, w[k2], 1, out=T["dpool"].view(N, 1, 1, -1), ws=ws)
+        self._conv_bwd_data(d24, w[k2], 1, out=T["dpool"].view(N, 1, 1, -1), ws=ws)
         ops.axpby(0.0, None, 1.0 / hw, T["dpool"])                       # d(mean)/dx = 1 / (h*w) on every pixel
         ops.chan_affine(None, A=T["dpool"], out=dx, accumulate=True)
 
@@ -621,22 +651,22 @@ class Learner:
             bn_b(D["zf"], dO, D["stf"], nf, D["dzf"], pre=True)
             ops.colsum(D["dzf"], None, nseg=N, out=D["tot"], ws=ws)
             ops.rsd_pool_bwd(D["dzf"], D["tot"], D["pool"], w[kf], 2 * co, dw=g[kf], dbias=g[bf], dpool=D["dpool"], ws=ws)
-            side(lambda pyr=pyr, dzf=D["dzf"], kf=kf: ops.conv2d_bwd_filter(pyr, dzf, 3, 1, partial=P.fold_part[kf]))   # rows of the 2*co convolved channels
-            ops.conv2d_bwd_data(D["dzf"], w[kf], 1, ci_begin=0, ci_count=2 * co, out=dpyr, ws=ws)
+            side(lambda pyr=pyr, dzf=D["dzf"], kf=kf: self._conv_bwd_filter(pyr, dzf, 3, 1, partial=P.fold_part[kf]))   # rows of the 2*co convolved channels
+            self._conv_bwd_data(D["dzf"], w[kf], 1, ci_begin=0, ci_count=2 * co, out=dpyr, ws=ws)
             d0, d1 = dpyr[..., :co], dpyr[..., co:2 * co]
             bn_b(D["z0"], d0, D["st0"], n0, d0, pre=True, dxsum_part=P.fold_part[b0])   # + conv-bias gradient slabs (batched fold)
             tail = P.filter_tail[j]
             cmain = cat[..., :m.c_cat - tail] if tail else cat
 
             def wgrad(dz, kname, kk, dil, cmain=cmain, ctail=cat[..., m.c_cat - tail:] if tail else None):
-                ops.conv2d_bwd_filter(cmain, dz, kk, dil, partial=P.fold_part[kname])
+                self._conv_bwd_filter(cmain, dz, kk, dil, partial=P.fold_part[kname])
                 if ctail is not None:   # the <= 16-channel sliver of the concat (see _Plan)
-                    ops.conv2d_bwd_filter(ctail, dz, kk, dil, partial=P.fold_part[kname + "#tail"])
+                    self._conv_bwd_filter(ctail, dz, kk, dil, partial=P.fold_part[kname + "#tail"])
             side(lambda d0=d0, k0=k0, wgrad=wgrad: wgrad(d0, k0, 1, 1))
-            ops.conv2d_bwd_data(d0, w[k0], 1, out=dcat, ws=ws)
+            self._conv_bwd_data(d0, w[k0], 1, out=dcat, ws=ws)
             bn_b(D["z1"], d1, D["st1"], n1, d1, pre=True, dxsum_part=P.fold_part[b1])
             side(lambda d1=d1, k1=k1, wgrad=wgrad: wgrad(d1, k1, 3, 2))
-            ops.conv2d_bwd_data(d1, w[k1], 2, out=dcat, accumulate=True, ws=ws)
+            self._conv_bwd_data(d1, w[k1], 2, out=dcat, accumulate=True, ws=ws)
             ops.chan_affine(None, A=D["dpool"], out=dcat, accumulate=True)   # d(mean)/d(cat) = dpool / (H*W) on every pixel
             # dU = dO + dcat[:, :c_deep] (residual);  dS = dcat[:, c_deep:]
             ops.chan_affine(dcat[..., :m.c_deep], out=dO, accumulate=True)
@@ -680,14 +710,24 @@ class Learner:
                  dskip=tgt if b.skip else None, dskip_accumulate=tgt_has)
             if b.skip:
                 tgt_has = True
-            side(lambda B=B, dout=dout, nm=nm: ops.conv2d_bwd_filter(B["a1"], dout, 1, 1, x_scale=B["gate"], partial=P.fold_part[nm["w_proj"]]))
+            side(lambda B=B, dout=dout, nm=nm: self._conv_bwd_filter(B["a1"], dout, 1, 1, x_scale=B["gate"], partial=P.fold_part[nm["w_proj"]]))
             da2 = B["da2"]
-            ops.conv2d_bwd_data(dout, w[nm["w_proj"]], 1, out=da2, ws=ws)
+            self._conv_bwd_data(dout, w[nm["w_proj"]], 1, out=da2, ws=ws)
             ops.colsum(da2, B["a1"], nseg=N, out=B["dgate"], ws=ws)
             se = nm["se"]
             # (the SE weight gradients of all blocks are computed by one batched launch after the loop: P.se_desc)
             ops.se_mlp_bwd(B["dgate"], B["gate"], B["s"], B["hpre"], w[se[0]], w[se[2]], hw,
                            dict(dpre1=B["dpre1"], dpre2=B["dpre2"], chan_add=B["chan_add"]))
+            if B["small"]:   # bn1 backward, depthwise filter gradient + backward-data, bn0 backward: one launch
+                da0, st0, st1, p0, p1 = B["da0"], B["st0"], B["st1"], nm["bn0"], nm["bn1"]
+                ops.mbconv_dw_bwd_small(da2, B["gate"], B["chan_add"], B["z1"], (st1[0], st1[1], w[p1 + "/gamma"], w[p1 + "/beta"]),
+                                        w[nm["w_dw"]], B["z0"], (st0[0], st0[1], w[p0 + "/gamma"], w[p0 + "/beta"]),
+                                        g[p1 + "/gamma"], g[p1 + "/beta"], g[nm["w_dw"]], g[p0 + "/gamma"], g[p0 + "/beta"], da0)
+                side(lambda B=B, da0=da0, nm=nm: self._conv_bwd_filter(B["x_in"], da0, 1, 1, partial=P.fold_part[nm["w_exp"]]))
+                self._conv_bwd_data(da0, w[nm["w_exp"]], 1, out=tgt, accumulate=tgt_has, ws=ws)
+                if bi > 0:
+                    has_grad[bi - 1] = True
+                continue
             bn_b(B["z1"], da2, B["st1"], nm["bn1"], da2, post=True, chan_scale=B["gate"], chan_add=B["chan_add"])
             dw_in = B["a0"] if b.expand != 1 else B["x_in"]
             side(lambda dw_in=dw_in, da2=da2, b=b, nm=nm: ops.dwconv_bwd_filter(dw_in, da2, b.k, b.stride, partial=P.fold_part[nm["w_dw"]]))
@@ -698,8 +738,8 @@ class Learner:
                 _, nb1 = ops.dwconv_bwd_data(da2, w[nm["w_dw"]], b.stride, (b.h_in, b.h_in), out=da0, part=P.stats_part,
                                              bn=(B["z0"], st0[0], st0[1], w[nm["bn0"] + "/gamma"], w[nm["bn0"] + "/beta"]))
                 bn_b(B["z0"], da0, st0, nm["bn0"], da0, post=True, stage1=(P.stats_part, nb1) if nb1 else None)
-                side(lambda B=B, da0=da0, nm=nm: ops.conv2d_bwd_filter(B["x_in"], da0, 1, 1, partial=P.fold_part[nm["w_exp"]]))
-                ops.conv2d_bwd_data(da0, w[nm["w_exp"]], 1, out=tgt, accumulate=tgt_has, ws=ws)
+                side(lambda B=B, da0=da0, nm=nm: self._conv_bwd_filter(B["x_in"], da0, 1, 1, partial=P.fold_part[nm["w_exp"]]))
+                self._conv_bwd_data(da0, w[nm["w_exp"]], 1, out=tgt, accumulate=tgt_has, ws=ws)
             else:
                 if tgt_has:  # no-expand block with identity skip (EfficientNet-B3 stage-1 repeats)
                     tmp = B["da0"]
@@ -749,7 +789,6 @@ class Learner:
         if max(batch_idx) >= self.n_shots or min(batch_idx) < 0:
             raise ValueError("batch index out of range of the resident task ({} shots)".format(self.n_shots))
         P = self._plan(N)
-        ops.set_matmul_precision(self.matmul_precision)   # the library switch is process-wide: re-assert this learner's choice
         with torch.cuda.stream(self.stream):
             if N <= self._idx_pin.shape[1]:
                 slot = self._idx_n % len(self._idx_ev)
@@ -836,7 +875,6 @@ class Learner:
         images = torch.as_tensor(images)
         N = images.shape[0]
         P = self._plan(N)
-        ops.set_matmul_precision(self.matmul_precision)
         with torch.cuda.stream(self.stream):
             x = images.to(device=self.device, dtype=torch.float32).contiguous()
             logits = self._forward(P, x, None, training)

@@ -62,20 +62,18 @@ def profile_resolve(records):
     return records
 
 
-def set_matmul_precision(precision: str):
-    """'fp32' (default) or 'bf16': operand precision of the matrix cores in the dense convs (process-wide; fp32 accumulation)."""
-    if precision not in ("fp32", "bf16"):
-        raise MliisError("matmul precision must be 'fp32' or 'bf16', got {!r}".format(precision))
-    lib.call("mliis_set_matmul_precision", int(precision == "bf16"))
+PRECISIONS = {"fp32": 0, "bf16": 1}   # MLIIS_PREC_* of include/mliis_hip.h: operand precision of the matrix cores, per call
 
 
-def get_matmul_precision() -> str:
-    return "bf16" if lib.raw("mliis_get_matmul_precision")() else "fp32"
+def _prec(precision) -> int:
+    if precision not in PRECISIONS:
+        raise MliisError("matmul precision must be one of {}, got {!r}".format(sorted(PRECISIONS), precision))
+    return PRECISIONS[precision]
 
 
-def conv2d_kernel_name(N, H, W, cred, nout, k, has_scale=False):
+def conv2d_kernel_name(N, H, W, cred, nout, k, has_scale=False, precision="fp32"):
     buf = C.create_string_buffer(80)
-    lib.call("mliis_conv2d_kernel_name", N, H, W, cred, nout, k, int(has_scale), C.cast(buf, C.c_void_p), 80)
+    lib.call("mliis_conv2d_kernel_name", N, H, W, cred, nout, k, int(has_scale), _prec(precision), C.cast(buf, C.c_void_p), 80)
     return buf.value.decode()
 
 
@@ -206,6 +204,35 @@ def dwconv_bwd_filter(x, dy, k, stride, out=None, ws: Optional[Workspace] = None
     return out
 
 
+# ------------------------------------------------------------------------------------------------ small-map MBConv depthwise half
+def mbconv_dw_small_supported(N, H, W, C_, k, stride) -> bool:
+    return bool(lib.raw("mliis_mbconv_dw_small_supported")(N, H, W, C_, k, stride))
+
+
+def mbconv_dw_fwd_small(z0, part0, nblk0, bn0, w, bn1, z1, a1, s, a0=None, eps=BN_EPS, momentum=BN_MOMENTUM):
+    """bn0 / bn1 = (gamma, beta, mean_out, rstd_out, moving_mean | None, moving_var | None).  One launch: fold bn0's statistics,
+    a0 = swish(bn0(z0)), depthwise k x k (stride 1), exact statistics of z1, a1 = swish(bn1(z1)), s = per-image mean of a1."""
+    N, H, W, C_ = z0.shape
+    k = w.shape[0]
+    g0, b0, m0, r0, mm0, mv0 = bn0
+    g1, b1, m1, r1, mm1, mv1 = bn1
+    lib.call("mliis_mbconv_dw_fwd_small", _ptr(_chk(z0)), _ptr(part0), int(nblk0), _ptr(g0), _ptr(b0), _ptr(m0), _ptr(r0), _ptr(mm0), _ptr(mv0),
+             _ptr(w), _ptr(g1), _ptr(b1), _ptr(m1), _ptr(r1), _ptr(mm1), _ptr(mv1), _ptr(a0), _ptr(z1), _ptr(a1), _ptr(s), N, H, W, C_, k,
+             float(eps), float(momentum), _stream())
+    return z1, a1, s
+
+
+def mbconv_dw_bwd_small(da2, gate, chan_add, z1, bn1, w, z0, bn0, dgamma1, dbeta1, dw, dgamma0, dbeta0, dz0):
+    """bn1 / bn0 = (mean, rstd, gamma, beta).  One launch: bn1 backward, depthwise filter gradient (complete) and backward-data, bn0
+    backward; dz0 = gradient w.r.t. the expand conv's output."""
+    N, H, W, C_ = z1.shape
+    k = w.shape[0]
+    lib.call("mliis_mbconv_dw_bwd_small", _ptr(_chk(da2)), _ptr(gate), _ptr(chan_add), _ptr(z1), _ptr(bn1[0]), _ptr(bn1[1]), _ptr(bn1[2]),
+             _ptr(bn1[3]), _ptr(w), _ptr(z0), _ptr(bn0[0]), _ptr(bn0[1]), _ptr(bn0[2]), _ptr(bn0[3]), _ptr(dgamma1), _ptr(dbeta1), _ptr(dw),
+             _ptr(dgamma0), _ptr(dbeta0), _ptr(dz0), N, H, W, C_, k, _stream())
+    return dz0
+
+
 # ------------------------------------------------------------------------------------------------ dense conv
 def transpose_weights(src, dst, desc):
     """dst <- HWOI copies of the dense-conv weights listed in desc (device int32 [n,4] = offset, taps, Cin, Cout)."""
@@ -221,7 +248,7 @@ def hwoi(w):
 
 
 def conv2d_fwd(x, w, bias=None, dil=1, out=None, accumulate=False, ws: Optional[Workspace] = None, nhw=None, stats_part=None,
-               stats_swish=False, wt=None, x_scale=None, border_bias=None, ci_begin=0):
+               stats_swish=False, wt=None, x_scale=None, border_bias=None, ci_begin=0, precision="fp32"):
     """x: [N,H,W,>=Cin] view (channel slice allowed); w: [k,k,Cin,Cout]; wt: its K-contiguous copy (built here when not given --
     the kernels only read wt).  With stats_part (a float buffer) the epilogue also emits the next batch norm's stage-1 statistics
     and the function returns (out, nblk); nblk == 0 means they were not produced."""
@@ -238,21 +265,22 @@ def conv2d_fwd(x, w, bias=None, dil=1, out=None, accumulate=False, ws: Optional[
     meta = {}
     if PROFILE is not None:
         tm, nt, sp = conv2d_plan(N, H, W, Cin, Cout, k)
-        meta = dict(kernel=conv2d_kernel_name(N, H, W, Cin, Cout, k, x_scale is not None), splits=sp,
+        meta = dict(kernel=conv2d_kernel_name(N, H, W, Cin, Cout, k, x_scale is not None, precision), splits=sp,
                     flops=2.0 * N * H * W * k * k * Cin * Cout, shape=(N, H, W, Cin, Cout, k, dil))
     nblk = C.c_int(0)
+    prec = _prec(precision)
     if stats_part is not None and stats_part.numel() < (-(-N * H * W // 64)) * 2 * Cout:
         raise MliisError("conv2d_fwd: stats_part too small")
     _timed("conv2d_fwd", meta, lambda: lib.call("mliis_conv2d_fwd", _ptr(x), ldx, _ptr(x_scale), _ptr(wt), _ptr(bias), _ptr(border_bias), _ptr(out), ldy, N, H, W,
                                                 Cin_total, ci_begin, Cin, Cout, k,
                                                 dil, int(accumulate), _ptr(stats_part), int(stats_swish), C.byref(nblk), _ptr(buf),
-                                                buf.numel(), _stream()))
+                                                buf.numel(), prec, _stream()))
     if stats_part is not None:
         return out, nblk.value
     return out
 
 
-def conv2d_bwd_data(dy, w, dil=1, ci_begin=0, ci_count=None, out=None, accumulate=False, ws: Optional[Workspace] = None):
+def conv2d_bwd_data(dy, w, dil=1, ci_begin=0, ci_count=None, out=None, accumulate=False, ws: Optional[Workspace] = None, precision="fp32"):
     N, H, W = dy.shape[:3]
     k, _, Cin, Cout = w.shape
     ci_count = Cin - ci_begin if ci_count is None else ci_count
@@ -263,26 +291,29 @@ def conv2d_bwd_data(dy, w, dil=1, ci_begin=0, ci_count=None, out=None, accumulat
     _, _, lddx = rows_ld(out)
     ws = ws or default_ws()
     buf = ws.get(lib.size("mliis_conv2d_workspace_floats", N, H, W, Cout, ci_count, k))
+    prec = _prec(precision)
     meta = {}
     if PROFILE is not None:
         tm, nt, sp = conv2d_plan(N, H, W, Cout, ci_count, k)
-        meta = dict(kernel=conv2d_kernel_name(N, H, W, Cout, ci_count, k), splits=sp, flops=2.0 * N * H * W * k * k * ci_count * Cout,
+        meta = dict(kernel=conv2d_kernel_name(N, H, W, Cout, ci_count, k, False, precision), splits=sp, flops=2.0 * N * H * W * k * k * ci_count * Cout,
                     shape=(N, H, W, ci_count, Cout, k, dil))
     _timed("conv2d_bwd_data", meta, lambda: lib.call("mliis_conv2d_bwd_data", _ptr(dy), lddy, _ptr(w), _ptr(out), lddx, N, H, W, Cin, ci_begin,
-                                                     ci_count, Cout, k, dil, int(accumulate), _ptr(buf), buf.numel(), _stream()))
+                                                     ci_count, Cout, k, dil, int(accumulate), _ptr(buf), buf.numel(), prec, _stream()))
     return out
 
 
-def conv2d_bwd_filter(x, dy, k, dil=1, out=None, accumulate=False, ws: Optional[Workspace] = None, x_scale=None, ci_begin=0, partial=None):
+def conv2d_bwd_filter(x, dy, k, dil=1, out=None, accumulate=False, ws: Optional[Workspace] = None, x_scale=None, ci_begin=0, partial=None,
+                      precision="fp32"):
     """Writes rows [ci_begin, ci_begin + x.channels) of `out` ([k,k,Cin_total,Cout]; Cin_total = x.channels when out is None).
     With `partial` (float buffer of conv2d_bwd_filter_floats(...) elements) only the per-split slabs are produced there; a later
     fold_batched() call reduces them."""
     N, H, W = dy.shape[:3]
     _, Cin, ldx = rows_ld(x)
     _, Cout, lddy = rows_ld(dy)
+    prec = _prec(precision)
     if partial is not None:
         lib.call("mliis_conv2d_bwd_filter", _ptr(x), ldx, _ptr(x_scale), _ptr(dy), lddy, None, N, H, W, Cin, 0, Cin, Cout, k, dil, 0,
-                 _ptr(partial), partial.numel(), _stream())
+                 _ptr(partial), partial.numel(), prec, _stream())
         return None
     out = torch.empty((k, k, Cin, Cout), dtype=torch.float32, device=x.device) if out is None else out
     Cin_total = out.shape[2]
@@ -291,7 +322,7 @@ def conv2d_bwd_filter(x, dy, k, dil=1, out=None, accumulate=False, ws: Optional[
     meta = dict(flops=2.0 * N * H * W * k * k * Cin * Cout, shape=(N, H, W, Cin, Cout, k, dil)) if PROFILE is not None else {}
     _timed("conv2d_bwd_filter", meta, lambda: lib.call("mliis_conv2d_bwd_filter", _ptr(x), ldx, _ptr(x_scale), _ptr(dy), lddy, _ptr(out), N, H, W, Cin_total, ci_begin,
                                                        Cin, Cout, k,
-                                                       dil, int(accumulate), _ptr(buf), buf.numel(), _stream()))
+                                                       dil, int(accumulate), _ptr(buf), buf.numel(), prec, _stream()))
     return out
 
 

@@ -557,7 +557,7 @@ def test_swish_mask_fwd_bwd(pre_mask):
 
 @pytest.mark.parametrize("k,dil,H,W,Cin,Cout,N", [(1, 1, 14, 14, 40, 240, 2), (3, 2, 14, 14, 136, 112, 2), (1, 1, 56, 56, 136, 144, 4), (3, 1, 8, 8, 20, 16, 2)])
 def test_conv2d_bf16_operands(k, dil, H, W, Cin, Cout, N):
-    """mliis_set_matmul_precision(1): bf16 operands on the matrix cores (v_mfma_f32_16x16x32_bf16), fp32 accumulation.  Exactly the fp32
+    """precision = MLIIS_PREC_BF16 (per call): bf16 operands on the matrix cores (v_mfma_f32_16x16x32_bf16), fp32 accumulation.  Exactly the fp32
     result of the bf16-ROUNDED operands up to accumulation order (tolerance 2e-5), i.e. within bf16 rounding (2^-9 relative per operand)
     of the full-precision result.  (The memory-bound short-K 1x1 convs -- conv1x1_stream_k, K <= 112 and >= 1024 pixels -- keep fp32
     operands in this mode too; the shapes here are the ones that do switch.)"""
@@ -571,18 +571,15 @@ def test_conv2d_bf16_operands(k, dil, H, W, Cin, Cout, N):
     dy32 = rnd(*y.shape, seed=83).float()
     dy = bf(dy32)
     gx, gw = torch.autograd.grad(y, [x, w], dy)
-    try:
-        ops.set_matmul_precision("bf16")
-        assert ops.get_matmul_precision() == "bf16"
-        xg, wg, dyg = x32.to(d), w32.to(d), nhwc(dy32).contiguous().to(d)
-        close(ops.conv2d_fwd(xg, wg, f32(b, d), dil), nhwc(y), 2e-5, "bf16 conv fwd")
-        close(ops.conv2d_bwd_data(dyg, wg, dil), gx, 1e-4, "bf16 conv bwd data")
-        close(ops.conv2d_bwd_filter(xg, dyg, k, dil), gw, 1e-4, "bf16 conv bwd filter")
-    finally:
-        ops.set_matmul_precision("fp32")
-    assert ops.get_matmul_precision() == "fp32"
+    xg, wg, dyg = x32.to(d), w32.to(d), nhwc(dy32).contiguous().to(d)
+    close(ops.conv2d_fwd(xg, wg, f32(b, d), dil, precision="bf16"), nhwc(y), 2e-5, "bf16 conv fwd")
+    close(ops.conv2d_bwd_data(dyg, wg, dil, precision="bf16"), gx, 1e-4, "bf16 conv bwd data")
+    close(ops.conv2d_bwd_filter(xg, dyg, k, dil, precision="bf16"), gw, 1e-4, "bf16 conv bwd filter")
+    # the precision is an argument of each call: an fp32 call right after gives the fp32 result of the UNROUNDED operands
+    y32 = R.conv2d_same(nchw(x32.double()), w32.double(), 1, dil, bias=b)
+    close(ops.conv2d_fwd(xg, wg, f32(b, d), dil), nhwc(y32), 2e-5, "fp32 conv fwd after a bf16 call")
     with pytest.raises(Exception):
-        ops.set_matmul_precision("fp8")
+        ops.conv2d_fwd(xg, wg, f32(b, d), dil, precision="fp4")
 
 
 @pytest.mark.parametrize("H,Cin,Cout,swish", [(32, 24, 144, False), (32, 112, 40, True), (32, 16, 20, False), (40, 96, 672, True), (23, 40, 8, False)])
@@ -655,3 +652,73 @@ def test_dwconv_bwd_data_emits_bn_backward_stage1(k, s, H, W, C):
     close(dx1, gz, 2e-4, "dx vs oracle")
     close(dg1, gg, 2e-4, "dgamma vs oracle")
     close(db1, gb, 2e-4, "dbeta vs oracle")
+
+
+# ------------------------------------------------------------------------------------------------ small-map MBConv depthwise half
+@pytest.mark.parametrize("k,N,H,W,C", [(3, 8, 14, 14, 480), (5, 8, 14, 14, 672), (5, 5, 14, 14, 480), (3, 8, 4, 4, 480), (5, 8, 16, 16, 40),
+                                       (3, 2, 24, 24, 8), (5, 3, 7, 9, 72), (3, 1, 1, 1, 16)])
+def test_mbconv_small_fused_fwd_bwd(k, N, H, W, C):
+    """mliis_mbconv_dw_fwd_small / _bwd_small (one launch per direction for the depthwise half of an MBConv block on small maps) vs the
+    float64 oracle ops + autograd: expand BN (statistics handed over as stage-1 partials) -> swish -> depthwise k x k -> BN -> swish ->
+    per-image means; both moving averages; backward with the squeeze-excite gate / pooled-gradient terms.  Shapes: the 14x14 layers of
+    EfficientLab-6-3 at N = 8 and N = 5 (FOMAML tail batch), the 64x64-input test sizes, ragged maps, a channel count that leaves
+    workgroups of the XCD-grouped grid idle, a single pixel."""
+    from mliis_amd import ops
+    from mliis_amd.spec import BN_EPS
+    d = dev()
+    assert ops.mbconv_dw_small_supported(N, H, W, C, k, 1)
+    assert not ops.mbconv_dw_small_supported(N, H, W, C, k, 2) and not ops.mbconv_dw_small_supported(64, 14, 14, C, k, 1)
+    z0 = (rnd(N, H, W, C, seed=1) * 1.5 + 0.3).requires_grad_(True)
+    wd = rnd(k, k, C, 1, seed=2, scale=0.4).requires_grad_(True)
+    g0, b0 = (1 + 0.2 * rnd(C, seed=3)).requires_grad_(True), (0.3 * rnd(C, seed=4)).requires_grad_(True)
+    g1, b1 = (1 + 0.2 * rnd(C, seed=5)).requires_grad_(True), (0.3 * rnd(C, seed=6)).requires_grad_(True)
+    gate, cadd, da2 = torch.sigmoid(rnd(N, C, seed=7)), 0.01 * rnd(N, C, seed=8), rnd(N, H, W, C, seed=9)
+    mm0, mv0, mm1, mv1 = 0.1 * rnd(C, seed=10), 1 + 0.1 * rnd(C, seed=11).abs(), 0.1 * rnd(C, seed=12), 1 + 0.1 * rnd(C, seed=13).abs()
+
+    def bn_ref(x, g, b):
+        m = x.mean(dim=(0, 1, 2))
+        v = ((x - m) ** 2).mean(dim=(0, 1, 2))
+        return (x - m) / torch.sqrt(v + BN_EPS) * g + b, m, v
+    y0, m0, v0 = bn_ref(z0, g0, b0)
+    a0 = R.swish(y0)
+    z1 = nhwc(R.conv2d_same(nchw(a0), wd, 1, groups=C))
+    y1, m1, v1 = bn_ref(z1, g1, b1)
+    a1 = R.swish(y1)
+    s_ref = a1.mean(dim=(1, 2))
+    up = da2 * gate[:, None, None, :] + cadd[:, None, None, :]
+    grads = torch.autograd.grad((a1 * up).sum(), [z0, wd, g0, b0, g1, b1])
+    # device: stage-1 statistics of z0 as the expand conv's epilogue would leave them
+    z0d = f32(z0, d)
+    part = torch.zeros(1 << 18, device=d)
+    nblk = ops.bn_stats_partial(z0d, False, part)
+    st = [torch.zeros(C, device=d) for _ in range(4)]
+    mov = [f32(t, d) for t in (mm0, mv0, mm1, mv1)]
+    a0d, z1d, a1d, sd = (torch.full((N, H, W, C), 9.0, device=d) for _ in range(3)), None, None, None
+    a0d, z1d, a1d = a0d
+    sd = torch.full((N, C), 9.0, device=d)
+    ops.mbconv_dw_fwd_small(z0d, part, nblk, (f32(g0, d), f32(b0, d), st[0], st[1], mov[0], mov[1]), f32(wd, d),
+                            (f32(g1, d), f32(b1, d), st[2], st[3], mov[2], mov[3]), z1d, a1d, sd, a0=a0d)
+    close(a0d, a0, 2e-5, "small fwd a0")
+    close(z1d, z1, 2e-5, "small fwd z1")
+    close(a1d, a1, 5e-5, "small fwd a1")
+    close(sd, s_ref, 2e-5, "small fwd pooled mean")
+    close(st[0], m0, 1e-5, "mean0"); close(st[1], 1 / torch.sqrt(v0 + BN_EPS), 1e-5, "rstd0")
+    close(st[2], m1, 2e-5, "mean1"); close(st[3], 1 / torch.sqrt(v1 + BN_EPS), 2e-5, "rstd1")
+    for got, old, stat in ((mov[0], mm0, m0), (mov[1], mv0, v0), (mov[2], mm1, m1), (mov[3], mv1, v1)):
+        close(got, old - (old - stat.detach()) * 0.01, 1e-5, "moving average")   # biased variance (non-fused BN, utils.py:87-134)
+    # a0 is optional
+    z1b, a1b, sb = torch.zeros_like(z1d), torch.zeros_like(a1d), torch.zeros_like(sd)
+    mov2 = [f32(t, d) for t in (mm0, mv0, mm1, mv1)]
+    ops.mbconv_dw_fwd_small(z0d, part, nblk, (f32(g0, d), f32(b0, d), st[0], st[1], mov2[0], mov2[1]), f32(wd, d),
+                            (f32(g1, d), f32(b1, d), st[2], st[3], mov2[2], mov2[3]), z1b, a1b, sb)
+    assert torch.equal(z1b, z1d) and torch.equal(a1b, a1d) and torch.equal(sb, sd)      # deterministic
+    # backward
+    outs = dict(dg1=torch.zeros(C, device=d), db1=torch.zeros(C, device=d), dw=torch.zeros(k, k, C, 1, device=d), dg0=torch.zeros(C, device=d),
+                db0=torch.zeros(C, device=d), dz0=torch.full((N, H, W, C), 9.0, device=d))
+    ops.mbconv_dw_bwd_small(f32(da2, d), f32(gate, d), f32(cadd, d), z1d, (st[2], st[3], f32(g1, d), f32(b1, d)), f32(wd, d), z0d,
+                            (st[0], st[1], f32(g0, d), f32(b0, d)), outs["dg1"], outs["db1"], outs["dw"], outs["dg0"], outs["db0"], outs["dz0"])
+    for name, ref in (("dz0", grads[0]), ("dw", grads[1]), ("dg0", grads[2]), ("db0", grads[3]), ("dg1", grads[4]), ("db1", grads[5])):
+        close(outs[name], ref, 2e-4, "small bwd " + name)
+    with pytest.raises(Exception):
+        ops.mbconv_dw_fwd_small(torch.zeros(64, 14, 14, C, device=d), part, nblk, (f32(g0, d), f32(b0, d), st[0], st[1], None, None), f32(wd, d),
+                                (f32(g1, d), f32(b1, d), st[2], st[3], None, None), z1b, a1b, sb)

@@ -369,13 +369,13 @@ def test_bf16_matrix_core_operands_track_the_fp32_trajectory():
     (operands carry 2^-9 relative rounding; the fp32 path holds 1e-4 / 1e-3), inference logits within 10 % of the logit range and
     masks equal to the oracle's wherever its logit margin exceeds that."""
     _need_gpu()
-    from mliis_amd import ops
     from mliis_amd.learner import Learner
     H, S = 64, 5
-    try:
+    if True:
         O = R.OracleLearner(image_size=H, seed=0, dtype=torch.float64, lr=1e-3, drop_connect=False)
         L = Learner(image_size=H, seed=100, use_graph=True, drop_connect=False, matmul_precision="bf16")
-        assert ops.get_matmul_precision() == "bf16"
+        Lf = Learner(image_size=H, seed=100, use_graph=False, drop_connect=False)   # an fp32 learner in the same process: the precision
+        assert (L.matmul_precision, Lf.matmul_precision) == ("bf16", "fp32")           # is per learner / per call, nothing process-wide
         L.load_named({k: v.numpy() for k, v in O.params.items()}, strict=False)
         x, y = _task(S, H, 4)
         L.load_task(x, y)
@@ -393,10 +393,8 @@ def test_bf16_matrix_core_operands_track_the_fp32_trajectory():
         assert (lgL.cpu().double() - lgO).abs().max().item() <= 1e-1 * scale
         margin = (lgO[..., 0] - lgO[..., 1]).abs() > 1e-1 * scale
         assert torch.equal(pL.cpu()[margin].double(), R.predictions(lgO)[margin])
-    finally:
-        ops.set_matmul_precision("fp32")
-    L2 = Learner(image_size=H, seed=1, use_graph=False)        # the default puts the library back to fp32 operands
-    assert ops.get_matmul_precision() == "fp32" and L2.matmul_precision == "fp32"
+    with pytest.raises(ValueError):
+        Learner(image_size=H, seed=1, use_graph=False, matmul_precision="fp4")
 
 
 @pytest.mark.parametrize("fomaml,H,bs", [(False, 64, 4), (True, 64, 4), (False, 224, 8)])
@@ -467,3 +465,146 @@ def test_concurrent_task_lanes_equal_the_sequential_evaluation(transductive):
     assert torch.equal(before["theta"], after["theta"]) and torch.equal(before["bn"], after["bn"])
     L.close()
     lane.close()
+
+
+# ------------------------------------------------------------------------------------------------ meta-step vs the oracle
+def _meta_pair(H, tasks_np, fomaml, lr=1e-3, **gk):
+    """(oracle learner + meta-learner, HIP learner + meta-learner) over the same tasks and initial weights."""
+    from mliis_amd.learner import Learner
+    from mliis_amd.metaseg import DeviceTask
+    from mliis_amd.reptile import FOMLIS, Gecko
+    O = R.OracleLearner(image_size=H, seed=0, dtype=torch.float64, lr=lr, drop_connect=False)
+    L = Learner(image_size=H, seed=11, use_graph=True, drop_connect=False, learning_rate=lr)
+    L.load_named({k: v.numpy() for k, v in O.params.items()}, strict=False)
+    dev = torch.device("cuda", 0)
+    tO = [DeviceTask("t%d" % i, torch.tensor(x).double(), torch.tensor(y).double()) for i, (x, y) in enumerate(tasks_np)]
+    tL = [DeviceTask("t%d" % i, torch.tensor(x).to(dev), torch.tensor(y).to(dev)) for i, (x, y) in enumerate(tasks_np)]
+    mk = (lambda ln: FOMLIS(ln, train_shots=10, tail_shots=5, **gk)) if fomaml else (lambda ln: Gecko(ln, **gk))
+    return (O, mk(O), tO), (L, mk(L), tL)
+
+
+def _compare_meta_state(O, L, tag, p_tol=2e-5):
+    th = L.arena.export_trainable_packed().cpu().double()
+    ref = torch.cat([O.params[p.name].reshape(-1) for p in L.arena.trainable])
+    err = (th - ref).abs().max().item()
+    assert err <= p_tol, "{} params: {:.3e}".format(tag, err)
+    mvL = L.arena.named_numpy()
+    for k, (mm, mv) in O.bn.items():
+        np.testing.assert_allclose(mvL[k + "/moving_mean"], mm.numpy(), rtol=1e-4, atol=1e-5, err_msg=tag + k)
+        np.testing.assert_allclose(mvL[k + "/moving_variance"], mv.numpy(), rtol=1e-4, atol=1e-5, err_msg=tag + k)
+
+
+@pytest.mark.parametrize("fomaml,lr_arg", [(False, None), (True, None), (False, 2e-3)])
+def test_meta_step_matches_oracle(fomaml, lr_arg):
+    """Gecko.train_step / FOMLIS.train_step (reptile.py:64-125, 605-663) on the HIP learner vs THE SAME host code on the float64
+    oracle learner: meta-batch 3, two meta-steps (the second starts from the first one's outer update), FOMAML with a 5-shot tail
+    batch (variable batch size), Reptile also with `lr` given (two optimizer steps per batch, quirk E1).  Compared after the outer
+    update: every trainable (2e-5 abs) and all BN moving tensors (sequential-average semantics; rel 1e-4)."""
+    _need_gpu()
+    H = 64
+    tasks_np = [_task(10, H, 30 + i) for i in range(4)]
+    (O, mO, tO), (L, mL, tL) = _meta_pair(H, tasks_np, fomaml, rng_mode="per_task", seed=5)
+    for it in range(2):
+        for m, ts in ((mO, tO), (mL, tL)):
+            m.train_step(ts, num_shots=10 if fomaml else 5, inner_batch_size=4, inner_iters=3, meta_step_size=0.5, meta_batch_size=3,
+                         lr=lr_arg)
+        L.synchronize()
+        _compare_meta_state(O, L, "meta-step %d " % it)
+    assert mO.meta_iter == mL.meta_iter == 2
+    L.close()
+
+
+class _EmulatedRank:
+    """Dist of ONE emulated rank of a P-rank job run sequentially on one GPU.  Pass 1 (`total` None): the all-reduce records this
+    rank's contribution.  Pass 2: the all-reduce delivers the sum over all ranks' recorded contributions."""
+
+    def __init__(self, rank, world, total=None):
+        self.rank, self.world, self.total, self.mine = rank, world, total, None
+
+    def all_reduce_sum(self, t):
+        if self.total is None:
+            self.mine = t.clone()
+        else:
+            t.copy_(self.total)
+        return t
+
+    def barrier(self):
+        pass
+
+    def any_true(self, flag, device=None):
+        return bool(flag)
+
+
+@pytest.mark.parametrize("fomaml,P", [(False, 2), (True, 2), (False, 4)])
+def test_rank_emulation_sharded_meta_step_equals_single_rank(fomaml, P):
+    """SURVEY.md 8(e) on one GPU: the P ranks of a sharded meta-step (task t -> rank t mod P, one all-reduce(sum) over
+    [sum of task deltas | BN moving-average contributions]) are run one after another on the same learner with the collective
+    emulated by summing their contribution buffers.  Every emulated rank must end in the state of the single-rank run (meta-batch 5:
+    uneven shards), for Reptile and FOMAML, and that state is checked against the oracle as well."""
+    _need_gpu()
+    from mliis_amd.reptile import FOMLIS, Gecko
+    H = 64
+    tasks_np = [_task(10, H, 60 + i) for i in range(4)]
+    (O, mO, tO), (L, mL, tL) = _meta_pair(H, tasks_np, fomaml, rng_mode="per_task", seed=2)
+    kw = dict(num_shots=10 if fomaml else 5, inner_batch_size=4, inner_iters=2, meta_step_size=0.7, meta_batch_size=5)
+    start = L.export_all()
+    mL.train_step(tL, **kw)
+    mO.train_step(tO, **kw)
+    L.synchronize()
+    _compare_meta_state(O, L, "world 1 ")
+    single = L.export_all()
+
+    def meta(dist):
+        m = FOMLIS(L, train_shots=10, tail_shots=5, rng_mode="per_task", seed=2, dist=dist) if fomaml else \
+            Gecko(L, rng_mode="per_task", seed=2, dist=dist)
+        return m
+    parts = []
+    for r in range(P):
+        L.import_all(start)
+        d = _EmulatedRank(r, P)
+        meta(d).train_step(tL, **kw)
+        parts.append(d.mine)
+    L.synchronize()                      # the contributions were produced on the learner's stream
+    total = torch.stack(parts).sum(0)
+    torch.cuda.synchronize()
+    for r in range(P):
+        L.import_all(start)
+        meta(_EmulatedRank(r, P, total)).train_step(tL, **kw)
+        got = L.export_all()
+        L.synchronize()
+        # same kernels, same per-task results; only the summation order of the task deltas differs (fp32): 1e-6 abs
+        assert (got["theta"] - single["theta"]).abs().max().item() <= 1e-6, r
+        assert (got["bn"] - single["bn"]).abs().max().item() <= 1e-5 * max(1.0, single["bn"].abs().max().item()), r
+    L.close()
+
+
+def test_full_size_eight_step_task_config2():
+    """BASELINE config 2, the workload bench.py times: one 5-shot task at 224x224, 8 inner SGD steps of batch 8 (wrap-around
+    batches), drop-connect masks injected, HIP-graph replay from step 3 on -- loss of every step vs the float64 oracle (rel 1e-4
+    first step, 1e-3 after), parameters after the task, inference-mode logits / masks on the 5 shots."""
+    _need_gpu()
+    import random
+    from mliis_amd.metaseg import mini_batch_indices
+    H, S = 224, 5
+    O, L = _pair(H, use_graph=True)
+    x, y = _task(S, H, 4)
+    L.load_task(x, y)
+    xd, yd = torch.tensor(x).double(), torch.tensor(y).double()
+    batches = [list(b) for b in mini_batch_indices(S, 8, 8, rng=random.Random(1))]
+    for step, idx in enumerate(batches):
+        dc = _dc(O, len(idx), 40 + step)
+        lo = O.inner_step(xd[idx], yd[idx], dc_scales=dc)
+        L.inner_step(idx, dc_scales=dc)
+        ll = L.loss_value()
+        assert abs(ll - lo) <= (1e-4 if step == 0 else 1e-3) * max(1.0, abs(lo)), (step, ll, lo)
+    assert L.plans[8].graph is not None
+    _compare_meta_state(O, L, "8-step task ", p_tol=5e-5)
+    with torch.no_grad():
+        lgO, _ = R.forward(O.a, O.params, O.bn, xd, False)
+    pL, lgL = L.predict(x, training=False, return_logits=True)
+    scale = lgO.abs().max().item()
+    assert (lgL.cpu().double() - lgO).abs().max().item() <= 2e-3 * scale
+    margin = (lgO[..., 0] - lgO[..., 1]).abs() > 1e-3 * scale
+    assert margin.float().mean().item() > 0.99
+    assert torch.equal(pL.cpu()[margin].double(), R.predictions(lgO)[margin])
+    L.close()
