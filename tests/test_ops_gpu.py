@@ -656,13 +656,13 @@ def test_dwconv_bwd_data_emits_bn_backward_stage1(k, s, H, W, C):
 
 # ------------------------------------------------------------------------------------------------ small-map MBConv depthwise half
 @pytest.mark.parametrize("k,N,H,W,C", [(3, 8, 14, 14, 480), (5, 8, 14, 14, 672), (5, 5, 14, 14, 480), (3, 8, 4, 4, 480), (5, 8, 16, 16, 40),
-                                       (3, 2, 24, 24, 8), (5, 3, 7, 9, 72), (3, 1, 1, 1, 16)])
+                                       (3, 2, 24, 24, 8), (5, 3, 7, 9, 72), (3, 2, 2, 3, 16)])
 def test_mbconv_small_fused_fwd_bwd(k, N, H, W, C):
     """mliis_mbconv_dw_fwd_small / _bwd_small (one launch per direction for the depthwise half of an MBConv block on small maps) vs the
     float64 oracle ops + autograd: expand BN (statistics handed over as stage-1 partials) -> swish -> depthwise k x k -> BN -> swish ->
     per-image means; both moving averages; backward with the squeeze-excite gate / pooled-gradient terms.  Shapes: the 14x14 layers of
     EfficientLab-6-3 at N = 8 and N = 5 (FOMAML tail batch), the 64x64-input test sizes, ragged maps, a channel count that leaves
-    workgroups of the XCD-grouped grid idle, a single pixel."""
+    workgroups of the XCD-grouped grid idle, a map smaller than one strip."""
     from mliis_amd import ops
     from mliis_amd.spec import BN_EPS
     d = dev()
