@@ -67,6 +67,15 @@ size_t mliis_dwconv_bwd_filter_workspace_floats(int N, int H, int W, int C, int 
 int mliis_dwconv_bwd_filter(const float* x, const float* dy, float* dw, int N, int H, int W, int C, int k, int stride, float* ws,
                             size_t ws_floats, hipStream_t stream);
 
+/* ---- masks of the stochastic ops of a training step, generated on the device inside the step's HIP graph (Philox4x32-10, counter =
+ *      (element, step, job), key = seed): drop-connect  floor(keep + u) / keep  per block and image (models/efficientnet/utils.py:
+ *      157-170) and dropout  (u < keep) / keep  per element (tf.layers.dropout: models/efficientlab.py:94-100,161-162,248-289).
+ *      state = device uint32[4] {seed lo, seed hi, step, 0}; the launch advances `step` itself (last workgroup), so graph replays
+ *      draw fresh masks.  Up to 6 jobs per launch; keeps[i] (device, nullable) gives a keep probability per row of row_len[i]
+ *      elements (drop-connect: one row per block), else keep[i] applies; outs[i] == NULL skips a job (its stream index is kept). */
+int mliis_rng_masks(unsigned* state, int njobs, float* const* outs, const long long* numels, const float* keep, const float* const* keeps,
+                    const int* row_len, const int* floor_form, hipStream_t stream);
+
 /* ---- the depthwise half of an MBConv block on SMALL maps in ONE launch per direction (mbconv_small.hip): expand BN -> swish ->
  *      depthwise k x k (stride 1) -> BN -> swish -> squeeze-excite mean (efficientnet_model.py:183-200,266-271,247; utils.py:87-134)
  *      and the whole backward of that chain.  Every op in it is per channel, so a workgroup that owns 8 channels over all of

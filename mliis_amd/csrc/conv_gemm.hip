@@ -152,6 +152,9 @@ static inline int pick_nt(int Nout) {
   return best;
 }
 
+static const bool kStreamK = getenv("MLIIS_NO_STREAMK") == nullptr;   // (A/B switch for profiles/r02_notes.md)
+constexpr int kSkMinChunks = 16;  // stream-K remainder only for K >= 512 (shorter K: the fixed cost of a part outweighs the balance)
+constexpr int kSkMinPart = 2;     // K chunks per part, at least
 constexpr int kGemmFill = 4;     // fwd / bwd-data: narrow the column tiles of sub-chip grids until there are this many blocks per CU
 constexpr int kFilterFill = 1;   // bwd-filter: same idea, one block per CU is enough (its slabs already split the pixel axis)
 
@@ -183,6 +186,34 @@ static inline GemmPlan plan_gemm(long long M, int Nout, int C, int ntaps, int nu
   }
   g.chunks_per_split = (nchunks + g.gz - 1) / g.gz;
   g.gz = (nchunks + g.chunks_per_split - 1) / g.chunks_per_split;
+  // data-parallel + stream-K remainder (conv_gemm_sk_k): long-K layers whose tile count leaves the last round of the chip part-empty
+  // (the 56x56 decoder convs: 392 / 784 / 1176 tiles on 256 CUs).  Needs a workspace for the segment slabs.
+  g.sk_full = g.sk_rem = g.sk_parts = g.sk_ipp = g.sk_nchunks = g.sk_smax = 0;
+  const long long tiles = (long long)g.gx * g.gy;
+  if (allow_split && kStreamK && g.tm == 1 && g.gz == 1 && !gemm_narrow(ntaps, C) && nchunks >= kSkMinChunks && tiles > num_cus &&
+      tiles % num_cus != 0 && tiles < (1 << 20)) {
+    int full = (int)(tiles / num_cus) * num_cus, rem = (int)(tiles - full);
+    static const bool kSkPure = getenv("MLIIS_SK_PURE") != nullptr;   // experiment: every tile through the parts, two equal parts per CU
+    if (kSkPure && tiles < 2 * num_cus) {
+      full = 0;
+      rem = (int)tiles;
+    }
+    long long total = (long long)rem * nchunks;
+    int parts = (kSkPure && full == 0) ? 2 * num_cus : num_cus;
+    if (parts > 4 * rem) parts = 4 * rem;         // at most ~5 slabs per remainder tile for the fix-up to add (a short tail of 16 tiles
+                                                  // cut 256 ways cost a 41 us fix-up: 16 workgroups adding 16 slabs each)
+    if (parts < rem) parts = rem;                 // (at most two segments per part)
+    if (total / parts < kSkMinPart) parts = (int)(total / kSkMinPart);   // parts of at least kSkMinPart chunks
+    if (parts >= 1) {
+      const int ipp = (int)((total + parts - 1) / parts);
+      g.sk_full = full;
+      g.sk_rem = rem;
+      g.sk_parts = (int)((total + ipp - 1) / ipp);
+      g.sk_ipp = ipp;
+      g.sk_nchunks = nchunks;
+      g.sk_smax = (nchunks + ipp - 1) / ipp + 1;
+    }
+  }
   return g;
 }
 
@@ -230,7 +261,12 @@ static inline FilterPlan plan_filter(long long M, int C, int Nout, int ntaps, in
 // Matrix-core operand precision of a dense-conv call (the `precision` argument of the three entry points): MLIIS_PREC_FP32 = fp32
 // operands (v_mfma_f32_16x16x4_f32), MLIIS_PREC_BF16 = operands rounded to bf16 in registers, fp32 accumulation
 // (v_mfma_f32_16x16x32_bf16).  Per call: nothing process-wide, a captured HIP graph keeps what each launch was issued with.
-static void launch_gemm(const GemmPlan& g, const ConvGemmParams& p, int precision, hipStream_t stream) {
+static void launch_gemm(const GemmPlan& g, const ConvGemmParams& p, int precision, hipStream_t stream, float* sk_slab = nullptr) {
+  if (g.sk_parts > 0 && sk_slab != nullptr) {
+    if (precision == MLIIS_PREC_BF16) launch_gemm_sk_bf16(g, p, sk_slab, stream);
+    else launch_gemm_sk_t<false>(g, p, sk_slab, stream);
+    return;
+  }
   if (precision == MLIIS_PREC_BF16) launch_gemm_bf16(g, p, stream);
   else launch_gemm_t<false>(g, p, stream);
 }
@@ -335,6 +371,10 @@ int mliis_conv2d_kernel_name(int Nimg, int H, int W, int Cred, int Nout, int ksi
     return MLIIS_OK;
   }
   GemmPlan g = plan_gemm((long long)Nimg * H * W, Nout, Cred, ksize * ksize, num_cus(), 1);
+  if (g.sk_parts > 0 && !has_scale) {   // (+ sk_fixup_k<NT> for the remainder tiles)
+    snprintf(buf, buf_len, "conv_gemm_sk_k<%d, 2, false, %s>", g.nt, precision == MLIIS_PREC_BF16 ? "true" : "false");
+    return MLIIS_OK;
+  }
   snprintf(buf, buf_len, "conv_gemm_nk_k<%d, %d, %d, %s, %s, %s, %s>", g.tm, g.nt, g.tm == 1 ? 2 : 1, has_scale ? "true" : "false",
            g.gz > 1 ? "true" : "false", gemm_narrow(ksize * ksize, Cred) ? "true" : "false", precision == MLIIS_PREC_BF16 ? "true" : "false");
   return MLIIS_OK;
@@ -344,7 +384,7 @@ int mliis_conv2d_kernel_name(int Nimg, int H, int W, int Cred, int Nout, int ksi
 size_t mliis_conv2d_workspace_floats(int Nimg, int H, int W, int Cred, int Nout, int ksize) {
   long long M = (long long)Nimg * H * W;
   const GemmPlan g = plan_gemm(M, Nout, Cred, ksize * ksize, num_cus(), 1);
-  return g.gz > 1 ? (size_t)g.gz * M * Nout : 0;
+  return g.gz > 1 ? (size_t)g.gz * M * Nout : g.sk_slab_floats();
 }
 
 // y[M, Cout] (ld = ldy) (+)= conv(x[M, Cin] (ld = ldx), w) + bias ; stride 1, TF-SAME, dilation dil; the weights come as the
@@ -406,7 +446,9 @@ int mliis_conv2d_fwd(const float* x, int ldx, const float* x_scale, const float*
                   "conv2d_fwd: split-K workspace too small (%zu needed, %zu given) or unaligned output", need, ws_floats);
     p.partial = ws;
   }
-  launch_gemm(g, p, precision, stream);
+  float* sk_slab = nullptr;
+  if (g.sk_parts > 0 && x_scale == nullptr && ws != nullptr && aligned16(ws) && g.sk_slab_floats() <= ws_floats && (ldy & 3) == 0) sk_slab = ws;
+  launch_gemm(g, p, precision, stream, sk_slab);
   MLIIS_CHECK_LAUNCH("conv2d_fwd");
   if (g.gz > 1 && stats_part != nullptr) {
     hipLaunchKernelGGL(splitk_reduce_stats_k, dim3((unsigned)((M + kRedRows - 1) / kRedRows), (Cout + 31) / 32), dim3(256), 0, stream, ws, g.gz,
@@ -454,7 +496,9 @@ int mliis_conv2d_bwd_data(const float* dy, int lddy, const float* w, float* dx, 
                   "conv2d_bwd_data: split-K workspace too small (%zu needed, %zu given) or unaligned output", need, ws_floats);
     p.partial = ws;
   }
-  launch_gemm(g, p, precision, stream);
+  float* sk_slab = nullptr;
+  if (g.sk_parts > 0 && ws != nullptr && aligned16(ws) && g.sk_slab_floats() <= ws_floats && (lddx & 3) == 0) sk_slab = ws;
+  launch_gemm(g, p, precision, stream, sk_slab);
   MLIIS_CHECK_LAUNCH("conv2d_bwd_data");
   if (g.gz > 1) {
     long long q = M * (Cin_out / 4);

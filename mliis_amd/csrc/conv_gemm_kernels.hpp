@@ -62,40 +62,45 @@ __device__ __forceinline__ float4 buf_ld4(__amdgpu_buffer_rsrc_t r, unsigned byt
   return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 
-template <int TM, int NT, int PF, bool SC, bool SPLIT, bool NARROW, bool BF>
-__global__ __launch_bounds__(256, 2) void conv_gemm_nk_k(ConvGemmParams p) {
+template <int TM, int NT>
+struct GemmSm {
+  static constexpr int BM = 64 * TM, BN = 16 * NT;
+  static constexpr int A_FLOATS = 8 * BM * 4, B_FLOATS = 8 * BN * 4, BUF_FLOATS = A_FLOATS + B_FLOATS;
+  static constexpr int LDS_STAGE = BN + 4;             // epilogue staging row stride (floats)
+  static constexpr int STAGE_FLOATS = 4 * 16 * LDS_STAGE;
+  static constexpr int SM_FLOATS = (2 * BUF_FLOATS) > STAGE_FLOATS ? (2 * BUF_FLOATS) : STAGE_FLOATS;
+};
+
+// One output tile (row tile bx, column tile by) over the K chunks [it0, it1) out of the workgroup's LDS buffer `sm`.
+// pdst == nullptr: finished tile -- bias / border bias / accumulate / fused BN statistics, staged row stores into p.Cmat.
+// pdst != nullptr: raw partial tile, element (row r, column c) of the tile to pdst[r * pstride + c] (split-K slabs [z][M][Nout]:
+// pstride = Nout; stream-K segment slabs [64][BN]: pstride = BN); a fold kernel finishes those tiles.
+template <int TM, int NT, int PF, bool SC, bool NARROW, bool BF>
+__device__ __forceinline__ void conv_gemm_tile(const ConvGemmParams& p, float* __restrict__ sm, unsigned bx, int by, int it0, int it1,
+                                               float* __restrict__ pdst, int pstride) {
   constexpr int BM = 64 * TM, BN = 16 * NT, BK = 32;
-  constexpr int A_FLOATS = 8 * BM * 4;
-  constexpr int B_FLOATS = 8 * BN * 4;
-  constexpr int BUF_FLOATS = A_FLOATS + B_FLOATS;
+  constexpr int A_FLOATS = GemmSm<TM, NT>::A_FLOATS;
+  constexpr int BUF_FLOATS = GemmSm<TM, NT>::BUF_FLOATS;
   constexpr int A_PER_THREAD = 2 * TM;          // float4 per thread per chunk
   constexpr int B_TOTAL = BN * 8;               // float4 per chunk
   constexpr int B_PER_THREAD = (B_TOTAL + 255) / 256;
-  constexpr int LDS_STAGE = BN + 4;             // epilogue staging row stride (floats)
-  constexpr int STAGE_FLOATS = 4 * 16 * LDS_STAGE;
-  constexpr int SM_FLOATS = (2 * BUF_FLOATS) > STAGE_FLOATS ? (2 * BUF_FLOATS) : STAGE_FLOATS;
-  constexpr int kDummy = SM_FLOATS;   // 16-byte scratch slot behind the buffers
-  __shared__ __attribute__((aligned(16))) float sm[SM_FLOATS + 4];
+  constexpr int LDS_STAGE = GemmSm<TM, NT>::LDS_STAGE;
+  constexpr int kDummy = GemmSm<TM, NT>::SM_FLOATS;   // 16-byte scratch slot behind the buffers
 
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
   const int l15 = lane & 15, g = lane >> 4;
   const long long M = (long long)p.Nimg * p.H * p.W;
-  const int n0 = blockIdx.y * BN;
+  const int n0 = by * BN;
   // K is the flattened (tap, channel) index cut into chunks of 32: chunks may straddle taps (every thread tracks the tap / channel of
   // ITS k quad), so only the very last chunk carries padding and every chunk is a full 2 x 4 x NT MFMA block -- no per-chunk branch.
-  const int nchunks_total = (p.ntaps * p.C + BK - 1) / BK;
-  const int it0 = blockIdx.z * p.chunks_per_split;
-  int it1 = it0 + p.chunks_per_split;
-  if (it1 > nchunks_total) it1 = nchunks_total;
 
-  constexpr bool split = SPLIT;   // split-K instance: raw partial tiles [z][M][Nout], the fold kernel finishes them
+  const bool split = pdst != nullptr;   // raw partial tile, a fold kernel finishes it
   const bool stats = (p.stats_part != nullptr) && !split;
   float s1[NT], s2[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) s1[j] = s2[j] = 0.f;
 
-  const unsigned bx = xcd_remap(blockIdx.x, gridDim.x);
   const long long m0 = (long long)bx * BM;
 
   const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, kBufRecords, 0x00020000);
@@ -294,12 +299,12 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_nk_k(ConvGemmParams p) {
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const long long m = m0 + wave * 16 * TM + i * 16 + g * 4 + r;
-        if (m >= M) continue;
+        const int row = wave * 16 * TM + i * 16 + g * 4 + r;
+        if (m0 + row >= M) continue;
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
           const int n = n0 + j * 16 + l15;
-          if (n < p.Nout) p.partial[((long long)blockIdx.z * M + m) * p.Nout + n] = acc[i][j][r];
+          if (n < p.Nout) pdst[(long long)row * pstride + j * 16 + l15] = acc[i][j][r];
         }
       }
     return;
@@ -388,6 +393,140 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_nk_k(ConvGemmParams p) {
     if (n < p.Nout) {
       const float r0 = red[(0 * 2 + v) * BN + col] + red[(1 * 2 + v) * BN + col] + red[(2 * 2 + v) * BN + col] + red[(3 * 2 + v) * BN + col];
       p.stats_part[((long long)bx * 2 + v) * p.Nout + n] = r0;
+    }
+  }
+}
+
+// grid = (row tiles, column tiles, K splits).  SPLIT: raw partial tiles [z][M][Nout], the fold kernel finishes them.
+template <int TM, int NT, int PF, bool SC, bool SPLIT, bool NARROW, bool BF>
+__global__ __launch_bounds__(256, 2) void conv_gemm_nk_k(ConvGemmParams p) {
+  __shared__ __attribute__((aligned(16))) float sm[GemmSm<TM, NT>::SM_FLOATS + 4];
+  const int nchunks_total = (p.ntaps * p.C + 31) / 32;
+  const int it0 = blockIdx.z * p.chunks_per_split;
+  int it1 = it0 + p.chunks_per_split;
+  if (it1 > nchunks_total) it1 = nchunks_total;
+  const unsigned bx = xcd_remap(blockIdx.x, gridDim.x);
+  float* pdst = nullptr;
+  if (SPLIT) {
+    const long long M = (long long)p.Nimg * p.H * p.W;
+    pdst = p.partial + ((long long)blockIdx.z * M + (long long)bx * (64 * TM)) * p.Nout + blockIdx.y * (16 * NT);
+  }
+  conv_gemm_tile<TM, NT, PF, SC, NARROW, BF>(p, sm, bx, blockIdx.y, it0, it1, pdst, p.Nout);
+}
+
+// ------------------------------------------------------------------------------------------------ data-parallel + stream-K remainder
+// A layer whose T = (row tiles) x (column tiles) output tiles are not a multiple of the CU count leaves the chip part-idle in its last
+// round (the 56x56 decoder convs: 392 tiles of 64 x 112 on 256 CUs -> the CUs holding two tiles set the time, 0.77 of the chip).
+// Here the first F = floor(T / CUs) * CUs tiles run as whole tiles (workgroups [0, F)), and the K iterations of the remaining R = T - F
+// tiles -- R * nchunks chunks of 32 -- are cut into `parts` equal contiguous ranges, one per workgroup [F, F + parts): a range covers
+// the tail of one remainder tile and the head of the next (at most two segments since parts >= R), each written as a raw 64 x BN
+// partial into its (tile, slot) slab; sk_fixup_k adds a tile's slots in a fixed order (deterministic), applies the epilogue and
+// emits its BN statistics.  Every CU then carries F / CUs whole tiles plus one equal share of the rest.
+struct SkPlan {
+  int full;      // F: tiles computed whole
+  int rem;       // R: tiles cut into parts
+  int parts;     // workgroups that share the remainder
+  int ipp;       // K chunks per part
+  int nchunks;   // K chunks per tile
+  int smax;      // slab slots per remainder tile
+  int gy;        // column tiles
+  float* slab;   // [rem][smax][64][BN]
+};
+
+template <int NT, int PF, bool SC, bool BF>
+__global__ __launch_bounds__(256, 2) void conv_gemm_sk_k(ConvGemmParams p, SkPlan k) {
+  __shared__ __attribute__((aligned(16))) float sm[GemmSm<1, NT>::SM_FLOATS + 4];
+  constexpr int BN = 16 * NT;
+  const int w = blockIdx.x;
+  if (w < k.full) {   // tile index tau -> (row tile tau / gy, column tile tau % gy): the column tiles of a row tile are neighbours
+    const unsigned tau = xcd_remap(w, k.full);
+    conv_gemm_tile<1, NT, PF, SC, false, BF>(p, sm, tau / k.gy, tau % k.gy, 0, k.nchunks, nullptr, 0);
+    return;
+  }
+  const int part = w - k.full;
+  int lo = part * k.ipp;
+  const int total = k.rem * k.nchunks;
+  int hi = lo + k.ipp;
+  if (hi > total) hi = total;
+#pragma unroll 1
+  while (lo < hi) {
+    const int rt = lo / k.nchunks, c0 = lo - rt * k.nchunks;
+    int c1 = c0 + (hi - lo);
+    if (c1 > k.nchunks) c1 = k.nchunks;
+    const int first = (rt * k.nchunks) / k.ipp;          // first part that touches this tile -> slot 0
+    const unsigned tau = k.full + rt;
+    float* dst = k.slab + ((long long)rt * k.smax + (part - first)) * (64 * BN);
+    conv_gemm_tile<1, NT, PF, SC, false, BF>(p, sm, tau / k.gy, tau % k.gy, c0, c1, dst, BN);
+    lo += c1 - c0;
+    __syncthreads();   // the next segment reuses the LDS buffers
+  }
+}
+
+// Finishes the remainder tiles of conv_gemm_sk_k: grid = (rem); 1024 threads = 32 column-quad slots x 32 row lanes (two rows per
+// thread: all slot loads of a row pair are issued together -- the kernel is a few dependent round trips, nothing else).
+template <int NT>
+__global__ __launch_bounds__(1024) void sk_fixup_k(ConvGemmParams p, SkPlan k) {
+  constexpr int BN = 16 * NT, QN = BN / 4;
+  __shared__ float4 red[2][32][32];
+  const int t = threadIdx.x, q = t & 31, rl = t >> 5;
+  const int rt = blockIdx.x;
+  const unsigned tau = k.full + rt;
+  const int bx = tau / k.gy, by = tau % k.gy;
+  const long long M = (long long)p.Nimg * p.H * p.W;
+  const long long m0 = (long long)bx * 64;
+  const int n = by * BN + q * 4;
+  const bool cok = q < QN && n < p.Nout;
+  const int first = (rt * k.nchunks) / k.ipp;
+  int last = ((rt + 1) * k.nchunks - 1) / k.ipp;
+  if (last > k.parts - 1) last = k.parts - 1;
+  const int nslots = last - first + 1;
+  const float* base = k.slab + (long long)rt * k.smax * (64 * BN) + q * 4;
+  float4 s1 = f4zero(), s2 = f4zero();
+  if (cok) {
+    const float4 bv = p.bias != nullptr ? ld4(p.bias + n) : f4zero();
+    const long long HWp = (long long)p.H * p.W;
+    float4 v[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) v[i] = ld4(base + (long long)(rl + 32 * i) * BN);
+    for (int z = 1; z < nslots; ++z) {
+      float4 u[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) u[i] = ld4(base + ((long long)z * 64 + rl + 32 * i) * BN);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) v[i] = f4add(v[i], u[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const long long m = m0 + rl + 32 * i;
+      if (m >= M) continue;
+      float4 o = f4add(v[i], bv);
+      if (p.border_bias != nullptr) {
+        const int ni = (int)(m / HWp);
+        const int rem = (int)(m - (long long)ni * HWp);
+        const int h = rem / p.W, w_ = rem - h * p.W;
+        const int cls = (h == 0 ? 0 : (h == p.H - 1 ? 2 : 1)) * 3 + (w_ == 0 ? 0 : (w_ == p.W - 1 ? 2 : 1));
+        o = f4add(o, ld4(p.border_bias + ((long long)ni * 9 + cls) * p.Nout + n));
+      }
+      float* dst = p.Cmat + m * p.ldc + n;
+      if (p.accumulate) o = f4add(o, ld4(dst));
+      st4(dst, o);
+      if (p.stats_swish) o = make_float4(swish_f(o.x), swish_f(o.y), swish_f(o.z), swish_f(o.w));
+      s1 = f4add(s1, o);
+      s2 = f4fma(o, o, s2);
+    }
+  }
+  if (p.stats_part == nullptr) return;
+  red[0][rl][q] = s1;
+  red[1][rl][q] = s2;
+  __syncthreads();
+  if (t < 64) {
+    const int v = t >> 5, qq = t & 31;
+    const int nn = by * BN + qq * 4;
+    if (qq < QN && nn < p.Nout) {
+      float4 a = red[v][0][qq];
+#pragma unroll 8
+      for (int r = 1; r < 32; ++r) a = f4add(a, red[v][r][qq]);
+      st4(p.stats_part + ((long long)bx * 2 + v) * p.Nout + nn, a);
     }
   }
 }
@@ -726,10 +865,34 @@ __global__ __launch_bounds__(256, 2) void conv_filter_grad2_k(FilterGradParams p
 // ------------------------------------------------------------------------------------------------ plans + instantiation switches
 struct GemmPlan {
   int tm, nt, gx, gy, gz, chunks_per_split;
+  // data-parallel + stream-K remainder (conv_gemm_sk_k): sk_parts > 0
+  int sk_full, sk_rem, sk_parts, sk_ipp, sk_nchunks, sk_smax;
+  size_t sk_slab_floats() const { return sk_parts > 0 ? (size_t)sk_rem * sk_smax * 64 * (16 * nt) : 0; }
 };
 
 // 3x3 convs over fewer than 32 channels: a 32-wide K chunk spans several taps (conv_gemm_nk_k<..., NARROW = true>)
 static inline bool gemm_narrow(int ntaps, int C) { return ntaps > 1 && C < 32; }
+
+template <bool BF>
+static void launch_gemm_sk_t(const GemmPlan& g, const ConvGemmParams& p, float* slab, hipStream_t stream) {
+  const SkPlan k{g.sk_full, g.sk_rem, g.sk_parts, g.sk_ipp, g.sk_nchunks, g.sk_smax, g.gy, slab};
+  dim3 grid(g.sk_full + g.sk_parts), block(256);
+#define SKL(NT_)                                                                                       \
+  hipLaunchKernelGGL((conv_gemm_sk_k<NT_, 2, false, BF>), grid, block, 0, stream, p, k);              \
+  hipLaunchKernelGGL((sk_fixup_k<NT_>), dim3(g.sk_rem), dim3(1024), 0, stream, p, k);                  \
+  break;
+  switch (g.nt) {
+    case 1: SKL(1)
+    case 2: SKL(2)
+    case 3: SKL(3)
+    case 4: SKL(4)
+    case 5: SKL(5)
+    case 6: SKL(6)
+    case 7: SKL(7)
+    default: SKL(8)
+  }
+#undef SKL
+}
 
 template <bool BF>
 static void launch_gemm_t(const GemmPlan& g, const ConvGemmParams& p, hipStream_t stream) {
@@ -799,6 +962,7 @@ static void launch_filter_t(const FilterPlan& f, const FilterGradParams& p, hipS
 
 // operand precision of the matrix cores: the fp32 instances live in conv_gemm.hip, the bf16 ones in conv_gemm_bf16.hip
 void launch_gemm_bf16(const GemmPlan& g, const ConvGemmParams& p, hipStream_t stream);
+void launch_gemm_sk_bf16(const GemmPlan& g, const ConvGemmParams& p, float* slab, hipStream_t stream);
 void launch_filter_bf16(const FilterPlan& f, const FilterGradParams& p, hipStream_t stream);
 
 }  // namespace mliis

@@ -54,7 +54,6 @@ class _Plan:
         self.blocks = []
         nskip = sum(1 for b in a.blocks if b.executed and b.skip)
         self.dc_all = torch.ones(max(nskip, 1), N, dtype=torch.float32, device=dev)
-        self.dc_pool, self.dc_pool_i = None, 0   # drop-connect masks drawn 16 steps at a time (Learner._fill_masks)
         si = 0
         gmax = 0
         for b in a.blocks:
@@ -172,8 +171,27 @@ class _Plan:
         self.fold_part = {k: self.fold_buf[o:o + n] for k, (o, n) in regs.items()}
         self.fold_desc = torch.tensor(rows, dtype=torch.int64, device=dev)
         self.fold_tiles = tile
-        self.graph = None           # captured hipGraphExec for the training step
+        # captured hipGraphExecs of the training step: key True = the step draws its masks on the device (mliis_rng_masks inside the graph),
+        # False = masks were handed in by the caller (parity tests inject them) and the graph starts after them
+        self.graphs = {}
         self.steps_run = 0
+        # ---- mask generation inside the step (ops.rng_masks): drop-connect scales of all skip blocks, final-layer dropout, ASPP dropouts
+        jobs = []
+        if L.drop_connect and nskip:
+            jobs.append((self.dc_all, L._dc_keeps, N, True))
+        if self.drop_mask is not None:
+            jobs.append((self.drop_mask, L.drop_keep_dev, self.drop_mask.numel(), False))
+        if self.aspp is not None:
+            for mbuf in self.aspp["masks"]:
+                jobs.append((mbuf, 1.0 - spec.ASPP_DROPOUT, 1, False))
+        self.mask_plan = ops.MaskPlan(jobs) if jobs else None
+
+    @property
+    def graph(self):
+        """Any captured graph of this plan (None: none yet)."""
+        for g in self.graphs.values():
+            return g
+        return None
 
 
 class Learner:
@@ -213,7 +231,6 @@ class Learner:
         self.small_fused = (os.environ.get("MLIIS_SMALL_FUSED", "1") != "0") if small_fused is None else bool(small_fused)
         self.use_graph = use_graph
         self.stream = torch.cuda.Stream(device=self.device)
-        self._dc_keeps = None
         # Optional (overlap_wgrad = 1 | 2): weight-gradient GEMMs on a second stream forked inside the HIP graph, one by one (1) or
         # handed over at a few points of the backward pass (2, wgrad_flush_before = block indices).  Neither beats the single stream
         # on MI355X (profiles/r01_notes.md), so it is off by default.
@@ -252,8 +269,12 @@ class Learner:
         self.shots_x = torch.zeros(max_shots, H, H, 3, dtype=torch.float32, device=self.device)
         self.shots_y = torch.zeros(max_shots, H, H, 2, dtype=torch.float32, device=self.device)
         self.n_shots = 0
-        self.rng = torch.Generator(device=self.device)
-        self.rng.manual_seed(seed)
+        # device RNG of the stochastic ops (drop-connect, dropout): Philox state advanced by the mask kernel itself (csrc/rng.hip)
+        self.rng_state = ops.rng_state(seed, self.device)
+        ex_ = [b for b in self.arch.blocks if b.executed and b.skip]
+        self._dc_keeps = torch.tensor([1.0 - b.drop_rate for b in ex_] or [1.0], dtype=torch.float32, device=self.device)
+        self.drop_keep_dev = torch.tensor([1.0 - self.final_layer_dropout_rate], dtype=torch.float32, device=self.device)
+        self._drop_keep_val = 1.0 - self.final_layer_dropout_rate
         self._pname()
         torch.cuda.synchronize(self.device)   # arena was initialised on the default stream; steps run on self.stream
 
@@ -404,9 +425,10 @@ class Learner:
             raise MliisError("workspace would grow to {} floats during HIP-graph capture (the eager first step of a plan sizes it)".format(floats))
         self.stream.synchronize()
         for P in self.plans.values():
-            if P.graph is not None:
-                lib.call("mliis_graph_destroy", P.graph)
-                P.graph = None
+            if P.graphs:
+                for gexec in P.graphs.values():
+                    lib.call("mliis_graph_destroy", gexec)
+                P.graphs = {}
                 P.steps_run = 0   # next step eager (re-sizes), the one after captures
 
     # ------------------------------------------------------------------------------------------- task data
@@ -770,7 +792,9 @@ class Learner:
             self.adam_t.add_(1.0)
             ops.adam_b1zero_fused(A.theta, A.grad, self.adam_v, self.adam_t, self.lr, A.l2_quad_mask, l2, self.lr_dev)
 
-    def _train_sequence(self, P: _Plan):
+    def _train_sequence(self, P: _Plan, draw_masks: bool):
+        if draw_masks and P.mask_plan is not None:
+            ops.rng_masks(self.rng_state, P.mask_plan)
         logits = self._forward(P, self.shots_x, P.idx, True)
         ops.softmax_ce(logits, self.shots_y, P.idx, self.label_smoothing, self.dice, 0.0, want_grad=True, want_pred=False,
                        dlogits=P.dlogits, out=P.loss_out, ws=self.ws)
@@ -809,65 +833,58 @@ class Learner:
                 self._lr_dev_val = lr_now
             if weight_decay_rate != 1.0:  # pre_step_op (variables.py:48-55)
                 ops.axpby(0.0, None, float(weight_decay_rate), self.arena.theta)
-            self._fill_masks(P, dc_scales, dropout_mask, drop_rate, aspp_masks)
+            draw = self._fill_masks(P, dc_scales, dropout_mask, drop_rate, aspp_masks)
             if self.use_graph and P.steps_run >= 1 and self.optimizer == "sgd":
-                if P.graph is None:
+                if draw not in P.graphs:
                     gexec = C.c_void_p()
                     lib.call("mliis_graph_begin_capture", self.stream.cuda_stream)
                     self._capturing = True
                     try:
-                        self._train_sequence(P)
+                        self._train_sequence(P, draw)
                     finally:
                         self._capturing = False
                         lib.call("mliis_graph_end_capture", self.stream.cuda_stream, C.byref(gexec))
-                    P.graph = gexec
-                lib.call("mliis_graph_launch", P.graph, self.stream.cuda_stream)
+                    P.graphs[draw] = gexec
+                lib.call("mliis_graph_launch", P.graphs[draw], self.stream.cuda_stream)
             else:
-                self._train_sequence(P)
+                self._train_sequence(P, draw)
             P.steps_run += 1
         self.last_loss = P.loss_out
         return P.loss_out
 
-    def _fill_masks(self, P: _Plan, dc_scales, dropout_mask, drop_rate=None, aspp_masks=None):
-        if P.aspp is not None:   # four tf.layers.dropout(rate=0.5) sites: scale 0 or 1/keep (injectable for parity tests)
-            keep = 1.0 - spec.ASPP_DROPOUT
-            for i, mbuf in enumerate(P.aspp["masks"]):
-                if aspp_masks is not None:
-                    mbuf.copy_(torch.as_tensor(aspp_masks[i], dtype=torch.float32).reshape(mbuf.shape))
-                else:
-                    mbuf.copy_((torch.rand(mbuf.shape, generator=self.rng, device=self.device) < keep).to(torch.float32) / keep)
+    def _fill_masks(self, P: _Plan, dc_scales, dropout_mask, drop_rate=None, aspp_masks=None) -> bool:
+        """Masks handed in by the caller (parity tests) are copied into the plan's buffers; returns True when the step has to draw its
+        masks itself -- on the device, inside the step (ops.rng_masks: no host RNG and no torch op on the path)."""
         if drop_rate is not None and P.drop_mask is None:
             raise ValueError("drop_rate given but the model was built without final-layer dropout (final_layer_dropout_rate = 0)")
         if drop_rate is not None and not 0.0 <= float(drop_rate) < 1.0:
             raise ValueError("drop_rate must be in [0, 1), got {}".format(drop_rate))
+        injected = dc_scales is not None or dropout_mask is not None or aspp_masks is not None
+        if P.drop_mask is not None and dropout_mask is None:   # keep probability of the final-layer dropout: a device scalar (graph-replay safe)
+            keep = 1.0 - (self.final_layer_dropout_rate if drop_rate is None else float(drop_rate))
+            if keep != self._drop_keep_val:
+                self.drop_keep_dev.fill_(keep)
+                self._drop_keep_val = keep
+        if not injected:
+            return P.mask_plan is not None
+        # ---- injected masks: every stochastic site not given explicitly is drawn once here with the same device generator
+        if P.mask_plan is not None:
+            ops.rng_masks(self.rng_state, P.mask_plan)
+        if P.aspp is not None and aspp_masks is not None:   # four tf.layers.dropout(rate=0.5) sites: scale 0 or 1/keep
+            for i, mbuf in enumerate(P.aspp["masks"]):
+                mbuf.copy_(torch.as_tensor(aspp_masks[i], dtype=torch.float32).reshape(mbuf.shape))
         ex = [b for b in self.arch.blocks if b.executed]
-        if self.drop_connect:
-            if dc_scales is not None:
-                for b, B in zip(ex, P.blocks):
-                    if b.skip and "dc" in B:
-                        v = dc_scales.get(b.idx)
-                        if v is None:
-                            B["dc"].fill_(1.0)
-                        else:
-                            B["dc"].copy_(torch.as_tensor(v, dtype=torch.float32))
-            else:
-                if self._dc_keeps is None:   # constant of the architecture: uploaded once (an upload per step would make the host
-                    # wait for the previous step of this stream before it can queue the next one)
-                    self._dc_keeps = torch.tensor([1.0 - b.drop_rate for b in ex if b.skip], dtype=torch.float32, device=self.device)[:, None]
-                keeps = self._dc_keeps
-                if keeps.numel():
-                    if P.dc_pool is None or P.dc_pool_i >= P.dc_pool.shape[0]:   # one draw per 16 steps: 1 small launch per step, not 4
-                        u = torch.rand((16,) + tuple(P.dc_all.shape), generator=self.rng, device=self.device)
-                        P.dc_pool, P.dc_pool_i = torch.floor(keeps + u) / keeps, 0   # utils.py:159-170
-                    P.dc_all.copy_(P.dc_pool[P.dc_pool_i])
-                    P.dc_pool_i += 1
-        if P.drop_mask is not None:
-            if dropout_mask is not None:
-                P.drop_mask.copy_(torch.as_tensor(dropout_mask, dtype=torch.float32))
-            else:
-                keep = 1.0 - (self.final_layer_dropout_rate if drop_rate is None else float(drop_rate))
-                u = torch.rand(P.drop_mask.shape, generator=self.rng, device=self.device)
-                P.drop_mask.copy_((u < keep).to(torch.float32) / keep)
+        if self.drop_connect and dc_scales is not None:
+            for b, B in zip(ex, P.blocks):
+                if b.skip and "dc" in B:
+                    v = dc_scales.get(b.idx)
+                    if v is None:
+                        B["dc"].fill_(1.0)
+                    else:
+                        B["dc"].copy_(torch.as_tensor(v, dtype=torch.float32))
+        if P.drop_mask is not None and dropout_mask is not None:
+            P.drop_mask.copy_(torch.as_tensor(dropout_mask, dtype=torch.float32))
+        return False
 
     # ------------------------------------------------------------------------------------------- inference
     def predict(self, images, training: bool = False, return_logits: bool = False):
@@ -895,9 +912,9 @@ class Learner:
         """Destroy the captured HIP graphs (the buffers themselves are torch tensors and go with the object)."""
         self.synchronize()
         for P in self.plans.values():
-            if P.graph is not None:
-                lib.call("mliis_graph_destroy", P.graph)
-                P.graph = None
+            for gexec in P.graphs.values():
+                lib.call("mliis_graph_destroy", gexec)
+            P.graphs = {}
 
     def gradients_packed(self) -> torch.Tensor:
         return self.arena.export_grad_packed()

@@ -574,6 +574,35 @@ def fold_batched(part_base, out_base, desc, total_tiles):
     lib.call("mliis_fold_batched", _ptr(part_base), _ptr(out_base), _ptr(desc), int(desc.shape[0]), int(total_tiles), _stream())
 
 
+# ------------------------------------------------------------------------------------------------ device RNG (masks)
+class MaskPlan:
+    """Argument block of one mliis_rng_masks launch (built once per plan: the host arrays must outlive every launch / graph capture).
+    jobs: list of (out tensor | None, keep probability | device tensor of per-row keep probabilities, row_len, floor_form)."""
+
+    def __init__(self, jobs):
+        n = len(jobs)
+        self.n = n
+        self.outs = (C.c_void_p * n)(*[_ptr(j[0]) for j in jobs])
+        self.numels = (C.c_longlong * n)(*[int(j[0].numel()) if j[0] is not None else 0 for j in jobs])
+        self.keep = (C.c_float * n)(*[float(j[1]) if not torch.is_tensor(j[1]) else 1.0 for j in jobs])
+        self.keeps = (C.c_void_p * n)(*[_ptr(j[1]) if torch.is_tensor(j[1]) else None for j in jobs])
+        self.row_len = (C.c_int * n)(*[int(j[2]) for j in jobs])
+        self.floor_form = (C.c_int * n)(*[int(bool(j[3])) for j in jobs])
+        self._keepalive = jobs
+
+
+def rng_state(seed: int, device) -> torch.Tensor:
+    """Device uint32[4] {seed lo, seed hi, step = 0, 0} (stored as int32 bits)."""
+    s = int(seed) & 0xFFFFFFFFFFFFFFFF
+    lo, hi = s & 0xFFFFFFFF, s >> 32
+    to_i32 = lambda v: v - (1 << 32) if v >= (1 << 31) else v  # noqa: E731
+    return torch.tensor([to_i32(lo), to_i32(hi), 0, 0], dtype=torch.int32, device=device)
+
+
+def rng_masks(state: torch.Tensor, plan: MaskPlan):
+    lib.call("mliis_rng_masks", _ptr(state), plan.n, plan.outs, plan.numels, plan.keep, plan.keeps, plan.row_len, plan.floor_form, _stream())
+
+
 # ------------------------------------------------------------------------------------------------ optimizer / arena
 def sgd_fused(w, g, lr, l2_quad_mask=None, l2=0.0, lr_dev=None):
     lib.call("mliis_sgd_fused", _ptr(w), _ptr(g), _ptr(l2_quad_mask), w.numel(), float(lr), _ptr(lr_dev), float(l2), _stream())

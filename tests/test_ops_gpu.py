@@ -722,3 +722,94 @@ def test_mbconv_small_fused_fwd_bwd(k, N, H, W, C):
     with pytest.raises(Exception):
         ops.mbconv_dw_fwd_small(torch.zeros(64, 14, 14, C, device=d), part, nblk, (f32(g0, d), f32(b0, d), st[0], st[1], None, None), f32(wd, d),
                                 (f32(g1, d), f32(b1, d), st[2], st[3], None, None), z1b, a1b, sb)
+
+
+# ------------------------------------------------------------------------------------------------ data-parallel + stream-K remainder
+@pytest.mark.parametrize("k,dil,H,Cin,Cout,N", [(3, 1, 56, 72, 112, 8), (3, 2, 56, 64, 136, 8), (3, 1, 56, 56, 224, 8), (1, 1, 64, 512, 112, 5)])
+def test_conv2d_stream_k_remainder(k, dil, H, Cin, Cout, N):
+    """Long-K layers whose tile count is not a multiple of the 256 CUs (the 56x56 decoder convs: 392 / 784 / 1176 tiles of 64 rows) run
+    their first floor(T / 256) * 256 tiles whole and cut the K range of the rest into equal parts (conv_gemm_sk_k + sk_fixup_k): forward
+    with bias, border-class bias and fused BN statistics (of swish(z)), accumulate, and backward-data, against the float64 oracle."""
+    from mliis_amd import ops
+    d = dev()
+    name = ops.conv2d_kernel_name(N, H, H, Cin, Cout, k)
+    assert name.startswith("conv_gemm_sk_k"), name
+    x = rnd(N, H, H, Cin, seed=90).requires_grad_(True)
+    w = rnd(k, k, Cin, Cout, seed=91, scale=1.0 / math.sqrt(k * k * Cin)).requires_grad_(True)
+    b = rnd(Cout, seed=92)
+    z = nhwc(R.conv2d_same(nchw(x), w, 1, dil, bias=b))
+    dy = rnd(*z.shape, seed=93)
+    (gx,) = torch.autograd.grad(z, [x], dy)
+    xg, wg, bg = f32(x, d), f32(w, d), f32(b, d)
+    part = torch.full((1 << 20,), 3.0, device=d)
+    zg, nblk = ops.conv2d_fwd(xg, wg, bg, dil, stats_part=part, stats_swish=True)
+    close(zg, z, 2e-5, "stream-K conv fwd")
+    assert nblk == -(-N * H * H // 64)
+    u = R.swish(z.detach())
+    sums = part[: nblk * 2 * Cout].view(nblk, 2, Cout).double().sum(0).cpu()
+    close(sums[0], u.sum(dim=(0, 1, 2)), 1e-5, "stream-K fused sum")
+    close(sums[1], (u * u).sum(dim=(0, 1, 2)), 1e-5, "stream-K fused sum of squares")
+    # deterministic, and identical to the plain data-parallel result up to the order of the K-range partial sums
+    zg2, _ = ops.conv2d_fwd(xg, wg, bg, dil, stats_part=part, stats_swish=True)
+    assert torch.equal(zg, zg2)
+    # accumulate into an existing tensor
+    base = f32(rnd(N, H, H, Cout, seed=94), d)
+    acc = base.clone()
+    ops.conv2d_fwd(xg, wg, bg, dil, out=acc, accumulate=True)
+    close(acc - base, z, 3e-5, "stream-K accumulate")
+    if k == 3 and dil == 1:   # border-class bias of spatially constant channels (the RSD pooled branch)
+        bb = rnd(N, 9, Cout, seed=95)
+        hh = torch.arange(H)
+        cls = (torch.where(hh == 0, 0, torch.where(hh == H - 1, 2, 1))[:, None] * 3 + torch.where(hh == 0, 0, torch.where(hh == H - 1, 2, 1))[None, :])
+        ref = z.detach() + bb[:, cls.reshape(-1), :].reshape(N, H, H, Cout)
+        close(ops.conv2d_fwd(xg, wg, bg, dil, border_bias=f32(bb, d)), ref, 2e-5, "stream-K border bias")
+    # backward-data: reduction over (taps, Cout), output Cin columns -- its own plan (stream-K when it qualifies)
+    close(ops.conv2d_bwd_data(f32(dy, d), wg, dil), gx, 1e-4, "conv bwd data")
+
+
+# ------------------------------------------------------------------------------------------------ device RNG (masks)
+def _philox4x32_10(c, k):
+    """Philox4x32-10 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3", SC'11), restated for the test."""
+    M0, M1, W0, W1, mask = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85, 0xFFFFFFFF
+    c, k = list(c), list(k)
+    for _ in range(10):
+        p0, p1 = M0 * c[0], M1 * c[2]
+        c = [(p1 >> 32) ^ c[1] ^ k[0], p1 & mask, (p0 >> 32) ^ c[3] ^ k[1], p0 & mask]
+        k = [(k[0] + W0) & mask, (k[1] + W1) & mask]
+    return c
+
+
+def test_rng_masks_are_philox_and_advance_per_launch():
+    """mliis_rng_masks: drop-connect scales floor(keep + u) / keep per (block, image) and dropout masks (u < keep) / keep per element,
+    u = 24 high bits of Philox4x32-10(counter = (quad index, 0, step, job), key = seed) / 2^24 -- bit for bit against a Python
+    restatement (known-answer: the all-zero counter / key block of the Random123 test vectors); the launch advances the step itself."""
+    from mliis_amd import ops
+    d = dev()
+    assert _philox4x32_10([0, 0, 0, 0], [0, 0]) == [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]     # Random123 kat_vectors
+    assert _philox4x32_10([0xFFFFFFFF] * 4, [0xFFFFFFFF] * 2) == [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]
+    seed = 0x1234_5678_9ABC_DEF1
+    state = ops.rng_state(seed, d)
+    keeps = torch.tensor([0.9636, 0.9273, 0.8182], device=d)
+    dc = torch.zeros(3, 5, device=d)
+    drop = torch.zeros(1003, device=d)       # not a multiple of 4: ragged last quad
+    keepv = torch.tensor([0.5], device=d)
+    skipped = None
+    plan = ops.MaskPlan([(dc, keeps, 5, True), (skipped, 0.5, 1, False), (drop, keepv, drop.numel(), False)])
+    k = [seed & 0xFFFFFFFF, seed >> 32]
+    for step in range(3):
+        ops.rng_masks(state, plan)
+        torch.cuda.synchronize()
+        assert state.cpu().tolist()[2:] == [step + 1, 0]
+        u = lambda job, i: (_philox4x32_10([i // 4, 0, step, job], k)[i % 4] >> 8) / 16777216.0  # noqa: E731
+        kk = keeps.cpu().numpy()
+        exp_dc = [[float(np.float32(np.floor(np.float32(kk[b]) + np.float32(u(0, b * 5 + n)))) / np.float32(kk[b])) for n in range(5)] for b in range(3)]
+        np.testing.assert_array_equal(dc.cpu().numpy(), np.array(exp_dc, dtype=np.float32))
+        exp_drop = np.array([2.0 if u(2, i) < 0.5 else 0.0 for i in range(1003)], dtype=np.float32)
+        np.testing.assert_array_equal(drop.cpu().numpy(), exp_drop)
+    big = torch.zeros(1 << 20, device=d)
+    ops.rng_masks(state, ops.MaskPlan([(big, 0.8, 1, False)]))
+    assert abs((big == 0).float().mean().item() - 0.2) < 2e-3 and abs(big.max().item() - 1.25) < 1e-6
+    state2 = ops.rng_state(seed + 1, d)      # another seed, another stream
+    big2 = torch.zeros(1 << 20, device=d)
+    ops.rng_masks(state2, ops.MaskPlan([(big2, 0.8, 1, False)]))
+    assert 0.6 < (big == big2).float().mean().item() < 0.75     # P(agree) = 0.8^2 + 0.2^2 = 0.68 for independent streams
