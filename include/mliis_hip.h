@@ -106,8 +106,13 @@ size_t mliis_conv2d_workspace_floats(int Nimg, int H, int W, int Cred, int Nout,
 /*      `precision` (per call; nothing process-wide): operand precision of the matrix cores.  MLIIS_PREC_FP32 = fp32 operands
  *      (BASELINE configs 1-3), MLIIS_PREC_BF16 = operands rounded to bf16 in registers with fp32 accumulation (configs 4-5 flavour:
  *      tensors, BN, depthwise and the optimiser stay fp32). */
+/*      MLIIS_PREC_FP8 (BASELINE configs[4], "fp8 MFMA on 1x1 pointwise convs"): forward 1x1 convs with OCP e4m3 operands
+ *      (v_mfma_f32_16x16x32_fp8_fp8) -- activations times fp8_act_scale, weights times 2^floor(log2(224 / *fp8_w_amax)), both saturated
+ *      at +-448 and converted in registers, the fp32 accumulators divided by the two scales; *fp8_w_amax = max |w| of the weight
+ *      tensor, written by mliis_transpose_weights.  A 3x3 forward call and every backward call given MLIIS_PREC_FP8 runs bf16. */
 #define MLIIS_PREC_FP32 0
 #define MLIIS_PREC_BF16 1
+#define MLIIS_PREC_FP8 2
 /*      tiling chosen for a fwd / bwd-data call (row-tile factor, column tiles, split-K factor) and the name of the kernel
  *      instantiation it launches, as rocprofv3 prints it (profiling aids: bench.py matches its live timings to the trace) */
 int mliis_conv2d_plan(int Nimg, int H, int W, int Cred, int Nout, int ksize, int* tm, int* nt, int* splits);
@@ -124,10 +129,11 @@ int mliis_conv2d_kernel_name(int Nimg, int H, int W, int Cred, int Nout, int ksi
 int mliis_conv2d_fwd(const float* x, int ldx, const float* x_scale, const float* wt, const float* bias,
                      const float* border_bias, float* y, int ldy, int Nimg, int H, int W, int Cin_total, int ci_begin, int Cin, int Cout,
                      int ksize, int dil, int accumulate, float* stats_part, int stats_swish, int* stats_nblk, float* ws,
-                     size_t ws_floats, int precision, hipStream_t stream);
+                     size_t ws_floats, int precision, float fp8_act_scale, const float* fp8_w_amax, hipStream_t stream);
 /*      batched HWIO -> HWOI copy of dense-conv weights between two arenas of identical layout; desc = device int32
  *      [ndesc][4] {offset, taps, Cin, Cout} */
-int mliis_transpose_weights(const float* src, float* dst, const int* desc, int ndesc, hipStream_t stream);
+/*      amax (nullable, device float[ndesc]): also max |w| per descriptor (the fp8 operand scale of MLIIS_PREC_FP8) */
+int mliis_transpose_weights(const float* src, float* dst, const int* desc, int ndesc, float* amax, hipStream_t stream);
 /*      gradient w.r.t. input channels [ci_begin, ci_begin+Cin_out) of a conv whose weight has Cin_total input channels */
 int mliis_conv2d_bwd_data(const float* dy, int lddy, const float* w, float* dx, int lddx, int Nimg, int H, int W, int Cin_total,
                           int ci_begin, int Cin_out, int Cout, int ksize, int dil, int accumulate, float* ws, size_t ws_floats,

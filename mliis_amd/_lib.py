@@ -38,12 +38,12 @@ SIGNATURES = {
     "mliis_conv2d_workspace_floats": (_sz, [_i, _i, _i, _i, _i, _i]),
     "mliis_conv2d_plan": (_i, [_i, _i, _i, _i, _i, _i, _p, _p, _p]),
     "mliis_conv2d_kernel_name": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _p, _sz]),
-    "mliis_conv2d_fwd": (_i, [_p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _p, _sz, _i, _p]),
+    "mliis_conv2d_fwd": (_i, [_p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _p, _sz, _i, _f, _p, _p]),
     "mliis_rsd_pool_fwd_workspace_floats": (_sz, [_i, _i]),
     "mliis_rsd_pool_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _sz, _p]),
     "mliis_rsd_pool_bwd_workspace_floats": (_sz, [_i, _i]),
     "mliis_rsd_pool_bwd": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _p]),
-    "mliis_transpose_weights": (_i, [_p, _p, _p, _i, _p]),
+    "mliis_transpose_weights": (_i, [_p, _p, _p, _i, _p, _p]),
     "mliis_conv2d_bwd_data": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _i, _p]),
     "mliis_conv2d_bwd_filter_workspace_floats": (_sz, [_i, _i, _i, _i, _i, _i]),
     "mliis_conv2d_bwd_filter": (_i, [_p, _i, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _i, _p]),

@@ -107,7 +107,7 @@ _EXT = [
     ("--concurrent-tasks", dict(type=int, default=1,
                                 help="adapt this many tasks of a meta-batch at once on separate learners / streams (same meta-update; "
                                      "4 is the optimum on MI355X, needs meta_batch_size / ranks >= 2 to matter)")),
-    ("--matmul-precision", dict(choices=["fp32", "bf16"], default="fp32",
+    ("--matmul-precision", dict(choices=["fp32", "bf16", "fp8"], default="fp32",
                                 help="operand precision of the matrix cores in the dense convs (bf16: fp32 tensors rounded on the fly, fp32 accumulation)")),
     ("--checkpoint-format", dict(choices=["npz", "tf"], default="npz",
                                  help="tensor container of written checkpoints: numpy .npz or a TensorFlow TensorBundle (.index/.data)")),

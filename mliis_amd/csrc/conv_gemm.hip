@@ -106,13 +106,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats_k(const float* __rest
 // inner step keeps a K-contiguous copy of all dense-conv weights so the FORWARD GEMM can use the same b128-fragment B path as
 // backward-data.  32x32 LDS tiles: coalesced reads along co, coalesced writes along ci.
 __global__ __launch_bounds__(256) void transpose_weights_k(const float* __restrict__ src, float* __restrict__ dst,
-                                                           const int* __restrict__ desc) {
+                                                           const int* __restrict__ desc, unsigned* __restrict__ amax_bits) {
   __shared__ float tile[32][33];
+  __shared__ float wmax[4];
   const int d = blockIdx.y;
   const int off = desc[4 * d + 0], taps = desc[4 * d + 1], Ci = desc[4 * d + 2], Co = desc[4 * d + 3];
   const int tci = (Ci + 31) / 32, tco = (Co + 31) / 32;
   const int ntiles = taps * tci * tco;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  float amax = 0.f;
   for (int tIdx = blockIdx.x; tIdx < ntiles; tIdx += gridDim.x) {
     const int tap = tIdx / (tci * tco);
     const int rem = tIdx - tap * tci * tco;
@@ -122,7 +124,9 @@ __global__ __launch_bounds__(256) void transpose_weights_k(const float* __restri
 #pragma unroll
     for (int r = ty; r < 32; r += 8) {
       const int ci = ci0 + r, co = co0 + tx;
-      tile[r][tx] = (ci < Ci && co < Co) ? s0[(long long)ci * Co + co] : 0.f;
+      const float v = (ci < Ci && co < Co) ? s0[(long long)ci * Co + co] : 0.f;
+      tile[r][tx] = v;
+      amax = fmaxf(amax, fabsf(v));
     }
     __syncthreads();
 #pragma unroll
@@ -132,6 +136,14 @@ __global__ __launch_bounds__(256) void transpose_weights_k(const float* __restri
     }
     __syncthreads();
   }
+  if (amax_bits == nullptr) return;   // (uniform)
+  // per-tensor max |w| for the fp8 operand scale: wave max, workgroup max, then one integer atomicMax per workgroup (non-negative
+  // floats order like their bit patterns; a maximum does not depend on the order of the updates: deterministic)
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+  if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = amax;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicMax(amax_bits + d, __float_as_uint(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]))));
 }
 
 // ------------------------------------------------------------------------------------------------ host-side planning
@@ -262,21 +274,25 @@ static inline FilterPlan plan_filter(long long M, int C, int Nout, int ntaps, in
 // operands (v_mfma_f32_16x16x4_f32), MLIIS_PREC_BF16 = operands rounded to bf16 in registers, fp32 accumulation
 // (v_mfma_f32_16x16x32_bf16).  Per call: nothing process-wide, a captured HIP graph keeps what each launch was issued with.
 static void launch_gemm(const GemmPlan& g, const ConvGemmParams& p, int precision, hipStream_t stream, float* sk_slab = nullptr) {
+  if (precision == MLIIS_PREC_FP8) {   // (1x1 forward convs only: never a stream-K plan's long-K 3x3 layer)
+    launch_gemm_fp8(g, p, stream);
+    return;
+  }
   if (g.sk_parts > 0 && sk_slab != nullptr) {
     if (precision == MLIIS_PREC_BF16) launch_gemm_sk_bf16(g, p, sk_slab, stream);
-    else launch_gemm_sk_t<false>(g, p, sk_slab, stream);
+    else launch_gemm_sk_t<0>(g, p, sk_slab, stream);
     return;
   }
   if (precision == MLIIS_PREC_BF16) launch_gemm_bf16(g, p, stream);
-  else launch_gemm_t<false>(g, p, stream);
+  else launch_gemm_t<0>(g, p, stream);
 }
 static void launch_filter(const FilterPlan& f, const FilterGradParams& p, int precision, hipStream_t stream) {
-  if (precision == MLIIS_PREC_BF16) launch_filter_bf16(f, p, stream);
+  if (precision != MLIIS_PREC_FP32) launch_filter_bf16(f, p, stream);   // (fp8 mode: the backward passes take bf16 operands)
   else launch_filter_t<false>(f, p, stream);
 }
 static int prec_check(const char* name, int precision) {
-  MLIIS_REQUIRE(precision == MLIIS_PREC_FP32 || precision == MLIIS_PREC_BF16, MLIIS_ERR_ARG,
-                "%s: precision must be MLIIS_PREC_FP32 (0) or MLIIS_PREC_BF16 (1), got %d", name, precision);
+  MLIIS_REQUIRE(precision == MLIIS_PREC_FP32 || precision == MLIIS_PREC_BF16 || precision == MLIIS_PREC_FP8, MLIIS_ERR_ARG,
+                "%s: precision must be MLIIS_PREC_FP32 (0), MLIIS_PREC_BF16 (1) or MLIIS_PREC_FP8 (2), got %d", name, precision);
   return MLIIS_OK;
 }
 
@@ -306,9 +322,10 @@ static inline bool stream_plan(long long M, int K, int Nout, int num_cus, Stream
   sp->gx = (int)gx;
   return true;
 }
-static bool launch_stream(const StreamPlan& sp, const ConvGemmParams& p, hipStream_t stream) {
+static bool launch_stream(const StreamPlan& sp, const ConvGemmParams& p, hipStream_t stream, int precision = MLIIS_PREC_FP32) {
   dim3 grid(sp.gx, sp.gy), block(256);
-#define S(KC_, NT_) hipLaunchKernelGGL((conv1x1_stream_k<KC_, NT_>), grid, block, 0, stream, p, sp.row_groups); break;
+  if (precision != MLIIS_PREC_FP32) return launch_stream_lowp(precision, sp.kc, sp.nt, grid, p, sp.row_groups, stream);
+#define S(KC_, NT_) hipLaunchKernelGGL((conv1x1_stream_k<KC_, NT_, 0>), grid, block, 0, stream, p, sp.row_groups); break;
   switch (sp.kc) {
     case 1: switch (sp.nt) { case 1: S(1, 1) case 2: S(1, 2) case 3: S(1, 3) case 4: S(1, 4) case 5: S(1, 5) case 6: S(1, 6) case 7: S(1, 7) case 8: S(1, 8) default: return false; } break;
     case 2: switch (sp.nt) { case 1: S(2, 1) case 2: S(2, 2) case 3: S(2, 3) case 4: S(2, 4) default: return false; } break;
@@ -367,16 +384,16 @@ int mliis_conv2d_kernel_name(int Nimg, int H, int W, int Cred, int Nout, int ksi
   MLIIS_REQUIRE(buf && buf_len >= 64, MLIIS_ERR_ARG, "conv2d_kernel_name: buffer too small");
   StreamPlan sp;
   if (ksize == 1 && !has_scale && stream_plan((long long)Nimg * H * W, Cred, Nout, num_cus(), &sp)) {
-    snprintf(buf, buf_len, "conv1x1_stream_k<%d, %d>", sp.kc, sp.nt);   // (a call without accumulate / border bias)
+    snprintf(buf, buf_len, "conv1x1_stream_k<%d, %d, %d>", sp.kc, sp.nt, precision);   // (a call without accumulate / border bias)
     return MLIIS_OK;
   }
   GemmPlan g = plan_gemm((long long)Nimg * H * W, Nout, Cred, ksize * ksize, num_cus(), 1);
   if (g.sk_parts > 0 && !has_scale) {   // (+ sk_fixup_k<NT> for the remainder tiles)
-    snprintf(buf, buf_len, "conv_gemm_sk_k<%d, 2, false, %s>", g.nt, precision == MLIIS_PREC_BF16 ? "true" : "false");
+    snprintf(buf, buf_len, "conv_gemm_sk_k<%d, 2, false, %d>", g.nt, precision == MLIIS_PREC_FP8 ? MLIIS_PREC_BF16 : precision);
     return MLIIS_OK;
   }
-  snprintf(buf, buf_len, "conv_gemm_nk_k<%d, %d, %d, %s, %s, %s, %s>", g.tm, g.nt, g.tm == 1 ? 2 : 1, has_scale ? "true" : "false",
-           g.gz > 1 ? "true" : "false", gemm_narrow(ksize * ksize, Cred) ? "true" : "false", precision == MLIIS_PREC_BF16 ? "true" : "false");
+  snprintf(buf, buf_len, "conv_gemm_nk_k<%d, %d, %d, %s, %s, %s, %d>", g.tm, g.nt, g.tm == 1 ? 2 : 1, has_scale ? "true" : "false",
+           g.gz > 1 ? "true" : "false", gemm_narrow(ksize * ksize, Cred) ? "true" : "false", (precision == MLIIS_PREC_FP8 && ksize != 1) ? MLIIS_PREC_BF16 : precision);
   return MLIIS_OK;
 }
 
@@ -392,7 +409,7 @@ size_t mliis_conv2d_workspace_floats(int Nimg, int H, int W, int Cred, int Nout,
 int mliis_conv2d_fwd(const float* x, int ldx, const float* x_scale, const float* wt, const float* bias,
                      const float* border_bias, float* y, int ldy, int Nimg, int H, int W, int Cin_total, int ci_begin, int Cin, int Cout,
                      int ksize, int dil, int accumulate, float* stats_part, int stats_swish, int* stats_nblk, float* ws,
-                     size_t ws_floats, int precision, hipStream_t stream) {
+                     size_t ws_floats, int precision, float fp8_act_scale, const float* fp8_w_amax, hipStream_t stream) {
   int rc = conv_check("conv2d_fwd", Nimg, H, W, Cin, Cout, ksize, dil);
   if (rc) return rc;
   if ((rc = prec_check("conv2d_fwd", precision))) return rc;
@@ -408,20 +425,24 @@ int mliis_conv2d_fwd(const float* x, int ldx, const float* x_scale, const float*
                 "conv2d_fwd: input-channel window out of range");
   MLIIS_REQUIRE(border_bias == nullptr || (ksize == 3 && dil == 1 && H >= 2 && W >= 2 && aligned16(border_bias)), MLIIS_ERR_ARG,
                 "conv2d_fwd: border_bias needs a 3x3 dilation-1 conv on a map of at least 2x2");
+  // fp8 operands are for the 1x1 convs (BASELINE configs[4]: "fp8 MFMA on 1x1 pointwise convs"); a 3x3 call in that mode takes bf16
+  if (precision == MLIIS_PREC_FP8 && ksize != 1) precision = MLIIS_PREC_BF16;
+  MLIIS_REQUIRE(precision != MLIIS_PREC_FP8 || (fp8_act_scale > 0.0f && fp8_w_amax != nullptr), MLIIS_ERR_ARG,
+                "conv2d_fwd: fp8 operands need a positive activation scale and the weight tensor's amax (mliis_transpose_weights)");
   ConvGemmParams p{x, ldx, Nimg, H, W, Cin, ksize * ksize, dil, +1, wt + ci_begin, (long long)Cin_total * Cout, Cin_total, Cout, y, ldy,
-                   bias, accumulate, nullptr, g.chunks_per_split, nullptr, 0, x_scale, border_bias};
+                   bias, accumulate, nullptr, g.chunks_per_split, nullptr, 0, x_scale, border_bias, fp8_act_scale, fp8_w_amax};
   MLIIS_REQUIRE(aligned16(x_scale) && (x_scale == nullptr || ksize == 1), MLIIS_ERR_ARG,
                 "conv2d_fwd: x_scale must be 16-byte aligned and is only supported for 1x1 convs");
   if (stats_nblk) *stats_nblk = 0;
   {  // short-K 1x1 convs (the MBConv expand convs): barrier-free streaming kernel
     StreamPlan sp;
-    // (also under bf16 matrix-core operands: these launches are memory-bound, fp32 operands cost nothing there and are more accurate)
+    // (the instance follows the call's operand precision: one rounding rule for every matrix-core conv of a reduced-precision step)
     if (ksize == 1 && x_scale == nullptr && border_bias == nullptr && !accumulate && M * ldx * 4 < (1LL << 31) &&
         M * ldy * 4 < (1LL << 31) && stream_plan(M, Cin, Cout, num_cus(), &sp)) {
       MLIIS_REQUIRE(stats_part == nullptr || stats_nblk, MLIIS_ERR_ARG, "conv2d_fwd: fused statistics need a stats_nblk output");
       p.stats_part = stats_part;
       p.stats_swish = stats_swish;
-      if (launch_stream(sp, p, stream)) {
+      if (launch_stream(sp, p, stream, precision)) {
         MLIIS_CHECK_LAUNCH("conv2d_fwd_stream");
         if (stats_part != nullptr) *stats_nblk = sp.gx;
         return MLIIS_OK;
@@ -480,12 +501,13 @@ int mliis_conv2d_bwd_data(const float* dy, int lddy, const float* w, float* dx, 
   MLIIS_REQUIRE(M * lddy * 4 < (1LL << 31) && (long long)ksize * ksize * Cin_total * Cout * 4 < (1LL << 31), MLIIS_ERR_UNSUPPORTED,
                 "conv2d_bwd_data: operand larger than 2 GiB (32-bit buffer offsets)");
   GemmPlan g = plan_gemm(M, Cin_out, Cout, ksize * ksize, num_cus(), ws != nullptr);
+  if (precision == MLIIS_PREC_FP8) precision = MLIIS_PREC_BF16;   // fp8 mode: forward 1x1 convs in e4m3, the backward passes in bf16
   ConvGemmParams p{dy, lddy, Nimg, H, W, Cout, ksize * ksize, dil, -1, w + (long long)ci_begin * Cout, (long long)Cin_total * Cout,
-                   Cout, Cin_out, dx, lddx, nullptr, accumulate, nullptr, g.chunks_per_split, nullptr, 0, nullptr, nullptr};
+                   Cout, Cin_out, dx, lddx, nullptr, accumulate, nullptr, g.chunks_per_split, nullptr, 0, nullptr, nullptr, 1.0f, nullptr};
   {  // short-K 1x1 convs (backward-data of the MBConv project convs): barrier-free streaming kernel
     StreamPlan sp;
     if (ksize == 1 && !accumulate && M * lddx * 4 < (1LL << 31) && stream_plan(M, Cout, Cin_out, num_cus(), &sp) &&
-        launch_stream(sp, p, stream)) {
+        launch_stream(sp, p, stream, precision)) {
       MLIIS_CHECK_LAUNCH("conv2d_bwd_data_stream");
       return MLIIS_OK;
     }
@@ -510,9 +532,14 @@ int mliis_conv2d_bwd_data(const float* dy, int lddy, const float* w, float* dx, 
 }
 
 // desc: device int32 [ndesc][4] = {offset (floats), taps, Cin, Cout}; src/dst: arenas with identical layout.
-int mliis_transpose_weights(const float* src, float* dst, const int* desc, int ndesc, hipStream_t stream) {
+int mliis_transpose_weights(const float* src, float* dst, const int* desc, int ndesc, float* amax, hipStream_t stream) {
   MLIIS_REQUIRE(src && dst && desc && ndesc > 0, MLIIS_ERR_ARG, "transpose_weights: bad arguments");
-  hipLaunchKernelGGL(transpose_weights_k, dim3(224, ndesc), dim3(256), 0, stream, src, dst, desc);   // (the largest tensor has ~2000 tiles)
+  if (amax != nullptr) {   // (a memset node when captured into a graph)
+    hipError_t e = hipMemsetAsync(amax, 0, (size_t)ndesc * sizeof(float), stream);
+    MLIIS_REQUIRE(e == hipSuccess, MLIIS_ERR_LAUNCH, "transpose_weights: memset failed: %s", hipGetErrorString(e));
+  }
+  hipLaunchKernelGGL(transpose_weights_k, dim3(224, ndesc), dim3(256), 0, stream, src, dst, desc,
+                     reinterpret_cast<unsigned*>(amax));   // (the largest tensor has ~2000 tiles)
   MLIIS_CHECK_LAUNCH("transpose_weights");
   return MLIIS_OK;
 }

@@ -36,7 +36,27 @@ struct ConvGemmParams {
   const float* border_bias;  // non-null => [Nimg][9][Nout] added per output pixel by its border class 3*rowclass + colclass
                              //             (0 = first, 1 = interior, 2 = last): the contribution of spatially CONSTANT input
                              //             channels of a 3x3 SAME conv (the RSD pooled branch) without convolving them
+  // fp8 (OCP e4m3) operands, PREC == 2 only: A is multiplied by a_qscale and B by 2^floor(log2(224 / *b_amax)) before the conversion
+  // (saturating at +-448); the accumulators are divided by the product of the two scales before the epilogue.
+  float a_qscale;
+  const float* b_amax;       // device scalar: max |B| of the weight tensor (mliis_transpose_weights)
 };
+
+// operand precision of an instance: 0 = fp32 (v_mfma_f32_16x16x4_f32), 1 = bf16 (v_mfma_f32_16x16x32_bf16), 2 = fp8 e4m3
+// (v_mfma_f32_16x16x32_fp8_fp8); operands are converted in registers from the fp32 tensors, accumulation is fp32
+constexpr float kFp8Max = 448.0f;
+__device__ __forceinline__ float fp8_weight_scale(const float* amax_ptr) {
+  const float amax = amax_ptr != nullptr ? *amax_ptr : 0.0f;
+  return (amax > 0.0f && amax < 3.0e38f) ? exp2f(floorf(log2f(224.0f / amax))) : 1.0f;
+}
+__device__ __forceinline__ long pack_fp8x8(float4 a, float4 b, float s) {
+  auto q = [s](float v) { return fminf(fmaxf(v * s, -kFp8Max), kFp8Max); };
+  int lo = __builtin_amdgcn_cvt_pk_fp8_f32(q(a.x), q(a.y), 0, false);
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(q(a.z), q(a.w), lo, true);
+  int hi = __builtin_amdgcn_cvt_pk_fp8_f32(q(b.x), q(b.y), 0, false);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(q(b.z), q(b.w), hi, true);
+  return (long)(((unsigned long)(unsigned)hi << 32) | (unsigned long)(unsigned)lo);
+}
 
 // ------------------------------------------------------------------------------------------------ forward / backward-data
 // Built so that the matrix pipe is not starved:
@@ -75,7 +95,7 @@ struct GemmSm {
 // pdst == nullptr: finished tile -- bias / border bias / accumulate / fused BN statistics, staged row stores into p.Cmat.
 // pdst != nullptr: raw partial tile, element (row r, column c) of the tile to pdst[r * pstride + c] (split-K slabs [z][M][Nout]:
 // pstride = Nout; stream-K segment slabs [64][BN]: pstride = BN); a fold kernel finishes those tiles.
-template <int TM, int NT, int PF, bool SC, bool NARROW, bool BF>
+template <int TM, int NT, int PF, bool SC, bool NARROW, int PREC>
 __device__ __forceinline__ void conv_gemm_tile(const ConvGemmParams& p, float* __restrict__ sm, unsigned bx, int by, int it0, int it1,
                                                float* __restrict__ pdst, int pstride) {
   constexpr int BM = 64 * TM, BN = 16 * NT, BK = 32;
@@ -208,6 +228,7 @@ __device__ __forceinline__ void conv_gemm_tile(const ConvGemmParams& p, float* _
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const float b_qscale = PREC == 2 ? fp8_weight_scale(p.b_amax) : 1.0f;
 
   // ---- software pipeline: chunk j is computed from LDS buffer (j - it0) & 1 while chunk j+1 waits in registers (loaded one
   // iteration earlier when PF == 2) and the loads of chunk j+PF are in flight; one barrier per chunk.
@@ -248,7 +269,20 @@ __device__ __forceinline__ void conv_gemm_tile(const ConvGemmParams& p, float* _
         }
       }
     };
-    if constexpr (BF) {
+    if constexpr (PREC == 2) {
+      // fp8 (e4m3) operands: as the bf16 form below with 8 fp8 values per lane and operand (v_cvt_pk_fp8_f32 after scaling)
+      read_frags(0);
+      read_frags(1);
+      long a8[TM], b8[NT];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a8[i] = pack_fp8x8(av[0][i], av[1][i], p.a_qscale);
+#pragma unroll
+      for (int jn = 0; jn < NT; ++jn) b8[jn] = pack_fp8x8(bv[0][jn], bv[1][jn], b_qscale);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int jn = 0; jn < NT; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a8[i], b8[jn], acc[i][jn], 0, 0, 0);
+    } else if constexpr (PREC == 1) {
       // bf16 operands, fp32 accumulation: ONE v_mfma_f32_16x16x32_bf16 per output tile and chunk.  Lane group g feeds the k values
       // {4g..4g+3} of both 16-wide halves of the chunk -- the same for A and B, so the fp32 fragment layout in LDS is used as it is
       // and the conversion happens in registers (v_cvt_pk_bf16_f32, round to nearest even).
@@ -293,6 +327,13 @@ __device__ __forceinline__ void conv_gemm_tile(const ConvGemmParams& p, float* _
   if (it + 1 < it1) step(U1{}, it + 1);
   if (it + 2 < it1) step(U0{}, it + 2);
 
+  if constexpr (PREC == 2) {   // undo the operand scales
+    const float inv = 1.0f / (p.a_qscale * b_qscale);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[i][j] *= inv;
+  }
   // ---- epilogue: C/D layout of 16x16x4: col = lane & 15, row = 4 * (lane >> 4) + reg
   if (split) {
 #pragma unroll
@@ -398,7 +439,7 @@ __device__ __forceinline__ void conv_gemm_tile(const ConvGemmParams& p, float* _
 }
 
 // grid = (row tiles, column tiles, K splits).  SPLIT: raw partial tiles [z][M][Nout], the fold kernel finishes them.
-template <int TM, int NT, int PF, bool SC, bool SPLIT, bool NARROW, bool BF>
+template <int TM, int NT, int PF, bool SC, bool SPLIT, bool NARROW, int PREC>
 __global__ __launch_bounds__(256, 2) void conv_gemm_nk_k(ConvGemmParams p) {
   __shared__ __attribute__((aligned(16))) float sm[GemmSm<TM, NT>::SM_FLOATS + 4];
   const int nchunks_total = (p.ntaps * p.C + 31) / 32;
@@ -411,7 +452,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_nk_k(ConvGemmParams p) {
     const long long M = (long long)p.Nimg * p.H * p.W;
     pdst = p.partial + ((long long)blockIdx.z * M + (long long)bx * (64 * TM)) * p.Nout + blockIdx.y * (16 * NT);
   }
-  conv_gemm_tile<TM, NT, PF, SC, NARROW, BF>(p, sm, bx, blockIdx.y, it0, it1, pdst, p.Nout);
+  conv_gemm_tile<TM, NT, PF, SC, NARROW, PREC>(p, sm, bx, blockIdx.y, it0, it1, pdst, p.Nout);
 }
 
 // ------------------------------------------------------------------------------------------------ data-parallel + stream-K remainder
@@ -433,14 +474,14 @@ struct SkPlan {
   float* slab;   // [rem][smax][64][BN]
 };
 
-template <int NT, int PF, bool SC, bool BF>
+template <int NT, int PF, bool SC, int PREC>
 __global__ __launch_bounds__(256, 2) void conv_gemm_sk_k(ConvGemmParams p, SkPlan k) {
   __shared__ __attribute__((aligned(16))) float sm[GemmSm<1, NT>::SM_FLOATS + 4];
   constexpr int BN = 16 * NT;
   const int w = blockIdx.x;
   if (w < k.full) {   // tile index tau -> (row tile tau / gy, column tile tau % gy): the column tiles of a row tile are neighbours
     const unsigned tau = xcd_remap(w, k.full);
-    conv_gemm_tile<1, NT, PF, SC, false, BF>(p, sm, tau / k.gy, tau % k.gy, 0, k.nchunks, nullptr, 0);
+    conv_gemm_tile<1, NT, PF, SC, false, PREC>(p, sm, tau / k.gy, tau % k.gy, 0, k.nchunks, nullptr, 0);
     return;
   }
   const int part = w - k.full;
@@ -456,7 +497,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_sk_k(ConvGemmParams p, SkPla
     const int first = (rt * k.nchunks) / k.ipp;          // first part that touches this tile -> slot 0
     const unsigned tau = k.full + rt;
     float* dst = k.slab + ((long long)rt * k.smax + (part - first)) * (64 * BN);
-    conv_gemm_tile<1, NT, PF, SC, false, BF>(p, sm, tau / k.gy, tau % k.gy, c0, c1, dst, BN);
+    conv_gemm_tile<1, NT, PF, SC, false, PREC>(p, sm, tau / k.gy, tau % k.gy, c0, c1, dst, BN);
     lo += c1 - c0;
     __syncthreads();   // the next segment reuses the LDS buffers
   }
@@ -539,7 +580,7 @@ __global__ __launch_bounds__(1024) void sk_fixup_k(ConvGemmParams p, SkPlan k) {
 // groups of A straight from memory in MFMA operand layout (lane (row, g) loads k = 16*kg + 4g..4g+3 as one 16-byte word), multiplies,
 // adds the bias, stores its accumulators and accumulates the batch-norm statistics; the next row group is in flight meanwhile.
 // One barrier at the very end folds the four waves' statistics.  grid = (row-group blocks, column tiles).
-template <int KC, int NT>
+template <int KC, int NT, int PREC>
 __global__ __launch_bounds__(256) void conv1x1_stream_k(ConvGemmParams p, int row_groups) {
   __shared__ float red[4][2][16 * NT];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -557,6 +598,23 @@ __global__ __launch_bounds__(256) void conv1x1_stream_k(ConvGemmParams p, int ro
       const int n = n0 + j * 16 + l15, k = kg * 16 + g * 4;
       bv[kg][j] = buf_ld4(rB, (n < p.Nout && k < p.C) ? (unsigned)((n * p.ldb + k) * 4) : kOob);
     }
+  // reduced-precision operands (PREC 1 = bf16, 2 = fp8 e4m3): two 16-wide K groups make one 32-deep MFMA -- lane group g supplies
+  // k = 16 kg + 4g..4g+3 of both groups, for A and B alike (the K order inside an MFMA is free as long as both operands agree)
+  constexpr int KC2 = (KC + 1) / 2;
+  const float b_qscale = PREC == 2 ? fp8_weight_scale(p.b_amax) : 1.0f;
+  const float out_scale = PREC == 2 ? 1.0f / (p.a_qscale * b_qscale) : 1.0f;
+  bf16x8 bq16[PREC == 1 ? KC2 : 1][PREC == 1 ? NT : 1];
+  long bq8[PREC == 2 ? KC2 : 1][PREC == 2 ? NT : 1];
+  if constexpr (PREC != 0) {
+#pragma unroll
+    for (int k2 = 0; k2 < KC2; ++k2)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const float4 lo = bv[2 * k2][j], hi = (2 * k2 + 1 < KC) ? bv[(2 * k2 + 1 < KC) ? 2 * k2 + 1 : 0][j] : f4zero();
+        if constexpr (PREC == 1) bq16[k2][j] = pack_bf16x8(lo, hi);
+        else bq8[k2][j] = pack_fp8x8(lo, hi, b_qscale);
+      }
+  }
   float bj[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
@@ -584,17 +642,33 @@ __global__ __launch_bounds__(256) void conv1x1_stream_k(ConvGemmParams p, int ro
     f32x4 acc[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if constexpr (PREC == 0) {
 #pragma unroll
-    for (int kg = 0; kg < KC; ++kg)
+      for (int kg = 0; kg < KC; ++kg)
 #pragma unroll
-      for (int sI = 0; sI < 4; ++sI) {
-        const float a = sI == 0 ? a_cur[kg].x : sI == 1 ? a_cur[kg].y : sI == 2 ? a_cur[kg].z : a_cur[kg].w;
+        for (int sI = 0; sI < 4; ++sI) {
+          const float a = sI == 0 ? a_cur[kg].x : sI == 1 ? a_cur[kg].y : sI == 2 ? a_cur[kg].z : a_cur[kg].w;
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          const float b = sI == 0 ? bv[kg][j].x : sI == 1 ? bv[kg][j].y : sI == 2 ? bv[kg][j].z : bv[kg][j].w;
-          acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[j], 0, 0, 0);
+          for (int j = 0; j < NT; ++j) {
+            const float b = sI == 0 ? bv[kg][j].x : sI == 1 ? bv[kg][j].y : sI == 2 ? bv[kg][j].z : bv[kg][j].w;
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[j], 0, 0, 0);
+          }
+        }
+    } else {
+#pragma unroll
+      for (int k2 = 0; k2 < KC2; ++k2) {
+        const float4 lo = a_cur[2 * k2], hi = (2 * k2 + 1 < KC) ? a_cur[(2 * k2 + 1 < KC) ? 2 * k2 + 1 : 0] : f4zero();
+        if constexpr (PREC == 1) {
+          const bf16x8 a8 = pack_bf16x8(lo, hi);
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, bq16[k2][j], acc[j], 0, 0, 0);
+        } else {
+          const long a8 = pack_fp8x8(lo, hi, p.a_qscale);
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a8, bq8[k2][j], acc[j], 0, 0, 0);
         }
       }
+    }
     // C/D layout: column l15 of tile j, rows 4 g + r
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -603,7 +677,7 @@ __global__ __launch_bounds__(256) void conv1x1_stream_k(ConvGemmParams p, int ro
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
           const int n = n0 + j * 16 + l15;
-          const float v = acc[j][r] + bj[j];
+          const float v = (PREC == 2 ? acc[j][r] * out_scale : acc[j][r]) + bj[j];
           if (n < p.Nout) p.Cmat[(long long)m * p.ldc + n] = v;
           if (stats) {
             const float u = p.stats_swish ? swish_f(v) : v;
@@ -873,12 +947,12 @@ struct GemmPlan {
 // 3x3 convs over fewer than 32 channels: a 32-wide K chunk spans several taps (conv_gemm_nk_k<..., NARROW = true>)
 static inline bool gemm_narrow(int ntaps, int C) { return ntaps > 1 && C < 32; }
 
-template <bool BF>
+template <int PREC>
 static void launch_gemm_sk_t(const GemmPlan& g, const ConvGemmParams& p, float* slab, hipStream_t stream) {
   const SkPlan k{g.sk_full, g.sk_rem, g.sk_parts, g.sk_ipp, g.sk_nchunks, g.sk_smax, g.gy, slab};
   dim3 grid(g.sk_full + g.sk_parts), block(256);
 #define SKL(NT_)                                                                                       \
-  hipLaunchKernelGGL((conv_gemm_sk_k<NT_, 2, false, BF>), grid, block, 0, stream, p, k);              \
+  hipLaunchKernelGGL((conv_gemm_sk_k<NT_, 2, false, PREC>), grid, block, 0, stream, p, k);            \
   hipLaunchKernelGGL((sk_fixup_k<NT_>), dim3(g.sk_rem), dim3(1024), 0, stream, p, k);                  \
   break;
   switch (g.nt) {
@@ -894,14 +968,14 @@ static void launch_gemm_sk_t(const GemmPlan& g, const ConvGemmParams& p, float* 
 #undef SKL
 }
 
-template <bool BF>
+template <int PREC>
 static void launch_gemm_t(const GemmPlan& g, const ConvGemmParams& p, hipStream_t stream) {
   dim3 grid(g.gx, g.gy, g.gz), block(256);
   const bool sp = p.partial != nullptr, sc = p.a_scale != nullptr, narrow = gemm_narrow(p.ntaps, p.C);
-#define NK(TM_, NT_, SC_, SP_) hipLaunchKernelGGL((conv_gemm_nk_k<TM_, NT_, (TM_ == 1 ? 2 : 1), SC_, SP_, false, BF>), grid, block, 0, stream, p)
+#define NK(TM_, NT_, SC_, SP_) hipLaunchKernelGGL((conv_gemm_nk_k<TM_, NT_, (TM_ == 1 ? 2 : 1), SC_, SP_, false, PREC>), grid, block, 0, stream, p)
 #define L(TM_, NT_)                                  \
   if (TM_ == 1 && narrow) {                          \
-    hipLaunchKernelGGL((conv_gemm_nk_k<1, NT_, 2, false, false, true, BF>), grid, block, 0, stream, p); \
+    hipLaunchKernelGGL((conv_gemm_nk_k<1, NT_, 2, false, false, true, PREC>), grid, block, 0, stream, p); \
   } else if (TM_ == 1 && sp) {                       \
     if (sc) NK(1, NT_, true, true);                  \
     else NK(1, NT_, false, true);                    \
@@ -963,6 +1037,8 @@ static void launch_filter_t(const FilterPlan& f, const FilterGradParams& p, hipS
 // operand precision of the matrix cores: the fp32 instances live in conv_gemm.hip, the bf16 ones in conv_gemm_bf16.hip
 void launch_gemm_bf16(const GemmPlan& g, const ConvGemmParams& p, hipStream_t stream);
 void launch_gemm_sk_bf16(const GemmPlan& g, const ConvGemmParams& p, float* slab, hipStream_t stream);
+void launch_gemm_fp8(const GemmPlan& g, const ConvGemmParams& p, hipStream_t stream);            // conv_gemm_fp8.hip
+bool launch_stream_lowp(int precision, int kc, int nt, dim3 grid, const ConvGemmParams& p, int row_groups, hipStream_t stream);   // conv_gemm_fp8.hip
 void launch_filter_bf16(const FilterPlan& f, const FilterGradParams& p, hipStream_t stream);
 
 }  // namespace mliis

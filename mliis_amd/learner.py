@@ -258,6 +258,13 @@ class Learner:
             if p.kind == "conv" and p.executed and "/se/" not in p.name and p.name not in (f"{fe}/stem/conv2d/kernel", "decode/final_layer_weights/kernel"):
                 desc.append([A.t_off[p.name], p.shape[0] * p.shape[1], p.shape[2], p.shape[3]])
         self.wt_desc = torch.tensor(desc, dtype=torch.int32, device=self.device)
+        # fp8 mode: max |w| of every dense-conv weight, refreshed by the same launch that refreshes the shadow copies
+        self.w_amax = torch.zeros(len(desc), dtype=torch.float32, device=self.device) if matmul_precision == "fp8" else None
+        self._amax_of = {}
+        if self.w_amax is not None:
+            names = [p.name for p in A.trainable if p.kind == "conv" and p.executed and "/se/" not in p.name and
+                     p.name not in (f"{fe}/stem/conv2d/kernel", "decode/final_layer_weights/kernel")]
+            self._amax_of = {n: self.w_amax[i:i + 1] for i, n in enumerate(names)}
         self.wt = {p.name: self.theta_t[A.t_off[p.name]:A.t_off[p.name] + p.size] for p in A.trainable}
         self.lr_dev = torch.tensor([self.lr], dtype=torch.float32, device=self.device)
         self._lr_dev_val = float(self.lr)
@@ -472,15 +479,16 @@ class Learner:
             torch.rsqrt(mv[prefix + "/moving_variance"] + spec.BN_EPS, out=st[1])
             return ops.bn_apply(xin, st[0], st[1], w[prefix + "/gamma"], w[prefix + "/beta"], pre, post, img_scale, res, out=y)
 
-        ops.transpose_weights(A.theta, self.theta_t, self.wt_desc)
+        ops.transpose_weights(A.theta, self.theta_t, self.wt_desc, self.w_amax)
 
         def conv(xin, wname, bname, dil, out, swish_stats, x_scale=None, border_bias=None):
             """dense conv; in training the epilogue also emits the following BN's statistics (returns their block count)."""
+            am = self._amax_of.get(wname)
             if training:
                 return self._conv_fwd(xin, w[wname], w[bname] if bname else None, dil, out=out, ws=ws, stats_part=P.stats_part,
-                                      stats_swish=swish_stats, wt=self.wt[wname], x_scale=x_scale, border_bias=border_bias)[1]
+                                      stats_swish=swish_stats, wt=self.wt[wname], x_scale=x_scale, border_bias=border_bias, fp8_w_amax=am)[1]
             self._conv_fwd(xin, w[wname], w[bname] if bname else None, dil, out=out, ws=ws, wt=self.wt[wname], x_scale=x_scale,
-                           border_bias=border_bias)
+                           border_bias=border_bias, fp8_w_amax=am)
             return 0
 
         ops.stem_conv_fwd(x, w[self.n_stem[0]], idx, out=P.z_stem)
@@ -572,15 +580,16 @@ class Learner:
         (k0, c0), (k1, c1), (k2, c2), (ko, co) = self.n_aspp
         m = T["masks"] if training else [None] * 4
         cat = T["cat"]
-        self._conv_fwd(x, w[k0], w[c0], 1, out=T["z0"], ws=ws, wt=self.wt[k0])
+        self._conv_fwd(x, w[k0], w[c0], 1, out=T["z0"], ws=ws, wt=self.wt[k0], fp8_w_amax=self._amax_of.get(k0))
         ops.swish_mask_fwd(T["z0"], m[0], out=cat[..., 2 * d:])
         self._conv_fwd(x, w[k1], w[c1], spec.ASPP_DILATION, out=T["z1"], ws=ws, wt=self.wt[k1])
         ops.swish_mask_fwd(T["z1"], m[1], out=cat[..., d:2 * d])
         ops.colsum(x, None, nseg=N, scale=1.0 / hw, out=T["pool"], ws=ws)
-        self._conv_fwd(T["pool"].view(N, 1, 1, -1), w[k2], w[c2], 1, out=T["z2"].view(N, 1, 1, d), ws=ws, wt=self.wt[k2])
+        self._conv_fwd(T["pool"].view(N, 1, 1, -1), w[k2], w[c2], 1, out=T["z2"].view(N, 1, 1, d), ws=ws, wt=self.wt[k2],
+                       fp8_w_amax=self._amax_of.get(k2))
         ops.swish_mask_fwd(T["z2"], m[2], out=T["b2"], pre_mask=True)
         ops.chan_affine(None, A=T["b2"], out=cat[..., :d])      # bilinear resize of the 1x1 pooled map = broadcast
-        self._conv_fwd(cat, w[ko], w[co], 1, out=T["zo"], ws=ws, wt=self.wt[ko])
+        self._conv_fwd(cat, w[ko], w[co], 1, out=T["zo"], ws=ws, wt=self.wt[ko], fp8_w_amax=self._amax_of.get(ko))
         ops.swish_mask_fwd(T["zo"], m[3], out=T["out"])
         T["trained"] = training
         return T["out"]

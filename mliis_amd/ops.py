@@ -62,7 +62,8 @@ def profile_resolve(records):
     return records
 
 
-PRECISIONS = {"fp32": 0, "bf16": 1}   # MLIIS_PREC_* of include/mliis_hip.h: operand precision of the matrix cores, per call
+PRECISIONS = {"fp32": 0, "bf16": 1, "fp8": 2}   # MLIIS_PREC_* of include/mliis_hip.h: operand precision of the matrix cores, per call
+FP8_ACT_SCALE = 16.0   # default power-of-two multiplier of activations before the e4m3 conversion (saturating at 448 / 16 = 28)
 
 
 def _prec(precision) -> int:
@@ -234,9 +235,10 @@ def mbconv_dw_bwd_small(da2, gate, chan_add, z1, bn1, w, z0, bn0, dgamma1, dbeta
 
 
 # ------------------------------------------------------------------------------------------------ dense conv
-def transpose_weights(src, dst, desc):
-    """dst <- HWOI copies of the dense-conv weights listed in desc (device int32 [n,4] = offset, taps, Cin, Cout)."""
-    lib.call("mliis_transpose_weights", _ptr(src), _ptr(dst), _ptr(desc), int(desc.shape[0]), _stream())
+def transpose_weights(src, dst, desc, amax=None):
+    """dst <- HWOI copies of the dense-conv weights listed in desc (device int32 [n,4] = offset, taps, Cin, Cout); amax (optional,
+    float [n]): also max |w| per tensor -- the fp8 operand scale."""
+    lib.call("mliis_transpose_weights", _ptr(src), _ptr(dst), _ptr(desc), int(desc.shape[0]), _ptr(amax), _stream())
 
 
 def hwoi(w):
@@ -248,7 +250,8 @@ def hwoi(w):
 
 
 def conv2d_fwd(x, w, bias=None, dil=1, out=None, accumulate=False, ws: Optional[Workspace] = None, nhw=None, stats_part=None,
-               stats_swish=False, wt=None, x_scale=None, border_bias=None, ci_begin=0, precision="fp32"):
+               stats_swish=False, wt=None, x_scale=None, border_bias=None, ci_begin=0, precision="fp32", fp8_act_scale=FP8_ACT_SCALE,
+               fp8_w_amax=None):
     """x: [N,H,W,>=Cin] view (channel slice allowed); w: [k,k,Cin,Cout]; wt: its K-contiguous copy (built here when not given --
     the kernels only read wt).  With stats_part (a float buffer) the epilogue also emits the next batch norm's stage-1 statistics
     and the function returns (out, nblk); nblk == 0 means they were not produced."""
@@ -269,12 +272,14 @@ def conv2d_fwd(x, w, bias=None, dil=1, out=None, accumulate=False, ws: Optional[
                     flops=2.0 * N * H * W * k * k * Cin * Cout, shape=(N, H, W, Cin, Cout, k, dil))
     nblk = C.c_int(0)
     prec = _prec(precision)
+    if prec == 2 and k == 1 and fp8_w_amax is None:   # stand-alone call: take the tensor's amax here (the learner gets it from the
+        fp8_w_amax = w.abs().max().reshape(1)          # per-step weight-shadow launch)
     if stats_part is not None and stats_part.numel() < (-(-N * H * W // 64)) * 2 * Cout:
         raise MliisError("conv2d_fwd: stats_part too small")
     _timed("conv2d_fwd", meta, lambda: lib.call("mliis_conv2d_fwd", _ptr(x), ldx, _ptr(x_scale), _ptr(wt), _ptr(bias), _ptr(border_bias), _ptr(out), ldy, N, H, W,
                                                 Cin_total, ci_begin, Cin, Cout, k,
                                                 dil, int(accumulate), _ptr(stats_part), int(stats_swish), C.byref(nblk), _ptr(buf),
-                                                buf.numel(), prec, _stream()))
+                                                buf.numel(), prec, float(fp8_act_scale), _ptr(fp8_w_amax), _stream()))
     if stats_part is not None:
         return out, nblk.value
     return out

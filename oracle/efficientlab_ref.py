@@ -162,6 +162,59 @@ def swish(x):
     return x * torch.sigmoid(x)
 
 
+# ---- reduced-precision matrix-core operands (BASELINE configs 4-5), emulated: the product converts the fp32 operands of every dense
+#      conv that runs on the matrix cores (MBConv 1x1 expand / project, RSD and ASPP convs) in registers -- bf16: round to nearest
+#      even; fp8 (forward 1x1 convs only): OCP e4m3 after a power-of-two scale, saturating at +-448 -- and accumulates in fp32.  The
+#      backward passes use bf16-rounded operands in both modes: dX = convT(round(dY), round(W)), dW = corr(round(X), round(dY)).
+FP8_ACT_SCALE = 16.0
+
+
+def round_bf16(t):
+    return t.to(torch.float32).to(torch.bfloat16).to(t.dtype)
+
+
+def fp8_weight_scale(w):
+    amax = float(w.detach().abs().max())
+    return 2.0 ** math.floor(math.log2(224.0 / amax)) if amax > 0 else 1.0
+
+
+def round_fp8(t, scale):
+    q = (t.to(torch.float32) * scale).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).to(torch.float32) / scale
+    return q.to(t.dtype)
+
+
+class _RoundedConv(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, stride, dilation, mode):
+        k = w.shape[0]
+        if mode == "fp8" and k == 1:
+            xr, wr = round_fp8(x, FP8_ACT_SCALE), round_fp8(w, fp8_weight_scale(w))
+        else:
+            xr, wr = round_bf16(x), round_bf16(w)
+        ctx.save_for_backward(round_bf16(x), round_bf16(w))
+        ctx.geom = (stride, dilation)
+        return conv2d_same(xr, wr, stride, dilation)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xb, wb = ctx.saved_tensors
+        stride, dilation = ctx.geom
+        dyr = round_bf16(dy)
+        with torch.enable_grad():
+            x_, w_ = xb.detach().requires_grad_(True), wb.detach().requires_grad_(True)
+            y = conv2d_same(x_, w_, stride, dilation)
+            gx, gw = torch.autograd.grad(y, [x_, w_], dyr)
+        return gx, gw, None, None, None
+
+
+def mm_conv(x, w_hwio, stride=1, dilation=1, bias=None, round_ops=None):
+    """A dense conv that the product runs on the matrix cores: exact, or with emulated reduced-precision operands."""
+    if round_ops is None:
+        return conv2d_same(x, w_hwio, stride, dilation, bias=bias)
+    y = _RoundedConv.apply(x, w_hwio, stride, dilation, round_ops)
+    return y if bias is None else y + bias[None, :, None, None]
+
+
 def batch_norm(x, gamma, beta, moving, training, new_moving: Optional[dict], key, fused):
     """x: NCHW.  training: batch stats (biased var for normalisation).  Records the EMA target in new_moving."""
     if training:
@@ -187,7 +240,7 @@ def resize_bilinear_ac(x, size):
 
 # -------------------------------------------------------------------------------------------------- forward
 def forward(a, params, bn, x_nhwc, training=True, dc_scales: Optional[Dict[int, torch.Tensor]] = None,
-            dropout_mask: Optional[torch.Tensor] = None, taps: Optional[dict] = None, aspp_masks=None):
+            dropout_mask: Optional[torch.Tensor] = None, taps: Optional[dict] = None, aspp_masks=None, round_ops=None):
     """x_nhwc: [N,H,W,3] in 0..255.  dc_scales[block_idx]: [N] tensor of 0 or 1/keep (training only; None -> no
     drop-connect).  dropout_mask: [N,h,w,C] of 0 or 1/(1-rate) applied before the final 1x1.  Returns
     (logits NHWC, new_moving dict).  `taps` (optional dict) receives named intermediates in NHWC."""
@@ -216,14 +269,14 @@ def forward(a, params, bn, x_nhwc, training=True, dc_scales: Optional[Dict[int, 
         cvs = [f"{s}/conv2d/kernel", f"{s}/conv2d_1/kernel"]
         inp = x
         if b["e"] != 1:
-            x = swish(BN(conv2d_same(x, P[cvs.pop(0)]), bns.pop(0)))
+            x = swish(BN(mm_conv(x, P[cvs.pop(0)], round_ops=round_ops), bns.pop(0)))
         ce = x.shape[1]
         x = swish(BN(conv2d_same(x, P[f"{s}/depthwise_conv2d/depthwise_kernel"], b["s"], groups=ce), bns.pop(0)))
         sq = x.mean(dim=(2, 3), keepdim=True)
         sq = swish(conv2d_same(sq, P[f"{s}/se/conv2d/kernel"], bias=P[f"{s}/se/conv2d/bias"]))
         sq = conv2d_same(sq, P[f"{s}/se/conv2d_1/kernel"], bias=P[f"{s}/se/conv2d_1/bias"])
         x = torch.sigmoid(sq) * x
-        x = BN(conv2d_same(x, P[cvs.pop(0)]), bns.pop(0))
+        x = BN(mm_conv(x, P[cvs.pop(0)], round_ops=round_ops), bns.pop(0))
         if b["s"] == 1 and b["i"] == b["o"]:
             if training and b["drop"] and dc_scales is not None and b["idx"] in dc_scales:
                 x = x * dc_scales[b["idx"]].to(dt)[:, None, None, None]
@@ -241,7 +294,7 @@ def forward(a, params, bn, x_nhwc, training=True, dc_scales: Optional[Dict[int, 
 
         def drop(t, m):
             return t if m is None else t * m
-        cv = lambda t, scope, d=1: conv2d_same(t, P[f"{scope}/conv2d/kernel"], 1, d, bias=P[f"{scope}/conv2d/bias"])  # noqa: E731
+        cv = lambda t, scope, d=1: mm_conv(t, P[f"{scope}/conv2d/kernel"], 1, d, bias=P[f"{scope}/conv2d/bias"], round_ops=round_ops)  # noqa: E731
         b0 = drop(swish(cv(dec, f"{s}/branch_0")), mk[0])
         b1 = drop(swish(cv(dec, f"{s}/branch_1", 6)), mk[1])
         b2 = swish(drop(cv(dec.mean(dim=(2, 3), keepdim=True), f"{s}/branch_2"), mk[2]))
@@ -256,7 +309,7 @@ def forward(a, params, bn, x_nhwc, training=True, dc_scales: Optional[Dict[int, 
 
         def branch(t, j, k, d):
             sfx = "" if j == 0 else f"_{j}"
-            t = conv2d_same(t, P[f"{s}/conv2d{sfx}/kernel"], 1, d, bias=P[f"{s}/conv2d{sfx}/bias"])
+            t = mm_conv(t, P[f"{s}/conv2d{sfx}/kernel"], 1, d, bias=P[f"{s}/conv2d{sfx}/bias"], round_ops=round_ops)
             return BN(swish(t), f"{s}/batch_normalization{sfx}", fused=True)
         b0 = branch(cat, 0, 1, 1)
         b1 = branch(cat, 1, 3, 2)
@@ -298,14 +351,14 @@ def predictions(logits):
 
 
 def inner_step(a, params, bn, x, y, lr, dc_scales=None, dropout_mask=None, label_smoothing=0.0, dice=False, l2=False,
-               weight_decay_rate=1.0, adam_state=None, aspp_masks=None):
+               weight_decay_rate=1.0, adam_state=None, aspp_masks=None, round_ops=None):
     """One `session.run(minimize_op)` (reptile.py:114-121,639-643): fwd + bwd + BN moving update + SGD apply.
     Mutates params / bn in place; returns (loss, grads dict, logits)."""
     if weight_decay_rate != 1.0:  # pre_step_op, meta_learners/variables.py:48-55
         for k in params:
             params[k] = params[k] * weight_decay_rate
     leaves = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()}
-    logits, new_moving = forward(a, leaves, bn, x, True, dc_scales, dropout_mask, aspp_masks=aspp_masks)
+    logits, new_moving = forward(a, leaves, bn, x, True, dc_scales, dropout_mask, aspp_masks=aspp_masks, round_ops=round_ops)
     loss = loss_fn(a, leaves, logits, y, label_smoothing, dice, l2)
     names = list(leaves)
     grads = torch.autograd.grad(loss, [leaves[k] for k in names], allow_unused=True)
@@ -338,7 +391,8 @@ class OracleLearner:
     meta-learner host logic (Gecko/FOMLIS, sharding, all-reduce) can be exercised without a GPU."""
 
     def __init__(self, name="efficientnet-b0", image_size=224, rsd=(2, 4), seed=0, dtype=torch.float64, lr=1e-3,
-                 l2=False, dice=False, label_smoothing=0.0, drop_connect=True, aspp=False):
+                 l2=False, dice=False, label_smoothing=0.0, drop_connect=True, aspp=False, round_ops=None):
+        self.round_ops = round_ops    # None | "bf16" | "fp8": emulated reduced-precision matrix-core operands
         self.a = arch(name, image_size, rsd, aspp)
         self.params, self.bn = init_state(self.a, seed, dtype)
         self.dtype, self.lr, self.l2, self.dice, self.ls = dtype, lr, l2, dice, label_smoothing
@@ -421,7 +475,7 @@ class OracleLearner:
             x, y = self._x[i], self._y[i]
         loss, _, _ = inner_step(self.a, self.params, self.bn, x, y, self.lr if lr is None else lr,
                                 dc_scales if self.drop_connect else None, dropout_mask, self.ls, self.dice, self.l2,
-                                weight_decay_rate, aspp_masks=aspp_masks)
+                                weight_decay_rate, aspp_masks=aspp_masks, round_ops=self.round_ops)
         return loss
 
     def export_all(self):
@@ -439,5 +493,5 @@ class OracleLearner:
 
     def predict(self, x, training=False):
         with torch.no_grad():
-            logits, _ = forward(self.a, self.params, self.bn, x, training)
+            logits, _ = forward(self.a, self.params, self.bn, x, training, round_ops=self.round_ops)
         return predictions(logits)

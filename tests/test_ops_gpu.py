@@ -813,3 +813,47 @@ def test_rng_masks_are_philox_and_advance_per_launch():
     big2 = torch.zeros(1 << 20, device=d)
     ops.rng_masks(state2, ops.MaskPlan([(big2, 0.8, 1, False)]))
     assert 0.6 < (big == big2).float().mean().item() < 0.75     # P(agree) = 0.8^2 + 0.2^2 = 0.68 for independent streams
+
+
+# ------------------------------------------------------------------------------------------------ fp8 (OCP e4m3) operands, 1x1 forward
+@pytest.mark.parametrize("H,Cin,Cout,N,gated", [(32, 24, 144, 2, False), (28, 240, 40, 2, True), (14, 672, 112, 2, True), (48, 40, 240, 2, False),
+                                                (14, 112, 672, 8, False)])
+def test_conv1x1_fp8_operands(H, Cin, Cout, N, gated):
+    """precision = MLIIS_PREC_FP8 (BASELINE configs[4]): 1x1 forward convs with e4m3 operands -- activations x 16, weights x
+    2^floor(log2(224 / max|w|)), saturated at +-448, converted in registers; fp32 accumulation, the scales divided out.  Equals the
+    float64 conv of the identically quantised operands (torch.float8_e4m3fn) to 2e-5: the streaming kernel (K <= 112), the LDS-tiled
+    kernel with the squeeze-excite gate applied on load, split-K plans; fused BN statistics ride along.  Backward calls in this mode take
+    bf16 operands."""
+    from mliis_amd import ops
+    d = dev()
+    x32 = (rnd(N, H, H, Cin, seed=70) * 1.3).float()
+    x32[0, 0, 0, 0] = 40.0                                        # beyond 448 / 16: saturates
+    w32 = rnd(1, 1, Cin, Cout, seed=71, scale=1.0 / math.sqrt(Cin)).float()
+    gate = torch.sigmoid(rnd(N, Cin, seed=72)).float() if gated else None
+    xs = x32 * gate[:, None, None, :] if gated else x32          # (the product multiplies in fp32, then converts)
+    xq = R.round_fp8(xs, R.FP8_ACT_SCALE).double()
+    wq = R.round_fp8(w32, R.fp8_weight_scale(w32)).double()
+    b = rnd(Cout, seed=73)
+    z = nhwc(R.conv2d_same(nchw(xq), wq, 1, 1, bias=b))
+    part = torch.zeros(1 << 18, device=d)
+    amax = w32.abs().max().reshape(1).to(d)
+    zg, nblk = ops.conv2d_fwd(x32.to(d), w32.to(d), f32(b, d), 1, precision="fp8", x_scale=gate.to(d) if gated else None,
+                              stats_part=part, fp8_w_amax=amax)
+    close(zg, z, 2e-4, "fp8 conv fwd")   # (the fp8 MFMA aligns the 32 products of a K block before adding: ~2^-14 relative, measured)
+    if nblk:
+        sums = part[: nblk * 2 * Cout].view(nblk, 2, Cout).double().sum(0).cpu()
+        close(sums[0], z.sum(dim=(0, 1, 2)), 2e-4, "fp8 fused sum")
+    # weights' amax comes from the weight-shadow launch in the learner
+    wt = torch.empty(Cin * Cout, device=d)
+    am2 = torch.full((1,), 5.0, device=d)
+    ops.transpose_weights(w32.to(d).view(-1), wt, torch.tensor([[0, 1, Cin, Cout]], dtype=torch.int32, device=d), am2)
+    assert am2.item() == w32.abs().max().item()
+    close(wt.view(Cout, Cin), w32.view(Cin, Cout).t().double(), 0.0, "weight shadow")
+    # backward calls given the fp8 mode take bf16 operands
+    bf = lambda t: t.to(torch.bfloat16).to(torch.float64)   # noqa: E731
+    dy32 = rnd(N, H, H, Cout, seed=74).float()
+    xb, wb = bf(xs).requires_grad_(True), bf(w32).requires_grad_(True)
+    gx, gw = torch.autograd.grad(R.conv2d_same(nchw(xb), wb, 1, 1), [xb, wb], nchw(bf(dy32)))
+    close(ops.conv2d_bwd_data(dy32.to(d), w32.to(d), 1, precision="fp8"), gx if not gated else gx, 1e-4, "fp8-mode bwd data (bf16)")
+    close(ops.conv2d_bwd_filter(x32.to(d), dy32.to(d), 1, 1, precision="fp8", x_scale=gate.to(d) if gated else None), gw, 1e-4,
+          "fp8-mode bwd filter (bf16)")
