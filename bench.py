@@ -46,7 +46,8 @@ def parse():
     ap.add_argument("--backbone", default="efficientnet-b0", choices=["efficientnet-b0", "efficientnet-b3"],
                     help="variant: EfficientNet-B3 encoder (BASELINE configs[3]); the metric's config is B0")
     ap.add_argument("--aspp", action="store_true", help="variant: ASPP decoder in front of the RSD modules (--spatial_pyramid_pooling)")
-    ap.add_argument("--augment", action="store_true", help="variant: host augmentation of every inner-loop batch (the reference's run.sh setting)")
+    ap.add_argument("--augment", action="store_true", help="variant: augmentation of every inner-loop batch (the reference's run.sh setting), pixels on the device")
+    ap.add_argument("--augment-on-host", action="store_true", help="with --augment: pixels in numpy / scipy on the host (draw-identical to the reference)")
     ap.add_argument("--augment-workers", type=int, default=-1, help="worker processes for the augmentation pixel work (0 = inline, -1 = cores - 1)")
     ap.add_argument("--overlap-wgrad", type=int, default=0, help="variant: weight-gradient kernels on a second stream inside the graph (1 | 2)")
     ap.add_argument("--concurrent-tasks", type=int, default=1,
@@ -273,7 +274,7 @@ def main():
 
 def _run(args):
     aug_pool = None
-    if args.augment and args.augment_workers != 0:   # forked workers: before anything initialises the GPU
+    if args.augment and args.augment_on_host and args.augment_workers != 0:   # forked workers: before anything initialises the GPU
         from mliis_amd.augment import AugmentPool
         aug_pool = AugmentPool(None if args.augment_workers < 0 else args.augment_workers)
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -297,7 +298,7 @@ def _run(args):
     shots = 10 if args.foml else args.shots
     L = Learner(feature_extractor_name=args.backbone, image_size=args.image_size, rsd=(2, 4), learning_rate=1e-3, optimizer="sgd", dice=False, l2=False, seed=0, device=device,
                 use_graph=not args.no_graph, max_shots=max(16, shots), spatial_pyramid_pooling=args.aspp, matmul_precision=args.precision,
-                overlap_wgrad=args.overlap_wgrad)
+                overlap_wgrad=args.overlap_wgrad, augment_batch_capacity=16 if (args.augment and not args.augment_on_host) else 0)
     lanes = [Learner(feature_extractor_name=args.backbone, image_size=args.image_size, rsd=(2, 4), learning_rate=1e-3, optimizer="sgd", dice=False,
                      l2=False, seed=k, device=device, use_graph=not args.no_graph, max_shots=max(16, shots),
                      spatial_pyramid_pooling=args.aspp, matmul_precision=args.precision) for k in range(1, args.concurrent_tasks)]
@@ -307,10 +308,12 @@ def _run(args):
         tasks.append(DeviceTask("synthetic_%d_%d" % (rank, i), torch.from_numpy(x).to(device), torch.from_numpy(y).to(device)))
     D = Dist()
     if args.foml:
-        meta = FOMLIS(L, train_shots=shots, tail_shots=5, dist=D, rng_mode="per_task", seed=0, augment=args.augment, aug_rate=0.5, aug_pool=aug_pool,
+        aug_mode = False if not args.augment else (True if args.augment_on_host else "device")
+        meta = FOMLIS(L, train_shots=shots, tail_shots=5, dist=D, rng_mode="per_task", seed=0, augment=aug_mode, aug_rate=0.5, aug_pool=aug_pool,
                       lanes=lanes)
     else:
-        meta = Gecko(L, dist=D, rng_mode="per_task", seed=0, augment=args.augment, aug_rate=0.5, aug_pool=aug_pool, lanes=lanes)
+        aug_mode = False if not args.augment else (True if args.augment_on_host else "device")
+        meta = Gecko(L, dist=D, rng_mode="per_task", seed=0, augment=aug_mode, aug_rate=0.5, aug_pool=aug_pool, lanes=lanes)
 
     def step():
         meta.train_step(tasks, num_shots=shots, inner_batch_size=args.inner_batch, inner_iters=args.inner_iters, replacement=False,
@@ -351,7 +354,7 @@ def _run(args):
                                                                  args.inner_iters,
                                                                  args.inner_batch, imgs_per_task, "FOMAML(tail 5)" if args.foml else "Reptile",
                                                                  ("" if args.precision == "fp32" else ", bf16 matrix-core operands") +
-                                                                 ((", host augmentation (aug_rate 0.5, %s)" % ("%d worker processes" % aug_pool.workers if aug_pool else "inline"))
+                                                                 ((", augmentation (aug_rate 0.5, %s)" % (("pixels on the host, %s" % ("%d worker processes" % aug_pool.workers if aug_pool else "inline")) if args.augment_on_host else "pixels on the device"))
                                                                   if args.augment else "") +
                                                                  (", %d tasks per GPU and meta-step" % args.tasks_per_gpu if args.tasks_per_gpu != 1 else "") +
                                                                  (", %d adapted concurrently" % args.concurrent_tasks if args.concurrent_tasks != 1 else "")),

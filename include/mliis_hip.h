@@ -67,6 +67,14 @@ size_t mliis_dwconv_bwd_filter_workspace_floats(int N, int H, int W, int C, int 
 int mliis_dwconv_bwd_filter(const float* x, const float* dy, float* dw, int N, int H, int W, int C, int k, int stride, float* ws,
                             size_t ws_floats, hipStream_t stream);
 
+/* ---- on-device pixel half of the inner-loop augmentation (augmenters/np_augmenters.py:9-131: random eraser, translate, flip,
+ *      Gaussian noise, exposure, rotate).  One launch = one stage of a mini-batch: sample b applies ops[b] (48-byte records {int op;
+ *      int i0..i3; float f0..f3; uint32 seed_lo, seed_hi; int src}: 0 copy, 1 erase, 2 translate, 3 flip, 4 noise, 5 exposure,
+ *      6 rotate -- parameter meaning in csrc/augment.hip) to image / mask `src` of (xin [.,H,W,3], yin [.,H,W,2]) and writes sample
+ *      out_base + b of (xout, yout).  The draws stay on the host in the reference's order; noise fields come from Philox on the device. */
+int mliis_augment_stage(const float* xin, const float* yin, float* xout, float* yout, const void* ops, int B, int H, int W, int out_base,
+                        hipStream_t stream);
+
 /* ---- masks of the stochastic ops of a training step, generated on the device inside the step's HIP graph (Philox4x32-10, counter =
  *      (element, step, job), key = seed): drop-connect  floor(keep + u) / keep  per block and image (models/efficientnet/utils.py:
  *      157-170) and dropout  (u < keep) / keep  per element (tf.layers.dropout: models/efficientlab.py:94-100,161-162,248-289).

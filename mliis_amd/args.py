@@ -102,6 +102,9 @@ _EXT = [
     ("--k-shot-test-samples", dict(type=int, default=20, help="held-out examples per task in the k-shot experiment (reference: 20)")),
     ("--skip-train-task-eval", dict(action="store_true",
                                     help="skip the evaluation pass over the meta-TRAIN tasks that the reference always runs before the test tasks")),
+    ("--augment-on-host", dict(action="store_true",
+                               help="with --augment: compute the augmented pixels in numpy / scipy on the host, draw-identical to the reference "
+                                    "(default: same draws, pixel work and noise fields on the device, csrc/augment.hip)")),
     ("--augment-workers", dict(type=int, default=-1,
                                help="worker processes for the pixel half of --augment (-1: host cores - 1, 0: inline like the reference)")),
     ("--concurrent-tasks", dict(type=int, default=1,
@@ -129,6 +132,13 @@ def _max_shots(a) -> int:
     return n
 
 
+def augment_mode(a):
+    """False | True (host pixels, --augment-on-host) | "device" -- the `augment` argument of the meta-learners."""
+    if not a.augment:
+        return False
+    return True if getattr(a, "augment_on_host", False) else "device"
+
+
 def model_kwargs(a) -> dict:
     """Keyword arguments of mliis_amd.learner.Learner from parsed flags (reference: args.py:121-160)."""
     a.model_name = a.model_name.lower()
@@ -139,7 +149,9 @@ def model_kwargs(a) -> dict:
                 dice=("dice" in a.loss_name), label_smoothing=a.label_smoothing, final_layer_dropout_rate=a.final_layer_dropout_rate,
                 spatial_pyramid_pooling=a.spatial_pyramid_pooling, skip_decoding=a.skip_decoding, seed=a.seed,
                 use_graph=not getattr(a, "no_hip_graph", False), max_shots=_max_shots(a),
-                matmul_precision=getattr(a, "matmul_precision", "fp32"))
+                matmul_precision=getattr(a, "matmul_precision", "fp32"),
+                augment_batch_capacity=(max(16, a.inner_batch, a.eval_batch, getattr(a, "batch_size_search_range_high", 0) or 0)
+                                        if augment_mode(a) == "device" else 0))
     # --disable_rsd_residual_connections is a no-op in the reference too (kwarg name mismatch)
 
 
@@ -165,7 +177,7 @@ def train_kwargs(a) -> dict:
 def evaluate_kwargs(a) -> dict:
     return dict(num_classes=a.classes, num_shots=a.shots, eval_inner_batch_size=a.eval_batch, eval_inner_iters=a.eval_iters,
                 replacement=a.replacement, weight_decay_rate=a.weight_decay, num_samples=a.eval_samples, transductive=a.transductive,
-                meta_fn=_meta_fn(a), augment=a.augment, lr=None, aug_rate=a.aug_rate,
+                meta_fn=_meta_fn(a), augment=augment_mode(a), lr=None, aug_rate=a.aug_rate,
                 eval_tasks_with_median_early_stopping_iterations=a.eval_tasks_with_median_early_stopping_iterations,
                 save_fine_tuned_checkpoints=a.save_fine_tuned_checkpoints, save_fine_tuned_checkpoints_dir=a.save_fine_tuned_checkpoints_dir)
 

@@ -133,11 +133,15 @@ class AugmentPool:
 
 class Augmenter:
     """`py` / `npr`: generator objects with the `random` / `numpy.random` call surface; default = the global modules (what the
-    reference consumes), pass `random.Random(seed)` / `numpy.random.RandomState(seed)` for a private stream."""
+    reference consumes), pass `random.Random(seed)` / `numpy.random.RandomState(seed)` for a private stream.
+    fields=False (the on-device pixel path, csrc/augment.hip): the two per-pixel random FIELDS -- the Gaussian noise image and the noise
+    fill of a constant-mode rotation -- are not drawn here; their steps carry a 64-bit seed for the device generator instead.  Every
+    scalar draw (which operations, how many, their parameters) is made exactly as before."""
 
-    def __init__(self, py=None, npr=None, verbose: bool = True):
+    def __init__(self, py=None, npr=None, verbose: bool = True, fields: bool = True):
         self.py = py if py is not None else _py_random
         self.npr = npr if npr is not None else np.random
+        self.fields = fields
         # persistent and process-wide (see _SHARED_ORDER), shuffled in place on every non-trivial call (np_augmenters.py:154);
         # an augmenter with private generators gets a private order
         self.order: List[str] = _SHARED_ORDER if (py is None and npr is None) else list(PRISTINE_ORDER)
@@ -146,8 +150,14 @@ class Augmenter:
             print("Initialized image segmentation augmenter.")
 
     # ------------------------------------------------------------------------------------------------ draw halves
+    def _seed(self):
+        lo, hi = self.npr.randint(0, 2 ** 31 - 1, 2)
+        return int(lo), int(hi)
+
     def plan_noise(self, shape, mean_sd: float = 5.1):
         sd = np.abs(self.npr.normal(mean_sd, 1, 1))
+        if not self.fields:
+            return ("noise", float(sd[0]), self._seed())
         return ("noise", self.npr.normal(0, sd, shape))
 
     def plan_exposure(self, shape, mean_sd: float = 12.75):
@@ -180,7 +190,7 @@ class Augmenter:
         cval, fill = 0, None
         if mode == "constant":
             if self.py.getrandbits(1):
-                cval, fill = -256, self.npr.randint(0, 256, size=shape)
+                cval, fill = -256, (self.npr.randint(0, 256, size=shape) if self.fields else self._seed())
             else:
                 cval = self.npr.randint(0, 256)
         return ("rotate", angle, mode, cval, fill)
@@ -196,6 +206,8 @@ class Augmenter:
 
     # ------------------------------------------------------------------------------------------------ reference call surface
     def _single(self, name, image, mask):
+        if not self.fields:
+            raise ValueError("an Augmenter built with fields=False only plans; the pixels are computed on the device (encode_device_ops)")
         return _apply_one(getattr(self, "plan_" + name)(image.shape), image, mask)
 
     def noise(self, image, mask):
@@ -221,3 +233,51 @@ class Augmenter:
         """With probability `prob_to_return_original` (None -> 1/7) the inputs come back untouched (as a tuple); otherwise a random
         number of the shuffled operations is applied to copies and [image, mask] (a list, like the reference) is returned."""
         return apply_recipe(self.plan(image.shape, prob_to_return_original), image, mask, return_image_mask_in_list)
+
+
+# ---------------------------------------------------------------------------------------------------- on-device pixel half
+# 48-byte records of csrc/augment.hip (struct AugOp)
+DEVICE_OP_DTYPE = np.dtype([("op", "<i4"), ("i0", "<i4"), ("i1", "<i4"), ("i2", "<i4"), ("i3", "<i4"), ("f0", "<f4"), ("f1", "<f4"), ("f2", "<f4"),
+                            ("f3", "<f4"), ("seed_lo", "<u4"), ("seed_hi", "<u4"), ("src", "<i4")])
+_ROTATE_MODES = {"reflect": 0, "constant": 1, "mirror": 2, "wrap": 3}
+
+
+def _encode_step(step, rec):
+    op = step[0]
+    if op == "erase":
+        _, y0, x0, bh, bw, value = step
+        rec["op"], rec["i0"], rec["i1"], rec["i2"], rec["i3"], rec["f0"] = 1, y0, x0, bh, bw, value
+    elif op == "translate":
+        _, ud, positive, shift, wrap, colour = step
+        rec["op"], rec["i0"], rec["i1"], rec["i2"], rec["i3"] = 2, int(ud), int(positive), int(shift), int(wrap)
+        if colour is not None:
+            rec["f0"], rec["f1"], rec["f2"] = colour
+    elif op == "flip":
+        rec["op"] = 3
+    elif op == "noise":
+        if not isinstance(step[2] if len(step) > 2 else None, tuple):
+            raise ValueError("noise step carries a host field: plan with Augmenter(fields=False) for the device path")
+        rec["op"], rec["f0"], rec["seed_lo"], rec["seed_hi"] = 4, step[1], step[2][0], step[2][1]
+    elif op == "exposure":
+        rec["op"], rec["f0"] = 5, float(np.asarray(step[1]).reshape(-1)[0])
+    elif op == "rotate":
+        _, angle, mode, cval, fill = step
+        rec["op"], rec["i0"], rec["f0"], rec["f1"] = 6, _ROTATE_MODES[mode], float(angle), float(cval)
+        if fill is not None:
+            if not isinstance(fill, tuple):
+                raise ValueError("rotate step carries a host noise field: plan with Augmenter(fields=False) for the device path")
+            rec["i1"], rec["seed_lo"], rec["seed_hi"] = 1, fill[0], fill[1]
+    else:
+        raise ValueError("unknown augmentation step {!r}".format(op))
+
+
+def encode_device_ops(recipes, src_idx) -> np.ndarray:
+    """[stages][B] array of device records for a mini-batch: recipes[b] = None (keep the original) or the list of planned steps of
+    sample b, src_idx[b] = its index among the resident shots.  Stage 0 reads the shots; samples with fewer steps pad with copies."""
+    B = len(recipes)
+    n = max([1] + [len(r) for r in recipes if r is not None])
+    out = np.zeros((n, B), dtype=DEVICE_OP_DTYPE)
+    for b, r in enumerate(recipes):
+        for k, step in enumerate(r or []):
+            _encode_step(step, out[k, b])
+    return out

@@ -200,7 +200,8 @@ class Learner:
                  dice: bool = False, label_smoothing: float = 0.0, final_layer_dropout_rate: float = 0.0,
                  spatial_pyramid_pooling: bool = False, skip_decoding: bool = False, drop_connect: bool = True, seed: int = 0,
                  device="cuda:0", use_graph: bool = True, max_shots: int = 16, matmul_precision: str = "fp32",
-                 overlap_wgrad: int = 0, wgrad_flush_before: Sequence[int] = (5,), small_fused: Optional[bool] = None):
+                 overlap_wgrad: int = 0, wgrad_flush_before: Sequence[int] = (5,), small_fused: Optional[bool] = None,
+                 augment_batch_capacity: int = 0):
         if skip_decoding:
             raise NotImplementedError("the DeepLabv3+ --skip_decoding decoder is not built (not part of EfficientLab-6-3; SURVEY.md 8(a) a18)")
         if l1 or darc1:
@@ -273,8 +274,18 @@ class Learner:
         self.plans: Dict[int, _Plan] = {}
         self.max_shots = max_shots
         H = image_size
-        self.shots_x = torch.zeros(max_shots, H, H, 3, dtype=torch.float32, device=self.device)
-        self.shots_y = torch.zeros(max_shots, H, H, 2, dtype=torch.float32, device=self.device)
+        # resident shots [0, max_shots) + (on-device augmentation) the slots of one augmented mini-batch behind them: the step's kernels
+        # address images through an index vector, so an augmented batch is just another set of indices -- same HIP graph
+        self.aug_capacity = int(augment_batch_capacity)
+        self.shots_x = torch.zeros(max_shots + self.aug_capacity, H, H, 3, dtype=torch.float32, device=self.device)
+        self.shots_y = torch.zeros(max_shots + self.aug_capacity, H, H, 2, dtype=torch.float32, device=self.device)
+        if self.aug_capacity:
+            self._aug_tmp_x = torch.zeros(self.aug_capacity, H, H, 3, dtype=torch.float32, device=self.device)
+            self._aug_tmp_y = torch.zeros(self.aug_capacity, H, H, 2, dtype=torch.float32, device=self.device)
+            self._aug_ops_dev = torch.zeros(8 * self.aug_capacity * 48, dtype=torch.uint8, device=self.device)
+            self._aug_ops_pin = torch.zeros((4, 8 * self.aug_capacity * 48), dtype=torch.uint8).pin_memory()
+            self._aug_ev = [None] * 4
+            self._aug_n = 0
         self.n_shots = 0
         # device RNG of the stochastic ops (drop-connect, dropout): Philox state advanced by the mask kernel itself (csrc/rng.hip)
         self.rng_state = ops.rng_state(seed, self.device)
@@ -455,6 +466,54 @@ class Learner:
             self.shots_x[:S].copy_(images.to(torch.float32), non_blocking=True)
             self.shots_y[:S].copy_(labels.to(torch.float32), non_blocking=True)
         self.n_shots = S
+        self._aug_valid = 0
+
+    def augment_batch(self, src_idx: Sequence[int], recipes) -> List[int]:
+        """On-device augmentation of one mini-batch (csrc/augment.hip): sample b = shot src_idx[b] of the resident task through the
+        planned steps recipes[b] (mliis_amd.augment.Augmenter(fields=False).plan; None = the original).  Returns the indices of the
+        augmented samples -- slots behind the resident shots -- to hand to inner_step()."""
+        from .augment import encode_device_ops
+        B = len(src_idx)
+        if not self.aug_capacity or B > self.aug_capacity:
+            raise ValueError("Learner was built with augment_batch_capacity={}; batch has {} samples".format(self.aug_capacity, B))
+        if max(src_idx) >= self.n_shots or min(src_idx) < 0:
+            raise ValueError("augment_batch: shot index out of range of the resident task ({} shots)".format(self.n_shots))
+        ops_np = encode_device_ops(recipes, src_idx)
+        n = ops_np.shape[0]
+        if n > 8:
+            raise ValueError("at most 8 augmentation stages per sample")
+        base = self.max_shots
+        for i in range(n):    # stage i reads: the shots (i = 0) or the previous stage's output; the LAST stage writes the batch slots
+            prev_in_shots = i > 0 and (n - 1 - (i - 1)) % 2 == 0
+            ops_np[i]["src"] = np.asarray(src_idx, dtype=np.int32) if i == 0 else (np.arange(B, dtype=np.int32) + (base if prev_in_shots else 0))
+        H = self.arch.image_size
+        nbytes = ops_np.nbytes
+        with torch.cuda.stream(self.stream):
+            slot = self._aug_n % 4
+            self._aug_n += 1
+            if self._aug_ev[slot] is not None:
+                self._aug_ev[slot].synchronize()
+            else:
+                self._aug_ev[slot] = torch.cuda.Event()
+            pin = self._aug_ops_pin[slot, :nbytes]
+            pin.copy_(torch.from_numpy(ops_np.reshape(-1).view(np.uint8)))
+            dev = self._aug_ops_dev[:nbytes]
+            dev.copy_(pin, non_blocking=True)
+            self._aug_ev[slot].record(self.stream)
+            for i in range(n):
+                to_shots = (n - 1 - i) % 2 == 0
+                from_shots = i == 0 or (n - 1 - (i - 1)) % 2 == 0
+                xin, yin = (self.shots_x, self.shots_y) if from_shots else (self._aug_tmp_x, self._aug_tmp_y)
+                xout, yout = (self.shots_x, self.shots_y) if to_shots else (self._aug_tmp_x, self._aug_tmp_y)
+                if xin is xout:   # (stage 0 reading the shots and writing the batch slots of the same allocation: disjoint sample ranges)
+                    xin_p, yin_p = xin.data_ptr(), yin.data_ptr()
+                    xout_p, yout_p = xout[base:].data_ptr(), yout[base:].data_ptr()
+                    ob = 0
+                else:
+                    xin_p, yin_p, xout_p, yout_p, ob = xin.data_ptr(), yin.data_ptr(), xout.data_ptr(), yout.data_ptr(), (base if to_shots else 0)
+                lib.call("mliis_augment_stage", xin_p, yin_p, xout_p, yout_p, dev.data_ptr() + i * B * 48, B, H, H, ob, self.stream.cuda_stream)
+        self._aug_valid = B
+        return [base + b for b in range(B)]
 
     def _plan(self, N: int) -> _Plan:
         if N not in self.plans:
@@ -819,7 +878,8 @@ class Learner:
         N = len(batch_idx)
         if N == 0:
             raise ValueError("empty mini-batch")
-        if max(batch_idx) >= self.n_shots or min(batch_idx) < 0:
+        lim = self.max_shots + self._aug_valid if getattr(self, "_aug_valid", 0) else self.n_shots
+        if min(batch_idx) < 0 or max(batch_idx) >= lim or any(self.n_shots <= i < self.max_shots for i in batch_idx):
             raise ValueError("batch index out of range of the resident task ({} shots)".format(self.n_shots))
         P = self._plan(N)
         with torch.cuda.stream(self.stream):

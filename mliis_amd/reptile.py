@@ -126,9 +126,14 @@ class Gecko:
         # aug_pool (augment.AugmentPool, optional): worker processes for the pixel half of the augmentation; the draws stay here.
         self.augmenter = None
         self.aug_pool = aug_pool
+        # augment: False | True (pixels on the host, draw-identical to the reference) | "device" (same draws of the operations and their
+        # parameters; the pixel work -- and the two per-pixel noise fields -- on the device: csrc/augment.hip, Learner.augment_batch)
+        self.device_aug = augment == "device"
         if augment:
             from .augment import Augmenter
-            self.augmenter = Augmenter()
+            self.augmenter = Augmenter(fields=not self.device_aug)
+            if self.device_aug and not getattr(learner, "aug_capacity", 0):
+                raise ValueError("augment='device' needs a learner built with augment_batch_capacity >= the inner batch size")
         print("Augmentation rate {}".format(self.aug_rate))
         if self.rng_mode == "reference" and self.dist.world > 1:
             raise ValueError("rng_mode='reference' consumes the global generator sequentially and is only valid on one rank")
@@ -146,8 +151,9 @@ class Gecko:
 
     def _sample(self, dataset, num_shots, rng):
         (images, labels) = metaseg.sample_task(dataset, num_shots, rng)
-        if self.augmenter is None:
+        if self.augmenter is None or self.device_aug:
             self.learner.load_task(images, labels)
+            self._host_task = (images, labels)     # (device path: only the shapes are read when the schedule is drawn)
         else:   # augmented batches are built on the host from these arrays and uploaded one inner step at a time
             self._host_task = (_to_numpy(images), _to_numpy(labels))
         return int(images.shape[0])
@@ -159,8 +165,11 @@ class Gecko:
         the pixel work to the pool, if there is one."""
         if rng is not None:   # per-task mode: private, reproducible streams for the augmenter as well
             import numpy as np
+            from .augment import PRISTINE_ORDER
             self.augmenter.py = rng
             self.augmenter.npr = np.random.RandomState(_task_rng(self.seed, self.meta_iter, task_idx).getrandbits(32))
+            self.augmenter.order = list(PRISTINE_ORDER)   # the reference's persistent shuffled order would make a task's draws depend on
+            #                                              which tasks this rank saw before (i.e. on the rank count): start every task fresh
         x, y = self._host_task
         wr = getattr(self, "sample_train_val_with_replacement", False)
         sched = metaseg.AugmentedSchedule(x, y, inner_batch_size, inner_iters, replacement, self.augmenter,
@@ -168,7 +177,7 @@ class Gecko:
                                           tail_shots=getattr(self, "tail_shots", None), fomaml=self._train_aug_rate_from_self,
                                           with_replacement_train_shots=self.train_shots if wr else None,
                                           npr=self._npr(rng) if wr else None)
-        return sched.submit(self.aug_pool) if self.aug_pool is not None else sched
+        return sched.submit(self.aug_pool) if (self.aug_pool is not None and not self.device_aug) else sched
 
     def _run_meta_batch(self, dataset, num_shots, inner_batch_size, inner_iters, replacement, meta_step_size, meta_batch_size, lr,
                         fomaml: bool):
@@ -192,7 +201,7 @@ class Gecko:
             # pool while the device trains on the earlier ones.
             mine = [t for t in range(meta_batch_size) if self.rng_mode == "reference" or t % D.world == D.rank]
             ahead = {}
-            if self.augmenter is not None:
+            if self.augmenter is not None and not self.device_aug:
                 for t in mine:
                     rng = self._rng(t)
                     self._sample(dataset, num_shots, rng)
@@ -206,6 +215,10 @@ class Gecko:
                     rng = self._rng(t)
                     n_shots = self._sample(dataset, num_shots, rng)
                     batches = self._task_batches(n_shots, inner_batch_size, inner_iters, replacement, rng)
+                elif self.device_aug:   # draws on the host (same order as the host path), pixels on the device, batch by batch
+                    rng = self._rng(t)
+                    self._sample(dataset, num_shots, rng)
+                    batches = self._augmented_task_schedule(inner_batch_size, inner_iters, replacement, rng, t).device_batches()
                 else:
                     batches = ahead.pop(t).batches()
                 L.import_bn(self._bn_zero)
@@ -213,7 +226,9 @@ class Gecko:
                 for j, idx in enumerate(batches):
                     if fomaml and j == inner_iters - 1:
                         last_backup = L.export_trainable()
-                    if self.augmenter is not None:   # idx is an augmented (images, labels) batch: make it the resident "task"
+                    if self.device_aug:              # idx = (recipes, shot indices): augmented on the device into the batch slots
+                        idx = self._device_batch(L, idx[1], idx[0])
+                    elif self.augmenter is not None:   # idx is an augmented (images, labels) batch: make it the resident "task"
                         L.load_task(idx[0], idx[1])
                         idx = list(range(int(idx[0].shape[0])))
                     self._step(idx, j, lr)
@@ -267,6 +282,14 @@ class Gecko:
 
     def _task_batches(self, n_shots, inner_batch_size, inner_iters, replacement, rng):
         return self._batches(n_shots, inner_batch_size, inner_iters, replacement, rng)
+
+    @staticmethod
+    def _device_batch(L, shot_idx, recipes):
+        """Indices of one inner step's samples: the shots themselves when no sample of the batch is augmented (FOMAML's raw tail batch,
+        or every draw kept the original), else the batch slots the device augmenter fills."""
+        if all(r is None for r in recipes):
+            return [int(i) for i in shot_idx]
+        return L.augment_batch(shot_idx, recipes)
 
     def _steps_per_batch(self, lr) -> int:
         """Optimizer steps (= BN moving-average updates) `_step` issues per mini-batch."""
@@ -385,6 +408,11 @@ class Gecko:
         inner_iter = 0
         if self.augmenter is None:
             schedule = metaseg.mini_batch_indices(len(train_idx), inner_batch_size, inner_iters, replacement)
+        elif self.device_aug:   # same draws, pixels on the device: (recipes, positions in train_idx) per step
+            shape = tuple(images.shape[1:]) if images is not None else (L.arch.image_size, L.arch.image_size, 3)
+            keep_p = None if aug_rate is None else 1.0 - aug_rate
+            schedule = metaseg.mini_batch_indices(len(train_idx), inner_batch_size, inner_iters, replacement,
+                                                  visit=lambda i: (self.augmenter.plan(shape, keep_p), i))
         else:   # fine-tune on augmented copies of the support examples (reptile.py:261-262), built on the host
             if images is None:
                 raise ValueError("_evaluate with augmentation needs the task's images")
@@ -394,6 +422,8 @@ class Gecko:
         for inner_iter, b in enumerate(schedule):
             if self.augmenter is None:
                 idx = [train_idx[i] for i in b]
+            elif self.device_aug:
+                idx = self._device_batch(L, [train_idx[i] for (_, i) in b], [r for (r, _) in b])
             else:
                 L.load_task(b[0], b[1])
                 idx = list(range(int(b[0].shape[0])))
@@ -402,7 +432,7 @@ class Gecko:
             from .checkpoint import save_fine_tuned_checkpoint
             L.synchronize()
             save_fine_tuned_checkpoint(L.named_numpy(), save_fine_tuned_checkpoints_dir, task_name, eval_sample_num, inner_iter)
-        if self.augmenter is not None:
+        if self.augmenter is not None and not self.device_aug:
             L.load_task(images, labels)   # the augmented batches replaced the resident task
         preds = self._test_predictions(train_idx, test_idx)
         lab = labels.detach().cpu().numpy() if hasattr(labels, "detach") else np.asarray(labels)
@@ -431,6 +461,11 @@ class Gecko:
         lab = _to_numpy(labels)
         if self.augmenter is None:
             schedule = metaseg.mini_batch_indices(len(train_idx), inner_batch_size, max_steps, replacement)
+        elif self.device_aug:   # drawn lazily batch by batch (the loop may stop early), pixels on the device
+            shape = (L.arch.image_size, L.arch.image_size, 3)
+            keep_p = None if aug_rate is None else 1.0 - aug_rate
+            schedule = metaseg.mini_batch_indices(len(train_idx), inner_batch_size, max_steps, replacement,
+                                                  visit=lambda i: (self.augmenter.plan(shape, keep_p), i))
         else:
             if images is None:
                 raise ValueError("_early_stopping_learn with augmentation needs the task's images")
@@ -440,11 +475,13 @@ class Gecko:
         for inner_iter, b in enumerate(schedule):
             if self.augmenter is None:
                 idx = [train_idx[i] for i in b]
+            elif self.device_aug:
+                idx = self._device_batch(L, [train_idx[i] for (_, i) in b], [r for (r, _) in b])
             else:
                 L.load_task(b[0], b[1])
                 idx = list(range(int(b[0].shape[0])))
             self._fine_tune_step(idx, inner_iter, lr, lr_scheduler, drop_rate)
-            if self.augmenter is not None:
+            if self.augmenter is not None and not self.device_aug:
                 L.load_task(images, labels)   # predictions read the ORIGINAL examples
             preds = self._test_predictions(train_idx, val_idx)
             miou = np.nanmean([_iou(preds[j], lab[val_idx[j]]) for j in range(len(val_idx))])

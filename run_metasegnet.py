@@ -9,7 +9,9 @@ Writes the reference's checkpoint directory layout (mliis_amd/checkpoint.py) and
 --optimize_update_hyperparms_on_val_set: update-hyperparameter search on the validation tasks (mliis_amd/hyperparam_search.py: the
 early-stopping harness of the reference + a built-in GP / expected-improvement optimiser in place of scikit-optimize);
 --run_k_shot_learning_curves_experiment: k-shot learning curves on the FP-k tasks (or on synthetic tasks with --k-shot-range).
---augment / --aug_rate: the reference's host numpy augmentation of the inner-loop batches (mliis_amd/augment.py, same draws).  Checkpoints: numpy .npz or TensorFlow TensorBundle files (--checkpoint-format tf; restoring takes either).  Data: --data-dir with FSS-1000 TFRecord-GZIP shards
+--augment / --aug_rate: the reference's augmentation of the inner-loop batches -- same draws of the operations and their parameters
+(mliis_amd/augment.py); the pixel work runs on the device (csrc/augment.hip), or in numpy / scipy on the host with --augment-on-host
+(draw-identical noise fields too).  Checkpoints: numpy .npz or TensorFlow TensorBundle files (--checkpoint-format tf; restoring takes either).  Data: --data-dir with FSS-1000 TFRecord-GZIP shards
 (mliis_amd/tfrecord.py, no TensorFlow needed) or --synthetic-tasks N.
 """
 import datetime
@@ -30,7 +32,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 from mliis_amd import checkpoint as ckpt  # noqa: E402
-from mliis_amd.args import argument_parser, evaluate_kwargs, hyper_search_kwargs, make_lr_scheduler, model_kwargs, train_kwargs  # noqa: E402
+from mliis_amd.args import argument_parser, augment_mode, evaluate_kwargs, hyper_search_kwargs, make_lr_scheduler, model_kwargs, train_kwargs  # noqa: E402
 
 
 def _dataset(args, device, rank):
@@ -100,7 +102,7 @@ def _evaluate(args, learner, lr_scheduler, train_set, val_set, test_set, aug_poo
             tp["meta_step_size"] = tp["meta_step_size_final"]
             train_gecko(learner, list(train_set) + list(val_set), test_set,
                         os.path.join(args.checkpoint, "fine-tuned_on_train_val_with_optimized_update_hyperparams"), lr_scheduler=lr_scheduler,
-                        augment=args.augment, dist=SingleRank(), seed=args.seed, checkpoint_format=args.checkpoint_format, aug_pool=aug_pool,
+                        augment=augment_mode(args), dist=SingleRank(), seed=args.seed, checkpoint_format=args.checkpoint_format, aug_pool=aug_pool,
                         **tp)   # this rank alone (the process group is gone by now): all tasks, no collective
     del ek["eval_tasks_with_median_early_stopping_iterations"]
     if args.run_k_shot_learning_curves_experiment:
@@ -144,7 +146,7 @@ def main(argv=None, learner_factory=None, device=None):
     args = argument_parser().parse_args(argv)
     random.seed(args.seed)
     aug_pool = None
-    if args.augment and args.augment_workers != 0:   # forked workers: created before anything initialises the GPU
+    if args.augment and args.augment_on_host and args.augment_workers != 0:   # forked workers: created before anything initialises the GPU
         from mliis_amd.augment import AugmentPool
         aug_pool = AugmentPool(None if args.augment_workers < 0 else args.augment_workers)
         print("Augmentation pixel work on {} worker processes.".format(aug_pool.workers))
@@ -185,7 +187,7 @@ def main(argv=None, learner_factory=None, device=None):
             path = ckpt.latest_checkpoint(args.continue_training_from_checkpoint)
             print("Continuing meta-training from checkpoint: {}".format(path))
             learner.load_named(ckpt.load(path))
-        train_gecko(learner, train_set, val_set or test_set, args.checkpoint, lr_scheduler=lr_scheduler, augment=args.augment, dist=Dist(),
+        train_gecko(learner, train_set, val_set or test_set, args.checkpoint, lr_scheduler=lr_scheduler, augment=augment_mode(args), dist=Dist(),
                     seed=args.seed, checkpoint_format=args.checkpoint_format, aug_pool=aug_pool, lanes=lanes, **train_kwargs(args))
     else:
         path = ckpt.latest_checkpoint(args.checkpoint)

@@ -144,3 +144,52 @@ def test_pooled_schedule_is_bit_identical_to_the_inline_one():
             assert any(not np.array_equal(b[0][i], x[j]) for b in ref[0][:4] for i in range(len(b[0])) for j in range(6))   # something was augmented
     finally:
         pool.close()
+
+
+def test_device_path_draws_and_record_encoding():
+    """The on-device pixel path (csrc/augment.hip) keeps every scalar draw of the host augmenter: Augmenter(fields=False) plans are the
+    host plans up to the first step that carries a per-pixel field (which the device generates from a drawn seed instead), and the
+    48-byte records the kernel reads encode the steps faithfully."""
+    import random
+
+    from mliis_amd import augment as A
+    n_checked = 0
+    for seed in range(60):
+        a = A.Augmenter(py=random.Random(seed), npr=np.random.RandomState(seed), verbose=False)
+        d = A.Augmenter(py=random.Random(seed), npr=np.random.RandomState(seed), verbose=False, fields=False)
+        pa, pd = a.plan((32, 32, 3), 0.3), d.plan((32, 32, 3), 0.3)
+        assert (pa is None) == (pd is None)
+        if pa is None:
+            continue
+        assert [s[0] for s in pa] == [s[0] for s in pd]             # same operations, same order, same count
+        for sa, sd in zip(pa, pd):
+            if sa[0] == "noise":
+                assert isinstance(sd[1], float) and isinstance(sd[2], tuple)
+                break
+            if sa[0] == "rotate":
+                assert sa[1:4] == sd[1:4]
+                if sa[4] is not None:
+                    assert isinstance(sd[4], tuple)
+                    break
+            elif sa[0] == "translate":
+                assert sa[1:5] == sd[1:5] and (sa[5] is None or np.array_equal(sa[5], sd[5]))
+            else:
+                assert all(np.array_equal(u, v) for u, v in zip(sa[1:], sd[1:]))
+            n_checked += 1
+    assert n_checked > 40
+    with pytest.raises(ValueError):
+        A.Augmenter(verbose=False, fields=False).noise(np.zeros((4, 4, 3), np.float32), np.zeros((4, 4, 2), np.float32))
+    rec = A.encode_device_ops([None, [("erase", 1, 2, 3, 4, 9.5), ("rotate", -13, "wrap", 0, None)],
+                               [("translate", 1, 0, 7, 0, np.array([1.0, 2.0, 3.0])), ("rotate", 30, "constant", -256, (11, 12)), ("exposure", np.array([4.5]))]],
+                              [5, 6, 7])
+    assert rec.shape == (3, 3) and rec.dtype.itemsize == 48
+    assert rec[0, 0]["op"] == 0 and rec[1, 0]["op"] == 0 and rec[2, 1]["op"] == 0            # padding = copies
+    e, r = rec[0, 1], rec[1, 1]
+    assert (e["op"], e["i0"], e["i1"], e["i2"], e["i3"], e["f0"]) == (1, 1, 2, 3, 4, 9.5)
+    assert (r["op"], r["i0"], r["i1"], r["f0"], r["f1"]) == (6, 3, 0, -13.0, 0.0)
+    t, r2, x = rec[0, 2], rec[1, 2], rec[2, 2]
+    assert (t["op"], t["i0"], t["i1"], t["i2"], t["i3"], t["f0"], t["f1"], t["f2"]) == (2, 1, 0, 7, 0, 1.0, 2.0, 3.0)
+    assert (r2["op"], r2["i0"], r2["i1"], r2["f1"], r2["seed_lo"], r2["seed_hi"]) == (6, 1, 1, -256.0, 11, 12)
+    assert (x["op"], x["f0"]) == (5, 4.5)
+    with pytest.raises(ValueError):
+        A.encode_device_ops([[("noise", np.zeros((2, 2, 3)))]], [0])          # a host field cannot go to the device
