@@ -244,18 +244,40 @@ def roofline(L, args):
             e1.synchronize()
             us = 1e3 * e0.elapsed_time(e1) / reps_k
             del variants, bufs
+            # practical ceiling at THIS size: a plain device copy that moves the same number of bytes (half read, half written), timed the
+            # same way (cold, rotating) -- a 25 MB launch cannot reach the 8 TB/s of a long stream: ramp-up, first-touch latency and drain
+            # are a fixed ~3-4 us
+            half = int(nbytes // 8)
+            csrc = [torch.empty(half, dtype=torch.float32, device=L.device).normal_() for _ in range(copies)]
+            cdst = [torch.empty(half, dtype=torch.float32, device=L.device) for _ in range(copies)]
+            for a_, b_ in zip(csrc, cdst):
+                b_.copy_(a_)
+            e0.record(L.stream)
+            for r in range(reps_k):
+                cdst[r % copies].copy_(csrc[r % copies])
+            e1.record(L.stream)
+            e1.synchronize()
+            cus = 1e3 * e0.elapsed_time(e1) / reps_k
+            del csrc, cdst
             layers.append({"entry": n[6:], "N,H,W,C,k,s": [nb, h, w_, c, kk, st], "us": round(us, 2), "algorithmic_MB": round(nbytes / 1e6, 2),
-                           "frac_of_8TBps": round(nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 3), "rotating_copies": copies})
+                           "frac_of_8TBps": round(nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 3), "rotating_copies": copies,
+                           "copy_same_bytes_us": round(cus, 2), "frac_of_copy": round(cus / us, 3)})
+            d_copy = dw.setdefault("_copy_us", {})
+            d_copy[fam_name] = d_copy.get(fam_name, 0.0) + cus
             d_ = dw.setdefault(fam_name, {"us_per_step": 0.0, "launches_per_step": 0, "algorithmic_MB_per_step": 0.0})
             d_["us_per_step"] += us
             d_["launches_per_step"] += 1
             d_["algorithmic_MB_per_step"] += nbytes / 1e6
-    for d_ in dw.values():
+    copy_us = dw.pop("_copy_us", {})
+    for k_, d_ in dw.items():
         d_["GBps"] = d_["algorithmic_MB_per_step"] * 1e6 / (d_["us_per_step"] * 1e-6) / 1e9
         d_["frac_of_8TBps"] = d_["GBps"] / HBM_PEAK_GBS
+        d_["copy_same_bytes_us_per_step"] = copy_us.get(k_)
+        d_["frac_of_copy"] = (copy_us[k_] / d_["us_per_step"]) if k_ in copy_us else None
     tot_us = sum(d_["us_per_step"] for d_ in dw.values())
     tot_mb = sum(d_["algorithmic_MB_per_step"] for d_ in dw.values())
     dw["all_depthwise_fwd_bwd"] = {"us_per_step": tot_us, "algorithmic_MB_per_step": tot_mb, "frac_of_8TBps": tot_mb * 1e6 / (tot_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                   "copy_same_bytes_us_per_step": sum(copy_us.values()), "frac_of_copy": sum(copy_us.values()) / tot_us,
                                    "method": "cold operands: rotating copies, > 320 MB between two touches of a tensor (Infinity Cache flushed)"}
     dw["per_layer"] = layers
     families = {k: {"us_per_step": 1e3 * v["ms"] / reps, "launches_per_step": v["n"] // reps,

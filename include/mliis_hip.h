@@ -258,14 +258,20 @@ size_t mliis_softmax_ce_workspace_floats(int N, int H, int W);
 int mliis_softmax_ce(const float* logits, const float* labels, const int* img_idx, int N, int H, int W, float label_smoothing, int dice,
                      float extra_loss, float* dlogits, float* pred, float* out, float* ws, size_t ws_floats, hipStream_t stream);
 
+/*      DARC1 regulariser (models/regularizers.py:20-22): weight * max over positions of sum_n |logits[n, pos]| added to out[0]
+ *      (nullable) and its gradient weight * sign(logits[n, argmax]) added to dlogits (nullable); logits [N, per_img]; ws >= 2048 floats. */
+int mliis_darc1(const float* logits, int N, long long per_img, float weight, float* dlogits, float* out, float* ws, size_t ws_floats,
+                hipStream_t stream);
+
 /* ---- optimizer + arena algebra.  tf.train.GradientDescentOptimizer / AdamOptimizer(beta1=0) apply
- *      (efficientlab.py:16,301,315-317; meta_learners/args.py:151-154) with the L2 gradient (models/regularizers.py:4-10)
- *      folded in through a per-quad byte mask; lr_dev (nullable device float) overrides lr so captured graphs can vary it.
+ *      (efficientlab.py:16,301,315-317; meta_learners/args.py:151-154) with the gradients of the weight regularisers -- l2 * w
+ *      (models/regularizers.py:4-10) and l1 * sign(w) (:13-19), non batch-norm variables only -- folded in through a per-quad
+ *      byte mask; lr_dev (nullable device float) overrides lr so captured graphs can vary it.
  *      axpby / lincomb implement meta_learners/variables.py:9-55 on the flat arena. */
-int mliis_sgd_fused(float* w, const float* g, const uint8_t* l2_quad_mask, long long n, float lr, const float* lr_dev, float l2,
+int mliis_sgd_fused(float* w, const float* g, const uint8_t* l2_quad_mask, long long n, float lr, const float* lr_dev, float l2, float l1,
                     hipStream_t stream);
 int mliis_adam_b1zero_fused(float* w, const float* g, float* v, const uint8_t* l2_quad_mask, long long n, float lr, const float* lr_dev,
-                            float l2, float beta2, float eps, const float* step_dev, hipStream_t stream);
+                            float l2, float l1, float beta2, float eps, const float* step_dev, hipStream_t stream);
 int mliis_axpby(float a, const float* x, float b, float* y, long long n, hipStream_t stream);
 int mliis_lincomb(float a, const float* x, float b, const float* y, float* out, long long n, hipStream_t stream);
 

@@ -304,6 +304,82 @@ __global__ __launch_bounds__(256) void ce_grad_k(const float* __restrict__ logit
   }
 }
 
+// ------------------------------------------------------------------------------------------------ DARC1 regulariser
+// models/regularizers.py:20-22: weight * max over (h, w, c) of sum_n |logits[n,h,w,c]|.  Gradient: weight * sign(logits[n, argmax]) for
+// every n at the ONE arg-max position (ties: the first index).  darc1_partial_k: per-block (max, index); darc1_apply_k (one block):
+// global arg-max in block order (deterministic), then the loss term and the N gradient entries.
+__global__ __launch_bounds__(256) void darc1_partial_k(const float* __restrict__ z, int N, long long per_img, float* __restrict__ pval,
+                                                       int* __restrict__ pidx) {
+  __shared__ float sv[256];
+  __shared__ int si[256];
+  float best = -1.f;
+  int bidx = 0;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < per_img; i += (long long)gridDim.x * 256) {
+    float s = 0.f;
+    for (int n = 0; n < N; ++n) s += fabsf(z[(long long)n * per_img + i]);
+    if (s > best) {
+      best = s;
+      bidx = (int)i;
+    }
+  }
+  sv[threadIdx.x] = best;
+  si[threadIdx.x] = bidx;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) {
+      const float a = sv[threadIdx.x], b = sv[threadIdx.x + o];
+      const int ia = si[threadIdx.x], ib = si[threadIdx.x + o];
+      if (b > a || (b == a && ib < ia)) {
+        sv[threadIdx.x] = b;
+        si[threadIdx.x] = ib;
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    pval[blockIdx.x] = sv[0];
+    pidx[blockIdx.x] = si[0];
+  }
+}
+
+__global__ __launch_bounds__(256) void darc1_apply_k(const float* __restrict__ z, int N, long long per_img, const float* __restrict__ pval,
+                                                     const int* __restrict__ pidx, int nblk, float weight, float* __restrict__ dlogits,
+                                                     float* __restrict__ out) {
+  __shared__ float sv[256];
+  __shared__ int si[256];
+  float best = -1.f;
+  int bidx = 0x7fffffff;
+  for (int b = threadIdx.x; b < nblk; b += 256) {
+    const float v = pval[b];
+    const int ix = pidx[b];
+    if (v > best || (v == best && ix < bidx)) {
+      best = v;
+      bidx = ix;
+    }
+  }
+  sv[threadIdx.x] = best;
+  si[threadIdx.x] = bidx;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) {
+      const float a = sv[threadIdx.x], b = sv[threadIdx.x + o];
+      const int ia = si[threadIdx.x], ib = si[threadIdx.x + o];
+      if (b > a || (b == a && ib < ia)) {
+        sv[threadIdx.x] = b;
+        si[threadIdx.x] = ib;
+      }
+    }
+    __syncthreads();
+  }
+  const int pos = si[0];
+  if (threadIdx.x == 0 && out != nullptr) out[0] += weight * sv[0];
+  if (dlogits != nullptr)
+    for (int n = threadIdx.x; n < N; n += 256) {
+      const float v = z[(long long)n * per_img + pos];
+      dlogits[(long long)n * per_img + pos] += weight * (v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f));
+    }
+}
+
 static inline int ew_blocks(long long q) {
   long long b = (q + 255) / 256;
   if (b > 4096) b = 4096;
@@ -484,6 +560,23 @@ int mliis_swish_mask_bwd(const float* dy, int lddy, const float* z, int ldz, con
   hipLaunchKernelGGL(swish_mask_bwd_k, dim3((unsigned)((q + 255) / 256 > 4096 ? 4096 : (q + 255) / 256)), dim3(256), 0, stream, dy, lddy, z, ldz, mask,
                      ldm, dz, lddz, rows, C, pre_mask);
   MLIIS_CHECK_LAUNCH("swish_mask_bwd");
+  return MLIIS_OK;
+}
+
+// DARC1 regulariser on the logits [N, per_img] (models/regularizers.py:20-22): adds weight * max_pos sum_n |logits| to out[0] (nullable)
+// and its gradient to dlogits (nullable).  ws: 2 * 1024 floats.
+int mliis_darc1(const float* logits, int N, long long per_img, float weight, float* dlogits, float* out, float* ws, size_t ws_floats,
+                hipStream_t stream) {
+  MLIIS_REQUIRE(logits && ws && N > 0 && per_img > 0 && per_img < (1LL << 31), MLIIS_ERR_ARG, "darc1: bad arguments");
+  MLIIS_REQUIRE(ws_floats >= 2048, MLIIS_ERR_WORKSPACE, "darc1: workspace too small (2048 floats needed, %zu given)", ws_floats);
+  int nblk = (int)((per_img + 255) / 256);
+  if (nblk > 1024) nblk = 1024;
+  float* pval = ws;
+  int* pidx = reinterpret_cast<int*>(ws + 1024);
+  hipLaunchKernelGGL(darc1_partial_k, dim3(nblk), dim3(256), 0, stream, logits, N, per_img, pval, pidx);
+  MLIIS_CHECK_LAUNCH("darc1_partial");
+  hipLaunchKernelGGL(darc1_apply_k, dim3(1), dim3(256), 0, stream, logits, N, per_img, pval, pidx, nblk, weight, dlogits, out);
+  MLIIS_CHECK_LAUNCH("darc1_apply");
   return MLIIS_OK;
 }
 }

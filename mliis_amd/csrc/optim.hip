@@ -21,14 +21,24 @@ int set_error(int code, const char* fmt, ...) {
   return code;
 }
 
-// w -= lr * (g + l2 * w * l2mask[quad]) ; lr read from device memory when lr_dev != null (graph replays re-read it)
+__device__ __forceinline__ float sign_f(float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); }   // tf.abs' gradient: sign(0) = 0
+// gradient of the weight regularisers of models/regularizers.py:4-19 on the masked (non batch-norm) quads: l2 * w + l1 * sign(w)
+__device__ __forceinline__ float4 add_reg(float4 gv, float4 wv, float l2, float l1) {
+  gv = f4fma(make_float4(l2, l2, l2, l2), wv, gv);
+  if (l1 != 0.f) {
+    gv.x += l1 * sign_f(wv.x); gv.y += l1 * sign_f(wv.y); gv.z += l1 * sign_f(wv.z); gv.w += l1 * sign_f(wv.w);
+  }
+  return gv;
+}
+
+// w -= lr * (g + (l2 * w + l1 * sign(w)) * l2mask[quad]) ; lr read from device memory when lr_dev != null (graph replays re-read it)
 __global__ __launch_bounds__(256) void sgd_k(float* __restrict__ w, const float* __restrict__ g, const uint8_t* __restrict__ l2mask,
-                                             long long nquads, float lr_host, const float* __restrict__ lr_dev, float l2) {
+                                             long long nquads, float lr_host, const float* __restrict__ lr_dev, float l2, float l1) {
   const float lr = lr_dev ? *lr_dev : lr_host;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nquads; i += (long long)gridDim.x * blockDim.x) {
     float4 wv = ld4(w + i * 4);
     float4 gv = ld4(g + i * 4);
-    if (l2mask && l2 != 0.f && l2mask[i]) gv = f4fma(make_float4(l2, l2, l2, l2), wv, gv);
+    if (l2mask && (l2 != 0.f || l1 != 0.f) && l2mask[i]) gv = add_reg(gv, wv, l2, l1);
     wv.x -= lr * gv.x;
     wv.y -= lr * gv.y;
     wv.z -= lr * gv.z;
@@ -41,14 +51,14 @@ __global__ __launch_bounds__(256) void sgd_k(float* __restrict__ w, const float*
 // lr_t = lr * sqrt(1 - b2^t) (beta1^t term is 1 - 0 = 1).  step_dev holds t (float) and is advanced by the caller.
 __global__ __launch_bounds__(256) void adam_b1zero_k(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ v,
                                                      const uint8_t* __restrict__ l2mask, long long nquads, float lr_host,
-                                                     const float* __restrict__ lr_dev, float l2, float beta2, float eps,
+                                                     const float* __restrict__ lr_dev, float l2, float l1, float beta2, float eps,
                                                      const float* __restrict__ step_dev) {
   const float lr = lr_dev ? *lr_dev : lr_host;
   const float tstep = *step_dev;
   const float lr_t = lr * sqrtf(1.f - powf(beta2, tstep));
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nquads; i += (long long)gridDim.x * blockDim.x) {
     float4 wv = ld4(w + i * 4), gv = ld4(g + i * 4), vv = ld4(v + i * 4);
-    if (l2mask && l2 != 0.f && l2mask[i]) gv = f4fma(make_float4(l2, l2, l2, l2), wv, gv);
+    if (l2mask && (l2 != 0.f || l1 != 0.f) && l2mask[i]) gv = add_reg(gv, wv, l2, l1);
     vv.x = beta2 * vv.x + (1.f - beta2) * gv.x * gv.x;
     vv.y = beta2 * vv.y + (1.f - beta2) * gv.y * gv.y;
     vv.z = beta2 * vv.z + (1.f - beta2) * gv.z * gv.z;
@@ -98,23 +108,23 @@ int mliis_version(void) { return 100; }
 
 const char* mliis_last_error(void) { return g_err; }
 
-int mliis_sgd_fused(float* w, const float* g, const uint8_t* l2_quad_mask, long long n, float lr, const float* lr_dev, float l2,
+int mliis_sgd_fused(float* w, const float* g, const uint8_t* l2_quad_mask, long long n, float lr, const float* lr_dev, float l2, float l1,
                     hipStream_t stream) {
   MLIIS_REQUIRE(w && g, MLIIS_ERR_ARG, "sgd_fused: null pointer");
   MLIIS_REQUIRE(n > 0 && (n & 3) == 0, MLIIS_ERR_ARG, "sgd_fused: n must be a positive multiple of 4 (arena is padded)");
   MLIIS_REQUIRE(aligned16(w) && aligned16(g), MLIIS_ERR_ALIGN, "sgd_fused: pointers must be 16-byte aligned");
-  hipLaunchKernelGGL(sgd_k, dim3(flat_blocks(n / 4)), dim3(256), 0, stream, w, g, l2_quad_mask, n / 4, lr, lr_dev, l2);
+  hipLaunchKernelGGL(sgd_k, dim3(flat_blocks(n / 4)), dim3(256), 0, stream, w, g, l2_quad_mask, n / 4, lr, lr_dev, l2, l1);
   MLIIS_CHECK_LAUNCH("sgd_fused");
   return MLIIS_OK;
 }
 
 int mliis_adam_b1zero_fused(float* w, const float* g, float* v, const uint8_t* l2_quad_mask, long long n, float lr, const float* lr_dev,
-                            float l2, float beta2, float eps, const float* step_dev, hipStream_t stream) {
+                            float l2, float l1, float beta2, float eps, const float* step_dev, hipStream_t stream) {
   MLIIS_REQUIRE(w && g && v && step_dev, MLIIS_ERR_ARG, "adam_b1zero_fused: null pointer");
   MLIIS_REQUIRE(n > 0 && (n & 3) == 0, MLIIS_ERR_ARG, "adam_b1zero_fused: n must be a positive multiple of 4");
   MLIIS_REQUIRE(aligned16(w) && aligned16(g) && aligned16(v), MLIIS_ERR_ALIGN, "adam_b1zero_fused: pointers must be 16-byte aligned");
-  hipLaunchKernelGGL(adam_b1zero_k, dim3(flat_blocks(n / 4)), dim3(256), 0, stream, w, g, v, l2_quad_mask, n / 4, lr, lr_dev, l2, beta2,
-                     eps, step_dev);
+  hipLaunchKernelGGL(adam_b1zero_k, dim3(flat_blocks(n / 4)), dim3(256), 0, stream, w, g, v, l2_quad_mask, n / 4, lr, lr_dev, l2, l1,
+                     beta2, eps, step_dev);
   MLIIS_CHECK_LAUNCH("adam_b1zero_fused");
   return MLIIS_OK;
 }

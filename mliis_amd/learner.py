@@ -204,8 +204,6 @@ class Learner:
                  augment_batch_capacity: int = 0):
         if skip_decoding:
             raise NotImplementedError("the DeepLabv3+ --skip_decoding decoder is not built (not part of EfficientLab-6-3; SURVEY.md 8(a) a18)")
-        if l1 or darc1:
-            raise NotImplementedError("--l1 / --darc1 regularisers are not built (off in run.sh)")
         if optimizer not in ("sgd", "adam"):
             raise ValueError("optimizer must be 'sgd' or 'adam' (Adam with beta1=0, the reference default)")
         if not torch.cuda.is_available():
@@ -226,6 +224,7 @@ class Learner:
         self.final_layer_scope = "decode/final_layer_weights"
         self.lr, self.optimizer = float(learning_rate), optimizer
         self.l2, self.dice, self.label_smoothing = bool(l2), bool(dice), float(label_smoothing)
+        self.l1, self.darc1 = bool(l1), bool(darc1)
         self.final_layer_dropout_rate = float(final_layer_dropout_rate or 0.0)
         self.drop_connect = drop_connect
         # small-map blocks through the one-launch-per-direction kernels of mbconv_small.hip (MLIIS_SMALL_FUSED=0: op by op, for A/B runs)
@@ -854,11 +853,12 @@ class Learner:
     def _apply(self):
         A = self.arena
         l2 = spec.L2_WEIGHT if self.l2 else 0.0
+        l1 = spec.L2_WEIGHT if self.l1 else 0.0     # (models/regularizers.py:13: the same 5e-4 default)
         if self.optimizer == "sgd":
-            ops.sgd_fused(A.theta, A.grad, self.lr, A.l2_quad_mask, l2, self.lr_dev)
+            ops.sgd_fused(A.theta, A.grad, self.lr, A.l2_quad_mask, l2, self.lr_dev, l1=l1)
         else:
             self.adam_t.add_(1.0)
-            ops.adam_b1zero_fused(A.theta, A.grad, self.adam_v, self.adam_t, self.lr, A.l2_quad_mask, l2, self.lr_dev)
+            ops.adam_b1zero_fused(A.theta, A.grad, self.adam_v, self.adam_t, self.lr, A.l2_quad_mask, l2, self.lr_dev, l1=l1)
 
     def _train_sequence(self, P: _Plan, draw_masks: bool):
         if draw_masks and P.mask_plan is not None:
@@ -866,6 +866,8 @@ class Learner:
         logits = self._forward(P, self.shots_x, P.idx, True)
         ops.softmax_ce(logits, self.shots_y, P.idx, self.label_smoothing, self.dice, 0.0, want_grad=True, want_pred=False,
                        dlogits=P.dlogits, out=P.loss_out, ws=self.ws)
+        if self.darc1:
+            ops.darc1(logits, spec.L2_WEIGHT, dlogits=P.dlogits, out=P.loss_out, ws=self.ws)
         self._backward(P, self.shots_x, P.idx)
         self._apply()
 

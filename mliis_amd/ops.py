@@ -574,6 +574,14 @@ def softmax_ce(logits, labels, idx=None, label_smoothing=0.0, dice=False, extra_
     return out, dlogits, pred
 
 
+def darc1(logits, weight, dlogits=None, out=None, ws: Optional[Workspace] = None):
+    """out[0] += weight * max_pos sum_n |logits[n, pos]|;  dlogits += its gradient (models/regularizers.py:20-22)."""
+    N = logits.shape[0]
+    ws = ws or default_ws()
+    buf = ws.get(2048)
+    lib.call("mliis_darc1", _ptr(_chk(logits)), N, logits.numel() // N, float(weight), _ptr(dlogits), _ptr(out), _ptr(buf), buf.numel(), _stream())
+
+
 def fold_batched(part_base, out_base, desc, total_tiles):
     """One launch folding every deferred weight-gradient slab set (desc: device int64 [n,8], see include/mliis_hip.h)."""
     lib.call("mliis_fold_batched", _ptr(part_base), _ptr(out_base), _ptr(desc), int(desc.shape[0]), int(total_tiles), _stream())
@@ -609,12 +617,12 @@ def rng_masks(state: torch.Tensor, plan: MaskPlan):
 
 
 # ------------------------------------------------------------------------------------------------ optimizer / arena
-def sgd_fused(w, g, lr, l2_quad_mask=None, l2=0.0, lr_dev=None):
-    lib.call("mliis_sgd_fused", _ptr(w), _ptr(g), _ptr(l2_quad_mask), w.numel(), float(lr), _ptr(lr_dev), float(l2), _stream())
+def sgd_fused(w, g, lr, l2_quad_mask=None, l2=0.0, lr_dev=None, l1=0.0):
+    lib.call("mliis_sgd_fused", _ptr(w), _ptr(g), _ptr(l2_quad_mask), w.numel(), float(lr), _ptr(lr_dev), float(l2), float(l1), _stream())
 
 
-def adam_b1zero_fused(w, g, v, step_dev, lr, l2_quad_mask=None, l2=0.0, lr_dev=None, beta2=0.999, eps=1e-8):
-    lib.call("mliis_adam_b1zero_fused", _ptr(w), _ptr(g), _ptr(v), _ptr(l2_quad_mask), w.numel(), float(lr), _ptr(lr_dev), float(l2),
+def adam_b1zero_fused(w, g, v, step_dev, lr, l2_quad_mask=None, l2=0.0, lr_dev=None, beta2=0.999, eps=1e-8, l1=0.0):
+    lib.call("mliis_adam_b1zero_fused", _ptr(w), _ptr(g), _ptr(v), _ptr(l2_quad_mask), w.numel(), float(lr), _ptr(lr_dev), float(l2), float(l1),
              float(beta2), float(eps), _ptr(step_dev), _stream())
 
 

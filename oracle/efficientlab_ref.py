@@ -325,7 +325,7 @@ def forward(a, params, bn, x_nhwc, training=True, dc_scales: Optional[Dict[int, 
     return logits.permute(0, 2, 3, 1), new_moving
 
 
-def loss_fn(a, params, logits, labels, label_smoothing=0.0, dice=False, l2=False):
+def loss_fn(a, params, logits, labels, label_smoothing=0.0, dice=False, l2=False, l1=False, darc1=False):
     """models/efficientlab.py:294-313.  logits/labels NHWC [N,H,W,2]."""
     t = labels.to(logits.dtype)
     if label_smoothing:
@@ -342,6 +342,10 @@ def loss_fn(a, params, logits, labels, label_smoothing=0.0, dice=False, l2=False
         loss = loss - torch.log(2 * iou / (iou + 1))
     if l2:
         loss = loss + 0.0005 * sum(0.5 * (v ** 2).sum() for k, v in params.items() if "batch_normalization" not in k)
+    if darc1:   # models/regularizers.py:20-22 (the reference adds it first, efficientlab.py:304-306)
+        loss = loss + 0.0005 * logits.abs().sum(dim=0).max()
+    if l1:   # models/regularizers.py:13-19
+        loss = loss + 0.0005 * sum(v.abs().sum() for k, v in params.items() if "batch_normalization" not in k)
     return loss
 
 
@@ -351,7 +355,7 @@ def predictions(logits):
 
 
 def inner_step(a, params, bn, x, y, lr, dc_scales=None, dropout_mask=None, label_smoothing=0.0, dice=False, l2=False,
-               weight_decay_rate=1.0, adam_state=None, aspp_masks=None, round_ops=None):
+               weight_decay_rate=1.0, adam_state=None, aspp_masks=None, round_ops=None, l1=False, darc1=False):
     """One `session.run(minimize_op)` (reptile.py:114-121,639-643): fwd + bwd + BN moving update + SGD apply.
     Mutates params / bn in place; returns (loss, grads dict, logits)."""
     if weight_decay_rate != 1.0:  # pre_step_op, meta_learners/variables.py:48-55
@@ -359,7 +363,7 @@ def inner_step(a, params, bn, x, y, lr, dc_scales=None, dropout_mask=None, label
             params[k] = params[k] * weight_decay_rate
     leaves = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()}
     logits, new_moving = forward(a, leaves, bn, x, True, dc_scales, dropout_mask, aspp_masks=aspp_masks, round_ops=round_ops)
-    loss = loss_fn(a, leaves, logits, y, label_smoothing, dice, l2)
+    loss = loss_fn(a, leaves, logits, y, label_smoothing, dice, l2, l1, darc1)
     names = list(leaves)
     grads = torch.autograd.grad(loss, [leaves[k] for k in names], allow_unused=True)
     out_g = {}
@@ -391,7 +395,8 @@ class OracleLearner:
     meta-learner host logic (Gecko/FOMLIS, sharding, all-reduce) can be exercised without a GPU."""
 
     def __init__(self, name="efficientnet-b0", image_size=224, rsd=(2, 4), seed=0, dtype=torch.float64, lr=1e-3,
-                 l2=False, dice=False, label_smoothing=0.0, drop_connect=True, aspp=False, round_ops=None):
+                 l2=False, dice=False, label_smoothing=0.0, drop_connect=True, aspp=False, round_ops=None, l1=False, darc1=False):
+        self.l1, self.darc1 = l1, darc1
         self.round_ops = round_ops    # None | "bf16" | "fp8": emulated reduced-precision matrix-core operands
         self.a = arch(name, image_size, rsd, aspp)
         self.params, self.bn = init_state(self.a, seed, dtype)
@@ -475,7 +480,7 @@ class OracleLearner:
             x, y = self._x[i], self._y[i]
         loss, _, _ = inner_step(self.a, self.params, self.bn, x, y, self.lr if lr is None else lr,
                                 dc_scales if self.drop_connect else None, dropout_mask, self.ls, self.dice, self.l2,
-                                weight_decay_rate, aspp_masks=aspp_masks, round_ops=self.round_ops)
+                                weight_decay_rate, aspp_masks=aspp_masks, round_ops=self.round_ops, l1=self.l1, darc1=self.darc1)
         return loss
 
     def export_all(self):

@@ -391,6 +391,16 @@ def test_sgd_l2_mask_and_arena_algebra():
     ops.adam_b1zero_fused(w2, gg, v, torch.tensor([1.0], device=d), 1e-3)
     vv = 0.001 * g * g
     close(w2, w - 1e-3 * math.sqrt(1 - 0.999) * g / (vv.sqrt() + 1e-8), 1e-5, "adam b1=0")
+    # --l1 (models/regularizers.py:13-19): + l1 * sign(w) on the same (non batch-norm) quads, together with L2; sign(0) = 0
+    w[8:12] = 0.0
+    w3 = f32(w, d)
+    ops.sgd_fused(w3, gg, 0.05, mask.to(torch.uint8).to(d), 5e-4, None, l1=2e-3)
+    close(w3, w - 0.05 * (g + (5e-4 * w + 2e-3 * torch.sign(w)) * l2m), 1e-6, "sgd + l1")
+    v = torch.zeros(n, device=d)
+    w4 = f32(w, d)
+    ops.adam_b1zero_fused(w4, gg, v, torch.tensor([1.0], device=d), 1e-3, mask.to(torch.uint8).to(d), 0.0, None, l1=2e-3)
+    g1 = g + 2e-3 * torch.sign(w) * l2m
+    close(w4, w - 1e-3 * math.sqrt(1 - 0.999) * g1 / ((0.001 * g1 * g1).sqrt() + 1e-8), 1e-5, "adam + l1")
 
 
 def test_errors_are_loud():

@@ -17,6 +17,8 @@ def family(n):
     n = n.replace("void mliis::", "").replace("mliis::", "").split("(")[0]
     if n.startswith("conv_gemm") or n.startswith("conv1x1_stream"):
         return "dense conv fwd / bwd-data (MFMA implicit GEMM)"
+    if n.startswith("mbconv_dw"):
+        return "small-map fused MBConv depthwise half (bn0 + dw + bn1 + pool | their backward)"
     if n.startswith("conv_filter"):
         return "dense conv bwd-filter (MFMA)"
     if n.startswith("dwconv"):
@@ -29,7 +31,7 @@ def family(n):
         return "per-image column sums (SE pool, bias grads)"
     if n.startswith("se_"):
         return "squeeze-excite MLP"
-    if n.startswith("fold") or n.startswith("splitk"):
+    if n.startswith("fold") or n.startswith("splitk") or n.startswith("sk_fixup"):
         return "slab folds (split-K, weight grads)"
     if n.startswith("at::") or n.startswith("__amd"):
         return "torch plumbing (mask RNG, arena copies)"
@@ -70,20 +72,47 @@ def main():
 
     def grid(items):
         return -(-items // 256) * 256
-    L += ["", "## Depthwise layers vs the HBM roofline (8.0 TB/s spec; algorithmic bytes = 4*(in+out+k*k*C) fwd, 4*(dY+dX+k*k*C) bwd-data, + 4*z0 for blocks 1-10 whose backward-data launch also reads z0 and emits the expand BN's backward statistics)", "",
-          "| block | C | k,s | map | fwd us | fwd GB/s (% of 8 TB/s) | bwd-data us | bwd-data GB/s (%) |", "|---|---|---|---|---|---|---|---|"]
-    tf = tb = bf = bb = 0.0
+    L += ["", "## Depthwise layers vs the HBM roofline, IN-STEP (graph replay: operands partly resident in the 256 MiB Infinity Cache, the producer "
+          "ran just before; bench.py's `depthwise_hbm` has the cold-operand figures)", "",
+          "8.0 TB/s spec; algorithmic bytes (SURVEY 8(d)): fwd 4*(in+out+k*k*C); bwd-data 4*(dY+dX+k*k*C) (+ 4*z0 where the launch also emits the expand "
+          "BN's backward sums); bwd-filter 4*(X+dY+k*k*C).  Blocks 6-10 (14x14): the depthwise op lives inside the fused small-map kernels "
+          "(`mbconv_dw_fwd_small_k` = bn0 apply + depthwise + bn1 statistics/apply + SE pooling; `mbconv_dw_bwd_small_k` = bn1 backward + "
+          "depthwise backward-data + backward-filter + bn0 backward): their whole duration is charged to the depthwise bytes (fwd; bwd = bwd-data + bwd-filter bytes).", "",
+          "| block | C | k,s | map | fwd us | fwd % of 8 TB/s | bwd-data us | % | bwd-filter us | % |", "|---|---|---|---|---|---|---|---|---|---|"]
+    tf = tb = tw = bf = bb = bw = 0.0
+    per_f = collections.defaultdict(list)
+    for r in trace:
+        n = r["Kernel_Name"]
+        if "mbconv_dw" in n or "dwconv_bwd_filter" in n:
+            per_f[(n.split("(")[0].replace("void mliis::", ""), int(r["Grid_Size_X"]), int(r["Grid_Size_Y"]))].append(
+                int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+
+    def med(v):
+        return sorted(v)[len(v) // 2] / 1e3
+
+    def grid(items):
+        return -(-items // 256) * 256
+    small_seen = collections.defaultdict(int)
     for b in a.blocks:
         q = b.cexp // 4
+        by = 4.0 * (N * b.h_in ** 2 * b.cexp + N * b.h_out ** 2 * b.cexp + b.k ** 2 * b.cexp)
+        byb = by + (4.0 * N * b.h_in ** 2 * b.cexp if b.expand != 1 else 0.0)   # + z0 where the launch also does the BN statistics
+        sg = ((((b.cexp + 31) // 32) + 7) // 8) * 8 * 8 * 512                     # grid of the fused small-map kernels (threads)
+        kfs = [v for (k, g, gy), v in per_f.items() if k == "mbconv_dw_fwd_small_k<%d>" % b.k and g == sg]
+        kbs = [v for (k, g, gy), v in per_f.items() if k == "mbconv_dw_bwd_small_k<%d>" % b.k and g == sg]
+        if kfs and kbs and b.stride == 1 and N * b.h_in ** 2 <= 2048 and b.expand != 1:
+            mf, mb = med(kfs[0]), med(kbs[0])
+            tf += mf; bf += by; tb += mb; bb += by + by
+            L.append("| %d | %d | %d,%d | %d->%d | %.1f (fused) | %.0f %% | %.1f (fused: bwd-data + bwd-filter) | %.0f %% | | |" % (
+                b.idx, b.cexp, b.k, b.stride, b.h_in, b.h_out, mf, by / mf / 1e3 / 80, mb, 2 * by / mb / 1e3 / 80))
+            continue
         gf = grid(N * b.h_out * (-(-b.h_out // 4)) * q)
         gb = grid(N * b.h_in * (-(-b.h_in // 4)) * q)
-        # training forward: dwconv_fwd_stats_k, grid (ceil(strips / 32) blocks of 256 threads, ceil(C / 32))
         gs = -(-(N * b.h_out * (-(-b.h_out // 4))) // 32) * 256
         kf = [v for (k, g, gy), v in per.items() if (k.startswith("dwconv_fwd_k<%d, %d" % (b.k, b.stride)) and g == gf) or
               (k.startswith("dwconv_fwd_stats_k<%d, %d" % (b.k, b.stride)) and g == gs and gy == -(-b.cexp // 32))]
         kb = [v for (k, g, gy), v in per.items() if k.startswith("dwconv_bwd_data_k<%d, %d" % (b.k, b.stride)) and g == gb]
-        # LDS-tile kernel dwconv_tile_k<K, S, TOH, TOW, TS, FLIP, STATS, DIL, BNB>: 7 x 16 output tiles; forward of the stride-1 5x5
-        # layers, backward-data (tiles the INPUT map; DIL for stride-2 layers; BNB = with the expand BN's backward statistics)
+
         def tiles(h, tow):
             return N * (-(-h // 7)) * (-(-h // tow)) * 256
         cy = -(-b.cexp // 32)
@@ -93,20 +122,27 @@ def main():
         dil = "true" if b.stride == 2 else "false"
         kb += [v for (k, g, gy), v in per.items() if k.startswith("dwconv_tile_k<%d, 1," % b.k) and (", true, false, %s, " % dil) in k and
                g == tiles(b.h_in, 16) and gy == cy]
+        # filter gradient: dwconv_bwd_filter_k<K, S, 4>, identified by its grid (dw_filter_geom of csrc/dwconv.hip)
+        qb = min(q, 64)
+        rp, ny = 256 // qb, -(-q // qb)
+        items = N * b.h_out * (-(-b.h_out // 4))
+        ipb = max(-(-items // max(1, 512 // ny)), rp)
+        ipb = -(-ipb // rp) * rp
+        nblk = -(-items // ipb)
+        kw = [v for (k, g, gy), v in per_f.items() if k.startswith("dwconv_bwd_filter_k<%d, %d" % (b.k, b.stride)) and gy == ny and g == nblk * 256]
         if not kf or not kb:
             continue
-        mf = sorted(kf[0])[len(kf[0]) // 2] / 1e3
-        mb = sorted(kb[0])[len(kb[0]) // 2] / 1e3
-        by = 4.0 * (N * b.h_in ** 2 * b.cexp + N * b.h_out ** 2 * b.cexp + b.k ** 2 * b.cexp)
-        byb = by + (4.0 * N * b.h_in ** 2 * b.cexp if b.expand != 1 else 0.0)   # + z0 where the launch also does the BN statistics
-        tf += mf
-        tb += mb
-        bf += by
-        bb += byb
-        L.append("| %d | %d | %d,%d | %d->%d | %.1f | %.0f (%.0f %%) | %.1f | %.0f (%.0f %%) |" % (
-            b.idx, b.cexp, b.k, b.stride, b.h_in, b.h_out, mf, by / mf / 1e3, by / mf / 1e3 / 80, mb, byb / mb / 1e3, byb / mb / 1e3 / 80))
+        mf, mb = med(kf[0]), med(kb[0])
+        tf += mf; tb += mb; bf += by; bb += byb
+        wtxt = ""
+        if kw:
+            mw = med(kw[0])
+            tw += mw; bw += by
+            wtxt = "%.1f | %.0f %%" % (mw, by / mw / 1e3 / 80)
+        L.append("| %d | %d | %d,%d | %d->%d | %.1f | %.0f %% | %.1f | %.0f %% | %s |" % (
+            b.idx, b.cexp, b.k, b.stride, b.h_in, b.h_out, mf, by / mf / 1e3 / 80, mb, byb / mb / 1e3 / 80, wtxt or " | "))
     if tf:
-        L.append("| **all** | | | | %.1f | %.0f (%.0f %%) | %.1f | %.0f (%.0f %%) |" % (tf, bf / tf / 1e3, bf / tf / 1e3 / 80, tb, bb / tb / 1e3, bb / tb / 1e3 / 80))
+        L.append("| **all** | | | | %.1f | %.0f %% | %.1f | %.0f %% | %.1f | %.0f %% |" % (tf, bf / tf / 1e3 / 80, tb, bb / tb / 1e3 / 80, tw, (bw / tw / 1e3 / 80) if tw else 0))
     open(out, "w").write("\n".join(L) + "\n")
     print("wrote", out)
 
