@@ -236,12 +236,12 @@ __global__ __launch_bounds__(kSmThreads) void mbconv_dw_fwd_small_k(SmallFwd p) 
   float4 acc[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) acc[j] = f4zero();
-  {
-    float4 wreg[K * K];
+  if (st.act) {
+    const float4* imgA = tileA + st.n * g.H * g.W;
+    if constexpr (K == 3) {   // all taps and the window rows in registers, fully unrolled (134 VGPRs, no spills)
+      float4 wreg[K * K];
 #pragma unroll
-    for (int i = 0; i < K * K; ++i) wreg[i] = wl[i];
-    if (st.act) {
-      const float4* imgA = tileA + st.n * g.H * g.W;
+      for (int i = 0; i < K * K; ++i) wreg[i] = wl[i];
 #pragma unroll
       for (int r = 0; r < K + 3; ++r) {
         const int hi = st.h0 - P + r;
@@ -260,7 +260,29 @@ __global__ __launch_bounds__(kSmThreads) void mbconv_dw_fwd_small_k(SmallFwd p) 
             for (int kx = 0; kx < K; ++kx) acc[j] = f4fma(row[kx], wreg[ky * K + kx], acc[j]);
           }
         }
-        if (K == 5) __builtin_amdgcn_sched_barrier(0);   // one window row in flight: hoisting all eight costs 140 VGPRs and spills
+      }
+    } else {
+      // 5x5: a ROLLED loop over the window rows; the taps of the (output row j, filter row r - j) pairs are read from LDS where they
+      // are used (one address for the whole wave: a broadcast).  Unrolled, the compiler hoists the 25 taps (100 VGPRs) and the window
+      // rows on top of each other and spills 65-320 VGPRs -- and every spill is a memory round trip that the next barrier waits for.
+#pragma unroll 1
+      for (int r = 0; r < K + 3; ++r) {
+        const int hi = st.h0 - P + r;
+        const bool rok = (unsigned)hi < (unsigned)g.H;
+        float4 row[K];
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) {
+          const int wi = st.w - P + kx;
+          row[kx] = (rok && (unsigned)wi < (unsigned)g.W) ? imgA[hi * g.W + wi] : f4zero();
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int ky = r - j;
+          if (ky >= 0 && ky < K) {
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) acc[j] = f4fma(row[kx], wl[ky * K + kx], acc[j]);
+          }
+        }
       }
     }
   }
@@ -459,32 +481,42 @@ __global__ __launch_bounds__(kSmThreads) void mbconv_dw_bwd_small_k(SmallBwd p) 
   float4 acc[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) acc[j] = f4zero();
-  {
-    float4 wreg[K * K];
+  if (st.act) {
+    const float4* imgD = tileD + st.n * g.H * g.W;
+    // window row r = image row h0 - P + r; pairs with (j, ky): r - j = (K - 1) - ky.  3x3: unrolled, taps in registers; 5x5: rolled, taps
+    // from LDS where they are used (see the forward kernel)
+    float4 wreg[K == 3 ? K * K : 1];
+    if constexpr (K == 3) {
 #pragma unroll
-    for (int i = 0; i < K * K; ++i) wreg[i] = wl[i];
-    if (st.act) {
-      const float4* imgD = tileD + st.n * g.H * g.W;
+      for (int i = 0; i < K * K; ++i) wreg[i] = wl[i];
+    }
+    auto body = [&](int r) {
+      const int hi = st.h0 - P + r;
+      const bool rok = (unsigned)hi < (unsigned)g.H;
+      float4 row[K];
 #pragma unroll
-      for (int r = 0; r < K + 3; ++r) {   // window row r = image row h0 - P + r; pairs with (j, ky): r - j = (K - 1) - ky
-        const int hi = st.h0 - P + r;
-        const bool rok = (unsigned)hi < (unsigned)g.H;
-        float4 row[K];
+      for (int x = 0; x < K; ++x) {
+        const int wi = st.w - P + x;
+        row[x] = (rok && (unsigned)wi < (unsigned)g.W) ? imgD[hi * g.W + wi] : f4zero();
+      }
 #pragma unroll
-        for (int x = 0; x < K; ++x) {
-          const int wi = st.w - P + x;
-          row[x] = (rok && (unsigned)wi < (unsigned)g.W) ? imgD[hi * g.W + wi] : f4zero();
-        }
+      for (int j = 0; j < 4; ++j) {
+        const int ky = (K - 1) - (r - j);
+        if (ky >= 0 && ky < K) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int ky = (K - 1) - (r - j);
-          if (ky >= 0 && ky < K) {
-#pragma unroll
-            for (int x = 0; x < K; ++x) acc[j] = f4fma(row[x], wreg[ky * K + (K - 1 - x)], acc[j]);
+          for (int x = 0; x < K; ++x) {
+            const float4 wv = K == 3 ? wreg[K == 3 ? ky * K + (K - 1 - x) : 0] : wl[ky * K + (K - 1 - x)];
+            acc[j] = f4fma(row[x], wv, acc[j]);
           }
         }
-        if (K == 5) __builtin_amdgcn_sched_barrier(0);
       }
+    };
+    if constexpr (K == 3) {
+#pragma unroll
+      for (int r = 0; r < K + 3; ++r) body(r);
+    } else {
+#pragma unroll 1
+      for (int r = 0; r < K + 3; ++r) body(r);
     }
   }
   __syncthreads();   // (the filter-gradient partials of all waves are in LDS)

@@ -25,4 +25,12 @@ for blocks in (256, 512, 1024, 2048):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1)
-    print("%d waves/SIMD: %.1f TFLOP/s" % (blocks // 256, blocks * 4 * iters * 8 * 2048.0 / ms / 1e9))
+    print("16x16x4: %d waves/SIMD: %.1f TFLOP/s" % (blocks // 256, blocks * 4 * iters * 8 * 2048.0 / ms / 1e9))
+    it32 = iters // 2
+    lib.mfma_probe32(ctypes.c_void_p(out.data_ptr()), blocks, it32, stream)
+    torch.cuda.synchronize()
+    e0.record()
+    lib.mfma_probe32(ctypes.c_void_p(out.data_ptr()), blocks, it32, stream)
+    e1.record()
+    torch.cuda.synchronize()
+    print("32x32x2: %d waves/SIMD: %.1f TFLOP/s" % (blocks // 256, blocks * 4 * it32 * 4 * 4096.0 / e0.elapsed_time(e1) / 1e9))
