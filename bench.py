@@ -150,7 +150,7 @@ def roofline(L, args):
     d = gemm[dom]
     # The per-op event pairs above include a few microseconds of dispatch per launch.  For the dominant kernel re-issue every one
     # of its launches of an inner step `burst` times back to back between two HIP events on the learner's stream, so that the
-    # figure is the kernel's own duration (what rocprofv3 --kernel-trace reports, profiles/r01_final_kernel_stats.csv).
+    # figure is the kernel's own duration (what rocprofv3 --kernel-trace reports, profiles/r02_final_kernel_stats.csv).
     import torch
 
     def burst_ms(sites, burst=20):
@@ -173,11 +173,11 @@ def roofline(L, args):
     reps_dom = 1
     ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
     traffic, tsrc = None, None
-    tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
     if os.path.exists(tpath):   # PMC counters cannot be sampled from inside this process: taken from the committed rocprofv3 --pmc passes
         k = json.load(open(tpath)).get("kernels", {}).get(dom.replace(", ", ","))
         if k:
-            traffic, tsrc = k["hbm_bytes_per_launch"], "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950-corrected)"
+            traffic, tsrc = k["hbm_bytes_per_launch"], "profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950-corrected)"
     peak = MFMA_F32_PEAK_TFLOPS if args.precision == "fp32" else MFMA_BF16_PEAK_TFLOPS
     out = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
            "traffic": traffic, "traffic_source": tsrc, "launches_per_step": d["n"] // reps_dom, "avg_launch_us": 1e3 * d["ms"] / d["n"],

@@ -10,7 +10,7 @@ from mliis_amd import ops  # noqa: E402
 
 SHAPES = {"rsd2.fuse": (3, 1, 56, 224, 112), "rsd2.br1": (3, 2, 56, 136, 112), "rsd2.br0": (1, 1, 56, 136, 112), "rsd4.fuse": (3, 1, 14, 224, 112),
           "b2.exp": (1, 1, 56, 24, 144), "b1.exp": (1, 1, 112, 16, 96), "b9.proj": (1, 1, 14, 672, 112),
-          "even512": (3, 1, 64, 224, 112)}   # 512 tiles of 64 rows: two whole tiles per CU, no stream-K remainder
+          "even512": (3, 1, 64, 224, 112), "big128": (3, 1, 128, 224, 112)}   # 512 tiles of 64 rows: two whole tiles per CU, no stream-K remainder
 
 
 def main():
