@@ -302,10 +302,20 @@ def _run(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = "nccl"
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        # MLIIS_DIST_BACKEND=gloo is a test hook: it lets the whole N > 1 flow (task sharding, the one all-reduce per meta-step, the
+        # max-over-ranks timing, rank 0's line) be exercised by several ranks that SHARE the GPU of a one-GPU box, where RCCL refuses
+        # duplicate devices.  The driver's runs use nccl (= RCCL).
+        backend = os.environ.get("MLIIS_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            local = local % max(1, torch.cuda.device_count())
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU path (the CPU oracle is only the reported baseline)")
     device = torch.device("cuda", local)
@@ -367,7 +377,8 @@ def _run(args):
         out = {
             "metric": "inner-loop images/sec (EfficientLab-6-3, 224x224, 5-shot)", "value": value, "unit": "images/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "bf16 matrix-core operands, f32 accumulate / tensors", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else ("bf16 matrix-core operands, f32 accumulate / tensors" if args.precision == "bf16" else
+                                                              "fp8 e4m3 operands on the 1x1 forward convs (bf16 elsewhere), f32 accumulate / tensors"), "data": "synthetic",
             "config": {"workload": "%s + %sRSD(4)+RSD(2)), %dx%d, meta-batch=%d (1 task/GPU), "
                                    "%d-shot x %d inner SGD steps of batch %d (%d image fwd+bwd+BN-EMA+SGD per task), %s outer update, fp32 tensors, "
                                    "CE loss, drop-connect on%s" % ("EfficientLab-6-3 (EfficientNet-B0 blocks 0-10" if args.backbone == "efficientnet-b0" else
@@ -375,7 +386,7 @@ def _run(args):
                                                                  "ASPP + " if args.aspp else "", args.image_size, args.image_size, world, shots,
                                                                  args.inner_iters,
                                                                  args.inner_batch, imgs_per_task, "FOMAML(tail 5)" if args.foml else "Reptile",
-                                                                 ("" if args.precision == "fp32" else ", bf16 matrix-core operands") +
+                                                                 ("" if args.precision == "fp32" else ", %s matrix-core operands" % args.precision) +
                                                                  ((", augmentation (aug_rate 0.5, %s)" % (("pixels on the host, %s" % ("%d worker processes" % aug_pool.workers if aug_pool else "inline")) if args.augment_on_host else "pixels on the device"))
                                                                   if args.augment else "") +
                                                                  (", %d tasks per GPU and meta-step" % args.tasks_per_gpu if args.tasks_per_gpu != 1 else "") +
@@ -384,7 +395,7 @@ def _run(args):
             "roofline": roof, "cpu_baseline": cpu,
             # what the first real multi-GPU run can be checked against: ranks, collective library, bytes of the ONE all-reduce(sum) per
             # meta-step (flat task delta + BN moving-average contributions, fp32)
-            "dist": {"world": world, "backend": "nccl (RCCL)" if world > 1 else None, "rccl_version": _rccl_version(),
+            "dist": {"world": world, "backend": ("nccl (RCCL)" if backend == "nccl" else backend + " (test hook, ranks share a GPU)") if world > 1 else None, "rccl_version": _rccl_version(),
                      "allreduce_bytes_per_meta_step": int(meta._comm.numel() * 4) if meta._comm is not None else None,
                      "tasks_per_meta_step": world * args.tasks_per_gpu},
         }

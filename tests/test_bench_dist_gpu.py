@@ -1,0 +1,34 @@
+"""The N > 1 flow of bench.py on the one GPU a development box has: two ranks launched by torch.distributed.run share cuda:0 and talk
+gloo (MLIIS_DIST_BACKEND test hook; RCCL refuses two ranks on one device).  Everything but the collective library itself is the
+driver's multi-GPU path: RANK / LOCAL_RANK / WORLD_SIZE from the launcher, task t -> rank t mod P, ONE all-reduce(sum) over
+[task deltas | BN contributions] per meta-step, barrier + max-over-ranks timing, rank 0 prints the one JSON line."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_two_ranks_on_one_gpu_run_the_sharded_meta_step_and_print_one_line():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = dict(os.environ, MLIIS_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-roofline",
+           "--image-size", "64"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                      # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 2 and d["value"] > 0
+    assert d["dist"]["world"] == 2 and d["dist"]["tasks_per_meta_step"] == 2
+    assert d["dist"]["allreduce_bytes_per_meta_step"] > 8_000_000    # flat theta (2.07 M floats) + BN contributions, fp32
+    assert d["cpu_baseline"] is None                                # the CPU baseline is timed at N = 1 only
+    # value = all ranks' images / max-over-ranks time: 2 tasks x 64 images x steps
+    assert abs(d["value"] - 2 * 64 * d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"])) < 1e-6 * d["value"]
