@@ -70,26 +70,7 @@ def _rccl_version():
         return None
 
 
-def usable_cores() -> int:
-    """Host cores this process may actually use: affinity mask, further limited by a cgroup CPU quota if one is set."""
-    try:
-        n = len(os.sched_getaffinity(0))
-    except AttributeError:
-        n = os.cpu_count() or 1
-    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
-        try:
-            txt = open(path).read().split()
-            if path.endswith("cpu.max"):
-                if txt[0] != "max":
-                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
-            else:
-                q = int(txt[0])
-                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
-                if q > 0:
-                    n = min(n, max(1, q // per))
-        except (OSError, ValueError, IndexError):
-            pass
-    return max(1, n)
+from mliis_amd.hostinfo import usable_cores  # noqa: E402
 
 
 def cpu_baseline(args):
@@ -175,9 +156,15 @@ def roofline(L, args):
     traffic, tsrc = None, None
     tpath = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
     if os.path.exists(tpath):   # PMC counters cannot be sampled from inside this process: taken from the committed rocprofv3 --pmc passes
-        k = json.load(open(tpath)).get("kernels", {}).get(dom.replace(", ", ","))
+        tj = json.load(open(tpath))
+        k = tj.get("kernels", {}).get(dom.replace(", ", ","))
         if k:
-            traffic, tsrc = k["hbm_bytes_per_launch"], "profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950-corrected)"
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            from pmc_traffic import csrc_sha1
+            current = tj.get("csrc_sha1") == csrc_sha1()     # collected on exactly the kernel sources this run was built from?
+            traffic = k["hbm_bytes_per_launch"]
+            tsrc = "profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950-corrected; %s)" % (
+                "collected on the current kernel sources" if current else "STALE: the kernel sources changed since it was collected")
     peak = MFMA_F32_PEAK_TFLOPS if args.precision == "fp32" else MFMA_BF16_PEAK_TFLOPS
     out = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
            "traffic": traffic, "traffic_source": tsrc, "launches_per_step": d["n"] // reps_dom, "avg_launch_us": 1e3 * d["ms"] / d["n"],

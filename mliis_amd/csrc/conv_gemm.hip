@@ -204,14 +204,10 @@ static inline GemmPlan plan_gemm(long long M, int Nout, int C, int ntaps, int nu
   const long long tiles = (long long)g.gx * g.gy;
   if (allow_split && kStreamK && g.tm == 1 && g.gz == 1 && !gemm_narrow(ntaps, C) && nchunks >= kSkMinChunks && tiles > num_cus &&
       tiles % num_cus != 0 && tiles < (1 << 20)) {
-    int full = (int)(tiles / num_cus) * num_cus, rem = (int)(tiles - full);
-    static const bool kSkPure = getenv("MLIIS_SK_PURE") != nullptr;   // experiment: every tile through the parts, two equal parts per CU
-    if (kSkPure && tiles < 2 * num_cus) {
-      full = 0;
-      rem = (int)tiles;
-    }
+    const int full = (int)(tiles / num_cus) * num_cus, rem = (int)(tiles - full);
+    // (pure stream-K -- every tile through the parts, two equal parts per CU -- was measured and not adopted: profiles/r02_notes.md)
     long long total = (long long)rem * nchunks;
-    int parts = (kSkPure && full == 0) ? 2 * num_cus : num_cus;
+    int parts = num_cus;
     if (parts > 4 * rem) parts = 4 * rem;         // at most ~5 slabs per remainder tile for the fix-up to add (a short tail of 16 tiles
                                                   // cut 256 ways cost a 41 us fix-up: 16 workgroups adding 16 slabs each)
     if (parts < rem) parts = rem;                 // (at most two segments per part)

@@ -5,7 +5,9 @@ import torch
 def run_smoke():
     from oracle import efficientlab_ref as R
     from mliis_amd.learner import Learner
+    from mliis_amd.hostinfo import usable_cores
     from mliis_amd.metaseg import synthetic_task
+    torch.set_num_threads(usable_cores())     # (the oracle step: the box shows more CPUs than its cgroup quota grants)
     H, S, idx = 64, 5, [0, 1, 2, 3, 4, 0, 1, 2]
     O = R.OracleLearner(image_size=H, seed=0, dtype=torch.float64)
     L = Learner(image_size=H, seed=1, use_graph=False, drop_connect=False)

@@ -6,8 +6,23 @@ counter unit = KiB; FETCH_SIZE under-reports wide coalesced read streams by exac
 """
 import collections
 import csv
+import glob
+import hashlib
 import json
+import os
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def csrc_sha1():
+    """Fingerprint of the kernel sources the counters were collected on (bench.py recomputes it and reports whether the committed
+    traffic file still describes the kernels it is running)."""
+    h = hashlib.sha1()
+    for f in sorted(glob.glob(os.path.join(ROOT, "mliis_amd", "csrc", "*.h*")) + [os.path.join(ROOT, "include", "mliis_hip.h")]):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
 
 
 def agg(path, counter):
@@ -39,7 +54,7 @@ def main():
                          "raw_FETCH_SIZE_KiB_per_launch": fs / max(fn, 1), "raw_WRITE_SIZE_KiB_per_launch": ws / max(wn, 1)}
     json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `bench.py --steps 1 --warmup 1 --no-graph`; "
                        "read = 2 * FETCH_SIZE * 1024 (gfx950 correction), write = WRITE_SIZE * 1024; averaged over all launches of a symbol",
-               "kernels": res}, open(out, "w"), indent=1, sort_keys=True)
+               "csrc_sha1": csrc_sha1(), "kernels": res}, open(out, "w"), indent=1, sort_keys=True)
     print("wrote", out, len(res), "kernels")
 
 
