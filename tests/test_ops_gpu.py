@@ -49,9 +49,20 @@ def f32(t, d):
 @pytest.mark.parametrize("k,s,H,W,C", [(3, 1, 14, 14, 32), (3, 2, 16, 16, 24), (5, 1, 14, 14, 40), (5, 2, 28, 28, 16),
                                        (3, 2, 15, 17, 8), (5, 2, 9, 11, 8), (3, 1, 5, 3, 4), (5, 1, 7, 30, 144)])
 def test_dwconv_all(k, s, H, W, C):
+    _dwconv_case(k, s, H, W, C, 2)
+
+
+# every depthwise layer of EfficientLab-6-3 at the BASELINE config-2 batch (N = 8, 224x224 input): blocks 0-5 are the large-map kernels,
+# blocks 6-10 the shapes the op-by-op path still serves at evaluation time (training uses the fused small-map kernels, tested below)
+@pytest.mark.parametrize("k,s,H,C", [(3, 1, 112, 32), (3, 2, 112, 96), (3, 1, 56, 144), (5, 2, 56, 144), (5, 1, 28, 240), (3, 2, 28, 240),
+                                     (3, 1, 14, 480), (5, 1, 14, 480), (5, 1, 14, 672)])
+def test_dwconv_baseline_shapes(k, s, H, C):
+    _dwconv_case(k, s, H, H, C, 8, part_floats=1 << 20)
+
+
+def _dwconv_case(k, s, H, W, C, N, part_floats=1 << 16):
     from mliis_amd import ops
     d = dev()
-    N = 2
     x = rnd(N, H, W, C, seed=1).requires_grad_(True)
     w = rnd(k, k, C, 1, seed=2).requires_grad_(True)
     y = R.conv2d_same(nchw(x), w, s, groups=C)
@@ -60,7 +71,7 @@ def test_dwconv_all(k, s, H, W, C):
     yg = ops.dwconv_fwd(f32(x, d), f32(w, d), s)
     close(yg, nhwc(y), 2e-5, "dw fwd")
     # training variant: same output plus the next batch norm's stage-1 statistics
-    part = torch.full((1 << 16,), 7.0, device=d)
+    part = torch.full((part_floats,), 7.0, device=d)
     ys, nblk = ops.dwconv_fwd(f32(x, d), f32(w, d), s, stats_part=part)
     assert torch.equal(ys, yg) and nblk > 0
     sums = part[: nblk * 2 * C].view(nblk, 2, C).double().sum(0).cpu()
@@ -81,6 +92,19 @@ def test_dwconv_all(k, s, H, W, C):
     (3, 1, 10, 10, 4, 8, 2), (3, 2, 9, 9, 12, 20, 1), (3, 1, 8, 8, 20, 4, 2), (3, 3, 8, 8, 28, 16, 1),
 ])
 def test_conv2d_all(k, dil, H, W, Cin, Cout, N):
+    _conv2d_case(k, dil, H, W, Cin, Cout, N)
+
+
+# the dense convs of BASELINE config 2 at their real sizes (N = 8, 224x224 input): MBConv expand / project convs of the large maps
+# (streaming kernel, 128-row tiles), a 14x14 pair (split-K), the RSD(4) convs and the three stream-K decoder launches of RSD(2)
+@pytest.mark.parametrize("k,dil,H,Cin,Cout", [(1, 1, 112, 16, 96), (1, 1, 112, 32, 16), (1, 1, 56, 144, 24), (1, 1, 28, 240, 40),
+                                               (1, 1, 14, 80, 480), (1, 1, 14, 672, 112), (1, 1, 14, 224, 112), (3, 2, 14, 224, 112),
+                                               (1, 1, 56, 136, 112), (3, 2, 56, 136, 112), (3, 1, 56, 224, 112)])
+def test_conv2d_baseline_shapes(k, dil, H, Cin, Cout):
+    _conv2d_case(k, dil, H, H, Cin, Cout, 8)
+
+
+def _conv2d_case(k, dil, H, W, Cin, Cout, N):
     from mliis_amd import ops
     d = dev()
     x = rnd(N, H, W, Cin, seed=4).requires_grad_(True)
@@ -150,7 +174,9 @@ def test_stem(H, W, Co):
 
 # ------------------------------------------------------------------------------------------------ batch norm
 @pytest.mark.parametrize("pre,post,C,rows_hw,N", [(0, 1, 32, 36, 3), (0, 0, 24, 49, 2), (1, 0, 112, 25, 2), (0, 1, 672, 9, 2), (0, 1, 8, 1000, 2),
-                                                  (0, 1, 32, 1500, 3), (1, 0, 40, 3001, 2), (0, 1, 672, 196, 8), (0, 0, 20, 832, 2), (1, 0, 20, 833, 2)])
+                                                  (0, 1, 32, 1500, 3), (1, 0, 40, 3001, 2), (0, 1, 672, 196, 8), (0, 0, 20, 832, 2), (1, 0, 20, 833, 2),
+                                                  # BASELINE config-2 sizes: block-1 expand BN (112x112x96), a project BN, the RSD(2) branch BN
+                                                  (0, 1, 96, 12544, 8), (0, 0, 24, 3136, 8), (1, 0, 112, 3136, 8)])
 def test_bn_train_fwd_bwd(pre, post, C, rows_hw, N):
     from mliis_amd import ops
     d = dev()

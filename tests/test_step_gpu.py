@@ -507,7 +507,7 @@ def test_meta_step_matches_oracle(fomaml, lr_arg):
     H = 64
     tasks_np = [_task(10, H, 30 + i) for i in range(4)]
     (O, mO, tO), (L, mL, tL) = _meta_pair(H, tasks_np, fomaml, rng_mode="per_task", seed=5)
-    n_meta, B = (1, 2) if lr_arg is not None else (2, 3)     # (the two-steps-per-batch variant costs the CPU oracle twice as much)
+    n_meta, B = 2, 3
     for it in range(n_meta):
         for m, ts in ((mO, tO), (mL, tL)):
             m.train_step(ts, num_shots=10 if fomaml else 5, inner_batch_size=4, inner_iters=3, meta_step_size=0.5, meta_batch_size=B,
@@ -515,6 +515,21 @@ def test_meta_step_matches_oracle(fomaml, lr_arg):
         L.synchronize()
         _compare_meta_state(O, L, "meta-step %d " % it)
     assert mO.meta_iter == mL.meta_iter == n_meta
+    L.close()
+
+
+def test_full_size_fomaml_meta_step_config3_flavour():
+    """BASELINE configs[2] as one rank sees it, at the real size: FOMLIS.train_step at 224x224, 10 train shots + 5-shot tail batch
+    (batch sizes 8, 8, 8, 5: two HIP-graph plans), meta-batch 2, against the same host code on the float64 oracle -- trainables and BN
+    moving tensors after the outer update."""
+    _need_gpu()
+    H = 224
+    tasks_np = [_task(10, H, 80 + i) for i in range(3)]
+    (O, mO, tO), (L, mL, tL) = _meta_pair(H, tasks_np, True, rng_mode="per_task", seed=9)
+    for m, ts in ((mO, tO), (mL, tL)):
+        m.train_step(ts, num_shots=10, inner_batch_size=8, inner_iters=4, meta_step_size=0.5, meta_batch_size=2)
+    L.synchronize()
+    _compare_meta_state(O, L, "224 FOMAML ", p_tol=5e-5)
     L.close()
 
 
@@ -539,7 +554,7 @@ class _EmulatedRank:
         return bool(flag)
 
 
-@pytest.mark.parametrize("fomaml,P", [(True, 2), (False, 4)])
+@pytest.mark.parametrize("fomaml,P", [(False, 2), (True, 2), (False, 4), (True, 4)])
 def test_rank_emulation_sharded_meta_step_equals_single_rank(fomaml, P):
     """SURVEY.md 8(e) on one GPU: the P ranks of a sharded meta-step (task t -> rank t mod P, one all-reduce(sum) over
     [sum of task deltas | BN moving-average contributions]) are run one after another on the same learner with the collective
