@@ -128,7 +128,8 @@ int mliis_conv2d_kernel_name(int Nimg, int H, int W, int Cred, int Nout, int ksi
 /*      stats_part (nullable): the epilogue also emits the following batch norm's stage-1 statistics -- per row-block column sums
  *      {sum v, sum v^2} (of swish(v) when stats_swish) as [*stats_nblk][2][Cout], written by the GEMM epilogue or, on a split-K
  *      plan, by the slab fold.  *stats_nblk == 0 means "not produced": the caller must run mliis_bn_stats_partial instead.
- *      Needs >= ceil(M/64) * 2 * Cout floats; requires accumulate == 0. */
+ *      Needs >= ceil(M/16) * 2 * Cout floats (at most one partial per 16-row group; most plans write one per 64 or 128 rows);
+ *      requires accumulate == 0. */
 /*      x_scale (nullable, [Nimg,Cin], 1x1 convs): x[m,c] is multiplied by x_scale[image(m),c] while it is staged -- the
  *      squeeze-excite gate (efficientnet_model.py:251) applied on the fly, so the gated tensor is never materialised. */
 /*      The weight tensor has Cin_total input channels; the conv reads its channels [ci_begin, ci_begin+Cin) against x's Cin

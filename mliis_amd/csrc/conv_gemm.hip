@@ -376,11 +376,44 @@ int mliis_conv2d_plan(int Nimg, int H, int W, int Cred, int Nout, int ksize, int
 
 // Name of the kernel instantiation (as rocprofv3 prints it, without the mliis:: prefix and argument list) that a conv2d_fwd /
 // conv2d_bwd_data call with these shapes launches (has_scale: an x_scale operand is given).
+// ------------------------------------------------------------------------------------------------ long-K 1x1 convs on small maps (conv1x1_ksplit_k)
+// K split over the 8 waves of a workgroup instead of over workgroups + a fold launch: the MBConv project convs forward and expand
+// convs backward-data of the 28x28 / 14x14 maps (K = 240..672, 1568..6272 rows at N = 8).
+constexpr long long kKsplitMaxRows = 8192;
+static const bool kKsplit = getenv("MLIIS_NO_KSPLIT") == nullptr;   // (A/B switch for profiles/r02_notes.md)
+static inline bool ksplit_plan(long long M, int K, int Nout, int num_cus, StreamPlan* sp) {
+  if (!kKsplit || K <= 112 || K > 7 * 128 || M > kKsplitMaxRows || M < 16) return false;
+  sp->kc = (K + 127) / 128;                // 16-wide K groups per wave
+  int nt = 8 / sp->kc;                     // B fragments of the wave's K slice in registers: KC * NT <= 8 quads
+  if (nt < 1) nt = 1;
+  if (nt > 7) nt = 7;                      // (the 8 x 16 x (16 NT + 4) staging tile must stay below 64 KB of static LDS)
+  const int tiles = (Nout + 15) / 16;
+  if (nt > tiles) nt = tiles;
+  const int gy = (tiles + nt - 1) / nt;    // balanced column tiles
+  sp->nt = (tiles + gy - 1) / gy;
+  sp->gy = gy;
+  sp->row_groups = (int)((M + 15) / 16);
+  long long gx = (2LL * num_cus + gy - 1) / gy;   // two 512-thread workgroups per CU
+  if (gx < 1) gx = 1;
+  if (gx > sp->row_groups) gx = sp->row_groups;
+  sp->gx = (int)gx;
+  return true;
+}
+static bool launch_ksplit(const StreamPlan& sp, const ConvGemmParams& p, hipStream_t stream, int precision) {
+  dim3 grid(sp.gx, sp.gy);
+  if (precision != MLIIS_PREC_FP32) return launch_ksplit_lowp(precision, sp.kc, sp.nt, grid, p, sp.row_groups, stream);
+  return launch_ksplit_t<0>(sp.kc, sp.nt, grid, p, sp.row_groups, stream);
+}
+
 int mliis_conv2d_kernel_name(int Nimg, int H, int W, int Cred, int Nout, int ksize, int has_scale, int precision, char* buf, size_t buf_len) {
   MLIIS_REQUIRE(buf && buf_len >= 64, MLIIS_ERR_ARG, "conv2d_kernel_name: buffer too small");
   StreamPlan sp;
   if (ksize == 1 && !has_scale && stream_plan((long long)Nimg * H * W, Cred, Nout, num_cus(), &sp)) {
     snprintf(buf, buf_len, "conv1x1_stream_k<%d, %d, %d>", sp.kc, sp.nt, precision);   // (a call without accumulate / border bias)
+    return MLIIS_OK;
+  }
+  if (ksize == 1 && ksplit_plan((long long)Nimg * H * W, Cred, Nout, num_cus(), &sp)) {
+    snprintf(buf, buf_len, "conv1x1_ksplit_k<%d, %d, 8, %d>", sp.kc, sp.nt, precision);
     return MLIIS_OK;
   }
   GemmPlan g = plan_gemm((long long)Nimg * H * W, Nout, Cred, ksize * ksize, num_cus(), 1);
@@ -440,6 +473,19 @@ int mliis_conv2d_fwd(const float* x, int ldx, const float* x_scale, const float*
       p.stats_swish = stats_swish;
       if (launch_stream(sp, p, stream, precision)) {
         MLIIS_CHECK_LAUNCH("conv2d_fwd_stream");
+        if (stats_part != nullptr) *stats_nblk = sp.gx;
+        return MLIIS_OK;
+      }
+      p.stats_part = nullptr;
+    }
+    // long-K 1x1 convs on small maps (the MBConv project convs, SE gate on load): K split inside the workgroup, one launch
+    if (ksize == 1 && border_bias == nullptr && M * ldx * 4 < (1LL << 31) && M * ldy * 4 < (1LL << 31) &&
+        (stats_part == nullptr || !accumulate) && ksplit_plan(M, Cin, Cout, num_cus(), &sp)) {
+      MLIIS_REQUIRE(stats_part == nullptr || stats_nblk, MLIIS_ERR_ARG, "conv2d_fwd: fused statistics need a stats_nblk output");
+      p.stats_part = stats_part;
+      p.stats_swish = stats_swish;
+      if (launch_ksplit(sp, p, stream, precision)) {
+        MLIIS_CHECK_LAUNCH("conv2d_fwd_ksplit");
         if (stats_part != nullptr) *stats_nblk = sp.gx;
         return MLIIS_OK;
       }
@@ -505,6 +551,12 @@ int mliis_conv2d_bwd_data(const float* dy, int lddy, const float* w, float* dx, 
     if (ksize == 1 && !accumulate && M * lddx * 4 < (1LL << 31) && stream_plan(M, Cout, Cin_out, num_cus(), &sp) &&
         launch_stream(sp, p, stream, precision)) {
       MLIIS_CHECK_LAUNCH("conv2d_bwd_data_stream");
+      return MLIIS_OK;
+    }
+    // long-K 1x1 convs on small maps (backward-data of the MBConv expand convs): K split inside the workgroup, one launch
+    if (ksize == 1 && M * lddx * 4 < (1LL << 31) && M * lddy * 4 < (1LL << 31) && ksplit_plan(M, Cout, Cin_out, num_cus(), &sp) &&
+        launch_ksplit(sp, p, stream, precision)) {
+      MLIIS_CHECK_LAUNCH("conv2d_bwd_data_ksplit");
       return MLIIS_OK;
     }
   }

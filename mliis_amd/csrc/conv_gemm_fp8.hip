@@ -1,5 +1,5 @@
 // fp8 (OCP e4m3) operand instances of the forward dense-conv GEMM (v_mfma_f32_16x16x32_fp8_fp8, fp32 accumulation) and the reduced-
-// precision (bf16 / fp8) instances of the short-K streaming kernel; see conv_gemm_kernels.hpp.  A translation unit of its own so the
+// precision (bf16 / fp8) instances of the short-K streaming kernel and of the small-map long-K kernel; see conv_gemm_kernels.hpp.  A translation unit of its own so the
 // instantiation sets compile in parallel.
 #include "conv_gemm_kernels.hpp"
 
@@ -28,6 +28,11 @@ static bool launch_stream_prec(int kc, int nt, dim3 grid, const ConvGemmParams& 
 bool launch_stream_lowp(int precision, int kc, int nt, dim3 grid, const ConvGemmParams& p, int row_groups, hipStream_t stream) {
   return precision == MLIIS_PREC_FP8 ? launch_stream_prec<2>(kc, nt, grid, p, row_groups, stream)
                                      : launch_stream_prec<1>(kc, nt, grid, p, row_groups, stream);
+}
+
+bool launch_ksplit_lowp(int precision, int kc, int nt, dim3 grid, const ConvGemmParams& p, int row_groups, hipStream_t stream) {
+  return precision == MLIIS_PREC_FP8 ? launch_ksplit_t<2>(kc, nt, grid, p, row_groups, stream)
+                                     : launch_ksplit_t<1>(kc, nt, grid, p, row_groups, stream);
 }
 
 }  // namespace mliis

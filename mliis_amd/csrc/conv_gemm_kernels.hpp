@@ -712,6 +712,151 @@ __global__ __launch_bounds__(256) void conv1x1_stream_k(ConvGemmParams p, int ro
   }
 }
 
+// ------------------------------------------------------------------------------------------------ long-K 1x1 convs on small maps
+// The MBConv project convs forward (K = 240..672 expanded channels, SE gate applied on load) and the expand convs' backward-data
+// (K = the same expanded channels) on the 28x28 / 14x14 maps have 1568-6272 rows: conv_gemm_nk_k needs split-K to occupy the chip
+// (25-98 row tiles) and then a second launch to fold the slabs -- 10 + 5 us for < 1 us of work.  Here the K split happens INSIDE a
+// workgroup: WV waves share one 16-row group, wave w multiplies the K slice [w * 16 KC, (w + 1) * 16 KC) exactly as
+// conv1x1_stream_k does (B fragments of the slice in registers, A straight from memory in MFMA operand layout, the next row group in
+// flight), the WV partial accumulators meet in LDS, and the first 64 NT threads finish the rows: sum in wave order (deterministic),
+// bias, accumulate, coalesced float4 stores, BN statistics.  One launch, no slabs, every load of a row group issued at once.
+// grid = (row-group blocks, column tiles); block = 64 WV threads.
+template <int KC, int NT, int WV, int PREC>
+__global__ __launch_bounds__(64 * WV) void conv1x1_ksplit_k(ConvGemmParams p, int row_groups) {
+  constexpr int BN = 16 * NT, RS = BN + 4, QN = BN / 4;
+  __shared__ __attribute__((aligned(16))) float red[WV][16][RS];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int M = p.Nimg * p.H * p.W, HW = p.H * p.W;
+  const int n0 = blockIdx.y * BN;
+  const int k0 = wave * 16 * KC;
+  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, kBufRecords, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, kBufRecords, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc((void*)(p.a_scale ? p.a_scale : p.A), 0, kBufRecords, 0x00020000);
+  const bool gated = p.a_scale != nullptr;
+  float4 bv[KC][NT];
+#pragma unroll
+  for (int kg = 0; kg < KC; ++kg)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int n = n0 + j * 16 + l15, k = k0 + kg * 16 + g * 4;
+      bv[kg][j] = buf_ld4(rB, (n < p.Nout && k < p.C) ? (unsigned)((n * p.ldb + k) * 4) : kOob);
+    }
+  constexpr int KC2 = (KC + 1) / 2;
+  const float b_qscale = PREC == 2 ? fp8_weight_scale(p.b_amax) : 1.0f;
+  const float out_scale = PREC == 2 ? 1.0f / (p.a_qscale * b_qscale) : 1.0f;
+  bf16x8 bq16[PREC == 1 ? KC2 : 1][PREC == 1 ? NT : 1];
+  long bq8[PREC == 2 ? KC2 : 1][PREC == 2 ? NT : 1];
+  if constexpr (PREC != 0) {
+#pragma unroll
+    for (int k2 = 0; k2 < KC2; ++k2)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const float4 lo = bv[2 * k2][j], hi = (2 * k2 + 1 < KC) ? bv[(2 * k2 + 1 < KC) ? 2 * k2 + 1 : 0][j] : f4zero();
+        if constexpr (PREC == 1) bq16[k2][j] = pack_bf16x8(lo, hi);
+        else bq8[k2][j] = pack_fp8x8(lo, hi, b_qscale);
+      }
+  }
+  // finishing threads: t < 16 * QN own (row t / QN, column quad t % QN) of every row group of this workgroup
+  const bool fin = t < 16 * QN;
+  const int frow = fin ? t / QN : 0, fq = fin ? t - frow * QN : 0;
+  const int fn = n0 + fq * 4;
+  const bool fcol = fin && fn < p.Nout;
+  const float4 fbias = (fcol && p.bias != nullptr) ? ld4(p.bias + fn) : f4zero();
+  float4 s1 = f4zero(), s2 = f4zero();
+  const bool stats = p.stats_part != nullptr;
+  auto load_a = [&](int rg, float4* a) {
+    const int m = rg * 16 + l15;
+    const bool rok = rg < row_groups && m < M;
+    const unsigned so = gated && rok ? (unsigned)((m / HW) * p.C) : 0u;
+#pragma unroll
+    for (int kg = 0; kg < KC; ++kg) {
+      const int k = k0 + kg * 16 + g * 4;
+      const bool ok = rok && k < p.C;
+      a[kg] = buf_ld4(rA, ok ? (unsigned)((m * p.lda + k) * 4) : kOob);
+      if (gated) a[kg] = f4mul(a[kg], buf_ld4(rS, ok ? (so + k) * 4u : kOob));
+    }
+  };
+  int rg = blockIdx.x;
+  float4 a_cur[KC], a_nxt[KC];
+  load_a(rg, a_cur);
+  for (; rg < row_groups; rg += gridDim.x) {
+    load_a(rg + gridDim.x, a_nxt);
+    f32x4 acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if constexpr (PREC == 0) {
+#pragma unroll
+      for (int kg = 0; kg < KC; ++kg)
+#pragma unroll
+        for (int sI = 0; sI < 4; ++sI) {
+          const float a = sI == 0 ? a_cur[kg].x : sI == 1 ? a_cur[kg].y : sI == 2 ? a_cur[kg].z : a_cur[kg].w;
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            const float b = sI == 0 ? bv[kg][j].x : sI == 1 ? bv[kg][j].y : sI == 2 ? bv[kg][j].z : bv[kg][j].w;
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[j], 0, 0, 0);
+          }
+        }
+    } else {
+#pragma unroll
+      for (int k2 = 0; k2 < KC2; ++k2) {
+        const float4 lo = a_cur[2 * k2], hi = (2 * k2 + 1 < KC) ? a_cur[(2 * k2 + 1 < KC) ? 2 * k2 + 1 : 0] : f4zero();
+        if constexpr (PREC == 1) {
+          const bf16x8 a8 = pack_bf16x8(lo, hi);
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, bq16[k2][j], acc[j], 0, 0, 0);
+        } else {
+          const long a8 = pack_fp8x8(lo, hi, p.a_qscale);
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a8, bq8[k2][j], acc[j], 0, 0, 0);
+        }
+      }
+    }
+    // C/D layout: column l15 of tile j, rows 4 g + r -> this wave's plane of the staging tile
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) red[wave][g * 4 + r][j * 16 + l15] = PREC == 2 ? acc[j][r] * out_scale : acc[j][r];
+    __syncthreads();
+    const int m = rg * 16 + frow;
+    if (fcol && m < M) {
+      float4 v = ld4(&red[0][frow][fq * 4]);
+#pragma unroll
+      for (int w = 1; w < WV; ++w) v = f4add(v, ld4(&red[w][frow][fq * 4]));
+      v = f4add(v, fbias);
+      float* dst = p.Cmat + (long long)m * p.ldc + fn;
+      if (p.accumulate) v = f4add(v, ld4(dst));
+      st4(dst, v);
+      if (stats) {
+        if (p.stats_swish) v = make_float4(swish_f(v.x), swish_f(v.y), swish_f(v.z), swish_f(v.w));
+        s1 = f4add(s1, v);
+        s2 = f4fma(v, v, s2);
+      }
+    }
+    __syncthreads();   // the staging tile is rewritten by the next row group
+#pragma unroll
+    for (int kg = 0; kg < KC; ++kg) a_cur[kg] = a_nxt[kg];
+  }
+  if (!stats) return;
+  // column sums over the 16 rows of the finishing threads: through the (now free) staging tile, [v][row][quad]
+  float4* fold = reinterpret_cast<float4*>(&red[0][0][0]);
+  if (fin) {
+    fold[(0 * 16 + frow) * QN + fq] = s1;
+    fold[(1 * 16 + frow) * QN + fq] = s2;
+  }
+  __syncthreads();
+  if (t < 2 * QN) {
+    const int v = t / QN, q = t - v * QN;
+    const int n = n0 + q * 4;
+    if (n < p.Nout) {
+      float4 a = fold[(v * 16) * QN + q];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) a = f4add(a, fold[(v * 16 + r) * QN + q]);
+      st4(p.stats_part + ((long long)blockIdx.x * 2 + v) * p.Nout + n, a);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ backward-filter
 struct FilterGradParams {
   const float* X;
@@ -1003,6 +1148,25 @@ static void launch_gemm_t(const GemmPlan& g, const ConvGemmParams& p, hipStream_
 #undef NK
 }
 
+// conv1x1_ksplit_k instances: KC 16-wide K groups per wave (8 waves: K <= 128 KC), NT column tiles, KC * NT <= 8, NT <= 7
+template <int PREC>
+static bool launch_ksplit_t(int kc, int nt, dim3 grid, const ConvGemmParams& p, int row_groups, hipStream_t stream) {
+  dim3 block(512);
+#define S(KC_, NT_) hipLaunchKernelGGL((conv1x1_ksplit_k<KC_, NT_, 8, PREC>), grid, block, 0, stream, p, row_groups); break;
+  switch (kc) {
+    case 1: switch (nt) { case 1: S(1, 1) case 2: S(1, 2) case 3: S(1, 3) case 4: S(1, 4) case 5: S(1, 5) case 6: S(1, 6) case 7: S(1, 7) default: return false; } break;
+    case 2: switch (nt) { case 1: S(2, 1) case 2: S(2, 2) case 3: S(2, 3) case 4: S(2, 4) default: return false; } break;
+    case 3: switch (nt) { case 1: S(3, 1) case 2: S(3, 2) default: return false; } break;
+    case 4: switch (nt) { case 1: S(4, 1) case 2: S(4, 2) default: return false; } break;
+    case 5: switch (nt) { case 1: S(5, 1) default: return false; } break;
+    case 6: switch (nt) { case 1: S(6, 1) default: return false; } break;
+    case 7: switch (nt) { case 1: S(7, 1) default: return false; } break;
+    default: return false;
+  }
+#undef S
+  return true;
+}
+
 struct FilterPlan {
   int tmf, nt, gx, gy, gz, rows_per_split, multitap;
 };
@@ -1039,6 +1203,7 @@ void launch_gemm_bf16(const GemmPlan& g, const ConvGemmParams& p, hipStream_t st
 void launch_gemm_sk_bf16(const GemmPlan& g, const ConvGemmParams& p, float* slab, hipStream_t stream);
 void launch_gemm_fp8(const GemmPlan& g, const ConvGemmParams& p, hipStream_t stream);            // conv_gemm_fp8.hip
 bool launch_stream_lowp(int precision, int kc, int nt, dim3 grid, const ConvGemmParams& p, int row_groups, hipStream_t stream);   // conv_gemm_fp8.hip
+bool launch_ksplit_lowp(int precision, int kc, int nt, dim3 grid, const ConvGemmParams& p, int row_groups, hipStream_t stream);   // conv_gemm_fp8.hip
 void launch_filter_bf16(const FilterPlan& f, const FilterGradParams& p, hipStream_t stream);
 
 }  // namespace mliis

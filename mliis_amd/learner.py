@@ -109,9 +109,9 @@ class _Plan:
         for b in a.blocks:
             if b.executed:
                 for rows, c in ((N * b.h_in ** 2, b.cexp), (N * b.h_out ** 2, b.cexp), (N * b.h_out ** 2, b.cout)):
-                    need = max(need, -(-rows // 64) * 2 * c, ops.bn_stats_partial_floats(rows, c))
+                    need = max(need, -(-rows // 16) * 2 * c, ops.bn_stats_partial_floats(rows, c))
         for m in a.rsd:
-            need = max(need, -(-(N * m.h * m.h) // 64) * 2 * m.c_out, ops.bn_stats_partial_floats(N * m.h * m.h, m.c_out))
+            need = max(need, -(-(N * m.h * m.h) // 16) * 2 * m.c_out, ops.bn_stats_partial_floats(N * m.h * m.h, m.c_out))
         need = max(need, ops.bn_stats_partial_floats(N * hs * hs, a.stem_out))
         self.stats_part = buf(need + 64)
         # squeeze-excite pooling partials of the bn1 apply pass: [N][ceil(rows_per_img / 128)][C]

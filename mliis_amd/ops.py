@@ -274,7 +274,7 @@ def conv2d_fwd(x, w, bias=None, dil=1, out=None, accumulate=False, ws: Optional[
     prec = _prec(precision)
     if prec == 2 and k == 1 and fp8_w_amax is None:   # stand-alone call: take the tensor's amax here (the learner gets it from the
         fp8_w_amax = w.abs().max().reshape(1)          # per-step weight-shadow launch)
-    if stats_part is not None and stats_part.numel() < (-(-N * H * W // 64)) * 2 * Cout:
+    if stats_part is not None and stats_part.numel() < (-(-N * H * W // 16)) * 2 * Cout:
         raise MliisError("conv2d_fwd: stats_part too small")
     _timed("conv2d_fwd", meta, lambda: lib.call("mliis_conv2d_fwd", _ptr(x), ldx, _ptr(x_scale), _ptr(wt), _ptr(bias), _ptr(border_bias), _ptr(out), ldy, N, H, W,
                                                 Cin_total, ci_begin, Cin, Cout, k,

@@ -636,7 +636,7 @@ def test_conv1x1_short_k_streaming_kernel(H, Cin, Cout, swish):
     (gx,) = torch.autograd.grad(y, [x], dy)
     xg = f32(xw, d)
     out = torch.full((N, H, H, Cout + 12), 5.0, device=d)
-    part = torch.full((1 << 18,), 7.0, device=d)
+    part = torch.full((1 << 19,), 7.0, device=d)
     _, nblk = ops.conv2d_fwd(xg[..., 4:4 + Cin], f32(w, d), f32(b, d), 1, out=out[..., 8:8 + Cout], stats_part=part, stats_swish=swish)
     close(out[..., 8:8 + Cout], nhwc(y), 2e-5, "stream fwd")
     assert (out[..., :8] == 5).all() and (out[..., 8 + Cout:] == 5).all() and nblk > 0
