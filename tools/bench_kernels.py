@@ -1,5 +1,6 @@
-"""Per-layer kernel timings on the GPU (EfficientLab-6-3 shapes, N=8): depthwise fwd/bwd vs the HBM roofline and the
-dense convs vs the fp32-MFMA roofline.  Usage: python tools/bench_kernels.py [--n 8] [--iters 20]"""
+"""Per-layer kernel timings on the GPU (EfficientLab-6-3 shapes, N=8): depthwise fwd/bwd vs the HBM roofline (cold operands:
+rotating copies, through the Python wrappers -- add ~3 us of host time per call to a launch that is shorter than that) and the
+dense convs vs the fp32-MFMA roofline.  Usage: python tools/bench_kernels.py [--n 8] [--iters 20] [--dw-only]"""
 import argparse
 import json
 import os
@@ -34,6 +35,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--out", default=None)
     ap.add_argument("--dense-only", action="store_true")
+    ap.add_argument("--dw-only", action="store_true")
     a = ap.parse_args()
     d = torch.device("cuda:0")
     arch = spec.derive()
@@ -42,15 +44,28 @@ def main():
     tot = dict(fwd_t=0, fwd_b=0, bwd_t=0, bwd_b=0)
     for b in ([] if a.dense_only else arch.blocks):
         C, k, s, hi, ho = b.cexp, b.k, b.stride, b.h_in, b.h_out
-        x = torch.randn(N, hi, hi, C, device=d)
+        # COLD operands: rotate over enough copies of the activation tensors that one is touched again only after > 320 MB of other
+        # traffic (the 256 MiB Infinity Cache is flushed in between), as bench.py's depthwise_hbm does
+        per = 4 * N * C * (hi * hi + ho * ho)
+        R_ = max(1, -(-320 * 2 ** 20 // per))
+        xs = [torch.randn(N, hi, hi, C, device=d) for _ in range(R_)]
         w = torch.randn(k, k, C, 1, device=d)
-        y = torch.empty(N, ho, ho, C, device=d)
-        dy = torch.randn(N, ho, ho, C, device=d)
-        dx = torch.empty_like(x)
+        ys = [torch.empty(N, ho, ho, C, device=d) for _ in range(R_)]
+        dys = [torch.randn(N, ho, ho, C, device=d) for _ in range(R_)]
+        dxs = [torch.empty_like(xs[0]) for _ in range(R_)]
         dw = torch.empty_like(w)
-        tf = timeit(lambda: ops.dwconv_fwd(x, w, s, out=y), a.iters)
-        tbd = timeit(lambda: ops.dwconv_bwd_data(dy, w, s, (hi, hi), out=dx), a.iters)
-        tbf = timeit(lambda: ops.dwconv_bwd_filter(x, dy, k, s, out=dw), a.iters)
+        ctr = [0]
+
+        def rot(fn):
+            def call():
+                i = ctr[0] % R_
+                ctr[0] += 1
+                fn(i)
+            return call
+        tf = timeit(rot(lambda i: ops.dwconv_fwd(xs[i], w, s, out=ys[i])), a.iters)
+        tbd = timeit(rot(lambda i: ops.dwconv_bwd_data(dys[i], w, s, (hi, hi), out=dxs[i])), a.iters)
+        tbf = timeit(rot(lambda i: ops.dwconv_bwd_filter(xs[i], dys[i], k, s, out=dw)), a.iters)
+        x, y = xs[0], ys[0]
         fb = 4 * (x.numel() + y.numel() + w.numel())
         bb = 4 * (2 * x.numel() + y.numel() + 2 * w.numel())
         res["depthwise"].append(dict(block=b.idx, C=C, k=k, s=s, h=hi, fwd_us=tf * 1e6, bwd_data_us=tbd * 1e6, bwd_filter_us=tbf * 1e6,
@@ -70,7 +85,7 @@ def main():
     dense = [("b1.exp", 1, 1, 112, 16, 96), ("b2.exp", 1, 1, 56, 24, 144), ("b4.exp", 1, 1, 28, 40, 240), ("b6.exp", 1, 1, 14, 80, 480),
              ("b9.proj", 1, 1, 14, 672, 112), ("rsd4.br1", 3, 2, 14, 224, 112), ("rsd4.fuse", 3, 1, 14, 224, 112),
              ("rsd2.br0", 1, 1, 56, 136, 112), ("rsd2.br1", 3, 2, 56, 136, 112), ("rsd2.fuse", 3, 1, 56, 224, 112)]
-    for name, k, dil, h, ci, co in dense:
+    for name, k, dil, h, ci, co in ([] if a.dw_only else dense):
         x = torch.randn(N, h, h, ci, device=d)
         w = torch.randn(k, k, ci, co, device=d) * 0.05
         bias = torch.zeros(co, device=d)

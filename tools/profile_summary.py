@@ -15,7 +15,7 @@ from mliis_amd import spec  # noqa: E402
 
 def family(n):
     n = n.replace("void mliis::", "").replace("mliis::", "").split("(")[0]
-    if n.startswith("conv_gemm") or n.startswith("conv1x1_stream"):
+    if n.startswith("conv_gemm") or n.startswith("conv1x1_"):
         return "dense conv fwd / bwd-data (MFMA implicit GEMM)"
     if n.startswith("mbconv_dw"):
         return "small-map fused MBConv depthwise half (bn0 + dw + bn1 + pool | their backward)"
