@@ -152,6 +152,16 @@ size_t mliis_conv2d_bwd_filter_workspace_floats(int Nimg, int H, int W, int Cin,
 int mliis_conv2d_bwd_filter(const float* x, int ldx, const float* x_scale, const float* dy, int lddy, float* dw, int Nimg, int H, int W,
                             int Cin_total, int ci_begin, int Cin, int Cout, int ksize, int dil, int accumulate, float* ws,
                             size_t ws_floats, int precision, hipStream_t stream);
+/*      Weight gradients are off the critical path of the backward pass (nothing but the optimizer reads them): several
+ *      mliis_conv2d_bwd_filter(dw = NULL) calls that resolve to the same kernel instantiation can be issued as ONE launch, so that
+ *      the small-map layers share the chip.  mliis_conv2d_bwd_filter_plan: plan[0..6] = {TMF, NT, multitap, gx, gy, gz (slabs left
+ *      in the workspace), rows_per_split} of a call.  mliis_conv2d_bwd_filter_batched: desc = DEVICE table int64 [nprob][16] rows
+ *      {x, dy, x_scale (0: none), workspace, ldx, lddy, Nimg, H, W, Cin, Cout, ksize, dil, rows_per_split | multitap << 32,
+ *       gx | gy << 20 | gz << 40, first workgroup of the problem in the grid}, blocks = sum of gx * gy * gz, all problems with the
+ *      same (TMF, NT, x_scale present); each problem's slabs land in its workspace exactly as the single call leaves them. */
+int mliis_conv2d_bwd_filter_plan(int Nimg, int H, int W, int Cin, int Cout, int ksize, int* plan);
+int mliis_conv2d_bwd_filter_batched(const long long* desc, int nprob, int blocks, int tmf, int nt, int has_scale, int precision,
+                                    hipStream_t stream);
 
 /* ---- RSD pooled branch (models/efficientlab.py:192-197,220-224) without convolving it: the Cp spatially constant channels
  *      [c_begin, c_begin+Cp) of the 3x3 fuse conv's input become a per-image, per-border-class bias (forward) and need only

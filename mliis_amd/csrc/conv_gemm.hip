@@ -598,6 +598,33 @@ size_t mliis_conv2d_bwd_filter_workspace_floats(int Nimg, int H, int W, int Cin,
   return (size_t)f.gz * ksize * ksize * Cin * Cout;
 }
 
+// The tiling of a filter-gradient call: plan[0..6] = {ci-block factor TMF, column tiles NT, multitap, gx, gy, gz (= slabs),
+// rows_per_split} -- what a caller needs to lay out the descriptor table of mliis_conv2d_bwd_filter_batched.
+int mliis_conv2d_bwd_filter_plan(int Nimg, int H, int W, int Cin, int Cout, int ksize, int* plan) {
+  int rc = conv_check("conv2d_bwd_filter_plan", Nimg, H, W, Cin, Cout, ksize, 1);
+  if (rc) return rc;
+  MLIIS_REQUIRE(plan, MLIIS_ERR_ARG, "conv2d_bwd_filter_plan: null pointer");
+  const FilterPlan f = plan_filter((long long)Nimg * H * W, Cin, Cout, ksize * ksize, num_cus());
+  plan[0] = f.tmf; plan[1] = f.nt; plan[2] = f.multitap; plan[3] = f.gx; plan[4] = f.gy; plan[5] = f.gz; plan[6] = f.rows_per_split;
+  return MLIIS_OK;
+}
+
+// nprob filter-gradient problems that share one kernel instantiation (TMF, NT, x_scale or not) as ONE launch of `blocks` workgroups;
+// every problem leaves its gz slabs in its own workspace region exactly as mliis_conv2d_bwd_filter(dw = NULL) does.  desc: DEVICE
+// table int64 [nprob][16], layout at conv_filter_grad2_batched_k; the caller owns it (it is read by the kernel, not by the host).
+int mliis_conv2d_bwd_filter_batched(const long long* desc, int nprob, int blocks, int tmf, int nt, int has_scale, int precision,
+                                    hipStream_t stream) {
+  int rc = prec_check("conv2d_bwd_filter_batched", precision);
+  if (rc) return rc;
+  MLIIS_REQUIRE(desc && nprob >= 1 && nprob <= 64 && blocks >= 1, MLIIS_ERR_ARG, "conv2d_bwd_filter_batched: bad table (1..64 problems)");
+  MLIIS_REQUIRE(aligned16(desc), MLIIS_ERR_ALIGN, "conv2d_bwd_filter_batched: table must be 16-byte aligned");
+  const bool ok = precision != MLIIS_PREC_FP32 ? launch_filter_batched_bf16(tmf, nt, has_scale != 0, desc, nprob, blocks, stream)
+                                               : launch_filter_batched_t<false>(tmf, nt, has_scale != 0, desc, nprob, blocks, stream);
+  MLIIS_REQUIRE(ok, MLIIS_ERR_ARG, "conv2d_bwd_filter_batched: no instantiation TMF = %d, NT = %d", tmf, nt);
+  MLIIS_CHECK_LAUNCH("conv2d_bwd_filter_batched");
+  return MLIIS_OK;
+}
+
 // dw[k,k,Cin,Cout] (+)= sum_pixels x[pixel + tap offset, ci] * dy[pixel, co]
 int mliis_conv2d_bwd_filter(const float* x, int ldx, const float* x_scale, const float* dy, int lddy, float* dw, int Nimg, int H, int W,
                             int Cin_total, int ci_begin, int Cin, int Cout, int ksize, int dil, int accumulate, float* ws,

@@ -878,18 +878,26 @@ struct FilterGradParams {
 // The pipeline of conv_gemm_nk_k applied to the pixel reduction: branch-free buffer loads
 // (out-of-range rows and halo pixels return zeros), per-row (h, w) advanced incrementally instead of two integer divisions per row
 // and chunk, double-buffered LDS (one barrier per 32-pixel chunk) and a two-chunk register prefetch.
+template <int TMF, int NT>
+struct FilterSm {
+  static constexpr int BCI = 64 * TMF, BN = 16 * NT, BKM = 32;
+  static constexpr int LDX = BCI + 16;
+  static constexpr int LDD = (BN % 32 == 0) ? BN + 16 : BN;
+  static constexpr int BUF_FLOATS = BKM * LDX + BKM * LDD;
+};
+
+// the block (bx, by, bz) of one filter-gradient problem: bx = (tap, channel block), by = output-column tile, bz = pixel split
 template <int TMF, int NT, bool SC, bool BF>
-__global__ __launch_bounds__(256, 2) void conv_filter_grad2_k(FilterGradParams p) {
+__device__ __forceinline__ void conv_filter_grad2_body(const FilterGradParams& p, float* __restrict__ sm, int bx, int by, int bz) {
   constexpr int BCI = 64 * TMF, BN = 16 * NT, BKM = 32;
-  constexpr int LDX = BCI + 16;
-  constexpr int LDD = (BN % 32 == 0) ? BN + 16 : BN;
+  constexpr int LDX = FilterSm<TMF, NT>::LDX;
+  constexpr int LDD = FilterSm<TMF, NT>::LDD;
   constexpr int X_PER_THREAD = (BKM * (BCI / 4)) / 256;  // 2 * TMF
   constexpr int D_TOTAL = BKM * (BN / 4);
   constexpr int D_PER_THREAD = (D_TOTAL + 255) / 256;
   constexpr int X_RSTEP = 256 / (BCI / 4);
-  constexpr int BUF_FLOATS = BKM * LDX + BKM * LDD;
+  constexpr int BUF_FLOATS = FilterSm<TMF, NT>::BUF_FLOATS;
   constexpr int PF = (TMF == 2 && (SC || NT >= 8)) ? 1 : 2;   // register budget: one staging set for the widest instances
-  __shared__ __attribute__((aligned(16))) float sm[2 * BUF_FLOATS];
 
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
@@ -897,10 +905,10 @@ __global__ __launch_bounds__(256, 2) void conv_filter_grad2_k(FilterGradParams p
   const int M = p.Nimg * p.H * p.W;            // host guarantees < 2^31
   const bool mt = p.multitap != 0;
   const int cblocks = mt ? 1 : (p.C + BCI - 1) / BCI;
-  const int tap = mt ? 0 : blockIdx.x / cblocks;
-  const int ci0 = mt ? 0 : (blockIdx.x - tap * cblocks) * BCI;
-  const int n0 = blockIdx.y * BN;
-  const int mbeg = blockIdx.z * p.rows_per_split;
+  const int tap = mt ? 0 : bx / cblocks;
+  const int ci0 = mt ? 0 : (bx - tap * cblocks) * BCI;
+  const int n0 = by * BN;
+  const int mbeg = bz * p.rows_per_split;
   int mend = mbeg + p.rows_per_split;
   if (mend > M) mend = M;
   const int HW = p.H * p.W;
@@ -1076,9 +1084,40 @@ __global__ __launch_bounds__(256, 2) void conv_filter_grad2_k(FilterGradParams p
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         const int n = n0 + j * 16 + l15;
-        if (n < p.Nout) p.partial[((long long)blockIdx.z * Ktot + (long long)tap * p.C + ci) * p.Nout + n] = acc[i][j][r];
+        if (n < p.Nout) p.partial[((long long)bz * Ktot + (long long)tap * p.C + ci) * p.Nout + n] = acc[i][j][r];
       }
     }
+}
+
+template <int TMF, int NT, bool SC, bool BF>
+__global__ __launch_bounds__(256, 2) void conv_filter_grad2_k(FilterGradParams p) {
+  __shared__ __attribute__((aligned(16))) float sm[2 * FilterSm<TMF, NT>::BUF_FLOATS];
+  conv_filter_grad2_body<TMF, NT, SC, BF>(p, sm, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Several filter-gradient problems of ONE instantiation as one grid (the weight gradients are off the critical path of the backward
+// pass: the learner defers the 1x1 MBConv ones to the end and issues them together, so the 14x14 layers' launches -- each far too
+// small for the chip -- share it).  desc: device int64 [nprob][16] rows
+//   {x, dy, x_scale (0: none), slabs, ldx, lddy, Nimg, H, W, Cin, Cout, ksize, dil, rows_per_split | multitap << 32,
+//    gx | gy << 20 | gz << 40, first block of the problem in this grid}
+// (the plan fields from mliis_conv2d_bwd_filter_plan); grid = sum of gx * gy * gz.
+constexpr int kFilterDescWords = 16;
+template <int TMF, int NT, bool SC, bool BF>
+__global__ __launch_bounds__(256, 2) void conv_filter_grad2_batched_k(const long long* __restrict__ desc, int nprob) {
+  __shared__ __attribute__((aligned(16))) float sm[2 * FilterSm<TMF, NT>::BUF_FLOATS];
+  const int b = blockIdx.x;
+  int j = 0;
+  for (int k = 1; k < nprob; ++k)
+    if (b >= (int)desc[k * kFilterDescWords + 15]) j = k;
+  const long long* d = desc + (long long)j * kFilterDescWords;
+  const int ks = (int)d[11];
+  const FilterGradParams p{reinterpret_cast<const float*>(d[0]), (int)d[4], (int)d[6], (int)d[7], (int)d[8], (int)d[9], ks * ks, (int)d[12],
+                           reinterpret_cast<const float*>(d[1]), (int)d[5], (int)d[10], reinterpret_cast<float*>(d[3]),
+                           (int)(d[13] & 0xffffffffLL), reinterpret_cast<const float*>(d[2]), (int)(d[13] >> 32)};
+  const int gx = (int)(d[14] & 0xfffff), gy = (int)((d[14] >> 20) & 0xfffff);
+  const int local = b - (int)d[15];
+  const int bx = local % gx, r = local / gx;
+  conv_filter_grad2_body<TMF, NT, SC, BF>(p, sm, bx, r % gy, r / gy);
 }
 
 // ------------------------------------------------------------------------------------------------ plans + instantiation switches
@@ -1172,6 +1211,37 @@ struct FilterPlan {
 };
 
 template <bool BF>
+static bool launch_filter_batched_t(int tmf, int nt, bool sc, const long long* desc, int nprob, int blocks, hipStream_t stream) {
+  dim3 grid(blocks), block(256);
+#define L(T_, NT_)                                                                                                            \
+  if (sc) hipLaunchKernelGGL((conv_filter_grad2_batched_k<T_, NT_, true, BF>), grid, block, 0, stream, desc, nprob);          \
+  else hipLaunchKernelGGL((conv_filter_grad2_batched_k<T_, NT_, false, BF>), grid, block, 0, stream, desc, nprob);            \
+  break;
+#define ROW(T_)       \
+  switch (nt) {       \
+    case 1: L(T_, 1)  \
+    case 2: L(T_, 2)  \
+    case 3: L(T_, 3)  \
+    case 4: L(T_, 4)  \
+    case 5: L(T_, 5)  \
+    case 6: L(T_, 6)  \
+    case 7: L(T_, 7)  \
+    case 8: L(T_, 8)  \
+    default: return false; \
+  }
+  if (tmf == 2) {
+    ROW(2)
+  } else if (tmf == 1) {
+    ROW(1)
+  } else {
+    return false;
+  }
+#undef ROW
+#undef L
+  return true;
+}
+
+template <bool BF>
 static void launch_filter_t(const FilterPlan& f, const FilterGradParams& p, hipStream_t stream) {
   dim3 grid(f.gx, f.gy, f.gz), block(256);
 #define L(T_, NT_)                                                                                                   \
@@ -1205,5 +1275,6 @@ void launch_gemm_fp8(const GemmPlan& g, const ConvGemmParams& p, hipStream_t str
 bool launch_stream_lowp(int precision, int kc, int nt, dim3 grid, const ConvGemmParams& p, int row_groups, hipStream_t stream);   // conv_gemm_fp8.hip
 bool launch_ksplit_lowp(int precision, int kc, int nt, dim3 grid, const ConvGemmParams& p, int row_groups, hipStream_t stream);   // conv_gemm_fp8.hip
 void launch_filter_bf16(const FilterPlan& f, const FilterGradParams& p, hipStream_t stream);
+bool launch_filter_batched_bf16(int tmf, int nt, bool sc, const long long* desc, int nprob, int blocks, hipStream_t stream);
 
 }  // namespace mliis

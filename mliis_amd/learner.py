@@ -175,6 +175,10 @@ class _Plan:
         # False = masks were handed in by the caller (parity tests inject them) and the graph starts after them
         self.graphs = {}
         self.steps_run = 0
+        # deferred 1x1 MBConv filter gradients: collected during the first (eager) backward pass of this plan, then one launch per
+        # kernel instantiation at the end of every backward pass (ops.FilterBatch)
+        self.wbatch = ops.FilterBatch(dev)
+        self.wbatch_ready = False
         # ---- mask generation inside the step (ops.rng_masks): drop-connect scales of all skip blocks, final-layer dropout, ASPP dropouts
         jobs = []
         if L.drop_connect and nskip:
@@ -217,6 +221,9 @@ class Learner:
         self._conv_fwd = functools.partial(ops.conv2d_fwd, precision=matmul_precision)
         self._conv_bwd_data = functools.partial(ops.conv2d_bwd_data, precision=matmul_precision)
         self._conv_bwd_filter = functools.partial(ops.conv2d_bwd_filter, precision=matmul_precision)
+        # the MBConv 1x1 filter gradients (21 launches, most of them far smaller than the chip) are off the critical path: issue them
+        # together at the end of the backward pass, one launch per kernel instantiation (MLIIS_BATCH_WGRAD=0: one by one, in place)
+        self.batch_wgrad = os.environ.get("MLIIS_BATCH_WGRAD", "1") != "0"
         self.device = torch.device(device)
         torch.cuda.set_device(self.device)
         self.arch = spec.derive(feature_extractor_name, image_size, list(rsd or []), final_layer_dropout_rate, spatial_pyramid_pooling)
@@ -731,6 +738,16 @@ class Learner:
                        dgamma=g[prefix + "/gamma"], dbeta=g[prefix + "/beta"], ws=ws, dskip=dskip, dskip_accumulate=dskip_accumulate,
                        dxsum_part=dxsum_part, stage1=stage1)
 
+        batch = self.batch_wgrad and not self.overlap_wgrad
+
+        def wgrad_1x1(xin, dz, kname, x_scale=None):
+            """filter gradient of an MBConv 1x1 conv: deferred into the plan's batch, or issued here"""
+            if batch:
+                if not P.wbatch_ready:
+                    P.wbatch.add(xin, dz, 1, 1, P.fold_part[kname], x_scale=x_scale)
+                return
+            side(lambda: self._conv_bwd_filter(xin, dz, 1, 1, x_scale=x_scale, partial=P.fold_part[kname]))
+
         rs = sorted([x.scope_index + 1 for x in a.rsd], reverse=True)
         for j in range(len(a.rsd) - 1, -1, -1):
             m, D, nm, r = a.rsd[j], P.rsd[j], self.n_rsd[j], rs[j]
@@ -799,7 +816,7 @@ class Learner:
                  dskip=tgt if b.skip else None, dskip_accumulate=tgt_has)
             if b.skip:
                 tgt_has = True
-            side(lambda B=B, dout=dout, nm=nm: self._conv_bwd_filter(B["a1"], dout, 1, 1, x_scale=B["gate"], partial=P.fold_part[nm["w_proj"]]))
+            wgrad_1x1(B["a1"], dout, nm["w_proj"], x_scale=B["gate"])
             da2 = B["da2"]
             self._conv_bwd_data(dout, w[nm["w_proj"]], 1, out=da2, ws=ws)
             ops.colsum(da2, B["a1"], nseg=N, out=B["dgate"], ws=ws)
@@ -812,7 +829,7 @@ class Learner:
                 ops.mbconv_dw_bwd_small(da2, B["gate"], B["chan_add"], B["z1"], (st1[0], st1[1], w[p1 + "/gamma"], w[p1 + "/beta"]),
                                         w[nm["w_dw"]], B["z0"], (st0[0], st0[1], w[p0 + "/gamma"], w[p0 + "/beta"]),
                                         g[p1 + "/gamma"], g[p1 + "/beta"], g[nm["w_dw"]], g[p0 + "/gamma"], g[p0 + "/beta"], da0)
-                side(lambda B=B, da0=da0, nm=nm: self._conv_bwd_filter(B["x_in"], da0, 1, 1, partial=P.fold_part[nm["w_exp"]]))
+                wgrad_1x1(B["x_in"], da0, nm["w_exp"])
                 self._conv_bwd_data(da0, w[nm["w_exp"]], 1, out=tgt, accumulate=tgt_has, ws=ws)
                 if bi > 0:
                     has_grad[bi - 1] = True
@@ -827,7 +844,7 @@ class Learner:
                 _, nb1 = ops.dwconv_bwd_data(da2, w[nm["w_dw"]], b.stride, (b.h_in, b.h_in), out=da0, part=P.stats_part,
                                              bn=(B["z0"], st0[0], st0[1], w[nm["bn0"] + "/gamma"], w[nm["bn0"] + "/beta"]))
                 bn_b(B["z0"], da0, st0, nm["bn0"], da0, post=True, stage1=(P.stats_part, nb1) if nb1 else None)
-                side(lambda B=B, da0=da0, nm=nm: self._conv_bwd_filter(B["x_in"], da0, 1, 1, partial=P.fold_part[nm["w_exp"]]))
+                wgrad_1x1(B["x_in"], da0, nm["w_exp"])
                 self._conv_bwd_data(da0, w[nm["w_exp"]], 1, out=tgt, accumulate=tgt_has, ws=ws)
             else:
                 if tgt_has:  # no-expand block with identity skip (EfficientNet-B3 stage-1 repeats)
@@ -845,6 +862,9 @@ class Learner:
             join = torch.cuda.Event()
             join.record(self.side_stream)
             self.stream.wait_event(join)
+        if batch:
+            P.wbatch_ready = True
+            P.wbatch.launch(self.matmul_precision)
         ops.se_wgrad_batched(P.se_desc, P.se_tiles)
         # all slabs written -> one batched fold into the gradient arena
         ops.fold_batched(P.fold_buf, A.grad, P.fold_desc, P.fold_tiles)

@@ -331,6 +331,53 @@ def conv2d_bwd_filter(x, dy, k, dil=1, out=None, accumulate=False, ws: Optional[
     return out
 
 
+class FilterBatch:
+    """Deferred filter gradients (the `partial` form of conv2d_bwd_filter: slabs only) grouped by kernel instantiation: add() the
+    calls of a backward pass once (the pointers are fixed for the life of a plan), then launch() issues ONE
+    mliis_conv2d_bwd_filter_batched per group.  The device tables are built here, on the host, once."""
+
+    def __init__(self, device):
+        self.device = device
+        self.groups = {}          # (tmf, nt, has_scale) -> list of rows
+        self.tables = None
+        self._keep = []           # the tensors whose addresses the tables hold
+
+    def add(self, x, dy, k, dil, partial, x_scale=None):
+        N, H, W = dy.shape[:3]
+        _, Cin, ldx = rows_ld(x)
+        _, Cout, lddy = rows_ld(dy)
+        plan = (C.c_int * 8)()
+        lib.call("mliis_conv2d_bwd_filter_plan", N, H, W, Cin, Cout, k, plan)
+        tmf, nt, multitap, gx, gy, gz, rps = [int(v) for v in plan[:7]]
+        if partial.numel() < gz * k * k * Cin * Cout:
+            raise MliisError("FilterBatch: slab region too small")
+        row = [x.data_ptr(), dy.data_ptr(), x_scale.data_ptr() if x_scale is not None else 0, partial.data_ptr(), ldx, lddy, N, H, W, Cin,
+               Cout, k, dil, rps | (multitap << 32), gx | (gy << 20) | (gz << 40), 0]
+        self.groups.setdefault((tmf, nt, x_scale is not None), []).append((row, gx * gy * gz))
+        self._keep += [x, dy, partial, x_scale]
+        self.tables = None
+
+    def _build(self):
+        self.tables = []
+        for (tmf, nt, sc), items in sorted(self.groups.items()):
+            for i0 in range(0, len(items), 64):          # (the kernel scans at most 64 rows)
+                rows, first = [], 0
+                for row, blocks in items[i0:i0 + 64]:
+                    rows.append(row[:15] + [first])
+                    first += blocks
+                self.tables.append((torch.tensor(rows, dtype=torch.int64, device=self.device), len(rows), first, tmf, nt, int(sc)))
+
+    def launch(self, precision="fp32"):
+        if self.tables is None:
+            self._build()
+        prec = _prec(precision)
+        for table, nprob, blocks, tmf, nt, sc in self.tables:
+            lib.call("mliis_conv2d_bwd_filter_batched", _ptr(table), nprob, blocks, tmf, nt, sc, prec, _stream())
+
+    def __len__(self):
+        return sum(len(v) for v in self.groups.values())
+
+
 def rsd_pool_fwd(pool, w, c_begin, out=None, ws: Optional[Workspace] = None):
     """border-class bias [N,9,Cout] of the constant channels [c_begin, c_begin+Cp) of a 3x3 conv with weights w."""
     N, Cp = pool.shape

@@ -893,3 +893,31 @@ def test_conv1x1_fp8_operands(H, Cin, Cout, N, gated):
     close(ops.conv2d_bwd_data(dy32.to(d), w32.to(d), 1, precision="fp8"), gx if not gated else gx, 1e-4, "fp8-mode bwd data (bf16)")
     close(ops.conv2d_bwd_filter(x32.to(d), dy32.to(d), 1, 1, precision="fp8", x_scale=gate.to(d) if gated else None), gw, 1e-4,
           "fp8-mode bwd filter (bf16)")
+
+
+def test_conv2d_bwd_filter_batched_equals_the_single_calls():
+    """ops.FilterBatch / mliis_conv2d_bwd_filter_batched: several filter-gradient problems as one launch per kernel instantiation
+    leave exactly the slabs the single calls leave (bit for bit: same blocks, same order of summation), for 1x1 convs with and
+    without the squeeze-excite gate on load, two map sizes and a 3x3 conv."""
+    from mliis_amd import ops
+    d = dev()
+    probs = []
+    for i, (N, H, Cin, Cout, k, dil, gated) in enumerate([(8, 14, 480, 80, 1, 1, True), (8, 14, 672, 112, 1, 1, True), (8, 14, 480, 112, 1, 1, True),
+                                                          (8, 14, 80, 480, 1, 1, False), (8, 14, 112, 672, 1, 1, False), (5, 28, 40, 240, 1, 1, False),
+                                                          (8, 28, 240, 40, 1, 1, True), (2, 14, 224, 112, 3, 2, False)]):
+        x = f32(rnd(N, H, H, Cin, seed=200 + i), d)
+        dy = f32(rnd(N, H, H, Cout, seed=300 + i), d)
+        gate = f32(torch.sigmoid(rnd(N, Cin, seed=400 + i)), d) if gated else None
+        n = ops.lib.size("mliis_conv2d_bwd_filter_workspace_floats", N, H, H, Cin, Cout, k)
+        probs.append((x, dy, k, dil, gate, torch.full((n,), 9.0, device=d), torch.full((n,), -9.0, device=d)))
+    fb = ops.FilterBatch(d)
+    for x, dy, k, dil, gate, pa, pb in probs:
+        ops.conv2d_bwd_filter(x, dy, k, dil, x_scale=gate, partial=pa)
+        fb.add(x, dy, k, dil, pb, x_scale=gate)
+    assert len(fb) == len(probs)
+    fb.launch()
+    fb.launch()          # idempotent: the slabs are overwritten, not accumulated
+    torch.cuda.synchronize()
+    assert len(fb.tables) < len(probs)     # problems sharing an instantiation share a launch
+    for i, (x, dy, k, dil, gate, pa, pb) in enumerate(probs):
+        assert torch.equal(pa, pb), i
