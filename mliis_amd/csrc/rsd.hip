@@ -183,18 +183,23 @@ size_t mliis_rsd_pool_fwd_workspace_floats(int N, int Co) { return (N > 0 && Co 
 int mliis_rsd_pool_fwd(const float* pool, const float* w, float* border_bias, int N, int Cp, int Cin_total, int c_begin, int Co, float* ws,
                        size_t ws_floats, hipStream_t stream) {
   MLIIS_REQUIRE(pool && w && border_bias, MLIIS_ERR_ARG, "rsd_pool_fwd: null pointer");
-  MLIIS_REQUIRE(N > 0 && N <= kRsdMaxN && Cp > 0 && Co > 0 && Co <= 1024 && c_begin >= 0 && c_begin + Cp <= Cin_total &&
-                    (size_t)N * Cp + kRsdThreads <= 15360,
-                MLIIS_ERR_ARG, "rsd_pool_fwd: bad shape (N <= %d)", kRsdMaxN);
+  MLIIS_REQUIRE(N > 0 && Cp > 0 && Co > 0 && Co <= 1024 && c_begin >= 0 && c_begin + Cp <= Cin_total &&
+                    (size_t)(N < kRsdMaxN ? N : kRsdMaxN) * Cp + kRsdThreads <= 15360,
+                MLIIS_ERR_ARG, "rsd_pool_fwd: bad shape");
   const int S = 8;   // channel chunks: 72 workgroups instead of 9, each streaming 1/8 of the weights
   MLIIS_REQUIRE(ws && (size_t)S * N * 9 * Co <= ws_floats, MLIIS_ERR_WORKSPACE, "rsd_pool_fwd: workspace too small");
-  hipLaunchKernelGGL(rsd_pool_fwd_k, dim3(9, S), dim3(kRsdThreads), ((size_t)N * Cp + kRsdThreads) * sizeof(float), stream, pool, w, ws, N,
-                     Cp, Cin_total, c_begin, Co);
-  MLIIS_CHECK_LAUNCH("rsd_pool_fwd");
-  const long long total = (long long)N * 9 * Co;
-  hipLaunchKernelGGL(fold_flat_k, dim3(ceil_div(total, kFoldX)), dim3(kFoldX, kFoldY), 0, stream, ws, S, total, 1.0f, border_bias, 0, total,
-                     0LL, 0LL);
-  MLIIS_CHECK_LAUNCH("rsd_pool_fwd_fold");
+  // the kernel keeps one accumulator per image in registers: batches beyond kRsdMaxN images go through in groups (the workspace
+  // is reused, stream-ordered)
+  for (int n0 = 0; n0 < N; n0 += kRsdMaxN) {
+    const int nc = N - n0 < kRsdMaxN ? N - n0 : kRsdMaxN;
+    hipLaunchKernelGGL(rsd_pool_fwd_k, dim3(9, S), dim3(kRsdThreads), ((size_t)nc * Cp + kRsdThreads) * sizeof(float), stream,
+                       pool + (size_t)n0 * Cp, w, ws, nc, Cp, Cin_total, c_begin, Co);
+    MLIIS_CHECK_LAUNCH("rsd_pool_fwd");
+    const long long total = (long long)nc * 9 * Co;
+    hipLaunchKernelGGL(fold_flat_k, dim3(ceil_div(total, kFoldX)), dim3(kFoldX, kFoldY), 0, stream, ws, S, total, 1.0f,
+                       border_bias + (size_t)n0 * 9 * Co, 0, total, 0LL, 0LL);
+    MLIIS_CHECK_LAUNCH("rsd_pool_fwd_fold");
+  }
   return MLIIS_OK;
 }
 

@@ -501,7 +501,7 @@ def test_conv1x1_with_se_gate_on_the_fly(H, W, Cin, Cout, N):
     close(ops.conv2d_bwd_filter(xg, f32(nhwc(dy), d), 1, 1, x_scale=gg), gw, 1e-4, "gated filter grad")
 
 
-@pytest.mark.parametrize("H,W,Cc,Cp,Co,N", [(14, 14, 224, 224, 112, 2), (9, 12, 48, 24, 16, 3), (56, 56, 224, 136, 112, 2), (2, 2, 16, 8, 16, 2)])
+@pytest.mark.parametrize("H,W,Cc,Cp,Co,N", [(14, 14, 224, 224, 112, 2), (9, 12, 48, 24, 16, 3), (56, 56, 224, 136, 112, 2), (2, 2, 16, 8, 16, 2), (6, 6, 32, 24, 16, 37)])   # (37 images: three groups of the per-image accumulators)
 def test_rsd_pooled_branch_as_border_bias(H, W, Cc, Cp, Co, N):
     """3x3 conv over [convolved Cc channels | Cp spatially-constant channels] == conv over the Cc channels + per-border-class
     bias; gradients of the constant channels / their weight rows from per-image border sums (rsd.hip)."""

@@ -686,3 +686,20 @@ def test_config5_fp8_pointwise_operands_match_the_quantised_oracle(H, N, steps):
     one) at 64 / 224 px."""
     _need_gpu()
     _lowp_step_check("efficientnet-b0", H, N, "fp8", steps=steps, loss_tol=6e-2, cos_min=0.85, l2_max=0.6, later_loss_tol=0.2)
+
+
+def test_inner_batch_of_32_images():
+    """Batch sizes beyond 16 images (the per-image accumulators of the RSD pooled-branch kernel go through in groups): one step of
+    batch 32 at 64x64 against the oracle."""
+    _need_gpu()
+    H, S = 64, 6
+    idx = [i % S for i in range(32)]
+    O, L = _pair(H, max_shots=32)
+    x, y = _task(S, H, 21)
+    L.load_task(x, y)
+    dc = _dc(O, len(idx), 5)
+    lo, gO, _ = R.inner_step(O.a, O.params, O.bn, torch.tensor(x[idx]).double(), torch.tensor(y[idx]).double(), 1e-3, dc)
+    L.inner_step(idx, dc_scales=dc)
+    ll = L.loss_value()
+    assert abs(ll - lo) <= 1e-4 * max(1.0, abs(lo)), (ll, lo)
+    _compare_state(O, L, gO, "batch 32")
