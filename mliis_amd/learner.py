@@ -175,7 +175,7 @@ class _Plan:
         # False = masks were handed in by the caller (parity tests inject them) and the graph starts after them
         self.graphs = {}
         self.steps_run = 0
-        # deferred 1x1 MBConv filter gradients: collected during the first (eager) backward pass of this plan, then one launch per
+        # deferred dense-conv filter gradients: collected during the first (eager) backward pass of this plan, then one launch per
         # kernel instantiation at the end of every backward pass (ops.FilterBatch)
         self.wbatch = ops.FilterBatch(dev)
         self.wbatch_ready = False
@@ -221,7 +221,7 @@ class Learner:
         self._conv_fwd = functools.partial(ops.conv2d_fwd, precision=matmul_precision)
         self._conv_bwd_data = functools.partial(ops.conv2d_bwd_data, precision=matmul_precision)
         self._conv_bwd_filter = functools.partial(ops.conv2d_bwd_filter, precision=matmul_precision)
-        # the MBConv 1x1 filter gradients (21 launches, most of them far smaller than the chip) are off the critical path: issue them
+        # the dense-conv filter gradients (36 launches, most of them far smaller than the chip) are off the critical path: issue them
         # together at the end of the backward pass, one launch per kernel instantiation (MLIIS_BATCH_WGRAD=0: one by one, in place)
         self.batch_wgrad = os.environ.get("MLIIS_BATCH_WGRAD", "1") != "0"
         self.device = torch.device(device)
@@ -740,13 +740,16 @@ class Learner:
 
         batch = self.batch_wgrad and not self.overlap_wgrad
 
-        def wgrad_1x1(xin, dz, kname, x_scale=None):
-            """filter gradient of an MBConv 1x1 conv: deferred into the plan's batch, or issued here"""
+        def wgrad_conv(xin, dz, kk, dil, key, x_scale=None):
+            """filter gradient of a dense conv (slabs into P.fold_part[key]): deferred into the plan's batch, or issued here"""
             if batch:
                 if not P.wbatch_ready:
-                    P.wbatch.add(xin, dz, 1, 1, P.fold_part[kname], x_scale=x_scale)
+                    P.wbatch.add(xin, dz, kk, dil, P.fold_part[key], x_scale=x_scale)
                 return
-            side(lambda: self._conv_bwd_filter(xin, dz, 1, 1, x_scale=x_scale, partial=P.fold_part[kname]))
+            side(lambda: self._conv_bwd_filter(xin, dz, kk, dil, x_scale=x_scale, partial=P.fold_part[key]))
+
+        def wgrad_1x1(xin, dz, kname, x_scale=None):
+            wgrad_conv(xin, dz, 1, 1, kname, x_scale=x_scale)
 
         rs = sorted([x.scope_index + 1 for x in a.rsd], reverse=True)
         for j in range(len(a.rsd) - 1, -1, -1):
@@ -757,7 +760,7 @@ class Learner:
             bn_b(D["zf"], dO, D["stf"], nf, D["dzf"], pre=True)
             ops.colsum(D["dzf"], None, nseg=N, out=D["tot"], ws=ws)
             ops.rsd_pool_bwd(D["dzf"], D["tot"], D["pool"], w[kf], 2 * co, dw=g[kf], dbias=g[bf], dpool=D["dpool"], ws=ws)
-            side(lambda pyr=pyr, dzf=D["dzf"], kf=kf: self._conv_bwd_filter(pyr, dzf, 3, 1, partial=P.fold_part[kf]))   # rows of the 2*co convolved channels
+            wgrad_conv(pyr, D["dzf"], 3, 1, kf)   # rows of the 2*co convolved channels
             self._conv_bwd_data(D["dzf"], w[kf], 1, ci_begin=0, ci_count=2 * co, out=dpyr, ws=ws)
             d0, d1 = dpyr[..., :co], dpyr[..., co:2 * co]
             bn_b(D["z0"], d0, D["st0"], n0, d0, pre=True, dxsum_part=P.fold_part[b0])   # + conv-bias gradient slabs (batched fold)
@@ -765,13 +768,13 @@ class Learner:
             cmain = cat[..., :m.c_cat - tail] if tail else cat
 
             def wgrad(dz, kname, kk, dil, cmain=cmain, ctail=cat[..., m.c_cat - tail:] if tail else None):
-                self._conv_bwd_filter(cmain, dz, kk, dil, partial=P.fold_part[kname])
+                wgrad_conv(cmain, dz, kk, dil, kname)
                 if ctail is not None:   # the <= 16-channel sliver of the concat (see _Plan)
-                    self._conv_bwd_filter(ctail, dz, kk, dil, partial=P.fold_part[kname + "#tail"])
-            side(lambda d0=d0, k0=k0, wgrad=wgrad: wgrad(d0, k0, 1, 1))
+                    wgrad_conv(ctail, dz, kk, dil, kname + "#tail")
+            wgrad(d0, k0, 1, 1)
             self._conv_bwd_data(d0, w[k0], 1, out=dcat, ws=ws)
             bn_b(D["z1"], d1, D["st1"], n1, d1, pre=True, dxsum_part=P.fold_part[b1])
-            side(lambda d1=d1, k1=k1, wgrad=wgrad: wgrad(d1, k1, 3, 2))
+            wgrad(d1, k1, 3, 2)
             self._conv_bwd_data(d1, w[k1], 2, out=dcat, accumulate=True, ws=ws)
             ops.chan_affine(None, A=D["dpool"], out=dcat, accumulate=True)   # d(mean)/d(cat) = dpool / (H*W) on every pixel
             # dU = dO + dcat[:, :c_deep] (residual);  dS = dcat[:, c_deep:]
