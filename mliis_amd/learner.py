@@ -91,7 +91,21 @@ class _Plan:
             D["bbias"], D["tot"] = buf(N, 9, m.c_out), buf(N, m.c_out)
             D["out"], D["dout"] = buf(N, h, h, m.c_out), buf(N, h, h, m.c_out)
             D["dzf"], D["dpyr"], D["dcat"] = buf(N, h, h, m.c_out), buf(N, h, h, 2 * m.c_out), buf(N, h, h, m.c_cat)
+            if m.upsample_conv:   # the residual operand's own 1x1 branch (efficientlab.py:213-215), deep channels != c_out
+                D["zu"], D["stu"], D["up2"] = buf(N, h, h, m.c_out), vec(m.c_out), buf(N, h, h, m.c_out)
+                D["dzu"], D["dup"] = buf(N, h, h, m.c_out), buf(N, h, h, m.c_deep)
             self.rsd.append(D)
+        self.skipdec = None
+        if a.skipdec is not None:   # --skip_decoding (efficientlab.py:133-149)
+            sd, h = a.skipdec, a.skipdec.h
+            T = dict(cat=buf(N, h, h, sd.c_cat), dcat=None, z0=buf(N, h, h, sd.c_skip), st0=vec(sd.c_skip), dz0=buf(N, h, h, sd.c_skip),
+                     dout=buf(N, h, h, sd.c_sep), sep=[])
+            cin = sd.c_cat
+            for _ in range(2):
+                T["sep"].append(dict(zd=buf(N, h, h, cin), std=vec(cin), ad=buf(N, h, h, cin), zp=buf(N, h, h, sd.c_sep), stp=vec(sd.c_sep),
+                                     out=buf(N, h, h, sd.c_sep), dad=buf(N, h, h, cin), din=buf(N, h, h, cin)))
+                cin = sd.c_sep
+            self.skipdec = T
         self.aspp = None
         if a.aspp:   # --spatial_pyramid_pooling (models/efficientlab.py:248-289)
             h, ci, d = a.aspp_h, a.aspp_cin, a.aspp_dimension
@@ -102,7 +116,7 @@ class _Plan:
         hd = a.h_dec
         self.small, self.dsmall = buf(N, hd, hd, 2), buf(N, hd, hd, 2)
         self.logits, self.dlogits, self.pred = buf(N, H, H, 2), buf(N, H, H, 2), buf(N, H, H, 2)
-        self.drop_mask = buf(N, hd, hd, a.aspp_dimension) if L.final_layer_dropout_rate > 0 else None
+        self.drop_mask = buf(N, hd, hd, a.c_final) if L.final_layer_dropout_rate > 0 else None
         self.loss_out = torch.zeros(4, dtype=torch.float32, device=dev)
         # stage-1 BN statistics handed from a producer (GEMM epilogue / stats kernel) to the fused fold+apply kernel
         need = 0
@@ -112,6 +126,10 @@ class _Plan:
                     need = max(need, -(-rows // 16) * 2 * c, ops.bn_stats_partial_floats(rows, c))
         for m in a.rsd:
             need = max(need, -(-(N * m.h * m.h) // 16) * 2 * m.c_out, ops.bn_stats_partial_floats(N * m.h * m.h, m.c_out))
+        if a.skipdec is not None:
+            rows = N * a.skipdec.h ** 2
+            for c in (a.skipdec.c_skip, a.skipdec.c_cat, a.skipdec.c_sep):
+                need = max(need, -(-rows // 16) * 2 * c, ops.bn_stats_partial_floats(rows, c))
         need = max(need, ops.bn_stats_partial_floats(N * hs * hs, a.stem_out))
         self.stats_part = buf(need + 64)
         # squeeze-excite pooling partials of the bn1 apply pass: [N][ceil(rows_per_img / 128)][C]
@@ -138,10 +156,23 @@ class _Plan:
             if not B["small"]:   # (the small-map backward kernel writes the complete depthwise filter gradient itself: no slabs)
                 add(nm["w_dw"], lib.size("mliis_dwconv_bwd_filter_workspace_floats", N, b.h_in, b.h_in, ce, b.k, b.stride), b.k * b.k * ce)
             add(nm["w_proj"], lib.size("mliis_conv2d_bwd_filter_workspace_floats", N, b.h_out, b.h_out, ce, b.cout, 1), ce * b.cout)
+        if a.skipdec is not None:
+            sd, h = a.skipdec, a.skipdec.h
+            ksk, seps = L.n_skipdec
+            add(ksk[0], lib.size("mliis_conv2d_bwd_filter_workspace_floats", N, h, h, sd.c_skip_in, sd.c_skip, 1), sd.c_skip_in * sd.c_skip)
+            cin = sd.c_cat
+            for (dwn, _, pwn, _) in seps:
+                add(dwn, lib.size("mliis_dwconv_bwd_filter_workspace_floats", N, h, h, cin, 3, 1), 9 * cin)
+                add(pwn, lib.size("mliis_conv2d_bwd_filter_workspace_floats", N, h, h, cin, sd.c_sep, 1), cin * sd.c_sep)
+                cin = sd.c_sep
         self.filter_tail = {}
         for j_rsd, (m, nm) in enumerate(zip(a.rsd, L.n_rsd)):
             (k0, b0_, _), (k1, b1_, _), (kf, _, _) = nm
             co = m.c_out
+            if m.upsample_conv:
+                ku, bu, _ = L.n_rsd_up[j_rsd]
+                add(ku, lib.size("mliis_conv2d_bwd_filter_workspace_floats", N, m.h, m.h, m.c_deep, co, 1), m.c_deep * co)
+                add(bu, ops.bn_bwd_dxsum_floats(N * m.h * m.h, co), co)
             for bias in (b0_, b1_):   # conv-bias gradients: column sums of dz leave the BN backward pass as slabs
                 add(bias, ops.bn_bwd_dxsum_floats(N * m.h * m.h, co), co)
             # filter gradients over the concatenated [deep | skip] channels.  A channel count like 136 = 2 * 64 + 8 leaves a third of
@@ -206,8 +237,6 @@ class Learner:
                  device="cuda:0", use_graph: bool = True, max_shots: int = 16, matmul_precision: str = "fp32",
                  overlap_wgrad: int = 0, wgrad_flush_before: Sequence[int] = (5,), small_fused: Optional[bool] = None,
                  augment_batch_capacity: int = 0):
-        if skip_decoding:
-            raise NotImplementedError("the DeepLabv3+ --skip_decoding decoder is not built (not part of EfficientLab-6-3; SURVEY.md 8(a) a18)")
         if optimizer not in ("sgd", "adam"):
             raise ValueError("optimizer must be 'sgd' or 'adam' (Adam with beta1=0, the reference default)")
         if not torch.cuda.is_available():
@@ -226,7 +255,8 @@ class Learner:
         self.batch_wgrad = os.environ.get("MLIIS_BATCH_WGRAD", "1") != "0"
         self.device = torch.device(device)
         torch.cuda.set_device(self.device)
-        self.arch = spec.derive(feature_extractor_name, image_size, list(rsd or []), final_layer_dropout_rate, spatial_pyramid_pooling)
+        self.arch = spec.derive(feature_extractor_name, image_size, list(rsd or []), final_layer_dropout_rate, spatial_pyramid_pooling,
+                                skip_decoding=bool(skip_decoding))
         self.feature_extractor_name = feature_extractor_name
         self.final_layer_scope = "decode/final_layer_weights"
         self.lr, self.optimizer = float(learning_rate), optimizer
@@ -320,10 +350,17 @@ class Learner:
             d["se"] = (f"{s}/se/conv2d/kernel", f"{s}/se/conv2d/bias", f"{s}/se/conv2d_1/kernel", f"{s}/se/conv2d_1/bias")
             d["w_proj"], d["bn2"] = cvs.pop(0), bns.pop(0)
             self.n_blocks.append(d)
-        self.n_rsd = []
+        self.n_rsd, self.n_rsd_up = [], []
         for m in self.arch.rsd:
             s = f"decode/decode_skip_connections_{m.scope_index}"
-            self.n_rsd.append([(f"{s}/conv2d{x}/kernel", f"{s}/conv2d{x}/bias", f"{s}/batch_normalization{x}") for x in ("", "_1", "_2")])
+            sfx = ["", "_1", "_2", "_3"]
+            trip = lambda x: (f"{s}/conv2d{x}/kernel", f"{s}/conv2d{x}/bias", f"{s}/batch_normalization{x}")   # noqa: E731
+            self.n_rsd_up.append(trip(sfx.pop(0)) if m.upsample_conv else None)   # (created first in the scope, efficientlab.py:213-215)
+            self.n_rsd.append([trip(sfx.pop(0)) for _ in range(3)])
+        s = "decode/decode_skip_connections"   # --skip_decoding: (1x1 kernel, its BN), then per sep_conv (dw kernel, BN, 1x1 kernel, BN)
+        self.n_skipdec = ((f"{s}/conv2d/kernel", f"{s}/batch_normalization"),
+                          [(f"{s}/depthwise_conv2d{'' if j == 0 else '_%d' % j}/depthwise_kernel", f"{s}/batch_normalization_{2 * j + 1}",
+                            f"{s}/conv2d_{j + 1}/kernel", f"{s}/batch_normalization_{2 * j + 2}") for j in range(2)])
         self.n_final = ("decode/final_layer_weights/kernel", "decode/final_layer_weights/bias")
         s = "decode/spatial_pyramid_pooling"
         self.n_aspp = [(f"{sc}/conv2d/kernel", f"{sc}/conv2d/bias") for sc in (f"{s}/branch_0", f"{s}/branch_1", f"{s}/branch_2", s)]
@@ -532,13 +569,16 @@ class Learner:
         A, a, ws, N = self.arena, self.arch, self.ws, P.N
         w, mv = A.w, A.mv
 
-        def bn(xin, st, prefix, y, pre=False, post=False, img_scale=None, res=None, fused=False, nblk=0, pool_part=None):
-            """nblk > 0: the producing conv already left the stage-1 statistics in P.stats_part."""
-            if training:
+        def bn(xin, st, prefix, y, pre=False, post=False, img_scale=None, res=None, fused=False, nblk=0, pool_part=None, always_batch=False):
+            """nblk > 0: the producing conv already left the stage-1 statistics in P.stats_part.  always_batch: a batch norm the
+            reference builds with training=True (the --skip_decoding decoder): batch statistics in inference too, moving averages
+            untouched there."""
+            if training or always_batch:
                 if nblk == 0:
                     nblk = ops.bn_stats_partial(xin, pre, P.stats_part)
                 return ops.bn_apply_fused(xin, P.stats_part, nblk, st[0], st[1], w[prefix + "/gamma"], w[prefix + "/beta"],
-                                          moving=(mv[prefix + "/moving_mean"], mv[prefix + "/moving_variance"]), unbiased_moving_var=fused,
+                                          moving=(mv[prefix + "/moving_mean"], mv[prefix + "/moving_variance"]) if training else None,
+                                          unbiased_moving_var=fused,
                                           pre_swish=pre, post_swish=post, img_scale=img_scale, res=res, out=y, pool_part=pool_part)
             st[0].copy_(mv[prefix + "/moving_mean"])
             torch.rsqrt(mv[prefix + "/moving_variance"] + spec.BN_EPS, out=st[1])
@@ -608,7 +648,28 @@ class Learner:
         dec = ends[4]
         if a.aspp:
             dec = self._aspp_forward(P, dec, training)
-        for m, D, nm, r in zip(a.rsd, P.rsd, self.n_rsd, sorted([x.scope_index + 1 for x in a.rsd], reverse=True)):
+        if a.skipdec is not None:
+            # efficientlab.py:133-149: [resize(embedded, input // 4) | swish(BN(conv1x1(reduction_2)))] -> two sep_convs (dw 3x3 -> BN ->
+            # swish -> 1x1 -> BN -> swish).  Every BN here is built with training=True in the reference.
+            sd, T = a.skipdec, P.skipdec
+            (k0, n0), seps = self.n_skipdec
+            cat = T["cat"]
+            ops.resize_bilinear_fwd(dec, (sd.h, sd.h), out=cat[..., :sd.c_in])
+            nb = conv(ends[2], k0, None, 1, T["z0"], False)
+            bn(T["z0"], T["st0"], n0, cat[..., sd.c_in:], post=True, fused=True, nblk=nb, always_batch=True)
+            cur_sd = cat
+            for S, (dwn, dbn, pwn, pbn) in zip(T["sep"], seps):
+                S["x_in"] = cur_sd
+                if training:
+                    nb = ops.dwconv_fwd(cur_sd, w[dwn], 1, out=S["zd"], stats_part=P.stats_part)[1]
+                else:
+                    ops.dwconv_fwd(cur_sd, w[dwn], 1, out=S["zd"])
+                    nb = 0
+                bn(S["zd"], S["std"], dbn, S["ad"], post=True, fused=True, nblk=nb, always_batch=True)
+                nb = conv(S["ad"], pwn, None, 1, S["zp"], False)
+                cur_sd = bn(S["zp"], S["stp"], pbn, S["out"], post=True, fused=True, nblk=nb, always_batch=True)
+            dec = cur_sd
+        for j_rsd, (m, D, nm, r) in enumerate(zip(a.rsd, P.rsd, self.n_rsd, sorted([x.scope_index + 1 for x in a.rsd], reverse=True))):
             skip = ends[r]
             cat = D["cat"]
             up = cat[..., :m.c_deep]
@@ -617,6 +678,11 @@ class Learner:
             else:
                 ops.resize_bilinear_fwd(dec, (m.h, m.h), out=up)
             ops.chan_affine(skip, out=cat[..., m.c_deep:])
+            res_up = up
+            if m.upsample_conv:   # the residual operand through its own conv -> swish -> BN branch; the concat keeps the resized map
+                ku, bu, nu = self.n_rsd_up[j_rsd]
+                nb = conv(up, ku, bu, 1, D["zu"], True)
+                res_up = bn(D["zu"], D["stu"], nu, D["up2"], pre=True, fused=True, nblk=nb)
             pyr = D["pyr"]
             (k0, b0, n0), (k1, b1, n1), (kf, bf, nf) = nm
             nb = conv(cat, k0, b0, 1, D["z0"], True)
@@ -627,7 +693,7 @@ class Learner:
             ops.colsum(cat, None, nseg=N, scale=1.0 / (m.h * m.h), out=D["pool"], ws=ws)
             ops.rsd_pool_fwd(D["pool"], w[kf], 2 * m.c_out, out=D["bbias"], ws=ws)
             nb = conv(pyr, kf, bf, 1, D["zf"], True, border_bias=D["bbias"])
-            dec = bn(D["zf"], D["stf"], nf, D["out"], pre=True, res=up, fused=True, nblk=nb)
+            dec = bn(D["zf"], D["stf"], nf, D["out"], pre=True, res=res_up, fused=True, nblk=nb)
         mask = P.drop_mask if (training and P.drop_mask is not None) else None
         P.dec_in = dec
         ops.final_conv_fwd(dec, w[self.n_final[0]], w[self.n_final[1]], mask, out=P.small)
@@ -701,9 +767,10 @@ class Learner:
         ops.final_conv_bwd_filter(P.dec_in, P.dsmall, mask, dw=g[self.n_final[0]], db=g[self.n_final[1]], ws=ws)
         ex = [b for b in a.blocks if b.executed]
         has_grad = [False] * len(P.blocks)
-        dtop = P.rsd[-1]["dout"] if P.rsd else (P.aspp["dout"] if a.aspp else P.blocks[-1]["dout"])
-        ops.final_conv_bwd_data(P.dsmall, w[self.n_final[0]], a.aspp_dimension, mask, out=dtop)
-        if not P.rsd and not a.aspp:
+        dtop = P.rsd[-1]["dout"] if P.rsd else (P.skipdec["dout"] if a.skipdec is not None else
+                                                 (P.aspp["dout"] if a.aspp else P.blocks[-1]["dout"]))
+        ops.final_conv_bwd_data(P.dsmall, w[self.n_final[0]], a.c_final, mask, out=dtop)
+        if not P.rsd and not a.aspp and a.skipdec is None:
             has_grad[-1] = True
 
         pending = []
@@ -777,27 +844,67 @@ class Learner:
             wgrad(d1, k1, 3, 2)
             self._conv_bwd_data(d1, w[k1], 2, out=dcat, accumulate=True, ws=ws)
             ops.chan_affine(None, A=D["dpool"], out=dcat, accumulate=True)   # d(mean)/d(cat) = dpool / (H*W) on every pixel
-            # dU = dO + dcat[:, :c_deep] (residual);  dS = dcat[:, c_deep:]
-            ops.chan_affine(dcat[..., :m.c_deep], out=dO, accumulate=True)
+            if m.upsample_conv:
+                # the residual operand came through its own conv -> swish -> BN branch (efficientlab.py:213-215): dO is its gradient;
+                # back through that branch to the resized deep map, where the concat's share joins
+                ku, bu, nu = self.n_rsd_up[j]
+                bn_b(D["zu"], dO, D["stu"], nu, D["dzu"], pre=True, dxsum_part=P.fold_part[bu])
+                wgrad_conv(cat[..., :m.c_deep], D["dzu"], 1, 1, ku)
+                self._conv_bwd_data(D["dzu"], w[ku], 1, out=D["dup"], ws=ws)
+                ops.chan_affine(dcat[..., :m.c_deep], out=D["dup"], accumulate=True)
+                dU = D["dup"]
+            else:
+                # dU = dO + dcat[:, :c_deep] (residual);  dS = dcat[:, c_deep:]
+                ops.chan_affine(dcat[..., :m.c_deep], out=dO, accumulate=True)
+                dU = dO
             # gradient w.r.t. the deep input
             if j > 0:
                 tgt, tgt_has = P.rsd[j - 1]["dout"], False
+            elif a.skipdec is not None:
+                tgt, tgt_has = P.skipdec["dout"], False
             elif a.aspp:
                 tgt, tgt_has = P.aspp["dout"], False
             else:
                 bi = a.reductions[4]
                 tgt, tgt_has = P.blocks[bi]["dout"], has_grad[bi]
             if m.h_in == m.h:
-                ops.chan_affine(dO, out=tgt, accumulate=tgt_has)
+                ops.chan_affine(dU, out=tgt, accumulate=tgt_has)
             else:
-                ops.resize_bilinear_bwd(dO, (m.h_in, m.h_in), out=tgt, accumulate=tgt_has)
-            if j == 0 and not a.aspp:
+                ops.resize_bilinear_bwd(dU, (m.h_in, m.h_in), out=tgt, accumulate=tgt_has)
+            if j == 0 and not a.aspp and a.skipdec is None:
                 has_grad[a.reductions[4]] = True
             # gradient w.r.t. the skip endpoint
             bi = a.reductions[r]
             ops.chan_affine(dcat[..., m.c_deep:], out=P.blocks[bi]["dout"], accumulate=has_grad[bi])
             has_grad[bi] = True
 
+        if a.skipdec is not None:
+            # --skip_decoding decoder backward: the two sep_convs in reverse, then the concat's two halves -- the projected reduction_2
+            # endpoint (conv1x1 -> BN -> swish) and the resized embedded image
+            sd, T = a.skipdec, P.skipdec
+            (k0, n0), seps = self.n_skipdec
+            d = T["dout"]     # from the first RSD module (or, without RSD modules, the final conv's input gradient)
+            for S, (dwn, dbn, pwn, pbn) in zip(reversed(T["sep"]), reversed(seps)):
+                bn_b(S["zp"], d, S["stp"], pbn, d, post=True)
+                wgrad_conv(S["ad"], d, 1, 1, pwn)
+                self._conv_bwd_data(d, w[pwn], 1, out=S["dad"], ws=ws)
+                bn_b(S["zd"], S["dad"], S["std"], dbn, S["dad"], post=True)
+                side(lambda S=S, dwn=dwn: ops.dwconv_bwd_filter(S["x_in"], S["dad"], 3, 1, partial=P.fold_part[dwn]))
+                ops.dwconv_bwd_data(S["dad"], w[dwn], 1, (sd.h, sd.h), out=S["din"])
+                d = S["din"]
+            dcat_sd = d                                   # [N, h, h, c_in + c_skip]
+            bi2 = a.reductions[2]
+            bn_b(T["z0"], dcat_sd[..., sd.c_in:], T["st0"], n0, T["dz0"], post=True)
+            wgrad_conv(P.blocks[bi2]["out"], T["dz0"], 1, 1, k0)
+            self._conv_bwd_data(T["dz0"], w[k0], 1, out=P.blocks[bi2]["dout"], accumulate=has_grad[bi2], ws=ws)
+            has_grad[bi2] = True
+            if a.aspp:
+                tgt, tgt_has = P.aspp["dout"], False
+            else:
+                bi = a.reductions[4]
+                tgt, tgt_has = P.blocks[bi]["dout"], has_grad[bi]
+                has_grad[bi] = True
+            ops.resize_bilinear_bwd(dcat_sd[..., :sd.c_in], (sd.h_in, sd.h_in), out=tgt, accumulate=tgt_has)
         if a.aspp:
             bi = a.reductions[4]
             self._aspp_backward(P, P.blocks[bi]["out"], P.blocks[bi]["dout"], has_grad[bi])

@@ -117,6 +117,22 @@ class RSD:
 
 
 @dataclass
+class SkipDec:
+    """The DeepLabv3+-style decoder of --skip_decoding (models/efficientlab.py:133-149): the embedded image resized to input / 4,
+    concatenated with a 1x1-projected reduction_2 endpoint, refined by two depthwise-separable convs (sep_conv, :445-474)."""
+    h_in: int          # embedded map side
+    h: int             # image_size // 4 = the reduction_2 map side
+    c_in: int          # channels of the embedded image (encoder output or ASPP output)
+    c_skip_in: int     # channels of the reduction_2 endpoint
+    c_skip: int        # aspp_dimension // 2
+    c_sep: int         # aspp_dimension + c_skip: output channels of both sep_convs
+
+    @property
+    def c_cat(self) -> int:
+        return self.c_in + self.c_skip
+
+
+@dataclass
 class Arch:
     name: str
     image_size: int
@@ -133,6 +149,8 @@ class Arch:
     aspp: bool = False              # --spatial_pyramid_pooling: ASPP between the encoder output and the RSD modules
     aspp_cin: int = 0               # channels / map side of the encoder output it reads (reduction_4)
     aspp_h: int = 0
+    skipdec: Optional[SkipDec] = None   # --skip_decoding: between the (ASPP'd) embedded image and the RSD modules
+    c_final: int = 0                # channels of the decoded map the final 1x1 conv reads
 
 
 ASPP_DILATION = 6        # models/efficientlab.py:265-267 (96 / downsample factor 16)
@@ -140,7 +158,7 @@ ASPP_DROPOUT = 0.5       # models/efficientlab.py:248
 
 
 def derive(name: str = "efficientnet-b0", image_size: int = 224, rsd: Optional[List[int]] = (2, 4),
-           final_layer_dropout_rate: float = 0.0, spatial_pyramid_pooling: bool = False) -> Arch:
+           final_layer_dropout_rate: float = 0.0, spatial_pyramid_pooling: bool = False, skip_decoding: bool = False) -> Arch:
     if name not in _COEFFS:
         raise ValueError("feature_extractor_name must be in {} but is: {}".format(sorted(_COEFFS), name))
     width, depth = _COEFFS[name]
@@ -187,6 +205,15 @@ def derive(name: str = "efficientnet-b0", image_size: int = 224, rsd: Optional[L
     aspp_cin, aspp_h = deep_c, deep_h
     if spatial_pyramid_pooling:   # the ASPP output (aspp_dimension channels, same map) replaces the embedded image (efficientlab.py:129-131)
         deep_c = dec["aspp_dimension"]
+    skipdec = None
+    if skip_decoding:   # efficientlab.py:133-149: resize to input // 4, concat with the projected reduction_2 endpoint, two sep_convs
+        sb = blocks[reductions[2]]
+        h4 = image_size // 4
+        if sb.h_out != h4:
+            raise ValueError("--skip_decoding needs the reduction_2 map ({0}x{0}) to be image_size // 4 = {1}".format(sb.h_out, h4))
+        c_skip = dec["aspp_dimension"] // 2
+        skipdec = SkipDec(h_in=deep_h, h=h4, c_in=deep_c, c_skip_in=sb.cout, c_skip=c_skip, c_sep=dec["aspp_dimension"] + c_skip)
+        deep_c, deep_h = skipdec.c_sep, h4
     for i in sorted(rsd or [], reverse=True):
         if not 1 <= i <= 4:
             raise ValueError("rsd entries must be reduction indices 1..4, got {}".format(i))
@@ -199,7 +226,7 @@ def derive(name: str = "efficientnet-b0", image_size: int = 224, rsd: Optional[L
                 rsd=mods, aspp_dimension=dec["aspp_dimension"],
                 final_dropout=bool(final_layer_dropout_rate and final_layer_dropout_rate > 0),
                 h_stem=h_stem, executed_blocks=last + 1, h_dec=deep_h, aspp=bool(spatial_pyramid_pooling), aspp_cin=aspp_cin,
-                aspp_h=aspp_h)
+                aspp_h=aspp_h, skipdec=skipdec, c_final=deep_c)
 
 
 # ----------------------------------------------------------------------------------------------------------
@@ -271,6 +298,21 @@ def param_table(arch: Arch) -> List[Param]:
                              (s, 1, 3 * d)):
             P.append(Param(f"{scope}/conv2d/kernel", (k, k, ci, d), "conv", True, True, "glorot_uniform"))
             P.append(Param(f"{scope}/conv2d/bias", (d,), "bias", True, True, "zeros"))
+    if arch.skipdec is not None:
+        # variable scope decode/decode_skip_connections (efficientlab.py:135): tf.layers.conv2d (glorot-uniform, no bias) + BN, then two
+        # sep_convs = keras DepthwiseConv2D + tf.layers.conv2d, both with conv_kernel_initializer, each followed by a BN.  Default layer
+        # names count up inside the scope.  (The keras layer's variable name under a tf.variable_scope is restated from memory.)
+        sd, s = arch.skipdec, "decode/decode_skip_connections"
+        P.append(Param(f"{s}/conv2d/kernel", (1, 1, sd.c_skip_in, sd.c_skip), "conv", True, True, "glorot_uniform"))
+        _bn(f"{s}/batch_normalization", sd.c_skip, P)
+        cin = sd.c_cat
+        for j in range(2):
+            dw = "depthwise_conv2d" + ("" if j == 0 else f"_{j}")
+            P.append(Param(f"{s}/{dw}/depthwise_kernel", (3, 3, cin, 1), "dw", True, True, "normal_fanout"))
+            _bn(f"{s}/batch_normalization_{2 * j + 1}", cin, P)
+            P.append(Param(f"{s}/conv2d_{j + 1}/kernel", (1, 1, cin, sd.c_sep), "conv", True, True, "normal_fanout"))
+            _bn(f"{s}/batch_normalization_{2 * j + 2}", sd.c_sep, P)
+            cin = sd.c_sep
     for m in arch.rsd:
         s = f"decode/decode_skip_connections_{m.scope_index}"
         convs = []
@@ -283,7 +325,7 @@ def param_table(arch: Arch) -> List[Param]:
             P.append(Param(f"{s}/{cn}/kernel", (k, k, ci, co), "conv", True, True, "glorot_uniform"))
             P.append(Param(f"{s}/{cn}/bias", (co,), "bias", True, True, "zeros"))
             _bn(f"{s}/{bn}", co, P)
-    P.append(Param("decode/final_layer_weights/kernel", (1, 1, arch.aspp_dimension, arch.n_out), "conv", True, True, "normal_fanout"))
+    P.append(Param("decode/final_layer_weights/kernel", (1, 1, arch.c_final, arch.n_out), "conv", True, True, "normal_fanout"))
     P.append(Param("decode/final_layer_weights/bias", (arch.n_out,), "bias", True, True, "zeros"))
     # l2_term's name filter ('batch_normalization' substring) exempts only BN gamma/beta.
     for p in P:
@@ -312,10 +354,15 @@ def forward_macs_per_image(arch: Arch) -> Dict[str, int]:
     if arch.aspp:
         d = arch.aspp_dimension
         out["decoder"] += arch.aspp_h ** 2 * (10 * arch.aspp_cin * d + 3 * d * d) + arch.aspp_cin * d
+    if arch.skipdec is not None:
+        sd = arch.skipdec
+        out["decoder"] += sd.h ** 2 * (sd.c_skip_in * sd.c_skip + 9 * sd.c_cat + sd.c_cat * sd.c_sep + 9 * sd.c_sep + sd.c_sep * sd.c_sep)
     for m in arch.rsd:
         px = m.h ** 2
+        if m.upsample_conv:
+            out["decoder"] += px * m.c_deep * m.c_out
         out["decoder"] += px * (m.c_cat * m.c_out + 9 * m.c_cat * m.c_out + 9 * m.c_pyr * m.c_out)
-    out["decoder"] += arch.h_dec ** 2 * arch.aspp_dimension * arch.n_out
+    out["decoder"] += arch.h_dec ** 2 * arch.c_final * arch.n_out
     return out
 
 

@@ -48,7 +48,7 @@ def _rf(f, w):
     return int(n + 8 if n < 0.9 * f2 else n)
 
 
-def arch(name="efficientnet-b0", image_size=224, rsd=(2, 4), aspp=False):
+def arch(name="efficientnet-b0", image_size=224, rsd=(2, 4), aspp=False, skip_decoding=False):
     w, d, max_block, dec_c = _SCALE[name]
     blocks, cum = [], 0
     for tok in _B0_NOTATION.split():
@@ -69,7 +69,7 @@ def arch(name="efficientnet-b0", image_size=224, rsd=(2, 4), aspp=False):
             red += 1
             endpoints[red] = j
     return dict(name=name, blocks=blocks, endpoints=endpoints, dec_c=dec_c, rsd=sorted(rsd or [], reverse=True),
-                stem=_rf(32, w), last=endpoints[4], image_size=image_size, aspp=bool(aspp))
+                stem=_rf(32, w), last=endpoints[4], image_size=image_size, aspp=bool(aspp), skipdec=bool(skip_decoding))
 
 
 def param_specs(a) -> List[Tuple[str, Tuple[int, ...], str]]:
@@ -100,18 +100,35 @@ def param_specs(a) -> List[Tuple[str, Tuple[int, ...], str]]:
         for scope, k, ci in ((f"{s}/branch_0", 1, deep), (f"{s}/branch_1", 3, deep), (f"{s}/branch_2", 1, deep), (s, 1, 3 * d)):
             out += [(f"{scope}/conv2d/kernel", (k, k, ci, d), "glorot"), (f"{scope}/conv2d/bias", (d,), "zeros")]
         deep = d
+    if a.get("skipdec"):   # models/efficientlab.py:133-149, 445-474 (DeepLabv3+-style decoder, --skip_decoding)
+        s = "decode/decode_skip_connections"
+        c2, csk = a["blocks"][a["endpoints"][2]]["o"], a["dec_c"] // 2
+        csep = a["dec_c"] + csk
+        out += [(f"{s}/conv2d/kernel", (1, 1, c2, csk), "glorot"),
+                (f"{s}/batch_normalization/gamma", (csk,), "ones"), (f"{s}/batch_normalization/beta", (csk,), "zeros")]
+        cin = deep + csk
+        for j in range(2):
+            dwn = "depthwise_conv2d" + ("" if j == 0 else f"_{j}")
+            out += [(f"{s}/{dwn}/depthwise_kernel", (3, 3, cin, 1), "normal"),
+                    (f"{s}/batch_normalization_{2 * j + 1}/gamma", (cin,), "ones"), (f"{s}/batch_normalization_{2 * j + 1}/beta", (cin,), "zeros"),
+                    (f"{s}/conv2d_{j + 1}/kernel", (1, 1, cin, csep), "normal"),
+                    (f"{s}/batch_normalization_{2 * j + 2}/gamma", (csep,), "ones"), (f"{s}/batch_normalization_{2 * j + 2}/beta", (csep,), "zeros")]
+            cin = csep
+        deep = csep
     for r in a["rsd"]:
         s = f"decode/decode_skip_connections_{r - 1}"
         cs = a["blocks"][a["endpoints"][r]]["o"]
         cc, co = deep + cs, a["dec_c"]
-        assert deep == co, "upsample 1x1 branch not restated (never hit for b0/b3 with rsd 2 4)"
-        for j, (k, ci) in enumerate([(1, cc), (3, cc), (3, 2 * co + cc)]):
+        convs = [(1, cc), (3, cc), (3, 2 * co + cc)]
+        if deep != co:   # "Increasing upsampled skip connection number of filters with 1x1 conv" (efficientlab.py:213-215): created first
+            convs = [(1, deep)] + convs
+        for j, (k, ci) in enumerate(convs):
             sfx = "" if j == 0 else f"_{j}"
             out += [(f"{s}/conv2d{sfx}/kernel", (k, k, ci, co), "glorot"), (f"{s}/conv2d{sfx}/bias", (co,), "zeros"),
                     (f"{s}/batch_normalization{sfx}/gamma", (co,), "ones"),
                     (f"{s}/batch_normalization{sfx}/beta", (co,), "zeros")]
         deep = co
-    out += [("decode/final_layer_weights/kernel", (1, 1, a["dec_c"], 2), "normal"),
+    out += [("decode/final_layer_weights/kernel", (1, 1, deep, 2), "normal"),
             ("decode/final_layer_weights/bias", (2,), "zeros")]
     return out
 
@@ -301,20 +318,41 @@ def forward(a, params, bn, x_nhwc, training=True, dc_scales: Optional[Dict[int, 
         b2 = b2.expand(-1, -1, dec.shape[2], dec.shape[3])     # bilinear align_corners resize of a 1x1 map = broadcast
         dec = drop(swish(cv(torch.cat([b2, b1, b0], dim=1), s)), mk[3])
         tap("aspp", dec)
+    if a.get("skipdec"):
+        # efficientlab.py:133-149: resize to input // 4, concat with swish(BN(conv1x1(reduction_2 endpoint))), two sep_convs
+        # (depthwise 3x3 -> BN -> swish -> 1x1 -> BN -> swish, :445-474).  These batch norms are built with training=True: batch
+        # statistics in inference too (their moving averages only move when the train op's update ops run).
+        s = "decode/decode_skip_connections"
+
+        def BNT(t, prefix):
+            return batch_norm(t, P[prefix + "/gamma"], P[prefix + "/beta"], bn[prefix], True, new_moving, prefix, True)
+        sk = ends[2]
+        up4 = resize_bilinear_ac(dec, sk.shape[2:])
+        dsk = swish(BNT(mm_conv(sk, P[f"{s}/conv2d/kernel"], round_ops=round_ops), f"{s}/batch_normalization"))
+        dec = torch.cat([up4, dsk], dim=1)
+        for j in range(2):
+            dwn = "depthwise_conv2d" + ("" if j == 0 else f"_{j}")
+            dec = swish(BNT(conv2d_same(dec, P[f"{s}/{dwn}/depthwise_kernel"], 1, groups=dec.shape[1]), f"{s}/batch_normalization_{2 * j + 1}"))
+            dec = swish(BNT(mm_conv(dec, P[f"{s}/conv2d_{j + 1}/kernel"], round_ops=round_ops), f"{s}/batch_normalization_{2 * j + 2}"))
+        tap("skipdec", dec)
     for r in a["rsd"]:
         s = f"decode/decode_skip_connections_{r - 1}"
         skip = ends[r]
         up = resize_bilinear_ac(dec, skip.shape[2:])
         cat = torch.cat([up, skip], dim=1)
+        j0 = [0]
 
-        def branch(t, j, k, d):
-            sfx = "" if j == 0 else f"_{j}"
+        def branch(t, k, d):
+            sfx = "" if j0[0] == 0 else f"_{j0[0]}"
+            j0[0] += 1
             t = mm_conv(t, P[f"{s}/conv2d{sfx}/kernel"], 1, d, bias=P[f"{s}/conv2d{sfx}/bias"], round_ops=round_ops)
             return BN(swish(t), f"{s}/batch_normalization{sfx}", fused=True)
-        b0 = branch(cat, 0, 1, 1)
-        b1 = branch(cat, 1, 3, 2)
+        if up.shape[1] != a["dec_c"]:   # efficientlab.py:213-215: the residual operand gets its own 1x1 branch; the concat keeps `up`
+            up = branch(up, 1, 1)
+        b0 = branch(cat, 1, 1)
+        b1 = branch(cat, 3, 2)
         b2 = cat.mean(dim=(2, 3), keepdim=True).expand_as(cat)
-        dec = branch(torch.cat([b0, b1, b2], dim=1), 2, 3, 1) + up
+        dec = branch(torch.cat([b0, b1, b2], dim=1), 3, 1) + up
         tap(f"rsd_{r}", dec)
     if dropout_mask is not None and training:
         dec = dec * dropout_mask.to(dt).permute(0, 3, 1, 2)
@@ -395,10 +433,11 @@ class OracleLearner:
     meta-learner host logic (Gecko/FOMLIS, sharding, all-reduce) can be exercised without a GPU."""
 
     def __init__(self, name="efficientnet-b0", image_size=224, rsd=(2, 4), seed=0, dtype=torch.float64, lr=1e-3,
-                 l2=False, dice=False, label_smoothing=0.0, drop_connect=True, aspp=False, round_ops=None, l1=False, darc1=False):
+                 l2=False, dice=False, label_smoothing=0.0, drop_connect=True, aspp=False, round_ops=None, l1=False, darc1=False,
+                 skip_decoding=False):
         self.l1, self.darc1 = l1, darc1
         self.round_ops = round_ops    # None | "bf16" | "fp8": emulated reduced-precision matrix-core operands
-        self.a = arch(name, image_size, rsd, aspp)
+        self.a = arch(name, image_size, rsd, aspp, skip_decoding)
         self.params, self.bn = init_state(self.a, seed, dtype)
         self.dtype, self.lr, self.l2, self.dice, self.ls = dtype, lr, l2, dice, label_smoothing
         self.drop_connect = drop_connect

@@ -124,3 +124,24 @@ def test_oracle_aspp_dropout_sites_and_inference():
         zero_out = [ones[0], ones[1], ones[2], torch.zeros(2, h, h, d)]
         R.forward(a, P, bn, x, True, aspp_masks=zero_out, taps=taps)
         assert taps["aspp"].abs().max().item() == 0.0
+
+
+def test_skip_decoding_variables_match_the_oracle_graph():
+    """--skip_decoding (models/efficientlab.py:133-149): the product's parameter table (names, creation order, shapes) equals the
+    oracle's restatement of the graph for B0 / B3, with and without RSD modules and the ASPP; RSD(4) then carries the extra 1x1 branch
+    of its residual operand (168 != 112 channels, efficientlab.py:213-215) and the final conv reads whatever the last decoder emits."""
+    import torch
+    from mliis_amd import spec
+    from oracle import efficientlab_ref as R
+    for name, rsd, aspp in (("efficientnet-b0", (2, 4), False), ("efficientnet-b0", (), False), ("efficientnet-b0", (2, 4), True),
+                            ("efficientnet-b3", (2,), False)):
+        a = spec.derive(name, 224, list(rsd), 0.0, aspp, skip_decoding=True)
+        O = R.arch(name, 224, rsd, aspp, True)
+        want = [(n, tuple(s)) for n, s, _ in R.param_specs(O)]
+        got = [(p.name, tuple(p.shape)) for p in spec.param_table(a) if p.trainable and p.executed]
+        ex = {p.name for p in spec.param_table(a) if p.trainable and not p.executed}
+        assert got == [w for w in want if w[0] not in ex], (name, rsd, aspp)
+    a = spec.derive("efficientnet-b0", 224, [2, 4], 0.0, False, skip_decoding=True)
+    assert a.skipdec.h == 56 and a.skipdec.c_cat == 168 and a.skipdec.c_sep == 168 and a.c_final == 112
+    assert [(m.h_in, m.h, m.c_deep, m.upsample_conv) for m in a.rsd] == [(56, 14, 168, True), (14, 56, 112, False)]
+    assert spec.derive("efficientnet-b0", 224, [], 0.0, False, skip_decoding=True).c_final == 168

@@ -703,3 +703,47 @@ def test_inner_batch_of_32_images():
     ll = L.loss_value()
     assert abs(ll - lo) <= 1e-4 * max(1.0, abs(lo)), (ll, lo)
     _compare_state(O, L, gO, "batch 32")
+
+
+@pytest.mark.parametrize("rsd,aspp,name", [((2, 4), False, "efficientnet-b0"), ((), False, "efficientnet-b0"), ((2, 4), True, "efficientnet-b0"),
+                                           ((2,), False, "efficientnet-b3")])
+def test_skip_decoding_decoder_step_and_inference(rsd, aspp, name):
+    """--skip_decoding (SURVEY 8(a) a18 second half; models/efficientlab.py:133-149, sep_conv :445-474): the DeepLabv3+-style decoder
+    -- embedded image resized to input / 4, concatenated with the projected reduction_2 endpoint, two depthwise-separable convs --
+    in front of the RSD modules (RSD(4) then DOWNsamples its 168-channel input and takes the residual operand through its own 1x1
+    branch, efficientlab.py:213-215), as the only decoder, behind the ASPP, and on the B3 encoder: training steps vs the float64 oracle
+    (loss, every gradient, post-step parameters, BN moving statistics; HIP-graph capture and replay), then inference -- where these
+    batch norms keep using batch statistics (the reference builds them with training=True)."""
+    _need_gpu()
+    from mliis_amd.learner import Learner
+    H, S, idx = 64, 5, [3, 1, 4, 0, 2, 3]
+    O = R.OracleLearner(name=name, image_size=H, seed=0, dtype=torch.float64, lr=1e-3, rsd=rsd, aspp=aspp, skip_decoding=True)
+    L = Learner(feature_extractor_name=name, image_size=H, seed=100, use_graph=True, rsd=rsd, spatial_pyramid_pooling=aspp, skip_decoding=True)
+    L.load_named({k: v.numpy() for k, v in O.params.items()}, strict=False)
+    assert [p.name for p in L.arena.trainable] == list(O.params)              # same variables, same (creation) order
+    x, y = _task(S, H, 3)
+    L.load_task(x, y)
+    N, d, h = len(idx), O.a["dec_c"], H // 16
+    g = np.random.default_rng(9)
+    for step in range(3):     # step 0 eager, step 1 captures the HIP graph, step 2 replays it
+        dc = _dc(O, N, 20 + step)
+        kw = {}
+        if aspp:
+            kw["aspp_masks"] = [torch.tensor(2.0 * (g.random(s) < 0.5)) for s in ((N, h, h, d), (N, h, h, d), (N, 1, 1, d), (N, h, h, d))]
+        lo, gO, _ = R.inner_step(O.a, O.params, O.bn, torch.tensor(x[idx]).double(), torch.tensor(y[idx]).double(), 1e-3, dc, **kw)
+        L.inner_step(idx, dc_scales=dc, **kw)
+        ll = L.loss_value()
+        assert abs(ll - lo) <= (1e-4 if step == 0 else 1e-3) * max(1.0, abs(lo)), (step, ll, lo)
+        if step == 0:
+            _compare_state(O, L, gO, "skipdec")
+    th = L.arena.export_trainable_packed().cpu().double()
+    ref = torch.cat([O.params[p.name].reshape(-1) for p in L.arena.trainable])
+    assert (th - ref).abs().max().item() <= 3e-5
+    with torch.no_grad():
+        lgO, _ = R.forward(O.a, O.params, O.bn, torch.tensor(x).double(), False)
+    pL, lgL = L.predict(x, training=False, return_logits=True)
+    scale = lgO.abs().max().item()
+    assert (lgL.cpu().double() - lgO).abs().max().item() <= 2e-3 * scale
+    margin = (lgO[..., 0] - lgO[..., 1]).abs() > 1e-3 * scale
+    assert torch.equal(pL.cpu()[margin].double(), R.predictions(lgO)[margin])
+    L.close()
