@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--backbone", default="efficientnet-b0", choices=["efficientnet-b0", "efficientnet-b3"],
                     help="variant: EfficientNet-B3 encoder (BASELINE configs[3]); the metric's config is B0")
     ap.add_argument("--aspp", action="store_true", help="variant: ASPP decoder in front of the RSD modules (--spatial_pyramid_pooling)")
+    ap.add_argument("--skip-decoding", action="store_true", help="variant: DeepLabv3+-style decoder in front of the RSD modules (--skip_decoding)")
     ap.add_argument("--augment", action="store_true", help="variant: augmentation of every inner-loop batch (the reference's run.sh setting), pixels on the device")
     ap.add_argument("--augment-on-host", action="store_true", help="with --augment: pixels in numpy / scipy on the host (draw-identical to the reference)")
     ap.add_argument("--augment-workers", type=int, default=-1, help="worker processes for the augmentation pixel work (0 = inline, -1 = cores - 1)")
@@ -317,10 +318,11 @@ def _run(args):
     shots = 10 if args.foml else args.shots
     L = Learner(feature_extractor_name=args.backbone, image_size=args.image_size, rsd=(2, 4), learning_rate=1e-3, optimizer="sgd", dice=False, l2=False, seed=0, device=device,
                 use_graph=not args.no_graph, max_shots=max(16, shots), spatial_pyramid_pooling=args.aspp, matmul_precision=args.precision,
-                overlap_wgrad=args.overlap_wgrad, augment_batch_capacity=16 if (args.augment and not args.augment_on_host) else 0)
+                skip_decoding=args.skip_decoding, overlap_wgrad=args.overlap_wgrad, augment_batch_capacity=16 if (args.augment and not args.augment_on_host) else 0)
     lanes = [Learner(feature_extractor_name=args.backbone, image_size=args.image_size, rsd=(2, 4), learning_rate=1e-3, optimizer="sgd", dice=False,
                      l2=False, seed=k, device=device, use_graph=not args.no_graph, max_shots=max(16, shots),
-                     spatial_pyramid_pooling=args.aspp, matmul_precision=args.precision) for k in range(1, args.concurrent_tasks)]
+                     spatial_pyramid_pooling=args.aspp, skip_decoding=args.skip_decoding, matmul_precision=args.precision)
+             for k in range(1, args.concurrent_tasks)]
     tasks = []
     for i in range(args.pool):
         x, y = synthetic_task(shots, args.image_size, seed=1000 * rank + i)
@@ -370,7 +372,7 @@ def _run(args):
                                    "%d-shot x %d inner SGD steps of batch %d (%d image fwd+bwd+BN-EMA+SGD per task), %s outer update, fp32 tensors, "
                                    "CE loss, drop-connect on%s" % ("EfficientLab-6-3 (EfficientNet-B0 blocks 0-10" if args.backbone == "efficientnet-b0" else
                                                                  "EfficientLab with the EfficientNet-B3 encoder (blocks 0-17",
-                                                                 "ASPP + " if args.aspp else "", args.image_size, args.image_size, world, shots,
+                                                                 ("ASPP + " if args.aspp else "") + ("DeepLabv3+-style skip decoder + " if args.skip_decoding else ""), args.image_size, args.image_size, world, shots,
                                                                  args.inner_iters,
                                                                  args.inner_batch, imgs_per_task, "FOMAML(tail 5)" if args.foml else "Reptile",
                                                                  ("" if args.precision == "fp32" else ", %s matrix-core operands" % args.precision) +

@@ -62,3 +62,20 @@ def test_main_on_the_device(tmp_path, fmt):
         assert "Meta-training..." not in o
         outs.append(json.load(open(os.path.join(d1, "meta-test_results.json"))))
     assert outs[0] == outs[1]
+
+
+def test_main_with_every_optional_decoder(tmp_path):
+    """`--spatial_pyramid_pooling --skip_decoding --l1 --darc1` through the command line: the ASPP, the DeepLabv3+-style decoder and
+    both extra regularisers train, checkpoint (their variables under the reference's scope names) and evaluate."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from mliis_amd import checkpoint as ckpt
+    d1 = str(tmp_path / "a")
+    out = _run(BASE + ["--sgd", "--spatial_pyramid_pooling", "--skip_decoding", "--l1", "--darc1", "--meta-iters", "2", "--eval-interval", "0",
+                       "--checkpoint", d1])
+    assert "Mean IoU over all meta-test tasks:" in out
+    vals = ckpt.load(ckpt.latest_checkpoint(d1))
+    for k in ("decode/spatial_pyramid_pooling/branch_1/conv2d/kernel", "decode/decode_skip_connections/depthwise_conv2d_1/depthwise_kernel",
+              "decode/decode_skip_connections/batch_normalization_4/moving_variance", "decode/decode_skip_connections_3/conv2d_3/kernel"):
+        assert k in vals and np.isfinite(vals[k]).all(), k
+    assert vals["decode/decode_skip_connections_3/conv2d/kernel"].shape == (1, 1, 168, 112)     # RSD(4)'s residual 1x1 branch
