@@ -99,6 +99,10 @@ class _Lib:
                 raise MliisError(
                     "libmliis_hip.so not found at {} -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                     "or `make -C mliis_amd/csrc`.  There is no CPU fallback.".format(LIB_PATH))
+            # PyTorch-ROCm carries its own HIP runtime: import it FIRST so that this library resolves libamdhip64 to the copy torch
+            # has already loaded.  Loaded the other way round, the process ends up with two HIP runtimes and the one this library is
+            # bound to sees no device ("no ROCm-capable device is detected" at the first launch).
+            import torch  # noqa: F401
             dll = C.CDLL(LIB_PATH)
             for name, (res, args) in SIGNATURES.items():
                 fn = getattr(dll, name)
