@@ -747,3 +747,29 @@ def test_skip_decoding_decoder_step_and_inference(rsd, aspp, name):
     margin = (lgO[..., 0] - lgO[..., 1]).abs() > 1e-3 * scale
     assert torch.equal(pL.cpu()[margin].double(), R.predictions(lgO)[margin])
     L.close()
+
+
+@pytest.mark.parametrize("H,N", [(100, 3), (72, 5)])
+def test_one_step_at_sizes_with_odd_feature_maps(H, N):
+    """Image sizes that are not a multiple of 32: 100 px -> maps 50 / 25 / 13 / 7 (odd sizes at every stride-2 layer: TF-SAME puts the
+    extra padding pixel at the bottom / right), 72 px -> 36 / 18 / 9 / 5.  One training step and inference vs the oracle."""
+    _need_gpu()
+    S = 4
+    idx = [i % S for i in range(N)]
+    O, L = _pair(H, use_graph=True)
+    x, y = _task(S, H, 31)
+    L.load_task(x, y)
+    for step in range(2):
+        dc = _dc(O, N, 7 + step)
+        lo, gO, _ = R.inner_step(O.a, O.params, O.bn, torch.tensor(x[idx]).double(), torch.tensor(y[idx]).double(), 1e-3, dc)
+        L.inner_step(idx, dc_scales=dc)
+        ll = L.loss_value()
+        assert abs(ll - lo) <= (1e-4 if step == 0 else 1e-3) * max(1.0, abs(lo)), (step, ll, lo)
+        if step == 0:
+            _compare_state(O, L, gO, "odd maps %d" % H)
+    with torch.no_grad():
+        lgO, _ = R.forward(O.a, O.params, O.bn, torch.tensor(x).double(), False)
+    pL, lgL = L.predict(x, training=False, return_logits=True)
+    scale = lgO.abs().max().item()
+    assert (lgL.cpu().double() - lgO).abs().max().item() <= 2e-3 * scale
+    L.close()
