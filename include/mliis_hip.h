@@ -232,6 +232,10 @@ int mliis_se_mlp_bwd(const float* dgate, const float* gate, const float* s, cons
                      float* dpre1, float* dpre2, float* chan_add, float* dw1, float* db1, float* dw2, float* db2, int N, int C, int R,
                      int HW, hipStream_t stream);
 int mliis_se_wgrad_batched(const long long* desc, int ndesc, long long total_tiles, hipStream_t stream);
+/*      y0[m, c] (+)= x[m, c] + A[n(m), c] for c < c0 and y1[m, c - c0] (+)= the same for c >= c0: the gradient of a channel concat
+ *      routed to its two inputs in one pass (tail of the RSD module's backward, models/efficientlab.py:206-208,226-228) */
+int mliis_chan_split(const float* x, int ldx, const float* A, float* y0, int ld0, int c0, int accumulate0, float* y1, int ld1, int accumulate1,
+                     long long rows, int C, int rows_per_img, hipStream_t stream);
 /*      y[m,c] (+)= x[m,c] * S[n(m),c] + A[n(m),c]  (x, S, A optional): gate apply, tf.tile of pooled vectors, pooled-gradient
  *      broadcast, strided channel-slice copy (tf.concat, efficientlab.py:208,222). */
 int mliis_chan_affine(const float* x, int ldx, const float* S, const float* A, float* y, int ldy, long long rows, int C,

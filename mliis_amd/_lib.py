@@ -62,6 +62,7 @@ SIGNATURES = {
     "mliis_se_mlp_bwd": (_i, [_p] * 13 + [_i, _i, _i, _i, _p]),
     "mliis_se_wgrad_batched": (_i, [_p, _i, _ll, _p]),
     "mliis_chan_affine": (_i, [_p, _i, _p, _p, _p, _i, _ll, _i, _i, _i, _p]),
+    "mliis_chan_split": (_i, [_p, _i, _p, _p, _i, _i, _i, _p, _i, _i, _ll, _i, _i, _p]),
     "mliis_swish_mask_fwd": (_i, [_p, _i, _p, _i, _p, _i, _ll, _i, _i, _p]),
     "mliis_swish_mask_bwd": (_i, [_p, _i, _p, _i, _p, _i, _p, _i, _ll, _i, _i, _p]),
     "mliis_resize_bilinear_fwd": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p]),

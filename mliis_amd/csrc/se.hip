@@ -230,6 +230,32 @@ __global__ __launch_bounds__(256) void chan_affine_k(const float* __restrict__ x
   }
 }
 
+// One pass over x [rows][C] (+ A[n(m), c]) routed to two destinations by channel: y0[m, c] for c < c0, y1[m, c - c0] otherwise,
+// each stored or accumulated -- the tail of the RSD module's backward (gradient of the concat: + the pooled branch's per-image term,
+// deep half added to the residual gradient, skip half to the endpoint's gradient) in one launch instead of three.
+__global__ __launch_bounds__(256) void chan_split_k(const float* __restrict__ x, int ldx, const float* __restrict__ A, float* __restrict__ y0,
+                                                    int ld0, int c0, int acc0, float* __restrict__ y1, int ld1, int acc1, long long rows, int C,
+                                                    int rows_per_img) {
+  const unsigned Q = (unsigned)C >> 2;
+  const unsigned total = (unsigned)rows * Q;   // host guarantees < 2^31
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const unsigned ru = i / Q;
+    const int c = (int)(i - ru * Q) << 2;
+    const long long r = ru;
+    const long long n = ru / (unsigned)rows_per_img;
+    const bool first = c < c0;
+    float* dst = first ? y0 + r * ld0 + c : y1 + r * ld1 + (c - c0);
+    const bool acc = first ? acc0 != 0 : acc1 != 0;
+    const float4 vx = ld4(x + r * ldx + c);
+    const float4 va = ld4(A ? A + n * C + c : x + r * ldx + c);
+    const float4 vo = ld4(dst);          // (read even when it is overwritten: one round trip, no branch around a load)
+    float4 v = vx;
+    if (A) v = f4add(v, va);
+    if (acc) v = f4add(v, vo);
+    st4(dst, v);
+  }
+}
+
 }  // namespace mliis
 
 using namespace mliis;
@@ -271,6 +297,22 @@ int mliis_se_wgrad_batched(const long long* desc, int ndesc, long long total_til
   MLIIS_REQUIRE(desc && ndesc > 0 && total_tiles > 0, MLIIS_ERR_ARG, "se_wgrad_batched: bad arguments");
   hipLaunchKernelGGL(se_wgrad_batched_k, dim3((unsigned)total_tiles), dim3(256), 0, stream, desc, ndesc);
   MLIIS_CHECK_LAUNCH("se_wgrad_batched");
+  return MLIIS_OK;
+}
+
+int mliis_chan_split(const float* x, int ldx, const float* A, float* y0, int ld0, int c0, int accumulate0, float* y1, int ld1, int accumulate1,
+                     long long rows, int C, int rows_per_img, hipStream_t stream) {
+  MLIIS_REQUIRE(x && y0 && y1, MLIIS_ERR_ARG, "chan_split: null pointer");
+  MLIIS_REQUIRE(rows > 0 && C > 0 && (C & 3) == 0 && c0 > 0 && c0 < C && (c0 & 3) == 0 && (ldx & 3) == 0 && ldx >= C && (ld0 & 3) == 0 &&
+                    ld0 >= c0 && (ld1 & 3) == 0 && ld1 >= C - c0 && rows_per_img > 0,
+                MLIIS_ERR_ARG, "chan_split: bad shape");
+  MLIIS_REQUIRE(aligned16(x) && aligned16(A) && aligned16(y0) && aligned16(y1), MLIIS_ERR_ALIGN, "chan_split: pointers must be 16-byte aligned");
+  MLIIS_REQUIRE(rows * (C / 4) < (1LL << 31), MLIIS_ERR_UNSUPPORTED, "chan_split: tensor too large for 32-bit indexing");
+  long long q = rows * (C / 4);
+  int blocks = (int)((q + 255) / 256 > 4096 ? 4096 : (q + 255) / 256);
+  hipLaunchKernelGGL(chan_split_k, dim3(blocks), dim3(256), 0, stream, x, ldx, A, y0, ld0, c0, accumulate0, y1, ld1, accumulate1, rows, C,
+                     rows_per_img);
+  MLIIS_CHECK_LAUNCH("chan_split");
   return MLIIS_OK;
 }
 

@@ -843,7 +843,9 @@ class Learner:
             bn_b(D["z1"], d1, D["st1"], n1, d1, pre=True, dxsum_part=P.fold_part[b1])
             wgrad(d1, k1, 3, 2)
             self._conv_bwd_data(d1, w[k1], 2, out=dcat, accumulate=True, ws=ws)
-            ops.chan_affine(None, A=D["dpool"], out=dcat, accumulate=True)   # d(mean)/d(cat) = dpool / (H*W) on every pixel
+            # gradient of the concat = dcat + dpool / (H*W) on every pixel (the pooled branch); its deep half joins the residual
+            # gradient, its skip half goes to the endpoint's gradient: one pass (mliis_chan_split)
+            bi_skip = a.reductions[r]
             if m.upsample_conv:
                 # the residual operand came through its own conv -> swish -> BN branch (efficientlab.py:213-215): dO is its gradient;
                 # back through that branch to the resized deep map, where the concat's share joins
@@ -851,13 +853,12 @@ class Learner:
                 bn_b(D["zu"], dO, D["stu"], nu, D["dzu"], pre=True, dxsum_part=P.fold_part[bu])
                 wgrad_conv(cat[..., :m.c_deep], D["dzu"], 1, 1, ku)
                 self._conv_bwd_data(D["dzu"], w[ku], 1, out=D["dup"], ws=ws)
-                ops.chan_affine(dcat[..., :m.c_deep], out=D["dup"], accumulate=True)
                 dU = D["dup"]
             else:
-                # dU = dO + dcat[:, :c_deep] (residual);  dS = dcat[:, c_deep:]
-                ops.chan_affine(dcat[..., :m.c_deep], out=dO, accumulate=True)
-                dU = dO
-            # gradient w.r.t. the deep input
+                dU = dO      # dU = dO + dcat[:, :c_deep] (residual)
+            ops.chan_split(dcat, m.c_deep, dU, True, P.blocks[bi_skip]["dout"], has_grad[bi_skip], A=D["dpool"])
+            has_grad[bi_skip] = True
+            # gradient w.r.t. the deep input (for RSD(4) without a decoder in front it is the same endpoint the skip half just went to)
             if j > 0:
                 tgt, tgt_has = P.rsd[j - 1]["dout"], False
             elif a.skipdec is not None:
@@ -873,10 +874,6 @@ class Learner:
                 ops.resize_bilinear_bwd(dU, (m.h_in, m.h_in), out=tgt, accumulate=tgt_has)
             if j == 0 and not a.aspp and a.skipdec is None:
                 has_grad[a.reductions[4]] = True
-            # gradient w.r.t. the skip endpoint
-            bi = a.reductions[r]
-            ops.chan_affine(dcat[..., m.c_deep:], out=P.blocks[bi]["dout"], accumulate=has_grad[bi])
-            has_grad[bi] = True
 
         if a.skipdec is not None:
             # --skip_decoding decoder backward: the two sep_convs in reverse, then the concat's two halves -- the projected reduction_2

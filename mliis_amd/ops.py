@@ -541,6 +541,14 @@ def chan_affine(x, S=None, A=None, out=None, accumulate=False, rows_per_img=None
     return out
 
 
+def chan_split(x, c0, out0, acc0, out1, acc1, A=None, rows_per_img=None):
+    """out0 (+)= x[..., :c0] + A[n, :c0];  out1 (+)= x[..., c0:] + A[n, c0:]   (one pass; channel-slice views allowed)"""
+    rows, C_, ldx = rows_ld(x)
+    rpi = rows_per_img or (rows // x.shape[0])
+    lib.call("mliis_chan_split", _ptr(x), ldx, _ptr(A), _ptr(out0), rows_ld(out0)[2], int(c0), int(acc0), _ptr(out1), rows_ld(out1)[2], int(acc1),
+             rows, C_, rpi, _stream())
+
+
 def swish_mask_fwd(z, mask=None, out=None, pre_mask=False):
     """ASPP activation: out = swish(z) * mask, or swish(z * mask) with pre_mask (mask None = inference).  Channel-slice views allowed."""
     rows, C_, ldz = rows_ld(z)
