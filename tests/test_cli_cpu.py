@@ -145,3 +145,19 @@ def test_skip_decoding_variables_match_the_oracle_graph():
     assert a.skipdec.h == 56 and a.skipdec.c_cat == 168 and a.skipdec.c_sep == 168 and a.c_final == 112
     assert [(m.h_in, m.h, m.c_deep, m.upsample_conv) for m in a.rsd] == [(56, 14, 168, True), (14, 56, 112, False)]
     assert spec.derive("efficientnet-b0", 224, [], 0.0, False, skip_decoding=True).c_final == 168
+
+
+def test_entry_points_fail_loudly_without_a_gpu():
+    """No CPU fallback anywhere on the product path: bench.py refuses to run, the Learner refuses to be built (this container has no
+    GPU; on a GPU box the test is vacuous and skips)."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"), "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "no CPU path" in (r.stderr + r.stdout)
+    assert not any(l.startswith("{") for l in r.stdout.splitlines())          # no bench line
+    from mliis_amd.learner import Learner
+    with pytest.raises(Exception):
+        Learner(image_size=64)
