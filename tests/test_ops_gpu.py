@@ -922,3 +922,63 @@ def test_conv2d_bwd_filter_batched_equals_the_single_calls():
     assert len(fb.tables) < len(probs)     # problems sharing an instantiation share a launch
     for i, (x, dy, k, dil, gate, pa, pb) in enumerate(probs):
         assert torch.equal(pa, pb), i
+
+
+def test_conv1x1_ksplit_random_shapes():
+    """conv1x1_ksplit_k (long-K 1x1 convs on small maps) over 28 seeded random shapes: K 113..896 (every KC 1..7, K tails), 16..8192
+    rows (row-group tails, maps from 2x2 up), 8..240 output channels (column tails), with / without bias, SE gate on load, fused
+    statistics (plain / swish), accumulate, channel-slice views on both sides; forward and backward-data against float64."""
+    from mliis_amd import ops
+    d = dev()
+    g = np.random.default_rng(123)
+    seen = set()
+    for case in range(28):
+        K = int(g.integers(29, 225)) * 4
+        N = int(g.integers(1, 9))
+        H = int(g.integers(2, 33))
+        W = int(g.integers(2, 33))
+        while N * H * W > 8192 or N * H * W < 16:
+            H, W = max(2, H // 2 + 1), max(2, W // 2 + 1)
+            N = max(N, 2)
+        Co = int(g.integers(2, 61)) * 4
+        gated, bias, stats, swish, acc = [bool(v) for v in g.integers(0, 2, 5)]
+        name = ops.conv2d_kernel_name(N, H, W, K, Co, 1, gated)
+        assert "conv1x1_ksplit_k" in name, (name, N, H, W, K, Co)
+        seen.add(name.split("<")[1].split(",")[0])
+        xw = rnd(N, H, W, K + 8, seed=500 + case)
+        x = xw[..., 4:4 + K]
+        w = rnd(1, 1, K, Co, seed=600 + case, scale=1.0 / math.sqrt(K))
+        b = rnd(Co, seed=700 + case) if bias else None
+        gate = torch.sigmoid(rnd(N, K, seed=800 + case)) if gated else None
+        xs = x * gate[:, None, None, :] if gated else x
+        y = (xs.reshape(-1, K) @ w.reshape(K, Co) + (b if bias else 0)).reshape(N, H, W, Co)
+        out = torch.full((N, H, W, Co + 12), 3.0, device=d)
+        prev = f32(rnd(N, H, W, Co, seed=900 + case), d)
+        if acc:
+            out[..., 8:8 + Co] = prev
+        part = torch.full((1 << 20,), 7.0, device=d) if (stats and not acc) else None
+        r = ops.conv2d_fwd(f32(xw, d)[..., 4:4 + K], f32(w, d), f32(b, d) if bias else None, 1, out=out[..., 8:8 + Co], accumulate=acc,
+                           stats_part=part, stats_swish=swish, x_scale=f32(gate, d) if gated else None)
+        ref = y + (prev.cpu().double() if acc else 0)
+        close(out[..., 8:8 + Co], ref, 2e-5, "ksplit fwd case %d" % case)
+        assert (out[..., :8] == 3).all() and (out[..., 8 + Co:] == 3).all()
+        if part is not None:
+            nblk = r[1]
+            assert nblk > 0
+            v = R.swish(y) if swish else y
+            sums = part[: nblk * 2 * Co].view(nblk, 2, Co).double().sum(0).cpu()
+            close(sums[0], v.sum(dim=(0, 1, 2)), 2e-5, "ksplit fused sum %d" % case)
+            close(sums[1], (v * v).sum(dim=(0, 1, 2)), 2e-5, "ksplit fused sum of squares %d" % case)
+            assert (part[nblk * 2 * Co:] == 7).all()
+        # backward-data of a conv with Cout = K of this case (the expand convs): dx = dy . W^T, here with K in the role of Cout
+        dy = rnd(N, H, W, K, seed=1000 + case)
+        w2 = rnd(1, 1, Co, K, seed=1100 + case, scale=1.0 / math.sqrt(K))
+        if "conv1x1_ksplit_k" in ops.conv2d_kernel_name(N, H, W, K, Co, 1):
+            dx = torch.full((N, H, W, Co + 4), -2.0, device=d)
+            if acc:
+                dx[..., :Co] = prev
+            ops.conv2d_bwd_data(f32(dy, d), f32(w2, d), 1, out=dx[..., :Co], accumulate=acc)
+            refx = (dy.reshape(-1, K) @ w2.reshape(Co, K).T).reshape(N, H, W, Co) + (prev.cpu().double() if acc else 0)
+            close(dx[..., :Co], refx, 1e-4, "ksplit bwd data case %d" % case)
+            assert (dx[..., Co:] == -2).all()
+    assert len(seen) >= 5, seen          # several KC instances were hit
