@@ -806,6 +806,8 @@ class Learner:
                        dxsum_part=dxsum_part, stage1=stage1)
 
         batch = self.batch_wgrad and not self.overlap_wgrad
+        if batch and not P.wbatch_ready:
+            P.wbatch = ops.FilterBatch(self.device)   # (a first backward pass that raised half-way must not leave half a table behind)
 
         def wgrad_conv(xin, dz, kk, dil, key, x_scale=None):
             """filter gradient of a dense conv (slabs into P.fold_part[key]): deferred into the plan's batch, or issued here"""
