@@ -32,3 +32,40 @@ def test_two_ranks_on_one_gpu_run_the_sharded_meta_step_and_print_one_line():
     assert d["cpu_baseline"] is None                                # the CPU baseline is timed at N = 1 only
     # value = all ranks' images / max-over-ranks time: 2 tasks x 64 images x steps
     assert abs(d["value"] - 2 * 64 * d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"])) < 1e-6 * d["value"]
+
+
+def test_rccl_single_rank_process_group_runs_the_collectives():
+    """RCCL itself on the box (world size 1 -- all a one-GPU machine allows): the process group comes up on backend "nccl", and the three
+    collectives the meta-learner issues (all-reduce SUM of the comm buffer on the learner's stream, all-reduce MAX of the stop flag,
+    broadcast of evaluation results) execute on device tensors."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    code = r'''
+import os, sys, torch
+sys.path.insert(0, %r)
+import torch.distributed as dist
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", RANK="0", WORLD_SIZE="1")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+from mliis_amd.reptile import Dist
+D = Dist()
+assert D.world == 1 and D.rank == 0 and dist.get_backend() == "nccl"
+s = torch.cuda.Stream()
+with torch.cuda.stream(s):
+    t = torch.arange(2_089_228, dtype=torch.float32, device="cuda")      # the size of [theta | BN contributions]
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+s.synchronize()
+assert float(t[-1]) == 2_089_227.0
+f = torch.tensor([1], dtype=torch.int32, device="cuda")
+dist.all_reduce(f, op=dist.ReduceOp.MAX)
+b = torch.tensor([0.25, 0.5], dtype=torch.float64, device="cuda")
+dist.broadcast(b, src=0)
+dist.barrier()
+torch.cuda.synchronize()
+assert int(f.item()) == 1 and b.tolist() == [0.25, 0.5]
+print("rccl ok", torch.cuda.nccl.version())
+dist.destroy_process_group()
+''' % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0 and "rccl ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
