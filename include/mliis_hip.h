@@ -147,6 +147,14 @@ int mliis_transpose_weights(const float* src, float* dst, const int* desc, int n
 int mliis_conv2d_bwd_data(const float* dy, int lddy, const float* w, float* dx, int lddx, int Nimg, int H, int W, int Cin_total,
                           int ci_begin, int Cin_out, int Cout, int ksize, int dil, int accumulate, float* ws, size_t ws_floats,
                           int precision, hipStream_t stream);
+/*      same, when dx is the gradient w.r.t. the OUTPUT of a plain batch norm over bn_x [M, Cin_out] (the project BN of the MBConv
+ *      block in front, efficientnet_model.py:225-236; bn_img_scale = its drop-connect scales, nullable): on the plans that finish
+ *      their rows inside one workgroup (the 28x28 / 14x14 maps) the launch also leaves stage 1 of that batch norm's backward
+ *      {sum g, sum g * xhat} in part [*nblk][2][Cin_out] for mliis_bn_bwd(stage1_part, stage1_nblk).  *nblk == 0: not produced. */
+int mliis_conv2d_bwd_data_bn(const float* dy, int lddy, const float* w, float* dx, int lddx, int Nimg, int H, int W, int Cin_total,
+                             int ci_begin, int Cin_out, int Cout, int ksize, int dil, int accumulate, float* ws, size_t ws_floats,
+                             int precision, const float* bn_x, int bn_ldx, const float* bn_mean, const float* bn_rstd,
+                             const float* bn_img_scale, float* part, size_t part_floats, int* nblk, hipStream_t stream);
 size_t mliis_conv2d_bwd_filter_workspace_floats(int Nimg, int H, int W, int Cin, int Cout, int ksize);
 /*      writes rows [ci_begin, ci_begin+Cin) (per tap) of the full [k,k,Cin_total,Cout] gradient tensor dw */
 int mliis_conv2d_bwd_filter(const float* x, int ldx, const float* x_scale, const float* dy, int lddy, float* dw, int Nimg, int H, int W,

@@ -46,6 +46,7 @@ SIGNATURES = {
     "mliis_rsd_pool_bwd": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _p]),
     "mliis_transpose_weights": (_i, [_p, _p, _p, _i, _p, _p]),
     "mliis_conv2d_bwd_data": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _i, _p]),
+    "mliis_conv2d_bwd_data_bn": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _i, _p, _i, _p, _p, _p, _p, _sz, _p, _p]),
     "mliis_conv2d_bwd_filter_workspace_floats": (_sz, [_i, _i, _i, _i, _i, _i]),
     "mliis_conv2d_bwd_filter": (_i, [_p, _i, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _i, _p]),
     "mliis_conv2d_bwd_filter_plan": (_i, [_i, _i, _i, _i, _i, _i, _p]),

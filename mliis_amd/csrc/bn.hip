@@ -841,11 +841,19 @@ int mliis_bn_bwd(const float* x, int ldx, const float* dy, int lddy, float* dx, 
   ColGeom g;
   int rc;
   if (stage1_part != nullptr) {   // stage 1 ({sum g, sum g * xhat} partials [stage1_nblk][2][C]) came from the producer of dy
-    MLIIS_REQUIRE(stage1_nblk > 0 && aligned16(stage1_part) && img_scale == nullptr && chan_scale == nullptr && chan_add == nullptr,
-                  MLIIS_ERR_ARG, "bn_bwd: external stage-1 partials need a plain (no per-image vectors) batch norm");
-    BnBwdCommon<false> p{x, ldx, dy, lddy, rows_per_img, C, mean, rstd, gamma, beta, pre_swish, post_swish, nullptr, nullptr, nullptr};
-    hipLaunchKernelGGL(bn_bwd_apply_fused_k<false>, dim3(gx, gy), dim3(256), 0, stream, p, rows, stage1_part, stage1_nblk, 1.0 / (double)rows,
-                       dgamma, dbeta, dx, lddx, rpb, skip, dxsum_part);
+    // (the producer computed its sums with the same g: the drop-connect scale may be part of it -- mliis_conv2d_bwd_data_bn -- the
+    // squeeze-excite vectors may not)
+    MLIIS_REQUIRE(stage1_nblk > 0 && aligned16(stage1_part) && chan_scale == nullptr && chan_add == nullptr, MLIIS_ERR_ARG,
+                  "bn_bwd: external stage-1 partials cannot be combined with the squeeze-excite vectors");
+    if (img_scale != nullptr) {
+      BnBwdCommon<true> p{x, ldx, dy, lddy, rows_per_img, C, mean, rstd, gamma, beta, pre_swish, post_swish, img_scale, nullptr, nullptr};
+      hipLaunchKernelGGL(bn_bwd_apply_fused_k<true>, dim3(gx, gy), dim3(256), 0, stream, p, rows, stage1_part, stage1_nblk, 1.0 / (double)rows,
+                         dgamma, dbeta, dx, lddx, rpb, skip, dxsum_part);
+    } else {
+      BnBwdCommon<false> p{x, ldx, dy, lddy, rows_per_img, C, mean, rstd, gamma, beta, pre_swish, post_swish, nullptr, nullptr, nullptr};
+      hipLaunchKernelGGL(bn_bwd_apply_fused_k<false>, dim3(gx, gy), dim3(256), 0, stream, p, rows, stage1_part, stage1_nblk, 1.0 / (double)rows,
+                         dgamma, dbeta, dx, lddx, rpb, skip, dxsum_part);
+    }
     MLIIS_CHECK_LAUNCH("bn_bwd_apply_fused");
     return MLIIS_OK;
   }

@@ -528,9 +528,46 @@ int mliis_conv2d_fwd(const float* x, int ldx, const float* x_scale, const float*
 
 // dx[M, Cin_out] (ld = lddx) (+)= conv_transpose(dy[M, Cout] (ld = lddy), w) restricted to input channels
 // [ci_begin, ci_begin + Cin_out) of a weight tensor w[k,k,Cin_total,Cout].
+struct BnbArgs {   // mliis_conv2d_bwd_data_bn: the batch norm whose output gradient this call produces
+  const float* x;
+  int ldx;
+  const float *mean, *rstd, *img_scale;
+  float* part;
+  size_t part_floats;
+  int* nblk;
+};
+static int conv2d_bwd_data_impl(const float* dy, int lddy, const float* w, float* dx, int lddx, int Nimg, int H, int W, int Cin_total,
+                                int ci_begin, int Cin_out, int Cout, int ksize, int dil, int accumulate, float* ws, size_t ws_floats,
+                                int precision, hipStream_t stream, const BnbArgs* bnb);
+
 int mliis_conv2d_bwd_data(const float* dy, int lddy, const float* w, float* dx, int lddx, int Nimg, int H, int W, int Cin_total,
                           int ci_begin, int Cin_out, int Cout, int ksize, int dil, int accumulate, float* ws, size_t ws_floats,
                           int precision, hipStream_t stream) {
+  return conv2d_bwd_data_impl(dy, lddy, w, dx, lddx, Nimg, H, W, Cin_total, ci_begin, Cin_out, Cout, ksize, dil, accumulate, ws, ws_floats,
+                              precision, stream, nullptr);
+}
+
+// Same, when dx is the gradient w.r.t. the output of a plain batch norm over bn_x [M, Cin_out] (the project BN of the MBConv block in
+// front: efficientnet_model.py:225-236): on the plans that finish their rows in one workgroup (conv1x1_ksplit_k: the 28x28 / 14x14
+// maps) the launch also leaves stage 1 of that batch norm's backward -- {sum g, sum g * xhat} per row-group block, g = dx *
+// img_scale[image] -- in part [*nblk][2][Cin_out] for mliis_bn_bwd(stage1_part, stage1_nblk).  *nblk == 0: not produced (another
+// plan, or part too small): run mliis_bn_bwd without stage-1 partials then.
+int mliis_conv2d_bwd_data_bn(const float* dy, int lddy, const float* w, float* dx, int lddx, int Nimg, int H, int W, int Cin_total,
+                             int ci_begin, int Cin_out, int Cout, int ksize, int dil, int accumulate, float* ws, size_t ws_floats,
+                             int precision, const float* bn_x, int bn_ldx, const float* bn_mean, const float* bn_rstd,
+                             const float* bn_img_scale, float* part, size_t part_floats, int* nblk, hipStream_t stream) {
+  MLIIS_REQUIRE(bn_x && bn_mean && bn_rstd && part && nblk, MLIIS_ERR_ARG, "conv2d_bwd_data_bn: null pointer");
+  MLIIS_REQUIRE((bn_ldx & 3) == 0 && bn_ldx >= Cin_out && aligned16(bn_x) && aligned16(bn_mean) && aligned16(bn_rstd) && aligned16(part),
+                MLIIS_ERR_ARG, "conv2d_bwd_data_bn: batch-norm operands misaligned or too narrow");
+  *nblk = 0;
+  const BnbArgs b{bn_x, bn_ldx, bn_mean, bn_rstd, bn_img_scale, part, part_floats, nblk};
+  return conv2d_bwd_data_impl(dy, lddy, w, dx, lddx, Nimg, H, W, Cin_total, ci_begin, Cin_out, Cout, ksize, dil, accumulate, ws, ws_floats,
+                              precision, stream, &b);
+}
+
+static int conv2d_bwd_data_impl(const float* dy, int lddy, const float* w, float* dx, int lddx, int Nimg, int H, int W, int Cin_total,
+                                int ci_begin, int Cin_out, int Cout, int ksize, int dil, int accumulate, float* ws, size_t ws_floats,
+                                int precision, hipStream_t stream, const BnbArgs* bnb) {
   int rc = conv_check("conv2d_bwd_data", Nimg, H, W, Cin_out, Cout, ksize, dil);
   if (rc) return rc;
   if ((rc = prec_check("conv2d_bwd_data", precision))) return rc;
@@ -554,10 +591,23 @@ int mliis_conv2d_bwd_data(const float* dy, int lddy, const float* w, float* dx, 
       return MLIIS_OK;
     }
     // long-K 1x1 convs on small maps (backward-data of the MBConv expand convs): K split inside the workgroup, one launch
-    if (ksize == 1 && M * lddx * 4 < (1LL << 31) && M * lddy * 4 < (1LL << 31) && ksplit_plan(M, Cout, Cin_out, num_cus(), &sp) &&
-        launch_ksplit(sp, p, stream, precision)) {
-      MLIIS_CHECK_LAUNCH("conv2d_bwd_data_ksplit");
-      return MLIIS_OK;
+    if (ksize == 1 && M * lddx * 4 < (1LL << 31) && M * lddy * 4 < (1LL << 31) && ksplit_plan(M, Cout, Cin_out, num_cus(), &sp)) {
+      const bool with_bn = bnb != nullptr && (size_t)sp.gx * 2 * Cin_out <= bnb->part_floats;
+      if (with_bn) {   // + stage 1 of the consumer batch norm's backward from the finishing threads
+        p.stats_part = bnb->part;
+        p.bnb_x = bnb->x;
+        p.bnb_ldx = bnb->ldx;
+        p.bnb_mean = bnb->mean;
+        p.bnb_rstd = bnb->rstd;
+        p.bnb_scale = bnb->img_scale;
+      }
+      if (launch_ksplit(sp, p, stream, precision)) {
+        MLIIS_CHECK_LAUNCH("conv2d_bwd_data_ksplit");
+        if (with_bn) *bnb->nblk = sp.gx;
+        return MLIIS_OK;
+      }
+      p.stats_part = nullptr;
+      p.bnb_x = nullptr;
     }
   }
   if (g.gz > 1) {

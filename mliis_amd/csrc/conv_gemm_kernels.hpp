@@ -40,6 +40,15 @@ struct ConvGemmParams {
   // (saturating at +-448); the accumulators are divided by the product of the two scales before the epilogue.
   float a_qscale;
   const float* b_amax;       // device scalar: max |B| of the weight tensor (mliis_transpose_weights)
+  // conv1x1_ksplit_k only, with stats_part: the output is the gradient w.r.t. the output of a plain batch norm y = gamma * xhat + beta
+  // (an MBConv project BN: no activation) whose input was bnb_x -- the statistics emitted are then stage 1 of THAT batch norm's
+  // backward, {sum g, sum g * xhat} with g = value * bnb_scale[image] (drop-connect) and xhat = (bnb_x - bnb_mean) * bnb_rstd,
+  // instead of {sum v, sum v^2}: mliis_bn_bwd skips its reduce pass (mliis_conv2d_bwd_data_bn)
+  const float* bnb_x = nullptr;
+  int bnb_ldx = 0;
+  const float* bnb_mean = nullptr;
+  const float* bnb_rstd = nullptr;
+  const float* bnb_scale = nullptr;   // nullable [Nimg]
 };
 
 // operand precision of an instance: 0 = fp32 (v_mfma_f32_16x16x4_f32), 1 = bf16 (v_mfma_f32_16x16x32_bf16), 2 = fp8 e4m3
@@ -765,6 +774,8 @@ __global__ __launch_bounds__(64 * WV) void conv1x1_ksplit_k(ConvGemmParams p, in
   const float4 fbias = (fcol && p.bias != nullptr) ? ld4(p.bias + fn) : f4zero();
   float4 s1 = f4zero(), s2 = f4zero();
   const bool stats = p.stats_part != nullptr;
+  const bool bnb = stats && p.bnb_x != nullptr;
+  const float4 bmean = (bnb && fcol) ? ld4(p.bnb_mean + fn) : f4zero(), brstd = (bnb && fcol) ? ld4(p.bnb_rstd + fn) : f4zero();
   auto load_a = [&](int rg, float4* a) {
     const int m = rg * 16 + l15;
     const bool rok = rg < row_groups && m < M;
@@ -827,7 +838,14 @@ __global__ __launch_bounds__(64 * WV) void conv1x1_ksplit_k(ConvGemmParams p, in
       float* dst = p.Cmat + (long long)m * p.ldc + fn;
       if (p.accumulate) v = f4add(v, ld4(dst));
       st4(dst, v);
-      if (stats) {
+      if (bnb) {   // stage 1 of the consumer batch norm's backward
+        const float4 xv = ld4(p.bnb_x + (long long)m * p.bnb_ldx + fn);
+        if (p.bnb_scale != nullptr) v = f4scale(v, p.bnb_scale[m / HW]);
+        const float4 xh = make_float4((xv.x - bmean.x) * brstd.x, (xv.y - bmean.y) * brstd.y, (xv.z - bmean.z) * brstd.z,
+                                      (xv.w - bmean.w) * brstd.w);
+        s1 = f4add(s1, v);
+        s2 = f4fma(v, xh, s2);
+      } else if (stats) {
         if (p.stats_swish) v = make_float4(swish_f(v.x), swish_f(v.y), swish_f(v.z), swish_f(v.w));
         s1 = f4add(s1, v);
         s2 = f4fma(v, v, s2);

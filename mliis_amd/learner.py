@@ -253,6 +253,9 @@ class Learner:
         # the dense-conv filter gradients (36 launches, most of them far smaller than the chip) are off the critical path: issue them
         # together at the end of the backward pass, one launch per kernel instantiation (MLIIS_BATCH_WGRAD=0: one by one, in place)
         self.batch_wgrad = os.environ.get("MLIIS_BATCH_WGRAD", "1") != "0"
+        # stage 1 of the project-BN backward from the epilogue of the expand backward-data launch that finishes its input (small maps;
+        # MLIIS_BN_STAGE1_FROM_GEMM=0: the batch norm's own reduce launch, for A/B runs)
+        self.bn_stage1_from_gemm = os.environ.get("MLIIS_BN_STAGE1_FROM_GEMM", "1") != "0"
         self.device = torch.device(device)
         torch.cuda.set_device(self.device)
         self.arch = spec.derive(feature_extractor_name, image_size, list(rsd or []), final_layer_dropout_rate, spatial_pyramid_pooling,
@@ -909,6 +912,19 @@ class Learner:
             self._aspp_backward(P, P.blocks[bi]["out"], P.blocks[bi]["dout"], has_grad[bi])
             has_grad[bi] = True
         flush()
+        stage1_next = None   # stage 1 of the NEXT block's (bi - 1) project-BN backward, when the expand backward-data launch produced it
+
+        def expand_bwd_data(bi, da0, wname, tgt, tgt_has):
+            """Backward-data of block bi's expand conv into the gradient of block bi - 1's output -- the last contribution to it, so the
+            launch can also emit stage 1 of that block's project-BN backward (mliis_conv2d_bwd_data_bn; small maps only)."""
+            if bi == 0 or not self.bn_stage1_from_gemm:
+                self._conv_bwd_data(da0, w[wname], 1, out=tgt, accumulate=tgt_has, ws=ws)
+                return None
+            Bp = P.blocks[bi - 1]
+            _, nb = self._conv_bwd_data(da0, w[wname], 1, out=tgt, accumulate=tgt_has, ws=ws,
+                                        bn=(Bp["z2"], Bp["st2"][0], Bp["st2"][1], Bp["dc"] if Bp["use_dc"] else None), part=P.stats_part)
+            return (P.stats_part, nb) if nb else None
+
         for bi in range(len(P.blocks) - 1, -1, -1):
             b, B, nm = ex[bi], P.blocks[bi], self.n_blocks[bi]
             if bi in self.wgrad_flush_before:
@@ -922,7 +938,8 @@ class Learner:
             tgt_has = has_grad[bi - 1] if bi > 0 else False
             # identity-skip part of the block-input gradient: written by the same pass that turns dout into the bn2 input gradient
             bn_b(B["z2"], dout, B["st2"], nm["bn2"], dout, img_scale=B["dc"] if B["use_dc"] else None,
-                 dskip=tgt if b.skip else None, dskip_accumulate=tgt_has)
+                 dskip=tgt if b.skip else None, dskip_accumulate=tgt_has, stage1=stage1_next)
+            stage1_next = None
             if b.skip:
                 tgt_has = True
             wgrad_1x1(B["a1"], dout, nm["w_proj"], x_scale=B["gate"])
@@ -939,7 +956,7 @@ class Learner:
                                         w[nm["w_dw"]], B["z0"], (st0[0], st0[1], w[p0 + "/gamma"], w[p0 + "/beta"]),
                                         g[p1 + "/gamma"], g[p1 + "/beta"], g[nm["w_dw"]], g[p0 + "/gamma"], g[p0 + "/beta"], da0)
                 wgrad_1x1(B["x_in"], da0, nm["w_exp"])
-                self._conv_bwd_data(da0, w[nm["w_exp"]], 1, out=tgt, accumulate=tgt_has, ws=ws)
+                stage1_next = expand_bwd_data(bi, da0, nm["w_exp"], tgt, tgt_has)
                 if bi > 0:
                     has_grad[bi - 1] = True
                 continue
@@ -954,7 +971,7 @@ class Learner:
                                              bn=(B["z0"], st0[0], st0[1], w[nm["bn0"] + "/gamma"], w[nm["bn0"] + "/beta"]))
                 bn_b(B["z0"], da0, st0, nm["bn0"], da0, post=True, stage1=(P.stats_part, nb1) if nb1 else None)
                 wgrad_1x1(B["x_in"], da0, nm["w_exp"])
-                self._conv_bwd_data(da0, w[nm["w_exp"]], 1, out=tgt, accumulate=tgt_has, ws=ws)
+                stage1_next = expand_bwd_data(bi, da0, nm["w_exp"], tgt, tgt_has)
             else:
                 if tgt_has:  # no-expand block with identity skip (EfficientNet-B3 stage-1 repeats)
                     tmp = B["da0"]

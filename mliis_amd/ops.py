@@ -285,7 +285,11 @@ def conv2d_fwd(x, w, bias=None, dil=1, out=None, accumulate=False, ws: Optional[
     return out
 
 
-def conv2d_bwd_data(dy, w, dil=1, ci_begin=0, ci_count=None, out=None, accumulate=False, ws: Optional[Workspace] = None, precision="fp32"):
+def conv2d_bwd_data(dy, w, dil=1, ci_begin=0, ci_count=None, out=None, accumulate=False, ws: Optional[Workspace] = None, precision="fp32",
+                    bn=None, part=None):
+    """bn = (x, mean, rstd, img_scale or None) with a float buffer `part`: `out` is the gradient w.r.t. the output of a plain batch norm
+    over x and the launch may also leave stage 1 of that batch norm's backward in `part`; returns (out, nblk) then -- pass
+    (part, nblk) to bn_bwd(stage1=...) when nblk > 0."""
     N, H, W = dy.shape[:3]
     k, _, Cin, Cout = w.shape
     ci_count = Cin - ci_begin if ci_count is None else ci_count
@@ -302,6 +306,14 @@ def conv2d_bwd_data(dy, w, dil=1, ci_begin=0, ci_count=None, out=None, accumulat
         tm, nt, sp = conv2d_plan(N, H, W, Cout, ci_count, k)
         meta = dict(kernel=conv2d_kernel_name(N, H, W, Cout, ci_count, k, False, precision), splits=sp, flops=2.0 * N * H * W * k * k * ci_count * Cout,
                     shape=(N, H, W, ci_count, Cout, k, dil))
+    if bn is not None:
+        bx, bmean, brstd, bscale = bn
+        nblk = C.c_int(0)
+        _timed("conv2d_bwd_data", meta, lambda: lib.call("mliis_conv2d_bwd_data_bn", _ptr(dy), lddy, _ptr(w), _ptr(out), lddx, N, H, W, Cin,
+                                                         ci_begin, ci_count, Cout, k, dil, int(accumulate), _ptr(buf), buf.numel(), prec,
+                                                         _ptr(bx), rows_ld(bx)[2], _ptr(bmean), _ptr(brstd), _ptr(bscale), _ptr(part),
+                                                         part.numel(), C.byref(nblk), _stream()))
+        return out, nblk.value
     _timed("conv2d_bwd_data", meta, lambda: lib.call("mliis_conv2d_bwd_data", _ptr(dy), lddy, _ptr(w), _ptr(out), lddx, N, H, W, Cin, ci_begin,
                                                      ci_count, Cout, k, dil, int(accumulate), _ptr(buf), buf.numel(), prec, _stream()))
     return out

@@ -982,3 +982,48 @@ def test_conv1x1_ksplit_random_shapes():
             close(dx[..., :Co], refx, 1e-4, "ksplit bwd data case %d" % case)
             assert (dx[..., Co:] == -2).all()
     assert len(seen) >= 5, seen          # several KC instances were hit
+
+
+@pytest.mark.parametrize("N,H,K,C,scaled,acc", [(8, 14, 480, 80, True, True), (8, 14, 672, 112, False, False), (5, 28, 240, 40, True, False),
+                                                (8, 14, 672, 112, True, True), (3, 7, 144, 24, False, True)])
+def test_conv2d_bwd_data_emits_bn_backward_stage1(N, H, K, C, scaled, acc):
+    """mliis_conv2d_bwd_data_bn: the backward-data of an expand conv (K = expanded channels) produces the gradient of the block in
+    front, which is the OUTPUT gradient of that block's project batch norm; on the small-map plan the launch also leaves
+    {sum g, sum g * xhat} (g = dx * drop-connect scale) so that mliis_bn_bwd skips its reduce pass.  Same dx as the plain call; the
+    batch norm's dx / dgamma / dbeta equal the two-pass path (itself checked against the oracle in test_bn_train_fwd_bwd)."""
+    from mliis_amd import ops
+    d = dev()
+    dy = f32(rnd(N, H, H, K, seed=31), d)
+    w = f32(rnd(1, 1, C, K, seed=32, scale=1.0 / math.sqrt(K)), d)
+    prev = f32(rnd(N, H, H, C, seed=33), d)
+    z64 = rnd(N, H, H, C, seed=34) * 1.5 + 0.3                          # the batch norm's input
+    z = f32(z64, d)
+    gamma, beta = f32(rnd(C, seed=35) * 0.5 + 1, d), f32(rnd(C, seed=36), d)
+    scale = f32(torch.tensor(np.random.default_rng(3).choice([0.0, 1.25], N)), d) if scaled else None
+    zz = z64.float().double().reshape(-1, C)
+    mean, var = zz.mean(0), zz.var(0, unbiased=False)
+    mean_g, rstd_g = mean.float().to(d), torch.rsqrt(var + 1e-3).float().to(d)
+    dx_plain = prev.clone() if acc else torch.empty_like(prev)
+    ops.conv2d_bwd_data(dy, w, 1, out=dx_plain, accumulate=acc)
+    dx_bn = prev.clone() if acc else torch.empty_like(prev)
+    part = torch.full((1 << 18,), 5.0, device=d)
+    _, nblk = ops.conv2d_bwd_data(dy, w, 1, out=dx_bn, accumulate=acc, bn=(z, mean_g, rstd_g, scale), part=part)
+    assert torch.equal(dx_plain, dx_bn)
+    assert nblk > 0 and "conv1x1_ksplit_k" in ops.conv2d_kernel_name(N, H, H, K, C, 1)
+    assert (part[nblk * 2 * C:] == 5).all()
+    # sums against float64
+    g64 = dx_bn.double().cpu().reshape(-1, C) * (scale.double().cpu().repeat_interleave(H * H)[:, None] if scaled else 1.0)
+    mean, var = mean.cpu(), var.cpu()
+    xh = (zz - mean) * torch.rsqrt(var + 1e-3)
+    sums = part[: nblk * 2 * C].view(nblk, 2, C).double().sum(0).cpu()
+    close(sums[0], g64.sum(0), 2e-5, "stage-1 sum g")
+    close(sums[1], (g64 * xh).sum(0), 2e-5, "stage-1 sum g xhat")
+    # the batch norm's backward with and without the handed-over stage 1
+    outs = []
+    for st in (None, (part, nblk)):
+        dxo = torch.empty_like(dx_bn)
+        dg, db = torch.empty(C, device=d), torch.empty(C, device=d)
+        ops.bn_bwd(z, dx_bn, mean_g, rstd_g, gamma, beta, False, False, scale, None, None, dx=dxo, dgamma=dg, dbeta=db, stage1=st)
+        outs.append((dxo, dg, db))
+    for a, b, what in zip(outs[0], outs[1], ("dx", "dgamma", "dbeta")):
+        close(b, a.double().cpu(), 2e-5, "bn backward with stage 1 from the GEMM: " + what)
