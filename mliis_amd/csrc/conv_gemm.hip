@@ -378,8 +378,8 @@ int mliis_conv2d_plan(int Nimg, int H, int W, int Cred, int Nout, int ksize, int
 // conv2d_bwd_data call with these shapes launches (has_scale: an x_scale operand is given).
 // ------------------------------------------------------------------------------------------------ long-K 1x1 convs on small maps (conv1x1_ksplit_k)
 // K split over the 8 waves of a workgroup instead of over workgroups + a fold launch: the MBConv project convs forward and expand
-// convs backward-data of the 28x28 / 14x14 maps (K = 240..672, 1568..6272 rows at N = 8).
-constexpr long long kKsplitMaxRows = 8192;
+// convs backward-data of the 56x56 / 28x28 / 14x14 maps (K = 144..672, 1568..25088 rows at N = 8).
+constexpr long long kKsplitMaxRows = 32768;   // up to the 56x56 maps (measured: 8192 -> 2868, 32768 -> 2872, 131072 -> 2875 images/s)
 static const bool kKsplit = getenv("MLIIS_NO_KSPLIT") == nullptr;   // (A/B switch for profiles/r02_notes.md)
 static inline bool ksplit_plan(long long M, int K, int Nout, int num_cus, StreamPlan* sp) {
   if (!kKsplit || K <= 112 || K > 7 * 128 || M > kKsplitMaxRows || M < 16) return false;
