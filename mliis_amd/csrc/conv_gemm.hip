@@ -585,10 +585,23 @@ static int conv2d_bwd_data_impl(const float* dy, int lddy, const float* w, float
                    Cout, Cin_out, dx, lddx, nullptr, accumulate, nullptr, g.chunks_per_split, nullptr, 0, nullptr, nullptr, 1.0f, nullptr};
   {  // short-K 1x1 convs (backward-data of the MBConv project convs): barrier-free streaming kernel
     StreamPlan sp;
-    if (ksize == 1 && !accumulate && M * lddx * 4 < (1LL << 31) && stream_plan(M, Cout, Cin_out, num_cus(), &sp) &&
-        launch_stream(sp, p, stream, precision)) {
-      MLIIS_CHECK_LAUNCH("conv2d_bwd_data_stream");
-      return MLIIS_OK;
+    if (ksize == 1 && !accumulate && M * lddx * 4 < (1LL << 31) && stream_plan(M, Cout, Cin_out, num_cus(), &sp)) {
+      const bool with_bn = bnb != nullptr && (size_t)sp.gx * 2 * Cin_out <= bnb->part_floats;
+      if (with_bn) {   // + stage 1 of the consumer batch norm's backward (per-wave sums, folded per block like the forward statistics)
+        p.stats_part = bnb->part;
+        p.bnb_x = bnb->x;
+        p.bnb_ldx = bnb->ldx;
+        p.bnb_mean = bnb->mean;
+        p.bnb_rstd = bnb->rstd;
+        p.bnb_scale = bnb->img_scale;
+      }
+      if (launch_stream(sp, p, stream, precision)) {
+        MLIIS_CHECK_LAUNCH("conv2d_bwd_data_stream");
+        if (with_bn) *bnb->nblk = sp.gx;
+        return MLIIS_OK;
+      }
+      p.stats_part = nullptr;
+      p.bnb_x = nullptr;
     }
     // long-K 1x1 convs on small maps (backward-data of the MBConv expand convs): K split inside the workgroup, one launch
     if (ksize == 1 && M * lddx * 4 < (1LL << 31) && M * lddy * 4 < (1LL << 31) && ksplit_plan(M, Cout, Cin_out, num_cus(), &sp)) {

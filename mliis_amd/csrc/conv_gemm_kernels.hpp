@@ -634,6 +634,15 @@ __global__ __launch_bounds__(256) void conv1x1_stream_k(ConvGemmParams p, int ro
 #pragma unroll
   for (int j = 0; j < NT; ++j) s1[j] = s2[j] = 0.f;
   const bool stats = p.stats_part != nullptr;
+  const bool bnb = stats && p.bnb_x != nullptr;
+  const int HWs = p.H * p.W;
+  float bmean[NT], brstd[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int n = n0 + j * 16 + l15;
+    bmean[j] = (bnb && n < p.Nout) ? p.bnb_mean[n] : 0.f;
+    brstd[j] = (bnb && n < p.Nout) ? p.bnb_rstd[n] : 0.f;
+  }
   const int stride = gridDim.x * 4;
   auto load_a = [&](int rg, float4* a) {
     const int m = rg * 16 + l15;
@@ -688,7 +697,14 @@ __global__ __launch_bounds__(256) void conv1x1_stream_k(ConvGemmParams p, int ro
           const int n = n0 + j * 16 + l15;
           const float v = (PREC == 2 ? acc[j][r] * out_scale : acc[j][r]) + bj[j];
           if (n < p.Nout) p.Cmat[(long long)m * p.ldc + n] = v;
-          if (stats) {
+          if (bnb) {   // stage 1 of the consumer batch norm's backward (mliis_conv2d_bwd_data_bn): {sum g, sum g * xhat}
+            if (n < p.Nout) {
+              const float gq = p.bnb_scale != nullptr ? v * p.bnb_scale[m / HWs] : v;
+              const float xh = (p.bnb_x[(long long)m * p.bnb_ldx + n] - bmean[j]) * brstd[j];
+              s1[j] += gq;
+              s2[j] = fmaf(gq, xh, s2[j]);
+            }
+          } else if (stats) {
             const float u = p.stats_swish ? swish_f(v) : v;
             s1[j] += u;
             s2[j] = fmaf(u, u, s2[j]);

@@ -985,7 +985,9 @@ def test_conv1x1_ksplit_random_shapes():
 
 
 @pytest.mark.parametrize("N,H,K,C,scaled,acc", [(8, 14, 480, 80, True, True), (8, 14, 672, 112, False, False), (5, 28, 240, 40, True, False),
-                                                (8, 14, 672, 112, True, True), (3, 7, 144, 24, False, True)])
+                                                (8, 14, 672, 112, True, True), (3, 7, 144, 24, False, True),
+                                                # short K, no accumulate: the streaming kernel's per-wave epilogue (block 1's expand conv)
+                                                (8, 112, 96, 16, False, False), (2, 40, 96, 24, True, False)])
 def test_conv2d_bwd_data_emits_bn_backward_stage1(N, H, K, C, scaled, acc):
     """mliis_conv2d_bwd_data_bn: the backward-data of an expand conv (K = expanded channels) produces the gradient of the block in
     front, which is the OUTPUT gradient of that block's project batch norm; on the small-map plan the launch also leaves
@@ -1009,7 +1011,7 @@ def test_conv2d_bwd_data_emits_bn_backward_stage1(N, H, K, C, scaled, acc):
     part = torch.full((1 << 18,), 5.0, device=d)
     _, nblk = ops.conv2d_bwd_data(dy, w, 1, out=dx_bn, accumulate=acc, bn=(z, mean_g, rstd_g, scale), part=part)
     assert torch.equal(dx_plain, dx_bn)
-    assert nblk > 0 and "conv1x1_ksplit_k" in ops.conv2d_kernel_name(N, H, H, K, C, 1)
+    assert nblk > 0 and ("conv1x1_ksplit_k" if K > 112 else "conv1x1_stream_k") in ops.conv2d_kernel_name(N, H, H, K, C, 1)
     assert (part[nblk * 2 * C:] == 5).all()
     # sums against float64
     g64 = dx_bn.double().cpu().reshape(-1, C) * (scale.double().cpu().repeat_interleave(H * H)[:, None] if scaled else 1.0)
