@@ -155,6 +155,13 @@ int mliis_conv2d_bwd_data_bn(const float* dy, int lddy, const float* w, float* d
                              int ci_begin, int Cin_out, int Cout, int ksize, int dil, int accumulate, float* ws, size_t ws_floats,
                              int precision, const float* bn_x, int bn_ldx, const float* bn_mean, const float* bn_rstd,
                              const float* bn_img_scale, float* part, size_t part_floats, int* nblk, hipStream_t stream);
+/*      same as mliis_conv2d_bwd_data, when dx is the gradient w.r.t. gate_x * gate[image] (the squeeze-excite gating in front of a
+ *      project conv, efficientnet_model.py:251): on the streaming plan the launch also leaves the column sums of dx * gate_x per
+ *      16-row group, split by image, in part [*groups][2][Cin_out]; mliis_se_mlp_bwd(dgate = part, dgate_row_groups = *groups) folds
+ *      them -- the gate's gradient without a pass over the two tensors.  *groups == 0: not produced (use mliis_colsum). */
+int mliis_conv2d_bwd_data_gate(const float* dy, int lddy, const float* w, float* dx, int lddx, int Nimg, int H, int W, int Cin_total,
+                               int ci_begin, int Cin_out, int Cout, int ksize, int dil, float* ws, size_t ws_floats, int precision,
+                               const float* gate_x, int gate_ldx, float* part, size_t part_floats, int* groups, hipStream_t stream);
 size_t mliis_conv2d_bwd_filter_workspace_floats(int Nimg, int H, int W, int Cin, int Cout, int ksize);
 /*      writes rows [ci_begin, ci_begin+Cin) (per tap) of the full [k,k,Cin_total,Cout] gradient tensor dw */
 int mliis_conv2d_bwd_filter(const float* x, int ldx, const float* x_scale, const float* dy, int lddy, float* dw, int Nimg, int H, int W,
@@ -236,9 +243,9 @@ int mliis_se_mlp_fwd(const float* s_part, int chunks, float scale, float* s_out,
 /*      dw1 .. db2 all NULL: the weight gradients are left to mliis_se_wgrad_batched (one launch for every block of a backward pass;
  *      desc = device int64 [ndesc][12] {s, hpre, dpre1, dpre2, dw1, db1, dw2, db2 as device addresses, N, C, R, tile_begin}, a tile =
  *      256 of the 2*C*R + C + R gradient elements of a block, tile_begin = running sum of ceil(elements / 256)). */
-int mliis_se_mlp_bwd(const float* dgate, const float* gate, const float* s, const float* hpre, const float* w1, const float* w2,
-                     float* dpre1, float* dpre2, float* chan_add, float* dw1, float* db1, float* dw2, float* db2, int N, int C, int R,
-                     int HW, hipStream_t stream);
+int mliis_se_mlp_bwd(const float* dgate, int dgate_row_groups, const float* gate, const float* s, const float* hpre, const float* w1,
+                     const float* w2, float* dpre1, float* dpre2, float* chan_add, float* dw1, float* db1, float* dw2, float* db2, int N,
+                     int C, int R, int HW, hipStream_t stream);
 int mliis_se_wgrad_batched(const long long* desc, int ndesc, long long total_tiles, hipStream_t stream);
 /*      y0[m, c] (+)= x[m, c] + A[n(m), c] for c < c0 and y1[m, c - c0] (+)= the same for c >= c0: the gradient of a channel concat
  *      routed to its two inputs in one pass (tail of the RSD module's backward, models/efficientlab.py:206-208,226-228) */

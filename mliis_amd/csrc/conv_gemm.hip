@@ -528,7 +528,8 @@ int mliis_conv2d_fwd(const float* x, int ldx, const float* x_scale, const float*
 
 // dx[M, Cin_out] (ld = lddx) (+)= conv_transpose(dy[M, Cout] (ld = lddy), w) restricted to input channels
 // [ci_begin, ci_begin + Cin_out) of a weight tensor w[k,k,Cin_total,Cout].
-struct BnbArgs {   // mliis_conv2d_bwd_data_bn: the batch norm whose output gradient this call produces
+struct BnbArgs {   // mliis_conv2d_bwd_data_bn: the batch norm whose output gradient this call produces;
+                   // mliis_conv2d_bwd_data_gate (mean == NULL): the tensor the output is multiplied with under the squeeze-excite gate
   const float* x;
   int ldx;
   const float *mean, *rstd, *img_scale;
@@ -565,6 +566,23 @@ int mliis_conv2d_bwd_data_bn(const float* dy, int lddy, const float* w, float* d
                               precision, stream, &b);
 }
 
+// Same as mliis_conv2d_bwd_data, when dx is the gradient w.r.t. the product gate_x * gate[image] (the squeeze-excite gating in front of
+// an MBConv project conv, efficientnet_model.py:251): on the streaming plan (short K, no accumulate) with maps of at least 16 pixels the
+// launch also leaves the column sums of dx * gate_x per 16-row group, split by image, in part [*groups][2][Cin_out] -- the gate's
+// gradient dgate[n][c] = sum over image n of dx * gate_x, which mliis_se_mlp_bwd(dgate_row_groups = *groups) folds itself.
+// *groups == 0: not produced (another plan, or part too small): run mliis_colsum then.
+int mliis_conv2d_bwd_data_gate(const float* dy, int lddy, const float* w, float* dx, int lddx, int Nimg, int H, int W, int Cin_total,
+                               int ci_begin, int Cin_out, int Cout, int ksize, int dil, float* ws, size_t ws_floats, int precision,
+                               const float* gate_x, int gate_ldx, float* part, size_t part_floats, int* groups, hipStream_t stream) {
+  MLIIS_REQUIRE(gate_x && part && groups, MLIIS_ERR_ARG, "conv2d_bwd_data_gate: null pointer");
+  MLIIS_REQUIRE((gate_ldx & 3) == 0 && gate_ldx >= Cin_out && aligned16(gate_x) && aligned16(part), MLIIS_ERR_ARG,
+                "conv2d_bwd_data_gate: operands misaligned or too narrow");
+  *groups = 0;
+  const BnbArgs b{gate_x, gate_ldx, nullptr, nullptr, nullptr, part, part_floats, groups};
+  return conv2d_bwd_data_impl(dy, lddy, w, dx, lddx, Nimg, H, W, Cin_total, ci_begin, Cin_out, Cout, ksize, dil, 0, ws, ws_floats, precision,
+                              stream, &b);
+}
+
 static int conv2d_bwd_data_impl(const float* dy, int lddy, const float* w, float* dx, int lddx, int Nimg, int H, int W, int Cin_total,
                                 int ci_begin, int Cin_out, int Cout, int ksize, int dil, int accumulate, float* ws, size_t ws_floats,
                                 int precision, hipStream_t stream, const BnbArgs* bnb) {
@@ -586,7 +604,9 @@ static int conv2d_bwd_data_impl(const float* dy, int lddy, const float* w, float
   {  // short-K 1x1 convs (backward-data of the MBConv project convs): barrier-free streaming kernel
     StreamPlan sp;
     if (ksize == 1 && !accumulate && M * lddx * 4 < (1LL << 31) && stream_plan(M, Cout, Cin_out, num_cus(), &sp)) {
-      const bool with_bn = bnb != nullptr && (size_t)sp.gx * 2 * Cin_out <= bnb->part_floats;
+      const bool gate = bnb != nullptr && bnb->mean == nullptr;
+      const bool with_bn = bnb != nullptr && !gate && (size_t)sp.gx * 2 * Cin_out <= bnb->part_floats;
+      const bool with_gate = gate && (long long)H * W >= 16 && (size_t)sp.row_groups * 2 * Cin_out <= bnb->part_floats;
       if (with_bn) {   // + stage 1 of the consumer batch norm's backward (per-wave sums, folded per block like the forward statistics)
         p.stats_part = bnb->part;
         p.bnb_x = bnb->x;
@@ -595,17 +615,24 @@ static int conv2d_bwd_data_impl(const float* dy, int lddy, const float* w, float
         p.bnb_rstd = bnb->rstd;
         p.bnb_scale = bnb->img_scale;
       }
+      if (with_gate) {   // + per-row-group sums of dx * gate_x (the squeeze-excite gate's gradient)
+        p.gp_x = bnb->x;
+        p.gp_ldx = bnb->ldx;
+        p.gp_part = bnb->part;
+      }
       if (launch_stream(sp, p, stream, precision)) {
         MLIIS_CHECK_LAUNCH("conv2d_bwd_data_stream");
         if (with_bn) *bnb->nblk = sp.gx;
+        if (with_gate) *bnb->nblk = sp.row_groups;
         return MLIIS_OK;
       }
       p.stats_part = nullptr;
       p.bnb_x = nullptr;
+      p.gp_part = nullptr;
     }
     // long-K 1x1 convs on small maps (backward-data of the MBConv expand convs): K split inside the workgroup, one launch
     if (ksize == 1 && M * lddx * 4 < (1LL << 31) && M * lddy * 4 < (1LL << 31) && ksplit_plan(M, Cout, Cin_out, num_cus(), &sp)) {
-      const bool with_bn = bnb != nullptr && (size_t)sp.gx * 2 * Cin_out <= bnb->part_floats;
+      const bool with_bn = bnb != nullptr && bnb->mean != nullptr && (size_t)sp.gx * 2 * Cin_out <= bnb->part_floats;
       if (with_bn) {   // + stage 1 of the consumer batch norm's backward from the finishing threads
         p.stats_part = bnb->part;
         p.bnb_x = bnb->x;

@@ -49,6 +49,13 @@ struct ConvGemmParams {
   const float* bnb_mean = nullptr;
   const float* bnb_rstd = nullptr;
   const float* bnb_scale = nullptr;   // nullable [Nimg]
+  // conv1x1_stream_k only: the output is the gradient w.r.t. gp_x * gate (the squeeze-excite product, efficientnet_model.py:251) --
+  // the launch also leaves, per 16-row group, the column sums of output * gp_x split by image (a group spans at most two images
+  // when H * W >= 16) in gp_part [row groups][2][Nout]: the gate's gradient without a pass over the two tensors
+  // (mliis_conv2d_bwd_data_gate; mliis_se_mlp_bwd folds the groups of an image)
+  const float* gp_x = nullptr;
+  int gp_ldx = 0;
+  float* gp_part = nullptr;
 };
 
 // operand precision of an instance: 0 = fp32 (v_mfma_f32_16x16x4_f32), 1 = bf16 (v_mfma_f32_16x16x32_bf16), 2 = fp8 e4m3
@@ -635,6 +642,7 @@ __global__ __launch_bounds__(256) void conv1x1_stream_k(ConvGemmParams p, int ro
   for (int j = 0; j < NT; ++j) s1[j] = s2[j] = 0.f;
   const bool stats = p.stats_part != nullptr;
   const bool bnb = stats && p.bnb_x != nullptr;
+  const bool gated_part = p.gp_part != nullptr;
   const int HWs = p.H * p.W;
   float bmean[NT], brstd[NT];
 #pragma unroll
@@ -688,6 +696,10 @@ __global__ __launch_bounds__(256) void conv1x1_stream_k(ConvGemmParams p, int ro
       }
     }
     // C/D layout: column l15 of tile j, rows 4 g + r
+    float gp0[NT], gp1[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) gp0[j] = gp1[j] = 0.f;
+    const int gp_bound = gated_part ? ((rg * 16) / HWs + 1) * HWs : 0;   // first row of the image after the one this group starts in
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int m = rg * 16 + g * 4 + r;
@@ -697,6 +709,11 @@ __global__ __launch_bounds__(256) void conv1x1_stream_k(ConvGemmParams p, int ro
           const int n = n0 + j * 16 + l15;
           const float v = (PREC == 2 ? acc[j][r] * out_scale : acc[j][r]) + bj[j];
           if (n < p.Nout) p.Cmat[(long long)m * p.ldc + n] = v;
+          if (gated_part && n < p.Nout) {
+            const float pv = v * p.gp_x[(long long)m * p.gp_ldx + n];
+            if (m < gp_bound) gp0[j] += pv;
+            else gp1[j] += pv;
+          }
           if (bnb) {   // stage 1 of the consumer batch norm's backward (mliis_conv2d_bwd_data_bn): {sum g, sum g * xhat}
             if (n < p.Nout) {
               const float gq = p.bnb_scale != nullptr ? v * p.bnb_scale[m / HWs] : v;
@@ -709,6 +726,21 @@ __global__ __launch_bounds__(256) void conv1x1_stream_k(ConvGemmParams p, int ro
             s1[j] += u;
             s2[j] = fmaf(u, u, s2[j]);
           }
+        }
+      }
+    }
+    if (gated_part) {   // the four row quads of the group (lane groups g) folded; lanes g == 0 publish [rg][slot][column]
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        float a = gp0[j], b = gp1[j];
+        a += __shfl_xor(a, 16, 64);
+        b += __shfl_xor(b, 16, 64);
+        a += __shfl_xor(a, 32, 64);
+        b += __shfl_xor(b, 32, 64);
+        const int n = n0 + j * 16 + l15;
+        if (g == 0 && n < p.Nout) {
+          p.gp_part[((long long)rg * 2 + 0) * p.Nout + n] = a;
+          p.gp_part[((long long)rg * 2 + 1) * p.Nout + n] = b;
         }
       }
     }

@@ -93,7 +93,11 @@ __global__ __launch_bounds__(kSeThreads) void se_mlp_fwd_k(const float* __restri
 }
 
 // one workgroup per image: dgate -> dpre2 [C], dpre1 [R], chan_add = ds / HW [C]
-__global__ __launch_bounds__(kSeThreads) void se_mlp_bwd_k(const float* __restrict__ dgate, const float* __restrict__ gate,
+// dgate_groups > 0: dgate holds per-16-row-group partial sums [groups][2][C] from the producer of the gradient
+// (mliis_conv2d_bwd_data_gate): slot 0 = rows of the image the group starts in, slot 1 = rows of the next image; image n owns rows
+// [n * HW, (n + 1) * HW).  Its groups are folded here in group order (deterministic), all loads of eight groups issued together.
+__global__ __launch_bounds__(kSeThreads) void se_mlp_bwd_k(const float* __restrict__ dgate, int dgate_groups, int HW,
+                                                    const float* __restrict__ gate,
                                                     const float* __restrict__ hpre, const float* __restrict__ w1,
                                                     const float* __restrict__ w2, float* __restrict__ dpre2,
                                                     float* __restrict__ dpre1, float* __restrict__ chan_add, int C, int R,
@@ -102,9 +106,27 @@ __global__ __launch_bounds__(kSeThreads) void se_mlp_bwd_k(const float* __restri
   extern __shared__ float sd2[];   // [C]
   const int n = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
   float* d2 = dpre2 + (long long)n * C;
+  const int g_lo = dgate_groups > 0 ? (n * HW) / 16 : 0, g_hi = dgate_groups > 0 ? ((n + 1) * HW - 1) / 16 : -1;
   for (int c = t; c < C; c += kSeThreads) {
     const float g = gate[(long long)n * C + c];
-    const float v = dgate[(long long)n * C + c] * g * (1.f - g);
+    float dg;
+    if (dgate_groups > 0) {
+      dg = 0.f;
+      for (int k = g_lo; k <= g_hi; k += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int rg = k + u <= g_hi ? k + u : g_hi;
+          const int slot = rg * 16 >= n * HW ? 0 : 1;          // the group starts inside image n, or in the image before it
+          v[u] = dgate[((long long)rg * 2 + slot) * C + c];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) dg += k + u <= g_hi ? v[u] : 0.f;
+      }
+    } else {
+      dg = dgate[(long long)n * C + c];
+    }
+    const float v = dg * g * (1.f - g);
     d2[c] = v;
     sd2[c] = v;
   }
@@ -275,16 +297,18 @@ int mliis_se_mlp_fwd(const float* s_part, int chunks, float scale, float* s_out,
 
 // dgate[N,C] = sum_hw dy * x (mliis_colsum).  Produces dpre1 [N,R], dpre2 [N,C] (scratch kept for the weight gradients),
 // chan_add [N,C] = (dL/ds)/HW, and the four weight gradients.
-int mliis_se_mlp_bwd(const float* dgate, const float* gate, const float* s, const float* hpre, const float* w1, const float* w2,
-                     float* dpre1, float* dpre2, float* chan_add, float* dw1, float* db1, float* dw2, float* db2, int N, int C, int R,
-                     int HW, hipStream_t stream) {
+int mliis_se_mlp_bwd(const float* dgate, int dgate_row_groups, const float* gate, const float* s, const float* hpre, const float* w1,
+                     const float* w2, float* dpre1, float* dpre2, float* chan_add, float* dw1, float* db1, float* dw2, float* db2, int N,
+                     int C, int R, int HW, hipStream_t stream) {
+  MLIIS_REQUIRE(dgate_row_groups == 0 || (HW >= 16 && (long long)dgate_row_groups * 16 >= (long long)N * HW), MLIIS_ERR_ARG,
+                "se_mlp_bwd: the row-group partials do not cover the N * HW rows (maps of at least 16 pixels)");
   MLIIS_REQUIRE(dgate && gate && s && hpre && w1 && w2 && dpre1 && dpre2 && chan_add, MLIIS_ERR_ARG, "se_mlp_bwd: null pointer");
   MLIIS_REQUIRE((dw1 && db1 && dw2 && db2) || (!dw1 && !db1 && !dw2 && !db2), MLIIS_ERR_ARG,
                 "se_mlp_bwd: the four weight-gradient outputs come together (all NULL = deferred to mliis_se_wgrad_batched)");
   MLIIS_REQUIRE(N > 0 && C > 0 && R > 0 && R <= kMaxR && HW > 0, MLIIS_ERR_ARG, "se_mlp_bwd: bad shape");
   MLIIS_REQUIRE(C <= 8192, MLIIS_ERR_UNSUPPORTED, "se_mlp_bwd: C > 8192");
-  hipLaunchKernelGGL(se_mlp_bwd_k, dim3(N), dim3(kSeThreads), (size_t)C * sizeof(float), stream, dgate, gate, hpre, w1, w2, dpre2, dpre1, chan_add, C, R,
-                     1.0f / (float)HW);
+  hipLaunchKernelGGL(se_mlp_bwd_k, dim3(N), dim3(kSeThreads), (size_t)C * sizeof(float), stream, dgate, dgate_row_groups, HW, gate, hpre, w1, w2,
+                     dpre2, dpre1, chan_add, C, R, 1.0f / (float)HW);
   MLIIS_CHECK_LAUNCH("se_mlp_bwd");
   if (dw1 == nullptr) return MLIIS_OK;
   int total = 2 * C * R + C + R;

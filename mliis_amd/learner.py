@@ -134,6 +134,9 @@ class _Plan:
         self.stats_part = buf(need + 64)
         # squeeze-excite pooling partials of the bn1 apply pass: [N][ceil(rows_per_img / 128)][C]
         self.pool_part = buf(max(N * (-(-(b.h_out * b.h_out) // 128)) * b.cexp for b in a.blocks if b.executed) + 64)
+        # gate-gradient partials of the project backward-data launch on the small maps: [16-row groups][2][C]
+        self.gate_part = buf(max([(-(-(N * b.h_out * b.h_out) // 16)) * 2 * b.cexp for b in a.blocks if b.executed and 16 <= b.h_out * b.h_out <= 256]
+                                 + [0]) + 64)
         # ---- deferred weight-gradient folds: every *_bwd_filter leaves its per-split slabs in a region of fold_buf and ONE
         #      mliis_fold_batched launch at the end of the backward pass reduces them all into the gradient arena
         A = L.arena
@@ -256,6 +259,8 @@ class Learner:
         # stage 1 of the project-BN backward from the epilogue of the expand backward-data launch that finishes its input (small maps;
         # MLIIS_BN_STAGE1_FROM_GEMM=0: the batch norm's own reduce launch, for A/B runs)
         self.bn_stage1_from_gemm = os.environ.get("MLIIS_BN_STAGE1_FROM_GEMM", "1") != "0"
+        # the squeeze-excite gate's gradient from the project backward-data launch on the small maps (MLIIS_GATE_GRAD_FROM_GEMM=0: colsum)
+        self.gate_grad_from_gemm = os.environ.get("MLIIS_GATE_GRAD_FROM_GEMM", "1") != "0"
         self.device = torch.device(device)
         torch.cuda.set_device(self.device)
         self.arch = spec.derive(feature_extractor_name, image_size, list(rsd or []), final_layer_dropout_rate, spatial_pyramid_pooling,
@@ -944,12 +949,19 @@ class Learner:
                 tgt_has = True
             wgrad_1x1(B["a1"], dout, nm["w_proj"], x_scale=B["gate"])
             da2 = B["da2"]
-            self._conv_bwd_data(dout, w[nm["w_proj"]], 1, out=da2, ws=ws)
-            ops.colsum(da2, B["a1"], nseg=N, out=B["dgate"], ws=ws)
             se = nm["se"]
+            groups = 0
+            if self.gate_grad_from_gemm and 16 <= hw <= 256:
+                # small maps: the project backward-data launch also leaves the gate gradient's per-row-group partial sums of da2 * a1
+                # and the SE kernel folds them -- no pass over the two tensors (mliis_conv2d_bwd_data_gate)
+                _, groups = self._conv_bwd_data(dout, w[nm["w_proj"]], 1, out=da2, ws=ws, gate=B["a1"], part=P.gate_part)
+            else:
+                self._conv_bwd_data(dout, w[nm["w_proj"]], 1, out=da2, ws=ws)
+            if not groups:
+                ops.colsum(da2, B["a1"], nseg=N, out=B["dgate"], ws=ws)
             # (the SE weight gradients of all blocks are computed by one batched launch after the loop: P.se_desc)
-            ops.se_mlp_bwd(B["dgate"], B["gate"], B["s"], B["hpre"], w[se[0]], w[se[2]], hw,
-                           dict(dpre1=B["dpre1"], dpre2=B["dpre2"], chan_add=B["chan_add"]))
+            ops.se_mlp_bwd(P.gate_part if groups else B["dgate"], B["gate"], B["s"], B["hpre"], w[se[0]], w[se[2]], hw,
+                           dict(dpre1=B["dpre1"], dpre2=B["dpre2"], chan_add=B["chan_add"]), dgate_groups=groups)
             if B["small"]:   # bn1 backward, depthwise filter gradient + backward-data, bn0 backward: one launch
                 da0, st0, st1, p0, p1 = B["da0"], B["st0"], B["st1"], nm["bn0"], nm["bn1"]
                 ops.mbconv_dw_bwd_small(da2, B["gate"], B["chan_add"], B["z1"], (st1[0], st1[1], w[p1 + "/gamma"], w[p1 + "/beta"]),

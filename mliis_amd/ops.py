@@ -286,7 +286,7 @@ def conv2d_fwd(x, w, bias=None, dil=1, out=None, accumulate=False, ws: Optional[
 
 
 def conv2d_bwd_data(dy, w, dil=1, ci_begin=0, ci_count=None, out=None, accumulate=False, ws: Optional[Workspace] = None, precision="fp32",
-                    bn=None, part=None):
+                    bn=None, part=None, gate=None):
     """bn = (x, mean, rstd, img_scale or None) with a float buffer `part`: `out` is the gradient w.r.t. the output of a plain batch norm
     over x and the launch may also leave stage 1 of that batch norm's backward in `part`; returns (out, nblk) then -- pass
     (part, nblk) to bn_bwd(stage1=...) when nblk > 0."""
@@ -306,6 +306,12 @@ def conv2d_bwd_data(dy, w, dil=1, ci_begin=0, ci_count=None, out=None, accumulat
         tm, nt, sp = conv2d_plan(N, H, W, Cout, ci_count, k)
         meta = dict(kernel=conv2d_kernel_name(N, H, W, Cout, ci_count, k, False, precision), splits=sp, flops=2.0 * N * H * W * k * k * ci_count * Cout,
                     shape=(N, H, W, ci_count, Cout, k, dil))
+    if gate is not None:   # out is the gradient w.r.t. gate_x * gate: the launch may leave the gate-gradient partials in `part`
+        groups = C.c_int(0)
+        _timed("conv2d_bwd_data", meta, lambda: lib.call("mliis_conv2d_bwd_data_gate", _ptr(dy), lddy, _ptr(w), _ptr(out), lddx, N, H, W, Cin,
+                                                         ci_begin, ci_count, Cout, k, dil, _ptr(buf), buf.numel(), prec, _ptr(gate),
+                                                         rows_ld(gate)[2], _ptr(part), part.numel(), C.byref(groups), _stream()))
+        return out, groups.value
     if bn is not None:
         bx, bmean, brstd, bscale = bn
         nblk = C.c_int(0)
@@ -527,8 +533,9 @@ def se_wgrad_batched(desc, total_tiles):
     lib.call("mliis_se_wgrad_batched", _ptr(desc), int(desc.shape[0]), int(total_tiles), _stream())
 
 
-def se_mlp_bwd(dgate, gate, s, hpre, w1, w2, hw, outs=None):
-    """outs without "dw1".."db2": the weight gradients are deferred to se_wgrad_batched."""
+def se_mlp_bwd(dgate, gate, s, hpre, w1, w2, hw, outs=None, dgate_groups=0):
+    """outs without "dw1".."db2": the weight gradients are deferred to se_wgrad_batched.  dgate_groups > 0: `dgate` holds the
+    per-row-group partial sums of conv2d_bwd_data(gate=...) and the kernel folds them."""
     N, C_ = s.shape
     R = hpre.shape[1]
     dev = s.device
@@ -536,7 +543,7 @@ def se_mlp_bwd(dgate, gate, s, hpre, w1, w2, hw, outs=None):
         outs = dict(dpre1=torch.empty((N, R), device=dev), dpre2=torch.empty((N, C_), device=dev), chan_add=torch.empty((N, C_), device=dev),
                     dw1=torch.empty((1, 1, C_, R), device=dev), db1=torch.empty(R, device=dev), dw2=torch.empty((1, 1, R, C_), device=dev),
                     db2=torch.empty(C_, device=dev))
-    lib.call("mliis_se_mlp_bwd", _ptr(dgate), _ptr(gate), _ptr(s), _ptr(hpre), _ptr(w1), _ptr(w2), _ptr(outs["dpre1"]), _ptr(outs["dpre2"]),
+    lib.call("mliis_se_mlp_bwd", _ptr(dgate), int(dgate_groups), _ptr(gate), _ptr(s), _ptr(hpre), _ptr(w1), _ptr(w2), _ptr(outs["dpre1"]), _ptr(outs["dpre2"]),
              _ptr(outs["chan_add"]), _ptr(outs.get("dw1")), _ptr(outs.get("db1")), _ptr(outs.get("dw2")), _ptr(outs.get("db2")), N, C_, R, hw,
              _stream())
     return outs

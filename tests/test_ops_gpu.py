@@ -1029,3 +1029,48 @@ def test_conv2d_bwd_data_emits_bn_backward_stage1(N, H, K, C, scaled, acc):
         outs.append((dxo, dg, db))
     for a, b, what in zip(outs[0], outs[1], ("dx", "dgamma", "dbeta")):
         close(b, a.double().cpu(), 2e-5, "bn backward with stage 1 from the GEMM: " + what)
+
+
+@pytest.mark.parametrize("N,H,Co,C", [(8, 14, 80, 480), (8, 14, 112, 672), (6, 14, 112, 672), (64, 4, 40, 240), (13, 9, 24, 144), (5, 14, 80, 480)])
+def test_conv2d_bwd_data_emits_gate_gradient_partials(N, H, Co, C):
+    """mliis_conv2d_bwd_data_gate + mliis_se_mlp_bwd(dgate_row_groups): the project conv's backward-data (K = its few output channels: the
+    streaming kernel) leaves per-16-row-group sums of dx * a1 split by image; the SE backward kernel folds the groups of each image.
+    Same dx as the plain call, same dpre1 / dpre2 / chan_add as with the colsum-made gate gradient, and the partials against float64
+    (maps of 196 / 16 / 81 pixels: groups that straddle two images)."""
+    from mliis_amd import ops
+    d = dev()
+    dy = f32(rnd(N, H, H, Co, seed=41), d)
+    w = f32(rnd(1, 1, C, Co, seed=42, scale=1.0 / math.sqrt(Co)), d)
+    a1 = f32(rnd(N, H, H, C, seed=43), d)
+    R_ = max(1, C // 24)
+    gate = f32(torch.sigmoid(rnd(N, C, seed=44)), d)
+    s_ = f32(rnd(N, C, seed=45), d)
+    hpre = f32(rnd(N, R_, seed=46), d)
+    w1, w2 = f32(rnd(1, 1, C, R_, seed=47, scale=0.2), d), f32(rnd(1, 1, R_, C, seed=48, scale=0.2), d)
+    dx_plain = ops.conv2d_bwd_data(dy, w, 1)
+    part = torch.full((1 << 20,), 9.0, device=d)
+    dx2 = torch.empty_like(dx_plain)
+    _, groups = ops.conv2d_bwd_data(dy, w, 1, out=dx2, gate=a1, part=part)
+    assert torch.equal(dx_plain, dx2)
+    if N * H * H < 1024:      # below the streaming kernel's range: the partials are not produced and the caller takes the colsum path
+        assert groups == 0 and "conv1x1_stream_k" not in ops.conv2d_kernel_name(N, H, H, Co, C, 1)
+        return
+    assert groups == -(-N * H * H // 16)
+    assert (part[groups * 2 * C:] == 9).all()
+    ref = (dx2.double() * a1.double()).reshape(N, H * H, C).sum(1).cpu()
+    p = part[: groups * 2 * C].view(groups, 2, C).double().cpu()
+    got = torch.zeros(N, C, dtype=torch.float64)
+    HW = H * H
+    for rg in range(groups):
+        n0 = (rg * 16) // HW
+        got[n0] += p[rg, 0]
+        if n0 + 1 < N:
+            got[n0 + 1] += p[rg, 1]
+        else:
+            assert p[rg, 1].abs().max().item() == 0
+    close(got, ref, 2e-5, "gate gradient from the row-group partials")
+    dgate = ops.colsum(dx2, a1, nseg=N)
+    o1 = ops.se_mlp_bwd(dgate.reshape(N, C), gate, s_, hpre, w1, w2, HW)
+    o2 = ops.se_mlp_bwd(part, gate, s_, hpre, w1, w2, HW, dgate_groups=groups)
+    for k in ("dpre1", "dpre2", "chan_add", "dw1", "db1", "dw2", "db2"):
+        close(o2[k], o1[k].double().cpu(), 2e-5, "se_mlp_bwd with folded partials: " + k)
