@@ -84,6 +84,30 @@ int mliis_augment_stage(const float* xin, const float* yin, float* xout, float* 
 int mliis_rng_masks(unsigned* state, int njobs, float* const* outs, const long long* numels, const float* keep, const float* const* keeps,
                     const int* row_len, const int* floor_form, hipStream_t stream);
 
+/* ---- the depthwise half of an MBConv block on the LARGE maps (dwmarch.hip): the depthwise conv with the batch norm + swish IN FRONT
+ *      of it applied while the input is staged -- expand conv -> BN -> swish -> depthwise k x k (efficientnet_model.py:175-196,
+ *      266-271; utils.py:87-134), and for block 0 the stem's BN -> swish (efficientnet_model.py:409-414).  A workgroup marches down
+ *      the rows of a (image, 32 channels, column band) with the input rows in an LDS ring: z is read ONCE, a = swish(bn(z)) is never
+ *      written, the backward is ONE pass over (dy, z).  H, W = the layer's INPUT size; w / dw [k,k,C]; k 3|5, stride 1|2.
+ *      forward: bn_gamma == NULL: no batch norm (y = dwconv(z)).  bn_nblk > 0: bn_part [bn_nblk][2][C] are the stage-1 sums {sum z,
+ *      sum z^2} of the producer (mliis_conv2d_fwd's stats_part): the launch folds them, writes bn_mean / bn_rstd (kept for the
+ *      backward pass) and updates the moving averages (nullable pair; biased variance, utils.py:118-131).  bn_nblk == 0: bn_mean /
+ *      bn_rstd are INPUTS (inference: moving statistics).  stats_part (nullable): the FOLLOWING batch norm's stage-1 sums {sum y,
+ *      sum y^2} as [*stats_nblk][2][C], *stats_nblk = mliis_dwconv_bn_fwd_blocks(...).
+ *      backward: dx = gradient w.r.t. a (bn_gamma == NULL: w.r.t. z itself); dw_part [*nblk][k*k][C] = slabs of the filter gradient
+ *      (for mliis_fold_batched; dw != NULL: also folded into dw here); bn_part (nullable) [*nblk][2][C] = stage 1 of the batch norm's
+ *      backward {sum g, sum g*xhat}, g = dx * swish'(gamma*xhat + beta), for mliis_bn_bwd(stage1_part, stage1_nblk);
+ *      *nblk = mliis_dwconv_bn_bwd_blocks(...). */
+int mliis_dwconv_bn_fwd_blocks(int N, int H, int W, int C, int k, int stride);
+int mliis_dwconv_bn_bwd_blocks(int N, int H, int W, int C, int k, int stride);
+int mliis_dwconv_bn_fwd(const float* z, const float* bn_part, int bn_nblk, const float* bn_gamma, const float* bn_beta, float* bn_mean,
+                        float* bn_rstd, float* bn_moving_mean, float* bn_moving_var, float eps, float momentum, const float* w, float* y,
+                        int N, int H, int W, int C, int k, int stride, float* stats_part, size_t stats_floats, int* stats_nblk,
+                        hipStream_t stream);
+int mliis_dwconv_bn_bwd(const float* dy, const float* z, const float* bn_mean, const float* bn_rstd, const float* bn_gamma,
+                        const float* bn_beta, const float* w, float* dx, float* dw, int N, int H, int W, int C, int k, int stride,
+                        float* dw_part, size_t dw_part_floats, float* bn_part, size_t bn_part_floats, int* nblk, hipStream_t stream);
+
 /* ---- the depthwise half of an MBConv block on SMALL maps in ONE launch per direction (mbconv_small.hip): expand BN -> swish ->
  *      depthwise k x k (stride 1) -> BN -> swish -> squeeze-excite mean (efficientnet_model.py:183-200,266-271,247; utils.py:87-134)
  *      and the whole backward of that chain.  Every op in it is per channel, so a workgroup that owns 8 channels over all of

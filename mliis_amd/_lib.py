@@ -31,6 +31,10 @@ SIGNATURES = {
     "mliis_dwconv_bwd_data_bn": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _sz, _p, _p]),
     "mliis_dwconv_bwd_filter_workspace_floats": (_sz, [_i, _i, _i, _i, _i, _i]),
     "mliis_dwconv_bwd_filter": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _sz, _p]),
+    "mliis_dwconv_bn_fwd_blocks": (_i, [_i, _i, _i, _i, _i, _i]),
+    "mliis_dwconv_bn_bwd_blocks": (_i, [_i, _i, _i, _i, _i, _i]),
+    "mliis_dwconv_bn_fwd": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _p, _f, _f, _p, _p, _i, _i, _i, _i, _i, _i, _p, _sz, _p, _p]),
+    "mliis_dwconv_bn_bwd": (_i, [_p] * 9 + [_i, _i, _i, _i, _i, _i, _p, _sz, _p, _sz, _p, _p]),
     "mliis_augment_stage": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "mliis_rng_masks": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _p]),
     "mliis_mbconv_dw_small_supported": (_i, [_i, _i, _i, _i, _i, _i]),

@@ -63,6 +63,9 @@ class _Plan:
             hi, ho, ce = b.h_in, b.h_out, b.cexp
             # small maps (14x14 at 224x224 inputs): the depthwise half of the block runs as ONE launch per direction (mbconv_small.hip)
             B["small"] = bool(L.small_fused and b.expand != 1 and ops.mbconv_dw_small_supported(N, hi, hi, ce, b.k, b.stride))
+            # every other block: the row-marching kernels (batch norm + swish in front of the depthwise conv applied while its input is
+            # staged; one-pass backward).  MLIIS_DW_MARCH=0: the op-by-op kernels of dwconv.hip, for A/B runs
+            B["march"] = bool(L.dw_march and not B["small"])
             if b.expand != 1:
                 B["z0"], B["a0"], B["st0"] = buf(N, hi, hi, ce), buf(N, hi, hi, ce), vec(ce)
             B["z1"], B["a1"], B["st1"] = buf(N, ho, ho, ce), buf(N, ho, ho, ce), vec(ce)
@@ -132,6 +135,14 @@ class _Plan:
                 need = max(need, -(-rows // 16) * 2 * c, ops.bn_stats_partial_floats(rows, c))
         need = max(need, ops.bn_stats_partial_floats(N * hs * hs, a.stem_out))
         self.stats_part = buf(need + 64)
+        # the row-marching depthwise kernels (ops.dwconv_bn_fwd / _bwd) READ the producer's partial sums from stats_part while other
+        # workgroups of the same launch already WRITE theirs: a second buffer
+        need2 = 0
+        for b in a.blocks:
+            if b.executed:
+                need2 = max(need2, lib.raw("mliis_dwconv_bn_fwd_blocks")(N, b.h_in, b.h_in, b.cexp, b.k, b.stride) * 2 * b.cexp,
+                            lib.raw("mliis_dwconv_bn_bwd_blocks")(N, b.h_in, b.h_in, b.cexp, b.k, b.stride) * 2 * b.cexp)
+        self.stats_part2 = buf(need2 + 64)
         # squeeze-excite pooling partials of the bn1 apply pass: [N][ceil(rows_per_img / 128)][C]
         self.pool_part = buf(max(N * (-(-(b.h_out * b.h_out) // 128)) * b.cexp for b in a.blocks if b.executed) + 64)
         # gate-gradient partials of the project backward-data launch on the small maps: [16-row groups][2][C]
@@ -156,7 +167,9 @@ class _Plan:
             ce = b.cexp
             if b.expand != 1:
                 add(nm["w_exp"], lib.size("mliis_conv2d_bwd_filter_workspace_floats", N, b.h_in, b.h_in, b.cin, ce, 1), b.cin * ce)
-            if not B["small"]:   # (the small-map backward kernel writes the complete depthwise filter gradient itself: no slabs)
+            if B["march"]:
+                add(nm["w_dw"], lib.raw("mliis_dwconv_bn_bwd_blocks")(N, b.h_in, b.h_in, ce, b.k, b.stride) * b.k * b.k * ce, b.k * b.k * ce)
+            elif not B["small"]:   # (the small-map backward kernel writes the complete depthwise filter gradient itself: no slabs)
                 add(nm["w_dw"], lib.size("mliis_dwconv_bwd_filter_workspace_floats", N, b.h_in, b.h_in, ce, b.k, b.stride), b.k * b.k * ce)
             add(nm["w_proj"], lib.size("mliis_conv2d_bwd_filter_workspace_floats", N, b.h_out, b.h_out, ce, b.cout, 1), ce * b.cout)
         if a.skipdec is not None:
@@ -274,6 +287,7 @@ class Learner:
         self.drop_connect = drop_connect
         # small-map blocks through the one-launch-per-direction kernels of mbconv_small.hip (MLIIS_SMALL_FUSED=0: op by op, for A/B runs)
         self.small_fused = (os.environ.get("MLIIS_SMALL_FUSED", "1") != "0") if small_fused is None else bool(small_fused)
+        self.dw_march = os.environ.get("MLIIS_DW_MARCH", "1") != "0"
         self.use_graph = use_graph
         self.stream = torch.cuda.Stream(device=self.device)
         # Optional (overlap_wgrad = 1 | 2): weight-gradient GEMMs on a second stream forked inside the HIP graph, one by one (1) or
@@ -577,14 +591,16 @@ class Learner:
         A, a, ws, N = self.arena, self.arch, self.ws, P.N
         w, mv = A.w, A.mv
 
-        def bn(xin, st, prefix, y, pre=False, post=False, img_scale=None, res=None, fused=False, nblk=0, pool_part=None, always_batch=False):
+        def bn(xin, st, prefix, y, pre=False, post=False, img_scale=None, res=None, fused=False, nblk=0, pool_part=None, always_batch=False,
+               part=None):
             """nblk > 0: the producing conv already left the stage-1 statistics in P.stats_part.  always_batch: a batch norm the
             reference builds with training=True (the --skip_decoding decoder): batch statistics in inference too, moving averages
             untouched there."""
             if training or always_batch:
+                part = P.stats_part if (part is None or nblk == 0) else part
                 if nblk == 0:
                     nblk = ops.bn_stats_partial(xin, pre, P.stats_part)
-                return ops.bn_apply_fused(xin, P.stats_part, nblk, st[0], st[1], w[prefix + "/gamma"], w[prefix + "/beta"],
+                return ops.bn_apply_fused(xin, part, nblk, st[0], st[1], w[prefix + "/gamma"], w[prefix + "/beta"],
                                           moving=(mv[prefix + "/moving_mean"], mv[prefix + "/moving_variance"]) if training else None,
                                           unbiased_moving_var=fused,
                                           pre_swish=pre, post_swish=post, img_scale=img_scale, res=res, out=y, pool_part=pool_part)
@@ -605,9 +621,29 @@ class Learner:
             return 0
 
         ops.stem_conv_fwd(x, w[self.n_stem[0]], idx, out=P.z_stem)
-        cur = bn(P.z_stem, P.st_stem, self.n_stem[1], P.a_stem, post=True)
         ex = [b for b in a.blocks if b.executed]
-        for b, B, nm in zip(ex, P.blocks, self.n_blocks):
+        # block 0 without an expand conv (EfficientNet-B0 ... B7) takes the stem's BN + swish into its depthwise launch: the activated
+        # stem output is only read there (no identity skip), so it is never written
+        fuse_stem = bool(ex and P.blocks[0]["march"] and ex[0].expand == 1 and not ex[0].skip)
+        P.fuse_stem = fuse_stem
+        if fuse_stem:
+            cur = None
+        else:
+            cur = bn(P.z_stem, P.st_stem, self.n_stem[1], P.a_stem, post=True)
+
+        def bn_in(z, st, prefix, nblk):
+            """The batch norm in front of a marching depthwise launch: (bn tuple, nblk) for ops.dwconv_bn_fwd.  Training: the launch
+            folds the producer's partial sums (P.stats_part) and updates the moving averages; inference: moving statistics given."""
+            g_, b_ = w[prefix + "/gamma"], w[prefix + "/beta"]
+            if training:
+                if nblk == 0:
+                    nblk = ops.bn_stats_partial(z, False, P.stats_part)
+                return (g_, b_, st[0], st[1], mv[prefix + "/moving_mean"], mv[prefix + "/moving_variance"]), nblk
+            st[0].copy_(mv[prefix + "/moving_mean"])
+            torch.rsqrt(mv[prefix + "/moving_variance"] + spec.BN_EPS, out=st[1])
+            return (g_, b_, st[0], st[1], None, None), 0
+
+        for bi_, (b, B, nm) in enumerate(zip(ex, P.blocks, self.n_blocks)):
             B["x_in"] = cur
             t = cur
             if training and B["small"]:
@@ -629,18 +665,39 @@ class Learner:
                 B["use_dc"] = use_dc
                 cur = bn(B["z2"], B["st2"], nm["bn2"], B["out"], img_scale=B["dc"] if use_dc else None, res=B["x_in"] if b.skip else None, nblk=nb)
                 continue
-            if b.expand != 1:
-                nb = conv(t, nm["w_exp"], None, 1, B["z0"], False)
-                t = bn(B["z0"], B["st0"], nm["bn0"], B["a0"], post=True, nblk=nb)
-            if training:   # the depthwise launch also leaves bn1's stage-1 statistics in P.stats_part
-                nb = ops.dwconv_fwd(t, w[nm["w_dw"]], b.stride, out=B["z1"], stats_part=P.stats_part)[1]
+            if B["march"]:
+                # expand GEMM (+ stage-1 statistics) -> ONE launch: bn0 fold + apply + swish while the rows are staged, depthwise conv,
+                # bn1 stage-1 statistics (P.stats_part2)
+                if b.expand != 1:
+                    nb = conv(t, nm["w_exp"], None, 1, B["z0"], False)
+                    bn0, nb = bn_in(B["z0"], B["st0"], nm["bn0"], nb)
+                    zin = B["z0"]
+                elif bi_ == 0 and fuse_stem:
+                    bn0, nb = bn_in(P.z_stem, P.st_stem, self.n_stem[1], 0)
+                    zin = P.z_stem
+                else:
+                    bn0, nb, zin = None, 0, t
+                if training:
+                    nb = ops.dwconv_bn_fwd(zin, w[nm["w_dw"]], b.stride, bn=bn0, part=P.stats_part, nblk=nb, out=B["z1"],
+                                           stats_part=P.stats_part2)[1]
+                else:
+                    ops.dwconv_bn_fwd(zin, w[nm["w_dw"]], b.stride, bn=bn0, out=B["z1"])
+                    nb = 0
+                st_part = P.stats_part2
             else:
-                ops.dwconv_fwd(t, w[nm["w_dw"]], b.stride, out=B["z1"])
-                nb = 0
+                if b.expand != 1:
+                    nb = conv(t, nm["w_exp"], None, 1, B["z0"], False)
+                    t = bn(B["z0"], B["st0"], nm["bn0"], B["a0"], post=True, nblk=nb)
+                if training:   # the depthwise launch also leaves bn1's stage-1 statistics in P.stats_part
+                    nb = ops.dwconv_fwd(t, w[nm["w_dw"]], b.stride, out=B["z1"], stats_part=P.stats_part)[1]
+                else:
+                    ops.dwconv_fwd(t, w[nm["w_dw"]], b.stride, out=B["z1"])
+                    nb = 0
+                st_part = P.stats_part
             hw = b.h_out * b.h_out
             se = nm["se"]
             if training:   # bn1's apply pass also pools its output per image (partial sums); the SE kernel folds them
-                chunks = bn(B["z1"], B["st1"], nm["bn1"], B["a1"], post=True, nblk=nb, pool_part=P.pool_part)[1]
+                chunks = bn(B["z1"], B["st1"], nm["bn1"], B["a1"], post=True, nblk=nb, pool_part=P.pool_part, part=st_part)[1]
                 ops.se_mlp_fwd(P.pool_part, w[se[0]], w[se[1]], w[se[2]], w[se[3]], B["hpre"], B["gate"], chunks=chunks, scale=1.0 / hw,
                                s_out=B["s"])
             else:
@@ -973,6 +1030,30 @@ class Learner:
                     has_grad[bi - 1] = True
                 continue
             bn_b(B["z1"], da2, B["st1"], nm["bn1"], da2, post=True, chan_scale=B["gate"], chan_add=B["chan_add"])
+            if B["march"]:
+                # ONE pass over (dz1, z0): depthwise backward-data, filter-gradient slabs and stage 1 of bn0's backward
+                wdw, slabs = w[nm["w_dw"]], P.fold_part[nm["w_dw"]]
+                if b.expand != 1:
+                    da0, st0, p0 = B["da0"], B["st0"], nm["bn0"]
+                    _, _, nb1 = ops.dwconv_bn_bwd(da2, B["z0"], wdw, b.stride, bn=(st0[0], st0[1], w[p0 + "/gamma"], w[p0 + "/beta"]), out=da0,
+                                                  dw_part=slabs, bn_part=P.stats_part2)
+                    bn_b(B["z0"], da0, st0, p0, da0, post=True, stage1=(P.stats_part2, nb1))
+                    wgrad_1x1(B["x_in"], da0, nm["w_exp"])
+                    stage1_next = expand_bwd_data(bi, da0, nm["w_exp"], tgt, tgt_has)
+                elif bi == 0 and P.fuse_stem:
+                    # (the stem's BN + swish went into this block's depthwise launch: P.dstem = gradient w.r.t. the activated stem output)
+                    st0, p0 = P.st_stem, self.n_stem[1]
+                    _, _, nb1 = ops.dwconv_bn_bwd(da2, P.z_stem, wdw, b.stride, bn=(st0[0], st0[1], w[p0 + "/gamma"], w[p0 + "/beta"]), out=tgt,
+                                                  dw_part=slabs, bn_part=P.stats_part2)
+                    P.stem_stage1 = (P.stats_part2, nb1)
+                elif tgt_has:   # no-expand block with identity skip (EfficientNet-B3 stage-1 repeats)
+                    ops.dwconv_bn_bwd(da2, B["x_in"], wdw, b.stride, out=B["da0"], dw_part=slabs)
+                    ops.chan_affine(B["da0"], out=tgt, accumulate=True)
+                else:
+                    ops.dwconv_bn_bwd(da2, B["x_in"], wdw, b.stride, out=tgt, dw_part=slabs)
+                if bi > 0:
+                    has_grad[bi - 1] = True
+                continue
             dw_in = B["a0"] if b.expand != 1 else B["x_in"]
             side(lambda dw_in=dw_in, da2=da2, b=b, nm=nm: ops.dwconv_bwd_filter(dw_in, da2, b.k, b.stride, partial=P.fold_part[nm["w_dw"]]))
             if b.expand != 1:
@@ -993,7 +1074,7 @@ class Learner:
                     ops.dwconv_bwd_data(da2, w[nm["w_dw"]], b.stride, (b.h_in, b.h_in), out=tgt)
             if bi > 0:
                 has_grad[bi - 1] = True
-        bn_b(P.z_stem, P.dstem, P.st_stem, self.n_stem[1], P.dstem, post=True)
+        bn_b(P.z_stem, P.dstem, P.st_stem, self.n_stem[1], P.dstem, post=True, stage1=P.stem_stage1 if P.fuse_stem else None)
         side(lambda: ops.stem_conv_bwd_filter(x, P.dstem, idx, partial=P.fold_part[self.n_stem[0]]))
         flush()
         if self.overlap_wgrad:

@@ -205,6 +205,52 @@ def dwconv_bwd_filter(x, dy, k, stride, out=None, ws: Optional[Workspace] = None
     return out
 
 
+# ------------------------------------------------------------------------------------------------ large-map MBConv depthwise half
+def dwconv_bn_fwd(z, w, stride, bn=None, part=None, nblk=0, out=None, stats_part=None, eps=BN_EPS, momentum=BN_MOMENTUM):
+    """y = dwconv(swish(bn(z))) with the batch norm applied while z is staged (csrc/dwmarch.hip); bn = (gamma, beta, mean, rstd,
+    moving_mean | None, moving_var | None) or None (plain depthwise conv of z).  nblk > 0: `part` holds the producer's stage-1 sums
+    [nblk][2][C] -- folded here, mean / rstd written, moving averages updated; nblk == 0: mean / rstd are inputs.  With stats_part
+    the launch also emits the next batch norm's stage-1 sums; returns (out, blocks)."""
+    N, H, W, C_ = z.shape
+    k = w.shape[0]
+    Ho, Wo = -(-H // stride), -(-W // stride)
+    out = torch.empty((N, Ho, Wo, C_), dtype=torch.float32, device=z.device) if out is None else out
+    g, b, m, r, mm, mv = bn if bn is not None else (None,) * 6
+    meta = dict(bytes=4.0 * (z.numel() + out.numel() + k * k * C_), shape=(N, H, W, C_, k, stride)) if PROFILE is not None else {}
+    nb = C.c_int(0)
+    _timed("dwconv_bn_fwd", meta, lambda: lib.call(
+        "mliis_dwconv_bn_fwd", _ptr(_chk(z)), _ptr(part) if nblk else None, int(nblk), _ptr(g), _ptr(b), _ptr(m), _ptr(r), _ptr(mm), _ptr(mv),
+        float(eps), float(momentum), _ptr(w), _ptr(out), N, H, W, C_, k, stride, _ptr(stats_part),
+        stats_part.numel() if stats_part is not None else 0, C.byref(nb), _stream()))
+    if stats_part is not None:
+        return out, nb.value
+    return out
+
+
+def dwconv_bn_bwd_blocks(N, H, W, C_, k, stride) -> int:
+    return int(lib.raw("mliis_dwconv_bn_bwd_blocks")(N, H, W, C_, k, stride))
+
+
+def dwconv_bn_bwd(dy, z, w, stride, bn=None, out=None, dw=None, dw_part=None, bn_part=None, ws: Optional[Workspace] = None):
+    """ONE pass over (dy, z): dx = gradient w.r.t. a = swish(bn(z)) (bn = (mean, rstd, gamma, beta); None: a = z), the depthwise filter
+    gradient as slabs in dw_part [blocks][k*k][C] (folded into `dw` when given; dw_part None: taken from ws and folded into a new /
+    the given dw) and, with bn_part, stage 1 of the batch norm's backward [blocks][2][C].  Returns (dx, dw | None, blocks)."""
+    N, H, W, C_ = z.shape
+    k = w.shape[0]
+    out = torch.empty((N, H, W, C_), dtype=torch.float32, device=z.device) if out is None else out
+    blocks = dwconv_bn_bwd_blocks(N, H, W, C_, k, stride)
+    if dw_part is None:
+        dw_part = (ws or default_ws()).get(blocks * k * k * C_)
+        dw = torch.empty((k, k, C_, 1), dtype=torch.float32, device=z.device) if dw is None else dw
+    m, r, g, b = bn if bn is not None else (None,) * 4
+    meta = dict(bytes=4.0 * (2 * z.numel() + dy.numel() + 2 * k * k * C_), shape=(N, H, W, C_, k, stride)) if PROFILE is not None else {}
+    nb = C.c_int(0)
+    _timed("dwconv_bn_bwd", meta, lambda: lib.call(
+        "mliis_dwconv_bn_bwd", _ptr(_chk(dy)), _ptr(_chk(z)), _ptr(m), _ptr(r), _ptr(g), _ptr(b), _ptr(w), _ptr(out), _ptr(dw), N, H, W, C_, k,
+        stride, _ptr(dw_part), dw_part.numel(), _ptr(bn_part), bn_part.numel() if bn_part is not None else 0, C.byref(nb), _stream()))
+    return out, dw, nb.value
+
+
 # ------------------------------------------------------------------------------------------------ small-map MBConv depthwise half
 def mbconv_dw_small_supported(N, H, W, C_, k, stride) -> bool:
     return bool(lib.raw("mliis_mbconv_dw_small_supported")(N, H, W, C_, k, stride))
