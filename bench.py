@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--tasks-per-gpu", type=int, default=1, help="variant: tasks per GPU and meta-step (the metric's config has 1)")
     ap.add_argument("--precision", choices=["fp32", "bf16", "fp8"], default="fp32",
                     help="variant: bf16 operands on the matrix cores (fp32 accumulation, fp32 tensors); the headline metric is fp32")
+    ap.add_argument("--adam", action="store_true", help="variant: Adam(beta1 = 0) inner optimizer, the reference's default when --sgd is absent (the metric's config is SGD)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -187,7 +188,11 @@ def roofline(L, args):
     dll = _lib.load()
     # entry point -> (family, index of N in the argument list, {pointer argument: "i" input-resolution | "o" output-resolution tensor},
     #                 pointer arguments nulled in the re-issues (moving averages: the learner's own state must not be advanced))
-    DW = {"mliis_dwconv_fwd": ("dwconv_fwd", 3, {0: "i", 2: "o"}, ()),
+    # (the row-marching kernels: forward = bn0 fold + apply + swish while staging + depthwise conv + bn1 stage-1 sums; backward = ONE pass
+    #  over (dy, z): dx, filter-gradient slabs, stage 1 of bn0's backward.  Their mean / rstd outputs go to scratch in the re-issues)
+    DW = {"mliis_dwconv_bn_fwd": ("dwconv_bn_fwd", 13, {0: "i", 12: "o"}, (7, 8)),
+          "mliis_dwconv_bn_bwd": ("dwconv_bn_bwd", 9, {0: "o", 1: "i", 7: "i"}, ()),
+          "mliis_dwconv_fwd": ("dwconv_fwd", 3, {0: "i", 2: "o"}, ()),
           "mliis_dwconv_bwd_data": ("dwconv_bwd_data", 3, {0: "o", 2: "i"}, ()),
           "mliis_dwconv_bwd_data_bn": ("dwconv_bwd_data", 3, {0: "o", 2: "i", 9: "i"}, ()),
           "mliis_dwconv_bwd_filter": ("dwconv_bwd_filter", 3, {0: "i", 1: "o"}, ()),
@@ -205,7 +210,7 @@ def roofline(L, args):
             ho, wo = same_pad(h, kk, st)[0], same_pad(w_, kk, st)[0]
             el = {"i": nb * h * w_ * c, "o": nb * ho * wo * c}
             w_el = kk * kk * c
-            if fam_name == "mbconv_small_bwd":   # backward-data + backward-filter of the depthwise op: dY, X read, dX written, W, dW
+            if fam_name in ("mbconv_small_bwd", "dwconv_bn_bwd"):   # backward-data + backward-filter of the depthwise op: dY, X read, dX written, W, dW
                 nbytes = 4.0 * (2 * el["i"] + el["o"] + 2 * w_el)
             else:                                # fwd: X + Y + W; bwd-data: dY + dX + W (+ z0 when the BN sums ride along); bwd-filter: X + dY + dW
                 nbytes = 4.0 * (el["i"] + el["o"] + w_el) + (4.0 * el["i"] if n.endswith("_bn") else 0.0)
@@ -219,6 +224,10 @@ def roofline(L, args):
                     args_r[ix] = buf.data_ptr()
                 for ix in nulled:
                     args_r[ix] = None
+                if n == "mliis_dwconv_bn_fwd" and args_r[3] is not None:   # batch statistics the launch writes: not into the learner's
+                    scr = torch.empty(2 * c, dtype=torch.float32, device=L.device)
+                    bufs.append(scr)
+                    args_r[5], args_r[6] = scr.data_ptr(), scr[c:].data_ptr()
                 variants.append(tuple(args_r))
             fn = getattr(dll, n)
             for v in variants:          # first touch of every copy (page mapping) outside the timed region
@@ -316,12 +325,13 @@ def _run(args):
         cpu = cpu_baseline(args)
 
     shots = 10 if args.foml else args.shots
-    L = Learner(feature_extractor_name=args.backbone, image_size=args.image_size, rsd=(2, 4), learning_rate=1e-3, optimizer="sgd", dice=False, l2=False, seed=0, device=device,
+    L = Learner(feature_extractor_name=args.backbone, image_size=args.image_size, rsd=(2, 4), learning_rate=1e-3, optimizer="adam" if args.adam else "sgd", dice=False, l2=False, seed=0, device=device,
                 use_graph=not args.no_graph, max_shots=max(16, shots), spatial_pyramid_pooling=args.aspp, matmul_precision=args.precision,
-                skip_decoding=args.skip_decoding, overlap_wgrad=args.overlap_wgrad, augment_batch_capacity=16 if (args.augment and not args.augment_on_host) else 0)
-    lanes = [Learner(feature_extractor_name=args.backbone, image_size=args.image_size, rsd=(2, 4), learning_rate=1e-3, optimizer="sgd", dice=False,
+                skip_decoding=args.skip_decoding, overlap_wgrad=args.overlap_wgrad, augment_batch_capacity=16 if (args.augment and not args.augment_on_host) else 0,
+                rng_stream=rank)
+    lanes = [Learner(feature_extractor_name=args.backbone, image_size=args.image_size, rsd=(2, 4), learning_rate=1e-3, optimizer="adam" if args.adam else "sgd", dice=False,
                      l2=False, seed=k, device=device, use_graph=not args.no_graph, max_shots=max(16, shots),
-                     spatial_pyramid_pooling=args.aspp, skip_decoding=args.skip_decoding, matmul_precision=args.precision)
+                     spatial_pyramid_pooling=args.aspp, skip_decoding=args.skip_decoding, matmul_precision=args.precision, rng_stream=rank)
              for k in range(1, args.concurrent_tasks)]
     tasks = []
     for i in range(args.pool):
@@ -375,7 +385,7 @@ def _run(args):
                                                                  ("ASPP + " if args.aspp else "") + ("DeepLabv3+-style skip decoder + " if args.skip_decoding else ""), args.image_size, args.image_size, world, shots,
                                                                  args.inner_iters,
                                                                  args.inner_batch, imgs_per_task, "FOMAML(tail 5)" if args.foml else "Reptile",
-                                                                 ("" if args.precision == "fp32" else ", %s matrix-core operands" % args.precision) +
+                                                                 ("" if args.precision == "fp32" else ", %s matrix-core operands" % args.precision) + (", Adam(beta1=0) inner optimizer" if args.adam else "") +
                                                                  ((", augmentation (aug_rate 0.5, %s)" % (("pixels on the host, %s" % ("%d worker processes" % aug_pool.workers if aug_pool else "inline")) if args.augment_on_host else "pixels on the device"))
                                                                   if args.augment else "") +
                                                                  (", %d tasks per GPU and meta-step" % args.tasks_per_gpu if args.tasks_per_gpu != 1 else "") +

@@ -324,8 +324,11 @@ int mliis_darc1(const float* logits, int N, long long per_img, float weight, flo
  *      axpby / lincomb implement meta_learners/variables.py:9-55 on the flat arena. */
 int mliis_sgd_fused(float* w, const float* g, const uint8_t* l2_quad_mask, long long n, float lr, const float* lr_dev, float l2, float l1,
                     hipStream_t stream);
+/*      Adam: step_dev (device float) = number of steps applied so far.  step_ticket == NULL: the caller advanced it before the call
+ *      (this launch is step *step_dev).  step_ticket != NULL (device uint32, zero): this launch is step *step_dev + 1 and advances
+ *      the count itself (last workgroup to finish) -- the form a captured HIP graph replays. */
 int mliis_adam_b1zero_fused(float* w, const float* g, float* v, const uint8_t* l2_quad_mask, long long n, float lr, const float* lr_dev,
-                            float l2, float l1, float beta2, float eps, const float* step_dev, hipStream_t stream);
+                            float l2, float l1, float beta2, float eps, float* step_dev, unsigned* step_ticket, hipStream_t stream);
 int mliis_axpby(float a, const float* x, float b, float* y, long long n, hipStream_t stream);
 int mliis_lincomb(float a, const float* x, float b, const float* y, float* out, long long n, hipStream_t stream);
 

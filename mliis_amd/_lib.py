@@ -80,7 +80,7 @@ SIGNATURES = {
     "mliis_softmax_ce": (_i, [_p, _p, _p, _i, _i, _i, _f, _i, _f, _p, _p, _p, _p, _sz, _p]),
     "mliis_darc1": (_i, [_p, _i, _ll, _f, _p, _p, _p, _sz, _p]),
     "mliis_sgd_fused": (_i, [_p, _p, _p, _ll, _f, _p, _f, _f, _p]),
-    "mliis_adam_b1zero_fused": (_i, [_p, _p, _p, _p, _ll, _f, _p, _f, _f, _f, _f, _p, _p]),
+    "mliis_adam_b1zero_fused": (_i, [_p, _p, _p, _p, _ll, _f, _p, _f, _f, _f, _f, _p, _p, _p]),
     "mliis_axpby": (_i, [_f, _p, _f, _p, _ll, _p]),
     "mliis_lincomb": (_i, [_f, _p, _f, _p, _p, _ll, _p]),
     "mliis_fold_batched": (_i, [_p, _p, _p, _i, _ll, _p]),

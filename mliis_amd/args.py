@@ -103,8 +103,10 @@ _EXT = [
     ("--skip-train-task-eval", dict(action="store_true",
                                     help="skip the evaluation pass over the meta-TRAIN tasks that the reference always runs before the test tasks")),
     ("--augment-on-host", dict(action="store_true",
-                               help="with --augment: compute the augmented pixels in numpy / scipy on the host, draw-identical to the reference "
-                                    "(default: same draws, pixel work and noise fields on the device, csrc/augment.hip)")),
+                               help="with --augment: compute the augmented pixels in numpy / scipy on the host, draw- and pixel-identical to "
+                                    "the reference -- REQUIRED for reference-parity runs.  Default: same scalar draws, pixel work on the device "
+                                    "(csrc/augment.hip): Philox noise fields, Keys-cubic rotation instead of scipy's prefiltered B-spline, "
+                                    "constant-mode holes by coordinate range -- statistically, not pixel-, identical")),
     ("--augment-workers", dict(type=int, default=-1,
                                help="worker processes for the pixel half of --augment (-1: host cores - 1, 0: inline like the reference)")),
     ("--concurrent-tasks", dict(type=int, default=1,

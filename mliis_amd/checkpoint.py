@@ -18,6 +18,34 @@ import numpy as np
 
 CKPT_PREFIX = "model.ckpt"
 
+# ---- Adam(beta1 = 0) step count in a checkpoint.  TF keeps it only as beta2_power = beta2^(t+1) in float32, which underflows to
+#      exactly 0 after ~103k steps (0.999^t < 1.4e-45) and is already wrong by hundreds of steps in the denormal range -- a default-
+#      optimizer run passes that after a few hundred meta-iterations.  Our own checkpoints therefore ALSO carry the count itself
+#      (`adam_step`, int64); beta2_power stays for TensorFlow's sake.
+ADAM_STEP_KEY = "adam_step"
+ADAM_SATURATED_STEPS = 1000000   # beta2_power too small to invert: the bias correction 1 / (1 - beta2^t) is 1 to fp32 from ~16k steps on
+
+
+def adam_step_entries(t: int, beta2: float) -> Dict[str, np.ndarray]:
+    """The optimizer-state scalars saved beside the `<var>/Adam_1` slots after t applied steps."""
+    return {"beta1_power": np.float32(0.0), "beta2_power": np.float32(float(beta2) ** (int(t) + 1.0)), ADAM_STEP_KEY: np.int64(int(t))}
+
+
+def adam_step_from(values, beta2: float) -> Optional[int]:
+    """Steps applied so far according to a checkpoint: the explicit count when present, else beta2_power inverted (TF-written
+    checkpoints), else None (no Adam state stored).  A beta2_power that has underflowed (or is not a valid power) means "many"."""
+    import math
+    if ADAM_STEP_KEY in values:
+        return max(int(np.asarray(values[ADAM_STEP_KEY]).reshape(-1)[0]), 0)
+    if "beta2_power" not in values:
+        return None
+    b2p = float(np.asarray(values["beta2_power"]).reshape(-1)[0])
+    if not (b2p > 1e-30):                    # underflowed, in the denormal range (or NaN): too many steps to invert
+        return ADAM_SATURATED_STEPS
+    if b2p > 1.0:                            # not a power of beta2: a fresh optimizer
+        return 0
+    return max(int(round(math.log(b2p) / math.log(float(beta2)))) - 1, 0)
+
 
 def latest_checkpoint(checkpoint_dir: str, ckpt_prefix: str = CKPT_PREFIX) -> str:
     with open(os.path.join(checkpoint_dir, "checkpoint")) as f:

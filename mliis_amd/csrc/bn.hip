@@ -21,6 +21,7 @@ constexpr int kChanBlock = 32;   // channels per block: 8 float4 lanes = one 128
 constexpr int kRowLanes = 32;    // rows walked in parallel by one block
 constexpr int kBatch = 4;        // rows per thread whose loads are issued before any of them is consumed
 constexpr int kPoolRows = 128;   // rows per pooling chunk of bn_apply_fused (one batch per thread)
+constexpr int kStatsPartialTarget = 256;   // workgroups of mliis_bn_stats_partial (= partial blocks its consumer folds)
 
 // Streaming geometry shared by the column reductions and the BN apply kernels: grid = (row chunks, ceil(C/32)[, segments]);
 // a block owns 32 channels x rows_per_block rows, its 256 threads = 8 channel quads x 32 row lanes.  Small maps are latency-bound
@@ -830,7 +831,8 @@ int mliis_bn_stats_partial(const float* x, int ldx, long long rows, int C, int p
   MLIIS_REQUIRE(aligned16(x) && aligned16(part), MLIIS_ERR_ALIGN, "bn_stats_partial: pointers must be 16-byte aligned");
   StatsOp op{x, ldx, pre_swish};
   ColGeom g;
-  int rc = launch_colreduce(op, rows, C, 1, part, part_floats, stream, &g, "bn_stats_partial");
+  // (fewer, taller blocks than the other column reductions: every workgroup of the consumer folds ALL these partials)
+  int rc = launch_colreduce(op, rows, C, 1, part, part_floats, stream, &g, "bn_stats_partial", kStatsPartialTarget);
   if (rc) return rc;
   *nblk_out = g.nblk;
   return MLIIS_OK;

@@ -312,14 +312,14 @@ static inline bool stream_plan(long long M, int K, int Nout, int num_cus, Stream
   sp->nt = (tiles + gy - 1) / gy;
   sp->gy = gy;
   sp->row_groups = (int)((M + 15) / 16);
-  long long gx = (4LL * num_cus) / gy;     // about 16 waves per CU in flight
+  long long gx = (16LL / kStreamWaves * num_cus) / gy;     // about 16 waves per CU in flight
   if (gx < 1) gx = 1;
-  if (gx > (sp->row_groups + 3) / 4) gx = (sp->row_groups + 3) / 4;
+  if (gx > (sp->row_groups + kStreamWaves - 1) / kStreamWaves) gx = (sp->row_groups + kStreamWaves - 1) / kStreamWaves;
   sp->gx = (int)gx;
   return true;
 }
 static bool launch_stream(const StreamPlan& sp, const ConvGemmParams& p, hipStream_t stream, int precision = MLIIS_PREC_FP32) {
-  dim3 grid(sp.gx, sp.gy), block(256);
+  dim3 grid(sp.gx, sp.gy), block(64 * kStreamWaves);
   if (precision != MLIIS_PREC_FP32) return launch_stream_lowp(precision, sp.kc, sp.nt, grid, p, sp.row_groups, stream);
 #define S(KC_, NT_) hipLaunchKernelGGL((conv1x1_stream_k<KC_, NT_, 0>), grid, block, 0, stream, p, sp.row_groups); break;
   switch (sp.kc) {

@@ -9,7 +9,7 @@ void launch_gemm_fp8(const GemmPlan& g, const ConvGemmParams& p, hipStream_t str
 
 template <int PREC>
 static bool launch_stream_prec(int kc, int nt, dim3 grid, const ConvGemmParams& p, int row_groups, hipStream_t stream) {
-  dim3 block(256);
+  dim3 block(64 * kStreamWaves);
 #define S(KC_, NT_) hipLaunchKernelGGL((conv1x1_stream_k<KC_, NT_, PREC>), grid, block, 0, stream, p, row_groups); break;
   switch (kc) {
     case 1: switch (nt) { case 1: S(1, 1) case 2: S(1, 2) case 3: S(1, 3) case 4: S(1, 4) case 5: S(1, 5) case 6: S(1, 6) case 7: S(1, 7) case 8: S(1, 8) default: return false; } break;

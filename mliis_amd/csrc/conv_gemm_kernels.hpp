@@ -596,9 +596,12 @@ __global__ __launch_bounds__(1024) void sk_fixup_k(ConvGemmParams p, SkPlan k) {
 // groups of A straight from memory in MFMA operand layout (lane (row, g) loads k = 16*kg + 4g..4g+3 as one 16-byte word), multiplies,
 // adds the bias, stores its accumulators and accumulates the batch-norm statistics; the next row group is in flight meanwhile.
 // One barrier at the very end folds the four waves' statistics.  grid = (row-group blocks, column tiles).
+// Workgroup = kStreamWaves waves (each streams its own row groups; nothing is shared but the final fold of the statistics): twice the
+// four of a 256-thread block, so a launch leaves half as many partial blocks -- every workgroup of the consumer folds ALL of them.
+constexpr int kStreamWaves = 8;
 template <int KC, int NT, int PREC>
-__global__ __launch_bounds__(256) void conv1x1_stream_k(ConvGemmParams p, int row_groups) {
-  __shared__ float red[4][2][16 * NT];
+__global__ __launch_bounds__(64 * kStreamWaves) void conv1x1_stream_k(ConvGemmParams p, int row_groups) {
+  __shared__ float red[kStreamWaves][2][16 * NT];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int l15 = lane & 15, g = lane >> 4;
   const int M = p.Nimg * p.H * p.W;                  // host guarantees < 2^31 and 32-bit byte offsets
@@ -651,7 +654,7 @@ __global__ __launch_bounds__(256) void conv1x1_stream_k(ConvGemmParams p, int ro
     bmean[j] = (bnb && n < p.Nout) ? p.bnb_mean[n] : 0.f;
     brstd[j] = (bnb && n < p.Nout) ? p.bnb_rstd[n] : 0.f;
   }
-  const int stride = gridDim.x * 4;
+  const int stride = gridDim.x * kStreamWaves;
   auto load_a = [&](int rg, float4* a) {
     const int m = rg * 16 + l15;
 #pragma unroll
@@ -660,7 +663,7 @@ __global__ __launch_bounds__(256) void conv1x1_stream_k(ConvGemmParams p, int ro
       a[kg] = buf_ld4(rA, (rg < row_groups && m < M && k < p.C) ? (unsigned)((m * p.lda + k) * 4) : kOob);
     }
   };
-  int rg = blockIdx.x * 4 + wave;
+  int rg = blockIdx.x * kStreamWaves + wave;
   float4 a_cur[KC], a_nxt[KC];
   load_a(rg, a_cur);
   for (; rg < row_groups; rg += stride) {
@@ -761,11 +764,15 @@ __global__ __launch_bounds__(256) void conv1x1_stream_k(ConvGemmParams p, int ro
     }
   }
   __syncthreads();
-  for (int idx = t; idx < 2 * 16 * NT; idx += 256) {
+  for (int idx = t; idx < 2 * 16 * NT; idx += 64 * kStreamWaves) {
     const int v = idx / (16 * NT), col = idx - v * (16 * NT);
     const int n = n0 + col;
-    if (n < p.Nout)
-      p.stats_part[((long long)blockIdx.x * 2 + v) * p.Nout + n] = red[0][v][col] + red[1][v][col] + red[2][v][col] + red[3][v][col];
+    if (n < p.Nout) {
+      float a = red[0][v][col];
+#pragma unroll
+      for (int wv = 1; wv < kStreamWaves; ++wv) a += red[wv][v][col];   // (wave order: deterministic)
+      p.stats_part[((long long)blockIdx.x * 2 + v) * p.Nout + n] = a;
+    }
   }
 }
 

@@ -117,21 +117,48 @@ __device__ __forceinline__ float4 dwm_act(const float4 z, const DwmQuad& k) {
   return make_float4(swish_f(u.x), swish_f(u.y), swish_f(u.z), swish_f(u.w));
 }
 
-// Fold (or fetch) the statistics of this workgroup's 32 channels and leave every thread its quad's constants.  Workgroup 0 of each
-// channel group (lead) publishes mean / rstd and applies the moving-average update.  smd: >= 16 KB of LDS scratch (aliased with the
-// ring, which is not live yet).  Statistics given (f.nblk == 0: inference, backward): plain loads, no LDS, no barrier.
-// Called BEFORE the workgroup issues its burst of input loads: vector-memory operations return in issue order, so parameter loads
-// issued behind the burst would wait for all of it (1.4 us on a 112 x 112 layer).
-__device__ __forceinline__ DwmQuad dwm_bn_setup(const DwmBn& bn, int C, int c0, int q, bool cok, bool lead, double* smd, float* s_mr /*[2][32]*/) {
-  const int t = threadIdx.x;
+// The statistics of this workgroup's 32 channels, in two halves around the workgroup's burst of input loads.  Vector-memory
+// operations return in issue order: the small loads (gamma, beta, the producer's partial sums or the given mean / rstd) go FIRST, the
+// burst behind them, and the fold's arithmetic, LDS exchange and barriers run while the burst is in flight (folded in front of the
+// burst they add 2-6 us to every workgroup; issued behind it the parameter loads wait for all of it).
+constexpr int kDwmFoldBatch = 8;    // partial blocks per lane and round trip: up to 256 in one (16 would spill: the burst's registers are live too)
+template <bool FOLD>    // FOLD = false: the statistics are always given (backward kernels): no fold state in registers
+struct DwmBnState {
+  float4 g, b, m, rs;
+  FoldAcc acc;
+  float4 u[FOLD ? kDwmFoldBatch : 1], v[FOLD ? kDwmFoldBatch : 1];
+  int k;
+};
+template <bool FOLD>
+__device__ __forceinline__ void dwm_bn_begin(const DwmBn& bn, int C, int c0, int q, bool cok, DwmBnState<FOLD>& st) {
   const int c = cok ? c0 + q * 4 : 0;
-  const float4 g = ld4(bn.gamma + c), b = ld4(bn.beta + c);
+  st.g = ld4(bn.gamma + c);
+  st.b = ld4(bn.beta + c);
+  if (FOLD && bn.f.nblk > 0) {   // (uniform)
+    const int bl = threadIdx.x >> 3;
+    st.k = bl;
+    // all rounds but the last are finished here; the last one's loads stay in flight
+    for (; st.k + 32 * kDwmFoldBatch < bn.f.nblk; st.k += 32 * kDwmFoldBatch) {
+      fold_issue<FOLD ? kDwmFoldBatch : 1>(bn.f.part, bn.f.nblk, C, c, st.k, bl, st.u, st.v);
+      if (cok) fold_add<FOLD ? kDwmFoldBatch : 1>(st.acc, bn.f.nblk, st.k, st.u, st.v);
+    }
+    fold_issue<FOLD ? kDwmFoldBatch : 1>(bn.f.part, bn.f.nblk, C, c, st.k, st.k < bn.f.nblk ? st.k : 0, st.u, st.v);
+  } else {
+    st.m = ld4(bn.f.mean + c);
+    st.rs = ld4(bn.f.rstd + c);
+  }
+}
+// Workgroup 0 of each channel group (lead) publishes mean / rstd and applies the moving-average update.  smd: >= 16 KB of LDS
+// scratch (aliased with the ring, which is not live yet).  Statistics given (f.nblk == 0: inference, backward): no LDS, no barrier.
+template <bool FOLD>
+__device__ __forceinline__ DwmQuad dwm_bn_end(const DwmBn& bn, int C, int c0, int q, bool cok, bool lead, double* smd, float* s_mr /*[2][32]*/,
+                                              DwmBnState<FOLD>& st) {
+  const int t = threadIdx.x;
   DwmQuad k;
-  if (bn.f.nblk > 0) {   // (uniform)
+  if (FOLD && bn.f.nblk > 0) {   // (uniform)
+    if (cok) fold_add<FOLD ? kDwmFoldBatch : 1>(st.acc, bn.f.nblk, st.k, st.u, st.v);
     double s, ss;
-    // (16 partial blocks per lane and round trip: the expand conv of a 112 x 112 layer leaves 1024)
-    if (bn.f.nblk > 256) fold32<16>(bn.f.part, bn.f.nblk, C, c0, smd, s, ss);
-    else fold32<8>(bn.f.part, bn.f.nblk, C, c0, smd, s, ss);
+    fold_finish(st.acc, smd, s, ss);
     if (t < 32) {
       const double m = s * bn.f.inv_n;
       double var = ss * bn.f.inv_n - m * m;
@@ -155,11 +182,11 @@ __device__ __forceinline__ DwmQuad dwm_bn_setup(const DwmBn& bn, int C, int c0, 
     k.rs = ld4(s_mr + 32 + q * 4);
     __syncthreads();   // (smd / s_mr reads done before the ring is written)
   } else {
-    k.m = ld4(bn.f.mean + c);
-    k.rs = ld4(bn.f.rstd + c);
+    k.m = st.m;
+    k.rs = st.rs;
   }
-  k.sc = f4mul(g, k.rs);
-  k.sh = make_float4(fmaf(-k.m.x, k.sc.x, b.x), fmaf(-k.m.y, k.sc.y, b.y), fmaf(-k.m.z, k.sc.z, b.z), fmaf(-k.m.w, k.sc.w, b.w));
+  k.sc = f4mul(st.g, k.rs);
+  k.sh = make_float4(fmaf(-k.m.x, k.sc.x, st.b.x), fmaf(-k.m.y, k.sc.y, st.b.y), fmaf(-k.m.z, k.sc.z, st.b.z), fmaf(-k.m.w, k.sc.w, st.b.w));
   return k;
 }
 
@@ -282,15 +309,19 @@ __global__ __launch_bounds__(256, BWD ? 1 : 2) void dwm_conv_k(const DwmArgs a) 
     // backward: tap (ky, kx) of the correlation with dy is w[K-1-ky][K-1-kx]
     if (cc < C) wreg = ld4(a.w + (long long)(BWD ? K * K - 1 - tap : tap) * C + cc);
   }
-  if (PRE) kq = dwm_bn_setup(a.bn, C, c0, q, cok, bx == 0, reinterpret_cast<double*>(ring), s_mr);
+  DwmBnState<!BWD> bst;
+  if (PRE) dwm_bn_begin(a.bn, C, c0, q, cok, bst);
   DWM_STAMP(1);
   float4 ra[NEW], rb_[NEW];
   float4 za[TS], zb[TS];
   {
+    // the window of step 0 (head rows + batch 0) first; the fold's arithmetic runs under their transfer; then the batches of steps
+    // 1 and 2 (needed at the end of steps 0 and 1)
     float4 h0[NEW], h1[NEW];
     issue(h0, HEAD);
     issue(h1, WIN - NEW);
     issue_z(za, 0);
+    if (PRE) kq = dwm_bn_end(a.bn, C, c0, q, cok, bx == 0, reinterpret_cast<double*>(ring), s_mr, bst);
     issue(ra, WIN);             // step 1
     issue(rb_, WIN + NEW);      // step 2
     issue_z(zb, 1);
@@ -341,19 +372,20 @@ __global__ __launch_bounds__(256, BWD ? 1 : 2) void dwm_conv_k(const DwmArgs a) 
         }
       }
     }
-#pragma unroll
-    for (int ky = 0; ky < (DWM_DBG_ON(a, 1) ? 0 : K); ++ky) {
+    // window row ky of this strip -> registers (K * WW ds_read_b128 per step and thread)
+    auto read_row = [&](int ky, float4 (&in)[WW]) {
       int slot = s0 + ky;
       if (slot >= NR) slot -= NR;
       const float4* rowp = ring + slot * (IBWP * 8) + colbase * 8 + q;
       const float4* A0 = rowp + sxpar * 8;   // columns whose swizzled index is even: je ^ sxpar = je + sxpar
       const float4* A1 = rowp - sxpar * 8;   // odd: je - sxpar
-      float4 in[WW];
 #pragma unroll
       for (int j = 0; j < WW; ++j) {
         const int je = j ^ ((j >> 2) & 1);
         in[j] = ((je & 1) ? A1 : A0)[je * 8];
       }
+    };
+    auto fma_row = [&](int ky, const float4 (&in)[WW]) {
       float4 wk[K];
 #pragma unroll
       for (int kx = 0; kx < K; ++kx) wk[kx] = wq[(ky * K + kx) * 8];
@@ -364,9 +396,28 @@ __global__ __launch_bounds__(256, BWD ? 1 : 2) void dwm_conv_k(const DwmArgs a) 
           acc[u] = f4fma(in[u * S + kx], wk[kx], acc[u]);
           if (BWD) dwacc[ky * K + kx] = f4fma(in[u + kx], av[u], dwacc[ky * K + kx]);
         }
-      // 5x5: one filter row at a time (left alone the scheduler hoists the window reads of all K rows -- K * WW float4 -- above the
-      // FMAs); 3x3: all 3 rows' reads may go first (one LDS latency instead of three)
-      if (K == 5) __builtin_amdgcn_sched_barrier(0);
+    };
+    if (!DWM_DBG_ON(a, 1)) {
+      if (K == 3) {
+        // 3x3: the scheduler may hoist all three rows' reads above the FMAs (18-27 float4: one LDS latency instead of three)
+        float4 in[WW];
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky) {
+          read_row(ky, in);
+          fma_row(ky, in);
+        }
+      } else {
+        // 5x5: two rows in registers -- the reads of row ky + 1 are in flight under the FMAs of row ky; a scheduling fence per row
+        // keeps the compiler from hoisting all K rows (K * WW float4 = 160-220 registers)
+        float4 inA[WW], inB[WW];
+        read_row(0, inA);
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky) {
+          if (ky + 1 < K) read_row(ky + 1, (ky & 1) ? inA : inB);
+          fma_row(ky, (ky & 1) ? inB : inA);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
     }
     // stores and sums without a branch (a conditional block here makes the compiler sink the FMAs of each output into it and keep the
     // whole K x WW window live): masked buffer stores, masked adds
@@ -533,7 +584,9 @@ __global__ __launch_bounds__(256, K == 5 ? 1 : 2) void dwm_bwd_s2_k(const DwmArg
     if (cc < C) wreg = ld4(a.w + (long long)tap * C + cc);
   }
   DwmQuad kq;
-  if (PRE) kq = dwm_bn_setup(a.bn, C, c0, q, cok, false, reinterpret_cast<double*>(ring), s_mr);
+  DwmBnState<false> bst;
+  if (PRE) dwm_bn_begin(a.bn, C, c0, q, cok, bst);
+  if (PRE) kq = dwm_bn_end(a.bn, C, c0, q, cok, false, reinterpret_cast<double*>(ring), s_mr, bst);   // (statistics are given here: no fold)
   float4 ra, rb_, h0, h1;
   float4 za[4], zb[4];
   issue(h0, HEAD);
@@ -672,26 +725,28 @@ static inline void same_pad(int H, int K, int S, int* Ho, int* pt) {
 }
 
 // Workgroups per launch: the maps of one inner step are small (7-48 MB), so the row ranges are cut until about two workgroups per
-// CU exist -- shorter ranges re-fetch the K - S seam rows more often (rows_per_chunk + K - S over rows_per_chunk).
-static int g_dwm_target = 0;
-static inline int dwm_target() {
-  if (g_dwm_target == 0) {
+// CU exist in the forward (two waves per SIMD) and one in the backward (its kernels hold one wave per SIMD) -- shorter ranges
+// re-fetch the K - S seam rows more often (rows_per_chunk + K - S over rows_per_chunk) and pay the prologue more often; measured
+// cold at N = 8 and N = 64 (tools/bench_dwmarch.py, MLIIS_DWM_TARGET): forward 256 / 512 equal, 1024+ slower; backward 256 best.
+static int g_dwm_target = -1;
+static inline int dwm_target(bool bwd) {
+  if (g_dwm_target < 0) {
     const char* e = getenv("MLIIS_DWM_TARGET");
-    g_dwm_target = e ? atoi(e) : 512;
-    if (g_dwm_target < 1) g_dwm_target = 512;
+    g_dwm_target = e ? atoi(e) : 0;
+    if (g_dwm_target < 0) g_dwm_target = 0;
   }
-  return g_dwm_target;
+  return g_dwm_target ? g_dwm_target : (bwd ? 256 : 512);
 }
 
 // produced extent P x Q (rows x columns); unit = produced rows per step; bmax = produced columns of a band (multiple of ts)
-static inline void march_split(int N, int cgs, int P, int Q, int unit, int bmax, int ts, MarchGeom* g) {
+static inline void march_split(int N, int cgs, int P, int Q, int unit, int bmax, int ts, bool bwd, MarchGeom* g) {
   g->bands = (Q + bmax - 1) / bmax;
   int bw = (Q + g->bands - 1) / g->bands;   // balanced bands
   bw = (bw + ts - 1) / ts * ts;
   g->bw = bw;
   g->bands = (Q + bw - 1) / bw;
   const long long base = (long long)N * cgs * g->bands;
-  long long chunks = dwm_target() / base;
+  long long chunks = dwm_target(bwd) / base;
   const int max_chunks = (P + 2 * unit - 1) / (2 * unit);   // at least two steps per chunk
   if (chunks > max_chunks) chunks = max_chunks;
   if (chunks < 1) chunks = 1;
@@ -707,8 +762,8 @@ static inline MarchGeom march_geom_fwd(int N, int H, int W, int C, int K, int S)
   MarchGeom g;
   same_pad(H, K, S, &g.Ho, &g.pt);
   same_pad(W, K, S, &g.Wo, &g.pl);
-  if (S == 1) march_split(N, ceil_div(C, 32), g.Ho, g.Wo, 4, 28, 4, &g);
-  else march_split(N, ceil_div(C, 32), g.Ho, g.Wo, 4, 14, 2, &g);
+  if (S == 1) march_split(N, ceil_div(C, 32), g.Ho, g.Wo, 4, 28, 4, false, &g);
+  else march_split(N, ceil_div(C, 32), g.Ho, g.Wo, 4, 14, 2, false, &g);
   return g;
 }
 
@@ -718,10 +773,10 @@ static inline MarchGeom march_geom_bwd(int N, int H, int W, int C, int K, int S)
   same_pad(H, K, S, &g.Ho, &g.pt);
   same_pad(W, K, S, &g.Wo, &g.pl);
   if (S == 1) {
-    march_split(N, ceil_div(C, 32), H, W, 4, 28, 4, &g);
+    march_split(N, ceil_div(C, 32), H, W, 4, 28, 4, true, &g);
   } else {
     const int py = ((H + g.pt - 1) >> 1) - (g.pt >> 1) + 1, pxn = ((W + g.pl - 1) >> 1) - (g.pl >> 1) + 1;
-    march_split(N, ceil_div(C, 32), py, pxn, 2, 14, 1, &g);
+    march_split(N, ceil_div(C, 32), py, pxn, 2, 14, 1, true, &g);
   }
   return g;
 }

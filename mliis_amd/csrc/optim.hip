@@ -48,13 +48,16 @@ __global__ __launch_bounds__(256) void sgd_k(float* __restrict__ w, const float*
 }
 
 // Adam with beta1 = 0 (models/efficientlab.py:16; args.py:153-154): v = b2 v + (1-b2) g^2 ; w -= lr_t * g / (sqrt(v) + eps)
-// lr_t = lr * sqrt(1 - b2^t) (beta1^t term is 1 - 0 = 1).  step_dev holds t (float) and is advanced by the caller.
+// lr_t = lr * sqrt(1 - b2^t) (beta1^t term is 1 - 0 = 1).  step_dev holds the number of steps applied so far (float).  ticket ==
+// nullptr: the caller has already advanced it (t = *step_dev).  ticket != nullptr (a zeroed device counter): this launch is step
+// *step_dev + 1 and advances the count itself -- every workgroup reads it before it takes a ticket, the last one to finish stores
+// t + 1 and re-arms the counter -- so that a captured HIP graph can replay the optimizer step with no host-side bookkeeping.
 __global__ __launch_bounds__(256) void adam_b1zero_k(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ v,
                                                      const uint8_t* __restrict__ l2mask, long long nquads, float lr_host,
                                                      const float* __restrict__ lr_dev, float l2, float l1, float beta2, float eps,
-                                                     const float* __restrict__ step_dev) {
+                                                     float* __restrict__ step_dev, unsigned* __restrict__ ticket) {
   const float lr = lr_dev ? *lr_dev : lr_host;
-  const float tstep = *step_dev;
+  const float tstep = *step_dev + (ticket != nullptr ? 1.0f : 0.0f);
   const float lr_t = lr * sqrtf(1.f - powf(beta2, tstep));
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nquads; i += (long long)gridDim.x * blockDim.x) {
     float4 wv = ld4(w + i * 4), gv = ld4(g + i * 4), vv = ld4(v + i * 4);
@@ -69,6 +72,16 @@ __global__ __launch_bounds__(256) void adam_b1zero_k(float* __restrict__ w, cons
     wv.w -= lr_t * gv.w / (sqrtf(vv.w) + eps);
     st4(v + i * 4, vv);
     st4(w + i * 4, wv);
+  }
+  if (ticket != nullptr) {   // (uniform)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const unsigned tk = atomicAdd(ticket, 1u);
+      if (tk == gridDim.x - 1u) {
+        *ticket = 0u;
+        *step_dev = tstep;
+      }
+    }
   }
 }
 
@@ -119,12 +132,12 @@ int mliis_sgd_fused(float* w, const float* g, const uint8_t* l2_quad_mask, long 
 }
 
 int mliis_adam_b1zero_fused(float* w, const float* g, float* v, const uint8_t* l2_quad_mask, long long n, float lr, const float* lr_dev,
-                            float l2, float l1, float beta2, float eps, const float* step_dev, hipStream_t stream) {
+                            float l2, float l1, float beta2, float eps, float* step_dev, unsigned* step_ticket, hipStream_t stream) {
   MLIIS_REQUIRE(w && g && v && step_dev, MLIIS_ERR_ARG, "adam_b1zero_fused: null pointer");
   MLIIS_REQUIRE(n > 0 && (n & 3) == 0, MLIIS_ERR_ARG, "adam_b1zero_fused: n must be a positive multiple of 4");
   MLIIS_REQUIRE(aligned16(w) && aligned16(g) && aligned16(v), MLIIS_ERR_ALIGN, "adam_b1zero_fused: pointers must be 16-byte aligned");
   hipLaunchKernelGGL(adam_b1zero_k, dim3(flat_blocks(n / 4)), dim3(256), 0, stream, w, g, v, l2_quad_mask, n / 4, lr, lr_dev, l2, l1,
-                     beta2, eps, step_dev);
+                     beta2, eps, step_dev, step_ticket);
   MLIIS_CHECK_LAUNCH("adam_b1zero_fused");
   return MLIIS_OK;
 }

@@ -252,7 +252,7 @@ class Learner:
                  spatial_pyramid_pooling: bool = False, skip_decoding: bool = False, drop_connect: bool = True, seed: int = 0,
                  device="cuda:0", use_graph: bool = True, max_shots: int = 16, matmul_precision: str = "fp32",
                  overlap_wgrad: int = 0, wgrad_flush_before: Sequence[int] = (5,), small_fused: Optional[bool] = None,
-                 augment_batch_capacity: int = 0):
+                 augment_batch_capacity: int = 0, rng_stream: int = 0):
         if optimizer not in ("sgd", "adam"):
             raise ValueError("optimizer must be 'sgd' or 'adam' (Adam with beta1=0, the reference default)")
         if not torch.cuda.is_available():
@@ -328,7 +328,8 @@ class Learner:
         self.lr_dev = torch.tensor([self.lr], dtype=torch.float32, device=self.device)
         self._lr_dev_val = float(self.lr)
         self.adam_v = torch.zeros_like(self.arena.theta) if optimizer == "adam" else None
-        self.adam_t = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self.adam_t = torch.zeros(1, dtype=torch.float32, device=self.device)          # Adam steps applied so far
+        self.adam_ticket = torch.zeros(1, dtype=torch.int32, device=self.device)   # the optimizer launch advances adam_t itself
         self.plans: Dict[int, _Plan] = {}
         self.max_shots = max_shots
         H = image_size
@@ -346,7 +347,9 @@ class Learner:
             self._aug_n = 0
         self.n_shots = 0
         # device RNG of the stochastic ops (drop-connect, dropout): Philox state advanced by the mask kernel itself (csrc/rng.hip)
-        self.rng_state = ops.rng_state(seed, self.device)
+        # `seed` is the same on every rank (the weights must start identical); `rng_stream` -- the rank -- goes into the high word of
+        # the Philox KEY only, so ranks that step in lock-step on different tasks do not draw identical drop-connect / dropout masks
+        self.rng_state = ops.rng_state((int(seed) & 0xFFFFFFFF) ^ ((int(rng_stream) & 0xFFFFFFFF) << 32) if rng_stream else seed, self.device)
         ex_ = [b for b in self.arch.blocks if b.executed and b.skip]
         self._dc_keeps = torch.tensor([1.0 - b.drop_rate for b in ex_] or [1.0], dtype=torch.float32, device=self.device)
         self.drop_keep_dev = torch.tensor([1.0 - self.final_layer_dropout_rate], dtype=torch.float32, device=self.device)
@@ -481,23 +484,33 @@ class Learner:
             for p in A.trainable:
                 o = A.t_off[p.name]
                 out[p.name + "/Adam_1"] = v[o:o + p.size].reshape(p.shape).copy()
-            t = float(self.adam_t.item())
-            out["beta1_power"] = np.float32(0.0)
-            out["beta2_power"] = np.float32(self.ADAM_BETA2 ** (t + 1.0))
+            from .checkpoint import adam_step_entries
+            out.update(adam_step_entries(int(round(float(self.adam_t.item()))), self.ADAM_BETA2))
         return out
 
     def load_named(self, values, **kw) -> int:
+        """Restore by name with the scope filters of EfficientLab.restore_model (prefixes / exclude_prefix / strict, forwarded to the
+        arena).  The Adam slots follow the SAME filters (a final layer that is not restored keeps fresh slots too); the global step
+        count is only taken over by an unfiltered restore."""
+        from .checkpoint import adam_step_from
         self.stream.synchronize()
         n = self.arena.load_named(values, **kw)
-        if self.adam_v is not None and "beta2_power" in values:   # Adam slots of a checkpoint written by named_numpy()
+        if self.adam_v is not None:
             A = self.arena
+            prefixes, exclude = kw.get("prefixes"), kw.get("exclude_prefix")
             for p in A.trainable:
                 key = p.name + "/Adam_1"
-                if key in values:
-                    o = A.t_off[p.name]
-                    self.adam_v[o:o + p.size].copy_(torch.from_numpy(np.asarray(values[key], dtype=np.float32).reshape(-1)))
-            t = round(math.log(float(values["beta2_power"])) / math.log(self.ADAM_BETA2)) - 1
-            self.adam_t.fill_(float(max(t, 0)))
+                if key not in values:
+                    continue
+                if prefixes is not None and not any(p.name.startswith(x) for x in prefixes):
+                    continue
+                if exclude is not None and p.name.startswith(exclude):
+                    continue
+                o = A.t_off[p.name]
+                self.adam_v[o:o + p.size].copy_(torch.from_numpy(np.asarray(values[key], dtype=np.float32).reshape(-1)))
+            t = adam_step_from(values, self.ADAM_BETA2)
+            if t is not None and prefixes is None and exclude is None:
+                self.adam_t.fill_(float(t))
         torch.cuda.synchronize(self.device)
         return n
 
@@ -1096,8 +1109,9 @@ class Learner:
         if self.optimizer == "sgd":
             ops.sgd_fused(A.theta, A.grad, self.lr, A.l2_quad_mask, l2, self.lr_dev, l1=l1)
         else:
-            self.adam_t.add_(1.0)
-            ops.adam_b1zero_fused(A.theta, A.grad, self.adam_v, self.adam_t, self.lr, A.l2_quad_mask, l2, self.lr_dev, l1=l1)
+            # (the launch reads the step count from device memory, uses t + 1 and stores it: the same graph replays every step)
+            ops.adam_b1zero_fused(A.theta, A.grad, self.adam_v, self.adam_t, self.lr, A.l2_quad_mask, l2, self.lr_dev, l1=l1,
+                                  ticket=self.adam_ticket)
 
     def _train_sequence(self, P: _Plan, draw_masks: bool):
         if draw_masks and P.mask_plan is not None:
@@ -1144,7 +1158,7 @@ class Learner:
             if weight_decay_rate != 1.0:  # pre_step_op (variables.py:48-55)
                 ops.axpby(0.0, None, float(weight_decay_rate), self.arena.theta)
             draw = self._fill_masks(P, dc_scales, dropout_mask, drop_rate, aspp_masks)
-            if self.use_graph and P.steps_run >= 1 and self.optimizer == "sgd":
+            if self.use_graph and P.steps_run >= 1:
                 if draw not in P.graphs:
                     gexec = C.c_void_p()
                     lib.call("mliis_graph_begin_capture", self.stream.cuda_stream)

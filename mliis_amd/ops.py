@@ -741,9 +741,11 @@ def sgd_fused(w, g, lr, l2_quad_mask=None, l2=0.0, lr_dev=None, l1=0.0):
     lib.call("mliis_sgd_fused", _ptr(w), _ptr(g), _ptr(l2_quad_mask), w.numel(), float(lr), _ptr(lr_dev), float(l2), float(l1), _stream())
 
 
-def adam_b1zero_fused(w, g, v, step_dev, lr, l2_quad_mask=None, l2=0.0, lr_dev=None, beta2=0.999, eps=1e-8, l1=0.0):
+def adam_b1zero_fused(w, g, v, step_dev, lr, l2_quad_mask=None, l2=0.0, lr_dev=None, beta2=0.999, eps=1e-8, l1=0.0, ticket=None):
+    """step_dev: device float, steps applied so far.  ticket None: the caller advanced it before the call; ticket (a zeroed device
+    int32): the launch is step step_dev + 1 and advances the count itself (graph-replay safe)."""
     lib.call("mliis_adam_b1zero_fused", _ptr(w), _ptr(g), _ptr(v), _ptr(l2_quad_mask), w.numel(), float(lr), _ptr(lr_dev), float(l2), float(l1),
-             float(beta2), float(eps), _ptr(step_dev), _stream())
+             float(beta2), float(eps), _ptr(step_dev), _ptr(ticket), _stream())
 
 
 def axpby(a, x, b, y):

@@ -109,9 +109,12 @@ class Gecko:
         # task-by-task -- the tasks are independent and the deltas are accumulated in task order -- except that every lane draws its
         # drop-connect masks from its own generator.
         self.lanes = list(lanes)
+        # Adam (the reference's default inner optimizer): every lane keeps its own second-moment slots and step count, exactly as every
+        # RANK does under multi-GPU sharding -- the reference's single sequential history over all tasks is not
+        # reproduced then; the SGD path (--sgd) stays bit-identical to the task-by-task loop.
         for ln in self.lanes:
-            if ln.n_trainable != learner.n_trainable or getattr(ln, "optimizer", "sgd") != "sgd" or getattr(learner, "optimizer", "sgd") != "sgd":
-                raise ValueError("lanes must share the learner's architecture and use the SGD inner optimizer (Adam keeps per-learner state)")
+            if ln.n_trainable != learner.n_trainable or getattr(ln, "optimizer", "sgd") != getattr(learner, "optimizer", "sgd"):
+                raise ValueError("lanes must share the learner's architecture and inner optimizer")
         self._transductive = transductive
         # pre_step_op: the reference passes a TF op that multiplies all trainables by `weight_decay_rate`
         # (variables.py:48-55); here it is that rate (float) or None.

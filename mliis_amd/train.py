@@ -75,6 +75,9 @@ def train_gecko(learner, train_set, test_set, save_dir, num_classes=5, num_shots
                 if rank0:
                     writers[name].add(i, IoU=float(mean_iou), meta_step_size=float(cur))
                 ious.append(mean_iou)
+            # rank 0's numbers on every rank: the per-rank device mask generators (and augmenter draws) may differ, and the
+            # best-checkpoint decision below must be the same everywhere
+            ious = D.broadcast_floats(ious, device=getattr(learner, "device", None))
             if rank0:
                 log_fn("Train step %d: train=%f test=%f" % (i, ious[0], ious[1]))
             if save_best_seen and ious[1] > best_eval_iou:

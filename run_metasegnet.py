@@ -166,7 +166,9 @@ def main(argv=None, learner_factory=None, device=None):
 
     print("Defining model architecture:")
     print("Using loss {}".format(args.loss_name))
-    learner = Learner(device=device, **model_kwargs(args))
+    # (multi-rank: the rank goes into the key of the device mask generator only -- same weights everywhere, different drop-connect draws)
+    rank_kw = dict(rng_stream=rank) if (world > 1 and learner_factory is None) else {}
+    learner = Learner(device=device, **model_kwargs(args), **rank_kw)
     lr_scheduler = make_lr_scheduler(args)
     print("Model contains {} trainable parameters.".format(learner.n_trainable))
     print("Meta-learning with algorithm:\n{}".format("FOMAML" if args.foml else "Reptile"))
@@ -175,7 +177,7 @@ def main(argv=None, learner_factory=None, device=None):
 
     lanes = []
     if args.concurrent_tasks > 1 and not args.augment:   # the augmented path uploads host batches step by step: one lane
-        lanes = [Learner(device=device, **dict(model_kwargs(args), seed=args.seed + 1000 * k)) for k in range(1, args.concurrent_tasks)]
+        lanes = [Learner(device=device, **dict(model_kwargs(args), seed=args.seed + 1000 * k), **rank_kw) for k in range(1, args.concurrent_tasks)]
 
     if args.restore_efficient_net_weights_from is not None and not args.pretrained:
         path = ckpt.latest_checkpoint(args.restore_efficient_net_weights_from)

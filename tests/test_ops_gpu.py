@@ -417,6 +417,14 @@ def test_sgd_l2_mask_and_arena_algebra():
     ops.adam_b1zero_fused(w2, gg, v, torch.tensor([1.0], device=d), 1e-3)
     vv = 0.001 * g * g
     close(w2, w - 1e-3 * math.sqrt(1 - 0.999) * g / (vv.sqrt() + 1e-8), 1e-5, "adam b1=0")
+    # the self-advancing form a captured graph replays: steps applied so far on the device, the launch uses t + 1 and stores it
+    v5, w5 = torch.zeros(n, device=d), f32(w, d)
+    t_dev, ticket = torch.zeros(1, device=d), torch.zeros(1, dtype=torch.int32, device=d)
+    ops.adam_b1zero_fused(w5, gg, v5, t_dev, 1e-3, ticket=ticket)
+    assert torch.equal(w5, w2) and torch.equal(v5, v) and t_dev.item() == 1.0 and ticket.item() == 0
+    ops.adam_b1zero_fused(w5, gg, v5, t_dev, 1e-3, ticket=ticket)
+    ops.adam_b1zero_fused(w2, gg, v, torch.tensor([2.0], device=d), 1e-3)
+    assert torch.equal(w5, w2) and torch.equal(v5, v) and t_dev.item() == 2.0 and ticket.item() == 0
     # --l1 (models/regularizers.py:13-19): + l1 * sign(w) on the same (non batch-norm) quads, together with L2; sign(0) = 0
     w[8:12] = 0.0
     w3 = f32(w, d)

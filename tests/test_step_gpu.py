@@ -126,21 +126,26 @@ def test_five_step_trajectory_and_masks():
         assert torch.equal(pL.cpu()[~tie], own[~tie])
 
 
-def test_graph_replay_equals_eager_and_variable_batch():
-    """HIP-graph replay is bit-identical to eager launches; FOMAML tail batches (N=5) coexist with N=8 plans."""
+@pytest.mark.parametrize("optimizer", ["sgd", "adam"])
+def test_graph_replay_equals_eager_and_variable_batch(optimizer):
+    """HIP-graph replay is bit-identical to eager launches; FOMAML tail batches (N=5) coexist with N=8 plans.  Adam(beta1 = 0) -- the
+    reference's default inner optimizer (meta_learners/args.py:151-154) -- replays too: its step count lives on the device and the
+    optimizer launch advances it."""
     _need_gpu()
     from mliis_amd.learner import Learner
     H, S = 64, 10
     x, y = _task(S, H, 3)
     runs = []
     for use_graph in (False, True):
-        L = Learner(image_size=H, seed=7, use_graph=use_graph, drop_connect=False)
+        L = Learner(image_size=H, seed=7, use_graph=use_graph, drop_connect=False, optimizer=optimizer)
         L.load_task(x, y)
         losses = []
         for idx in ([0, 1, 2, 3, 4, 5, 6, 7], [7, 6, 5, 4, 3, 2, 1, 0], [1, 1, 2, 2, 3, 3, 4, 4], [5, 6, 7, 8, 9], [0, 2, 4, 6, 8, 1, 3, 5], [9, 8, 7, 6, 5]):
             L.inner_step(idx)
             losses.append(L.loss_value())
         runs.append((losses, L.export_trainable().cpu(), L.export_bn().cpu()))
+        if optimizer == "adam":
+            assert L.adam_t.item() == 6.0 and L.adam_ticket.item() == 0
         L.close()                                   # destroys the captured graphs; the next step captures again
         assert all(P.graph is None for P in L.plans.values())
         L.inner_step([0, 1, 2, 3, 4, 5, 6, 7])
@@ -229,11 +234,11 @@ def test_dropout_adam_and_b3_variants():
     _compare_state(O, L, gO, "dropout")
     # (b) Adam(beta1 = 0), two steps
     O = R.OracleLearner(image_size=H, seed=0, dtype=torch.float64, lr=1e-3)
-    L = Learner(image_size=H, seed=3, optimizer="adam", use_graph=False, drop_connect=False)
+    L = Learner(image_size=H, seed=3, optimizer="adam", use_graph=True, drop_connect=False)   # (eager, captured, replayed)
     L.load_named({k: v.numpy() for k, v in O.params.items()}, strict=False)
     L.load_task(x, y)
     st = {"t": 0, "v": {}}
-    for _ in range(2):
+    for _ in range(3):
         lo, _, _ = R.inner_step(O.a, O.params, O.bn, xb, yb, 1e-3, None, None, adam_state=st)
         L.inner_step(idx)
         assert abs(L.loss_value() - lo) <= 1e-3 * max(1.0, abs(lo))

@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--out", default=None)
     ap.add_argument("--dense-only", action="store_true")
     ap.add_argument("--dw-only", action="store_true")
+    ap.add_argument("--old-dw", action="store_true", help="time the depthwise kernels of csrc/dwconv.hip instead of the row-marching ones")
     a = ap.parse_args()
     d = torch.device("cuda:0")
     arch = spec.derive()
@@ -62,9 +63,18 @@ def main():
                 ctr[0] += 1
                 fn(i)
             return call
-        tf = timeit(rot(lambda i: ops.dwconv_fwd(xs[i], w, s, out=ys[i])), a.iters)
-        tbd = timeit(rot(lambda i: ops.dwconv_bwd_data(dys[i], w, s, (hi, hi), out=dxs[i])), a.iters)
-        tbf = timeit(rot(lambda i: ops.dwconv_bwd_filter(xs[i], dys[i], k, s, out=dw)), a.iters)
+        if a.old_dw:   # the sliding-window / tile kernels of csrc/dwconv.hip (rounds 1-2; the skip decoder still uses them)
+            tf = timeit(rot(lambda i: ops.dwconv_fwd(xs[i], w, s, out=ys[i])), a.iters)
+            tbd = timeit(rot(lambda i: ops.dwconv_bwd_data(dys[i], w, s, (hi, hi), out=dxs[i])), a.iters)
+            tbf = timeit(rot(lambda i: ops.dwconv_bwd_filter(xs[i], dys[i], k, s, out=dw)), a.iters)
+        else:          # the row-marching kernels (csrc/dwmarch.hip): forward with the batch norm + swish applied while staging (statistics
+            #            given), backward = ONE pass (dx + filter-gradient slabs + the batch norm's stage-1 sums)
+            gam, bet, mean, rstd = (torch.rand(C, device=d) + 0.5 for _ in range(4))
+            slabs = torch.empty(ops.dwconv_bn_bwd_blocks(N, hi, hi, C, k, s) * k * k * C, device=d)
+            part = torch.empty(1 << 22, device=d)
+            tf = timeit(rot(lambda i: ops.dwconv_bn_fwd(xs[i], w, s, bn=(gam, bet, mean, rstd, None, None), out=ys[i], stats_part=part)), a.iters)
+            tbd = timeit(rot(lambda i: ops.dwconv_bn_bwd(dys[i], xs[i], w, s, bn=(mean, rstd, gam, bet), out=dxs[i], dw_part=slabs, bn_part=part)), a.iters)
+            tbf = 0.0
         x, y = xs[0], ys[0]
         fb = 4 * (x.numel() + y.numel() + w.numel())
         bb = 4 * (2 * x.numel() + y.numel() + 2 * w.numel())
@@ -74,8 +84,9 @@ def main():
         tot["fwd_b"] += fb
         tot["bwd_t"] += tbd + tbf
         tot["bwd_b"] += bb
-        print("dw b%-2d C=%-3d k%d s%d h=%-3d fwd %7.1f us (%4.1f%% HBM)  bwd_data %7.1f  bwd_filter %7.1f (%4.1f%% HBM)" % (
-            b.idx, C, k, s, hi, tf * 1e6, 100 * fb / tf / HBM_PEAK, tbd * 1e6, tbf * 1e6, 100 * bb / (tbd + tbf) / HBM_PEAK), flush=True)
+        print("dw b%-2d C=%-3d k%d s%d h=%-3d fwd %7.1f us (%4.1f%% HBM)  bwd%s %7.1f%s (%4.1f%% HBM)" % (
+            b.idx, C, k, s, hi, tf * 1e6, 100 * fb / tf / HBM_PEAK, "_data" if a.old_dw else " (one pass)", tbd * 1e6,
+            ("  bwd_filter %7.1f" % (tbf * 1e6)) if a.old_dw else "", 100 * bb / (tbd + tbf) / HBM_PEAK), flush=True)
     if not a.dense_only:
       res["depthwise_total"] = dict(fwd_us=tot["fwd_t"] * 1e6, bwd_us=tot["bwd_t"] * 1e6, fwd_frac=tot["fwd_b"] / tot["fwd_t"] / HBM_PEAK,
                                   bwd_frac=tot["bwd_b"] / tot["bwd_t"] / HBM_PEAK)

@@ -21,6 +21,8 @@ def family(n):
         return "small-map fused MBConv depthwise half (bn0 + dw + bn1 + pool | their backward)"
     if n.startswith("conv_filter"):
         return "dense conv bwd-filter (MFMA)"
+    if n.startswith("dwm_"):
+        return "depthwise, row-marching (bn0 + swish on load + dw + bn1 sums | one-pass backward)"
     if n.startswith("dwconv"):
         return "depthwise " + n.split("_k")[0].replace("dwconv_", "")
     if n.startswith("bn_") or "BnBwdOp" in n or "StatsOp" in n:
@@ -74,7 +76,8 @@ def main():
         return -(-items // 256) * 256
     L += ["", "## Depthwise layers vs the HBM roofline, IN-STEP (graph replay: operands partly resident in the 256 MiB Infinity Cache, the producer "
           "ran just before; bench.py's `depthwise_hbm` has the cold-operand figures)", "",
-          "8.0 TB/s spec; algorithmic bytes (SURVEY 8(d)): fwd 4*(in+out+k*k*C); bwd-data 4*(dY+dX+k*k*C) (+ 4*z0 where the launch also emits the expand "
+          "8.0 TB/s spec; algorithmic bytes (SURVEY 8(d)): fwd 4*(in+out+k*k*C); one-pass backward 4*(2*in+out+2*k*k*C) (dY and X read, dX written); "
+          "for the op-by-op kernels bwd-data 4*(dY+dX+k*k*C) (+ 4*z0 where the launch also emits the expand "
           "BN's backward sums); bwd-filter 4*(X+dY+k*k*C).  Blocks 6-10 (14x14): the depthwise op lives inside the fused small-map kernels "
           "(`mbconv_dw_fwd_small_k` = bn0 apply + depthwise + bn1 statistics/apply + SE pooling; `mbconv_dw_bwd_small_k` = bn1 backward + "
           "depthwise backward-data + backward-filter + bn0 backward): their whole duration is charged to the depthwise bytes (fwd; bwd = bwd-data + bwd-filter bytes).", "",
@@ -93,6 +96,13 @@ def main():
     def grid(items):
         return -(-items // 256) * 256
     small_seen = collections.defaultdict(int)
+    from mliis_amd._lib import lib as _lib
+    per_m = collections.defaultdict(list)
+    for r in trace:
+        n = r["Kernel_Name"]
+        if "dwm_" in n:
+            per_m[(n.split("(")[0].replace("void mliis::", ""), int(r["Grid_Size_X"]), int(r["Grid_Size_Y"]))].append(
+                int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     for b in a.blocks:
         q = b.cexp // 4
         by = 4.0 * (N * b.h_in ** 2 * b.cexp + N * b.h_out ** 2 * b.cexp + b.k ** 2 * b.cexp)
@@ -105,6 +115,20 @@ def main():
             tf += mf; bf += by; tb += mb; bb += by + by
             L.append("| %d | %d | %d,%d | %d->%d | %.1f (fused) | %.0f %% | %.1f (fused: bwd-data + bwd-filter) | %.0f %% | | |" % (
                 b.idx, b.cexp, b.k, b.stride, b.h_in, b.h_out, mf, by / mf / 1e3 / 80, mb, 2 * by / mb / 1e3 / 80))
+            continue
+        # row-marching kernels (csrc/dwmarch.hip): identified by instantiation + grid (the library's own block-count queries)
+        cy_ = -(-b.cexp // 32)
+        gfm = _lib.raw("mliis_dwconv_bn_fwd_blocks")(N, b.h_in, b.h_in, b.cexp, b.k, b.stride)
+        gbm = _lib.raw("mliis_dwconv_bn_bwd_blocks")(N, b.h_in, b.h_in, b.cexp, b.k, b.stride)
+        mfw = [v for (k, g, gy), v in per_m.items() if k.startswith("dwm_conv_k<%d, %d, " % (b.k, b.stride)) and k.endswith("false>") and g == gfm * 256 and gy == cy_]
+        mbw = [v for (k, g, gy), v in per_m.items() if ((k.startswith("dwm_conv_k<%d, 1, " % b.k) and k.endswith("true>")) if b.stride == 1 else
+                                                        k.startswith("dwm_bwd_s2_k<%d, " % b.k)) and g == gbm * 256 and gy == cy_]
+        if mfw and mbw:
+            mf, mb = med(mfw[0]), med(mbw[0])
+            byb2 = 4.0 * (2 * N * b.h_in ** 2 * b.cexp + N * b.h_out ** 2 * b.cexp + 2 * b.k ** 2 * b.cexp)
+            tf += mf; bf += by; tb += mb; bb += byb2
+            L.append("| %d | %d | %d,%d | %d->%d | %.1f (march: + bn0 fold/apply, bn1 sums) | %.0f %% | %.1f (march, one pass: dx + dW slabs + bn0 sums) | %.0f %% | | |" % (
+                b.idx, b.cexp, b.k, b.stride, b.h_in, b.h_out, mf, by / mf / 1e3 / 80, mb, byb2 / mb / 1e3 / 80))
             continue
         gf = grid(N * b.h_out * (-(-b.h_out // 4)) * q)
         gb = grid(N * b.h_in * (-(-b.h_in // 4)) * q)
