@@ -249,8 +249,8 @@ int mliis_bn_bwd(const float* x, int ldx, const float* dy, int lddy, float* dx, 
                  const float* img_scale, const float* chan_scale, const float* chan_add, float* dgamma, float* dbeta, float* dskip,
                  int lddskip, int dskip_accumulate, float* dxsum_part, size_t dxsum_floats, float* ws, size_t ws_floats,
                  const float* stage1_part, int stage1_nblk, hipStream_t stream);
-/*      stage1_part (nullable, [stage1_nblk][2][C]): the reduce pass's partial sums {sum g, sum g*xhat} already produced by the kernel
- *      that wrote dy (mliis_dwconv_bwd_data_bn); mliis_bn_bwd then runs its apply pass only (plain batch norms: no per-image vectors) */
+/*      stage1_part (nullable, [stage1_nblk][2][C]): the reduce pass's partial sums {sum g, sum g*xhat} already produced elsewhere with the
+ *      SAME g (mliis_dwconv_bwd_data_bn, mliis_dwconv_bn_bwd, mliis_conv2d_bwd_data_bn, mliis_se_mlp_bwd_bn); mliis_bn_bwd then runs its apply pass only */
 
 /* ---- per-image column sums: out[seg,c] (+)= scale * sum_rows a[row,c] * b[row,c]  (b nullable).  Serves tf.reduce_mean over
  *      H,W of squeeze-excite (efficientnet_model.py:247) and of the RSD pooled branch (efficientlab.py:192-197), their
@@ -270,6 +270,19 @@ int mliis_se_mlp_fwd(const float* s_part, int chunks, float scale, float* s_out,
 int mliis_se_mlp_bwd(const float* dgate, int dgate_row_groups, const float* gate, const float* s, const float* hpre, const float* w1,
                      const float* w2, float* dpre1, float* dpre2, float* chan_add, float* dw1, float* db1, float* dw2, float* db2, int N,
                      int C, int R, int HW, hipStream_t stream);
+/*      The squeeze-excite backward and the depthwise batch norm's backward of an MBConv block (efficientnet_model.py:238-251,271) share
+ *      ONE pass over (da2, z1): mliis_se_bn_bwd_sums leaves, per image and row chunk, part [N][*nblk][5][C] = {sum da2*a1, sum da2*s',
+ *      sum da2*s'*xhat, sum s', sum s'*xhat} (a1 = swish(u), s' = swish'(u), u = gamma*xhat + beta); mliis_se_mlp_bwd_bn folds value 0
+ *      into the gate's gradient, runs the MLP backward (dpre1, dpre2, chan_add as mliis_se_mlp_bwd) and, since the batch norm's upstream
+ *      gradient is g = (da2*gate[n] + chan_add[n]) * s', emits its stage-1 sums per image, stage1 [N][2][C], for
+ *      mliis_bn_bwd(chan_scale = gate, chan_add, stage1_part = stage1, stage1_nblk = N).  Replaces mliis_colsum(da2, a1) and the
+ *      batch norm's own reduce pass. */
+size_t mliis_se_bn_bwd_sums_floats(int N, int rows_per_img, int C);
+int mliis_se_bn_bwd_sums(const float* x, int ldx, const float* dy, int lddy, int N, int rows_per_img, int C, const float* mean,
+                         const float* rstd, const float* gamma, const float* beta, float* part, size_t part_floats, int* nblk,
+                         hipStream_t stream);
+int mliis_se_mlp_bwd_bn(const float* sums, int sums_nblk, const float* gate, const float* hpre, const float* w1, const float* w2,
+                        float* dpre1, float* dpre2, float* chan_add, float* stage1, int N, int C, int R, int HW, hipStream_t stream);
 int mliis_se_wgrad_batched(const long long* desc, int ndesc, long long total_tiles, hipStream_t stream);
 /*      y0[m, c] (+)= x[m, c] + A[n(m), c] for c < c0 and y1[m, c - c0] (+)= the same for c >= c0: the gradient of a channel concat
  *      routed to its two inputs in one pass (tail of the RSD module's backward, models/efficientlab.py:206-208,226-228) */

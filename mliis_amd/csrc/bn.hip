@@ -543,6 +543,51 @@ struct SumOp {  // column sum of a (optionally times b)
   __device__ __forceinline__ void eval(const Ctx&, const Raw& r, float4* o) const { o[0] = f4mul(r.a, r.b); }
 };
 
+// ONE pass over (da2, z1) of an MBConv block for everything the squeeze-excite backward and the depthwise batch norm's backward need
+// from those two tensors (efficientnet_model.py:238-251,271): with u = gamma * xhat + beta, a1 = swish(u), the upstream gradient of
+// a1 is g1 = da2 * gate[n] + chan_add[n] (per-image vectors that only exist after the squeeze-excite backward), so per image n
+//     v0 = sum da2 * a1                  (the gate's gradient)
+//     v1 = sum da2 * swish'(u)           v2 = sum da2 * swish'(u) * xhat
+//     v3 = sum swish'(u)                 v4 = sum swish'(u) * xhat
+// and the batch norm's stage-1 sums follow without touching the tensors again:
+//     sum g = sum_n gate[n] v1[n] + chan_add[n] v3[n],   sum g xhat = sum_n gate[n] v2[n] + chan_add[n] v4[n]
+// (mliis_se_mlp_bwd_bn forms them).  Replaces the gate-gradient column sum (+ its finalize) and the batch norm's reduce pass.
+struct SeBnOp {
+  static constexpr int NV = 5;
+  const float* x;    // z1: the batch norm's input
+  int ldx;
+  const float* dy;   // da2
+  int lddy;
+  const float *mean, *rstd, *gamma, *beta;
+  struct Raw { float4 x, g; };
+  struct Ctx { float4 m, rs, ga, be; };
+  __device__ __forceinline__ Ctx ctx(int c) const { return Ctx{ld4(mean + c), ld4(rstd + c), ld4(gamma + c), ld4(beta + c)}; }
+  __device__ __forceinline__ void load(int, long long row, int c, Raw& r) const {
+    r.x = ld4(x + row * ldx + c);
+    r.g = ld4(dy + row * lddy + c);
+  }
+  __device__ __forceinline__ void one(float x, float g, float m, float rs, float ga, float be, float* o) const {
+    const float xh = (x - m) * rs;
+    const float u = fmaf(xh, ga, be);
+    const float sg = sigmoid_f(u);
+    const float d = sg * (1.0f + u * (1.0f - sg));   // swish'(u)
+    o[0] = g * u * sg;
+    o[1] = g * d;
+    o[2] = g * d * xh;
+    o[3] = d;
+    o[4] = d * xh;
+  }
+  __device__ __forceinline__ void eval(const Ctx& k, const Raw& r, float4* o) const {
+    float a[5], b[5], c[5], d[5];
+    one(r.x.x, r.g.x, k.m.x, k.rs.x, k.ga.x, k.be.x, a);
+    one(r.x.y, r.g.y, k.m.y, k.rs.y, k.ga.y, k.be.y, b);
+    one(r.x.z, r.g.z, k.m.z, k.rs.z, k.ga.z, k.be.z, c);
+    one(r.x.w, r.g.w, k.m.w, k.rs.w, k.ga.w, k.be.w, d);
+#pragma unroll
+    for (int v = 0; v < 5; ++v) o[v] = make_float4(a[v], b[v], c[v], d[v]);
+  }
+};
+
 // sum_rows x[row, c] * (mask[row,c]) * dy[row, j], j = 0,1   (final 1x1 conv, Cout = 2: weight gradient)
 struct Outer2Op {
   static constexpr int NV = 2;
@@ -789,12 +834,11 @@ int mliis_bn_bwd(const float* x, int ldx, const float* dy, int lddy, float* dx, 
   ColGeom g;
   int rc;
   if (stage1_part != nullptr) {   // stage 1 ({sum g, sum g * xhat} partials [stage1_nblk][2][C]) came from the producer of dy
-    // (the producer computed its sums with the same g: the drop-connect scale may be part of it -- mliis_conv2d_bwd_data_bn -- the
-    // squeeze-excite vectors may not)
-    MLIIS_REQUIRE(stage1_nblk > 0 && aligned16(stage1_part) && chan_scale == nullptr && chan_add == nullptr, MLIIS_ERR_ARG,
-                  "bn_bwd: external stage-1 partials cannot be combined with the squeeze-excite vectors");
-    if (img_scale != nullptr) {
-      BnBwdCommon<true> p{x, ldx, dy, lddy, rows_per_img, C, mean, rstd, gamma, beta, pre_swish, post_swish, img_scale, nullptr, nullptr};
+    // (the producer computed its sums with the same g: the drop-connect scale -- mliis_conv2d_bwd_data_bn -- or the squeeze-excite
+    // vectors -- mliis_se_bn_bwd_sums + mliis_se_mlp_bwd_bn -- are part of it)
+    MLIIS_REQUIRE(stage1_nblk > 0 && aligned16(stage1_part), MLIIS_ERR_ARG, "bn_bwd: bad external stage-1 partials");
+    if (img_scale != nullptr || chan_scale != nullptr || chan_add != nullptr) {
+      BnBwdCommon<true> p{x, ldx, dy, lddy, rows_per_img, C, mean, rstd, gamma, beta, pre_swish, post_swish, img_scale, chan_scale, chan_add};
       hipLaunchKernelGGL(bn_bwd_apply_fused_k<true>, dim3(gx, gy), dim3(256), 0, stream, p, rows, stage1_part, stage1_nblk, 1.0 / (double)rows,
                          dgamma, dbeta, dx, lddx, rpb, skip, dxsum_part);
     } else {
@@ -820,6 +864,31 @@ int mliis_bn_bwd(const float* x, int ldx, const float* dy, int lddy, float* dx, 
   }
   MLIIS_CHECK_LAUNCH("bn_bwd_apply_fused");
   return MLIIS_OK;
+}
+
+// part [N][*nblk][5][C]: per image and row chunk, the five sums of SeBnOp over (dy = da2, x = z1).
+int mliis_se_bn_bwd_sums(const float* x, int ldx, const float* dy, int lddy, int N, int rows_per_img, int C, const float* mean,
+                         const float* rstd, const float* gamma, const float* beta, float* part, size_t part_floats, int* nblk,
+                         hipStream_t stream) {
+  MLIIS_REQUIRE(x && dy && mean && rstd && gamma && beta && part && nblk, MLIIS_ERR_ARG, "se_bn_bwd_sums: null pointer");
+  MLIIS_REQUIRE(N > 0 && rows_per_img > 0 && C > 0 && (C & 3) == 0 && (ldx & 3) == 0 && (lddy & 3) == 0 && ldx >= C && lddy >= C &&
+                    (long long)N * rows_per_img < (1LL << 31),
+                MLIIS_ERR_ARG, "se_bn_bwd_sums: bad shape");
+  MLIIS_REQUIRE(aligned16(x) && aligned16(dy) && aligned16(mean) && aligned16(rstd) && aligned16(gamma) && aligned16(beta) && aligned16(part),
+                MLIIS_ERR_ALIGN, "se_bn_bwd_sums: pointers must be 16-byte aligned");
+  SeBnOp op{x, ldx, dy, lddy, mean, rstd, gamma, beta};
+  ColGeom g;
+  // (about two workgroups per CU: the squeeze-excite backward folds an image's chunks itself)
+  int rc = launch_colreduce(op, rows_per_img, C, N, part, part_floats, stream, &g, "se_bn_bwd_sums", 512);
+  if (rc) return rc;
+  *nblk = g.nblk;
+  return MLIIS_OK;
+}
+
+size_t mliis_se_bn_bwd_sums_floats(int N, int rows_per_img, int C) {
+  if (N <= 0 || rows_per_img <= 0 || C <= 0 || (C & 3)) return 0;
+  const ColGeom g = col_geom(rows_per_img, C, N, 512);
+  return (size_t)N * g.nblk * 5 * C;
 }
 
 // Stage 1 only: per-block column sums {sum x, sum x^2} (of swish(x) when pre_swish) into part [nblk][2][C]; *nblk_out = nblk.

@@ -96,21 +96,43 @@ __global__ __launch_bounds__(kSeThreads) void se_mlp_fwd_k(const float* __restri
 // dgate_groups > 0: dgate holds per-16-row-group partial sums [groups][2][C] from the producer of the gradient
 // (mliis_conv2d_bwd_data_gate): slot 0 = rows of the image the group starts in, slot 1 = rows of the next image; image n owns rows
 // [n * HW, (n + 1) * HW).  Its groups are folded here in group order (deterministic), all loads of eight groups issued together.
+// sums (nullable, [N][sums_nblk][5][C] from mliis_se_bn_bwd_sums): dgate = the image's chunks of value 0, folded here; values 1..4 and
+// the finished gate / chan_add give stage 1 of the depthwise batch norm's backward for this image, stage1 [N][2][C].
 __global__ __launch_bounds__(kSeThreads) void se_mlp_bwd_k(const float* __restrict__ dgate, int dgate_groups, int HW,
                                                     const float* __restrict__ gate,
                                                     const float* __restrict__ hpre, const float* __restrict__ w1,
                                                     const float* __restrict__ w2, float* __restrict__ dpre2,
                                                     float* __restrict__ dpre1, float* __restrict__ chan_add, int C, int R,
-                                                    float inv_hw) {
+                                                    float inv_hw, const float* __restrict__ sums, int sums_nblk,
+                                                    float* __restrict__ stage1) {
   __shared__ float sd1[kMaxR];
-  extern __shared__ float sd2[];   // [C]
+  extern __shared__ float sd2[];   // [C] (+ [4][C] with sums)
   const int n = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
   float* d2 = dpre2 + (long long)n * C;
   const int g_lo = dgate_groups > 0 ? (n * HW) / 16 : 0, g_hi = dgate_groups > 0 ? ((n + 1) * HW - 1) / 16 : -1;
   for (int c = t; c < C; c += kSeThreads) {
     const float g = gate[(long long)n * C + c];
     float dg;
-    if (dgate_groups > 0) {
+    if (sums != nullptr) {   // chunks of this image in chunk order (deterministic); the five values of a chunk fetched together
+      float p[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+      const float* base = sums + ((long long)n * sums_nblk) * 5 * C + c;
+      for (int b = 0; b < sums_nblk; b += 2) {
+        float v[2][5];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int k = 0; k < 5; ++k) v[u][k] = base[((long long)(b + u < sums_nblk ? b + u : b) * 5 + k) * C];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+          if (b + u < sums_nblk) {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) p[k] += v[u][k];
+          }
+      }
+      dg = p[0];
+#pragma unroll
+      for (int k = 1; k < 5; ++k) sd2[k * C + c] = p[k];
+    } else if (dgate_groups > 0) {
       dg = 0.f;
       for (int k = g_lo; k <= g_hi; k += 8) {
         float v[8];
@@ -159,7 +181,13 @@ __global__ __launch_bounds__(kSeThreads) void se_mlp_bwd_k(const float* __restri
 #pragma unroll
       for (int u = 0; u < 8; ++u) a = fmaf(k + u < R ? sd1[k + u] : 0.f, wv[u], a);
     }
-    chan_add[(long long)n * C + c] = a * inv_hw;
+    const float ca = a * inv_hw;
+    chan_add[(long long)n * C + c] = ca;
+    if (sums != nullptr) {   // {sum g, sum g xhat} of this image, g = (da2 * gate + chan_add) * swish'
+      const float gt = gate[(long long)n * C + c];
+      stage1[((long long)n * 2 + 0) * C + c] = fmaf(gt, sd2[1 * C + c], ca * sd2[3 * C + c]);
+      stage1[((long long)n * 2 + 1) * C + c] = fmaf(gt, sd2[2 * C + c], ca * sd2[4 * C + c]);
+    }
   }
 }
 
@@ -308,12 +336,25 @@ int mliis_se_mlp_bwd(const float* dgate, int dgate_row_groups, const float* gate
   MLIIS_REQUIRE(N > 0 && C > 0 && R > 0 && R <= kMaxR && HW > 0, MLIIS_ERR_ARG, "se_mlp_bwd: bad shape");
   MLIIS_REQUIRE(C <= 8192, MLIIS_ERR_UNSUPPORTED, "se_mlp_bwd: C > 8192");
   hipLaunchKernelGGL(se_mlp_bwd_k, dim3(N), dim3(kSeThreads), (size_t)C * sizeof(float), stream, dgate, dgate_row_groups, HW, gate, hpre, w1, w2,
-                     dpre2, dpre1, chan_add, C, R, 1.0f / (float)HW);
+                     dpre2, dpre1, chan_add, C, R, 1.0f / (float)HW, nullptr, 0, nullptr);
   MLIIS_CHECK_LAUNCH("se_mlp_bwd");
   if (dw1 == nullptr) return MLIIS_OK;
   int total = 2 * C * R + C + R;
   hipLaunchKernelGGL(se_wgrad_k, dim3(ceil_div(total, 256)), dim3(256), 0, stream, s, hpre, dpre1, dpre2, dw1, db1, dw2, db2, N, C, R);
   MLIIS_CHECK_LAUNCH("se_wgrad");
+  return MLIIS_OK;
+}
+
+// The squeeze-excite backward fed by mliis_se_bn_bwd_sums (sums [N][sums_nblk][5][C]): the gate's gradient is folded from value 0, and
+// stage 1 of the depthwise batch norm's backward leaves as stage1 [N][2][C] for mliis_bn_bwd(chan_scale = gate, chan_add,
+// stage1_part = stage1, stage1_nblk = N).  The weight gradients are left to mliis_se_wgrad_batched.
+int mliis_se_mlp_bwd_bn(const float* sums, int sums_nblk, const float* gate, const float* hpre, const float* w1, const float* w2,
+                        float* dpre1, float* dpre2, float* chan_add, float* stage1, int N, int C, int R, int HW, hipStream_t stream) {
+  MLIIS_REQUIRE(sums && sums_nblk > 0 && gate && hpre && w1 && w2 && dpre1 && dpre2 && chan_add && stage1, MLIIS_ERR_ARG, "se_mlp_bwd_bn: null pointer");
+  MLIIS_REQUIRE(N > 0 && C > 0 && C <= 8192 && R > 0 && R <= kMaxR && HW > 0, MLIIS_ERR_ARG, "se_mlp_bwd_bn: bad shape (R <= %d, C <= 8192)", kMaxR);
+  hipLaunchKernelGGL(se_mlp_bwd_k, dim3(N), dim3(kSeThreads), (size_t)5 * C * sizeof(float), stream, nullptr, 0, HW, gate, hpre, w1, w2, dpre2,
+                     dpre1, chan_add, C, R, 1.0f / (float)HW, sums, sums_nblk, stage1);
+  MLIIS_CHECK_LAUNCH("se_mlp_bwd_bn");
   return MLIIS_OK;
 }
 

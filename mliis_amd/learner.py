@@ -143,6 +143,10 @@ class _Plan:
                 need2 = max(need2, lib.raw("mliis_dwconv_bn_fwd_blocks")(N, b.h_in, b.h_in, b.cexp, b.k, b.stride) * 2 * b.cexp,
                             lib.raw("mliis_dwconv_bn_bwd_blocks")(N, b.h_in, b.h_in, b.cexp, b.k, b.stride) * 2 * b.cexp)
         self.stats_part2 = buf(need2 + 64)
+        # the squeeze-excite backward and the depthwise batch norm's backward share ONE pass over (da2, z1) (ops.se_bn_bwd_sums): its
+        # per-image chunk sums, and the batch norm's stage-1 sums per image that ops.se_mlp_bwd_bn forms from them
+        self.sums_part = buf(max([ops.se_bn_bwd_sums_floats(N, b.h_out * b.h_out, b.cexp) for b in a.blocks if b.executed] + [0]) + 64)
+        self.stage1_se = buf(max([2 * N * b.cexp for b in a.blocks if b.executed] + [0]) + 64)
         # squeeze-excite pooling partials of the bn1 apply pass: [N][ceil(rows_per_img / 128)][C]
         self.pool_part = buf(max(N * (-(-(b.h_out * b.h_out) // 128)) * b.cexp for b in a.blocks if b.executed) + 64)
         # gate-gradient partials of the project backward-data launch on the small maps: [16-row groups][2][C]
@@ -288,6 +292,9 @@ class Learner:
         # small-map blocks through the one-launch-per-direction kernels of mbconv_small.hip (MLIIS_SMALL_FUSED=0: op by op, for A/B runs)
         self.small_fused = (os.environ.get("MLIIS_SMALL_FUSED", "1") != "0") if small_fused is None else bool(small_fused)
         self.dw_march = os.environ.get("MLIIS_DW_MARCH", "1") != "0"
+        # gate gradient + depthwise-BN backward sums from one pass over (da2, z1) (MLIIS_SE_BN_SUMS=0: column sum + the batch norm's own
+        # reduce pass, for A/B runs)
+        self.se_bn_sums = os.environ.get("MLIIS_SE_BN_SUMS", "1") != "0"
         self.use_graph = use_graph
         self.stream = torch.cuda.Stream(device=self.device)
         # Optional (overlap_wgrad = 1 | 2): weight-gradient GEMMs on a second stream forked inside the HIP graph, one by one (1) or
@@ -1027,11 +1034,21 @@ class Learner:
                 _, groups = self._conv_bwd_data(dout, w[nm["w_proj"]], 1, out=da2, ws=ws, gate=B["a1"], part=P.gate_part)
             else:
                 self._conv_bwd_data(dout, w[nm["w_proj"]], 1, out=da2, ws=ws)
-            if not groups:
-                ops.colsum(da2, B["a1"], nseg=N, out=B["dgate"], ws=ws)
-            # (the SE weight gradients of all blocks are computed by one batched launch after the loop: P.se_desc)
-            ops.se_mlp_bwd(P.gate_part if groups else B["dgate"], B["gate"], B["s"], B["hpre"], w[se[0]], w[se[2]], hw,
-                           dict(dpre1=B["dpre1"], dpre2=B["dpre2"], chan_add=B["chan_add"]), dgate_groups=groups)
+            se_outs = dict(dpre1=B["dpre1"], dpre2=B["dpre2"], chan_add=B["chan_add"])
+            bn1_stage1 = None
+            if not groups and not B["small"] and self.se_bn_sums:
+                # ONE pass over (da2, z1): the gate's gradient and everything bn1's backward needs from the two tensors; the SE kernel
+                # folds it and emits bn1's stage-1 sums per image -- no column-sum launch, no reduce pass of the batch norm
+                st1, p1 = B["st1"], nm["bn1"]
+                nbs = ops.se_bn_bwd_sums(B["z1"], da2, st1[0], st1[1], w[p1 + "/gamma"], w[p1 + "/beta"], P.sums_part)
+                ops.se_mlp_bwd_bn(P.sums_part, nbs, B["gate"], B["hpre"], w[se[0]], w[se[2]], hw, se_outs, P.stage1_se)
+                bn1_stage1 = (P.stage1_se, N)
+            else:
+                if not groups:
+                    ops.colsum(da2, B["a1"], nseg=N, out=B["dgate"], ws=ws)
+                # (the SE weight gradients of all blocks are computed by one batched launch after the loop: P.se_desc)
+                ops.se_mlp_bwd(P.gate_part if groups else B["dgate"], B["gate"], B["s"], B["hpre"], w[se[0]], w[se[2]], hw, se_outs,
+                               dgate_groups=groups)
             if B["small"]:   # bn1 backward, depthwise filter gradient + backward-data, bn0 backward: one launch
                 da0, st0, st1, p0, p1 = B["da0"], B["st0"], B["st1"], nm["bn0"], nm["bn1"]
                 ops.mbconv_dw_bwd_small(da2, B["gate"], B["chan_add"], B["z1"], (st1[0], st1[1], w[p1 + "/gamma"], w[p1 + "/beta"]),
@@ -1042,7 +1059,7 @@ class Learner:
                 if bi > 0:
                     has_grad[bi - 1] = True
                 continue
-            bn_b(B["z1"], da2, B["st1"], nm["bn1"], da2, post=True, chan_scale=B["gate"], chan_add=B["chan_add"])
+            bn_b(B["z1"], da2, B["st1"], nm["bn1"], da2, post=True, chan_scale=B["gate"], chan_add=B["chan_add"], stage1=bn1_stage1)
             if B["march"]:
                 # ONE pass over (dz1, z0): depthwise backward-data, filter-gradient slabs and stage 1 of bn0's backward
                 wdw, slabs = w[nm["w_dw"]], P.fold_part[nm["w_dw"]]

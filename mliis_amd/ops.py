@@ -595,6 +595,32 @@ def se_mlp_bwd(dgate, gate, s, hpre, w1, w2, hw, outs=None, dgate_groups=0):
     return outs
 
 
+def se_bn_bwd_sums(z1, da2, mean, rstd, gamma, beta, part):
+    """ONE pass over (da2, z1) for the squeeze-excite backward and the depthwise batch norm's backward: part [N][nblk][5][C];
+    returns nblk (feed part + nblk to se_mlp_bwd_bn)."""
+    N = z1.shape[0]
+    rows, C_, ldx = rows_ld(z1)
+    _, _, ldd = rows_ld(da2)
+    nb = C.c_int(0)
+    lib.call("mliis_se_bn_bwd_sums", _ptr(_chk(z1)), ldx, _ptr(_chk(da2)), ldd, N, rows // N, C_, _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta),
+             _ptr(part), part.numel(), C.byref(nb), _stream())
+    return nb.value
+
+
+def se_bn_bwd_sums_floats(N, rows_per_img, C_):
+    return lib.size("mliis_se_bn_bwd_sums_floats", N, rows_per_img, C_)
+
+
+def se_mlp_bwd_bn(sums, nblk, gate, hpre, w1, w2, hw, outs, stage1):
+    """se_mlp_bwd fed by se_bn_bwd_sums; also leaves stage 1 of the depthwise batch norm's backward in stage1 [N][2][C] (pass
+    (stage1, N) to bn_bwd(stage1=...) together with chan_scale = gate and chan_add)."""
+    N, C_ = gate.shape
+    R = hpre.shape[1]
+    lib.call("mliis_se_mlp_bwd_bn", _ptr(sums), int(nblk), _ptr(gate), _ptr(hpre), _ptr(w1), _ptr(w2), _ptr(outs["dpre1"]), _ptr(outs["dpre2"]),
+             _ptr(outs["chan_add"]), _ptr(stage1), N, C_, R, hw, _stream())
+    return outs
+
+
 def chan_affine(x, S=None, A=None, out=None, accumulate=False, rows_per_img=None, like=None):
     ref = x if x is not None else (out if out is not None else like)
     rows, C_, _ = rows_ld(ref)

@@ -288,6 +288,59 @@ def test_se(C, Rr, N, HW):
     close(dx, gx, 1e-4, "se dx")
 
 
+@pytest.mark.parametrize("C,Rr,N,HW", [(40, 10, 3, 196), (144, 6, 8, 3136), (24, 6, 2, 784), (96, 4, 8, 300), (32, 8, 2, 12544)])
+def test_se_and_bn_backward_share_one_pass(C, Rr, N, HW):
+    """mliis_se_bn_bwd_sums + mliis_se_mlp_bwd_bn + mliis_bn_bwd(stage1 = per-image sums, chan_scale, chan_add): the backward of
+    z1 -> BN -> swish -> squeeze-excite -> (a1 * gate) (efficientnet_model.py:238-251,271) with ONE reduce pass over (da2, z1), against
+    autograd in float64: the batch norm's input gradient and parameter gradients, the SE weight gradients, and against the
+    separate column-sum + reduce-pass path on the device."""
+    from mliis_amd import ops
+    d = dev()
+    z = (rnd(N, HW, 1, C, seed=70) * 1.3 + 0.4).requires_grad_(True)
+    gamma, beta = (rnd(C, seed=71) * 0.3 + 1).requires_grad_(True), rnd(C, seed=72).requires_grad_(True)
+    w1, b1 = rnd(1, 1, C, Rr, seed=73, scale=0.3).requires_grad_(True), rnd(Rr, seed=74).requires_grad_(True)
+    w2, b2 = rnd(1, 1, Rr, C, seed=75, scale=0.3).requires_grad_(True), rnd(C, seed=76).requires_grad_(True)
+    mean = z.mean(dim=(0, 1, 2))
+    var = z.var(dim=(0, 1, 2), unbiased=False)
+    rstd = 1.0 / torch.sqrt(var + 1e-3)
+    a1 = R.swish((z - mean) * rstd * gamma + beta)
+    sp = a1.mean(dim=(1, 2))
+    hpre = sp @ w1[0, 0] + b1
+    gate = torch.sigmoid(R.swish(hpre) @ w2[0, 0] + b2)
+    y = a1 * gate[:, None, None, :]
+    dy = rnd(*y.shape, seed=77)
+    gz, gga, gbe, gw1, gb1, gw2, gb2 = torch.autograd.grad(y, [z, gamma, beta, w1, b1, w2, b2], dy)
+    zg, dyg = f32(z, d), f32(dy, d)
+    mg, rg, gg, bg = f32(mean, d), f32(rstd, d), f32(gamma, d), f32(beta, d)
+    gateg, hpg, spg = f32(gate, d), f32(hpre, d), f32(sp, d)
+    w1g, w2g = f32(w1, d), f32(w2, d)
+    part = torch.full((ops.se_bn_bwd_sums_floats(N, HW, C) + 8,), 7.0, device=d)
+    nb = ops.se_bn_bwd_sums(zg, dyg, mg, rg, gg, bg, part)
+    assert nb > 0 and N * nb * 5 * C == part.numel() - 8 and (part[-8:] == 7.0).all()
+    outs = dict(dpre1=torch.empty(N, Rr, device=d), dpre2=torch.empty(N, C, device=d), chan_add=torch.empty(N, C, device=d))
+    stage1 = torch.empty(N, 2, C, device=d)
+    ops.se_mlp_bwd_bn(part, nb, gateg, hpg, w1g, w2g, HW, outs, stage1)
+    dz = torch.empty_like(zg)
+    dga, dbe = torch.empty(C, device=d), torch.empty(C, device=d)
+    ops.bn_bwd(zg, dyg, mg, rg, gg, bg, post_swish=True, chan_scale=gateg, chan_add=outs["chan_add"], dx=dz, dgamma=dga, dbeta=dbe,
+               stage1=(stage1, N))
+    close(dz, gz, 1e-4, "dz1 (one-pass sums)")
+    close(dga, gga, 1e-4, "dgamma1")
+    close(dbe, gbe, 1e-4, "dbeta1")
+    # the SE weight gradients from the kernel's dpre1 / dpre2
+    close(spg.t() @ outs["dpre1"], gw1[0, 0], 1e-4, "se dw1")
+    close(outs["dpre1"].sum(0), gb1, 1e-4, "se db1")
+    close(f32(R.swish(hpre), d).t() @ outs["dpre2"], gw2[0, 0], 1e-4, "se dw2")
+    close(outs["dpre2"].sum(0), gb2, 1e-4, "se db2")
+    # the separate path on the device: column sum of da2 * a1, SE backward, the batch norm's own reduce pass
+    a1g = f32(a1, d)
+    o2 = ops.se_mlp_bwd(ops.colsum(dyg, a1g, nseg=N), gateg, spg, hpg, w1g, w2g, HW)
+    close(outs["chan_add"], o2["chan_add"].double().cpu(), 2e-5, "chan_add vs the column-sum path")
+    dz2, dga2, dbe2 = ops.bn_bwd(zg, dyg, mg, rg, gg, bg, post_swish=True, chan_scale=gateg, chan_add=o2["chan_add"])
+    close(dz, dz2.double().cpu(), 2e-5, "dz1 vs the reduce-pass path")
+    close(dga, dga2.double().cpu(), 2e-5, "dgamma1 vs the reduce-pass path")
+
+
 @pytest.mark.parametrize("C,Rr,N,HW", [(40, 10, 3, 196), (672, 28, 2, 49), (24, 6, 2, 784), (144, 6, 8, 300)])
 def test_bn_apply_pools_for_squeeze_excite(C, Rr, N, HW):
     """bn_apply_fused(pool_part=...) leaves per-image partial sums of its output; se_mlp_fwd(chunks, scale) folds them: the pooled
