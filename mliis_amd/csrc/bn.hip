@@ -262,7 +262,9 @@ __global__ __launch_bounds__(256) void bn_apply_fused_k(const float* __restrict_
   }
   const float4 g = ld4(gamma + c), b = ld4(beta + c);   // (before the fold: they do not depend on it)
   double s, ss;
-  fold32(f.part, f.nblk, C, c0, smd, s, ss);
+  // (16 partial blocks per lane and round trip when a producer left many: one round per 512 instead of per 256)
+  if (f.nblk > 256) fold32<16>(f.part, f.nblk, C, c0, smd, s, ss);
+  else fold32<8>(f.part, f.nblk, C, c0, smd, s, ss);
   if (t < 32) {
     double m = s * f.inv_n;
     double var = ss * f.inv_n - m * m;
@@ -460,7 +462,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fused_k(BnBwdCommon<SE> p, l
   }
   const typename BnBwdCommon<SE>::Ctx kc = p.ctx(c);
   double s, sx;
-  fold32(part, nblk, p.C, c0, smd, s, sx);
+  if (nblk > 256) fold32<16>(part, nblk, p.C, c0, smd, s, sx);
+  else fold32<8>(part, nblk, p.C, c0, smd, s, sx);
   if (t < 32) {
     s_c1[t] = (float)(s * inv_n);
     s_c2[t] = (float)(sx * inv_n);

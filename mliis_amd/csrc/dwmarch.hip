@@ -735,7 +735,7 @@ static inline int dwm_target(bool bwd) {
     g_dwm_target = e ? atoi(e) : 0;
     if (g_dwm_target < 0) g_dwm_target = 0;
   }
-  return g_dwm_target ? g_dwm_target : (bwd ? 256 : 512);
+  return g_dwm_target ? g_dwm_target : 256;   // (forward: 256 and 512 time the same; 256 leaves the next batch norm half the partial blocks)
 }
 
 // produced extent P x Q (rows x columns); unit = produced rows per step; bmax = produced columns of a band (multiple of ts)
