@@ -103,3 +103,33 @@ def test_checkpoint_directory_with_bundles(tmp_path):
     assert np.array_equal(back["a/kernel"], vals["a/kernel"] + 3)
     with pytest.raises(ValueError):
         ckpt.Saver(fmt="hdf5")
+
+
+def test_bundle_written_by_an_independent_writer_reads_back(tmp_path):
+    """tests/independent_bundle.py shares no code with mliis_amd.tfbundle (own CRC-32C, no prefix compression, a restart point per
+    entry, small data blocks -> a multi-entry index block, explicit zero-valued proto fields): the product READER must restore its
+    files, dtype / shape / values and checksums."""
+    from tests.independent_bundle import write_bundle_independent, _crc32c
+    assert _crc32c(b"123456789") == 0xE3069283 == crc32c(b"123456789")
+    rng = np.random.default_rng(3)
+    tensors = {"efficientnet-b0/stem/conv2d/kernel": rng.standard_normal((3, 3, 3, 32)).astype(np.float32),
+               "efficientnet-b0/stem/tpu_batch_normalization/gamma": rng.random(32).astype(np.float32),
+               "decode/final_layer_weights/bias": np.array([0.5, -0.25], np.float32), "global_step": np.array(77, dtype=np.int64),
+               "adam_step": np.array(200000, dtype=np.int64), "beta2_power": np.array(0.0, dtype=np.float32),
+               "wide": rng.standard_normal((5, 700)).astype(np.float64), "ints": np.arange(12, dtype=np.int32).reshape(3, 4)}
+    for epb in (1, 3, 100):
+        prefix = str(tmp_path / ("model.ckpt-%d" % epb))
+        write_bundle_independent(prefix, tensors, entries_per_block=epb)
+        assert tb.is_bundle(prefix)
+        back = tb.read_bundle(prefix)
+        assert set(back) == set(tensors)
+        for k, v in tensors.items():
+            assert back[k].dtype == v.dtype and back[k].shape == v.shape and np.array_equal(back[k], v), (epb, k)
+        assert tb.list_bundle(prefix)["global_step"]["shape"] == ()
+    # and a flipped payload bit is caught through the independent writer's checksum
+    d = prefix + ".data-00000-of-00001"
+    raw = bytearray(open(d, "rb").read())
+    raw[3] ^= 2
+    open(d, "wb").write(raw)
+    with pytest.raises(ValueError, match="checksum"):
+        tb.read_bundle(prefix)
