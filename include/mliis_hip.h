@@ -243,6 +243,21 @@ int mliis_bn_apply_fused(const float* x, int ldx, float* y, int ldy, long long r
  *      its own.  dxsum_part (nullable): per-row-chunk column sums of dx, [chunks][C] with chunks * C = mliis_bn_bwd_dxsum_floats(rows, C) --
  *      slabs for mliis_fold_batched: the bias gradient of a conv -> swish -> BN stack (efficientlab.py:185-190) without a pass of
  *      its own. */
+/*      Two batch norms of the same shape, flags and leading dimensions in ONE launch each -- the 1x1 and the 3x3-dilated branch of an
+ *      RSD module are independent (efficientlab.py:185-197): forward = fold + apply of both (arguments as mliis_bn_apply_fused, per
+ *      problem; no per-image scale, residual or pooling); backward = one reduce launch + one apply launch for both (plain batch norms:
+ *      no per-image vectors, no skip output; dxsum0 / dxsum1 as dxsum_part above, dxsum_floats each; ws = 2 x
+ *      mliis_colreduce_workspace_floats(rows, C, 1, 2) floats). */
+int mliis_bn_apply_fused_pair(const float* x0, float* y0, const float* part0, int nblk0, float* mean0, float* rstd0, float* moving_mean0,
+                              float* moving_var0, const float* gamma0, const float* beta0, const float* x1, float* y1, const float* part1,
+                              int nblk1, float* mean1, float* rstd1, float* moving_mean1, float* moving_var1, const float* gamma1,
+                              const float* beta1, int ldx, int ldy, long long rows, int C, float eps, float momentum,
+                              int unbiased_moving_var, int pre_swish, int post_swish, hipStream_t stream);
+int mliis_bn_bwd_pair(const float* x0, const float* dy0, float* dx0, const float* mean0, const float* rstd0, const float* gamma0,
+                      const float* beta0, float* dgamma0, float* dbeta0, float* dxsum0, const float* x1, const float* dy1, float* dx1,
+                      const float* mean1, const float* rstd1, const float* gamma1, const float* beta1, float* dgamma1, float* dbeta1,
+                      float* dxsum1, int ldx, int lddy, int lddx, long long rows, int C, int pre_swish, int post_swish, size_t dxsum_floats,
+                      float* ws, size_t ws_floats, hipStream_t stream);
 size_t mliis_bn_bwd_dxsum_floats(long long rows, int C);
 int mliis_bn_bwd(const float* x, int ldx, const float* dy, int lddy, float* dx, int lddx, long long rows, int C, int rows_per_img,
                  const float* mean, const float* rstd, const float* gamma, const float* beta, int pre_swish, int post_swish,

@@ -62,6 +62,8 @@ SIGNATURES = {
     "mliis_bn_stats_partial": (_i, [_p, _i, _ll, _i, _i, _p, _sz, _p, _p]),
     "mliis_bn_apply_fused": (_i, [_p, _i, _p, _i, _ll, _i, _i, _p, _i, _f, _f, _i, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _i, _p, _sz, _p, _p]),
     "mliis_bn_bwd": (_i, [_p, _i, _p, _i, _p, _i, _ll, _i, _i, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _i, _i, _p, _sz, _p, _sz, _p, _i, _p]),
+    "mliis_bn_apply_fused_pair": (_i, [_p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _ll, _i, _f, _f, _i, _i, _i, _p]),
+    "mliis_bn_bwd_pair": (_i, [_p] * 20 + [_i, _i, _i, _ll, _i, _i, _i, _sz, _p, _sz, _p]),
     "mliis_bn_bwd_dxsum_floats": (_sz, [_ll, _i]),
     "mliis_colsum": (_i, [_p, _i, _p, _i, _ll, _i, _i, _f, _p, _i, _p, _sz, _p]),
     "mliis_se_mlp_fwd": (_i, [_p, _i, _f, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),

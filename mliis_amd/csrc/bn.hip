@@ -221,12 +221,28 @@ __global__ __launch_bounds__(256) void bn_apply_k(const float* __restrict__ x, i
 // (8 float4 lanes = one 128-byte line per row).  Blocks with blockIdx.y == 0 publish mean / rstd for the backward pass and
 // apply the moving-average update -- so no separate finalize launch exists.
 // ---------------------------------------------------------------------------------------------------------------
+// A second batch norm of the same shape and flags in the same launch (gridDim.z == 2: the two independent branches of an RSD module,
+// models/efficientlab.py:185-197): workgroups with blockIdx.z == 1 take their tensors and parameters from `alt`.
+struct BnApplyAlt {
+  const float* x;
+  float* y;
+  BnFold f;
+  const float* gamma;
+  const float* beta;
+};
 __global__ __launch_bounds__(256) void bn_apply_fused_k(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy,
                                                         long long rows, int C, int rows_per_img, BnFold f,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         int pre_swish, int post_swish, const float* __restrict__ img_scale,
                                                         const float* __restrict__ res, int ldr, int rows_per_block,
-                                                        float* __restrict__ pool_part, int pool_chunks) {
+                                                        float* __restrict__ pool_part, int pool_chunks, BnApplyAlt alt) {
+  if (blockIdx.z == 1) {   // (uniform)
+    x = alt.x;
+    y = alt.y;
+    f = alt.f;
+    gamma = alt.gamma;
+    beta = alt.beta;
+  }
   __shared__ double smd[2 * 32 * 32];
   __shared__ __attribute__((aligned(16))) float s_mean[kChanBlock], s_rstd[kChanBlock];
   const int t = threadIdx.x;
@@ -424,6 +440,23 @@ struct BnBwdOp {
   }
 };
 
+// two plain batch-norm backward reduce passes of the same shape in one launch: segment (blockIdx.z) = problem
+struct BnBwdPairOp {
+  static constexpr int NV = 2;
+  BnBwdCommon<false> p[2];
+  long long rows;
+  typedef BnBwdCommon<false>::Raw Raw;
+  typedef BnBwdCommon<false>::Ctx Ctx;
+  __device__ __forceinline__ Ctx ctx(int c) const { return p[blockIdx.z].ctx(c); }
+  __device__ __forceinline__ void load(int seg, long long row, int c, Raw& r) const { p[seg].load_raw(row - seg * rows, c, r); }
+  __device__ __forceinline__ void eval(const Ctx& k, const Raw& r, float4* o) const {
+    float4 xin, xhat, g;
+    p[blockIdx.z].finish(k, r, xin, xhat, g);
+    o[0] = g;
+    o[1] = f4mul(g, xhat);
+  }
+};
+
 // finalize (fold the two gradient sums of this block's 32 channels) + input-gradient pass in one launch
 // Identity-skip gradient written by the same pass: dskip[r, c] (+)= dy[r, c] (the raw upstream gradient, before any scale).
 struct SkipOut {
@@ -437,11 +470,20 @@ struct SkipOut {
   }
 };
 
+// (second problem of the same shape in the same launch, as BnApplyAlt)
+struct BnBwdAlt {
+  const float *x, *dy, *mean, *rstd, *gamma, *beta, *part;
+  float *dgamma, *dbeta, *dx, *dxsum_part;
+};
 template <bool SE>
 __global__ __launch_bounds__(256) void bn_bwd_apply_fused_k(BnBwdCommon<SE> p, long long rows, const float* __restrict__ part, int nblk,
                                                             double inv_n, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                             float* __restrict__ dx, int lddx, int rows_per_block, SkipOut skip,
-                                                            float* __restrict__ dxsum_part) {
+                                                            float* __restrict__ dxsum_part, BnBwdAlt alt) {
+  if (blockIdx.z == 1) {   // (uniform)
+    p.x = alt.x; p.dy = alt.dy; p.mean = alt.mean; p.rstd = alt.rstd; p.gamma = alt.gamma; p.beta = alt.beta;
+    part = alt.part; dgamma = alt.dgamma; dbeta = alt.dbeta; dx = alt.dx; dxsum_part = alt.dxsum_part;
+  }
   __shared__ double smd[2 * 32 * 32];
   __shared__ __attribute__((aligned(16))) float s_c1[kChanBlock], s_c2[kChanBlock];
   const int t = threadIdx.x;
@@ -843,11 +885,11 @@ int mliis_bn_bwd(const float* x, int ldx, const float* dy, int lddy, float* dx, 
     if (img_scale != nullptr || chan_scale != nullptr || chan_add != nullptr) {
       BnBwdCommon<true> p{x, ldx, dy, lddy, rows_per_img, C, mean, rstd, gamma, beta, pre_swish, post_swish, img_scale, chan_scale, chan_add};
       hipLaunchKernelGGL(bn_bwd_apply_fused_k<true>, dim3(gx, gy), dim3(256), 0, stream, p, rows, stage1_part, stage1_nblk, 1.0 / (double)rows,
-                         dgamma, dbeta, dx, lddx, rpb, skip, dxsum_part);
+                         dgamma, dbeta, dx, lddx, rpb, skip, dxsum_part, BnBwdAlt{});
     } else {
       BnBwdCommon<false> p{x, ldx, dy, lddy, rows_per_img, C, mean, rstd, gamma, beta, pre_swish, post_swish, nullptr, nullptr, nullptr};
       hipLaunchKernelGGL(bn_bwd_apply_fused_k<false>, dim3(gx, gy), dim3(256), 0, stream, p, rows, stage1_part, stage1_nblk, 1.0 / (double)rows,
-                         dgamma, dbeta, dx, lddx, rpb, skip, dxsum_part);
+                         dgamma, dbeta, dx, lddx, rpb, skip, dxsum_part, BnBwdAlt{});
     }
     MLIIS_CHECK_LAUNCH("bn_bwd_apply_fused");
     return MLIIS_OK;
@@ -857,13 +899,13 @@ int mliis_bn_bwd(const float* x, int ldx, const float* dy, int lddy, float* dx, 
     rc = launch_colreduce(BnBwdOp<true>{p}, rows, C, 1, ws, ws_floats, stream, &g, "bn_bwd", target);
     if (rc) return rc;
     hipLaunchKernelGGL(bn_bwd_apply_fused_k<true>, dim3(gx, gy), dim3(256), 0, stream, p, rows, ws, g.nblk, 1.0 / (double)rows, dgamma, dbeta,
-                       dx, lddx, rpb, skip, dxsum_part);
+                       dx, lddx, rpb, skip, dxsum_part, BnBwdAlt{});
   } else {
     BnBwdCommon<false> p{x, ldx, dy, lddy, rows_per_img, C, mean, rstd, gamma, beta, pre_swish, post_swish, nullptr, nullptr, nullptr};
     rc = launch_colreduce(BnBwdOp<false>{p}, rows, C, 1, ws, ws_floats, stream, &g, "bn_bwd", target);
     if (rc) return rc;
     hipLaunchKernelGGL(bn_bwd_apply_fused_k<false>, dim3(gx, gy), dim3(256), 0, stream, p, rows, ws, g.nblk, 1.0 / (double)rows, dgamma, dbeta,
-                       dx, lddx, rpb, skip, dxsum_part);
+                       dx, lddx, rpb, skip, dxsum_part, BnBwdAlt{});
   }
   MLIIS_CHECK_LAUNCH("bn_bwd_apply_fused");
   return MLIIS_OK;
@@ -952,8 +994,79 @@ int mliis_bn_apply_fused(const float* x, int ldx, float* y, int ldy, long long r
     *pool_chunks = cpi;
   }
   hipLaunchKernelGGL(bn_apply_fused_k, dim3(gx, gy), dim3(256), 0, stream, x, ldx, y, ldy, rows, C, rows_per_img, f, gamma, beta, pre_swish,
-                     post_swish, img_scale, res, ldr, rpb, pool_part, cpi);
+                     post_swish, img_scale, res, ldr, rpb, pool_part, cpi, BnApplyAlt{});
   MLIIS_CHECK_LAUNCH("bn_apply_fused");
+  return MLIIS_OK;
+}
+
+// Two batch norms of the same shape, flags and leading dimensions in ONE launch (the 1x1 and the 3x3-dilated branch of an RSD module
+// are independent: efficientlab.py:185-197).  Arguments as mliis_bn_apply_fused, per problem.
+int mliis_bn_apply_fused_pair(const float* x0, float* y0, const float* part0, int nblk0, float* mean0, float* rstd0, float* moving_mean0,
+                              float* moving_var0, const float* gamma0, const float* beta0, const float* x1, float* y1, const float* part1,
+                              int nblk1, float* mean1, float* rstd1, float* moving_mean1, float* moving_var1, const float* gamma1,
+                              const float* beta1, int ldx, int ldy, long long rows, int C, float eps, float momentum,
+                              int unbiased_moving_var, int pre_swish, int post_swish, hipStream_t stream) {
+  MLIIS_REQUIRE(x0 && y0 && part0 && mean0 && rstd0 && gamma0 && beta0 && x1 && y1 && part1 && mean1 && rstd1 && gamma1 && beta1, MLIIS_ERR_ARG,
+                "bn_apply_fused_pair: null pointer");
+  MLIIS_REQUIRE(rows > 1 && rows < (1LL << 31) && nblk0 > 0 && nblk1 > 0 && C > 0 && (C & 3) == 0 && (ldx & 3) == 0 && (ldy & 3) == 0 && ldx >= C &&
+                    ldy >= C,
+                MLIIS_ERR_ARG, "bn_apply_fused_pair: bad shape");
+  MLIIS_REQUIRE(aligned16(x0) && aligned16(y0) && aligned16(gamma0) && aligned16(beta0) && aligned16(x1) && aligned16(y1) && aligned16(gamma1) &&
+                    aligned16(beta1) && aligned16(part0) && aligned16(part1),
+                MLIIS_ERR_ALIGN, "bn_apply_fused_pair: pointers must be 16-byte aligned");
+  MLIIS_REQUIRE((moving_mean0 == nullptr) == (moving_var0 == nullptr) && (moving_mean1 == nullptr) == (moving_var1 == nullptr), MLIIS_ERR_ARG,
+                "bn_apply_fused_pair: moving stats must come as a pair");
+  const double n = (double)rows;
+  const float omm = (float)(1.0 - (double)momentum), evf = unbiased_moving_var ? (float)(n / (n - 1.0)) : 1.0f;
+  BnFold f0{part0, nblk0, 1.0 / n, eps, omm, evf, mean0, rstd0, moving_mean0, moving_var0};
+  BnFold f1{part1, nblk1, 1.0 / n, eps, omm, evf, mean1, rstd1, moving_mean1, moving_var1};
+  int gx, gy, rpb;
+  chan_grid(rows, C, &gx, &gy, &rpb);
+  if ((nblk0 > nblk1 ? nblk0 : nblk1) >= kManyPartials) {
+    const ColGeom g2 = col_geom(rows, C, 1, 512);
+    gx = g2.gx;
+    gy = g2.nblk;
+    rpb = g2.rows_per_block;
+  }
+  hipLaunchKernelGGL(bn_apply_fused_k, dim3(gx, gy, 2), dim3(256), 0, stream, x0, ldx, y0, ldy, rows, C, (int)rows, f0, gamma0, beta0, pre_swish,
+                     post_swish, nullptr, nullptr, 0, rpb, nullptr, 0, BnApplyAlt{x1, y1, f1, gamma1, beta1});
+  MLIIS_CHECK_LAUNCH("bn_apply_fused_pair");
+  return MLIIS_OK;
+}
+
+// The backward of two such batch norms (no per-image vectors, no skip output): ONE reduce launch and ONE apply launch for both.
+// dxsum0 / dxsum1 (nullable pair): per-row-chunk column sums of dx, as mliis_bn_bwd's dxsum_part.  ws: 2 x
+// mliis_colreduce_workspace_floats(rows, C, 1, 2) floats.
+int mliis_bn_bwd_pair(const float* x0, const float* dy0, float* dx0, const float* mean0, const float* rstd0, const float* gamma0,
+                      const float* beta0, float* dgamma0, float* dbeta0, float* dxsum0, const float* x1, const float* dy1, float* dx1,
+                      const float* mean1, const float* rstd1, const float* gamma1, const float* beta1, float* dgamma1, float* dbeta1,
+                      float* dxsum1, int ldx, int lddy, int lddx, long long rows, int C, int pre_swish, int post_swish, size_t dxsum_floats,
+                      float* ws, size_t ws_floats, hipStream_t stream) {
+  MLIIS_REQUIRE(x0 && dy0 && dx0 && mean0 && rstd0 && gamma0 && beta0 && dgamma0 && dbeta0 && x1 && dy1 && dx1 && mean1 && rstd1 && gamma1 && beta1 &&
+                    dgamma1 && dbeta1 && ws,
+                MLIIS_ERR_ARG, "bn_bwd_pair: null pointer");
+  MLIIS_REQUIRE(rows > 1 && rows < (1LL << 30) && C > 0 && (C & 3) == 0 && (ldx & 3) == 0 && (lddy & 3) == 0 && (lddx & 3) == 0 && ldx >= C &&
+                    lddy >= C && lddx >= C && (dxsum0 == nullptr) == (dxsum1 == nullptr),
+                MLIIS_ERR_ARG, "bn_bwd_pair: bad shape");
+  MLIIS_REQUIRE(aligned16(x0) && aligned16(dy0) && aligned16(dx0) && aligned16(x1) && aligned16(dy1) && aligned16(dx1) && aligned16(ws) &&
+                    aligned16(mean0) && aligned16(rstd0) && aligned16(gamma0) && aligned16(beta0) && aligned16(mean1) && aligned16(rstd1) &&
+                    aligned16(gamma1) && aligned16(beta1) && aligned16(dgamma0) && aligned16(dbeta0) && aligned16(dgamma1) && aligned16(dbeta1) &&
+                    aligned16(dxsum0) && aligned16(dxsum1),
+                MLIIS_ERR_ALIGN, "bn_bwd_pair: pointers must be 16-byte aligned");
+  int gx, gy, rpb;
+  bn_bwd_grid(rows, C, &gx, &gy, &rpb);
+  MLIIS_REQUIRE(dxsum0 == nullptr || (size_t)gy * C <= dxsum_floats, MLIIS_ERR_WORKSPACE, "bn_bwd_pair: column-sum buffers too small (%zu floats each)",
+                (size_t)gy * C);
+  BnBwdCommon<false> p0{x0, ldx, dy0, lddy, (int)rows, C, mean0, rstd0, gamma0, beta0, pre_swish, post_swish, nullptr, nullptr, nullptr};
+  BnBwdCommon<false> p1{x1, ldx, dy1, lddy, (int)rows, C, mean1, rstd1, gamma1, beta1, pre_swish, post_swish, nullptr, nullptr, nullptr};
+  ColGeom g;
+  int rc = launch_colreduce(BnBwdPairOp{{p0, p1}, rows}, rows, C, 2, ws, ws_floats, stream, &g, "bn_bwd_pair", bn_bwd_target(rows, C));
+  if (rc) return rc;
+  const float* part1 = ws + (size_t)g.nblk * 2 * C;   // part layout [seg][blk][2][C]
+  hipLaunchKernelGGL(bn_bwd_apply_fused_k<false>, dim3(gx, gy, 2), dim3(256), 0, stream, p0, rows, ws, g.nblk, 1.0 / (double)rows, dgamma0, dbeta0,
+                     dx0, lddx, rpb, SkipOut{nullptr, 0, 0}, dxsum0,
+                     BnBwdAlt{x1, dy1, mean1, rstd1, gamma1, beta1, part1, dgamma1, dbeta1, dx1, dxsum1});
+  MLIIS_CHECK_LAUNCH("bn_bwd_pair");
   return MLIIS_OK;
 }
 

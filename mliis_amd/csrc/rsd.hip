@@ -99,72 +99,73 @@ __global__ __launch_bounds__(kRsdThreads) void rsd_border_sums_k(const float* __
   }
 }
 
-// G[n][tap][co] = Tot - excluded row - excluded column + corner      (one thread per element)
-__global__ __launch_bounds__(256) void rsd_gsum_k(const float* __restrict__ dz, int ld, const float* __restrict__ tot,
-                                                  const float* __restrict__ B, float* __restrict__ G, int N, int H, int W, int Co) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= N * 9 * Co) return;
-  const int co = i % Co, tap = (i / Co) % 9, n = i / (9 * Co);
-  const int ty = tap / 3, tx = tap - ty * 3;
-  const float* d = dz + (long long)n * H * W * ld;
-  const float* Bn = B + (long long)n * 4 * Co;
-  const float rex = ty == 0 ? Bn[0 * Co + co] : (ty == 2 ? Bn[1 * Co + co] : 0.f);
-  const float cex = tx == 0 ? Bn[2 * Co + co] : (tx == 2 ? Bn[3 * Co + co] : 0.f);
-  float cor = 0.f;
-  if (ty != 1 && tx != 1) {
+// G[n][tap][co] = Tot - excluded row - excluded column + corner: the sum of dZ over the pixels where tap (ty, tx) of the 3x3 window
+// falls inside the image.  Evaluated where it is used (four loads), not stored: one launch and one round trip fewer.
+struct RsdG {
+  const float* dz;   // [N,H,W,ld]
+  int ld;
+  const float* tot;  // [N][Co]
+  const float* B;    // [N][4][Co]: first row, last row, first column, last column
+  int H, W, Co;
+  __device__ __forceinline__ float at(int n, int tap, int co) const {
+    const int ty = tap / 3, tx = tap - ty * 3;
+    const float* Bn = B + (long long)n * 4 * Co;
+    // (all four loads issued; the excluded ones weighted by zero -- no dependent branches around memory)
+    const float r0 = Bn[(ty == 2 ? 1 : 0) * Co + co], c0 = Bn[(tx == 2 ? 3 : 2) * Co + co];
     const long long py = ty == 0 ? 0 : H - 1, px = tx == 0 ? 0 : W - 1;
-    cor = d[(py * W + px) * ld + co];
+    const float cr = dz[(((long long)n * H + py) * W + px) * ld + co];
+    const float t = tot[(long long)n * Co + co];
+    return t - (ty != 1 ? r0 : 0.f) - (tx != 1 ? c0 : 0.f) + ((ty != 1 && tx != 1) ? cr : 0.f);
   }
-  G[i] = tot[(long long)n * Co + co] - rex - cex + cor;
-}
+};
 
-// weight-gradient rows of the constant channels (one thread per element) and the bias gradient
-__global__ __launch_bounds__(256) void rsd_pool_dw_k(const float* __restrict__ G, const float* __restrict__ tot,
-                                                     const float* __restrict__ pool, float* __restrict__ dw, float* __restrict__ dbias,
-                                                     int N, int Cp, int Cin_total, int c_begin, int Co) {
-  const long long nW = 9LL * Cp * Co;
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i < nW) {
-    const int co = (int)(i % Co);
-    const long long r = i / Co;
-    const int c = (int)(r % Cp), tap = (int)(r / Cp);
-    float a = 0.f;
-    for (int n0 = 0; n0 < N; n0 += 8) {   // all loads of eight images first
-      float pv[8], gv[8];
+// ONE launch for the two independent consumers of G: workgroups [0, dw_blocks) = the weight-gradient rows of the constant channels
+// (one thread per element) and the bias gradient; the rest = dpool[n][c] = inv_hw * sum_tap sum_co G[n][tap][co] * W[tap][c_begin+c][co]
+// (one wave per (n, c)).
+__global__ __launch_bounds__(256) void rsd_pool_bwd_k(RsdG g, const float* __restrict__ pool, const float* __restrict__ w,
+                                                      float* __restrict__ dw, float* __restrict__ dbias, float* __restrict__ dpool, int N,
+                                                      int Cp, int Cin_total, int c_begin, int Co, float inv_hw, int dw_blocks) {
+  if ((int)blockIdx.x < dw_blocks) {
+    const long long nW = 9LL * Cp * Co;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < nW) {
+      const int co = (int)(i % Co);
+      const long long r = i / Co;
+      const int c = (int)(r % Cp), tap = (int)(r / Cp);
+      float a = 0.f;
+      for (int n0 = 0; n0 < N; n0 += 8) {   // all loads of eight images first
+        float pv[8], gv[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int n = n0 + u < N ? n0 + u : N - 1;
-        pv[u] = pool[(long long)n * Cp + c];
-        gv[u] = G[((long long)n * 9 + tap) * Co + co];
+        for (int u = 0; u < 8; ++u) {
+          const int n = n0 + u < N ? n0 + u : N - 1;
+          pv[u] = pool[(long long)n * Cp + c];
+          gv[u] = g.at(n, tap, co);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a = fmaf(n0 + u < N ? pv[u] : 0.f, gv[u], a);
       }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) a = fmaf(n0 + u < N ? pv[u] : 0.f, gv[u], a);
+      dw[((long long)tap * Cin_total + c_begin + c) * Co + co] = a;
+    } else if (dbias != nullptr && i < nW + Co) {
+      const int co = (int)(i - nW);
+      float a = 0.f;
+      for (int n = 0; n < N; ++n) a += g.tot[(long long)n * Co + co];
+      dbias[co] = a;
     }
-    dw[((long long)tap * Cin_total + c_begin + c) * Co + co] = a;
-  } else if (dbias != nullptr && i < nW + Co) {
-    const int co = (int)(i - nW);
-    float a = 0.f;
-    for (int n = 0; n < N; ++n) a += tot[(long long)n * Co + co];
-    dbias[co] = a;
+    return;
   }
-}
-
-// dpool[n][c] = inv_hw * sum_tap sum_co G[n][tap][co] * W[tap][c_begin+c][co]      (one wave per (n, c))
-__global__ __launch_bounds__(256) void rsd_pool_dpool_k(const float* __restrict__ G, const float* __restrict__ w, float* __restrict__ dpool,
-                                                        int N, int Cp, int Cin_total, int c_begin, int Co, float inv_hw) {
-  const int wv = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  const int wv = (((int)blockIdx.x - dw_blocks) * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
   if (wv >= N * Cp) return;
   const int c = wv % Cp, n = wv / Cp;
   float a = 0.f;
   for (int co = lane; co < Co; co += 64) {   // the nine taps' loads of a column first (one round trip per 64 columns)
-    float gv[9], wv[9];
+    float gv[9], wt[9];
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
-      wv[tap] = w[((long long)tap * Cin_total + c_begin + c) * Co + co];
-      gv[tap] = G[((long long)n * 9 + tap) * Co + co];
+      wt[tap] = w[((long long)tap * Cin_total + c_begin + c) * Co + co];
+      gv[tap] = g.at(n, tap, co);
     }
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) a = fmaf(gv[tap], wv[tap], a);
+    for (int tap = 0; tap < 9; ++tap) a = fmaf(gv[tap], wt[tap], a);
   }
   a = wave_sum(a);
   if (lane == 0) dpool[wv] = a * inv_hw;
@@ -215,17 +216,13 @@ int mliis_rsd_pool_bwd(const float* dz, int lddz, const float* tot, const float*
   MLIIS_REQUIRE(N > 0 && H >= 2 && W >= 2 && Cp > 0 && Co > 0 && lddz >= Co && c_begin >= 0 && c_begin + Cp <= Cin_total, MLIIS_ERR_ARG,
                 "rsd_pool_bwd: bad shape");
   MLIIS_REQUIRE((size_t)N * 13 * Co <= ws_floats && Co <= 1024, MLIIS_ERR_WORKSPACE, "rsd_pool_bwd: workspace too small");
-  float* G = ws;                          // [N][9][Co]
-  float* B = ws + (size_t)N * 9 * Co;     // [N][4][Co]
+  float* B = ws;     // [N][4][Co] border sums (the per-tap sums G are formed from them where they are used)
   hipLaunchKernelGGL(rsd_border_sums_k, dim3(N, 4), dim3(kRsdThreads), 0, stream, dz, lddz, B, H, W, Co);
   MLIIS_CHECK_LAUNCH("rsd_border_sums");
-  hipLaunchKernelGGL(rsd_gsum_k, dim3(ceil_div((long long)N * 9 * Co, 256)), dim3(256), 0, stream, dz, lddz, tot, B, G, N, H, W, Co);
-  MLIIS_CHECK_LAUNCH("rsd_gsum");
-  hipLaunchKernelGGL(rsd_pool_dw_k, dim3(ceil_div(9LL * Cp * Co + Co, 256)), dim3(256), 0, stream, G, tot, pool, dw, dbias, N, Cp, Cin_total,
-                     c_begin, Co);
-  MLIIS_CHECK_LAUNCH("rsd_pool_dw");
-  hipLaunchKernelGGL(rsd_pool_dpool_k, dim3(ceil_div((long long)N * Cp * 64, 256)), dim3(256), 0, stream, G, w, dpool, N, Cp, Cin_total,
-                     c_begin, Co, 1.0f / ((float)H * (float)W));
+  const int dw_blocks = ceil_div(9LL * Cp * Co + Co, 256), dp_blocks = ceil_div((long long)N * Cp * 64, 256);
+  const RsdG g{dz, lddz, tot, B, H, W, Co};
+  hipLaunchKernelGGL(rsd_pool_bwd_k, dim3(dw_blocks + dp_blocks), dim3(256), 0, stream, g, pool, w, dw, dbias, dpool, N, Cp, Cin_total, c_begin,
+                     Co, 1.0f / ((float)H * (float)W), dw_blocks);
   MLIIS_CHECK_LAUNCH("rsd_pool_bwd");
   return MLIIS_OK;
 }

@@ -142,6 +142,8 @@ class _Plan:
             if b.executed:
                 need2 = max(need2, lib.raw("mliis_dwconv_bn_fwd_blocks")(N, b.h_in, b.h_in, b.cexp, b.k, b.stride) * 2 * b.cexp,
                             lib.raw("mliis_dwconv_bn_bwd_blocks")(N, b.h_in, b.h_in, b.cexp, b.k, b.stride) * 2 * b.cexp)
+        for m in a.rsd:   # (and the second RSD branch GEMM's statistics, folded together with the first's by ops.bn_apply_fused_pair)
+            need2 = max(need2, -(-(N * m.h * m.h) // 16) * 2 * m.c_out, ops.bn_stats_partial_floats(N * m.h * m.h, m.c_out))
         self.stats_part2 = buf(need2 + 64)
         # the squeeze-excite backward and the depthwise batch norm's backward share ONE pass over (da2, z1) (ops.se_bn_bwd_sums): its
         # per-image chunk sums, and the batch norm's stage-1 sums per image that ops.se_mlp_bwd_bn forms from them
@@ -295,6 +297,8 @@ class Learner:
         # gate gradient + depthwise-BN backward sums from one pass over (da2, z1) (MLIIS_SE_BN_SUMS=0: column sum + the batch norm's own
         # reduce pass, for A/B runs)
         self.se_bn_sums = os.environ.get("MLIIS_SE_BN_SUMS", "1") != "0"
+        # the two independent branch batch norms of an RSD module in one launch per pass (MLIIS_RSD_BN_PAIR=0: one by one)
+        self.rsd_bn_pair = os.environ.get("MLIIS_RSD_BN_PAIR", "1") != "0"
         self.use_graph = use_graph
         self.stream = torch.cuda.Stream(device=self.device)
         # Optional (overlap_wgrad = 1 | 2): weight-gradient GEMMs on a second stream forked inside the HIP graph, one by one (1) or
@@ -770,10 +774,23 @@ class Learner:
                 res_up = bn(D["zu"], D["stu"], nu, D["up2"], pre=True, fused=True, nblk=nb)
             pyr = D["pyr"]
             (k0, b0, n0), (k1, b1, n1), (kf, bf, nf) = nm
-            nb = conv(cat, k0, b0, 1, D["z0"], True)
-            bn(D["z0"], D["st0"], n0, pyr[..., :m.c_out], pre=True, fused=True, nblk=nb)
-            nb = conv(cat, k1, b1, 2, D["z1"], True)
-            bn(D["z1"], D["st1"], n1, pyr[..., m.c_out:2 * m.c_out], pre=True, fused=True, nblk=nb)
+            if training and self.rsd_bn_pair:
+                # the 1x1 and the 3x3-dilated branch are independent: both GEMMs first (statistics in two buffers), then ONE launch for
+                # the two conv -> swish -> BN tails
+                nb0 = self._conv_fwd(cat, w[k0], w[b0], 1, out=D["z0"], ws=ws, stats_part=P.stats_part, stats_swish=True, wt=self.wt[k0],
+                                     fp8_w_amax=self._amax_of.get(k0))[1]
+                nb1 = self._conv_fwd(cat, w[k1], w[b1], 2, out=D["z1"], ws=ws, stats_part=P.stats_part2, stats_swish=True, wt=self.wt[k1],
+                                     fp8_w_amax=self._amax_of.get(k1))[1]
+                ops.bn_apply_fused_pair([(D["z" + i], pt, nb_, D["st" + i][0], D["st" + i][1], w[nn + "/gamma"], w[nn + "/beta"],
+                                          (mv[nn + "/moving_mean"], mv[nn + "/moving_variance"]), out_)
+                                         for i, pt, nb_, nn, out_ in (("0", P.stats_part, nb0, n0, pyr[..., :m.c_out]),
+                                                                      ("1", P.stats_part2, nb1, n1, pyr[..., m.c_out:2 * m.c_out]))],
+                                        pre_swish=True, unbiased_moving_var=True)
+            else:
+                nb = conv(cat, k0, b0, 1, D["z0"], True)
+                bn(D["z0"], D["st0"], n0, pyr[..., :m.c_out], pre=True, fused=True, nblk=nb)
+                nb = conv(cat, k1, b1, 2, D["z1"], True)
+                bn(D["z1"], D["st1"], n1, pyr[..., m.c_out:2 * m.c_out], pre=True, fused=True, nblk=nb)
             # pooled branch: per-image mean of `cat`, folded into the fuse conv as a border-class bias (rsd.hip)
             ops.colsum(cat, None, nseg=N, scale=1.0 / (m.h * m.h), out=D["pool"], ws=ws)
             ops.rsd_pool_fwd(D["pool"], w[kf], 2 * m.c_out, out=D["bbias"], ws=ws)
@@ -917,7 +934,12 @@ class Learner:
             wgrad_conv(pyr, D["dzf"], 3, 1, kf)   # rows of the 2*co convolved channels
             self._conv_bwd_data(D["dzf"], w[kf], 1, ci_begin=0, ci_count=2 * co, out=dpyr, ws=ws)
             d0, d1 = dpyr[..., :co], dpyr[..., co:2 * co]
-            bn_b(D["z0"], d0, D["st0"], n0, d0, pre=True, dxsum_part=P.fold_part[b0])   # + conv-bias gradient slabs (batched fold)
+            if self.rsd_bn_pair:   # both branches' batch norms: one reduce launch + one apply launch (+ conv-bias gradient slabs)
+                ops.bn_bwd_pair([(D["z" + i], d_, D["st" + i][0], D["st" + i][1], w[nn + "/gamma"], w[nn + "/beta"], d_, g[nn + "/gamma"],
+                                  g[nn + "/beta"], P.fold_part[bb]) for i, d_, nn, bb in (("0", d0, n0, b0), ("1", d1, n1, b1))],
+                                pre_swish=True, ws=ws)
+            else:
+                bn_b(D["z0"], d0, D["st0"], n0, d0, pre=True, dxsum_part=P.fold_part[b0])   # + conv-bias gradient slabs (batched fold)
             tail = P.filter_tail[j]
             cmain = cat[..., :m.c_cat - tail] if tail else cat
 
@@ -927,7 +949,8 @@ class Learner:
                     wgrad_conv(ctail, dz, kk, dil, kname + "#tail")
             wgrad(d0, k0, 1, 1)
             self._conv_bwd_data(d0, w[k0], 1, out=dcat, ws=ws)
-            bn_b(D["z1"], d1, D["st1"], n1, d1, pre=True, dxsum_part=P.fold_part[b1])
+            if not self.rsd_bn_pair:
+                bn_b(D["z1"], d1, D["st1"], n1, d1, pre=True, dxsum_part=P.fold_part[b1])
             wgrad(d1, k1, 3, 2)
             self._conv_bwd_data(d1, w[k1], 2, out=dcat, accumulate=True, ws=ws)
             # gradient of the concat = dcat + dpool / (H*W) on every pixel (the pooled branch); its deep half joins the residual

@@ -544,6 +544,39 @@ def bn_bwd(x, dy, mean, rstd, gamma, beta, pre_swish=False, post_swish=False, im
     return dx, dgamma, dbeta
 
 
+def bn_apply_fused_pair(probs, pre_swish=False, post_swish=False, unbiased_moving_var=False, eps=BN_EPS, momentum=BN_MOMENTUM):
+    """Two batch norms of the same shape in one launch.  probs = 2 x (x, part, nblk, mean, rstd, gamma, beta, (moving_mean, moving_var) |
+    None, out)."""
+    (x0, pt0, nb0, m0, r0, g0, b0, mv0, y0), (x1, pt1, nb1, m1, r1, g1, b1, mv1, y1) = probs
+    rows, C_, ldx = rows_ld(x0)
+    _, _, ldy = rows_ld(y0)
+    if rows_ld(x1) != (rows, C_, ldx) or rows_ld(y1) != (rows, C_, ldy):
+        raise MliisError("bn_apply_fused_pair: the two problems must have the same shape and leading dimensions")
+    mm0, mw0 = mv0 if mv0 is not None else (None, None)
+    mm1, mw1 = mv1 if mv1 is not None else (None, None)
+    lib.call("mliis_bn_apply_fused_pair", _ptr(_chk(x0)), _ptr(y0), _ptr(pt0), int(nb0), _ptr(m0), _ptr(r0), _ptr(mm0), _ptr(mw0), _ptr(g0), _ptr(b0),
+             _ptr(_chk(x1)), _ptr(y1), _ptr(pt1), int(nb1), _ptr(m1), _ptr(r1), _ptr(mm1), _ptr(mw1), _ptr(g1), _ptr(b1), ldx, ldy, rows, C_,
+             float(eps), float(momentum), int(unbiased_moving_var), int(pre_swish), int(post_swish), _stream())
+    return y0, y1
+
+
+def bn_bwd_pair(probs, pre_swish=False, post_swish=False, ws: Optional[Workspace] = None):
+    """The backward of two plain batch norms of the same shape: one reduce launch + one apply launch for both.
+    probs = 2 x (x, dy, mean, rstd, gamma, beta, dx, dgamma, dbeta, dxsum_part | None)."""
+    (x0, dy0, m0, r0, g0, b0, dx0, dg0, db0, ds0), (x1, dy1, m1, r1, g1, b1, dx1, dg1, db1, ds1) = probs
+    rows, C_, ldx = rows_ld(x0)
+    _, _, lddy = rows_ld(dy0)
+    _, _, lddx = rows_ld(dx0)
+    if rows_ld(x1) != (rows, C_, ldx) or rows_ld(dy1) != (rows, C_, lddy) or rows_ld(dx1) != (rows, C_, lddx):
+        raise MliisError("bn_bwd_pair: the two problems must have the same shape and leading dimensions")
+    ws = ws or default_ws()
+    buf = ws.get(lib.size("mliis_colreduce_workspace_floats", rows, C_, 2, 2))
+    lib.call("mliis_bn_bwd_pair", _ptr(_chk(x0)), _ptr(dy0), _ptr(dx0), _ptr(m0), _ptr(r0), _ptr(g0), _ptr(b0), _ptr(dg0), _ptr(db0), _ptr(ds0),
+             _ptr(_chk(x1)), _ptr(dy1), _ptr(dx1), _ptr(m1), _ptr(r1), _ptr(g1), _ptr(b1), _ptr(dg1), _ptr(db1), _ptr(ds1), ldx, lddy, lddx, rows, C_,
+             int(pre_swish), int(post_swish), min(ds0.numel(), ds1.numel()) if ds0 is not None else 0, _ptr(buf), buf.numel(), _stream())
+    return dx0, dx1
+
+
 def bn_bwd_dxsum_floats(rows, C_):
     return lib.size("mliis_bn_bwd_dxsum_floats", rows, C_)
 

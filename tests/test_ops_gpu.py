@@ -288,6 +288,58 @@ def test_se(C, Rr, N, HW):
     close(dx, gx, 1e-4, "se dx")
 
 
+@pytest.mark.parametrize("rows,C", [(1568, 112), (25088, 112), (300, 136), (77, 8)])
+def test_batch_norm_pairs_equal_the_single_launches(rows, C):
+    """mliis_bn_apply_fused_pair / mliis_bn_bwd_pair (the two independent branch batch norms of an RSD module in one launch per pass)
+    against two single launches: forward bit-identical (outputs into channel slices of a shared buffer, statistics, moving averages),
+    backward to fp32 rounding (gradients, bias-gradient slabs)."""
+    from mliis_amd import ops
+    d = dev()
+    xs = [f32(rnd(rows, C, seed=80 + i) * (1 + i) + 0.3 * i, d) for i in range(2)]
+    gam = [f32(rnd(C, seed=82 + i) * 0.3 + 1, d) for i in range(2)]
+    bet = [f32(rnd(C, seed=84 + i), d) for i in range(2)]
+    parts, nbs = [], []
+    for i in range(2):
+        pt = torch.empty(ops.bn_stats_partial_floats(rows, C) + 8, device=d)
+        nbs.append(ops.bn_stats_partial(xs[i], True, pt))
+        parts.append(pt)
+
+    def fresh():
+        return ([torch.zeros(C, device=d) for _ in range(2)], [torch.zeros(C, device=d) for _ in range(2)],
+                [f32(rnd(C, seed=86 + i), d) for i in range(2)], [f32(rnd(C, seed=88 + i).abs() + 0.5, d) for i in range(2)],
+                torch.zeros(rows, 2 * C, device=d))
+    m1, r1, mm1, mv1, pyr1 = fresh()
+    for i in range(2):
+        ops.bn_apply_fused(xs[i], parts[i], nbs[i], m1[i], r1[i], gam[i], bet[i], moving=(mm1[i], mv1[i]), unbiased_moving_var=True,
+                           pre_swish=True, out=pyr1[:, i * C:(i + 1) * C])
+    m2, r2, mm2, mv2, pyr2 = fresh()
+    ops.bn_apply_fused_pair([(xs[i], parts[i], nbs[i], m2[i], r2[i], gam[i], bet[i], (mm2[i], mv2[i]), pyr2[:, i * C:(i + 1) * C]) for i in range(2)],
+                            pre_swish=True, unbiased_moving_var=True)
+    assert torch.equal(pyr1, pyr2)
+    for a_, b_ in zip(m1 + r1 + mm1 + mv1, m2 + r2 + mm2 + mv2):
+        assert torch.equal(a_, b_)
+    # backward, in place on channel slices of a shared gradient buffer
+    dy = f32(rnd(rows, 2 * C, seed=90), d)
+    nsl = ops.bn_bwd_dxsum_floats(rows, C)
+    res = []
+    for pair in (False, True):
+        dp = dy.clone()
+        dg, db = [torch.zeros(C, device=d) for _ in range(2)], [torch.zeros(C, device=d) for _ in range(2)]
+        sl = [torch.zeros(nsl, device=d) for _ in range(2)]
+        if pair:
+            ops.bn_bwd_pair([(xs[i], dp[:, i * C:(i + 1) * C], m1[i], r1[i], gam[i], bet[i], dp[:, i * C:(i + 1) * C], dg[i], db[i], sl[i])
+                             for i in range(2)], pre_swish=True)
+        else:
+            for i in range(2):
+                v = dp[:, i * C:(i + 1) * C]
+                ops.bn_bwd(xs[i], v, m1[i], r1[i], gam[i], bet[i], pre_swish=True, dx=v, dgamma=dg[i], dbeta=db[i], dxsum_part=sl[i])
+        res.append([dp] + dg + db + sl)
+    # (the paired reduce pass cuts the rows into chunks for two problems at once: another summation order on large inputs, so the
+    #  gradients agree to fp32 rounding, not bit for bit)
+    for a_, b_ in zip(*res):
+        close(a_, b_.double().cpu(), 2e-6, "paired batch-norm backward")
+
+
 @pytest.mark.parametrize("C,Rr,N,HW", [(40, 10, 3, 196), (144, 6, 8, 3136), (24, 6, 2, 784), (96, 4, 8, 300), (32, 8, 2, 12544)])
 def test_se_and_bn_backward_share_one_pass(C, Rr, N, HW):
     """mliis_se_bn_bwd_sums + mliis_se_mlp_bwd_bn + mliis_bn_bwd(stage1 = per-image sums, chan_scale, chan_add): the backward of
