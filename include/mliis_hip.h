@@ -108,6 +108,18 @@ int mliis_dwconv_bn_bwd(const float* dy, const float* z, const float* bn_mean, c
                         const float* bn_beta, const float* w, float* dx, float* dw, int N, int H, int W, int C, int k, int stride,
                         float* dw_part, size_t dw_part_floats, float* bn_part, size_t bn_part_floats, int* nblk, hipStream_t stream);
 
+/*      mliis_mbconv_dw_bwd_march: the same backward with the depthwise batch norm's (bn1, efficientnet_model.py:271) backward APPLY
+ *      formed while its operands are staged: da2 = the project conv's backward-data output (gradient w.r.t. a1 * gate), z1 = bn1's
+ *      input, gate / chan_add [N,C] and stage1 [stage1_nimg][2][C] from mliis_se_mlp_bwd_bn.  The launch forms
+ *      dz1 = gamma1 rstd1 (g - mean(g) - xhat1 mean(g xhat1)), g = (da2 gate + chan_add) swish'(gamma1 xhat1 + beta1), on the fly (the
+ *      tensor dz1 is never written), writes dgamma1 / dbeta1, and continues as mliis_dwconv_bn_bwd with the batch norm in front (bn0:
+ *      z0, mean0 .. beta0): dx, dw_part, bn_part, *nblk. */
+int mliis_mbconv_dw_bwd_march(const float* da2, const float* z1, const float* mean1, const float* rstd1, const float* gamma1, const float* beta1,
+                              const float* gate, const float* chan_add, const float* stage1, int stage1_nimg, float* dgamma1, float* dbeta1,
+                              const float* z0, const float* mean0, const float* rstd0, const float* gamma0, const float* beta0, const float* w,
+                              float* dx, int N, int H, int W, int C, int k, int stride, float* dw_part, size_t dw_part_floats, float* bn_part,
+                              size_t bn_part_floats, int* nblk, hipStream_t stream);
+
 /* ---- the depthwise half of an MBConv block on SMALL maps in ONE launch per direction (mbconv_small.hip): expand BN -> swish ->
  *      depthwise k x k (stride 1) -> BN -> swish -> squeeze-excite mean (efficientnet_model.py:183-200,266-271,247; utils.py:87-134)
  *      and the whole backward of that chain.  Every op in it is per channel, so a workgroup that owns 8 channels over all of

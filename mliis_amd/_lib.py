@@ -35,6 +35,7 @@ SIGNATURES = {
     "mliis_dwconv_bn_bwd_blocks": (_i, [_i, _i, _i, _i, _i, _i]),
     "mliis_dwconv_bn_fwd": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _p, _f, _f, _p, _p, _i, _i, _i, _i, _i, _i, _p, _sz, _p, _p]),
     "mliis_dwconv_bn_bwd": (_i, [_p] * 9 + [_i, _i, _i, _i, _i, _i, _p, _sz, _p, _sz, _p, _p]),
+    "mliis_mbconv_dw_bwd_march": (_i, [_p] * 9 + [_i] + [_p] * 9 + [_i, _i, _i, _i, _i, _i, _p, _sz, _p, _sz, _p, _p]),
     "mliis_augment_stage": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "mliis_rng_masks": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _p]),
     "mliis_mbconv_dw_small_supported": (_i, [_i, _i, _i, _i, _i, _i]),

@@ -90,6 +90,76 @@ struct DwmBn {
   const float* beta;
 };
 
+// Backward kernels with DYBN: the gradient that enters the ring is not read but FORMED while it is staged -- the input gradient of the
+// depthwise batch norm (bn1) from the project conv's backward-data output da2 and bn1's input z1 (efficientnet_model.py:271, 238-251):
+//     g = (da2 * gate[n] + chan_add[n]) * swish'(u),  u = gamma xhat + beta,     dz1 = gamma rstd (g - mean(g) - xhat mean(g xhat))
+// with the two means from the per-image stage-1 sums of mliis_se_mlp_bwd_bn.  The batch norm's apply pass, its write of dz1 and the
+// re-read here disappear.  Per channel: u = z sc + sh, dz1 = sc g + z k1 + k0.
+struct DwmDyBn {
+  const float* z;          // z1 [N,Hd,Wd,C], same shape as the ring-side tensor
+  const float *mean, *rstd, *gamma, *beta;
+  const float *gate, *chan_add;   // [N][C]
+  const float* stage1;     // [nimg][2][C] {sum g, sum g xhat} per image
+  int nimg;
+  double inv_rows;         // 1 / (N Hd Wd)
+  float *dgamma, *dbeta;   // written by workgroup 0 of every channel group
+};
+struct DwmDyQuad {
+  float4 sc, sh, gt, ca, k1, k0;
+};
+__device__ __forceinline__ DwmDyQuad dwm_dybn_setup(const DwmDyBn& d, int C, int c0, int q, bool cok, int n, bool lead) {
+  const int c = cok ? c0 + q * 4 : 0;
+  const float4 m = ld4(d.mean + c), rs = ld4(d.rstd + c), ga = ld4(d.gamma + c), be = ld4(d.beta + c);
+  DwmDyQuad k;
+  k.gt = ld4(d.gate + (long long)n * C + c);
+  k.ca = ld4(d.chan_add + (long long)n * C + c);
+  double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+  for (int i0 = 0; i0 < d.nimg; i0 += 8) {   // image order (deterministic), eight images' loads together
+    float4 u[8], v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int i = i0 + j < d.nimg ? i0 + j : d.nimg - 1;
+      u[j] = ld4(d.stage1 + ((long long)i * 2 + 0) * C + c);
+      v[j] = ld4(d.stage1 + ((long long)i * 2 + 1) * C + c);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (i0 + j < d.nimg) {
+        s1[0] += u[j].x; s1[1] += u[j].y; s1[2] += u[j].z; s1[3] += u[j].w;
+        s2[0] += v[j].x; s2[1] += v[j].y; s2[2] += v[j].z; s2[3] += v[j].w;
+      }
+  }
+  if (lead && cok && (threadIdx.x >> 3) == 0) {   // one thread per quad publishes the parameter gradients
+    st4(d.dbeta + c, make_float4((float)s1[0], (float)s1[1], (float)s1[2], (float)s1[3]));
+    st4(d.dgamma + c, make_float4((float)s2[0], (float)s2[1], (float)s2[2], (float)s2[3]));
+  }
+  const float4 a = make_float4((float)(s1[0] * d.inv_rows), (float)(s1[1] * d.inv_rows), (float)(s1[2] * d.inv_rows), (float)(s1[3] * d.inv_rows));
+  const float4 b = make_float4((float)(s2[0] * d.inv_rows), (float)(s2[1] * d.inv_rows), (float)(s2[2] * d.inv_rows), (float)(s2[3] * d.inv_rows));
+  k.sc = f4mul(ga, rs);
+  k.sh = make_float4(fmaf(-m.x, k.sc.x, be.x), fmaf(-m.y, k.sc.y, be.y), fmaf(-m.z, k.sc.z, be.z), fmaf(-m.w, k.sc.w, be.w));
+  // dz1 = sc (g - a - xhat b),  xhat = (z - m) rs   ->   sc g + z k1 + k0
+  k.k1 = make_float4(-k.sc.x * b.x * rs.x, -k.sc.y * b.y * rs.y, -k.sc.z * b.z * rs.z, -k.sc.w * b.w * rs.w);
+  k.k0 = make_float4(-k.sc.x * a.x - k.k1.x * m.x, -k.sc.y * a.y - k.k1.y * m.y, -k.sc.z * a.z - k.k1.z * m.z, -k.sc.w * a.w - k.k1.w * m.w);
+  return k;
+}
+__device__ __forceinline__ float dwm_dz1(float da2, float z, float sc, float sh, float gt, float ca, float k1, float k0) {
+  const float u = fmaf(z, sc, sh);
+  const float sg = sigmoid_f(u);
+  const float g = fmaf(da2, gt, ca) * (sg * (1.0f + u * (1.0f - sg)));
+  return fmaf(sc, g, fmaf(z, k1, k0));
+}
+__device__ __forceinline__ float4 dwm_dz1(const float4 da2, const float4 z, const DwmDyQuad& k) {
+  return make_float4(dwm_dz1(da2.x, z.x, k.sc.x, k.sh.x, k.gt.x, k.ca.x, k.k1.x, k.k0.x), dwm_dz1(da2.y, z.y, k.sc.y, k.sh.y, k.gt.y, k.ca.y, k.k1.y, k.k0.y),
+                     dwm_dz1(da2.z, z.z, k.sc.z, k.sh.z, k.gt.z, k.ca.z, k.k1.z, k.k0.z), dwm_dz1(da2.w, z.w, k.sc.w, k.sh.w, k.gt.w, k.ca.w, k.k1.w, k.k0.w));
+}
+
+// one batch of ring rows in registers (DYBN: two tensors)
+template <int NEW, bool TWO>
+struct DwmBatch {
+  float4 a[NEW];
+  float4 b[TWO ? NEW : 1];
+};
+
 struct DwmArgs {
   const float* x;      // the tensor the ring is fed from: forward [N,Hi,Wi,C] z (or a plain input); backward dy [N,Ho,Wo,C]
   const float* w;      // [K,K,C]
@@ -103,6 +173,7 @@ struct DwmArgs {
   int dbg;             // diagnosis: 1 = no window FMAs, 2 = no global loads, 4 = no stores, 8 = no march (prologue only)
   unsigned long long* stamps;   // [gridDim.x * gridDim.y][16] wall-clock stamps (100 MHz) of wave 0, or null
 #endif
+  DwmDyBn dyb;         // backward with DYBN: x = da2, dyb.z = z1 -- the ring receives dz1, the depthwise batch norm's input gradient
   const float* z;      // backward: the batch norm's input at the produced positions [N,Ho,Wo,C] (plain input when bn.gamma == nullptr)
   float* dw_part;      // backward: [gridDim.x][K*K][C]
 };
@@ -221,8 +292,9 @@ __device__ __forceinline__ void dwm_emit_pair(const float4 s1, const float4 s2, 
 // loads z at its own produced pixels and accumulates the filter gradient (K*K float4 accumulators) and the batch norm's backward
 // sums.  PRE: the batch norm + swish (forward: applied to the staged input; backward: recomputed at the produced pixels).
 // ---------------------------------------------------------------------------------------------------------------------------------
-template <int K, int S, bool PRE, bool BWD>
+template <int K, int S, bool PRE, bool BWD, bool DYBN = false>
 __global__ __launch_bounds__(256, BWD ? 1 : 2) void dwm_conv_k(const DwmArgs a) {
+  static_assert(!DYBN || BWD, "DYBN is a backward mode");
   typedef MarchCfg<K, S> G;
   constexpr int TS = G::TS, SPR = G::SPR, RS = G::RS, IBW = G::IBW, IBWP = G::IBWP, WIN = G::WIN, NEW = G::NEW, NR = G::NR, WW = G::WW;
   static_assert(!BWD || S == 1, "the stride-2 backward is dwm_bwd_s2_k");
@@ -267,16 +339,23 @@ __global__ __launch_bounds__(256, BWD ? 1 : 2) void dwm_conv_k(const DwmArgs a) 
   const int rowbytes = Wi * C * 4;
   const int lcol = p < IBWP ? (p ^ ((p >> 2) & 1)) * 8 + q : kTrash + q;   // (lanes beyond the pitch write the spare pixel)
   auto row_in = [&](int rr) { return rr >= 0 && rr < rows_needed && (unsigned)(iy0 + rr) < (unsigned)Hi; };
-  auto issue = [&](float4 (&r)[NEW], int rb) {
-#pragma unroll
-    for (int j = 0; j < NEW; ++j) r[j] = dwm_load(rX, tbase + (rb + j) * rowbytes, colok && row_in(rb + j));
-  };
-  DwmQuad kq;
-  auto commit = [&](const float4 (&r)[NEW], int rb, int sb) {
+  typedef DwmBatch<NEW, DYBN> Batch;
+  const __amdgpu_buffer_rsrc_t rX2 = dwm_rsrc(DYBN ? a.dyb.z : a.x);
+  auto issue = [&](Batch& r, int rb) {
 #pragma unroll
     for (int j = 0; j < NEW; ++j) {
-      float4 v = r[j];
+      r.a[j] = dwm_load(rX, tbase + (rb + j) * rowbytes, colok && row_in(rb + j));
+      if (DYBN) r.b[j] = dwm_load(rX2, tbase + (rb + j) * rowbytes, colok && row_in(rb + j));
+    }
+  };
+  DwmQuad kq;
+  DwmDyQuad dq;
+  auto commit = [&](const Batch& r, int rb, int sb) {
+#pragma unroll
+    for (int j = 0; j < NEW; ++j) {
+      float4 v = r.a[j];
       if (PRE && !BWD) v = f4sel(colok && row_in(rb + j), dwm_act(v, kq));   // zero padding applies to the ACTIVATION (swish(bn(0)) != 0)
+      if (DYBN) v = f4sel(colok && row_in(rb + j), dwm_dz1(v, r.b[j], dq));   // (dz1 of a pixel outside the map is zero, not k0)
       int slot = sb + j;
       if (slot >= NR) slot -= NR;
       if (rb + j >= 0) ring[(p < IBWP ? slot * (IBWP * 8) : 0) + lcol] = v;   // (uniform branch: only the head batch has rows < 0)
@@ -311,13 +390,14 @@ __global__ __launch_bounds__(256, BWD ? 1 : 2) void dwm_conv_k(const DwmArgs a) 
   }
   DwmBnState<!BWD> bst;
   if (PRE) dwm_bn_begin(a.bn, C, c0, q, cok, bst);
+  if (DYBN) dq = dwm_dybn_setup(a.dyb, C, c0, q, cok, n, bx == 0);
   DWM_STAMP(1);
-  float4 ra[NEW], rb_[NEW];
+  Batch ra, rb_;
   float4 za[TS], zb[TS];
   {
     // the window of step 0 (head rows + batch 0) first; the fold's arithmetic runs under their transfer; then the batches of steps
     // 1 and 2 (needed at the end of steps 0 and 1)
-    float4 h0[NEW], h1[NEW];
+    Batch h0, h1;
     issue(h0, HEAD);
     issue(h1, WIN - NEW);
     issue_z(za, 0);
@@ -508,8 +588,8 @@ __global__ __launch_bounds__(256, BWD ? 1 : 2) void dwm_conv_k(const DwmArgs a) 
 // holds dy rows (1/4 of the input's size); z is read and dx written by the owning thread directly.
 // Pixel lane -> (pair row rp = p >> 4 of the step, patch px = p & 15): a step = 2 pair rows = 4 input rows.
 // ---------------------------------------------------------------------------------------------------------------------------------
-template <int K, bool PRE>
-__global__ __launch_bounds__(256, K == 5 ? 1 : 2) void dwm_bwd_s2_k(const DwmArgs a) {
+template <int K, bool PRE, bool DYBN = false>
+__global__ __launch_bounds__(256, (K == 5 || DYBN) ? 1 : 2) void dwm_bwd_s2_k(const DwmArgs a) {
   constexpr int BP = 14;                    // patches per band (28 input columns, as the stride-1 kernels)
   constexpr int D = (K - 1) / 2;            // dy rows / columns behind a patch
   constexpr int NEWD = 2, WIND = 2 + D, NR = WIND + NEWD, IBW = 16;   // ring row = 16 dy pixels (BP + D needed): one batch = 2 rows = the 32 pixel lanes
@@ -548,14 +628,20 @@ __global__ __launch_bounds__(256, K == 5 ? 1 : 2) void dwm_bwd_s2_k(const DwmArg
   const bool colok = cok && scol < bpa + D && (unsigned)(x0 - D + scol) < (unsigned)Wd;
   const int tbase = (((n * Hd + m0 - D + sl) * Wd + x0 - D + scol) * C + c) * 4;
   const int rowbytes = Wd * C * 4;
-  auto issue = [&](float4& r, int rb) {
-    const int rr = rb + sl;
-    r = dwm_load(rX, tbase + rb * rowbytes, colok && rr >= 0 && rr < rows_needed && (unsigned)(m0 - D + rr) < (unsigned)Hd);
+  typedef DwmBatch<1, DYBN> Batch;
+  const __amdgpu_buffer_rsrc_t rX2 = dwm_rsrc(DYBN ? a.dyb.z : a.x);
+  auto row_in = [&](int rr) { return rr >= 0 && rr < rows_needed && (unsigned)(m0 - D + rr) < (unsigned)Hd; };
+  auto issue = [&](Batch& r, int rb) {
+    r.a[0] = dwm_load(rX, tbase + rb * rowbytes, colok && row_in(rb + sl));
+    if (DYBN) r.b[0] = dwm_load(rX2, tbase + rb * rowbytes, colok && row_in(rb + sl));
   };
-  auto commit = [&](const float4& r, int rb, int sb) {
+  DwmDyQuad dq;
+  auto commit = [&](const Batch& r, int rb, int sb) {
     int slot = sb + sl;
     if (slot >= NR) slot -= NR;
-    if (rb + sl >= 0) ring[slot * (IBW * 8) + scol * 8 + q] = r;
+    float4 v = r.a[0];
+    if (DYBN) v = f4sel(colok && row_in(rb + sl), dwm_dz1(v, r.b[0], dq));
+    if (rb + sl >= 0) ring[slot * (IBW * 8) + scol * 8 + q] = v;
   };
 
   // ---- this thread's patch: pair row m0 + 2 step + rp, pair column x0 + px; pixel (u >> 1, u & 1)
@@ -587,7 +673,8 @@ __global__ __launch_bounds__(256, K == 5 ? 1 : 2) void dwm_bwd_s2_k(const DwmArg
   DwmBnState<false> bst;
   if (PRE) dwm_bn_begin(a.bn, C, c0, q, cok, bst);
   if (PRE) kq = dwm_bn_end(a.bn, C, c0, q, cok, false, reinterpret_cast<double*>(ring), s_mr, bst);   // (statistics are given here: no fold)
-  float4 ra, rb_, h0, h1;
+  if (DYBN) dq = dwm_dybn_setup(a.dyb, C, c0, q, cok, n, bx == 0);
+  Batch ra, rb_, h0, h1;
   float4 za[4], zb[4];
   issue(h0, HEAD);
   issue(h1, WIND - NEWD);
@@ -807,6 +894,13 @@ template <int K, bool PRE>
 static void launch_bwd_s2(const MarchGeom& g, const DwmArgs& a, hipStream_t stream) {
   hipLaunchKernelGGL((dwm_bwd_s2_k<K, PRE>), dim3((unsigned)g.gx, g.gy), dim3(256), 0, stream, a);
 }
+// (DYBN: always with the batch norm in front -- the MBConv blocks with an expand conv, or block 0 behind the stem)
+template <int K>
+static void launch_bwd_dybn(const MarchGeom& g, const DwmArgs& a, int stride, hipStream_t stream) {
+  const dim3 grid((unsigned)g.gx, g.gy);
+  if (stride == 1) hipLaunchKernelGGL((dwm_conv_k<K, 1, true, true, true>), grid, dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL((dwm_bwd_s2_k<K, true, true>), grid, dim3(256), 0, stream, a);
+}
 
 }  // namespace mliis
 
@@ -925,6 +1019,47 @@ int mliis_dwconv_bn_bwd(const float* dy, const float* z, const float* bn_mean, c
                        dw, 0, (long long)k * k * C, 0LL, 0LL);
     MLIIS_CHECK_LAUNCH("dwconv_bn_bwd_fold");
   }
+  return MLIIS_OK;
+}
+
+// The backward of the depthwise half of an MBConv block on the large maps in ONE launch: the depthwise batch norm's (bn1) backward
+// apply formed while da2 / z1 are staged (see DwmDyBn), the depthwise conv's backward-data and filter-gradient slabs, stage 1 of the
+// batch norm in front (bn0).  H, W = the depthwise conv's INPUT size; da2 / z1 [N,Ho,Wo,C]; z0 / dx [N,H,W,C].
+int mliis_mbconv_dw_bwd_march(const float* da2, const float* z1, const float* mean1, const float* rstd1, const float* gamma1, const float* beta1,
+                              const float* gate, const float* chan_add, const float* stage1, int stage1_nimg, float* dgamma1, float* dbeta1,
+                              const float* z0, const float* mean0, const float* rstd0, const float* gamma0, const float* beta0, const float* w,
+                              float* dx, int N, int H, int W, int C, int k, int stride, float* dw_part, size_t dw_part_floats, float* bn_part,
+                              size_t bn_part_floats, int* nblk, hipStream_t stream) {
+  int rc = dwm_check("mbconv_dw_bwd_march", N, H, W, C, k, stride);
+  if (rc) return rc;
+  MLIIS_REQUIRE(da2 && z1 && mean1 && rstd1 && gamma1 && beta1 && gate && chan_add && stage1 && stage1_nimg > 0 && dgamma1 && dbeta1 && z0 && mean0 &&
+                    rstd0 && gamma0 && beta0 && w && dx && dw_part && bn_part && nblk,
+                MLIIS_ERR_ARG, "mbconv_dw_bwd_march: null pointer");
+  MLIIS_REQUIRE(aligned16(da2) && aligned16(z1) && aligned16(mean1) && aligned16(rstd1) && aligned16(gamma1) && aligned16(beta1) && aligned16(gate) &&
+                    aligned16(chan_add) && aligned16(stage1) && aligned16(dgamma1) && aligned16(dbeta1) && aligned16(z0) && aligned16(mean0) &&
+                    aligned16(rstd0) && aligned16(gamma0) && aligned16(beta0) && aligned16(w) && aligned16(dx) && aligned16(dw_part) && aligned16(bn_part),
+                MLIIS_ERR_ALIGN, "mbconv_dw_bwd_march: pointers must be 16-byte aligned");
+  const MarchGeom g = march_geom_bwd(N, H, W, C, k, stride);
+  MLIIS_REQUIRE(g.gx < (1LL << 31), MLIIS_ERR_UNSUPPORTED, "mbconv_dw_bwd_march: too many workgroups");
+  MLIIS_REQUIRE((size_t)g.gx * k * k * C <= dw_part_floats && (size_t)g.gx * 2 * C <= bn_part_floats, MLIIS_ERR_WORKSPACE,
+                "mbconv_dw_bwd_march: slab buffers too small (%zu / %zu floats needed)", (size_t)g.gx * k * k * C, (size_t)g.gx * 2 * C);
+  *nblk = (int)g.gx;
+  DwmArgs a{};
+  a.x = da2; a.w = w; a.y = dx; a.z = z0;
+  a.C = C;
+  a.bands = g.bands; a.bw = g.bw; a.chunks = g.chunks; a.rpc = g.rpc;
+  a.stats_part = bn_part;
+  a.dw_part = dw_part;
+  a.bn = make_bn(nullptr, 0, 1, gamma0, beta0, const_cast<float*>(mean0), const_cast<float*>(rstd0), nullptr, nullptr, 0.f, 0.f, 0);
+  a.dyb = DwmDyBn{z1, mean1, rstd1, gamma1, beta1, gate, chan_add, stage1, stage1_nimg, 1.0 / ((double)N * g.Ho * g.Wo), dgamma1, dbeta1};
+  if (stride == 1) {
+    a.Hi = H; a.Wi = W; a.Ho = H; a.Wo = W; a.pt = k - 1 - g.pt; a.pl = k - 1 - g.pl;
+  } else {
+    a.Hi = g.Ho; a.Wi = g.Wo; a.Ho = H; a.Wo = W; a.pt = g.pt; a.pl = g.pl;
+  }
+  if (k == 3) launch_bwd_dybn<3>(g, a, stride, stream);
+  else launch_bwd_dybn<5>(g, a, stride, stream);
+  MLIIS_CHECK_LAUNCH("mbconv_dw_bwd_march");
   return MLIIS_OK;
 }
 }

@@ -299,6 +299,8 @@ class Learner:
         self.se_bn_sums = os.environ.get("MLIIS_SE_BN_SUMS", "1") != "0"
         # the two independent branch batch norms of an RSD module in one launch per pass (MLIIS_RSD_BN_PAIR=0: one by one)
         self.rsd_bn_pair = os.environ.get("MLIIS_RSD_BN_PAIR", "1") != "0"
+        # the depthwise batch norm's backward apply inside the marching depthwise backward launch (MLIIS_DW_BWD_BN1=0: its own launch)
+        self.dw_bwd_bn1 = os.environ.get("MLIIS_DW_BWD_BN1", "1") != "0"
         self.use_graph = use_graph
         self.stream = torch.cuda.Stream(device=self.device)
         # Optional (overlap_wgrad = 1 | 2): weight-gradient GEMMs on a second stream forked inside the HIP graph, one by one (1) or
@@ -1082,7 +1084,30 @@ class Learner:
                 if bi > 0:
                     has_grad[bi - 1] = True
                 continue
-            bn_b(B["z1"], da2, B["st1"], nm["bn1"], da2, post=True, chan_scale=B["gate"], chan_add=B["chan_add"], stage1=bn1_stage1)
+            # bn1's backward apply inside the depthwise backward launch (its operands are staged there anyway; dz1 is never written)
+            fuse_bn1 = bool(B["march"] and bn1_stage1 is not None and self.dw_bwd_bn1 and not (b.k == 5 and b.stride == 1) and
+                            (b.expand != 1 or (bi == 0 and P.fuse_stem)))
+            if not fuse_bn1:
+                bn_b(B["z1"], da2, B["st1"], nm["bn1"], da2, post=True, chan_scale=B["gate"], chan_add=B["chan_add"], stage1=bn1_stage1)
+            if fuse_bn1:
+                st1, p1 = B["st1"], nm["bn1"]
+                if b.expand != 1:
+                    zin, st0, p0, dxo = B["z0"], B["st0"], nm["bn0"], B["da0"]
+                else:
+                    zin, st0, p0, dxo = P.z_stem, P.st_stem, self.n_stem[1], tgt
+                nb1 = ops.mbconv_dw_bwd_march(da2, B["z1"], (st1[0], st1[1], w[p1 + "/gamma"], w[p1 + "/beta"]), B["gate"], B["chan_add"],
+                                              P.stage1_se[:2 * N * ce].view(N, 2, ce), g[p1 + "/gamma"], g[p1 + "/beta"], zin,
+                                              (st0[0], st0[1], w[p0 + "/gamma"], w[p0 + "/beta"]), w[nm["w_dw"]], b.stride, dxo,
+                                              P.fold_part[nm["w_dw"]], P.stats_part2)
+                if b.expand != 1:
+                    bn_b(B["z0"], dxo, st0, p0, dxo, post=True, stage1=(P.stats_part2, nb1))
+                    wgrad_1x1(B["x_in"], dxo, nm["w_exp"])
+                    stage1_next = expand_bwd_data(bi, dxo, nm["w_exp"], tgt, tgt_has)
+                else:
+                    P.stem_stage1 = (P.stats_part2, nb1)
+                if bi > 0:
+                    has_grad[bi - 1] = True
+                continue
             if B["march"]:
                 # ONE pass over (dz1, z0): depthwise backward-data, filter-gradient slabs and stage 1 of bn0's backward
                 wdw, slabs = w[nm["w_dw"]], P.fold_part[nm["w_dw"]]

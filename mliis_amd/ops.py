@@ -251,6 +251,21 @@ def dwconv_bn_bwd(dy, z, w, stride, bn=None, out=None, dw=None, dw_part=None, bn
     return out, dw, nb.value
 
 
+def mbconv_dw_bwd_march(da2, z1, bn1, gate, chan_add, stage1, dgamma1, dbeta1, z0, bn0, w, stride, out, dw_part, bn_part):
+    """dwconv_bn_bwd with the depthwise batch norm's backward apply formed while (da2, z1) are staged: bn1 / bn0 = (mean, rstd, gamma,
+    beta); stage1 [N][2][C] from se_mlp_bwd_bn.  Returns the block count (slabs of dw_part, blocks of bn_part)."""
+    N, H, W, C_ = z0.shape
+    k = w.shape[0]
+    nb = C.c_int(0)
+    meta = dict(bytes=4.0 * (2 * z0.numel() + 2 * z1.numel() + 2 * k * k * C_), shape=(N, H, W, C_, k, stride)) if PROFILE is not None else {}
+    _timed("dwconv_bn_bwd", meta, lambda: lib.call(
+        "mliis_mbconv_dw_bwd_march", _ptr(_chk(da2)), _ptr(_chk(z1)), _ptr(bn1[0]), _ptr(bn1[1]), _ptr(bn1[2]), _ptr(bn1[3]), _ptr(gate),
+        _ptr(chan_add), _ptr(stage1), int(stage1.shape[0]) if stage1.dim() == 3 else N, _ptr(dgamma1), _ptr(dbeta1), _ptr(_chk(z0)), _ptr(bn0[0]),
+        _ptr(bn0[1]), _ptr(bn0[2]), _ptr(bn0[3]), _ptr(w), _ptr(out), N, H, W, C_, k, stride, _ptr(dw_part), dw_part.numel(), _ptr(bn_part),
+        bn_part.numel(), C.byref(nb), _stream()))
+    return nb.value
+
+
 # ------------------------------------------------------------------------------------------------ small-map MBConv depthwise half
 def mbconv_dw_small_supported(N, H, W, C_, k, stride) -> bool:
     return bool(lib.raw("mliis_mbconv_dw_small_supported")(N, H, W, C_, k, stride))

@@ -111,6 +111,54 @@ def test_dwmarch_baseline_shapes(k, s, H, C):
     _case(k, s, H, H, C, 8 if H <= 112 else 2, pre=True)
 
 
+@pytest.mark.parametrize("k,s,H,W,C,N", [(3, 1, 28, 28, 40, 3), (3, 2, 30, 34, 24, 2), (5, 2, 28, 28, 16, 2), (5, 1, 14, 20, 8, 2), (3, 1, 56, 56, 144, 8),
+                                         (3, 2, 112, 112, 96, 8), (5, 2, 56, 56, 144, 8), (3, 1, 9, 7, 4, 1)])
+def test_depthwise_backward_with_the_batch_norm_backward_formed_on_load(k, s, H, W, C, N):
+    """mliis_mbconv_dw_bwd_march = mliis_bn_bwd (depthwise batch norm bn1, squeeze-excite vectors, stage 1 given per image) followed by
+    mliis_dwconv_bn_bwd, without the tensor dz1 in between: against that composition on the device (each half is tested against the
+    float64 oracle on its own: test_se_and_bn_backward_share_one_pass, test_dwmarch_shapes) -- dx, the filter gradient, bn0's stage-1
+    sums, dgamma1 / dbeta1."""
+    from mliis_amd import ops
+    d = dev()
+    Ho, Wo = -(-H // s), -(-W // s)
+    z0 = f32(rnd(N, H, W, C, seed=1) * 1.5 + 0.3, d)
+    z1 = f32(rnd(N, Ho, Wo, C, seed=2) * 1.2 - 0.2, d)
+    da2 = f32(rnd(N, Ho, Wo, C, seed=3), d)
+    w = f32(rnd(k, k, C, 1, seed=4), d)
+    gate = f32(torch.sigmoid(rnd(N, C, seed=5)), d)
+    ca = f32(rnd(N, C, seed=6) * 0.01, d)
+
+    def stats(t):
+        td = t.double()
+        m = td.mean(dim=(0, 1, 2))
+        return f32(m, d), f32(1.0 / torch.sqrt(td.var(dim=(0, 1, 2), unbiased=False) + EPS), d)
+    m0, r0 = stats(z0.cpu())
+    m1, r1 = stats(z1.cpu())
+    g0, b0, g1, b1 = (f32(1.0 + 0.2 * rnd(C, seed=7 + i), d) for i in range(4))
+    # stage 1 of bn1 per image, as mliis_se_mlp_bwd_bn leaves it
+    xh = (z1.double().cpu() - m1.double().cpu()) * r1.double().cpu()
+    u = xh * g1.double().cpu() + b1.double().cpu()
+    sg = torch.sigmoid(u)
+    gg = (da2.double().cpu() * gate.double().cpu()[:, None, None, :] + ca.double().cpu()[:, None, None, :]) * (sg * (1 + u * (1 - sg)))
+    stage1 = f32(torch.stack([gg.sum(dim=(1, 2)), (gg * xh).sum(dim=(1, 2))], dim=1), d)     # [N, 2, C]
+    # composition
+    dz1, dga_ref, dbe_ref = ops.bn_bwd(z1, da2, m1, r1, g1, b1, post_swish=True, chan_scale=gate, chan_add=ca, stage1=(stage1, N))
+    nbb = ops.dwconv_bn_bwd_blocks(N, H, W, C, k, s)
+    slabs_ref, part_ref = torch.zeros(nbb * k * k * C, device=d), torch.zeros(nbb * 2 * C, device=d)
+    dx_ref, _, _ = ops.dwconv_bn_bwd(dz1, z0, w, s, bn=(m0, r0, g0, b0), dw_part=slabs_ref, bn_part=part_ref)
+    # fused
+    slabs, part = torch.zeros_like(slabs_ref), torch.zeros_like(part_ref)
+    dx = torch.empty_like(z0)
+    dga, dbe = torch.empty(C, device=d), torch.empty(C, device=d)
+    nb = ops.mbconv_dw_bwd_march(da2, z1, (m1, r1, g1, b1), gate, ca, stage1, dga, dbe, z0, (m0, r0, g0, b0), w, s, dx, slabs, part)
+    assert nb == nbb
+    close(dx, dx_ref.double().cpu(), 2e-5, "dx")
+    close(slabs.view(nbb, -1).sum(0), slabs_ref.view(nbb, -1).double().sum(0).cpu(), 5e-5, "filter gradient")
+    close(part.view(nbb, 2, C).sum(0), part_ref.view(nbb, 2, C).double().sum(0).cpu(), 5e-5, "bn0 stage 1")
+    close(dga, dga_ref.double().cpu(), 1e-5, "dgamma1")
+    close(dbe, dbe_ref.double().cpu(), 1e-5, "dbeta1")
+
+
 def test_dwmarch_workgroup_target_does_not_change_results(monkeypatch):
     """The row-chunk count only changes which workgroup owns a row (MLIIS_DWM_TARGET is read once per process: checked through the
     block-count query against the default)."""
