@@ -1119,42 +1119,52 @@ int mliis_final_conv_bwd_filter(const float* x, int ldx, const float* mask, cons
 }
 
 namespace mliis {
-__global__ __launch_bounds__(256) void final_dw_finalize_k(const float* __restrict__ part, int nblk, int C, float* __restrict__ dw) {
+// blockIdx.y < 2: weight-gradient column j of 16 channels (fold of the Outer2Op partials); blockIdx.y == 2 (one workgroup): the bias
+// gradient db[j] = sum_rows dy[row, j] -- independent of the fold, so it rides in the same launch (it used to be one of its own).
+__global__ __launch_bounds__(256) void final_dw_finalize_k(const float* __restrict__ part, int nblk, int C, float* __restrict__ dw,
+                                                           const float* __restrict__ dy, long long rows, float* __restrict__ db) {
   __shared__ double sm[kFoldY * (kFoldX + 1)];
+  if (blockIdx.y == 2) {   // (uniform)
+    if (blockIdx.x != 0) return;
+    __shared__ double sb[2][256];
+    const int t = threadIdx.y * kFoldX + threadIdx.x;
+    double a0 = 0.0, a1 = 0.0;
+    const long long pairs = rows >> 1;
+    for (long long r = t; r < pairs; r += 4 * 256) {   // two rows per float4 load, four loads in flight
+      float4 d[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) d[u] = r + u * 256 < pairs ? ld4(dy + (r + u * 256) * 4) : f4zero();
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        a0 += (double)d[u].x + (double)d[u].z;
+        a1 += (double)d[u].y + (double)d[u].w;
+      }
+    }
+    if ((rows & 1) && t == 0) {
+      a0 += dy[(rows - 1) * 2];
+      a1 += dy[(rows - 1) * 2 + 1];
+    }
+    sb[0][t] = a0;
+    sb[1][t] = a1;
+    __syncthreads();
+    for (int s_ = 128; s_ > 0; s_ >>= 1) {
+      if (t < s_) {
+        sb[0][t] += sb[0][t + s_];
+        sb[1][t] += sb[1][t + s_];
+      }
+      __syncthreads();
+    }
+    if (t == 0) {
+      db[0] = (float)sb[0][0];
+      db[1] = (float)sb[1][0];
+    }
+    return;
+  }
   const int c = blockIdx.x * kFoldX + threadIdx.x;
   const int j = blockIdx.y;
   const bool ok = c < C;
   const double s = fold_partials(part, nblk, 2LL * C, (long long)j * C + c, ok, sm);
   if (ok && threadIdx.y == 0) dw[c * 2 + j] = (float)s;
-}
-__global__ __launch_bounds__(1024) void sum2_k(const float* __restrict__ dy, long long rows, float* __restrict__ db) {
-  // single block: db[j] = sum_rows dy[row, j]; two rows per float4 load
-  __shared__ double sm[2][1024];
-  double a0 = 0.0, a1 = 0.0;
-  const long long pairs = rows >> 1;
-  for (long long r = threadIdx.x; r < pairs; r += 1024) {
-    const float4 d = ld4(dy + r * 4);
-    a0 += (double)d.x + (double)d.z;
-    a1 += (double)d.y + (double)d.w;
-  }
-  if ((rows & 1) && threadIdx.x == 0) {
-    a0 += dy[(rows - 1) * 2];
-    a1 += dy[(rows - 1) * 2 + 1];
-  }
-  sm[0][threadIdx.x] = a0;
-  sm[1][threadIdx.x] = a1;
-  __syncthreads();
-  for (int s = 512; s > 0; s >>= 1) {
-    if ((int)threadIdx.x < s) {
-      sm[0][threadIdx.x] += sm[0][threadIdx.x + s];
-      sm[1][threadIdx.x] += sm[1][threadIdx.x + s];
-    }
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) {
-    db[0] = (float)sm[0][0];
-    db[1] = (float)sm[1][0];
-  }
 }
 }  // namespace mliis
 
@@ -1167,9 +1177,7 @@ extern "C" int mliis_final_conv_bwd_filter(const float* x, int ldx, const float*
   ColGeom g;
   int rc = launch_colreduce(op, rows, C, 1, ws, ws_floats, stream, &g, "final_conv_bwd_filter");
   if (rc) return rc;
-  hipLaunchKernelGGL(final_dw_finalize_k, dim3(ceil_div(C, kFoldX), 2), dim3(kFoldX, kFoldY), 0, stream, ws, g.nblk, C, dw);
+  hipLaunchKernelGGL(final_dw_finalize_k, dim3(ceil_div(C, kFoldX), 3), dim3(kFoldX, kFoldY), 0, stream, ws, g.nblk, C, dw, dy, rows, db);
   MLIIS_CHECK_LAUNCH("final_dw_finalize");
-  hipLaunchKernelGGL(sum2_k, dim3(1), dim3(1024), 0, stream, dy, rows, db);
-  MLIIS_CHECK_LAUNCH("final_db");
   return MLIIS_OK;
 }

@@ -222,8 +222,8 @@ __global__ __launch_bounds__(256) void ce_partial_k(const float* __restrict__ lo
 // out: [0] loss, [1] ce, [2] iou ; coef[n] = {A_n, B_n} for the dice gradient (0 when dice off).  One block: 8 images at a time,
 // 32 lanes per image fold that image's partial blocks (double precision), a lane butterfly finishes the image, thread 0 adds the
 // images up in index order (fixed order: deterministic).
-__global__ __launch_bounds__(256) void ce_finalize_k(const float* __restrict__ part, int nblk, int N, int HW, int dice, float extra_loss,
-                                                     float* __restrict__ out, float* __restrict__ coef) {
+__device__ __forceinline__ void ce_finalize(const float* __restrict__ part, int nblk, int N, int HW, int dice, float extra_loss,
+                                            float* __restrict__ out, float* __restrict__ coef) {
   __shared__ double s_ce[8], s_iou[8];
   double ce = 0.0, iou = 0.0;
   const double eps = 1e-7;
@@ -277,15 +277,24 @@ __global__ __launch_bounds__(256) void ce_finalize_k(const float* __restrict__ p
   out[2] = (float)iou;
 }
 
+__global__ __launch_bounds__(256) void ce_finalize_k(const float* __restrict__ part, int nblk, int N, int HW, int dice, float extra_loss,
+                                                     float* __restrict__ out, float* __restrict__ coef) {
+  ce_finalize(part, nblk, N, HW, dice, extra_loss, out, coef);
+}
+
+// fin_part != nullptr (no dice term: the gradient needs nothing from the finalize step): workgroup (0, 0) also folds the loss partials
+// into out[] before its share of the gradient -- one launch fewer than ce_partial -> ce_finalize -> ce_grad.
 __global__ __launch_bounds__(256) void ce_grad_k(const float* __restrict__ logits, const float* __restrict__ labels,
                                                  const int* __restrict__ idx, int HW, float ls, float inv_rows,
                                                  const float* __restrict__ coef, float* __restrict__ dlogits,
-                                                 float* __restrict__ pred) {
+                                                 float* __restrict__ pred, const float* __restrict__ fin_part, int fin_nblk, int N,
+                                                 float extra_loss, float* __restrict__ fin_out, float* __restrict__ fin_coef) {
+  if (fin_part != nullptr && blockIdx.x == 0 && blockIdx.y == 0) ce_finalize(fin_part, fin_nblk, N, HW, 0, extra_loss, fin_out, fin_coef);
   const int n = blockIdx.y;
   const int src = idx ? idx[n] : n;
   const float* z = logits + (long long)n * HW * 2;
   const float* t = labels + (long long)src * HW * 2;
-  const float An = coef[2 * n], Bn = coef[2 * n + 1];
+  const float An = fin_part != nullptr ? 0.f : coef[2 * n], Bn = fin_part != nullptr ? 0.f : coef[2 * n + 1];
   for (int p = blockIdx.x * 256 + threadIdx.x; p < HW; p += gridDim.x * 256) {
     const float2 zz = *reinterpret_cast<const float2*>(z + (long long)p * 2);
     const float2 tt = *reinterpret_cast<const float2*>(t + (long long)p * 2);
@@ -520,12 +529,15 @@ int mliis_softmax_ce(const float* logits, const float* labels, const int* img_id
   float* coef = ws + (size_t)N * nblk * 4;
   hipLaunchKernelGGL(ce_partial_k, dim3(nblk, N), dim3(256), 0, stream, logits, labels, img_idx, HW, label_smoothing, ws);
   MLIIS_CHECK_LAUNCH("softmax_ce_partial");
-  hipLaunchKernelGGL(ce_finalize_k, dim3(1), dim3(256), 0, stream, ws, nblk, N, HW, dice, extra_loss, out, coef);
-  MLIIS_CHECK_LAUNCH("softmax_ce_finalize");
+  const bool merged = !dice && (dlogits || pred);   // (without the dice term the gradient does not depend on the finalize step)
+  if (!merged) {
+    hipLaunchKernelGGL(ce_finalize_k, dim3(1), dim3(256), 0, stream, ws, nblk, N, HW, dice, extra_loss, out, coef);
+    MLIIS_CHECK_LAUNCH("softmax_ce_finalize");
+  }
   if (dlogits || pred) {
     // one pixel per thread (the partial-sum pass above keeps its coarser grid: its block count is the finalize kernel's work)
     hipLaunchKernelGGL(ce_grad_k, dim3(ceil_div(HW, 256), N), dim3(256), 0, stream, logits, labels, img_idx, HW, label_smoothing,
-                       1.0f / ((float)N * (float)HW), coef, dlogits, pred);
+                       1.0f / ((float)N * (float)HW), coef, dlogits, pred, merged ? ws : nullptr, nblk, N, extra_loss, out, coef);
     MLIIS_CHECK_LAUNCH("softmax_ce_grad");
   }
   return MLIIS_OK;
