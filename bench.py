@@ -156,7 +156,9 @@ def roofline(L, args):
     reps_dom = 1
     ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
     traffic, tsrc = None, None
-    tpath = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+    if not os.path.exists(tpath):
+        tpath = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
     if os.path.exists(tpath):   # PMC counters cannot be sampled from inside this process: taken from the committed rocprofv3 --pmc passes
         tj = json.load(open(tpath))
         k = tj.get("kernels", {}).get(dom.replace(", ", ","))
@@ -165,8 +167,8 @@ def roofline(L, args):
             from pmc_traffic import csrc_sha1
             current = tj.get("csrc_sha1") == csrc_sha1()     # collected on exactly the kernel sources this run was built from?
             traffic = k["hbm_bytes_per_launch"]
-            tsrc = "profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950-corrected; %s)" % (
-                "collected on the current kernel sources" if current else "STALE: the kernel sources changed since it was collected")
+            tsrc = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950-corrected; %s)" % (
+                os.path.basename(tpath), "collected on the current kernel sources" if current else "STALE: the kernel sources changed since it was collected")
     peak = MFMA_F32_PEAK_TFLOPS if args.precision == "fp32" else MFMA_BF16_PEAK_TFLOPS
     out = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
            "traffic": traffic, "traffic_source": tsrc, "launches_per_step": d["n"] // reps_dom, "avg_launch_us": 1e3 * d["ms"] / d["n"],

@@ -301,6 +301,7 @@ class Learner:
         self.rsd_bn_pair = os.environ.get("MLIIS_RSD_BN_PAIR", "1") != "0"
         # the depthwise batch norm's backward apply inside the marching depthwise backward launch (MLIIS_DW_BWD_BN1=0: its own launch)
         self.dw_bwd_bn1 = os.environ.get("MLIIS_DW_BWD_BN1", "1") != "0"
+        self.dw_bwd_bn1_k5s1 = os.environ.get("MLIIS_DW_BWD_BN1", "1") == "2"   # (5x5 stride 1: that instantiation spills: measured, see notes)
         self.use_graph = use_graph
         self.stream = torch.cuda.Stream(device=self.device)
         # Optional (overlap_wgrad = 1 | 2): weight-gradient GEMMs on a second stream forked inside the HIP graph, one by one (1) or
@@ -1085,7 +1086,7 @@ class Learner:
                     has_grad[bi - 1] = True
                 continue
             # bn1's backward apply inside the depthwise backward launch (its operands are staged there anyway; dz1 is never written)
-            fuse_bn1 = bool(B["march"] and bn1_stage1 is not None and self.dw_bwd_bn1 and not (b.k == 5 and b.stride == 1) and
+            fuse_bn1 = bool(B["march"] and bn1_stage1 is not None and self.dw_bwd_bn1 and (self.dw_bwd_bn1_k5s1 or not (b.k == 5 and b.stride == 1)) and
                             (b.expand != 1 or (bi == 0 and P.fuse_stem)))
             if not fuse_bn1:
                 bn_b(B["z1"], da2, B["st1"], nm["bn1"], da2, post=True, chan_scale=B["gate"], chan_add=B["chan_add"], stage1=bn1_stage1)
