@@ -294,8 +294,10 @@ int mliis_se_mlp_fwd(const float* s_part, int chunks, float scale, float* s_out,
 /*      dw1 .. db2 all NULL: the weight gradients are left to mliis_se_wgrad_batched (one launch for every block of a backward pass;
  *      desc = device int64 [ndesc][12] {s, hpre, dpre1, dpre2, dw1, db1, dw2, db2 as device addresses, N, C, R, tile_begin}, a tile =
  *      256 of the 2*C*R + C + R gradient elements of a block, tile_begin = running sum of ceil(elements / 256)). */
+/*      w1t (nullable): w1 transposed to [R,C] (the shadow copy mliis_transpose_weights maintains): the last phase needs a column of w1
+ *      per channel, coalesced only from the transpose.  Same results either way. */
 int mliis_se_mlp_bwd(const float* dgate, int dgate_row_groups, const float* gate, const float* s, const float* hpre, const float* w1,
-                     const float* w2, float* dpre1, float* dpre2, float* chan_add, float* dw1, float* db1, float* dw2, float* db2, int N,
+                     const float* w1t, const float* w2, float* dpre1, float* dpre2, float* chan_add, float* dw1, float* db1, float* dw2, float* db2, int N,
                      int C, int R, int HW, hipStream_t stream);
 /*      The squeeze-excite backward and the depthwise batch norm's backward of an MBConv block (efficientnet_model.py:238-251,271) share
  *      ONE pass over (da2, z1): mliis_se_bn_bwd_sums leaves, per image and row chunk, part [N][*nblk][5][C] = {sum da2*a1, sum da2*s',
@@ -308,7 +310,7 @@ size_t mliis_se_bn_bwd_sums_floats(int N, int rows_per_img, int C);
 int mliis_se_bn_bwd_sums(const float* x, int ldx, const float* dy, int lddy, int N, int rows_per_img, int C, const float* mean,
                          const float* rstd, const float* gamma, const float* beta, float* part, size_t part_floats, int* nblk,
                          hipStream_t stream);
-int mliis_se_mlp_bwd_bn(const float* sums, int sums_nblk, const float* gate, const float* hpre, const float* w1, const float* w2,
+int mliis_se_mlp_bwd_bn(const float* sums, int sums_nblk, const float* gate, const float* hpre, const float* w1, const float* w1t, const float* w2,
                         float* dpre1, float* dpre2, float* chan_add, float* stage1, int N, int C, int R, int HW, hipStream_t stream);
 int mliis_se_wgrad_batched(const long long* desc, int ndesc, long long total_tiles, hipStream_t stream);
 /*      y0[m, c] (+)= x[m, c] + A[n(m), c] for c < c0 and y1[m, c - c0] (+)= the same for c >= c0: the gradient of a channel concat

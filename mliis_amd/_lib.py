@@ -68,10 +68,10 @@ SIGNATURES = {
     "mliis_bn_bwd_dxsum_floats": (_sz, [_ll, _i]),
     "mliis_colsum": (_i, [_p, _i, _p, _i, _ll, _i, _i, _f, _p, _i, _p, _sz, _p]),
     "mliis_se_mlp_fwd": (_i, [_p, _i, _f, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
-    "mliis_se_mlp_bwd": (_i, [_p, _i] + [_p] * 12 + [_i, _i, _i, _i, _p]),
+    "mliis_se_mlp_bwd": (_i, [_p, _i] + [_p] * 13 + [_i, _i, _i, _i, _p]),
     "mliis_se_bn_bwd_sums_floats": (_sz, [_i, _i, _i]),
     "mliis_se_bn_bwd_sums": (_i, [_p, _i, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _sz, _p, _p]),
-    "mliis_se_mlp_bwd_bn": (_i, [_p, _i] + [_p] * 8 + [_i, _i, _i, _i, _p]),
+    "mliis_se_mlp_bwd_bn": (_i, [_p, _i] + [_p] * 9 + [_i, _i, _i, _i, _p]),
     "mliis_se_wgrad_batched": (_i, [_p, _i, _ll, _p]),
     "mliis_chan_affine": (_i, [_p, _i, _p, _p, _p, _i, _ll, _i, _i, _i, _p]),
     "mliis_chan_split": (_i, [_p, _i, _p, _p, _i, _i, _i, _p, _i, _i, _ll, _i, _i, _p]),

@@ -32,6 +32,11 @@ __device__ __forceinline__ float dot_strided(const float* __restrict__ a, int sa
 // one workgroup per image.  The pooled vector arrives as `chunks` partial sums per image (s_part [N][chunks][C], from the epilogue
 // of the batch-norm apply that produced the activation, or chunks = 1 for a finished vector); phase 0 folds them (x scale) into LDS
 // and publishes s [N][C] for the backward pass.
+// FAST (C <= 1024, R <= 32, at most kSeFastDot phase-1 terms per thread: every layer of EfficientLab-6-3 / B0): the kernel is one latency
+// chain, so every weight a thread will need (its w1 column slice, its w2 column, the biases) is requested before phase 0 instead of
+// phase by phase -- the chain is one memory round trip + the three barriers.  Same summation order as the general form (bit-identical).
+constexpr int kSeFastDot = 24;
+template <bool FAST>
 __global__ __launch_bounds__(kSeThreads) void se_mlp_fwd_k(const float* __restrict__ s_part, int chunks, float scale,
                                                     float* __restrict__ s_out, const float* __restrict__ w1,
                                                     const float* __restrict__ b1, const float* __restrict__ w2,
@@ -42,6 +47,19 @@ __global__ __launch_bounds__(kSeThreads) void se_mlp_fwd_k(const float* __restri
   __shared__ float red2[8 * kMaxR];
   extern __shared__ float sn[];   // [C]
   const int n = blockIdx.x, t = threadIdx.x;
+  const int CL = kSeThreads / R;
+  const int j = t % R, cl = t / R;
+  const int cnt = (cl < CL && cl < C) ? (C - cl + CL - 1) / CL : 0;
+  float w1v[FAST ? kSeFastDot : 1], w2v[FAST ? 32 : 1], b1v = 0.f, b2v = 0.f;
+  if constexpr (FAST) {
+    const int cc = t < C ? t : C - 1;
+#pragma unroll
+    for (int i = 0; i < kSeFastDot; ++i) w1v[i] = w1[(long long)(cl + (i < cnt ? i : 0) * CL < C ? cl + (i < cnt ? i : 0) * CL : 0) * R + j];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) w2v[k] = w2[(long long)(k < R ? k : R - 1) * C + cc];
+    b1v = b1[t < R ? t : 0];
+    b2v = b2[cc];
+  }
   for (int c = t; c < C; c += kSeThreads) {
     const float* pp = s_part + ((long long)n * chunks) * C + c;
     float a = 0.f;
@@ -58,10 +76,13 @@ __global__ __launch_bounds__(kSeThreads) void se_mlp_fwd_k(const float* __restri
   }
   __syncthreads();
   // phase 1: h_j = b1[j] + sum_c s[c] * w1[c][j];  threads laid out (c-lane, j) so w1 reads are contiguous
-  const int CL = kSeThreads / R;
-  const int j = t % R, cl = t / R;
   float part = 0.f;
-  if (cl < CL && cl < C) part = dot_strided<8>(sn + cl, CL, w1 + (long long)cl * R + j, (long long)CL * R, (C - cl + CL - 1) / CL);
+  if constexpr (FAST) {
+#pragma unroll
+    for (int i = 0; i < kSeFastDot; ++i) part = fmaf(i < cnt ? sn[cl + i * CL] : 0.f, w1v[i], part);
+  } else {
+    if (cnt > 0) part = dot_strided<8>(sn + cl, CL, w1 + (long long)cl * R + j, (long long)CL * R, cnt);
+  }
   red[t] = part;
   __syncthreads();
   if (t < 8 * R) {   // two-level fold of the CL c-lanes: 8 groups, then 8 values (fixed order)
@@ -72,13 +93,22 @@ __global__ __launch_bounds__(kSeThreads) void se_mlp_fwd_k(const float* __restri
   }
   __syncthreads();
   if (t < R) {
-    float h = b1[t];
+    float h = FAST ? b1v : b1[t];
 #pragma unroll
     for (int g = 0; g < 8; ++g) h += red2[g * R + t];
     hpre[(long long)n * R + t] = h;
     sh[t] = swish_f(h);
   }
   __syncthreads();
+  if constexpr (FAST) {
+    if (t < C) {
+      float a = b2v;
+#pragma unroll
+      for (int k = 0; k < 32; ++k) a = fmaf(k < R ? sh[k] : 0.f, w2v[k], a);
+      gate[(long long)n * C + t] = sigmoid_f(a);
+    }
+    return;
+  }
   for (int c = t; c < C; c += kSeThreads) {
     float a = b2[c];
     for (int k = 0; k < R; k += 8) {
@@ -98,18 +128,126 @@ __global__ __launch_bounds__(kSeThreads) void se_mlp_fwd_k(const float* __restri
 // [n * HW, (n + 1) * HW).  Its groups are folded here in group order (deterministic), all loads of eight groups issued together.
 // sums (nullable, [N][sums_nblk][5][C] from mliis_se_bn_bwd_sums): dgate = the image's chunks of value 0, folded here; values 1..4 and
 // the finished gate / chan_add give stage 1 of the depthwise batch norm's backward for this image, stage1 [N][2][C].
+// w1t (nullable): the [R][C] transpose of w1 (the learner's shadow copy, mliis_transpose_weights) -- the last phase reads a COLUMN of w1
+// per channel, which straight from w1 [C][R] is 64 different rows per wave load (measured: the launch's critical path at C = 672).
+// FAST (C <= 1024, R <= 32): one channel per thread; the w2 rows of this wave, the w1 column of this thread and hpre are requested
+// before the gate gradient is folded (the general form pays a round trip per batch of eight and one more per row for hpre), and an
+// image's chunk partials are folded by kSeThreads / C thread groups side by side (chunk b -> group b mod G, groups summed in order).
+template <bool FAST>
 __global__ __launch_bounds__(kSeThreads) void se_mlp_bwd_k(const float* __restrict__ dgate, int dgate_groups, int HW,
                                                     const float* __restrict__ gate,
                                                     const float* __restrict__ hpre, const float* __restrict__ w1,
+                                                    const float* __restrict__ w1t,
                                                     const float* __restrict__ w2, float* __restrict__ dpre2,
                                                     float* __restrict__ dpre1, float* __restrict__ chan_add, int C, int R,
                                                     float inv_hw, const float* __restrict__ sums, int sums_nblk,
                                                     float* __restrict__ stage1) {
   __shared__ float sd1[kMaxR];
-  extern __shared__ float sd2[];   // [C] (+ [4][C] with sums)
+  extern __shared__ float sd2[];   // [C] (+ [4][C] with sums; FAST: + [G][5][C] behind them)
   const int n = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
   float* d2 = dpre2 + (long long)n * C;
   const int g_lo = dgate_groups > 0 ? (n * HW) / 16 : 0, g_hi = dgate_groups > 0 ? ((n + 1) * HW - 1) / 16 : -1;
+  if constexpr (FAST) {
+    const int cc = t < C ? t : C - 1;
+    const float gte = gate[(long long)n * C + cc];
+    float w2v[2][16], w1v[32], hp[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int jj = wave + 16 * r < R ? wave + 16 * r : R - 1;
+      hp[r] = hpre[(long long)n * R + jj];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) w2v[r][u] = w2[(long long)jj * C + (lane + 64 * u < C ? lane + 64 * u : C - 1)];
+    }
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+      const int kk = k < R ? k : R - 1;
+      w1v[k] = w1t != nullptr ? w1t[(long long)kk * C + cc] : w1[(long long)cc * R + kk];
+    }
+    float dg = 0.f;
+    if (sums != nullptr) {
+      const int G = kSeThreads / C;
+      const int g = t / C, c = t - g * C;
+      float* scr = sd2 + 5 * C;
+      if (g < G) {
+        float p[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+        const float* base = sums + ((long long)n * sums_nblk) * 5 * C + c;
+        for (int b = g; b < sums_nblk; b += 4 * G) {
+          float v[4][5];
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int k = 0; k < 5; ++k) v[u][k] = base[((long long)(b + u * G < sums_nblk ? b + u * G : b) * 5 + k) * C];
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (b + u * G < sums_nblk) {
+#pragma unroll
+              for (int k = 0; k < 5; ++k) p[k] += v[u][k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 5; ++k) scr[(g * 5 + k) * C + c] = p[k];
+      }
+      __syncthreads();
+      if (t < C) {
+        float p[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int gg = 0; gg < G; ++gg) {
+#pragma unroll
+          for (int k = 0; k < 5; ++k) p[k] += scr[(gg * 5 + k) * C + t];
+        }
+        dg = p[0];
+#pragma unroll
+        for (int k = 1; k < 5; ++k) sd2[k * C + t] = p[k];
+      }
+    } else if (dgate_groups > 0) {
+      for (int k = g_lo; k <= g_hi; k += 16) {
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const int rg = k + u <= g_hi ? k + u : g_hi;
+          const int slot = rg * 16 >= n * HW ? 0 : 1;          // the group starts inside image n, or in the image before it
+          v[u] = dgate[((long long)rg * 2 + slot) * C + cc];
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) dg += k + u <= g_hi ? v[u] : 0.f;
+      }
+    } else {
+      dg = dgate[(long long)n * C + cc];
+    }
+    if (t < C) {
+      const float v = dg * gte * (1.f - gte);
+      d2[t] = v;
+      sd2[t] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int jj = wave + 16 * r;
+      if (jj < R) {
+        float p = 0.f;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) p = fmaf(lane + 64 * u < C ? sd2[lane + 64 * u] : 0.f, w2v[r][u], p);
+        p = wave_sum(p);
+        if (lane == 0) {
+          const float d = p * swish_grad_f(hp[r]);
+          sd1[jj] = d;
+          dpre1[(long long)n * R + jj] = d;
+        }
+      }
+    }
+    __syncthreads();
+    if (t < C) {
+      float a = 0.f;
+#pragma unroll
+      for (int k = 0; k < 32; ++k) a = fmaf(k < R ? sd1[k] : 0.f, w1v[k], a);
+      const float ca = a * inv_hw;
+      chan_add[(long long)n * C + t] = ca;
+      if (sums != nullptr) {   // {sum g, sum g xhat} of this image, g = (da2 * gate + chan_add) * swish'
+        stage1[((long long)n * 2 + 0) * C + t] = fmaf(gte, sd2[1 * C + t], ca * sd2[3 * C + t]);
+        stage1[((long long)n * 2 + 1) * C + t] = fmaf(gte, sd2[2 * C + t], ca * sd2[4 * C + t]);
+      }
+    }
+    return;
+  }
   for (int c = t; c < C; c += kSeThreads) {
     const float g = gate[(long long)n * C + c];
     float dg;
@@ -172,12 +310,14 @@ __global__ __launch_bounds__(kSeThreads) void se_mlp_bwd_k(const float* __restri
   }
   __syncthreads();
   for (int c = t; c < C; c += kSeThreads) {
-    const float* wr = w1 + (long long)c * R;
     float a = 0.f;
     for (int k = 0; k < R; k += 8) {
       float wv[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) wv[u] = wr[k + u < R ? k + u : R - 1];
+      for (int u = 0; u < 8; ++u) {
+        const int kk = k + u < R ? k + u : R - 1;
+        wv[u] = w1t != nullptr ? w1t[(long long)kk * C + c] : w1[(long long)c * R + kk];
+      }
 #pragma unroll
       for (int u = 0; u < 8; ++u) a = fmaf(k + u < R ? sd1[k + u] : 0.f, wv[u], a);
     }
@@ -317,8 +457,13 @@ int mliis_se_mlp_fwd(const float* s_part, int chunks, float scale, float* s_out,
   MLIIS_REQUIRE(s_part && w1 && b1 && w2 && b2 && hpre && gate, MLIIS_ERR_ARG, "se_mlp_fwd: null pointer");
   MLIIS_REQUIRE(N > 0 && C > 0 && C <= 8192 && R > 0 && R <= kMaxR && chunks > 0, MLIIS_ERR_ARG, "se_mlp_fwd: bad shape (R <= %d, C <= 8192)",
                 kMaxR);
-  hipLaunchKernelGGL(se_mlp_fwd_k, dim3(N), dim3(kSeThreads), (size_t)C * sizeof(float), stream, s_part, chunks, scale, s_out, w1, b1, w2, b2,
-                     hpre, gate, C, R);
+  const int CL = kSeThreads / R;
+  if (C <= kSeThreads && R <= 32 && (C + CL - 1) / CL <= kSeFastDot)
+    hipLaunchKernelGGL(se_mlp_fwd_k<true>, dim3(N), dim3(kSeThreads), (size_t)C * sizeof(float), stream, s_part, chunks, scale, s_out, w1, b1, w2,
+                       b2, hpre, gate, C, R);
+  else
+    hipLaunchKernelGGL(se_mlp_fwd_k<false>, dim3(N), dim3(kSeThreads), (size_t)C * sizeof(float), stream, s_part, chunks, scale, s_out, w1, b1, w2,
+                       b2, hpre, gate, C, R);
   MLIIS_CHECK_LAUNCH("se_mlp_fwd");
   return MLIIS_OK;
 }
@@ -326,17 +471,21 @@ int mliis_se_mlp_fwd(const float* s_part, int chunks, float scale, float* s_out,
 // dgate[N,C] = sum_hw dy * x (mliis_colsum).  Produces dpre1 [N,R], dpre2 [N,C] (scratch kept for the weight gradients),
 // chan_add [N,C] = (dL/ds)/HW, and the four weight gradients.
 int mliis_se_mlp_bwd(const float* dgate, int dgate_row_groups, const float* gate, const float* s, const float* hpre, const float* w1,
-                     const float* w2, float* dpre1, float* dpre2, float* chan_add, float* dw1, float* db1, float* dw2, float* db2, int N,
+                     const float* w1t, const float* w2, float* dpre1, float* dpre2, float* chan_add, float* dw1, float* db1, float* dw2, float* db2, int N,
                      int C, int R, int HW, hipStream_t stream) {
   MLIIS_REQUIRE(dgate_row_groups == 0 || (HW >= 16 && (long long)dgate_row_groups * 16 >= (long long)N * HW), MLIIS_ERR_ARG,
                 "se_mlp_bwd: the row-group partials do not cover the N * HW rows (maps of at least 16 pixels)");
-  MLIIS_REQUIRE(dgate && gate && s && hpre && w1 && w2 && dpre1 && dpre2 && chan_add, MLIIS_ERR_ARG, "se_mlp_bwd: null pointer");
+  MLIIS_REQUIRE(dgate && gate && s && hpre && w1 && w2 && dpre1 && dpre2 && chan_add, MLIIS_ERR_ARG, "se_mlp_bwd: null pointer (w1t alone may be NULL)");
   MLIIS_REQUIRE((dw1 && db1 && dw2 && db2) || (!dw1 && !db1 && !dw2 && !db2), MLIIS_ERR_ARG,
                 "se_mlp_bwd: the four weight-gradient outputs come together (all NULL = deferred to mliis_se_wgrad_batched)");
   MLIIS_REQUIRE(N > 0 && C > 0 && R > 0 && R <= kMaxR && HW > 0, MLIIS_ERR_ARG, "se_mlp_bwd: bad shape");
   MLIIS_REQUIRE(C <= 8192, MLIIS_ERR_UNSUPPORTED, "se_mlp_bwd: C > 8192");
-  hipLaunchKernelGGL(se_mlp_bwd_k, dim3(N), dim3(kSeThreads), (size_t)C * sizeof(float), stream, dgate, dgate_row_groups, HW, gate, hpre, w1, w2,
-                     dpre2, dpre1, chan_add, C, R, 1.0f / (float)HW, nullptr, 0, nullptr);
+  if (C <= kSeThreads && R <= 32)
+    hipLaunchKernelGGL(se_mlp_bwd_k<true>, dim3(N), dim3(kSeThreads), (size_t)C * sizeof(float), stream, dgate, dgate_row_groups, HW, gate, hpre, w1,
+                       w1t, w2, dpre2, dpre1, chan_add, C, R, 1.0f / (float)HW, nullptr, 0, nullptr);
+  else
+    hipLaunchKernelGGL(se_mlp_bwd_k<false>, dim3(N), dim3(kSeThreads), (size_t)C * sizeof(float), stream, dgate, dgate_row_groups, HW, gate, hpre, w1,
+                       w1t, w2, dpre2, dpre1, chan_add, C, R, 1.0f / (float)HW, nullptr, 0, nullptr);
   MLIIS_CHECK_LAUNCH("se_mlp_bwd");
   if (dw1 == nullptr) return MLIIS_OK;
   int total = 2 * C * R + C + R;
@@ -348,12 +497,17 @@ int mliis_se_mlp_bwd(const float* dgate, int dgate_row_groups, const float* gate
 // The squeeze-excite backward fed by mliis_se_bn_bwd_sums (sums [N][sums_nblk][5][C]): the gate's gradient is folded from value 0, and
 // stage 1 of the depthwise batch norm's backward leaves as stage1 [N][2][C] for mliis_bn_bwd(chan_scale = gate, chan_add,
 // stage1_part = stage1, stage1_nblk = N).  The weight gradients are left to mliis_se_wgrad_batched.
-int mliis_se_mlp_bwd_bn(const float* sums, int sums_nblk, const float* gate, const float* hpre, const float* w1, const float* w2,
+int mliis_se_mlp_bwd_bn(const float* sums, int sums_nblk, const float* gate, const float* hpre, const float* w1, const float* w1t, const float* w2,
                         float* dpre1, float* dpre2, float* chan_add, float* stage1, int N, int C, int R, int HW, hipStream_t stream) {
   MLIIS_REQUIRE(sums && sums_nblk > 0 && gate && hpre && w1 && w2 && dpre1 && dpre2 && chan_add && stage1, MLIIS_ERR_ARG, "se_mlp_bwd_bn: null pointer");
   MLIIS_REQUIRE(N > 0 && C > 0 && C <= 8192 && R > 0 && R <= kMaxR && HW > 0, MLIIS_ERR_ARG, "se_mlp_bwd_bn: bad shape (R <= %d, C <= 8192)", kMaxR);
-  hipLaunchKernelGGL(se_mlp_bwd_k, dim3(N), dim3(kSeThreads), (size_t)5 * C * sizeof(float), stream, nullptr, 0, HW, gate, hpre, w1, w2, dpre2,
-                     dpre1, chan_add, C, R, 1.0f / (float)HW, sums, sums_nblk, stage1);
+  if (C <= kSeThreads && R <= 32)
+    hipLaunchKernelGGL(se_mlp_bwd_k<true>, dim3(N), dim3(kSeThreads), (size_t)(5 * C + 5 * kSeThreads) * sizeof(float), stream, nullptr, 0, HW, gate, hpre, w1,
+                       w1t, w2, dpre2,
+                       dpre1, chan_add, C, R, 1.0f / (float)HW, sums, sums_nblk, stage1);
+  else
+    hipLaunchKernelGGL(se_mlp_bwd_k<false>, dim3(N), dim3(kSeThreads), (size_t)5 * C * sizeof(float), stream, nullptr, 0, HW, gate, hpre, w1, w1t, w2, dpre2,
+                       dpre1, chan_add, C, R, 1.0f / (float)HW, sums, sums_nblk, stage1);
   MLIIS_CHECK_LAUNCH("se_mlp_bwd_bn");
   return MLIIS_OK;
 }

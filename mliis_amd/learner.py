@@ -330,9 +330,13 @@ class Learner:
         for p in A.trainable:
             if p.kind == "conv" and p.executed and "/se/" not in p.name and p.name not in (f"{fe}/stem/conv2d/kernel", "decode/final_layer_weights/kernel"):
                 desc.append([A.t_off[p.name], p.shape[0] * p.shape[1], p.shape[2], p.shape[3]])
+        n_dense = len(desc)
+        for p in A.trainable:   # the squeeze-excite reduce weights [C, R] too: the MLP's backward reads a column of them per channel
+            if p.kind == "conv" and p.executed and p.name.endswith("/se/conv2d/kernel"):
+                desc.append([A.t_off[p.name], 1, p.shape[2], p.shape[3]])
         self.wt_desc = torch.tensor(desc, dtype=torch.int32, device=self.device)
         # fp8 mode: max |w| of every dense-conv weight, refreshed by the same launch that refreshes the shadow copies
-        self.w_amax = torch.zeros(len(desc), dtype=torch.float32, device=self.device) if matmul_precision == "fp8" else None
+        self.w_amax = torch.zeros(len(desc), dtype=torch.float32, device=self.device) if matmul_precision == "fp8" else None   # ([:n_dense] used)
         self._amax_of = {}
         if self.w_amax is not None:
             names = [p.name for p in A.trainable if p.kind == "conv" and p.executed and "/se/" not in p.name and
@@ -1067,14 +1071,14 @@ class Learner:
                 # folds it and emits bn1's stage-1 sums per image -- no column-sum launch, no reduce pass of the batch norm
                 st1, p1 = B["st1"], nm["bn1"]
                 nbs = ops.se_bn_bwd_sums(B["z1"], da2, st1[0], st1[1], w[p1 + "/gamma"], w[p1 + "/beta"], P.sums_part)
-                ops.se_mlp_bwd_bn(P.sums_part, nbs, B["gate"], B["hpre"], w[se[0]], w[se[2]], hw, se_outs, P.stage1_se)
+                ops.se_mlp_bwd_bn(P.sums_part, nbs, B["gate"], B["hpre"], w[se[0]], w[se[2]], hw, se_outs, P.stage1_se, w1t=self.wt[se[0]])
                 bn1_stage1 = (P.stage1_se, N)
             else:
                 if not groups:
                     ops.colsum(da2, B["a1"], nseg=N, out=B["dgate"], ws=ws)
                 # (the SE weight gradients of all blocks are computed by one batched launch after the loop: P.se_desc)
                 ops.se_mlp_bwd(P.gate_part if groups else B["dgate"], B["gate"], B["s"], B["hpre"], w[se[0]], w[se[2]], hw, se_outs,
-                               dgate_groups=groups)
+                               dgate_groups=groups, w1t=self.wt[se[0]])
             if B["small"]:   # bn1 backward, depthwise filter gradient + backward-data, bn0 backward: one launch
                 da0, st0, st1, p0, p1 = B["da0"], B["st0"], B["st1"], nm["bn0"], nm["bn1"]
                 ops.mbconv_dw_bwd_small(da2, B["gate"], B["chan_add"], B["z1"], (st1[0], st1[1], w[p1 + "/gamma"], w[p1 + "/beta"]),

@@ -627,9 +627,10 @@ def se_wgrad_batched(desc, total_tiles):
     lib.call("mliis_se_wgrad_batched", _ptr(desc), int(desc.shape[0]), int(total_tiles), _stream())
 
 
-def se_mlp_bwd(dgate, gate, s, hpre, w1, w2, hw, outs=None, dgate_groups=0):
+def se_mlp_bwd(dgate, gate, s, hpre, w1, w2, hw, outs=None, dgate_groups=0, w1t=None):
     """outs without "dw1".."db2": the weight gradients are deferred to se_wgrad_batched.  dgate_groups > 0: `dgate` holds the
-    per-row-group partial sums of conv2d_bwd_data(gate=...) and the kernel folds them."""
+    per-row-group partial sums of conv2d_bwd_data(gate=...) and the kernel folds them.  w1t: w1 transposed to [R, C] (optional; the
+    kernel's last phase reads it coalesced)."""
     N, C_ = s.shape
     R = hpre.shape[1]
     dev = s.device
@@ -637,8 +638,8 @@ def se_mlp_bwd(dgate, gate, s, hpre, w1, w2, hw, outs=None, dgate_groups=0):
         outs = dict(dpre1=torch.empty((N, R), device=dev), dpre2=torch.empty((N, C_), device=dev), chan_add=torch.empty((N, C_), device=dev),
                     dw1=torch.empty((1, 1, C_, R), device=dev), db1=torch.empty(R, device=dev), dw2=torch.empty((1, 1, R, C_), device=dev),
                     db2=torch.empty(C_, device=dev))
-    lib.call("mliis_se_mlp_bwd", _ptr(dgate), int(dgate_groups), _ptr(gate), _ptr(s), _ptr(hpre), _ptr(w1), _ptr(w2), _ptr(outs["dpre1"]), _ptr(outs["dpre2"]),
-             _ptr(outs["chan_add"]), _ptr(outs.get("dw1")), _ptr(outs.get("db1")), _ptr(outs.get("dw2")), _ptr(outs.get("db2")), N, C_, R, hw,
+    lib.call("mliis_se_mlp_bwd", _ptr(dgate), int(dgate_groups), _ptr(gate), _ptr(s), _ptr(hpre), _ptr(w1), _ptr(w1t), _ptr(w2), _ptr(outs["dpre1"]),
+             _ptr(outs["dpre2"]), _ptr(outs["chan_add"]), _ptr(outs.get("dw1")), _ptr(outs.get("db1")), _ptr(outs.get("dw2")), _ptr(outs.get("db2")), N, C_, R, hw,
              _stream())
     return outs
 
@@ -659,13 +660,13 @@ def se_bn_bwd_sums_floats(N, rows_per_img, C_):
     return lib.size("mliis_se_bn_bwd_sums_floats", N, rows_per_img, C_)
 
 
-def se_mlp_bwd_bn(sums, nblk, gate, hpre, w1, w2, hw, outs, stage1):
+def se_mlp_bwd_bn(sums, nblk, gate, hpre, w1, w2, hw, outs, stage1, w1t=None):
     """se_mlp_bwd fed by se_bn_bwd_sums; also leaves stage 1 of the depthwise batch norm's backward in stage1 [N][2][C] (pass
     (stage1, N) to bn_bwd(stage1=...) together with chan_scale = gate and chan_add)."""
     N, C_ = gate.shape
     R = hpre.shape[1]
-    lib.call("mliis_se_mlp_bwd_bn", _ptr(sums), int(nblk), _ptr(gate), _ptr(hpre), _ptr(w1), _ptr(w2), _ptr(outs["dpre1"]), _ptr(outs["dpre2"]),
-             _ptr(outs["chan_add"]), _ptr(stage1), N, C_, R, hw, _stream())
+    lib.call("mliis_se_mlp_bwd_bn", _ptr(sums), int(nblk), _ptr(gate), _ptr(hpre), _ptr(w1), _ptr(w1t), _ptr(w2), _ptr(outs["dpre1"]),
+             _ptr(outs["dpre2"]), _ptr(outs["chan_add"]), _ptr(stage1), N, C_, R, hw, _stream())
     return outs
 
 

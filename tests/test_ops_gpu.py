@@ -257,7 +257,7 @@ def test_colsum_segments_and_product():
 
 
 # ------------------------------------------------------------------------------------------------ squeeze-excite
-@pytest.mark.parametrize("C,Rr,N,HW", [(32, 8, 3, 16), (96, 4, 2, 9), (672, 28, 2, 4), (144, 6, 5, 49)])
+@pytest.mark.parametrize("C,Rr,N,HW", [(32, 8, 3, 16), (96, 4, 2, 9), (672, 28, 2, 4), (144, 6, 5, 49), (1536, 64, 2, 16), (1000, 34, 2, 4)])
 def test_se(C, Rr, N, HW):
     from mliis_amd import ops
     d = dev()
@@ -280,6 +280,9 @@ def test_se(C, Rr, N, HW):
     close(ops.chan_affine(xg, S=gg), y, 2e-5, "se scale")
     dgate = ops.colsum(dyg, xg, nseg=N)
     o = ops.se_mlp_bwd(dgate, gg, sg, hp, f32(w1, d), f32(w2, d), HW)
+    ot = ops.se_mlp_bwd(dgate, gg, sg, hp, f32(w1, d), f32(w2, d), HW, w1t=f32(w1, d)[0, 0].t().contiguous())   # coalesced column reads
+    for k in o:
+        assert torch.equal(o[k], ot[k]), "se_mlp_bwd with the transposed w1: " + k
     close(o["dw1"], gw1, 1e-4, "dw1")
     close(o["db1"], gb1, 1e-4, "db1")
     close(o["dw2"], gw2, 1e-4, "dw2")
@@ -340,7 +343,7 @@ def test_batch_norm_pairs_equal_the_single_launches(rows, C):
         close(a_, b_.double().cpu(), 2e-6, "paired batch-norm backward")
 
 
-@pytest.mark.parametrize("C,Rr,N,HW", [(40, 10, 3, 196), (144, 6, 8, 3136), (24, 6, 2, 784), (96, 4, 8, 300), (32, 8, 2, 12544)])
+@pytest.mark.parametrize("C,Rr,N,HW", [(40, 10, 3, 196), (144, 6, 8, 3136), (24, 6, 2, 784), (96, 4, 8, 300), (32, 8, 2, 12544), (1152, 48, 2, 196)])
 def test_se_and_bn_backward_share_one_pass(C, Rr, N, HW):
     """mliis_se_bn_bwd_sums + mliis_se_mlp_bwd_bn + mliis_bn_bwd(stage1 = per-image sums, chan_scale, chan_add): the backward of
     z1 -> BN -> swish -> squeeze-excite -> (a1 * gate) (efficientnet_model.py:238-251,271) with ONE reduce pass over (da2, z1), against
@@ -372,6 +375,10 @@ def test_se_and_bn_backward_share_one_pass(C, Rr, N, HW):
     outs = dict(dpre1=torch.empty(N, Rr, device=d), dpre2=torch.empty(N, C, device=d), chan_add=torch.empty(N, C, device=d))
     stage1 = torch.empty(N, 2, C, device=d)
     ops.se_mlp_bwd_bn(part, nb, gateg, hpg, w1g, w2g, HW, outs, stage1)
+    outs_t = {k: torch.empty_like(v) for k, v in outs.items()}
+    stage1_t = torch.empty_like(stage1)
+    ops.se_mlp_bwd_bn(part, nb, gateg, hpg, w1g, w2g, HW, outs_t, stage1_t, w1t=w1g[0, 0].t().contiguous())
+    assert torch.equal(stage1, stage1_t) and all(torch.equal(outs[k], outs_t[k]) for k in outs), "se_mlp_bwd_bn with the transposed w1"
     dz = torch.empty_like(zg)
     dga, dbe = torch.empty(C, device=d), torch.empty(C, device=d)
     ops.bn_bwd(zg, dyg, mg, rg, gg, bg, post_swish=True, chan_scale=gateg, chan_add=outs["chan_add"], dx=dz, dgamma=dga, dbeta=dbe,
