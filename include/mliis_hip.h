@@ -217,12 +217,18 @@ int mliis_conv2d_bwd_filter_batched(const long long* desc, int nprob, int blocks
 /* ---- RSD pooled branch (models/efficientlab.py:192-197,220-224) without convolving it: the Cp spatially constant channels
  *      [c_begin, c_begin+Cp) of the 3x3 fuse conv's input become a per-image, per-border-class bias (forward) and need only
  *      per-image sums of the output gradient over the map, its border rows/columns and corners (backward).  tot[n][co] =
- *      per-image column sums of dz (mliis_colsum with nseg = N).  dpool = (dL/dpool) / (H*W). */
-size_t mliis_rsd_pool_fwd_workspace_floats(int N, int Co);
-int mliis_rsd_pool_fwd(const float* pool, const float* w, float* border_bias, int N, int Cp, int Cin_total, int c_begin, int Co, float* ws,
-                       size_t ws_floats, hipStream_t stream);
+ *      per-image column sums of dz -- an OUTPUT of mliis_rsd_pool_bwd (formed by its border-sum launch).  dpool = (dL/dpool) / (H*W).
+ *      mliis_rsd_concat_pool writes the module's input cat = [deep map, copied or bilinearly resized (efficientlab.py:205-206) | skip
+ *      feature] (tf.concat, efficientlab.py:208) and, in the same pass, the per-image column sums of cat in *chunks partials per image,
+ *      pool_part [N][*chunks][Cd+Cs]; mliis_rsd_pool_fwd folds them (pool = scale * sum; chunks = 1, scale = 1 for a finished vector),
+ *      keeps the folded vectors in pool_out (nullable) for the backward pass and forms the border-class bias -- one launch each. */
+size_t mliis_rsd_concat_pool_floats(int N, int H, int W, int C);
+int mliis_rsd_concat_pool(const float* deep, int ld_deep, int Hi, int Wi, int Cd, const float* skip, int ld_skip, int Cs, float* cat, int ldcat,
+                          int N, int H, int W, float* pool_part, size_t pool_part_floats, int* chunks, hipStream_t stream);
+int mliis_rsd_pool_fwd(const float* pool_part, int chunks, float scale, float* pool_out, const float* w, float* border_bias, int N, int Cp,
+                       int Cin_total, int c_begin, int Co, hipStream_t stream);
 size_t mliis_rsd_pool_bwd_workspace_floats(int N, int Co);
-int mliis_rsd_pool_bwd(const float* dz, int lddz, const float* tot, const float* pool, const float* w, float* dw, float* dbias,
+int mliis_rsd_pool_bwd(const float* dz, int lddz, float* tot, const float* pool, const float* w, float* dw, float* dbias,
                        float* dpool, int N, int H, int W, int Cp, int Cin_total, int c_begin, int Co, float* ws, size_t ws_floats,
                        hipStream_t stream);
 

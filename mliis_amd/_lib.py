@@ -45,8 +45,9 @@ SIGNATURES = {
     "mliis_conv2d_plan": (_i, [_i, _i, _i, _i, _i, _i, _p, _p, _p]),
     "mliis_conv2d_kernel_name": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _p, _sz]),
     "mliis_conv2d_fwd": (_i, [_p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _p, _sz, _i, _f, _p, _p]),
-    "mliis_rsd_pool_fwd_workspace_floats": (_sz, [_i, _i]),
-    "mliis_rsd_pool_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _sz, _p]),
+    "mliis_rsd_concat_pool_floats": (_sz, [_i, _i, _i, _i]),
+    "mliis_rsd_concat_pool": (_i, [_p, _i, _i, _i, _i, _p, _i, _i, _p, _i, _i, _i, _i, _p, _sz, _p, _p]),
+    "mliis_rsd_pool_fwd": (_i, [_p, _i, _f, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "mliis_rsd_pool_bwd_workspace_floats": (_sz, [_i, _i]),
     "mliis_rsd_pool_bwd": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _p]),
     "mliis_transpose_weights": (_i, [_p, _p, _p, _i, _p, _p]),

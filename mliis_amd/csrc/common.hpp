@@ -44,6 +44,16 @@ __device__ __forceinline__ float swish_grad_f(float x) {
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+// source row/column pair and weight of one output coordinate of tf.image.resize_images(BILINEAR, align_corners=True)
+// (scale = (in - 1) / (out - 1)); head.hip's resize kernels and rsd.hip's concat share it
+__device__ __forceinline__ void src_coord(int o, float scale, int in_size, int& i0, int& i1, float& l) {
+  const float f = (float)o * scale;
+  i0 = (int)floorf(f);
+  if (i0 > in_size - 1) i0 = in_size - 1;
+  i1 = i0 + 1 < in_size ? i0 + 1 : in_size - 1;
+  l = f - (float)i0;
+}
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float4 f4mul(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }

@@ -28,14 +28,6 @@ __device__ __forceinline__ float4 vzero<float4>() { return make_float4(0.f, 0.f,
 template <>
 __device__ __forceinline__ float2 vzero<float2>() { return make_float2(0.f, 0.f); }
 
-__device__ __forceinline__ void src_coord(int o, float scale, int in_size, int& i0, int& i1, float& l) {
-  const float f = (float)o * scale;
-  i0 = (int)floorf(f);
-  if (i0 > in_size - 1) i0 = in_size - 1;
-  i1 = i0 + 1 < in_size ? i0 + 1 : in_size - 1;
-  l = f - (float)i0;
-}
-
 template <int V>
 __global__ __launch_bounds__(256) void resize_fwd_k(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy, int N,
                                                     int Hi, int Wi, int Ho, int Wo, int C, float sh, float sw) {

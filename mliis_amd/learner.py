@@ -91,6 +91,7 @@ class _Plan:
             D["st0"], D["st1"], D["stf"] = vec(m.c_out), vec(m.c_out), vec(m.c_out)
             D["pyr"] = buf(N, h, h, 2 * m.c_out)        # the pooled third of the reference's "pyramid" is never materialised
             D["pool"], D["dpool"] = buf(N, m.c_cat), buf(N, m.c_cat)
+            D["pool_part"] = buf(max(1, ops.rsd_concat_pool_floats(N, h, h, m.c_cat)))
             D["bbias"], D["tot"] = buf(N, 9, m.c_out), buf(N, m.c_out)
             D["out"], D["dout"] = buf(N, h, h, m.c_out), buf(N, h, h, m.c_out)
             D["dzf"], D["dpyr"], D["dcat"] = buf(N, h, h, m.c_out), buf(N, h, h, 2 * m.c_out), buf(N, h, h, m.c_cat)
@@ -769,11 +770,16 @@ class Learner:
             skip = ends[r]
             cat = D["cat"]
             up = cat[..., :m.c_deep]
-            if m.h_in == m.h:
-                ops.chan_affine(dec, out=up)
+            # the concat of the (resized) deep map and the skip feature, and the pooled branch's per-image sums of it: one launch
+            pool_chunks = 0
+            if m.c_deep % 4 == 0 and (m.c_cat - m.c_deep) % 4 == 0 and m.h > 1:
+                pool_chunks = ops.rsd_concat_pool(dec, skip, cat, D["pool_part"])
             else:
-                ops.resize_bilinear_fwd(dec, (m.h, m.h), out=up)
-            ops.chan_affine(skip, out=cat[..., m.c_deep:])
+                if m.h_in == m.h:
+                    ops.chan_affine(dec, out=up)
+                else:
+                    ops.resize_bilinear_fwd(dec, (m.h, m.h), out=up)
+                ops.chan_affine(skip, out=cat[..., m.c_deep:])
             res_up = up
             if m.upsample_conv:   # the residual operand through its own conv -> swish -> BN branch; the concat keeps the resized map
                 ku, bu, nu = self.n_rsd_up[j_rsd]
@@ -799,8 +805,11 @@ class Learner:
                 nb = conv(cat, k1, b1, 2, D["z1"], True)
                 bn(D["z1"], D["st1"], n1, pyr[..., m.c_out:2 * m.c_out], pre=True, fused=True, nblk=nb)
             # pooled branch: per-image mean of `cat`, folded into the fuse conv as a border-class bias (rsd.hip)
-            ops.colsum(cat, None, nseg=N, scale=1.0 / (m.h * m.h), out=D["pool"], ws=ws)
-            ops.rsd_pool_fwd(D["pool"], w[kf], 2 * m.c_out, out=D["bbias"], ws=ws)
+            if pool_chunks:
+                ops.rsd_pool_fwd(D["pool_part"], w[kf], 2 * m.c_out, out=D["bbias"], chunks=pool_chunks, scale=1.0 / (m.h * m.h), pool_out=D["pool"])
+            else:
+                ops.colsum(cat, None, nseg=N, scale=1.0 / (m.h * m.h), out=D["pool"], ws=ws)
+                ops.rsd_pool_fwd(D["pool"], w[kf], 2 * m.c_out, out=D["bbias"])
             nb = conv(pyr, kf, bf, 1, D["zf"], True, border_bias=D["bbias"])
             dec = bn(D["zf"], D["stf"], nf, D["out"], pre=True, res=res_up, fused=True, nblk=nb)
         mask = P.drop_mask if (training and P.drop_mask is not None) else None
@@ -936,7 +945,6 @@ class Learner:
             co, hw = m.c_out, m.h * m.h
             dO, cat, pyr, dpyr, dcat = D["dout"], D["cat"], D["pyr"], D["dpyr"], D["dcat"]
             bn_b(D["zf"], dO, D["stf"], nf, D["dzf"], pre=True)
-            ops.colsum(D["dzf"], None, nseg=N, out=D["tot"], ws=ws)
             ops.rsd_pool_bwd(D["dzf"], D["tot"], D["pool"], w[kf], 2 * co, dw=g[kf], dbias=g[bf], dpool=D["dpool"], ws=ws)
             wgrad_conv(pyr, D["dzf"], 3, 1, kf)   # rows of the 2*co convolved channels
             self._conv_bwd_data(D["dzf"], w[kf], 1, ci_begin=0, ci_count=2 * co, out=dpyr, ws=ws)

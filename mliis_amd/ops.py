@@ -457,18 +457,34 @@ class FilterBatch:
         return sum(len(v) for v in self.groups.values())
 
 
-def rsd_pool_fwd(pool, w, c_begin, out=None, ws: Optional[Workspace] = None):
-    """border-class bias [N,9,Cout] of the constant channels [c_begin, c_begin+Cp) of a 3x3 conv with weights w."""
-    N, Cp = pool.shape
+def rsd_concat_pool(deep, skip, cat, pool_part):
+    """cat = [deep (copied, or bilinearly resized to cat's map) | skip] and the per-image column sums of cat as chunk partials in
+    pool_part; returns the chunk count (feed pool_part, chunks and scale = 1 / (H W) to rsd_pool_fwd)."""
+    N, H, W = cat.shape[:3]
+    _, Cd, ldd = rows_ld(deep)
+    _, Cs, lds = rows_ld(skip)
+    ch = C.c_int(0)
+    lib.call("mliis_rsd_concat_pool", _ptr(_chk(deep)), ldd, deep.shape[1], deep.shape[2], Cd, _ptr(_chk(skip)), lds, Cs, _ptr(cat), rows_ld(cat)[2],
+             N, H, W, _ptr(pool_part), pool_part.numel(), C.byref(ch), _stream())
+    return ch.value
+
+
+def rsd_concat_pool_floats(N, H, W, C_):
+    return lib.size("mliis_rsd_concat_pool_floats", N, H, W, C_)
+
+
+def rsd_pool_fwd(pool, w, c_begin, out=None, chunks=1, scale=1.0, pool_out=None):
+    """border-class bias [N,9,Cout] of the constant channels [c_begin, c_begin+Cp) of a 3x3 conv with weights w.  pool [N, Cp], or
+    (chunks > 1) the chunk partials [N, chunks, Cp] of rsd_concat_pool with their scale; pool_out [N, Cp] keeps the folded vectors."""
+    N, Cp = (pool.shape[0], pool.shape[-1]) if pool_out is None else pool_out.shape   # (the partials may arrive as a flat buffer)
     _, _, Cin_total, Co = w.shape
     out = torch.empty((N, 9, Co), dtype=torch.float32, device=pool.device) if out is None else out
-    ws = ws or default_ws()
-    buf = ws.get(lib.size("mliis_rsd_pool_fwd_workspace_floats", N, Co))
-    lib.call("mliis_rsd_pool_fwd", _ptr(pool), _ptr(w), _ptr(out), N, Cp, Cin_total, c_begin, Co, _ptr(buf), buf.numel(), _stream())
+    lib.call("mliis_rsd_pool_fwd", _ptr(pool), int(chunks), float(scale), _ptr(pool_out), _ptr(w), _ptr(out), N, Cp, Cin_total, c_begin, Co, _stream())
     return out
 
 
 def rsd_pool_bwd(dz, tot, pool, w, c_begin, dw, dbias=None, dpool=None, ws: Optional[Workspace] = None):
+    """tot [N, Co] is an OUTPUT (per-image column sums of dz, formed by the border-sum launch)."""
     N, H, W = dz.shape[:3]
     _, Co, lddz = rows_ld(dz)
     Cp = pool.shape[1]

@@ -638,18 +638,42 @@ def test_rsd_pooled_branch_as_border_bias(H, W, Cc, Cp, Co, N):
     xg, pg, wg, bg, dzg = f32(xc, d), f32(pool, d), f32(w, d), f32(b, d), f32(dz, d)
     wt = wg.permute(0, 1, 3, 2).contiguous().view(-1)
     E = ops.rsd_pool_fwd(pg, wg, Cc)
+    # the same vectors as chunk partials with a scale (what rsd_concat_pool hands over), folded by the launch
+    parts = torch.stack([f32(pool * a, d) for a in (0.5, 1.25, 0.25)], dim=1).contiguous()   # [N, 3, Cp], sum = 2 * pool
+    pool_out = torch.empty(N, Cp, device=d)
+    E2 = ops.rsd_pool_fwd(parts, wg, Cc, chunks=3, scale=0.5, pool_out=pool_out)
+    close(pool_out, pool.detach(), 1e-6, "folded pool")
+    close(E2, E.double().cpu(), 1e-5, "border bias from chunk partials")
     for kw in (dict(), dict(wt=wt)):
         close(ops.conv2d_fwd(xg, wg, bg, 1, border_bias=E, **kw), z, 2e-5, "fwd with border bias")
     dw = torch.full((3, 3, Cc + Cp, Co), float("nan"), device=d)
     db = torch.empty(Co, device=d)
-    tot = ops.colsum(dzg, None, nseg=N)
+    tot = torch.full((N, Co), float("nan"), device=d)   # an output: the per-image column sums of dz come from the border-sum launch
     dpool = ops.rsd_pool_bwd(dzg, tot, pg, wg, Cc, dw=dw, dbias=db)
+    close(tot, dz.sum(dim=(1, 2)), 1e-4, "per-image sums of dz")
     ops.conv2d_bwd_filter(xg, dzg, 3, 1, out=dw)
     assert not torch.isnan(dw).any()
     close(dw, gw, 1e-4, "dw (convolved + constant rows)")
     close(db, gb, 1e-4, "dbias")
     close(dpool * (H * W), gp, 1e-4, "dpool")
     close(ops.conv2d_bwd_data(dzg, wg, 1, ci_begin=0, ci_count=Cc), gx, 1e-4, "dx of the convolved channels")
+
+
+@pytest.mark.parametrize("N,Hi,H,Cd,Cs", [(8, 14, 14, 112, 112), (8, 14, 56, 112, 24), (3, 5, 9, 8, 4), (2, 7, 28, 40, 16), (2, 96, 96, 112, 24)])
+def test_rsd_concat_and_pooled_sums(N, Hi, H, Cd, Cs):
+    """mliis_rsd_concat_pool: cat = [deep copied / bilinearly resized (bit-identical to mliis_resize_bilinear_fwd) | skip] and the
+    per-image column sums of cat as chunk partials (models/efficientlab.py:192-197,205-208)."""
+    from mliis_amd import ops
+    d = dev()
+    deep, skip = f32(rnd(N, Hi, Hi, Cd, seed=75), d), f32(rnd(N, H, H, Cs, seed=76), d)
+    cat = torch.full((N, H, H, Cd + Cs), float("nan"), device=d)
+    part = torch.full((ops.rsd_concat_pool_floats(N, H, H, Cd + Cs) + 4,), 7.0, device=d)
+    chunks = ops.rsd_concat_pool(deep, skip, cat, part)
+    assert chunks >= 1 and N * chunks * (Cd + Cs) == part.numel() - 4 and (part[-4:] == 7.0).all()
+    ref_up = deep if Hi == H else ops.resize_bilinear_fwd(deep, (H, H))
+    assert torch.equal(cat[..., :Cd], ref_up) and torch.equal(cat[..., Cd:], skip)
+    sums = part[:-4].view(N, chunks, Cd + Cs).double().sum(1).cpu()
+    close(sums, cat.double().sum(dim=(1, 2)).cpu(), 1e-5, "per-image column sums of the concat")
 
 
 # ------------------------------------------------------------------------------------------------ batched slab fold
