@@ -25,14 +25,15 @@ __device__ __forceinline__ float4 f4sfma(float s, float4 a, float4 c) {
 // The RSD module's input: cat[n,h,w,:] = [deep map (copied, or bilinearly resized to HxW: efficientlab.py:205-206) | skip feature]
 // (tf.concat, efficientlab.py:208) written in ONE pass that also leaves the per-image column sums of what it wrote -- the pooled
 // branch's spatial mean (efficientlab.py:192-197) -- as `chunks` partials per image, part [N][chunks][Cd + Cs].
-// grid (chunks, N); thread = (channel quad, pixel lane); four pixels in flight per thread.
+// grid (chunks, N); thread = (channel quad, pixel lane) of a 1024-thread workgroup; four pixels in flight per thread.
+constexpr int kCatThreads = 1024;
 template <bool RESIZE>
-__global__ __launch_bounds__(256) void rsd_concat_pool_k(const float* __restrict__ deep, int ld_deep, int Hi, int Wi, int Cd,
+__global__ __launch_bounds__(kCatThreads) void rsd_concat_pool_k(const float* __restrict__ deep, int ld_deep, int Hi, int Wi, int Cd,
                                                          const float* __restrict__ skip, int ld_skip, int Cs, float* __restrict__ cat, int ldcat,
                                                          int H, int W, float sh, float sw, int chunks, float* __restrict__ part) {
-  __shared__ float4 red[256];
+  __shared__ float4 red[kCatThreads];
   const int C = Cd + Cs, Q = C >> 2;
-  const int RL = 256 / Q;
+  const int RL = kCatThreads / Q;
   const int t = threadIdx.x, rl = t / Q, q = t - rl * Q;
   const int n = blockIdx.y, HW = H * W;
   const int ppc = (HW + chunks - 1) / chunks;
@@ -106,6 +107,24 @@ __global__ __launch_bounds__(kRsdThreads) void rsd_pool_fwd_k(const float* __res
   float* red = dyn + (size_t)N * Cp;
   const int cls = blockIdx.x, n0 = blockIdx.y * 16;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int col = t & 15, cl = t >> 4;
+  const int co = n0 + col < Co ? n0 + col : Co - 1;
+  const int rc = cls / 3, cc = cls - rc * 3;
+  // the class-summed weights of this thread's first four channels (Cp <= 256: all of them) are requested before the pooled sums are
+  // folded: the launch is one latency chain, and the weights do not depend on the data
+  float wsum[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = cl + 64 * i < Cp ? cl + 64 * i : Cp - 1;
+    float wt[9], ws = 0.f;   // all nine taps fetched together (valid addresses either way), the excluded ones weighted by zero
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp) wt[tp] = w[((long long)tp * Cin_total + c_begin + c) * Co + co];
+#pragma unroll
+    for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+      for (int tx = 0; tx < 3; ++tx) ws += (tap_valid(ty, rc) && tap_valid(tx, cc)) ? wt[ty * 3 + tx] : 0.f;
+    wsum[i] = ws;
+  }
   for (int i = t; i < N * Cp; i += kRsdThreads) {
     const int n = i / Cp, c = i - n * Cp;
     const float* pp = part + ((long long)n * chunks) * Cp + c;
@@ -122,14 +141,20 @@ __global__ __launch_bounds__(kRsdThreads) void rsd_pool_fwd_k(const float* __res
     if (pool_out != nullptr && blockIdx.x == 0 && blockIdx.y == 0) pool_out[i] = a;
   }
   __syncthreads();
-  const int col = t & 15, cl = t >> 4;
-  const int co = n0 + col < Co ? n0 + col : Co - 1;
-  const int rc = cls / 3, cc = cls - rc * 3;
   float a[kRsdMaxN];
 #pragma unroll
   for (int n = 0; n < kRsdMaxN; ++n) a[n] = 0.f;
-  for (int c = cl; c < Cp; c += 64) {
-    float wt[9], ws = 0.f;   // all nine taps fetched together (valid addresses either way), the excluded ones weighted by zero
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = cl + 64 * i;
+    if (c < Cp) {
+#pragma unroll
+      for (int n = 0; n < kRsdMaxN; ++n)
+        if (n < N) a[n] = fmaf(sp[n * Cp + c], wsum[i], a[n]);
+    }
+  }
+  for (int c = cl + 256; c < Cp; c += 64) {
+    float wt[9], ws = 0.f;
 #pragma unroll
     for (int tp = 0; tp < 9; ++tp) wt[tp] = w[((long long)tp * Cin_total + c_begin + c) * Co + co];
 #pragma unroll
@@ -303,19 +328,19 @@ size_t mliis_rsd_concat_pool_floats(int N, int H, int W, int C) {
 int mliis_rsd_concat_pool(const float* deep, int ld_deep, int Hi, int Wi, int Cd, const float* skip, int ld_skip, int Cs, float* cat, int ldcat,
                           int N, int H, int W, float* pool_part, size_t pool_part_floats, int* chunks, hipStream_t stream) {
   MLIIS_REQUIRE(deep && skip && cat && pool_part && chunks, MLIIS_ERR_ARG, "rsd_concat_pool: null pointer");
-  MLIIS_REQUIRE(N > 0 && N < 65536 && H > 1 && W > 1 && Hi > 0 && Wi > 0 && Cd > 0 && Cs > 0 && (Cd & 3) == 0 && (Cs & 3) == 0 && Cd + Cs <= 1024 &&
+  MLIIS_REQUIRE(N > 0 && N < 65536 && H > 1 && W > 1 && Hi > 0 && Wi > 0 && Cd > 0 && Cs > 0 && (Cd & 3) == 0 && (Cs & 3) == 0 && Cd + Cs <= 4 * kCatThreads &&
                     ld_deep >= Cd && ld_skip >= Cs && ldcat >= Cd + Cs && ((ld_deep | ld_skip | ldcat) & 3) == 0,
-                MLIIS_ERR_ARG, "rsd_concat_pool: bad shape (channel counts and leading dimensions multiples of 4, Cd + Cs <= 1024)");
+                MLIIS_ERR_ARG, "rsd_concat_pool: bad shape (channel counts and leading dimensions multiples of 4, Cd + Cs <= 4096)");
   MLIIS_REQUIRE(aligned16(deep) && aligned16(skip) && aligned16(cat) && aligned16(pool_part), MLIIS_ERR_ALIGN,
                 "rsd_concat_pool: pointers must be 16-byte aligned");
   const int ch = rsd_concat_chunks(H, W);
   MLIIS_REQUIRE((size_t)N * ch * (Cd + Cs) <= pool_part_floats, MLIIS_ERR_WORKSPACE, "rsd_concat_pool: pool_part too small");
   const float sh = (float)(Hi - 1) / (float)(H - 1), sw = (float)(Wi - 1) / (float)(W - 1);
   if (Hi == H && Wi == W)
-    hipLaunchKernelGGL(rsd_concat_pool_k<false>, dim3(ch, N), dim3(256), 0, stream, deep, ld_deep, Hi, Wi, Cd, skip, ld_skip, Cs, cat, ldcat, H, W, sh,
+    hipLaunchKernelGGL(rsd_concat_pool_k<false>, dim3(ch, N), dim3(kCatThreads), 0, stream, deep, ld_deep, Hi, Wi, Cd, skip, ld_skip, Cs, cat, ldcat, H, W, sh,
                        sw, ch, pool_part);
   else
-    hipLaunchKernelGGL(rsd_concat_pool_k<true>, dim3(ch, N), dim3(256), 0, stream, deep, ld_deep, Hi, Wi, Cd, skip, ld_skip, Cs, cat, ldcat, H, W, sh,
+    hipLaunchKernelGGL(rsd_concat_pool_k<true>, dim3(ch, N), dim3(kCatThreads), 0, stream, deep, ld_deep, Hi, Wi, Cd, skip, ld_skip, Cs, cat, ldcat, H, W, sh,
                        sw, ch, pool_part);
   MLIIS_CHECK_LAUNCH("rsd_concat_pool");
   *chunks = ch;
