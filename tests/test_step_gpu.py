@@ -2,6 +2,8 @@
 drop-connect masks.  Tolerances (fp32 vs fp64): loss rel 1e-4 per step, 1e-3 after 5 steps; gradients 2e-4 of the largest
 gradient entry per tensor (+1e-6 of the global max); parameters after the step 1e-5 abs; masks bit-exact wherever the oracle's logit margin
 exceeds 1e-3."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -679,7 +681,7 @@ def test_full_size_eight_step_task_config2():
 
 
 # ------------------------------------------------------------------------------------------------ reduced-precision configs
-def _lowp_step_check(name, H, N, precision, steps, loss_tol, cos_min, l2_max, later_loss_tol, seed=13):
+def _lowp_step_check(name, H, N, precision, steps, loss_tol, cos_min, l2_max, later_loss_tol, seed=13, vs_exact_factor=0.0):
     """One step of the HIP learner with reduced-precision matrix-core operands against the float64 oracle with the SAME operand
     rounding emulated (oracle/efficientlab_ref.py round_ops: every matrix-core conv multiplies rounded operands in the forward and in
     both backward products) and against the exact oracle.  The op-level tests pin the arithmetic bit-faithfully (tests/test_ops_gpu.py:
@@ -699,7 +701,7 @@ def _lowp_step_check(name, H, N, precision, steps, loss_tol, cos_min, l2_max, la
     lo_r, g_r, _ = R.inner_step(Or.a, Or.params, Or.bn, xd, yd, 1e-3, round_ops=precision)
     lo_x, g_x, _ = R.inner_step(Ox.a, Ox.params, Ox.bn, xd, yd, 1e-3)
     L.inner_step(idx)
-    ll = L.loss_value()
+    ll = ll0 = L.loss_value()
     gL = L.arena.export_grad_packed().cpu().double()
     flat = lambda g: torch.cat([g[p.name].reshape(-1) for p in L.arena.trainable])  # noqa: E731
     fr, fx = flat(g_r), flat(g_x)
@@ -708,11 +710,23 @@ def _lowp_step_check(name, H, N, precision, steps, loss_tol, cos_min, l2_max, la
     assert abs(ll - lo_r) <= loss_tol * abs(lo_r), (ll, lo_r)
     assert cos >= cos_min and l2_r <= l2_max, (cos, l2_r)
     assert l2_r < l2_x, (l2_r, l2_x)          # the rounding model explains the device result better than exact arithmetic does
+    worst = worst_rx = 0.0
     for step in range(1, steps):
         lo = Or.inner_step(xd[idx], yd[idx])
         L.inner_step(idx)
         ll = L.loss_value()
+        worst = max(worst, abs(ll - lo) / abs(lo))
+        if vs_exact_factor:   # the exact oracle's trajectory too: how far rounding ITSELF moves the loss of this step
+            lx = Ox.inner_step(xd[idx], yd[idx])
+            worst_rx = max(worst_rx, abs(lo - lx) / abs(lx))
+            if os.environ.get("MLIIS_TEST_VERBOSE"):
+                print("  step %2d: device %.5f  rounded oracle %.5f  exact oracle %.5f" % (step, ll, lo, lx))
         assert np.isfinite(ll) and abs(ll - lo) <= later_loss_tol * abs(lo), (step, ll, lo)
+    if vs_exact_factor:
+        print("worst |rounded - exact| / exact over the later steps: %.2e" % worst_rx)
+        assert worst <= vs_exact_factor * worst_rx, (worst, worst_rx)
+    print("%s %s %dx%d N=%d: first-step loss rel %.2e, gradient cosine %.5f, rel L2 %.3e; worst later-step loss rel %.2e over %d steps" % (
+        name, precision, H, H, N, abs(ll0 - lo_r) / abs(lo_r), cos, l2_r, worst, steps - 1))
     if steps > 2:
         assert L.plans[N].graph is not None
     L.close()
@@ -724,6 +738,17 @@ def test_config4_b3_bf16_operands_match_the_rounded_oracle():
     rounded oracle (4.2e-2 against the exact one)."""
     _need_gpu()
     _lowp_step_check("efficientnet-b3", 224, 8, "bf16", steps=2, loss_tol=5e-3, cos_min=0.998, l2_max=6e-2, later_loss_tol=5e-2)
+
+
+def test_config4_schedule_ten_shots_twenty_steps_bf16():
+    """BASELINE configs[3]'s schedule in full -- EfficientNet-B3, 10 shots, 20 inner steps, bf16 matrix-core operands, HIP-graph
+    replay from the third step on -- at 96x96 so that the float64 oracles finish in a minute (the 224x224 shapes are in the test
+    above).  From a random initialisation at lr 1e-3 the loss falls 22 -> 2.5 in these 20 steps and the trajectory is sensitive:
+    operand rounding ALONE moves a later step's loss by up to 26 % (rounded oracle vs exact oracle, both float64).  The bars are
+    therefore relative to that: the device stays within 2.5 x that distance of the rounded oracle at every step (measured 1.6 x:
+    worst step 42 %), first step as in the test above (loss 5e-4, gradient cosine 0.9991, relative L2 4.2e-2)."""
+    _need_gpu()
+    _lowp_step_check("efficientnet-b3", 96, 10, "bf16", steps=20, loss_tol=5e-3, cos_min=0.998, l2_max=6e-2, later_loss_tol=0.6, vs_exact_factor=2.5)
 
 
 def test_fp8_forward_activations_of_the_first_blocks_match_the_quantised_oracle():
