@@ -194,6 +194,9 @@ def roofline(L, args):
     #  over (dy, z): dx, filter-gradient slabs, stage 1 of bn0's backward.  Their mean / rstd outputs go to scratch in the re-issues)
     DW = {"mliis_dwconv_bn_fwd": ("dwconv_bn_fwd", 13, {0: "i", 12: "o"}, (7, 8)),
           "mliis_dwconv_bn_bwd": ("dwconv_bn_bwd", 9, {0: "o", 1: "i", 7: "i"}, ()),
+          # (the same pass with the depthwise batch norm's backward apply formed while (da2, z1) are staged: it ALSO reads z1, 4 * out
+          #  bytes that the depthwise formula below does not count -- its fraction is understated by that much)
+          "mliis_mbconv_dw_bwd_march": ("dwconv_bn_bwd", 19, {0: "o", 1: "o", 12: "i", 18: "i"}, ()),
           "mliis_dwconv_fwd": ("dwconv_fwd", 3, {0: "i", 2: "o"}, ()),
           "mliis_dwconv_bwd_data": ("dwconv_bwd_data", 3, {0: "o", 2: "i"}, ()),
           "mliis_dwconv_bwd_data_bn": ("dwconv_bwd_data", 3, {0: "o", 2: "i", 9: "i"}, ()),

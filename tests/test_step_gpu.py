@@ -66,6 +66,22 @@ def _compare_state(O, L, gO, tag):
         np.testing.assert_allclose(mvL[k + "/moving_variance"], mv.numpy(), rtol=1e-4, atol=1e-5, err_msg=tag + k)
 
 
+def _mask_check(pL, lgO, frac_margin, label, min_outside=None):
+    """Prediction masks: (softmax > 0.5) of the device against the oracle's.  fp32 logits cannot reproduce a float64 argmax at pixels
+    whose two logits are closer than the device's own rounding error, so equality is asserted OUTSIDE a margin of `frac_margin` of the
+    logit scale; the fraction of pixels inside the margin and the disagreements among them are reported (python -m pytest -s)."""
+    scale = lgO.abs().max().item()
+    outside = (lgO[..., 0] - lgO[..., 1]).abs() > frac_margin * scale
+    pO = R.predictions(lgO)
+    same = pL.cpu().double() == pO
+    inside = ~outside
+    print("%s: %.4f %% of %d pixels inside the %.0e margin, %d of them differ from the oracle's mask" % (
+        label, 100.0 * inside.double().mean().item(), inside.numel(), int((~same & inside).sum())))
+    if min_outside is not None:
+        assert outside.double().mean().item() > min_outside
+    assert bool(same[outside].all()), label
+
+
 @pytest.mark.parametrize("kw", [dict(), dict(l2=True, dice=True, label_smoothing=0.1), dict(l1=True, l2=True), dict(darc1=True)])
 def test_one_step_grads_params_bn(kw):
     _need_gpu()
@@ -119,9 +135,7 @@ def test_five_step_trajectory_and_masks():
         pL, lgL = L.predict(x, training=training, return_logits=True)
         scale = lgO.abs().max().item()
         assert (lgL.cpu().double() - lgO).abs().max().item() <= 2e-3 * scale
-        margin = (lgO[..., 0] - lgO[..., 1]).abs() > 1e-3 * scale
-        assert margin.float().mean().item() > 0.99
-        assert torch.equal(pL.cpu()[margin].double(), pO[margin])
+        _mask_check(pL, lgO, 1e-3, "five-step trajectory at 64x64, %s-mode masks" % ("training" if training else "inference"), min_outside=0.99)
         # integer path bit-exact: mask == threshold rule applied to the device's own logits
         own = (torch.softmax(lgL.cpu().double(), -1) > 0.5).float()
         tie = (lgL[..., 0] == lgL[..., 1]).cpu()
@@ -674,9 +688,7 @@ def test_full_size_eight_step_task_config2():
     pL, lgL = L.predict(x, training=False, return_logits=True)
     scale = lgO.abs().max().item()
     assert (lgL.cpu().double() - lgO).abs().max().item() <= 2e-3 * scale
-    margin = (lgO[..., 0] - lgO[..., 1]).abs() > 1e-3 * scale
-    assert margin.float().mean().item() > 0.99
-    assert torch.equal(pL.cpu()[margin].double(), R.predictions(lgO)[margin])
+    _mask_check(pL, lgO, 1e-3, "8-step task at 224x224, inference masks", min_outside=0.99)
     L.close()
 
 
