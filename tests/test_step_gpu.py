@@ -73,10 +73,10 @@ def _mask_check(pL, lgO, frac_margin, label, min_outside=None):
     scale = lgO.abs().max().item()
     outside = (lgO[..., 0] - lgO[..., 1]).abs() > frac_margin * scale
     pO = R.predictions(lgO)
-    same = pL.cpu().double() == pO
+    same = (pL.cpu().double() == pO).all(dim=-1)
     inside = ~outside
     print("%s: %.4f %% of %d pixels inside the %.0e margin, %d of them differ from the oracle's mask" % (
-        label, 100.0 * inside.double().mean().item(), inside.numel(), int((~same & inside).sum())))
+        label, 100.0 * inside.double().mean().item(), inside.numel(), frac_margin, int((~same & inside).sum())))
     if min_outside is not None:
         assert outside.double().mean().item() > min_outside
     assert bool(same[outside].all()), label
