@@ -240,8 +240,11 @@ static inline void plan_filter_split(FilterPlan& f, long long M, int C, int Nout
   }
   if (want < 1) want = 1;
   long long rps = (M + want - 1) / want;
-  if (rps < 128) rps = 128;   // (whole step on one box: 32 -> 2395, 64 -> 2404, 96 -> 2409, 128 -> 2416, 192 -> 2408, 256 -> 2406 images/s:
-                               //  fewer, longer slabs on the 14x14 layers also halve what the batched fold has to read)
+  // at least 256 pixel rows per slab.  (Round 1, every problem its own launch: 32 -> 2395, 64 -> 2404, 96 -> 2409, 128 -> 2416,
+  // 192 -> 2408, 256 -> 2406 images/s.  Round 3, the problems of a kernel instantiation batched into one grid -- the other problems'
+  // workgroups fill the chip, so the 14x14 layers' 13 slabs of 4 chunks each were mostly pipeline fill and slab traffic:
+  // 128 -> 3081, 192 -> 3104, 256 -> 3113-3122, 384 -> 3110, 512 -> 3104, 800 -> 3082, 1568 -> 2917 images/s.)
+  if (rps < 256) rps = 256;
   rps = (rps + 31) / 32 * 32;
   f.rows_per_split = (int)rps;
   f.gz = (int)((M + rps - 1) / rps);
@@ -258,6 +261,7 @@ static inline FilterPlan plan_filter(long long M, int C, int Nout, int ntaps, in
   if (f.multitap) f.tmf = ntaps * C > 64 ? 2 : 1;
   plan_filter_split(f, M, C, Nout, ntaps, num_cus);
   // small maps cannot be split further along the pixels (64 rows per slab): narrower tiles instead (latency-bound, see plan_gemm)
+  // (round 3, batched launches: thresholds of 0 .. 8 x num_cus blocks: 3033 / 3060 / 3086 / 3096 / 3117-3122 / 3119 / 3120 / 3125 images/s)
   while ((long long)f.gx * f.gy * f.gz < (long long)kFilterFill * num_cus && ((f.tmf == 2 && !f.multitap) || f.nt > 2)) {
     if (f.tmf == 2 && !f.multitap) f.tmf = 1;
     else f.nt = (f.nt + 1) / 2;
