@@ -309,7 +309,10 @@ static inline bool stream_plan(long long M, int K, int Nout, int num_cus, Stream
   // 4 -> 2447, 2 -> 2439 images/s: more column blocks = more waves in flight beats fewer re-reads of A.)
   int nt = 8 / sp->kc;
   if (nt < 1) nt = 1;
-  if (nt > 8) nt = 8;
+  // NT <= 4: the instances with 5-8 column tiles need 153-199 VGPRs, so only ONE 512-thread workgroup fits a CU and the grid of two per
+  // CU ran in two rounds (stamps build, round 3: the second half of the waves of the 16 -> 96 expand conv started 6-13 us after the
+  // first; 23 us per launch).  Two column blocks of NT = 3 (102 VGPRs) are all resident at once.
+  if (nt > 4) nt = 4;
   const int tiles = (Nout + 15) / 16;
   if (nt > tiles) nt = tiles;
   const int gy = (tiles + nt - 1) / nt;   // balanced column tiles: Nout = 144 -> 9 tiles -> 2 x NT 5 rather than NT 8 + a sliver
