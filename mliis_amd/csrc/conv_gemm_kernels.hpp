@@ -600,8 +600,13 @@ __global__ __launch_bounds__(1024) void sk_fixup_k(ConvGemmParams p, SkPlan k) {
 // four of a 256-thread block, so a launch leaves half as many partial blocks -- every workgroup of the consumer folds ALL of them.
 constexpr int kStreamWaves = 8;
 template <int KC, int NT, int PREC>
-__global__ __launch_bounds__(64 * kStreamWaves) void conv1x1_stream_k(ConvGemmParams p, int row_groups) {
+__global__ __launch_bounds__(64 * kStreamWaves, 4) void conv1x1_stream_k(ConvGemmParams p, int row_groups) {   // (4 waves per SIMD: <= 128 VGPRs, two workgroups per CU)
   __shared__ float red[kStreamWaves][2][16 * NT];
+  // per-wave staging tile of a finished row group, [16 rows][16 NT + 4]: the accumulators (C/D layout: a lane holds 4 rows x NT
+  // columns 64 bytes apart) leave as whole-row 16-byte stores -- a dword store of that layout is four 64-byte segments per instruction
+  // and the address path, not HBM, bound the large launches (stamps build, round 3: 3.2 us per row group in the store phase)
+  constexpr int SROW = 16 * NT + 4;
+  __shared__ __attribute__((aligned(16))) float stage[kStreamWaves][16 * SROW];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int l15 = lane & 15, g = lane >> 4;
   const int M = p.Nimg * p.H * p.W;                  // host guarantees < 2^31 and 32-bit byte offsets
@@ -711,7 +716,7 @@ __global__ __launch_bounds__(64 * kStreamWaves) void conv1x1_stream_k(ConvGemmPa
         for (int j = 0; j < NT; ++j) {
           const int n = n0 + j * 16 + l15;
           const float v = (PREC == 2 ? acc[j][r] * out_scale : acc[j][r]) + bj[j];
-          if (n < p.Nout) p.Cmat[(long long)m * p.ldc + n] = v;
+          stage[wave][(g * 4 + r) * SROW + j * 16 + l15] = v;
           if (gated_part && n < p.Nout) {
             const float pv = v * p.gp_x[(long long)m * p.gp_ldx + n];
             if (m < gp_bound) gp0[j] += pv;
@@ -730,6 +735,17 @@ __global__ __launch_bounds__(64 * kStreamWaves) void conv1x1_stream_k(ConvGemmPa
             s2[j] = fmaf(u, u, s2[j]);
           }
         }
+      }
+    }
+    {   // the staged tile -> memory, a float4 per lane and trip (the wave reads what it wrote itself: LDS is in order, no barrier)
+      constexpr int QN = 4 * NT;
+#pragma unroll
+      for (int u = 0; u < NT; ++u) {
+        const int e = lane + 64 * u;
+        const int row = e / QN, q4 = e - row * QN;
+        const int m = rg * 16 + row, n = n0 + q4 * 4;
+        const float4 v4 = ld4(&stage[wave][row * SROW + q4 * 4]);
+        if (m < M && n < p.Nout) st4(p.Cmat + (long long)m * p.ldc + n, v4);
       }
     }
     if (gated_part) {   // the four row quads of the group (lane groups g) folded; lanes g == 0 publish [rg][slot][column]
