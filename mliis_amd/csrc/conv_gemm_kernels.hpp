@@ -708,35 +708,50 @@ __global__ __launch_bounds__(64 * kStreamWaves, 4) void conv1x1_stream_k(ConvGem
 #pragma unroll
     for (int j = 0; j < NT; ++j) gp0[j] = gp1[j] = 0.f;
     const int gp_bound = gated_part ? ((rg * 16) / HWs + 1) * HWs : 0;   // first row of the image after the one this group starts in
+    // The extras of the epilogue are picked ONCE per row group by uniform branches and each form is straight-line code with
+    // predicated contributions (rows >= M / columns >= Nout add zeros; their side loads are clamped).  Testing the run-time flags per
+    // element cost ~30 instructions and four scalar branches for each of the 4 NT values of a lane: the launch was bound by
+    // instruction issue in its epilogue (stamps build, round 3: 1.9 us of a row group's 2.8 us).
+    // MODE 0: store only; 1: BN statistics; 2: statistics of swish(value); 3: stage 1 of the consumer BN's backward; 4: gate-gradient sums
+    auto epilogue = [&](auto mode_c) {
+      constexpr int MODE = decltype(mode_c)::value;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int m = rg * 16 + g * 4 + r;
-      if (m < M) {
+      for (int r = 0; r < 4; ++r) {
+        const int m = rg * 16 + g * 4 + r;
+        const bool rok = m < M;
+        const long long mcl = rok ? m : M - 1;
+        float rscale = 1.f;
+        if constexpr (MODE == 3) rscale = p.bnb_scale != nullptr ? p.bnb_scale[mcl / HWs] : 1.f;
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
           const int n = n0 + j * 16 + l15;
+          const bool cok = n < p.Nout;
+          const int ncl = cok ? n : p.Nout - 1;
           const float v = (PREC == 2 ? acc[j][r] * out_scale : acc[j][r]) + bj[j];
           stage[wave][(g * 4 + r) * SROW + j * 16 + l15] = v;
-          if (gated_part && n < p.Nout) {
-            const float pv = v * p.gp_x[(long long)m * p.gp_ldx + n];
-            if (m < gp_bound) gp0[j] += pv;
-            else gp1[j] += pv;
-          }
-          if (bnb) {   // stage 1 of the consumer batch norm's backward (mliis_conv2d_bwd_data_bn): {sum g, sum g * xhat}
-            if (n < p.Nout) {
-              const float gq = p.bnb_scale != nullptr ? v * p.bnb_scale[m / HWs] : v;
-              const float xh = (p.bnb_x[(long long)m * p.bnb_ldx + n] - bmean[j]) * brstd[j];
-              s1[j] += gq;
-              s2[j] = fmaf(gq, xh, s2[j]);
-            }
-          } else if (stats) {
-            const float u = p.stats_swish ? swish_f(v) : v;
+          if constexpr (MODE == 4) {
+            const float pv = (rok && cok) ? v * p.gp_x[mcl * p.gp_ldx + ncl] : 0.f;
+            gp0[j] += m < gp_bound ? pv : 0.f;
+            gp1[j] += m < gp_bound ? 0.f : pv;
+          } else if constexpr (MODE == 3) {   // (mliis_conv2d_bwd_data_bn): {sum g, sum g * xhat}
+            const float gq = (rok && cok) ? v * rscale : 0.f;
+            const float xh = (p.bnb_x[mcl * p.bnb_ldx + ncl] - bmean[j]) * brstd[j];
+            s1[j] += gq;
+            s2[j] = fmaf(gq, xh, s2[j]);
+          } else if constexpr (MODE == 1 || MODE == 2) {
+            const float u0 = MODE == 2 ? swish_f(v) : v;
+            const float u = rok ? u0 : 0.f;
             s1[j] += u;
             s2[j] = fmaf(u, u, s2[j]);
           }
         }
       }
-    }
+    };
+    if (bnb) epilogue(std::integral_constant<int, 3>{});
+    else if (gated_part) epilogue(std::integral_constant<int, 4>{});
+    else if (stats && p.stats_swish) epilogue(std::integral_constant<int, 2>{});
+    else if (stats) epilogue(std::integral_constant<int, 1>{});
+    else epilogue(std::integral_constant<int, 0>{});
     {   // the staged tile -> memory, a float4 per lane and trip (the wave reads what it wrote itself: LDS is in order, no barrier)
       constexpr int QN = 4 * NT;
 #pragma unroll
