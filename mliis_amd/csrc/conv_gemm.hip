@@ -313,6 +313,7 @@ static inline bool stream_plan(long long M, int K, int Nout, int num_cus, Stream
   // CU ran in two rounds (stamps build, round 3: the second half of the waves of the 16 -> 96 expand conv started 6-13 us after the
   // first; 23 us per launch).  Two column blocks of NT = 3 (102 VGPRs) are all resident at once.
   if (nt > 4) nt = 4;
+  if (sp->kc == 2 && nt > 3) nt = 3;   // (<2, 4> spills 11 registers at that budget)
   const int tiles = (Nout + 15) / 16;
   if (nt > tiles) nt = tiles;
   const int gy = (tiles + nt - 1) / nt;   // balanced column tiles: Nout = 144 -> 9 tiles -> 2 x NT 5 rather than NT 8 + a sliver

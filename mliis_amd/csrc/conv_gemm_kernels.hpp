@@ -673,6 +673,23 @@ __global__ __launch_bounds__(64 * kStreamWaves, 4) void conv1x1_stream_k(ConvGem
   load_a(rg, a_cur);
   for (; rg < row_groups; rg += stride) {
     load_a(rg + stride, a_nxt);
+    // the side operand of the gate-gradient / BN-backward epilogues (the element of gp_x / bnb_x beside each accumulator element, C/D
+    // layout) is requested here, under the MFMAs, not where it is used: one memory round trip per row group less
+    float side[4][NT];
+    if (gated_part || bnb) {   // (uniform)
+      const float* sx = gated_part ? p.gp_x : p.bnb_x;
+      const int sld = gated_part ? p.gp_ldx : p.bnb_ldx;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = rg * 16 + g * 4 + r;
+        const long long mcl = m < M ? m : M - 1;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const int n = n0 + j * 16 + l15;
+          side[r][j] = sx[mcl * sld + (n < p.Nout ? n : p.Nout - 1)];
+        }
+      }
+    }
     f32x4 acc[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -730,12 +747,12 @@ __global__ __launch_bounds__(64 * kStreamWaves, 4) void conv1x1_stream_k(ConvGem
           const float v = (PREC == 2 ? acc[j][r] * out_scale : acc[j][r]) + bj[j];
           stage[wave][(g * 4 + r) * SROW + j * 16 + l15] = v;
           if constexpr (MODE == 4) {
-            const float pv = (rok && cok) ? v * p.gp_x[mcl * p.gp_ldx + ncl] : 0.f;
+            const float pv = (rok && cok) ? v * side[r][j] : 0.f;
             gp0[j] += m < gp_bound ? pv : 0.f;
             gp1[j] += m < gp_bound ? 0.f : pv;
           } else if constexpr (MODE == 3) {   // (mliis_conv2d_bwd_data_bn): {sum g, sum g * xhat}
             const float gq = (rok && cok) ? v * rscale : 0.f;
-            const float xh = (p.bnb_x[mcl * p.bnb_ldx + ncl] - bmean[j]) * brstd[j];
+            const float xh = (side[r][j] - bmean[j]) * brstd[j];
             s1[j] += gq;
             s2[j] = fmaf(gq, xh, s2[j]);
           } else if constexpr (MODE == 1 || MODE == 2) {
@@ -879,6 +896,15 @@ __global__ __launch_bounds__(64 * WV) void conv1x1_ksplit_k(ConvGemmParams p, in
   load_a(rg, a_cur);
   for (; rg < row_groups; rg += gridDim.x) {
     load_a(rg + gridDim.x, a_nxt);
+    // what the finishing threads add to / read beside their float4 (the accumulate target, the BN input of the stage-1 sums) is
+    // requested here, under the MFMAs and the barrier, not after them: one memory round trip per row group less
+    float4 pre_dst = f4zero(), pre_x = f4zero();
+    {
+      const int mf = rg * 16 + frow;
+      const bool pok = fcol && mf < M;
+      if (p.accumulate && pok) pre_dst = ld4(p.Cmat + (long long)mf * p.ldc + fn);
+      if (bnb && pok) pre_x = ld4(p.bnb_x + (long long)mf * p.bnb_ldx + fn);
+    }
     f32x4 acc[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -922,10 +948,10 @@ __global__ __launch_bounds__(64 * WV) void conv1x1_ksplit_k(ConvGemmParams p, in
       for (int w = 1; w < WV; ++w) v = f4add(v, ld4(&red[w][frow][fq * 4]));
       v = f4add(v, fbias);
       float* dst = p.Cmat + (long long)m * p.ldc + fn;
-      if (p.accumulate) v = f4add(v, ld4(dst));
+      if (p.accumulate) v = f4add(v, pre_dst);
       st4(dst, v);
       if (bnb) {   // stage 1 of the consumer batch norm's backward
-        const float4 xv = ld4(p.bnb_x + (long long)m * p.bnb_ldx + fn);
+        const float4 xv = pre_x;
         if (p.bnb_scale != nullptr) v = f4scale(v, p.bnb_scale[m / HW]);
         const float4 xh = make_float4((xv.x - bmean.x) * brstd.x, (xv.y - bmean.y) * brstd.y, (xv.z - bmean.z) * brstd.z,
                                       (xv.w - bmean.w) * brstd.w);
