@@ -401,7 +401,9 @@ static inline bool ksplit_plan(long long M, int K, int Nout, int num_cus, Stream
   sp->nt = (tiles + gy - 1) / gy;
   sp->gy = gy;
   sp->row_groups = (int)((M + 15) / 16);
-  long long gx = (2LL * num_cus) / gy;     // two 512-thread workgroups per CU, ONE round (rounding up spills a few workgroups into a second)
+  // two 512-thread workgroups per CU, ONE round (rounding up spills a few workgroups into a second); the KC = 7 instances need 132
+  // VGPRs: one workgroup per CU
+  long long gx = ((sp->kc >= 7 ? 1LL : 2LL) * num_cus) / gy;
   if (gx < 1) gx = 1;
   if (gx > sp->row_groups) gx = sp->row_groups;
   sp->gx = (int)gx;
