@@ -230,7 +230,9 @@ struct BnApplyAlt {
   const float* gamma;
   const float* beta;
 };
-__global__ __launch_bounds__(256) void bn_apply_fused_k(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy,
+// (<= 168 VGPRs: three workgroups per CU.  With the 16-block fold batches of an earlier form the kernel needed 216 and two fitted -- the
+//  600-1568-workgroup launches of the large maps ran in two or three rounds with few waves in flight; stamps build, round 3)
+__global__ __launch_bounds__(256, 3) void bn_apply_fused_k(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy,
                                                         long long rows, int C, int rows_per_img, BnFold f,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         int pre_swish, int post_swish, const float* __restrict__ img_scale,
@@ -279,8 +281,7 @@ __global__ __launch_bounds__(256) void bn_apply_fused_k(const float* __restrict_
   const float4 g = ld4(gamma + c), b = ld4(beta + c);   // (before the fold: they do not depend on it)
   double s, ss;
   // (16 partial blocks per lane and round trip when a producer left many: one round per 512 instead of per 256)
-  if (f.nblk > 256) fold32<16>(f.part, f.nblk, C, c0, smd, s, ss);
-  else fold32<8>(f.part, f.nblk, C, c0, smd, s, ss);
+  fold32<8>(f.part, f.nblk, C, c0, smd, s, ss);
   if (t < 32) {
     double m = s * f.inv_n;
     double var = ss * f.inv_n - m * m;
@@ -350,6 +351,15 @@ __global__ __launch_bounds__(256) void bn_apply_fused_k(const float* __restrict_
     st4(pool_part + (long long)blockIdx.y * C + c0 + t * 4, f4add(f4add(smp[t], smp[8 + t]), f4add(smp[16 + t], smp[24 + t])));
 }
 
+// The apply kernels keep three workgroups per CU resident (<= 168 VGPRs): a grid in (768, 1536] would run a second, mostly empty round.
+// Taller row chunks until the launch fits one round of 256 CUs.
+static inline int bn_max_blocks() { return 768; }   // (whole step: no cap 3167-3169, 1024: 3170, 768: 3173-3178, 512: 3170-3174 images/s)
+static inline void fit_one_round(long long rows, int gx, int z, int* gy, int* rpb) {
+  while ((long long)gx * *gy * z > bn_max_blocks() && *gy > 1) {
+    *rpb *= 2;
+    *gy = (int)((rows + *rpb - 1) / *rpb);
+  }
+}
 static inline void chan_grid(long long rows, int C, int* gx, int* gy, int* rows_per_block) {
   const ColGeom g = col_geom(rows, C, 1);
   *gx = g.gx;
@@ -367,6 +377,7 @@ static inline void bn_bwd_grid(long long rows, int C, int* gx, int* gy, int* row
   *gx = g.gx;
   *gy = g.nblk;
   *rows_per_block = g.rows_per_block;
+  fit_one_round(rows, *gx, 1, gy, rows_per_block);
 }
 
 // upstream gradient seen by the BN output: dy * img_scale[n] * chan_scale[n,c] + chan_add[n,c]
@@ -476,7 +487,7 @@ struct BnBwdAlt {
   float *dgamma, *dbeta, *dx, *dxsum_part;
 };
 template <bool SE>
-__global__ __launch_bounds__(256) void bn_bwd_apply_fused_k(BnBwdCommon<SE> p, long long rows, const float* __restrict__ part, int nblk,
+__global__ __launch_bounds__(256, SE ? 2 : 3) void bn_bwd_apply_fused_k(BnBwdCommon<SE> p, long long rows, const float* __restrict__ part, int nblk,
                                                             double inv_n, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                             float* __restrict__ dx, int lddx, int rows_per_block, SkipOut skip,
                                                             float* __restrict__ dxsum_part, BnBwdAlt alt) {
@@ -504,8 +515,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fused_k(BnBwdCommon<SE> p, l
   }
   const typename BnBwdCommon<SE>::Ctx kc = p.ctx(c);
   double s, sx;
-  if (nblk > 256) fold32<16>(part, nblk, p.C, c0, smd, s, sx);
-  else fold32<8>(part, nblk, p.C, c0, smd, s, sx);
+  fold32<8>(part, nblk, p.C, c0, smd, s, sx);
   if (t < 32) {
     s_c1[t] = (float)(s * inv_n);
     s_c2[t] = (float)(sx * inv_n);
@@ -981,11 +991,13 @@ int mliis_bn_apply_fused(const float* x, int ldx, float* y, int ldy, long long r
     gy = g2.nblk;
     rpb = g2.rows_per_block;
   }
+  fit_one_round(rows, gx, 1, &gy, &rpb);
   if (pool_part != nullptr) {   // per-image pooling of the output: row chunks are cut per image (about 128 rows each)
     MLIIS_REQUIRE(pool_chunks && aligned16(pool_part) && rows % rows_per_img == 0, MLIIS_ERR_ARG,
                   "bn_apply_fused: pooling needs an aligned buffer, a pool_chunks output and whole images");
     const long long nimg = rows / rows_per_img;
-    const int pool_rows = many_partials ? 4 * kPoolRows : kPoolRows;
+    int pool_rows = many_partials ? 4 * kPoolRows : kPoolRows;
+    while ((long long)gx * nimg * ((rows_per_img + pool_rows - 1) / pool_rows) > bn_max_blocks() && pool_rows < rows_per_img) pool_rows *= 2;
     cpi = (rows_per_img + pool_rows - 1) / pool_rows;
     rpb = (rows_per_img + cpi - 1) / cpi;
     gy = (int)(nimg * cpi);
@@ -1028,6 +1040,7 @@ int mliis_bn_apply_fused_pair(const float* x0, float* y0, const float* part0, in
     gy = g2.nblk;
     rpb = g2.rows_per_block;
   }
+  fit_one_round(rows, gx, 2, &gy, &rpb);
   hipLaunchKernelGGL(bn_apply_fused_k, dim3(gx, gy, 2), dim3(256), 0, stream, x0, ldx, y0, ldy, rows, C, (int)rows, f0, gamma0, beta0, pre_swish,
                      post_swish, nullptr, nullptr, 0, rpb, nullptr, 0, BnApplyAlt{x1, y1, f1, gamma1, beta1});
   MLIIS_CHECK_LAUNCH("bn_apply_fused_pair");
