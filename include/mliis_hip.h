@@ -160,6 +160,9 @@ size_t mliis_conv2d_workspace_floats(int Nimg, int H, int W, int Cred, int Nout,
 /*      tiling chosen for a fwd / bwd-data call (row-tile factor, column tiles, split-K factor) and the name of the kernel
  *      instantiation it launches, as rocprofv3 prints it (profiling aids: bench.py matches its live timings to the trace) */
 int mliis_conv2d_plan(int Nimg, int H, int W, int Cred, int Nout, int ksize, int* tm, int* nt, int* splits);
+/*      workgroups of a 1x1 kernel instance the runtime fits on one CU (kind 0: conv1x1_stream_k<kc, nt>, 1: conv1x1_ksplit_k<kc, nt, 8>):
+ *      the planners launch two per CU, a test checks that two fit */
+int mliis_conv1x1_occupancy(int kind, int kc, int nt, int* blocks_per_cu);
 int mliis_conv2d_kernel_name(int Nimg, int H, int W, int Cred, int Nout, int ksize, int has_scale, int precision, char* buf, size_t buf_len);
 /*      stats_part (nullable): the epilogue also emits the following batch norm's stage-1 statistics -- per row-block column sums
  *      {sum v, sum v^2} (of swish(v) when stats_swish) as [*stats_nblk][2][Cout], written by the GEMM epilogue or, on a split-K

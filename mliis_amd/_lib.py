@@ -43,6 +43,7 @@ SIGNATURES = {
     "mliis_mbconv_dw_bwd_small": (_i, [_p] * 20 + [_i, _i, _i, _i, _i, _p]),
     "mliis_conv2d_workspace_floats": (_sz, [_i, _i, _i, _i, _i, _i]),
     "mliis_conv2d_plan": (_i, [_i, _i, _i, _i, _i, _i, _p, _p, _p]),
+    "mliis_conv1x1_occupancy": (_i, [_i, _i, _i, _p]),
     "mliis_conv2d_kernel_name": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _p, _sz]),
     "mliis_conv2d_fwd": (_i, [_p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _p, _sz, _i, _f, _p, _p]),
     "mliis_rsd_concat_pool_floats": (_sz, [_i, _i, _i, _i]),

@@ -372,6 +372,27 @@ using namespace mliis;
 
 extern "C" {
 
+// Workgroups of a 1x1 kernel instance that fit one CU according to the runtime (profiling aid: the planners assume two 512-thread
+// workgroups per CU -- a register count above 128 silently halves that and the grid runs in two rounds).  kind 0: conv1x1_stream_k<kc, nt>,
+// 1: conv1x1_ksplit_k<kc, nt, 8>; fp32 instances.  Returns MLIIS_ERR_ARG for a combination that is not instantiated.
+int mliis_conv1x1_occupancy(int kind, int kc, int nt, int* blocks_per_cu) {
+  MLIIS_REQUIRE(blocks_per_cu, MLIIS_ERR_ARG, "conv1x1_occupancy: null pointer");
+  const void* fn = nullptr;
+#define ST(KC_, NT_) if (kind == 0 && kc == KC_ && nt == NT_) fn = reinterpret_cast<const void*>(&conv1x1_stream_k<KC_, NT_, 0>);
+#define KS(KC_, NT_) if (kind == 1 && kc == KC_ && nt == NT_) fn = reinterpret_cast<const void*>(&conv1x1_ksplit_k<KC_, NT_, 8, 0>);
+  ST(1, 1) ST(1, 2) ST(1, 3) ST(1, 4) ST(2, 1) ST(2, 2) ST(2, 3) ST(3, 1) ST(3, 2) ST(4, 1) ST(4, 2) ST(5, 1) ST(6, 1) ST(7, 1)
+  KS(1, 1) KS(1, 2) KS(1, 3) KS(1, 4) KS(1, 5) KS(1, 6) KS(1, 7) KS(2, 1) KS(2, 2) KS(2, 3) KS(2, 4) KS(3, 1) KS(3, 2) KS(4, 1) KS(4, 2)
+  KS(5, 1) KS(6, 1) KS(7, 1)
+#undef ST
+#undef KS
+  MLIIS_REQUIRE(fn != nullptr, MLIIS_ERR_ARG, "conv1x1_occupancy: no instance kind %d <%d, %d>", kind, kc, nt);
+  int nb = 0;
+  const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 512, 0);
+  MLIIS_REQUIRE(e == hipSuccess, MLIIS_ERR_LAUNCH, "conv1x1_occupancy: %s", hipGetErrorString(e));
+  *blocks_per_cu = nb;
+  return MLIIS_OK;
+}
+
 // Tiling the planner picks for a conv2d_fwd / conv2d_bwd_data call (profiling aid: row-tile factor, column tiles, split-K factor).
 int mliis_conv2d_plan(int Nimg, int H, int W, int Cred, int Nout, int ksize, int* tm, int* nt, int* splits) {
   MLIIS_REQUIRE(tm && nt && splits, MLIIS_ERR_ARG, "conv2d_plan: null pointer");
