@@ -676,6 +676,23 @@ def test_rsd_concat_and_pooled_sums(N, Hi, H, Cd, Cs):
     close(sums, cat.double().sum(dim=(1, 2)).cpu(), 1e-5, "per-image column sums of the concat")
 
 
+def test_the_1x1_kernel_instances_fit_the_residency_their_planner_assumes():
+    """stream_plan / ksplit_plan launch two 512-thread workgroups per CU in ONE round.  An instance whose register count crosses 128
+    silently fits one, and the grid then runs in two rounds (round 3: the 16 -> 96 expand conv at 23 us instead of 12.6).  The runtime's
+    own occupancy figure for every instance the planners can pick (mliis_conv1x1_occupancy)."""
+    import ctypes as C
+    from mliis_amd._lib import lib
+    dev()
+    stream = [(1, 1), (1, 2), (1, 3), (1, 4), (2, 1), (2, 2), (2, 3), (3, 1), (3, 2), (4, 1), (4, 2), (5, 1), (6, 1), (7, 1)]
+    ksplit = [(1, n) for n in range(1, 8)] + [(2, 1), (2, 2), (2, 3), (2, 4), (3, 1), (3, 2), (4, 1), (4, 2), (5, 1), (6, 1), (7, 1)]
+    for kind, combos in ((0, stream), (1, ksplit)):
+        for kc, nt in combos:
+            nb = C.c_int(0)
+            lib.call("mliis_conv1x1_occupancy", kind, kc, nt, C.byref(nb))
+            need = 1 if (kind == 1 and kc >= 7) else 2     # (ksplit_plan launches one per CU for KC = 7)
+            assert nb.value >= need, ("stream" if kind == 0 else "ksplit", kc, nt, nb.value)
+
+
 # ------------------------------------------------------------------------------------------------ batched slab fold
 def test_fold_batched_dense_segmented_and_ragged():
     """mliis_fold_batched: several descriptors in one launch -- a dense vector path, a segmented (channel-window) output, a total that
