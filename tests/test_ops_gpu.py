@@ -155,7 +155,7 @@ def test_conv2d_slices_and_accumulate():
 
 
 # ------------------------------------------------------------------------------------------------ stem
-@pytest.mark.parametrize("H,W,Co", [(16, 16, 32), (15, 13, 32), (8, 8, 40)])
+@pytest.mark.parametrize("H,W,Co", [(16, 16, 32), (15, 13, 32), (8, 8, 40), (224, 224, 32), (131, 67, 40), (66, 130, 8)])
 def test_stem(H, W, Co):
     from mliis_amd import ops
     d = dev()
