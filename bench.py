@@ -254,12 +254,15 @@ def roofline(L, args):
             cdst = [torch.empty(half, dtype=torch.float32, device=L.device) for _ in range(copies)]
             for a_, b_ in zip(csrc, cdst):
                 b_.copy_(a_)
-            e0.record(L.stream)
-            for r in range(reps_k):
-                cdst[r % copies].copy_(csrc[r % copies])
-            e1.record(L.stream)
-            e1.synchronize()
-            cus = 1e3 * e0.elapsed_time(e1) / reps_k
+            cus_ = []
+            for _ in range(3):   # (median of three bursts: a single burst of a 4-8 us copy is noisy -- VERDICT r02)
+                e0.record(L.stream)
+                for r in range(reps_k):
+                    cdst[r % copies].copy_(csrc[r % copies])
+                e1.record(L.stream)
+                e1.synchronize()
+                cus_.append(1e3 * e0.elapsed_time(e1) / reps_k)
+            cus = sorted(cus_)[1]
             del csrc, cdst
             layers.append({"entry": n[6:], "N,H,W,C,k,s": [nb, h, w_, c, kk, st], "us": round(us, 2), "algorithmic_MB": round(nbytes / 1e6, 2),
                            "frac_of_8TBps": round(nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 3), "rotating_copies": copies,
