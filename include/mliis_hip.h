@@ -180,8 +180,10 @@ int mliis_conv2d_fwd(const float* x, int ldx, const float* x_scale, const float*
                      size_t ws_floats, int precision, float fp8_act_scale, const float* fp8_w_amax, hipStream_t stream);
 /*      batched HWIO -> HWOI copy of dense-conv weights between two arenas of identical layout; desc = device int32
  *      [ndesc][4] {offset, taps, Cin, Cout} */
-/*      amax (nullable, device float[ndesc]): also max |w| per descriptor (the fp8 operand scale of MLIIS_PREC_FP8) */
-int mliis_transpose_weights(const float* src, float* dst, const int* desc, int ndesc, float* amax, hipStream_t stream);
+/*      amax (nullable, device float[ndesc]): also max |w| per descriptor (the fp8 operand scale of MLIIS_PREC_FP8).
+ *      total_tiles > 0: sum over the descriptors of taps * ceil(Cin / 32) * ceil(Cout / 32) -- one workgroup per 32 x 32 tile; 0: a
+ *      fixed 224 x ndesc grid (the caller does not know the table's contents) */
+int mliis_transpose_weights(const float* src, float* dst, const int* desc, int ndesc, long long total_tiles, float* amax, hipStream_t stream);
 /*      gradient w.r.t. input channels [ci_begin, ci_begin+Cin_out) of a conv whose weight has Cin_total input channels */
 int mliis_conv2d_bwd_data(const float* dy, int lddy, const float* w, float* dx, int lddx, int Nimg, int H, int W, int Cin_total,
                           int ci_begin, int Cin_out, int Cout, int ksize, int dil, int accumulate, float* ws, size_t ws_floats,

@@ -105,17 +105,49 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats_k(const float* __rest
 // dst[off + tap*Ci*Co + co*Ci + ci] = src[off + tap*Ci*Co + ci*Co + co] for every descriptor (off, taps, Ci, Co): one launch per
 // inner step keeps a K-contiguous copy of all dense-conv weights so the FORWARD GEMM can use the same b128-fragment B path as
 // backward-data.  32x32 LDS tiles: coalesced reads along co, coalesced writes along ci.
+// ndesc_flat > 0: ONE tile per workgroup over a grid of exactly the tiles of all descriptors (the caller knows their total): workgroup b
+// finds its descriptor with a wave prefix scan of the tile counts (64 descriptors per pass).  The two-dimensional form (descriptor =
+// blockIdx.y, 224 workgroups each) launched 8512 workgroups for ~2000 tiles, most of them only to find nothing to do.
 __global__ __launch_bounds__(256) void transpose_weights_k(const float* __restrict__ src, float* __restrict__ dst,
-                                                           const int* __restrict__ desc, unsigned* __restrict__ amax_bits) {
+                                                           const int* __restrict__ desc, unsigned* __restrict__ amax_bits, int ndesc_flat) {
   __shared__ float tile[32][33];
   __shared__ float wmax[4];
-  const int d = blockIdx.y;
+  __shared__ int s_d[2];
+  int d = blockIdx.y, t_first = blockIdx.x, t_step = gridDim.x;
+  if (ndesc_flat > 0) {   // (uniform)
+    if (threadIdx.x < 64) {
+      const int lane = threadIdx.x, b = blockIdx.x;
+      int base = 0;
+      for (int d0 = 0; d0 < ndesc_flat; d0 += 64) {
+        const int dd = d0 + lane;
+        int nt = 0;
+        if (dd < ndesc_flat) nt = desc[4 * dd + 1] * ((desc[4 * dd + 2] + 31) / 32) * ((desc[4 * dd + 3] + 31) / 32);
+        int incl = nt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const int up = __shfl_up(incl, o, 64);
+          if (lane >= o) incl += up;
+        }
+        const int lo = base + incl - nt, hi = base + incl;
+        if (b >= lo && b < hi) {
+          s_d[0] = dd;
+          s_d[1] = b - lo;
+        }
+        base += __shfl(incl, 63, 64);
+        if (b < base) break;   // (uniform: base is a wave-wide value)
+      }
+    }
+    __syncthreads();
+    d = s_d[0];
+    t_first = s_d[1];
+    t_step = 1 << 30;
+  }
   const int off = desc[4 * d + 0], taps = desc[4 * d + 1], Ci = desc[4 * d + 2], Co = desc[4 * d + 3];
   const int tci = (Ci + 31) / 32, tco = (Co + 31) / 32;
   const int ntiles = taps * tci * tco;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
   float amax = 0.f;
-  for (int tIdx = blockIdx.x; tIdx < ntiles; tIdx += gridDim.x) {
+  for (int tIdx = t_first; tIdx < ntiles; tIdx += t_step) {
     const int tap = tIdx / (tci * tco);
     const int rem = tIdx - tap * tci * tco;
     const int ci0 = (rem / tco) * 32, co0 = (rem % tco) * 32;
@@ -701,14 +733,20 @@ static int conv2d_bwd_data_impl(const float* dy, int lddy, const float* w, float
 }
 
 // desc: device int32 [ndesc][4] = {offset (floats), taps, Cin, Cout}; src/dst: arenas with identical layout.
-int mliis_transpose_weights(const float* src, float* dst, const int* desc, int ndesc, float* amax, hipStream_t stream) {
-  MLIIS_REQUIRE(src && dst && desc && ndesc > 0, MLIIS_ERR_ARG, "transpose_weights: bad arguments");
+// total_tiles > 0: the sum over the descriptors of taps * ceil(Cin / 32) * ceil(Cout / 32) (the caller built the table, it knows):
+// one workgroup per tile.  0: a 224 x ndesc grid whose workgroups stride over their descriptor's tiles.
+int mliis_transpose_weights(const float* src, float* dst, const int* desc, int ndesc, long long total_tiles, float* amax, hipStream_t stream) {
+  MLIIS_REQUIRE(src && dst && desc && ndesc > 0 && total_tiles >= 0 && total_tiles < (1LL << 30), MLIIS_ERR_ARG, "transpose_weights: bad arguments");
   if (amax != nullptr) {   // (a memset node when captured into a graph)
     hipError_t e = hipMemsetAsync(amax, 0, (size_t)ndesc * sizeof(float), stream);
     MLIIS_REQUIRE(e == hipSuccess, MLIIS_ERR_LAUNCH, "transpose_weights: memset failed: %s", hipGetErrorString(e));
   }
-  hipLaunchKernelGGL(transpose_weights_k, dim3(224, ndesc), dim3(256), 0, stream, src, dst, desc,
-                     reinterpret_cast<unsigned*>(amax));   // (the largest tensor has ~2000 tiles)
+  if (total_tiles > 0)
+    hipLaunchKernelGGL(transpose_weights_k, dim3((unsigned)total_tiles), dim3(256), 0, stream, src, dst, desc, reinterpret_cast<unsigned*>(amax),
+                       ndesc);
+  else
+    hipLaunchKernelGGL(transpose_weights_k, dim3(224, ndesc), dim3(256), 0, stream, src, dst, desc, reinterpret_cast<unsigned*>(amax),
+                       0);   // (the largest tensor has ~2000 tiles)
   MLIIS_CHECK_LAUNCH("transpose_weights");
   return MLIIS_OK;
 }

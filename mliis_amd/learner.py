@@ -336,6 +336,7 @@ class Learner:
             if p.kind == "conv" and p.executed and p.name.endswith("/se/conv2d/kernel"):
                 desc.append([A.t_off[p.name], 1, p.shape[2], p.shape[3]])
         self.wt_desc = torch.tensor(desc, dtype=torch.int32, device=self.device)
+        self.wt_tiles = ops.transpose_tiles(desc)
         # fp8 mode: max |w| of every dense-conv weight, refreshed by the same launch that refreshes the shadow copies
         self.w_amax = torch.zeros(len(desc), dtype=torch.float32, device=self.device) if matmul_precision == "fp8" else None   # ([:n_dense] used)
         self._amax_of = {}
@@ -640,7 +641,7 @@ class Learner:
             torch.rsqrt(mv[prefix + "/moving_variance"] + spec.BN_EPS, out=st[1])
             return ops.bn_apply(xin, st[0], st[1], w[prefix + "/gamma"], w[prefix + "/beta"], pre, post, img_scale, res, out=y)
 
-        ops.transpose_weights(A.theta, self.theta_t, self.wt_desc, self.w_amax)
+        ops.transpose_weights(A.theta, self.theta_t, self.wt_desc, self.w_amax, tiles=self.wt_tiles)
 
         def conv(xin, wname, bname, dil, out, swish_stats, x_scale=None, border_bias=None):
             """dense conv; in training the epilogue also emits the following BN's statistics (returns their block count)."""

@@ -296,17 +296,24 @@ def mbconv_dw_bwd_small(da2, gate, chan_add, z1, bn1, w, z0, bn0, dgamma1, dbeta
 
 
 # ------------------------------------------------------------------------------------------------ dense conv
-def transpose_weights(src, dst, desc, amax=None):
+def transpose_tiles(desc_rows):
+    """Tile count of a transpose table given as HOST rows (offset, taps, Cin, Cout): pass it to transpose_weights(tiles=...)."""
+    return int(sum(int(t) * ((int(ci) + 31) // 32) * ((int(co) + 31) // 32) for _, t, ci, co in desc_rows))
+
+
+def transpose_weights(src, dst, desc, amax=None, tiles=0):
     """dst <- HWOI copies of the dense-conv weights listed in desc (device int32 [n,4] = offset, taps, Cin, Cout); amax (optional,
-    float [n]): also max |w| per tensor -- the fp8 operand scale."""
-    lib.call("mliis_transpose_weights", _ptr(src), _ptr(dst), _ptr(desc), int(desc.shape[0]), _ptr(amax), _stream())
+    float [n]): also max |w| per tensor -- the fp8 operand scale.  tiles = transpose_tiles(rows of desc): one workgroup per 32 x 32
+    tile; 0: a fixed grid that strides over the tiles."""
+    lib.call("mliis_transpose_weights", _ptr(src), _ptr(dst), _ptr(desc), int(desc.shape[0]), int(tiles), _ptr(amax), _stream())
 
 
 def hwoi(w):
     """K-contiguous copy [k,k,Cout,Cin] of one HWIO weight tensor (what the learner keeps for its whole arena, refreshed per step)."""
     k, _, cin, cout = w.shape
     dst = torch.empty((k, k, cout, cin), dtype=torch.float32, device=w.device)
-    transpose_weights(w.contiguous(), dst, torch.tensor([[0, k * k, cin, cout]], dtype=torch.int32, device=w.device))
+    rows = [[0, k * k, cin, cout]]
+    transpose_weights(w.contiguous(), dst, torch.tensor(rows, dtype=torch.int32, device=w.device), tiles=transpose_tiles(rows))
     return dst
 
 
