@@ -1,10 +1,13 @@
 """Headline benchmark: inner-loop images/sec of the Reptile/FOMAML adaptation loop over EfficientLab-6-3 (224x224, 5-shot).
 
-    python bench.py --gpus N --steps K --warmup W          (N = 1)
+    python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 Launch contract: for N > 1 the launcher (torch.distributed.run) exports RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*; this process
-binds cuda:LOCAL_RANK and joins the nccl (= RCCL) group BEFORE its first GPU call; nothing here re-executes the program.
+binds cuda:LOCAL_RANK and joins the nccl (= RCCL) group BEFORE its first GPU call.  A plain `python bench.py --gpus N` (N > 1, no
+WORLD_SIZE in the environment) starts that launcher ITSELF as a child process -- before anything has touched the GPU, nothing is
+re-executed in place -- relays rank 0's JSON line and exits with the child's code.  A WORLD_SIZE that disagrees with --gpus is an
+error (exit 2): the line's `n_gpus` is always the number of ranks that really ran.
 
 One "step" = one meta-step: every rank adapts ONE synthetic 5-shot task (BASELINE.json configs[1]: 8 inner SGD steps of batch 8
 = 64 image passes, fp32, drop-connect on), then the outer Reptile update (one RCCL all-reduce of the flat delta when N > 1).
@@ -33,7 +36,7 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA (the --precision bf16 variant 
 HBM_PEAK_GBS = 8000.0          # ibid., HBM3E spec
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -50,7 +53,8 @@ def parse():
     ap.add_argument("--augment", action="store_true", help="variant: augmentation of every inner-loop batch (the reference's run.sh setting), pixels on the device")
     ap.add_argument("--augment-on-host", action="store_true", help="with --augment: pixels in numpy / scipy on the host (draw-identical to the reference)")
     ap.add_argument("--augment-workers", type=int, default=-1, help="worker processes for the augmentation pixel work (0 = inline, -1 = cores - 1)")
-    ap.add_argument("--overlap-wgrad", type=int, default=0, help="variant: weight-gradient kernels on a second stream inside the graph (1 | 2)")
+    ap.add_argument("--overlap-wgrad", type=int, default=1, help="0: the decoder's filter gradients in line instead of on the side branch of the step (A/B)")
+    ap.add_argument("--side-workgroups", type=int, default=256, help="grid cap of the side-branch filter-gradient launches")
     ap.add_argument("--concurrent-tasks", type=int, default=1,
                     help="variant (with --tasks-per-gpu > 1): adapt this many tasks of the meta-batch at once on separate learners / streams")
     ap.add_argument("--tasks-per-gpu", type=int, default=1, help="variant: tasks per GPU and meta-step (the metric's config has 1)")
@@ -61,7 +65,55 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--pool", type=int, default=8, help="number of distinct synthetic tasks resident per GPU")
-    return ap.parse_args()
+    ap.add_argument("--cpu-baseline-from", default=None,
+                    help="N > 1 lines do not time the CPU oracle; carry `cpu_baseline` by value from this N = 1 bench line (a JSON file, e.g. BENCH_rNN.json)")
+    return ap.parse_args(argv)
+
+
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` with N > 1 outside a launcher: run torch.distributed.run as a CHILD (one rank per GPU), relay its
+    stdout (rank 0's one JSON line; the ranks' stderr passes through) and return its exit code.  Called before any GPU call."""
+    import subprocess
+    port = os.environ.get("MASTER_PORT") or str(_free_port())
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this pool (RCCL needs it across processes)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
+    text = p.stdout.decode(errors="replace")
+    lines = [ln for ln in text.splitlines() if ln.lstrip().startswith("{")]
+    if lines:
+        print(lines[-1], flush=True)
+    for ln in text.splitlines():
+        if not ln.lstrip().startswith("{"):
+            print(ln, file=sys.stderr)
+    if p.returncode == 0 and not lines:
+        print("bench.py: the %d-rank child printed no JSON line" % args.gpus, file=sys.stderr)
+        return 3
+    return p.returncode
+
+
+def check_world(args, environ=None):
+    """--gpus against the launcher's WORLD_SIZE.  Returns "launch" (spawn the ranks), "run" (this process is a rank / the only rank)."""
+    environ = os.environ if environ is None else environ
+    ws = environ.get("WORLD_SIZE")
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if ws is None:
+        return "launch" if args.gpus > 1 else "run"
+    if int(ws) != args.gpus:
+        print("bench.py: --gpus %d but the launcher's WORLD_SIZE is %s; refusing to report a line whose n_gpus differs from the request"
+              % (args.gpus, ws), file=sys.stderr)
+        raise SystemExit(2)
+    return "run"
 
 
 def _rccl_version():
@@ -292,7 +344,10 @@ def roofline(L, args):
 
 def main():
     import contextlib
-    args = parse()
+    argv = sys.argv[1:]
+    args = parse(argv)
+    if check_world(args) == "launch":
+        sys.exit(launch_ranks(args, argv))
     with contextlib.redirect_stdout(sys.stderr):   # stdout carries exactly ONE JSON line
         out = _run(args)
     if out is not None:
@@ -308,6 +363,8 @@ def _run(args):
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     backend = "nccl"
+    if torch.cuda.device_count() == 0:        # (counting devices does not initialise the GPU)
+        raise SystemExit("bench.py needs an MI355X; there is no CPU path (the CPU oracle is only the reported baseline)")
     if world > 1:
         import torch.distributed as dist
         # MLIIS_DIST_BACKEND=gloo is a test hook: it lets the whole N > 1 flow (task sharding, the one all-reduce per meta-step, the
@@ -331,15 +388,20 @@ def _run(args):
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args)
+    elif rank == 0 and world > 1 and args.cpu_baseline_from:
+        src = json.load(open(args.cpu_baseline_from))
+        src = src.get("parsed", src) if isinstance(src, dict) else {}
+        if isinstance(src.get("cpu_baseline"), dict):
+            cpu = dict(src["cpu_baseline"], carried_from=os.path.basename(args.cpu_baseline_from) + " (N = 1 line; not re-timed in this run)")
 
     shots = 10 if args.foml else args.shots
     L = Learner(feature_extractor_name=args.backbone, image_size=args.image_size, rsd=(2, 4), learning_rate=1e-3, optimizer="adam" if args.adam else "sgd", dice=False, l2=False, seed=0, device=device,
                 use_graph=not args.no_graph, max_shots=max(16, shots), spatial_pyramid_pooling=args.aspp, matmul_precision=args.precision,
-                skip_decoding=args.skip_decoding, overlap_wgrad=args.overlap_wgrad, augment_batch_capacity=16 if (args.augment and not args.augment_on_host) else 0,
+                skip_decoding=args.skip_decoding, overlap_wgrad=bool(args.overlap_wgrad) and args.concurrent_tasks == 1, side_workgroups=args.side_workgroups, augment_batch_capacity=16 if (args.augment and not args.augment_on_host) else 0,
                 rng_stream=rank)
     lanes = [Learner(feature_extractor_name=args.backbone, image_size=args.image_size, rsd=(2, 4), learning_rate=1e-3, optimizer="adam" if args.adam else "sgd", dice=False,
                      l2=False, seed=k, device=device, use_graph=not args.no_graph, max_shots=max(16, shots),
-                     spatial_pyramid_pooling=args.aspp, skip_decoding=args.skip_decoding, matmul_precision=args.precision, rng_stream=rank)
+                     spatial_pyramid_pooling=args.aspp, skip_decoding=args.skip_decoding, matmul_precision=args.precision, rng_stream=rank, overlap_wgrad=False)
              for k in range(1, args.concurrent_tasks)]
     tasks = []
     for i in range(args.pool):

@@ -28,6 +28,12 @@ extern "C" {
 typedef struct ihipStream_t* hipStream_t;
 #endif
 
+/* The library is built with -fvisibility=hidden: ONLY the entry points declared between this push and the pop at the end of the
+ * file are dynamic symbols of libmliis_hip.so (tests/test_abi.py checks `nm -D` against this header). */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
+
 #define MLIIS_OK 0
 #define MLIIS_ERR_ARG (-1)
 #define MLIIS_ERR_UNSUPPORTED (-2)
@@ -98,6 +104,7 @@ int mliis_rng_masks(unsigned* state, int njobs, float* const* outs, const long l
  *      (for mliis_fold_batched; dw != NULL: also folded into dw here); bn_part (nullable) [*nblk][2][C] = stage 1 of the batch norm's
  *      backward {sum g, sum g*xhat}, g = dx * swish'(gamma*xhat + beta), for mliis_bn_bwd(stage1_part, stage1_nblk);
  *      *nblk = mliis_dwconv_bn_bwd_blocks(...). */
+int mliis_dwconv_bn_supported(int N, int H, int W, int C, int k, int stride);   /* 1: the marching entry points take this layer */
 int mliis_dwconv_bn_fwd_blocks(int N, int H, int W, int C, int k, int stride);
 int mliis_dwconv_bn_bwd_blocks(int N, int H, int W, int C, int k, int stride);
 int mliis_dwconv_bn_fwd(const float* z, const float* bn_part, int bn_nblk, const float* bn_gamma, const float* bn_beta, float* bn_mean,
@@ -214,10 +221,12 @@ int mliis_conv2d_bwd_filter(const float* x, int ldx, const float* x_scale, const
  *      in the workspace), rows_per_split} of a call.  mliis_conv2d_bwd_filter_batched: desc = DEVICE table int64 [nprob][16] rows
  *      {x, dy, x_scale (0: none), workspace, ldx, lddy, Nimg, H, W, Cin, Cout, ksize, dil, rows_per_split | multitap << 32,
  *       gx | gy << 20 | gz << 40, first workgroup of the problem in the grid}, blocks = sum of gx * gy * gz, all problems with the
- *      same (TMF, NT, x_scale present); each problem's slabs land in its workspace exactly as the single call leaves them. */
+ *      same (TMF, NT, x_scale present); each problem's slabs land in its workspace exactly as the single call leaves them.
+ *      max_workgroups: 0 = one workgroup per tile; > 0 = at most that many workgroups, each walking tiles b, b + grid, ... (the
+ *      form launched on a side branch of the captured step beside the small-map backward chain; same slabs bit for bit). */
 int mliis_conv2d_bwd_filter_plan(int Nimg, int H, int W, int Cin, int Cout, int ksize, int* plan);
 int mliis_conv2d_bwd_filter_batched(const long long* desc, int nprob, int blocks, int tmf, int nt, int has_scale, int precision,
-                                    hipStream_t stream);
+                                    int max_workgroups, hipStream_t stream);
 
 /* ---- RSD pooled branch (models/efficientlab.py:192-197,220-224) without convolving it: the Cp spatially constant channels
  *      [c_begin, c_begin+Cp) of the 3x3 fuse conv's input become a per-image, per-border-class bias (forward) and need only
@@ -398,6 +407,10 @@ int mliis_graph_begin_capture(hipStream_t stream);
 int mliis_graph_end_capture(hipStream_t stream, void** graph_exec_out);
 int mliis_graph_launch(void* graph_exec, hipStream_t stream);
 int mliis_graph_destroy(void* graph_exec);
+
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 
 #ifdef __cplusplus
 }

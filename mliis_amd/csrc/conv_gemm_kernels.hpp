@@ -1230,12 +1230,15 @@ __global__ __launch_bounds__(256, 2) void conv_filter_grad2_k(FilterGradParams p
 // small for the chip -- share it).  desc: device int64 [nprob][16] rows
 //   {x, dy, x_scale (0: none), slabs, ldx, lddy, Nimg, H, W, Cin, Cout, ksize, dil, rows_per_split | multitap << 32,
 //    gx | gy << 20 | gz << 40, first block of the problem in this grid}
-// (the plan fields from mliis_conv2d_bwd_filter_plan); grid = sum of gx * gy * gz.
+// (the plan fields from mliis_conv2d_bwd_filter_plan); `total` = sum of gx * gy * gz blocks.  grid = total, or a CAPPED grid whose
+// workgroups walk the blocks b, b + gridDim.x, ... (round 4: the decoder's filter gradients run on a side branch of the captured step
+// beside the latency-bound backward chain of the small-map blocks; a grid of at most one workgroup per CU leaves that chain its slots.
+// The body's last action before its epilogue is a barrier behind the last LDS read, so the next block may refill the tiles at once).
 constexpr int kFilterDescWords = 16;
 template <int TMF, int NT, bool SC, bool BF>
-__global__ __launch_bounds__(256, 2) void conv_filter_grad2_batched_k(const long long* __restrict__ desc, int nprob) {
+__global__ __launch_bounds__(256, 2) void conv_filter_grad2_batched_k(const long long* __restrict__ desc, int nprob, int total) {
   __shared__ __attribute__((aligned(16))) float sm[2 * FilterSm<TMF, NT>::BUF_FLOATS];
-  const int b = blockIdx.x;
+  for (int b = blockIdx.x; b < total; b += gridDim.x) {
   int j = 0;
   for (int k = 1; k < nprob; ++k)
     if (b >= (int)desc[k * kFilterDescWords + 15]) j = k;
@@ -1248,6 +1251,7 @@ __global__ __launch_bounds__(256, 2) void conv_filter_grad2_batched_k(const long
   const int local = b - (int)d[15];
   const int bx = local % gx, r = local / gx;
   conv_filter_grad2_body<TMF, NT, SC, BF>(p, sm, bx, r % gy, r / gy);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ plans + instantiation switches
@@ -1341,11 +1345,11 @@ struct FilterPlan {
 };
 
 template <bool BF>
-static bool launch_filter_batched_t(int tmf, int nt, bool sc, const long long* desc, int nprob, int blocks, hipStream_t stream) {
-  dim3 grid(blocks), block(256);
+static bool launch_filter_batched_t(int tmf, int nt, bool sc, const long long* desc, int nprob, int blocks, int max_wg, hipStream_t stream) {
+  dim3 grid(max_wg > 0 && max_wg < blocks ? max_wg : blocks), block(256);
 #define L(T_, NT_)                                                                                                            \
-  if (sc) hipLaunchKernelGGL((conv_filter_grad2_batched_k<T_, NT_, true, BF>), grid, block, 0, stream, desc, nprob);          \
-  else hipLaunchKernelGGL((conv_filter_grad2_batched_k<T_, NT_, false, BF>), grid, block, 0, stream, desc, nprob);            \
+  if (sc) hipLaunchKernelGGL((conv_filter_grad2_batched_k<T_, NT_, true, BF>), grid, block, 0, stream, desc, nprob, blocks);  \
+  else hipLaunchKernelGGL((conv_filter_grad2_batched_k<T_, NT_, false, BF>), grid, block, 0, stream, desc, nprob, blocks);    \
   break;
 #define ROW(T_)       \
   switch (nt) {       \
@@ -1405,6 +1409,6 @@ void launch_gemm_fp8(const GemmPlan& g, const ConvGemmParams& p, hipStream_t str
 bool launch_stream_lowp(int precision, int kc, int nt, dim3 grid, const ConvGemmParams& p, int row_groups, hipStream_t stream);   // conv_gemm_fp8.hip
 bool launch_ksplit_lowp(int precision, int kc, int nt, dim3 grid, const ConvGemmParams& p, int row_groups, hipStream_t stream);   // conv_gemm_fp8.hip
 void launch_filter_bf16(const FilterPlan& f, const FilterGradParams& p, hipStream_t stream);
-bool launch_filter_batched_bf16(int tmf, int nt, bool sc, const long long* desc, int nprob, int blocks, hipStream_t stream);
+bool launch_filter_batched_bf16(int tmf, int nt, bool sc, const long long* desc, int nprob, int blocks, int max_wg, hipStream_t stream);
 
 }  // namespace mliis

@@ -916,6 +916,12 @@ static int dwm_check(const char* name, int N, int H, int W, int C, int k, int st
 
 extern "C" {
 
+// 1 when the row-marching entry points take this layer (the planner's query: unsupported shapes run op by op through dwconv.hip).
+int mliis_dwconv_bn_supported(int N, int H, int W, int C, int k, int stride) {
+  if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || (k != 3 && k != 5) || (stride != 1 && stride != 2)) return 0;
+  return ((long long)N * H * W * C * 4 < (1LL << 31)) ? 1 : 0;
+}
+
 // Number of workgroups along x of mliis_dwconv_bn_fwd (= blocks of its stats_part output).
 int mliis_dwconv_bn_fwd_blocks(int N, int H, int W, int C, int k, int stride) {
   if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || (k != 3 && k != 5) || (stride != 1 && stride != 2)) return 0;

@@ -49,7 +49,7 @@ class _Plan:
         self.idx = torch.zeros(N, dtype=torch.int32, device=dev)
         H = a.image_size
         hs = a.h_stem
-        self.z_stem, self.a_stem = buf(N, hs, hs, a.stem_out), buf(N, hs, hs, a.stem_out)
+        self.z_stem, self.a_stem = buf(N, hs, hs, a.stem_out), None   # (a_stem: only when block 0 does not take the stem's BN + swish, below)
         self.st_stem = vec(a.stem_out)
         self.blocks = []
         nskip = sum(1 for b in a.blocks if b.executed and b.skip)
@@ -64,10 +64,12 @@ class _Plan:
             # small maps (14x14 at 224x224 inputs): the depthwise half of the block runs as ONE launch per direction (mbconv_small.hip)
             B["small"] = bool(L.small_fused and b.expand != 1 and ops.mbconv_dw_small_supported(N, hi, hi, ce, b.k, b.stride))
             # every other block: the row-marching kernels (batch norm + swish in front of the depthwise conv applied while its input is
-            # staged; one-pass backward).  MLIIS_DW_MARCH=0: the op-by-op kernels of dwconv.hip, for A/B runs
-            B["march"] = bool(L.dw_march and not B["small"])
+            # staged; one-pass backward).  A shape neither family takes (>= 2 GiB tensors, other k / stride) runs op by op (dwconv.hip)
+            B["march"] = bool(L.dw_march and not B["small"] and lib.raw("mliis_dwconv_bn_supported")(N, hi, hi, ce, b.k, b.stride))
             if b.expand != 1:
-                B["z0"], B["a0"], B["st0"] = buf(N, hi, hi, ce), buf(N, hi, hi, ce), vec(ce)
+                B["z0"], B["st0"] = buf(N, hi, hi, ce), vec(ce)
+                if not B["march"]:   # (the marching kernels apply bn0 + swish on load: a0 is never written; small-map blocks run op by op in inference)
+                    B["a0"] = buf(N, hi, hi, ce)
             B["z1"], B["a1"], B["st1"] = buf(N, ho, ho, ce), buf(N, ho, ho, ce), vec(ce)
             B["s"], B["hpre"], B["gate"] = buf(N, ce), buf(N, b.se), buf(N, ce)
             B["z2"], B["st2"], B["out"] = buf(N, ho, ho, b.cout), vec(b.cout), buf(N, ho, ho, b.cout)
@@ -82,6 +84,12 @@ class _Plan:
             B["da0"] = buf(N, hi, hi, ce)
             self.blocks.append(B)
         self.dstem = buf(N, hs, hs, a.stem_out)
+        ex0 = [b for b in a.blocks if b.executed]
+        # block 0 without an expand conv (EfficientNet-B0 ... B7) takes the stem's BN + swish into its depthwise launch: the activated
+        # stem output is only read there (no identity skip), so it is never written
+        self.fuse_stem = bool(ex0 and self.blocks[0]["march"] and ex0[0].expand == 1 and not ex0[0].skip)
+        if not self.fuse_stem:
+            self.a_stem = buf(N, hs, hs, a.stem_out)
         self.rsd = []
         for m in a.rsd:
             D = {}
@@ -231,7 +239,7 @@ class _Plan:
         self.steps_run = 0
         # deferred dense-conv filter gradients: collected during the first (eager) backward pass of this plan, then one launch per
         # kernel instantiation at the end of every backward pass (ops.FilterBatch)
-        self.wbatch = ops.FilterBatch(dev)
+        self.wbatch, self.wbatch_dec = ops.FilterBatch(dev), ops.FilterBatch(dev)
         self.wbatch_ready = False
         # ---- mask generation inside the step (ops.rng_masks): drop-connect scales of all skip blocks, final-layer dropout, ASPP dropouts
         jobs = []
@@ -258,7 +266,7 @@ class Learner:
                  dice: bool = False, label_smoothing: float = 0.0, final_layer_dropout_rate: float = 0.0,
                  spatial_pyramid_pooling: bool = False, skip_decoding: bool = False, drop_connect: bool = True, seed: int = 0,
                  device="cuda:0", use_graph: bool = True, max_shots: int = 16, matmul_precision: str = "fp32",
-                 overlap_wgrad: int = 0, wgrad_flush_before: Sequence[int] = (5,), small_fused: Optional[bool] = None,
+                 overlap_wgrad: bool = True, side_workgroups: int = 256, small_fused: Optional[bool] = None, dw_march: Optional[bool] = None,
                  augment_batch_capacity: int = 0, rng_stream: int = 0):
         if optimizer not in ("sgd", "adam"):
             raise ValueError("optimizer must be 'sgd' or 'adam' (Adam with beta1=0, the reference default)")
@@ -273,14 +281,6 @@ class Learner:
         self._conv_fwd = functools.partial(ops.conv2d_fwd, precision=matmul_precision)
         self._conv_bwd_data = functools.partial(ops.conv2d_bwd_data, precision=matmul_precision)
         self._conv_bwd_filter = functools.partial(ops.conv2d_bwd_filter, precision=matmul_precision)
-        # the dense-conv filter gradients (36 launches, most of them far smaller than the chip) are off the critical path: issue them
-        # together at the end of the backward pass, one launch per kernel instantiation (MLIIS_BATCH_WGRAD=0: one by one, in place)
-        self.batch_wgrad = os.environ.get("MLIIS_BATCH_WGRAD", "1") != "0"
-        # stage 1 of the project-BN backward from the epilogue of the expand backward-data launch that finishes its input (small maps;
-        # MLIIS_BN_STAGE1_FROM_GEMM=0: the batch norm's own reduce launch, for A/B runs)
-        self.bn_stage1_from_gemm = os.environ.get("MLIIS_BN_STAGE1_FROM_GEMM", "1") != "0"
-        # the squeeze-excite gate's gradient from the project backward-data launch on the small maps (MLIIS_GATE_GRAD_FROM_GEMM=0: colsum)
-        self.gate_grad_from_gemm = os.environ.get("MLIIS_GATE_GRAD_FROM_GEMM", "1") != "0"
         self.device = torch.device(device)
         torch.cuda.set_device(self.device)
         self.arch = spec.derive(feature_extractor_name, image_size, list(rsd or []), final_layer_dropout_rate, spatial_pyramid_pooling,
@@ -292,27 +292,22 @@ class Learner:
         self.l1, self.darc1 = bool(l1), bool(darc1)
         self.final_layer_dropout_rate = float(final_layer_dropout_rate or 0.0)
         self.drop_connect = drop_connect
-        # small-map blocks through the one-launch-per-direction kernels of mbconv_small.hip (MLIIS_SMALL_FUSED=0: op by op, for A/B runs)
-        self.small_fused = (os.environ.get("MLIIS_SMALL_FUSED", "1") != "0") if small_fused is None else bool(small_fused)
-        self.dw_march = os.environ.get("MLIIS_DW_MARCH", "1") != "0"
-        # gate gradient + depthwise-BN backward sums from one pass over (da2, z1) (MLIIS_SE_BN_SUMS=0: column sum + the batch norm's own
-        # reduce pass, for A/B runs)
-        self.se_bn_sums = os.environ.get("MLIIS_SE_BN_SUMS", "1") != "0"
-        # the two independent branch batch norms of an RSD module in one launch per pass (MLIIS_RSD_BN_PAIR=0: one by one)
-        self.rsd_bn_pair = os.environ.get("MLIIS_RSD_BN_PAIR", "1") != "0"
-        # the depthwise batch norm's backward apply inside the marching depthwise backward launch (MLIIS_DW_BWD_BN1=0: its own launch)
-        self.dw_bwd_bn1 = os.environ.get("MLIIS_DW_BWD_BN1", "1") != "0"
-        self.dw_bwd_bn1_k5s1 = os.environ.get("MLIIS_DW_BWD_BN1", "1") == "2"   # (5x5 stride 1: that instantiation spills: measured, see notes)
+        # small-map blocks through the one-launch-per-direction kernels of mbconv_small.hip, the other blocks through the row-marching
+        # kernels of dwmarch.hip; a block whose shape neither family takes (their *_supported queries) runs op by op (dwconv.hip).
+        # small_fused / dw_march = False force that op-by-op path (tests of the fallback).
+        self.small_fused = True if small_fused is None else bool(small_fused)
+        self.dw_march = True if dw_march is None else bool(dw_march)
         self.use_graph = use_graph
         self.stream = torch.cuda.Stream(device=self.device)
-        # Optional (overlap_wgrad = 1 | 2): weight-gradient GEMMs on a second stream forked inside the HIP graph, one by one (1) or
-        # handed over at a few points of the backward pass (2, wgrad_flush_before = block indices).  Neither beats the single stream
-        # on MI355X (profiles/r01_notes.md), so it is off by default.
-        self.overlap_wgrad = int(overlap_wgrad)
-        self.wgrad_flush_before = set(int(v) for v in wgrad_flush_before)
+        # overlap_wgrad (default on): the decoder's dense-conv filter gradients -- MFMA-bound, nothing but the slab fold reads them --
+        # run on ONE side branch of the step, forked when the backward pass enters the encoder, with grids capped at
+        # `side_workgroups` (<= one workgroup per CU) so that the latency-bound backward chain of the small-map blocks keeps its slots;
+        # joined before the batched filter gradients of the encoder.  Same slabs bit for bit (the capped grid walks the same tiles).
+        self.overlap_wgrad = bool(overlap_wgrad)
+        self.side_workgroups = int(side_workgroups)
         # created only when used: HIP multiplexes a process's streams onto a few hardware queues, and the lanes of a concurrent
         # meta-batch (reptile.Gecko lanes) want one each
-        self.side_stream = torch.cuda.Stream(device=self.device) if self.overlap_wgrad else None
+        self.side_stream = None
         # batch indices go up through a ring of pinned slots: an upload from pageable memory makes the host wait for this stream
         self._idx_pin = torch.empty((16, 64), dtype=torch.int32).pin_memory()
         self._idx_ev = [None] * 16
@@ -350,6 +345,7 @@ class Learner:
         self.adam_v = torch.zeros_like(self.arena.theta) if optimizer == "adam" else None
         self.adam_t = torch.zeros(1, dtype=torch.float32, device=self.device)          # Adam steps applied so far
         self.adam_ticket = torch.zeros(1, dtype=torch.int32, device=self.device)   # the optimizer launch advances adam_t itself
+        self.adam_epoch = 0     # bumped whenever the Adam slots are REPLACED from outside (restore / import_all): lanes follow (reptile.py)
         self.plans: Dict[int, _Plan] = {}
         self.max_shots = max_shots
         H = image_size
@@ -469,6 +465,17 @@ class Learner:
             if self.adam_v is not None and "adam_v" in st:
                 self.adam_v.copy_(st["adam_v"])
                 self.adam_t.copy_(st["adam_t"])
+                self.adam_epoch += 1
+
+    def import_adam(self, adam_v: torch.Tensor, adam_t: torch.Tensor):
+        """Replace only the Adam slots (second moments + step count): how a lane takes over the main learner's restored optimizer state."""
+        if self.adam_v is None:
+            return
+        self._in()
+        with torch.cuda.stream(self.stream):
+            self.adam_v.copy_(adam_v)
+            self.adam_t.copy_(adam_t)
+        self.adam_epoch += 1
 
     def axpby(self, a: float, x: torch.Tensor, b: float, y: torch.Tensor):
         """y <- a*x + b*y on flat arena-shaped buffers (meta_learners/variables.py:9-45 on the device)."""
@@ -510,8 +517,11 @@ class Learner:
 
     def load_named(self, values, **kw) -> int:
         """Restore by name with the scope filters of EfficientLab.restore_model (prefixes / exclude_prefix / strict, forwarded to the
-        arena).  The Adam slots follow the SAME filters (a final layer that is not restored keeps fresh slots too); the global step
-        count is only taken over by an unfiltered restore."""
+        arena).  The Adam slots follow the SAME filters (a final layer that is not restored keeps fresh slots too).  The step count
+        (`beta2_power` / `adam_step`, top-level names) is restored unless a `prefixes` whitelist excludes it: restore_model's
+        `filter_out_scope=final_layer_scope` keeps every global variable that does not start with that scope, the beta powers among
+        them (efficientlab.py restore_model) -- so a --pretrained --do_not_restore_final_layer_weights run fine-tunes with a
+        warm bias correction, as the reference does."""
         from .checkpoint import adam_step_from
         self.stream.synchronize()
         n = self.arena.load_named(values, **kw)
@@ -529,8 +539,9 @@ class Learner:
                 o = A.t_off[p.name]
                 self.adam_v[o:o + p.size].copy_(torch.from_numpy(np.asarray(values[key], dtype=np.float32).reshape(-1)))
             t = adam_step_from(values, self.ADAM_BETA2)
-            if t is not None and prefixes is None and exclude is None:
+            if t is not None and prefixes is None:
                 self.adam_t.fill_(float(t))
+            self.adam_epoch += 1
         torch.cuda.synchronize(self.device)
         return n
 
@@ -655,10 +666,7 @@ class Learner:
 
         ops.stem_conv_fwd(x, w[self.n_stem[0]], idx, out=P.z_stem)
         ex = [b for b in a.blocks if b.executed]
-        # block 0 without an expand conv (EfficientNet-B0 ... B7) takes the stem's BN + swish into its depthwise launch: the activated
-        # stem output is only read there (no identity skip), so it is never written
-        fuse_stem = bool(ex and P.blocks[0]["march"] and ex[0].expand == 1 and not ex[0].skip)
-        P.fuse_stem = fuse_stem
+        fuse_stem = P.fuse_stem   # (block 0 takes the stem's BN + swish into its depthwise launch: _Plan)
         if fuse_stem:
             cur = None
         else:
@@ -788,7 +796,7 @@ class Learner:
                 res_up = bn(D["zu"], D["stu"], nu, D["up2"], pre=True, fused=True, nblk=nb)
             pyr = D["pyr"]
             (k0, b0, n0), (k1, b1, n1), (kf, bf, nf) = nm
-            if training and self.rsd_bn_pair:
+            if training:
                 # the 1x1 and the 3x3-dilated branch are independent: both GEMMs first (statistics in two buffers), then ONE launch for
                 # the two conv -> swish -> BN tails
                 nb0 = self._conv_fwd(cat, w[k0], w[b0], 1, out=D["z0"], ws=ws, stats_part=P.stats_part, stats_swish=True, wt=self.wt[k0],
@@ -892,49 +900,20 @@ class Learner:
         if not P.rsd and not a.aspp and a.skipdec is None:
             has_grad[-1] = True
 
-        pending = []
-
-        def flush():
-            """(phased overlap) hand the collected weight-gradient producers to the side stream, ordered after everything queued on the
-            main stream so far."""
-            if not pending:
-                return
-            ev = torch.cuda.Event()
-            ev.record(self.stream)
-            with torch.cuda.stream(self.side_stream):
-                self.side_stream.wait_event(ev)
-                for f_ in pending:
-                    f_()
-            pending.clear()
-
-        def side(fn):
-            """A weight-gradient producer.  These kernels only read activations / finished per-layer gradient buffers and write their own
-            slab region, so they may run any time before the batched fold: inline (overlap_wgrad = 0), forked one by one onto the side
-            stream (1), or collected and handed over at a few points of the backward pass (2: the decoder's large MFMA-bound
-            weight-gradient GEMMs then overlap the latency-bound chain of the 14x14 blocks)."""
-            if not self.overlap_wgrad:
-                return fn()
-            pending.append(fn)
-            if self.overlap_wgrad == 1:
-                flush()
-
         def bn_b(xin, dy, st, prefix, dx, pre=False, post=False, img_scale=None, chan_scale=None, chan_add=None, dskip=None,
                  dskip_accumulate=False, dxsum_part=None, stage1=None):
             ops.bn_bwd(xin, dy, st[0], st[1], w[prefix + "/gamma"], w[prefix + "/beta"], pre, post, img_scale, chan_scale, chan_add, dx=dx,
                        dgamma=g[prefix + "/gamma"], dbeta=g[prefix + "/beta"], ws=ws, dskip=dskip, dskip_accumulate=dskip_accumulate,
                        dxsum_part=dxsum_part, stage1=stage1)
 
-        batch = self.batch_wgrad and not self.overlap_wgrad
-        if batch and not P.wbatch_ready:
-            P.wbatch = ops.FilterBatch(self.device)   # (a first backward pass that raised half-way must not leave half a table behind)
+        if not P.wbatch_ready:   # (a first backward pass that raised half-way must not leave half a table behind)
+            P.wbatch, P.wbatch_dec = ops.FilterBatch(self.device), ops.FilterBatch(self.device)
 
-        def wgrad_conv(xin, dz, kk, dil, key, x_scale=None):
-            """filter gradient of a dense conv (slabs into P.fold_part[key]): deferred into the plan's batch, or issued here"""
-            if batch:
-                if not P.wbatch_ready:
-                    P.wbatch.add(xin, dz, kk, dil, P.fold_part[key], x_scale=x_scale)
-                return
-            side(lambda: self._conv_bwd_filter(xin, dz, kk, dil, x_scale=x_scale, partial=P.fold_part[key]))
+        def wgrad_conv(xin, dz, kk, dil, key, x_scale=None, dec=False):
+            """filter gradient of a dense conv (slabs into P.fold_part[key]): deferred into one of the plan's two batches -- the decoder's
+            (dec: launched on the side branch when the backward pass reaches the encoder) or the encoder's (end of the pass)"""
+            if not P.wbatch_ready:
+                (P.wbatch_dec if dec else P.wbatch).add(xin, dz, kk, dil, P.fold_part[key], x_scale=x_scale)
 
         def wgrad_1x1(xin, dz, kname, x_scale=None):
             wgrad_conv(xin, dz, 1, 1, kname, x_scale=x_scale)
@@ -947,26 +926,22 @@ class Learner:
             dO, cat, pyr, dpyr, dcat = D["dout"], D["cat"], D["pyr"], D["dpyr"], D["dcat"]
             bn_b(D["zf"], dO, D["stf"], nf, D["dzf"], pre=True)
             ops.rsd_pool_bwd(D["dzf"], D["tot"], D["pool"], w[kf], 2 * co, dw=g[kf], dbias=g[bf], dpool=D["dpool"], ws=ws)
-            wgrad_conv(pyr, D["dzf"], 3, 1, kf)   # rows of the 2*co convolved channels
+            wgrad_conv(pyr, D["dzf"], 3, 1, kf, dec=True)   # rows of the 2*co convolved channels
             self._conv_bwd_data(D["dzf"], w[kf], 1, ci_begin=0, ci_count=2 * co, out=dpyr, ws=ws)
             d0, d1 = dpyr[..., :co], dpyr[..., co:2 * co]
-            if self.rsd_bn_pair:   # both branches' batch norms: one reduce launch + one apply launch (+ conv-bias gradient slabs)
-                ops.bn_bwd_pair([(D["z" + i], d_, D["st" + i][0], D["st" + i][1], w[nn + "/gamma"], w[nn + "/beta"], d_, g[nn + "/gamma"],
-                                  g[nn + "/beta"], P.fold_part[bb]) for i, d_, nn, bb in (("0", d0, n0, b0), ("1", d1, n1, b1))],
-                                pre_swish=True, ws=ws)
-            else:
-                bn_b(D["z0"], d0, D["st0"], n0, d0, pre=True, dxsum_part=P.fold_part[b0])   # + conv-bias gradient slabs (batched fold)
+            # both branches' batch norms: one reduce launch + one apply launch (+ conv-bias gradient slabs for the batched fold)
+            ops.bn_bwd_pair([(D["z" + i], d_, D["st" + i][0], D["st" + i][1], w[nn + "/gamma"], w[nn + "/beta"], d_, g[nn + "/gamma"],
+                              g[nn + "/beta"], P.fold_part[bb]) for i, d_, nn, bb in (("0", d0, n0, b0), ("1", d1, n1, b1))],
+                            pre_swish=True, ws=ws)
             tail = P.filter_tail[j]
             cmain = cat[..., :m.c_cat - tail] if tail else cat
 
             def wgrad(dz, kname, kk, dil, cmain=cmain, ctail=cat[..., m.c_cat - tail:] if tail else None):
-                wgrad_conv(cmain, dz, kk, dil, kname)
+                wgrad_conv(cmain, dz, kk, dil, kname, dec=True)
                 if ctail is not None:   # the <= 16-channel sliver of the concat (see _Plan)
-                    wgrad_conv(ctail, dz, kk, dil, kname + "#tail")
+                    wgrad_conv(ctail, dz, kk, dil, kname + "#tail", dec=True)
             wgrad(d0, k0, 1, 1)
             self._conv_bwd_data(d0, w[k0], 1, out=dcat, ws=ws)
-            if not self.rsd_bn_pair:
-                bn_b(D["z1"], d1, D["st1"], n1, d1, pre=True, dxsum_part=P.fold_part[b1])
             wgrad(d1, k1, 3, 2)
             self._conv_bwd_data(d1, w[k1], 2, out=dcat, accumulate=True, ws=ws)
             # gradient of the concat = dcat + dpool / (H*W) on every pixel (the pooled branch); its deep half joins the residual
@@ -977,7 +952,7 @@ class Learner:
                 # back through that branch to the resized deep map, where the concat's share joins
                 ku, bu, nu = self.n_rsd_up[j]
                 bn_b(D["zu"], dO, D["stu"], nu, D["dzu"], pre=True, dxsum_part=P.fold_part[bu])
-                wgrad_conv(cat[..., :m.c_deep], D["dzu"], 1, 1, ku)
+                wgrad_conv(cat[..., :m.c_deep], D["dzu"], 1, 1, ku, dec=True)
                 self._conv_bwd_data(D["dzu"], w[ku], 1, out=D["dup"], ws=ws)
                 dU = D["dup"]
             else:
@@ -1009,16 +984,16 @@ class Learner:
             d = T["dout"]     # from the first RSD module (or, without RSD modules, the final conv's input gradient)
             for S, (dwn, dbn, pwn, pbn) in zip(reversed(T["sep"]), reversed(seps)):
                 bn_b(S["zp"], d, S["stp"], pbn, d, post=True)
-                wgrad_conv(S["ad"], d, 1, 1, pwn)
+                wgrad_conv(S["ad"], d, 1, 1, pwn, dec=True)
                 self._conv_bwd_data(d, w[pwn], 1, out=S["dad"], ws=ws)
                 bn_b(S["zd"], S["dad"], S["std"], dbn, S["dad"], post=True)
-                side(lambda S=S, dwn=dwn: ops.dwconv_bwd_filter(S["x_in"], S["dad"], 3, 1, partial=P.fold_part[dwn]))
+                ops.dwconv_bwd_filter(S["x_in"], S["dad"], 3, 1, partial=P.fold_part[dwn])
                 ops.dwconv_bwd_data(S["dad"], w[dwn], 1, (sd.h, sd.h), out=S["din"])
                 d = S["din"]
             dcat_sd = d                                   # [N, h, h, c_in + c_skip]
             bi2 = a.reductions[2]
             bn_b(T["z0"], dcat_sd[..., sd.c_in:], T["st0"], n0, T["dz0"], post=True)
-            wgrad_conv(P.blocks[bi2]["out"], T["dz0"], 1, 1, k0)
+            wgrad_conv(P.blocks[bi2]["out"], T["dz0"], 1, 1, k0, dec=True)
             self._conv_bwd_data(T["dz0"], w[k0], 1, out=P.blocks[bi2]["dout"], accumulate=has_grad[bi2], ws=ws)
             has_grad[bi2] = True
             if a.aspp:
@@ -1032,13 +1007,27 @@ class Learner:
             bi = a.reductions[4]
             self._aspp_backward(P, P.blocks[bi]["out"], P.blocks[bi]["dout"], has_grad[bi])
             has_grad[bi] = True
-        flush()
+        # ---- the decoder is done: its filter gradients (MFMA-bound) go to the side branch, beside the encoder's backward chain
+        side_join = None
+        if len(P.wbatch_dec):
+            if self.overlap_wgrad:
+                if self.side_stream is None:
+                    self.side_stream = torch.cuda.Stream(device=self.device)
+                fork = torch.cuda.Event()
+                fork.record(self.stream)
+                with torch.cuda.stream(self.side_stream):
+                    self.side_stream.wait_event(fork)
+                    P.wbatch_dec.launch(self.matmul_precision, max_workgroups=self.side_workgroups)
+                    side_join = torch.cuda.Event()
+                    side_join.record(self.side_stream)
+            else:
+                P.wbatch_dec.launch(self.matmul_precision)
         stage1_next = None   # stage 1 of the NEXT block's (bi - 1) project-BN backward, when the expand backward-data launch produced it
 
         def expand_bwd_data(bi, da0, wname, tgt, tgt_has):
             """Backward-data of block bi's expand conv into the gradient of block bi - 1's output -- the last contribution to it, so the
             launch can also emit stage 1 of that block's project-BN backward (mliis_conv2d_bwd_data_bn; small maps only)."""
-            if bi == 0 or not self.bn_stage1_from_gemm:
+            if bi == 0:
                 self._conv_bwd_data(da0, w[wname], 1, out=tgt, accumulate=tgt_has, ws=ws)
                 return None
             Bp = P.blocks[bi - 1]
@@ -1048,8 +1037,6 @@ class Learner:
 
         for bi in range(len(P.blocks) - 1, -1, -1):
             b, B, nm = ex[bi], P.blocks[bi], self.n_blocks[bi]
-            if bi in self.wgrad_flush_before:
-                flush()
             if not has_grad[bi]:
                 raise MliisError("internal: block {} has no upstream gradient".format(bi))
             dout = B["dout"]
@@ -1067,7 +1054,7 @@ class Learner:
             da2 = B["da2"]
             se = nm["se"]
             groups = 0
-            if self.gate_grad_from_gemm and 16 <= hw <= 256:
+            if 16 <= hw <= 256:
                 # small maps: the project backward-data launch also leaves the gate gradient's per-row-group partial sums of da2 * a1
                 # and the SE kernel folds them -- no pass over the two tensors (mliis_conv2d_bwd_data_gate)
                 _, groups = self._conv_bwd_data(dout, w[nm["w_proj"]], 1, out=da2, ws=ws, gate=B["a1"], part=P.gate_part)
@@ -1075,7 +1062,7 @@ class Learner:
                 self._conv_bwd_data(dout, w[nm["w_proj"]], 1, out=da2, ws=ws)
             se_outs = dict(dpre1=B["dpre1"], dpre2=B["dpre2"], chan_add=B["chan_add"])
             bn1_stage1 = None
-            if not groups and not B["small"] and self.se_bn_sums:
+            if not groups and not B["small"]:
                 # ONE pass over (da2, z1): the gate's gradient and everything bn1's backward needs from the two tensors; the SE kernel
                 # folds it and emits bn1's stage-1 sums per image -- no column-sum launch, no reduce pass of the batch norm
                 st1, p1 = B["st1"], nm["bn1"]
@@ -1099,7 +1086,8 @@ class Learner:
                     has_grad[bi - 1] = True
                 continue
             # bn1's backward apply inside the depthwise backward launch (its operands are staged there anyway; dz1 is never written)
-            fuse_bn1 = bool(B["march"] and bn1_stage1 is not None and self.dw_bwd_bn1 and (self.dw_bwd_bn1_k5s1 or not (b.k == 5 and b.stride == 1)) and
+            # (not the 5x5 stride-1 layer: that instantiation spills, measured without gain -- profiles/r03_notes.md)
+            fuse_bn1 = bool(B["march"] and bn1_stage1 is not None and not (b.k == 5 and b.stride == 1) and
                             (b.expand != 1 or (bi == 0 and P.fuse_stem)))
             if not fuse_bn1:
                 bn_b(B["z1"], da2, B["st1"], nm["bn1"], da2, post=True, chan_scale=B["gate"], chan_add=B["chan_add"], stage1=bn1_stage1)
@@ -1147,7 +1135,7 @@ class Learner:
                     has_grad[bi - 1] = True
                 continue
             dw_in = B["a0"] if b.expand != 1 else B["x_in"]
-            side(lambda dw_in=dw_in, da2=da2, b=b, nm=nm: ops.dwconv_bwd_filter(dw_in, da2, b.k, b.stride, partial=P.fold_part[nm["w_dw"]]))
+            ops.dwconv_bwd_filter(dw_in, da2, b.k, b.stride, partial=P.fold_part[nm["w_dw"]])
             if b.expand != 1:
                 da0 = B["da0"]
                 # the depthwise backward-data launch also emits stage 1 of bn0's backward (sums over (z0, da0)): no reduce pass
@@ -1167,15 +1155,11 @@ class Learner:
             if bi > 0:
                 has_grad[bi - 1] = True
         bn_b(P.z_stem, P.dstem, P.st_stem, self.n_stem[1], P.dstem, post=True, stage1=P.stem_stage1 if P.fuse_stem else None)
-        side(lambda: ops.stem_conv_bwd_filter(x, P.dstem, idx, partial=P.fold_part[self.n_stem[0]]))
-        flush()
-        if self.overlap_wgrad:
-            join = torch.cuda.Event()
-            join.record(self.side_stream)
-            self.stream.wait_event(join)
-        if batch:
-            P.wbatch_ready = True
-            P.wbatch.launch(self.matmul_precision)
+        ops.stem_conv_bwd_filter(x, P.dstem, idx, partial=P.fold_part[self.n_stem[0]])
+        if side_join is not None:
+            self.stream.wait_event(side_join)
+        P.wbatch_ready = True
+        P.wbatch.launch(self.matmul_precision)
         ops.se_wgrad_batched(P.se_desc, P.se_tiles)
         # all slabs written -> one batched fold into the gradient arena
         ops.fold_batched(P.fold_buf, A.grad, P.fold_desc, P.fold_tiles)

@@ -111,7 +111,10 @@ class Gecko:
         self.lanes = list(lanes)
         # Adam (the reference's default inner optimizer): every lane keeps its own second-moment slots and step count, exactly as every
         # RANK does under multi-GPU sharding -- the reference's single sequential history over all tasks is not
-        # reproduced then; the SGD path (--sgd) stays bit-identical to the task-by-task loop.
+        # reproduced then (Adam with concurrent lanes is NOT reference-parity; parity runs use --sgd or one lane); the SGD path (--sgd)
+        # stays bit-identical to the task-by-task loop.  What IS kept: a restored / imported optimizer state (checkpoint resume,
+        # evaluation's restore) reaches every lane, so lanes never start cold beside a warm main learner.
+        self._lane_adam_epoch = None
         for ln in self.lanes:
             if ln.n_trainable != learner.n_trainable or getattr(ln, "optimizer", "sgd") != getattr(learner, "optimizer", "sgd"):
                 raise ValueError("lanes must share the learner's architecture and inner optimizer")
@@ -254,6 +257,7 @@ class Gecko:
         export_* / import_* / axpby calls below order the lanes' streams against the main learner's)."""
         L = self.learner
         lanes = [L] + self.lanes
+        self._sync_lane_optimizer_state()
         decay, T = BN_MOMENTUM, inner_iters * self._steps_per_batch(lr)
         for g0 in range(0, len(mine), len(lanes)):
             group = []
@@ -282,6 +286,17 @@ class Gecko:
                 L.axpby(-1.0, last_backup if fomaml else old, 1.0, delta)
                 L.axpby(decay ** ((meta_batch_size - 1 - t) * T), lane.export_bn(), 1.0, bn_acc)
             L.import_trainable(old)
+
+    def _sync_lane_optimizer_state(self):
+        """Adam only: after the main learner's slots were replaced from outside (load_named / import_all) copy them into every lane."""
+        L = self.learner
+        ep = getattr(L, "adam_epoch", None)
+        if getattr(L, "adam_v", None) is None or ep is None or ep == self._lane_adam_epoch:
+            return
+        st = L.export_all()
+        for ln in self.lanes:
+            ln.import_adam(st["adam_v"], st["adam_t"])
+        self._lane_adam_epoch = ep
 
     def _task_batches(self, n_shots, inner_batch_size, inner_iters, replacement, rng):
         return self._batches(n_shots, inner_batch_size, inner_iters, replacement, rng)

@@ -34,6 +34,26 @@ def test_two_ranks_on_one_gpu_run_the_sharded_meta_step_and_print_one_line():
     assert abs(d["value"] - 2 * 64 * d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"])) < 1e-6 * d["value"]
 
 
+def test_plain_bench_command_with_gpus_2_launches_two_ranks_by_itself(tmp_path):
+    """`python bench.py --gpus 2` -- no launcher, no WORLD_SIZE -- starts torch.distributed.run as a child, the
+    line says n_gpus 2 / world 2, and `--cpu-baseline-from` carries the N = 1 line's cpu_baseline by value."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(MLIIS_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    one = tmp_path / "BENCH_one.json"
+    one.write_text(json.dumps({"parsed": {"n_gpus": 1, "cpu_baseline": {"value": 18.5, "unit": "images/s", "cores": 16, "kind": "port", "sample": "x"}}}))
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-roofline", "--image-size", "64",
+           "--cpu-baseline-from", str(one)]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["dist"]["world"] == 2 and d["dist"]["tasks_per_meta_step"] == 2 and d["value"] > 0
+    assert d["cpu_baseline"]["value"] == 18.5 and "BENCH_one.json" in d["cpu_baseline"]["carried_from"]
+
+
 def test_rccl_single_rank_process_group_runs_the_collectives():
     """RCCL itself on the box (world size 1 -- all a one-GPU machine allows): the process group comes up on backend "nccl", and the three
     collectives the meta-learner issues (all-reduce SUM of the comm buffer on the learner's stream, all-reduce MAX of the stop flag,

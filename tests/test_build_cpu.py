@@ -1,0 +1,45 @@
+"""The shipped library is a build of the committed sources: a CLEAN out-of-tree `make` of mliis_amd/csrc cross-compiles every HIP
+translation unit for gfx950 without a GPU and links a library that exports exactly the C ABI (VERDICT r03 hygiene items)."""
+import os
+import re
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "mliis_amd", "csrc")
+
+
+def _dynamic_symbols(path):
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    return [ln.split()[-1] for ln in out.splitlines() if ln.strip()]
+
+
+def _header_names():
+    src = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "mliis_hip.h")).read(), flags=re.S)
+    return set(re.findall(r"\b(mliis_\w+)\s*\(", src))
+
+
+def test_clean_make_cross_compiles_and_exports_only_the_c_abi(tmp_path):
+    build = str(tmp_path / "obj")
+    jobs = str(max(1, min(8, os.cpu_count() or 1)))
+    r = subprocess.run(["make", "-C", CSRC, "-j" + jobs, "BUILD=" + build, "clean", "all"], capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    so = os.path.join(build, "libmliis_hip.so")
+    assert os.path.exists(so)
+    objs = [f for f in os.listdir(build) if f.endswith(".o")]
+    assert len(objs) == len([f for f in os.listdir(CSRC) if f.endswith(".hip")]) >= 14
+    assert "error" not in r.stderr.lower()
+    syms = _dynamic_symbols(so)
+    assert set(syms) == _header_names(), set(syms) ^ _header_names()
+    # a gfx950 code object is embedded (and no other architecture)
+    blob = open(so, "rb").read()
+    assert b"gfx950" in blob and b"gfx942" not in blob and b"gfx90a" not in blob
+
+
+def test_in_tree_library_exports_only_the_c_abi():
+    from mliis_amd._lib import LIB_PATH
+    if not os.path.exists(LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    syms = _dynamic_symbols(LIB_PATH)
+    assert syms and all(s.startswith("mliis_") for s in syms), [s for s in syms if not s.startswith("mliis_")][:5]
+    assert set(syms) == _header_names()

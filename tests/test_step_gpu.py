@@ -82,7 +82,9 @@ def _mask_check(pL, lgO, frac_margin, label, min_outside=None):
     assert bool(same[outside].all()), label
 
 
-@pytest.mark.parametrize("kw", [dict(), dict(l2=True, dice=True, label_smoothing=0.1), dict(l1=True, l2=True), dict(darc1=True)])
+@pytest.mark.parametrize("kw", [dict(), dict(l2=True, dice=True, label_smoothing=0.1), dict(l1=True, l2=True), dict(darc1=True),
+                                dict(small_fused=False, dw_march=False),      # the op-by-op depthwise path (shapes neither fused family takes)
+                                dict(overlap_wgrad=False)])                    # decoder filter gradients in line (no side branch)
 def test_one_step_grads_params_bn(kw):
     _need_gpu()
     H, S, idx = 64, 5, [3, 1, 4, 0, 2, 3, 1, 1]
@@ -108,6 +110,58 @@ def test_one_step_grads_params_bn(kw):
     th = L.arena.export_trainable_packed().cpu().double()
     ref = torch.cat([O.params[p.name].reshape(-1) for p in L.arena.trainable])
     assert (th - ref).abs().max().item() <= 1e-5
+
+
+def test_side_branch_filter_gradients_are_bit_identical_to_the_inline_form():
+    """The decoder's filter gradients on the side branch (capped grids walking the tiles) against the same launches in line, eager and
+    as a replayed HIP graph: gradients and parameters after three steps are bit-identical for every cap."""
+    _need_gpu()
+    from mliis_amd.learner import Learner
+    H, S, idx = 64, 5, [3, 1, 4, 0, 2, 3, 1, 1]
+    x, y = _task(S, H, 1)
+    ref = None
+    for kw in (dict(overlap_wgrad=False, use_graph=False), dict(overlap_wgrad=True, side_workgroups=256, use_graph=False),
+               dict(overlap_wgrad=True, side_workgroups=7, use_graph=True), dict(overlap_wgrad=True, side_workgroups=100000, use_graph=True)):
+        L = Learner(image_size=H, seed=3, drop_connect=False, **kw)
+        L.load_task(x, y)
+        for _ in range(4):
+            L.inner_step(idx)
+        L.synchronize()
+        got = (L.arena.export_grad_packed().cpu(), L.arena.export_trainable_packed().cpu())
+        if ref is None:
+            ref = got
+        else:
+            assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), kw
+        L.close()
+
+
+def test_adam_step_count_is_restored_under_an_exclude_prefix_filter():
+    """restore_model(filter_out_scope=final_layer_scope) keeps the top-level beta powers, so a --pretrained
+    --do_not_restore_final_layer_weights restore must take over the Adam step count (warm bias correction) while the final layer's
+    slots stay fresh; a `prefixes` whitelist (encoder-only restore) does not."""
+    _need_gpu()
+    from mliis_amd.learner import Learner
+    H, S, idx = 64, 5, [0, 1, 2, 3, 4, 0, 1, 2]
+    x, y = _task(S, H, 1)
+    A = Learner(image_size=H, seed=1, optimizer="adam", use_graph=False)
+    A.load_task(x, y)
+    for _ in range(3):
+        A.inner_step(idx)
+    vals = A.named_numpy()
+    fin = A.final_layer_scope
+    B = Learner(image_size=H, seed=2, optimizer="adam", use_graph=False)
+    e0 = B.adam_epoch
+    B.load_named(vals, exclude_prefix=fin, strict=False)
+    assert B.adam_t.item() == 3.0 and B.adam_epoch > e0
+    o = B.arena.t_off[fin + "/kernel"]
+    n = [p for p in B.arena.trainable if p.name == fin + "/kernel"][0].size
+    assert float(B.adam_v[o:o + n].abs().max()) == 0.0                      # final layer: fresh slots
+    k = [p for p in B.arena.trainable if not p.name.startswith(fin)][0]
+    ok = B.arena.t_off[k.name]
+    np.testing.assert_array_equal(B.adam_v[ok:ok + k.size].cpu().numpy(), vals[k.name + "/Adam_1"].reshape(-1))
+    C_ = Learner(image_size=H, seed=2, optimizer="adam", use_graph=False)
+    C_.load_named(vals, prefixes=[C_.arch.name + "/"], strict=False)
+    assert C_.adam_t.item() == 0.0
 
 
 def test_five_step_trajectory_and_masks():
