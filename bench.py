@@ -53,8 +53,8 @@ def parse(argv=None):
     ap.add_argument("--augment", action="store_true", help="variant: augmentation of every inner-loop batch (the reference's run.sh setting), pixels on the device")
     ap.add_argument("--augment-on-host", action="store_true", help="with --augment: pixels in numpy / scipy on the host (draw-identical to the reference)")
     ap.add_argument("--augment-workers", type=int, default=-1, help="worker processes for the augmentation pixel work (0 = inline, -1 = cores - 1)")
-    ap.add_argument("--overlap-wgrad", type=int, default=1, help="0: the decoder's filter gradients in line instead of on the side branch of the step (A/B)")
-    ap.add_argument("--side-workgroups", type=int, default=256, help="grid cap of the side-branch filter-gradient launches")
+    ap.add_argument("--overlap-wgrad", type=int, default=0, help="1: the decoder filter gradients on a side branch of the step (capped grids) instead of in line; measured neutral to negative, profiles/r04_notes.md")
+    ap.add_argument("--side-workgroups", type=int, default=128, help="grid cap of the side-branch filter-gradient launches")
     ap.add_argument("--concurrent-tasks", type=int, default=1,
                     help="variant (with --tasks-per-gpu > 1): adapt this many tasks of the meta-batch at once on separate learners / streams")
     ap.add_argument("--tasks-per-gpu", type=int, default=1, help="variant: tasks per GPU and meta-step (the metric's config has 1)")

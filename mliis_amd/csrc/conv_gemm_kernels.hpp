@@ -601,6 +601,7 @@ __global__ __launch_bounds__(1024) void sk_fixup_k(ConvGemmParams p, SkPlan k) {
 constexpr int kStreamWaves = 8;
 template <int KC, int NT, int PREC>
 __global__ __launch_bounds__(64 * kStreamWaves, 4) void conv1x1_stream_k(ConvGemmParams p, int row_groups) {   // (4 waves per SIMD: <= 128 VGPRs, two workgroups per CU)
+  chain_prio();
   __shared__ float red[kStreamWaves][2][16 * NT];
   // per-wave staging tile of a finished row group, [16 rows][16 NT + 4]: the accumulators (C/D layout: a lane holds 4 rows x NT
   // columns 64 bytes apart) leave as whole-row 16-byte stores -- a dword store of that layout is four 64-byte segments per instruction
@@ -835,6 +836,7 @@ __global__ __launch_bounds__(64 * kStreamWaves, 4) void conv1x1_stream_k(ConvGem
 // grid = (row-group blocks, column tiles); block = 64 WV threads.
 template <int KC, int NT, int WV, int PREC>
 __global__ __launch_bounds__(64 * WV) void conv1x1_ksplit_k(ConvGemmParams p, int row_groups) {
+  chain_prio();
   constexpr int BN = 16 * NT, RS = BN + 4, QN = BN / 4;
   __shared__ __attribute__((aligned(16))) float red[WV][16][RS];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;

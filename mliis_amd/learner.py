@@ -266,7 +266,7 @@ class Learner:
                  dice: bool = False, label_smoothing: float = 0.0, final_layer_dropout_rate: float = 0.0,
                  spatial_pyramid_pooling: bool = False, skip_decoding: bool = False, drop_connect: bool = True, seed: int = 0,
                  device="cuda:0", use_graph: bool = True, max_shots: int = 16, matmul_precision: str = "fp32",
-                 overlap_wgrad: bool = True, side_workgroups: int = 256, small_fused: Optional[bool] = None, dw_march: Optional[bool] = None,
+                 overlap_wgrad: bool = False, side_workgroups: int = 128, small_fused: Optional[bool] = None, dw_march: Optional[bool] = None,
                  augment_batch_capacity: int = 0, rng_stream: int = 0):
         if optimizer not in ("sgd", "adam"):
             raise ValueError("optimizer must be 'sgd' or 'adam' (Adam with beta1=0, the reference default)")
@@ -299,10 +299,13 @@ class Learner:
         self.dw_march = True if dw_march is None else bool(dw_march)
         self.use_graph = use_graph
         self.stream = torch.cuda.Stream(device=self.device)
-        # overlap_wgrad (default on): the decoder's dense-conv filter gradients -- MFMA-bound, nothing but the slab fold reads them --
-        # run on ONE side branch of the step, forked when the backward pass enters the encoder, with grids capped at
-        # `side_workgroups` (<= one workgroup per CU) so that the latency-bound backward chain of the small-map blocks keeps its slots;
-        # joined before the batched filter gradients of the encoder.  Same slabs bit for bit (the capped grid walks the same tiles).
+        # overlap_wgrad (default OFF): the decoder's dense-conv filter gradients -- MFMA-bound, nothing but the slab fold reads them --
+        # on ONE side branch of the step, forked when the backward pass enters the encoder, with grids capped at `side_workgroups`
+        # (<= one workgroup per CU), joined before the encoder's batched filter gradients.  Same slabs bit for bit (the capped grid
+        # walks the same tiles).  Measured on MI355X (profiles/r04_notes.md, r04_overlap_timeline_*.txt): the 300 us of side work DO
+        # run beside the small-map backward chain, but that chain is not idle hardware -- its kernels slow down by about as much as
+        # the side branch saves (the one-workgroup-per-CU depthwise kernels cannot co-reside with a side workgroup at all) --
+        # 3057-3090 images/s at 128 workgroups against 3081-3094 in line, worse at every other cap.  Kept as an option.
         self.overlap_wgrad = bool(overlap_wgrad)
         self.side_workgroups = int(side_workgroups)
         # created only when used: HIP multiplexes a process's streams onto a few hardware queues, and the lanes of a concurrent

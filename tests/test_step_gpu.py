@@ -84,7 +84,7 @@ def _mask_check(pL, lgO, frac_margin, label, min_outside=None):
 
 @pytest.mark.parametrize("kw", [dict(), dict(l2=True, dice=True, label_smoothing=0.1), dict(l1=True, l2=True), dict(darc1=True),
                                 dict(small_fused=False, dw_march=False),      # the op-by-op depthwise path (shapes neither fused family takes)
-                                dict(overlap_wgrad=False)])                    # decoder filter gradients in line (no side branch)
+                                dict(overlap_wgrad=True)])                     # decoder filter gradients on the side branch (default: in line)
 def test_one_step_grads_params_bn(kw):
     _need_gpu()
     H, S, idx = 64, 5, [3, 1, 4, 0, 2, 3, 1, 1]
