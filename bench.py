@@ -53,8 +53,6 @@ def parse(argv=None):
     ap.add_argument("--augment", action="store_true", help="variant: augmentation of every inner-loop batch (the reference's run.sh setting), pixels on the device")
     ap.add_argument("--augment-on-host", action="store_true", help="with --augment: pixels in numpy / scipy on the host (draw-identical to the reference)")
     ap.add_argument("--augment-workers", type=int, default=-1, help="worker processes for the augmentation pixel work (0 = inline, -1 = cores - 1)")
-    ap.add_argument("--overlap-wgrad", type=int, default=0, help="1: the decoder filter gradients on a side branch of the step (capped grids) instead of in line; measured neutral to negative, profiles/r04_notes.md")
-    ap.add_argument("--side-workgroups", type=int, default=128, help="grid cap of the side-branch filter-gradient launches")
     ap.add_argument("--concurrent-tasks", type=int, default=1,
                     help="variant (with --tasks-per-gpu > 1): adapt this many tasks of the meta-batch at once on separate learners / streams")
     ap.add_argument("--tasks-per-gpu", type=int, default=1, help="variant: tasks per GPU and meta-step (the metric's config has 1)")
@@ -397,11 +395,11 @@ def _run(args):
     shots = 10 if args.foml else args.shots
     L = Learner(feature_extractor_name=args.backbone, image_size=args.image_size, rsd=(2, 4), learning_rate=1e-3, optimizer="adam" if args.adam else "sgd", dice=False, l2=False, seed=0, device=device,
                 use_graph=not args.no_graph, max_shots=max(16, shots), spatial_pyramid_pooling=args.aspp, matmul_precision=args.precision,
-                skip_decoding=args.skip_decoding, overlap_wgrad=bool(args.overlap_wgrad) and args.concurrent_tasks == 1, side_workgroups=args.side_workgroups, augment_batch_capacity=16 if (args.augment and not args.augment_on_host) else 0,
+                skip_decoding=args.skip_decoding, augment_batch_capacity=16 if (args.augment and not args.augment_on_host) else 0,
                 rng_stream=rank)
     lanes = [Learner(feature_extractor_name=args.backbone, image_size=args.image_size, rsd=(2, 4), learning_rate=1e-3, optimizer="adam" if args.adam else "sgd", dice=False,
                      l2=False, seed=k, device=device, use_graph=not args.no_graph, max_shots=max(16, shots),
-                     spatial_pyramid_pooling=args.aspp, skip_decoding=args.skip_decoding, matmul_precision=args.precision, rng_stream=rank, overlap_wgrad=False)
+                     spatial_pyramid_pooling=args.aspp, skip_decoding=args.skip_decoding, matmul_precision=args.precision, rng_stream=rank)
              for k in range(1, args.concurrent_tasks)]
     tasks = []
     for i in range(args.pool):

@@ -221,12 +221,10 @@ int mliis_conv2d_bwd_filter(const float* x, int ldx, const float* x_scale, const
  *      in the workspace), rows_per_split} of a call.  mliis_conv2d_bwd_filter_batched: desc = DEVICE table int64 [nprob][16] rows
  *      {x, dy, x_scale (0: none), workspace, ldx, lddy, Nimg, H, W, Cin, Cout, ksize, dil, rows_per_split | multitap << 32,
  *       gx | gy << 20 | gz << 40, first workgroup of the problem in the grid}, blocks = sum of gx * gy * gz, all problems with the
- *      same (TMF, NT, x_scale present); each problem's slabs land in its workspace exactly as the single call leaves them.
- *      max_workgroups: 0 = one workgroup per tile; > 0 = at most that many workgroups, each walking tiles b, b + grid, ... (the
- *      form launched on a side branch of the captured step beside the small-map backward chain; same slabs bit for bit). */
+ *      same (TMF, NT, x_scale present); each problem's slabs land in its workspace exactly as the single call leaves them. */
 int mliis_conv2d_bwd_filter_plan(int Nimg, int H, int W, int Cin, int Cout, int ksize, int* plan);
 int mliis_conv2d_bwd_filter_batched(const long long* desc, int nprob, int blocks, int tmf, int nt, int has_scale, int precision,
-                                    int max_workgroups, hipStream_t stream);
+                                    hipStream_t stream);
 
 /* ---- RSD pooled branch (models/efficientlab.py:192-197,220-224) without convolving it: the Cp spatially constant channels
  *      [c_begin, c_begin+Cp) of the 3x3 fuse conv's input become a per-image, per-border-class bias (forward) and need only

@@ -59,7 +59,7 @@ SIGNATURES = {
     "mliis_conv2d_bwd_filter_workspace_floats": (_sz, [_i, _i, _i, _i, _i, _i]),
     "mliis_conv2d_bwd_filter": (_i, [_p, _i, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _i, _p]),
     "mliis_conv2d_bwd_filter_plan": (_i, [_i, _i, _i, _i, _i, _i, _p]),
-    "mliis_conv2d_bwd_filter_batched": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "mliis_conv2d_bwd_filter_batched": (_i, [_p, _i, _i, _i, _i, _i, _i, _p]),
     "mliis_colreduce_workspace_floats": (_sz, [_ll, _i, _i, _i]),
     "mliis_bn_stats": (_i, [_p, _i, _ll, _i, _i, _f, _f, _i, _p, _p, _p, _p, _p, _sz, _p]),
     "mliis_bn_apply": (_i, [_p, _i, _p, _i, _ll, _i, _i, _p, _p, _p, _p, _i, _i, _p, _p, _i, _p]),

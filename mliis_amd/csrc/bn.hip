@@ -54,7 +54,6 @@ static inline ColGeom col_geom(long long rows_per_seg, int C, int nseg, int targ
 template <class Op>
 __global__ __launch_bounds__(kColThreads) void colreduce_partial_k(Op op, int rows_per_seg, int C, int rows_per_block, int nblk,
                                                                     float* __restrict__ part) {
-  chain_prio();
   constexpr int NV = Op::NV;
   __shared__ float4 sm[NV][4][8];
   const int t = threadIdx.x;
@@ -492,7 +491,6 @@ __global__ __launch_bounds__(256, SE ? 2 : 3) void bn_bwd_apply_fused_k(BnBwdCom
                                                             double inv_n, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                             float* __restrict__ dx, int lddx, int rows_per_block, SkipOut skip,
                                                             float* __restrict__ dxsum_part, BnBwdAlt alt) {
-  chain_prio();
   if (blockIdx.z == 1) {   // (uniform)
     p.x = alt.x; p.dy = alt.dy; p.mean = alt.mean; p.rstd = alt.rstd; p.gamma = alt.gamma; p.beta = alt.beta;
     part = alt.part; dgamma = alt.dgamma; dbeta = alt.dbeta; dx = alt.dx; dxsum_part = alt.dxsum_part;

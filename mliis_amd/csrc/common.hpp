@@ -81,14 +81,6 @@ __device__ __forceinline__ float wave_sum(float v) {
 // Second stage of the deterministic two-stage reductions: fold `nblk` partial vectors.  Launch with blockDim = (16, 16):
 // threadIdx.x = column inside the block, threadIdx.y = one of 16 lanes that stride over the partial blocks; the lanes are
 // combined through LDS in double precision in a fixed order, so the result does not depend on scheduling.
-// Wave priority of the kernels on the step's DEPENDENT chain (the backward pass of the small-map blocks): when the decoder's filter
-// gradients run beside them on the side branch (conv_filter_grad2_batched_k, priority 0), the chain's waves win the issue arbitration
-// of the SIMDs they share.  No effect when a kernel has the CU to itself.
-#ifndef MLIIS_CHAIN_PRIO
-#define MLIIS_CHAIN_PRIO 3
-#endif
-__device__ __forceinline__ void chain_prio() { __builtin_amdgcn_s_setprio(MLIIS_CHAIN_PRIO); }
-
 // Returns the column sum in every thread with threadIdx.y == 0 (others return garbage-free partials; ignore them).
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kFoldX = 16, kFoldY = 16;

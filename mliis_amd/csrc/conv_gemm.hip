@@ -774,15 +774,14 @@ int mliis_conv2d_bwd_filter_plan(int Nimg, int H, int W, int Cin, int Cout, int 
 // nprob filter-gradient problems that share one kernel instantiation (TMF, NT, x_scale or not) as ONE launch of `blocks` workgroups;
 // every problem leaves its gz slabs in its own workspace region exactly as mliis_conv2d_bwd_filter(dw = NULL) does.  desc: DEVICE
 // table int64 [nprob][16], layout at conv_filter_grad2_batched_k; the caller owns it (it is read by the kernel, not by the host).
-// max_workgroups > 0 caps the grid: its workgroups then walk the `blocks` tiles in strides of the grid (same slabs, bit for bit).
 int mliis_conv2d_bwd_filter_batched(const long long* desc, int nprob, int blocks, int tmf, int nt, int has_scale, int precision,
-                                    int max_workgroups, hipStream_t stream) {
+                                    hipStream_t stream) {
   int rc = prec_check("conv2d_bwd_filter_batched", precision);
   if (rc) return rc;
-  MLIIS_REQUIRE(desc && nprob >= 1 && nprob <= 64 && blocks >= 1 && max_workgroups >= 0, MLIIS_ERR_ARG, "conv2d_bwd_filter_batched: bad table (1..64 problems)");
+  MLIIS_REQUIRE(desc && nprob >= 1 && nprob <= 64 && blocks >= 1, MLIIS_ERR_ARG, "conv2d_bwd_filter_batched: bad table (1..64 problems)");
   MLIIS_REQUIRE(aligned16(desc), MLIIS_ERR_ALIGN, "conv2d_bwd_filter_batched: table must be 16-byte aligned");
-  const bool ok = precision != MLIIS_PREC_FP32 ? launch_filter_batched_bf16(tmf, nt, has_scale != 0, desc, nprob, blocks, max_workgroups, stream)
-                                               : launch_filter_batched_t<false>(tmf, nt, has_scale != 0, desc, nprob, blocks, max_workgroups, stream);
+  const bool ok = precision != MLIIS_PREC_FP32 ? launch_filter_batched_bf16(tmf, nt, has_scale != 0, desc, nprob, blocks, stream)
+                                               : launch_filter_batched_t<false>(tmf, nt, has_scale != 0, desc, nprob, blocks, stream);
   MLIIS_REQUIRE(ok, MLIIS_ERR_ARG, "conv2d_bwd_filter_batched: no instantiation TMF = %d, NT = %d", tmf, nt);
   MLIIS_CHECK_LAUNCH("conv2d_bwd_filter_batched");
   return MLIIS_OK;

@@ -6,8 +6,8 @@ namespace mliis {
 void launch_gemm_bf16(const GemmPlan& g, const ConvGemmParams& p, hipStream_t stream) { launch_gemm_t<1>(g, p, stream); }
 void launch_gemm_sk_bf16(const GemmPlan& g, const ConvGemmParams& p, float* slab, hipStream_t stream) { launch_gemm_sk_t<1>(g, p, slab, stream); }
 void launch_filter_bf16(const FilterPlan& f, const FilterGradParams& p, hipStream_t stream) { launch_filter_t<true>(f, p, stream); }
-bool launch_filter_batched_bf16(int tmf, int nt, bool sc, const long long* desc, int nprob, int blocks, int max_wg, hipStream_t stream) {
-  return launch_filter_batched_t<true>(tmf, nt, sc, desc, nprob, blocks, max_wg, stream);
+bool launch_filter_batched_bf16(int tmf, int nt, bool sc, const long long* desc, int nprob, int blocks, hipStream_t stream) {
+  return launch_filter_batched_t<true>(tmf, nt, sc, desc, nprob, blocks, stream);
 }
 
 }  // namespace mliis

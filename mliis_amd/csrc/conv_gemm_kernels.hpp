@@ -601,7 +601,6 @@ __global__ __launch_bounds__(1024) void sk_fixup_k(ConvGemmParams p, SkPlan k) {
 constexpr int kStreamWaves = 8;
 template <int KC, int NT, int PREC>
 __global__ __launch_bounds__(64 * kStreamWaves, 4) void conv1x1_stream_k(ConvGemmParams p, int row_groups) {   // (4 waves per SIMD: <= 128 VGPRs, two workgroups per CU)
-  chain_prio();
   __shared__ float red[kStreamWaves][2][16 * NT];
   // per-wave staging tile of a finished row group, [16 rows][16 NT + 4]: the accumulators (C/D layout: a lane holds 4 rows x NT
   // columns 64 bytes apart) leave as whole-row 16-byte stores -- a dword store of that layout is four 64-byte segments per instruction
@@ -836,7 +835,6 @@ __global__ __launch_bounds__(64 * kStreamWaves, 4) void conv1x1_stream_k(ConvGem
 // grid = (row-group blocks, column tiles); block = 64 WV threads.
 template <int KC, int NT, int WV, int PREC>
 __global__ __launch_bounds__(64 * WV) void conv1x1_ksplit_k(ConvGemmParams p, int row_groups) {
-  chain_prio();
   constexpr int BN = 16 * NT, RS = BN + 4, QN = BN / 4;
   __shared__ __attribute__((aligned(16))) float red[WV][16][RS];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -1232,15 +1230,12 @@ __global__ __launch_bounds__(256, 2) void conv_filter_grad2_k(FilterGradParams p
 // small for the chip -- share it).  desc: device int64 [nprob][16] rows
 //   {x, dy, x_scale (0: none), slabs, ldx, lddy, Nimg, H, W, Cin, Cout, ksize, dil, rows_per_split | multitap << 32,
 //    gx | gy << 20 | gz << 40, first block of the problem in this grid}
-// (the plan fields from mliis_conv2d_bwd_filter_plan); `total` = sum of gx * gy * gz blocks.  grid = total, or a CAPPED grid whose
-// workgroups walk the blocks b, b + gridDim.x, ... (round 4: the decoder's filter gradients run on a side branch of the captured step
-// beside the latency-bound backward chain of the small-map blocks; a grid of at most one workgroup per CU leaves that chain its slots.
-// The body's last action before its epilogue is a barrier behind the last LDS read, so the next block may refill the tiles at once).
+// (the plan fields from mliis_conv2d_bwd_filter_plan); grid = sum of gx * gy * gz.
 constexpr int kFilterDescWords = 16;
 template <int TMF, int NT, bool SC, bool BF>
-__global__ __launch_bounds__(256, 2) void conv_filter_grad2_batched_k(const long long* __restrict__ desc, int nprob, int total) {
+__global__ __launch_bounds__(256, 2) void conv_filter_grad2_batched_k(const long long* __restrict__ desc, int nprob) {
   __shared__ __attribute__((aligned(16))) float sm[2 * FilterSm<TMF, NT>::BUF_FLOATS];
-  for (int b = blockIdx.x; b < total; b += gridDim.x) {
+  const int b = blockIdx.x;
   int j = 0;
   for (int k = 1; k < nprob; ++k)
     if (b >= (int)desc[k * kFilterDescWords + 15]) j = k;
@@ -1253,7 +1248,6 @@ __global__ __launch_bounds__(256, 2) void conv_filter_grad2_batched_k(const long
   const int local = b - (int)d[15];
   const int bx = local % gx, r = local / gx;
   conv_filter_grad2_body<TMF, NT, SC, BF>(p, sm, bx, r % gy, r / gy);
-  }
 }
 
 // ------------------------------------------------------------------------------------------------ plans + instantiation switches
@@ -1347,11 +1341,11 @@ struct FilterPlan {
 };
 
 template <bool BF>
-static bool launch_filter_batched_t(int tmf, int nt, bool sc, const long long* desc, int nprob, int blocks, int max_wg, hipStream_t stream) {
-  dim3 grid(max_wg > 0 && max_wg < blocks ? max_wg : blocks), block(256);
+static bool launch_filter_batched_t(int tmf, int nt, bool sc, const long long* desc, int nprob, int blocks, hipStream_t stream) {
+  dim3 grid(blocks), block(256);
 #define L(T_, NT_)                                                                                                            \
-  if (sc) hipLaunchKernelGGL((conv_filter_grad2_batched_k<T_, NT_, true, BF>), grid, block, 0, stream, desc, nprob, blocks);  \
-  else hipLaunchKernelGGL((conv_filter_grad2_batched_k<T_, NT_, false, BF>), grid, block, 0, stream, desc, nprob, blocks);    \
+  if (sc) hipLaunchKernelGGL((conv_filter_grad2_batched_k<T_, NT_, true, BF>), grid, block, 0, stream, desc, nprob);          \
+  else hipLaunchKernelGGL((conv_filter_grad2_batched_k<T_, NT_, false, BF>), grid, block, 0, stream, desc, nprob);            \
   break;
 #define ROW(T_)       \
   switch (nt) {       \
@@ -1411,6 +1405,6 @@ void launch_gemm_fp8(const GemmPlan& g, const ConvGemmParams& p, hipStream_t str
 bool launch_stream_lowp(int precision, int kc, int nt, dim3 grid, const ConvGemmParams& p, int row_groups, hipStream_t stream);   // conv_gemm_fp8.hip
 bool launch_ksplit_lowp(int precision, int kc, int nt, dim3 grid, const ConvGemmParams& p, int row_groups, hipStream_t stream);   // conv_gemm_fp8.hip
 void launch_filter_bf16(const FilterPlan& f, const FilterGradParams& p, hipStream_t stream);
-bool launch_filter_batched_bf16(int tmf, int nt, bool sc, const long long* desc, int nprob, int blocks, int max_wg, hipStream_t stream);
+bool launch_filter_batched_bf16(int tmf, int nt, bool sc, const long long* desc, int nprob, int blocks, hipStream_t stream);
 
 }  // namespace mliis

@@ -294,7 +294,6 @@ __device__ __forceinline__ void dwm_emit_pair(const float4 s1, const float4 s2, 
 // ---------------------------------------------------------------------------------------------------------------------------------
 template <int K, int S, bool PRE, bool BWD, bool DYBN = false>
 __global__ __launch_bounds__(256, BWD ? 1 : 2) void dwm_conv_k(const DwmArgs a) {
-  chain_prio();
   static_assert(!DYBN || BWD, "DYBN is a backward mode");
   typedef MarchCfg<K, S> G;
   constexpr int TS = G::TS, SPR = G::SPR, RS = G::RS, IBW = G::IBW, IBWP = G::IBWP, WIN = G::WIN, NEW = G::NEW, NR = G::NR, WW = G::WW;
@@ -591,7 +590,6 @@ __global__ __launch_bounds__(256, BWD ? 1 : 2) void dwm_conv_k(const DwmArgs a) 
 // ---------------------------------------------------------------------------------------------------------------------------------
 template <int K, bool PRE, bool DYBN = false>
 __global__ __launch_bounds__(256, (K == 5 || DYBN) ? 1 : 2) void dwm_bwd_s2_k(const DwmArgs a) {
-  chain_prio();
   constexpr int BP = 14;                    // patches per band (28 input columns, as the stride-1 kernels)
   constexpr int D = (K - 1) / 2;            // dy rows / columns behind a patch
   constexpr int NEWD = 2, WIND = 2 + D, NR = WIND + NEWD, IBW = 16;   // ring row = 16 dy pixels (BP + D needed): one batch = 2 rows = the 32 pixel lanes

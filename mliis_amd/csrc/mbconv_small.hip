@@ -377,7 +377,6 @@ struct SmallBwd {
 
 template <int K>
 __global__ __launch_bounds__(kSmThreads) void mbconv_dw_bwd_small_k(SmallBwd p) {
-  chain_prio();
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const SmallGeom g = p.g;
   float4* tileA = reinterpret_cast<float4*>(smem);         // [npix] a0 = swish(bn0(z0))

@@ -142,7 +142,6 @@ __global__ __launch_bounds__(kSeThreads) void se_mlp_bwd_k(const float* __restri
                                                     float* __restrict__ dpre1, float* __restrict__ chan_add, int C, int R,
                                                     float inv_hw, const float* __restrict__ sums, int sums_nblk,
                                                     float* __restrict__ stage1) {
-  chain_prio();
   __shared__ float sd1[kMaxR];
   extern __shared__ float sd2[];   // [C] (+ [4][C] with sums; FAST: + [G][5][C] behind them)
   const int n = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;

@@ -239,7 +239,7 @@ class _Plan:
         self.steps_run = 0
         # deferred dense-conv filter gradients: collected during the first (eager) backward pass of this plan, then one launch per
         # kernel instantiation at the end of every backward pass (ops.FilterBatch)
-        self.wbatch, self.wbatch_dec = ops.FilterBatch(dev), ops.FilterBatch(dev)
+        self.wbatch = ops.FilterBatch(dev)
         self.wbatch_ready = False
         # ---- mask generation inside the step (ops.rng_masks): drop-connect scales of all skip blocks, final-layer dropout, ASPP dropouts
         jobs = []
@@ -266,7 +266,7 @@ class Learner:
                  dice: bool = False, label_smoothing: float = 0.0, final_layer_dropout_rate: float = 0.0,
                  spatial_pyramid_pooling: bool = False, skip_decoding: bool = False, drop_connect: bool = True, seed: int = 0,
                  device="cuda:0", use_graph: bool = True, max_shots: int = 16, matmul_precision: str = "fp32",
-                 overlap_wgrad: bool = False, side_workgroups: int = 128, small_fused: Optional[bool] = None, dw_march: Optional[bool] = None,
+                 small_fused: Optional[bool] = None, dw_march: Optional[bool] = None,
                  augment_batch_capacity: int = 0, rng_stream: int = 0):
         if optimizer not in ("sgd", "adam"):
             raise ValueError("optimizer must be 'sgd' or 'adam' (Adam with beta1=0, the reference default)")
@@ -299,18 +299,6 @@ class Learner:
         self.dw_march = True if dw_march is None else bool(dw_march)
         self.use_graph = use_graph
         self.stream = torch.cuda.Stream(device=self.device)
-        # overlap_wgrad (default OFF): the decoder's dense-conv filter gradients -- MFMA-bound, nothing but the slab fold reads them --
-        # on ONE side branch of the step, forked when the backward pass enters the encoder, with grids capped at `side_workgroups`
-        # (<= one workgroup per CU), joined before the encoder's batched filter gradients.  Same slabs bit for bit (the capped grid
-        # walks the same tiles).  Measured on MI355X (profiles/r04_notes.md, r04_overlap_timeline_*.txt): the 300 us of side work DO
-        # run beside the small-map backward chain, but that chain is not idle hardware -- its kernels slow down by about as much as
-        # the side branch saves (the one-workgroup-per-CU depthwise kernels cannot co-reside with a side workgroup at all) --
-        # 3057-3090 images/s at 128 workgroups against 3081-3094 in line, worse at every other cap.  Kept as an option.
-        self.overlap_wgrad = bool(overlap_wgrad)
-        self.side_workgroups = int(side_workgroups)
-        # created only when used: HIP multiplexes a process's streams onto a few hardware queues, and the lanes of a concurrent
-        # meta-batch (reptile.Gecko lanes) want one each
-        self.side_stream = None
         # batch indices go up through a ring of pinned slots: an upload from pageable memory makes the host wait for this stream
         self._idx_pin = torch.empty((16, 64), dtype=torch.int32).pin_memory()
         self._idx_ev = [None] * 16
@@ -910,13 +898,14 @@ class Learner:
                        dxsum_part=dxsum_part, stage1=stage1)
 
         if not P.wbatch_ready:   # (a first backward pass that raised half-way must not leave half a table behind)
-            P.wbatch, P.wbatch_dec = ops.FilterBatch(self.device), ops.FilterBatch(self.device)
+            P.wbatch = ops.FilterBatch(self.device)
 
-        def wgrad_conv(xin, dz, kk, dil, key, x_scale=None, dec=False):
-            """filter gradient of a dense conv (slabs into P.fold_part[key]): deferred into one of the plan's two batches -- the decoder's
-            (dec: launched on the side branch when the backward pass reaches the encoder) or the encoder's (end of the pass)"""
+        def wgrad_conv(xin, dz, kk, dil, key, x_scale=None):
+            """filter gradient of a dense conv (slabs into P.fold_part[key]): deferred into the plan's batch, launched at the end of the
+            pass, one launch per kernel instantiation.  (Round 4 ran the decoder's share on a side branch of the captured step with
+            capped grids beside the encoder's backward chain: measured neutral to negative -- profiles/r04_notes.md -- and removed.)"""
             if not P.wbatch_ready:
-                (P.wbatch_dec if dec else P.wbatch).add(xin, dz, kk, dil, P.fold_part[key], x_scale=x_scale)
+                P.wbatch.add(xin, dz, kk, dil, P.fold_part[key], x_scale=x_scale)
 
         def wgrad_1x1(xin, dz, kname, x_scale=None):
             wgrad_conv(xin, dz, 1, 1, kname, x_scale=x_scale)
@@ -929,7 +918,7 @@ class Learner:
             dO, cat, pyr, dpyr, dcat = D["dout"], D["cat"], D["pyr"], D["dpyr"], D["dcat"]
             bn_b(D["zf"], dO, D["stf"], nf, D["dzf"], pre=True)
             ops.rsd_pool_bwd(D["dzf"], D["tot"], D["pool"], w[kf], 2 * co, dw=g[kf], dbias=g[bf], dpool=D["dpool"], ws=ws)
-            wgrad_conv(pyr, D["dzf"], 3, 1, kf, dec=True)   # rows of the 2*co convolved channels
+            wgrad_conv(pyr, D["dzf"], 3, 1, kf)   # rows of the 2*co convolved channels
             self._conv_bwd_data(D["dzf"], w[kf], 1, ci_begin=0, ci_count=2 * co, out=dpyr, ws=ws)
             d0, d1 = dpyr[..., :co], dpyr[..., co:2 * co]
             # both branches' batch norms: one reduce launch + one apply launch (+ conv-bias gradient slabs for the batched fold)
@@ -940,9 +929,9 @@ class Learner:
             cmain = cat[..., :m.c_cat - tail] if tail else cat
 
             def wgrad(dz, kname, kk, dil, cmain=cmain, ctail=cat[..., m.c_cat - tail:] if tail else None):
-                wgrad_conv(cmain, dz, kk, dil, kname, dec=True)
+                wgrad_conv(cmain, dz, kk, dil, kname)
                 if ctail is not None:   # the <= 16-channel sliver of the concat (see _Plan)
-                    wgrad_conv(ctail, dz, kk, dil, kname + "#tail", dec=True)
+                    wgrad_conv(ctail, dz, kk, dil, kname + "#tail")
             wgrad(d0, k0, 1, 1)
             self._conv_bwd_data(d0, w[k0], 1, out=dcat, ws=ws)
             wgrad(d1, k1, 3, 2)
@@ -955,7 +944,7 @@ class Learner:
                 # back through that branch to the resized deep map, where the concat's share joins
                 ku, bu, nu = self.n_rsd_up[j]
                 bn_b(D["zu"], dO, D["stu"], nu, D["dzu"], pre=True, dxsum_part=P.fold_part[bu])
-                wgrad_conv(cat[..., :m.c_deep], D["dzu"], 1, 1, ku, dec=True)
+                wgrad_conv(cat[..., :m.c_deep], D["dzu"], 1, 1, ku)
                 self._conv_bwd_data(D["dzu"], w[ku], 1, out=D["dup"], ws=ws)
                 dU = D["dup"]
             else:
@@ -987,7 +976,7 @@ class Learner:
             d = T["dout"]     # from the first RSD module (or, without RSD modules, the final conv's input gradient)
             for S, (dwn, dbn, pwn, pbn) in zip(reversed(T["sep"]), reversed(seps)):
                 bn_b(S["zp"], d, S["stp"], pbn, d, post=True)
-                wgrad_conv(S["ad"], d, 1, 1, pwn, dec=True)
+                wgrad_conv(S["ad"], d, 1, 1, pwn)
                 self._conv_bwd_data(d, w[pwn], 1, out=S["dad"], ws=ws)
                 bn_b(S["zd"], S["dad"], S["std"], dbn, S["dad"], post=True)
                 ops.dwconv_bwd_filter(S["x_in"], S["dad"], 3, 1, partial=P.fold_part[dwn])
@@ -996,7 +985,7 @@ class Learner:
             dcat_sd = d                                   # [N, h, h, c_in + c_skip]
             bi2 = a.reductions[2]
             bn_b(T["z0"], dcat_sd[..., sd.c_in:], T["st0"], n0, T["dz0"], post=True)
-            wgrad_conv(P.blocks[bi2]["out"], T["dz0"], 1, 1, k0, dec=True)
+            wgrad_conv(P.blocks[bi2]["out"], T["dz0"], 1, 1, k0)
             self._conv_bwd_data(T["dz0"], w[k0], 1, out=P.blocks[bi2]["dout"], accumulate=has_grad[bi2], ws=ws)
             has_grad[bi2] = True
             if a.aspp:
@@ -1010,21 +999,6 @@ class Learner:
             bi = a.reductions[4]
             self._aspp_backward(P, P.blocks[bi]["out"], P.blocks[bi]["dout"], has_grad[bi])
             has_grad[bi] = True
-        # ---- the decoder is done: its filter gradients (MFMA-bound) go to the side branch, beside the encoder's backward chain
-        side_join = None
-        if len(P.wbatch_dec):
-            if self.overlap_wgrad:
-                if self.side_stream is None:
-                    self.side_stream = torch.cuda.Stream(device=self.device)
-                fork = torch.cuda.Event()
-                fork.record(self.stream)
-                with torch.cuda.stream(self.side_stream):
-                    self.side_stream.wait_event(fork)
-                    P.wbatch_dec.launch(self.matmul_precision, max_workgroups=self.side_workgroups)
-                    side_join = torch.cuda.Event()
-                    side_join.record(self.side_stream)
-            else:
-                P.wbatch_dec.launch(self.matmul_precision)
         stage1_next = None   # stage 1 of the NEXT block's (bi - 1) project-BN backward, when the expand backward-data launch produced it
 
         def expand_bwd_data(bi, da0, wname, tgt, tgt_has):
@@ -1159,8 +1133,6 @@ class Learner:
                 has_grad[bi - 1] = True
         bn_b(P.z_stem, P.dstem, P.st_stem, self.n_stem[1], P.dstem, post=True, stage1=P.stem_stage1 if P.fuse_stem else None)
         ops.stem_conv_bwd_filter(x, P.dstem, idx, partial=P.fold_part[self.n_stem[0]])
-        if side_join is not None:
-            self.stream.wait_event(side_join)
         P.wbatch_ready = True
         P.wbatch.launch(self.matmul_precision)
         ops.se_wgrad_batched(P.se_desc, P.se_tiles)

@@ -453,13 +453,12 @@ class FilterBatch:
                     first += blocks
                 self.tables.append((torch.tensor(rows, dtype=torch.int64, device=self.device), len(rows), first, tmf, nt, int(sc)))
 
-    def launch(self, precision="fp32", max_workgroups=0):
-        """max_workgroups > 0: capped grids (each workgroup walks several tiles) -- the side-branch form, see Learner._backward."""
+    def launch(self, precision="fp32"):
         if self.tables is None:
             self._build()
         prec = _prec(precision)
         for table, nprob, blocks, tmf, nt, sc in self.tables:
-            lib.call("mliis_conv2d_bwd_filter_batched", _ptr(table), nprob, blocks, tmf, nt, sc, prec, int(max_workgroups), _stream())
+            lib.call("mliis_conv2d_bwd_filter_batched", _ptr(table), nprob, blocks, tmf, nt, sc, prec, _stream())
 
     def __len__(self):
         return sum(len(v) for v in self.groups.values())

@@ -83,8 +83,7 @@ def _mask_check(pL, lgO, frac_margin, label, min_outside=None):
 
 
 @pytest.mark.parametrize("kw", [dict(), dict(l2=True, dice=True, label_smoothing=0.1), dict(l1=True, l2=True), dict(darc1=True),
-                                dict(small_fused=False, dw_march=False),      # the op-by-op depthwise path (shapes neither fused family takes)
-                                dict(overlap_wgrad=True)])                     # decoder filter gradients on the side branch (default: in line)
+                                dict(small_fused=False, dw_march=False)])     # the op-by-op depthwise path (shapes neither fused family takes)
 def test_one_step_grads_params_bn(kw):
     _need_gpu()
     H, S, idx = 64, 5, [3, 1, 4, 0, 2, 3, 1, 1]
@@ -110,29 +109,6 @@ def test_one_step_grads_params_bn(kw):
     th = L.arena.export_trainable_packed().cpu().double()
     ref = torch.cat([O.params[p.name].reshape(-1) for p in L.arena.trainable])
     assert (th - ref).abs().max().item() <= 1e-5
-
-
-def test_side_branch_filter_gradients_are_bit_identical_to_the_inline_form():
-    """The decoder's filter gradients on the side branch (capped grids walking the tiles) against the same launches in line, eager and
-    as a replayed HIP graph: gradients and parameters after three steps are bit-identical for every cap."""
-    _need_gpu()
-    from mliis_amd.learner import Learner
-    H, S, idx = 64, 5, [3, 1, 4, 0, 2, 3, 1, 1]
-    x, y = _task(S, H, 1)
-    ref = None
-    for kw in (dict(overlap_wgrad=False, use_graph=False), dict(overlap_wgrad=True, side_workgroups=256, use_graph=False),
-               dict(overlap_wgrad=True, side_workgroups=7, use_graph=True), dict(overlap_wgrad=True, side_workgroups=100000, use_graph=True)):
-        L = Learner(image_size=H, seed=3, drop_connect=False, **kw)
-        L.load_task(x, y)
-        for _ in range(4):
-            L.inner_step(idx)
-        L.synchronize()
-        got = (L.arena.export_grad_packed().cpu(), L.arena.export_trainable_packed().cpu())
-        if ref is None:
-            ref = got
-        else:
-            assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), kw
-        L.close()
 
 
 def test_adam_step_count_is_restored_under_an_exclude_prefix_filter():
