@@ -251,7 +251,7 @@ def roofline(L, args):
           "mliis_dwconv_bwd_data": ("dwconv_bwd_data", 3, {0: "o", 2: "i"}, ()),
           "mliis_dwconv_bwd_data_bn": ("dwconv_bwd_data", 3, {0: "o", 2: "i", 9: "i"}, ()),
           "mliis_dwconv_bwd_filter": ("dwconv_bwd_filter", 3, {0: "i", 1: "o"}, ()),
-          "mliis_mbconv_dw_fwd_small": ("mbconv_small_fwd", 20, {0: "i", 17: "o", 18: "o"}, (7, 8, 14, 15)),
+          "mliis_mbconv_dw_fwd_small": ("mbconv_small_fwd", 20, {0: "i", 17: "o", 18: "o"}, (7, 8, 14, 15)),     # (group_width rides along unchanged)
           "mliis_mbconv_dw_bwd_small": ("mbconv_small_bwd", 20, {0: "o", 3: "o", 9: "i", 19: "i"}, ())}
     FLUSH = 320e6
     dw, layers = {}, []

@@ -129,9 +129,11 @@ int mliis_mbconv_dw_bwd_march(const float* da2, const float* z1, const float* me
 
 /* ---- the depthwise half of an MBConv block on SMALL maps in ONE launch per direction (mbconv_small.hip): expand BN -> swish ->
  *      depthwise k x k (stride 1) -> BN -> swish -> squeeze-excite mean (efficientnet_model.py:183-200,266-271,247; utils.py:87-134)
- *      and the whole backward of that chain.  Every op in it is per channel, so a workgroup that owns 8 channels over all of
- *      [N,H,W] needs no grid-wide dependency.  Eligible shapes (else MLIIS_ERR_UNSUPPORTED, nothing launched; use the op-by-op
- *      entry points): stride 1, k 3|5, C % 8 == 0, N*H*W <= 2048, N*ceil(H/4)*W <= 512, N <= 32.
+ *      and the whole backward of that chain.  Every op in it is per channel, so a workgroup that owns a group of `group_width`
+ *      channels over all of [N,H,W] needs no grid-wide dependency.  group_width: 0 = the planner's choice
+ *      (mliis_mbconv_dw_small_group_width: quads -- 16-byte accesses -- except pairs for 5x5 layers whose C / 2 workgroups fit
+ *      one round of the chip), or 2 | 4.  Eligible shapes (else MLIIS_ERR_UNSUPPORTED, nothing launched; use
+ *      the op-by-op entry points): stride 1, k 3|5, C % 4 == 0, N*H*W <= 2048, N*ceil(H/4)*W <= 512.
  *      forward: z0 = expand conv output with its stage-1 statistics part0 [nblk0][2][C] (mliis_conv2d_fwd's stats_part); writes the
  *      batch statistics of both batch norms (mean / rstd, for the backward pass), updates both pairs of moving averages (nullable),
  *      z1 = depthwise output, a1 = swish(bn1(z1)), s [N,C] = per-image mean of a1, and (nullable) a0 = swish(bn0(z0)).
@@ -139,14 +141,16 @@ int mliis_mbconv_dw_bwd_march(const float* da2, const float* z1, const float* me
  *      chan_scale / chan_add (nullable); writes both BN parameter gradients, the COMPLETE depthwise filter gradient dw [k,k,C] (no
  *      slabs) and dz0 = gradient w.r.t. the expand conv's output. */
 int mliis_mbconv_dw_small_supported(int N, int H, int W, int C, int k, int stride);
+int mliis_mbconv_dw_small_group_width(int C, int k);
 int mliis_mbconv_dw_fwd_small(const float* z0, const float* part0, int nblk0, const float* gamma0, const float* beta0, float* mean0,
                               float* rstd0, float* moving_mean0, float* moving_var0, const float* w, const float* gamma1, const float* beta1,
                               float* mean1, float* rstd1, float* moving_mean1, float* moving_var1, float* a0, float* z1, float* a1, float* s,
-                              int N, int H, int W, int C, int k, float eps, float momentum, hipStream_t stream);
+                              int N, int H, int W, int C, int k, float eps, float momentum, int group_width, hipStream_t stream);
 int mliis_mbconv_dw_bwd_small(const float* da2, const float* gate, const float* chan_add, const float* z1, const float* mean1,
                               const float* rstd1, const float* gamma1, const float* beta1, const float* w, const float* z0, const float* mean0,
                               const float* rstd0, const float* gamma0, const float* beta0, float* dgamma1, float* dbeta1, float* dw,
-                              float* dgamma0, float* dbeta0, float* dz0, int N, int H, int W, int C, int k, hipStream_t stream);
+                              float* dgamma0, float* dbeta0, float* dz0, int N, int H, int W, int C, int k, int group_width,
+                              hipStream_t stream);
 
 /* ---- dense conv (k 1|3, stride 1, TF-SAME, dilation >= 1, optional bias) on the fp32 matrix cores:
  *      tf.layers.Conv2D 1x1 expand/project (efficientnet_model.py:175-182,225-232) and tf.layers.conv2d of the RSD decoder /

@@ -853,18 +853,23 @@ def test_dwconv_bwd_data_emits_bn_backward_stage1(k, s, H, W, C):
 
 
 # ------------------------------------------------------------------------------------------------ small-map MBConv depthwise half
-@pytest.mark.parametrize("k,N,H,W,C", [(3, 8, 14, 14, 480), (5, 8, 14, 14, 672), (5, 5, 14, 14, 480), (3, 8, 4, 4, 480), (5, 8, 16, 16, 40),
-                                       (3, 2, 24, 24, 8), (5, 3, 7, 9, 72), (3, 2, 2, 3, 16)])
-def test_mbconv_small_fused_fwd_bwd(k, N, H, W, C):
+@pytest.mark.parametrize("k,N,H,W,C,V", [(3, 8, 14, 14, 480, 0), (5, 8, 14, 14, 672, 0), (5, 5, 14, 14, 480, 0), (3, 8, 4, 4, 480, 0), (5, 8, 16, 16, 40, 0),
+                                         (3, 2, 24, 24, 8, 0), (5, 3, 7, 9, 72, 0), (3, 2, 2, 3, 16, 0),
+                                         (5, 8, 14, 14, 816, 0), (3, 8, 14, 14, 1152, 0),          # EfficientNet-B3's 14x14 / widest layers: quads
+                                         (5, 8, 14, 14, 480, 4), (3, 8, 14, 14, 672, 2), (5, 8, 14, 14, 672, 2), (3, 8, 14, 14, 480, 2),
+                                         (5, 3, 7, 9, 72, 4), (3, 2, 2, 3, 12, 2)])
+def test_mbconv_small_fused_fwd_bwd(k, N, H, W, C, V):
     """mliis_mbconv_dw_fwd_small / _bwd_small (one launch per direction for the depthwise half of an MBConv block on small maps) vs the
     float64 oracle ops + autograd: expand BN (statistics handed over as stage-1 partials) -> swish -> depthwise k x k -> BN -> swish ->
     per-image means; both moving averages; backward with the squeeze-excite gate / pooled-gradient terms.  Shapes: the 14x14 layers of
     EfficientLab-6-3 at N = 8 and N = 5 (FOMAML tail batch), the 64x64-input test sizes, ragged maps, a channel count that leaves
-    workgroups of the XCD-grouped grid idle, a map smaller than one strip."""
+    workgroups of the XCD-grouped grid idle, a map smaller than one strip.  V = channels per workgroup: 0 = the planner's choice (quads; pairs for
+    5x5 layers of up to 512 channels), or forced: every (k, V) instantiation is covered."""
     from mliis_amd import ops
     from mliis_amd.spec import BN_EPS
     d = dev()
     assert ops.mbconv_dw_small_supported(N, H, W, C, k, 1)
+    assert ops.mbconv_dw_small_group_width(C, k) == (2 if (k == 5 and C <= 512) else 4)
     assert not ops.mbconv_dw_small_supported(N, H, W, C, k, 2) and not ops.mbconv_dw_small_supported(64, 14, 14, C, k, 1)
     z0 = (rnd(N, H, W, C, seed=1) * 1.5 + 0.3).requires_grad_(True)
     wd = rnd(k, k, C, 1, seed=2, scale=0.4).requires_grad_(True)
@@ -895,7 +900,7 @@ def test_mbconv_small_fused_fwd_bwd(k, N, H, W, C):
     a0d, z1d, a1d = a0d
     sd = torch.full((N, C), 9.0, device=d)
     ops.mbconv_dw_fwd_small(z0d, part, nblk, (f32(g0, d), f32(b0, d), st[0], st[1], mov[0], mov[1]), f32(wd, d),
-                            (f32(g1, d), f32(b1, d), st[2], st[3], mov[2], mov[3]), z1d, a1d, sd, a0=a0d)
+                            (f32(g1, d), f32(b1, d), st[2], st[3], mov[2], mov[3]), z1d, a1d, sd, a0=a0d, group_width=V)
     close(a0d, a0, 2e-5, "small fwd a0")
     close(z1d, z1, 2e-5, "small fwd z1")
     close(a1d, a1, 5e-5, "small fwd a1")
@@ -908,13 +913,14 @@ def test_mbconv_small_fused_fwd_bwd(k, N, H, W, C):
     z1b, a1b, sb = torch.zeros_like(z1d), torch.zeros_like(a1d), torch.zeros_like(sd)
     mov2 = [f32(t, d) for t in (mm0, mv0, mm1, mv1)]
     ops.mbconv_dw_fwd_small(z0d, part, nblk, (f32(g0, d), f32(b0, d), st[0], st[1], mov2[0], mov2[1]), f32(wd, d),
-                            (f32(g1, d), f32(b1, d), st[2], st[3], mov2[2], mov2[3]), z1b, a1b, sb)
+                            (f32(g1, d), f32(b1, d), st[2], st[3], mov2[2], mov2[3]), z1b, a1b, sb, group_width=V)
     assert torch.equal(z1b, z1d) and torch.equal(a1b, a1d) and torch.equal(sb, sd)      # deterministic
     # backward
     outs = dict(dg1=torch.zeros(C, device=d), db1=torch.zeros(C, device=d), dw=torch.zeros(k, k, C, 1, device=d), dg0=torch.zeros(C, device=d),
                 db0=torch.zeros(C, device=d), dz0=torch.full((N, H, W, C), 9.0, device=d))
     ops.mbconv_dw_bwd_small(f32(da2, d), f32(gate, d), f32(cadd, d), z1d, (st[2], st[3], f32(g1, d), f32(b1, d)), f32(wd, d), z0d,
-                            (st[0], st[1], f32(g0, d), f32(b0, d)), outs["dg1"], outs["db1"], outs["dw"], outs["dg0"], outs["db0"], outs["dz0"])
+                            (st[0], st[1], f32(g0, d), f32(b0, d)), outs["dg1"], outs["db1"], outs["dw"], outs["dg0"], outs["db0"], outs["dz0"],
+                            group_width=V)
     for name, ref in (("dz0", grads[0]), ("dw", grads[1]), ("dg0", grads[2]), ("db0", grads[3]), ("dg1", grads[4]), ("db1", grads[5])):
         close(outs[name], ref, 2e-4, "small bwd " + name)
     with pytest.raises(Exception):

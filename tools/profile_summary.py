@@ -107,9 +107,13 @@ def main():
         q = b.cexp // 4
         by = 4.0 * (N * b.h_in ** 2 * b.cexp + N * b.h_out ** 2 * b.cexp + b.k ** 2 * b.cexp)
         byb = by + (4.0 * N * b.h_in ** 2 * b.cexp if b.expand != 1 else 0.0)   # + z0 where the launch also does the BN statistics
-        sg = ((((b.cexp + 31) // 32) + 7) // 8) * 8 * 8 * 512                     # grid of the fused small-map kernels (threads)
-        kfs = [v for (k, g, gy), v in per_f.items() if k == "mbconv_dw_fwd_small_k<%d>" % b.k and g == sg]
-        kbs = [v for (k, g, gy), v in per_f.items() if k == "mbconv_dw_bwd_small_k<%d>" % b.k and g == sg]
+        # grid of the fused small-map kernels (threads): V channels per workgroup (quads; pairs for 5x5 layers with C / 2 <= 256 CUs),
+        # runs of R groups per XCD (mbconv_small.hip: sm_group_width / sm_grid)
+        V = 2 if (b.k == 5 and b.cexp % 2 == 0 and b.cexp // 2 <= 256) else 4
+        R = 11 if V == 3 else 32 // V
+        sg = ((-(-(b.cexp // V) // R) + 7) // 8) * 8 * R * 512
+        kfs = [v for (k, g, gy), v in per_f.items() if k == "mbconv_dw_fwd_small_k<%d, %d>" % (b.k, V) and g == sg]
+        kbs = [v for (k, g, gy), v in per_f.items() if k == "mbconv_dw_bwd_small_k<%d, %d>" % (b.k, V) and g == sg]
         if kfs and kbs and b.stride == 1 and N * b.h_in ** 2 <= 2048 and b.expand != 1:
             mf, mb = med(kfs[0]), med(kbs[0])
             tf += mf; bf += by; tb += mb; bb += by + by

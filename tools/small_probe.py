@@ -25,15 +25,17 @@ z1, a1, s = torch.empty_like(z0), torch.empty_like(z0), torch.empty(N, C, device
 da2, gate, cadd = r(N, H, H, C), torch.sigmoid(r(N, C)), r(N, C) * 0.01
 outs = [vec() for _ in range(2)] + [torch.zeros(k, k, C, 1, device=d)] + [vec() for _ in range(2)] + [torch.empty_like(z0)]
 torch.cuda.synchronize()
-e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-e[0].record()
-for _ in range(reps):
-    ops.mbconv_dw_fwd_small(z0, part, nblk, (g0, b0, st[0], st[1], None, None), w, (g1, b1, st[2], st[3], None, None), z1, a1, s)
-e[1].record()
-for _ in range(reps):
-    ops.mbconv_dw_bwd_small(da2, gate, cadd, z1, (st[2], st[3], g1, b1), w, z0, (st[0], st[1], g0, b0), outs[0], outs[1], outs[2], outs[3], outs[4],
-                            outs[5])
-e[2].record()
-torch.cuda.synchronize()
-print("C=%d k=%d: fwd %.1f us, bwd %.1f us per launch (hot, host-issued back to back)" % (C, k, 1e3 * e[0].elapsed_time(e[1]) / reps,
-                                                                                           1e3 * e[1].elapsed_time(e[2]) / reps))
+for V in [0] + [2, 4]:    # 0 = the planner's choice
+    for _warm in range(2):
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        e[0].record()
+        for _ in range(reps):
+            ops.mbconv_dw_fwd_small(z0, part, nblk, (g0, b0, st[0], st[1], None, None), w, (g1, b1, st[2], st[3], None, None), z1, a1, s, group_width=V)
+        e[1].record()
+        for _ in range(reps):
+            ops.mbconv_dw_bwd_small(da2, gate, cadd, z1, (st[2], st[3], g1, b1), w, z0, (st[0], st[1], g0, b0), outs[0], outs[1], outs[2], outs[3], outs[4],
+                                    outs[5], group_width=V)
+        e[2].record()
+        torch.cuda.synchronize()
+    print("C=%d k=%d V=%d (%s): fwd %.1f us, bwd %.1f us per launch (hot, host-issued back to back)" % (
+        C, k, V or ops.mbconv_dw_small_group_width(C, k), "planner" if V == 0 else "forced", 1e3 * e[0].elapsed_time(e[1]) / reps, 1e3 * e[1].elapsed_time(e[2]) / reps))
