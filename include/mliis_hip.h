@@ -110,10 +110,14 @@ int mliis_dwconv_bn_bwd_blocks(int N, int H, int W, int C, int k, int stride);
 int mliis_dwconv_bn_fwd(const float* z, const float* bn_part, int bn_nblk, const float* bn_gamma, const float* bn_beta, float* bn_mean,
                         float* bn_rstd, float* bn_moving_mean, float* bn_moving_var, float eps, float momentum, const float* w, float* y,
                         int N, int H, int W, int C, int k, int stride, float* stats_part, size_t stats_floats, int* stats_nblk,
-                        hipStream_t stream);
+                        int in_dtype, int out_dtype, hipStream_t stream);
 int mliis_dwconv_bn_bwd(const float* dy, const float* z, const float* bn_mean, const float* bn_rstd, const float* bn_gamma,
                         const float* bn_beta, const float* w, float* dx, float* dw, int N, int H, int W, int C, int k, int stride,
-                        float* dw_part, size_t dw_part_floats, float* bn_part, size_t bn_part_floats, int* nblk, hipStream_t stream);
+                        float* dw_part, size_t dw_part_floats, float* bn_part, size_t bn_part_floats, int* nblk, int dy_dtype, int zx_dtype,
+                        hipStream_t stream);
+/*      Storage types (MLIIS_DT_*): forward (in_dtype of z, out_dtype of y) in {(F32, F32), (F32, BF16), (BF16, BF16)}; backward (dy_dtype of
+ *      dy [and z1], zx_dtype of z and dx) in {(F32, F32), (BF16, F32), (BF16, BF16)} -- the fp32 sides are a block's fp32 input / input
+ *      gradient (block 0 behind the stem, blocks without an expand conv).  Statistics are formed from the values as stored. */
 
 /*      mliis_mbconv_dw_bwd_march: the same backward with the depthwise batch norm's (bn1, efficientnet_model.py:271) backward APPLY
  *      formed while its operands are staged: da2 = the project conv's backward-data output (gradient w.r.t. a1 * gate), z1 = bn1's
@@ -125,7 +129,7 @@ int mliis_mbconv_dw_bwd_march(const float* da2, const float* z1, const float* me
                               const float* gate, const float* chan_add, const float* stage1, int stage1_nimg, float* dgamma1, float* dbeta1,
                               const float* z0, const float* mean0, const float* rstd0, const float* gamma0, const float* beta0, const float* w,
                               float* dx, int N, int H, int W, int C, int k, int stride, float* dw_part, size_t dw_part_floats, float* bn_part,
-                              size_t bn_part_floats, int* nblk, hipStream_t stream);
+                              size_t bn_part_floats, int* nblk, int dy_dtype, int zx_dtype, hipStream_t stream);
 
 /* ---- the depthwise half of an MBConv block on SMALL maps in ONE launch per direction (mbconv_small.hip): expand BN -> swish ->
  *      depthwise k x k (stride 1) -> BN -> swish -> squeeze-excite mean (efficientnet_model.py:183-200,266-271,247; utils.py:87-134)
@@ -145,11 +149,12 @@ int mliis_mbconv_dw_small_group_width(int C, int k);
 int mliis_mbconv_dw_fwd_small(const float* z0, const float* part0, int nblk0, const float* gamma0, const float* beta0, float* mean0,
                               float* rstd0, float* moving_mean0, float* moving_var0, const float* w, const float* gamma1, const float* beta1,
                               float* mean1, float* rstd1, float* moving_mean1, float* moving_var1, float* a0, float* z1, float* a1, float* s,
-                              int N, int H, int W, int C, int k, float eps, float momentum, int group_width, hipStream_t stream);
+                              int N, int H, int W, int C, int k, float eps, float momentum, int group_width, int act_dtype,
+                              hipStream_t stream);
 int mliis_mbconv_dw_bwd_small(const float* da2, const float* gate, const float* chan_add, const float* z1, const float* mean1,
                               const float* rstd1, const float* gamma1, const float* beta1, const float* w, const float* z0, const float* mean0,
                               const float* rstd0, const float* gamma0, const float* beta0, float* dgamma1, float* dbeta1, float* dw,
-                              float* dgamma0, float* dbeta0, float* dz0, int N, int H, int W, int C, int k, int group_width,
+                              float* dgamma0, float* dbeta0, float* dz0, int N, int H, int W, int C, int k, int group_width, int act_dtype,
                               hipStream_t stream);
 
 /* ---- dense conv (k 1|3, stride 1, TF-SAME, dilation >= 1, optional bias) on the fp32 matrix cores:
@@ -165,6 +170,12 @@ size_t mliis_conv2d_workspace_floats(int Nimg, int H, int W, int Cred, int Nout,
  *      (v_mfma_f32_16x16x32_fp8_fp8) -- activations times fp8_act_scale, weights times 2^floor(log2(224 / *fp8_w_amax)), both saturated
  *      at +-448 and converted in registers, the fp32 accumulators divided by the two scales; *fp8_w_amax = max |w| of the weight
  *      tensor, written by mliis_transpose_weights.  A 3x3 forward call and every backward call given MLIIS_PREC_FP8 runs bf16. */
+/*      Storage type of the EXPANDED tensors of an MBConv block (z0, z1, a1 and their gradients), `act_dtype` / `a_dtype` / `out_dtype`
+ *      arguments below: MLIIS_DT_F32, or MLIIS_DT_BF16 = bf16 in HBM (BASELINE configs[3]: models/efficientnet/efficientnet_model.py:
+ *      175-236, utils.py:87-134 run on bf16 activations there) -- the pointer then addresses 2-byte elements (leading dimensions stay in
+ *      elements), loads widen exactly, stores round to nearest even, every sum / statistic / accumulator is fp32. */
+#define MLIIS_DT_F32 0
+#define MLIIS_DT_BF16 1
 #define MLIIS_PREC_FP32 0
 #define MLIIS_PREC_BF16 1
 #define MLIIS_PREC_FP8 2
@@ -188,7 +199,7 @@ int mliis_conv2d_kernel_name(int Nimg, int H, int W, int Cred, int Nout, int ksi
 int mliis_conv2d_fwd(const float* x, int ldx, const float* x_scale, const float* wt, const float* bias,
                      const float* border_bias, float* y, int ldy, int Nimg, int H, int W, int Cin_total, int ci_begin, int Cin, int Cout,
                      int ksize, int dil, int accumulate, float* stats_part, int stats_swish, int* stats_nblk, float* ws,
-                     size_t ws_floats, int precision, float fp8_act_scale, const float* fp8_w_amax, hipStream_t stream);
+                     size_t ws_floats, int precision, float fp8_act_scale, const float* fp8_w_amax, int x_dtype, int y_dtype, hipStream_t stream);
 /*      batched HWIO -> HWOI copy of dense-conv weights between two arenas of identical layout; desc = device int32
  *      [ndesc][4] {offset, taps, Cin, Cout} */
 /*      amax (nullable, device float[ndesc]): also max |w| per descriptor (the fp8 operand scale of MLIIS_PREC_FP8).
@@ -198,7 +209,7 @@ int mliis_transpose_weights(const float* src, float* dst, const int* desc, int n
 /*      gradient w.r.t. input channels [ci_begin, ci_begin+Cin_out) of a conv whose weight has Cin_total input channels */
 int mliis_conv2d_bwd_data(const float* dy, int lddy, const float* w, float* dx, int lddx, int Nimg, int H, int W, int Cin_total,
                           int ci_begin, int Cin_out, int Cout, int ksize, int dil, int accumulate, float* ws, size_t ws_floats,
-                          int precision, hipStream_t stream);
+                          int precision, int dy_dtype, int dx_dtype, hipStream_t stream);
 /*      same, when dx is the gradient w.r.t. the OUTPUT of a plain batch norm over bn_x [M, Cin_out] (the project BN of the MBConv
  *      block in front, efficientnet_model.py:225-236; bn_img_scale = its drop-connect scales, nullable): on the plans that finish
  *      their rows inside one workgroup (the 28x28 / 14x14 maps) the launch also leaves stage 1 of that batch norm's backward
@@ -206,14 +217,14 @@ int mliis_conv2d_bwd_data(const float* dy, int lddy, const float* w, float* dx, 
 int mliis_conv2d_bwd_data_bn(const float* dy, int lddy, const float* w, float* dx, int lddx, int Nimg, int H, int W, int Cin_total,
                              int ci_begin, int Cin_out, int Cout, int ksize, int dil, int accumulate, float* ws, size_t ws_floats,
                              int precision, const float* bn_x, int bn_ldx, const float* bn_mean, const float* bn_rstd,
-                             const float* bn_img_scale, float* part, size_t part_floats, int* nblk, hipStream_t stream);
+                             const float* bn_img_scale, float* part, size_t part_floats, int* nblk, int dy_dtype, int dx_dtype, hipStream_t stream);
 /*      same as mliis_conv2d_bwd_data, when dx is the gradient w.r.t. gate_x * gate[image] (the squeeze-excite gating in front of a
  *      project conv, efficientnet_model.py:251): on the streaming plan the launch also leaves the column sums of dx * gate_x per
  *      16-row group, split by image, in part [*groups][2][Cin_out]; mliis_se_mlp_bwd(dgate = part, dgate_row_groups = *groups) folds
  *      them -- the gate's gradient without a pass over the two tensors.  *groups == 0: not produced (use mliis_colsum). */
 int mliis_conv2d_bwd_data_gate(const float* dy, int lddy, const float* w, float* dx, int lddx, int Nimg, int H, int W, int Cin_total,
                                int ci_begin, int Cin_out, int Cout, int ksize, int dil, float* ws, size_t ws_floats, int precision,
-                               const float* gate_x, int gate_ldx, float* part, size_t part_floats, int* groups, hipStream_t stream);
+                               const float* gate_x, int gate_ldx, float* part, size_t part_floats, int* groups, int dy_dtype, int dx_dtype, hipStream_t stream);
 size_t mliis_conv2d_bwd_filter_workspace_floats(int Nimg, int H, int W, int Cin, int Cout, int ksize);
 /*      writes rows [ci_begin, ci_begin+Cin) (per tap) of the full [k,k,Cin_total,Cout] gradient tensor dw */
 int mliis_conv2d_bwd_filter(const float* x, int ldx, const float* x_scale, const float* dy, int lddy, float* dw, int Nimg, int H, int W,
@@ -271,7 +282,7 @@ int mliis_bn_stats_partial(const float* x, int ldx, long long rows, int C, int p
 int mliis_bn_apply_fused(const float* x, int ldx, float* y, int ldy, long long rows, int C, int rows_per_img, const float* part, int nblk,
                          float eps, float momentum, int unbiased_moving_var, float* mean, float* rstd, float* moving_mean,
                          float* moving_var, const float* gamma, const float* beta, int pre_swish, int post_swish, const float* img_scale,
-                         const float* res, int ldr, float* pool_part, size_t pool_floats, int* pool_chunks, hipStream_t stream);
+                         const float* res, int ldr, float* pool_part, size_t pool_floats, int* pool_chunks, int act_dtype, hipStream_t stream);
 /*      workspace: mliis_colreduce_workspace_floats(rows, C, 1, 2) floats.  dskip (nullable): the same pass also writes the
  *      identity-skip gradient dskip[r,c] (+)= dy[r,c] (MBConv residual, efficientnet_model.py:286-288), so it needs no launch of
  *      its own.  dxsum_part (nullable): per-row-chunk column sums of dx, [chunks][C] with chunks * C = mliis_bn_bwd_dxsum_floats(rows, C) --
@@ -297,7 +308,7 @@ int mliis_bn_bwd(const float* x, int ldx, const float* dy, int lddy, float* dx, 
                  const float* mean, const float* rstd, const float* gamma, const float* beta, int pre_swish, int post_swish,
                  const float* img_scale, const float* chan_scale, const float* chan_add, float* dgamma, float* dbeta, float* dskip,
                  int lddskip, int dskip_accumulate, float* dxsum_part, size_t dxsum_floats, float* ws, size_t ws_floats,
-                 const float* stage1_part, int stage1_nblk, hipStream_t stream);
+                 const float* stage1_part, int stage1_nblk, int act_dtype, hipStream_t stream);
 /*      stage1_part (nullable, [stage1_nblk][2][C]): the reduce pass's partial sums {sum g, sum g*xhat} already produced elsewhere with the
  *      SAME g (mliis_dwconv_bwd_data_bn, mliis_dwconv_bn_bwd, mliis_conv2d_bwd_data_bn, mliis_se_mlp_bwd_bn); mliis_bn_bwd then runs its apply pass only */
 
@@ -331,7 +342,7 @@ int mliis_se_mlp_bwd(const float* dgate, int dgate_row_groups, const float* gate
 size_t mliis_se_bn_bwd_sums_floats(int N, int rows_per_img, int C);
 int mliis_se_bn_bwd_sums(const float* x, int ldx, const float* dy, int lddy, int N, int rows_per_img, int C, const float* mean,
                          const float* rstd, const float* gamma, const float* beta, float* part, size_t part_floats, int* nblk,
-                         hipStream_t stream);
+                         int act_dtype, hipStream_t stream);
 int mliis_se_mlp_bwd_bn(const float* sums, int sums_nblk, const float* gate, const float* hpre, const float* w1, const float* w1t, const float* w2,
                         float* dpre1, float* dpre2, float* chan_add, float* stage1, int N, int C, int R, int HW, hipStream_t stream);
 int mliis_se_wgrad_batched(const long long* desc, int ndesc, long long total_tiles, hipStream_t stream);

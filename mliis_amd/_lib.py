@@ -34,29 +34,29 @@ SIGNATURES = {
     "mliis_dwconv_bn_fwd_blocks": (_i, [_i, _i, _i, _i, _i, _i]),
     "mliis_dwconv_bn_supported": (_i, [_i, _i, _i, _i, _i, _i]),
     "mliis_dwconv_bn_bwd_blocks": (_i, [_i, _i, _i, _i, _i, _i]),
-    "mliis_dwconv_bn_fwd": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _p, _f, _f, _p, _p, _i, _i, _i, _i, _i, _i, _p, _sz, _p, _p]),
-    "mliis_dwconv_bn_bwd": (_i, [_p] * 9 + [_i, _i, _i, _i, _i, _i, _p, _sz, _p, _sz, _p, _p]),
-    "mliis_mbconv_dw_bwd_march": (_i, [_p] * 9 + [_i] + [_p] * 9 + [_i, _i, _i, _i, _i, _i, _p, _sz, _p, _sz, _p, _p]),
+    "mliis_dwconv_bn_fwd": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _p, _f, _f, _p, _p, _i, _i, _i, _i, _i, _i, _p, _sz, _p, _i, _i, _p]),
+    "mliis_dwconv_bn_bwd": (_i, [_p] * 9 + [_i, _i, _i, _i, _i, _i, _p, _sz, _p, _sz, _p, _i, _i, _p]),
+    "mliis_mbconv_dw_bwd_march": (_i, [_p] * 9 + [_i] + [_p] * 9 + [_i, _i, _i, _i, _i, _i, _p, _sz, _p, _sz, _p, _i, _i, _p]),
     "mliis_augment_stage": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "mliis_rng_masks": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _p]),
     "mliis_mbconv_dw_small_supported": (_i, [_i, _i, _i, _i, _i, _i]),
     "mliis_mbconv_dw_small_group_width": (_i, [_i, _i]),
-    "mliis_mbconv_dw_fwd_small": (_i, [_p, _p, _i] + [_p] * 17 + [_i, _i, _i, _i, _i, _f, _f, _i, _p]),
-    "mliis_mbconv_dw_bwd_small": (_i, [_p] * 20 + [_i, _i, _i, _i, _i, _i, _p]),
+    "mliis_mbconv_dw_fwd_small": (_i, [_p, _p, _i] + [_p] * 17 + [_i, _i, _i, _i, _i, _f, _f, _i, _i, _p]),
+    "mliis_mbconv_dw_bwd_small": (_i, [_p] * 20 + [_i, _i, _i, _i, _i, _i, _i, _p]),
     "mliis_conv2d_workspace_floats": (_sz, [_i, _i, _i, _i, _i, _i]),
     "mliis_conv2d_plan": (_i, [_i, _i, _i, _i, _i, _i, _p, _p, _p]),
     "mliis_conv1x1_occupancy": (_i, [_i, _i, _i, _p]),
     "mliis_conv2d_kernel_name": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _p, _sz]),
-    "mliis_conv2d_fwd": (_i, [_p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _p, _sz, _i, _f, _p, _p]),
+    "mliis_conv2d_fwd": (_i, [_p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _p, _sz, _i, _f, _p, _i, _i, _p]),
     "mliis_rsd_concat_pool_floats": (_sz, [_i, _i, _i, _i]),
     "mliis_rsd_concat_pool": (_i, [_p, _i, _i, _i, _i, _p, _i, _i, _p, _i, _i, _i, _i, _p, _sz, _p, _p]),
     "mliis_rsd_pool_fwd": (_i, [_p, _i, _f, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "mliis_rsd_pool_bwd_workspace_floats": (_sz, [_i, _i]),
     "mliis_rsd_pool_bwd": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _p]),
     "mliis_transpose_weights": (_i, [_p, _p, _p, _i, _ll, _p, _p]),
-    "mliis_conv2d_bwd_data": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _i, _p]),
-    "mliis_conv2d_bwd_data_bn": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _i, _p, _i, _p, _p, _p, _p, _sz, _p, _p]),
-    "mliis_conv2d_bwd_data_gate": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _i, _p, _i, _p, _sz, _p, _p]),
+    "mliis_conv2d_bwd_data": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _i, _i, _i, _p]),
+    "mliis_conv2d_bwd_data_bn": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _i, _p, _i, _p, _p, _p, _p, _sz, _p, _i, _i, _p]),
+    "mliis_conv2d_bwd_data_gate": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _i, _p, _i, _p, _sz, _p, _i, _i, _p]),
     "mliis_conv2d_bwd_filter_workspace_floats": (_sz, [_i, _i, _i, _i, _i, _i]),
     "mliis_conv2d_bwd_filter": (_i, [_p, _i, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _i, _p]),
     "mliis_conv2d_bwd_filter_plan": (_i, [_i, _i, _i, _i, _i, _i, _p]),
@@ -65,8 +65,8 @@ SIGNATURES = {
     "mliis_bn_stats": (_i, [_p, _i, _ll, _i, _i, _f, _f, _i, _p, _p, _p, _p, _p, _sz, _p]),
     "mliis_bn_apply": (_i, [_p, _i, _p, _i, _ll, _i, _i, _p, _p, _p, _p, _i, _i, _p, _p, _i, _p]),
     "mliis_bn_stats_partial": (_i, [_p, _i, _ll, _i, _i, _p, _sz, _p, _p]),
-    "mliis_bn_apply_fused": (_i, [_p, _i, _p, _i, _ll, _i, _i, _p, _i, _f, _f, _i, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _i, _p, _sz, _p, _p]),
-    "mliis_bn_bwd": (_i, [_p, _i, _p, _i, _p, _i, _ll, _i, _i, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _i, _i, _p, _sz, _p, _sz, _p, _i, _p]),
+    "mliis_bn_apply_fused": (_i, [_p, _i, _p, _i, _ll, _i, _i, _p, _i, _f, _f, _i, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _i, _p, _sz, _p, _i, _p]),
+    "mliis_bn_bwd": (_i, [_p, _i, _p, _i, _p, _i, _ll, _i, _i, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _i, _i, _p, _sz, _p, _sz, _p, _i, _i, _p]),
     "mliis_bn_apply_fused_pair": (_i, [_p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _ll, _i, _f, _f, _i, _i, _i, _p]),
     "mliis_bn_bwd_pair": (_i, [_p] * 20 + [_i, _i, _i, _ll, _i, _i, _i, _sz, _p, _sz, _p]),
     "mliis_bn_bwd_dxsum_floats": (_sz, [_ll, _i]),
@@ -74,7 +74,7 @@ SIGNATURES = {
     "mliis_se_mlp_fwd": (_i, [_p, _i, _f, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "mliis_se_mlp_bwd": (_i, [_p, _i] + [_p] * 13 + [_i, _i, _i, _i, _p]),
     "mliis_se_bn_bwd_sums_floats": (_sz, [_i, _i, _i]),
-    "mliis_se_bn_bwd_sums": (_i, [_p, _i, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _sz, _p, _p]),
+    "mliis_se_bn_bwd_sums": (_i, [_p, _i, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _sz, _p, _i, _p]),
     "mliis_se_mlp_bwd_bn": (_i, [_p, _i] + [_p] * 9 + [_i, _i, _i, _i, _p]),
     "mliis_se_wgrad_batched": (_i, [_p, _i, _ll, _p]),
     "mliis_chan_affine": (_i, [_p, _i, _p, _p, _p, _i, _ll, _i, _i, _i, _p]),

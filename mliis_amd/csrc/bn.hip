@@ -232,15 +232,17 @@ struct BnApplyAlt {
 };
 // (<= 168 VGPRs: three workgroups per CU.  With the 16-block fold batches of an earlier form the kernel needed 216 and two fitted -- the
 //  600-1568-workgroup launches of the large maps ran in two or three rounds with few waves in flight; stamps build, round 3)
-__global__ __launch_bounds__(256, 3) void bn_apply_fused_k(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy,
+// TX / TY: storage types of x and y (float | bf16s: the expanded tensors of `--precision bf16-storage`; the pair form is float only)
+template <typename TX, typename TY>
+__global__ __launch_bounds__(256, 3) void bn_apply_fused_k(const TX* __restrict__ x, int ldx, TY* __restrict__ y, int ldy,
                                                         long long rows, int C, int rows_per_img, BnFold f,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         int pre_swish, int post_swish, const float* __restrict__ img_scale,
                                                         const float* __restrict__ res, int ldr, int rows_per_block,
                                                         float* __restrict__ pool_part, int pool_chunks, BnApplyAlt alt) {
   if (blockIdx.z == 1) {   // (uniform)
-    x = alt.x;
-    y = alt.y;
+    x = reinterpret_cast<const TX*>(alt.x);
+    y = reinterpret_cast<TY*>(alt.y);
     f = alt.f;
     gamma = alt.gamma;
     beta = alt.beta;
@@ -265,8 +267,9 @@ __global__ __launch_bounds__(256, 3) void bn_apply_fused_k(const float* __restri
   // The first batch of rows does not depend on the statistics: fetch it BEFORE folding them, so the small-map launches (one batch
   // per thread) pay one memory round trip instead of two.
   long long r = r0 + rl;
-  const float* rbase = res != nullptr ? res : x;   // no residual: the loads shadow x (ignored later) -- no branch around them
-  const int rld = res != nullptr ? ldr : ldx;
+  const float* rbase = res != nullptr ? res : gamma;   // no residual: the loads shadow gamma (ignored later) -- no branch around them
+  const int rld = res != nullptr ? ldr : 0;
+  const int rcol = res != nullptr ? c : 0;
   const float* isb = img_scale != nullptr ? img_scale : gamma;   // (absent: shadows gamma, ignored)
   float4 v0[kBatch], rv0[kBatch];
   float is0[kBatch];
@@ -274,8 +277,8 @@ __global__ __launch_bounds__(256, 3) void bn_apply_fused_k(const float* __restri
   for (int u = 0; u < kBatch; ++u) {
     const long long ru = r + u * kRowLanes;
     const long long rr = ru < r1 ? ru : 0;
-    v0[u] = ld4(x + rr * ldx + c);
-    rv0[u] = ld4(rbase + rr * rld + c);
+    v0[u] = ldq(x + rr * ldx + c);
+    rv0[u] = ld4(rbase + rr * rld + rcol);
     is0[u] = isb[img_scale != nullptr ? (int)rr / rows_per_img : 0];
   }
   const float4 g = ld4(gamma + c), b = ld4(beta + c);   // (before the fold: they do not depend on it)
@@ -313,8 +316,9 @@ __global__ __launch_bounds__(256, 3) void bn_apply_fused_k(const float* __restri
     if (post_swish) o = make_float4(swish_f(o.x), swish_f(o.y), swish_f(o.z), swish_f(o.w));
     if (img_scale != nullptr) o = f4scale(o, isc);
     if (res != nullptr) o = f4add(o, rv);
+    o = stored_value(y, o);   // (bf16 storage: the pooled means see what the consumers will read)
     pool = f4add(pool, o);
-    st4(y + rw * ldy + c, o);
+    stq(y + rw * ldy + c, o);
   };
 #pragma unroll
   for (int u = 0; u < kBatch; ++u)
@@ -325,15 +329,15 @@ __global__ __launch_bounds__(256, 3) void bn_apply_fused_k(const float* __restri
     float is[kBatch];
 #pragma unroll
     for (int u = 0; u < kBatch; ++u) {
-      v[u] = ld4(x + (r + u * kRowLanes) * ldx + c);
-      rv[u] = ld4(rbase + (r + u * kRowLanes) * rld + c);
+      v[u] = ldq(x + (r + u * kRowLanes) * ldx + c);
+      rv[u] = ld4(rbase + (r + u * kRowLanes) * rld + rcol);
       is[u] = isb[img_scale != nullptr ? (int)(r + u * kRowLanes) / rows_per_img : 0];
     }
 #pragma unroll
     for (int u = 0; u < kBatch; ++u) finish(r + u * kRowLanes, v[u], rv[u], is[u]);
   }
   for (; r < r1; r += kRowLanes)
-    finish(r, ld4(x + r * ldx + c), ld4(rbase + r * rld + c), isb[img_scale != nullptr ? (int)r / rows_per_img : 0]);
+    finish(r, ldq(x + r * ldx + c), ld4(rbase + r * rld + rcol), isb[img_scale != nullptr ? (int)r / rows_per_img : 0]);
   if (pool_part == nullptr) return;   // (uniform)
   // pooled partial of this block: butterfly over the 8 row lanes of a wave that share a quad, then the 4 waves through LDS
 #pragma unroll
@@ -381,11 +385,11 @@ static inline void bn_bwd_grid(long long rows, int C, int* gx, int* gy, int* row
 }
 
 // upstream gradient seen by the BN output: dy * img_scale[n] * chan_scale[n,c] + chan_add[n,c]
-template <bool SE>   // SE: per-image vectors (drop-connect scale, squeeze-excite gate / pooled gradient) are present
-struct BnBwdCommon {
-  const float* x;   // conv output saved in forward (pre-BN, pre-swish if pre_swish)
+template <bool SE, typename T = float>   // SE: per-image vectors (drop-connect scale, squeeze-excite gate / pooled gradient) are present;
+struct BnBwdCommon {                       // T: storage type of x and dy (and of the dx the apply kernel writes)
+  const T* x;   // conv output saved in forward (pre-BN, pre-swish if pre_swish)
   int ldx;
-  const float* dy;
+  const T* dy;
   int lddy;
   int rows_per_img;
   int C;
@@ -401,8 +405,8 @@ struct BnBwdCommon {
   // one dependent round trip per row)
   struct Raw { float4 x, g, cs, ca; float is; };
   __device__ __forceinline__ void load_raw(long long row, int c, Raw& r) const {
-    r.x = ld4(x + row * ldx + c);
-    r.g = ld4(dy + row * lddy + c);
+    r.x = ldq(x + row * ldx + c);
+    r.g = ldq(dy + row * lddy + c);
     if (SE) {
       const long long n = (int)row / rows_per_img;     // rows < 2^31 (checked on the host)
       // absent vectors read a valid dummy (the mean vector) and are ignored in finish(): no branch around the loads
@@ -486,14 +490,15 @@ struct BnBwdAlt {
   const float *x, *dy, *mean, *rstd, *gamma, *beta, *part;
   float *dgamma, *dbeta, *dx, *dxsum_part;
 };
-template <bool SE>
-__global__ __launch_bounds__(256, SE ? 2 : 3) void bn_bwd_apply_fused_k(BnBwdCommon<SE> p, long long rows, const float* __restrict__ part, int nblk,
+template <bool SE, typename T = float>
+__global__ __launch_bounds__(256, SE ? 2 : 3) void bn_bwd_apply_fused_k(BnBwdCommon<SE, T> p, long long rows, const float* __restrict__ part, int nblk,
                                                             double inv_n, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                            float* __restrict__ dx, int lddx, int rows_per_block, SkipOut skip,
+                                                            T* __restrict__ dx, int lddx, int rows_per_block, SkipOut skip,
                                                             float* __restrict__ dxsum_part, BnBwdAlt alt) {
-  if (blockIdx.z == 1) {   // (uniform)
-    p.x = alt.x; p.dy = alt.dy; p.mean = alt.mean; p.rstd = alt.rstd; p.gamma = alt.gamma; p.beta = alt.beta;
-    part = alt.part; dgamma = alt.dgamma; dbeta = alt.dbeta; dx = alt.dx; dxsum_part = alt.dxsum_part;
+  if (blockIdx.z == 1) {   // (uniform; the pair form is float only)
+    p.x = reinterpret_cast<const T*>(alt.x); p.dy = reinterpret_cast<const T*>(alt.dy); p.mean = alt.mean; p.rstd = alt.rstd; p.gamma = alt.gamma;
+    p.beta = alt.beta;
+    part = alt.part; dgamma = alt.dgamma; dbeta = alt.dbeta; dx = reinterpret_cast<T*>(alt.dx); dxsum_part = alt.dxsum_part;
   }
   __shared__ double smd[2 * 32 * 32];
   __shared__ __attribute__((aligned(16))) float s_c1[kChanBlock], s_c2[kChanBlock];
@@ -507,13 +512,13 @@ __global__ __launch_bounds__(256, SE ? 2 : 3) void bn_bwd_apply_fused_k(BnBwdCom
   long long r = (long long)blockIdx.y * rows_per_block + rl;
   if (!cok) r1 = r;
   // first batch of rows fetched BEFORE the fold of the gradient sums (it does not depend on them): one round trip on small maps
-  typename BnBwdCommon<SE>::Raw raw0[kBatch];
+  typename BnBwdCommon<SE, T>::Raw raw0[kBatch];
 #pragma unroll
   for (int u = 0; u < kBatch; ++u) {
     const long long ru = r + u * kRowLanes;
     p.load_raw(ru < r1 ? ru : 0, c, raw0[u]);
   }
-  const typename BnBwdCommon<SE>::Ctx kc = p.ctx(c);
+  const typename BnBwdCommon<SE, T>::Ctx kc = p.ctx(c);
   double s, sx;
   fold32<8>(part, nblk, p.C, c0, smd, s, sx);
   if (t < 32) {
@@ -529,7 +534,7 @@ __global__ __launch_bounds__(256, SE ? 2 : 3) void bn_bwd_apply_fused_k(BnBwdCom
   if (!cok && dxsum_part == nullptr) return;   // (surplus lanes stay for the column-sum reduction, with an empty row range)
   const float4 a = ld4(s_c1 + q * 4), b = ld4(s_c2 + q * 4), ga = kc.ga, rs = kc.rs;
   float4 dsum = f4zero();   // column sum of this thread's dx rows (bias gradient of a conv -> swish -> BN stack)
-  auto finish = [&](long long rw, const typename BnBwdCommon<SE>::Raw& raw) {
+  auto finish = [&](long long rw, const typename BnBwdCommon<SE, T>::Raw& raw) {
     float4 xin, xhat, g;
     skip.put(rw, c, raw.g);
     p.finish(kc, raw, xin, xhat, g);
@@ -545,21 +550,21 @@ __global__ __launch_bounds__(256, SE ? 2 : 3) void bn_bwd_apply_fused_k(BnBwdCom
       d.w *= swish_grad_f(xin.w);
     }
     dsum = f4add(dsum, d);
-    st4(dx + rw * lddx + c, d);
+    stq(dx + rw * lddx + c, d);
   };
 #pragma unroll
   for (int u = 0; u < kBatch; ++u)
     if (r + u * kRowLanes < r1) finish(r + u * kRowLanes, raw0[u]);
   r += kBatch * kRowLanes;
   for (; r + (kBatch - 1) * kRowLanes < r1; r += kBatch * kRowLanes) {
-    typename BnBwdCommon<SE>::Raw raw[kBatch];
+    typename BnBwdCommon<SE, T>::Raw raw[kBatch];
 #pragma unroll
     for (int u = 0; u < kBatch; ++u) p.load_raw(r + u * kRowLanes, c, raw[u]);
 #pragma unroll
     for (int u = 0; u < kBatch; ++u) finish(r + u * kRowLanes, raw[u]);
   }
   for (; r < r1; r += kRowLanes) {
-    typename BnBwdCommon<SE>::Raw raw;
+    typename BnBwdCommon<SE, T>::Raw raw;
     p.load_raw(r, c, raw);
     finish(r, raw);
   }
@@ -607,19 +612,20 @@ struct SumOp {  // column sum of a (optionally times b)
 // and the batch norm's stage-1 sums follow without touching the tensors again:
 //     sum g = sum_n gate[n] v1[n] + chan_add[n] v3[n],   sum g xhat = sum_n gate[n] v2[n] + chan_add[n] v4[n]
 // (mliis_se_mlp_bwd_bn forms them).  Replaces the gate-gradient column sum (+ its finalize) and the batch norm's reduce pass.
+template <typename T = float>   // T: storage type of z1 and da2
 struct SeBnOp {
   static constexpr int NV = 5;
-  const float* x;    // z1: the batch norm's input
+  const T* x;    // z1: the batch norm's input
   int ldx;
-  const float* dy;   // da2
+  const T* dy;   // da2
   int lddy;
   const float *mean, *rstd, *gamma, *beta;
   struct Raw { float4 x, g; };
   struct Ctx { float4 m, rs, ga, be; };
   __device__ __forceinline__ Ctx ctx(int c) const { return Ctx{ld4(mean + c), ld4(rstd + c), ld4(gamma + c), ld4(beta + c)}; }
   __device__ __forceinline__ void load(int, long long row, int c, Raw& r) const {
-    r.x = ld4(x + row * ldx + c);
-    r.g = ld4(dy + row * lddy + c);
+    r.x = ldq(x + row * ldx + c);
+    r.g = ldq(dy + row * lddy + c);
   }
   __device__ __forceinline__ void one(float x, float g, float m, float rs, float ga, float be, float* o) const {
     const float xh = (x - m) * rs;
@@ -869,8 +875,31 @@ int mliis_bn_bwd(const float* x, int ldx, const float* dy, int lddy, float* dx, 
                  int rows_per_img, const float* mean, const float* rstd, const float* gamma, const float* beta, int pre_swish,
                  int post_swish, const float* img_scale, const float* chan_scale, const float* chan_add, float* dgamma,
                  float* dbeta, float* dskip, int lddskip, int dskip_accumulate, float* dxsum_part, size_t dxsum_floats, float* ws,
-                 size_t ws_floats, const float* stage1_part, int stage1_nblk, hipStream_t stream) {
+                 size_t ws_floats, const float* stage1_part, int stage1_nblk, int act_dtype, hipStream_t stream) {
   MLIIS_REQUIRE(x && dy && dx && mean && rstd && gamma && beta && dgamma && dbeta && ws, MLIIS_ERR_ARG, "bn_bwd: null pointer");
+  MLIIS_REQUIRE(act_dtype == MLIIS_DT_F32 || act_dtype == MLIIS_DT_BF16, MLIIS_ERR_ARG, "bn_bwd: act_dtype must be MLIIS_DT_F32 or MLIIS_DT_BF16");
+  if (act_dtype == MLIIS_DT_BF16) {   // x, dy, dx are bf16 tensors (an expanded MBConv tensor and its gradient): stage 1 comes from the producer
+    MLIIS_REQUIRE(stage1_part != nullptr && stage1_nblk > 0 && dskip == nullptr && dxsum_part == nullptr, MLIIS_ERR_UNSUPPORTED,
+                  "bn_bwd: bf16 tensors need the producer's stage-1 sums and take no skip / column-sum outputs");
+    MLIIS_REQUIRE(rows > 1 && rows < (1LL << 31) && C > 0 && (C & 3) == 0 && (ldx & 3) == 0 && (lddy & 3) == 0 && (lddx & 3) == 0 && ldx >= C &&
+                      lddy >= C && lddx >= C && rows_per_img > 0 && aligned16(x) && aligned16(dy) && aligned16(dx) && aligned16(stage1_part),
+                  MLIIS_ERR_ARG, "bn_bwd: bad shape / alignment");
+    int gx_, gy_, rpb_;
+    bn_bwd_grid(rows, C, &gx_, &gy_, &rpb_);
+    const bf16s *xb = reinterpret_cast<const bf16s*>(x), *gb = reinterpret_cast<const bf16s*>(dy);
+    bf16s* db = reinterpret_cast<bf16s*>(dx);
+    if (img_scale != nullptr || chan_scale != nullptr || chan_add != nullptr) {
+      BnBwdCommon<true, bf16s> p{xb, ldx, gb, lddy, rows_per_img, C, mean, rstd, gamma, beta, pre_swish, post_swish, img_scale, chan_scale, chan_add};
+      hipLaunchKernelGGL((bn_bwd_apply_fused_k<true, bf16s>), dim3(gx_, gy_), dim3(256), 0, stream, p, rows, stage1_part, stage1_nblk,
+                         1.0 / (double)rows, dgamma, dbeta, db, lddx, rpb_, SkipOut{nullptr, 0, 0}, (float*)nullptr, BnBwdAlt{});
+    } else {
+      BnBwdCommon<false, bf16s> p{xb, ldx, gb, lddy, rows_per_img, C, mean, rstd, gamma, beta, pre_swish, post_swish, nullptr, nullptr, nullptr};
+      hipLaunchKernelGGL((bn_bwd_apply_fused_k<false, bf16s>), dim3(gx_, gy_), dim3(256), 0, stream, p, rows, stage1_part, stage1_nblk,
+                         1.0 / (double)rows, dgamma, dbeta, db, lddx, rpb_, SkipOut{nullptr, 0, 0}, (float*)nullptr, BnBwdAlt{});
+    }
+    MLIIS_CHECK_LAUNCH("bn_bwd_apply_fused (bf16)");
+    return MLIIS_OK;
+  }
   MLIIS_REQUIRE(dskip == nullptr || (aligned16(dskip) && (lddskip & 3) == 0 && lddskip >= C && dskip != dx), MLIIS_ERR_ARG,
                 "bn_bwd: bad skip-gradient output");
   MLIIS_REQUIRE(aligned16(dgamma) && aligned16(dbeta), MLIIS_ERR_ALIGN, "bn_bwd: dgamma / dbeta must be 16-byte aligned");
@@ -924,17 +953,24 @@ int mliis_bn_bwd(const float* x, int ldx, const float* dy, int lddy, float* dx, 
 // part [N][*nblk][5][C]: per image and row chunk, the five sums of SeBnOp over (dy = da2, x = z1).
 int mliis_se_bn_bwd_sums(const float* x, int ldx, const float* dy, int lddy, int N, int rows_per_img, int C, const float* mean,
                          const float* rstd, const float* gamma, const float* beta, float* part, size_t part_floats, int* nblk,
-                         hipStream_t stream) {
+                         int act_dtype, hipStream_t stream) {
   MLIIS_REQUIRE(x && dy && mean && rstd && gamma && beta && part && nblk, MLIIS_ERR_ARG, "se_bn_bwd_sums: null pointer");
+  MLIIS_REQUIRE(act_dtype == MLIIS_DT_F32 || act_dtype == MLIIS_DT_BF16, MLIIS_ERR_ARG, "se_bn_bwd_sums: bad act_dtype");
   MLIIS_REQUIRE(N > 0 && rows_per_img > 0 && C > 0 && (C & 3) == 0 && (ldx & 3) == 0 && (lddy & 3) == 0 && ldx >= C && lddy >= C &&
                     (long long)N * rows_per_img < (1LL << 31),
                 MLIIS_ERR_ARG, "se_bn_bwd_sums: bad shape");
   MLIIS_REQUIRE(aligned16(x) && aligned16(dy) && aligned16(mean) && aligned16(rstd) && aligned16(gamma) && aligned16(beta) && aligned16(part),
                 MLIIS_ERR_ALIGN, "se_bn_bwd_sums: pointers must be 16-byte aligned");
-  SeBnOp op{x, ldx, dy, lddy, mean, rstd, gamma, beta};
   ColGeom g;
   // (about two workgroups per CU: the squeeze-excite backward folds an image's chunks itself)
-  int rc = launch_colreduce(op, rows_per_img, C, N, part, part_floats, stream, &g, "se_bn_bwd_sums", 512);
+  int rc;
+  if (act_dtype == MLIIS_DT_BF16) {
+    SeBnOp<bf16s> op{reinterpret_cast<const bf16s*>(x), ldx, reinterpret_cast<const bf16s*>(dy), lddy, mean, rstd, gamma, beta};
+    rc = launch_colreduce(op, rows_per_img, C, N, part, part_floats, stream, &g, "se_bn_bwd_sums", 512);
+  } else {
+    SeBnOp<float> op{x, ldx, dy, lddy, mean, rstd, gamma, beta};
+    rc = launch_colreduce(op, rows_per_img, C, N, part, part_floats, stream, &g, "se_bn_bwd_sums", 512);
+  }
   if (rc) return rc;
   *nblk = g.nblk;
   return MLIIS_OK;
@@ -968,8 +1004,9 @@ int mliis_bn_stats_partial(const float* x, int ldx, long long rows, int C, int p
 int mliis_bn_apply_fused(const float* x, int ldx, float* y, int ldy, long long rows, int C, int rows_per_img, const float* part, int nblk,
                          float eps, float momentum, int unbiased_moving_var, float* mean, float* rstd, float* moving_mean,
                          float* moving_var, const float* gamma, const float* beta, int pre_swish, int post_swish, const float* img_scale,
-                         const float* res, int ldr, float* pool_part, size_t pool_floats, int* pool_chunks, hipStream_t stream) {
+                         const float* res, int ldr, float* pool_part, size_t pool_floats, int* pool_chunks, int act_dtype, hipStream_t stream) {
   MLIIS_REQUIRE(x && y && part && mean && rstd && gamma && beta, MLIIS_ERR_ARG, "bn_apply_fused: null pointer");
+  MLIIS_REQUIRE(act_dtype == MLIIS_DT_F32 || act_dtype == MLIIS_DT_BF16, MLIIS_ERR_ARG, "bn_apply_fused: bad act_dtype");
   MLIIS_REQUIRE(rows > 1 && rows < (1LL << 31) && nblk > 0 && C > 0 && (C & 3) == 0 && (ldx & 3) == 0 && (ldy & 3) == 0 && ldx >= C && ldy >= C &&
                     rows_per_img > 0 && (res == nullptr || ((ldr & 3) == 0 && ldr >= C)),
                 MLIIS_ERR_ARG, "bn_apply_fused: bad shape");
@@ -1005,8 +1042,13 @@ int mliis_bn_apply_fused(const float* x, int ldx, float* y, int ldy, long long r
                   (size_t)gy * C, pool_floats);
     *pool_chunks = cpi;
   }
-  hipLaunchKernelGGL(bn_apply_fused_k, dim3(gx, gy), dim3(256), 0, stream, x, ldx, y, ldy, rows, C, rows_per_img, f, gamma, beta, pre_swish,
-                     post_swish, img_scale, res, ldr, rpb, pool_part, cpi, BnApplyAlt{});
+  if (act_dtype == MLIIS_DT_BF16)   // x and y are bf16 tensors (z1 -> a1 of an MBConv block)
+    hipLaunchKernelGGL((bn_apply_fused_k<bf16s, bf16s>), dim3(gx, gy), dim3(256), 0, stream, reinterpret_cast<const bf16s*>(x), ldx,
+                       reinterpret_cast<bf16s*>(y), ldy, rows, C, rows_per_img, f, gamma, beta, pre_swish, post_swish, img_scale, res, ldr, rpb,
+                       pool_part, cpi, BnApplyAlt{});
+  else
+    hipLaunchKernelGGL((bn_apply_fused_k<float, float>), dim3(gx, gy), dim3(256), 0, stream, x, ldx, y, ldy, rows, C, rows_per_img, f, gamma, beta,
+                       pre_swish, post_swish, img_scale, res, ldr, rpb, pool_part, cpi, BnApplyAlt{});
   MLIIS_CHECK_LAUNCH("bn_apply_fused");
   return MLIIS_OK;
 }
@@ -1041,7 +1083,7 @@ int mliis_bn_apply_fused_pair(const float* x0, float* y0, const float* part0, in
     rpb = g2.rows_per_block;
   }
   fit_one_round(rows, gx, 2, &gy, &rpb);
-  hipLaunchKernelGGL(bn_apply_fused_k, dim3(gx, gy, 2), dim3(256), 0, stream, x0, ldx, y0, ldy, rows, C, (int)rows, f0, gamma0, beta0, pre_swish,
+  hipLaunchKernelGGL((bn_apply_fused_k<float, float>), dim3(gx, gy, 2), dim3(256), 0, stream, x0, ldx, y0, ldy, rows, C, (int)rows, f0, gamma0, beta0, pre_swish,
                      post_swish, nullptr, nullptr, 0, rpb, nullptr, 0, BnApplyAlt{x1, y1, f1, gamma1, beta1});
   MLIIS_CHECK_LAUNCH("bn_apply_fused_pair");
   return MLIIS_OK;

@@ -45,6 +45,38 @@ __device__ __forceinline__ float swish_grad_f(float x) {
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 
+// ---- storage element types of the expanded MBConv tensors (z0, z1, a1 and their gradients): float, or bf16 in HBM with fp32
+//      arithmetic everywhere (BASELINE configs[3], `--precision bf16-storage`).  Loads widen exactly (bf16 -> fp32 is a 16-bit shift),
+//      stores round to nearest even (v_cvt_pk_bf16_f32) -- the rounding the oracle's storage points apply (oracle/efficientlab_ref.py).
+//      A quad of 4 consecutive channels is 16 bytes (float) or 8 bytes (bf16s); leading dimensions are in ELEMENTS.
+struct bf16s {
+  unsigned short u;
+};
+#define MLIIS_DT_F32 0
+#define MLIIS_DT_BF16 1
+typedef __bf16 mliis_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_bf16_pair(float lo, float hi) {
+  mliis_bf16x2 t;
+  t[0] = (__bf16)lo;
+  t[1] = (__bf16)hi;
+  return __builtin_bit_cast(unsigned, t);
+}
+__device__ __forceinline__ float bf16_round_f(float v) { return __uint_as_float(pack_bf16_pair(v, 0.f) << 16); }
+__device__ __forceinline__ float4 unpack_bf16x4(uint2 u) {
+  return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+}
+__device__ __forceinline__ uint2 pack_bf16x4(float4 v) { return make_uint2(pack_bf16_pair(v.x, v.y), pack_bf16_pair(v.z, v.w)); }
+__device__ __forceinline__ float4 ldq(const float* p) { return ld4(p); }
+__device__ __forceinline__ float4 ldq(const bf16s* p) { return unpack_bf16x4(*reinterpret_cast<const uint2*>(p)); }
+__device__ __forceinline__ void stq(float* p, float4 v) { st4(p, v); }
+__device__ __forceinline__ void stq(bf16s* p, float4 v) { *reinterpret_cast<uint2*>(p) = pack_bf16x4(v); }
+// the value a consumer will read back after stq(): identity for float, the bf16 rounding for bf16s
+__device__ __forceinline__ float4 stored_value(const float*, float4 v) { return v; }
+__device__ __forceinline__ float4 stored_value(const bf16s*, float4 v) {
+  return make_float4(bf16_round_f(v.x), bf16_round_f(v.y), bf16_round_f(v.z), bf16_round_f(v.w));
+}
+template <typename T> struct ElemBytes { static constexpr int value = (int)sizeof(T); };
+
 // source row/column pair and weight of one output coordinate of tf.image.resize_images(BILINEAR, align_corners=True)
 // (scale = (in - 1) / (out - 1)); head.hip's resize kernels and rsd.hip's concat share it
 __device__ __forceinline__ void src_coord(int o, float scale, int in_size, int& i0, int& i1, float& l) {

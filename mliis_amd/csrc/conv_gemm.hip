@@ -504,10 +504,21 @@ size_t mliis_conv2d_workspace_floats(int Nimg, int H, int W, int Cred, int Nout,
 int mliis_conv2d_fwd(const float* x, int ldx, const float* x_scale, const float* wt, const float* bias,
                      const float* border_bias, float* y, int ldy, int Nimg, int H, int W, int Cin_total, int ci_begin, int Cin, int Cout,
                      int ksize, int dil, int accumulate, float* stats_part, int stats_swish, int* stats_nblk, float* ws,
-                     size_t ws_floats, int precision, float fp8_act_scale, const float* fp8_w_amax, hipStream_t stream) {
+                     size_t ws_floats, int precision, float fp8_act_scale, const float* fp8_w_amax, int x_dtype, int y_dtype,
+                     hipStream_t stream) {
   int rc = conv_check("conv2d_fwd", Nimg, H, W, Cin, Cout, ksize, dil);
   if (rc) return rc;
   if ((rc = prec_check("conv2d_fwd", precision))) return rc;
+  // bf16 STORAGE of x and / or y (an expanded MBConv tensor): bf16 operands on the matrix cores, a 1x1 conv, no accumulate, and no
+  // plan that finishes its tiles in a second launch (split-K / stream-K slabs) -- the statistics are formed from the rounded output
+  const bool xbf = x_dtype == MLIIS_DT_BF16, ybf = y_dtype == MLIIS_DT_BF16;
+  MLIIS_REQUIRE((x_dtype == MLIIS_DT_F32 || xbf) && (y_dtype == MLIIS_DT_F32 || ybf), MLIIS_ERR_ARG, "conv2d_fwd: bad storage type");
+  if (xbf || ybf) {
+    MLIIS_REQUIRE(precision == MLIIS_PREC_BF16 && ksize == 1 && border_bias == nullptr && !(ybf && accumulate), MLIIS_ERR_UNSUPPORTED,
+                  "conv2d_fwd: bf16 tensors need MLIIS_PREC_BF16, a 1x1 conv and (bf16 output) no accumulate");
+    ws = nullptr;   // (no split-K / stream-K)
+    ws_floats = 0;
+  }
   MLIIS_REQUIRE(x && wt && y, MLIIS_ERR_ARG, "conv2d_fwd: null pointer");
   MLIIS_REQUIRE((ldx & 3) == 0 && ldx >= Cin && (ldy & 3) == 0 && ldy >= Cout, MLIIS_ERR_ARG, "conv2d_fwd: bad leading dimensions");
   MLIIS_REQUIRE(aligned16(x) && aligned16(wt) && aligned16(bias) && aligned16(y), MLIIS_ERR_ALIGN,
@@ -526,14 +537,16 @@ int mliis_conv2d_fwd(const float* x, int ldx, const float* x_scale, const float*
                 "conv2d_fwd: fp8 operands need a positive activation scale and the weight tensor's amax (mliis_transpose_weights)");
   ConvGemmParams p{x, ldx, Nimg, H, W, Cin, ksize * ksize, dil, +1, wt + ci_begin, (long long)Cin_total * Cout, Cin_total, Cout, y, ldy,
                    bias, accumulate, nullptr, g.chunks_per_split, nullptr, 0, x_scale, border_bias, fp8_act_scale, fp8_w_amax};
+  p.a_bf16 = xbf;
+  p.out_bf16 = ybf;
   MLIIS_REQUIRE(aligned16(x_scale) && (x_scale == nullptr || ksize == 1), MLIIS_ERR_ARG,
                 "conv2d_fwd: x_scale must be 16-byte aligned and is only supported for 1x1 convs");
   if (stats_nblk) *stats_nblk = 0;
   {  // short-K 1x1 convs (the MBConv expand convs): barrier-free streaming kernel
     StreamPlan sp;
     // (the instance follows the call's operand precision: one rounding rule for every matrix-core conv of a reduced-precision step)
-    if (ksize == 1 && x_scale == nullptr && border_bias == nullptr && !accumulate && M * ldx * 4 < (1LL << 31) &&
-        M * ldy * 4 < (1LL << 31) && stream_plan(M, Cin, Cout, num_cus(), &sp)) {
+    if (ksize == 1 && x_scale == nullptr && border_bias == nullptr && !accumulate && !xbf && M * ldx * 4 < (1LL << 31) &&
+        M * ldy * 4 < (1LL << 31) && stream_plan(M, Cin, Cout, num_cus(), &sp)) {   // (the streaming kernel reads an fp32 A)
       MLIIS_REQUIRE(stats_part == nullptr || stats_nblk, MLIIS_ERR_ARG, "conv2d_fwd: fused statistics need a stats_nblk output");
       p.stats_part = stats_part;
       p.stats_swish = stats_swish;
@@ -545,8 +558,8 @@ int mliis_conv2d_fwd(const float* x, int ldx, const float* x_scale, const float*
       p.stats_part = nullptr;
     }
     // long-K 1x1 convs on small maps (the MBConv project convs, SE gate on load): K split inside the workgroup, one launch
-    if (ksize == 1 && border_bias == nullptr && M * ldx * 4 < (1LL << 31) && M * ldy * 4 < (1LL << 31) &&
-        (stats_part == nullptr || !accumulate) && ksplit_plan(M, Cin, Cout, num_cus(), &sp)) {
+    if (ksize == 1 && border_bias == nullptr && !ybf && M * ldx * 4 < (1LL << 31) && M * ldy * 4 < (1LL << 31) &&
+        (stats_part == nullptr || !accumulate) && ksplit_plan(M, Cin, Cout, num_cus(), &sp)) {   // (its finishing threads write fp32)
       MLIIS_REQUIRE(stats_part == nullptr || stats_nblk, MLIIS_ERR_ARG, "conv2d_fwd: fused statistics need a stats_nblk output");
       p.stats_part = stats_part;
       p.stats_swish = stats_swish;
@@ -605,13 +618,13 @@ struct BnbArgs {   // mliis_conv2d_bwd_data_bn: the batch norm whose output grad
 };
 static int conv2d_bwd_data_impl(const float* dy, int lddy, const float* w, float* dx, int lddx, int Nimg, int H, int W, int Cin_total,
                                 int ci_begin, int Cin_out, int Cout, int ksize, int dil, int accumulate, float* ws, size_t ws_floats,
-                                int precision, hipStream_t stream, const BnbArgs* bnb);
+                                int precision, hipStream_t stream, const BnbArgs* bnb, int dy_dtype, int dx_dtype);
 
 int mliis_conv2d_bwd_data(const float* dy, int lddy, const float* w, float* dx, int lddx, int Nimg, int H, int W, int Cin_total,
                           int ci_begin, int Cin_out, int Cout, int ksize, int dil, int accumulate, float* ws, size_t ws_floats,
-                          int precision, hipStream_t stream) {
+                          int precision, int dy_dtype, int dx_dtype, hipStream_t stream) {
   return conv2d_bwd_data_impl(dy, lddy, w, dx, lddx, Nimg, H, W, Cin_total, ci_begin, Cin_out, Cout, ksize, dil, accumulate, ws, ws_floats,
-                              precision, stream, nullptr);
+                              precision, stream, nullptr, dy_dtype, dx_dtype);
 }
 
 // Same, when dx is the gradient w.r.t. the output of a plain batch norm over bn_x [M, Cin_out] (the project BN of the MBConv block in
@@ -622,14 +635,15 @@ int mliis_conv2d_bwd_data(const float* dy, int lddy, const float* w, float* dx, 
 int mliis_conv2d_bwd_data_bn(const float* dy, int lddy, const float* w, float* dx, int lddx, int Nimg, int H, int W, int Cin_total,
                              int ci_begin, int Cin_out, int Cout, int ksize, int dil, int accumulate, float* ws, size_t ws_floats,
                              int precision, const float* bn_x, int bn_ldx, const float* bn_mean, const float* bn_rstd,
-                             const float* bn_img_scale, float* part, size_t part_floats, int* nblk, hipStream_t stream) {
+                             const float* bn_img_scale, float* part, size_t part_floats, int* nblk, int dy_dtype, int dx_dtype,
+                             hipStream_t stream) {
   MLIIS_REQUIRE(bn_x && bn_mean && bn_rstd && part && nblk, MLIIS_ERR_ARG, "conv2d_bwd_data_bn: null pointer");
   MLIIS_REQUIRE((bn_ldx & 3) == 0 && bn_ldx >= Cin_out && aligned16(bn_x) && aligned16(bn_mean) && aligned16(bn_rstd) && aligned16(part),
                 MLIIS_ERR_ARG, "conv2d_bwd_data_bn: batch-norm operands misaligned or too narrow");
   *nblk = 0;
   const BnbArgs b{bn_x, bn_ldx, bn_mean, bn_rstd, bn_img_scale, part, part_floats, nblk};
   return conv2d_bwd_data_impl(dy, lddy, w, dx, lddx, Nimg, H, W, Cin_total, ci_begin, Cin_out, Cout, ksize, dil, accumulate, ws, ws_floats,
-                              precision, stream, &b);
+                              precision, stream, &b, dy_dtype, dx_dtype);
 }
 
 // Same as mliis_conv2d_bwd_data, when dx is the gradient w.r.t. the product gate_x * gate[image] (the squeeze-excite gating in front of
@@ -639,22 +653,31 @@ int mliis_conv2d_bwd_data_bn(const float* dy, int lddy, const float* w, float* d
 // *groups == 0: not produced (another plan, or part too small): run mliis_colsum then.
 int mliis_conv2d_bwd_data_gate(const float* dy, int lddy, const float* w, float* dx, int lddx, int Nimg, int H, int W, int Cin_total,
                                int ci_begin, int Cin_out, int Cout, int ksize, int dil, float* ws, size_t ws_floats, int precision,
-                               const float* gate_x, int gate_ldx, float* part, size_t part_floats, int* groups, hipStream_t stream) {
+                               const float* gate_x, int gate_ldx, float* part, size_t part_floats, int* groups, int dy_dtype, int dx_dtype,
+                               hipStream_t stream) {   // (gate_x has dx's storage type: a1 beside the gradient of a1 * gate)
   MLIIS_REQUIRE(gate_x && part && groups, MLIIS_ERR_ARG, "conv2d_bwd_data_gate: null pointer");
   MLIIS_REQUIRE((gate_ldx & 3) == 0 && gate_ldx >= Cin_out && aligned16(gate_x) && aligned16(part), MLIIS_ERR_ARG,
                 "conv2d_bwd_data_gate: operands misaligned or too narrow");
   *groups = 0;
   const BnbArgs b{gate_x, gate_ldx, nullptr, nullptr, nullptr, part, part_floats, groups};
   return conv2d_bwd_data_impl(dy, lddy, w, dx, lddx, Nimg, H, W, Cin_total, ci_begin, Cin_out, Cout, ksize, dil, 0, ws, ws_floats, precision,
-                              stream, &b);
+                              stream, &b, dy_dtype, dx_dtype);
 }
 
 static int conv2d_bwd_data_impl(const float* dy, int lddy, const float* w, float* dx, int lddx, int Nimg, int H, int W, int Cin_total,
                                 int ci_begin, int Cin_out, int Cout, int ksize, int dil, int accumulate, float* ws, size_t ws_floats,
-                                int precision, hipStream_t stream, const BnbArgs* bnb) {
+                                int precision, hipStream_t stream, const BnbArgs* bnb, int dy_dtype, int dx_dtype) {
   int rc = conv_check("conv2d_bwd_data", Nimg, H, W, Cin_out, Cout, ksize, dil);
   if (rc) return rc;
   if ((rc = prec_check("conv2d_bwd_data", precision))) return rc;
+  const bool dybf = dy_dtype == MLIIS_DT_BF16, dxbf = dx_dtype == MLIIS_DT_BF16;   // (as in mliis_conv2d_fwd)
+  MLIIS_REQUIRE((dy_dtype == MLIIS_DT_F32 || dybf) && (dx_dtype == MLIIS_DT_F32 || dxbf), MLIIS_ERR_ARG, "conv2d_bwd_data: bad storage type");
+  if (dybf || dxbf) {
+    MLIIS_REQUIRE(precision != MLIIS_PREC_FP32 && ksize == 1 && !(dxbf && accumulate), MLIIS_ERR_UNSUPPORTED,
+                  "conv2d_bwd_data: bf16 tensors need bf16 operands, a 1x1 conv and (bf16 output) no accumulate");
+    ws = nullptr;
+    ws_floats = 0;
+  }
   MLIIS_REQUIRE(dy && w && dx, MLIIS_ERR_ARG, "conv2d_bwd_data: null pointer");
   MLIIS_REQUIRE(ci_begin >= 0 && ci_begin + Cin_out <= Cin_total, MLIIS_ERR_ARG, "conv2d_bwd_data: channel window out of range");
   MLIIS_REQUIRE((lddy & 3) == 0 && lddy >= Cout && (lddx & 3) == 0 && lddx >= Cin_out && (ci_begin & 3) == 0, MLIIS_ERR_ARG,
@@ -667,9 +690,12 @@ static int conv2d_bwd_data_impl(const float* dy, int lddy, const float* w, float
   if (precision == MLIIS_PREC_FP8) precision = MLIIS_PREC_BF16;   // fp8 mode: forward 1x1 convs in e4m3, the backward passes in bf16
   ConvGemmParams p{dy, lddy, Nimg, H, W, Cout, ksize * ksize, dil, -1, w + (long long)ci_begin * Cout, (long long)Cin_total * Cout,
                    Cout, Cin_out, dx, lddx, nullptr, accumulate, nullptr, g.chunks_per_split, nullptr, 0, nullptr, nullptr, 1.0f, nullptr};
+  p.a_bf16 = dybf;
+  p.out_bf16 = dxbf;
+  p.side_bf16 = dxbf;
   {  // short-K 1x1 convs (backward-data of the MBConv project convs): barrier-free streaming kernel
     StreamPlan sp;
-    if (ksize == 1 && !accumulate && M * lddx * 4 < (1LL << 31) && stream_plan(M, Cout, Cin_out, num_cus(), &sp)) {
+    if (ksize == 1 && !accumulate && !dybf && M * lddx * 4 < (1LL << 31) && stream_plan(M, Cout, Cin_out, num_cus(), &sp)) {
       const bool gate = bnb != nullptr && bnb->mean == nullptr;
       const bool with_bn = bnb != nullptr && !gate && (size_t)sp.gx * 2 * Cin_out <= bnb->part_floats;
       const bool with_gate = gate && (long long)H * W >= 16 && (size_t)sp.row_groups * 2 * Cin_out <= bnb->part_floats;
@@ -697,7 +723,7 @@ static int conv2d_bwd_data_impl(const float* dy, int lddy, const float* w, float
       p.gp_part = nullptr;
     }
     // long-K 1x1 convs on small maps (backward-data of the MBConv expand convs): K split inside the workgroup, one launch
-    if (ksize == 1 && M * lddx * 4 < (1LL << 31) && M * lddy * 4 < (1LL << 31) && ksplit_plan(M, Cout, Cin_out, num_cus(), &sp)) {
+    if (ksize == 1 && !dxbf && M * lddx * 4 < (1LL << 31) && M * lddy * 4 < (1LL << 31) && ksplit_plan(M, Cout, Cin_out, num_cus(), &sp)) {
       const bool with_bn = bnb != nullptr && bnb->mean != nullptr && (size_t)sp.gx * 2 * Cin_out <= bnb->part_floats;
       if (with_bn) {   // + stage 1 of the consumer batch norm's backward from the finishing threads
         p.stats_part = bnb->part;

@@ -56,7 +56,13 @@ struct ConvGemmParams {
   const float* gp_x = nullptr;
   int gp_ldx = 0;
   float* gp_part = nullptr;
+  // bf16 STORAGE of the expanded MBConv tensors (`--precision bf16-storage`; honoured by the PREC == 1 instances only, as uniform
+  // run-time branches -- the fp32 instances are untouched): A / Cmat / gp_x address 2-byte elements (leading dimensions in elements);
+  // loads widen exactly, the output is rounded to nearest even BEFORE the fused statistics are formed (they see what consumers read).
+  int a_bf16 = 0, out_bf16 = 0, side_bf16 = 0;
 };
+
+__device__ __forceinline__ float4 buf_ld4_bf16(__amdgpu_buffer_rsrc_t r, unsigned byte_off);
 
 // operand precision of an instance: 0 = fp32 (v_mfma_f32_16x16x4_f32), 1 = bf16 (v_mfma_f32_16x16x32_bf16), 2 = fp8 e4m3
 // (v_mfma_f32_16x16x32_fp8_fp8); operands are converted in registers from the fp32 tensors, accumulation is fp32
@@ -96,6 +102,12 @@ constexpr unsigned kBufRecords = 0x80000000u;   // host guarantees every legal b
 __device__ __forceinline__ float4 buf_ld4(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
   const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);
   return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
+__device__ __forceinline__ float4 buf_ld4_bf16(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {   // 4 bf16 (8 bytes) -> float4
+  typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+  const u32x2_ v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)byte_off, 0, 0);
+  return unpack_bf16x4(make_uint2(v.x, v.y));
 }
 
 template <int TM, int NT>
@@ -138,6 +150,8 @@ __device__ __forceinline__ void conv_gemm_tile(const ConvGemmParams& p, float* _
   for (int j = 0; j < NT; ++j) s1[j] = s2[j] = 0.f;
 
   const long long m0 = (long long)bx * BM;
+  const bool abf = PREC == 1 && p.a_bf16 != 0, obf = PREC == 1 && p.out_bf16 != 0;   // (uniform; fp32 / fp8 instances: compile-time false)
+  const int ab = abf ? 2 : 4;   // bytes per element of A
 
   const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, kBufRecords, 0x00020000);
   const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, kBufRecords, 0x00020000);
@@ -155,7 +169,7 @@ __device__ __forceinline__ void conv_gemm_tile(const ConvGemmParams& p, float* _
     a_off[i] = s_off[i] = 0;
     if (m < M) {
       a_h[i] = a_w[i] = 0;   // 1x1 convs never leave the pixel: no (h, w) needed -- and no integer divisions in the prologue
-      a_off[i] = (unsigned)(m * p.lda * 4);
+      a_off[i] = (unsigned)(m * p.lda * ab);
       if (p.ntaps > 1 || SC) {
         const int HWp = p.H * p.W;
         const int n = (int)(m / HWp);
@@ -197,11 +211,12 @@ __device__ __forceinline__ void conv_gemm_tile(const ConvGemmParams& p, float* _
     const bool kok = live & (k_tap < p.ntaps);
     // (recomputed from (k_th, k_tw, k_c) every chunk: carrying the two byte offsets and (dh, dw) incrementally instead removes every
     // integer multiply from the K loop but measured 4 % SLOWER on the 3x3 decoder convs -- three more live registers per thread)
-    const unsigned da = (unsigned)(((dh * p.W + dw) * p.lda + k_c) * 4);
+    const unsigned da = (unsigned)(((dh * p.W + dw) * p.lda + k_c) * ab);
 #pragma unroll
     for (int i = 0; i < A_PER_THREAD; ++i) {
       const bool ok = kok & ((unsigned)(a_h[i] + dh) < (unsigned)p.H) & ((unsigned)(a_w[i] + dw) < (unsigned)p.W);
-      ra_[i] = buf_ld4(rA, ok ? a_off[i] + da : kOob);
+      if (PREC == 1 && abf) ra_[i] = buf_ld4_bf16(rA, ok ? a_off[i] + da : kOob);
+      else ra_[i] = buf_ld4(rA, ok ? a_off[i] + da : kOob);
       if (SC) rs_[i] = buf_ld4(rS, ok ? s_off[i] + (unsigned)(k_c * 4) : kOob);
     }
     const unsigned db = (unsigned)(((long long)k_tap * p.b_tap_stride + k_c) * 4);
@@ -395,6 +410,7 @@ __device__ __forceinline__ void conv_gemm_tile(const ConvGemmParams& p, float* _
         const int n = n0 + j * 16 + l15;
         float v = acc[i][j][r] + bj[j];
         if (bb != nullptr && n < p.Nout) v += bb[n];
+        if (PREC == 1 && obf) v = bf16_round_f(v);
         acc[i][j][r] = v;
         stage[(g * 4 + r) * LDS_STAGE + j * 16 + l15] = v;
       }
@@ -408,9 +424,13 @@ __device__ __forceinline__ void conv_gemm_tile(const ConvGemmParams& p, float* _
       const int n = n0 + q * 4;
       if (m < M && n < p.Nout) {
         float4 v = ld4(stage + row * LDS_STAGE + q * 4);
-        float* dst = p.Cmat + m * p.ldc + n;
-        if (p.accumulate) v = f4add(v, ld4(dst));
-        st4(dst, v);
+        if (PREC == 1 && obf) {   // (no accumulate into a bf16 tensor: checked on the host)
+          stq(reinterpret_cast<bf16s*>(p.Cmat) + m * p.ldc + n, v);
+        } else {
+          float* dst = p.Cmat + m * p.ldc + n;
+          if (p.accumulate) v = f4add(v, ld4(dst));
+          st4(dst, v);
+        }
       }
     }
     __syncthreads();
@@ -686,7 +706,10 @@ __global__ __launch_bounds__(64 * kStreamWaves, 4) void conv1x1_stream_k(ConvGem
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
           const int n = n0 + j * 16 + l15;
-          side[r][j] = sx[mcl * sld + (n < p.Nout ? n : p.Nout - 1)];
+          if (PREC == 1 && p.side_bf16 && gated_part)
+            side[r][j] = __uint_as_float((unsigned)reinterpret_cast<const unsigned short*>(sx)[mcl * sld + (n < p.Nout ? n : p.Nout - 1)] << 16);
+          else
+            side[r][j] = sx[mcl * sld + (n < p.Nout ? n : p.Nout - 1)];
         }
       }
     }
@@ -744,7 +767,8 @@ __global__ __launch_bounds__(64 * kStreamWaves, 4) void conv1x1_stream_k(ConvGem
           const int n = n0 + j * 16 + l15;
           const bool cok = n < p.Nout;
           const int ncl = cok ? n : p.Nout - 1;
-          const float v = (PREC == 2 ? acc[j][r] * out_scale : acc[j][r]) + bj[j];
+          float v = (PREC == 2 ? acc[j][r] * out_scale : acc[j][r]) + bj[j];
+          if (PREC == 1 && p.out_bf16) v = bf16_round_f(v);   // (the sums below see what the consumers will read)
           stage[wave][(g * 4 + r) * SROW + j * 16 + l15] = v;
           if constexpr (MODE == 4) {
             const float pv = (rok && cok) ? v * side[r][j] : 0.f;
@@ -777,7 +801,10 @@ __global__ __launch_bounds__(64 * kStreamWaves, 4) void conv1x1_stream_k(ConvGem
         const int row = e / QN, q4 = e - row * QN;
         const int m = rg * 16 + row, n = n0 + q4 * 4;
         const float4 v4 = ld4(&stage[wave][row * SROW + q4 * 4]);
-        if (m < M && n < p.Nout) st4(p.Cmat + (long long)m * p.ldc + n, v4);
+        if (m < M && n < p.Nout) {
+          if (PREC == 1 && p.out_bf16) stq(reinterpret_cast<bf16s*>(p.Cmat) + (long long)m * p.ldc + n, v4);
+          else st4(p.Cmat + (long long)m * p.ldc + n, v4);
+        }
       }
     }
     if (gated_part) {   // the four row quads of the group (lane groups g) folded; lanes g == 0 publish [rg][slot][column]
@@ -887,7 +914,8 @@ __global__ __launch_bounds__(64 * WV) void conv1x1_ksplit_k(ConvGemmParams p, in
     for (int kg = 0; kg < KC; ++kg) {
       const int k = k0 + kg * 16 + g * 4;
       const bool ok = rok && k < p.C;
-      a[kg] = buf_ld4(rA, ok ? (unsigned)((m * p.lda + k) * 4) : kOob);
+      if (PREC == 1 && p.a_bf16) a[kg] = buf_ld4_bf16(rA, ok ? (unsigned)((m * p.lda + k) * 2) : kOob);
+      else a[kg] = buf_ld4(rA, ok ? (unsigned)((m * p.lda + k) * 4) : kOob);
       if (gated) a[kg] = f4mul(a[kg], buf_ld4(rS, ok ? (so + k) * 4u : kOob));
     }
   };
@@ -1002,6 +1030,7 @@ struct FilterGradParams {
   const float* x_scale;  // nullable [Nimg][C]: X[m][c] *= x_scale[image(m)][c] on load
   int multitap;          // != 0: ntaps * C <= 64 * TMF -- ONE channel block holds all taps (its rows are the flattened (tap, channel)
                          //       index), so dY is read once instead of once per tap (the 8-channel sliver of the RSD concat)
+  int x_bf16 = 0, dy_bf16 = 0;   // bf16 STORAGE of X / dY (an expanded MBConv tensor: a1, dz0); honoured by the bf16-operand instances only
 };
 
 // ------------------------------------------------------------------------------------------------ backward-filter kernel
@@ -1043,6 +1072,8 @@ __device__ __forceinline__ void conv_filter_grad2_body(const FilterGradParams& p
   if (mend > M) mend = M;
   const int HW = p.H * p.W;
   const int adv_h = BKM / p.W, adv_w = BKM - adv_h * p.W;   // one chunk = 32 pixels further along the flattened (n, h, w) index
+  const bool xbf = BF && p.x_bf16 != 0, dbf = BF && p.dy_bf16 != 0;   // (uniform; fp32 instances: compile-time false)
+  const int xb = xbf ? 2 : 4, db = dbf ? 2 : 4;                       // bytes per element of X / dY
 
   const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)p.X, 0, kBufRecords, 0x00020000);
   const __amdgpu_buffer_rsrc_t rD = __builtin_amdgcn_make_buffer_rsrc((void*)p.dY, 0, kBufRecords, 0x00020000);
@@ -1073,9 +1104,9 @@ __device__ __forceinline__ void conv_filter_grad2_body(const FilterGradParams& p
     const int rem = m - x_n[i] * HW;
     x_h[i] = rem / p.W;
     x_w[i] = rem - x_h[i] * p.W;
-    x_off[i] = (unsigned)((((long long)m + (long long)dh * p.W + dw) * p.ldx + l_c) * 4);
+    x_off[i] = (unsigned)((((long long)m + (long long)dh * p.W + dw) * p.ldx + l_c) * xb);
   }
-  const unsigned x_step = (unsigned)(BKM * p.ldx * 4);
+  const unsigned x_step = (unsigned)(BKM * p.ldx * xb);
   // ---- per-thread dY elements
   int d_m[D_PER_THREAD];
   unsigned d_off[D_PER_THREAD];
@@ -1086,16 +1117,17 @@ __device__ __forceinline__ void conv_filter_grad2_body(const FilterGradParams& p
     const int r = idx / (BN / 4), nq = idx - r * (BN / 4);
     d_m[i] = mbeg + r;
     d_ok[i] = (idx < D_TOTAL) && (n0 + nq * 4 < p.Nout);
-    d_off[i] = (unsigned)((((long long)mbeg + r) * p.lddy + n0 + nq * 4) * 4);
+    d_off[i] = (unsigned)((((long long)mbeg + r) * p.lddy + n0 + nq * 4) * db);
   }
-  const unsigned d_step = (unsigned)(BKM * p.lddy * 4);
+  const unsigned d_step = (unsigned)(BKM * p.lddy * db);
 
   float4 rx[PF][X_PER_THREAD], rs[PF][X_PER_THREAD], rd[PF][D_PER_THREAD];
   auto load_chunk = [&](float4* rx_, float4* rs_, float4* rd_) {   // next 32 pixel rows -> registers, then advance
 #pragma unroll
     for (int i = 0; i < X_PER_THREAD; ++i) {
       const bool ok = x_cok & (x_m[i] < mend) & ((unsigned)(x_h[i] + dh) < (unsigned)p.H) & ((unsigned)(x_w[i] + dw) < (unsigned)p.W);
-      rx_[i] = buf_ld4(rX, ok ? x_off[i] : kOob);
+      if (BF && xbf) rx_[i] = buf_ld4_bf16(rX, ok ? x_off[i] : kOob);
+      else rx_[i] = buf_ld4(rX, ok ? x_off[i] : kOob);
       if (SC) rs_[i] = buf_ld4(rS, ok ? (unsigned)((x_n[i] * p.C + l_c) * 4) : kOob);
       x_m[i] += BKM;
       x_off[i] += x_step;
@@ -1113,7 +1145,8 @@ __device__ __forceinline__ void conv_filter_grad2_body(const FilterGradParams& p
     }
 #pragma unroll
     for (int i = 0; i < D_PER_THREAD; ++i) {
-      rd_[i] = buf_ld4(rD, (d_ok[i] & (d_m[i] < mend)) ? d_off[i] : kOob);
+      if (BF && dbf) rd_[i] = buf_ld4_bf16(rD, (d_ok[i] & (d_m[i] < mend)) ? d_off[i] : kOob);
+      else rd_[i] = buf_ld4(rD, (d_ok[i] & (d_m[i] < mend)) ? d_off[i] : kOob);
       d_m[i] += BKM;
       d_off[i] += d_step;
     }
@@ -1228,7 +1261,7 @@ __global__ __launch_bounds__(256, 2) void conv_filter_grad2_k(FilterGradParams p
 // Several filter-gradient problems of ONE instantiation as one grid (the weight gradients are off the critical path of the backward
 // pass: the learner defers the 1x1 MBConv ones to the end and issues them together, so the 14x14 layers' launches -- each far too
 // small for the chip -- share it).  desc: device int64 [nprob][16] rows
-//   {x, dy, x_scale (0: none), slabs, ldx, lddy, Nimg, H, W, Cin, Cout, ksize, dil, rows_per_split | multitap << 32,
+//   {x, dy, x_scale (0: none), slabs, ldx, lddy, Nimg, H, W, Cin, Cout, ksize | x_bf16 << 8 | dy_bf16 << 9, dil, rows_per_split | multitap << 32,
 //    gx | gy << 20 | gz << 40, first block of the problem in this grid}
 // (the plan fields from mliis_conv2d_bwd_filter_plan); grid = sum of gx * gy * gz.
 constexpr int kFilterDescWords = 16;
@@ -1240,10 +1273,11 @@ __global__ __launch_bounds__(256, 2) void conv_filter_grad2_batched_k(const long
   for (int k = 1; k < nprob; ++k)
     if (b >= (int)desc[k * kFilterDescWords + 15]) j = k;
   const long long* d = desc + (long long)j * kFilterDescWords;
-  const int ks = (int)d[11];
+  const int ks = (int)(d[11] & 0xff);   // (bits 8 / 9: X / dY stored as bf16)
   const FilterGradParams p{reinterpret_cast<const float*>(d[0]), (int)d[4], (int)d[6], (int)d[7], (int)d[8], (int)d[9], ks * ks, (int)d[12],
                            reinterpret_cast<const float*>(d[1]), (int)d[5], (int)d[10], reinterpret_cast<float*>(d[3]),
-                           (int)(d[13] & 0xffffffffLL), reinterpret_cast<const float*>(d[2]), (int)(d[13] >> 32)};
+                           (int)(d[13] & 0xffffffffLL), reinterpret_cast<const float*>(d[2]), (int)(d[13] >> 32),
+                           (int)((d[11] >> 8) & 1), (int)((d[11] >> 9) & 1)};
   const int gx = (int)(d[14] & 0xfffff), gy = (int)((d[14] >> 20) & 0xfffff);
   const int local = b - (int)d[15];
   const int bx = local % gx, r = local / gx;

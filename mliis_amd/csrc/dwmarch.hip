@@ -51,12 +51,28 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t dwm_rsrc(const void* p) {
 #define DWM_STAMP(k) do { } while (0)
 #endif
 
+// T = storage type of the tensor behind the resource (float: 16-byte quads; bf16s: 8-byte quads, widened exactly); `off` in BYTES
+typedef unsigned dwm_u32x2 __attribute__((ext_vector_type(2)));
+template <typename T = float>
 __device__ __forceinline__ float4 dwm_load(__amdgpu_buffer_rsrc_t r, int off, bool ok) {
-  const dwm_u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(r, ok ? off : (int)kDwmOob, 0, 0);
-  return make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
+  if constexpr (sizeof(T) == 4) {
+    const dwm_u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(r, ok ? off : (int)kDwmOob, 0, 0);
+    return make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
+  } else {
+    const dwm_u32x2 u = __builtin_amdgcn_raw_buffer_load_b64(r, ok ? off : (int)kDwmOob, 0, 0);
+    return unpack_bf16x4(make_uint2(u.x, u.y));
+  }
 }
 
+template <typename T = float>
 __device__ __forceinline__ void dwm_store(__amdgpu_buffer_rsrc_t r, int off, bool ok, const float4 v) {
+  if constexpr (sizeof(T) == 2) {   // bf16 storage: round to nearest even, 8-byte quad
+    const uint2 pk = pack_bf16x4(v);
+    dwm_u32x2 u2;
+    u2.x = pk.x; u2.y = pk.y;
+    __builtin_amdgcn_raw_buffer_store_b64(u2, r, ok ? off : (int)kDwmOob, 0, DWM_STORE_AUX);
+    return;
+  }
   dwm_u32x4 u;
   u.x = __float_as_uint(v.x); u.y = __float_as_uint(v.y); u.z = __float_as_uint(v.z); u.w = __float_as_uint(v.w);
   // (out of range: dropped by the range check, no branch.)  DWM_STORE_AUX: cache policy of the output stores (gfx950 aux bits:
@@ -65,6 +81,7 @@ __device__ __forceinline__ void dwm_store(__amdgpu_buffer_rsrc_t r, int off, boo
   __builtin_amdgcn_raw_buffer_store_b128(u, r, ok ? off : (int)kDwmOob, 0, DWM_STORE_AUX);
 }
 __device__ __forceinline__ float4 f4sel(bool ok, const float4 v) { return ok ? v : make_float4(0.f, 0.f, 0.f, 0.f); }
+template <typename T> __device__ __forceinline__ float4 dwm_stored(const float4 v) { return stored_value(static_cast<const T*>(nullptr), v); }
 
 template <int K, int S>
 struct MarchCfg {
@@ -292,8 +309,11 @@ __device__ __forceinline__ void dwm_emit_pair(const float4 s1, const float4 s2, 
 // loads z at its own produced pixels and accumulates the filter gradient (K*K float4 accumulators) and the batch norm's backward
 // sums.  PRE: the batch norm + swish (forward: applied to the staged input; backward: recomputed at the produced pixels).
 // ---------------------------------------------------------------------------------------------------------------------------------
-template <int K, int S, bool PRE, bool BWD, bool DYBN = false>
+// TA / TB: storage types.  Forward: TA = the ring-side input (z, or a plain fp32 input), TB = the output y.  Backward: TA = dy (and, DYBN,
+// z1), TB = z at the produced pixels and dx.  float everywhere, or the bf16-storage combinations of `--precision bf16-storage`.
+template <int K, int S, bool PRE, bool BWD, bool DYBN = false, typename TA = float, typename TB = float>
 __global__ __launch_bounds__(256, BWD ? 1 : 2) void dwm_conv_k(const DwmArgs a) {
+  constexpr int EA = (int)sizeof(TA), EB = (int)sizeof(TB);
   static_assert(!DYBN || BWD, "DYBN is a backward mode");
   typedef MarchCfg<K, S> G;
   constexpr int TS = G::TS, SPR = G::SPR, RS = G::RS, IBW = G::IBW, IBWP = G::IBWP, WIN = G::WIN, NEW = G::NEW, NR = G::NR, WW = G::WW;
@@ -335,8 +355,8 @@ __global__ __launch_bounds__(256, BWD ? 1 : 2) void dwm_conv_k(const DwmArgs a) 
   // ---- staging map: pixel lane p <-> ring column p, load j of a batch <-> its row j.  Everything that depends on the row is
   //      wave-uniform (a scalar offset, a scalar predicate), everything per lane is computed once: three instructions per load
   const bool colok = cok && p < ibw && (unsigned)(ix0 + p) < (unsigned)Wi && !DWM_DBG_ON(a, 2);
-  const int tbase = (((n * Hi + iy0) * Wi + ix0 + p) * C + c) * 4;   // byte offset of ring row 0 at this lane's column ("negative": masked)
-  const int rowbytes = Wi * C * 4;
+  const int tbase = (((n * Hi + iy0) * Wi + ix0 + p) * C + c) * EA;   // byte offset of ring row 0 at this lane's column ("negative": masked)
+  const int rowbytes = Wi * C * EA;
   const int lcol = p < IBWP ? (p ^ ((p >> 2) & 1)) * 8 + q : kTrash + q;   // (lanes beyond the pitch write the spare pixel)
   auto row_in = [&](int rr) { return rr >= 0 && rr < rows_needed && (unsigned)(iy0 + rr) < (unsigned)Hi; };
   typedef DwmBatch<NEW, DYBN> Batch;
@@ -344,8 +364,8 @@ __global__ __launch_bounds__(256, BWD ? 1 : 2) void dwm_conv_k(const DwmArgs a) 
   auto issue = [&](Batch& r, int rb) {
 #pragma unroll
     for (int j = 0; j < NEW; ++j) {
-      r.a[j] = dwm_load(rX, tbase + (rb + j) * rowbytes, colok && row_in(rb + j));
-      if (DYBN) r.b[j] = dwm_load(rX2, tbase + (rb + j) * rowbytes, colok && row_in(rb + j));
+      r.a[j] = dwm_load<TA>(rX, tbase + (rb + j) * rowbytes, colok && row_in(rb + j));
+      if (DYBN) r.b[j] = dwm_load<TA>(rX2, tbase + (rb + j) * rowbytes, colok && row_in(rb + j));
     }
   };
   DwmQuad kq;
@@ -367,13 +387,13 @@ __global__ __launch_bounds__(256, BWD ? 1 : 2) void dwm_conv_k(const DwmArgs a) 
   const bool item_ok = sx < SPR && cok;
   const int colbase = sx < SPR ? sx * (TS * S) : 0;
   const int sxpar = sx & 1;
-  const int zbase = BWD ? (((n * Ho + oy0 + ro) * Wo + ox0 + sx * TS) * C + c) * 4 : 0;
+  const int zbase = BWD ? (((n * Ho + oy0 + ro) * Wo + ox0 + sx * TS) * C + c) * EB : 0;
   auto issue_z = [&](float4 (&zr)[TS], int step) {
     if (BWD) {
       const int oy = oy0 + step * RS + ro;
-      const int base = zbase + step * RS * Wo * C * 4;
+      const int base = zbase + step * RS * Wo * C * EB;
 #pragma unroll
-      for (int u = 0; u < TS; ++u) zr[u] = dwm_load(rZ, base + u * C * 4, item_ok && oy < oy1 && sx * TS + u < bwa);
+      for (int u = 0; u < TS; ++u) zr[u] = dwm_load<TB>(rZ, base + u * C * EB, item_ok && oy < oy1 && sx * TS + u < bwa);
     }
   };
 
@@ -501,11 +521,13 @@ __global__ __launch_bounds__(256, BWD ? 1 : 2) void dwm_conv_k(const DwmArgs a) 
     }
     // stores and sums without a branch (a conditional block here makes the compiler sink the FMAs of each output into it and keep the
     // whole K x WW window live): masked buffer stores, masked adds
-    const int ybase = (((n * Ho + oy) * Wo + ox0 + sx * TS) * C + c) * 4;
+    const int ybase = (((n * Ho + oy) * Wo + ox0 + sx * TS) * C + c) * EB;
+    if (K == 5 && EB == 2) __builtin_amdgcn_sched_barrier(0);   // (the bf16 conversions must not be interleaved with the last window rows: spills)
 #pragma unroll
     for (int u = 0; u < TS; ++u) {
       const bool ok = row_ok && sx * TS + u < bwa;
-      dwm_store(rY, ybase + u * C * 4, ok && !DWM_DBG_ON(a, 4), acc[u]);
+      if (!(K == 5 && !BWD)) acc[u] = dwm_stored<TB>(acc[u]);   // (bf16 storage: the sums below see what the consumers will read back)
+      dwm_store<TB>(rY, ybase + u * C * EB, ok && !DWM_DBG_ON(a, 4), acc[u]);
       if (!BWD) {
         const float4 v = f4sel(ok, acc[u]);
         s1 = f4add(s1, v);
@@ -588,8 +610,9 @@ __global__ __launch_bounds__(256, BWD ? 1 : 2) void dwm_conv_k(const DwmArgs a) 
 // holds dy rows (1/4 of the input's size); z is read and dx written by the owning thread directly.
 // Pixel lane -> (pair row rp = p >> 4 of the step, patch px = p & 15): a step = 2 pair rows = 4 input rows.
 // ---------------------------------------------------------------------------------------------------------------------------------
-template <int K, bool PRE, bool DYBN = false>
+template <int K, bool PRE, bool DYBN = false, typename TA = float, typename TB = float>   // TA: dy (and z1), TB: z and dx (see dwm_conv_k)
 __global__ __launch_bounds__(256, (K == 5 || DYBN) ? 1 : 2) void dwm_bwd_s2_k(const DwmArgs a) {
+  constexpr int EA = (int)sizeof(TA), EB = (int)sizeof(TB);
   constexpr int BP = 14;                    // patches per band (28 input columns, as the stride-1 kernels)
   constexpr int D = (K - 1) / 2;            // dy rows / columns behind a patch
   constexpr int NEWD = 2, WIND = 2 + D, NR = WIND + NEWD, IBW = 16;   // ring row = 16 dy pixels (BP + D needed): one batch = 2 rows = the 32 pixel lanes
@@ -626,14 +649,14 @@ __global__ __launch_bounds__(256, (K == 5 || DYBN) ? 1 : 2) void dwm_bwd_s2_k(co
   //      m0 - D + r, column col <-> dy column x0 - D + col
   const int sl = p >> 4, scol = p & 15;
   const bool colok = cok && scol < bpa + D && (unsigned)(x0 - D + scol) < (unsigned)Wd;
-  const int tbase = (((n * Hd + m0 - D + sl) * Wd + x0 - D + scol) * C + c) * 4;
-  const int rowbytes = Wd * C * 4;
+  const int tbase = (((n * Hd + m0 - D + sl) * Wd + x0 - D + scol) * C + c) * EA;
+  const int rowbytes = Wd * C * EA;
   typedef DwmBatch<1, DYBN> Batch;
   const __amdgpu_buffer_rsrc_t rX2 = dwm_rsrc(DYBN ? a.dyb.z : a.x);
   auto row_in = [&](int rr) { return rr >= 0 && rr < rows_needed && (unsigned)(m0 - D + rr) < (unsigned)Hd; };
   auto issue = [&](Batch& r, int rb) {
-    r.a[0] = dwm_load(rX, tbase + rb * rowbytes, colok && row_in(rb + sl));
-    if (DYBN) r.b[0] = dwm_load(rX2, tbase + rb * rowbytes, colok && row_in(rb + sl));
+    r.a[0] = dwm_load<TA>(rX, tbase + rb * rowbytes, colok && row_in(rb + sl));
+    if (DYBN) r.b[0] = dwm_load<TA>(rX2, tbase + rb * rowbytes, colok && row_in(rb + sl));
   };
   DwmDyQuad dq;
   auto commit = [&](const Batch& r, int rb, int sb) {
@@ -655,11 +678,11 @@ __global__ __launch_bounds__(256, (K == 5 || DYBN) ? 1 : 2) void dwm_bwd_s2_k(co
   };
   auto pix_off = [&](int step, int u) {
     const int hi = 2 * (m0 + 2 * step + rp) + (u >> 1) - pt, wi = wi0 + (u & 1);
-    return (((n * H + hi) * W + wi) * C + c) * 4;
+    return (((n * H + hi) * W + wi) * C + c) * EB;
   };
   auto issue_z = [&](float4 (&zr)[4], int step) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) zr[u] = dwm_load(rZ, pix_off(step, u), pix_ok(step, u));
+    for (int u = 0; u < 4; ++u) zr[u] = dwm_load<TB>(rZ, pix_off(step, u), pix_ok(step, u));
   };
 
   constexpr int HEAD = WIND - 2 * NEWD;   // = D - 2 <= 0
@@ -741,7 +764,8 @@ __global__ __launch_bounds__(256, (K == 5 || DYBN) ? 1 : 2) void dwm_bwd_s2_k(co
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      dwm_store(rY, pix_off(step, u), pix_ok(step, u), acc[u]);
+      acc[u] = dwm_stored<TB>(acc[u]);
+      dwm_store<TB>(rY, pix_off(step, u), pix_ok(step, u), acc[u]);
       if (PRE) {
         const float4 z = zr[u], sg_ = sgm[u];    // (the sigmoid is zero outside the image: so is g)
         const float4 uu = make_float4(fmaf(z.x, kq.sc.x, kq.sh.x), fmaf(z.y, kq.sc.y, kq.sh.y), fmaf(z.z, kq.sc.z, kq.sh.z), fmaf(z.w, kq.sc.w, kq.sh.w));
@@ -886,20 +910,41 @@ static inline DwmBn make_bn(const float* part, int nblk, long long count, const 
   return b;
 }
 
+// storage-type combination (ta, tb) of a launch (MLIIS_DT_*): forward (ring input, output) in {(f32, f32), (f32, bf16), (bf16, bf16)};
+// backward (dy [and z1], z and dx) in {(f32, f32), (bf16, f32), (bf16, bf16)} -- the fp32 sides are block 0 behind the stem and the
+// no-expand blocks, whose input / input gradient are fp32 block tensors
+static inline bool dwm_types_ok(bool bwd, int ta, int tb) {
+  if (ta == MLIIS_DT_F32 && tb == MLIIS_DT_F32) return true;
+  if (ta == MLIIS_DT_BF16 && tb == MLIIS_DT_BF16) return true;
+  return bwd ? (ta == MLIIS_DT_BF16 && tb == MLIIS_DT_F32) : (ta == MLIIS_DT_F32 && tb == MLIIS_DT_BF16);
+}
 template <int K, int S, bool PRE, bool BWD>
-static void launch_conv(const MarchGeom& g, const DwmArgs& a, hipStream_t stream) {
-  hipLaunchKernelGGL((dwm_conv_k<K, S, PRE, BWD>), dim3((unsigned)g.gx, g.gy), dim3(256), 0, stream, a);
+static void launch_conv(const MarchGeom& g, const DwmArgs& a, int ta, int tb, hipStream_t stream) {
+  const dim3 grid((unsigned)g.gx, g.gy);
+  if (ta == MLIIS_DT_F32 && tb == MLIIS_DT_F32) hipLaunchKernelGGL((dwm_conv_k<K, S, PRE, BWD, false, float, float>), grid, dim3(256), 0, stream, a);
+  else if (ta == MLIIS_DT_BF16 && tb == MLIIS_DT_BF16) hipLaunchKernelGGL((dwm_conv_k<K, S, PRE, BWD, false, bf16s, bf16s>), grid, dim3(256), 0, stream, a);
+  else if constexpr (BWD) hipLaunchKernelGGL((dwm_conv_k<K, S, PRE, BWD, false, bf16s, float>), grid, dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL((dwm_conv_k<K, S, PRE, BWD, false, float, bf16s>), grid, dim3(256), 0, stream, a);
 }
 template <int K, bool PRE>
-static void launch_bwd_s2(const MarchGeom& g, const DwmArgs& a, hipStream_t stream) {
-  hipLaunchKernelGGL((dwm_bwd_s2_k<K, PRE>), dim3((unsigned)g.gx, g.gy), dim3(256), 0, stream, a);
+static void launch_bwd_s2(const MarchGeom& g, const DwmArgs& a, int ta, int tb, hipStream_t stream) {
+  const dim3 grid((unsigned)g.gx, g.gy);
+  if (ta == MLIIS_DT_F32) hipLaunchKernelGGL((dwm_bwd_s2_k<K, PRE, false, float, float>), grid, dim3(256), 0, stream, a);
+  else if (tb == MLIIS_DT_BF16) hipLaunchKernelGGL((dwm_bwd_s2_k<K, PRE, false, bf16s, bf16s>), grid, dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL((dwm_bwd_s2_k<K, PRE, false, bf16s, float>), grid, dim3(256), 0, stream, a);
 }
 // (DYBN: always with the batch norm in front -- the MBConv blocks with an expand conv, or block 0 behind the stem)
-template <int K>
-static void launch_bwd_dybn(const MarchGeom& g, const DwmArgs& a, int stride, hipStream_t stream) {
+template <int K, typename TA, typename TB>
+static void launch_bwd_dybn_t(const MarchGeom& g, const DwmArgs& a, int stride, hipStream_t stream) {
   const dim3 grid((unsigned)g.gx, g.gy);
-  if (stride == 1) hipLaunchKernelGGL((dwm_conv_k<K, 1, true, true, true>), grid, dim3(256), 0, stream, a);
-  else hipLaunchKernelGGL((dwm_bwd_s2_k<K, true, true>), grid, dim3(256), 0, stream, a);
+  if (stride == 1) hipLaunchKernelGGL((dwm_conv_k<K, 1, true, true, true, TA, TB>), grid, dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL((dwm_bwd_s2_k<K, true, true, TA, TB>), grid, dim3(256), 0, stream, a);
+}
+template <int K>
+static void launch_bwd_dybn(const MarchGeom& g, const DwmArgs& a, int stride, int ta, int tb, hipStream_t stream) {
+  if (ta == MLIIS_DT_F32) launch_bwd_dybn_t<K, float, float>(g, a, stride, stream);
+  else if (tb == MLIIS_DT_BF16) launch_bwd_dybn_t<K, bf16s, bf16s>(g, a, stride, stream);
+  else launch_bwd_dybn_t<K, bf16s, float>(g, a, stride, stream);
 }
 
 }  // namespace mliis
@@ -937,9 +982,10 @@ int mliis_dwconv_bn_bwd_blocks(int N, int H, int W, int C, int k, int stride) {
 int mliis_dwconv_bn_fwd(const float* z, const float* bn_part, int bn_nblk, const float* bn_gamma, const float* bn_beta, float* bn_mean,
                         float* bn_rstd, float* bn_moving_mean, float* bn_moving_var, float eps, float momentum, const float* w, float* y,
                         int N, int H, int W, int C, int k, int stride, float* stats_part, size_t stats_floats, int* stats_nblk,
-                        hipStream_t stream) {
+                        int in_dtype, int out_dtype, hipStream_t stream) {
   int rc = dwm_check("dwconv_bn_fwd", N, H, W, C, k, stride);
   if (rc) return rc;
+  MLIIS_REQUIRE(dwm_types_ok(false, in_dtype, out_dtype), MLIIS_ERR_ARG, "dwconv_bn_fwd: unsupported storage types (in %d, out %d)", in_dtype, out_dtype);
   MLIIS_REQUIRE(z && w && y && aligned16(z) && aligned16(w) && aligned16(y), MLIIS_ERR_ARG, "dwconv_bn_fwd: null or unaligned pointer");
   const bool pre = bn_gamma != nullptr;
   if (pre) {
@@ -969,8 +1015,8 @@ int mliis_dwconv_bn_fwd(const float* z, const float* bn_part, int bn_nblk, const
   if (pre) a.bn = make_bn(bn_part, bn_nblk, (long long)N * H * W, bn_gamma, bn_beta, bn_mean, bn_rstd, bn_moving_mean, bn_moving_var, eps, momentum, 0);
 #define DWM_FWD(K_, S_)                                             \
   do {                                                              \
-    if (pre) launch_conv<K_, S_, true, false>(g, a, stream);        \
-    else launch_conv<K_, S_, false, false>(g, a, stream);           \
+    if (pre) launch_conv<K_, S_, true, false>(g, a, in_dtype, out_dtype, stream);  \
+    else launch_conv<K_, S_, false, false>(g, a, in_dtype, out_dtype, stream);     \
   } while (0)
   if (k == 3 && stride == 1) DWM_FWD(3, 1);
   else if (k == 3) DWM_FWD(3, 2);
@@ -985,9 +1031,11 @@ int mliis_dwconv_bn_fwd(const float* z, const float* bn_part, int bn_nblk, const
 // gradient (folded into dw when dw != NULL); bn_part [blocks][2][C] = stage 1 of the batch norm's backward for mliis_bn_bwd.
 int mliis_dwconv_bn_bwd(const float* dy, const float* z, const float* bn_mean, const float* bn_rstd, const float* bn_gamma,
                         const float* bn_beta, const float* w, float* dx, float* dw, int N, int H, int W, int C, int k, int stride,
-                        float* dw_part, size_t dw_part_floats, float* bn_part, size_t bn_part_floats, int* nblk, hipStream_t stream) {
+                        float* dw_part, size_t dw_part_floats, float* bn_part, size_t bn_part_floats, int* nblk, int dy_dtype, int zx_dtype,
+                        hipStream_t stream) {
   int rc = dwm_check("dwconv_bn_bwd", N, H, W, C, k, stride);
   if (rc) return rc;
+  MLIIS_REQUIRE(dwm_types_ok(true, dy_dtype, zx_dtype), MLIIS_ERR_ARG, "dwconv_bn_bwd: unsupported storage types (dy %d, z / dx %d)", dy_dtype, zx_dtype);
   MLIIS_REQUIRE(dy && z && w && dx && dw_part && nblk && aligned16(dy) && aligned16(z) && aligned16(w) && aligned16(dx) && aligned16(dw_part),
                 MLIIS_ERR_ARG, "dwconv_bn_bwd: null or unaligned pointer");
   const bool pre = bn_gamma != nullptr;
@@ -1011,12 +1059,12 @@ int mliis_dwconv_bn_bwd(const float* dy, const float* z, const float* bn_mean, c
   if (stride == 1) {
     // dx = dy correlated with the reversed filter, padding K - 1 - pad; ring side and produced side have the same size
     a.Hi = H; a.Wi = W; a.Ho = H; a.Wo = W; a.pt = k - 1 - g.pt; a.pl = k - 1 - g.pl;
-    if (k == 3) { if (pre) launch_conv<3, 1, true, true>(g, a, stream); else launch_conv<3, 1, false, true>(g, a, stream); }
-    else { if (pre) launch_conv<5, 1, true, true>(g, a, stream); else launch_conv<5, 1, false, true>(g, a, stream); }
+    if (k == 3) { if (pre) launch_conv<3, 1, true, true>(g, a, dy_dtype, zx_dtype, stream); else launch_conv<3, 1, false, true>(g, a, dy_dtype, zx_dtype, stream); }
+    else { if (pre) launch_conv<5, 1, true, true>(g, a, dy_dtype, zx_dtype, stream); else launch_conv<5, 1, false, true>(g, a, dy_dtype, zx_dtype, stream); }
   } else {
     a.Hi = g.Ho; a.Wi = g.Wo; a.Ho = H; a.Wo = W; a.pt = g.pt; a.pl = g.pl;
-    if (k == 3) { if (pre) launch_bwd_s2<3, true>(g, a, stream); else launch_bwd_s2<3, false>(g, a, stream); }
-    else { if (pre) launch_bwd_s2<5, true>(g, a, stream); else launch_bwd_s2<5, false>(g, a, stream); }
+    if (k == 3) { if (pre) launch_bwd_s2<3, true>(g, a, dy_dtype, zx_dtype, stream); else launch_bwd_s2<3, false>(g, a, dy_dtype, zx_dtype, stream); }
+    else { if (pre) launch_bwd_s2<5, true>(g, a, dy_dtype, zx_dtype, stream); else launch_bwd_s2<5, false>(g, a, dy_dtype, zx_dtype, stream); }
   }
   MLIIS_CHECK_LAUNCH("dwconv_bn_bwd");
   if (dw != nullptr) {
@@ -1035,9 +1083,10 @@ int mliis_mbconv_dw_bwd_march(const float* da2, const float* z1, const float* me
                               const float* gate, const float* chan_add, const float* stage1, int stage1_nimg, float* dgamma1, float* dbeta1,
                               const float* z0, const float* mean0, const float* rstd0, const float* gamma0, const float* beta0, const float* w,
                               float* dx, int N, int H, int W, int C, int k, int stride, float* dw_part, size_t dw_part_floats, float* bn_part,
-                              size_t bn_part_floats, int* nblk, hipStream_t stream) {
+                              size_t bn_part_floats, int* nblk, int dy_dtype, int zx_dtype, hipStream_t stream) {
   int rc = dwm_check("mbconv_dw_bwd_march", N, H, W, C, k, stride);
   if (rc) return rc;
+  MLIIS_REQUIRE(dwm_types_ok(true, dy_dtype, zx_dtype), MLIIS_ERR_ARG, "mbconv_dw_bwd_march: unsupported storage types (da2 / z1 %d, z0 / dx %d)", dy_dtype, zx_dtype);
   MLIIS_REQUIRE(da2 && z1 && mean1 && rstd1 && gamma1 && beta1 && gate && chan_add && stage1 && stage1_nimg > 0 && dgamma1 && dbeta1 && z0 && mean0 &&
                     rstd0 && gamma0 && beta0 && w && dx && dw_part && bn_part && nblk,
                 MLIIS_ERR_ARG, "mbconv_dw_bwd_march: null pointer");
@@ -1063,8 +1112,8 @@ int mliis_mbconv_dw_bwd_march(const float* da2, const float* z1, const float* me
   } else {
     a.Hi = g.Ho; a.Wi = g.Wo; a.Ho = H; a.Wo = W; a.pt = g.pt; a.pl = g.pl;
   }
-  if (k == 3) launch_bwd_dybn<3>(g, a, stride, stream);
-  else launch_bwd_dybn<5>(g, a, stride, stream);
+  if (k == 3) launch_bwd_dybn<3>(g, a, stride, dy_dtype, zx_dtype, stream);
+  else launch_bwd_dybn<5>(g, a, stride, dy_dtype, zx_dtype, stream);
   MLIIS_CHECK_LAUNCH("mbconv_dw_bwd_march");
   return MLIIS_OK;
 }

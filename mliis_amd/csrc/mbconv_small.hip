@@ -188,10 +188,18 @@ constexpr unsigned kSmOob = 0xFFFFFFF0u;
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t sm_rsrc(const void* p) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x80000000u, 0x00020000);
 }
-template <int V>
+// T = storage type of the tensor (float, or bf16s: `--precision bf16-storage`); `off` in BYTES
+template <int V, typename T = float>
 __device__ __forceinline__ SmV<V> sm_ld(__amdgpu_buffer_rsrc_t r, unsigned off) {
   SmV<V> o;
-  if constexpr (V == 2) {
+  if constexpr (sizeof(T) == 2 && V == 2) {
+    const unsigned u = __builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0);
+    o.v[0] = __uint_as_float(u << 16); o.v[1] = __uint_as_float(u & 0xffff0000u);
+  } else if constexpr (sizeof(T) == 2) {
+    const sm_u32x2 u = __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, 0);
+    o.v[0] = __uint_as_float(u.x << 16); o.v[1] = __uint_as_float(u.x & 0xffff0000u);
+    o.v[2] = __uint_as_float(u.y << 16); o.v[V - 1] = __uint_as_float(u.y & 0xffff0000u);
+  } else if constexpr (V == 2) {
     const sm_u32x2 u = __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, 0);
     o.v[0] = __uint_as_float(u.x); o.v[1] = __uint_as_float(u.y);
   } else {
@@ -200,9 +208,15 @@ __device__ __forceinline__ SmV<V> sm_ld(__amdgpu_buffer_rsrc_t r, unsigned off) 
   }
   return o;
 }
-template <int V>
+template <int V, typename T = float>
 __device__ __forceinline__ void sm_st(__amdgpu_buffer_rsrc_t r, unsigned off, SmV<V> a) {
-  if constexpr (V == 2) {
+  if constexpr (sizeof(T) == 2 && V == 2) {
+    __builtin_amdgcn_raw_buffer_store_b32(pack_bf16_pair(a.v[0], a.v[1]), r, (int)off, 0, 0);
+  } else if constexpr (sizeof(T) == 2) {
+    sm_u32x2 u;
+    u.x = pack_bf16_pair(a.v[0], a.v[1]); u.y = pack_bf16_pair(a.v[2], a.v[V - 1]);
+    __builtin_amdgcn_raw_buffer_store_b64(u, r, (int)off, 0, 0);
+  } else if constexpr (V == 2) {
     sm_u32x2 u;
     u.x = __float_as_uint(a.v[0]); u.y = __float_as_uint(a.v[1]);
     __builtin_amdgcn_raw_buffer_store_b64(u, r, (int)off, 0, 0);
@@ -211,6 +225,15 @@ __device__ __forceinline__ void sm_st(__amdgpu_buffer_rsrc_t r, unsigned off, Sm
     u.x = __float_as_uint(a.v[0]); u.y = __float_as_uint(a.v[1]); u.z = __float_as_uint(a.v[2]); u.w = __float_as_uint(a.v[V - 1]);
     __builtin_amdgcn_raw_buffer_store_b128(u, r, (int)off, 0, 0);
   }
+}
+
+// the values as a consumer reads them back from a tensor of storage type T
+template <int V, typename T> __device__ __forceinline__ SmV<V> sm_stored(SmV<V> a) {
+  if constexpr (sizeof(T) == 2) {
+#pragma unroll
+    for (int i = 0; i < V; ++i) a.v[i] = bf16_round_f(a.v[i]);
+  }
+  return a;
 }
 
 // strip decode shared by both kernels
@@ -222,7 +245,7 @@ struct SmStrip {
   __device__ __forceinline__ unsigned poff(int j) const { return (act && h0 + j < H) ? off0 + (unsigned)j * rstride : kSmOob; }
   __device__ __forceinline__ bool ok(int j) const { return act && h0 + j < H; }
 };
-__device__ __forceinline__ SmStrip sm_strip(const SmallGeom& g, int c) {
+__device__ __forceinline__ SmStrip sm_strip(const SmallGeom& g, int c, int esize = 4) {
   SmStrip s;
   const int pl = threadIdx.x;
   s.act = pl < g.nitems;
@@ -237,8 +260,8 @@ __device__ __forceinline__ SmStrip sm_strip(const SmallGeom& g, int c) {
   s.h0 = hs * 4;
   s.w = w_;
   s.H = g.H;
-  s.off0 = (unsigned)((((n * g.H + s.h0) * g.W + w_) * g.C + c) * 4);
-  s.rstride = (unsigned)(g.W * g.C * 4);
+  s.off0 = (unsigned)((((n * g.H + s.h0) * g.W + w_) * g.C + c) * esize);
+  s.rstride = (unsigned)(g.W * g.C * esize);
   return s;
 }
 
@@ -266,7 +289,7 @@ struct SmallFwd {
 // taps in registers (fully unrolled window loop) where K*K*V floats fit beside the window: every form but the 5x5 quads
 template <int K, int V> struct SmTapsInRegs { static constexpr bool value = K == 3 || V <= 2; };
 
-template <int K, int V>
+template <int K, int V, typename T = float>   // T: storage type of z0, z1, a1 (and a0)
 __global__ __launch_bounds__(kSmThreads) void mbconv_dw_fwd_small_k(SmallFwd p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   typedef SmV<V> VT;
@@ -284,12 +307,12 @@ __global__ __launch_bounds__(kSmThreads) void mbconv_dw_fwd_small_k(SmallFwd p) 
   SM_STAMP(0);
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int c = cq * V;
-  const SmStrip st = sm_strip(g, c);
+  const SmStrip st = sm_strip(g, c, (int)sizeof(T));
   // own pixels' z0 first (does not depend on the statistics fold)
   const __amdgpu_buffer_rsrc_t rz0 = sm_rsrc(p.z0);
   VT zin[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) zin[j] = sm_ld<V>(rz0, st.poff(j));
+  for (int j = 0; j < 4; ++j) zin[j] = sm_ld<V, T>(rz0, st.poff(j));
   if (t < K * K) lds_st<V>(wl, t, vld<V>(p.w + (long long)t * g.C + c));
   // ---- fold the expand conv's stage-1 statistics of this group (double precision, fixed order): wave w owns column w of the 2 V
   //      {sum, sum of squares} x V channels; its lanes take the partial blocks (ONE memory round trip for up to 64 of them)
@@ -335,7 +358,7 @@ __global__ __launch_bounds__(kSmThreads) void mbconv_dw_fwd_small_k(SmallFwd p) 
       if (st.ok(j)) {
         const VT a = vswish(vaffine(vxhat(zin[j], m0, r0), ga, be));
         lds_st<V>(tileA, (st.n * g.H + st.h0 + j) * g.W + st.w, a);
-        if (p.a0 != nullptr) sm_st<V>(ra0, st.poff(j), a);
+        if (p.a0 != nullptr) sm_st<V, T>(ra0, st.poff(j), a);
       }
     }
   }
@@ -403,7 +426,10 @@ __global__ __launch_bounds__(kSmThreads) void mbconv_dw_fwd_small_k(SmallFwd p) 
   {
     const __amdgpu_buffer_rsrc_t rz1 = sm_rsrc(p.z1);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) sm_st<V>(rz1, st.poff(j), acc[j]);
+    for (int j = 0; j < 4; ++j) {
+      acc[j] = sm_stored<V, T>(acc[j]);   // (bf16 storage: the statistics see what the backward pass will read)
+      sm_st<V, T>(rz1, st.poff(j), acc[j]);
+    }
   }
   // ---- statistics of z1: exact two-pass in the workgroup (mean, then centred second moment)
   VT s1 = vzero<V>(), s2 = vzero<V>();
@@ -434,13 +460,13 @@ __global__ __launch_bounds__(kSmThreads) void mbconv_dw_fwd_small_k(SmallFwd p) 
     VT ps = vzero<V>();
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      a1v[j] = vswish(vaffine(vxhat(acc[j], m1, r1), ga, be));
+      a1v[j] = sm_stored<V, T>(vswish(vaffine(vxhat(acc[j], m1, r1), ga, be)));
       if (st.ok(j)) ps = vadd(ps, a1v[j]);
     }
     lds_st<V>(pool, t, ps);
     const __amdgpu_buffer_rsrc_t ra1 = sm_rsrc(p.a1);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) sm_st<V>(ra1, st.poff(j), a1v[j]);
+    for (int j = 0; j < 4; ++j) sm_st<V, T>(ra1, st.poff(j), a1v[j]);
   }
   sm_lds_barrier();
   SM_STAMP(8);
@@ -499,7 +525,7 @@ struct SmallBwd {
 #endif
 };
 
-template <int K, int V>
+template <int K, int V, typename T = float>   // T: storage type of da2, z1, z0 and dz0
 __global__ __launch_bounds__(kSmThreads) void mbconv_dw_bwd_small_k(SmallBwd p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   typedef SmV<V> VT;
@@ -521,7 +547,7 @@ __global__ __launch_bounds__(kSmThreads) void mbconv_dw_bwd_small_k(SmallBwd p) 
   SM_STAMP(0);
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int c = cq * V;
-  const SmStrip st = sm_strip(g, c);
+  const SmStrip st = sm_strip(g, c, (int)sizeof(T));
   const float inv_n = 1.0f / (float)g.npix;
   // all global loads of the own strip up front: one memory round trip
   VT zv[4], dv[4], z0v[4];
@@ -529,9 +555,9 @@ __global__ __launch_bounds__(kSmThreads) void mbconv_dw_bwd_small_k(SmallBwd p) 
     const __amdgpu_buffer_rsrc_t rz1 = sm_rsrc(p.z1), rd = sm_rsrc(p.da2), rz0 = sm_rsrc(p.z0);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      zv[j] = sm_ld<V>(rz1, st.poff(j));
-      dv[j] = sm_ld<V>(rd, st.poff(j));
-      z0v[j] = sm_ld<V>(rz0, st.poff(j));
+      zv[j] = sm_ld<V, T>(rz1, st.poff(j));
+      dv[j] = sm_ld<V, T>(rd, st.poff(j));
+      z0v[j] = sm_ld<V, T>(rz0, st.poff(j));
     }
   }
   if (t < K * K) lds_st<V>(wl, t, vld<V>(p.w + (long long)t * g.C + c));
@@ -706,7 +732,7 @@ __global__ __launch_bounds__(kSmThreads) void mbconv_dw_bwd_small_k(SmallBwd p) 
     const __amdgpu_buffer_rsrc_t rdz = sm_rsrc(p.dz0);
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      if (st.ok(j)) sm_st<V>(rdz, st.poff(j), vbn_dx(acc[j], z0v[j], a, b, ga0, r0));
+      if (st.ok(j)) sm_st<V, T>(rdz, st.poff(j), vbn_dx(acc[j], z0v[j], a, b, ga0, r0));
   }
   SM_STAMP(10);
   SM_STAMP_FLUSH(p.stamps);
@@ -750,21 +776,29 @@ static int sm_num_cus() {
 }
 static SmallGeom small_max_geom() { return SmallGeom{1, 1, 1, 4, 1, kSmThreads, kSmMaxPix}; }
 
-template <int K, int V>
-static int small_launch_fwd(const SmallFwd& p, int C, size_t lds, hipStream_t stream) {
+template <int K, int V, typename T>
+static int small_launch_fwd_t(const SmallFwd& p, int C, size_t lds, hipStream_t stream) {
   static int attr = 0;
   int rc;
-  if ((rc = small_attr(mbconv_dw_fwd_small_k<K, V>, small_fwd_lds(small_max_geom(), K), &attr))) return rc;
-  hipLaunchKernelGGL((mbconv_dw_fwd_small_k<K, V>), dim3(sm_grid(C, V)), dim3(kSmThreads), lds, stream, p);
+  if ((rc = small_attr(mbconv_dw_fwd_small_k<K, V, T>, small_fwd_lds(small_max_geom(), K), &attr))) return rc;
+  hipLaunchKernelGGL((mbconv_dw_fwd_small_k<K, V, T>), dim3(sm_grid(C, V)), dim3(kSmThreads), lds, stream, p);
   return MLIIS_OK;
 }
 template <int K, int V>
-static int small_launch_bwd(const SmallBwd& p, int C, size_t lds, hipStream_t stream) {
+static int small_launch_fwd(const SmallFwd& p, int C, size_t lds, int dt, hipStream_t stream) {
+  return dt == MLIIS_DT_BF16 ? small_launch_fwd_t<K, V, bf16s>(p, C, lds, stream) : small_launch_fwd_t<K, V, float>(p, C, lds, stream);
+}
+template <int K, int V, typename T>
+static int small_launch_bwd_t(const SmallBwd& p, int C, size_t lds, hipStream_t stream) {
   static int attr = 0;
   int rc;
-  if ((rc = small_attr(mbconv_dw_bwd_small_k<K, V>, small_bwd_lds(small_max_geom(), K), &attr))) return rc;
-  hipLaunchKernelGGL((mbconv_dw_bwd_small_k<K, V>), dim3(sm_grid(C, V)), dim3(kSmThreads), lds, stream, p);
+  if ((rc = small_attr(mbconv_dw_bwd_small_k<K, V, T>, small_bwd_lds(small_max_geom(), K), &attr))) return rc;
+  hipLaunchKernelGGL((mbconv_dw_bwd_small_k<K, V, T>), dim3(sm_grid(C, V)), dim3(kSmThreads), lds, stream, p);
   return MLIIS_OK;
+}
+template <int K, int V>
+static int small_launch_bwd(const SmallBwd& p, int C, size_t lds, int dt, hipStream_t stream) {
+  return dt == MLIIS_DT_BF16 ? small_launch_bwd_t<K, V, bf16s>(p, C, lds, stream) : small_launch_bwd_t<K, V, float>(p, C, lds, stream);
 }
 
 }  // namespace mliis
@@ -785,7 +819,7 @@ int mliis_mbconv_dw_small_group_width(int C, int k) { return C > 0 ? sm_group_wi
 int mliis_mbconv_dw_fwd_small(const float* z0, const float* part0, int nblk0, const float* gamma0, const float* beta0, float* mean0,
                               float* rstd0, float* moving_mean0, float* moving_var0, const float* w, const float* gamma1, const float* beta1,
                               float* mean1, float* rstd1, float* moving_mean1, float* moving_var1, float* a0, float* z1, float* a1, float* s,
-                              int N, int H, int W, int C, int k, float eps, float momentum, int group_width, hipStream_t stream) {
+                              int N, int H, int W, int C, int k, float eps, float momentum, int group_width, int act_dtype, hipStream_t stream) {
   SmallGeom g;
   MLIIS_REQUIRE(small_geom(N, H, W, C, k, 1, &g), MLIIS_ERR_UNSUPPORTED,
                 "mbconv_dw_fwd_small: shape N=%d H=%d W=%d C=%d k=%d is not eligible (mliis_mbconv_dw_small_supported)", N, H, W, C, k);
@@ -806,8 +840,9 @@ int mliis_mbconv_dw_fwd_small(const float* z0, const float* part0, int nblk0, co
 #endif
   const size_t lds = small_fwd_lds(g, k);
   int rc;
-  if (k == 3) rc = V == 2 ? small_launch_fwd<3, 2>(p, C, lds, stream) : small_launch_fwd<3, 4>(p, C, lds, stream);
-  else rc = V == 2 ? small_launch_fwd<5, 2>(p, C, lds, stream) : small_launch_fwd<5, 4>(p, C, lds, stream);
+  MLIIS_REQUIRE(act_dtype == MLIIS_DT_F32 || act_dtype == MLIIS_DT_BF16, MLIIS_ERR_ARG, "mbconv_dw_fwd_small: bad act_dtype");
+  if (k == 3) rc = V == 2 ? small_launch_fwd<3, 2>(p, C, lds, act_dtype, stream) : small_launch_fwd<3, 4>(p, C, lds, act_dtype, stream);
+  else rc = V == 2 ? small_launch_fwd<5, 2>(p, C, lds, act_dtype, stream) : small_launch_fwd<5, 4>(p, C, lds, act_dtype, stream);
   if (rc) return rc;
   MLIIS_CHECK_LAUNCH("mbconv_dw_fwd_small");
   return MLIIS_OK;
@@ -816,7 +851,8 @@ int mliis_mbconv_dw_fwd_small(const float* z0, const float* part0, int nblk0, co
 int mliis_mbconv_dw_bwd_small(const float* da2, const float* gate, const float* chan_add, const float* z1, const float* mean1,
                               const float* rstd1, const float* gamma1, const float* beta1, const float* w, const float* z0, const float* mean0,
                               const float* rstd0, const float* gamma0, const float* beta0, float* dgamma1, float* dbeta1, float* dw,
-                              float* dgamma0, float* dbeta0, float* dz0, int N, int H, int W, int C, int k, int group_width, hipStream_t stream) {
+                              float* dgamma0, float* dbeta0, float* dz0, int N, int H, int W, int C, int k, int group_width, int act_dtype,
+                              hipStream_t stream) {
   SmallGeom g;
   MLIIS_REQUIRE(small_geom(N, H, W, C, k, 1, &g), MLIIS_ERR_UNSUPPORTED,
                 "mbconv_dw_bwd_small: shape N=%d H=%d W=%d C=%d k=%d is not eligible (mliis_mbconv_dw_small_supported)", N, H, W, C, k);
@@ -837,8 +873,9 @@ int mliis_mbconv_dw_bwd_small(const float* da2, const float* gate, const float* 
 #endif
   const size_t lds = small_bwd_lds(g, k);
   int rc;
-  if (k == 3) rc = V == 2 ? small_launch_bwd<3, 2>(p, C, lds, stream) : small_launch_bwd<3, 4>(p, C, lds, stream);
-  else rc = V == 2 ? small_launch_bwd<5, 2>(p, C, lds, stream) : small_launch_bwd<5, 4>(p, C, lds, stream);
+  MLIIS_REQUIRE(act_dtype == MLIIS_DT_F32 || act_dtype == MLIIS_DT_BF16, MLIIS_ERR_ARG, "mbconv_dw_bwd_small: bad act_dtype");
+  if (k == 3) rc = V == 2 ? small_launch_bwd<3, 2>(p, C, lds, act_dtype, stream) : small_launch_bwd<3, 4>(p, C, lds, act_dtype, stream);
+  else rc = V == 2 ? small_launch_bwd<5, 2>(p, C, lds, act_dtype, stream) : small_launch_bwd<5, 4>(p, C, lds, act_dtype, stream);
   if (rc) return rc;
   MLIIS_CHECK_LAUNCH("mbconv_dw_bwd_small");
   return MLIIS_OK;

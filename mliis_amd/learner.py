@@ -37,12 +37,19 @@ from .arena import Arena
 class _Plan:
     """All activation / gradient buffers of one inner step for a fixed batch size N."""
 
-    def __init__(self, L: "Learner", N: int):
+    def __init__(self, L: "Learner", N: int, act_dtype=torch.float32):
         a, dev = L.arch, L.device
         self.N = N
+        # storage type of the EXPANDED tensors of the MBConv blocks (z0, z1, a1, da2, da0 / dz0): fp32, or bf16 for the training plan of
+        # `--precision bf16-storage` (BASELINE configs[3]).  Everything else -- block inputs / outputs, the decoder, statistics, sums,
+        # parameters -- is fp32 in every mode.
+        self.act_dtype = act_dtype
 
         def buf(*shape):
             return torch.empty(shape, dtype=torch.float32, device=dev)
+
+        def xbuf(*shape):
+            return torch.empty(shape, dtype=act_dtype, device=dev)
 
         def vec(c):
             return buf(c), buf(c)
@@ -66,11 +73,14 @@ class _Plan:
             # every other block: the row-marching kernels (batch norm + swish in front of the depthwise conv applied while its input is
             # staged; one-pass backward).  A shape neither family takes (>= 2 GiB tensors, other k / stride) runs op by op (dwconv.hip)
             B["march"] = bool(L.dw_march and not B["small"] and lib.raw("mliis_dwconv_bn_supported")(N, hi, hi, ce, b.k, b.stride))
+            if act_dtype != torch.float32 and not (B["march"] or B["small"]):
+                raise MliisError("bf16 storage: block {} ({}x{}x{}, k {}, stride {}) is taken by neither fused depthwise family".format(
+                    b.idx, hi, hi, ce, b.k, b.stride))
             if b.expand != 1:
-                B["z0"], B["st0"] = buf(N, hi, hi, ce), vec(ce)
+                B["z0"], B["st0"] = xbuf(N, hi, hi, ce), vec(ce)
                 if not B["march"]:   # (the marching kernels apply bn0 + swish on load: a0 is never written; small-map blocks run op by op in inference)
-                    B["a0"] = buf(N, hi, hi, ce)
-            B["z1"], B["a1"], B["st1"] = buf(N, ho, ho, ce), buf(N, ho, ho, ce), vec(ce)
+                    B["a0"] = xbuf(N, hi, hi, ce)
+            B["z1"], B["a1"], B["st1"] = xbuf(N, ho, ho, ce), xbuf(N, ho, ho, ce), vec(ce)
             B["s"], B["hpre"], B["gate"] = buf(N, ce), buf(N, b.se), buf(N, ce)
             B["z2"], B["st2"], B["out"] = buf(N, ho, ho, b.cout), vec(b.cout), buf(N, ho, ho, b.cout)
             B["dout"] = buf(N, ho, ho, b.cout)
@@ -80,8 +90,9 @@ class _Plan:
                 si += 1
             # gradients w.r.t. the expanded activations: one pair PER BLOCK (not a shared scratch) so the weight-gradient kernels of a
             # block can run on the side stream while the main stream already works on the next block
-            B["da2"] = buf(N, ho, ho, ce)
-            B["da0"] = buf(N, hi, hi, ce)
+            B["da2"] = xbuf(N, ho, ho, ce)
+            # (a block without an expand conv: the depthwise backward's output is the gradient of the block's fp32 input)
+            B["da0"] = xbuf(N, hi, hi, ce) if b.expand != 1 else buf(N, hi, hi, ce)
             self.blocks.append(B)
         self.dstem = buf(N, hs, hs, a.stem_out)
         ex0 = [b for b in a.blocks if b.executed]
@@ -275,8 +286,14 @@ class Learner:
         lib.load()  # fail loudly if the HIP extension is missing
         # operand precision of the matrix cores in the dense convs: "fp32" (BASELINE configs 1-3) or "bf16" (operands rounded to bf16 on
         # the fly, fp32 accumulation; everything else stays fp32).  Passed with every dense-conv call (nothing process-wide).
+        # "bf16-storage" (BASELINE configs[3]): bf16 operands AND the expanded tensors of the MBConv blocks (z0, z1, a1 and their
+        # gradients) stored as bf16 in HBM during training steps; statistics, sums, accumulators, block outputs, the decoder and the
+        # master weights stay fp32; inference (predict) runs on fp32 tensors
+        self.act_dtype = torch.float32
+        if matmul_precision == "bf16-storage":
+            matmul_precision, self.act_dtype = "bf16", torch.bfloat16
         if matmul_precision not in ops.PRECISIONS:
-            raise ValueError("matmul_precision must be one of {}, got {!r}".format(sorted(ops.PRECISIONS), matmul_precision))
+            raise ValueError("matmul_precision must be one of {} or 'bf16-storage', got {!r}".format(sorted(ops.PRECISIONS), matmul_precision))
         self.matmul_precision = matmul_precision
         self._conv_fwd = functools.partial(ops.conv2d_fwd, precision=matmul_precision)
         self._conv_bwd_data = functools.partial(ops.conv2d_bwd_data, precision=matmul_precision)
@@ -337,7 +354,7 @@ class Learner:
         self.adam_t = torch.zeros(1, dtype=torch.float32, device=self.device)          # Adam steps applied so far
         self.adam_ticket = torch.zeros(1, dtype=torch.int32, device=self.device)   # the optimizer launch advances adam_t itself
         self.adam_epoch = 0     # bumped whenever the Adam slots are REPLACED from outside (restore / import_all): lanes follow (reptile.py)
-        self.plans: Dict[int, _Plan] = {}
+        self.plans: Dict[object, _Plan] = {}   # key: batch size (training plan) or (batch size, "infer") in bf16-storage mode
         self.max_shots = max_shots
         H = image_size
         # resident shots [0, max_shots) + (on-device augmentation) the slots of one augmented mini-batch behind them: the step's kernels
@@ -615,11 +632,14 @@ class Learner:
         self._aug_valid = B
         return [base + b for b in range(B)]
 
-    def _plan(self, N: int) -> _Plan:
-        if N not in self.plans:
+    def _plan(self, N: int, infer: bool = False) -> _Plan:
+        """The buffers of a batch size.  bf16-storage mode keeps a second, fp32 plan for inference (the op-by-op inference kernels read
+        fp32 tensors); in every other mode training and inference share one."""
+        key = (N, "infer") if (infer and self.act_dtype != torch.float32) else N
+        if key not in self.plans:
             with torch.cuda.stream(self.stream):
-                self.plans[N] = _Plan(self, N)
-        return self.plans[N]
+                self.plans[key] = _Plan(self, N, torch.float32 if isinstance(key, tuple) else self.act_dtype)
+        return self.plans[key]
 
     # ------------------------------------------------------------------------------------------- forward
     def _forward(self, P: _Plan, x, idx, training: bool):
@@ -1253,7 +1273,7 @@ class Learner:
         """predictions tensor of the reference: (softmax(logits) > 0.5) as float, [N,H,W,2]."""
         images = torch.as_tensor(images)
         N = images.shape[0]
-        P = self._plan(N)
+        P = self._plan(N, infer=True)
         with torch.cuda.stream(self.stream):
             x = images.to(device=self.device, dtype=torch.float32).contiguous()
             logits = self._forward(P, x, None, training)

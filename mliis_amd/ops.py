@@ -27,6 +27,17 @@ def _ptr(t: Optional[torch.Tensor]):
         return None
     if not t.is_cuda:
         raise MliisError("mliis_amd ops need device tensors (no CPU path)")
+    if t.dtype == torch.bfloat16:
+        raise MliisError("this entry point reads fp32 tensors; a bfloat16 tensor was passed (bf16 storage is taken by the fused MBConv kernels only)")
+    return t.data_ptr()
+
+
+def _aptr(t: Optional[torch.Tensor]):
+    """Pointer of an activation tensor whose storage type (float32 | bfloat16) is passed beside it (_dt)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise MliisError("mliis_amd ops need device tensors (no CPU path)")
     return t.data_ptr()
 
 
@@ -34,6 +45,17 @@ def _chk(t: torch.Tensor, dtype=torch.float32):
     if t.dtype != dtype:
         raise MliisError("expected {} tensor, got {}".format(dtype, t.dtype))
     return t
+
+
+DT_F32, DT_BF16 = 0, 1   # MLIIS_DT_* of include/mliis_hip.h: storage type of the expanded MBConv tensors (z0, z1, a1 and their gradients)
+
+
+def _dt(*tensors) -> int:
+    """Storage-type code of tensors that must share it: float32 -> MLIIS_DT_F32, bfloat16 -> MLIIS_DT_BF16."""
+    d = tensors[0].dtype
+    if d not in (torch.float32, torch.bfloat16) or any(t.dtype != d for t in tensors):
+        raise MliisError("expected float32 or bfloat16 tensors of ONE storage type, got {}".format([t.dtype for t in tensors]))
+    return DT_BF16 if d == torch.bfloat16 else DT_F32
 
 
 # ---- optional per-call timing (bench.py / tools): PROFILE = [] enables it; every wrapped call appends
@@ -214,14 +236,15 @@ def dwconv_bn_fwd(z, w, stride, bn=None, part=None, nblk=0, out=None, stats_part
     N, H, W, C_ = z.shape
     k = w.shape[0]
     Ho, Wo = -(-H // stride), -(-W // stride)
-    out = torch.empty((N, Ho, Wo, C_), dtype=torch.float32, device=z.device) if out is None else out
+    out = torch.empty((N, Ho, Wo, C_), dtype=z.dtype, device=z.device) if out is None else out
     g, b, m, r, mm, mv = bn if bn is not None else (None,) * 6
-    meta = dict(bytes=4.0 * (z.numel() + out.numel() + k * k * C_), shape=(N, H, W, C_, k, stride)) if PROFILE is not None else {}
+    meta = dict(bytes=float(z.numel() * z.element_size() + out.numel() * out.element_size() + 4 * k * k * C_),
+                shape=(N, H, W, C_, k, stride)) if PROFILE is not None else {}
     nb = C.c_int(0)
     _timed("dwconv_bn_fwd", meta, lambda: lib.call(
-        "mliis_dwconv_bn_fwd", _ptr(_chk(z)), _ptr(part) if nblk else None, int(nblk), _ptr(g), _ptr(b), _ptr(m), _ptr(r), _ptr(mm), _ptr(mv),
-        float(eps), float(momentum), _ptr(w), _ptr(out), N, H, W, C_, k, stride, _ptr(stats_part),
-        stats_part.numel() if stats_part is not None else 0, C.byref(nb), _stream()))
+        "mliis_dwconv_bn_fwd", _aptr(z), _ptr(part) if nblk else None, int(nblk), _ptr(g), _ptr(b), _ptr(m), _ptr(r), _ptr(mm), _ptr(mv),
+        float(eps), float(momentum), _ptr(w), _aptr(out), N, H, W, C_, k, stride, _ptr(stats_part),
+        stats_part.numel() if stats_part is not None else 0, C.byref(nb), _dt(z), _dt(out), _stream()))
     if stats_part is not None:
         return out, nb.value
     return out
@@ -237,7 +260,7 @@ def dwconv_bn_bwd(dy, z, w, stride, bn=None, out=None, dw=None, dw_part=None, bn
     the given dw) and, with bn_part, stage 1 of the batch norm's backward [blocks][2][C].  Returns (dx, dw | None, blocks)."""
     N, H, W, C_ = z.shape
     k = w.shape[0]
-    out = torch.empty((N, H, W, C_), dtype=torch.float32, device=z.device) if out is None else out
+    out = torch.empty((N, H, W, C_), dtype=z.dtype, device=z.device) if out is None else out
     blocks = dwconv_bn_bwd_blocks(N, H, W, C_, k, stride)
     if dw_part is None:
         dw_part = (ws or default_ws()).get(blocks * k * k * C_)
@@ -246,8 +269,9 @@ def dwconv_bn_bwd(dy, z, w, stride, bn=None, out=None, dw=None, dw_part=None, bn
     meta = dict(bytes=4.0 * (2 * z.numel() + dy.numel() + 2 * k * k * C_), shape=(N, H, W, C_, k, stride)) if PROFILE is not None else {}
     nb = C.c_int(0)
     _timed("dwconv_bn_bwd", meta, lambda: lib.call(
-        "mliis_dwconv_bn_bwd", _ptr(_chk(dy)), _ptr(_chk(z)), _ptr(m), _ptr(r), _ptr(g), _ptr(b), _ptr(w), _ptr(out), _ptr(dw), N, H, W, C_, k,
-        stride, _ptr(dw_part), dw_part.numel(), _ptr(bn_part), bn_part.numel() if bn_part is not None else 0, C.byref(nb), _stream()))
+        "mliis_dwconv_bn_bwd", _aptr(dy), _aptr(z), _ptr(m), _ptr(r), _ptr(g), _ptr(b), _ptr(w), _aptr(out), _ptr(dw), N, H, W, C_, k,
+        stride, _ptr(dw_part), dw_part.numel(), _ptr(bn_part), bn_part.numel() if bn_part is not None else 0, C.byref(nb), _dt(dy), _dt(z, out),
+        _stream()))
     return out, dw, nb.value
 
 
@@ -259,10 +283,10 @@ def mbconv_dw_bwd_march(da2, z1, bn1, gate, chan_add, stage1, dgamma1, dbeta1, z
     nb = C.c_int(0)
     meta = dict(bytes=4.0 * (2 * z0.numel() + 2 * z1.numel() + 2 * k * k * C_), shape=(N, H, W, C_, k, stride)) if PROFILE is not None else {}
     _timed("dwconv_bn_bwd", meta, lambda: lib.call(
-        "mliis_mbconv_dw_bwd_march", _ptr(_chk(da2)), _ptr(_chk(z1)), _ptr(bn1[0]), _ptr(bn1[1]), _ptr(bn1[2]), _ptr(bn1[3]), _ptr(gate),
-        _ptr(chan_add), _ptr(stage1), int(stage1.shape[0]) if stage1.dim() == 3 else N, _ptr(dgamma1), _ptr(dbeta1), _ptr(_chk(z0)), _ptr(bn0[0]),
-        _ptr(bn0[1]), _ptr(bn0[2]), _ptr(bn0[3]), _ptr(w), _ptr(out), N, H, W, C_, k, stride, _ptr(dw_part), dw_part.numel(), _ptr(bn_part),
-        bn_part.numel(), C.byref(nb), _stream()))
+        "mliis_mbconv_dw_bwd_march", _aptr(da2), _aptr(z1), _ptr(bn1[0]), _ptr(bn1[1]), _ptr(bn1[2]), _ptr(bn1[3]), _ptr(gate),
+        _ptr(chan_add), _ptr(stage1), int(stage1.shape[0]) if stage1.dim() == 3 else N, _ptr(dgamma1), _ptr(dbeta1), _aptr(z0), _ptr(bn0[0]),
+        _ptr(bn0[1]), _ptr(bn0[2]), _ptr(bn0[3]), _ptr(w), _aptr(out), N, H, W, C_, k, stride, _ptr(dw_part), dw_part.numel(), _ptr(bn_part),
+        bn_part.numel(), C.byref(nb), _dt(da2, z1), _dt(z0, out), _stream()))
     return nb.value
 
 
@@ -284,9 +308,9 @@ def mbconv_dw_fwd_small(z0, part0, nblk0, bn0, w, bn1, z1, a1, s, a0=None, eps=B
     k = w.shape[0]
     g0, b0, m0, r0, mm0, mv0 = bn0
     g1, b1, m1, r1, mm1, mv1 = bn1
-    lib.call("mliis_mbconv_dw_fwd_small", _ptr(_chk(z0)), _ptr(part0), int(nblk0), _ptr(g0), _ptr(b0), _ptr(m0), _ptr(r0), _ptr(mm0), _ptr(mv0),
-             _ptr(w), _ptr(g1), _ptr(b1), _ptr(m1), _ptr(r1), _ptr(mm1), _ptr(mv1), _ptr(a0), _ptr(z1), _ptr(a1), _ptr(s), N, H, W, C_, k,
-             float(eps), float(momentum), int(group_width), _stream())
+    lib.call("mliis_mbconv_dw_fwd_small", _aptr(z0), _ptr(part0), int(nblk0), _ptr(g0), _ptr(b0), _ptr(m0), _ptr(r0), _ptr(mm0), _ptr(mv0),
+             _ptr(w), _ptr(g1), _ptr(b1), _ptr(m1), _ptr(r1), _ptr(mm1), _ptr(mv1), _aptr(a0), _aptr(z1), _aptr(a1), _ptr(s), N, H, W, C_, k,
+             float(eps), float(momentum), int(group_width), _dt(z0, z1, a1) if a0 is None else _dt(z0, z1, a1, a0), _stream())
     return z1, a1, s
 
 
@@ -295,9 +319,9 @@ def mbconv_dw_bwd_small(da2, gate, chan_add, z1, bn1, w, z0, bn0, dgamma1, dbeta
     backward; dz0 = gradient w.r.t. the expand conv's output."""
     N, H, W, C_ = z1.shape
     k = w.shape[0]
-    lib.call("mliis_mbconv_dw_bwd_small", _ptr(_chk(da2)), _ptr(gate), _ptr(chan_add), _ptr(z1), _ptr(bn1[0]), _ptr(bn1[1]), _ptr(bn1[2]),
-             _ptr(bn1[3]), _ptr(w), _ptr(z0), _ptr(bn0[0]), _ptr(bn0[1]), _ptr(bn0[2]), _ptr(bn0[3]), _ptr(dgamma1), _ptr(dbeta1), _ptr(dw),
-             _ptr(dgamma0), _ptr(dbeta0), _ptr(dz0), N, H, W, C_, k, int(group_width), _stream())
+    lib.call("mliis_mbconv_dw_bwd_small", _aptr(da2), _ptr(gate), _ptr(chan_add), _aptr(z1), _ptr(bn1[0]), _ptr(bn1[1]), _ptr(bn1[2]),
+             _ptr(bn1[3]), _ptr(w), _aptr(z0), _ptr(bn0[0]), _ptr(bn0[1]), _ptr(bn0[2]), _ptr(bn0[3]), _ptr(dgamma1), _ptr(dbeta1), _ptr(dw),
+             _ptr(dgamma0), _ptr(dbeta0), _aptr(dz0), N, H, W, C_, k, int(group_width), _dt(da2, z1, z0, dz0), _stream())
     return dz0
 
 
@@ -350,10 +374,10 @@ def conv2d_fwd(x, w, bias=None, dil=1, out=None, accumulate=False, ws: Optional[
         fp8_w_amax = w.abs().max().reshape(1)          # per-step weight-shadow launch)
     if stats_part is not None and stats_part.numel() < (-(-N * H * W // 16)) * 2 * Cout:
         raise MliisError("conv2d_fwd: stats_part too small")
-    _timed("conv2d_fwd", meta, lambda: lib.call("mliis_conv2d_fwd", _ptr(x), ldx, _ptr(x_scale), _ptr(wt), _ptr(bias), _ptr(border_bias), _ptr(out), ldy, N, H, W,
+    _timed("conv2d_fwd", meta, lambda: lib.call("mliis_conv2d_fwd", _aptr(x), ldx, _ptr(x_scale), _ptr(wt), _ptr(bias), _ptr(border_bias), _aptr(out), ldy, N, H, W,
                                                 Cin_total, ci_begin, Cin, Cout, k,
                                                 dil, int(accumulate), _ptr(stats_part), int(stats_swish), C.byref(nblk), _ptr(buf),
-                                                buf.numel(), prec, float(fp8_act_scale), _ptr(fp8_w_amax), _stream()))
+                                                buf.numel(), prec, float(fp8_act_scale), _ptr(fp8_w_amax), _dt(x), _dt(out), _stream()))
     if stats_part is not None:
         return out, nblk.value
     return out
@@ -382,20 +406,22 @@ def conv2d_bwd_data(dy, w, dil=1, ci_begin=0, ci_count=None, out=None, accumulat
                     shape=(N, H, W, ci_count, Cout, k, dil))
     if gate is not None:   # out is the gradient w.r.t. gate_x * gate: the launch may leave the gate-gradient partials in `part`
         groups = C.c_int(0)
-        _timed("conv2d_bwd_data", meta, lambda: lib.call("mliis_conv2d_bwd_data_gate", _ptr(dy), lddy, _ptr(w), _ptr(out), lddx, N, H, W, Cin,
-                                                         ci_begin, ci_count, Cout, k, dil, _ptr(buf), buf.numel(), prec, _ptr(gate),
-                                                         rows_ld(gate)[2], _ptr(part), part.numel(), C.byref(groups), _stream()))
+        _timed("conv2d_bwd_data", meta, lambda: lib.call("mliis_conv2d_bwd_data_gate", _aptr(dy), lddy, _ptr(w), _aptr(out), lddx, N, H, W, Cin,
+                                                         ci_begin, ci_count, Cout, k, dil, _ptr(buf), buf.numel(), prec, _aptr(gate),
+                                                         rows_ld(gate)[2], _ptr(part), part.numel(), C.byref(groups), _dt(dy), _dt(out, gate),
+                                                         _stream()))
         return out, groups.value
     if bn is not None:
         bx, bmean, brstd, bscale = bn
         nblk = C.c_int(0)
-        _timed("conv2d_bwd_data", meta, lambda: lib.call("mliis_conv2d_bwd_data_bn", _ptr(dy), lddy, _ptr(w), _ptr(out), lddx, N, H, W, Cin,
+        _timed("conv2d_bwd_data", meta, lambda: lib.call("mliis_conv2d_bwd_data_bn", _aptr(dy), lddy, _ptr(w), _aptr(out), lddx, N, H, W, Cin,
                                                          ci_begin, ci_count, Cout, k, dil, int(accumulate), _ptr(buf), buf.numel(), prec,
                                                          _ptr(bx), rows_ld(bx)[2], _ptr(bmean), _ptr(brstd), _ptr(bscale), _ptr(part),
-                                                         part.numel(), C.byref(nblk), _stream()))
+                                                         part.numel(), C.byref(nblk), _dt(dy), _dt(out), _stream()))
         return out, nblk.value
-    _timed("conv2d_bwd_data", meta, lambda: lib.call("mliis_conv2d_bwd_data", _ptr(dy), lddy, _ptr(w), _ptr(out), lddx, N, H, W, Cin, ci_begin,
-                                                     ci_count, Cout, k, dil, int(accumulate), _ptr(buf), buf.numel(), prec, _stream()))
+    _timed("conv2d_bwd_data", meta, lambda: lib.call("mliis_conv2d_bwd_data", _aptr(dy), lddy, _ptr(w), _aptr(out), lddx, N, H, W, Cin, ci_begin,
+                                                     ci_count, Cout, k, dil, int(accumulate), _ptr(buf), buf.numel(), prec, _dt(dy), _dt(out),
+                                                     _stream()))
     return out
 
 
@@ -443,8 +469,9 @@ class FilterBatch:
         tmf, nt, multitap, gx, gy, gz, rps = [int(v) for v in plan[:7]]
         if partial.numel() < gz * k * k * Cin * Cout:
             raise MliisError("FilterBatch: slab region too small")
+        # (ksize word: bits 8 / 9 = X / dY stored as bf16 -- an expanded MBConv tensor under `--precision bf16-storage`)
         row = [x.data_ptr(), dy.data_ptr(), x_scale.data_ptr() if x_scale is not None else 0, partial.data_ptr(), ldx, lddy, N, H, W, Cin,
-               Cout, k, dil, rps | (multitap << 32), gx | (gy << 20) | (gz << 40), 0]
+               Cout, k | (_dt(x) << 8) | (_dt(dy) << 9), dil, rps | (multitap << 32), gx | (gy << 20) | (gz << 40), 0]
         self.groups.setdefault((tmf, nt, x_scale is not None), []).append((row, gx * gy * gz))
         self._keep += [x, dy, partial, x_scale]
         self.tables = None
@@ -463,6 +490,8 @@ class FilterBatch:
         if self.tables is None:
             self._build()
         prec = _prec(precision)
+        if prec == 0 and any((row[11] >> 8) for items in self.groups.values() for row, _ in items):
+            raise MliisError("FilterBatch: bf16 tensors need the bf16-operand instances (precision 'bf16')")
         for table, nprob, blocks, tmf, nt, sc in self.tables:
             lib.call("mliis_conv2d_bwd_filter_batched", _ptr(table), nprob, blocks, tmf, nt, sc, prec, _stream())
 
@@ -541,15 +570,16 @@ def bn_apply_fused(x, part, nblk, mean, rstd, gamma, beta, moving=None, unbiased
     """pool_part (a float buffer): the pass also leaves per-image partial sums of its output there and the function returns
     (out, chunks_per_image) -- feed both to se_mlp_fwd."""
     rows, C_, ldx = rows_ld(x)
-    out = torch.empty(x.shape, dtype=torch.float32, device=x.device) if out is None else out
+    out = torch.empty(x.shape, dtype=x.dtype, device=x.device) if out is None else out
     _, _, ldy = rows_ld(out)
     rpi = rows_per_img or (rows // x.shape[0])
     ldr = rows_ld(res)[2] if res is not None else 0
     mm, mv = (None, None) if moving is None else moving
     chunks = C.c_int(0)
-    lib.call("mliis_bn_apply_fused", _ptr(x), ldx, _ptr(out), ldy, rows, C_, rpi, _ptr(part), int(nblk), eps, momentum,
+    lib.call("mliis_bn_apply_fused", _aptr(x), ldx, _aptr(out), ldy, rows, C_, rpi, _ptr(part), int(nblk), eps, momentum,
              int(unbiased_moving_var), _ptr(mean), _ptr(rstd), _ptr(mm), _ptr(mv), _ptr(gamma), _ptr(beta), int(pre_swish), int(post_swish),
-             _ptr(img_scale), _ptr(res), ldr, _ptr(pool_part), pool_part.numel() if pool_part is not None else 0, C.byref(chunks), _stream())
+             _ptr(img_scale), _ptr(res), ldr, _ptr(pool_part), pool_part.numel() if pool_part is not None else 0, C.byref(chunks), _dt(x, out),
+             _stream())
     if pool_part is not None:
         return out, chunks.value
     return out
@@ -573,18 +603,18 @@ def bn_bwd(x, dy, mean, rstd, gamma, beta, pre_swish=False, post_swish=False, im
     dxsum_part (optional, bn_bwd_dxsum_floats(rows, C) floats): per-row-chunk column sums of dx (slabs for fold_batched)."""
     rows, C_, ldx = rows_ld(x)
     _, _, lddy = rows_ld(dy)
-    dx = torch.empty(x.shape, dtype=torch.float32, device=x.device) if dx is None else dx
+    dx = torch.empty(x.shape, dtype=x.dtype, device=x.device) if dx is None else dx
     _, _, lddx = rows_ld(dx)
     dgamma = torch.empty(C_, dtype=torch.float32, device=x.device) if dgamma is None else dgamma
     dbeta = torch.empty(C_, dtype=torch.float32, device=x.device) if dbeta is None else dbeta
     rpi = rows_per_img or (rows // x.shape[0])
     ws = ws or default_ws()
     buf = ws.get(lib.size("mliis_colreduce_workspace_floats", rows, C_, 1, 2))
-    lib.call("mliis_bn_bwd", _ptr(x), ldx, _ptr(dy), lddy, _ptr(dx), lddx, rows, C_, rpi, _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta),
+    lib.call("mliis_bn_bwd", _aptr(x), ldx, _aptr(dy), lddy, _aptr(dx), lddx, rows, C_, rpi, _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta),
              int(pre_swish), int(post_swish), _ptr(img_scale), _ptr(chan_scale), _ptr(chan_add), _ptr(dgamma), _ptr(dbeta), _ptr(dskip),
              rows_ld(dskip)[2] if dskip is not None else 0, int(dskip_accumulate), _ptr(dxsum_part),
              dxsum_part.numel() if dxsum_part is not None else 0, _ptr(buf), buf.numel(),
-             _ptr(stage1[0]) if stage1 else None, int(stage1[1]) if stage1 else 0, _stream())
+             _ptr(stage1[0]) if stage1 else None, int(stage1[1]) if stage1 else 0, _dt(x, dy, dx), _stream())
     return dx, dgamma, dbeta
 
 
@@ -680,8 +710,8 @@ def se_bn_bwd_sums(z1, da2, mean, rstd, gamma, beta, part):
     rows, C_, ldx = rows_ld(z1)
     _, _, ldd = rows_ld(da2)
     nb = C.c_int(0)
-    lib.call("mliis_se_bn_bwd_sums", _ptr(_chk(z1)), ldx, _ptr(_chk(da2)), ldd, N, rows // N, C_, _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta),
-             _ptr(part), part.numel(), C.byref(nb), _stream())
+    lib.call("mliis_se_bn_bwd_sums", _aptr(z1), ldx, _aptr(da2), ldd, N, rows // N, C_, _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta),
+             _ptr(part), part.numel(), C.byref(nb), _dt(z1, da2), _stream())
     return nb.value
 
 
