@@ -56,8 +56,9 @@ def parse(argv=None):
     ap.add_argument("--concurrent-tasks", type=int, default=1,
                     help="variant (with --tasks-per-gpu > 1): adapt this many tasks of the meta-batch at once on separate learners / streams")
     ap.add_argument("--tasks-per-gpu", type=int, default=1, help="variant: tasks per GPU and meta-step (the metric's config has 1)")
-    ap.add_argument("--precision", choices=["fp32", "bf16", "fp8"], default="fp32",
-                    help="variant: bf16 operands on the matrix cores (fp32 accumulation, fp32 tensors); the headline metric is fp32")
+    ap.add_argument("--precision", choices=["fp32", "bf16", "fp8", "bf16-storage"], default="fp32",
+                    help="variant: bf16 / fp8 operands on the matrix cores (fp32 accumulation, fp32 tensors); bf16-storage: bf16 operands AND the "
+                         "expanded MBConv tensors as bf16 in HBM (BASELINE configs[3]); the headline metric is fp32")
     ap.add_argument("--adam", action="store_true", help="variant: Adam(beta1 = 0) inner optimizer, the reference's default when --sgd is absent (the metric's config is SGD)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -445,6 +446,7 @@ def _run(args):
             "metric": "inner-loop images/sec (EfficientLab-6-3, 224x224, 5-shot)", "value": value, "unit": "images/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else ("bf16 matrix-core operands, f32 accumulate / tensors" if args.precision == "bf16" else
+                                                              "bf16 matrix-core operands and bf16 expanded MBConv tensors in HBM (z0, z1, a1 and their gradients), f32 accumulate / statistics / block tensors / weights" if args.precision == "bf16-storage" else
                                                               "fp8 e4m3 operands on the 1x1 forward convs (bf16 elsewhere), f32 accumulate / tensors"), "data": "synthetic",
             "config": {"workload": "%s + %sRSD(4)+RSD(2)), %dx%d, meta-batch=%d (1 task/GPU), "
                                    "%d-shot x %d inner SGD steps of batch %d (%d image fwd+bwd+BN-EMA+SGD per task), %s outer update, fp32 tensors, "

@@ -316,7 +316,7 @@ int mliis_bn_bwd(const float* x, int ldx, const float* dy, int lddy, float* dx, 
  *      H,W of squeeze-excite (efficientnet_model.py:247) and of the RSD pooled branch (efficientlab.py:192-197), their
  *      gradients, and conv bias gradients.  workspace: mliis_colreduce_workspace_floats(rows_per_seg, C, nseg, 1). */
 int mliis_colsum(const float* a, int lda, const float* b, int ldb, long long rows_per_seg, int nseg, int C, float scale, float* out,
-                 int accumulate, float* ws, size_t ws_floats, hipStream_t stream);
+                 int accumulate, float* ws, size_t ws_floats, int ab_dtype, hipStream_t stream);
 
 /* ---- squeeze-excite gate (efficientnet_model.py:238-251): hpre = W1.s + b1; gate = sigmoid(W2.swish(hpre) + b2).
  *      w1 [C,R], w2 [R,C] (TF HWIO 1x1).  R <= 128. */

@@ -70,7 +70,7 @@ SIGNATURES = {
     "mliis_bn_apply_fused_pair": (_i, [_p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _ll, _i, _f, _f, _i, _i, _i, _p]),
     "mliis_bn_bwd_pair": (_i, [_p] * 20 + [_i, _i, _i, _ll, _i, _i, _i, _sz, _p, _sz, _p]),
     "mliis_bn_bwd_dxsum_floats": (_sz, [_ll, _i]),
-    "mliis_colsum": (_i, [_p, _i, _p, _i, _ll, _i, _i, _f, _p, _i, _p, _sz, _p]),
+    "mliis_colsum": (_i, [_p, _i, _p, _i, _ll, _i, _i, _f, _p, _i, _p, _sz, _i, _p]),
     "mliis_se_mlp_fwd": (_i, [_p, _i, _f, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "mliis_se_mlp_bwd": (_i, [_p, _i] + [_p] * 13 + [_i, _i, _i, _i, _p]),
     "mliis_se_bn_bwd_sums_floats": (_sz, [_i, _i, _i]),

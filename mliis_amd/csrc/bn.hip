@@ -439,12 +439,12 @@ struct BnBwdCommon {                       // T: storage type of x and dy (and o
   }
 };
 
-template <bool SE>
+template <bool SE, typename T = float>
 struct BnBwdOp {
   static constexpr int NV = 2;
-  BnBwdCommon<SE> p;
-  typedef typename BnBwdCommon<SE>::Raw Raw;
-  typedef typename BnBwdCommon<SE>::Ctx Ctx;
+  BnBwdCommon<SE, T> p;
+  typedef typename BnBwdCommon<SE, T>::Raw Raw;
+  typedef typename BnBwdCommon<SE, T>::Ctx Ctx;
   __device__ __forceinline__ Ctx ctx(int c) const { return p.ctx(c); }
   __device__ __forceinline__ void load(int, long long row, int c, Raw& r) const { p.load_raw(row, c, r); }
   __device__ __forceinline__ void eval(const Ctx& k, const Raw& r, float4* o) const {
@@ -587,18 +587,19 @@ __global__ __launch_bounds__(256, SE ? 2 : 3) void bn_bwd_apply_fused_k(BnBwdCom
 // ---------------------------------------------------------------------------------------------------------------
 // Generic sums: out[seg][v][c] = scale * sum_rows f(...)
 // ---------------------------------------------------------------------------------------------------------------
+template <typename T = float>   // T: storage type of a and b
 struct SumOp {  // column sum of a (optionally times b)
   static constexpr int NV = 1;
-  const float* a;
+  const T* a;
   int lda;
-  const float* b;  // nullable
+  const T* b;  // nullable
   int ldb;
   struct Raw { float4 a, b; };
   struct Ctx {};
   __device__ __forceinline__ Ctx ctx(int) const { return Ctx(); }
   __device__ __forceinline__ void load(int, long long row, int c, Raw& r) const {
-    r.a = ld4(a + row * lda + c);
-    r.b = b != nullptr ? ld4(b + row * ldb + c) : make_float4(1.f, 1.f, 1.f, 1.f);
+    r.a = ldq(a + row * lda + c);
+    r.b = b != nullptr ? ldq(b + row * ldb + c) : make_float4(1.f, 1.f, 1.f, 1.f);
   }
   __device__ __forceinline__ void eval(const Ctx&, const Raw& r, float4* o) const { o[0] = f4mul(r.a, r.b); }
 };
@@ -764,7 +765,8 @@ __global__ __launch_bounds__(256) void fold_batched_k(const float* __restrict__ 
 
 // Short segments (<= 1024 rows, e.g. squeeze-excite pools on 28x28 / 14x14 maps): one block per (segment, 32 channels) walks all
 // rows of the segment and finishes the sum itself -- no partials, no second launch.
-__global__ __launch_bounds__(256) void colsum_small_k(const float* __restrict__ a, int lda, const float* __restrict__ b, int ldb,
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_small_k(const T* __restrict__ a, int lda, const T* __restrict__ b, int ldb,
                                                       int rows_per_seg, int C, float scale, float* __restrict__ out, int accumulate) {
   __shared__ float4 sm[256];
   const int t = threadIdx.x, q = t & 7, rl = t >> 3;
@@ -779,15 +781,15 @@ __global__ __launch_bounds__(256) void colsum_small_k(const float* __restrict__ 
       float4 va[U], vb[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        va[u] = ld4(a + (r0 + r + u * 32) * lda + c);
-        vb[u] = b != nullptr ? ld4(b + (r0 + r + u * 32) * ldb + c) : make_float4(1.f, 1.f, 1.f, 1.f);
+        va[u] = ldq(a + (r0 + r + u * 32) * lda + c);
+        vb[u] = b != nullptr ? ldq(b + (r0 + r + u * 32) * ldb + c) : make_float4(1.f, 1.f, 1.f, 1.f);
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) acc = f4add(acc, f4mul(va[u], vb[u]));
     }
     for (; r < rows_per_seg; r += 32) {
-      float4 v = ld4(a + (r0 + r) * lda + c);
-      if (b != nullptr) v = f4mul(v, ld4(b + (r0 + r) * ldb + c));
+      float4 v = ldq(a + (r0 + r) * lda + c);
+      if (b != nullptr) v = f4mul(v, ldq(b + (r0 + r) * ldb + c));
       acc = f4add(acc, v);
     }
   }
@@ -878,17 +880,32 @@ int mliis_bn_bwd(const float* x, int ldx, const float* dy, int lddy, float* dx, 
                  size_t ws_floats, const float* stage1_part, int stage1_nblk, int act_dtype, hipStream_t stream) {
   MLIIS_REQUIRE(x && dy && dx && mean && rstd && gamma && beta && dgamma && dbeta && ws, MLIIS_ERR_ARG, "bn_bwd: null pointer");
   MLIIS_REQUIRE(act_dtype == MLIIS_DT_F32 || act_dtype == MLIIS_DT_BF16, MLIIS_ERR_ARG, "bn_bwd: act_dtype must be MLIIS_DT_F32 or MLIIS_DT_BF16");
-  if (act_dtype == MLIIS_DT_BF16) {   // x, dy, dx are bf16 tensors (an expanded MBConv tensor and its gradient): stage 1 comes from the producer
-    MLIIS_REQUIRE(stage1_part != nullptr && stage1_nblk > 0 && dskip == nullptr && dxsum_part == nullptr, MLIIS_ERR_UNSUPPORTED,
-                  "bn_bwd: bf16 tensors need the producer's stage-1 sums and take no skip / column-sum outputs");
+  if (act_dtype == MLIIS_DT_BF16) {   // x, dy, dx are bf16 tensors (an expanded MBConv tensor and its gradient)
+    MLIIS_REQUIRE(dskip == nullptr && dxsum_part == nullptr, MLIIS_ERR_UNSUPPORTED, "bn_bwd: bf16 tensors take no skip / column-sum outputs");
     MLIIS_REQUIRE(rows > 1 && rows < (1LL << 31) && C > 0 && (C & 3) == 0 && (ldx & 3) == 0 && (lddy & 3) == 0 && (lddx & 3) == 0 && ldx >= C &&
-                      lddy >= C && lddx >= C && rows_per_img > 0 && aligned16(x) && aligned16(dy) && aligned16(dx) && aligned16(stage1_part),
+                      lddy >= C && lddx >= C && rows_per_img > 0 && aligned16(x) && aligned16(dy) && aligned16(dx) && aligned16(stage1_part) &&
+                      aligned16(ws) && (stage1_part == nullptr || stage1_nblk > 0),
                   MLIIS_ERR_ARG, "bn_bwd: bad shape / alignment");
     int gx_, gy_, rpb_;
     bn_bwd_grid(rows, C, &gx_, &gy_, &rpb_);
     const bf16s *xb = reinterpret_cast<const bf16s*>(x), *gb = reinterpret_cast<const bf16s*>(dy);
     bf16s* db = reinterpret_cast<bf16s*>(dx);
-    if (img_scale != nullptr || chan_scale != nullptr || chan_add != nullptr) {
+    const bool se_ = img_scale != nullptr || chan_scale != nullptr || chan_add != nullptr;
+    if (stage1_part == nullptr) {   // no producer left stage 1 (the stride-2 layer that lands on a small map): the reduce pass, on bf16 tensors
+      ColGeom g_;
+      int rc_;
+      if (se_) {
+        BnBwdCommon<true, bf16s> p{xb, ldx, gb, lddy, rows_per_img, C, mean, rstd, gamma, beta, pre_swish, post_swish, img_scale, chan_scale, chan_add};
+        rc_ = launch_colreduce(BnBwdOp<true, bf16s>{p}, rows, C, 1, ws, ws_floats, stream, &g_, "bn_bwd", bn_bwd_target(rows, C));
+      } else {
+        BnBwdCommon<false, bf16s> p{xb, ldx, gb, lddy, rows_per_img, C, mean, rstd, gamma, beta, pre_swish, post_swish, nullptr, nullptr, nullptr};
+        rc_ = launch_colreduce(BnBwdOp<false, bf16s>{p}, rows, C, 1, ws, ws_floats, stream, &g_, "bn_bwd", bn_bwd_target(rows, C));
+      }
+      if (rc_) return rc_;
+      stage1_part = ws;
+      stage1_nblk = g_.nblk;
+    }
+    if (se_) {
       BnBwdCommon<true, bf16s> p{xb, ldx, gb, lddy, rows_per_img, C, mean, rstd, gamma, beta, pre_swish, post_swish, img_scale, chan_scale, chan_add};
       hipLaunchKernelGGL((bn_bwd_apply_fused_k<true, bf16s>), dim3(gx_, gy_), dim3(256), 0, stream, p, rows, stage1_part, stage1_nblk,
                          1.0 / (double)rows, dgamma, dbeta, db, lddx, rpb_, SkipOut{nullptr, 0, 0}, (float*)nullptr, BnBwdAlt{});
@@ -1146,21 +1163,24 @@ int mliis_fold_batched(const float* part_base, float* out_base, const long long*
 
 // out[seg, c] (+)= scale * sum_{rows of seg} a[row,c] * (b[row,c] if b)
 int mliis_colsum(const float* a, int lda, const float* b, int ldb, long long rows_per_seg, int nseg, int C, float scale,
-                 float* out, int accumulate, float* ws, size_t ws_floats, hipStream_t stream) {
+                 float* out, int accumulate, float* ws, size_t ws_floats, int ab_dtype, hipStream_t stream) {
   MLIIS_REQUIRE(a && out && ws, MLIIS_ERR_ARG, "colsum: null pointer");
+  MLIIS_REQUIRE(ab_dtype == MLIIS_DT_F32 || ab_dtype == MLIIS_DT_BF16, MLIIS_ERR_ARG, "colsum: bad ab_dtype");
+  const bool bf = ab_dtype == MLIIS_DT_BF16;   // a and b are bf16 tensors (da2 and a1 of an MBConv block)
+  const bf16s *ab_ = reinterpret_cast<const bf16s*>(a), *bb_ = reinterpret_cast<const bf16s*>(b);
   MLIIS_REQUIRE(rows_per_seg > 0 && nseg > 0 && C > 0 && (C & 3) == 0 && (lda & 3) == 0 && lda >= C &&
                     (b == nullptr || ((ldb & 3) == 0 && ldb >= C)),
                 MLIIS_ERR_ARG, "colsum: bad shape");
   MLIIS_REQUIRE(aligned16(a) && aligned16(b) && aligned16(ws), MLIIS_ERR_ALIGN, "colsum: pointers must be 16-byte aligned");
   if (rows_per_seg <= 1024 && aligned16(out)) {
-    hipLaunchKernelGGL(colsum_small_k, dim3(ceil_div(C, 32), nseg), dim3(256), 0, stream, a, lda, b, ldb, (int)rows_per_seg, C, scale, out,
-                       accumulate);
+    if (bf) hipLaunchKernelGGL(colsum_small_k<bf16s>, dim3(ceil_div(C, 32), nseg), dim3(256), 0, stream, ab_, lda, bb_, ldb, (int)rows_per_seg, C, scale, out, accumulate);
+    else hipLaunchKernelGGL(colsum_small_k<float>, dim3(ceil_div(C, 32), nseg), dim3(256), 0, stream, a, lda, b, ldb, (int)rows_per_seg, C, scale, out, accumulate);
     MLIIS_CHECK_LAUNCH("colsum_small");
     return MLIIS_OK;
   }
-  SumOp op{a, lda, b, ldb};
   ColGeom g;
-  int rc = launch_colreduce(op, rows_per_seg, C, nseg, ws, ws_floats, stream, &g, "colsum");
+  int rc = bf ? launch_colreduce(SumOp<bf16s>{ab_, lda, bb_, ldb}, rows_per_seg, C, nseg, ws, ws_floats, stream, &g, "colsum")
+              : launch_colreduce(SumOp<float>{a, lda, b, ldb}, rows_per_seg, C, nseg, ws, ws_floats, stream, &g, "colsum");
   if (rc) return rc;
   hipLaunchKernelGGL(sum_finalize_k, dim3(ceil_div(C, kFoldX), 1, nseg), dim3(kFoldX, kFoldY), 0, stream, ws, g.nblk, 1, C, nseg, scale, out,
                      accumulate);

@@ -661,8 +661,8 @@ def colsum(a, b=None, nseg=1, scale=1.0, out=None, accumulate=False, ws: Optiona
     out = torch.empty((nseg, C_), dtype=torch.float32, device=a.device) if out is None else out
     ws = ws or default_ws()
     buf = ws.get(lib.size("mliis_colreduce_workspace_floats", rows // nseg, C_, nseg, 1))
-    lib.call("mliis_colsum", _ptr(a), lda, _ptr(b), ldb, rows // nseg, nseg, C_, float(scale), _ptr(out), int(accumulate), _ptr(buf),
-             buf.numel(), _stream())
+    lib.call("mliis_colsum", _aptr(a), lda, _aptr(b), ldb, rows // nseg, nseg, C_, float(scale), _ptr(out), int(accumulate), _ptr(buf),
+             buf.numel(), _dt(a) if b is None else _dt(a, b), _stream())
     return out
 
 

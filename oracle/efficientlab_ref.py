@@ -224,6 +224,26 @@ class _RoundedConv(torch.autograd.Function):
         return gx, gw, None, None, None
 
 
+# ---- bf16 STORAGE points (`--precision bf16-storage`, BASELINE configs[3]): the product keeps the expanded tensors of an MBConv block
+#      (z0, z1, a1) and their gradients as bf16 in HBM.  A tensor that is written and read back is rounded to nearest even where it is
+#      written: in the forward pass (`fwd`), in the backward pass (its gradient, `bwd`), or both.  Which gradients exist as tensors
+#      depends on the kernel family that runs the block (`store(block)` -> "march" | "small" | None, given by the test from the
+#      product's plan): the fused families form some of them in registers only.
+class _StorePoint(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, fwd, bwd):
+        ctx.bwd = bwd
+        return round_bf16(x) if fwd else x.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        return (round_bf16(g) if ctx.bwd else g), None, None
+
+
+def store_point(x, fwd=True, bwd=True):
+    return _StorePoint.apply(x, fwd, bwd)
+
+
 def mm_conv(x, w_hwio, stride=1, dilation=1, bias=None, round_ops=None):
     """A dense conv that the product runs on the matrix cores: exact, or with emulated reduced-precision operands."""
     if round_ops is None:
@@ -257,7 +277,7 @@ def resize_bilinear_ac(x, size):
 
 # -------------------------------------------------------------------------------------------------- forward
 def forward(a, params, bn, x_nhwc, training=True, dc_scales: Optional[Dict[int, torch.Tensor]] = None,
-            dropout_mask: Optional[torch.Tensor] = None, taps: Optional[dict] = None, aspp_masks=None, round_ops=None):
+            dropout_mask: Optional[torch.Tensor] = None, taps: Optional[dict] = None, aspp_masks=None, round_ops=None, store=None):
     """x_nhwc: [N,H,W,3] in 0..255.  dc_scales[block_idx]: [N] tensor of 0 or 1/keep (training only; None -> no
     drop-connect).  dropout_mask: [N,h,w,C] of 0 or 1/(1-rate) applied before the final 1x1.  Returns
     (logits NHWC, new_moving dict).  `taps` (optional dict) receives named intermediates in NHWC."""
@@ -285,14 +305,28 @@ def forward(a, params, bn, x_nhwc, training=True, dc_scales: Optional[Dict[int, 
         bns = [f"{s}/tpu_batch_normalization", f"{s}/tpu_batch_normalization_1", f"{s}/tpu_batch_normalization_2"]
         cvs = [f"{s}/conv2d/kernel", f"{s}/conv2d_1/kernel"]
         inp = x
+        fam = store(b) if (store is not None and training) else None   # bf16 storage points of this block (None: fp32 tensors)
         if b["e"] != 1:
-            x = swish(BN(mm_conv(x, P[cvs.pop(0)], round_ops=round_ops), bns.pop(0)))
+            z0 = mm_conv(x, P[cvs.pop(0)], round_ops=round_ops)
+            if fam:   # z0 and its gradient dz0 are bf16 tensors
+                z0 = store_point(z0)
+            x = swish(BN(z0, bns.pop(0)))
+            if fam == "march":   # the marching backward writes da0 (the gradient of the activation), the bn0 backward apply reads it
+                x = store_point(x, fwd=False, bwd=True)
         ce = x.shape[1]
-        x = swish(BN(conv2d_same(x, P[f"{s}/depthwise_conv2d/depthwise_kernel"], b["s"], groups=ce), bns.pop(0)))
+        z1 = conv2d_same(x, P[f"{s}/depthwise_conv2d/depthwise_kernel"], b["s"], groups=ce)
+        if fam:   # z1 is a bf16 tensor; its gradient dz1 exists as a tensor only where the depthwise batch norm's backward apply is a
+            #       launch of its own (the 5x5 stride-1 marching layers) -- the fused forms keep it in registers
+            z1 = store_point(z1, bwd=(fam == "march" and b["k"] == 5 and b["s"] == 1))
+        x = swish(BN(z1, bns.pop(0)))
+        if fam:   # a1 is a bf16 tensor (its gradient is formed in registers from da2)
+            x = store_point(x, bwd=False)
         sq = x.mean(dim=(2, 3), keepdim=True)
         sq = swish(conv2d_same(sq, P[f"{s}/se/conv2d/kernel"], bias=P[f"{s}/se/conv2d/bias"]))
         sq = conv2d_same(sq, P[f"{s}/se/conv2d_1/kernel"], bias=P[f"{s}/se/conv2d_1/bias"])
         x = torch.sigmoid(sq) * x
+        if fam:   # da2, the gradient of the gated activation (the project conv's backward-data output), is a bf16 tensor
+            x = store_point(x, fwd=False, bwd=True)
         x = BN(mm_conv(x, P[cvs.pop(0)], round_ops=round_ops), bns.pop(0))
         if b["s"] == 1 and b["i"] == b["o"]:
             if training and b["drop"] and dc_scales is not None and b["idx"] in dc_scales:
@@ -393,14 +427,14 @@ def predictions(logits):
 
 
 def inner_step(a, params, bn, x, y, lr, dc_scales=None, dropout_mask=None, label_smoothing=0.0, dice=False, l2=False,
-               weight_decay_rate=1.0, adam_state=None, aspp_masks=None, round_ops=None, l1=False, darc1=False):
+               weight_decay_rate=1.0, adam_state=None, aspp_masks=None, round_ops=None, l1=False, darc1=False, store=None):
     """One `session.run(minimize_op)` (reptile.py:114-121,639-643): fwd + bwd + BN moving update + SGD apply.
     Mutates params / bn in place; returns (loss, grads dict, logits)."""
     if weight_decay_rate != 1.0:  # pre_step_op, meta_learners/variables.py:48-55
         for k in params:
             params[k] = params[k] * weight_decay_rate
     leaves = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()}
-    logits, new_moving = forward(a, leaves, bn, x, True, dc_scales, dropout_mask, aspp_masks=aspp_masks, round_ops=round_ops)
+    logits, new_moving = forward(a, leaves, bn, x, True, dc_scales, dropout_mask, aspp_masks=aspp_masks, round_ops=round_ops, store=store)
     loss = loss_fn(a, leaves, logits, y, label_smoothing, dice, l2, l1, darc1)
     names = list(leaves)
     grads = torch.autograd.grad(loss, [leaves[k] for k in names], allow_unused=True)
@@ -437,6 +471,7 @@ class OracleLearner:
                  skip_decoding=False):
         self.l1, self.darc1 = l1, darc1
         self.round_ops = round_ops    # None | "bf16" | "fp8": emulated reduced-precision matrix-core operands
+        self.store = None             # callable(block) -> "march" | "small" | None: bf16 storage points of the training step (forward())
         self.a = arch(name, image_size, rsd, aspp, skip_decoding)
         self.params, self.bn = init_state(self.a, seed, dtype)
         self.dtype, self.lr, self.l2, self.dice, self.ls = dtype, lr, l2, dice, label_smoothing
@@ -519,7 +554,7 @@ class OracleLearner:
             x, y = self._x[i], self._y[i]
         loss, _, _ = inner_step(self.a, self.params, self.bn, x, y, self.lr if lr is None else lr,
                                 dc_scales if self.drop_connect else None, dropout_mask, self.ls, self.dice, self.l2,
-                                weight_decay_rate, aspp_masks=aspp_masks, round_ops=self.round_ops, l1=self.l1, darc1=self.darc1)
+                                weight_decay_rate, aspp_masks=aspp_masks, round_ops=self.round_ops, l1=self.l1, darc1=self.darc1, store=self.store)
         return loss
 
     def export_all(self):
