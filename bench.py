@@ -18,6 +18,7 @@ timed live with HIP events on the launch stream) and `cpu_baseline` (the CPU ora
 import argparse
 import json
 import os
+import re
 import sys
 import time
 
@@ -207,9 +208,9 @@ def roofline(L, args):
     reps_dom = 1
     ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
     traffic, tsrc = None, None
-    tpath = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
-    if not os.path.exists(tpath):
-        tpath = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    # newest committed rocprofv3 --pmc summary (profiles/rNN_pmc_traffic.json, tools/final_profile.sh)
+    cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if re.match(r"r\d+_pmc_traffic\.json$", f))
+    tpath = os.path.join(ROOT, "profiles", cands[-1]) if cands else ""
     if os.path.exists(tpath):   # PMC counters cannot be sampled from inside this process: taken from the committed rocprofv3 --pmc passes
         tj = json.load(open(tpath))
         k = tj.get("kernels", {}).get(dom.replace(", ", ","))

@@ -79,9 +79,9 @@ def main():
             return [one(tuple(x)) for x in argsets]
         nbp = C.byref(nb)
         new_f = mk(dll.mliis_dwconv_bn_fwd, [(p(z[i]), None, 0, p(gamma), p(beta), p(mean), p(rstd), None, None, 1e-3, 0.99, p(w), p(y[i]), N, hi, hi, Cc, k, s,
-                                             p(part), part.numel(), nbp, sp) for i in range(copies)])
+                                             p(part), part.numel(), nbp, 0, 0, sp) for i in range(copies)])
         new_b = mk(dll.mliis_dwconv_bn_bwd, [(p(y[i]), p(z[i]), p(mean), p(rstd), p(gamma), p(beta), p(w), p(dx[i]), None, N, hi, hi, Cc, k, s, p(slabs),
-                                             slabs.numel(), p(part), part.numel(), nbp, sp) for i in range(copies)])
+                                             slabs.numel(), p(part), part.numel(), nbp, 0, 0, sp) for i in range(copies)])
         old_f = mk(dll.mliis_dwconv_fwd, [(p(z[i]), p(w), p(y[i]), N, hi, hi, Cc, k, s, p(part), part.numel(), nbp, sp) for i in range(copies)])
         old_bd = mk(dll.mliis_dwconv_bwd_data_bn, [(p(y[i]), p(w), p(dx[i]), N, hi, hi, Cc, k, s, p(z[i]), p(mean), p(rstd), p(gamma), p(beta), p(part),
                                                    part.numel(), nbp, sp) for i in range(copies)])

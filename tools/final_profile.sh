@@ -1,10 +1,10 @@
 #!/bin/bash
 # Round-end evidence on the GPU box (run through gpurun): kernel trace + statistics of the headline bench, PMC traffic passes (the
 # dominant kernels of a step; the depthwise layers, cold), the bench line, the depthwise tables at N = 8 / 64, the variants.
-# Everything lands under gpurun_out/$1 (default r03_final); tools/collect_profiles.sh copies the summaries into profiles/.
+# Everything lands under gpurun_out/$1 (default r04_final); tools/collect_profiles.sh copies the summaries into profiles/.
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-TAG=${1:-r03_final}
+TAG=${1:-r04_final}
 O=$R/gpurun_out/$TAG
 rm -rf $O; mkdir -p $O
 cd $R
@@ -22,7 +22,8 @@ python tools/bench_kernels.py --n 64 --iters 10 --dw-only 2>/dev/null | grep -v 
 python bench.py > $O/bench_final.json 2> $O/bench_final.err
 {
 for V in "--foml" "--adam" "--aspp" "--skip-decoding" "--augment" "--precision bf16" "--precision fp8" "--inner-batch 16" "--inner-batch 64" \
-         "--backbone efficientnet-b3 --shots 10 --inner-iters 20" "--backbone efficientnet-b3 --shots 10 --inner-iters 20 --precision bf16" \
+         "--precision bf16-storage" "--backbone efficientnet-b3 --shots 10 --inner-iters 20" "--backbone efficientnet-b3 --shots 10 --inner-iters 20 --precision bf16" \
+         "--backbone efficientnet-b3 --shots 10 --inner-iters 20 --precision bf16-storage" \
          "--image-size 384" "--image-size 384 --precision fp8" "--tasks-per-gpu 8 --concurrent-tasks 4" "--tasks-per-gpu 8 --concurrent-tasks 4 --precision bf16"; do
   python bench.py $V --steps 6 --warmup 2 --no-cpu-baseline --no-roofline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('%-75s %8.1f images/s  %7.2f ms/step  loss %.4f' % ('$V', d['value'], d['ms_per_step'], d['config']['final_loss']))"
 done

@@ -112,8 +112,8 @@ def main():
         V = 2 if (b.k == 5 and b.cexp % 2 == 0 and b.cexp // 2 <= 256) else 4
         R = 11 if V == 3 else 32 // V
         sg = ((-(-(b.cexp // V) // R) + 7) // 8) * 8 * R * 512
-        kfs = [v for (k, g, gy), v in per_f.items() if k == "mbconv_dw_fwd_small_k<%d, %d>" % (b.k, V) and g == sg]
-        kbs = [v for (k, g, gy), v in per_f.items() if k == "mbconv_dw_bwd_small_k<%d, %d>" % (b.k, V) and g == sg]
+        kfs = [v for (k, g, gy), v in per_f.items() if k.startswith("mbconv_dw_fwd_small_k<%d, %d" % (b.k, V)) and g == sg]
+        kbs = [v for (k, g, gy), v in per_f.items() if k.startswith("mbconv_dw_bwd_small_k<%d, %d" % (b.k, V)) and g == sg]
         if kfs and kbs and b.stride == 1 and N * b.h_in ** 2 <= 2048 and b.expand != 1:
             mf, mb = med(kfs[0]), med(kbs[0])
             tf += mf; bf += by; tb += mb; bb += by + by
@@ -124,8 +124,11 @@ def main():
         cy_ = -(-b.cexp // 32)
         gfm = _lib.raw("mliis_dwconv_bn_fwd_blocks")(N, b.h_in, b.h_in, b.cexp, b.k, b.stride)
         gbm = _lib.raw("mliis_dwconv_bn_bwd_blocks")(N, b.h_in, b.h_in, b.cexp, b.k, b.stride)
-        mfw = [v for (k, g, gy), v in per_m.items() if k.startswith("dwm_conv_k<%d, %d, " % (b.k, b.stride)) and k.endswith("false>") and g == gfm * 256 and gy == cy_]
-        mbw = [v for (k, g, gy), v in per_m.items() if ((k.startswith("dwm_conv_k<%d, 1, " % b.k) and k.endswith("true>")) if b.stride == 1 else
+        # template arguments: dwm_conv_k<K, S, PRE, BWD, DYBN, TA, TB>, dwm_bwd_s2_k<K, PRE, DYBN, TA, TB>
+        def targs(k):
+            return [x.strip() for x in k[k.index("<") + 1:k.rindex(">")].split(",")]
+        mfw = [v for (k, g, gy), v in per_m.items() if k.startswith("dwm_conv_k<%d, %d, " % (b.k, b.stride)) and targs(k)[3] == "false" and g == gfm * 256 and gy == cy_]
+        mbw = [v for (k, g, gy), v in per_m.items() if ((k.startswith("dwm_conv_k<%d, 1, " % b.k) and targs(k)[3] == "true") if b.stride == 1 else
                                                         k.startswith("dwm_bwd_s2_k<%d, " % b.k)) and g == gbm * 256 and gy == cy_]
         if mfw and mbw:
             mf, mb = med(mfw[0]), med(mbw[0])
