@@ -253,8 +253,9 @@ def roofline(L, args):
           "mliis_dwconv_bwd_data": ("dwconv_bwd_data", 3, {0: "o", 2: "i"}, ()),
           "mliis_dwconv_bwd_data_bn": ("dwconv_bwd_data", 3, {0: "o", 2: "i", 9: "i"}, ()),
           "mliis_dwconv_bwd_filter": ("dwconv_bwd_filter", 3, {0: "i", 1: "o"}, ()),
-          "mliis_mbconv_dw_fwd_small": ("mbconv_small_fwd", 20, {0: "i", 17: "o", 18: "o"}, (7, 8, 14, 15)),     # (group_width rides along unchanged)
-          "mliis_mbconv_dw_bwd_small": ("mbconv_small_bwd", 20, {0: "o", 3: "o", 9: "i", 19: "i"}, ())}
+          # (+ the group-blocked copy of z0 the forward leaves for the backward: written / read, so it rotates with the other tensors)
+          "mliis_mbconv_dw_fwd_small": ("mbconv_small_fwd", 20, {0: "i", 17: "o", 18: "o", 29: "i"}, (7, 8, 14, 15)),
+          "mliis_mbconv_dw_bwd_small": ("mbconv_small_bwd", 20, {0: "o", 3: "o", 9: "i", 19: "i", 27: "i"}, ())}
     FLUSH = 320e6
     dw, layers = {}, []
     with torch.cuda.stream(L.stream):
@@ -276,6 +277,8 @@ def roofline(L, args):
             for r in range(copies):
                 args_r = list(a)
                 for ix, which in rot.items():
+                    if args_r[ix] is None:      # (a nullable tensor argument that this launch does not use)
+                        continue
                     buf = torch.empty(int(el[which]), dtype=torch.float32, device=L.device).normal_()
                     bufs.append(buf)
                     args_r[ix] = buf.data_ptr()

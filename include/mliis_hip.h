@@ -150,12 +150,16 @@ int mliis_mbconv_dw_fwd_small(const float* z0, const float* part0, int nblk0, co
                               float* rstd0, float* moving_mean0, float* moving_var0, const float* w, const float* gamma1, const float* beta1,
                               float* mean1, float* rstd1, float* moving_mean1, float* moving_var1, float* a0, float* z1, float* a1, float* s,
                               int N, int H, int W, int C, int k, float eps, float momentum, int group_width, int act_dtype,
-                              hipStream_t stream);
+                              float* z0_blocked, int z1_blocked, hipStream_t stream);
 int mliis_mbconv_dw_bwd_small(const float* da2, const float* gate, const float* chan_add, const float* z1, const float* mean1,
                               const float* rstd1, const float* gamma1, const float* beta1, const float* w, const float* z0, const float* mean0,
                               const float* rstd0, const float* gamma0, const float* beta0, float* dgamma1, float* dbeta1, float* dw,
                               float* dgamma0, float* dbeta0, float* dz0, int N, int H, int W, int C, int k, int group_width, int act_dtype,
-                              hipStream_t stream);
+                              const float* z0_blocked, int z1_blocked, hipStream_t stream);
+/*      z0_blocked (nullable) / z1_blocked: the two saved tensors of the layer in the GROUP-BLOCKED layout [C / group_width][N H W][group_width]
+ *      -- the forward launch writes a blocked copy of z0 and / or writes z1 blocked, the backward launch of the same layer (same
+ *      group_width) reads them: a workgroup's channel group is then contiguous (196 cache lines per tensor instead of 16 bytes of each of
+ *      1568 lines), which is what the backward pass's cold re-read of the two forward tensors costs (profiles/r04_notes.md). */
 
 /* ---- dense conv (k 1|3, stride 1, TF-SAME, dilation >= 1, optional bias) on the fp32 matrix cores:
  *      tf.layers.Conv2D 1x1 expand/project (efficientnet_model.py:175-182,225-232) and tf.layers.conv2d of the RSD decoder /

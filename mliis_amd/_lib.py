@@ -41,8 +41,8 @@ SIGNATURES = {
     "mliis_rng_masks": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _p]),
     "mliis_mbconv_dw_small_supported": (_i, [_i, _i, _i, _i, _i, _i]),
     "mliis_mbconv_dw_small_group_width": (_i, [_i, _i]),
-    "mliis_mbconv_dw_fwd_small": (_i, [_p, _p, _i] + [_p] * 17 + [_i, _i, _i, _i, _i, _f, _f, _i, _i, _p]),
-    "mliis_mbconv_dw_bwd_small": (_i, [_p] * 20 + [_i, _i, _i, _i, _i, _i, _i, _p]),
+    "mliis_mbconv_dw_fwd_small": (_i, [_p, _p, _i] + [_p] * 17 + [_i, _i, _i, _i, _i, _f, _f, _i, _i, _p, _i, _p]),
+    "mliis_mbconv_dw_bwd_small": (_i, [_p] * 20 + [_i, _i, _i, _i, _i, _i, _i, _p, _i, _p]),
     "mliis_conv2d_workspace_floats": (_sz, [_i, _i, _i, _i, _i, _i]),
     "mliis_conv2d_plan": (_i, [_i, _i, _i, _i, _i, _i, _p, _p, _p]),
     "mliis_conv1x1_occupancy": (_i, [_i, _i, _i, _p]),

@@ -243,9 +243,13 @@ struct SmStrip {
   unsigned off0, rstride;   // byte offset of the strip's first pixel / of one image row, in any [N,H,W,C] tensor
   int H;
   __device__ __forceinline__ unsigned poff(int j) const { return (act && h0 + j < H) ? off0 + (unsigned)j * rstride : kSmOob; }
+  // the same pixel in the GROUP-BLOCKED layout [C / V][N H W][V] (a workgroup's channel group is contiguous: its 1568 pixels are 196
+  // lines instead of 16 bytes of 1568 lines): byte offset = boff0 + j * brow
+  unsigned boff0, brow;
+  __device__ __forceinline__ unsigned bpoff(int j) const { return (act && h0 + j < H) ? boff0 + (unsigned)j * brow : kSmOob; }
   __device__ __forceinline__ bool ok(int j) const { return act && h0 + j < H; }
 };
-__device__ __forceinline__ SmStrip sm_strip(const SmallGeom& g, int c, int esize = 4) {
+__device__ __forceinline__ SmStrip sm_strip(const SmallGeom& g, int c, int esize = 4, int V = 4) {
   SmStrip s;
   const int pl = threadIdx.x;
   s.act = pl < g.nitems;
@@ -262,6 +266,8 @@ __device__ __forceinline__ SmStrip sm_strip(const SmallGeom& g, int c, int esize
   s.H = g.H;
   s.off0 = (unsigned)((((n * g.H + s.h0) * g.W + w_) * g.C + c) * esize);
   s.rstride = (unsigned)(g.W * g.C * esize);
+  s.boff0 = (unsigned)((((c / V) * g.npix + (n * g.H + s.h0) * g.W + w_) * V) * esize);
+  s.brow = (unsigned)(g.W * V * esize);
   return s;
 }
 
@@ -279,6 +285,8 @@ struct SmallFwd {
   float* z1;            // [N,H,W,C] out: depthwise output
   float* a1;            // [N,H,W,C] out: swish(bn1(z1))
   float* s;             // [N,C] out: per-image mean of a1 (squeeze-excite input)
+  float* z0b;           // nullable out: a copy of z0 in the group-blocked layout (for the backward kernel's contiguous re-read)
+  int z1_blocked;       // != 0: z1 is written in the group-blocked layout (only the backward kernel of the same layer reads it)
   SmallGeom g;
   float eps, one_minus_momentum;
 #ifdef SM_DBG
@@ -307,12 +315,17 @@ __global__ __launch_bounds__(kSmThreads) void mbconv_dw_fwd_small_k(SmallFwd p) 
   SM_STAMP(0);
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int c = cq * V;
-  const SmStrip st = sm_strip(g, c, (int)sizeof(T));
+  const SmStrip st = sm_strip(g, c, (int)sizeof(T), V);
   // own pixels' z0 first (does not depend on the statistics fold)
   const __amdgpu_buffer_rsrc_t rz0 = sm_rsrc(p.z0);
   VT zin[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) zin[j] = sm_ld<V, T>(rz0, st.poff(j));
+  if (p.z0b != nullptr) {   // (contiguous stores: lanes run along W)
+    const __amdgpu_buffer_rsrc_t rzb = sm_rsrc(p.z0b);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sm_st<V, T>(rzb, st.bpoff(j), zin[j]);
+  }
   if (t < K * K) lds_st<V>(wl, t, vld<V>(p.w + (long long)t * g.C + c));
   // ---- fold the expand conv's stage-1 statistics of this group (double precision, fixed order): wave w owns column w of the 2 V
   //      {sum, sum of squares} x V channels; its lanes take the partial blocks (ONE memory round trip for up to 64 of them)
@@ -428,7 +441,7 @@ __global__ __launch_bounds__(kSmThreads) void mbconv_dw_fwd_small_k(SmallFwd p) 
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       acc[j] = sm_stored<V, T>(acc[j]);   // (bf16 storage: the statistics see what the backward pass will read)
-      sm_st<V, T>(rz1, st.poff(j), acc[j]);
+      sm_st<V, T>(rz1, p.z1_blocked ? st.bpoff(j) : st.poff(j), acc[j]);
     }
   }
   // ---- statistics of z1: exact two-pass in the workgroup (mean, then centred second moment)
@@ -519,6 +532,8 @@ struct SmallBwd {
   const float *mean0, *rstd0, *gamma0, *beta0;
   float *dgamma1, *dbeta1, *dw, *dgamma0, *dbeta0;
   float* dz0;              // [N,H,W,C] out: gradient w.r.t. the expand conv's output
+  const float* z0b;        // nullable: z0 in the group-blocked layout (mbconv_dw_fwd_small's z0b), read instead of z0
+  int z1_blocked;          // != 0: z1 is in the group-blocked layout
   SmallGeom g;
 #ifdef SM_DBG
   unsigned long long* stamps;
@@ -547,17 +562,18 @@ __global__ __launch_bounds__(kSmThreads) void mbconv_dw_bwd_small_k(SmallBwd p) 
   SM_STAMP(0);
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int c = cq * V;
-  const SmStrip st = sm_strip(g, c, (int)sizeof(T));
+  const SmStrip st = sm_strip(g, c, (int)sizeof(T), V);
   const float inv_n = 1.0f / (float)g.npix;
   // all global loads of the own strip up front: one memory round trip
   VT zv[4], dv[4], z0v[4];
   {
-    const __amdgpu_buffer_rsrc_t rz1 = sm_rsrc(p.z1), rd = sm_rsrc(p.da2), rz0 = sm_rsrc(p.z0);
+    const bool zb = p.z0b != nullptr;
+    const __amdgpu_buffer_rsrc_t rz1 = sm_rsrc(p.z1), rd = sm_rsrc(p.da2), rz0 = sm_rsrc(zb ? p.z0b : p.z0);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      zv[j] = sm_ld<V, T>(rz1, st.poff(j));
+      zv[j] = sm_ld<V, T>(rz1, p.z1_blocked ? st.bpoff(j) : st.poff(j));
       dv[j] = sm_ld<V, T>(rd, st.poff(j));
-      z0v[j] = sm_ld<V, T>(rz0, st.poff(j));
+      z0v[j] = sm_ld<V, T>(rz0, zb ? st.bpoff(j) : st.poff(j));
     }
   }
   if (t < K * K) lds_st<V>(wl, t, vld<V>(p.w + (long long)t * g.C + c));
@@ -819,7 +835,8 @@ int mliis_mbconv_dw_small_group_width(int C, int k) { return C > 0 ? sm_group_wi
 int mliis_mbconv_dw_fwd_small(const float* z0, const float* part0, int nblk0, const float* gamma0, const float* beta0, float* mean0,
                               float* rstd0, float* moving_mean0, float* moving_var0, const float* w, const float* gamma1, const float* beta1,
                               float* mean1, float* rstd1, float* moving_mean1, float* moving_var1, float* a0, float* z1, float* a1, float* s,
-                              int N, int H, int W, int C, int k, float eps, float momentum, int group_width, int act_dtype, hipStream_t stream) {
+                              int N, int H, int W, int C, int k, float eps, float momentum, int group_width, int act_dtype, float* z0_blocked,
+                              int z1_blocked, hipStream_t stream) {
   SmallGeom g;
   MLIIS_REQUIRE(small_geom(N, H, W, C, k, 1, &g), MLIIS_ERR_UNSUPPORTED,
                 "mbconv_dw_fwd_small: shape N=%d H=%d W=%d C=%d k=%d is not eligible (mliis_mbconv_dw_small_supported)", N, H, W, C, k);
@@ -833,8 +850,9 @@ int mliis_mbconv_dw_fwd_small(const float* z0, const float* part0, int nblk0, co
                 MLIIS_ERR_ALIGN, "mbconv_dw_fwd_small: pointers must be 16-byte aligned");
   const int V = group_width ? group_width : sm_group_width(C, k, sm_num_cus());
   MLIIS_REQUIRE((V == 2 || V == 4) && C % V == 0, MLIIS_ERR_ARG, "mbconv_dw_fwd_small: group_width %d must be 0, 2 or 4 and divide C = %d", V, C);
+  MLIIS_REQUIRE(aligned16(z0_blocked), MLIIS_ERR_ALIGN, "mbconv_dw_fwd_small: z0_blocked must be 16-byte aligned");
   SmallFwd p{z0, part0, nblk0, gamma0, beta0, mean0, rstd0, moving_mean0, moving_var0, w, gamma1, beta1, mean1, rstd1, moving_mean1,
-             moving_var1, a0, z1, a1, s, g, eps, 1.0f - momentum};
+             moving_var1, a0, z1, a1, s, z0_blocked, z1_blocked, g, eps, 1.0f - momentum};
 #ifdef SM_DBG
   p.stamps = getenv("MLIIS_SM_STAMPS") ? reinterpret_cast<unsigned long long*>(strtoull(getenv("MLIIS_SM_STAMPS"), nullptr, 10)) : nullptr;
 #endif
@@ -852,7 +870,7 @@ int mliis_mbconv_dw_bwd_small(const float* da2, const float* gate, const float* 
                               const float* rstd1, const float* gamma1, const float* beta1, const float* w, const float* z0, const float* mean0,
                               const float* rstd0, const float* gamma0, const float* beta0, float* dgamma1, float* dbeta1, float* dw,
                               float* dgamma0, float* dbeta0, float* dz0, int N, int H, int W, int C, int k, int group_width, int act_dtype,
-                              hipStream_t stream) {
+                              const float* z0_blocked, int z1_blocked, hipStream_t stream) {
   SmallGeom g;
   MLIIS_REQUIRE(small_geom(N, H, W, C, k, 1, &g), MLIIS_ERR_UNSUPPORTED,
                 "mbconv_dw_bwd_small: shape N=%d H=%d W=%d C=%d k=%d is not eligible (mliis_mbconv_dw_small_supported)", N, H, W, C, k);
@@ -866,8 +884,9 @@ int mliis_mbconv_dw_bwd_small(const float* da2, const float* gate, const float* 
                 MLIIS_ERR_ALIGN, "mbconv_dw_bwd_small: pointers must be 16-byte aligned");
   const int V = group_width ? group_width : sm_group_width(C, k, sm_num_cus());
   MLIIS_REQUIRE((V == 2 || V == 4) && C % V == 0, MLIIS_ERR_ARG, "mbconv_dw_bwd_small: group_width %d must be 0, 2 or 4 and divide C = %d", V, C);
+  MLIIS_REQUIRE(aligned16(z0_blocked), MLIIS_ERR_ALIGN, "mbconv_dw_bwd_small: z0_blocked must be 16-byte aligned");
   SmallBwd p{da2, gate, chan_add, z1, mean1, rstd1, gamma1, beta1, w, z0, mean0, rstd0, gamma0, beta0, dgamma1, dbeta1, dw, dgamma0, dbeta0,
-             dz0, g};
+             dz0, z0_blocked, z1_blocked, g};
 #ifdef SM_DBG
   p.stamps = getenv("MLIIS_SM_STAMPS") ? reinterpret_cast<unsigned long long*>(strtoull(getenv("MLIIS_SM_STAMPS"), nullptr, 10)) : nullptr;
 #endif

@@ -81,6 +81,8 @@ class _Plan:
                 if not B["march"]:   # (the marching kernels apply bn0 + swish on load: a0 is never written; small-map blocks run op by op in inference)
                     B["a0"] = xbuf(N, hi, hi, ce)
             B["z1"], B["a1"], B["st1"] = xbuf(N, ho, ho, ce), xbuf(N, ho, ho, ce), vec(ce)
+            if B["small"]:   # the fused small-map kernels save z0 (a copy) and z1 in their group-blocked layout for the backward launch
+                B["z0b"] = xbuf(N, hi, hi, ce)
             B["s"], B["hpre"], B["gate"] = buf(N, ce), buf(N, b.se), buf(N, ce)
             B["z2"], B["st2"], B["out"] = buf(N, ho, ho, b.cout), vec(b.cout), buf(N, ho, ho, b.cout)
             B["dout"] = buf(N, ho, ho, b.cout)
@@ -709,7 +711,7 @@ class Learner:
                                         (w[p0 + "/gamma"], w[p0 + "/beta"], B["st0"][0], B["st0"][1], mv[p0 + "/moving_mean"], mv[p0 + "/moving_variance"]),
                                         w[nm["w_dw"]],
                                         (w[p1 + "/gamma"], w[p1 + "/beta"], B["st1"][0], B["st1"][1], mv[p1 + "/moving_mean"], mv[p1 + "/moving_variance"]),
-                                        B["z1"], B["a1"], B["s"])
+                                        B["z1"], B["a1"], B["s"], z0_blocked=B["z0b"], z1_blocked=True)   # (the backward's re-reads: contiguous)
                 se = nm["se"]
                 ops.se_mlp_fwd(B["s"], w[se[0]], w[se[1]], w[se[2]], w[se[3]], B["hpre"], B["gate"])
                 nb = conv(B["a1"], nm["w_proj"], None, 1, B["z2"], False, x_scale=B["gate"])
@@ -1076,7 +1078,8 @@ class Learner:
                 da0, st0, st1, p0, p1 = B["da0"], B["st0"], B["st1"], nm["bn0"], nm["bn1"]
                 ops.mbconv_dw_bwd_small(da2, B["gate"], B["chan_add"], B["z1"], (st1[0], st1[1], w[p1 + "/gamma"], w[p1 + "/beta"]),
                                         w[nm["w_dw"]], B["z0"], (st0[0], st0[1], w[p0 + "/gamma"], w[p0 + "/beta"]),
-                                        g[p1 + "/gamma"], g[p1 + "/beta"], g[nm["w_dw"]], g[p0 + "/gamma"], g[p0 + "/beta"], da0)
+                                        g[p1 + "/gamma"], g[p1 + "/beta"], g[nm["w_dw"]], g[p0 + "/gamma"], g[p0 + "/beta"], da0,
+                                        z0_blocked=B["z0b"], z1_blocked=True)
                 wgrad_1x1(B["x_in"], da0, nm["w_exp"])
                 stage1_next = expand_bwd_data(bi, da0, nm["w_exp"], tgt, tgt_has)
                 if bi > 0:

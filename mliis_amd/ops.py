@@ -300,28 +300,41 @@ def mbconv_dw_small_group_width(C_, k) -> int:
     return int(lib.raw("mliis_mbconv_dw_small_group_width")(C_, k))
 
 
-def mbconv_dw_fwd_small(z0, part0, nblk0, bn0, w, bn1, z1, a1, s, a0=None, eps=BN_EPS, momentum=BN_MOMENTUM, group_width=0):
+def _blocked_ptr(z0, z0_blocked):
+    if z0_blocked is None:
+        return None
+    if z0_blocked.dtype != z0.dtype or z0_blocked.numel() < z0.numel():
+        raise MliisError("z0_blocked must have z0's storage type and size")
+    return _aptr(z0_blocked)
+
+
+def mbconv_dw_fwd_small(z0, part0, nblk0, bn0, w, bn1, z1, a1, s, a0=None, eps=BN_EPS, momentum=BN_MOMENTUM, group_width=0, z0_blocked=None,
+                        z1_blocked=False):
     """bn0 / bn1 = (gamma, beta, mean_out, rstd_out, moving_mean | None, moving_var | None).  One launch: fold bn0's statistics,
     a0 = swish(bn0(z0)), depthwise k x k (stride 1), exact statistics of z1, a1 = swish(bn1(z1)), s = per-image mean of a1.
-    group_width: channels per workgroup (0 = the planner's choice)."""
+    group_width: channels per workgroup (0 = the planner's choice).  z0_blocked (a buffer of z0's size and type) / z1_blocked: leave a
+    copy of z0 / write z1 in the group-blocked layout that mbconv_dw_bwd_small(z0_blocked=..., z1_blocked=True) re-reads contiguously."""
     N, H, W, C_ = z0.shape
     k = w.shape[0]
     g0, b0, m0, r0, mm0, mv0 = bn0
     g1, b1, m1, r1, mm1, mv1 = bn1
     lib.call("mliis_mbconv_dw_fwd_small", _aptr(z0), _ptr(part0), int(nblk0), _ptr(g0), _ptr(b0), _ptr(m0), _ptr(r0), _ptr(mm0), _ptr(mv0),
              _ptr(w), _ptr(g1), _ptr(b1), _ptr(m1), _ptr(r1), _ptr(mm1), _ptr(mv1), _aptr(a0), _aptr(z1), _aptr(a1), _ptr(s), N, H, W, C_, k,
-             float(eps), float(momentum), int(group_width), _dt(z0, z1, a1) if a0 is None else _dt(z0, z1, a1, a0), _stream())
+             float(eps), float(momentum), int(group_width), _dt(z0, z1, a1) if a0 is None else _dt(z0, z1, a1, a0),
+             _blocked_ptr(z0, z0_blocked), int(bool(z1_blocked)), _stream())
     return z1, a1, s
 
 
-def mbconv_dw_bwd_small(da2, gate, chan_add, z1, bn1, w, z0, bn0, dgamma1, dbeta1, dw, dgamma0, dbeta0, dz0, group_width=0):
+def mbconv_dw_bwd_small(da2, gate, chan_add, z1, bn1, w, z0, bn0, dgamma1, dbeta1, dw, dgamma0, dbeta0, dz0, group_width=0, z0_blocked=None,
+                        z1_blocked=False):
     """bn1 / bn0 = (mean, rstd, gamma, beta).  One launch: bn1 backward, depthwise filter gradient (complete) and backward-data, bn0
     backward; dz0 = gradient w.r.t. the expand conv's output."""
     N, H, W, C_ = z1.shape
     k = w.shape[0]
     lib.call("mliis_mbconv_dw_bwd_small", _aptr(da2), _ptr(gate), _ptr(chan_add), _aptr(z1), _ptr(bn1[0]), _ptr(bn1[1]), _ptr(bn1[2]),
              _ptr(bn1[3]), _ptr(w), _aptr(z0), _ptr(bn0[0]), _ptr(bn0[1]), _ptr(bn0[2]), _ptr(bn0[3]), _ptr(dgamma1), _ptr(dbeta1), _ptr(dw),
-             _ptr(dgamma0), _ptr(dbeta0), _aptr(dz0), N, H, W, C_, k, int(group_width), _dt(da2, z1, z0, dz0), _stream())
+             _ptr(dgamma0), _ptr(dbeta0), _aptr(dz0), N, H, W, C_, k, int(group_width), _dt(da2, z1, z0, dz0),
+             _blocked_ptr(z0, z0_blocked), int(bool(z1_blocked)), _stream())
     return dz0
 
 

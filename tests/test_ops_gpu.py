@@ -923,6 +923,20 @@ def test_mbconv_small_fused_fwd_bwd(k, N, H, W, C, V):
                             group_width=V)
     for name, ref in (("dz0", grads[0]), ("dw", grads[1]), ("dg0", grads[2]), ("db0", grads[3]), ("dg1", grads[4]), ("db1", grads[5])):
         close(outs[name], ref, 2e-4, "small bwd " + name)
+    # the saved tensors in the group-blocked layout [C / V][N H W][V] (what the learner uses): same results bit for bit
+    Vb = V or ops.mbconv_dw_small_group_width(C, k)
+    z0blk, z1blk, a1c, sc = torch.zeros_like(z0d), torch.zeros_like(z1d), torch.zeros_like(a1d), torch.zeros_like(sd)
+    mov3 = [f32(t, d) for t in (mm0, mv0, mm1, mv1)]
+    ops.mbconv_dw_fwd_small(z0d, part, nblk, (f32(g0, d), f32(b0, d), st[0], st[1], mov3[0], mov3[1]), f32(wd, d),
+                            (f32(g1, d), f32(b1, d), st[2], st[3], mov3[2], mov3[3]), z1blk, a1c, sc, group_width=V, z0_blocked=z0blk, z1_blocked=True)
+    unblock = lambda t: t.view(C // Vb, N * H * W, Vb).permute(1, 0, 2).reshape(N, H, W, C)  # noqa: E731
+    assert torch.equal(unblock(z1blk), z1d) and torch.equal(unblock(z0blk), z0d) and torch.equal(a1c, a1d) and torch.equal(sc, sd)
+    outs2 = {k_: torch.zeros_like(v) for k_, v in outs.items()}
+    ops.mbconv_dw_bwd_small(f32(da2, d), f32(gate, d), f32(cadd, d), z1blk, (st[2], st[3], f32(g1, d), f32(b1, d)), f32(wd, d), z0d,
+                            (st[0], st[1], f32(g0, d), f32(b0, d)), outs2["dg1"], outs2["db1"], outs2["dw"], outs2["dg0"], outs2["db0"], outs2["dz0"],
+                            group_width=V, z0_blocked=z0blk, z1_blocked=True)
+    for name in outs:
+        assert torch.equal(outs2[name], outs[name]), "blocked layout: " + name
     with pytest.raises(Exception):
         ops.mbconv_dw_fwd_small(torch.zeros(64, 14, 14, C, device=d), part, nblk, (f32(g0, d), f32(b0, d), st[0], st[1], None, None), f32(wd, d),
                                 (f32(g1, d), f32(b1, d), st[2], st[3], None, None), z1b, a1b, sb)
