@@ -345,18 +345,36 @@ __device__ __forceinline__ void conv_gemm_tile(const ConvGemmParams& p, float* _
   };
   typedef std::integral_constant<int, 0> U0;
   typedef std::integral_constant<int, 1 % PF> U1;
+  typedef std::integral_constant<int, 2 % PF> U2;
   int it = it0;
-  // Main loop: four chunks per trip.  The compiler flushes the load counter at a loop header (it cannot prove across the back edge
-  // that only the newest chunk is in flight), so the long body keeps that flush to every fourth chunk; the tail is straight-line.
-  for (; it + 4 <= it1; it += 4) {
-    step(U0{}, it);
-    step(U1{}, it + 1);
-    step(U0{}, it + 2);
-    step(U1{}, it + 3);
+  // Main loop: four (PF = 3: six) chunks per trip.  The compiler flushes the load counter at a loop header (it cannot prove across the
+  // back edge that only the newest chunks are in flight), so the long body keeps that flush to every fourth chunk; the tail is
+  // straight-line.  The register sets rotate with period PF.
+  if constexpr (PF == 3) {
+    for (; it + 6 <= it1; it += 6) {
+      step(U0{}, it);
+      step(U1{}, it + 1);
+      step(U2{}, it + 2);
+      step(U0{}, it + 3);
+      step(U1{}, it + 4);
+      step(U2{}, it + 5);
+    }
+    if (it < it1) step(U0{}, it);
+    if (it + 1 < it1) step(U1{}, it + 1);
+    if (it + 2 < it1) step(U2{}, it + 2);
+    if (it + 3 < it1) step(U0{}, it + 3);
+    if (it + 4 < it1) step(U1{}, it + 4);
+  } else {
+    for (; it + 4 <= it1; it += 4) {
+      step(U0{}, it);
+      step(U1{}, it + 1);
+      step(U0{}, it + 2);
+      step(U1{}, it + 3);
+    }
+    if (it < it1) step(U0{}, it);
+    if (it + 1 < it1) step(U1{}, it + 1);
+    if (it + 2 < it1) step(U0{}, it + 2);
   }
-  if (it < it1) step(U0{}, it);
-  if (it + 1 < it1) step(U1{}, it + 1);
-  if (it + 2 < it1) step(U0{}, it + 2);
 
   if constexpr (PREC == 2) {   // undo the operand scales
     const float inv = 1.0f / (p.a_qscale * b_qscale);
@@ -1299,8 +1317,11 @@ template <int PREC>
 static void launch_gemm_sk_t(const GemmPlan& g, const ConvGemmParams& p, float* slab, hipStream_t stream) {
   const SkPlan k{g.sk_full, g.sk_rem, g.sk_parts, g.sk_ipp, g.sk_nchunks, g.sk_smax, g.gy, slab};
   dim3 grid(g.sk_full + g.sk_parts), block(256);
+#ifndef GEMM_SK_PF
+#define GEMM_SK_PF 2   // chunks of global loads in flight per thread in the stream-K kernel (3 measured: see profiles/r04_notes.md)
+#endif
 #define SKL(NT_)                                                                                       \
-  hipLaunchKernelGGL((conv_gemm_sk_k<NT_, 2, false, PREC>), grid, block, 0, stream, p, k);            \
+  hipLaunchKernelGGL((conv_gemm_sk_k<NT_, GEMM_SK_PF, false, PREC>), grid, block, 0, stream, p, k);   \
   hipLaunchKernelGGL((sk_fixup_k<NT_>), dim3(g.sk_rem), dim3(1024), 0, stream, p, k);                  \
   break;
   switch (g.nt) {
