@@ -241,16 +241,15 @@ __device__ __forceinline__ void conv_gemm_tile(const ConvGemmParams& p, float* _
     float* smB = buf + A_FLOATS;
 #pragma unroll
     for (int i = 0; i < A_PER_THREAD; ++i) {
-      const int row = a_r0 + 32 * i;
       float4 v = ra_[i];
       if (SC) v = f4mul(v, rs_[i]);
-      st4(smA + (kq * BM + (row ^ kq)) * 4, v);
+      st4(smA + (kq * BM + (a_r0 ^ kq)) * 4 + 32 * i * 4, v);   // row a_r0 + 32 i, swizzled: (row ^ kq) = 32 i + (a_r0 ^ kq) as kq < 8
     }
 #pragma unroll
     for (int i = 0; i < B_PER_THREAD; ++i) {
       const int idx = t + 256 * i;
-      if (256 * (i + 1) <= B_TOTAL) st4(smB + (kq * BN + ((idx >> 3) ^ kq)) * 4, rb_[i]);
-      else st4(idx < B_TOTAL ? smB + (kq * BN + ((idx >> 3) ^ kq)) * 4 : sm + kDummy, rb_[i]);   // surplus lanes: a scratch slot, no branch
+      if (256 * (i + 1) <= B_TOTAL) st4(smB + (kq * BN + (a_r0 ^ kq)) * 4 + 32 * i * 4, rb_[i]);   // column (t >> 3) + 32 i, swizzled as above
+      else st4(idx < B_TOTAL ? smB + (kq * BN + (a_r0 ^ kq)) * 4 + 32 * i * 4 : sm + kDummy, rb_[i]);   // surplus lanes: a scratch slot, no branch
     }
   };
 
@@ -282,9 +281,9 @@ __device__ __forceinline__ void conv_gemm_tile(const ConvGemmParams& p, float* _
     auto read_frags = [&](int q) {
       const int fq = q * 4 + g;
 #pragma unroll
-      for (int i = 0; i < TM; ++i) av[q][i] = ld4(smA + (fq * BM + ((wave * 16 * TM + i * 16 + l15) ^ fq)) * 4);
+      for (int i = 0; i < TM; ++i) av[q][i] = ld4(smA + (fq * BM + wave * 16 * TM + (l15 ^ fq)) * 4 + i * 64);   // (= (row ^ fq) as fq < 8: one address, immediate offsets)
 #pragma unroll
-      for (int jn = 0; jn < NT; ++jn) bv[q][jn] = ld4(smB + (fq * BN + ((jn * 16 + l15) ^ fq)) * 4);
+      for (int jn = 0; jn < NT; ++jn) bv[q][jn] = ld4(smB + (fq * BN + (l15 ^ fq)) * 4 + jn * 64);
     };
     auto multiply = [&](int q) {
 #pragma unroll
