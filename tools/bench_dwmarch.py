@@ -41,6 +41,8 @@ def main():
     ap.add_argument("--reps", type=int, default=40)
     ap.add_argument("--all", action="store_true")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--blocks", default=None, help="comma-separated block indices (default: every large-map block)")
+    ap.add_argument("--march-only", action="store_true", help="skip the sliding-window kernels and the copies")
     a = ap.parse_args()
     d = torch.device("cuda:0")
     dll = lib.load()
@@ -52,6 +54,8 @@ def main():
     tot = {}
     for b in arch.blocks:
         if not b.executed or (b.h_out <= 14 and b.h_in <= 14 and not a.all):
+            continue
+        if a.blocks is not None and str(b.idx) not in a.blocks.split(","):
             continue
         Cc, k, s, hi, ho = b.cexp, b.k, b.stride, b.h_in, b.h_out
         ein, eout, ew = N * hi * hi * Cc, N * ho * ho * Cc, k * k * Cc
@@ -94,8 +98,10 @@ def main():
         with torch.cuda.stream(st):
             r = dict(block=b.idx, C=Cc, k=k, s=s, h=hi, fwd_MB=fb / 1e6, bwd_MB=bb / 1e6,
                      fwd_blocks=int(dll.mliis_dwconv_bn_fwd_blocks(N, hi, hi, Cc, k, s)), bwd_blocks=int(dll.mliis_dwconv_bn_bwd_blocks(N, hi, hi, Cc, k, s)),
-                     march_fwd_us=burst(new_f, reps, st), march_bwd_us=burst(new_b, reps, st), old_fwd_us=burst(old_f, reps, st),
-                     old_bwd_us=burst(old_bd, reps, st) + burst(old_bf, reps, st), copy_fwd_us=burst(cp_f, reps, st), copy_bwd_us=burst(cp_b, reps, st))
+                     march_fwd_us=burst(new_f, reps, st), march_bwd_us=burst(new_b, reps, st))
+            skip = a.march_only
+            r.update(old_fwd_us=1.0 if skip else burst(old_f, reps, st), old_bwd_us=1.0 if skip else burst(old_bd, reps, st) + burst(old_bf, reps, st),
+                     copy_fwd_us=1.0 if skip else burst(cp_f, reps, st), copy_bwd_us=1.0 if skip else burst(cp_b, reps, st))
         r["march_fwd_frac"] = fb / (r["march_fwd_us"] * 1e-6) / HBM
         r["march_bwd_frac"] = bb / (r["march_bwd_us"] * 1e-6) / HBM
         r["old_fwd_frac"] = fb / (r["old_fwd_us"] * 1e-6) / HBM
