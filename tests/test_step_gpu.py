@@ -723,7 +723,7 @@ def test_full_size_eight_step_task_config2():
 
 
 # ------------------------------------------------------------------------------------------------ reduced-precision configs
-def _lowp_step_check(name, H, N, precision, steps, loss_tol, cos_min, l2_max, later_loss_tol, seed=13, vs_exact_factor=0.0):
+def _lowp_step_check(name, H, N, precision, steps, loss_tol, cos_min, l2_max, later_loss_tol, seed=13, vs_exact_factor=0.0, vs_exact_floor=0.0):
     """One step of the HIP learner with reduced-precision matrix-core operands against the float64 oracle with the SAME operand
     rounding emulated (oracle/efficientlab_ref.py round_ops: every matrix-core conv multiplies rounded operands in the forward and in
     both backward products) and against the exact oracle.  The op-level tests pin the arithmetic bit-faithfully (tests/test_ops_gpu.py:
@@ -774,7 +774,7 @@ def _lowp_step_check(name, H, N, precision, steps, loss_tol, cos_min, l2_max, la
         assert np.isfinite(ll) and abs(ll - lo) <= later_loss_tol * abs(lo), (step, ll, lo)
     if vs_exact_factor:
         print("worst |rounded - exact| / exact over the later steps: %.2e" % worst_rx)
-        assert worst <= vs_exact_factor * worst_rx, (worst, worst_rx)
+        assert worst <= max(vs_exact_factor * worst_rx, vs_exact_floor), (worst, worst_rx)
     print("%s %s %dx%d N=%d: first-step loss rel %.2e, gradient cosine %.5f, rel L2 %.3e; worst later-step loss rel %.2e over %d steps" % (
         name, precision, H, H, N, abs(ll0 - lo_r) / abs(lo_r), cos, l2_r, worst, steps - 1))
     if steps > 2:
@@ -832,6 +832,20 @@ def test_config4_schedule_ten_shots_twenty_steps_bf16():
     worst step 42 %), first step as in the test above (loss 5e-4, gradient cosine 0.9991, relative L2 4.2e-2)."""
     _need_gpu()
     _lowp_step_check("efficientnet-b3", 96, 10, "bf16", steps=20, loss_tol=5e-3, cos_min=0.998, l2_max=6e-2, later_loss_tol=0.6, vs_exact_factor=2.5)
+
+
+@pytest.mark.skipif(os.environ.get("MLIIS_TEST_FULL_CONFIGS") != "1", reason="10 minutes of float64 oracle: set MLIIS_TEST_FULL_CONFIGS=1")
+@pytest.mark.parametrize("precision", ["bf16", "bf16-storage"])
+def test_config4_as_stated_224_ten_shots_twenty_steps(precision):
+    """BASELINE configs[3] exactly as stated, on one GPU: EfficientNet-B3, 224x224, 10 shots, 20 inner steps (HIP-graph replay from
+    the third), bf16 operands / bf16 operands + bf16 storage, every step's loss against the rounded AND the exact float64 oracle.
+    Opt-in (two float64 B3 oracles x 20 steps at 224x224: 7 minutes); the output of the last run is profiles/r04_config4_as_stated.txt.
+    The trajectory (loss 9.1 -> 2.3) is as sensitive as at 96x96: the two float64 oracles (rounded, exact) differ by up to 14.7 % at a
+    step with bf16 operands and 3.9 % with bf16 storage on top, the device by up to 10.7 % / 15.3 % from the rounded oracle, and all
+    three meet again at step 19 (2.28-2.32).  Bar: within 3 x the oracles' own distance or 20 %, whichever is larger."""
+    _need_gpu()
+    _lowp_step_check("efficientnet-b3", 224, 10, precision, steps=20, loss_tol=1e-2, cos_min=0.995, l2_max=0.1, later_loss_tol=0.6, vs_exact_factor=3.0,
+                     vs_exact_floor=0.2)
 
 
 def test_fp8_forward_activations_of_the_first_blocks_match_the_quantised_oracle():
