@@ -22,8 +22,6 @@ from __future__ import annotations
 
 import ctypes as C
 import functools
-import math
-import os
 from typing import Dict, List, Optional, Sequence
 
 import numpy as np
@@ -32,248 +30,11 @@ import torch
 from . import ops, spec
 from ._lib import MliisError, lib
 from .arena import Arena
+from .passes import _Passes
+from .plan import _Plan
 
 
-class _Plan:
-    """All activation / gradient buffers of one inner step for a fixed batch size N."""
-
-    def __init__(self, L: "Learner", N: int, act_dtype=torch.float32):
-        a, dev = L.arch, L.device
-        self.N = N
-        # storage type of the EXPANDED tensors of the MBConv blocks (z0, z1, a1, da2, da0 / dz0): fp32, or bf16 for the training plan of
-        # `--precision bf16-storage` (BASELINE configs[3]).  Everything else -- block inputs / outputs, the decoder, statistics, sums,
-        # parameters -- is fp32 in every mode.
-        self.act_dtype = act_dtype
-
-        def buf(*shape):
-            return torch.empty(shape, dtype=torch.float32, device=dev)
-
-        def xbuf(*shape):
-            return torch.empty(shape, dtype=act_dtype, device=dev)
-
-        def vec(c):
-            return buf(c), buf(c)
-        self.idx = torch.zeros(N, dtype=torch.int32, device=dev)
-        H = a.image_size
-        hs = a.h_stem
-        self.z_stem, self.a_stem = buf(N, hs, hs, a.stem_out), None   # (a_stem: only when block 0 does not take the stem's BN + swish, below)
-        self.st_stem = vec(a.stem_out)
-        self.blocks = []
-        nskip = sum(1 for b in a.blocks if b.executed and b.skip)
-        self.dc_all = torch.ones(max(nskip, 1), N, dtype=torch.float32, device=dev)
-        si = 0
-        gmax = 0
-        for b in a.blocks:
-            if not b.executed:
-                continue
-            B = {}
-            hi, ho, ce = b.h_in, b.h_out, b.cexp
-            # small maps (14x14 at 224x224 inputs): the depthwise half of the block runs as ONE launch per direction (mbconv_small.hip)
-            B["small"] = bool(L.small_fused and b.expand != 1 and ops.mbconv_dw_small_supported(N, hi, hi, ce, b.k, b.stride))
-            # every other block: the row-marching kernels (batch norm + swish in front of the depthwise conv applied while its input is
-            # staged; one-pass backward).  A shape neither family takes (>= 2 GiB tensors, other k / stride) runs op by op (dwconv.hip)
-            B["march"] = bool(L.dw_march and not B["small"] and lib.raw("mliis_dwconv_bn_supported")(N, hi, hi, ce, b.k, b.stride))
-            if act_dtype != torch.float32 and not (B["march"] or B["small"]):
-                raise MliisError("bf16 storage: block {} ({}x{}x{}, k {}, stride {}) is taken by neither fused depthwise family".format(
-                    b.idx, hi, hi, ce, b.k, b.stride))
-            if b.expand != 1:
-                B["z0"], B["st0"] = xbuf(N, hi, hi, ce), vec(ce)
-                if not B["march"]:   # (the marching kernels apply bn0 + swish on load: a0 is never written; small-map blocks run op by op in inference)
-                    B["a0"] = xbuf(N, hi, hi, ce)
-            B["z1"], B["a1"], B["st1"] = xbuf(N, ho, ho, ce), xbuf(N, ho, ho, ce), vec(ce)
-            if B["small"]:   # the fused small-map kernels save z0 (a copy) and z1 in their group-blocked layout for the backward launch
-                B["z0b"] = xbuf(N, hi, hi, ce)
-            B["s"], B["hpre"], B["gate"] = buf(N, ce), buf(N, b.se), buf(N, ce)
-            B["z2"], B["st2"], B["out"] = buf(N, ho, ho, b.cout), vec(b.cout), buf(N, ho, ho, b.cout)
-            B["dout"] = buf(N, ho, ho, b.cout)
-            B["dgate"], B["dpre1"], B["dpre2"], B["chan_add"] = buf(N, ce), buf(N, b.se), buf(N, ce), buf(N, ce)
-            if b.skip:
-                B["dc"] = self.dc_all[si]
-                si += 1
-            # gradients w.r.t. the expanded activations: one pair PER BLOCK (not a shared scratch) so the weight-gradient kernels of a
-            # block can run on the side stream while the main stream already works on the next block
-            B["da2"] = xbuf(N, ho, ho, ce)
-            # (a block without an expand conv: the depthwise backward's output is the gradient of the block's fp32 input)
-            B["da0"] = xbuf(N, hi, hi, ce) if b.expand != 1 else buf(N, hi, hi, ce)
-            self.blocks.append(B)
-        self.dstem = buf(N, hs, hs, a.stem_out)
-        ex0 = [b for b in a.blocks if b.executed]
-        # block 0 without an expand conv (EfficientNet-B0 ... B7) takes the stem's BN + swish into its depthwise launch: the activated
-        # stem output is only read there (no identity skip), so it is never written
-        self.fuse_stem = bool(ex0 and self.blocks[0]["march"] and ex0[0].expand == 1 and not ex0[0].skip)
-        if not self.fuse_stem:
-            self.a_stem = buf(N, hs, hs, a.stem_out)
-        self.rsd = []
-        for m in a.rsd:
-            D = {}
-            h = m.h
-            D["cat"] = buf(N, h, h, m.c_cat)
-            D["z0"], D["z1"], D["zf"] = buf(N, h, h, m.c_out), buf(N, h, h, m.c_out), buf(N, h, h, m.c_out)
-            D["st0"], D["st1"], D["stf"] = vec(m.c_out), vec(m.c_out), vec(m.c_out)
-            D["pyr"] = buf(N, h, h, 2 * m.c_out)        # the pooled third of the reference's "pyramid" is never materialised
-            D["pool"], D["dpool"] = buf(N, m.c_cat), buf(N, m.c_cat)
-            D["pool_part"] = buf(max(1, ops.rsd_concat_pool_floats(N, h, h, m.c_cat)))
-            D["bbias"], D["tot"] = buf(N, 9, m.c_out), buf(N, m.c_out)
-            D["out"], D["dout"] = buf(N, h, h, m.c_out), buf(N, h, h, m.c_out)
-            D["dzf"], D["dpyr"], D["dcat"] = buf(N, h, h, m.c_out), buf(N, h, h, 2 * m.c_out), buf(N, h, h, m.c_cat)
-            if m.upsample_conv:   # the residual operand's own 1x1 branch (efficientlab.py:213-215), deep channels != c_out
-                D["zu"], D["stu"], D["up2"] = buf(N, h, h, m.c_out), vec(m.c_out), buf(N, h, h, m.c_out)
-                D["dzu"], D["dup"] = buf(N, h, h, m.c_out), buf(N, h, h, m.c_deep)
-            self.rsd.append(D)
-        self.skipdec = None
-        if a.skipdec is not None:   # --skip_decoding (efficientlab.py:133-149)
-            sd, h = a.skipdec, a.skipdec.h
-            T = dict(cat=buf(N, h, h, sd.c_cat), dcat=None, z0=buf(N, h, h, sd.c_skip), st0=vec(sd.c_skip), dz0=buf(N, h, h, sd.c_skip),
-                     dout=buf(N, h, h, sd.c_sep), sep=[])
-            cin = sd.c_cat
-            for _ in range(2):
-                T["sep"].append(dict(zd=buf(N, h, h, cin), std=vec(cin), ad=buf(N, h, h, cin), zp=buf(N, h, h, sd.c_sep), stp=vec(sd.c_sep),
-                                     out=buf(N, h, h, sd.c_sep), dad=buf(N, h, h, cin), din=buf(N, h, h, cin)))
-                cin = sd.c_sep
-            self.skipdec = T
-        self.aspp = None
-        if a.aspp:   # --spatial_pyramid_pooling (models/efficientlab.py:248-289)
-            h, ci, d = a.aspp_h, a.aspp_cin, a.aspp_dimension
-            self.aspp = dict(z0=buf(N, h, h, d), z1=buf(N, h, h, d), cat=buf(N, h, h, 3 * d), dcat=buf(N, h, h, 3 * d), zo=buf(N, h, h, d),
-                             out=buf(N, h, h, d), dout=buf(N, h, h, d), dzo=buf(N, h, h, d), pool=buf(N, ci), dpool=buf(N, ci),
-                             z2=buf(N, d), b2=buf(N, d), db2=buf(N, d),
-                             masks=[buf(N, h, h, d), buf(N, h, h, d), buf(N, d), buf(N, h, h, d)])
-        hd = a.h_dec
-        self.small, self.dsmall = buf(N, hd, hd, 2), buf(N, hd, hd, 2)
-        self.logits, self.dlogits, self.pred = buf(N, H, H, 2), buf(N, H, H, 2), buf(N, H, H, 2)
-        self.drop_mask = buf(N, hd, hd, a.c_final) if L.final_layer_dropout_rate > 0 else None
-        self.loss_out = torch.zeros(4, dtype=torch.float32, device=dev)
-        # stage-1 BN statistics handed from a producer (GEMM epilogue / stats kernel) to the fused fold+apply kernel
-        need = 0
-        for b in a.blocks:
-            if b.executed:
-                for rows, c in ((N * b.h_in ** 2, b.cexp), (N * b.h_out ** 2, b.cexp), (N * b.h_out ** 2, b.cout)):
-                    need = max(need, -(-rows // 16) * 2 * c, ops.bn_stats_partial_floats(rows, c))
-        for m in a.rsd:
-            need = max(need, -(-(N * m.h * m.h) // 16) * 2 * m.c_out, ops.bn_stats_partial_floats(N * m.h * m.h, m.c_out))
-        if a.skipdec is not None:
-            rows = N * a.skipdec.h ** 2
-            for c in (a.skipdec.c_skip, a.skipdec.c_cat, a.skipdec.c_sep):
-                need = max(need, -(-rows // 16) * 2 * c, ops.bn_stats_partial_floats(rows, c))
-        need = max(need, ops.bn_stats_partial_floats(N * hs * hs, a.stem_out))
-        self.stats_part = buf(need + 64)
-        # the row-marching depthwise kernels (ops.dwconv_bn_fwd / _bwd) READ the producer's partial sums from stats_part while other
-        # workgroups of the same launch already WRITE theirs: a second buffer
-        need2 = 0
-        for b in a.blocks:
-            if b.executed:
-                need2 = max(need2, lib.raw("mliis_dwconv_bn_fwd_blocks")(N, b.h_in, b.h_in, b.cexp, b.k, b.stride) * 2 * b.cexp,
-                            lib.raw("mliis_dwconv_bn_bwd_blocks")(N, b.h_in, b.h_in, b.cexp, b.k, b.stride) * 2 * b.cexp)
-        for m in a.rsd:   # (and the second RSD branch GEMM's statistics, folded together with the first's by ops.bn_apply_fused_pair)
-            need2 = max(need2, -(-(N * m.h * m.h) // 16) * 2 * m.c_out, ops.bn_stats_partial_floats(N * m.h * m.h, m.c_out))
-        self.stats_part2 = buf(need2 + 64)
-        # the squeeze-excite backward and the depthwise batch norm's backward share ONE pass over (da2, z1) (ops.se_bn_bwd_sums): its
-        # per-image chunk sums, and the batch norm's stage-1 sums per image that ops.se_mlp_bwd_bn forms from them
-        self.sums_part = buf(max([ops.se_bn_bwd_sums_floats(N, b.h_out * b.h_out, b.cexp) for b in a.blocks if b.executed] + [0]) + 64)
-        self.stage1_se = buf(max([2 * N * b.cexp for b in a.blocks if b.executed] + [0]) + 64)
-        # squeeze-excite pooling partials of the bn1 apply pass: [N][ceil(rows_per_img / 128)][C]
-        self.pool_part = buf(max(N * (-(-(b.h_out * b.h_out) // 128)) * b.cexp for b in a.blocks if b.executed) + 64)
-        # gate-gradient partials of the project backward-data launch on the small maps: [16-row groups][2][C]
-        self.gate_part = buf(max([(-(-(N * b.h_out * b.h_out) // 16)) * 2 * b.cexp for b in a.blocks if b.executed and 16 <= b.h_out * b.h_out <= 256]
-                                 + [0]) + 64)
-        # ---- deferred weight-gradient folds: every *_bwd_filter leaves its per-split slabs in a region of fold_buf and ONE
-        #      mliis_fold_batched launch at the end of the backward pass reduces them all into the gradient arena
-        A = L.arena
-        regs, rows, off, tile = {}, [], 0, 0
-        fold_tile = lib.raw("mliis_fold_tile_outputs")()
-
-        def add(name, ws_floats, total, seg=None, key=None):
-            nonlocal off, tile
-            seg_len, seg_stride, seg_off = seg or (total, 0, 0)
-            regs[key or name] = (off, ws_floats)
-            rows.append([off, A.t_off[name], total, seg_len, seg_stride, seg_off, ws_floats // total, tile])
-            off += (ws_floats + 3) // 4 * 4
-            tile += -(-total // fold_tile)
-        fe = a.name
-        add(f"{fe}/stem/conv2d/kernel", lib.size("mliis_stem_conv_bwd_filter_workspace_floats", N, H, H, a.stem_out), 27 * a.stem_out)
-        for b, nm, B in zip([b for b in a.blocks if b.executed], L.n_blocks, self.blocks):
-            ce = b.cexp
-            if b.expand != 1:
-                add(nm["w_exp"], lib.size("mliis_conv2d_bwd_filter_workspace_floats", N, b.h_in, b.h_in, b.cin, ce, 1), b.cin * ce)
-            if B["march"]:
-                add(nm["w_dw"], lib.raw("mliis_dwconv_bn_bwd_blocks")(N, b.h_in, b.h_in, ce, b.k, b.stride) * b.k * b.k * ce, b.k * b.k * ce)
-            elif not B["small"]:   # (the small-map backward kernel writes the complete depthwise filter gradient itself: no slabs)
-                add(nm["w_dw"], lib.size("mliis_dwconv_bwd_filter_workspace_floats", N, b.h_in, b.h_in, ce, b.k, b.stride), b.k * b.k * ce)
-            add(nm["w_proj"], lib.size("mliis_conv2d_bwd_filter_workspace_floats", N, b.h_out, b.h_out, ce, b.cout, 1), ce * b.cout)
-        if a.skipdec is not None:
-            sd, h = a.skipdec, a.skipdec.h
-            ksk, seps = L.n_skipdec
-            add(ksk[0], lib.size("mliis_conv2d_bwd_filter_workspace_floats", N, h, h, sd.c_skip_in, sd.c_skip, 1), sd.c_skip_in * sd.c_skip)
-            cin = sd.c_cat
-            for (dwn, _, pwn, _) in seps:
-                add(dwn, lib.size("mliis_dwconv_bwd_filter_workspace_floats", N, h, h, cin, 3, 1), 9 * cin)
-                add(pwn, lib.size("mliis_conv2d_bwd_filter_workspace_floats", N, h, h, cin, sd.c_sep, 1), cin * sd.c_sep)
-                cin = sd.c_sep
-        self.filter_tail = {}
-        for j_rsd, (m, nm) in enumerate(zip(a.rsd, L.n_rsd)):
-            (k0, b0_, _), (k1, b1_, _), (kf, _, _) = nm
-            co = m.c_out
-            if m.upsample_conv:
-                ku, bu, _ = L.n_rsd_up[j_rsd]
-                add(ku, lib.size("mliis_conv2d_bwd_filter_workspace_floats", N, m.h, m.h, m.c_deep, co, 1), m.c_deep * co)
-                add(bu, ops.bn_bwd_dxsum_floats(N * m.h * m.h, co), co)
-            for bias in (b0_, b1_):   # conv-bias gradients: column sums of dz leave the BN backward pass as slabs
-                add(bias, ops.bn_bwd_dxsum_floats(N * m.h * m.h, co), co)
-            # filter gradients over the concatenated [deep | skip] channels.  A channel count like 136 = 2 * 64 + 8 leaves a third of
-            # the 64-channel blocks of the filter-gradient kernel nearly empty while they still occupy a CU slot each: the sliver
-            # (c_cat mod 64 <= 16 channels) gets its own small launch and fold region instead (profiles/r01_notes.md).
-            tail = m.c_cat % 64 if (m.c_cat > 64 and 0 < m.c_cat % 64 <= 16) else 0
-            self.filter_tail[j_rsd] = tail
-            for kk, kname in ((1, k0), (3, k1)):
-                main_c = m.c_cat - tail
-                add(kname, lib.size("mliis_conv2d_bwd_filter_workspace_floats", N, m.h, m.h, main_c, co, kk), kk * kk * main_c * co,
-                    seg=(main_c * co, m.c_cat * co, 0) if tail else None)
-                if tail:
-                    add(kname, lib.size("mliis_conv2d_bwd_filter_workspace_floats", N, m.h, m.h, tail, co, kk), kk * kk * tail * co,
-                        seg=(tail * co, m.c_cat * co, main_c * co), key=kname + "#tail")
-            add(kf, lib.size("mliis_conv2d_bwd_filter_workspace_floats", N, m.h, m.h, 2 * co, co, 3), 9 * 2 * co * co,
-                seg=(2 * co * co, m.c_pyr * co, 0))
-        # squeeze-excite weight gradients of all blocks: one launch (descriptor table of device addresses)
-        rows_se, se_tile = [], 0
-        for b, B, nm in zip([b for b in a.blocks if b.executed], self.blocks, L.n_blocks):
-            se = nm["se"]
-            rows_se.append([B["s"].data_ptr(), B["hpre"].data_ptr(), B["dpre1"].data_ptr(), B["dpre2"].data_ptr()] +
-                           [A.g[k].data_ptr() for k in se] + [N, b.cexp, b.se, se_tile])
-            se_tile += -(-(2 * b.cexp * b.se + b.cexp + b.se) // 256)
-        self.se_desc = torch.tensor(rows_se, dtype=torch.int64, device=dev)
-        self.se_tiles = se_tile
-        self.fold_buf = buf(off + 16)
-        self.fold_part = {k: self.fold_buf[o:o + n] for k, (o, n) in regs.items()}
-        self.fold_desc = torch.tensor(rows, dtype=torch.int64, device=dev)
-        self.fold_tiles = tile
-        # captured hipGraphExecs of the training step: key True = the step draws its masks on the device (mliis_rng_masks inside the graph),
-        # False = masks were handed in by the caller (parity tests inject them) and the graph starts after them
-        self.graphs = {}
-        self.steps_run = 0
-        # deferred dense-conv filter gradients: collected during the first (eager) backward pass of this plan, then one launch per
-        # kernel instantiation at the end of every backward pass (ops.FilterBatch)
-        self.wbatch = ops.FilterBatch(dev)
-        self.wbatch_ready = False
-        # ---- mask generation inside the step (ops.rng_masks): drop-connect scales of all skip blocks, final-layer dropout, ASPP dropouts
-        jobs = []
-        if L.drop_connect and nskip:
-            jobs.append((self.dc_all, L._dc_keeps, N, True))
-        if self.drop_mask is not None:
-            jobs.append((self.drop_mask, L.drop_keep_dev, self.drop_mask.numel(), False))
-        if self.aspp is not None:
-            for mbuf in self.aspp["masks"]:
-                jobs.append((mbuf, 1.0 - spec.ASPP_DROPOUT, 1, False))
-        self.mask_plan = ops.MaskPlan(jobs) if jobs else None
-
-    @property
-    def graph(self):
-        """Any captured graph of this plan (None: none yet)."""
-        for g in self.graphs.values():
-            return g
-        return None
-
-
-class Learner:
+class Learner(_Passes):
     def __init__(self, feature_extractor_name: str = "efficientnet-b0", image_size: int = 224, rsd: Optional[Sequence[int]] = (2, 4),
                  learning_rate: float = 1e-3, optimizer: str = "sgd", l2: bool = False, l1: bool = False, darc1: bool = False,
                  dice: bool = False, label_smoothing: float = 0.0, final_layer_dropout_rate: float = 0.0,
@@ -642,525 +403,6 @@ class Learner:
             with torch.cuda.stream(self.stream):
                 self.plans[key] = _Plan(self, N, torch.float32 if isinstance(key, tuple) else self.act_dtype)
         return self.plans[key]
-
-    # ------------------------------------------------------------------------------------------- forward
-    def _forward(self, P: _Plan, x, idx, training: bool):
-        A, a, ws, N = self.arena, self.arch, self.ws, P.N
-        w, mv = A.w, A.mv
-
-        def bn(xin, st, prefix, y, pre=False, post=False, img_scale=None, res=None, fused=False, nblk=0, pool_part=None, always_batch=False,
-               part=None):
-            """nblk > 0: the producing conv already left the stage-1 statistics in P.stats_part.  always_batch: a batch norm the
-            reference builds with training=True (the --skip_decoding decoder): batch statistics in inference too, moving averages
-            untouched there."""
-            if training or always_batch:
-                part = P.stats_part if (part is None or nblk == 0) else part
-                if nblk == 0:
-                    nblk = ops.bn_stats_partial(xin, pre, P.stats_part)
-                return ops.bn_apply_fused(xin, part, nblk, st[0], st[1], w[prefix + "/gamma"], w[prefix + "/beta"],
-                                          moving=(mv[prefix + "/moving_mean"], mv[prefix + "/moving_variance"]) if training else None,
-                                          unbiased_moving_var=fused,
-                                          pre_swish=pre, post_swish=post, img_scale=img_scale, res=res, out=y, pool_part=pool_part)
-            st[0].copy_(mv[prefix + "/moving_mean"])
-            torch.rsqrt(mv[prefix + "/moving_variance"] + spec.BN_EPS, out=st[1])
-            return ops.bn_apply(xin, st[0], st[1], w[prefix + "/gamma"], w[prefix + "/beta"], pre, post, img_scale, res, out=y)
-
-        ops.transpose_weights(A.theta, self.theta_t, self.wt_desc, self.w_amax, tiles=self.wt_tiles)
-
-        def conv(xin, wname, bname, dil, out, swish_stats, x_scale=None, border_bias=None):
-            """dense conv; in training the epilogue also emits the following BN's statistics (returns their block count)."""
-            am = self._amax_of.get(wname)
-            if training:
-                return self._conv_fwd(xin, w[wname], w[bname] if bname else None, dil, out=out, ws=ws, stats_part=P.stats_part,
-                                      stats_swish=swish_stats, wt=self.wt[wname], x_scale=x_scale, border_bias=border_bias, fp8_w_amax=am)[1]
-            self._conv_fwd(xin, w[wname], w[bname] if bname else None, dil, out=out, ws=ws, wt=self.wt[wname], x_scale=x_scale,
-                           border_bias=border_bias, fp8_w_amax=am)
-            return 0
-
-        ops.stem_conv_fwd(x, w[self.n_stem[0]], idx, out=P.z_stem)
-        ex = [b for b in a.blocks if b.executed]
-        fuse_stem = P.fuse_stem   # (block 0 takes the stem's BN + swish into its depthwise launch: _Plan)
-        if fuse_stem:
-            cur = None
-        else:
-            cur = bn(P.z_stem, P.st_stem, self.n_stem[1], P.a_stem, post=True)
-
-        def bn_in(z, st, prefix, nblk):
-            """The batch norm in front of a marching depthwise launch: (bn tuple, nblk) for ops.dwconv_bn_fwd.  Training: the launch
-            folds the producer's partial sums (P.stats_part) and updates the moving averages; inference: moving statistics given."""
-            g_, b_ = w[prefix + "/gamma"], w[prefix + "/beta"]
-            if training:
-                if nblk == 0:
-                    nblk = ops.bn_stats_partial(z, False, P.stats_part)
-                return (g_, b_, st[0], st[1], mv[prefix + "/moving_mean"], mv[prefix + "/moving_variance"]), nblk
-            st[0].copy_(mv[prefix + "/moving_mean"])
-            torch.rsqrt(mv[prefix + "/moving_variance"] + spec.BN_EPS, out=st[1])
-            return (g_, b_, st[0], st[1], None, None), 0
-
-        for bi_, (b, B, nm) in enumerate(zip(ex, P.blocks, self.n_blocks)):
-            B["x_in"] = cur
-            t = cur
-            if training and B["small"]:
-                # expand GEMM (+ stage-1 statistics) -> ONE launch: bn0 fold + apply + swish, depthwise, bn1 statistics + apply + swish,
-                # squeeze-excite means, both moving averages -> SE MLP -> project GEMM
-                nb = conv(t, nm["w_exp"], None, 1, B["z0"], False)
-                if nb == 0:
-                    nb = ops.bn_stats_partial(B["z0"], False, P.stats_part)
-                p0, p1 = nm["bn0"], nm["bn1"]
-                ops.mbconv_dw_fwd_small(B["z0"], P.stats_part, nb,
-                                        (w[p0 + "/gamma"], w[p0 + "/beta"], B["st0"][0], B["st0"][1], mv[p0 + "/moving_mean"], mv[p0 + "/moving_variance"]),
-                                        w[nm["w_dw"]],
-                                        (w[p1 + "/gamma"], w[p1 + "/beta"], B["st1"][0], B["st1"][1], mv[p1 + "/moving_mean"], mv[p1 + "/moving_variance"]),
-                                        B["z1"], B["a1"], B["s"], z0_blocked=B["z0b"], z1_blocked=True)   # (the backward's re-reads: contiguous)
-                se = nm["se"]
-                ops.se_mlp_fwd(B["s"], w[se[0]], w[se[1]], w[se[2]], w[se[3]], B["hpre"], B["gate"])
-                nb = conv(B["a1"], nm["w_proj"], None, 1, B["z2"], False, x_scale=B["gate"])
-                use_dc = self.drop_connect and b.skip and b.drop_rate > 0
-                B["use_dc"] = use_dc
-                cur = bn(B["z2"], B["st2"], nm["bn2"], B["out"], img_scale=B["dc"] if use_dc else None, res=B["x_in"] if b.skip else None, nblk=nb)
-                continue
-            if B["march"]:
-                # expand GEMM (+ stage-1 statistics) -> ONE launch: bn0 fold + apply + swish while the rows are staged, depthwise conv,
-                # bn1 stage-1 statistics (P.stats_part2)
-                if b.expand != 1:
-                    nb = conv(t, nm["w_exp"], None, 1, B["z0"], False)
-                    bn0, nb = bn_in(B["z0"], B["st0"], nm["bn0"], nb)
-                    zin = B["z0"]
-                elif bi_ == 0 and fuse_stem:
-                    bn0, nb = bn_in(P.z_stem, P.st_stem, self.n_stem[1], 0)
-                    zin = P.z_stem
-                else:
-                    bn0, nb, zin = None, 0, t
-                if training:
-                    nb = ops.dwconv_bn_fwd(zin, w[nm["w_dw"]], b.stride, bn=bn0, part=P.stats_part, nblk=nb, out=B["z1"],
-                                           stats_part=P.stats_part2)[1]
-                else:
-                    ops.dwconv_bn_fwd(zin, w[nm["w_dw"]], b.stride, bn=bn0, out=B["z1"])
-                    nb = 0
-                st_part = P.stats_part2
-            else:
-                if b.expand != 1:
-                    nb = conv(t, nm["w_exp"], None, 1, B["z0"], False)
-                    t = bn(B["z0"], B["st0"], nm["bn0"], B["a0"], post=True, nblk=nb)
-                if training:   # the depthwise launch also leaves bn1's stage-1 statistics in P.stats_part
-                    nb = ops.dwconv_fwd(t, w[nm["w_dw"]], b.stride, out=B["z1"], stats_part=P.stats_part)[1]
-                else:
-                    ops.dwconv_fwd(t, w[nm["w_dw"]], b.stride, out=B["z1"])
-                    nb = 0
-                st_part = P.stats_part
-            hw = b.h_out * b.h_out
-            se = nm["se"]
-            if training:   # bn1's apply pass also pools its output per image (partial sums); the SE kernel folds them
-                chunks = bn(B["z1"], B["st1"], nm["bn1"], B["a1"], post=True, nblk=nb, pool_part=P.pool_part, part=st_part)[1]
-                ops.se_mlp_fwd(P.pool_part, w[se[0]], w[se[1]], w[se[2]], w[se[3]], B["hpre"], B["gate"], chunks=chunks, scale=1.0 / hw,
-                               s_out=B["s"])
-            else:
-                bn(B["z1"], B["st1"], nm["bn1"], B["a1"], post=True, nblk=nb)
-                ops.colsum(B["a1"], None, nseg=N, scale=1.0 / hw, out=B["s"], ws=ws)
-                ops.se_mlp_fwd(B["s"], w[se[0]], w[se[1]], w[se[2]], w[se[3]], B["hpre"], B["gate"])
-            # squeeze-excite gate applied inside the project GEMM's A loader (the gated tensor is never written)
-            nb = conv(B["a1"], nm["w_proj"], None, 1, B["z2"], False, x_scale=B["gate"])
-            use_dc = training and self.drop_connect and b.skip and b.drop_rate > 0
-            B["use_dc"] = use_dc
-            cur = bn(B["z2"], B["st2"], nm["bn2"], B["out"], img_scale=B["dc"] if use_dc else None, res=B["x_in"] if b.skip else None, nblk=nb)
-        ends = {r: P.blocks[bi]["out"] for r, bi in a.reductions.items() if bi < len(P.blocks)}
-        dec = ends[4]
-        if a.aspp:
-            dec = self._aspp_forward(P, dec, training)
-        if a.skipdec is not None:
-            # efficientlab.py:133-149: [resize(embedded, input // 4) | swish(BN(conv1x1(reduction_2)))] -> two sep_convs (dw 3x3 -> BN ->
-            # swish -> 1x1 -> BN -> swish).  Every BN here is built with training=True in the reference.
-            sd, T = a.skipdec, P.skipdec
-            (k0, n0), seps = self.n_skipdec
-            cat = T["cat"]
-            ops.resize_bilinear_fwd(dec, (sd.h, sd.h), out=cat[..., :sd.c_in])
-            nb = conv(ends[2], k0, None, 1, T["z0"], False)
-            bn(T["z0"], T["st0"], n0, cat[..., sd.c_in:], post=True, fused=True, nblk=nb, always_batch=True)
-            cur_sd = cat
-            for S, (dwn, dbn, pwn, pbn) in zip(T["sep"], seps):
-                S["x_in"] = cur_sd
-                if training:
-                    nb = ops.dwconv_fwd(cur_sd, w[dwn], 1, out=S["zd"], stats_part=P.stats_part)[1]
-                else:
-                    ops.dwconv_fwd(cur_sd, w[dwn], 1, out=S["zd"])
-                    nb = 0
-                bn(S["zd"], S["std"], dbn, S["ad"], post=True, fused=True, nblk=nb, always_batch=True)
-                nb = conv(S["ad"], pwn, None, 1, S["zp"], False)
-                cur_sd = bn(S["zp"], S["stp"], pbn, S["out"], post=True, fused=True, nblk=nb, always_batch=True)
-            dec = cur_sd
-        for j_rsd, (m, D, nm, r) in enumerate(zip(a.rsd, P.rsd, self.n_rsd, sorted([x.scope_index + 1 for x in a.rsd], reverse=True))):
-            skip = ends[r]
-            cat = D["cat"]
-            up = cat[..., :m.c_deep]
-            # the concat of the (resized) deep map and the skip feature, and the pooled branch's per-image sums of it: one launch
-            pool_chunks = 0
-            if m.c_deep % 4 == 0 and (m.c_cat - m.c_deep) % 4 == 0 and m.h > 1:
-                pool_chunks = ops.rsd_concat_pool(dec, skip, cat, D["pool_part"])
-            else:
-                if m.h_in == m.h:
-                    ops.chan_affine(dec, out=up)
-                else:
-                    ops.resize_bilinear_fwd(dec, (m.h, m.h), out=up)
-                ops.chan_affine(skip, out=cat[..., m.c_deep:])
-            res_up = up
-            if m.upsample_conv:   # the residual operand through its own conv -> swish -> BN branch; the concat keeps the resized map
-                ku, bu, nu = self.n_rsd_up[j_rsd]
-                nb = conv(up, ku, bu, 1, D["zu"], True)
-                res_up = bn(D["zu"], D["stu"], nu, D["up2"], pre=True, fused=True, nblk=nb)
-            pyr = D["pyr"]
-            (k0, b0, n0), (k1, b1, n1), (kf, bf, nf) = nm
-            if training:
-                # the 1x1 and the 3x3-dilated branch are independent: both GEMMs first (statistics in two buffers), then ONE launch for
-                # the two conv -> swish -> BN tails
-                nb0 = self._conv_fwd(cat, w[k0], w[b0], 1, out=D["z0"], ws=ws, stats_part=P.stats_part, stats_swish=True, wt=self.wt[k0],
-                                     fp8_w_amax=self._amax_of.get(k0))[1]
-                nb1 = self._conv_fwd(cat, w[k1], w[b1], 2, out=D["z1"], ws=ws, stats_part=P.stats_part2, stats_swish=True, wt=self.wt[k1],
-                                     fp8_w_amax=self._amax_of.get(k1))[1]
-                ops.bn_apply_fused_pair([(D["z" + i], pt, nb_, D["st" + i][0], D["st" + i][1], w[nn + "/gamma"], w[nn + "/beta"],
-                                          (mv[nn + "/moving_mean"], mv[nn + "/moving_variance"]), out_)
-                                         for i, pt, nb_, nn, out_ in (("0", P.stats_part, nb0, n0, pyr[..., :m.c_out]),
-                                                                      ("1", P.stats_part2, nb1, n1, pyr[..., m.c_out:2 * m.c_out]))],
-                                        pre_swish=True, unbiased_moving_var=True)
-            else:
-                nb = conv(cat, k0, b0, 1, D["z0"], True)
-                bn(D["z0"], D["st0"], n0, pyr[..., :m.c_out], pre=True, fused=True, nblk=nb)
-                nb = conv(cat, k1, b1, 2, D["z1"], True)
-                bn(D["z1"], D["st1"], n1, pyr[..., m.c_out:2 * m.c_out], pre=True, fused=True, nblk=nb)
-            # pooled branch: per-image mean of `cat`, folded into the fuse conv as a border-class bias (rsd.hip)
-            if pool_chunks:
-                ops.rsd_pool_fwd(D["pool_part"], w[kf], 2 * m.c_out, out=D["bbias"], chunks=pool_chunks, scale=1.0 / (m.h * m.h), pool_out=D["pool"])
-            else:
-                ops.colsum(cat, None, nseg=N, scale=1.0 / (m.h * m.h), out=D["pool"], ws=ws)
-                ops.rsd_pool_fwd(D["pool"], w[kf], 2 * m.c_out, out=D["bbias"])
-            nb = conv(pyr, kf, bf, 1, D["zf"], True, border_bias=D["bbias"])
-            dec = bn(D["zf"], D["stf"], nf, D["out"], pre=True, res=res_up, fused=True, nblk=nb)
-        mask = P.drop_mask if (training and P.drop_mask is not None) else None
-        P.dec_in = dec
-        ops.final_conv_fwd(dec, w[self.n_final[0]], w[self.n_final[1]], mask, out=P.small)
-        H = a.image_size
-        ops.resize_bilinear_fwd(P.small, (H, H), out=P.logits)
-        return P.logits
-
-    # ------------------------------------------------------------------------------------------- ASPP (--spatial_pyramid_pooling)
-    def _aspp_forward(self, P: _Plan, x, training: bool):
-        """models/efficientlab.py:248-289 on the encoder output x [N,h,h,Cin]: 1x1 / 3x3-dilation-6 / image-pooling branches written
-        straight into channel slices of the concat buffer ([pooled | 3x3 | 1x1], the reference's order), then 1x1 conv + swish +
-        dropout.  The dense convs are the MFMA implicit GEMM, the activations mliis_swish_mask_*."""
-        a, w, ws, T, N = self.arch, self.arena.w, self.ws, P.aspp, P.N
-        d, hw = a.aspp_dimension, a.aspp_h * a.aspp_h
-        (k0, c0), (k1, c1), (k2, c2), (ko, co) = self.n_aspp
-        m = T["masks"] if training else [None] * 4
-        cat = T["cat"]
-        self._conv_fwd(x, w[k0], w[c0], 1, out=T["z0"], ws=ws, wt=self.wt[k0], fp8_w_amax=self._amax_of.get(k0))
-        ops.swish_mask_fwd(T["z0"], m[0], out=cat[..., 2 * d:])
-        self._conv_fwd(x, w[k1], w[c1], spec.ASPP_DILATION, out=T["z1"], ws=ws, wt=self.wt[k1])
-        ops.swish_mask_fwd(T["z1"], m[1], out=cat[..., d:2 * d])
-        ops.colsum(x, None, nseg=N, scale=1.0 / hw, out=T["pool"], ws=ws)
-        self._conv_fwd(T["pool"].view(N, 1, 1, -1), w[k2], w[c2], 1, out=T["z2"].view(N, 1, 1, d), ws=ws, wt=self.wt[k2],
-                       fp8_w_amax=self._amax_of.get(k2))
-        ops.swish_mask_fwd(T["z2"], m[2], out=T["b2"], pre_mask=True)
-        ops.chan_affine(None, A=T["b2"], out=cat[..., :d])      # bilinear resize of the 1x1 pooled map = broadcast
-        self._conv_fwd(cat, w[ko], w[co], 1, out=T["zo"], ws=ws, wt=self.wt[ko], fp8_w_amax=self._amax_of.get(ko))
-        ops.swish_mask_fwd(T["zo"], m[3], out=T["out"])
-        T["trained"] = training
-        return T["out"]
-
-    def _aspp_backward(self, P: _Plan, x, dx, dx_has: bool):
-        """Gradients of the ASPP parameters (straight into the gradient arena) and of its input (accumulated into dx when dx_has)."""
-        a, A, ws, T, N = self.arch, self.arena, self.ws, P.aspp, P.N
-        w, g = A.w, A.g
-        d, hw = a.aspp_dimension, a.aspp_h * a.aspp_h
-        (k0, c0), (k1, c1), (k2, c2), (ko, co) = self.n_aspp
-        m = T["masks"]
-        cat, dcat = T["cat"], T["dcat"]
-        dzo = ops.swish_mask_bwd(T["dout"], T["zo"], m[3], out=T["dzo"])
-        self._conv_bwd_filter(cat, dzo, 1, 1, out=g[ko], ws=ws)
-        ops.colsum(dzo, out=g[co], ws=ws)
-        self._conv_bwd_data(dzo, w[ko], 1, out=dcat, ws=ws)
-        # 1x1 branch (the pre-activation gradient overwrites its slice of dcat)
-        d0 = ops.swish_mask_bwd(dcat[..., 2 * d:], T["z0"], m[0], out=dcat[..., 2 * d:])
-        self._conv_bwd_filter(x, d0, 1, 1, out=g[k0], ws=ws)
-        ops.colsum(d0, out=g[c0], ws=ws)
-        self._conv_bwd_data(d0, w[k0], 1, out=dx, accumulate=dx_has, ws=ws)
-        # 3x3 dilation-6 branch
-        d1 = ops.swish_mask_bwd(dcat[..., d:2 * d], T["z1"], m[1], out=dcat[..., d:2 * d])
-        self._conv_bwd_filter(x, d1, 3, spec.ASPP_DILATION, out=g[k1], ws=ws)
-        ops.colsum(d1, out=g[c1], ws=ws)
-        self._conv_bwd_data(d1, w[k1], spec.ASPP_DILATION, out=dx, accumulate=True, ws=ws)
-        # image-pooling branch: per-image sums of the broadcast slice -> [N, d] chain -> mean's gradient on every pixel
-        ops.colsum(dcat[..., :d], None, nseg=N, out=T["db2"], ws=ws)
-        d2 = ops.swish_mask_bwd(T["db2"], T["z2"], m[2], out=T["db2"], pre_mask=True)
-        pool4, d24 = T["pool"].view(N, 1, 1, -1), d2.view(N, 1, 1, d)
-        self._conv_bwd_filter(pool4, d24, 1, 1, out=g[k2], ws=ws)
-        ops.colsum(d2, out=g[c2], ws=ws)
-        self._conv_bwd_data(d24, w[k2], 1, out=T["dpool"].view(N, 1, 1, -1), ws=ws)
-        ops.axpby(0.0, None, 1.0 / hw, T["dpool"])                       # d(mean)/dx = 1 / (h*w) on every pixel
-        ops.chan_affine(None, A=T["dpool"], out=dx, accumulate=True)
-
-    # ------------------------------------------------------------------------------------------- backward
-    def _backward(self, P: _Plan, x, idx):
-        A, a, ws, N = self.arena, self.arch, self.ws, P.N
-        w, g = A.w, A.g
-        hd = a.h_dec
-        ops.resize_bilinear_bwd(P.dlogits, (hd, hd), out=P.dsmall)
-        mask = P.drop_mask
-        ops.final_conv_bwd_filter(P.dec_in, P.dsmall, mask, dw=g[self.n_final[0]], db=g[self.n_final[1]], ws=ws)
-        ex = [b for b in a.blocks if b.executed]
-        has_grad = [False] * len(P.blocks)
-        dtop = P.rsd[-1]["dout"] if P.rsd else (P.skipdec["dout"] if a.skipdec is not None else
-                                                 (P.aspp["dout"] if a.aspp else P.blocks[-1]["dout"]))
-        ops.final_conv_bwd_data(P.dsmall, w[self.n_final[0]], a.c_final, mask, out=dtop)
-        if not P.rsd and not a.aspp and a.skipdec is None:
-            has_grad[-1] = True
-
-        def bn_b(xin, dy, st, prefix, dx, pre=False, post=False, img_scale=None, chan_scale=None, chan_add=None, dskip=None,
-                 dskip_accumulate=False, dxsum_part=None, stage1=None):
-            ops.bn_bwd(xin, dy, st[0], st[1], w[prefix + "/gamma"], w[prefix + "/beta"], pre, post, img_scale, chan_scale, chan_add, dx=dx,
-                       dgamma=g[prefix + "/gamma"], dbeta=g[prefix + "/beta"], ws=ws, dskip=dskip, dskip_accumulate=dskip_accumulate,
-                       dxsum_part=dxsum_part, stage1=stage1)
-
-        if not P.wbatch_ready:   # (a first backward pass that raised half-way must not leave half a table behind)
-            P.wbatch = ops.FilterBatch(self.device)
-
-        def wgrad_conv(xin, dz, kk, dil, key, x_scale=None):
-            """filter gradient of a dense conv (slabs into P.fold_part[key]): deferred into the plan's batch, launched at the end of the
-            pass, one launch per kernel instantiation.  (Round 4 ran the decoder's share on a side branch of the captured step with
-            capped grids beside the encoder's backward chain: measured neutral to negative -- profiles/r04_notes.md -- and removed.)"""
-            if not P.wbatch_ready:
-                P.wbatch.add(xin, dz, kk, dil, P.fold_part[key], x_scale=x_scale)
-
-        def wgrad_1x1(xin, dz, kname, x_scale=None):
-            wgrad_conv(xin, dz, 1, 1, kname, x_scale=x_scale)
-
-        rs = sorted([x.scope_index + 1 for x in a.rsd], reverse=True)
-        for j in range(len(a.rsd) - 1, -1, -1):
-            m, D, nm, r = a.rsd[j], P.rsd[j], self.n_rsd[j], rs[j]
-            (k0, b0, n0), (k1, b1, n1), (kf, bf, nf) = nm
-            co, hw = m.c_out, m.h * m.h
-            dO, cat, pyr, dpyr, dcat = D["dout"], D["cat"], D["pyr"], D["dpyr"], D["dcat"]
-            bn_b(D["zf"], dO, D["stf"], nf, D["dzf"], pre=True)
-            ops.rsd_pool_bwd(D["dzf"], D["tot"], D["pool"], w[kf], 2 * co, dw=g[kf], dbias=g[bf], dpool=D["dpool"], ws=ws)
-            wgrad_conv(pyr, D["dzf"], 3, 1, kf)   # rows of the 2*co convolved channels
-            self._conv_bwd_data(D["dzf"], w[kf], 1, ci_begin=0, ci_count=2 * co, out=dpyr, ws=ws)
-            d0, d1 = dpyr[..., :co], dpyr[..., co:2 * co]
-            # both branches' batch norms: one reduce launch + one apply launch (+ conv-bias gradient slabs for the batched fold)
-            ops.bn_bwd_pair([(D["z" + i], d_, D["st" + i][0], D["st" + i][1], w[nn + "/gamma"], w[nn + "/beta"], d_, g[nn + "/gamma"],
-                              g[nn + "/beta"], P.fold_part[bb]) for i, d_, nn, bb in (("0", d0, n0, b0), ("1", d1, n1, b1))],
-                            pre_swish=True, ws=ws)
-            tail = P.filter_tail[j]
-            cmain = cat[..., :m.c_cat - tail] if tail else cat
-
-            def wgrad(dz, kname, kk, dil, cmain=cmain, ctail=cat[..., m.c_cat - tail:] if tail else None):
-                wgrad_conv(cmain, dz, kk, dil, kname)
-                if ctail is not None:   # the <= 16-channel sliver of the concat (see _Plan)
-                    wgrad_conv(ctail, dz, kk, dil, kname + "#tail")
-            wgrad(d0, k0, 1, 1)
-            self._conv_bwd_data(d0, w[k0], 1, out=dcat, ws=ws)
-            wgrad(d1, k1, 3, 2)
-            self._conv_bwd_data(d1, w[k1], 2, out=dcat, accumulate=True, ws=ws)
-            # gradient of the concat = dcat + dpool / (H*W) on every pixel (the pooled branch); its deep half joins the residual
-            # gradient, its skip half goes to the endpoint's gradient: one pass (mliis_chan_split)
-            bi_skip = a.reductions[r]
-            if m.upsample_conv:
-                # the residual operand came through its own conv -> swish -> BN branch (efficientlab.py:213-215): dO is its gradient;
-                # back through that branch to the resized deep map, where the concat's share joins
-                ku, bu, nu = self.n_rsd_up[j]
-                bn_b(D["zu"], dO, D["stu"], nu, D["dzu"], pre=True, dxsum_part=P.fold_part[bu])
-                wgrad_conv(cat[..., :m.c_deep], D["dzu"], 1, 1, ku)
-                self._conv_bwd_data(D["dzu"], w[ku], 1, out=D["dup"], ws=ws)
-                dU = D["dup"]
-            else:
-                dU = dO      # dU = dO + dcat[:, :c_deep] (residual)
-            ops.chan_split(dcat, m.c_deep, dU, True, P.blocks[bi_skip]["dout"], has_grad[bi_skip], A=D["dpool"])
-            has_grad[bi_skip] = True
-            # gradient w.r.t. the deep input (for RSD(4) without a decoder in front it is the same endpoint the skip half just went to)
-            if j > 0:
-                tgt, tgt_has = P.rsd[j - 1]["dout"], False
-            elif a.skipdec is not None:
-                tgt, tgt_has = P.skipdec["dout"], False
-            elif a.aspp:
-                tgt, tgt_has = P.aspp["dout"], False
-            else:
-                bi = a.reductions[4]
-                tgt, tgt_has = P.blocks[bi]["dout"], has_grad[bi]
-            if m.h_in == m.h:
-                ops.chan_affine(dU, out=tgt, accumulate=tgt_has)
-            else:
-                ops.resize_bilinear_bwd(dU, (m.h_in, m.h_in), out=tgt, accumulate=tgt_has)
-            if j == 0 and not a.aspp and a.skipdec is None:
-                has_grad[a.reductions[4]] = True
-
-        if a.skipdec is not None:
-            # --skip_decoding decoder backward: the two sep_convs in reverse, then the concat's two halves -- the projected reduction_2
-            # endpoint (conv1x1 -> BN -> swish) and the resized embedded image
-            sd, T = a.skipdec, P.skipdec
-            (k0, n0), seps = self.n_skipdec
-            d = T["dout"]     # from the first RSD module (or, without RSD modules, the final conv's input gradient)
-            for S, (dwn, dbn, pwn, pbn) in zip(reversed(T["sep"]), reversed(seps)):
-                bn_b(S["zp"], d, S["stp"], pbn, d, post=True)
-                wgrad_conv(S["ad"], d, 1, 1, pwn)
-                self._conv_bwd_data(d, w[pwn], 1, out=S["dad"], ws=ws)
-                bn_b(S["zd"], S["dad"], S["std"], dbn, S["dad"], post=True)
-                ops.dwconv_bwd_filter(S["x_in"], S["dad"], 3, 1, partial=P.fold_part[dwn])
-                ops.dwconv_bwd_data(S["dad"], w[dwn], 1, (sd.h, sd.h), out=S["din"])
-                d = S["din"]
-            dcat_sd = d                                   # [N, h, h, c_in + c_skip]
-            bi2 = a.reductions[2]
-            bn_b(T["z0"], dcat_sd[..., sd.c_in:], T["st0"], n0, T["dz0"], post=True)
-            wgrad_conv(P.blocks[bi2]["out"], T["dz0"], 1, 1, k0)
-            self._conv_bwd_data(T["dz0"], w[k0], 1, out=P.blocks[bi2]["dout"], accumulate=has_grad[bi2], ws=ws)
-            has_grad[bi2] = True
-            if a.aspp:
-                tgt, tgt_has = P.aspp["dout"], False
-            else:
-                bi = a.reductions[4]
-                tgt, tgt_has = P.blocks[bi]["dout"], has_grad[bi]
-                has_grad[bi] = True
-            ops.resize_bilinear_bwd(dcat_sd[..., :sd.c_in], (sd.h_in, sd.h_in), out=tgt, accumulate=tgt_has)
-        if a.aspp:
-            bi = a.reductions[4]
-            self._aspp_backward(P, P.blocks[bi]["out"], P.blocks[bi]["dout"], has_grad[bi])
-            has_grad[bi] = True
-        stage1_next = None   # stage 1 of the NEXT block's (bi - 1) project-BN backward, when the expand backward-data launch produced it
-
-        def expand_bwd_data(bi, da0, wname, tgt, tgt_has):
-            """Backward-data of block bi's expand conv into the gradient of block bi - 1's output -- the last contribution to it, so the
-            launch can also emit stage 1 of that block's project-BN backward (mliis_conv2d_bwd_data_bn; small maps only)."""
-            if bi == 0:
-                self._conv_bwd_data(da0, w[wname], 1, out=tgt, accumulate=tgt_has, ws=ws)
-                return None
-            Bp = P.blocks[bi - 1]
-            _, nb = self._conv_bwd_data(da0, w[wname], 1, out=tgt, accumulate=tgt_has, ws=ws,
-                                        bn=(Bp["z2"], Bp["st2"][0], Bp["st2"][1], Bp["dc"] if Bp["use_dc"] else None), part=P.stats_part)
-            return (P.stats_part, nb) if nb else None
-
-        for bi in range(len(P.blocks) - 1, -1, -1):
-            b, B, nm = ex[bi], P.blocks[bi], self.n_blocks[bi]
-            if not has_grad[bi]:
-                raise MliisError("internal: block {} has no upstream gradient".format(bi))
-            dout = B["dout"]
-            ce, hw = b.cexp, b.h_out * b.h_out
-            # gradient for the block input: identity-skip part first (before dout is overwritten in place)
-            tgt = P.blocks[bi - 1]["dout"] if bi > 0 else P.dstem
-            tgt_has = has_grad[bi - 1] if bi > 0 else False
-            # identity-skip part of the block-input gradient: written by the same pass that turns dout into the bn2 input gradient
-            bn_b(B["z2"], dout, B["st2"], nm["bn2"], dout, img_scale=B["dc"] if B["use_dc"] else None,
-                 dskip=tgt if b.skip else None, dskip_accumulate=tgt_has, stage1=stage1_next)
-            stage1_next = None
-            if b.skip:
-                tgt_has = True
-            wgrad_1x1(B["a1"], dout, nm["w_proj"], x_scale=B["gate"])
-            da2 = B["da2"]
-            se = nm["se"]
-            groups = 0
-            if 16 <= hw <= 256:
-                # small maps: the project backward-data launch also leaves the gate gradient's per-row-group partial sums of da2 * a1
-                # and the SE kernel folds them -- no pass over the two tensors (mliis_conv2d_bwd_data_gate)
-                _, groups = self._conv_bwd_data(dout, w[nm["w_proj"]], 1, out=da2, ws=ws, gate=B["a1"], part=P.gate_part)
-            else:
-                self._conv_bwd_data(dout, w[nm["w_proj"]], 1, out=da2, ws=ws)
-            se_outs = dict(dpre1=B["dpre1"], dpre2=B["dpre2"], chan_add=B["chan_add"])
-            bn1_stage1 = None
-            if not groups and not B["small"]:
-                # ONE pass over (da2, z1): the gate's gradient and everything bn1's backward needs from the two tensors; the SE kernel
-                # folds it and emits bn1's stage-1 sums per image -- no column-sum launch, no reduce pass of the batch norm
-                st1, p1 = B["st1"], nm["bn1"]
-                nbs = ops.se_bn_bwd_sums(B["z1"], da2, st1[0], st1[1], w[p1 + "/gamma"], w[p1 + "/beta"], P.sums_part)
-                ops.se_mlp_bwd_bn(P.sums_part, nbs, B["gate"], B["hpre"], w[se[0]], w[se[2]], hw, se_outs, P.stage1_se, w1t=self.wt[se[0]])
-                bn1_stage1 = (P.stage1_se, N)
-            else:
-                if not groups:
-                    ops.colsum(da2, B["a1"], nseg=N, out=B["dgate"], ws=ws)
-                # (the SE weight gradients of all blocks are computed by one batched launch after the loop: P.se_desc)
-                ops.se_mlp_bwd(P.gate_part if groups else B["dgate"], B["gate"], B["s"], B["hpre"], w[se[0]], w[se[2]], hw, se_outs,
-                               dgate_groups=groups, w1t=self.wt[se[0]])
-            if B["small"]:   # bn1 backward, depthwise filter gradient + backward-data, bn0 backward: one launch
-                da0, st0, st1, p0, p1 = B["da0"], B["st0"], B["st1"], nm["bn0"], nm["bn1"]
-                ops.mbconv_dw_bwd_small(da2, B["gate"], B["chan_add"], B["z1"], (st1[0], st1[1], w[p1 + "/gamma"], w[p1 + "/beta"]),
-                                        w[nm["w_dw"]], B["z0"], (st0[0], st0[1], w[p0 + "/gamma"], w[p0 + "/beta"]),
-                                        g[p1 + "/gamma"], g[p1 + "/beta"], g[nm["w_dw"]], g[p0 + "/gamma"], g[p0 + "/beta"], da0,
-                                        z0_blocked=B["z0b"], z1_blocked=True)
-                wgrad_1x1(B["x_in"], da0, nm["w_exp"])
-                stage1_next = expand_bwd_data(bi, da0, nm["w_exp"], tgt, tgt_has)
-                if bi > 0:
-                    has_grad[bi - 1] = True
-                continue
-            # bn1's backward apply inside the depthwise backward launch (its operands are staged there anyway; dz1 is never written)
-            # (not the 5x5 stride-1 layer: that instantiation spills, measured without gain -- profiles/r03_notes.md)
-            fuse_bn1 = bool(B["march"] and bn1_stage1 is not None and not (b.k == 5 and b.stride == 1) and
-                            (b.expand != 1 or (bi == 0 and P.fuse_stem)))
-            if not fuse_bn1:
-                bn_b(B["z1"], da2, B["st1"], nm["bn1"], da2, post=True, chan_scale=B["gate"], chan_add=B["chan_add"], stage1=bn1_stage1)
-            if fuse_bn1:
-                st1, p1 = B["st1"], nm["bn1"]
-                if b.expand != 1:
-                    zin, st0, p0, dxo = B["z0"], B["st0"], nm["bn0"], B["da0"]
-                else:
-                    zin, st0, p0, dxo = P.z_stem, P.st_stem, self.n_stem[1], tgt
-                nb1 = ops.mbconv_dw_bwd_march(da2, B["z1"], (st1[0], st1[1], w[p1 + "/gamma"], w[p1 + "/beta"]), B["gate"], B["chan_add"],
-                                              P.stage1_se[:2 * N * ce].view(N, 2, ce), g[p1 + "/gamma"], g[p1 + "/beta"], zin,
-                                              (st0[0], st0[1], w[p0 + "/gamma"], w[p0 + "/beta"]), w[nm["w_dw"]], b.stride, dxo,
-                                              P.fold_part[nm["w_dw"]], P.stats_part2)
-                if b.expand != 1:
-                    bn_b(B["z0"], dxo, st0, p0, dxo, post=True, stage1=(P.stats_part2, nb1))
-                    wgrad_1x1(B["x_in"], dxo, nm["w_exp"])
-                    stage1_next = expand_bwd_data(bi, dxo, nm["w_exp"], tgt, tgt_has)
-                else:
-                    P.stem_stage1 = (P.stats_part2, nb1)
-                if bi > 0:
-                    has_grad[bi - 1] = True
-                continue
-            if B["march"]:
-                # ONE pass over (dz1, z0): depthwise backward-data, filter-gradient slabs and stage 1 of bn0's backward
-                wdw, slabs = w[nm["w_dw"]], P.fold_part[nm["w_dw"]]
-                if b.expand != 1:
-                    da0, st0, p0 = B["da0"], B["st0"], nm["bn0"]
-                    _, _, nb1 = ops.dwconv_bn_bwd(da2, B["z0"], wdw, b.stride, bn=(st0[0], st0[1], w[p0 + "/gamma"], w[p0 + "/beta"]), out=da0,
-                                                  dw_part=slabs, bn_part=P.stats_part2)
-                    bn_b(B["z0"], da0, st0, p0, da0, post=True, stage1=(P.stats_part2, nb1))
-                    wgrad_1x1(B["x_in"], da0, nm["w_exp"])
-                    stage1_next = expand_bwd_data(bi, da0, nm["w_exp"], tgt, tgt_has)
-                elif bi == 0 and P.fuse_stem:
-                    # (the stem's BN + swish went into this block's depthwise launch: P.dstem = gradient w.r.t. the activated stem output)
-                    st0, p0 = P.st_stem, self.n_stem[1]
-                    _, _, nb1 = ops.dwconv_bn_bwd(da2, P.z_stem, wdw, b.stride, bn=(st0[0], st0[1], w[p0 + "/gamma"], w[p0 + "/beta"]), out=tgt,
-                                                  dw_part=slabs, bn_part=P.stats_part2)
-                    P.stem_stage1 = (P.stats_part2, nb1)
-                elif tgt_has:   # no-expand block with identity skip (EfficientNet-B3 stage-1 repeats)
-                    ops.dwconv_bn_bwd(da2, B["x_in"], wdw, b.stride, out=B["da0"], dw_part=slabs)
-                    ops.chan_affine(B["da0"], out=tgt, accumulate=True)
-                else:
-                    ops.dwconv_bn_bwd(da2, B["x_in"], wdw, b.stride, out=tgt, dw_part=slabs)
-                if bi > 0:
-                    has_grad[bi - 1] = True
-                continue
-            dw_in = B["a0"] if b.expand != 1 else B["x_in"]
-            ops.dwconv_bwd_filter(dw_in, da2, b.k, b.stride, partial=P.fold_part[nm["w_dw"]])
-            if b.expand != 1:
-                da0 = B["da0"]
-                # the depthwise backward-data launch also emits stage 1 of bn0's backward (sums over (z0, da0)): no reduce pass
-                st0 = B["st0"]
-                _, nb1 = ops.dwconv_bwd_data(da2, w[nm["w_dw"]], b.stride, (b.h_in, b.h_in), out=da0, part=P.stats_part,
-                                             bn=(B["z0"], st0[0], st0[1], w[nm["bn0"] + "/gamma"], w[nm["bn0"] + "/beta"]))
-                bn_b(B["z0"], da0, st0, nm["bn0"], da0, post=True, stage1=(P.stats_part, nb1) if nb1 else None)
-                wgrad_1x1(B["x_in"], da0, nm["w_exp"])
-                stage1_next = expand_bwd_data(bi, da0, nm["w_exp"], tgt, tgt_has)
-            else:
-                if tgt_has:  # no-expand block with identity skip (EfficientNet-B3 stage-1 repeats)
-                    tmp = B["da0"]
-                    ops.dwconv_bwd_data(da2, w[nm["w_dw"]], b.stride, (b.h_in, b.h_in), out=tmp)
-                    ops.chan_affine(tmp, out=tgt, accumulate=True)
-                else:
-                    ops.dwconv_bwd_data(da2, w[nm["w_dw"]], b.stride, (b.h_in, b.h_in), out=tgt)
-            if bi > 0:
-                has_grad[bi - 1] = True
-        bn_b(P.z_stem, P.dstem, P.st_stem, self.n_stem[1], P.dstem, post=True, stage1=P.stem_stage1 if P.fuse_stem else None)
-        ops.stem_conv_bwd_filter(x, P.dstem, idx, partial=P.fold_part[self.n_stem[0]])
-        P.wbatch_ready = True
-        P.wbatch.launch(self.matmul_precision)
-        ops.se_wgrad_batched(P.se_desc, P.se_tiles)
-        # all slabs written -> one batched fold into the gradient arena
-        ops.fold_batched(P.fold_buf, A.grad, P.fold_desc, P.fold_tiles)
 
     # ------------------------------------------------------------------------------------------- one optimisation step
     def _apply(self):
