@@ -19,6 +19,7 @@ python tools/pmc_depthwise.py $(find $O/dw_fetch -name "*counter_collection.csv"
 python tools/bench_dwmarch.py --n 8 --out $O/depthwise_cold_n8.json 2>/dev/null | grep -v amdgpu > $O/depthwise_cold_n8.txt
 python tools/bench_dwmarch.py --n 64 --reps 12 --out $O/depthwise_cold_n64.json 2>/dev/null | grep -v amdgpu > $O/depthwise_cold_n64.txt
 python tools/bench_kernels.py --n 64 --iters 10 --dw-only 2>/dev/null | grep -v amdgpu > $O/bench_kernels_n64.txt
+cp $O/pmc_traffic.json profiles/${TAG%%_*}_pmc_traffic.json     # (bench.py quotes the newest profiles/rNN_pmc_traffic.json and checks its source hash)
 python bench.py > $O/bench_final.json 2> $O/bench_final.err
 {
 for V in "--foml" "--adam" "--aspp" "--skip-decoding" "--augment" "--precision bf16" "--precision fp8" "--inner-batch 16" "--inner-batch 64" \
