@@ -416,8 +416,10 @@ int mliis_lincomb(float a, const float* x, float b, const float* y, float* out, 
  *      {part_off, out_off, total, seg_len, seg_stride, seg_off, nblk, tile_begin} (offsets in floats; one tile =
  *      mliis_fold_tile_outputs() consecutive outputs of a descriptor, tile_begin = running sum of ceil(total / tile)). */
 int mliis_fold_tile_outputs(void);
+/*      se_desc (nullable, with n_se rows and se_tiles tiles, else NULL, 0, 0): the table of mliis_se_wgrad_batched -- the squeeze-excite
+ *      weight gradients of the pass ride in the same launch as se_tiles more workgroups (nothing but the optimizer reads either). */
 int mliis_fold_batched(const float* part_base, float* out_base, const long long* desc, int ndesc, long long total_tiles,
-                       hipStream_t stream);
+                       const long long* se_desc, int n_se, long long se_tiles, hipStream_t stream);
 
 /* ---- HIP-graph capture of one inner step (replaces the per-op dispatch of session.run) */
 int mliis_graph_begin_capture(hipStream_t stream);

@@ -12,6 +12,7 @@
 // models/efficientlab.py:185-190 (decoder: conv -> swish -> BN, fused BN => unbiased variance into the moving average),
 // models/efficientnet/efficientnet_model.py:266,271,280-288 (BN -> swish, drop-connect + residual).
 #include "common.hpp"
+#include "se_wgrad.hpp"
 #include "bn_fold.hpp"
 
 namespace mliis {
@@ -694,9 +695,14 @@ __global__ __launch_bounds__(256) void sum_finalize_k(const float* __restrict__ 
 constexpr int kFoldTile = 256;
 
 __global__ __launch_bounds__(256) void fold_batched_k(const float* __restrict__ part_base, float* __restrict__ out_base,
-                                                      const long long* __restrict__ desc, int ndesc) {
+                                                      const long long* __restrict__ desc, int ndesc, long long fold_tiles,
+                                                      const long long* __restrict__ se_desc, int n_se) {
   __shared__ double sm[3][64][4];
   const long long tile = blockIdx.x;
+  if (tile >= fold_tiles) {   // (uniform) the squeeze-excite weight gradients of the pass ride behind the fold's tiles (se_wgrad.hpp)
+    se_wgrad_tile(se_desc, n_se, tile - fold_tiles);
+    return;
+  }
   int lo = 0, hi = ndesc - 1;
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
@@ -1153,10 +1159,13 @@ size_t mliis_bn_bwd_dxsum_floats(long long rows, int C) {
 }
 
 int mliis_fold_batched(const float* part_base, float* out_base, const long long* desc, int ndesc, long long total_tiles,
-                       hipStream_t stream) {
+                       const long long* se_desc, int n_se, long long se_tiles, hipStream_t stream) {
   MLIIS_REQUIRE(part_base && out_base && desc && ndesc > 0 && total_tiles > 0, MLIIS_ERR_ARG, "fold_batched: bad arguments");
   MLIIS_REQUIRE(aligned16(part_base) && aligned16(out_base), MLIIS_ERR_ALIGN, "fold_batched: bases must be 16-byte aligned");
-  hipLaunchKernelGGL(fold_batched_k, dim3((unsigned)total_tiles), dim3(256), 0, stream, part_base, out_base, desc, ndesc);
+  MLIIS_REQUIRE((se_desc == nullptr && n_se == 0 && se_tiles == 0) || (se_desc != nullptr && n_se > 0 && se_tiles > 0), MLIIS_ERR_ARG,
+                "fold_batched: the squeeze-excite table comes with its row and tile counts (or NULL, 0, 0)");
+  hipLaunchKernelGGL(fold_batched_k, dim3((unsigned)(total_tiles + se_tiles)), dim3(256), 0, stream, part_base, out_base, desc, ndesc, total_tiles,
+                     se_desc, n_se);
   MLIIS_CHECK_LAUNCH("fold_batched");
   return MLIIS_OK;
 }

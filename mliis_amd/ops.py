@@ -849,9 +849,11 @@ def darc1(logits, weight, dlogits=None, out=None, ws: Optional[Workspace] = None
     lib.call("mliis_darc1", _ptr(_chk(logits)), N, logits.numel() // N, float(weight), _ptr(dlogits), _ptr(out), _ptr(buf), buf.numel(), _stream())
 
 
-def fold_batched(part_base, out_base, desc, total_tiles):
-    """One launch folding every deferred weight-gradient slab set (desc: device int64 [n,8], see include/mliis_hip.h)."""
-    lib.call("mliis_fold_batched", _ptr(part_base), _ptr(out_base), _ptr(desc), int(desc.shape[0]), int(total_tiles), _stream())
+def fold_batched(part_base, out_base, desc, total_tiles, se_desc=None, se_tiles=0):
+    """One launch folding every deferred weight-gradient slab set (desc: device int64 [n,8], see include/mliis_hip.h).  se_desc /
+    se_tiles (the arguments of se_wgrad_batched): the squeeze-excite weight gradients ride in the same launch."""
+    lib.call("mliis_fold_batched", _ptr(part_base), _ptr(out_base), _ptr(desc), int(desc.shape[0]), int(total_tiles),
+             _ptr(se_desc), int(se_desc.shape[0]) if se_desc is not None else 0, int(se_tiles) if se_desc is not None else 0, _stream())
 
 
 # ------------------------------------------------------------------------------------------------ device RNG (masks)

@@ -530,6 +530,5 @@ class _Passes:
         ops.stem_conv_bwd_filter(x, P.dstem, idx, partial=P.fold_part[self.n_stem[0]])
         P.wbatch_ready = True
         P.wbatch.launch(self.matmul_precision)
-        ops.se_wgrad_batched(P.se_desc, P.se_tiles)
-        # all slabs written -> one batched fold into the gradient arena
-        ops.fold_batched(P.fold_buf, A.grad, P.fold_desc, P.fold_tiles)
+        # all slabs written -> one batched fold into the gradient arena; the squeeze-excite weight gradients of every block ride in it
+        ops.fold_batched(P.fold_buf, A.grad, P.fold_desc, P.fold_tiles, se_desc=P.se_desc, se_tiles=P.se_tiles)

@@ -728,6 +728,27 @@ def test_fold_batched_dense_segmented_and_ragged():
         got = out[off:off + span]
         assert torch.equal(got == -7.0, want == -7.0), "fold wrote outside its window"
         close(got, want, 1e-6, "fold_batched total={}".format(total))
+    # the squeeze-excite weight gradients of a pass as extra workgroups of the same launch: the fold's outputs and the gradients are bit
+    # for bit what the two launches (mliis_fold_batched alone, mliis_se_wgrad_batched) leave
+    se_rows, se_ref, se_got, keep, se_tile = [], [], [], [], 0
+    for i, (N, C, Rr) in enumerate([(8, 96, 4), (8, 672, 28), (5, 240, 10)]):
+        s_, hp, d1, d2 = f32(rnd(N, C, seed=40 + i), d), f32(rnd(N, Rr, seed=50 + i), d), f32(rnd(N, Rr, seed=60 + i), d), f32(rnd(N, C, seed=70 + i), d)
+        a = [torch.full(sh, 3.0, device=d) for sh in ((C, Rr), (Rr,), (Rr, C), (C,))]
+        b = [torch.full(sh, 4.0, device=d) for sh in ((C, Rr), (Rr,), (Rr, C), (C,))]
+        keep += [s_, hp, d1, d2]
+        se_ref.append(a); se_got.append(b)
+        for dst, tgt in ((se_rows, b),):
+            dst.append([s_.data_ptr(), hp.data_ptr(), d1.data_ptr(), d2.data_ptr()] + [t.data_ptr() for t in tgt] + [N, C, Rr, se_tile])
+        se_tile += -(-(2 * C * Rr + C + Rr) // 256)
+    ref_rows = [r[:4] + [t.data_ptr() for t in a] + r[8:] for r, a in zip(se_rows, se_ref)]
+    ops.se_wgrad_batched(torch.tensor(ref_rows, dtype=torch.int64, device=d), se_tile)
+    out2 = torch.full((ooff + 16,), -7.0, device=d)
+    ops.fold_batched(buf, out2, torch.tensor(rows, dtype=torch.int64, device=d), tcount, se_desc=torch.tensor(se_rows, dtype=torch.int64, device=d),
+                     se_tiles=se_tile)
+    assert torch.equal(out2.cpu().double(), out)
+    for a, b in zip(se_ref, se_got):
+        for x_, y_ in zip(a, b):
+            assert torch.equal(x_, y_) and not torch.any(y_ == 4.0)
 
 
 @pytest.mark.parametrize("pre_mask", [False, True])
