@@ -465,7 +465,11 @@ static inline bool ksplit_plan(long long M, int K, int Nout, int num_cus, Stream
   sp->gx = (int)gx;
   return true;
 }
-static bool launch_ksplit(const StreamPlan& sp, const ConvGemmParams& p, hipStream_t stream, int precision) {
+static bool launch_ksplit(const StreamPlan& sp, const ConvGemmParams& p_, hipStream_t stream, int precision) {
+  ConvGemmParams p = p_;
+#ifdef KS_DBG
+  p.dbg_stamps = getenv("MLIIS_KS_STAMPS") ? (unsigned long long*)strtoull(getenv("MLIIS_KS_STAMPS"), nullptr, 0) : nullptr;
+#endif
   dim3 grid(sp.gx, sp.gy);
   if (precision != MLIIS_PREC_FP32) return launch_ksplit_lowp(precision, sp.kc, sp.nt, grid, p, sp.row_groups, stream);
   return launch_ksplit_t<0>(sp.kc, sp.nt, grid, p, sp.row_groups, stream);
@@ -478,7 +482,7 @@ int mliis_conv2d_kernel_name(int Nimg, int H, int W, int Cred, int Nout, int ksi
     snprintf(buf, buf_len, "conv1x1_stream_k<%d, %d, %d>", sp.kc, sp.nt, precision);   // (a call without accumulate / border bias)
     return MLIIS_OK;
   }
-  if (ksize == 1 && ksplit_plan((long long)Nimg * H * W, Cred, Nout, num_cus(), &sp)) {
+  if (ksize == 1 && (!has_scale || H * W >= 16) && ksplit_plan((long long)Nimg * H * W, Cred, Nout, num_cus(), &sp)) {
     snprintf(buf, buf_len, "conv1x1_ksplit_k<%d, %d, 8, %d>", sp.kc, sp.nt, precision);
     return MLIIS_OK;
   }
@@ -559,7 +563,8 @@ int mliis_conv2d_fwd(const float* x, int ldx, const float* x_scale, const float*
     }
     // long-K 1x1 convs on small maps (the MBConv project convs, SE gate on load): K split inside the workgroup, one launch
     if (ksize == 1 && border_bias == nullptr && !ybf && M * ldx * 4 < (1LL << 31) && M * ldy * 4 < (1LL << 31) &&
-        (stats_part == nullptr || !accumulate) && ksplit_plan(M, Cin, Cout, num_cus(), &sp)) {   // (its finishing threads write fp32)
+        (stats_part == nullptr || !accumulate) && (x_scale == nullptr || H * W >= 16) &&   // (the gate goes through LDS: two images per row group at most)
+        ksplit_plan(M, Cin, Cout, num_cus(), &sp)) {   // (its finishing threads write fp32)
       MLIIS_REQUIRE(stats_part == nullptr || stats_nblk, MLIIS_ERR_ARG, "conv2d_fwd: fused statistics need a stats_nblk output");
       p.stats_part = stats_part;
       p.stats_swish = stats_swish;

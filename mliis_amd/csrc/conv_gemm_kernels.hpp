@@ -60,6 +60,9 @@ struct ConvGemmParams {
   // run-time branches -- the fp32 instances are untouched): A / Cmat / gp_x address 2-byte elements (leading dimensions in elements);
   // loads widen exactly, the output is rounded to nearest even BEFORE the fused statistics are formed (they see what consumers read).
   int a_bf16 = 0, out_bf16 = 0, side_bf16 = 0;
+#ifdef KS_DBG
+  unsigned long long* dbg_stamps = nullptr;   // [workgroups][8] wall-clock stamps (100 MHz) of thread 0
+#endif
 };
 
 __device__ __forceinline__ float4 buf_ld4_bf16(__amdgpu_buffer_rsrc_t r, unsigned byte_off);
@@ -877,14 +880,24 @@ __global__ __launch_bounds__(64 * kStreamWaves, 4) void conv1x1_stream_k(ConvGem
 // flight), the WV partial accumulators meet in LDS, and the first 64 NT threads finish the rows: sum in wave order (deterministic),
 // bias, accumulate, coalesced float4 stores, BN statistics.  One launch, no slabs, every load of a row group issued at once.
 // grid = (row-group blocks, column tiles); block = 64 WV threads.
+#ifdef KS_DBG
+#define KS_STAMP(k) do { ks_st[k] = wall_clock64(); } while (0)
+#else
+#define KS_STAMP(k) do { } while (0)
+#endif
 template <int KC, int NT, int WV, int PREC>
-__global__ __launch_bounds__(64 * WV) void conv1x1_ksplit_k(ConvGemmParams p, int row_groups) {
+__global__ __launch_bounds__(64 * WV, KC <= 6 ? 4 : 2) void conv1x1_ksplit_k(ConvGemmParams p, int row_groups) {   // (KC <= 6: two workgroups per CU)
+#ifdef KS_DBG
+  unsigned long long ks_st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  KS_STAMP(0);
   constexpr int BN = 16 * NT, RS = BN + 4, QN = BN / 4;
   __shared__ __attribute__((aligned(16))) float red[WV][16][RS];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int l15 = lane & 15, g = lane >> 4;
   const int M = p.Nimg * p.H * p.W, HW = p.H * p.W;
-  const int n0 = blockIdx.y * BN;
+  const int bx = blockIdx.x, by = blockIdx.y;
+  const int n0 = by * BN;
   const int k0 = wave * 16 * KC;
   const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, kBufRecords, 0x00020000);
   const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, kBufRecords, 0x00020000);
@@ -923,24 +936,54 @@ __global__ __launch_bounds__(64 * WV) void conv1x1_ksplit_k(ConvGemmParams p, in
   const bool stats = p.stats_part != nullptr;
   const bool bnb = stats && p.bnb_x != nullptr;
   const float4 bmean = (bnb && fcol) ? ld4(p.bnb_mean + fn) : f4zero(), brstd = (bnb && fcol) ? ld4(p.bnb_rstd + fn) : f4zero();
+  // The squeeze-excite gate of a row group's (at most two) images goes through LDS: one 16-byte load per thread for the whole
+  // workgroup instead of KC per lane -- a third of the launch's vector-memory instructions, each of them the same 64 bytes for the
+  // sixteen rows of a wave (stamps build, round 4: the operand phase of the 672-channel project convs is bound by the number of
+  // vector-memory instructions, 5.5 us for 18 per lane).
+  // (The host sends gated calls here only for maps of >= 16 pixels.)
+  __shared__ __attribute__((aligned(16))) float sgate[2][16 * KC * WV];
   auto load_a = [&](int rg, float4* a) {
     const int m = rg * 16 + l15;
     const bool rok = rg < row_groups && m < M;
-    const unsigned so = gated && rok ? (unsigned)((m / HW) * p.C) : 0u;
 #pragma unroll
     for (int kg = 0; kg < KC; ++kg) {
       const int k = k0 + kg * 16 + g * 4;
       const bool ok = rok && k < p.C;
       if (PREC == 1 && p.a_bf16) a[kg] = buf_ld4_bf16(rA, ok ? (unsigned)((m * p.lda + k) * 2) : kOob);
       else a[kg] = buf_ld4(rA, ok ? (unsigned)((m * p.lda + k) * 4) : kOob);
-      if (gated) a[kg] = f4mul(a[kg], buf_ld4(rS, ok ? (so + k) * 4u : kOob));
     }
   };
-  int rg = blockIdx.x;
+  // the gate rows of the two images of row group rg: one float4 per thread of the first 2 GQ, requested a row group ahead
+  constexpr int GQ = 4 * KC * WV;                       // float4 per image row of the gate slice the workgroup covers (K <= 16 KC WV)
+  auto gate_fetch = [&](int rg) {
+    float4 v = f4zero();
+    if (gated && t < 2 * GQ) {
+      const int im = t / GQ, q = t - im * GQ;
+      const int m0 = rg * 16;
+      const int img = (m0 < M ? m0 : M - 1) / HW + im;
+      if (rg < row_groups && img < p.Nimg && q * 4 < p.C) v = buf_ld4(rS, (unsigned)((img * p.C + q * 4) * 4));
+    }
+    return v;
+  };
+  auto gate_apply = [&](int rg, float4* a) {
+    const int m = rg * 16 + l15;
+    const int im = (m < M ? m : M - 1) / HW - (rg * 16 < M ? rg * 16 : M - 1) / HW;   // 0 or 1: the image of this row among the group's
+#pragma unroll
+    for (int kg = 0; kg < KC; ++kg) a[kg] = f4mul(a[kg], ld4(&sgate[im][k0 + kg * 16 + g * 4]));
+  };
+  int rg = bx;
   float4 a_cur[KC], a_nxt[KC];
+  float4 gq = gate_fetch(rg);
   load_a(rg, a_cur);
+  KS_STAMP(1);
   for (; rg < row_groups; rg += gridDim.x) {
     load_a(rg + gridDim.x, a_nxt);
+    if (gated) {   // (uniform)
+      if (t < 2 * GQ) st4(&sgate[0][0] + t * 4, gq);
+      __syncthreads();
+      gate_apply(rg, a_cur);
+      gq = gate_fetch(rg + gridDim.x);   // (stored to LDS at the top of the next row group: two barriers behind these reads)
+    }
     // what the finishing threads add to / read beside their float4 (the accumulate target, the BN input of the stage-1 sums) is
     // requested here, under the MFMAs and the barrier, not after them: one memory round trip per row group less
     float4 pre_dst = f4zero(), pre_x = f4zero();
@@ -985,7 +1028,9 @@ __global__ __launch_bounds__(64 * WV) void conv1x1_ksplit_k(ConvGemmParams p, in
     for (int r = 0; r < 4; ++r)
 #pragma unroll
       for (int j = 0; j < NT; ++j) red[wave][g * 4 + r][j * 16 + l15] = PREC == 2 ? acc[j][r] * out_scale : acc[j][r];
+    if (rg == bx) KS_STAMP(2);
     __syncthreads();
+    if (rg == bx) KS_STAMP(3);
     const int m = rg * 16 + frow;
     if (fcol && m < M) {
       float4 v = ld4(&red[0][frow][fq * 4]);
@@ -1008,11 +1053,22 @@ __global__ __launch_bounds__(64 * WV) void conv1x1_ksplit_k(ConvGemmParams p, in
         s2 = f4fma(v, v, s2);
       }
     }
+    if (rg == bx) KS_STAMP(4);
     __syncthreads();   // the staging tile is rewritten by the next row group
 #pragma unroll
     for (int kg = 0; kg < KC; ++kg) a_cur[kg] = a_nxt[kg];
   }
-  if (!stats) return;
+  KS_STAMP(5);
+#ifdef KS_DBG
+  auto ks_flush = [&]() {
+    KS_STAMP(7);
+    if (p.dbg_stamps != nullptr && threadIdx.x == 0)
+      for (int k = 0; k < 8; ++k) p.dbg_stamps[((long long)blockIdx.y * gridDim.x + blockIdx.x) * 8 + k] = ks_st[k];
+  };
+#else
+  auto ks_flush = [&]() {};
+#endif
+  if (!stats) { ks_flush(); return; }
   // column sums over the 16 rows of the finishing threads: through the (now free) staging tile, [v][row][quad]
   float4* fold = reinterpret_cast<float4*>(&red[0][0][0]);
   if (fin) {
@@ -1027,9 +1083,11 @@ __global__ __launch_bounds__(64 * WV) void conv1x1_ksplit_k(ConvGemmParams p, in
       float4 a = fold[(v * 16) * QN + q];
 #pragma unroll
       for (int r = 1; r < 16; ++r) a = f4add(a, fold[(v * 16 + r) * QN + q]);
-      st4(p.stats_part + ((long long)blockIdx.x * 2 + v) * p.Nout + n, a);
+      st4(p.stats_part + ((long long)bx * 2 + v) * p.Nout + n, a);
     }
   }
+  KS_STAMP(6);
+  ks_flush();
 }
 
 // ------------------------------------------------------------------------------------------------ backward-filter
