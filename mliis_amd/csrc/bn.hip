@@ -234,7 +234,10 @@ struct BnApplyAlt {
 // (<= 168 VGPRs: three workgroups per CU.  With the 16-block fold batches of an earlier form the kernel needed 216 and two fitted -- the
 //  600-1568-workgroup launches of the large maps ran in two or three rounds with few waves in flight; stamps build, round 3)
 // TX / TY: storage types of x and y (float | bf16s: the expanded tensors of `--precision bf16-storage`; the pair form is float only)
-template <typename TX, typename TY>
+// RES / ISC: a residual operand / a per-image scale exist.  Compile-time: without them a row is ONE load instruction instead of three
+// (the shadow loads that used to stand in for absent operands were L1 hits, but these launches are bound by the number of
+// vector-memory instructions, not by bytes -- profiles/r04_notes.md).
+template <typename TX, typename TY, bool RES = true, bool ISC = true>
 __global__ __launch_bounds__(256, 3) void bn_apply_fused_k(const TX* __restrict__ x, int ldx, TY* __restrict__ y, int ldy,
                                                         long long rows, int C, int rows_per_img, BnFold f,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -279,8 +282,8 @@ __global__ __launch_bounds__(256, 3) void bn_apply_fused_k(const TX* __restrict_
     const long long ru = r + u * kRowLanes;
     const long long rr = ru < r1 ? ru : 0;
     v0[u] = ldq(x + rr * ldx + c);
-    rv0[u] = ld4(rbase + rr * rld + rcol);
-    is0[u] = isb[img_scale != nullptr ? (int)rr / rows_per_img : 0];
+    rv0[u] = RES ? ld4(rbase + rr * rld + rcol) : f4zero();
+    is0[u] = ISC ? isb[img_scale != nullptr ? (int)rr / rows_per_img : 0] : 1.f;
   }
   const float4 g = ld4(gamma + c), b = ld4(beta + c);   // (before the fold: they do not depend on it)
   double s, ss;
@@ -331,14 +334,14 @@ __global__ __launch_bounds__(256, 3) void bn_apply_fused_k(const TX* __restrict_
 #pragma unroll
     for (int u = 0; u < kBatch; ++u) {
       v[u] = ldq(x + (r + u * kRowLanes) * ldx + c);
-      rv[u] = ld4(rbase + (r + u * kRowLanes) * rld + rcol);
-      is[u] = isb[img_scale != nullptr ? (int)(r + u * kRowLanes) / rows_per_img : 0];
+      rv[u] = RES ? ld4(rbase + (r + u * kRowLanes) * rld + rcol) : f4zero();
+      is[u] = ISC ? isb[img_scale != nullptr ? (int)(r + u * kRowLanes) / rows_per_img : 0] : 1.f;
     }
 #pragma unroll
     for (int u = 0; u < kBatch; ++u) finish(r + u * kRowLanes, v[u], rv[u], is[u]);
   }
   for (; r < r1; r += kRowLanes)
-    finish(r, ldq(x + r * ldx + c), ld4(rbase + r * rld + rcol), isb[img_scale != nullptr ? (int)r / rows_per_img : 0]);
+    finish(r, ldq(x + r * ldx + c), RES ? ld4(rbase + r * rld + rcol) : f4zero(), ISC ? isb[img_scale != nullptr ? (int)r / rows_per_img : 0] : 1.f);
   if (pool_part == nullptr) return;   // (uniform)
   // pooled partial of this block: butterfly over the 8 row lanes of a wave that share a quad, then the 4 waves through LDS
 #pragma unroll
@@ -1065,13 +1068,22 @@ int mliis_bn_apply_fused(const float* x, int ldx, float* y, int ldy, long long r
                   (size_t)gy * C, pool_floats);
     *pool_chunks = cpi;
   }
-  if (act_dtype == MLIIS_DT_BF16)   // x and y are bf16 tensors (z1 -> a1 of an MBConv block)
-    hipLaunchKernelGGL((bn_apply_fused_k<bf16s, bf16s>), dim3(gx, gy), dim3(256), 0, stream, reinterpret_cast<const bf16s*>(x), ldx,
-                       reinterpret_cast<bf16s*>(y), ldy, rows, C, rows_per_img, f, gamma, beta, pre_swish, post_swish, img_scale, res, ldr, rpb,
-                       pool_part, cpi, BnApplyAlt{});
-  else
-    hipLaunchKernelGGL((bn_apply_fused_k<float, float>), dim3(gx, gy), dim3(256), 0, stream, x, ldx, y, ldy, rows, C, rows_per_img, f, gamma, beta,
-                       pre_swish, post_swish, img_scale, res, ldr, rpb, pool_part, cpi, BnApplyAlt{});
+#define BN_APPLY(TX_, TY_, RES_, ISC_)                                                                                                        \
+  hipLaunchKernelGGL((bn_apply_fused_k<TX_, TY_, RES_, ISC_>), dim3(gx, gy), dim3(256), 0, stream, reinterpret_cast<const TX_*>(x), ldx,         \
+                     reinterpret_cast<TY_*>(y), ldy, rows, C, rows_per_img, f, gamma, beta, pre_swish, post_swish, img_scale, res, ldr, rpb,   \
+                     pool_part, cpi, BnApplyAlt{})
+  const bool has_res = res != nullptr, has_isc = img_scale != nullptr;
+  if (act_dtype == MLIIS_DT_BF16) {   // x and y are bf16 tensors (z1 -> a1 of an MBConv block)
+    if (!has_res && !has_isc) BN_APPLY(bf16s, bf16s, false, false);
+    else BN_APPLY(bf16s, bf16s, true, true);
+  } else if (!has_res && !has_isc) {
+    BN_APPLY(float, float, false, false);
+  } else if (has_res && !has_isc) {
+    BN_APPLY(float, float, true, false);
+  } else {
+    BN_APPLY(float, float, true, true);
+  }
+#undef BN_APPLY
   MLIIS_CHECK_LAUNCH("bn_apply_fused");
   return MLIIS_OK;
 }
@@ -1106,7 +1118,7 @@ int mliis_bn_apply_fused_pair(const float* x0, float* y0, const float* part0, in
     rpb = g2.rows_per_block;
   }
   fit_one_round(rows, gx, 2, &gy, &rpb);
-  hipLaunchKernelGGL((bn_apply_fused_k<float, float>), dim3(gx, gy, 2), dim3(256), 0, stream, x0, ldx, y0, ldy, rows, C, (int)rows, f0, gamma0, beta0, pre_swish,
+  hipLaunchKernelGGL((bn_apply_fused_k<float, float, false, false>), dim3(gx, gy, 2), dim3(256), 0, stream, x0, ldx, y0, ldy, rows, C, (int)rows, f0, gamma0, beta0, pre_swish,
                      post_swish, nullptr, nullptr, 0, rpb, nullptr, 0, BnApplyAlt{x1, y1, f1, gamma1, beta1});
   MLIIS_CHECK_LAUNCH("bn_apply_fused_pair");
   return MLIIS_OK;
