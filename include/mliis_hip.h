@@ -143,7 +143,11 @@ int mliis_mbconv_dw_bwd_march(const float* da2, const float* z1, const float* me
  *      z1 = depthwise output, a1 = swish(bn1(z1)), s [N,C] = per-image mean of a1, and (nullable) a0 = swish(bn0(z0)).
  *      backward: da2 = gradient w.r.t. a1 * gate (the project conv's backward-data), gate / chan_add [N,C] as in mliis_bn_bwd's
  *      chan_scale / chan_add (nullable); writes both BN parameter gradients, the COMPLETE depthwise filter gradient dw [k,k,C] (no
- *      slabs) and dz0 = gradient w.r.t. the expand conv's output. */
+ *      slabs) and dz0 = gradient w.r.t. the expand conv's output.
+ *      Blocked operands (group-blocked layout [C / group_width][N*H*W][group_width], what a workgroup reads contiguously): forward
+ *      z0_blocked = a buffer that receives a copy of z0 in that layout -- or z0 itself when the expand conv wrote it blocked
+ *      (MLIIS_DT_BLOCKED: z0_blocked == z0, nothing is copied); z1_blocked != 0: z1 is written blocked.  backward: z0_blocked read
+ *      instead of z0; z1_blocked bit 0: z1 is blocked, bit 1: da2 is blocked (mliis_conv2d_bwd_data_gate with MLIIS_DT_BLOCKED). */
 int mliis_mbconv_dw_small_supported(int N, int H, int W, int C, int k, int stride);
 int mliis_mbconv_dw_small_group_width(int C, int k);
 int mliis_mbconv_dw_fwd_small(const float* z0, const float* part0, int nblk0, const float* gamma0, const float* beta0, float* mean0,
@@ -180,6 +184,12 @@ size_t mliis_conv2d_workspace_floats(int Nimg, int H, int W, int Cred, int Nout,
  *      elements), loads widen exactly, stores round to nearest even, every sum / statistic / accumulator is fp32. */
 #define MLIIS_DT_F32 0
 #define MLIIS_DT_BF16 1
+/* OR into y_dtype of mliis_conv2d_fwd / dx_dtype of mliis_conv2d_bwd_data_gate: the output is written in the group-blocked layout
+ * [C / v][N*H*W][v] (v = 2 | 4, fp32 storage; ldy / lddx are then not used) that the small-map fused MBConv kernels read with
+ * contiguous accesses (a workgroup there owns v channels over all pixels): mliis_mbconv_dw_fwd_small(z0 == z0_blocked),
+ * mliis_mbconv_dw_bwd_small(z1_blocked bit 1).  Only calls that take the streamed 1x1 plan (mliis_conv2d_kernel_name:
+ * conv1x1_stream_k) support it; others return MLIIS_ERR_UNSUPPORTED. */
+#define MLIIS_DT_BLOCKED(v) ((v) << 8)
 #define MLIIS_PREC_FP32 0
 #define MLIIS_PREC_BF16 1
 #define MLIIS_PREC_FP8 2

@@ -515,6 +515,10 @@ int mliis_conv2d_fwd(const float* x, int ldx, const float* x_scale, const float*
   if ((rc = prec_check("conv2d_fwd", precision))) return rc;
   // bf16 STORAGE of x and / or y (an expanded MBConv tensor): bf16 operands on the matrix cores, a 1x1 conv, no accumulate, and no
   // plan that finishes its tiles in a second launch (split-K / stream-K slabs) -- the statistics are formed from the rounded output
+  const int y_block = (y_dtype >> 8) & 0xff;   // MLIIS_DT_BLOCKED(v): y in the group-blocked layout [Cout / v][N H W][v]
+  y_dtype &= 0xff;
+  MLIIS_REQUIRE(y_block == 0 || ((y_block == 2 || y_block == 4) && y_dtype == MLIIS_DT_F32 && Cout % y_block == 0), MLIIS_ERR_ARG,
+                "conv2d_fwd: a group-blocked output takes v = 2 | 4 dividing Cout and fp32 storage");
   const bool xbf = x_dtype == MLIIS_DT_BF16, ybf = y_dtype == MLIIS_DT_BF16;
   MLIIS_REQUIRE((x_dtype == MLIIS_DT_F32 || xbf) && (y_dtype == MLIIS_DT_F32 || ybf), MLIIS_ERR_ARG, "conv2d_fwd: bad storage type");
   if (xbf || ybf) {
@@ -554,13 +558,16 @@ int mliis_conv2d_fwd(const float* x, int ldx, const float* x_scale, const float*
       MLIIS_REQUIRE(stats_part == nullptr || stats_nblk, MLIIS_ERR_ARG, "conv2d_fwd: fused statistics need a stats_nblk output");
       p.stats_part = stats_part;
       p.stats_swish = stats_swish;
+      p.c_block = y_block;
       if (launch_stream(sp, p, stream, precision)) {
         MLIIS_CHECK_LAUNCH("conv2d_fwd_stream");
         if (stats_part != nullptr) *stats_nblk = sp.gx;
         return MLIIS_OK;
       }
       p.stats_part = nullptr;
+      p.c_block = 0;
     }
+    MLIIS_REQUIRE(y_block == 0, MLIIS_ERR_UNSUPPORTED, "conv2d_fwd: a group-blocked output needs the streamed 1x1 plan (mliis_conv2d_kernel_name)");
     // long-K 1x1 convs on small maps (the MBConv project convs, SE gate on load): K split inside the workgroup, one launch
     if (ksize == 1 && border_bias == nullptr && !ybf && M * ldx * 4 < (1LL << 31) && M * ldy * 4 < (1LL << 31) &&
         (stats_part == nullptr || !accumulate) && (x_scale == nullptr || H * W >= 16) &&   // (the gate goes through LDS: two images per row group at most)
@@ -675,6 +682,11 @@ static int conv2d_bwd_data_impl(const float* dy, int lddy, const float* w, float
   int rc = conv_check("conv2d_bwd_data", Nimg, H, W, Cin_out, Cout, ksize, dil);
   if (rc) return rc;
   if ((rc = prec_check("conv2d_bwd_data", precision))) return rc;
+  const int dx_block = (dx_dtype >> 8) & 0xff;   // MLIIS_DT_BLOCKED(v): dx in the group-blocked layout (as y in mliis_conv2d_fwd)
+  dx_dtype &= 0xff;
+  MLIIS_REQUIRE(dx_block == 0 || ((dx_block == 2 || dx_block == 4) && dx_dtype == MLIIS_DT_F32 && Cin_out % dx_block == 0 && ci_begin == 0 &&
+                                  Cin_out == Cin_total),
+                MLIIS_ERR_ARG, "conv2d_bwd_data: a group-blocked output takes v = 2 | 4 dividing the channel count, all channels and fp32 storage");
   const bool dybf = dy_dtype == MLIIS_DT_BF16, dxbf = dx_dtype == MLIIS_DT_BF16;   // (as in mliis_conv2d_fwd)
   MLIIS_REQUIRE((dy_dtype == MLIIS_DT_F32 || dybf) && (dx_dtype == MLIIS_DT_F32 || dxbf), MLIIS_ERR_ARG, "conv2d_bwd_data: bad storage type");
   if (dybf || dxbf) {
@@ -717,6 +729,7 @@ static int conv2d_bwd_data_impl(const float* dy, int lddy, const float* w, float
         p.gp_ldx = bnb->ldx;
         p.gp_part = bnb->part;
       }
+      p.c_block = dx_block;
       if (launch_stream(sp, p, stream, precision)) {
         MLIIS_CHECK_LAUNCH("conv2d_bwd_data_stream");
         if (with_bn) *bnb->nblk = sp.gx;
@@ -726,7 +739,9 @@ static int conv2d_bwd_data_impl(const float* dy, int lddy, const float* w, float
       p.stats_part = nullptr;
       p.bnb_x = nullptr;
       p.gp_part = nullptr;
+      p.c_block = 0;
     }
+    MLIIS_REQUIRE(dx_block == 0, MLIIS_ERR_UNSUPPORTED, "conv2d_bwd_data: a group-blocked output needs the streamed 1x1 plan");
     // long-K 1x1 convs on small maps (backward-data of the MBConv expand convs): K split inside the workgroup, one launch
     if (ksize == 1 && !dxbf && M * lddx * 4 < (1LL << 31) && M * lddy * 4 < (1LL << 31) && ksplit_plan(M, Cout, Cin_out, num_cus(), &sp)) {
       const bool with_bn = bnb != nullptr && bnb->mean != nullptr && (size_t)sp.gx * 2 * Cin_out <= bnb->part_floats;

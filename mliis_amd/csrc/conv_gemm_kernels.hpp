@@ -60,6 +60,9 @@ struct ConvGemmParams {
   // run-time branches -- the fp32 instances are untouched): A / Cmat / gp_x address 2-byte elements (leading dimensions in elements);
   // loads widen exactly, the output is rounded to nearest even BEFORE the fused statistics are formed (they see what consumers read).
   int a_bf16 = 0, out_bf16 = 0, side_bf16 = 0;
+  // conv1x1_stream_k only: c_block = v (2 | 4): Cmat is written in the group-blocked layout [Nout / v][M][v] (fp32) that the small-map
+  // fused MBConv kernels read contiguously (mbconv_small.hip: a workgroup owns v channels over all pixels); ldc is not used then
+  int c_block = 0;
 #ifdef KS_DBG
   unsigned long long* dbg_stamps = nullptr;   // [workgroups][8] wall-clock stamps (100 MHz) of thread 0
 #endif
@@ -813,7 +816,26 @@ __global__ __launch_bounds__(64 * kStreamWaves, 4) void conv1x1_stream_k(ConvGem
     else if (stats && p.stats_swish) epilogue(std::integral_constant<int, 2>{});
     else if (stats) epilogue(std::integral_constant<int, 1>{});
     else epilogue(std::integral_constant<int, 0>{});
-    {   // the staged tile -> memory, a float4 per lane and trip (the wave reads what it wrote itself: LDS is in order, no barrier)
+    if (p.c_block != 0) {   // (uniform) group-blocked output: 16 consecutive lanes write the 16 rows of one channel quad (256 contiguous
+                            // bytes per quad for v = 4; two 128-byte runs for v = 2)
+      constexpr int QN = 4 * NT;
+#pragma unroll
+      for (int u = 0; u < NT; ++u) {
+        const int e = lane + 64 * u;
+        const int q4 = e >> 4, row = e & 15;
+        const int m = rg * 16 + row, n = n0 + q4 * 4;
+        const float4 v4 = ld4(&stage[wave][row * SROW + q4 * 4]);
+        if (q4 < QN && m < M && n < p.Nout) {
+          if (p.c_block == 4) {
+            st4(p.Cmat + ((long long)(n >> 2) * M + m) * 4, v4);
+          } else {
+            float* d0 = p.Cmat + ((long long)(n >> 1) * M + m) * 2;
+            *reinterpret_cast<float2*>(d0) = make_float2(v4.x, v4.y);
+            *reinterpret_cast<float2*>(d0 + (long long)M * 2) = make_float2(v4.z, v4.w);
+          }
+        }
+      }
+    } else {   // the staged tile -> memory, a float4 per lane and trip (the wave reads what it wrote itself: LDS is in order, no barrier)
       constexpr int QN = 4 * NT;
 #pragma unroll
       for (int u = 0; u < NT; ++u) {

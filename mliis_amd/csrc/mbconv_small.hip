@@ -319,9 +319,12 @@ __global__ __launch_bounds__(kSmThreads) void mbconv_dw_fwd_small_k(SmallFwd p) 
   // own pixels' z0 first (does not depend on the statistics fold)
   const __amdgpu_buffer_rsrc_t rz0 = sm_rsrc(p.z0);
   VT zin[4];
+  // z0b == z0: the expand conv has written z0 in the group-blocked layout already (mliis_conv2d_fwd, MLIIS_DT_BLOCKED): contiguous
+  // loads here, no copy to make
+  const bool z0_in_b = p.z0b != nullptr && static_cast<const void*>(p.z0b) == static_cast<const void*>(p.z0);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) zin[j] = sm_ld<V, T>(rz0, st.poff(j));
-  if (p.z0b != nullptr) {   // (contiguous stores: lanes run along W)
+  for (int j = 0; j < 4; ++j) zin[j] = sm_ld<V, T>(rz0, z0_in_b ? st.bpoff(j) : st.poff(j));
+  if (p.z0b != nullptr && !z0_in_b) {   // (contiguous stores: lanes run along W)
     const __amdgpu_buffer_rsrc_t rzb = sm_rsrc(p.z0b);
 #pragma unroll
     for (int j = 0; j < 4; ++j) sm_st<V, T>(rzb, st.bpoff(j), zin[j]);
@@ -533,7 +536,7 @@ struct SmallBwd {
   float *dgamma1, *dbeta1, *dw, *dgamma0, *dbeta0;
   float* dz0;              // [N,H,W,C] out: gradient w.r.t. the expand conv's output
   const float* z0b;        // nullable: z0 in the group-blocked layout (mbconv_dw_fwd_small's z0b), read instead of z0
-  int z1_blocked;          // != 0: z1 is in the group-blocked layout
+  int z1_blocked;          // bit 0: z1 is in the group-blocked layout; bit 1: so is da2 (mliis_conv2d_bwd_data_gate, MLIIS_DT_BLOCKED)
   SmallGeom g;
 #ifdef SM_DBG
   unsigned long long* stamps;
@@ -571,8 +574,8 @@ __global__ __launch_bounds__(kSmThreads) void mbconv_dw_bwd_small_k(SmallBwd p) 
     const __amdgpu_buffer_rsrc_t rz1 = sm_rsrc(p.z1), rd = sm_rsrc(p.da2), rz0 = sm_rsrc(zb ? p.z0b : p.z0);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      zv[j] = sm_ld<V, T>(rz1, p.z1_blocked ? st.bpoff(j) : st.poff(j));
-      dv[j] = sm_ld<V, T>(rd, st.poff(j));
+      zv[j] = sm_ld<V, T>(rz1, (p.z1_blocked & 1) ? st.bpoff(j) : st.poff(j));
+      dv[j] = sm_ld<V, T>(rd, (p.z1_blocked & 2) ? st.bpoff(j) : st.poff(j));
       z0v[j] = sm_ld<V, T>(rz0, zb ? st.bpoff(j) : st.poff(j));
     }
   }

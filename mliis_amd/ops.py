@@ -326,15 +326,16 @@ def mbconv_dw_fwd_small(z0, part0, nblk0, bn0, w, bn1, z1, a1, s, a0=None, eps=B
 
 
 def mbconv_dw_bwd_small(da2, gate, chan_add, z1, bn1, w, z0, bn0, dgamma1, dbeta1, dw, dgamma0, dbeta0, dz0, group_width=0, z0_blocked=None,
-                        z1_blocked=False):
+                        z1_blocked=False, da2_blocked=False):
     """bn1 / bn0 = (mean, rstd, gamma, beta).  One launch: bn1 backward, depthwise filter gradient (complete) and backward-data, bn0
-    backward; dz0 = gradient w.r.t. the expand conv's output."""
+    backward; dz0 = gradient w.r.t. the expand conv's output.  da2_blocked: da2 arrives in the group-blocked layout
+    (conv2d_bwd_data(gate=..., out_block=group width))."""
     N, H, W, C_ = z1.shape
     k = w.shape[0]
     lib.call("mliis_mbconv_dw_bwd_small", _aptr(da2), _ptr(gate), _ptr(chan_add), _aptr(z1), _ptr(bn1[0]), _ptr(bn1[1]), _ptr(bn1[2]),
              _ptr(bn1[3]), _ptr(w), _aptr(z0), _ptr(bn0[0]), _ptr(bn0[1]), _ptr(bn0[2]), _ptr(bn0[3]), _ptr(dgamma1), _ptr(dbeta1), _ptr(dw),
              _ptr(dgamma0), _ptr(dbeta0), _aptr(dz0), N, H, W, C_, k, int(group_width), _dt(da2, z1, z0, dz0),
-             _blocked_ptr(z0, z0_blocked), int(bool(z1_blocked)), _stream())
+             _blocked_ptr(z0, z0_blocked), int(bool(z1_blocked)) | (2 if da2_blocked else 0), _stream())
     return dz0
 
 
@@ -362,10 +363,11 @@ def hwoi(w):
 
 def conv2d_fwd(x, w, bias=None, dil=1, out=None, accumulate=False, ws: Optional[Workspace] = None, nhw=None, stats_part=None,
                stats_swish=False, wt=None, x_scale=None, border_bias=None, ci_begin=0, precision="fp32", fp8_act_scale=FP8_ACT_SCALE,
-               fp8_w_amax=None):
+               fp8_w_amax=None, out_block=0):
     """x: [N,H,W,>=Cin] view (channel slice allowed); w: [k,k,Cin,Cout]; wt: its K-contiguous copy (built here when not given --
     the kernels only read wt).  With stats_part (a float buffer) the epilogue also emits the next batch norm's stage-1 statistics
-    and the function returns (out, nblk); nblk == 0 means they were not produced."""
+    and the function returns (out, nblk); nblk == 0 means they were not produced.  out_block = v (2 | 4): `out` receives the
+    group-blocked layout [Cout / v][N H W][v] (streamed 1x1 plan only: conv1x1_stream_eligible)."""
     N, H, W = nhw if nhw is not None else x.shape[:3]
     k, _, Cin_total, Cout = w.shape
     wt = hwoi(w) if wt is None else wt
@@ -390,14 +392,21 @@ def conv2d_fwd(x, w, bias=None, dil=1, out=None, accumulate=False, ws: Optional[
     _timed("conv2d_fwd", meta, lambda: lib.call("mliis_conv2d_fwd", _aptr(x), ldx, _ptr(x_scale), _ptr(wt), _ptr(bias), _ptr(border_bias), _aptr(out), ldy, N, H, W,
                                                 Cin_total, ci_begin, Cin, Cout, k,
                                                 dil, int(accumulate), _ptr(stats_part), int(stats_swish), C.byref(nblk), _ptr(buf),
-                                                buf.numel(), prec, float(fp8_act_scale), _ptr(fp8_w_amax), _dt(x), _dt(out), _stream()))
+                                                buf.numel(), prec, float(fp8_act_scale), _ptr(fp8_w_amax), _dt(x), _dt(out) | (int(out_block) << 8),
+                                                _stream()))
     if stats_part is not None:
         return out, nblk.value
     return out
 
 
+def conv1x1_stream_eligible(N, H, W, cred, nout, precision="fp32"):
+    """True when a plain 1x1 conv of this shape (no input scale, accumulate or border bias) takes the streamed kernel -- the plan that can
+    write its output group-blocked (conv2d_fwd(out_block=...), conv2d_bwd_data(gate=..., out_block=...))."""
+    return conv2d_kernel_name(N, H, W, cred, nout, 1, False, precision).startswith("conv1x1_stream_k")
+
+
 def conv2d_bwd_data(dy, w, dil=1, ci_begin=0, ci_count=None, out=None, accumulate=False, ws: Optional[Workspace] = None, precision="fp32",
-                    bn=None, part=None, gate=None):
+                    bn=None, part=None, gate=None, out_block=0):
     """bn = (x, mean, rstd, img_scale or None) with a float buffer `part`: `out` is the gradient w.r.t. the output of a plain batch norm
     over x and the launch may also leave stage 1 of that batch norm's backward in `part`; returns (out, nblk) then -- pass
     (part, nblk) to bn_bwd(stage1=...) when nblk > 0."""
@@ -421,8 +430,8 @@ def conv2d_bwd_data(dy, w, dil=1, ci_begin=0, ci_count=None, out=None, accumulat
         groups = C.c_int(0)
         _timed("conv2d_bwd_data", meta, lambda: lib.call("mliis_conv2d_bwd_data_gate", _aptr(dy), lddy, _ptr(w), _aptr(out), lddx, N, H, W, Cin,
                                                          ci_begin, ci_count, Cout, k, dil, _ptr(buf), buf.numel(), prec, _aptr(gate),
-                                                         rows_ld(gate)[2], _ptr(part), part.numel(), C.byref(groups), _dt(dy), _dt(out, gate),
-                                                         _stream()))
+                                                         rows_ld(gate)[2], _ptr(part), part.numel(), C.byref(groups), _dt(dy),
+                                                         _dt(out, gate) | (int(out_block) << 8), _stream()))   # (out_block: out group-blocked)
         return out, groups.value
     if bn is not None:
         bx, bmean, brstd, bscale = bn

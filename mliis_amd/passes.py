@@ -39,12 +39,13 @@ class _Passes:
 
         ops.transpose_weights(A.theta, self.theta_t, self.wt_desc, self.w_amax, tiles=self.wt_tiles)
 
-        def conv(xin, wname, bname, dil, out, swish_stats, x_scale=None, border_bias=None):
+        def conv(xin, wname, bname, dil, out, swish_stats, x_scale=None, border_bias=None, out_block=0):
             """dense conv; in training the epilogue also emits the following BN's statistics (returns their block count)."""
             am = self._amax_of.get(wname)
             if training:
                 return self._conv_fwd(xin, w[wname], w[bname] if bname else None, dil, out=out, ws=ws, stats_part=P.stats_part,
-                                      stats_swish=swish_stats, wt=self.wt[wname], x_scale=x_scale, border_bias=border_bias, fp8_w_amax=am)[1]
+                                      stats_swish=swish_stats, wt=self.wt[wname], x_scale=x_scale, border_bias=border_bias, fp8_w_amax=am,
+                                      out_block=out_block)[1]
             self._conv_fwd(xin, w[wname], w[bname] if bname else None, dil, out=out, ws=ws, wt=self.wt[wname], x_scale=x_scale,
                            border_bias=border_bias, fp8_w_amax=am)
             return 0
@@ -75,11 +76,14 @@ class _Passes:
             if training and B["small"]:
                 # expand GEMM (+ stage-1 statistics) -> ONE launch: bn0 fold + apply + swish, depthwise, bn1 statistics + apply + swish,
                 # squeeze-excite means, both moving averages -> SE MLP -> project GEMM
-                nb = conv(t, nm["w_exp"], None, 1, B["z0"], False)
+                z0 = B["z0b"] if B["blk"] else B["z0"]     # (blk: the expand conv writes the group-blocked layout itself)
+                nb = conv(t, nm["w_exp"], None, 1, z0, False, out_block=B["blk"])
                 if nb == 0:
-                    nb = ops.bn_stats_partial(B["z0"], False, P.stats_part)
+                    if B["blk"]:
+                        raise MliisError("internal: the streamed expand conv of block {} left no statistics".format(b.idx))
+                    nb = ops.bn_stats_partial(z0, False, P.stats_part)
                 p0, p1 = nm["bn0"], nm["bn1"]
-                ops.mbconv_dw_fwd_small(B["z0"], P.stats_part, nb,
+                ops.mbconv_dw_fwd_small(z0, P.stats_part, nb,
                                         (w[p0 + "/gamma"], w[p0 + "/beta"], B["st0"][0], B["st0"][1], mv[p0 + "/moving_mean"], mv[p0 + "/moving_variance"]),
                                         w[nm["w_dw"]],
                                         (w[p1 + "/gamma"], w[p1 + "/beta"], B["st1"][0], B["st1"][1], mv[p1 + "/moving_mean"], mv[p1 + "/moving_variance"]),
@@ -428,7 +432,8 @@ class _Passes:
             if 16 <= hw <= 256:
                 # small maps: the project backward-data launch also leaves the gate gradient's per-row-group partial sums of da2 * a1
                 # and the SE kernel folds them -- no pass over the two tensors (mliis_conv2d_bwd_data_gate)
-                _, groups = self._conv_bwd_data(dout, w[nm["w_proj"]], 1, out=da2, ws=ws, gate=B["a1"], part=P.gate_part)
+                _, groups = self._conv_bwd_data(dout, w[nm["w_proj"]], 1, out=da2, ws=ws, gate=B["a1"], part=P.gate_part,
+                                                out_block=B["blk"] if B["small"] else 0)
             else:
                 self._conv_bwd_data(dout, w[nm["w_proj"]], 1, out=da2, ws=ws)
             se_outs = dict(dpre1=B["dpre1"], dpre2=B["dpre2"], chan_add=B["chan_add"])
@@ -451,7 +456,7 @@ class _Passes:
                 ops.mbconv_dw_bwd_small(da2, B["gate"], B["chan_add"], B["z1"], (st1[0], st1[1], w[p1 + "/gamma"], w[p1 + "/beta"]),
                                         w[nm["w_dw"]], B["z0"], (st0[0], st0[1], w[p0 + "/gamma"], w[p0 + "/beta"]),
                                         g[p1 + "/gamma"], g[p1 + "/beta"], g[nm["w_dw"]], g[p0 + "/gamma"], g[p0 + "/beta"], da0,
-                                        z0_blocked=B["z0b"], z1_blocked=True)
+                                        z0_blocked=B["z0b"], z1_blocked=True, da2_blocked=bool(B["blk"]))
                 wgrad_1x1(B["x_in"], da0, nm["w_exp"])
                 stage1_next = expand_bwd_data(bi, da0, nm["w_exp"], tgt, tgt_has)
                 if bi > 0:

@@ -57,8 +57,15 @@ class _Plan:
                 if not B["march"]:   # (the marching kernels apply bn0 + swish on load: a0 is never written; small-map blocks run op by op in inference)
                     B["a0"] = xbuf(N, hi, hi, ce)
             B["z1"], B["a1"], B["st1"] = xbuf(N, ho, ho, ce), xbuf(N, ho, ho, ce), vec(ce)
+            B["blk"] = 0
             if B["small"]:   # the fused small-map kernels save z0 (a copy) and z1 in their group-blocked layout for the backward launch
                 B["z0b"] = xbuf(N, hi, hi, ce)
+                # fp32 storage and both 1x1 convs beside the fused launches on the streamed plan: they WRITE the group-blocked layout
+                # themselves (z0 by the expand conv: no copy; da2 by the project conv's backward-data) -- every access of the fused
+                # launches to the expanded tensors but a1 / dz0 is then contiguous
+                if (act_dtype == torch.float32 and b.expand != 1 and ops.conv1x1_stream_eligible(N, hi, hi, b.cin, ce, L.matmul_precision)
+                        and ops.conv1x1_stream_eligible(N, ho, ho, b.cout, ce, L.matmul_precision) and 16 <= ho * ho <= 256):
+                    B["blk"] = ops.mbconv_dw_small_group_width(ce, b.k)
             B["s"], B["hpre"], B["gate"] = buf(N, ce), buf(N, b.se), buf(N, ce)
             B["z2"], B["st2"], B["out"] = buf(N, ho, ho, b.cout), vec(b.cout), buf(N, ho, ho, b.cout)
             B["dout"] = buf(N, ho, ho, b.cout)

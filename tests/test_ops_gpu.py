@@ -958,9 +958,49 @@ def test_mbconv_small_fused_fwd_bwd(k, N, H, W, C, V):
                             group_width=V, z0_blocked=z0blk, z1_blocked=True)
     for name in outs:
         assert torch.equal(outs2[name], outs[name]), "blocked layout: " + name
+    # ... and with the operands ARRIVING blocked (z0 written blocked by the expand conv: z0_blocked is z0; da2 by the project conv's
+    # backward-data): same bits again
+    blk = lambda t: t.reshape(N * H * W, C // Vb, Vb).permute(1, 0, 2).contiguous().view(N, H, W, C)   # noqa: E731
+    z0in, z1c, a1d2, sd2 = blk(z0d), torch.zeros_like(z1d), torch.zeros_like(a1d), torch.zeros_like(sd)
+    mov4 = [f32(t, d) for t in (mm0, mv0, mm1, mv1)]
+    ops.mbconv_dw_fwd_small(z0in, part, nblk, (f32(g0, d), f32(b0, d), st[0], st[1], mov4[0], mov4[1]), f32(wd, d),
+                            (f32(g1, d), f32(b1, d), st[2], st[3], mov4[2], mov4[3]), z1c, a1d2, sd2, group_width=V, z0_blocked=z0in, z1_blocked=True)
+    assert torch.equal(z1c, z1blk) and torch.equal(a1d2, a1d) and torch.equal(sd2, sd) and torch.equal(z0in, blk(z0d))
+    outs3 = {k_: torch.zeros_like(v) for k_, v in outs.items()}
+    ops.mbconv_dw_bwd_small(blk(f32(da2, d)), f32(gate, d), f32(cadd, d), z1blk, (st[2], st[3], f32(g1, d), f32(b1, d)), f32(wd, d), z0d,
+                            (st[0], st[1], f32(g0, d), f32(b0, d)), outs3["dg1"], outs3["db1"], outs3["dw"], outs3["dg0"], outs3["db0"], outs3["dz0"],
+                            group_width=V, z0_blocked=z0in, z1_blocked=True, da2_blocked=True)
+    for name in outs:
+        assert torch.equal(outs3[name], outs[name]), "blocked operands: " + name
     with pytest.raises(Exception):
         ops.mbconv_dw_fwd_small(torch.zeros(64, 14, 14, C, device=d), part, nblk, (f32(g0, d), f32(b0, d), st[0], st[1], None, None), f32(wd, d),
                                 (f32(g1, d), f32(b1, d), st[2], st[3], None, None), z1b, a1b, sb)
+
+
+@pytest.mark.parametrize("N,H,Cin,Cout,V", [(8, 14, 80, 480, 4), (8, 14, 112, 672, 4), (8, 14, 80, 480, 2), (6, 14, 112, 672, 4), (8, 16, 40, 96, 2)])
+def test_streamed_1x1_convs_write_the_group_blocked_layout(N, H, Cin, Cout, V):
+    """MLIIS_DT_BLOCKED: the streamed 1x1 conv (MBConv expand forward; project backward-data with the gate-gradient partials) writes its
+    output as [C / v][N H W][v] -- bit for bit the row-major result, permuted; statistics and gate partials unchanged.  A call the streamed
+    plan does not take refuses the layout."""
+    from mliis_amd import ops
+    d = dev()
+    assert ops.conv1x1_stream_eligible(N, H, H, Cin, Cout)
+    blk = lambda t, C_: t.reshape(N * H * H, C_ // V, V).permute(1, 0, 2).contiguous().view(N, H, H, C_)   # noqa: E731
+    x, w = f32(rnd(N, H, H, Cin, seed=1), d), f32(rnd(1, 1, Cin, Cout, seed=2, scale=0.1), d)
+    pa, pb = torch.zeros(1 << 20, device=d), torch.zeros(1 << 20, device=d)
+    y, na = ops.conv2d_fwd(x, w, None, 1, stats_part=pa)
+    yb, nb = ops.conv2d_fwd(x, w, None, 1, stats_part=pb, out=torch.full_like(y, 9.0), out_block=V)
+    assert na == nb and na > 0 and torch.equal(pa[:na * 2 * Cout], pb[:nb * 2 * Cout])
+    assert torch.equal(yb, blk(y, Cout))
+    # project backward-data: dy [.., Cin] -> da2 [.., Cout] through w2 [1,1,Cout,Cin], gate partials beside it
+    dy, w2, a1 = f32(rnd(N, H, H, Cin, seed=3), d), f32(rnd(1, 1, Cout, Cin, seed=4, scale=0.1), d), f32(rnd(N, H, H, Cout, seed=5), d)
+    ga, gb = torch.zeros(1 << 20, device=d), torch.zeros(1 << 20, device=d)
+    da, gra = ops.conv2d_bwd_data(dy, w2, 1, gate=a1, part=ga)
+    db, grb = ops.conv2d_bwd_data(dy, w2, 1, gate=a1, part=gb, out=torch.full_like(da, 9.0), out_block=V)
+    assert gra == grb and gra > 0 and torch.equal(ga[:gra * 2 * Cout], gb[:grb * 2 * Cout])
+    assert torch.equal(db, blk(da, Cout))
+    with pytest.raises(Exception):     # a long-K conv (K-split plan) cannot write it
+        ops.conv2d_fwd(f32(rnd(N, H, H, 480, seed=6), d), f32(rnd(1, 1, 480, 80, seed=7), d), None, 1, out_block=4)
 
 
 # ------------------------------------------------------------------------------------------------ data-parallel + stream-K remainder
