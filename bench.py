@@ -57,7 +57,7 @@ def parse(argv=None):
     ap.add_argument("--concurrent-tasks", type=int, default=1,
                     help="variant (with --tasks-per-gpu > 1): adapt this many tasks of the meta-batch at once on separate learners / streams")
     ap.add_argument("--tasks-per-gpu", type=int, default=1, help="variant: tasks per GPU and meta-step (the metric's config has 1)")
-    ap.add_argument("--precision", choices=["fp32", "bf16", "fp8", "bf16-storage"], default="fp32",
+    ap.add_argument("--precision", choices=["fp32", "fp32-native", "bf16", "fp8", "bf16-storage"], default="fp32",
                     help="variant: bf16 / fp8 operands on the matrix cores (fp32 accumulation, fp32 tensors); bf16-storage: bf16 operands AND the "
                          "expanded MBConv tensors as bf16 in HBM (BASELINE configs[3]); the headline metric is fp32")
     ap.add_argument("--adam", action="store_true", help="variant: Adam(beta1 = 0) inner optimizer, the reference's default when --sgd is absent (the metric's config is SGD)")

@@ -239,6 +239,28 @@ int mliis_conv2d_bwd_data_bn(const float* dy, int lddy, const float* w, float* d
 int mliis_conv2d_bwd_data_gate(const float* dy, int lddy, const float* w, float* dx, int lddx, int Nimg, int H, int W, int Cin_total,
                                int ci_begin, int Cin_out, int Cout, int ksize, int dil, float* ws, size_t ws_floats, int precision,
                                const float* gate_x, int gate_ldx, float* part, size_t part_floats, int* groups, int dy_dtype, int dx_dtype, hipStream_t stream);
+/* ---- MLIIS_PREC_F32X3 for the long-K dense convs (the RSD decoder's 3x3 / 3x3-dilated convs, models/efficientlab.py:185-190,218-224;
+ *      same products as tf.layers.conv2d in fp32): a kernel of its own whose B operand is a pre-split WEIGHT IMAGE.
+ *      mliis_x3_pack_weights splits the weights of every listed conv direction once per inner step (after the optimizer step, like
+ *      mliis_transpose_weights) into [K chunk of 32][16-column tile][term hi|mid|lo][lane group 4][column 16][8 bf16];
+ *      desc: DEVICE int64 [ndesc][8] rows {source offset in theta (floats), taps, Cin_total, Cout, ci_begin, Cin (window),
+ *      mode | first block << 8, image offset (bytes)} with mode 0 = forward (columns = Cout, K = (tap, ci of the window)) and mode 1 =
+ *      backward-data (columns = the ci window, K = (tap, co)); an image takes mliis_x3_image_bytes(Cred, Nout, ksize) bytes and
+ *      mliis_x3_image_blocks(...) workgroups of the pack launch (`first block` = running sum, total_blocks = their sum).
+ *      mliis_conv2d_fwd_x3 / mliis_conv2d_bwd_data_x3: arguments as mliis_conv2d_fwd / mliis_conv2d_bwd_data with the image in place of
+ *      wt / w (the channel window is the image's); activations are read straight from memory in matrix-core operand layout and split
+ *      in registers; 128-row tiles, two workgroups per CU, stream-K remainder with a deterministic fix-up launch (slabs in ws:
+ *      mliis_conv2d_x3_workspace_floats); *stats_nblk = the number of 128-row tiles.  Cred >= 32. */
+size_t mliis_x3_image_bytes(int Cred, int Nout, int ksize);
+int mliis_x3_image_blocks(int Cred, int Nout, int ksize);
+int mliis_x3_pack_weights(const float* theta, void* images, const long long* desc, int ndesc, int total_blocks, hipStream_t stream);
+size_t mliis_conv2d_x3_workspace_floats(int Nimg, int H, int W, int Cred, int Nout, int ksize);
+int mliis_conv2d_x3_plan(int Nimg, int H, int W, int Cred, int Nout, int ksize, int* plan);
+int mliis_conv2d_fwd_x3(const float* x, int ldx, const void* image, const float* bias, const float* border_bias, float* y, int ldy, int Nimg,
+                        int H, int W, int Cin, int Cout, int ksize, int dil, int accumulate, float* stats_part, int stats_swish,
+                        int* stats_nblk, float* ws, size_t ws_floats, hipStream_t stream);
+int mliis_conv2d_bwd_data_x3(const float* dy, int lddy, const void* image, float* dx, int lddx, int Nimg, int H, int W, int Cin_out, int Cout,
+                             int ksize, int dil, int accumulate, float* ws, size_t ws_floats, hipStream_t stream);
 size_t mliis_conv2d_bwd_filter_workspace_floats(int Nimg, int H, int W, int Cin, int Cout, int ksize);
 /*      writes rows [ci_begin, ci_begin+Cin) (per tap) of the full [k,k,Cin_total,Cout] gradient tensor dw */
 int mliis_conv2d_bwd_filter(const float* x, int ldx, const float* x_scale, const float* dy, int lddy, float* dw, int Nimg, int H, int W,

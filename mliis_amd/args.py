@@ -112,7 +112,7 @@ _EXT = [
     ("--concurrent-tasks", dict(type=int, default=1,
                                 help="adapt this many tasks of a meta-batch at once on separate learners / streams (same meta-update; "
                                      "4 is the optimum on MI355X, needs meta_batch_size / ranks >= 2 to matter)")),
-    ("--matmul-precision", dict(choices=["fp32", "bf16", "fp8", "bf16-storage"], default="fp32",
+    ("--matmul-precision", dict(choices=["fp32", "fp32-native", "bf16", "fp8", "bf16-storage"], default="fp32",
                                 help="operand precision of the matrix cores in the dense convs (bf16: fp32 tensors rounded on the fly, fp32 accumulation); "
                                      "bf16-storage: bf16 operands and the expanded MBConv tensors (z0, z1, a1, their gradients) as bf16 in HBM during "
                                      "training steps, fp32 statistics / accumulation / weights (BASELINE configs[3])")),

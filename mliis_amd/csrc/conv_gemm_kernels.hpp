@@ -102,6 +102,26 @@ __device__ __forceinline__ bf16x8 pack_bf16x8(float4 a, float4 b) {
   r[4] = (__bf16)b.x; r[5] = (__bf16)b.y; r[6] = (__bf16)b.z; r[7] = (__bf16)b.w;
   return r;
 }
+// x = hi + mid + lo with hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid) (round to nearest even, v_cvt_pk_bf16_f32): the
+// remainders are exact in fp32 and three 8-bit significands cover the 24 of an fp32 value, so the sum of the three terms IS x (finite
+// x above the bf16 underflow range; an infinity gives NaN terms).  Four values -> 4 bf16 of each term, k order kept.  (conv_x3.hip)
+__device__ __forceinline__ unsigned pk_bf16x2(float a, float b) {
+  typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+  bf16x2_ r;
+  r[0] = (__bf16)a;
+  r[1] = (__bf16)b;
+  return __builtin_bit_cast(unsigned, r);
+}
+__device__ __forceinline__ void split3(float4 v, uint2& h, uint2& m, uint2& l) {
+  h.x = pk_bf16x2(v.x, v.y);
+  h.y = pk_bf16x2(v.z, v.w);
+  const float rx = v.x - __uint_as_float(h.x << 16), ry = v.y - __uint_as_float(h.x & 0xffff0000u);
+  const float rz = v.z - __uint_as_float(h.y << 16), rw = v.w - __uint_as_float(h.y & 0xffff0000u);
+  m.x = pk_bf16x2(rx, ry);
+  m.y = pk_bf16x2(rz, rw);
+  l.x = pk_bf16x2(rx - __uint_as_float(m.x << 16), ry - __uint_as_float(m.x & 0xffff0000u));
+  l.y = pk_bf16x2(rz - __uint_as_float(m.y << 16), rw - __uint_as_float(m.y & 0xffff0000u));
+}
 constexpr unsigned kOob = 0xFFFFFFF0u;          // beyond any num_records: the load returns 0
 constexpr unsigned kBufRecords = 0x80000000u;   // host guarantees every legal byte offset is below 2 GiB
 

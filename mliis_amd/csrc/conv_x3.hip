@@ -1,0 +1,719 @@
+// fp32-EQUIVALENT dense convolutions on the bf16 matrix cores: the long-K convs of the RSD decoder (models/efficientlab.py:185-190,
+// 218-224: 3x3 and 3x3-dilated over 136..224 channels, K = 1008..2016) forward and backward-data.
+//
+// Every fp32 operand value is written EXACTLY as three bf16 terms x = hi + mid + lo (hi = bf16(x), mid = bf16(x - hi), lo = bf16(x -
+// hi - mid): 3 x 8 = 24 significand bits) and six of the nine term products (all but mid*lo, lo*mid, lo*lo: below 2^-24 |a b|) run on
+// v_mfma_f32_16x16x32_bf16 with fp32 accumulation: 6 matrix instructions of 16 cycles per 16x16x32 block instead of 8 fp32
+// instructions (v_mfma_f32_16x16x4_f32) of 32 -- 2.67x less matrix-pipe time for the same products.  With the matrix pipe that short,
+// everything else in a chunk of the fp32 kernel (conv_gemm_tile: both operands through LDS, every wave re-reading the whole B tile,
+// the split itself) became the bound (the split done inside that kernel: 120 -> 95 us, and 82 us with NO split arithmetic at all), so
+// this kernel is laid out for the split product (how each choice measured: profiles/r05_notes.md):
+//   * B (the weights) is split ONCE per inner step by x3_pack_k into an image that is already the LDS image of the kernel:
+//     [K chunk of 32][16-column tile][term 3][lane group g 4][column 16][8 bf16] = 3072 bytes per (chunk, column tile), every tap padded
+//     to whole chunks (a chunk belongs to one tap: tap offset and tap validity are scalars of the chunk).  A chunk of a workgroup's B
+//     tile is ONE contiguous run of NT x 3072 bytes: linear 16-byte loads, linear ds_write_b128, conflict-free ds_read_b128
+//     fragments, no arithmetic;
+//   * A (the activations) does not go through LDS at all: a wave owns 32 rows (two 16-row blocks) and loads its own A fragments from
+//     memory in MFMA operand layout (lane (row, g): k = 4g..4g+3 and 16+4g..16+4g+3 of the chunk: two 16-byte loads per row block,
+//     each instruction 16 rows x 64 contiguous bytes), two chunks ahead, splits them in registers BETWEEN its matrix instructions
+//     (each element is split exactly once on the chip) and multiplies them with every B fragment: 2 x NT x 6 MFMAs per 3 NT reads;
+//   * workgroup = 8 waves = 256 rows x 16 NT columns sharing the B tile, one per CU; the barrier of a chunk waits for LDS only
+//     (__syncthreads() also drains the wave's global loads: the prefetched chunks would be pinned to the chunk they are requested in);
+//   * the K iterations of the tiles that do not fill whole rounds of the chip are cut stream-K fashion into equal contiguous parts
+//     (x3_fixup_k adds a tile's segments in a fixed order, applies bias / border bias / accumulate and emits the BN statistics:
+//     deterministic).
+// Results are within the fp32 tolerances of every conv test (rel 2e-5 of max-abs forward, 1e-4 backward): error against float64
+// 0.6-1.5e-6 of max-abs, against 1.4-2.0e-6 for the native fp32 instruction (tools/x3_probe.py) -- the 16x16x32 instruction adds its 32
+// products in one pass, the fp32 path rounds after each of its eight 16x16x4 steps.
+#include "conv_gemm_kernels.hpp"
+
+namespace mliis {
+
+constexpr int kX3Block = 3072;   // bytes of one (chunk, 16-column tile) block of a weight image
+constexpr int kX3BM = 256;       // rows of a workgroup tile (eight waves of 32)
+
+// ------------------------------------------------------------------------------------------------ weight images
+// desc rows (int64 [ndesc][8]): {source offset (floats) in `theta`, taps, Cin_total, Cout, ci_begin, Cin (window), mode | first block
+// << 8, image offset (bytes)}.  mode 0 (forward): B[n = co][k = tap * Cin + c] = w[tap][ci_begin + c][co];  mode 1 (backward-data):
+// B[n = ci - ci_begin][k = tap * Cout + co] = w[tap][ci][co].  One workgroup (128 threads) per (chunk, 16-column tile) block.
+constexpr int kX3DescWords = 8;
+__global__ __launch_bounds__(128) void x3_pack_k(const float* __restrict__ theta, char* __restrict__ images, const long long* __restrict__ desc,
+                                                  int ndesc) {
+  const int b = blockIdx.x;
+  int j = 0;
+  for (int k = 1; k < ndesc; ++k)
+    if (b >= (int)(desc[k * kX3DescWords + 6] >> 8)) j = k;
+  const long long* d = desc + (long long)j * kX3DescWords;
+  const float* w = theta + d[0];
+  const int taps = (int)d[1], cin_total = (int)d[2], cout = (int)d[3], ci_begin = (int)d[4], cin = (int)d[5], mode = (int)(d[6] & 0xff);
+  const int local = b - (int)(d[6] >> 8);
+  const int nn = mode == 0 ? cout : cin, kc = mode == 0 ? cin : cout;   // columns of B, K per tap
+  const int ncol16 = (nn + 15) / 16;
+  const int chunk = local / ncol16, c16 = local - chunk * ncol16;
+  const int t = threadIdx.x, nl = t & 15, kq = t >> 4;   // column of the tile, k quad 0..7 of the chunk
+  const int n = c16 * 16 + nl;
+  const int cpt = (kc + 31) / 32;                    // chunks per tap: a chunk never straddles a tap (the last one of a tap is zero-padded)
+  const int tap = chunk / cpt, c = (chunk - tap * cpt) * 32 + kq * 4;
+  float4 v = f4zero();
+  if (n < nn && c < kc) {
+    if (mode == 0) {
+      const float* s = w + ((long long)tap * cin_total + ci_begin + c) * cout + n;
+      v = make_float4(s[0], s[cout], s[2 * (long long)cout], s[3 * (long long)cout]);
+    } else {
+      v = ld4(w + ((long long)tap * cin_total + ci_begin + n) * cout + c);
+    }
+  }
+  uint2 h, m, l;
+  split3(v, h, m, l);
+  // lane group g = kq & 3 holds k = 4g..4g+3 (elements 0..3) and 16 + 4g..16 + 4g + 3 (elements 4..7) of the chunk
+  char* dst = images + d[7] + (long long)local * kX3Block + (kq & 3) * 256 + nl * 16 + (kq >> 2) * 8;
+  *reinterpret_cast<uint2*>(dst) = h;
+  *reinterpret_cast<uint2*>(dst + 1024) = m;
+  *reinterpret_cast<uint2*>(dst + 2048) = l;
+}
+
+// ------------------------------------------------------------------------------------------------ the tile
+struct X3Params {
+  ConvGemmParams g;      // A, lda, Nimg, H, W, C (K per tap), ntaps, dil, sign, Nout, Cmat, ldc, bias, accumulate, stats_part, stats_swish,
+                         // border_bias as in conv_gemm_tile; B / ldb / b_tap_stride are not used
+  const char* image;     // weight image of this conv and direction (x3_pack_k)
+  int ncol16;            // its 16-column tiles
+#ifdef X3_CLK
+  unsigned long long* dbg;   // [workgroups][4]: {shader clock, 100 MHz clock} at the start and the end of the first segment's main loop
+#endif
+};
+
+// Workgroup barrier that orders LDS traffic only: __syncthreads() carries a fence that drains EVERY outstanding global load of the wave
+// (s_waitcnt vmcnt(0)), which would pin the loads of the next chunks -- requested so that they land a chunk or two later -- to the
+// chunk they are requested in.  Here only the wave's LDS operations are waited for; gfx950 backs a barrier off under pending memory
+// operations, so no wider wait is needed (MI355X_MICROARCH.md: "barriers do not drain VMEM").
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int NT>
+struct X3Sm {
+  static constexpr int BN = 16 * NT;
+  static constexpr int B_BYTES = NT * kX3Block;
+  static constexpr int LDS_STAGE = BN + 4;                       // epilogue staging row stride (floats)
+  static constexpr int STAGE_BYTES = 4 * 16 * LDS_STAGE * 4;     // one 16-row staging tile per wave
+  static constexpr int BYTES = (2 * B_BYTES > STAGE_BYTES ? 2 * B_BYTES : STAGE_BYTES) + 64;
+};
+
+// One output tile (256-row tile bx, column tile by) over the K chunks [it0, it1).  pdst == nullptr: finished tile (bias, border bias,
+// accumulate, staged row stores, BN statistics); else the raw partial tile to pdst[row * BN + column] (a stream-K segment slab).
+// Wave w of the eight owns rows 32 w .. 32 w + 31 of the tile.
+template <int NT>
+__device__ __forceinline__ void conv_x3_tile(const X3Params& q, char* __restrict__ sm, unsigned bx, int by, int it0, int it1,
+                                             float* __restrict__ pdst) {
+  constexpr int BN = 16 * NT;
+  constexpr int B_BYTES = X3Sm<NT>::B_BYTES;
+  constexpr int NB = (NT * 192 + 511) / 512;   // 16-byte pieces of a B chunk per thread
+  constexpr int LDS_STAGE = X3Sm<NT>::LDS_STAGE;
+  const ConvGemmParams& p = q.g;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int grp = wave >> 2, wv = wave & 3;   // (the epilogue stages the two halves of the tile one after the other)
+  const int l15 = lane & 15, g = lane >> 4;
+  const long long M = (long long)p.Nimg * p.H * p.W;
+  const long long m0 = (long long)bx * kX3BM;
+  const int n0 = by * BN;
+  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, kBufRecords, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)q.image, 0, kBufRecords, 0x00020000);
+
+  // ---- this lane's two rows (row blocks rb = 0, 1 of the wave's 32 rows): byte offset of the row's k quads and the 9-bit mask of the
+  // taps whose source pixel lies inside the image (a K chunk belongs to ONE tap -- the image pads every tap to whole chunks -- so the
+  // tap offset, the channel offset and the tap bit are scalars of the chunk)
+  const int wrow = grp * 128 + wv * 32;   // first row of this wave inside the tile
+  unsigned a_off[2][2], a_taps[2];
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb) {
+    const long long m = m0 + wrow + rb * 16 + l15;
+    a_taps[rb] = 0;
+    a_off[rb][0] = a_off[rb][1] = 0;
+    if (m < M) {
+      a_off[rb][0] = (unsigned)((m * p.lda + g * 4) * 4);
+      a_off[rb][1] = a_off[rb][0] + 64u;
+      if (p.ntaps > 1) {
+        const int HWp = p.H * p.W;
+        const int n = (int)(m / HWp);
+        const int rem = (int)(m - (long long)n * HWp);
+        const int h = rem / p.W, w_ = rem - h * p.W;
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp) {
+          const int dh = (tp / 3 - 1) * p.dil * p.sign, dw = (tp % 3 - 1) * p.dil * p.sign;
+          if ((unsigned)(h + dh) < (unsigned)p.H && (unsigned)(w_ + dw) < (unsigned)p.W) a_taps[rb] |= 1u << tp;
+        }
+      } else {
+        a_taps[rb] = 1u;
+      }
+    }
+  }
+  const int klane = g * 4;   // first channel of this lane's quad 0 inside a chunk (quad 1: + 16)
+  // ---- the next A chunk to LOAD: tap s_tap, first channel s_c0; the next B chunk to load: byte offset s_boff (uniform per wave; past
+  // the last chunk of the range the SAME chunk is requested again -- cache hits, never used -- so the hot path has no predicate)
+  const int cpt = (p.C + 31) / 32;
+  int s_tap = it0 / cpt, s_c0 = (it0 - s_tap * cpt) * 32;
+  int s_aleft = it1 - it0, s_bleft = it1 - it0;
+  int ncol_here = q.ncol16 - by * NT;
+  if (ncol_here > NT) ncol_here = NT;
+  const unsigned b_lim = (unsigned)ncol_here * 192u;   // 16-byte pieces of a chunk present in the image (beyond: zeros)
+  const unsigned b_step = (unsigned)q.ncol16 * kX3Block;
+  unsigned b_voff[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) b_voff[i] = ((unsigned)t + 512u * i < b_lim) ? (unsigned)(by * NT) * kX3Block + ((unsigned)t + 512u * i) * 16u : kOob;
+  unsigned s_boff = (unsigned)it0 * b_step;
+
+  float4 ra[2][2];    // [row block][quad]: the next A chunk, fp32
+  float4 ra2[2][2];   // the A chunk after that
+  u32x4 rbv[NB];      // this thread's pieces of the next B chunk
+  auto load_a_into = [&](float4 (&ra)[2][2]) {
+    const int th = p.ntaps > 1 ? s_tap / 3 : 1, tw = p.ntaps > 1 ? s_tap - th * 3 : 1;
+    const int dh = (th - 1) * p.dil * p.sign, dw = (tw - 1) * p.dil * p.sign;
+    const unsigned s_aoff = (unsigned)(((dh * p.W + dw) * p.lda + s_c0) * 4);   // (two's complement: the sum with a row's offset is exact)
+    const unsigned tapbit = 1u << s_tap;
+    const int cleft = p.C - s_c0;
+#pragma unroll
+    for (int qd = 0; qd < 2; ++qd) {
+      const bool cok = klane + 16 * qd < cleft;
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) {
+        ra[rb][qd] = buf_ld4(rA, (cok & ((a_taps[rb] & tapbit) != 0)) ? a_off[rb][qd] + s_aoff : kOob);
+      }
+    }
+    const int adv = s_aleft > 1 ? 1 : 0;   // (branch-free advance)
+    s_aleft -= adv;
+    const int c_next = s_c0 + 32;
+    const int wrap = c_next >= p.C ? 1 : 0;
+    s_c0 = adv ? (wrap ? 0 : c_next) : s_c0;
+    s_tap += adv & wrap;
+  };
+  auto load_b = [&]() {
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      rbv[i] = __builtin_amdgcn_raw_buffer_load_b128(rB, (int)b_voff[i], (int)s_boff, 0);
+    }
+    const int adv = s_bleft > 1 ? 1 : 0;
+    s_bleft -= adv;
+    s_boff += adv ? b_step : 0u;
+  };
+  auto store_b = [&](char* buf) {
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int idx = t + 512 * i;
+      char* d = (512 * (i + 1) <= NT * 192 || idx < NT * 192) ? buf + idx * 16 : sm + 2 * B_BYTES + (t & 3) * 16;   // surplus lanes: scratch
+      *reinterpret_cast<u32x4*>(d) = rbv[i];
+    }
+  };
+  bf16x8 a3[3][2], a3n[3][2];
+  auto split_into = [&](const float4 (&ra)[2][2], bf16x8 (&a3)[3][2]) {
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      uint2 h0, m0_, l0, h1, m1, l1;
+      split3(ra[rb][0], h0, m0_, l0);
+      split3(ra[rb][1], h1, m1, l1);
+      a3[0][rb] = __builtin_bit_cast(bf16x8, (u32x4){h0.x, h0.y, h1.x, h1.y});
+      a3[1][rb] = __builtin_bit_cast(bf16x8, (u32x4){m0_.x, m0_.y, m1.x, m1.y});
+      a3[2][rb] = __builtin_bit_cast(bf16x8, (u32x4){l0.x, l0.y, l1.x, l1.y});
+    }
+  };
+  f32x4 acc[2][NT];
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[rb][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // One chunk's products out of LDS buffer `buf` and the registers a3; the fragments of column tile jn + 1 are requested before the
+  // products of tile jn.  The split of the A chunk multiplied NEXT (rs -> a3n) is cut into its four 16-byte pieces and each piece is
+  // placed behind the twelve matrix instructions of one column tile, fenced, so that the vector work is spread over the chunk
+  // instead of following it (a matrix instruction leaves the SIMD's vector issue free for half of its 16 cycles, and the partner
+  // wave's matrix instructions fill the pipe meanwhile)
+  auto compute_split = [&](const char* buf, const float4 (&rs)[2][2]) {
+    const char* pb = buf + g * 256 + l15 * 16;
+    bf16x8 b3[2][3];
+    uint2 sh[2][2], sm_[2][2], sl[2][2];
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) b3[0][pl] = *reinterpret_cast<const bf16x8*>(pb + pl * 1024);
+#pragma unroll
+    for (int jn = 0; jn < NT; ++jn) {
+      if (jn + 1 < NT) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) b3[(jn + 1) & 1][pl] = *reinterpret_cast<const bf16x8*>(pb + (jn + 1) * kX3Block + pl * 1024);
+      }
+#define X3_MM(PA, PB)                                                                                                 \
+  acc[0][jn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3[PA][0], b3[jn & 1][PB], acc[0][jn], 0, 0, 0);             \
+  acc[1][jn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3[PA][1], b3[jn & 1][PB], acc[1][jn], 0, 0, 0);
+      X3_MM(2, 0) X3_MM(0, 2) X3_MM(1, 1) X3_MM(1, 0) X3_MM(0, 1) X3_MM(0, 0)
+#undef X3_MM
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if ((k * NT) / 4 == jn) {
+          uint2& h = sh[k >> 1][k & 1];
+          uint2& m = sm_[k >> 1][k & 1];
+          uint2& l = sl[k >> 1][k & 1];
+          split3(rs[k >> 1][k & 1], h, m, l);
+          // (an empty statement that "uses" the piece here: without it the optimiser sinks the arithmetic to the first real use, the
+          // assembly of a3n behind the last matrix instruction)
+          asm volatile("" : "+v"(h.x), "+v"(h.y), "+v"(m.x), "+v"(m.y), "+v"(l.x), "+v"(l.y));
+        }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      a3n[0][rb] = __builtin_bit_cast(bf16x8, (u32x4){sh[rb][0].x, sh[rb][0].y, sh[rb][1].x, sh[rb][1].y});
+      a3n[1][rb] = __builtin_bit_cast(bf16x8, (u32x4){sm_[rb][0].x, sm_[rb][0].y, sm_[rb][1].x, sm_[rb][1].y});
+      a3n[2][rb] = __builtin_bit_cast(bf16x8, (u32x4){sl[rb][0].x, sl[rb][0].y, sl[rb][1].x, sl[rb][1].y});
+    }
+  };
+#ifdef X3_CLK
+  const unsigned long long ck0 = __builtin_amdgcn_s_memtime(), cr0 = __builtin_amdgcn_s_memrealtime();
+  unsigned long long c_comp = 0, c_skel = 0, c_bar = 0, c_t = ck0;
+#define X3_TICK(acc_) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); acc_ += n_ - c_t; c_t = n_; } while (0)
+#else
+#define X3_TICK(acc_) do { } while (0)
+#endif
+  // ---- main loop: every wave multiplies chunk j and, between its own matrix instructions, splits the A chunk it multiplies next; the
+  // A chunk after that and the B chunk after next are in flight meanwhile (requested a whole chunk before their first use)
+  const int nper = it1 - it0;
+  load_a_into(ra);     // A(it0)
+  load_b();            // B(it0)
+  store_b(sm);
+  load_b();            // B(it0 + 1)
+  split_into(ra, a3);
+  load_a_into(ra);     // A(it0 + 1)
+  load_a_into(ra2);    // A(it0 + 2)
+  lds_barrier();
+  auto chunk = [&](char* cur, char* nxt, float4 (&rs)[2][2]) {   // rs: the registers holding A of the chunk after this one
+    compute_split(cur, rs);
+    X3_TICK(c_comp);
+    store_b(nxt);        // B of the next chunk (requested one chunk ago)
+    load_b();            // B of the chunk after next
+    load_a_into(rs);     // A two chunks after the one just split
+    X3_TICK(c_skel);
+    lds_barrier();
+    X3_TICK(c_bar);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) a3[pl][rb] = a3n[pl][rb];
+  };
+  {
+    int it = 0;
+    for (; it + 2 <= nper; it += 2) {
+      chunk(sm, sm + B_BYTES, ra);
+      chunk(sm + B_BYTES, sm, ra2);
+    }
+    if (it < nper) chunk(sm, sm + B_BYTES, ra);
+  }
+#ifdef X3_CLK
+  if (q.dbg != nullptr && lane == 0 && (wave & 3) == 0) {
+    unsigned long long* d = q.dbg + ((long long)blockIdx.x * 2 + grp) * 8;
+    if (d[0] == 0) {
+      d[0] = ck0;
+      d[1] = cr0;
+      d[2] = __builtin_amdgcn_s_memtime();
+      d[3] = __builtin_amdgcn_s_memrealtime();
+      d[4] = c_comp;
+      d[5] = c_skel;
+      d[6] = c_bar;
+      d[7] = nper;
+    }
+  }
+#endif
+  // ---- epilogue: C/D layout: col = lane & 15, row = 4 * (lane >> 4) + reg
+  if (pdst != nullptr) {
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = wrow + rb * 16 + g * 4 + r;
+        if (m0 + row >= M) continue;
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          if (n0 + j * 16 + l15 < p.Nout) pdst[(long long)row * BN + j * 16 + l15] = acc[rb][j][r];
+      }
+    return;
+  }
+  float* stage = reinterpret_cast<float*>(sm) + wv * 16 * LDS_STAGE;   // (the two groups stage one after the other)
+  float bj[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int n = n0 + j * 16 + l15;
+    bj[j] = (p.bias != nullptr && n < p.Nout) ? p.bias[n] : 0.f;
+  }
+  const long long HWp = (long long)p.H * p.W;
+  for (int e = 0; e < 2; ++e) {
+    if (grp == e) {
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) {
+        const long long mbase = m0 + wrow + rb * 16;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float* bb = nullptr;
+          if (p.border_bias != nullptr) {
+            const long long m = mbase + g * 4 + r;
+            if (m < M) {
+              const int ni = (int)(m / HWp);
+              const int rem = (int)(m - (long long)ni * HWp);
+              const int h = rem / p.W, w_ = rem - h * p.W;
+              const int cls = (h == 0 ? 0 : (h == p.H - 1 ? 2 : 1)) * 3 + (w_ == 0 ? 0 : (w_ == p.W - 1 ? 2 : 1));
+              bb = p.border_bias + ((long long)ni * 9 + cls) * p.Nout;
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            const int n = n0 + j * 16 + l15;
+            float v = acc[rb][j][r] + bj[j];
+            if (bb != nullptr && n < p.Nout) v += bb[n];
+            acc[rb][j][r] = v;
+            stage[(g * 4 + r) * LDS_STAGE + j * 16 + l15] = v;
+          }
+        }
+        // (the staging tile is this wave's own: LDS is in order within a wave, no barrier)
+#pragma unroll
+        for (int itq = 0; itq < NT; ++itq) {
+          const int idx = itq * 64 + lane;
+          const int row = idx / (BN / 4), qq = idx - row * (BN / 4);
+          const long long m = mbase + row;
+          const int n = n0 + qq * 4;
+          if (m < M && n < p.Nout) {
+            float4 v = ld4(stage + row * LDS_STAGE + qq * 4);
+            float* dst = p.Cmat + m * p.ldc + n;
+            if (p.accumulate) v = f4add(v, ld4(dst));
+            st4(dst, v);
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (p.stats_part == nullptr) return;
+  float s1[NT], s2[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) s1[j] = s2[j] = 0.f;
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const long long m = m0 + wrow + rb * 16 + g * 4 + r;
+      if (m >= M) continue;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const float v = acc[rb][j][r];
+        const float u = p.stats_swish ? swish_f(v) : v;
+        s1[j] += u;
+        s2[j] = fmaf(u, u, s2[j]);
+      }
+    }
+  float* red = reinterpret_cast<float*>(sm);   // [wave 8][2][BN]
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    float a = s1[j], b = s2[j];
+    a += __shfl_xor(a, 16, 64);
+    b += __shfl_xor(b, 16, 64);
+    a += __shfl_xor(a, 32, 64);
+    b += __shfl_xor(b, 32, 64);
+    if (g == 0) {
+      red[(wave * 2 + 0) * BN + j * 16 + l15] = a;
+      red[(wave * 2 + 1) * BN + j * 16 + l15] = b;
+    }
+  }
+  __syncthreads();
+  for (int idx = t; idx < 2 * BN; idx += 512) {
+    const int v = idx / BN, col = idx - v * BN;
+    const int n = n0 + col;
+    if (n < p.Nout) {
+      float r0 = red[(0 * 2 + v) * BN + col];
+#pragma unroll
+      for (int wq = 1; wq < 8; ++wq) r0 += red[(wq * 2 + v) * BN + col];   // (wave order: deterministic)
+      p.stats_part[((long long)bx * 2 + v) * p.Nout + n] = r0;
+    }
+  }
+}
+
+// workgroups [0, full): whole tiles; [full, full + parts): equal contiguous ranges of the remaining tiles' K iterations (SkPlan as in
+// conv_gemm_sk_k, with 256-row tiles: slab [rem][smax][256][BN]); one 512-thread workgroup per CU
+template <int NT>
+__global__ __launch_bounds__(512) void conv_x3_k(X3Params q, SkPlan k) {
+  __shared__ __attribute__((aligned(16))) char sm[X3Sm<NT>::BYTES];
+  constexpr int BN = 16 * NT;
+  const int w = blockIdx.x;
+  if (w < k.full) {
+    const unsigned tau = xcd_remap(w, k.full);
+    conv_x3_tile<NT>(q, sm, tau / k.gy, tau % k.gy, 0, k.nchunks, nullptr);
+    return;
+  }
+  const int part = w - k.full;
+  int lo = part * k.ipp;
+  const int total = k.rem * k.nchunks;
+  int hi = lo + k.ipp;
+  if (hi > total) hi = total;
+#pragma unroll 1
+  while (lo < hi) {
+    const int rt = lo / k.nchunks, c0 = lo - rt * k.nchunks;
+    int c1 = c0 + (hi - lo);
+    if (c1 > k.nchunks) c1 = k.nchunks;
+    const int first = (rt * k.nchunks) / k.ipp;   // first part that touches this tile -> slot 0
+    const unsigned tau = k.full + rt;
+    float* dst = k.slab + ((long long)rt * k.smax + (part - first)) * (kX3BM * BN);
+    conv_x3_tile<NT>(q, sm, tau / k.gy, tau % k.gy, c0, c1, dst);
+    lo += c1 - c0;
+    __syncthreads();   // the next segment reuses the LDS buffers
+  }
+}
+
+// Finishes the stream-K tiles: grid = (rem); 1024 threads = 32 column-quad slots x 32 row lanes, eight rows per thread.
+template <int NT>
+__global__ __launch_bounds__(1024) void x3_fixup_k(ConvGemmParams p, SkPlan k) {
+  constexpr int BN = 16 * NT, QN = BN / 4, RPT = kX3BM / 32;
+  __shared__ float4 red[2][32][32];
+  const int t = threadIdx.x, q = t & 31, rl = t >> 5;
+  const int rt = blockIdx.x;
+  const unsigned tau = k.full + rt;
+  const int bx = tau / k.gy, by = tau % k.gy;
+  const long long M = (long long)p.Nimg * p.H * p.W;
+  const long long m0 = (long long)bx * kX3BM;
+  const int n = by * BN + q * 4;
+  const bool cok = q < QN && n < p.Nout;
+  const int first = (rt * k.nchunks) / k.ipp;
+  int last = ((rt + 1) * k.nchunks - 1) / k.ipp;
+  if (last > k.parts - 1) last = k.parts - 1;
+  const int nslots = last - first + 1;
+  const float* base = k.slab + (long long)rt * k.smax * (kX3BM * BN) + q * 4;
+  float4 s1 = f4zero(), s2 = f4zero();
+  if (cok) {
+    const float4 bv = p.bias != nullptr ? ld4(p.bias + n) : f4zero();
+    const long long HWp = (long long)p.H * p.W;
+    float4 v[RPT];
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) v[i] = (m0 + rl + 32 * i < M) ? ld4(base + (long long)(rl + 32 * i) * BN) : f4zero();
+    for (int z = 1; z < nslots; ++z) {
+      float4 u[RPT];
+#pragma unroll
+      for (int i = 0; i < RPT; ++i) u[i] = (m0 + rl + 32 * i < M) ? ld4(base + ((long long)z * kX3BM + rl + 32 * i) * BN) : f4zero();
+#pragma unroll
+      for (int i = 0; i < RPT; ++i) v[i] = f4add(v[i], u[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+      const long long m = m0 + rl + 32 * i;
+      if (m >= M) continue;
+      float4 o = f4add(v[i], bv);
+      if (p.border_bias != nullptr) {
+        const int ni = (int)(m / HWp);
+        const int rem = (int)(m - (long long)ni * HWp);
+        const int h = rem / p.W, w_ = rem - h * p.W;
+        const int cls = (h == 0 ? 0 : (h == p.H - 1 ? 2 : 1)) * 3 + (w_ == 0 ? 0 : (w_ == p.W - 1 ? 2 : 1));
+        o = f4add(o, ld4(p.border_bias + ((long long)ni * 9 + cls) * p.Nout + n));
+      }
+      float* dst = p.Cmat + m * p.ldc + n;
+      if (p.accumulate) o = f4add(o, ld4(dst));
+      st4(dst, o);
+      if (p.stats_swish) o = make_float4(swish_f(o.x), swish_f(o.y), swish_f(o.z), swish_f(o.w));
+      s1 = f4add(s1, o);
+      s2 = f4fma(o, o, s2);
+    }
+  }
+  if (p.stats_part == nullptr) return;
+  red[0][rl][q] = s1;
+  red[1][rl][q] = s2;
+  __syncthreads();
+  if (t < 64) {
+    const int v = t >> 5, qq = t & 31;
+    const int nn = by * BN + qq * 4;
+    if (qq < QN && nn < p.Nout) {
+      float4 a = red[v][0][qq];
+#pragma unroll 8
+      for (int r = 1; r < 32; ++r) a = f4add(a, red[v][r][qq]);
+      st4(p.stats_part + ((long long)bx * 2 + v) * p.Nout + nn, a);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+struct X3Plan {
+  int nt, gx, gy, nchunks;
+  int full, rem, parts, ipp, smax;
+  size_t slab_floats() const { return (size_t)rem * smax * kX3BM * (16 * nt); }
+};
+constexpr int kX3MinPart = 4;   // K chunks per stream-K part, at least
+
+static int x3_pick_nt(int Nout) {   // the widest column tile that does not pad the output width by much (as conv_gemm.hip: pick_nt)
+  int best = 1;
+  double best_cost = 1e30;
+  const int tiles = (Nout + 15) / 16;
+  for (int nt = 1; nt <= 8; ++nt) {
+    const int blocks = (tiles + nt - 1) / nt;
+    const double cost = (double)(blocks * nt * 16) / (double)Nout * (1.0 + 0.03 * (8 - nt));
+    if (cost < best_cost - 1e-9 || (cost < best_cost + 1e-9 && nt > best)) {
+      best_cost = cost;
+      best = nt;
+    }
+  }
+  return best;
+}
+
+static inline int x3_chunks(int ntaps, int Cred) { return ntaps * ((Cred + 31) / 32); }   // every tap padded to whole chunks of 32
+static X3Plan x3_plan(long long M, int Nout, int ntaps, int Cred, int num_cus) {
+  X3Plan g;
+  g.nt = x3_pick_nt(Nout);
+  g.gy = (Nout + g.nt * 16 - 1) / (g.nt * 16);
+  g.gx = (int)((M + kX3BM - 1) / kX3BM);
+  g.nchunks = x3_chunks(ntaps, Cred);
+  const int slots = num_cus;   // one 512-thread workgroup per CU
+  // small maps (the 14x14 level: 13 row tiles): narrower column tiles until the K iterations can be dealt over the chip
+  while (g.nt > 2 && (long long)g.gx * g.gy * g.nchunks < (long long)slots * 2 * kX3MinPart) {
+    g.nt = (g.nt + 1) / 2;
+    g.gy = (Nout + g.nt * 16 - 1) / (g.nt * 16);
+  }
+  const long long tiles = (long long)g.gx * g.gy;
+  g.full = (int)(tiles / slots) * slots;
+  g.rem = (int)(tiles - g.full);
+  g.parts = g.ipp = g.smax = 0;
+  if (g.rem > 0) {
+    const long long total = (long long)g.rem * g.nchunks;
+    long long parts = slots;
+    if (parts > 8LL * g.rem) parts = 8LL * g.rem;
+    if (parts < g.rem) parts = g.rem;
+    if (total / parts < kX3MinPart) parts = total / kX3MinPart;
+    if (parts < g.rem) parts = g.rem;   // (at most two segments per part)
+    g.ipp = (int)((total + parts - 1) / parts);
+    g.parts = (int)((total + g.ipp - 1) / g.ipp);
+    g.smax = (g.nchunks + g.ipp - 1) / g.ipp + 1;
+  }
+  return g;
+}
+
+static int g_x3_cus = 0;
+static int x3_num_cus() {
+  if (g_x3_cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    g_x3_cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                   ? prop.multiProcessorCount
+                   : 256;
+  }
+  return g_x3_cus;
+}
+
+static void x3_launch(const X3Plan& g, const X3Params& q_, float* slab, hipStream_t stream) {
+  X3Params q = q_;
+#ifdef X3_CLK
+  q.dbg = getenv("MLIIS_X3_STAMPS") ? (unsigned long long*)strtoull(getenv("MLIIS_X3_STAMPS"), nullptr, 0) : nullptr;
+#endif
+  const SkPlan k{g.full, g.rem, g.parts, g.ipp, g.nchunks, g.smax, g.gy, slab};
+  dim3 grid(g.full + g.parts), block(512);
+#define L(NT_)                                                                                  \
+  hipLaunchKernelGGL((conv_x3_k<NT_>), grid, block, 0, stream, q, k);                           \
+  if (g.rem > 0) hipLaunchKernelGGL((x3_fixup_k<NT_>), dim3(g.rem), dim3(1024), 0, stream, q.g, k); \
+  break;
+  switch (g.nt) {
+    case 1: L(1)
+    case 2: L(2)
+    case 3: L(3)
+    case 4: L(4)
+    case 5: L(5)
+    case 6: L(6)
+    case 7: L(7)
+    default: L(8)
+  }
+#undef L
+}
+
+static int x3_shape_check(const char* name, int Nimg, int H, int W, int Cred, int Nout, int ksize, int dil) {
+  MLIIS_REQUIRE(Nimg > 0 && H > 0 && W > 0 && Cred >= 32 && Nout > 0, MLIIS_ERR_ARG, "%s: bad shape (the reduced channel count must be >= 32)", name);
+  MLIIS_REQUIRE((Cred & 3) == 0 && (Nout & 3) == 0, MLIIS_ERR_ARG, "%s: channel counts must be multiples of 4", name);
+  MLIIS_REQUIRE(ksize == 1 || ksize == 3, MLIIS_ERR_UNSUPPORTED, "%s: kernel size %d unsupported (1 or 3)", name, ksize);
+  MLIIS_REQUIRE(dil >= 1, MLIIS_ERR_ARG, "%s: dilation must be >= 1", name);
+  return MLIIS_OK;
+}
+
+}  // namespace mliis
+
+using namespace mliis;
+
+extern "C" {
+
+// bytes of the weight image of a conv direction that reduces over Cred channels per tap and produces Nout columns
+size_t mliis_x3_image_bytes(int Cred, int Nout, int ksize) {
+  return (size_t)x3_chunks(ksize * ksize, Cred) * ((Nout + 15) / 16) * kX3Block;
+}
+
+// blocks of x3_pack_k for that image (the `first block` column of the descriptor table is the running sum of these)
+int mliis_x3_image_blocks(int Cred, int Nout, int ksize) { return x3_chunks(ksize * ksize, Cred) * ((Nout + 15) / 16); }
+
+int mliis_x3_pack_weights(const float* theta, void* images, const long long* desc, int ndesc, int total_blocks, hipStream_t stream) {
+  MLIIS_REQUIRE(theta && images && desc && ndesc >= 1 && ndesc <= 64 && total_blocks >= 1, MLIIS_ERR_ARG, "x3_pack_weights: bad arguments");
+  MLIIS_REQUIRE(aligned16(theta) && aligned16(images) && aligned16(desc), MLIIS_ERR_ALIGN, "x3_pack_weights: pointers must be 16-byte aligned");
+  hipLaunchKernelGGL(x3_pack_k, dim3(total_blocks), dim3(128), 0, stream, theta, reinterpret_cast<char*>(images), desc, ndesc);
+  MLIIS_CHECK_LAUNCH("x3_pack_weights");
+  return MLIIS_OK;
+}
+
+size_t mliis_conv2d_x3_workspace_floats(int Nimg, int H, int W, int Cred, int Nout, int ksize) {
+  return x3_plan((long long)Nimg * H * W, Nout, ksize * ksize, Cred, x3_num_cus()).slab_floats();
+}
+
+// tiling of an x3 call: plan[0..5] = {column tiles NT, row tiles, column tiles per row, whole-tile workgroups, stream-K parts, K chunks per part}
+int mliis_conv2d_x3_plan(int Nimg, int H, int W, int Cred, int Nout, int ksize, int* plan) {
+  MLIIS_REQUIRE(plan, MLIIS_ERR_ARG, "conv2d_x3_plan: null pointer");
+  const X3Plan g = x3_plan((long long)Nimg * H * W, Nout, ksize * ksize, Cred, x3_num_cus());
+  plan[0] = g.nt; plan[1] = g.gx; plan[2] = g.gy; plan[3] = g.full; plan[4] = g.parts; plan[5] = g.ipp;
+  return MLIIS_OK;
+}
+
+// y[M, Cout] (ld = ldy) (+)= conv(x[M, Cin] (ld = ldx), w) + bias (+ border_bias), stride 1, TF-SAME, dilation dil, the weights as the
+// mode-0 image of mliis_x3_pack_weights over the same Cin window.  stats_part / stats_swish / stats_nblk as mliis_conv2d_fwd
+// (*stats_nblk = the number of 128-row tiles).  ws: stream-K slabs (mliis_conv2d_x3_workspace_floats).
+int mliis_conv2d_fwd_x3(const float* x, int ldx, const void* image, const float* bias, const float* border_bias, float* y, int ldy, int Nimg,
+                        int H, int W, int Cin, int Cout, int ksize, int dil, int accumulate, float* stats_part, int stats_swish,
+                        int* stats_nblk, float* ws, size_t ws_floats, hipStream_t stream) {
+  int rc = x3_shape_check("conv2d_fwd_x3", Nimg, H, W, Cin, Cout, ksize, dil);
+  if (rc) return rc;
+  MLIIS_REQUIRE(x && image && y, MLIIS_ERR_ARG, "conv2d_fwd_x3: null pointer");
+  MLIIS_REQUIRE((ldx & 3) == 0 && ldx >= Cin && (ldy & 3) == 0 && ldy >= Cout, MLIIS_ERR_ARG, "conv2d_fwd_x3: bad leading dimensions");
+  MLIIS_REQUIRE(aligned16(x) && aligned16(image) && aligned16(bias) && aligned16(y) && aligned16(border_bias) && aligned16(ws), MLIIS_ERR_ALIGN,
+                "conv2d_fwd_x3: pointers must be 16-byte aligned");
+  const long long M = (long long)Nimg * H * W;
+  MLIIS_REQUIRE(M * ldx * 4 < (1LL << 31) && mliis_x3_image_bytes(Cin, Cout, ksize) < (1ULL << 31), MLIIS_ERR_UNSUPPORTED,
+                "conv2d_fwd_x3: operand larger than 2 GiB (32-bit buffer offsets)");
+  MLIIS_REQUIRE(border_bias == nullptr || (ksize == 3 && dil == 1 && H >= 2 && W >= 2), MLIIS_ERR_ARG,
+                "conv2d_fwd_x3: border_bias needs a 3x3 dilation-1 conv on a map of at least 2x2");
+  MLIIS_REQUIRE(stats_part == nullptr || (!accumulate && stats_nblk), MLIIS_ERR_ARG,
+                "conv2d_fwd_x3: fused statistics need accumulate == 0 and a stats_nblk output");
+  const X3Plan g = x3_plan(M, Cout, ksize * ksize, Cin, x3_num_cus());
+  MLIIS_REQUIRE(g.slab_floats() == 0 || (ws != nullptr && g.slab_floats() <= ws_floats), MLIIS_ERR_WORKSPACE,
+                "conv2d_fwd_x3: workspace too small (%zu needed, %zu given)", g.slab_floats(), ws_floats);
+  X3Params q{};
+  q.g = ConvGemmParams{x, ldx, Nimg, H, W, Cin, ksize * ksize, dil, +1, nullptr, 0, 0, Cout, y, ldy, bias, accumulate, nullptr, 0,
+                       stats_part, stats_swish, nullptr, border_bias, 1.0f, nullptr};
+  q.image = reinterpret_cast<const char*>(image);
+  q.ncol16 = (Cout + 15) / 16;
+  x3_launch(g, q, ws, stream);
+  MLIIS_CHECK_LAUNCH("conv2d_fwd_x3");
+  if (stats_nblk) *stats_nblk = stats_part != nullptr ? g.gx : 0;
+  return MLIIS_OK;
+}
+
+// dx[M, Cin_out] (ld = lddx) (+)= conv_transpose(dy[M, Cout] (ld = lddy), w) over the input-channel window the mode-1 image was packed for
+int mliis_conv2d_bwd_data_x3(const float* dy, int lddy, const void* image, float* dx, int lddx, int Nimg, int H, int W, int Cin_out, int Cout,
+                             int ksize, int dil, int accumulate, float* ws, size_t ws_floats, hipStream_t stream) {
+  int rc = x3_shape_check("conv2d_bwd_data_x3", Nimg, H, W, Cout, Cin_out, ksize, dil);
+  if (rc) return rc;
+  MLIIS_REQUIRE(dy && image && dx, MLIIS_ERR_ARG, "conv2d_bwd_data_x3: null pointer");
+  MLIIS_REQUIRE((lddy & 3) == 0 && lddy >= Cout && (lddx & 3) == 0 && lddx >= Cin_out, MLIIS_ERR_ARG, "conv2d_bwd_data_x3: bad leading dimensions");
+  MLIIS_REQUIRE(aligned16(dy) && aligned16(image) && aligned16(dx) && aligned16(ws), MLIIS_ERR_ALIGN,
+                "conv2d_bwd_data_x3: pointers must be 16-byte aligned");
+  const long long M = (long long)Nimg * H * W;
+  MLIIS_REQUIRE(M * lddy * 4 < (1LL << 31) && mliis_x3_image_bytes(Cout, Cin_out, ksize) < (1ULL << 31), MLIIS_ERR_UNSUPPORTED,
+                "conv2d_bwd_data_x3: operand larger than 2 GiB (32-bit buffer offsets)");
+  const X3Plan g = x3_plan(M, Cin_out, ksize * ksize, Cout, x3_num_cus());
+  MLIIS_REQUIRE(g.slab_floats() == 0 || (ws != nullptr && g.slab_floats() <= ws_floats), MLIIS_ERR_WORKSPACE,
+                "conv2d_bwd_data_x3: workspace too small (%zu needed, %zu given)", g.slab_floats(), ws_floats);
+  X3Params q{};
+  q.g = ConvGemmParams{dy, lddy, Nimg, H, W, Cout, ksize * ksize, dil, -1, nullptr, 0, 0, Cin_out, dx, lddx, nullptr, accumulate, nullptr, 0,
+                       nullptr, 0, nullptr, nullptr, 1.0f, nullptr};
+  q.image = reinterpret_cast<const char*>(image);
+  q.ncol16 = (Cin_out + 15) / 16;
+  x3_launch(g, q, ws, stream);
+  MLIIS_CHECK_LAUNCH("conv2d_bwd_data_x3");
+  return MLIIS_OK;
+}
+}

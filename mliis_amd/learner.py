@@ -55,8 +55,15 @@ class Learner(_Passes):
         self.act_dtype = torch.float32
         if matmul_precision == "bf16-storage":
             matmul_precision, self.act_dtype = "bf16", torch.bfloat16
+        # "fp32" multiplies the long-K decoder convs as fp32 EQUIVALENT products on the bf16 matrix cores (every operand value split
+        # exactly into three bf16 terms, six term products, fp32 accumulation: csrc/conv_x3.hip -- closer to float64 than the fp32
+        # instruction's own accumulation, 1.5x faster on the dominant launch); every other conv takes the native fp32 instruction.
+        # "fp32-native": the native fp32 matrix instruction (v_mfma_f32_16x16x4_f32) everywhere.  Same tolerances in every parity test.
+        self.x3_on = matmul_precision == "fp32"
+        if matmul_precision == "fp32-native":
+            matmul_precision = "fp32"
         if matmul_precision not in ops.PRECISIONS:
-            raise ValueError("matmul_precision must be one of {} or 'bf16-storage', got {!r}".format(sorted(ops.PRECISIONS), matmul_precision))
+            raise ValueError("matmul_precision must be one of {}, 'fp32-native' or 'bf16-storage', got {!r}".format(sorted(ops.PRECISIONS), matmul_precision))
         self.matmul_precision = matmul_precision
         self._conv_fwd = functools.partial(ops.conv2d_fwd, precision=matmul_precision)
         self._conv_bwd_data = functools.partial(ops.conv2d_bwd_data, precision=matmul_precision)
@@ -142,6 +149,21 @@ class Learner(_Passes):
         self.drop_keep_dev = torch.tensor([1.0 - self.final_layer_dropout_rate], dtype=torch.float32, device=self.device)
         self._drop_keep_val = 1.0 - self.final_layer_dropout_rate
         self._pname()
+        # fp32x3: weight images of the decoder's 3x3 convs (the dilated branch over the whole concat, the fuse conv over its convolved
+        # channels), both directions, re-split once per step beside the shadow transpose
+        self.x3 = None
+        if self.x3_on:
+            self.x3 = ops.X3Images(self.device)
+            shapes = {p.name: p.shape for p in A.trainable}
+            for m, nm in zip(self.arch.rsd, self.n_rsd):
+                (k0, _, _), (k1, _, _), (kf, _, _) = nm
+                for name, cin in ((k1, None), (kf, 2 * m.c_out)):
+                    kk, _, cin_total, cout = shapes[name]
+                    win = cin_total if cin is None else cin
+                    if ops.X3Images.eligible(win, cout, kk) and ops.X3Images.eligible(cout, win, kk):
+                        self.x3.add(name, "fwd", A.t_off[name], kk, cin_total, cout, 0, win)
+                        self.x3.add(name, "bwd", A.t_off[name], kk, cin_total, cout, 0, win)
+            self.x3.finish()
         torch.cuda.synchronize(self.device)   # arena was initialised on the default stream; steps run on self.stream
 
     # ------------------------------------------------------------------------------------------- names

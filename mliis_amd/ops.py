@@ -399,6 +399,97 @@ def conv2d_fwd(x, w, bias=None, dil=1, out=None, accumulate=False, ws: Optional[
     return out
 
 
+class X3Images:
+    """Pre-split weight images of the dense convs that run under MLIIS_PREC_F32X3 (csrc/conv_x3.hip): add() every (conv, direction)
+    once, finish() builds the device descriptor table, pack(theta) re-splits all of them in ONE launch (once per inner step: the
+    weights change with every optimizer step)."""
+
+    X3_MIN_K = 512   # reductions shorter than this stay on the native fp32 instruction (those launches are not matrix-pipe-bound)
+
+    def __init__(self, device):
+        self.device = device
+        self.rows, self.view, self.blocks, self.bytes = [], {}, 0, 0
+        self.images = self.desc = None
+
+    @staticmethod
+    def eligible(cred, nout, k) -> bool:
+        return cred >= 32 and cred % 4 == 0 and nout % 4 == 0 and k * k * cred >= X3Images.X3_MIN_K
+
+    def add(self, key, mode, theta_off, k, cin_total, cout, ci_begin=0, cin=None):
+        """mode "fwd": columns = cout, reduction over the window [ci_begin, ci_begin + cin); "bwd": columns = that window, reduction over cout."""
+        cin = cin_total - ci_begin if cin is None else cin
+        cred, nout = (cin, cout) if mode == "fwd" else (cout, cin)
+        nbytes = lib.size("mliis_x3_image_bytes", cred, nout, k)
+        nblk = lib.size("mliis_x3_image_blocks", cred, nout, k)
+        self.rows.append([int(theta_off), k * k, cin_total, cout, ci_begin, cin, (0 if mode == "fwd" else 1) | (self.blocks << 8), self.bytes])
+        self.view[(key, mode)] = (self.bytes, nbytes)
+        self.blocks += nblk
+        self.bytes += nbytes
+
+    def finish(self):
+        self.images = torch.zeros(max(self.bytes, 16), dtype=torch.uint8, device=self.device)
+        self.desc = torch.tensor(self.rows, dtype=torch.int64, device=self.device) if self.rows else None
+        return self
+
+    def pack(self, theta):
+        if self.desc is not None:
+            lib.call("mliis_x3_pack_weights", _ptr(theta), _ptr(self.images), _ptr(self.desc), len(self.rows), self.blocks, _stream())
+
+    def image(self, key, mode):
+        off, n = self.view[(key, mode)]
+        return self.images[off:off + n]
+
+    def has(self, key, mode):
+        return (key, mode) in self.view
+
+
+def x3_image_of(w, mode, ci_begin=0, cin=None):
+    """Stand-alone image of one weight tensor [k,k,Cin,Cout] (tests / probes: the learner keeps an X3Images over its arena)."""
+    k, _, cin_total, cout = w.shape
+    im = X3Images(w.device)
+    im.add("w", mode, 0, k, cin_total, cout, ci_begin, cin)
+    im.finish().pack(w.contiguous().view(-1))
+    return im.image("w", mode)
+
+
+def conv2d_fwd_x3(x, image, k, cout, bias=None, dil=1, out=None, accumulate=False, ws: Optional[Workspace] = None, stats_part=None,
+                  stats_swish=False, border_bias=None):
+    """conv2d_fwd under MLIIS_PREC_F32X3 with the conv's forward weight image (X3Images / x3_image_of); x may be a channel-sliced view
+    -- the window is the one the image was packed for.  Returns out, or (out, nblk) with stats_part."""
+    N, H, W = x.shape[:3]
+    rows, Cin, ldx = rows_ld(x)
+    out = torch.empty((N, H, W, cout), dtype=torch.float32, device=x.device) if out is None else out
+    _, co, ldy = rows_ld(out)
+    ws = ws or default_ws()
+    buf = ws.get(lib.size("mliis_conv2d_x3_workspace_floats", N, H, W, Cin, cout, k))
+    nblk = C.c_int(0)
+    meta = {}
+    if PROFILE is not None:
+        meta = dict(kernel="conv_x3_k", flops=2.0 * N * H * W * k * k * Cin * cout, shape=(N, H, W, Cin, cout, k, dil))
+    _timed("conv2d_fwd_x3", meta, lambda: lib.call("mliis_conv2d_fwd_x3", _aptr(x), ldx, _ptr(image), _ptr(bias), _ptr(border_bias), _aptr(out), ldy,
+                                                   N, H, W, Cin, cout, k, dil, int(accumulate), _ptr(stats_part), int(stats_swish), C.byref(nblk),
+                                                   _ptr(buf), buf.numel(), _stream()))
+    if stats_part is not None:
+        return out, nblk.value
+    return out
+
+
+def conv2d_bwd_data_x3(dy, image, k, cin_out, dil=1, out=None, accumulate=False, ws: Optional[Workspace] = None):
+    """conv2d_bwd_data under MLIIS_PREC_F32X3 with the conv's backward weight image (its input-channel window has cin_out channels)."""
+    N, H, W = dy.shape[:3]
+    rows, Cout, lddy = rows_ld(dy)
+    out = torch.empty((N, H, W, cin_out), dtype=torch.float32, device=dy.device) if out is None else out
+    _, ci, lddx = rows_ld(out)
+    ws = ws or default_ws()
+    buf = ws.get(lib.size("mliis_conv2d_x3_workspace_floats", N, H, W, Cout, cin_out, k))
+    meta = {}
+    if PROFILE is not None:
+        meta = dict(kernel="conv_x3_k", flops=2.0 * N * H * W * k * k * cin_out * Cout, shape=(N, H, W, Cout, cin_out, k, dil))
+    _timed("conv2d_bwd_data_x3", meta, lambda: lib.call("mliis_conv2d_bwd_data_x3", _aptr(dy), lddy, _ptr(image), _aptr(out), lddx, N, H, W, cin_out,
+                                                        Cout, k, dil, int(accumulate), _ptr(buf), buf.numel(), _stream()))
+    return out
+
+
 def conv1x1_stream_eligible(N, H, W, cred, nout, precision="fp32"):
     """True when a plain 1x1 conv of this shape (no input scale, accumulate or border bias) takes the streamed kernel -- the plan that can
     write its output group-blocked (conv2d_fwd(out_block=...), conv2d_bwd_data(gate=..., out_block=...))."""

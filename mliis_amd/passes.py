@@ -16,6 +16,12 @@ from .plan import _Plan
 
 class _Passes:
     # ------------------------------------------------------------------------------------------- forward
+    X3_MIN_ROWS = 8192   # fp32x3 only on maps with at least this many pixels in the batch (32 row tiles of 256): below, the stream-K
+                         # parts are a few chunks each and the native kernel wins (14x14 level: 31 against 20 us per launch)
+
+    def _x3_takes(self, wname, xin) -> bool:
+        return self.x3 is not None and self.x3.has(wname, "fwd") and xin.shape[0] * xin.shape[1] * xin.shape[2] >= self.X3_MIN_ROWS
+
     def _forward(self, P: _Plan, x, idx, training: bool):
         A, a, ws, N = self.arena, self.arch, self.ws, P.N
         w, mv = A.w, A.mv
@@ -38,10 +44,20 @@ class _Passes:
             return ops.bn_apply(xin, st[0], st[1], w[prefix + "/gamma"], w[prefix + "/beta"], pre, post, img_scale, res, out=y)
 
         ops.transpose_weights(A.theta, self.theta_t, self.wt_desc, self.w_amax, tiles=self.wt_tiles)
+        if self.x3 is not None:
+            self.x3.pack(A.theta)
 
         def conv(xin, wname, bname, dil, out, swish_stats, x_scale=None, border_bias=None, out_block=0):
             """dense conv; in training the epilogue also emits the following BN's statistics (returns their block count)."""
             am = self._amax_of.get(wname)
+            if self._x3_takes(wname, xin):   # (fp32x3: a long-K decoder conv on a map large enough to fill the chip)
+                k_, co_ = w[wname].shape[0], w[wname].shape[3]
+                if training:
+                    return ops.conv2d_fwd_x3(xin, self.x3.image(wname, "fwd"), k_, co_, w[bname] if bname else None, dil, out=out, ws=ws,
+                                             stats_part=P.stats_part, stats_swish=swish_stats, border_bias=border_bias)[1]
+                ops.conv2d_fwd_x3(xin, self.x3.image(wname, "fwd"), k_, co_, w[bname] if bname else None, dil, out=out, ws=ws,
+                                  border_bias=border_bias)
+                return 0
             if training:
                 return self._conv_fwd(xin, w[wname], w[bname] if bname else None, dil, out=out, ws=ws, stats_part=P.stats_part,
                                       stats_swish=swish_stats, wt=self.wt[wname], x_scale=x_scale, border_bias=border_bias, fp8_w_amax=am,
@@ -190,8 +206,12 @@ class _Passes:
                 # the two conv -> swish -> BN tails
                 nb0 = self._conv_fwd(cat, w[k0], w[b0], 1, out=D["z0"], ws=ws, stats_part=P.stats_part, stats_swish=True, wt=self.wt[k0],
                                      fp8_w_amax=self._amax_of.get(k0))[1]
-                nb1 = self._conv_fwd(cat, w[k1], w[b1], 2, out=D["z1"], ws=ws, stats_part=P.stats_part2, stats_swish=True, wt=self.wt[k1],
-                                     fp8_w_amax=self._amax_of.get(k1))[1]
+                if self._x3_takes(k1, cat):
+                    nb1 = ops.conv2d_fwd_x3(cat, self.x3.image(k1, "fwd"), 3, m.c_out, w[b1], 2, out=D["z1"], ws=ws, stats_part=P.stats_part2,
+                                            stats_swish=True)[1]
+                else:
+                    nb1 = self._conv_fwd(cat, w[k1], w[b1], 2, out=D["z1"], ws=ws, stats_part=P.stats_part2, stats_swish=True, wt=self.wt[k1],
+                                         fp8_w_amax=self._amax_of.get(k1))[1]
                 ops.bn_apply_fused_pair([(D["z" + i], pt, nb_, D["st" + i][0], D["st" + i][1], w[nn + "/gamma"], w[nn + "/beta"],
                                           (mv[nn + "/moving_mean"], mv[nn + "/moving_variance"]), out_)
                                          for i, pt, nb_, nn, out_ in (("0", P.stats_part, nb0, n0, pyr[..., :m.c_out]),
@@ -317,7 +337,10 @@ class _Passes:
             bn_b(D["zf"], dO, D["stf"], nf, D["dzf"], pre=True)
             ops.rsd_pool_bwd(D["dzf"], D["tot"], D["pool"], w[kf], 2 * co, dw=g[kf], dbias=g[bf], dpool=D["dpool"], ws=ws)
             wgrad_conv(pyr, D["dzf"], 3, 1, kf)   # rows of the 2*co convolved channels
-            self._conv_bwd_data(D["dzf"], w[kf], 1, ci_begin=0, ci_count=2 * co, out=dpyr, ws=ws)
+            if self._x3_takes(kf, D["dzf"]):
+                ops.conv2d_bwd_data_x3(D["dzf"], self.x3.image(kf, "bwd"), 3, 2 * co, 1, out=dpyr, ws=ws)
+            else:
+                self._conv_bwd_data(D["dzf"], w[kf], 1, ci_begin=0, ci_count=2 * co, out=dpyr, ws=ws)
             d0, d1 = dpyr[..., :co], dpyr[..., co:2 * co]
             # both branches' batch norms: one reduce launch + one apply launch (+ conv-bias gradient slabs for the batched fold)
             ops.bn_bwd_pair([(D["z" + i], d_, D["st" + i][0], D["st" + i][1], w[nn + "/gamma"], w[nn + "/beta"], d_, g[nn + "/gamma"],
@@ -333,7 +356,10 @@ class _Passes:
             wgrad(d0, k0, 1, 1)
             self._conv_bwd_data(d0, w[k0], 1, out=dcat, ws=ws)
             wgrad(d1, k1, 3, 2)
-            self._conv_bwd_data(d1, w[k1], 2, out=dcat, accumulate=True, ws=ws)
+            if self._x3_takes(k1, d1):
+                ops.conv2d_bwd_data_x3(d1, self.x3.image(k1, "bwd"), 3, m.c_cat, 2, out=dcat, accumulate=True, ws=ws)
+            else:
+                self._conv_bwd_data(d1, w[k1], 2, out=dcat, accumulate=True, ws=ws)
             # gradient of the concat = dcat + dpool / (H*W) on every pixel (the pooled branch); its deep half joins the residual
             # gradient, its skip half goes to the endpoint's gradient: one pass (mliis_chan_split)
             bi_skip = a.reductions[r]

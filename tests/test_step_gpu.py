@@ -201,11 +201,14 @@ def test_graph_replay_equals_eager_and_variable_batch(optimizer):
     assert torch.equal(runs[0][1], runs[1][1]) and torch.equal(runs[0][2], runs[1][2])
 
 
-def test_full_size_step_config2():
-    """EfficientLab-6-3 at 224x224, N = 8 (BASELINE config 2 shapes): one step, loss + a sample of gradients."""
+@pytest.mark.parametrize("precision", ["fp32", "fp32-native"])
+def test_full_size_step_config2(precision):
+    """EfficientLab-6-3 at 224x224, N = 8 (BASELINE config 2 shapes): one step, loss + every gradient.  "fp32" (the default) multiplies
+    the 56x56 decoder convs as split products on the bf16 matrix cores (csrc/conv_x3.hip), "fp32-native" with the fp32 instruction:
+    the same tolerances."""
     _need_gpu()
     H, S, idx = 224, 5, [0, 1, 2, 3, 4, 0, 1, 2]
-    O, L = _pair(H)
+    O, L = _pair(H, matmul_precision=precision)
     x, y = _task(S, H, 0)
     L.load_task(x, y)
     dc = _dc(O, 8, 3)
@@ -692,15 +695,17 @@ def test_rank_emulation_sharded_meta_step_equals_single_rank(fomaml, P):
     L.close()
 
 
-def test_full_size_eight_step_task_config2():
+@pytest.mark.parametrize("precision", ["fp32", "fp32-native"])
+def test_full_size_eight_step_task_config2(precision):
     """BASELINE config 2, the workload bench.py times: one 5-shot task at 224x224, 8 inner SGD steps of batch 8 (wrap-around
     batches), drop-connect masks injected, HIP-graph replay from step 3 on -- loss of every step vs the float64 oracle (rel 1e-4
-    first step, 1e-3 after), parameters after the task, inference-mode logits / masks on the 5 shots."""
+    first step, 1e-3 after), parameters after the task, inference-mode logits / masks on the 5 shots.  Both fp32 forms of the decoder
+    convs (split products on the bf16 matrix cores / the native fp32 instruction) under the same tolerances."""
     _need_gpu()
     import random
     from mliis_amd.metaseg import mini_batch_indices
     H, S = 224, 5
-    O, L = _pair(H, use_graph=True)
+    O, L = _pair(H, use_graph=True, matmul_precision=precision)
     x, y = _task(S, H, 4)
     L.load_task(x, y)
     xd, yd = torch.tensor(x).double(), torch.tensor(y).double()
