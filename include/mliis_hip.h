@@ -193,6 +193,11 @@ size_t mliis_conv2d_workspace_floats(int Nimg, int H, int W, int Cred, int Nout,
 #define MLIIS_PREC_FP32 0
 #define MLIIS_PREC_BF16 1
 #define MLIIS_PREC_FP8 2
+/*      MLIIS_PREC_F32X3 (mliis_conv2d_bwd_filter_batched only; the forward / backward-data form has its own entry points,
+ *      mliis_conv2d_fwd_x3 / mliis_conv2d_bwd_data_x3): fp32-EQUIVALENT products on the bf16 matrix cores -- every fp32 operand value split
+ *      exactly into three bf16 terms, six of the nine term products, fp32 accumulation -- for the groups of 128-channel tiles; the
+ *      other groups run the fp32 instruction under this value too. */
+#define MLIIS_PREC_F32X3 3
 /*      tiling chosen for a fwd / bwd-data call (row-tile factor, column tiles, split-K factor) and the name of the kernel
  *      instantiation it launches, as rocprofv3 prints it (profiling aids: bench.py matches its live timings to the trace) */
 int mliis_conv2d_plan(int Nimg, int H, int W, int Cred, int Nout, int ksize, int* tm, int* nt, int* splits);

@@ -822,12 +822,21 @@ int mliis_conv2d_bwd_filter_plan(int Nimg, int H, int W, int Cin, int Cout, int 
 // table int64 [nprob][16], layout at conv_filter_grad2_batched_k; the caller owns it (it is read by the kernel, not by the host).
 int mliis_conv2d_bwd_filter_batched(const long long* desc, int nprob, int blocks, int tmf, int nt, int has_scale, int precision,
                                     hipStream_t stream) {
+  // MLIIS_PREC_F32X3: the groups of 128-channel tiles (TMF = 2, at least 4 column tiles, no x_scale) as fp32-equivalent split products
+  // on the bf16 matrix cores (conv_x3.hip: conv_filter_x3_batched_k); every other group runs the native fp32 instruction
+  bool x3_done = false;
+  if (precision == MLIIS_PREC_F32X3) {
+    precision = MLIIS_PREC_FP32;
+    MLIIS_REQUIRE(desc && nprob >= 1 && nprob <= 64 && blocks >= 1 && aligned16(desc), MLIIS_ERR_ARG, "conv2d_bwd_filter_batched: bad table");
+    if (tmf == 2 && !has_scale) x3_done = launch_filter_batched_x3(nt, desc, nprob, blocks, stream);
+  }
   int rc = prec_check("conv2d_bwd_filter_batched", precision);
   if (rc) return rc;
   MLIIS_REQUIRE(desc && nprob >= 1 && nprob <= 64 && blocks >= 1, MLIIS_ERR_ARG, "conv2d_bwd_filter_batched: bad table (1..64 problems)");
   MLIIS_REQUIRE(aligned16(desc), MLIIS_ERR_ALIGN, "conv2d_bwd_filter_batched: table must be 16-byte aligned");
-  const bool ok = precision != MLIIS_PREC_FP32 ? launch_filter_batched_bf16(tmf, nt, has_scale != 0, desc, nprob, blocks, stream)
-                                               : launch_filter_batched_t<false>(tmf, nt, has_scale != 0, desc, nprob, blocks, stream);
+  const bool ok = x3_done ? true
+                  : precision != MLIIS_PREC_FP32 ? launch_filter_batched_bf16(tmf, nt, has_scale != 0, desc, nprob, blocks, stream)
+                                                 : launch_filter_batched_t<false>(tmf, nt, has_scale != 0, desc, nprob, blocks, stream);
   MLIIS_REQUIRE(ok, MLIIS_ERR_ARG, "conv2d_bwd_filter_batched: no instantiation TMF = %d, NT = %d", tmf, nt);
   MLIIS_CHECK_LAUNCH("conv2d_bwd_filter_batched");
   return MLIIS_OK;

@@ -122,6 +122,11 @@ __device__ __forceinline__ void split3(float4 v, uint2& h, uint2& m, uint2& l) {
   l.x = pk_bf16x2(rx - __uint_as_float(m.x << 16), ry - __uint_as_float(m.x & 0xffff0000u));
   l.y = pk_bf16x2(rz - __uint_as_float(m.y << 16), rw - __uint_as_float(m.y & 0xffff0000u));
 }
+// Workgroup barrier that orders LDS traffic only: __syncthreads() carries a fence that also drains every outstanding global load of the
+// wave (s_waitcnt vmcnt(0)), pinning register-prefetched chunks to the chunk they were requested in; gfx950 backs a barrier off under
+// pending memory operations, so waiting for the wave's own LDS operations is enough for an LDS hand-over.  (conv_x3.hip; in the fp32
+// kernels below the loads of a chunk are requested at the top of the chunk before, and the change measured nothing: 3340 images/s both.)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 constexpr unsigned kOob = 0xFFFFFFF0u;          // beyond any num_records: the load returns 0
 constexpr unsigned kBufRecords = 0x80000000u;   // host guarantees every legal byte offset is below 2 GiB
 
@@ -1560,5 +1565,6 @@ bool launch_stream_lowp(int precision, int kc, int nt, dim3 grid, const ConvGemm
 bool launch_ksplit_lowp(int precision, int kc, int nt, dim3 grid, const ConvGemmParams& p, int row_groups, hipStream_t stream);   // conv_gemm_fp8.hip
 void launch_filter_bf16(const FilterPlan& f, const FilterGradParams& p, hipStream_t stream);
 bool launch_filter_batched_bf16(int tmf, int nt, bool sc, const long long* desc, int nprob, int blocks, hipStream_t stream);
+bool launch_filter_batched_x3(int nt, const long long* desc, int nprob, int blocks, hipStream_t stream);   // conv_x3.hip: the (TMF = 2, NT >= 4, no x_scale) groups as split products
 
 }  // namespace mliis

@@ -83,12 +83,6 @@ struct X3Params {
 #endif
 };
 
-// Workgroup barrier that orders LDS traffic only: __syncthreads() carries a fence that drains EVERY outstanding global load of the wave
-// (s_waitcnt vmcnt(0)), which would pin the loads of the next chunks -- requested so that they land a chunk or two later -- to the
-// chunk they are requested in.  Here only the wave's LDS operations are waited for; gfx950 backs a barrier off under pending memory
-// operations, so no wider wait is needed (MI355X_MICROARCH.md: "barriers do not drain VMEM").
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
 template <int NT>
 struct X3Sm {
   static constexpr int BN = 16 * NT;
@@ -525,6 +519,249 @@ __global__ __launch_bounds__(1024) void x3_fixup_k(ConvGemmParams p, SkPlan k) {
       st4(p.stats_part + ((long long)bx * 2 + v) * p.Nout + nn, a);
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------------ backward-filter
+// dW[tap][ci][co] = sum over pixels of X[pixel + tap offset][ci] * dY[pixel][co] with the same split products: the reduction runs over
+// the PIXELS, so both operands need k-major fragments of tensors whose channels are contiguous.  A chunk of 32 pixels is staged once
+// per workgroup: every fp32 value is split while it is stored (each element once), as three row-major bf16 planes [pixel][channel]
+// (X: 128 input channels, dY: up to 128 output columns; 256-byte rows whose 32-byte column chunks are XOR-swizzled by the pixel), and
+// the fragments come back TRANSPOSED through ds_read_b64_tr_b16 (a 16-lane group reads 4 pixel rows x 16 channels and every lane
+// receives its channel's four pixels: two reads make the eight k values of a 16x16x32 operand).  Workgroup = 8 waves = 4 blocks of 32
+// input channels x 2 halves of the column tiles (the two waves of a SIMD hold one half each: 12 + 9 fragment reads for 48 + 36 matrix
+// instructions per chunk and SIMD pair); tile, slabs and descriptor table are those of conv_filter_grad2_batched_k<2, NT> (one tap per
+// workgroup, the multitap form of the concat's sliver included), so the plan, the workspace and the batched fold do not change.
+typedef short x3_v4s __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint2 ds_read_tr16(const char* p) {
+  const x3_v4s r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((x3_v4s __attribute__((address_space(3)))*)(p));
+  return __builtin_bit_cast(uint2, r);
+}
+constexpr int kF3Rows = 32;                          // pixels per chunk
+constexpr int kF3Plane = kF3Rows * 256;              // bytes of one term plane of one operand (32 rows x 128 channels x 2 bytes)
+constexpr int kF3Stage = 6 * kF3Plane;               // X planes + dY planes
+__device__ __forceinline__ int f3_swz(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }   // chunk XOR of a pixel row
+
+template <int NT>
+__device__ __forceinline__ void conv_filter_x3_body(const FilterGradParams& p, char* __restrict__ sm, int bx, int by, int bz) {
+  constexpr int BCI = 128, BN = 16 * NT;
+  constexpr int D_TOTAL = kF3Rows * (BN / 4);
+  constexpr int D_PER_THREAD = (D_TOTAL + 511) / 512;
+  constexpr int NT0 = (NT + 1) / 2, NT1 = NT / 2;   // column tiles of the two wave halves
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int cib = wave & 3, half = wave >> 2;       // 32-channel block of the tile's 128; column half
+  const int l15 = lane & 15, g = lane >> 4;
+  const int M = p.Nimg * p.H * p.W;
+  const bool mt = p.multitap != 0;
+  const int cblocks = mt ? 1 : (p.C + BCI - 1) / BCI;
+  const int tap = mt ? 0 : bx / cblocks;
+  const int ci0 = mt ? 0 : (bx - tap * cblocks) * BCI;
+  const int n0 = by * BN;
+  const int mbeg = bz * p.rows_per_split;
+  int mend = mbeg + p.rows_per_split;
+  if (mend > M) mend = M;
+  const int HW = p.H * p.W;
+  const int adv_h = kF3Rows / p.W, adv_w = kF3Rows - adv_h * p.W;
+  const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)p.X, 0, kBufRecords, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rD = __builtin_amdgcn_make_buffer_rsrc((void*)p.dY, 0, kBufRecords, 0x00020000);
+
+  // ---- X: thread t loads the channel quad x_cq of pixel rows x_r0 and x_r0 + 16 of every chunk
+  const int x_cq = t & 31, x_r0 = t >> 5;
+  int l_tap = tap, l_c = ci0 + x_cq * 4;
+  if (mt) {
+    l_tap = (x_cq * 4) / p.C;
+    l_c = x_cq * 4 - l_tap * p.C;
+  }
+  const bool x_cok = mt ? l_tap < p.ntaps : l_c < p.C;
+  int dh = 0, dw = 0;
+  if (p.ntaps > 1) {
+    dh = (l_tap / 3 - 1) * p.dil;
+    dw = (l_tap % 3 - 1) * p.dil;
+  }
+  int x_m[2], x_h[2], x_w[2];
+  unsigned x_off[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int m = mbeg + x_r0 + 16 * i;
+    x_m[i] = m;
+    const int n = m / HW;
+    const int rem = m - n * HW;
+    x_h[i] = rem / p.W;
+    x_w[i] = rem - x_h[i] * p.W;
+    x_off[i] = (unsigned)((((long long)m + (long long)dh * p.W + dw) * p.ldx + l_c) * 4);
+  }
+  const unsigned x_step = (unsigned)(kF3Rows * p.ldx * 4);
+  int d_m[D_PER_THREAD];
+  unsigned d_off[D_PER_THREAD];
+  bool d_ok[D_PER_THREAD];
+  int d_lds[D_PER_THREAD];
+#pragma unroll
+  for (int i = 0; i < D_PER_THREAD; ++i) {
+    const int idx = t + 512 * i;
+    const int r = idx / (BN / 4), nq = idx - r * (BN / 4);
+    d_m[i] = mbeg + r;
+    d_ok[i] = (idx < D_TOTAL) && (n0 + nq * 4 < p.Nout);
+    d_off[i] = (unsigned)((((long long)mbeg + r) * p.lddy + n0 + nq * 4) * 4);
+    d_lds[i] = idx < D_TOTAL ? 3 * kF3Plane + r * 256 + (((nq >> 2) ^ f3_swz(r)) * 32) + (nq & 3) * 8 : -1;
+  }
+  const unsigned d_step = (unsigned)(kF3Rows * p.lddy * 4);
+  int x_lds[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = x_r0 + 16 * i;
+    x_lds[i] = r * 256 + (((x_cq >> 2) ^ f3_swz(r)) * 32) + (x_cq & 3) * 8;
+  }
+
+  float4 rx[2], rd[D_PER_THREAD];
+  auto load_chunk = [&]() {   // next 32 pixel rows -> registers, then advance (rows beyond mend / halo pixels come back as zeros)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const bool ok = x_cok & (x_m[i] < mend) & ((unsigned)(x_h[i] + dh) < (unsigned)p.H) & ((unsigned)(x_w[i] + dw) < (unsigned)p.W);
+      rx[i] = buf_ld4(rX, ok ? x_off[i] : kOob);
+      x_m[i] += kF3Rows;
+      x_off[i] += x_step;
+      x_w[i] += adv_w;
+      x_h[i] += adv_h;
+      if (x_w[i] >= p.W) {
+        x_w[i] -= p.W;
+        ++x_h[i];
+      }
+      if (x_h[i] >= p.H) x_h[i] -= (x_h[i] / p.H) * p.H;   // crossed into the next image(s)
+    }
+#pragma unroll
+    for (int i = 0; i < D_PER_THREAD; ++i) {
+      rd[i] = buf_ld4(rD, (d_ok[i] & (d_m[i] < mend)) ? d_off[i] : kOob);
+      d_m[i] += kF3Rows;
+      d_off[i] += d_step;
+    }
+  };
+  auto store_chunk = [&](char* buf) {   // split while storing: three planes of 4 bf16 (8 bytes) per 16-byte quad
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      uint2 h, m, l;
+      split3(rx[i], h, m, l);
+      char* d = buf + x_lds[i];
+      *reinterpret_cast<uint2*>(d) = h;
+      *reinterpret_cast<uint2*>(d + kF3Plane) = m;
+      *reinterpret_cast<uint2*>(d + 2 * kF3Plane) = l;
+    }
+#pragma unroll
+    for (int i = 0; i < D_PER_THREAD; ++i) {
+      uint2 h, m, l;
+      split3(rd[i], h, m, l);
+      if (512 * (i + 1) <= D_TOTAL || d_lds[i] >= 0) {
+        char* d = buf + d_lds[i];
+        *reinterpret_cast<uint2*>(d) = h;
+        *reinterpret_cast<uint2*>(d + kF3Plane) = m;
+        *reinterpret_cast<uint2*>(d + 2 * kF3Plane) = l;
+      }
+    }
+  };
+  constexpr int NTW = NT0;   // accumulator tiles per wave (half 1 uses NT1 of them)
+  f32x4 acc[2][NTW];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // fragment addresses: lane (g, q = l15 >> 2, pq = l15 & 3) supplies pixel row 8 g + 4 hh + q, columns 4 pq .. 4 pq + 3 of a 16-channel chunk
+  const int fq = l15 >> 2, fp = l15 & 3;
+  int a_row[2], a_sw[2];
+#pragma unroll
+  for (int hh = 0; hh < 2; ++hh) {
+    const int r = 8 * g + 4 * hh + fq;
+    a_row[hh] = r * 256 + fp * 8;
+    a_sw[hh] = f3_swz(r);
+  }
+  const bool wave_live = mt ? cib * 32 < p.ntaps * p.C : ci0 + cib * 32 < p.C;
+  const int jn0 = half == 0 ? 0 : NT0;           // first column tile of this wave
+  const int njn = half == 0 ? NT0 : NT1;
+  auto frag = [&](const char* plane, int chunk16) {   // the 8 k values of one 16-channel block: two transposed reads
+    const uint2 lo = ds_read_tr16(plane + a_row[0] + ((chunk16 ^ a_sw[0]) * 32));
+    const uint2 hi = ds_read_tr16(plane + a_row[1] + ((chunk16 ^ a_sw[1]) * 32));
+    return __builtin_bit_cast(bf16x8, (u32x4){lo.x, lo.y, hi.x, hi.y});
+  };
+  auto compute = [&](const char* buf) {
+    if (!wave_live) return;
+    bf16x8 a3[3][2];
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) a3[pl][rb] = frag(buf + pl * kF3Plane, cib * 2 + rb);
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+      if (j < njn) {   // (uniform)
+        bf16x8 b3[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) b3[pl] = frag(buf + (3 + pl) * kF3Plane, jn0 + j);
+#define X3_MM(PA, PB)                                                                                   \
+  acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3[PA][0], b3[PB], acc[0][j], 0, 0, 0);         \
+  acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3[PA][1], b3[PB], acc[1][j], 0, 0, 0);
+        X3_MM(2, 0) X3_MM(0, 2) X3_MM(1, 1) X3_MM(1, 0) X3_MM(0, 1) X3_MM(0, 0)
+#undef X3_MM
+      }
+    }
+  };
+
+  const int nchunks = (mend - mbeg + kF3Rows - 1) / kF3Rows;
+  load_chunk();
+  store_chunk(sm);
+  load_chunk();
+  lds_barrier();
+  for (int it = 0; it < nchunks; ++it) {
+    char* cur = sm + (it & 1) * kF3Stage;
+    char* nxt = sm + ((it & 1) ^ 1) * kF3Stage;
+    compute(cur);
+    store_chunk(nxt);   // (zeros after the last chunk: nobody reads them)
+    load_chunk();
+    lds_barrier();
+  }
+
+  const long long Ktot = (long long)p.ntaps * p.C;
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ci = ci0 + cib * 32 + rb * 16 + g * 4 + r;   // multitap: the flattened (tap, channel) row, tap == 0 in the index below
+      if (ci >= (mt ? p.ntaps * p.C : p.C)) continue;
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) {
+        const int n = n0 + (jn0 + j) * 16 + l15;
+        if (j < njn && n < p.Nout) p.partial[((long long)bz * Ktot + (long long)tap * p.C + ci) * p.Nout + n] = acc[rb][j][r];
+      }
+    }
+}
+
+// the problems of one (TMF = 2, NT) group of a FilterBatch as one grid: descriptor table as conv_filter_grad2_batched_k
+template <int NT>
+__global__ __launch_bounds__(512) void conv_filter_x3_batched_k(const long long* __restrict__ desc, int nprob) {
+  __shared__ __attribute__((aligned(16))) char sm[2 * kF3Stage];
+  const int b = blockIdx.x;
+  int j = 0;
+  for (int k = 1; k < nprob; ++k)
+    if (b >= (int)desc[k * kFilterDescWords + 15]) j = k;
+  const long long* d = desc + (long long)j * kFilterDescWords;
+  const int ks = (int)(d[11] & 0xff);
+  const FilterGradParams p{reinterpret_cast<const float*>(d[0]), (int)d[4], (int)d[6], (int)d[7], (int)d[8], (int)d[9], ks * ks, (int)d[12],
+                           reinterpret_cast<const float*>(d[1]), (int)d[5], (int)d[10], reinterpret_cast<float*>(d[3]),
+                           (int)(d[13] & 0xffffffffLL), nullptr, (int)(d[13] >> 32), 0, 0};
+  const int gx = (int)(d[14] & 0xfffff), gy = (int)((d[14] >> 20) & 0xfffff);
+  const int local = b - (int)d[15];
+  const int bx = local % gx, r = local / gx;
+  conv_filter_x3_body<NT>(p, sm, bx, r % gy, r / gy);
+}
+
+bool launch_filter_batched_x3(int nt, const long long* desc, int nprob, int blocks, hipStream_t stream) {
+  dim3 grid(blocks), block(512);
+#define L(NT_) hipLaunchKernelGGL((conv_filter_x3_batched_k<NT_>), grid, block, 0, stream, desc, nprob); return true;
+  switch (nt) {
+    case 4: L(4)
+    case 5: L(5)
+    case 6: L(6)
+    case 7: L(7)
+    case 8: L(8)
+    default: return false;
+  }
+#undef L
 }
 
 // ------------------------------------------------------------------------------------------------ host side

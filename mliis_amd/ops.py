@@ -600,10 +600,12 @@ class FilterBatch:
                 self.tables.append((torch.tensor(rows, dtype=torch.int64, device=self.device), len(rows), first, tmf, nt, int(sc)))
 
     def launch(self, precision="fp32"):
+        """precision "fp32x3": the groups of 128-channel tiles as fp32-equivalent split products on the bf16 matrix cores
+        (MLIIS_PREC_F32X3), the other groups on the fp32 instruction."""
         if self.tables is None:
             self._build()
-        prec = _prec(precision)
-        if prec == 0 and any((row[11] >> 8) for items in self.groups.values() for row, _ in items):
+        prec = 3 if precision == "fp32x3" else _prec(precision)
+        if prec in (0, 3) and any((row[11] >> 8) for items in self.groups.values() for row, _ in items):
             raise MliisError("FilterBatch: bf16 tensors need the bf16-operand instances (precision 'bf16')")
         for table, nprob, blocks, tmf, nt, sc in self.tables:
             lib.call("mliis_conv2d_bwd_filter_batched", _ptr(table), nprob, blocks, tmf, nt, sc, prec, _stream())

@@ -560,6 +560,6 @@ class _Passes:
         bn_b(P.z_stem, P.dstem, P.st_stem, self.n_stem[1], P.dstem, post=True, stage1=P.stem_stage1 if P.fuse_stem else None)
         ops.stem_conv_bwd_filter(x, P.dstem, idx, partial=P.fold_part[self.n_stem[0]])
         P.wbatch_ready = True
-        P.wbatch.launch(self.matmul_precision)
+        P.wbatch.launch("fp32x3" if self.x3 is not None else self.matmul_precision)
         # all slabs written -> one batched fold into the gradient arena; the squeeze-excite weight gradients of every block ride in it
         ops.fold_batched(P.fold_buf, A.grad, P.fold_desc, P.fold_tiles, se_desc=P.se_desc, se_tiles=P.se_tiles)

@@ -159,3 +159,72 @@ def test_learner_takes_the_split_products_for_the_large_decoder_maps_only():
     L0 = Learner(image_size=64, use_graph=False, matmul_precision="fp32-native")
     assert L0.x3 is None
     L0.close()
+
+
+def _fold(partial, total):
+    n = partial.numel() // total
+    return partial[: n * total].view(n, total).double().sum(0)
+
+
+@pytest.mark.parametrize("N,H,Cbuf,Cin,Cout,k,dil,x3", [(8, 56, 360, 224, 112, 3, 1, True), (8, 56, 136, 128, 112, 3, 2, True),
+                                                        (8, 28, 224, 224, 112, 3, 2, None), (6, 37, 200, 200, 80, 1, 1, None),
+                                                        (4, 40, 128, 128, 128, 3, 1, None), (8, 56, 136, 128, 112, 1, 1, None),
+                                                        (2, 14, 224, 224, 112, 3, 2, False)])
+def test_x3_filter_gradients_match_the_oracle(N, H, Cbuf, Cin, Cout, k, dil, x3):
+    """FilterBatch.launch("fp32x3"): the groups of 128-channel tiles as split products (conv_filter_x3_batched_k): the decoder's two
+    56x56 problems at their real sizes (the fuse conv over a channel window of the pyramid buffer, the dilated branch's 128-channel
+    main part), a 14x14 problem, a ragged map with channel / column tails, a full 128 x 128 tile, a 1x1 conv -- each with a second
+    problem in the same launch -- against float64 autograd at the tolerance of the native kernel (1e-4 of max-abs), and no further
+    from float64 than the native kernel."""
+    from mliis_amd import ops
+    d = dev()
+    buf = rnd(N, H, H, Cbuf, seed=21)
+    x = buf[..., :Cin].clone().requires_grad_(True)
+    w = rnd(k, k, Cin, Cout, seed=22, scale=1.0 / math.sqrt(k * k * Cin)).requires_grad_(True)
+    dy = rnd(N, H, H, Cout, seed=23)
+    gw = torch.autograd.grad(R.conv2d_same(nchw(x), w, 1, dil), [w], nchw(dy))[0]
+    bufg, dyg = f32(buf, d), f32(dy, d)
+    plan = (ops.C.c_int * 8)()
+    ops.lib.call("mliis_conv2d_bwd_filter_plan", N, H, H, Cin, Cout, k, plan)
+    takes = plan[0] == 2 and plan[1] >= 4   # a group of 128-channel tiles: split products; any other plan runs the fp32 instruction
+    assert x3 is None or takes == x3, (takes, list(plan[:7]))
+    n = ops.lib.size("mliis_conv2d_bwd_filter_workspace_floats", N, H, H, Cin, Cout, k)
+    total = k * k * Cin * Cout
+    res = {}
+    for prec in ("fp32x3", "fp32"):
+        pa, pb = torch.full((n,), 9.0, device=d), torch.full((n,), -9.0, device=d)
+        fb = ops.FilterBatch(d)
+        fb.add(bufg[..., :Cin], dyg, k, dil, pa)
+        fb.add(bufg[..., :Cin], dyg * 0.5, k, dil, pb)      # a second problem in the same grid
+        fb.launch(prec)
+        torch.cuda.synchronize()
+        ga, gb = _fold(pa, total).view(k, k, Cin, Cout).cpu(), _fold(pb, total).view(k, k, Cin, Cout).cpu()
+        close(ga, gw, 1e-4, prec + " filter gradient")
+        close(gb, 0.5 * gw, 1e-4, prec + " filter gradient, second problem")
+        res[prec] = (ga - gw).abs().max().item() / gw.abs().max().item()
+    print("filter gradient, %d pixels: split product %.2e, native fp32 %.2e of max-abs from float64" % (N * H * H, res["fp32x3"], res["fp32"]))
+    print("   (plan: TMF %d, NT %d -> %s)" % (plan[0], plan[1], "conv_filter_x3_batched_k" if takes else "native instruction"))
+    assert res["fp32x3"] <= 1.5 * res["fp32"] + 2e-7
+
+
+def test_x3_filter_gradient_of_the_concat_sliver_takes_the_multitap_form():
+    """The 8-channel tail of the 136-channel concat under a 3x3 conv: all nine taps in ONE 128-row block (72 flattened (tap, channel)
+    rows), in the same launch as a plain problem of the group."""
+    from mliis_amd import ops
+    d = dev()
+    N, H, Cbuf, Cout = 8, 56, 136, 112
+    buf = rnd(N, H, H, Cbuf, seed=31)
+    dy = rnd(N, H, H, Cout, seed=32)
+    xt = buf[..., 128:].clone().requires_grad_(True)
+    w = rnd(3, 3, 8, Cout, seed=33).requires_grad_(True)
+    gw = torch.autograd.grad(R.conv2d_same(nchw(xt), w, 1, 2), [w], nchw(dy))[0]
+    plan = (ops.C.c_int * 8)()
+    ops.lib.call("mliis_conv2d_bwd_filter_plan", N, H, H, 8, Cout, 3, plan)
+    assert plan[2] == 1 and plan[0] == 2, "multitap plan expected"
+    bufg, dyg = f32(buf, d), f32(dy, d)
+    n = ops.lib.size("mliis_conv2d_bwd_filter_workspace_floats", N, H, H, 8, Cout, 3)
+    pa = torch.full((n,), 9.0, device=d)
+    fb = ops.FilterBatch(d)
+    fb.add(bufg[..., 128:], dyg, 3, 2, pa)
+    fb.launch("fp32x3")
+    close(_fold(pa, 9 * 8 * Cout).view(3, 3, 8, Cout).cpu(), gw, 1e-4, "x3 multitap filter gradient")
