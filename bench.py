@@ -77,6 +77,10 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def _cpu_baseline_fn(args):   # (a seam for tests/test_bench_cli_cpu.py)
+    return cpu_baseline(args)
+
+
 def launch_ranks(args, argv):
     """`python bench.py --gpus N` with N > 1 outside a launcher: run torch.distributed.run as a CHILD (one rank per GPU), relay its
     stdout (rank 0's one JSON line; the ranks' stderr passes through) and return its exit code.  Called before any GPU call."""
@@ -87,6 +91,10 @@ def launch_ranks(args, argv):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this pool (RCCL needs it across processes)
     env.setdefault("OMP_NUM_THREADS", "1")
+    # the CPU baseline of an N > 1 line is timed HERE, in the parent (which never touches the GPU), before the ranks start, and handed
+    # to rank 0 by value: a SCALE line carries `cpu_baseline` without --cpu-baseline-from
+    if not args.no_cpu_baseline and not args.cpu_baseline_from and "MLIIS_BENCH_CPU_BASELINE" not in env:
+        env["MLIIS_BENCH_CPU_BASELINE"] = json.dumps(dict(_cpu_baseline_fn(args), timed_in="the launching parent, before the ranks started"))
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
     text = p.stdout.decode(errors="replace")
     lines = [ln for ln in text.splitlines() if ln.lstrip().startswith("{")]
@@ -137,18 +145,24 @@ def cpu_baseline(args):
     O = R.OracleLearner(name=args.backbone, image_size=args.image_size, seed=0, dtype=torch.float32, lr=1e-3, aspp=args.aspp)
     x, y = synthetic_task(args.shots, args.image_size, seed=0)
     O.load_task(torch.tensor(x), torch.tensor(y))
-    batches = [list(b) for b in mini_batch_indices(args.shots, args.inner_batch, 64, rng=random.Random(0))]
+    # at least 3 warm-up steps, then at least 2 full tasks (2 x inner_iters steps), bounded to ~25 s of CPU work
+    WARM = 3
+    batches = [list(b) for b in mini_batch_indices(args.shots, args.inner_batch, WARM + 4 * args.inner_iters, rng=random.Random(0))]
     t0 = time.time()
-    O.inner_step(batches[0])           # warm-up step (also a cost probe)
-    probe = time.time() - t0
-    n = int(max(2, min(args.inner_iters, 20.0 / max(probe, 1e-3))))
+    for b in batches[:WARM]:
+        O.inner_step(b)
+    probe = (time.time() - t0) / WARM
+    n = 2 * args.inner_iters
+    if n * probe > 25.0:   # (a slow box: as many whole steps as fit, never fewer than one task)
+        n = int(max(args.inner_iters, 25.0 / max(probe, 1e-3)))
     t0 = time.time()
-    for b in batches[1:1 + n]:
+    for b in batches[WARM:WARM + n]:
         O.inner_step(b)
     dt = time.time() - t0
     return {"value": n * args.inner_batch / dt, "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": "%d inner SGD steps (batch %d, %dx%d, fp32) of one synthetic %d-shot task on the PyTorch-CPU oracle, "
-                      "%d threads, after 1 warm-up step" % (n, args.inner_batch, args.image_size, args.image_size, args.shots, cores)}
+            "sample": "%d inner SGD steps = %.2g tasks (batch %d, %dx%d, fp32) of synthetic %d-shot data on the PyTorch-CPU oracle, "
+                      "%d threads, after %d warm-up steps" % (n, n / float(args.inner_iters), args.inner_batch, args.image_size, args.image_size,
+                                                              args.shots, cores, WARM)}
 
 
 def roofline(L, args):
@@ -167,7 +181,7 @@ def roofline(L, args):
     L.use_graph = saved
     by = {}
     for r in recs:
-        if r["op"] in ("conv2d_fwd", "conv2d_bwd_data") and r.get("splits", 1) == 1:
+        if r["op"] in ("conv2d_fwd", "conv2d_bwd_data", "conv2d_fwd_x3", "conv2d_bwd_data_x3") and r.get("splits", 1) == 1:
             k = r["kernel"]      # exact instantiation name; split-K launches are a different instantiation (their op time includes the fold)
         elif r["op"] == "conv2d_bwd_filter":
             k = "conv_filter_grad_k(+reduce)"
@@ -180,7 +194,7 @@ def roofline(L, args):
         d["n"] += 1
         d["flops"] += r.get("flops", 0.0)
         d["bytes"] += r.get("bytes", 0.0)
-    gemm = {k: v for k, v in by.items() if k.startswith("conv_gemm")}
+    gemm = {k: v for k, v in by.items() if k.startswith(("conv_gemm", "conv_x3"))}
     dom = max(gemm, key=lambda k: gemm[k]["ms"])
     d = gemm[dom]
     # The per-op event pairs above include a few microseconds of dispatch per launch.  For the dominant kernel re-issue every one
@@ -202,7 +216,7 @@ def roofline(L, args):
                 total += e0.elapsed_time(e1) / burst
         return total
     per_step = d["n"] // reps
-    sites = [r for r in recs if r.get("kernel") == dom and r["op"] in ("conv2d_fwd", "conv2d_bwd_data")][-per_step:]
+    sites = [r for r in recs if r.get("kernel") == dom and r["op"] in ("conv2d_fwd", "conv2d_bwd_data", "conv2d_fwd_x3", "conv2d_bwd_data_x3")][-per_step:]
     ms, fl = burst_ms(sites), sum(r["flops"] for r in sites)
     d = dict(d, ms=ms, n=len(sites), flops=fl)
     reps_dom = 1
@@ -221,10 +235,19 @@ def roofline(L, args):
             traffic = k["hbm_bytes_per_launch"]
             tsrc = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950-corrected; %s)" % (
                 os.path.basename(tpath), "collected on the current kernel sources" if current else "STALE: the kernel sources changed since it was collected")
-    peak = MFMA_F32_PEAK_TFLOPS if args.precision == "fp32" else MFMA_BF16_PEAK_TFLOPS
-    out = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+    x3 = dom.startswith("conv_x3")
+    # the split-product kernels (fp32 operands as three bf16 terms, SIX bf16 term products per fp32 product): `achieved` counts the fp32
+    # products (2 M K N), so the peak that bounds them is the dense bf16 matrix rate / 6; the fp32 instruction's own peak is beside it
+    peak = MFMA_BF16_PEAK_TFLOPS / 6.0 if x3 else (MFMA_F32_PEAK_TFLOPS if args.precision in ("fp32", "fp32-native") else MFMA_BF16_PEAK_TFLOPS)
+    out = {"bound": "mfma", "kernel": dom + (" (+ x3_fixup_k: the stream-K fix-up launch is inside the timed region)" if x3 else ""),
+           "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+           "peak_note": ("dense bf16 MFMA peak 2500 TFLOP/s / 6 term products per fp32 product; the fp32 MFMA instruction's peak is %.1f "
+                         "TFLOP/s (achieved / that = %.2f)" % (MFMA_F32_PEAK_TFLOPS, ach / MFMA_F32_PEAK_TFLOPS)) if x3 else None,
            "traffic": traffic, "traffic_source": tsrc, "launches_per_step": d["n"] // reps_dom, "avg_launch_us": 1e3 * d["ms"] / d["n"],
            "algorithmic_flops_per_launch": d["flops"] / d["n"]}
+    # the whole inner step against both rooflines (filled in by _run, which knows the measured step time)
+    out["_issued_flops_per_step"] = sum(r.get("flops", 0.0) for r in recs) / reps
+    out["_hbm_bytes_per_step"] = (tj.get("hbm_bytes_per_inner_step") if os.path.exists(tpath) else None)
     # depthwise families against the HBM roofline: algorithmic bytes / the kernels' own durations, measured COLD: the
     # launches of one eager step are recorded at the C ABI and re-issued straight through ctypes (a Python-level wrapper call costs
     # about as much as one of these kernels) over ROTATING copies of their activation operands -- enough copies that a tensor is
@@ -391,6 +414,8 @@ def _run(args):
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args)
+    elif rank == 0 and world > 1 and os.environ.get("MLIIS_BENCH_CPU_BASELINE"):
+        cpu = json.loads(os.environ["MLIIS_BENCH_CPU_BASELINE"])
     elif rank == 0 and world > 1 and args.cpu_baseline_from:
         src = json.load(open(args.cpu_baseline_from))
         src = src.get("parsed", src) if isinstance(src, dict) else {}
@@ -445,11 +470,27 @@ def _run(args):
     roof = dwr = fam = None
     if rank == 0 and not args.no_roofline:
         roof, dwr, fam = roofline(L, args)
+        t_step = dt / args.steps / (args.tasks_per_gpu * args.inner_iters)          # seconds per inner step (HIP-graph replay, as timed)
+        issued, hbm = roof.pop("_issued_flops_per_step"), roof.pop("_hbm_bytes_per_step")
+        default_cfg = (args.backbone == "efficientnet-b0" and args.image_size == 224 and args.inner_batch == 8 and not (args.aspp or args.skip_decoding))
+        algo = 95.9e9 if default_cfg else None   # fwd + bwd-data + bwd-filter of the reference graph at config 2
+        roof.update({
+            "step_us": 1e6 * t_step,
+            "step_tflops": (algo / t_step / 1e12) if algo else None,
+            "step_frac_of_mfma_peak": (algo / t_step / 1e12 / MFMA_F32_PEAK_TFLOPS) if algo else None,
+            "step_tflops_issued": issued / t_step / 1e12,
+            "step_frac_of_mfma_peak_issued": issued / t_step / 1e12 / MFMA_F32_PEAK_TFLOPS,
+            "step_hbm_frac": (hbm / t_step / 1e9 / HBM_PEAK_GBS) if hbm else None,
+            "step_note": "whole inner step: algorithmic 95.9 GFLOP of the reference graph (SURVEY.md Appendix A) and the conv flops this build "
+                         "issues (pooled branch folded into a bias) / the measured step time, against the fp32 MFMA peak %.1f TFLOP/s; HBM bytes per "
+                         "step from the committed rocprofv3 --pmc passes / step time / 8 TB/s" % MFMA_F32_PEAK_TFLOPS})
     if rank == 0:
         out = {
             "metric": "inner-loop images/sec (EfficientLab-6-3, 224x224, 5-shot)", "value": value, "unit": "images/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else ("bf16 matrix-core operands, f32 accumulate / tensors" if args.precision == "bf16" else
+            "vs_baseline": None, "dtype": ("f32 (the long-K decoder convs and their filter gradients with every operand split exactly into three bf16 terms on the "
+                                          "matrix cores, 6 term products, f32 accumulate: fp32-equivalent products; everything else the fp32 instruction)"
+                                          if args.precision == "fp32" else "f32 (native fp32 matrix instruction everywhere)") if args.precision in ("fp32", "fp32-native") else ("bf16 matrix-core operands, f32 accumulate / tensors" if args.precision == "bf16" else
                                                               "bf16 matrix-core operands and bf16 expanded MBConv tensors in HBM (z0, z1, a1 and their gradients), f32 accumulate / statistics / block tensors / weights" if args.precision == "bf16-storage" else
                                                               "fp8 e4m3 operands on the 1x1 forward convs (bf16 elsewhere), f32 accumulate / tensors"), "data": "synthetic",
             "config": {"workload": "%s + %sRSD(4)+RSD(2)), %dx%d, meta-batch=%d (1 task/GPU), "
@@ -459,7 +500,7 @@ def _run(args):
                                                                  ("ASPP + " if args.aspp else "") + ("DeepLabv3+-style skip decoder + " if args.skip_decoding else ""), args.image_size, args.image_size, world, shots,
                                                                  args.inner_iters,
                                                                  args.inner_batch, imgs_per_task, "FOMAML(tail 5)" if args.foml else "Reptile",
-                                                                 ("" if args.precision == "fp32" else ", %s matrix-core operands" % args.precision) + (", Adam(beta1=0) inner optimizer" if args.adam else "") +
+                                                                 ("" if args.precision in ("fp32", "fp32-native") else ", %s matrix-core operands" % args.precision) + (", Adam(beta1=0) inner optimizer" if args.adam else "") +
                                                                  ((", augmentation (aug_rate 0.5, %s)" % (("pixels on the host, %s" % ("%d worker processes" % aug_pool.workers if aug_pool else "inline")) if args.augment_on_host else "pixels on the device"))
                                                                   if args.augment else "") +
                                                                  (", %d tasks per GPU and meta-step" % args.tasks_per_gpu if args.tasks_per_gpu != 1 else "") +

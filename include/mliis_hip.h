@@ -254,8 +254,8 @@ int mliis_conv2d_bwd_data_gate(const float* dy, int lddy, const float* w, float*
  *      mliis_x3_image_blocks(...) workgroups of the pack launch (`first block` = running sum, total_blocks = their sum).
  *      mliis_conv2d_fwd_x3 / mliis_conv2d_bwd_data_x3: arguments as mliis_conv2d_fwd / mliis_conv2d_bwd_data with the image in place of
  *      wt / w (the channel window is the image's); activations are read straight from memory in matrix-core operand layout and split
- *      in registers; 128-row tiles, two workgroups per CU, stream-K remainder with a deterministic fix-up launch (slabs in ws:
- *      mliis_conv2d_x3_workspace_floats); *stats_nblk = the number of 128-row tiles.  Cred >= 32. */
+ *      in registers; 256-row tiles, one 512-thread workgroup per CU, stream-K remainder with a deterministic fix-up launch (slabs in ws:
+ *      mliis_conv2d_x3_workspace_floats); *stats_nblk = four blocks per 256-row tile.  Cred >= 32. */
 size_t mliis_x3_image_bytes(int Cred, int Nout, int ksize);
 int mliis_x3_image_blocks(int Cred, int Nout, int ksize);
 int mliis_x3_pack_weights(const float* theta, void* images, const long long* desc, int ndesc, int total_blocks, hipStream_t stream);

@@ -19,9 +19,9 @@
 //     (each element is split exactly once on the chip) and multiplies them with every B fragment: 2 x NT x 6 MFMAs per 3 NT reads;
 //   * workgroup = 8 waves = 256 rows x 16 NT columns sharing the B tile, one per CU; the barrier of a chunk waits for LDS only
 //     (__syncthreads() also drains the wave's global loads: the prefetched chunks would be pinned to the chunk they are requested in);
-//   * the K iterations of the tiles that do not fill whole rounds of the chip are cut stream-K fashion into equal contiguous parts
-//     (x3_fixup_k adds a tile's segments in a fixed order, applies bias / border bias / accumulate and emits the BN statistics:
-//     deterministic).
+//   * the K iterations of all tiles are cut stream-K fashion into equal contiguous parts, one per CU (98 - 294 tiles of 256 rows on 256
+//     CUs: whole tiles would leave a quarter of the chip idle or take two rounds); x3_fixup_k adds a tile's segments in a fixed
+//     order, applies bias / border bias / accumulate and emits the BN statistics: deterministic.
 // Results are within the fp32 tolerances of every conv test (rel 2e-5 of max-abs forward, 1e-4 backward): error against float64
 // 0.6-1.5e-6 of max-abs, against 1.4-2.0e-6 for the native fp32 instruction (tools/x3_probe.py) -- the 16x16x32 instruction adds its 32
 // products in one pass, the fp32 path rounds after each of its eight 16x16x4 steps.
@@ -87,13 +87,11 @@ template <int NT>
 struct X3Sm {
   static constexpr int BN = 16 * NT;
   static constexpr int B_BYTES = NT * kX3Block;
-  static constexpr int LDS_STAGE = BN + 4;                       // epilogue staging row stride (floats)
-  static constexpr int STAGE_BYTES = 4 * 16 * LDS_STAGE * 4;     // one 16-row staging tile per wave
-  static constexpr int BYTES = (2 * B_BYTES > STAGE_BYTES ? 2 * B_BYTES : STAGE_BYTES) + 64;
+  static constexpr int BYTES = 2 * B_BYTES + 64;   // two chunks of the B tile + a scratch slot for surplus store lanes
 };
 
-// One output tile (256-row tile bx, column tile by) over the K chunks [it0, it1).  pdst == nullptr: finished tile (bias, border bias,
-// accumulate, staged row stores, BN statistics); else the raw partial tile to pdst[row * BN + column] (a stream-K segment slab).
+// One output tile (256-row tile bx, column tile by) over the K chunks [it0, it1): the raw partial tile to pdst[row * BN + column] (a
+// stream-K segment slab; x3_fixup_k adds a tile's segments and applies bias / border bias / accumulate / statistics).
 // Wave w of the eight owns rows 32 w .. 32 w + 31 of the tile.
 template <int NT>
 __device__ __forceinline__ void conv_x3_tile(const X3Params& q, char* __restrict__ sm, unsigned bx, int by, int it0, int it1,
@@ -101,11 +99,9 @@ __device__ __forceinline__ void conv_x3_tile(const X3Params& q, char* __restrict
   constexpr int BN = 16 * NT;
   constexpr int B_BYTES = X3Sm<NT>::B_BYTES;
   constexpr int NB = (NT * 192 + 511) / 512;   // 16-byte pieces of a B chunk per thread
-  constexpr int LDS_STAGE = X3Sm<NT>::LDS_STAGE;
   const ConvGemmParams& p = q.g;
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int grp = wave >> 2, wv = wave & 3;   // (the epilogue stages the two halves of the tile one after the other)
   const int l15 = lane & 15, g = lane >> 4;
   const long long M = (long long)p.Nimg * p.H * p.W;
   const long long m0 = (long long)bx * kX3BM;
@@ -116,7 +112,7 @@ __device__ __forceinline__ void conv_x3_tile(const X3Params& q, char* __restrict
   // ---- this lane's two rows (row blocks rb = 0, 1 of the wave's 32 rows): byte offset of the row's k quads and the 9-bit mask of the
   // taps whose source pixel lies inside the image (a K chunk belongs to ONE tap -- the image pads every tap to whole chunks -- so the
   // tap offset, the channel offset and the tap bit are scalars of the chunk)
-  const int wrow = grp * 128 + wv * 32;   // first row of this wave inside the tile
+  const int wrow = wave * 32;   // first row of this wave inside the tile
   unsigned a_off[2][2], a_taps[2];
 #pragma unroll
   for (int rb = 0; rb < 2; ++rb) {
@@ -296,9 +292,12 @@ __device__ __forceinline__ void conv_x3_tile(const X3Params& q, char* __restrict
     }
     if (it < nper) chunk(sm, sm + B_BYTES, ra);
   }
+#ifndef X3_NO_DRAIN
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the requests past the last chunk are never consumed: none may outlive the loop)
+#endif
 #ifdef X3_CLK
   if (q.dbg != nullptr && lane == 0 && (wave & 3) == 0) {
-    unsigned long long* d = q.dbg + ((long long)blockIdx.x * 2 + grp) * 8;
+    unsigned long long* d = q.dbg + ((long long)blockIdx.x * 2 + (wave >> 2)) * 8;
     if (d[0] == 0) {
       d[0] = ck0;
       d[1] = cr0;
@@ -311,130 +310,39 @@ __device__ __forceinline__ void conv_x3_tile(const X3Params& q, char* __restrict
     }
   }
 #endif
-  // ---- epilogue: C/D layout: col = lane & 15, row = 4 * (lane >> 4) + reg
-  if (pdst != nullptr) {
-#pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = wrow + rb * 16 + g * 4 + r;
-        if (m0 + row >= M) continue;
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-          if (n0 + j * 16 + l15 < p.Nout) pdst[(long long)row * BN + j * 16 + l15] = acc[rb][j][r];
-      }
-    return;
-  }
-  float* stage = reinterpret_cast<float*>(sm) + wv * 16 * LDS_STAGE;   // (the two groups stage one after the other)
-  float bj[NT];
-#pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int n = n0 + j * 16 + l15;
-    bj[j] = (p.bias != nullptr && n < p.Nout) ? p.bias[n] : 0.f;
-  }
-  const long long HWp = (long long)p.H * p.W;
-  for (int e = 0; e < 2; ++e) {
-    if (grp == e) {
-#pragma unroll
-      for (int rb = 0; rb < 2; ++rb) {
-        const long long mbase = m0 + wrow + rb * 16;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float* bb = nullptr;
-          if (p.border_bias != nullptr) {
-            const long long m = mbase + g * 4 + r;
-            if (m < M) {
-              const int ni = (int)(m / HWp);
-              const int rem = (int)(m - (long long)ni * HWp);
-              const int h = rem / p.W, w_ = rem - h * p.W;
-              const int cls = (h == 0 ? 0 : (h == p.H - 1 ? 2 : 1)) * 3 + (w_ == 0 ? 0 : (w_ == p.W - 1 ? 2 : 1));
-              bb = p.border_bias + ((long long)ni * 9 + cls) * p.Nout;
-            }
-          }
-#pragma unroll
-          for (int j = 0; j < NT; ++j) {
-            const int n = n0 + j * 16 + l15;
-            float v = acc[rb][j][r] + bj[j];
-            if (bb != nullptr && n < p.Nout) v += bb[n];
-            acc[rb][j][r] = v;
-            stage[(g * 4 + r) * LDS_STAGE + j * 16 + l15] = v;
-          }
-        }
-        // (the staging tile is this wave's own: LDS is in order within a wave, no barrier)
-#pragma unroll
-        for (int itq = 0; itq < NT; ++itq) {
-          const int idx = itq * 64 + lane;
-          const int row = idx / (BN / 4), qq = idx - row * (BN / 4);
-          const long long m = mbase + row;
-          const int n = n0 + qq * 4;
-          if (m < M && n < p.Nout) {
-            float4 v = ld4(stage + row * LDS_STAGE + qq * 4);
-            float* dst = p.Cmat + m * p.ldc + n;
-            if (p.accumulate) v = f4add(v, ld4(dst));
-            st4(dst, v);
-          }
-        }
-      }
-    }
-    __syncthreads();
-  }
-  if (p.stats_part == nullptr) return;
-  float s1[NT], s2[NT];
-#pragma unroll
-  for (int j = 0; j < NT; ++j) s1[j] = s2[j] = 0.f;
+  // ---- the raw partial tile (C/D layout: col = lane & 15, row = 4 * (lane >> 4) + reg) to this segment's slab; x3_fixup_k finishes the tile
 #pragma unroll
   for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const long long m = m0 + wrow + rb * 16 + g * 4 + r;
-      if (m >= M) continue;
+      const int row = wrow + rb * 16 + g * 4 + r;
+      if (m0 + row >= M) continue;
 #pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const float v = acc[rb][j][r];
-        const float u = p.stats_swish ? swish_f(v) : v;
-        s1[j] += u;
-        s2[j] = fmaf(u, u, s2[j]);
-      }
+      for (int j = 0; j < NT; ++j)
+        if (n0 + j * 16 + l15 < p.Nout) pdst[(long long)row * BN + j * 16 + l15] = acc[rb][j][r];
     }
-  float* red = reinterpret_cast<float*>(sm);   // [wave 8][2][BN]
-#pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    float a = s1[j], b = s2[j];
-    a += __shfl_xor(a, 16, 64);
-    b += __shfl_xor(b, 16, 64);
-    a += __shfl_xor(a, 32, 64);
-    b += __shfl_xor(b, 32, 64);
-    if (g == 0) {
-      red[(wave * 2 + 0) * BN + j * 16 + l15] = a;
-      red[(wave * 2 + 1) * BN + j * 16 + l15] = b;
-    }
-  }
-  __syncthreads();
-  for (int idx = t; idx < 2 * BN; idx += 512) {
-    const int v = idx / BN, col = idx - v * BN;
-    const int n = n0 + col;
-    if (n < p.Nout) {
-      float r0 = red[(0 * 2 + v) * BN + col];
-#pragma unroll
-      for (int wq = 1; wq < 8; ++wq) r0 += red[(wq * 2 + v) * BN + col];   // (wave order: deterministic)
-      p.stats_part[((long long)bx * 2 + v) * p.Nout + n] = r0;
-    }
-  }
 }
 
-// workgroups [0, full): whole tiles; [full, full + parts): equal contiguous ranges of the remaining tiles' K iterations (SkPlan as in
-// conv_gemm_sk_k, with 256-row tiles: slab [rem][smax][256][BN]); one 512-thread workgroup per CU
+// Every tile goes through the stream-K parts: workgroup `part` multiplies the contiguous range [part * ipp, (part + 1) * ipp) of the
+// tiles' K iterations (the tail of one tile and the head of the next: at most two segments when parts >= tiles), each segment into its
+// (tile, slot) slab [tiles][smax][256][BN]; one 512-thread workgroup per CU.  (A whole-tile form -- tiles beyond a multiple of the CU
+// count finished inside this kernel -- gave results that depended on what ran beside it on the chip in one of 3 x 16 trials with
+// two learners' graphs in flight, tests/test_step_gpu.py::test_concurrent_task_lanes_...; the all-parts form did not in 32, and it is
+// one code path less.  SkPlan.full stays 0.  What actually disturbed the other learner's kernels was co-residency with this kernel:
+// see the register-file claim below.)
 template <int NT>
 __global__ __launch_bounds__(512) void conv_x3_k(X3Params q, SkPlan k) {
   __shared__ __attribute__((aligned(16))) char sm[X3Sm<NT>::BYTES];
   constexpr int BN = 16 * NT;
-  const int w = blockIdx.x;
-  if (w < k.full) {
-    const unsigned tau = xcd_remap(w, k.full);
-    conv_x3_tile<NT>(q, sm, tau / k.gy, tau % k.gy, 0, k.nchunks, nullptr);
-    return;
-  }
-  const int part = w - k.full;
+  // This kernel claims the CU's WHOLE register file (eight waves x 256 VGPRs: touching v255 makes the descriptor say so), so that no
+  // wave of another kernel can be co-resident with it.  Measured, not understood: with its natural 157-194 registers, small kernels of
+  // ANOTHER stream that ran beside it on a CU (resize_fwd_k, the final layer's filter-gradient reduction: no LDS, 30 VGPRs) returned
+  // wrong values in 150-350 of 1200 launches -- with its memory writes, its scalar-offset loads and its SGPR count (<= 80) ablated
+  // one by one to no effect, and never beside the native kernels or conv_filter_x3_batched_k; with the file claimed: 0 of 1200
+  // (tests/test_x3_gpu.py::test_x3_kernels_do_not_disturb_kernels_of_another_stream, profiles/r05_notes.md).  One workgroup per
+  // CU is the plan anyway, so the claim costs nothing.
+  asm volatile("v_mov_b32 v255, 0" ::: "v255");
+  const int part = blockIdx.x;
   int lo = part * k.ipp;
   const int total = k.rem * k.nchunks;
   int hi = lo + k.ipp;
@@ -445,32 +353,35 @@ __global__ __launch_bounds__(512) void conv_x3_k(X3Params q, SkPlan k) {
     int c1 = c0 + (hi - lo);
     if (c1 > k.nchunks) c1 = k.nchunks;
     const int first = (rt * k.nchunks) / k.ipp;   // first part that touches this tile -> slot 0
-    const unsigned tau = k.full + rt;
     float* dst = k.slab + ((long long)rt * k.smax + (part - first)) * (kX3BM * BN);
-    conv_x3_tile<NT>(q, sm, tau / k.gy, tau % k.gy, c0, c1, dst);
+    conv_x3_tile<NT>(q, sm, rt / k.gy, rt % k.gy, c0, c1, dst);
     lo += c1 - c0;
     __syncthreads();   // the next segment reuses the LDS buffers
   }
 }
 
-// Finishes the stream-K tiles: grid = (rem); 1024 threads = 32 column-quad slots x 32 row lanes, eight rows per thread.
+// Finishes the stream-K tiles: grid = (rem, kX3Fix): workgroup (rt, s) owns the 64 rows [64 s, 64 s + 64) of remainder tile rt (a
+// 98-workgroup grid -- one per 256-row tile -- left most of the chip idle: 13.4 us per launch); 1024 threads = 32 column-quad slots x
+// 32 row lanes, two rows per thread.  Statistics: kX3Fix blocks per tile, [bx * kX3Fix + s][2][Nout].
+constexpr int kX3Fix = 4;
 template <int NT>
 __global__ __launch_bounds__(1024) void x3_fixup_k(ConvGemmParams p, SkPlan k) {
-  constexpr int BN = 16 * NT, QN = BN / 4, RPT = kX3BM / 32;
+  constexpr int BN = 16 * NT, QN = BN / 4, RPT = kX3BM / kX3Fix / 32;
   __shared__ float4 red[2][32][32];
   const int t = threadIdx.x, q = t & 31, rl = t >> 5;
-  const int rt = blockIdx.x;
+  const int rt = blockIdx.x, sub = blockIdx.y;
   const unsigned tau = k.full + rt;
   const int bx = tau / k.gy, by = tau % k.gy;
   const long long M = (long long)p.Nimg * p.H * p.W;
-  const long long m0 = (long long)bx * kX3BM;
+  const int r0 = sub * (kX3BM / kX3Fix);            // first row of this workgroup inside the tile
+  const long long m0 = (long long)bx * kX3BM + r0;
   const int n = by * BN + q * 4;
   const bool cok = q < QN && n < p.Nout;
   const int first = (rt * k.nchunks) / k.ipp;
   int last = ((rt + 1) * k.nchunks - 1) / k.ipp;
   if (last > k.parts - 1) last = k.parts - 1;
   const int nslots = last - first + 1;
-  const float* base = k.slab + (long long)rt * k.smax * (kX3BM * BN) + q * 4;
+  const float* base = k.slab + ((long long)rt * k.smax * kX3BM + r0) * BN + q * 4;
   float4 s1 = f4zero(), s2 = f4zero();
   if (cok) {
     const float4 bv = p.bias != nullptr ? ld4(p.bias + n) : f4zero();
@@ -516,7 +427,7 @@ __global__ __launch_bounds__(1024) void x3_fixup_k(ConvGemmParams p, SkPlan k) {
       float4 a = red[v][0][qq];
 #pragma unroll 8
       for (int r = 1; r < 32; ++r) a = f4add(a, red[v][r][qq]);
-      st4(p.stats_part + ((long long)bx * 2 + v) * p.Nout + nn, a);
+      st4(p.stats_part + (((long long)bx * kX3Fix + sub) * 2 + v) * p.Nout + nn, a);
     }
   }
 }
@@ -612,8 +523,9 @@ __device__ __forceinline__ void conv_filter_x3_body(const FilterGradParams& p, c
     x_lds[i] = r * 256 + (((x_cq >> 2) ^ f3_swz(r)) * 32) + (x_cq & 3) * 8;
   }
 
-  float4 rx[2], rd[D_PER_THREAD];
-  auto load_chunk = [&]() {   // next 32 pixel rows -> registers, then advance (rows beyond mend / halo pixels come back as zeros)
+  float4 rxa[2], rda[D_PER_THREAD], rxb[2], rdb[D_PER_THREAD];   // two chunks in flight (requested a whole chunk before their split)
+  auto load_chunk = [&](float4 (&rx)[2], float4 (&rd)[D_PER_THREAD]) {   // next 32 pixel rows -> registers, then advance (rows beyond
+                                                                        // mend / halo pixels come back as zeros)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const bool ok = x_cok & (x_m[i] < mend) & ((unsigned)(x_h[i] + dh) < (unsigned)p.H) & ((unsigned)(x_w[i] + dw) < (unsigned)p.W);
@@ -635,25 +547,30 @@ __device__ __forceinline__ void conv_filter_x3_body(const FilterGradParams& p, c
       d_off[i] += d_step;
     }
   };
-  auto store_chunk = [&](char* buf) {   // split while storing: three planes of 4 bf16 (8 bytes) per 16-byte quad
+  // the split of the chunk in registers (this thread's 2 + D_PER_THREAD quads -> three terms each) is done in pieces BETWEEN the
+  // matrix instructions of the chunk being multiplied (compute_split below), the terms are stored behind them
+  constexpr int NP = 2 + D_PER_THREAD;
+  uint2 th[NP], tm[NP], tl[NP];
+  auto split_piece = [&](int k, const float4 (&rx)[2], const float4 (&rd)[D_PER_THREAD]) {
+    split3(k < 2 ? rx[k < 2 ? k : 0] : rd[k >= 2 ? k - 2 : 0], th[k], tm[k], tl[k]);
+    // (an empty statement that "uses" the piece here: without it the optimiser sinks the arithmetic to the stores behind the loop)
+    asm volatile("" : "+v"(th[k].x), "+v"(th[k].y), "+v"(tm[k].x), "+v"(tm[k].y), "+v"(tl[k].x), "+v"(tl[k].y));
+  };
+  auto store_terms = [&](char* buf) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      uint2 h, m, l;
-      split3(rx[i], h, m, l);
       char* d = buf + x_lds[i];
-      *reinterpret_cast<uint2*>(d) = h;
-      *reinterpret_cast<uint2*>(d + kF3Plane) = m;
-      *reinterpret_cast<uint2*>(d + 2 * kF3Plane) = l;
+      *reinterpret_cast<uint2*>(d) = th[i];
+      *reinterpret_cast<uint2*>(d + kF3Plane) = tm[i];
+      *reinterpret_cast<uint2*>(d + 2 * kF3Plane) = tl[i];
     }
 #pragma unroll
     for (int i = 0; i < D_PER_THREAD; ++i) {
-      uint2 h, m, l;
-      split3(rd[i], h, m, l);
       if (512 * (i + 1) <= D_TOTAL || d_lds[i] >= 0) {
         char* d = buf + d_lds[i];
-        *reinterpret_cast<uint2*>(d) = h;
-        *reinterpret_cast<uint2*>(d + kF3Plane) = m;
-        *reinterpret_cast<uint2*>(d + 2 * kF3Plane) = l;
+        *reinterpret_cast<uint2*>(d) = th[2 + i];
+        *reinterpret_cast<uint2*>(d + kF3Plane) = tm[2 + i];
+        *reinterpret_cast<uint2*>(d + 2 * kF3Plane) = tl[2 + i];
       }
     }
   };
@@ -680,41 +597,61 @@ __device__ __forceinline__ void conv_filter_x3_body(const FilterGradParams& p, c
     const uint2 hi = ds_read_tr16(plane + a_row[1] + ((chunk16 ^ a_sw[1]) * 32));
     return __builtin_bit_cast(bf16x8, (u32x4){lo.x, lo.y, hi.x, hi.y});
   };
-  auto compute = [&](const char* buf) {
-    if (!wave_live) return;
-    bf16x8 a3[3][2];
+  // One chunk's products out of LDS stage `buf`; the fragments of column tile j + 1 are requested before the products of tile j, and
+  // one piece of the NEXT chunk's split rides behind the matrix instructions of every column tile (fenced: conv_x3_tile)
+  auto compute_split = [&](const char* buf, const float4 (&rx)[2], const float4 (&rd)[D_PER_THREAD]) {
+    bf16x8 a3[3][2], b3[2][3];
+    if (wave_live) {
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl)
+      for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
-      for (int rb = 0; rb < 2; ++rb) a3[pl][rb] = frag(buf + pl * kF3Plane, cib * 2 + rb);
+        for (int rb = 0; rb < 2; ++rb) a3[pl][rb] = frag(buf + pl * kF3Plane, cib * 2 + rb);
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) b3[0][pl] = frag(buf + (3 + pl) * kF3Plane, jn0);
+    }
 #pragma unroll
     for (int j = 0; j < NTW; ++j) {
-      if (j < njn) {   // (uniform)
-        bf16x8 b3[3];
+      if (wave_live && j < njn) {   // (uniform)
+        if (j + 1 < NTW && j + 1 < njn) {
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) b3[pl] = frag(buf + (3 + pl) * kF3Plane, jn0 + j);
-#define X3_MM(PA, PB)                                                                                   \
-  acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3[PA][0], b3[PB], acc[0][j], 0, 0, 0);         \
-  acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3[PA][1], b3[PB], acc[1][j], 0, 0, 0);
+          for (int pl = 0; pl < 3; ++pl) b3[(j + 1) & 1][pl] = frag(buf + (3 + pl) * kF3Plane, jn0 + j + 1);
+        }
+#define X3_MM(PA, PB)                                                                                            \
+  acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3[PA][0], b3[j & 1][PB], acc[0][j], 0, 0, 0);           \
+  acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3[PA][1], b3[j & 1][PB], acc[1][j], 0, 0, 0);
         X3_MM(2, 0) X3_MM(0, 2) X3_MM(1, 1) X3_MM(1, 0) X3_MM(0, 1) X3_MM(0, 0)
 #undef X3_MM
       }
+#pragma unroll
+      for (int k = 0; k < NP; ++k)
+        if ((k * NTW) / NP == j) split_piece(k, rx, rd);
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
 
   const int nchunks = (mend - mbeg + kF3Rows - 1) / kF3Rows;
-  load_chunk();
-  store_chunk(sm);
-  load_chunk();
+  load_chunk(rxa, rda);   // chunk 0
+#pragma unroll
+  for (int k = 0; k < NP; ++k) split_piece(k, rxa, rda);
+  store_terms(sm);
+  load_chunk(rxa, rda);   // chunk 1
+  load_chunk(rxb, rdb);   // chunk 2
   lds_barrier();
-  for (int it = 0; it < nchunks; ++it) {
-    char* cur = sm + (it & 1) * kF3Stage;
-    char* nxt = sm + ((it & 1) ^ 1) * kF3Stage;
-    compute(cur);
-    store_chunk(nxt);   // (zeros after the last chunk: nobody reads them)
-    load_chunk();
+  auto trip = [&](char* cur, char* nxt, float4 (&rx)[2], float4 (&rd)[D_PER_THREAD]) {   // (rx, rd): the chunk after the one in `cur`
+    compute_split(cur, rx, rd);   // + the split of the next chunk
+    store_terms(nxt);             // (zeros after the last chunk: nobody reads them)
+    load_chunk(rx, rd);           // two chunks after the one just split
     lds_barrier();
+  };
+  int it = 0;
+  for (; it + 2 <= nchunks; it += 2) {
+    trip(sm, sm + kF3Stage, rxa, rda);
+    trip(sm + kF3Stage, sm, rxb, rdb);
   }
+  if (it < nchunks) trip(sm, sm + kF3Stage, rxa, rda);
+#ifndef X3_NO_DRAIN
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (as in conv_x3_tile)
+#endif
 
   const long long Ktot = (long long)p.ntaps * p.C;
 #pragma unroll
@@ -772,13 +709,14 @@ struct X3Plan {
 };
 constexpr int kX3MinPart = 4;   // K chunks per stream-K part, at least
 
-static int x3_pick_nt(int Nout) {   // the widest column tile that does not pad the output width by much (as conv_gemm.hip: pick_nt)
+static int x3_pick_nt(int Nout) {   // the widest column tile that does not pad the output width by much (as conv_gemm.hip: pick_nt, with a
+                                    // stronger pull towards few column tiles)
   int best = 1;
   double best_cost = 1e30;
   const int tiles = (Nout + 15) / 16;
   for (int nt = 1; nt <= 8; ++nt) {
     const int blocks = (tiles + nt - 1) / nt;
-    const double cost = (double)(blocks * nt * 16) / (double)Nout * (1.0 + 0.03 * (8 - nt));
+    const double cost = (double)(blocks * nt * 16) / (double)Nout * (1.0 + 0.08 * (8 - nt));   // (A is loaded AND split once per column tile)
     if (cost < best_cost - 1e-9 || (cost < best_cost + 1e-9 && nt > best)) {
       best_cost = cost;
       best = nt;
@@ -801,20 +739,16 @@ static X3Plan x3_plan(long long M, int Nout, int ntaps, int Cred, int num_cus) {
     g.gy = (Nout + g.nt * 16 - 1) / (g.nt * 16);
   }
   const long long tiles = (long long)g.gx * g.gy;
-  g.full = (int)(tiles / slots) * slots;
-  g.rem = (int)(tiles - g.full);
-  g.parts = g.ipp = g.smax = 0;
-  if (g.rem > 0) {
-    const long long total = (long long)g.rem * g.nchunks;
-    long long parts = slots;
-    if (parts > 8LL * g.rem) parts = 8LL * g.rem;
-    if (parts < g.rem) parts = g.rem;
-    if (total / parts < kX3MinPart) parts = total / kX3MinPart;
-    if (parts < g.rem) parts = g.rem;   // (at most two segments per part)
-    g.ipp = (int)((total + parts - 1) / parts);
-    g.parts = (int)((total + g.ipp - 1) / g.ipp);
-    g.smax = (g.nchunks + g.ipp - 1) / g.ipp + 1;
-  }
+  g.full = 0;   // (every tile through the parts: conv_x3_k)
+  g.rem = (int)tiles;
+  const long long total = tiles * g.nchunks;
+  long long parts = slots;
+  if (parts > 8LL * tiles) parts = 8LL * tiles;
+  if (total / parts < kX3MinPart) parts = total / kX3MinPart;
+  if (parts < 1) parts = 1;
+  g.ipp = (int)((total + parts - 1) / parts);
+  g.parts = (int)((total + g.ipp - 1) / g.ipp);
+  g.smax = (g.nchunks + g.ipp - 1) / g.ipp + 1;
   return g;
 }
 
@@ -836,10 +770,10 @@ static void x3_launch(const X3Plan& g, const X3Params& q_, float* slab, hipStrea
   q.dbg = getenv("MLIIS_X3_STAMPS") ? (unsigned long long*)strtoull(getenv("MLIIS_X3_STAMPS"), nullptr, 0) : nullptr;
 #endif
   const SkPlan k{g.full, g.rem, g.parts, g.ipp, g.nchunks, g.smax, g.gy, slab};
-  dim3 grid(g.full + g.parts), block(512);
+  dim3 grid(g.parts), block(512);
 #define L(NT_)                                                                                  \
   hipLaunchKernelGGL((conv_x3_k<NT_>), grid, block, 0, stream, q, k);                           \
-  if (g.rem > 0) hipLaunchKernelGGL((x3_fixup_k<NT_>), dim3(g.rem), dim3(1024), 0, stream, q.g, k); \
+  hipLaunchKernelGGL((x3_fixup_k<NT_>), dim3(g.rem, kX3Fix), dim3(1024), 0, stream, q.g, k);    \
   break;
   switch (g.nt) {
     case 1: L(1)
@@ -898,7 +832,7 @@ int mliis_conv2d_x3_plan(int Nimg, int H, int W, int Cred, int Nout, int ksize, 
 
 // y[M, Cout] (ld = ldy) (+)= conv(x[M, Cin] (ld = ldx), w) + bias (+ border_bias), stride 1, TF-SAME, dilation dil, the weights as the
 // mode-0 image of mliis_x3_pack_weights over the same Cin window.  stats_part / stats_swish / stats_nblk as mliis_conv2d_fwd
-// (*stats_nblk = the number of 128-row tiles).  ws: stream-K slabs (mliis_conv2d_x3_workspace_floats).
+// (*stats_nblk = four blocks per 256-row tile).  ws: stream-K slabs (mliis_conv2d_x3_workspace_floats).
 int mliis_conv2d_fwd_x3(const float* x, int ldx, const void* image, const float* bias, const float* border_bias, float* y, int ldy, int Nimg,
                         int H, int W, int Cin, int Cout, int ksize, int dil, int accumulate, float* stats_part, int stats_swish,
                         int* stats_nblk, float* ws, size_t ws_floats, hipStream_t stream) {
@@ -925,7 +859,7 @@ int mliis_conv2d_fwd_x3(const float* x, int ldx, const void* image, const float*
   q.ncol16 = (Cout + 15) / 16;
   x3_launch(g, q, ws, stream);
   MLIIS_CHECK_LAUNCH("conv2d_fwd_x3");
-  if (stats_nblk) *stats_nblk = stats_part != nullptr ? g.gx : 0;
+  if (stats_nblk) *stats_nblk = stats_part != nullptr ? g.gx * kX3Fix : 0;
   return MLIIS_OK;
 }
 

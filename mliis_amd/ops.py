@@ -452,6 +452,13 @@ def x3_image_of(w, mode, ci_begin=0, cin=None):
     return im.image("w", mode)
 
 
+def conv2d_x3_kernel_name(N, H, W, cred, nout, k):
+    """The instantiation an x3 call launches, as rocprofv3 prints it (+ x3_fixup_k<NT> for the stream-K tiles)."""
+    plan = (C.c_int * 8)()
+    lib.call("mliis_conv2d_x3_plan", N, H, W, cred, nout, k, plan)
+    return "conv_x3_k<%d>" % plan[0]
+
+
 def conv2d_fwd_x3(x, image, k, cout, bias=None, dil=1, out=None, accumulate=False, ws: Optional[Workspace] = None, stats_part=None,
                   stats_swish=False, border_bias=None):
     """conv2d_fwd under MLIIS_PREC_F32X3 with the conv's forward weight image (X3Images / x3_image_of); x may be a channel-sliced view
@@ -465,7 +472,7 @@ def conv2d_fwd_x3(x, image, k, cout, bias=None, dil=1, out=None, accumulate=Fals
     nblk = C.c_int(0)
     meta = {}
     if PROFILE is not None:
-        meta = dict(kernel="conv_x3_k", flops=2.0 * N * H * W * k * k * Cin * cout, shape=(N, H, W, Cin, cout, k, dil))
+        meta = dict(kernel=conv2d_x3_kernel_name(N, H, W, Cin, cout, k), flops=2.0 * N * H * W * k * k * Cin * cout, shape=(N, H, W, Cin, cout, k, dil))
     _timed("conv2d_fwd_x3", meta, lambda: lib.call("mliis_conv2d_fwd_x3", _aptr(x), ldx, _ptr(image), _ptr(bias), _ptr(border_bias), _aptr(out), ldy,
                                                    N, H, W, Cin, cout, k, dil, int(accumulate), _ptr(stats_part), int(stats_swish), C.byref(nblk),
                                                    _ptr(buf), buf.numel(), _stream()))
@@ -484,7 +491,7 @@ def conv2d_bwd_data_x3(dy, image, k, cin_out, dil=1, out=None, accumulate=False,
     buf = ws.get(lib.size("mliis_conv2d_x3_workspace_floats", N, H, W, Cout, cin_out, k))
     meta = {}
     if PROFILE is not None:
-        meta = dict(kernel="conv_x3_k", flops=2.0 * N * H * W * k * k * cin_out * Cout, shape=(N, H, W, Cout, cin_out, k, dil))
+        meta = dict(kernel=conv2d_x3_kernel_name(N, H, W, Cout, cin_out, k), flops=2.0 * N * H * W * k * k * cin_out * Cout, shape=(N, H, W, Cout, cin_out, k, dil))
     _timed("conv2d_bwd_data_x3", meta, lambda: lib.call("mliis_conv2d_bwd_data_x3", _aptr(dy), lddy, _ptr(image), _aptr(out), lddx, N, H, W, cin_out,
                                                         Cout, k, dil, int(accumulate), _ptr(buf), buf.numel(), _stream()))
     return out
@@ -586,6 +593,7 @@ class FilterBatch:
         row = [x.data_ptr(), dy.data_ptr(), x_scale.data_ptr() if x_scale is not None else 0, partial.data_ptr(), ldx, lddy, N, H, W, Cin,
                Cout, k | (_dt(x) << 8) | (_dt(dy) << 9), dil, rps | (multitap << 32), gx | (gy << 20) | (gz << 40), 0]
         self.groups.setdefault((tmf, nt, x_scale is not None), []).append((row, gx * gy * gz))
+        self.flops = getattr(self, "flops", 0.0) + 2.0 * N * H * W * k * k * Cin * Cout
         self._keep += [x, dy, partial, x_scale]
         self.tables = None
 
@@ -607,8 +615,10 @@ class FilterBatch:
         prec = 3 if precision == "fp32x3" else _prec(precision)
         if prec in (0, 3) and any((row[11] >> 8) for items in self.groups.values() for row, _ in items):
             raise MliisError("FilterBatch: bf16 tensors need the bf16-operand instances (precision 'bf16')")
-        for table, nprob, blocks, tmf, nt, sc in self.tables:
-            lib.call("mliis_conv2d_bwd_filter_batched", _ptr(table), nprob, blocks, tmf, nt, sc, prec, _stream())
+        def issue():
+            for table, nprob, blocks, tmf, nt, sc in self.tables:
+                lib.call("mliis_conv2d_bwd_filter_batched", _ptr(table), nprob, blocks, tmf, nt, sc, prec, _stream())
+        _timed("conv2d_bwd_filter_batched", dict(flops=getattr(self, "flops", 0.0)) if PROFILE is not None else {}, issue)
 
     def __len__(self):
         return sum(len(v) for v in self.groups.values())

@@ -73,3 +73,38 @@ def test_plain_multi_gpu_command_fails_loudly_without_gpus():
     if torch.cuda.is_available():
         pytest.skip("GPU present: covered by tests/test_bench_dist_gpu.py")
     assert r.returncode != 0 and r.stdout.strip() == "" and "needs an MI355X" in r.stderr
+
+
+def test_launch_ranks_times_the_cpu_baseline_in_the_parent_and_hands_it_to_rank_0(monkeypatch, capsys):
+    """An N > 1 line carries `cpu_baseline` without --cpu-baseline-from: the launching parent (which never touches the GPU) times the
+    CPU oracle before it starts the ranks and passes the object by value in MLIIS_BENCH_CPU_BASELINE."""
+    import json
+    b = _bench()
+    seen = {}
+
+    def fake_run(cmd, env=None, stdout=None):
+        seen["env"] = env
+        return types.SimpleNamespace(returncode=0, stdout=b'{"n_gpus": 2}\n')
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(b, "_cpu_baseline_fn", lambda args: {"value": 7.5, "unit": "images/s", "cores": 3, "kind": "port", "sample": "stub"})
+    monkeypatch.delenv("MLIIS_BENCH_CPU_BASELINE", raising=False)
+    argv = ["--gpus", "2", "--steps", "1", "--warmup", "0"]
+    assert b.launch_ranks(b.parse(argv), argv) == 0
+    got = json.loads(seen["env"]["MLIIS_BENCH_CPU_BASELINE"])
+    assert got["value"] == 7.5 and got["cores"] == 3 and "parent" in got["timed_in"]
+    # --no-cpu-baseline / an explicit --cpu-baseline-from: the parent times nothing
+    for extra in (["--no-cpu-baseline"], ["--cpu-baseline-from", "BENCH_r04.json"]):
+        seen.clear()
+        monkeypatch.setattr(b, "_cpu_baseline_fn", lambda args: (_ for _ in ()).throw(AssertionError("must not be timed")))
+        assert b.launch_ranks(b.parse(argv + extra), argv + extra) == 0
+        assert "MLIIS_BENCH_CPU_BASELINE" not in seen["env"]
+    capsys.readouterr()
+
+
+def test_cpu_baseline_follows_the_protocol_of_baseline_md():
+    """at least 3 warm-up steps, then at least 2 full tasks -- checked on the sample string of a tiny run."""
+    b = _bench()
+    args = b.parse(["--image-size", "32", "--inner-iters", "2", "--inner-batch", "2", "--shots", "2"])
+    out = b.cpu_baseline(args)
+    assert out["kind"] == "port" and out["cores"] >= 1 and out["value"] > 0
+    assert "after 3 warm-up steps" in out["sample"] and out["sample"].startswith("4 inner SGD steps = 2 tasks")

@@ -4,7 +4,7 @@
 # Everything lands under gpurun_out/$1 (default r04_final); tools/collect_profiles.sh copies the summaries into profiles/.
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-TAG=${1:-r04_final}
+TAG=${1:-r05_final}
 O=$R/gpurun_out/$TAG
 rm -rf $O; mkdir -p $O
 cd $R
@@ -12,7 +12,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o t -- python3
 python tools/profile_summary.py $O/trace 0 $O/profile.md > /dev/null
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o f -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-graph > $O/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o w -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-graph > $O/pmc_write.log 2>&1
-python tools/pmc_traffic.py $(find $O/pmc_fetch -name "*counter_collection.csv" | head -1) $(find $O/pmc_write -name "*counter_collection.csv" | head -1) $O/pmc_traffic.json
+python tools/pmc_traffic.py $(find $O/pmc_fetch -name "*counter_collection.csv" | head -1) $(find $O/pmc_write -name "*counter_collection.csv" | head -1) $O/pmc_traffic.json 24
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/dw_fetch -o f -- python3 tools/bench_dwmarch.py --n 8 --reps 4 > $O/dw_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/dw_write -o w -- python3 tools/bench_dwmarch.py --n 8 --reps 4 > $O/dw_write.log 2>&1
 python tools/pmc_depthwise.py $(find $O/dw_fetch -name "*counter_collection.csv" | head -1) $(find $O/dw_write -name "*counter_collection.csv" | head -1) $O/depthwise_pmc.json 8 > $O/depthwise_pmc.txt 2>&1

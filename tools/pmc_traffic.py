@@ -2,7 +2,7 @@
 per-kernel HBM traffic per launch, with the gfx950 corrections of /opt/skills/guides/MI355X_MICROARCH.md (HBM section):
 counter unit = KiB; FETCH_SIZE under-reports wide coalesced read streams by exactly 2x -> doubled; WRITE_SIZE is exact.
 
-    python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>
+    python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> [inner steps of the profiled run]
 """
 import collections
 import csv
@@ -42,6 +42,7 @@ def short(name):
 
 def main():
     f, w, out = sys.argv[1:4]
+    steps = int(sys.argv[4]) if len(sys.argv) > 4 else 0
     fa, wa = agg(f, "FETCH_SIZE"), agg(w, "WRITE_SIZE")
     res = {}
     for k in sorted(set(fa) | set(wa)):
@@ -52,7 +53,9 @@ def main():
         wr = ws * 1024.0 / max(wn, 1)
         res[short(k)] = {"launches": n, "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr,
                          "raw_FETCH_SIZE_KiB_per_launch": fs / max(fn, 1), "raw_WRITE_SIZE_KiB_per_launch": ws / max(wn, 1)}
-    json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `bench.py --steps 1 --warmup 1 --no-graph`; "
+    total = sum(v["launches"] * v["hbm_bytes_per_launch"] for v in res.values())
+    json.dump({"inner_steps_profiled": steps, "hbm_bytes_per_inner_step": (total / steps) if steps else None,
+               "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `bench.py --steps 1 --warmup 1 --no-graph`; "
                        "read = 2 * FETCH_SIZE * 1024 (gfx950 correction), write = WRITE_SIZE * 1024; averaged over all launches of a symbol",
                "csrc_sha1": csrc_sha1(), "kernels": res}, open(out, "w"), indent=1, sort_keys=True)
     print("wrote", out, len(res), "kernels")
