@@ -299,12 +299,16 @@ def roofline(L, args):
             bufs, variants = [], []
             for r in range(copies):
                 args_r = list(a)
-                for ix, which in rot.items():
+                same = {}                       # arguments that ALIAS in the recorded call alias in the re-issue too (a layer whose producer
+                for ix, which in rot.items():   # already wrote the group-blocked z0 passes one tensor as z0 and as its blocked copy)
                     if args_r[ix] is None:      # (a nullable tensor argument that this launch does not use)
+                        continue
+                    if a[ix] in same:
+                        args_r[ix] = same[a[ix]]
                         continue
                     buf = torch.empty(int(el[which]), dtype=torch.float32, device=L.device).normal_()
                     bufs.append(buf)
-                    args_r[ix] = buf.data_ptr()
+                    args_r[ix] = same[a[ix]] = buf.data_ptr()
                 for ix in nulled:
                     args_r[ix] = None
                 if n == "mliis_dwconv_bn_fwd" and args_r[3] is not None:   # batch statistics the launch writes: not into the learner's

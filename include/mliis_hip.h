@@ -117,7 +117,10 @@ int mliis_dwconv_bn_bwd(const float* dy, const float* z, const float* bn_mean, c
                         hipStream_t stream);
 /*      Storage types (MLIIS_DT_*): forward (in_dtype of z, out_dtype of y) in {(F32, F32), (F32, BF16), (BF16, BF16)}; backward (dy_dtype of
  *      dy [and z1], zx_dtype of z and dx) in {(F32, F32), (BF16, F32), (BF16, BF16)} -- the fp32 sides are a block's fp32 input / input
- *      gradient (block 0 behind the stem, blocks without an expand conv).  Statistics are formed from the values as stored. */
+ *      gradient (block 0 behind the stem, blocks without an expand conv).  Statistics are formed from the values as stored -- with ONE
+ *      exception: the 5x5 FORWARD kernel with a bf16 output sums its fp32 accumulators (rounding them first costs the kernel
+ *      registers it does not have); the backward normalises the stored z1 with that mean / rstd.  oracle/efficientlab_ref.py models
+ *      exactly this (batch_norm(stats_of=...)). */
 
 /*      mliis_mbconv_dw_bwd_march: the same backward with the depthwise batch norm's (bn1, efficientnet_model.py:271) backward APPLY
  *      formed while its operands are staged: da2 = the project conv's backward-data output (gradient w.r.t. a1 * gate), z1 = bn1's

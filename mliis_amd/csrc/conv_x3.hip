@@ -335,12 +335,13 @@ __global__ __launch_bounds__(512) void conv_x3_k(X3Params q, SkPlan k) {
   __shared__ __attribute__((aligned(16))) char sm[X3Sm<NT>::BYTES];
   constexpr int BN = 16 * NT;
   // This kernel claims the CU's WHOLE register file (eight waves x 256 VGPRs: touching v255 makes the descriptor say so), so that no
-  // wave of another kernel can be co-resident with it.  Measured, not understood: with its natural 157-194 registers, small kernels of
-  // ANOTHER stream that ran beside it on a CU (resize_fwd_k, the final layer's filter-gradient reduction: no LDS, 30 VGPRs) returned
-  // wrong values in 150-350 of 1200 launches -- with its memory writes, its scalar-offset loads and its SGPR count (<= 80) ablated
-  // one by one to no effect, and never beside the native kernels or conv_filter_x3_batched_k; with the file claimed: 0 of 1200
-  // (tests/test_x3_gpu.py::test_x3_kernels_do_not_disturb_kernels_of_another_stream, profiles/r05_notes.md).  One workgroup per
-  // CU is the plan anyway, so the claim costs nothing.
+  // wave of another kernel can be co-resident with it.  Measured, not understood (profiles/r05_notes.md, tools/x3_race_probe.py): with
+  // its natural 157-194 registers, small kernels of ANOTHER stream that ran beside it on a CU (resize_fwd_k, the final layer's
+  // filter-gradient reduction: no LDS, 30 VGPRs) returned wrong values in 150-350 of 1200 launches -- with its memory writes, its
+  // scalar-offset loads and its SGPR count ablated one by one to no effect, and never beside the native kernels; with the file
+  // claimed: 0 of 1200 for this kernel alone.  (Together with conv_filter_x3_batched_k on the same stream the victims are still
+  // disturbed now and then, so the meta-learner's concurrent lanes do not use the split-product kernels at all: reptile.py.)  One
+  // workgroup per CU is the plan anyway: the claim costs nothing.
   asm volatile("v_mov_b32 v255, 0" ::: "v255");
   const int part = blockIdx.x;
   int lo = part * k.ipp;

@@ -1,5 +1,9 @@
 // Depthwise k x k convolution (k in {3,5}, stride in {1,2}, TF-SAME padding), NHWC fp32: forward, backward-data,
-// backward-filter.  Reference call sites: models/efficientnet/efficientnet_model.py:190-196,271 and
+// backward-filter.
+// WHO STILL CALLS THIS FILE (since round 3 the MBConv blocks of the training step run the row-marching kernels of dwmarch.hip and the
+// fused small-map kernels of mbconv_small.hip): the depthwise convs of the `--skip_decoding` decoder's separable convs, blocks in
+// inference / evaluation at shapes neither fused family takes (their *_supported queries), and Learner(small_fused=False, dw_march=False),
+// the op-by-op path that tests/test_step_gpu.py::test_one_step_grads_params_bn[small_fused=False] keeps covered.  Reference call sites: models/efficientnet/efficientnet_model.py:190-196,271 and
 // models/efficientnet/utils.py:219-222 (keras DepthwiseConv2D, depth_multiplier 1, no bias).
 //
 // HBM-bound (arithmetic intensity 0.9-6.2 flop/B).  Lanes run along C in float4, so one wave

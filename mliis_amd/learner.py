@@ -250,7 +250,10 @@ class Learner(_Passes):
             self._out(v)
         return st
 
-    def import_all(self, st):
+    def import_all(self, st, external: bool = False):
+        """Restore every variable from an export_all() state.  external=True: the state comes from OUTSIDE this training run (a
+        checkpoint), so concurrent lanes must take over its Adam slots too (adam_epoch); the evaluation path's own save / restore
+        around a fine-tune (reptile.py: _evaluate) is not such an event -- it must not erase the lanes' second-moment history."""
         self._in()
         with torch.cuda.stream(self.stream):
             self.arena.theta.copy_(st["theta"])
@@ -258,7 +261,8 @@ class Learner(_Passes):
             if self.adam_v is not None and "adam_v" in st:
                 self.adam_v.copy_(st["adam_v"])
                 self.adam_t.copy_(st["adam_t"])
-                self.adam_epoch += 1
+                if external:
+                    self.adam_epoch += 1
 
     def import_adam(self, adam_v: torch.Tensor, adam_t: torch.Tensor):
         """Replace only the Adam slots (second moments + step count): how a lane takes over the main learner's restored optimizer state."""
@@ -337,6 +341,22 @@ class Learner(_Passes):
             self.adam_epoch += 1
         torch.cuda.synchronize(self.device)
         return n
+
+    def disable_split_products(self):
+        """Back to the native fp32 matrix instruction for the decoder convs (matmul_precision "fp32-native"): the concurrent-lanes
+        variant calls this (reptile.py).  Captured graphs hold the x3 launches: dropped, the next step of each plan is eager again."""
+        if self.x3 is None:
+            return
+        self.stream.synchronize()
+        self.x3 = None
+        self.x3_on = False
+        for P in self.plans.values():
+            if P.graphs:
+                for gexec in P.graphs.values():
+                    lib.call("mliis_graph_destroy", gexec)
+                P.graphs = {}
+                P.steps_run = 0
+            P.wbatch_ready = False   # (the deferred filter-gradient batch is launched with the learner's precision: rebuilt)
 
     def _on_workspace_grow(self, floats: int):
         """The shared scratch buffer is about to be replaced by a larger one (a plan with more images than any before).  Captured

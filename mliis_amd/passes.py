@@ -473,6 +473,9 @@ class _Passes:
                 bn1_stage1 = (P.stage1_se, N)
             else:
                 if not groups:
+                    if B["small"] and B["blk"]:   # (da2 is group-blocked here, a1 is not: their product needs the launch's own partial sums)
+                        raise MliisError("internal: the project backward-data launch of block {} left no gate-gradient partials for its "
+                                         "group-blocked output".format(b.idx))
                     ops.colsum(da2, B["a1"], nseg=N, out=B["dgate"], ws=ws)
                 # (the SE weight gradients of all blocks are computed by one batched launch after the loop: P.se_desc)
                 ops.se_mlp_bwd(P.gate_part if groups else B["dgate"], B["gate"], B["s"], B["hpre"], w[se[0]], w[se[2]], hw, se_outs,

@@ -118,6 +118,14 @@ class Gecko:
         for ln in self.lanes:
             if ln.n_trainable != learner.n_trainable or getattr(ln, "optimizer", "sgd") != getattr(learner, "optimizer", "sgd"):
                 raise ValueError("lanes must share the learner's architecture and inner optimizer")
+        if self.lanes:
+            # Several learners' HIP graphs in flight: every learner falls back to the native fp32 matrix instruction for the decoder
+            # convs.  Measured (profiles/r05_notes.md): while the split-product kernels of one stream run, small kernels of ANOTHER
+            # stream that execute beside them return wrong values now and then; one stream alone is unaffected.  Not understood, so
+            # not risked: the concurrent-lanes variant does not use those kernels.
+            for ln in [learner] + self.lanes:
+                if getattr(ln, "x3", None) is not None:
+                    ln.disable_split_products()
         self._transductive = transductive
         # pre_step_op: the reference passes a TF op that multiplies all trainables by `weight_decay_rate`
         # (variables.py:48-55); here it is that rate (float) or None.
@@ -293,9 +301,8 @@ class Gecko:
         ep = getattr(L, "adam_epoch", None)
         if getattr(L, "adam_v", None) is None or ep is None or ep == self._lane_adam_epoch:
             return
-        st = L.export_all()
         for ln in self.lanes:
-            ln.import_adam(st["adam_v"], st["adam_t"])
+            ln.import_adam(L.adam_v, L.adam_t)
         self._lane_adam_epoch = ep
 
     def _task_batches(self, n_shots, inner_batch_size, inner_iters, replacement, rng):

@@ -472,7 +472,9 @@ def test_concurrent_task_lanes_equal_the_sequential_meta_step(fomaml, H, bs):
         tasks.append(DeviceTask("t%d" % i, torch.tensor(x).to(dev), torch.tensor(y).to(dev)))
 
     def run(n_lanes):
-        L = Learner(image_size=H, seed=1, use_graph=True, drop_connect=False)
+        # (concurrent lanes run the native fp32 matrix instruction -- Learner.disable_split_products, profiles/r05_notes.md -- so the
+        #  task-by-task loop they must reproduce bit for bit is the one on that instruction too)
+        L = Learner(image_size=H, seed=1, use_graph=True, drop_connect=False, matmul_precision="fp32" if n_lanes else "fp32-native")
         lanes = [Learner(image_size=H, seed=50 + k, use_graph=True, drop_connect=False) for k in range(n_lanes)]
         kw = dict(rng_mode="per_task", seed=9, lanes=lanes)
         meta = FOMLIS(L, train_shots=10, tail_shots=5, **kw) if fomaml else Gecko(L, **kw)
@@ -728,7 +730,13 @@ def test_full_size_eight_step_task_config2(precision):
 
 
 # ------------------------------------------------------------------------------------------------ reduced-precision configs
-def _lowp_step_check(name, H, N, precision, steps, loss_tol, cos_min, l2_max, later_loss_tol, seed=13, vs_exact_factor=0.0, vs_exact_floor=0.0):
+# config 4 as stated, calibrated on the float32 oracle (profiles/r05_notes.md, item 5): (device worst step / float32 oracle's worst step,
+# device at a step / float32 oracle's running maximum up to that step).  Measured 1.50 and 3.30; MLIIS_TEST_VERBOSE=1 prints every step.
+FP32_FACTOR = (2.5, 5.0)
+
+
+def _lowp_step_check(name, H, N, precision, steps, loss_tol, cos_min, l2_max, later_loss_tol, seed=13, vs_exact_factor=0.0, vs_exact_floor=0.0,
+                     fp32_oracle_factor=0.0):
     """One step of the HIP learner with reduced-precision matrix-core operands against the float64 oracle with the SAME operand
     rounding emulated (oracle/efficientlab_ref.py round_ops: every matrix-core conv multiplies rounded operands in the forward and in
     both backward products) and against the exact oracle.  The op-level tests pin the arithmetic bit-faithfully (tests/test_ops_gpu.py:
@@ -753,8 +761,17 @@ def _lowp_step_check(name, H, N, precision, steps, loss_tol, cos_min, l2_max, la
         assert P.act_dtype == torch.bfloat16 and all(B["z1"].dtype == torch.bfloat16 and B["da2"].dtype == torch.bfloat16 for B in P.blocks)
         fam = {b.idx: ("small" if B["small"] else "march") for b, B in zip([b for b in L.arch.blocks if b.executed], P.blocks)}
         Or.store = lambda blk: fam.get(blk["idx"])
+    Of = None
+    if fp32_oracle_factor:
+        # the measured sensitivity of the trajectory to fp32 arithmetic: the SAME rounded / storage-rounded oracle run in float32 (an
+        # independent fp32 implementation of the step: PyTorch-CPU kernels, other summation orders) beside the float64 one
+        Of = R.OracleLearner(name=name, image_size=H, seed=0, dtype=torch.float32, lr=1e-3, drop_connect=False, round_ops=ops_prec)
+        Of.store = Or.store
+        xf, yf = torch.tensor(x).float(), torch.tensor(y).float()
     lo_r, g_r, _ = R.inner_step(Or.a, Or.params, Or.bn, xd, yd, 1e-3, round_ops=ops_prec, store=Or.store)
     lo_x, g_x, _ = R.inner_step(Ox.a, Ox.params, Ox.bn, xd, yd, 1e-3)
+    if Of is not None:
+        Of.inner_step(xf[idx], yf[idx])
     L.inner_step(idx)
     ll = ll0 = L.loss_value()
     gL = L.arena.export_grad_packed().cpu().double()
@@ -765,18 +782,30 @@ def _lowp_step_check(name, H, N, precision, steps, loss_tol, cos_min, l2_max, la
     assert abs(ll - lo_r) <= loss_tol * abs(lo_r), (ll, lo_r)
     assert cos >= cos_min and l2_r <= l2_max, (cos, l2_r)
     assert l2_r < l2_x, (l2_r, l2_x)          # the rounding model explains the device result better than exact arithmetic does
-    worst = worst_rx = 0.0
+    worst = worst_rx = spread = ratio = 0.0
     for step in range(1, steps):
         lo = Or.inner_step(xd[idx], yd[idx])
         L.inner_step(idx)
         ll = L.loss_value()
         worst = max(worst, abs(ll - lo) / abs(lo))
+        if Of is not None:
+            lf = Of.inner_step(xf[idx], yf[idx])
+            spread = max(spread, abs(lf - lo) / abs(lo))   # how far fp32 arithmetic has moved the trajectory by this step
+            dev = abs(ll - lo) / abs(lo)
+            ratio = max(ratio, dev / max(spread, 1e-4))
+            if os.environ.get("MLIIS_TEST_VERBOSE"):
+                print("  step %2d: device %.5f (%.2e)  float32 oracle %.5f (%.2e)  float64 oracle %.5f" % (step, ll, dev, lf, abs(lf - lo) / abs(lo), lo))
+            assert dev <= max(fp32_oracle_factor[1] * spread, 1e-3), (step, ll, lf, lo)
         if vs_exact_factor:   # the exact oracle's trajectory too: how far rounding ITSELF moves the loss of this step
             lx = Ox.inner_step(xd[idx], yd[idx])
             worst_rx = max(worst_rx, abs(lo - lx) / abs(lx))
             if os.environ.get("MLIIS_TEST_VERBOSE"):
                 print("  step %2d: device %.5f  rounded oracle %.5f  exact oracle %.5f" % (step, ll, lo, lx))
         assert np.isfinite(ll) and abs(ll - lo) <= later_loss_tol * abs(lo), (step, ll, lo)
+    if Of is not None:
+        print("float32 oracle vs float64 oracle, worst later-step loss rel %.2e; device's worst step / that %.2f; device / running maximum at most %.2f" % (
+            spread, worst / spread, ratio))
+        assert worst <= fp32_oracle_factor[0] * spread, (worst, spread)
     if vs_exact_factor:
         print("worst |rounded - exact| / exact over the later steps: %.2e" % worst_rx)
         assert worst <= max(vs_exact_factor * worst_rx, vs_exact_floor), (worst, worst_rx)
@@ -839,18 +868,28 @@ def test_config4_schedule_ten_shots_twenty_steps_bf16():
     _lowp_step_check("efficientnet-b3", 96, 10, "bf16", steps=20, loss_tol=5e-3, cos_min=0.998, l2_max=6e-2, later_loss_tol=0.6, vs_exact_factor=2.5)
 
 
-@pytest.mark.skipif(os.environ.get("MLIIS_TEST_FULL_CONFIGS") != "1", reason="10 minutes of float64 oracle: set MLIIS_TEST_FULL_CONFIGS=1")
-@pytest.mark.parametrize("precision", ["bf16", "bf16-storage"])
+@pytest.mark.parametrize("precision", [pytest.param("bf16", marks=pytest.mark.skipif(os.environ.get("MLIIS_TEST_FULL_CONFIGS") != "1",
+                                                                                      reason="the bf16-storage case below is the one BASELINE configs[3] states; set MLIIS_TEST_FULL_CONFIGS=1 for this one too")),
+                                       "bf16-storage"])
 def test_config4_as_stated_224_ten_shots_twenty_steps(precision):
     """BASELINE configs[3] exactly as stated, on one GPU: EfficientNet-B3, 224x224, 10 shots, 20 inner steps (HIP-graph replay from
-    the third), bf16 operands / bf16 operands + bf16 storage, every step's loss against the rounded AND the exact float64 oracle.
-    Opt-in (two float64 B3 oracles x 20 steps at 224x224: 7 minutes); the output of the last run is profiles/r04_config4_as_stated.txt.
-    The trajectory (loss 9.1 -> 2.3) is as sensitive as at 96x96: the two float64 oracles (rounded, exact) differ by up to 14.7 % at a
-    step with bf16 operands and 3.9 % with bf16 storage on top, the device by up to 10.7 % / 15.3 % from the rounded oracle, and all
-    three meet again at step 19 (2.28-2.32).  Bar: within 3 x the oracles' own distance or 20 %, whichever is larger."""
+    the third), bf16 operands + bf16 storage of the expanded MBConv tensors (the plain bf16-operand variant is opt-in), every step's
+    loss against the storage-rounded float64 oracle, the exact float64 oracle and -- the calibration of the bar --
+    the SAME storage-rounded oracle run in float32: an independent fp32 implementation of the step, whose distance from the float64
+    trajectory is the measured sensitivity of this 20-step schedule to fp32 arithmetic.  The trajectory (loss 9.1 -> 2.3 from a random
+    initialisation) is chaotic at the per-cent level.  Measured on MI355X (gpurun_out/config4_calib.txt, round 5): the float32 oracle
+    drifts up to 10.2 % of a step's loss from the float64 one (steps 6, 10, 16: 8.1 %, 7.8 %, 10.2 %), the device up to 15.3 % (steps 9,
+    10; 1.1e-3 at step 11), i.e. 1.50 x the float32 oracle's worst step; against the RUNNING maximum of that spread the device's worst
+    ratio is 3.30 (step 3: 3.2 % while the float32 oracle had reached 0.96 %).  Bars, both computed from the float32 oracle in the same
+    run on the same data: worst device step <= 2.5 x the float32 oracle's worst step, and every step <= 5 x the running maximum.  First
+    step: loss 3.0e-3, gradient cosine 0.9979, relative L2 6.5e-2 of the storage-rounded oracle."""
     _need_gpu()
-    _lowp_step_check("efficientnet-b3", 224, 10, precision, steps=20, loss_tol=1e-2, cos_min=0.995, l2_max=0.1, later_loss_tol=0.6, vs_exact_factor=3.0,
-                     vs_exact_floor=0.2)
+    if precision == "bf16":
+        _lowp_step_check("efficientnet-b3", 224, 10, precision, steps=20, loss_tol=1e-2, cos_min=0.995, l2_max=0.1, later_loss_tol=0.6, vs_exact_factor=3.0,
+                         vs_exact_floor=0.2)
+    else:
+        _lowp_step_check("efficientnet-b3", 224, 10, precision, steps=20, loss_tol=1e-2, cos_min=0.995, l2_max=0.1, later_loss_tol=0.6,
+                         fp32_oracle_factor=FP32_FACTOR)
 
 
 def test_fp8_forward_activations_of_the_first_blocks_match_the_quantised_oracle():
@@ -891,6 +930,60 @@ def test_fp8_forward_activations_of_the_first_blocks_match_the_quantised_oracle(
     # of the activation scale
     for i, (mean, q, mx) in enumerate(stats):
         assert mean <= BOUNDS[i][0] and q <= BOUNDS[i][1] and mx <= BOUNDS[i][2], (i, stats)
+
+
+def test_bf16_storage_first_step_per_block_against_the_store_point_oracle():
+    """between the op-level storage tests (bit-faithful) and the statistical whole-step tests -- the first step of the
+    metric's network at 224x224, batch 8, bf16 storage, block by block against the float64 oracle that rounds the same operands and
+    the same stored tensors (store points per kernel family; the 5x5 marching forward's statistics exception included): the forward
+    output of EVERY block (blocks 0-5 on the marching kernels, 6-10 on the small-map kernels) relative to its max-abs, and the
+    gradient of every block's parameters (cosine and relative L2 over the block's tensors)."""
+    _need_gpu()
+    from mliis_amd.learner import Learner
+    H, N = 224, 8
+    x, y = _task(N, H, 21)
+    xd, yd = torch.tensor(x).double(), torch.tensor(y).double()
+    Or = R.OracleLearner(image_size=H, seed=0, dtype=torch.float64, lr=1e-3, drop_connect=False, round_ops="bf16")
+    L = Learner(image_size=H, seed=100, use_graph=False, drop_connect=False, matmul_precision="bf16-storage")
+    L.load_named({k: v.numpy() for k, v in Or.params.items()}, strict=False)
+    L.load_task(x, y)
+    P = L._plan(N)
+    executed = [b for b in L.arch.blocks if b.executed]
+    fam = {b.idx: ("small" if B["small"] else "march") for b, B in zip(executed, P.blocks)}
+    assert set(fam.values()) == {"small", "march"}
+    store = lambda blk: fam.get(blk["idx"])   # noqa: E731
+    taps = {}
+    with torch.no_grad():
+        R.forward(Or.a, Or.params, Or.bn, xd, True, taps=taps, round_ops="bf16", store=store)
+    _, gO, _ = R.inner_step(Or.a, Or.params, Or.bn, xd, yd, 1e-3, round_ops="bf16", store=store)
+    L.inner_step(list(range(N)))
+    L.synchronize()
+    gL = L.arena.g
+    fwd, grd = [], []
+    for i, b in enumerate(executed):
+        ref = taps["block_%d" % i]
+        got = P.blocks[i]["out"].float().cpu().double()
+        err = (got - ref).abs() / ref.abs().max().item()
+        q = torch.quantile(err.reshape(-1)[::7], 0.999).item()
+        names = [p.name for p in L.arena.trainable if "/blocks_%d/" % b.idx in p.name]
+        a = torch.cat([gL[n_].reshape(-1).cpu().double() for n_ in names])
+        r = torch.cat([gO[n_].reshape(-1) for n_ in names])
+        cos, l2 = float((a * r).sum() / (a.norm() * r.norm())), float((a - r).norm() / r.norm())
+        print("bf16 storage, block %2d (%s): forward rel err mean %.2e p99.9 %.2e max %.2e; gradient cosine %.5f rel L2 %.2e" % (
+            b.idx, fam[b.idx], err.mean().item(), q, err.max().item(), cos, l2))
+        fwd.append((err.mean().item(), q, err.max().item()))
+        grd.append((cos, l2))
+    L.close()
+    for i, ((mean, q, mx), (cos, l2)) in enumerate(zip(fwd, grd)):
+        assert mean <= BF16_STORAGE_FWD[0] and q <= BF16_STORAGE_FWD[1] and mx <= BF16_STORAGE_FWD[2], (i, fwd)
+        assert cos >= BF16_STORAGE_GRAD[0] and l2 <= BF16_STORAGE_GRAD[1], (i, grd)
+
+
+# (forward mean / p99.9 / max of the block output's max-abs; gradient cosine / relative L2 per block -- about 2x the measured worst block)
+# measured on MI355X: forward grows from 1.2e-7 / 1.1e-5 / 2.9e-3 (block 0) to 3.0e-3 / 1.5e-2 / 2.4e-2 (block 10) -- every block adds its
+# own storage roundings to what it inherits; gradient cosine 0.99910 .. 0.99947, relative L2 3.3e-2 .. 4.3e-2 for every block
+BF16_STORAGE_FWD = (6e-3, 3e-2, 5e-2)
+BF16_STORAGE_GRAD = (0.998, 8e-2)
 
 
 @pytest.mark.parametrize("H,N,steps", [(64, 8, 3), (384, 2, 1), (384, 8, 2)])

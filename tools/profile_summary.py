@@ -15,8 +15,8 @@ from mliis_amd import spec  # noqa: E402
 
 def family(n):
     n = n.replace("void mliis::", "").replace("mliis::", "").split("(")[0]
-    if n.startswith("conv_gemm") or n.startswith("conv1x1_"):
-        return "dense conv fwd / bwd-data (MFMA implicit GEMM)"
+    if n.startswith("conv_gemm") or n.startswith("conv1x1_") or n.startswith("conv_x3_k") or n.startswith("x3_fixup") or n.startswith("x3_pack"):
+        return "dense conv fwd / bwd-data (MFMA implicit GEMM; conv_x3_k + x3_fixup_k + x3_pack_k: split products on the bf16 matrix cores)"
     if n.startswith("mbconv_dw"):
         return "small-map fused MBConv depthwise half (bn0 + dw + bn1 + pool | their backward)"
     if n.startswith("conv_filter"):
