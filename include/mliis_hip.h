@@ -222,6 +222,24 @@ int mliis_conv2d_fwd(const float* x, int ldx, const float* x_scale, const float*
                      const float* border_bias, float* y, int ldy, int Nimg, int H, int W, int Cin_total, int ci_begin, int Cin, int Cout,
                      int ksize, int dil, int accumulate, float* stats_part, int stats_swish, int* stats_nblk, float* ws,
                      size_t ws_floats, int precision, float fp8_act_scale, const float* fp8_w_amax, int x_dtype, int y_dtype, hipStream_t stream);
+/*      mliis_conv2d_fwd_bnin: the 1x1 conv of the NEXT MBConv block's expand step (efficientnet_model.py:175-182) with the plain batch
+ *      norm in front of it -- the previous block's project BN, its drop-connect scale and identity skip (efficientnet_model.py:
+ *      283-288, utils.py:157-170) -- applied while the rows are loaded:
+ *          a = ((z - mean) * rstd * gamma + beta) * img_scale[image] + res;   y = conv1x1(a, wt)
+ *      The launch folds the batch norm's stage-1 partials bn_part [bn_nblk][2][Cin] (the stats_part of the conv that produced z),
+ *      publishes mean / rstd (kept for the backward pass), advances the moving averages (nullable pair; biased variance) and writes
+ *      the finished tensor a to a_out [N*H*W, Cin] (ld = lda_out: the block output -- residual of the next block, endpoint, X operand
+ *      of the filter gradient).  Replaces mliis_bn_apply_fused (no activation) + mliis_conv2d_fwd: one launch instead of two, z read
+ *      once.  img_scale [Nimg] and res (ld = ldr) nullable; z, res, a_out fp32; wt [Cout][Cin] (mliis_transpose_weights);
+ *      stats_part / stats_swish / stats_nblk, precision, fp8 scales and y_dtype (MLIIS_DT_BF16, MLIIS_DT_BLOCKED) as for
+ *      mliis_conv2d_fwd.  Only the streamed 1x1 plan implements it (Cin <= 112, N*H*W >= 1024: mliis_conv2d_fwd_bnin_ok returns 1);
+ *      other shapes: MLIIS_ERR_UNSUPPORTED, nothing launched. */
+int mliis_conv2d_fwd_bnin_ok(int Nimg, int H, int W, int Cin, int Cout);
+int mliis_conv2d_fwd_bnin(const float* z, int ldz, const float* bn_part, int bn_nblk, float eps, float momentum, float* mean, float* rstd,
+                          float* moving_mean, float* moving_var, const float* gamma, const float* beta, const float* img_scale,
+                          const float* res, int ldr, float* a_out, int lda_out, const float* wt, float* y, int ldy, int Nimg, int H, int W,
+                          int Cin, int Cout, float* stats_part, int stats_swish, int* stats_nblk, int precision, float fp8_act_scale,
+                          const float* fp8_w_amax, int y_dtype, hipStream_t stream);
 /*      batched HWIO -> HWOI copy of dense-conv weights between two arenas of identical layout; desc = device int32
  *      [ndesc][4] {offset, taps, Cin, Cout} */
 /*      amax (nullable, device float[ndesc]): also max |w| per descriptor (the fp8 operand scale of MLIIS_PREC_FP8).
@@ -430,6 +448,16 @@ int mliis_final_conv_bwd_filter(const float* x, int ldx, const float* mask, cons
 size_t mliis_softmax_ce_workspace_floats(int N, int H, int W);
 int mliis_softmax_ce(const float* logits, const float* labels, const int* img_idx, int N, int H, int W, float label_smoothing, int dice,
                      float extra_loss, float* dlogits, float* pred, float* out, float* ws, size_t ws_floats, hipStream_t stream);
+/*      mliis_head_ce_fused: the tail of a training step WITHOUT the dice term in two launches instead of five -- logits = bilinear
+ *      resize (align_corners, efficientlab.py:166-173) of small [N,Hd,Wd,2] to [H,W]; per-pixel softmax cross-entropy with label
+ *      smoothing (efficientlab.py:294-303) against labels [S,H,W,2] (through img_idx, nullable); dsmall = the gradient w.r.t. small --
+ *      what mliis_resize_bilinear_fwd -> mliis_softmax_ce -> mliis_resize_bilinear_bwd compute, without writing the full-resolution
+ *      logits and their gradient; out[0..2] = {loss + extra_loss, ce, iou}. */
+int mliis_head_ce_fused_supported(int Hd, int Wd, int H, int W);   /* 1: up-sampling factor within the kernel's tile footprint (<= ~4.5) */
+size_t mliis_head_ce_fused_workspace_floats(int N, int Hd, int Wd);
+int mliis_head_ce_fused(const float* small, const float* labels, const int* img_idx, int N, int Hd, int Wd, int H, int W,
+                        float label_smoothing, float extra_loss, float* dsmall, float* out, float* ws, size_t ws_floats,
+                        hipStream_t stream);
 
 /*      DARC1 regulariser (models/regularizers.py:20-22): weight * max over positions of sum_n |logits[n, pos]| added to out[0]
  *      (nullable) and its gradient weight * sign(logits[n, argmax]) added to dlogits (nullable); logits [N, per_img]; ws >= 2048 floats. */

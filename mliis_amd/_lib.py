@@ -48,6 +48,12 @@ SIGNATURES = {
     "mliis_conv1x1_occupancy": (_i, [_i, _i, _i, _p]),
     "mliis_conv2d_kernel_name": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _p, _sz]),
     "mliis_conv2d_fwd": (_i, [_p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _p, _sz, _i, _f, _p, _i, _i, _p]),
+    "mliis_head_ce_fused_supported": (_i, [_i, _i, _i, _i]),
+    "mliis_head_ce_fused_workspace_floats": (_sz, [_i, _i, _i]),
+    "mliis_head_ce_fused": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _p, _p, _p, _sz, _p]),
+    "mliis_conv2d_fwd_bnin_ok": (_i, [_i, _i, _i, _i, _i]),
+    "mliis_conv2d_fwd_bnin": (_i, [_p, _i, _p, _i, _f, _f, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p, _i,
+                                   _f, _p, _i, _p]),
     "mliis_rsd_concat_pool_floats": (_sz, [_i, _i, _i, _i]),
     "mliis_rsd_concat_pool": (_i, [_p, _i, _i, _i, _i, _p, _i, _i, _p, _i, _i, _i, _i, _p, _sz, _p, _p]),
     "mliis_rsd_pool_fwd": (_i, [_p, _i, _f, _p, _p, _p, _i, _i, _i, _i, _i, _p]),

@@ -361,12 +361,13 @@ static inline bool stream_plan(long long M, int K, int Nout, int num_cus, Stream
   sp->gx = (int)gx;
   return true;
 }
-static bool launch_stream(const StreamPlan& sp, const ConvGemmParams& p, hipStream_t stream, int precision = MLIIS_PREC_FP32) {
+template <bool AIN>
+static bool launch_stream_f32(const StreamPlan& sp, const ConvGemmParams& p, hipStream_t stream) {
   dim3 grid(sp.gx, sp.gy), block(64 * kStreamWaves);
-  if (precision != MLIIS_PREC_FP32) return launch_stream_lowp(precision, sp.kc, sp.nt, grid, p, sp.row_groups, stream);
-#define S(KC_, NT_) hipLaunchKernelGGL((conv1x1_stream_k<KC_, NT_, 0>), grid, block, 0, stream, p, sp.row_groups); break;
+#define S(KC_, NT_) hipLaunchKernelGGL((conv1x1_stream_k<KC_, NT_, 0, AIN>), grid, block, 0, stream, p, sp.row_groups); break;
+#define SN(KC_, NT_) if constexpr (AIN) return false; else { S(KC_, NT_) }   // (stream_plan gives at most four column tiles: no AIN instance)
   switch (sp.kc) {
-    case 1: switch (sp.nt) { case 1: S(1, 1) case 2: S(1, 2) case 3: S(1, 3) case 4: S(1, 4) case 5: S(1, 5) case 6: S(1, 6) case 7: S(1, 7) case 8: S(1, 8) default: return false; } break;
+    case 1: switch (sp.nt) { case 1: S(1, 1) case 2: S(1, 2) case 3: S(1, 3) case 4: S(1, 4) case 5: SN(1, 5) case 6: SN(1, 6) case 7: SN(1, 7) case 8: SN(1, 8) default: return false; } break;
     case 2: switch (sp.nt) { case 1: S(2, 1) case 2: S(2, 2) case 3: S(2, 3) case 4: S(2, 4) default: return false; } break;
     case 3: switch (sp.nt) { case 1: S(3, 1) case 2: S(3, 2) default: return false; } break;
     case 4: switch (sp.nt) { case 1: S(4, 1) case 2: S(4, 2) default: return false; } break;
@@ -375,8 +376,13 @@ static bool launch_stream(const StreamPlan& sp, const ConvGemmParams& p, hipStre
     case 7: switch (sp.nt) { case 1: S(7, 1) default: return false; } break;
     default: return false;
   }
+#undef SN
 #undef S
   return true;
+}
+static bool launch_stream(const StreamPlan& sp, const ConvGemmParams& p, hipStream_t stream, int precision = MLIIS_PREC_FP32, bool ain = false) {
+  if (precision != MLIIS_PREC_FP32) return launch_stream_lowp(precision, sp.kc, sp.nt, dim3(sp.gx, sp.gy), p, sp.row_groups, stream, ain);
+  return ain ? launch_stream_f32<true>(sp, p, stream) : launch_stream_f32<false>(sp, p, stream);
 }
 
 static int g_num_cus = 0;
@@ -614,6 +620,79 @@ int mliis_conv2d_fwd(const float* x, int ldx, const float* x_scale, const float*
     hipLaunchKernelGGL(splitk_reduce_k, dim3(blocks), dim3(256), 0, stream, ws, g.gz, M, Cout, y, ldy, bias, accumulate, border_bias, H, W);
     MLIIS_CHECK_LAUNCH("conv2d_fwd_splitk_reduce");
   }
+  return MLIIS_OK;
+}
+
+// 1 when a 1x1 conv of this shape runs on the streaming plan, i.e. when mliis_conv2d_fwd_bnin accepts it (the MBConv expand convs:
+// Cin <= 112, N H W >= 1024); 0 otherwise.
+int mliis_conv2d_fwd_bnin_ok(int Nimg, int H, int W, int Cin, int Cout) {
+  StreamPlan sp;
+  const long long M = (long long)Nimg * H * W;
+  if (Nimg <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (Cin & 3) || (Cout & 3) || M * Cin * 4 >= (1LL << 31) || M * Cout * 4 >= (1LL << 31))
+    return 0;
+  return stream_plan(M, Cin, Cout, num_cus(), &sp) ? 1 : 0;
+}
+
+// y = conv1x1(a, w) with  a = ((z - mean) * rstd * gamma + beta) * img_scale[image] + res  formed while z is loaded: the plain batch
+// norm in FRONT of the conv (an MBConv project BN, efficientnet_model.py:283-288: drop-connect and the identity skip behind it,
+// utils.py:157-170) fused into the NEXT block's expand conv (efficientnet_model.py:175-182).  The launch folds the batch norm's
+// stage-1 partials bn_part [bn_nblk][2][Cin] (left by the conv that produced z), publishes mean / rstd, advances the moving
+// averages (nullable pair) and writes the finished tensor a to a_out [M, Cin] (ld = lda_out): exactly what mliis_bn_apply_fused
+// (no activation) followed by mliis_conv2d_fwd computes, in one launch.  z, res, a_out: fp32.  stats_part / y_dtype (incl.
+// MLIIS_DT_BLOCKED) / precision as for mliis_conv2d_fwd.  MLIIS_ERR_UNSUPPORTED unless mliis_conv2d_fwd_bnin_ok(...).
+int mliis_conv2d_fwd_bnin(const float* z, int ldz, const float* bn_part, int bn_nblk, float eps, float momentum, float* mean, float* rstd,
+                          float* moving_mean, float* moving_var, const float* gamma, const float* beta, const float* img_scale,
+                          const float* res, int ldr, float* a_out, int lda_out, const float* wt, float* y, int ldy, int Nimg, int H, int W,
+                          int Cin, int Cout, float* stats_part, int stats_swish, int* stats_nblk, int precision, float fp8_act_scale,
+                          const float* fp8_w_amax, int y_dtype, hipStream_t stream) {
+  int rc = conv_check("conv2d_fwd_bnin", Nimg, H, W, Cin, Cout, 1, 1);
+  if (rc) return rc;
+  if ((rc = prec_check("conv2d_fwd_bnin", precision))) return rc;
+  MLIIS_REQUIRE(z && bn_part && mean && rstd && gamma && beta && a_out && wt && y, MLIIS_ERR_ARG, "conv2d_fwd_bnin: null pointer");
+  MLIIS_REQUIRE(bn_nblk > 0 && (moving_mean == nullptr) == (moving_var == nullptr), MLIIS_ERR_ARG,
+                "conv2d_fwd_bnin: needs stage-1 partials; the moving statistics come as a pair");
+  const int y_block = (y_dtype >> 8) & 0xff;
+  y_dtype &= 0xff;
+  MLIIS_REQUIRE(y_block == 0 || ((y_block == 2 || y_block == 4) && y_dtype == MLIIS_DT_F32 && Cout % y_block == 0), MLIIS_ERR_ARG,
+                "conv2d_fwd_bnin: a group-blocked output takes v = 2 | 4 dividing Cout and fp32 storage");
+  const bool ybf = y_dtype == MLIIS_DT_BF16;
+  MLIIS_REQUIRE(y_dtype == MLIIS_DT_F32 || ybf, MLIIS_ERR_ARG, "conv2d_fwd_bnin: bad storage type");
+  MLIIS_REQUIRE(!ybf || precision == MLIIS_PREC_BF16, MLIIS_ERR_UNSUPPORTED, "conv2d_fwd_bnin: a bf16 output needs MLIIS_PREC_BF16");
+  MLIIS_REQUIRE((ldz & 3) == 0 && ldz >= Cin && (lda_out & 3) == 0 && lda_out >= Cin && (ldy & 3) == 0 && ldy >= Cout &&
+                    (res == nullptr || ((ldr & 3) == 0 && ldr >= Cin)),
+                MLIIS_ERR_ARG, "conv2d_fwd_bnin: bad leading dimensions");
+  MLIIS_REQUIRE(aligned16(z) && aligned16(bn_part) && aligned16(gamma) && aligned16(beta) && aligned16(res) && aligned16(a_out) &&
+                    aligned16(wt) && aligned16(y),
+                MLIIS_ERR_ALIGN, "conv2d_fwd_bnin: pointers must be 16-byte aligned");
+  const long long M = (long long)Nimg * H * W;
+  MLIIS_REQUIRE(M > 1 && M * ldz * 4 < (1LL << 31) && M * ldy * 4 < (1LL << 31) && M * lda_out * 4 < (1LL << 31) &&
+                    (res == nullptr || M * ldr * 4 < (1LL << 31)),
+                MLIIS_ERR_UNSUPPORTED, "conv2d_fwd_bnin: operand larger than 2 GiB (32-bit buffer offsets)");
+  MLIIS_REQUIRE(precision != MLIIS_PREC_FP8 || (fp8_act_scale > 0.0f && fp8_w_amax != nullptr), MLIIS_ERR_ARG,
+                "conv2d_fwd_bnin: fp8 operands need a positive activation scale and the weight tensor's amax");
+  MLIIS_REQUIRE(stats_part == nullptr || stats_nblk, MLIIS_ERR_ARG, "conv2d_fwd_bnin: fused statistics need a stats_nblk output");
+  StreamPlan sp;
+  MLIIS_REQUIRE(stream_plan(M, Cin, Cout, num_cus(), &sp), MLIIS_ERR_UNSUPPORTED,
+                "conv2d_fwd_bnin: not a streamed 1x1 shape (mliis_conv2d_fwd_bnin_ok)");
+  ConvGemmParams p{z, ldz, Nimg, H, W, Cin, 1, 1, +1, wt, (long long)Cin * Cout, Cin, Cout, y, ldy,
+                   nullptr, 0, nullptr, 0, nullptr, 0, nullptr, nullptr, fp8_act_scale, fp8_w_amax};
+  p.out_bf16 = ybf;
+  p.stats_part = stats_part;
+  p.stats_swish = stats_swish;
+  p.c_block = y_block;
+  const double n = (double)M;
+  p.ain = BnFold{bn_part, bn_nblk, 1.0 / n, eps, (float)(1.0 - (double)momentum), 1.0f, mean, rstd, moving_mean, moving_var};
+  p.ain_gamma = gamma;
+  p.ain_beta = beta;
+  p.ain_res = res;
+  p.ain_ldr = ldr;
+  p.ain_scale = img_scale;
+  p.ain_out = a_out;
+  p.ain_ldo = lda_out;
+  if (stats_nblk) *stats_nblk = 0;
+  MLIIS_REQUIRE(launch_stream(sp, p, stream, precision, true), MLIIS_ERR_UNSUPPORTED, "conv2d_fwd_bnin: no instance <%d, %d>", sp.kc, sp.nt);
+  MLIIS_CHECK_LAUNCH("conv2d_fwd_bnin");
+  if (stats_part != nullptr) *stats_nblk = sp.gx;
   return MLIIS_OK;
 }
 

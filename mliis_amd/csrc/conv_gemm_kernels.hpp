@@ -7,6 +7,7 @@
 
 #include <type_traits>
 
+#include "bn_fold.hpp"
 #include "common.hpp"
 
 namespace mliis {
@@ -63,6 +64,21 @@ struct ConvGemmParams {
   // conv1x1_stream_k only: c_block = v (2 | 4): Cmat is written in the group-blocked layout [Nout / v][M][v] (fp32) that the small-map
   // fused MBConv kernels read contiguously (mbconv_small.hip: a workgroup owns v channels over all pixels); ldc is not used then
   int c_block = 0;
+  // conv1x1_stream_k<..., AIN = true> only (mliis_conv2d_fwd_bnin): A is the INPUT z of a plain batch norm (an MBConv project BN,
+  // efficientnet_model.py:283-288: no activation) whose output -- x drop-connect scale per image, + the block's residual -- is this
+  // conv's operand.  The launch folds that batch norm's stage-1 partials (ain.part [nblk][2][C], left by the conv that produced z) in
+  // its prologue, forms  a = ((z - mean) * (rstd * gamma) + beta) * ain_scale[image] + ain_res  while the rows are loaded, and the
+  // workgroups of column tile 0 write the finished tensor to ain_out (the block output: residual of the next block, endpoint, X
+  // operand of the filter gradient); workgroup (0, 0) publishes mean / rstd and advances the moving averages.  The stand-alone
+  // apply launch between the two convs (mliis_bn_apply_fused) is gone.
+  BnFold ain = {};
+  const float* ain_gamma = nullptr;
+  const float* ain_beta = nullptr;
+  const float* ain_res = nullptr;
+  int ain_ldr = 0;
+  const float* ain_scale = nullptr;   // nullable [Nimg]
+  float* ain_out = nullptr;
+  int ain_ldo = 0;
 #ifdef KS_DBG
   unsigned long long* dbg_stamps = nullptr;   // [workgroups][8] wall-clock stamps (100 MHz) of thread 0
 #endif
@@ -667,9 +683,19 @@ __global__ __launch_bounds__(1024) void sk_fixup_k(ConvGemmParams p, SkPlan k) {
 // Workgroup = kStreamWaves waves (each streams its own row groups; nothing is shared but the final fold of the statistics): twice the
 // four of a 256-thread block, so a launch leaves half as many partial blocks -- every workgroup of the consumer folds ALL of them.
 constexpr int kStreamWaves = 8;
-template <int KC, int NT, int PREC>
+// AIN: the batch norm in front of the conv applied while A is loaded (ConvGemmParams::ain).  Fold scratch: K / 4 channel quads x L
+// fold lanes = the 512 threads (L <= 32), double partials.
+template <int KC>
+struct AinFold {
+  static constexpr int NQ = KC * 4;
+  static constexpr int L = (64 * 8 / NQ) > 32 ? 32 : (64 * 8 / NQ);
+};
+template <int KC, int NT, int PREC, bool AIN = false>
 __global__ __launch_bounds__(64 * kStreamWaves, 4) void conv1x1_stream_k(ConvGemmParams p, int row_groups) {   // (4 waves per SIMD: <= 128 VGPRs, two workgroups per CU)
   __shared__ float red[kStreamWaves][2][16 * NT];
+  constexpr int FL = AinFold<KC>::L, FQ = AinFold<KC>::NQ;
+  __shared__ double ain_scr[AIN ? 2 * FL * FQ * 4 : 1];
+  __shared__ __attribute__((aligned(16))) float ain_m[AIN ? KC * 16 : 4], ain_sc[AIN ? KC * 16 : 4], ain_b[AIN ? KC * 16 : 4];
   // per-wave staging tile of a finished row group, [16 rows][16 NT + 4]: the accumulators (C/D layout: a lane holds 4 rows x NT
   // columns 64 bytes apart) leave as whole-row 16-byte stores -- a dword store of that layout is four 64-byte segments per instruction
   // and the address path, not HBM, bound the large launches (stamps build, round 3: 3.2 us per row group in the store phase)
@@ -683,13 +709,15 @@ __global__ __launch_bounds__(64 * kStreamWaves, 4) void conv1x1_stream_k(ConvGem
   const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, kBufRecords, 0x00020000);
   // B fragments: column n0 + 16 j + l15, k = 16 kg + 4 g .. + 3 (zero beyond K / Nout)
   float4 bv[KC][NT];
+  auto load_bv = [&]() {
 #pragma unroll
-  for (int kg = 0; kg < KC; ++kg)
+    for (int kg = 0; kg < KC; ++kg)
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int n = n0 + j * 16 + l15, k = kg * 16 + g * 4;
-      bv[kg][j] = buf_ld4(rB, (n < p.Nout && k < p.C) ? (unsigned)((n * p.ldb + k) * 4) : kOob);
-    }
+      for (int j = 0; j < NT; ++j) {
+        const int n = n0 + j * 16 + l15, k = kg * 16 + g * 4;
+        bv[kg][j] = buf_ld4(rB, (n < p.Nout && k < p.C) ? (unsigned)((n * p.ldb + k) * 4) : kOob);
+      }
+  };
   // reduced-precision operands (PREC 1 = bf16, 2 = fp8 e4m3): two 16-wide K groups make one 32-deep MFMA -- lane group g supplies
   // k = 16 kg + 4g..4g+3 of both groups, for A and B alike (the K order inside an MFMA is free as long as both operands agree)
   constexpr int KC2 = (KC + 1) / 2;
@@ -697,16 +725,20 @@ __global__ __launch_bounds__(64 * kStreamWaves, 4) void conv1x1_stream_k(ConvGem
   const float out_scale = PREC == 2 ? 1.0f / (p.a_qscale * b_qscale) : 1.0f;
   bf16x8 bq16[PREC == 1 ? KC2 : 1][PREC == 1 ? NT : 1];
   long bq8[PREC == 2 ? KC2 : 1][PREC == 2 ? NT : 1];
-  if constexpr (PREC != 0) {
+  auto prep_b = [&]() {
+    load_bv();
+    if constexpr (PREC != 0) {
 #pragma unroll
-    for (int k2 = 0; k2 < KC2; ++k2)
+      for (int k2 = 0; k2 < KC2; ++k2)
 #pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const float4 lo = bv[2 * k2][j], hi = (2 * k2 + 1 < KC) ? bv[(2 * k2 + 1 < KC) ? 2 * k2 + 1 : 0][j] : f4zero();
-        if constexpr (PREC == 1) bq16[k2][j] = pack_bf16x8(lo, hi);
-        else bq8[k2][j] = pack_fp8x8(lo, hi, b_qscale);
-      }
-  }
+        for (int j = 0; j < NT; ++j) {
+          const float4 lo = bv[2 * k2][j], hi = (2 * k2 + 1 < KC) ? bv[(2 * k2 + 1 < KC) ? 2 * k2 + 1 : 0][j] : f4zero();
+          if constexpr (PREC == 1) bq16[k2][j] = pack_bf16x8(lo, hi);
+          else bq8[k2][j] = pack_fp8x8(lo, hi, b_qscale);
+        }
+    }
+  };
+  if constexpr (!AIN) prep_b();   // (AIN: requested behind the fold of the statistics, whose batches of loads need the registers)
   float bj[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
@@ -728,6 +760,7 @@ __global__ __launch_bounds__(64 * kStreamWaves, 4) void conv1x1_stream_k(ConvGem
     brstd[j] = (bnb && n < p.Nout) ? p.bnb_rstd[n] : 0.f;
   }
   const int stride = gridDim.x * kStreamWaves;
+  const __amdgpu_buffer_rsrc_t rR = __builtin_amdgcn_make_buffer_rsrc((void*)(AIN && p.ain_res != nullptr ? p.ain_res : p.A), 0, kBufRecords, 0x00020000);
   auto load_a = [&](int rg, float4* a) {
     const int m = rg * 16 + l15;
 #pragma unroll
@@ -736,11 +769,123 @@ __global__ __launch_bounds__(64 * kStreamWaves, 4) void conv1x1_stream_k(ConvGem
       a[kg] = buf_ld4(rA, (rg < row_groups && m < M && k < p.C) ? (unsigned)((m * p.lda + k) * 4) : kOob);
     }
   };
+  // (AIN) the residual quads and the per-image scale of the same rows, requested with the rows themselves
+  auto load_side = [&](int rg, float4* r, float& isc) {
+    if constexpr (AIN) {
+      const int m = rg * 16 + l15;
+      const bool rok = rg < row_groups && m < M;
+#pragma unroll
+      for (int kg = 0; kg < KC; ++kg) {
+        const int k = kg * 16 + g * 4;
+        r[kg] = buf_ld4(rR, (p.ain_res != nullptr && rok && k < p.C) ? (unsigned)((m * p.ain_ldr + k) * 4) : kOob);
+      }
+      isc = (p.ain_scale != nullptr && rok) ? p.ain_scale[m / HWs] : 1.f;
+    }
+  };
   int rg = blockIdx.x * kStreamWaves + wave;
   float4 a_cur[KC], a_nxt[KC];
+  float4 r_cur[AIN ? KC : 1], r_nxt[AIN ? KC : 1];
+  float is_cur = 1.f, is_nxt = 1.f;
   load_a(rg, a_cur);
+  if constexpr (AIN) {
+    // ---- fold the stage-1 partials of the batch norm in front (every workgroup, all K channels): thread (quad fq, lane fl) adds the
+    // blocks fl, fl + FL, ... of its four channels in double, eight loads in flight; the FL lanes of a channel are summed in lane order
+    const int fq = t % FQ, fl = t / FQ;
+    const int fc = fq * 4;
+    FoldAcc f;
+    if (fl < FL && fc < p.C) {
+      // (a descriptor that ends with the last partial block: the surplus slots of a batch read zeros -- no clamps, no predicates,
+      //  and the batch's addresses are one lane offset + uniform strides)
+      const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc((void*)p.ain.part, 0, p.ain.nblk * 2 * p.C * 4, 0x00020000);
+      const int bstride = FL * 2 * p.C * 4;
+      for (int k = fl; k < p.ain.nblk; k += FL * 8) {
+        const int off = (k * 2 * p.C + fc) * 4;
+        u32x4 u[8], v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          u[j] = __builtin_amdgcn_raw_buffer_load_b128(rP, off, j * bstride, 0);
+          v[j] = __builtin_amdgcn_raw_buffer_load_b128(rP, off + p.C * 4, j * bstride, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          f.a0 += __uint_as_float(u[j].x); f.a1 += __uint_as_float(u[j].y); f.a2 += __uint_as_float(u[j].z); f.a3 += __uint_as_float(u[j].w);
+          f.b0 += __uint_as_float(v[j].x); f.b1 += __uint_as_float(v[j].y); f.b2 += __uint_as_float(v[j].z); f.b3 += __uint_as_float(v[j].w);
+        }
+      }
+    }
+    prep_b();
+    load_side(rg, r_cur, is_cur);
+    if (fl < FL) {
+      double* d0 = ain_scr + ((0 * FL + fl) * FQ + fq) * 4;
+      double* d1 = ain_scr + ((1 * FL + fl) * FQ + fq) * 4;
+      d0[0] = f.a0; d0[1] = f.a1; d0[2] = f.a2; d0[3] = f.a3;
+      d1[0] = f.b0; d1[1] = f.b1; d1[2] = f.b2; d1[3] = f.b3;
+    }
+    __syncthreads();
+    if (t < KC * 16) {
+      float mf = 0.f, scf = 0.f, bf = 0.f;
+      if (t < p.C) {
+        double s = 0.0, ss = 0.0;
+#pragma unroll 8
+        for (int k = 0; k < FL; ++k) {
+          s += ain_scr[(0 * FL + k) * FQ * 4 + t];
+          ss += ain_scr[(1 * FL + k) * FQ * 4 + t];
+        }
+        const double m = s * p.ain.inv_n;
+        double var = ss * p.ain.inv_n - m * m;
+        if (var < 0.0) var = 0.0;
+        mf = (float)m;
+        const float rf = (float)(1.0 / sqrt(var + (double)p.ain.eps));
+        scf = rf * p.ain_gamma[t];
+        bf = p.ain_beta[t];
+        if (blockIdx.x == 0 && blockIdx.y == 0) {
+          p.ain.mean[t] = mf;
+          p.ain.rstd[t] = rf;
+          if (p.ain.moving_mean != nullptr) {
+            const float mm = p.ain.moving_mean[t], mv = p.ain.moving_var[t];
+            p.ain.moving_mean[t] = mm - (mm - mf) * p.ain.one_minus_momentum;
+            p.ain.moving_var[t] = mv - (mv - (float)(var * (double)p.ain.ema_var_factor)) * p.ain.one_minus_momentum;
+          }
+        }
+      }
+      ain_m[t] = mf;      // (channels beyond K: zeros -- their A elements become zeros, as the loader's out-of-range zeros were)
+      ain_sc[t] = scf;
+      ain_b[t] = bf;
+    }
+    __syncthreads();
+  }
+  // (AIN) raw rows -> the conv's operand, in place; column tile 0 also writes the finished tensor
+  auto bn_in = [&](int rg, float4* a, const float4* r, float isc) {
+    if constexpr (AIN) {
+      const int m = rg * 16 + l15;
+      // (the per-channel constants are re-read from LDS for every row group: hoisted out of the loop -- loop-invariant loads -- they
+      //  would hold 12 KC registers and the kernel would spill)
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int kg = 0; kg < KC; ++kg) {
+        const int k = kg * 16 + g * 4;
+        const float4 mq = ld4(ain_m + k), sq = ld4(ain_sc + k), bq = ld4(ain_b + k);
+        float4 o;
+        o.x = fmaf(a[kg].x - mq.x, sq.x, bq.x);
+        o.y = fmaf(a[kg].y - mq.y, sq.y, bq.y);
+        o.z = fmaf(a[kg].z - mq.z, sq.z, bq.z);
+        o.w = fmaf(a[kg].w - mq.w, sq.w, bq.w);
+        if (p.ain_scale != nullptr) o = f4scale(o, isc);
+        if (p.ain_res != nullptr) o = f4add(o, r[kg]);
+        a[kg] = o;
+        if (blockIdx.y == 0 && m < M && k < p.C) st4(p.ain_out + (long long)m * p.ain_ldo + k, o);
+      }
+    }
+  };
+  bn_in(rg, a_cur, r_cur, is_cur);
+  // (AIN with K > 64: no register room for the next row group beside the residual's -- and these are the 14x14 layers, one or two row
+  //  groups per wave: the next rows are requested when the current ones are done)
+  constexpr bool PF = !(AIN && KC >= 5);
   for (; rg < row_groups; rg += stride) {
-    load_a(rg + stride, a_nxt);
+    if constexpr (PF) {
+      load_a(rg + stride, a_nxt);
+      load_side(rg + stride, r_nxt, is_nxt);
+    }
     // the side operand of the gate-gradient / BN-backward epilogues (the element of gp_x / bnb_x beside each accumulator element, C/D
     // layout) is requested here, under the MFMAs, not where it is used: one memory round trip per row group less
     float side[4][NT];
@@ -889,8 +1034,19 @@ __global__ __launch_bounds__(64 * kStreamWaves, 4) void conv1x1_stream_k(ConvGem
         }
       }
     }
+    if constexpr (PF) {
 #pragma unroll
-    for (int kg = 0; kg < KC; ++kg) a_cur[kg] = a_nxt[kg];
+      for (int kg = 0; kg < KC; ++kg) a_cur[kg] = a_nxt[kg];
+      if constexpr (AIN) {
+        if (rg + stride < row_groups) bn_in(rg + stride, a_cur, r_nxt, is_nxt);
+      }
+    } else {
+      if (rg + stride < row_groups) {
+        load_a(rg + stride, a_cur);
+        load_side(rg + stride, r_cur, is_cur);
+        bn_in(rg + stride, a_cur, r_cur, is_cur);
+      }
+    }
   }
   if (!stats) return;
 #pragma unroll
@@ -1561,7 +1717,7 @@ static void launch_filter_t(const FilterPlan& f, const FilterGradParams& p, hipS
 void launch_gemm_bf16(const GemmPlan& g, const ConvGemmParams& p, hipStream_t stream);
 void launch_gemm_sk_bf16(const GemmPlan& g, const ConvGemmParams& p, float* slab, hipStream_t stream);
 void launch_gemm_fp8(const GemmPlan& g, const ConvGemmParams& p, hipStream_t stream);            // conv_gemm_fp8.hip
-bool launch_stream_lowp(int precision, int kc, int nt, dim3 grid, const ConvGemmParams& p, int row_groups, hipStream_t stream);   // conv_gemm_fp8.hip
+bool launch_stream_lowp(int precision, int kc, int nt, dim3 grid, const ConvGemmParams& p, int row_groups, hipStream_t stream, bool ain = false);   // conv_gemm_fp8.hip
 bool launch_ksplit_lowp(int precision, int kc, int nt, dim3 grid, const ConvGemmParams& p, int row_groups, hipStream_t stream);   // conv_gemm_fp8.hip
 void launch_filter_bf16(const FilterPlan& f, const FilterGradParams& p, hipStream_t stream);
 bool launch_filter_batched_bf16(int tmf, int nt, bool sc, const long long* desc, int nprob, int blocks, hipStream_t stream);

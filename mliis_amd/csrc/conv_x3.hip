@@ -238,7 +238,13 @@ __device__ __forceinline__ void conv_x3_tile(const X3Params& q, char* __restrict
           uint2& h = sh[k >> 1][k & 1];
           uint2& m = sm_[k >> 1][k & 1];
           uint2& l = sl[k >> 1][k & 1];
+#ifdef X3_NOSPLIT   // ablation: no split arithmetic (wrong numbers: what the loop costs without its vector work)
+          h = make_uint2(__float_as_uint(rs[k >> 1][k & 1].x), __float_as_uint(rs[k >> 1][k & 1].y));
+          m = make_uint2(__float_as_uint(rs[k >> 1][k & 1].z), __float_as_uint(rs[k >> 1][k & 1].w));
+          l = h;
+#else
           split3(rs[k >> 1][k & 1], h, m, l);
+#endif
           // (an empty statement that "uses" the piece here: without it the optimiser sinks the arithmetic to the first real use, the
           // assembly of a3n behind the last matrix instruction)
           asm volatile("" : "+v"(h.x), "+v"(h.y), "+v"(m.x), "+v"(m.y), "+v"(l.x), "+v"(l.y));

@@ -305,6 +305,125 @@ __global__ __launch_bounds__(256) void ce_grad_k(const float* __restrict__ logit
   }
 }
 
+// ------------------------------------------------------------------------------------------------ resize -> softmax CE -> resize^T, one pass
+// The tail of a training step without the dice term: logits = resize(small) (models/efficientlab.py:166-173), per-pixel softmax
+// cross-entropy (:294-303), its gradient (p - t) / (N H W) -- which needs no global sum -- and the transpose of the resize back to
+// the decoder's map.  A workgroup owns an 8 x 8 tile of DECODER pixels:
+//   phase 1: every image pixel that a pixel of the tile reaches (the tile's footprint, <= kHeadFoot^2 pixels) gets its logits rebuilt
+//            from the four decoder pixels around it (resize_fwd_k's arithmetic) and its gradient formed (ce_grad_k's arithmetic) into
+//            LDS; the loss terms of an image pixel are added by the tile that holds its top-left source pixel (one owner each);
+//   phase 2: the 8 lanes of a decoder pixel walk its candidates exactly as resize_bwd_k does, reading the gradients from LDS.
+// The full-resolution logits / gradient tensors are never written (four launches and 4 x 3.2 MB of traffic at 224x224, N = 8, become
+// two).  Loss partials per workgroup [n][tile][4] as ce_partial_k's, folded by ce_finalize_k -- a launch of its own: a last-arriver
+// fold inside this kernel needs device-scope fences, which on this eight-L2 part write back and invalidate a whole L2 each
+// (measured: 39 us for the launch, more than the four it replaces).  (A first form without the LDS phase -- every decoder pixel
+// rebuilding its ~100 candidates itself -- took 69 us: one dependent load chain per candidate.)
+constexpr int kHeadTile = 8, kHeadFoot = 48;
+__device__ __forceinline__ int head_lo(int i, float s) {
+  const int v = (int)floorf((float)(i - 1) / s) - 1;
+  return v < 0 ? 0 : v;
+}
+__device__ __forceinline__ int head_hi(int i, float s, int n) {
+  const int v = (int)ceilf((float)(i + 1) / s) + 1;
+  return v > n - 1 ? n - 1 : v;
+}
+__global__ __launch_bounds__(256) void head_ce_fused_k(const float* __restrict__ small, const float* __restrict__ labels,
+                                                       const int* __restrict__ idx, int N, int Hi, int Wi, int Ho, int Wo, float sh, float sw,
+                                                       float ls, float inv_rows, float* __restrict__ dsmall, float* __restrict__ part,
+                                                       int tiles_x) {
+  __shared__ float2 gl[kHeadFoot * kHeadFoot];
+  __shared__ float sm[4][4];
+  const int t = threadIdx.x;
+  const int n = blockIdx.y;
+  const int src = idx ? idx[n] : n;
+  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+  const int hi0 = ty * kHeadTile, wi0 = tx * kHeadTile;
+  const int hi1 = hi0 + kHeadTile - 1 < Hi - 1 ? hi0 + kHeadTile - 1 : Hi - 1;
+  const int wi1 = wi0 + kHeadTile - 1 < Wi - 1 ? wi0 + kHeadTile - 1 : Wi - 1;
+  const int fo0 = head_lo(hi0, sh), fo1 = head_hi(hi1, sh, Ho), fw0 = head_lo(wi0, sw), fw1 = head_hi(wi1, sw, Wo);
+  const int FH = fo1 - fo0 + 1, FW = fw1 - fw0 + 1;   // (host: <= kHeadFoot)
+  const float* zb = small + (long long)n * Hi * Wi * 2;
+  const float* tb = labels + (long long)src * Ho * Wo * 2;
+  float ce = 0.f, I = 0.f, Sp = 0.f, St = 0.f;
+  for (int p = t; p < FH * FW; p += 256) {
+    const int fr = p / FW, fc = p - fr * FW;
+    const int ho = fo0 + fr, wo = fw0 + fc;
+    int y0, y1, x0, x1;
+    float ly, lx;
+    src_coord(ho, sh, Hi, y0, y1, ly);
+    src_coord(wo, sw, Wi, x0, x1, lx);
+    const float2 tl = *reinterpret_cast<const float2*>(zb + ((long long)y0 * Wi + x0) * 2);
+    const float2 tr = *reinterpret_cast<const float2*>(zb + ((long long)y0 * Wi + x1) * 2);
+    const float2 bl = *reinterpret_cast<const float2*>(zb + ((long long)y1 * Wi + x0) * 2);
+    const float2 br = *reinterpret_cast<const float2*>(zb + ((long long)y1 * Wi + x1) * 2);
+    const float2 tt = *reinterpret_cast<const float2*>(tb + ((long long)ho * Wo + wo) * 2);
+    float2 zz = make_float2(0.f, 0.f);
+    zz = vfma((1.f - ly) * (1.f - lx), tl, zz);
+    zz = vfma((1.f - ly) * lx, tr, zz);
+    zz = vfma(ly * (1.f - lx), bl, zz);
+    zz = vfma(ly * lx, br, zz);
+    const float m = fmaxf(zz.x, zz.y);
+    const float e0 = expf(zz.x - m), e1 = expf(zz.y - m);
+    const float inv = 1.f / (e0 + e1);
+    const float p0 = e0 * inv, p1 = e1 * inv;
+    const float t0 = tt.x * (1.f - ls) + 0.5f * ls, t1 = tt.y * (1.f - ls) + 0.5f * ls;
+    const float ts = t0 + t1;
+    gl[fr * kHeadFoot + fc] = make_float2((p0 * ts - t0) * inv_rows, (p1 * ts - t1) * inv_rows);
+    if (y0 >= hi0 && y0 <= hi1 && x0 >= wi0 && x0 <= wi1) {   // this tile owns the image pixel's loss terms
+      const float lse = m + logf(e0 + e1);
+      ce -= t0 * (zz.x - lse) + t1 * (zz.y - lse);
+      const float q1 = e1 / (e0 + e1);
+      I += q1 * tt.y;
+      Sp += q1;
+      St += tt.y;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int pg = (t >> 3) + 32 * it, rl = t & 7;
+    const int hi = hi0 + pg / kHeadTile, wi = wi0 + pg % kHeadTile;
+    const bool live = hi <= hi1 && wi <= wi1;
+    const int hc = live ? hi : hi0, wc = live ? wi : wi0;
+    const int ho_lo = head_lo(hc, sh), ho_hi = head_hi(hc, sh, Ho), wo_lo = head_lo(wc, sw), wo_hi = head_hi(wc, sw, Wo);
+    float2 acc = make_float2(0.f, 0.f);
+    for (int ho = ho_lo + rl; ho <= ho_hi; ho += 8) {
+      int y0, y1;
+      float ly;
+      src_coord(ho, sh, Hi, y0, y1, ly);
+      const float wy = (y0 == hc ? 1.f - ly : 0.f) + (y1 == hc ? ly : 0.f);
+      if (wy == 0.f) continue;
+      const float2* row = gl + (ho - fo0) * kHeadFoot - fw0;
+      for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+        int x0, x1;
+        float lx;
+        src_coord(wo, sw, Wi, x0, x1, lx);
+        const float wx = (x0 == wc ? 1.f - lx : 0.f) + (x1 == wc ? lx : 0.f);
+        acc = vfma(wy * wx, row[wo], acc);
+      }
+    }
+#pragma unroll
+    for (int off = 1; off < 8; off <<= 1) {
+      acc.x += __shfl_xor(acc.x, off);
+      acc.y += __shfl_xor(acc.y, off);
+    }
+    if (live && rl == 0) *reinterpret_cast<float2*>(dsmall + ((long long)n * Hi * Wi + (long long)hi * Wi + wi) * 2) = acc;
+  }
+  ce = wave_sum(ce);
+  I = wave_sum(I);
+  Sp = wave_sum(Sp);
+  St = wave_sum(St);
+  const int lane = t & 63, wave = t >> 6;
+  if (lane == 0) {
+    sm[wave][0] = ce;
+    sm[wave][1] = I;
+    sm[wave][2] = Sp;
+    sm[wave][3] = St;
+  }
+  __syncthreads();
+  if (t < 4) part[((long long)n * gridDim.x + blockIdx.x) * 4 + t] = sm[0][t] + sm[1][t] + sm[2][t] + sm[3][t];
+}
+
 // ------------------------------------------------------------------------------------------------ DARC1 regulariser
 // models/regularizers.py:20-22: weight * max over (h, w, c) of sum_n |logits[n,h,w,c]|.  Gradient: weight * sign(logits[n, argmax]) for
 // every n at the ONE arg-max position (ties: the first index).  darc1_partial_k: per-block (max, index); darc1_apply_k (one block):
@@ -534,6 +653,49 @@ int mliis_softmax_ce(const float* logits, const float* labels, const int* img_id
   }
   return MLIIS_OK;
 }
+static inline int head_tiles(int n) { return (n + kHeadTile - 1) / kHeadTile; }
+// 1 when mliis_head_ce_fused takes this pair of maps (the image-side footprint of an 8 x 8 tile of the decoder's map fits its LDS
+// buffer: up-sampling factors up to ~4.5), else 0: use mliis_resize_bilinear_fwd -> mliis_softmax_ce -> mliis_resize_bilinear_bwd.
+int mliis_head_ce_fused_supported(int Hd, int Wd, int H, int W) {
+  if (Hd <= 1 || Wd <= 1 || H <= 1 || W <= 1) return 0;
+  const float sh = (float)(Hd - 1) / (float)(H - 1), sw = (float)(Wd - 1) / (float)(W - 1);
+  const int fh = (int)ceilf((float)(kHeadTile + 1) / sh) + 5, fw = (int)ceilf((float)(kHeadTile + 1) / sw) + 5;
+  return fh <= kHeadFoot && fw <= kHeadFoot;
+}
+
+size_t mliis_head_ce_fused_workspace_floats(int N, int Hd, int Wd) {
+  if (N <= 0 || Hd <= 0 || Wd <= 0) return 0;
+  return (size_t)N * head_tiles(Hd) * head_tiles(Wd) * 4 + 2 * (size_t)N + 8;
+}
+
+// The training step's tail (no dice term) in two launches instead of five: small [N,Hd,Wd,2] = the final conv's output on the
+// decoder's map; logits = bilinear resize (align_corners) to [H,W]; softmax cross-entropy against labels [S,H,W,2] (addressed through
+// img_idx, nullable) with label smoothing; dsmall [N,Hd,Wd,2] = the gradient w.r.t. small (what mliis_resize_bilinear_fwd ->
+// mliis_softmax_ce -> mliis_resize_bilinear_bwd compute, the same arithmetic per element); out[0..2] = {loss + extra_loss, ce, iou}
+// (folded from the launch's per-workgroup partials by ce_finalize_k).  ws: mliis_head_ce_fused_workspace_floats(N, Hd, Wd) floats.
+int mliis_head_ce_fused(const float* small, const float* labels, const int* img_idx, int N, int Hd, int Wd, int H, int W,
+                        float label_smoothing, float extra_loss, float* dsmall, float* out, float* ws, size_t ws_floats,
+                        hipStream_t stream) {
+  MLIIS_REQUIRE(small && labels && dsmall && out && ws, MLIIS_ERR_ARG, "head_ce_fused: null pointer");
+  MLIIS_REQUIRE(N > 0 && Hd > 1 && Wd > 1 && H > 1 && W > 1 && N <= 65535, MLIIS_ERR_ARG, "head_ce_fused: bad shape (both maps must be larger than 1x1)");
+  MLIIS_REQUIRE(mliis_head_ce_fused_supported(Hd, Wd, H, W), MLIIS_ERR_UNSUPPORTED,
+                "head_ce_fused: up-sampling factor too large for the tile footprint (mliis_head_ce_fused_supported)");
+  MLIIS_REQUIRE((reinterpret_cast<uintptr_t>(small) & 7u) == 0 && (reinterpret_cast<uintptr_t>(labels) & 7u) == 0 &&
+                    (reinterpret_cast<uintptr_t>(dsmall) & 7u) == 0,
+                MLIIS_ERR_ALIGN, "head_ce_fused: tensors must be 8-byte aligned");
+  const int tx = head_tiles(Wd), nblk = head_tiles(Hd) * tx;
+  MLIIS_REQUIRE((size_t)N * nblk * 4 + 2 * (size_t)N <= ws_floats && aligned16(ws), MLIIS_ERR_WORKSPACE,
+                "head_ce_fused: workspace too small or unaligned");
+  float* coef = ws + (size_t)N * nblk * 4;
+  const float sh = (float)(Hd - 1) / (float)(H - 1), sw = (float)(Wd - 1) / (float)(W - 1);
+  hipLaunchKernelGGL(head_ce_fused_k, dim3(nblk, N), dim3(256), 0, stream, small, labels, img_idx, N, Hd, Wd, H, W, sh, sw, label_smoothing,
+                     1.0f / ((float)N * (float)H * (float)W), dsmall, ws, tx);
+  MLIIS_CHECK_LAUNCH("head_ce_fused");
+  hipLaunchKernelGGL(ce_finalize_k, dim3(1), dim3(256), 0, stream, ws, nblk, N, H * W, 0, extra_loss, out, coef);
+  MLIIS_CHECK_LAUNCH("head_ce_fused_finalize");
+  return MLIIS_OK;
+}
+
 static int swish_mask_check(const char* name, const void* a, int lda, const void* b, int ldb, const void* m, int ldm, const void* o, int ldo,
                             long long rows, int C) {
   MLIIS_REQUIRE(a && b && o, MLIIS_ERR_ARG, "%s: null pointer", name);

@@ -22,6 +22,7 @@ from __future__ import annotations
 
 import ctypes as C
 import functools
+import os
 from typing import Dict, List, Optional, Sequence
 
 import numpy as np
@@ -40,7 +41,7 @@ class Learner(_Passes):
                  dice: bool = False, label_smoothing: float = 0.0, final_layer_dropout_rate: float = 0.0,
                  spatial_pyramid_pooling: bool = False, skip_decoding: bool = False, drop_connect: bool = True, seed: int = 0,
                  device="cuda:0", use_graph: bool = True, max_shots: int = 16, matmul_precision: str = "fp32",
-                 small_fused: Optional[bool] = None, dw_march: Optional[bool] = None,
+                 small_fused: Optional[bool] = None, dw_march: Optional[bool] = None, fuse_bn2: Optional[bool] = None, fuse_head: Optional[bool] = None,
                  augment_batch_capacity: int = 0, rng_stream: int = 0):
         if optimizer not in ("sgd", "adam"):
             raise ValueError("optimizer must be 'sgd' or 'adam' (Adam with beta1=0, the reference default)")
@@ -84,6 +85,14 @@ class Learner(_Passes):
         # small_fused / dw_march = False force that op-by-op path (tests of the fallback).
         self.small_fused = True if small_fused is None else bool(small_fused)
         self.dw_march = True if dw_march is None else bool(dw_march)
+        # fuse_bn2 = True: a block's project batch norm (+ drop-connect, + identity skip) is applied by the NEXT block's expand conv while
+        # it loads its rows (ops.conv2d_fwd_bnin: ten launches fewer per step).  Built and parity-tested in round 5, measured SLOWER
+        # than the stand-alone apply launches (-0.8 % on the step: every one of the 390-512 workgroups of an expand conv needs all K
+        # channels' statistics and folds all the producer's partial blocks itself -- 24-44 MB of redundant L2 reads per launch against
+        # 3 MB in the 39-52 workgroups of the apply kernel; profiles/r05_notes.md), so OFF by default; MLIIS_FUSE_BN2=1 turns it on
+        self.fuse_bn2 = (os.environ.get("MLIIS_FUSE_BN2") == "1") if fuse_bn2 is None else bool(fuse_bn2)
+        # fuse_head = False: resize -> softmax cross-entropy -> gradient -> resize^T as four launches (the form before round 5)
+        self.fuse_head = (os.environ.get("MLIIS_NO_FUSE_HEAD") is None) if fuse_head is None else bool(fuse_head)
         self.use_graph = use_graph
         self.stream = torch.cuda.Stream(device=self.device)
         # batch indices go up through a ring of pinned slots: an upload from pageable memory makes the host wait for this stream
@@ -461,12 +470,20 @@ class Learner(_Passes):
     def _train_sequence(self, P: _Plan, draw_masks: bool):
         if draw_masks and P.mask_plan is not None:
             ops.rng_masks(self.rng_state, P.mask_plan)
-        logits = self._forward(P, self.shots_x, P.idx, True)
-        ops.softmax_ce(logits, self.shots_y, P.idx, self.label_smoothing, self.dice, 0.0, want_grad=True, want_pred=False,
-                       dlogits=P.dlogits, out=P.loss_out, ws=self.ws)
-        if self.darc1:
-            ops.darc1(logits, spec.L2_WEIGHT, dlogits=P.dlogits, out=P.loss_out, ws=self.ws)
-        self._backward(P, self.shots_x, P.idx)
+        # Without the dice term (and DARC1, which reads the full-resolution logits) the tail of the step -- resize to the image size,
+        # softmax cross-entropy, its gradient, the resize's transpose -- is ONE launch on the decoder's map (ops.head_ce_fused)
+        hd_, H_ = self.arch.h_dec, self.arch.image_size
+        head_fused = bool(self.fuse_head and not self.dice and not self.darc1 and lib.size("mliis_head_ce_fused_supported", hd_, hd_, H_, H_))
+        logits = self._forward(P, self.shots_x, P.idx, True, upsample=not head_fused)
+        if head_fused:
+            H = self.arch.image_size
+            ops.head_ce_fused(P.small, self.shots_y, P.idx, (H, H), self.label_smoothing, P.dsmall, P.loss_out, ws=self.ws)
+        else:
+            ops.softmax_ce(logits, self.shots_y, P.idx, self.label_smoothing, self.dice, 0.0, want_grad=True, want_pred=False,
+                           dlogits=P.dlogits, out=P.loss_out, ws=self.ws)
+            if self.darc1:
+                ops.darc1(logits, spec.L2_WEIGHT, dlogits=P.dlogits, out=P.loss_out, ws=self.ws)
+        self._backward(P, self.shots_x, P.idx, head_fused=head_fused)
         self._apply()
 
     def inner_step(self, batch_idx: Sequence[int], lr: Optional[float] = None, dc_scales: Optional[Dict[int, torch.Tensor]] = None,

@@ -399,6 +399,44 @@ def conv2d_fwd(x, w, bias=None, dil=1, out=None, accumulate=False, ws: Optional[
     return out
 
 
+def conv2d_fwd_bnin_ok(N, H, W, Cin, Cout) -> bool:
+    """True when a 1x1 conv of this shape takes the streamed plan, i.e. when conv2d_fwd_bnin accepts it."""
+    return bool(lib.size("mliis_conv2d_fwd_bnin_ok", N, H, W, Cin, Cout))
+
+
+def conv2d_fwd_bnin(z, part, nblk, mean, rstd, gamma, beta, a_out, w, out, moving=None, img_scale=None, res=None, stats_part=None,
+                    stats_swish=False, wt=None, precision="fp32", fp8_act_scale=FP8_ACT_SCALE, fp8_w_amax=None, out_block=0, eps=BN_EPS,
+                    momentum=BN_MOMENTUM):
+    """out = conv1x1(a, w) with a = bn(z) * img_scale[image] + res formed while z is loaded (the project batch norm of the MBConv block
+    in front, fused into this block's expand conv); a is also written to a_out, mean / rstd / moving averages as bn_apply_fused does.
+    Returns (out, stats_nblk)."""
+    N, H, W = z.shape[:3]
+    _, Cin, ldz = rows_ld(z)
+    k, _, Cin_w, Cout = w.shape
+    if k != 1 or Cin_w != Cin:
+        raise MliisError("conv2d_fwd_bnin: a 1x1 weight over the {} channels of z expected, got {}".format(Cin, tuple(w.shape)))
+    wt = hwoi(w) if wt is None else wt
+    _, _, ldy = rows_ld(out)
+    _, _, ldo = rows_ld(a_out)
+    ldr = rows_ld(res)[2] if res is not None else 0
+    mm, mv = (None, None) if moving is None else moving
+    prec = _prec(precision)
+    if prec == 2 and fp8_w_amax is None:
+        fp8_w_amax = w.abs().max().reshape(1)
+    if stats_part is not None and stats_part.numel() < (-(-N * H * W // 16)) * 2 * Cout:
+        raise MliisError("conv2d_fwd_bnin: stats_part too small")
+    meta = {}
+    if PROFILE is not None:
+        meta = dict(kernel=conv2d_kernel_name(N, H, W, Cin, Cout, 1, False, precision), splits=1, flops=2.0 * N * H * W * Cin * Cout,
+                    shape=(N, H, W, Cin, Cout, 1, 1))
+    nb = C.c_int(0)
+    _timed("conv2d_fwd", meta, lambda: lib.call("mliis_conv2d_fwd_bnin", _ptr(_chk(z)), ldz, _ptr(part), int(nblk), eps, momentum, _ptr(mean), _ptr(rstd),
+                                                _ptr(mm), _ptr(mv), _ptr(gamma), _ptr(beta), _ptr(img_scale), _ptr(res), ldr, _ptr(a_out), ldo,
+                                                _ptr(wt), _aptr(out), ldy, N, H, W, Cin, Cout, _ptr(stats_part), int(stats_swish), C.byref(nb), prec,
+                                                float(fp8_act_scale), _ptr(fp8_w_amax), _dt(out) | (int(out_block) << 8), _stream()))
+    return out, nb.value
+
+
 class X3Images:
     """Pre-split weight images of the dense convs that run under MLIIS_PREC_F32X3 (csrc/conv_x3.hip): add() every (conv, direction)
     once, finish() builds the device descriptor table, pack(theta) re-splits all of them in ONE launch (once per inner step: the
@@ -951,6 +989,17 @@ def softmax_ce(logits, labels, idx=None, label_smoothing=0.0, dice=False, extra_
     lib.call("mliis_softmax_ce", _ptr(logits), _ptr(labels), _ptr(idx), N, H, W, float(label_smoothing), int(dice), float(extra_loss),
              _ptr(dlogits) if want_grad else None, _ptr(pred) if want_pred else None, _ptr(out), _ptr(buf), buf.numel(), _stream())
     return out, dlogits, pred
+
+
+def head_ce_fused(small, labels, idx, size, label_smoothing, dsmall, out, extra_loss=0.0, ws: Optional[Workspace] = None):
+    """resize(small -> size) -> softmax cross-entropy (no dice term) -> gradient -> resize^T: dsmall and out[0..2] = {loss, ce, iou};
+    the full-resolution logits are never written (two launches instead of five)."""
+    N, Hd, Wd, _ = small.shape
+    ws = ws or default_ws()
+    buf = ws.get(lib.size("mliis_head_ce_fused_workspace_floats", N, Hd, Wd))
+    _timed("head_ce_fused", {}, lambda: lib.call("mliis_head_ce_fused", _ptr(_chk(small)), _ptr(labels), _ptr(idx), N, Hd, Wd, int(size[0]), int(size[1]),
+                                                 float(label_smoothing), float(extra_loss), _ptr(dsmall), _ptr(out), _ptr(buf), buf.numel(), _stream()))
+    return out, dsmall
 
 
 def darc1(logits, weight, dlogits=None, out=None, ws: Optional[Workspace] = None):

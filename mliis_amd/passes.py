@@ -22,7 +22,7 @@ class _Passes:
     def _x3_takes(self, wname, xin) -> bool:
         return self.x3 is not None and self.x3.has(wname, "fwd") and xin.shape[0] * xin.shape[1] * xin.shape[2] >= self.X3_MIN_ROWS
 
-    def _forward(self, P: _Plan, x, idx, training: bool):
+    def _forward(self, P: _Plan, x, idx, training: bool, upsample: bool = True):
         A, a, ws, N = self.arena, self.arch, self.ws, P.N
         w, mv = A.w, A.mv
 
@@ -47,9 +47,17 @@ class _Passes:
         if self.x3 is not None:
             self.x3.pack(A.theta)
 
-        def conv(xin, wname, bname, dil, out, swish_stats, x_scale=None, border_bias=None, out_block=0):
-            """dense conv; in training the epilogue also emits the following BN's statistics (returns their block count)."""
+        def conv(xin, wname, bname, dil, out, swish_stats, x_scale=None, border_bias=None, out_block=0, part=None, bnin=None):
+            """dense conv; in training the epilogue also emits the following BN's statistics (returns their block count) into
+            P.stats_part, or `part`.  bnin: the batch norm in front of this conv (the previous block's project BN, deferred: see the end
+            of the block loop) applied while the conv loads its rows -- xin is then that batch norm's OUTPUT buffer, written by the launch."""
             am = self._amax_of.get(wname)
+            if bnin is not None:
+                st, prefix = bnin["st"], bnin["prefix"]
+                return ops.conv2d_fwd_bnin(bnin["z"], P.stats_part3, bnin["nblk"], st[0], st[1], w[prefix + "/gamma"], w[prefix + "/beta"], xin,
+                                           w[wname], out, moving=(mv[prefix + "/moving_mean"], mv[prefix + "/moving_variance"]),
+                                           img_scale=bnin["img_scale"], res=bnin["res"], stats_part=P.stats_part, stats_swish=swish_stats,
+                                           wt=self.wt[wname], precision=self.matmul_precision, fp8_w_amax=am, out_block=out_block)[1]
             if self._x3_takes(wname, xin):   # (fp32x3: a long-K decoder conv on a map large enough to fill the chip)
                 k_, co_ = w[wname].shape[0], w[wname].shape[3]
                 if training:
@@ -59,7 +67,7 @@ class _Passes:
                                   border_bias=border_bias)
                 return 0
             if training:
-                return self._conv_fwd(xin, w[wname], w[bname] if bname else None, dil, out=out, ws=ws, stats_part=P.stats_part,
+                return self._conv_fwd(xin, w[wname], w[bname] if bname else None, dil, out=out, ws=ws, stats_part=P.stats_part if part is None else part,
                                       stats_swish=swish_stats, wt=self.wt[wname], x_scale=x_scale, border_bias=border_bias, fp8_w_amax=am,
                                       out_block=out_block)[1]
             self._conv_fwd(xin, w[wname], w[bname] if bname else None, dil, out=out, ws=ws, wt=self.wt[wname], x_scale=x_scale,
@@ -86,14 +94,31 @@ class _Passes:
             torch.rsqrt(mv[prefix + "/moving_variance"] + spec.BN_EPS, out=st[1])
             return (g_, b_, st[0], st[1], None, None), 0
 
+        pend = None   # the previous block's project batch norm, when this block's expand conv applies it on load (P.bn2_deferred)
+
+        def block_end(bi_, b, B, nm, nb, use_dc):
+            """The block's project batch norm (+ drop-connect scale, + identity skip): a launch of its own, or -- training, the next
+            block's expand conv on the streamed plan -- handed to that conv, which forms the block output while it loads its rows
+            and writes it to B["out"] (ops.conv2d_fwd_bnin: one launch and one pass over z2 less per block)."""
+            nonlocal pend
+            img_scale, res = (B["dc"] if use_dc else None), (B["x_in"] if b.skip else None)
+            if training and P.bn2_deferred[bi_]:
+                if nb == 0:
+                    nb = ops.bn_stats_partial(B["z2"], False, P.stats_part3)
+                pend = dict(z=B["z2"], nblk=nb, st=B["st2"], prefix=nm["bn2"], img_scale=img_scale, res=res)
+                return B["out"]
+            return bn(B["z2"], B["st2"], nm["bn2"], B["out"], img_scale=img_scale, res=res, nblk=nb)
+
         for bi_, (b, B, nm) in enumerate(zip(ex, P.blocks, self.n_blocks)):
             B["x_in"] = cur
             t = cur
+            bnin, pend = pend, None
+            defer = training and P.bn2_deferred[bi_]
             if training and B["small"]:
                 # expand GEMM (+ stage-1 statistics) -> ONE launch: bn0 fold + apply + swish, depthwise, bn1 statistics + apply + swish,
                 # squeeze-excite means, both moving averages -> SE MLP -> project GEMM
                 z0 = B["z0b"] if B["blk"] else B["z0"]     # (blk: the expand conv writes the group-blocked layout itself)
-                nb = conv(t, nm["w_exp"], None, 1, z0, False, out_block=B["blk"])
+                nb = conv(t, nm["w_exp"], None, 1, z0, False, out_block=B["blk"], bnin=bnin)
                 if nb == 0:
                     if B["blk"]:
                         raise MliisError("internal: the streamed expand conv of block {} left no statistics".format(b.idx))
@@ -106,16 +131,16 @@ class _Passes:
                                         B["z1"], B["a1"], B["s"], z0_blocked=B["z0b"], z1_blocked=True)   # (the backward's re-reads: contiguous)
                 se = nm["se"]
                 ops.se_mlp_fwd(B["s"], w[se[0]], w[se[1]], w[se[2]], w[se[3]], B["hpre"], B["gate"])
-                nb = conv(B["a1"], nm["w_proj"], None, 1, B["z2"], False, x_scale=B["gate"])
+                nb = conv(B["a1"], nm["w_proj"], None, 1, B["z2"], False, x_scale=B["gate"], part=P.stats_part3 if defer else None)
                 use_dc = self.drop_connect and b.skip and b.drop_rate > 0
                 B["use_dc"] = use_dc
-                cur = bn(B["z2"], B["st2"], nm["bn2"], B["out"], img_scale=B["dc"] if use_dc else None, res=B["x_in"] if b.skip else None, nblk=nb)
+                cur = block_end(bi_, b, B, nm, nb, use_dc)
                 continue
             if B["march"]:
                 # expand GEMM (+ stage-1 statistics) -> ONE launch: bn0 fold + apply + swish while the rows are staged, depthwise conv,
                 # bn1 stage-1 statistics (P.stats_part2)
                 if b.expand != 1:
-                    nb = conv(t, nm["w_exp"], None, 1, B["z0"], False)
+                    nb = conv(t, nm["w_exp"], None, 1, B["z0"], False, bnin=bnin)
                     bn0, nb = bn_in(B["z0"], B["st0"], nm["bn0"], nb)
                     zin = B["z0"]
                 elif bi_ == 0 and fuse_stem:
@@ -132,7 +157,7 @@ class _Passes:
                 st_part = P.stats_part2
             else:
                 if b.expand != 1:
-                    nb = conv(t, nm["w_exp"], None, 1, B["z0"], False)
+                    nb = conv(t, nm["w_exp"], None, 1, B["z0"], False, bnin=bnin)
                     t = bn(B["z0"], B["st0"], nm["bn0"], B["a0"], post=True, nblk=nb)
                 if training:   # the depthwise launch also leaves bn1's stage-1 statistics in P.stats_part
                     nb = ops.dwconv_fwd(t, w[nm["w_dw"]], b.stride, out=B["z1"], stats_part=P.stats_part)[1]
@@ -151,10 +176,12 @@ class _Passes:
                 ops.colsum(B["a1"], None, nseg=N, scale=1.0 / hw, out=B["s"], ws=ws)
                 ops.se_mlp_fwd(B["s"], w[se[0]], w[se[1]], w[se[2]], w[se[3]], B["hpre"], B["gate"])
             # squeeze-excite gate applied inside the project GEMM's A loader (the gated tensor is never written)
-            nb = conv(B["a1"], nm["w_proj"], None, 1, B["z2"], False, x_scale=B["gate"])
+            nb = conv(B["a1"], nm["w_proj"], None, 1, B["z2"], False, x_scale=B["gate"], part=P.stats_part3 if defer else None)
             use_dc = training and self.drop_connect and b.skip and b.drop_rate > 0
             B["use_dc"] = use_dc
-            cur = bn(B["z2"], B["st2"], nm["bn2"], B["out"], img_scale=B["dc"] if use_dc else None, res=B["x_in"] if b.skip else None, nblk=nb)
+            cur = block_end(bi_, b, B, nm, nb, use_dc)
+        if pend is not None:
+            raise MliisError("internal: a deferred project batch norm was not consumed")
         ends = {r: P.blocks[bi]["out"] for r, bi in a.reductions.items() if bi < len(P.blocks)}
         dec = ends[4]
         if a.aspp:
@@ -234,6 +261,8 @@ class _Passes:
         P.dec_in = dec
         ops.final_conv_fwd(dec, w[self.n_final[0]], w[self.n_final[1]], mask, out=P.small)
         H = a.image_size
+        if not upsample:   # (the fused head launch reads the decoder-resolution logits: Learner._train_sequence)
+            return None
         ops.resize_bilinear_fwd(P.small, (H, H), out=P.logits)
         return P.logits
 
@@ -294,11 +323,12 @@ class _Passes:
         ops.chan_affine(None, A=T["dpool"], out=dx, accumulate=True)
 
     # ------------------------------------------------------------------------------------------- backward
-    def _backward(self, P: _Plan, x, idx):
+    def _backward(self, P: _Plan, x, idx, head_fused: bool = False):
         A, a, ws, N = self.arena, self.arch, self.ws, P.N
         w, g = A.w, A.g
         hd = a.h_dec
-        ops.resize_bilinear_bwd(P.dlogits, (hd, hd), out=P.dsmall)
+        if not head_fused:   # (ops.head_ce_fused left the gradient on the decoder's map already)
+            ops.resize_bilinear_bwd(P.dlogits, (hd, hd), out=P.dsmall)
         mask = P.drop_mask
         ops.final_conv_bwd_filter(P.dec_in, P.dsmall, mask, dw=g[self.n_final[0]], db=g[self.n_final[1]], ws=ws)
         ex = [b for b in a.blocks if b.executed]

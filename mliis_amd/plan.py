@@ -150,6 +150,14 @@ class _Plan:
         for m in a.rsd:   # (and the second RSD branch GEMM's statistics, folded together with the first's by ops.bn_apply_fused_pair)
             need2 = max(need2, -(-(N * m.h * m.h) // 16) * 2 * m.c_out, ops.bn_stats_partial_floats(N * m.h * m.h, m.c_out))
         self.stats_part2 = buf(need2 + 64)
+        # project-BN-on-load (ops.conv2d_fwd_bnin): block i's project conv leaves its statistics in a THIRD buffer -- block i + 1's expand
+        # conv folds them while its own workgroups already write the next batch norm's into stats_part.  bn2_deferred[i]: block i's
+        # project batch norm (+ drop-connect, + identity skip) is applied by block i + 1's expand conv while it loads its rows
+        # (training passes; inference keeps the stand-alone apply)
+        ex_ = [b for b in a.blocks if b.executed]
+        self.bn2_deferred = [bool(L.fuse_bn2 and i + 1 < len(ex_) and ex_[i + 1].expand != 1 and act_dtype in (torch.float32, torch.bfloat16) and
+                                  ops.conv2d_fwd_bnin_ok(N, ex_[i].h_out, ex_[i].h_out, ex_[i].cout, ex_[i + 1].cexp)) for i in range(len(ex_))]
+        self.stats_part3 = buf(max([-(-(N * b.h_out ** 2) // 16) * 2 * b.cout for b, d in zip(ex_, self.bn2_deferred) if d] + [0]) + 64)
         # the squeeze-excite backward and the depthwise batch norm's backward share ONE pass over (da2, z1) (ops.se_bn_bwd_sums): its
         # per-image chunk sums, and the batch norm's stage-1 sums per image that ops.se_mlp_bwd_bn forms from them
         self.sums_part = buf(max([ops.se_bn_bwd_sums_floats(N, b.h_out * b.h_out, b.cexp) for b in a.blocks if b.executed] + [0]) + 64)

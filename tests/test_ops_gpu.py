@@ -603,6 +603,106 @@ def test_conv_epilogue_statistics_and_fused_bn(k, dil, H, W, Cin, Cout, N, swish
     close(y2, y, 3e-5, "fused bn apply (stats kernel)")
 
 
+@pytest.mark.parametrize("N,hd,H,ls,S", [(8, 56, 224, 0.0, 5), (3, 16, 64, 0.1, 3), (2, 24, 96, 0.0, 2), (5, 7, 28, 0.2, 5), (1, 56, 224, 0.0, 1),
+                                         (2, 96, 384, 0.0, 2), (2, 13, 37, 0.1, 2), (3, 21, 21, 0.0, 3)])
+def test_head_ce_fused_equals_the_four_launch_tail(N, hd, H, ls, S):
+    """mliis_head_ce_fused (resize -> softmax cross-entropy -> gradient -> resize^T on the decoder's map) == the chain
+    mliis_resize_bilinear_fwd -> mliis_softmax_ce -> mliis_resize_bilinear_bwd to fp32 rounding; both against the float64 oracle
+    (efficientlab.py:166-173,294-303); a second launch gives the same bits."""
+    from mliis_amd import ops
+    d = dev()
+    small = rnd(N, hd, hd, 2, seed=90) * 3
+    lab = (torch.rand(S, H, H, 1, generator=torch.Generator().manual_seed(91)) > 0.6).double()
+    labels = torch.cat([1 - lab, lab], dim=-1)
+    idx = torch.tensor([i % S for i in range(N)], dtype=torch.int32)
+    sg, lg, ig = f32(small, d), f32(labels, d), idx.to(d)
+    # oracle
+    sm = small.clone().requires_grad_(True)
+    logits = nhwc(F.interpolate(nchw(sm), size=(H, H), mode="bilinear", align_corners=True))
+    t = labels[idx.long()] * (1 - ls) + 0.5 * ls
+    ce = -(t * torch.log_softmax(logits, dim=-1)).sum(-1).mean()
+    (gs,) = torch.autograd.grad(ce, [sm])
+    # four launches
+    lo = ops.resize_bilinear_fwd(sg, (H, H))
+    out1 = torch.zeros(4, device=d)
+    _, dl, _ = ops.softmax_ce(lo, lg, ig, ls, False, 0.0, want_grad=True, out=out1)
+    ds1 = ops.resize_bilinear_bwd(dl, (hd, hd))
+    # fused
+    out2, ds2 = torch.zeros(4, device=d), torch.full_like(sg, float("nan"))
+    ops.head_ce_fused(sg, lg, ig, (H, H), ls, ds2, out2)
+    close(ds2, ds1, 3e-6, "gradient vs the five-launch tail")   # (the same arithmetic per element; fp contraction may differ between kernels)
+    close(ds2, gs, 2e-5, "gradient on the decoder's map")
+    assert abs(out2[0].item() - ce.item()) <= 2e-6 * max(1.0, abs(ce.item())), (out2, ce)
+    assert torch.allclose(out2[:3], out1[:3], rtol=2e-6, atol=1e-7), (out1, out2)
+    out3, ds3 = torch.zeros(4, device=d), torch.empty_like(sg)
+    ops.head_ce_fused(sg, lg, ig, (H, H), ls, ds3, out3)
+    assert torch.equal(ds3, ds2) and torch.equal(out3, out2)
+
+
+# (N, H, W, Cin, Cout, residual, drop-connect, precision): the five expand convs of EfficientLab-6-3 at 224x224 (16 -> 96 at 112x112,
+#  24 -> 144 at 56x56, 40 -> 240 at 28x28, 80 -> 480 and 112 -> 672 at 14x14), a map whose row count is no multiple of 16 with images
+#  that end inside a row group, a channel count that pads a K group, and the reduced-precision instances
+@pytest.mark.parametrize("N,H,W,Cin,Cout,res,dc,prec", [(8, 112, 112, 16, 96, False, False, "fp32"), (8, 56, 56, 24, 144, True, True, "fp32"),
+                                                        (8, 28, 28, 40, 240, True, True, "fp32"), (8, 14, 14, 80, 480, True, False, "fp32"),
+                                                        (8, 14, 14, 112, 672, True, True, "fp32"), (3, 19, 21, 24, 40, True, True, "fp32"),
+                                                        (5, 15, 15, 36, 100, False, True, "fp32"), (8, 14, 14, 112, 672, True, True, "bf16"),
+                                                        (8, 28, 28, 40, 240, True, True, "fp8")])
+def test_conv1x1_with_the_batch_norm_in_front_applied_on_load(N, H, W, Cin, Cout, res, dc, prec):
+    """mliis_conv2d_fwd_bnin: the project batch norm of the MBConv block in front (+ drop-connect scale per image, + identity skip:
+    efficientnet_model.py:283-288, utils.py:157-170) applied while the next block's expand conv loads its rows == bn_apply_fused +
+    conv2d_fwd (two launches) == float64 oracle: the conv output and its fused statistics, the finished block tensor a_out, mean /
+    rstd and the moving averages."""
+    from mliis_amd import ops
+    d = dev()
+    if not ops.conv2d_fwd_bnin_ok(N, H, W, Cin, Cout):
+        pytest.skip("not a streamed 1x1 shape")
+    z = rnd(N, H, W, Cin, seed=70) * (rnd(Cin, seed=71).abs() + 0.5) + rnd(Cin, seed=72)
+    w = rnd(1, 1, Cin, Cout, seed=73, scale=1.0 / math.sqrt(Cin))
+    gamma, beta = rnd(Cin, seed=74) * 0.3 + 1, rnd(Cin, seed=75)
+    r = rnd(N, H, W, Cin, seed=76) if res else None
+    sc = (torch.rand(N, generator=torch.Generator().manual_seed(77), dtype=torch.float64) > 0.3).double() / 0.7 if dc else None
+    mean, var = z.mean(dim=(0, 1, 2)), z.var(dim=(0, 1, 2), unbiased=False)
+    a = (z - mean) * torch.rsqrt(var + 1e-3) * gamma + beta
+    if dc:
+        a = a * sc[:, None, None, None]
+    if res:
+        a = a + r
+    y = nhwc(R.conv2d_same(nchw(a), w, 1, 1))
+    zg, wg = f32(z, d), f32(w, d)
+    nst = (-(-N * H * W // 16)) * 2 * Cout + 64
+    part, part2, part3 = torch.empty(1 << 18, device=d), torch.empty(nst, device=d), torch.empty(nst, device=d)
+    nblk = ops.bn_stats_partial(zg, False, part)
+    m1, r1, m2, r2 = (torch.empty(Cin, device=d) for _ in range(4))
+    mm1, mv1, mm2, mv2 = torch.zeros(Cin, device=d), torch.ones(Cin, device=d), torch.zeros(Cin, device=d), torch.ones(Cin, device=d)
+    rg_, scg = (f32(r, d) if res else None), (f32(sc, d) if dc else None)
+    # two launches
+    a1 = ops.bn_apply_fused(zg, part, nblk, m1, r1, f32(gamma, d), f32(beta, d), moving=(mm1, mv1), img_scale=scg, res=rg_)
+    y1, nb1 = ops.conv2d_fwd(a1, wg, None, 1, stats_part=part2, precision=prec)
+    # one launch
+    a2, y2 = torch.full_like(a1, float("nan")), torch.empty_like(y1)
+    _, nb2 = ops.conv2d_fwd_bnin(zg, part, nblk, m2, r2, f32(gamma, d), f32(beta, d), a2, wg, y2, moving=(mm2, mv2), img_scale=scg, res=rg_,
+                                 stats_part=part3, precision=prec)
+    tol = {"fp32": 2e-5, "bf16": 1e-2, "fp8": 1e-1}[prec]
+    close(a2, a, 3e-5, "block tensor")
+    close(a2, a1, 2e-6, "block tensor vs the stand-alone apply")
+    close(y2, y, tol, "conv of the normalised tensor")
+    close(y2, y1, 2e-6 if prec == "fp32" else tol, "conv vs the two-launch form")
+    close(m2, mean, 1e-5, "mean")
+    close(r2, torch.rsqrt(var + 1e-3), 1e-5, "rstd")
+    assert torch.equal(m2, m1) and torch.equal(r2, r1) and torch.equal(mm2, mm1) and torch.equal(mv2, mv1)   # (the same fold, bit for bit)
+    close(mm2, 0.01 * mean, 1e-5, "moving mean")
+    close(mv2, 0.99 + 0.01 * var, 1e-5, "moving var")
+    assert nb1 == nb2 and nb2 > 0
+    s1 = part2[: nb1 * 2 * Cout].view(nb1, 2, Cout).double().sum(0)
+    s2 = part3[: nb2 * 2 * Cout].view(nb2, 2, Cout).double().sum(0)
+    close(s2, s1, 1e-5 if prec == "fp32" else tol, "statistics of the conv output")
+    # group-blocked output (what the small-map fused kernels read) through the same loader
+    if prec == "fp32" and Cout % 4 == 0 and H * W <= 256:
+        y3 = torch.empty(N, H, W, Cout, device=d)
+        ops.conv2d_fwd_bnin(zg, part, nblk, m2, r2, f32(gamma, d), f32(beta, d), a2, wg, y3, img_scale=scg, res=rg_, stats_part=part3, out_block=4)
+        assert torch.equal(y3.view(Cout // 4, N * H * W, 4).permute(1, 0, 2).reshape(N, H, W, Cout), y2)
+
+
 @pytest.mark.parametrize("H,W,Cin,Cout,N", [(14, 14, 240, 40, 3), (7, 9, 96, 24, 2), (28, 28, 144, 40, 2)])
 def test_conv1x1_with_se_gate_on_the_fly(H, W, Cin, Cout, N):
     """x_scale: the squeeze-excite gate applied inside the GEMM loaders == conv / filter-gradient of the gated tensor."""

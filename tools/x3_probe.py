@@ -47,7 +47,7 @@ def main():
         gflop = 2.0 * N * h * h * k * k * ci * co * 1e-9
         for mode in ("fwd", "bwd_data"):
             row = [name, mode]
-            for prec in ("fp32", "fp32x3", "x3k"):
+            for prec in ("fp32", "x3k"):
                 if prec == "x3k" and mode == "fwd":
                     y = torch.empty(N, h, h, co, device=d)
                     im = ops.x3_image_of(w, "fwd")
