@@ -475,7 +475,11 @@ __device__ __forceinline__ void conv_filter_x3_body(const FilterGradParams& p, c
   const int tap = mt ? 0 : bx / cblocks;
   const int ci0 = mt ? 0 : (bx - tap * cblocks) * BCI;
   const int n0 = by * BN;
+#ifdef F3_SAMEBZ   // ablation: every pixel split reads the FIRST pixel range (wrong numbers: the kernel with its operands L2-resident)
+  const int mbeg = 0;
+#else
   const int mbeg = bz * p.rows_per_split;
+#endif
   int mend = mbeg + p.rows_per_split;
   if (mend > M) mend = M;
   const int HW = p.H * p.W;
@@ -626,12 +630,18 @@ __device__ __forceinline__ void conv_filter_x3_body(const FilterGradParams& p, c
 #define X3_MM(PA, PB)                                                                                            \
   acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3[PA][0], b3[j & 1][PB], acc[0][j], 0, 0, 0);           \
   acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3[PA][1], b3[j & 1][PB], acc[1][j], 0, 0, 0);
+#ifdef F3_NOMFMA   // ablation: the chunk skeleton without its matrix instructions (one per accumulator keeps the fragments live)
+        X3_MM(0, 0)
+#else
         X3_MM(2, 0) X3_MM(0, 2) X3_MM(1, 1) X3_MM(1, 0) X3_MM(0, 1) X3_MM(0, 0)
+#endif
 #undef X3_MM
       }
+#ifndef F3_NOSTAGE
 #pragma unroll
       for (int k = 0; k < NP; ++k)
         if ((k * NTW) / NP == j) split_piece(k, rx, rd);
+#endif
       __builtin_amdgcn_sched_barrier(0);
     }
   };
@@ -646,7 +656,9 @@ __device__ __forceinline__ void conv_filter_x3_body(const FilterGradParams& p, c
   lds_barrier();
   auto trip = [&](char* cur, char* nxt, float4 (&rx)[2], float4 (&rd)[D_PER_THREAD]) {   // (rx, rd): the chunk after the one in `cur`
     compute_split(cur, rx, rd);   // + the split of the next chunk
+#ifndef F3_NOSTAGE                // (ablation: no split arithmetic, no LDS stores -- the products run on stale stages)
     store_terms(nxt);             // (zeros after the last chunk: nobody reads them)
+#endif
     load_chunk(rx, rd);           // two chunks after the one just split
     lds_barrier();
   };
@@ -675,10 +687,19 @@ __device__ __forceinline__ void conv_filter_x3_body(const FilterGradParams& p, c
     }
 }
 
+// (Round 5, measured and removed: a form in which a workgroup multiplies the THREE taps of one kernel row per staged chunk -- a chunk
+//  = a segment of one image row, the X window of 32 + 2 dil pixels staged once, dY staged once for three taps, 16 channels x all column
+//  tiles per wave.  Ablations of the one-tap form on the decoder's two 56x56 problems, 178 us as one cold launch
+//  (-DF3_NOMFMA / -DF3_NOSTAGE / -DF3_SAMEBZ): 1 of 6 matrix instructions 116 us; no split arithmetic and no LDS stores 97 us; both
+//  40 us; every workgroup on the same pixels 163 us -- the parts add and traffic is not the bound.  The kernel-row form: 158 us cold,
+//  149 against 151 us inside the step, 3424 / 3416 against 3409 / 3418 images/s: no gain where it counts, 330 lines: not kept.)
 // the problems of one (TMF = 2, NT) group of a FilterBatch as one grid: descriptor table as conv_filter_grad2_batched_k
 template <int NT>
 __global__ __launch_bounds__(512) void conv_filter_x3_batched_k(const long long* __restrict__ desc, int nprob) {
   __shared__ __attribute__((aligned(16))) char sm[2 * kF3Stage];
+  // (The 18 (tap, channel-block) workgroups of one pixel range read the same dY rows and overlapping X rows and have consecutive block
+  //  ids, which the hardware deals round-robin over the eight XCDs.  Remapped so that they share ONE L2 -- xcd_remap -- the launch
+  //  took 183 us instead of 152: eight L2s serve the hot lines faster than one.  Plain order.)
   const int b = blockIdx.x;
   int j = 0;
   for (int k = 1; k < nprob; ++k)
