@@ -351,7 +351,9 @@ class _Passes:
         def wgrad_conv(xin, dz, kk, dil, key, x_scale=None):
             """filter gradient of a dense conv (slabs into P.fold_part[key]): deferred into the plan's batch, launched at the end of the
             pass, one launch per kernel instantiation.  (Round 4 ran the decoder's share on a side branch of the captured step with
-            capped grids beside the encoder's backward chain: measured neutral to negative -- profiles/r04_notes.md -- and removed.)"""
+            capped grids beside the encoder's backward chain: neutral to negative.  Round 5 ran it as a graph of its own on a stream
+            masked to 64-96 CUs beside the chain on the other 160-192: the masks hold, the chain slows by what the move saves --
+            profiles/r05_notes.md, tools/cumask_probe.py -- removed again.)"""
             if not P.wbatch_ready:
                 P.wbatch.add(xin, dz, kk, dil, P.fold_part[key], x_scale=x_scale)
 
@@ -454,6 +456,9 @@ class _Passes:
             self._aspp_backward(P, P.blocks[bi]["out"], P.blocks[bi]["dout"], has_grad[bi])
             has_grad[bi] = True
         stage1_next = None   # stage 1 of the NEXT block's (bi - 1) project-BN backward, when the expand backward-data launch produced it
+        hook = getattr(self, "_segment_hook", None)   # (tools/cumask_probe.py cuts the pass into separately captured graphs here)
+        if hook is not None:
+            hook("encoder_backward")
 
         def expand_bwd_data(bi, da0, wname, tgt, tgt_has):
             """Backward-data of block bi's expand conv into the gradient of block bi - 1's output -- the last contribution to it, so the
@@ -593,6 +598,10 @@ class _Passes:
         bn_b(P.z_stem, P.dstem, P.st_stem, self.n_stem[1], P.dstem, post=True, stage1=P.stem_stage1 if P.fuse_stem else None)
         ops.stem_conv_bwd_filter(x, P.dstem, idx, partial=P.fold_part[self.n_stem[0]])
         P.wbatch_ready = True
+        if hook is not None:
+            hook("filter_gradients")
         P.wbatch.launch("fp32x3" if self.x3 is not None else self.matmul_precision)
+        if hook is not None:
+            hook("fold")
         # all slabs written -> one batched fold into the gradient arena; the squeeze-excite weight gradients of every block ride in it
         ops.fold_batched(P.fold_buf, A.grad, P.fold_desc, P.fold_tiles, se_desc=P.se_desc, se_tiles=P.se_tiles)
