@@ -219,6 +219,33 @@ def test_full_size_step_config2(precision):
     _compare_state(O, L, gO, "full")
 
 
+@pytest.mark.parametrize("H,fuse_head", [(224, True), (64, True), (224, False)])
+def test_project_batch_norm_on_load_and_unfused_head_steps(H, fuse_head):
+    """The two launch-diet options of round 5 that are not the default path: Learner(fuse_bn2=True) -- every block's project batch norm
+    (+ drop-connect, + identity skip) applied by the NEXT block's expand conv while it loads its rows (mliis_conv2d_fwd_bnin: ten
+    launches fewer; measured slower, so opt-in) -- and Learner(fuse_head=False) -- the step's tail as the five launches it was before
+    mliis_head_ce_fused.  One step + two more (moving averages, captured and replayed) against the oracle, fp32 tolerances."""
+    _need_gpu()
+    S, idx = 5, [0, 1, 2, 3, 4, 0, 1, 2]
+    O, L = _pair(H, fuse_bn2=True, fuse_head=fuse_head, use_graph=True)
+    x, y = _task(S, H, 0)
+    L.load_task(x, y)
+    dc = _dc(O, 8, 3)
+    lo, gO, _ = R.inner_step(O.a, O.params, O.bn, torch.tensor(x[idx]).double(), torch.tensor(y[idx]).double(), 1e-3, dc)
+    L.inner_step(idx, dc_scales=dc)
+    ll = L.loss_value()
+    assert abs(ll - lo) <= 1e-4 * max(1.0, abs(lo)), (ll, lo)
+    assert any(L.plans[8].bn2_deferred)
+    _compare_state(O, L, gO, "project BN on load")
+    for step in range(2):   # (drop-connect off: the device would draw its own masks)
+        O.drop_connect = False
+        lo = O.inner_step(torch.tensor(x[idx]).double(), torch.tensor(y[idx]).double())
+        L.inner_step(idx, dc_scales={k: torch.ones_like(v) for k, v in dc.items()})
+        ll = L.loss_value()
+        assert abs(ll - lo) <= 2e-4 * max(1.0, abs(lo)), (step, ll, lo)
+    L.close()
+
+
 def test_step_at_384_config5_shapes():
     """BASELINE config 5 input size (384x384: maps 192/96/48/24, other tile / split plans than 224x224), fp32, N = 2: one step."""
     _need_gpu()
