@@ -31,6 +31,10 @@ namespace mliis {
 
 constexpr int kX3Block = 3072;   // bytes of one (chunk, 16-column tile) block of a weight image
 constexpr int kX3BM = 256;       // rows of a workgroup tile (eight waves of 32)
+#ifndef X3_PF
+#define X3_PF 2
+#endif
+constexpr int kX3PF = X3_PF;     // column tiles of B fragments requested ahead of their products
 
 // ------------------------------------------------------------------------------------------------ weight images
 // desc rows (int64 [ndesc][8]): {source offset (floats) in `theta`, taps, Cin_total, Cout, ci_begin, Cin (window), mode | first block
@@ -217,19 +221,26 @@ __device__ __forceinline__ void conv_x3_tile(const X3Params& q, char* __restrict
   // wave's matrix instructions fill the pipe meanwhile)
   auto compute_split = [&](const char* buf, const float4 (&rs)[2][2]) {
     const char* pb = buf + g * 256 + l15 * 16;
-    bf16x8 b3[2][3];
+    // B fragments kX3PF column tiles ahead of their products (three buffers): with one tile ahead the twelve matrix instructions of a
+    // tile (192 cycles when the wave has the pipe to itself -- its SIMD partner finishes first) did not cover the LDS round trip
+    constexpr int PF = kX3PF;
+    bf16x8 b3[PF + 1][3];
     uint2 sh[2][2], sm_[2][2], sl[2][2];
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) b3[0][pl] = *reinterpret_cast<const bf16x8*>(pb + pl * 1024);
+    for (int d = 0; d < PF; ++d)
+      if (d < NT) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) b3[d][pl] = *reinterpret_cast<const bf16x8*>(pb + d * kX3Block + pl * 1024);
+      }
 #pragma unroll
     for (int jn = 0; jn < NT; ++jn) {
-      if (jn + 1 < NT) {
+      if (jn + PF < NT) {
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) b3[(jn + 1) & 1][pl] = *reinterpret_cast<const bf16x8*>(pb + (jn + 1) * kX3Block + pl * 1024);
+        for (int pl = 0; pl < 3; ++pl) b3[(jn + PF) % (PF + 1)][pl] = *reinterpret_cast<const bf16x8*>(pb + (jn + PF) * kX3Block + pl * 1024);
       }
-#define X3_MM(PA, PB)                                                                                                 \
-  acc[0][jn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3[PA][0], b3[jn & 1][PB], acc[0][jn], 0, 0, 0);             \
-  acc[1][jn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3[PA][1], b3[jn & 1][PB], acc[1][jn], 0, 0, 0);
+#define X3_MM(PA, PB)                                                                                                           \
+  acc[0][jn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3[PA][0], b3[jn % (PF + 1)][PB], acc[0][jn], 0, 0, 0);                \
+  acc[1][jn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3[PA][1], b3[jn % (PF + 1)][PB], acc[1][jn], 0, 0, 0);
       X3_MM(2, 0) X3_MM(0, 2) X3_MM(1, 1) X3_MM(1, 0) X3_MM(0, 1) X3_MM(0, 0)
 #undef X3_MM
 #pragma unroll

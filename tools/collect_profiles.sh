@@ -1,9 +1,10 @@
 #!/bin/bash
 # copies the summaries tools/final_profile.sh left under gpurun_out/<tag> into profiles/ (tracked), named per round
-TAG=${1:-r04_final}; R=${2:-r04}
+TAG=${1:-r05_final}; R=${2:-r05}
 S=gpurun_out/$TAG
 cp $S/trace/t_kernel_stats.csv profiles/${R}_final_kernel_stats.csv
 cp $S/profile.md profiles/${R}_final_profile.md
+cp $S/final_timeline.txt profiles/${R}_final_timeline.txt
 cp $S/pmc_traffic.json profiles/${R}_pmc_traffic.json
 cp $S/depthwise_pmc.json profiles/${R}_depthwise_pmc.json
 cp $S/depthwise_pmc.txt profiles/${R}_depthwise_pmc.txt

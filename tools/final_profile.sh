@@ -10,6 +10,8 @@ rm -rf $O; mkdir -p $O
 cd $R
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o t -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-roofline > $O/trace.log 2>&1
 python tools/profile_summary.py $O/trace 0 $O/profile.md > /dev/null
+python tools/timeline.py $O/trace $O/final_timeline.txt > /dev/null
+find $O/trace -name "*kernel_trace.csv" -delete     # (tens of MB of per-dispatch rows: the statistics and the last step's timeline are kept)
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o f -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-graph > $O/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o w -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-graph > $O/pmc_write.log 2>&1
 python tools/pmc_traffic.py $(find $O/pmc_fetch -name "*counter_collection.csv" | head -1) $(find $O/pmc_write -name "*counter_collection.csv" | head -1) $O/pmc_traffic.json 24
@@ -22,12 +24,16 @@ python tools/bench_kernels.py --n 64 --iters 10 --dw-only 2>/dev/null | grep -v 
 cp $O/pmc_traffic.json profiles/${TAG%%_*}_pmc_traffic.json     # (bench.py quotes the newest profiles/rNN_pmc_traffic.json and checks its source hash)
 python bench.py > $O/bench_final.json 2> $O/bench_final.err
 {
-for V in "--foml" "--adam" "--aspp" "--skip-decoding" "--augment" "--precision bf16" "--precision fp8" "--inner-batch 16" "--inner-batch 64" \
+for V in "--precision fp32-native" "--foml" "--adam" "--aspp" "--skip-decoding" "--augment" "--precision bf16" "--precision fp8" "--inner-batch 16" "--inner-batch 64" \
          "--precision bf16-storage" "--backbone efficientnet-b3 --shots 10 --inner-iters 20" "--backbone efficientnet-b3 --shots 10 --inner-iters 20 --precision bf16" \
          "--backbone efficientnet-b3 --shots 10 --inner-iters 20 --precision bf16-storage" \
          "--image-size 384" "--image-size 384 --precision fp8" "--tasks-per-gpu 8 --concurrent-tasks 4" "--tasks-per-gpu 8 --concurrent-tasks 4 --precision bf16"; do
   python bench.py $V --steps 6 --warmup 2 --no-cpu-baseline --no-roofline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('%-75s %8.1f images/s  %7.2f ms/step  loss %.4f' % ('$V', d['value'], d['ms_per_step'], d['config']['final_loss']))"
 done
+for E in "MLIIS_FUSE_BN2=1" "MLIIS_NO_FUSE_HEAD=1"; do
+  env $E python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-roofline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('%-75s %8.1f images/s  %7.2f ms/step  loss %.4f' % ('(environment) $E', d['value'], d['ms_per_step'], d['config']['final_loss']))"
+done
+python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-roofline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('%-75s %8.1f images/s  %7.2f ms/step  loss %.4f' % ('(default, again: same box, end of the list)', d['value'], d['ms_per_step'], d['config']['final_loss']))"
 } > $O/variants.txt 2>&1
 rm -rf $O/pmc_fetch $O/pmc_write $O/dw_fetch $O/dw_write     # (hundreds of MB of per-dispatch rows; the aggregates above are what is kept)
 du -sh $O; head -8 $O/profile.md; cat $O/depthwise_pmc.txt; cat $O/depthwise_cold_n8.txt; cat $O/depthwise_cold_n64.txt; cat $O/variants.txt; tail -c 300 $O/bench_final.err
