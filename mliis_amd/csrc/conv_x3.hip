@@ -32,7 +32,7 @@ namespace mliis {
 constexpr int kX3Block = 3072;   // bytes of one (chunk, 16-column tile) block of a weight image
 constexpr int kX3BM = 256;       // rows of a workgroup tile (eight waves of 32)
 #ifndef X3_PF
-#define X3_PF 2
+#define X3_PF 1
 #endif
 constexpr int kX3PF = X3_PF;     // column tiles of B fragments requested ahead of their products
 
@@ -221,8 +221,8 @@ __device__ __forceinline__ void conv_x3_tile(const X3Params& q, char* __restrict
   // wave's matrix instructions fill the pipe meanwhile)
   auto compute_split = [&](const char* buf, const float4 (&rs)[2][2]) {
     const char* pb = buf + g * 256 + l15 * 16;
-    // B fragments kX3PF column tiles ahead of their products (three buffers): with one tile ahead the twelve matrix instructions of a
-    // tile (192 cycles when the wave has the pipe to itself -- its SIMD partner finishes first) did not cover the LDS round trip
+    // B fragments kX3PF column tiles ahead of their products (-DX3_PF=2 | 3 measured: 79.0 / 80.7 against 79.9 us with one tile ahead on
+    // the 224 -> 112 conv -- the LDS round trip is not what the slower wave of a SIMD waits for)
     constexpr int PF = kX3PF;
     bf16x8 b3[PF + 1][3];
     uint2 sh[2][2], sm_[2][2], sl[2][2];
