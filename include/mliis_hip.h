@@ -246,6 +246,10 @@ int mliis_conv2d_fwd_bnin(const float* z, int ldz, const float* bn_part, int bn_
  *      total_tiles > 0: sum over the descriptors of taps * ceil(Cin / 32) * ceil(Cout / 32) -- one workgroup per 32 x 32 tile; 0: a
  *      fixed 224 x ndesc grid (the caller does not know the table's contents) */
 int mliis_transpose_weights(const float* src, float* dst, const int* desc, int ndesc, long long total_tiles, float* amax, hipStream_t stream);
+/*      mliis_weight_shadows: mliis_transpose_weights and mliis_x3_pack_weights (same arguments) in ONE launch -- the two per-step
+ *      shadows of the weight arena; total_tiles > 0 required */
+int mliis_weight_shadows(const float* src, float* dst, const int* desc, int ndesc, long long total_tiles, float* amax, void* x3_images,
+                         const long long* x3_desc, int x3_ndesc, int x3_blocks, hipStream_t stream);
 /*      gradient w.r.t. input channels [ci_begin, ci_begin+Cin_out) of a conv whose weight has Cin_total input channels */
 int mliis_conv2d_bwd_data(const float* dy, int lddy, const float* w, float* dx, int lddx, int Nimg, int H, int W, int Cin_total,
                           int ci_begin, int Cin_out, int Cout, int ksize, int dil, int accumulate, float* ws, size_t ws_floats,

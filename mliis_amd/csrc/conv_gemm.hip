@@ -108,8 +108,21 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats_k(const float* __rest
 // ndesc_flat > 0: ONE tile per workgroup over a grid of exactly the tiles of all descriptors (the caller knows their total): workgroup b
 // finds its descriptor with a wave prefix scan of the tile counts (64 descriptors per pass).  The two-dimensional form (descriptor =
 // blockIdx.y, 224 workgroups each) launched 8512 workgroups for ~2000 tiles, most of them only to find nothing to do.
+// x3 (mliis_weight_shadows; flat form only): the workgroups behind the first x3.first_block build the split-product weight images
+// of conv_x3.hip -- two 128-thread pack blocks each -- so the two weight shadows of a step are ONE launch.
+struct X3PackArgs {
+  char* images;
+  const long long* desc;
+  int ndesc, blocks, first_block;   // first_block = the transposes' tile count; blocks == 0: no images
+};
 __global__ __launch_bounds__(256) void transpose_weights_k(const float* __restrict__ src, float* __restrict__ dst,
-                                                           const int* __restrict__ desc, unsigned* __restrict__ amax_bits, int ndesc_flat) {
+                                                           const int* __restrict__ desc, unsigned* __restrict__ amax_bits, int ndesc_flat,
+                                                           X3PackArgs x3) {
+  if (x3.blocks > 0 && (int)blockIdx.x >= x3.first_block) {   // (uniform)
+    const int pb = ((int)blockIdx.x - x3.first_block) * 2 + (int)(threadIdx.x >> 7);
+    if (pb < x3.blocks) x3_pack_block(src, x3.images, x3.desc, x3.ndesc, pb, (int)(threadIdx.x & 127));
+    return;
+  }
   __shared__ float tile[32][33];
   __shared__ float wmax[4];
   __shared__ int s_d[2];
@@ -863,20 +876,37 @@ static int conv2d_bwd_data_impl(const float* dy, int lddy, const float* w, float
 // desc: device int32 [ndesc][4] = {offset (floats), taps, Cin, Cout}; src/dst: arenas with identical layout.
 // total_tiles > 0: the sum over the descriptors of taps * ceil(Cin / 32) * ceil(Cout / 32) (the caller built the table, it knows):
 // one workgroup per tile.  0: a 224 x ndesc grid whose workgroups stride over their descriptor's tiles.
-int mliis_transpose_weights(const float* src, float* dst, const int* desc, int ndesc, long long total_tiles, float* amax, hipStream_t stream) {
-  MLIIS_REQUIRE(src && dst && desc && ndesc > 0 && total_tiles >= 0 && total_tiles < (1LL << 30), MLIIS_ERR_ARG, "transpose_weights: bad arguments");
+static int weight_shadows(const char* name, const float* src, float* dst, const int* desc, int ndesc, long long total_tiles, float* amax,
+                          void* x3_images, const long long* x3_desc, int x3_ndesc, int x3_blocks, hipStream_t stream) {
+  MLIIS_REQUIRE(src && dst && desc && ndesc > 0 && total_tiles >= 0 && total_tiles < (1LL << 30), MLIIS_ERR_ARG, "%s: bad arguments", name);
+  MLIIS_REQUIRE(x3_blocks == 0 || (total_tiles > 0 && x3_images && x3_desc && x3_ndesc >= 1 && x3_ndesc <= 64 && x3_blocks > 0 &&
+                                   aligned16(src) && aligned16(x3_images) && aligned16(x3_desc)),
+                MLIIS_ERR_ARG, "%s: the weight images need the one-tile-per-workgroup form, a table of 1..64 rows and 16-byte aligned pointers", name);
   if (amax != nullptr) {   // (a memset node when captured into a graph)
     hipError_t e = hipMemsetAsync(amax, 0, (size_t)ndesc * sizeof(float), stream);
-    MLIIS_REQUIRE(e == hipSuccess, MLIIS_ERR_LAUNCH, "transpose_weights: memset failed: %s", hipGetErrorString(e));
+    MLIIS_REQUIRE(e == hipSuccess, MLIIS_ERR_LAUNCH, "%s: memset failed: %s", name, hipGetErrorString(e));
   }
+  const X3PackArgs x3{reinterpret_cast<char*>(x3_images), x3_desc, x3_ndesc, x3_blocks, (int)total_tiles};
   if (total_tiles > 0)
-    hipLaunchKernelGGL(transpose_weights_k, dim3((unsigned)total_tiles), dim3(256), 0, stream, src, dst, desc, reinterpret_cast<unsigned*>(amax),
-                       ndesc);
+    hipLaunchKernelGGL(transpose_weights_k, dim3((unsigned)(total_tiles + (x3_blocks + 1) / 2)), dim3(256), 0, stream, src, dst, desc,
+                       reinterpret_cast<unsigned*>(amax), ndesc, x3);
   else
     hipLaunchKernelGGL(transpose_weights_k, dim3(224, ndesc), dim3(256), 0, stream, src, dst, desc, reinterpret_cast<unsigned*>(amax),
-                       0);   // (the largest tensor has ~2000 tiles)
-  MLIIS_CHECK_LAUNCH("transpose_weights");
+                       0, x3);   // (the largest tensor has ~2000 tiles)
+  MLIIS_CHECK_LAUNCH(name);
   return MLIIS_OK;
+}
+
+int mliis_transpose_weights(const float* src, float* dst, const int* desc, int ndesc, long long total_tiles, float* amax, hipStream_t stream) {
+  return weight_shadows("transpose_weights", src, dst, desc, ndesc, total_tiles, amax, nullptr, nullptr, 0, 0, stream);
+}
+
+// mliis_transpose_weights + mliis_x3_pack_weights (same arguments) in ONE launch: both read the weight arena once per optimizer step and
+// depend on nothing else of the step.  total_tiles must be > 0 (one workgroup per transpose tile, the pack blocks behind them).
+int mliis_weight_shadows(const float* src, float* dst, const int* desc, int ndesc, long long total_tiles, float* amax, void* x3_images,
+                         const long long* x3_desc, int x3_ndesc, int x3_blocks, hipStream_t stream) {
+  MLIIS_REQUIRE(x3_blocks > 0, MLIIS_ERR_ARG, "weight_shadows: no image blocks (use mliis_transpose_weights)");
+  return weight_shadows("weight_shadows", src, dst, desc, ndesc, total_tiles, amax, x3_images, x3_desc, x3_ndesc, x3_blocks, stream);
 }
 
 size_t mliis_conv2d_bwd_filter_workspace_floats(int Nimg, int H, int W, int Cin, int Cout, int ksize) {

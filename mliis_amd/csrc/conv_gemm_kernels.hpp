@@ -1714,6 +1714,46 @@ static void launch_filter_t(const FilterPlan& f, const FilterGradParams& p, hipS
 }
 
 // operand precision of the matrix cores: the fp32 instances live in conv_gemm.hip, the bf16 ones in conv_gemm_bf16.hip
+// ------------------------------------------------------------------------------------------------ split-product weight images (conv_x3.hip)
+// One 128-thread block of the pack: see conv_x3.hip for the image layout.  Shared with conv_gemm.hip, whose weight-shadow launch
+// (mliis_weight_shadows) builds the K-contiguous weight copies and these images in ONE grid.
+constexpr int kX3Block = 3072;   // bytes of one (chunk, 16-column tile) block of a weight image
+constexpr int kX3DescWords = 8;
+__device__ __forceinline__ void x3_pack_block(const float* __restrict__ theta, char* __restrict__ images, const long long* __restrict__ desc,
+                                              int ndesc, int b, int t) {
+  int j = 0;
+  for (int k = 1; k < ndesc; ++k)
+    if (b >= (int)(desc[k * kX3DescWords + 6] >> 8)) j = k;
+  const long long* d = desc + (long long)j * kX3DescWords;
+  const float* w = theta + d[0];
+  const int taps = (int)d[1], cin_total = (int)d[2], cout = (int)d[3], ci_begin = (int)d[4], cin = (int)d[5], mode = (int)(d[6] & 0xff);
+  const int local = b - (int)(d[6] >> 8);
+  const int nn = mode == 0 ? cout : cin, kc = mode == 0 ? cin : cout;   // columns of B, K per tap
+  const int ncol16 = (nn + 15) / 16;
+  const int chunk = local / ncol16, c16 = local - chunk * ncol16;
+  const int nl = t & 15, kq = t >> 4;   // column of the tile, k quad 0..7 of the chunk
+  const int n = c16 * 16 + nl;
+  const int cpt = (kc + 31) / 32;                    // chunks per tap: a chunk never straddles a tap (the last one of a tap is zero-padded)
+  const int tap = chunk / cpt, c = (chunk - tap * cpt) * 32 + kq * 4;
+  float4 v = f4zero();
+  if (n < nn && c < kc) {
+    if (mode == 0) {
+      const float* s = w + ((long long)tap * cin_total + ci_begin + c) * cout + n;
+      v = make_float4(s[0], s[cout], s[2 * (long long)cout], s[3 * (long long)cout]);
+    } else {
+      v = ld4(w + ((long long)tap * cin_total + ci_begin + n) * cout + c);
+    }
+  }
+  uint2 h, m, l;
+  split3(v, h, m, l);
+  // lane group g = kq & 3 holds k = 4g..4g+3 (elements 0..3) and 16 + 4g..16 + 4g + 3 (elements 4..7) of the chunk
+  char* dst = images + d[7] + (long long)local * kX3Block + (kq & 3) * 256 + nl * 16 + (kq >> 2) * 8;
+  *reinterpret_cast<uint2*>(dst) = h;
+  *reinterpret_cast<uint2*>(dst + 1024) = m;
+  *reinterpret_cast<uint2*>(dst + 2048) = l;
+}
+
+
 void launch_gemm_bf16(const GemmPlan& g, const ConvGemmParams& p, hipStream_t stream);
 void launch_gemm_sk_bf16(const GemmPlan& g, const ConvGemmParams& p, float* slab, hipStream_t stream);
 void launch_gemm_fp8(const GemmPlan& g, const ConvGemmParams& p, hipStream_t stream);            // conv_gemm_fp8.hip

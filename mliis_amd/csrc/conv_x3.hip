@@ -29,7 +29,8 @@
 
 namespace mliis {
 
-constexpr int kX3Block = 3072;   // bytes of one (chunk, 16-column tile) block of a weight image
+// (kX3Block = 3072 bytes of one (chunk, 16-column tile) block of a weight image, x3_pack_block: conv_gemm_kernels.hpp -- the weight
+//  shadows of a step, transposes and images, are one launch: mliis_weight_shadows)
 constexpr int kX3BM = 256;       // rows of a workgroup tile (eight waves of 32)
 #ifndef X3_PF
 #define X3_PF 1
@@ -40,40 +41,9 @@ constexpr int kX3PF = X3_PF;     // column tiles of B fragments requested ahead 
 // desc rows (int64 [ndesc][8]): {source offset (floats) in `theta`, taps, Cin_total, Cout, ci_begin, Cin (window), mode | first block
 // << 8, image offset (bytes)}.  mode 0 (forward): B[n = co][k = tap * Cin + c] = w[tap][ci_begin + c][co];  mode 1 (backward-data):
 // B[n = ci - ci_begin][k = tap * Cout + co] = w[tap][ci][co].  One workgroup (128 threads) per (chunk, 16-column tile) block.
-constexpr int kX3DescWords = 8;
 __global__ __launch_bounds__(128) void x3_pack_k(const float* __restrict__ theta, char* __restrict__ images, const long long* __restrict__ desc,
                                                   int ndesc) {
-  const int b = blockIdx.x;
-  int j = 0;
-  for (int k = 1; k < ndesc; ++k)
-    if (b >= (int)(desc[k * kX3DescWords + 6] >> 8)) j = k;
-  const long long* d = desc + (long long)j * kX3DescWords;
-  const float* w = theta + d[0];
-  const int taps = (int)d[1], cin_total = (int)d[2], cout = (int)d[3], ci_begin = (int)d[4], cin = (int)d[5], mode = (int)(d[6] & 0xff);
-  const int local = b - (int)(d[6] >> 8);
-  const int nn = mode == 0 ? cout : cin, kc = mode == 0 ? cin : cout;   // columns of B, K per tap
-  const int ncol16 = (nn + 15) / 16;
-  const int chunk = local / ncol16, c16 = local - chunk * ncol16;
-  const int t = threadIdx.x, nl = t & 15, kq = t >> 4;   // column of the tile, k quad 0..7 of the chunk
-  const int n = c16 * 16 + nl;
-  const int cpt = (kc + 31) / 32;                    // chunks per tap: a chunk never straddles a tap (the last one of a tap is zero-padded)
-  const int tap = chunk / cpt, c = (chunk - tap * cpt) * 32 + kq * 4;
-  float4 v = f4zero();
-  if (n < nn && c < kc) {
-    if (mode == 0) {
-      const float* s = w + ((long long)tap * cin_total + ci_begin + c) * cout + n;
-      v = make_float4(s[0], s[cout], s[2 * (long long)cout], s[3 * (long long)cout]);
-    } else {
-      v = ld4(w + ((long long)tap * cin_total + ci_begin + n) * cout + c);
-    }
-  }
-  uint2 h, m, l;
-  split3(v, h, m, l);
-  // lane group g = kq & 3 holds k = 4g..4g+3 (elements 0..3) and 16 + 4g..16 + 4g + 3 (elements 4..7) of the chunk
-  char* dst = images + d[7] + (long long)local * kX3Block + (kq & 3) * 256 + nl * 16 + (kq >> 2) * 8;
-  *reinterpret_cast<uint2*>(dst) = h;
-  *reinterpret_cast<uint2*>(dst + 1024) = m;
-  *reinterpret_cast<uint2*>(dst + 2048) = l;
+  x3_pack_block(theta, images, desc, ndesc, blockIdx.x, threadIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------ the tile

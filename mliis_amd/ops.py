@@ -345,11 +345,17 @@ def transpose_tiles(desc_rows):
     return int(sum(int(t) * ((int(ci) + 31) // 32) * ((int(co) + 31) // 32) for _, t, ci, co in desc_rows))
 
 
-def transpose_weights(src, dst, desc, amax=None, tiles=0):
+def transpose_weights(src, dst, desc, amax=None, tiles=0, x3=None):
     """dst <- HWOI copies of the dense-conv weights listed in desc (device int32 [n,4] = offset, taps, Cin, Cout); amax (optional,
     float [n]): also max |w| per tensor -- the fp8 operand scale.  tiles = transpose_tiles(rows of desc): one workgroup per 32 x 32
-    tile; 0: a fixed grid that strides over the tiles."""
+    tile; 0: a fixed grid that strides over the tiles.  x3 (an X3Images over the same arena): its images are rebuilt too."""
+    if x3 is not None and x3.desc is not None and tiles > 0:   # the split-product weight images ride in the same launch
+        lib.call("mliis_weight_shadows", _ptr(src), _ptr(dst), _ptr(desc), int(desc.shape[0]), int(tiles), _ptr(amax), _ptr(x3.images), _ptr(x3.desc),
+                 len(x3.rows), x3.blocks, _stream())
+        return
     lib.call("mliis_transpose_weights", _ptr(src), _ptr(dst), _ptr(desc), int(desc.shape[0]), int(tiles), _ptr(amax), _stream())
+    if x3 is not None:
+        x3.pack(src)
 
 
 def hwoi(w):
