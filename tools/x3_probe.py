@@ -1,5 +1,5 @@
 """Split-operand (MLIIS_PREC_F32X3) dense convs beside the native fp32 instances: error against a float64 reference and launch time.
-python tools/x3_probe.py [iters]   (prints one row per shape and direction)"""
+python tools/x3_probe.py [iters [shape]]   (prints one row per shape and direction)"""
 import os
 import sys
 
@@ -35,10 +35,13 @@ def timeit(fn, iters):
 
 def main():
     iters = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+    only = sys.argv[2] if len(sys.argv) > 2 else None    # one shape only (counter passes)
     d = torch.device("cuda:0")
     torch.manual_seed(0)
     N = 8
     for name, (k, dil, h, ci, co) in SHAPES.items():
+        if only is not None and name != only:
+            continue
         x = torch.randn(N, h, h, ci, device=d)
         w = torch.randn(k, k, ci, co, device=d) * 0.05
         wt = w.permute(0, 1, 3, 2).contiguous().view(-1)
