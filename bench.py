@@ -64,6 +64,7 @@ def parse(argv=None):
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-native-retime", action="store_true", help="skip the extra `fp32_native_images_per_s` key (a second learner on the fp32 matrix instruction, 5 tasks)")
     ap.add_argument("--pool", type=int, default=8, help="number of distinct synthetic tasks resident per GPU")
     ap.add_argument("--cpu-baseline-from", default=None,
                     help="N > 1 lines do not time the CPU oracle; carry `cpu_baseline` by value from this N = 1 bench line (a JSON file, e.g. BENCH_rNN.json)")
@@ -367,9 +368,140 @@ def roofline(L, args):
                                    "copy_same_bytes_us_per_step": sum(copy_us.values()), "frac_of_copy": sum(copy_us.values()) / tot_us,
                                    "method": "cold operands: rotating copies, > 320 MB between two touches of a tensor (Infinity Cache flushed)"}
     dw["per_layer"] = layers
+    bnr = batchnorm_hbm(L, calls, dll, FLUSH) if args.precision in ("fp32", "fp32-native") else None
     families = {k: {"us_per_step": 1e3 * v["ms"] / reps, "launches_per_step": v["n"] // reps,
                     "TFLOPs": (v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["flops"] else None} for k, v in sorted(by.items())}
-    return out, dw, families
+    return out, dw, families, bnr
+
+
+def retime_native(args, device, tasks, shots, imgs_per_task):
+    """The same workload on a second learner that uses the native fp32 matrix instruction everywhere (`--precision fp32-native`), timed
+    after the headline region: 2 warm-up tasks + 5 timed tasks on this rank alone (no collective)."""
+    import torch
+    from mliis_amd.learner import Learner
+    from mliis_amd.reptile import FOMLIS, Gecko, SingleRank
+    L2 = Learner(feature_extractor_name=args.backbone, image_size=args.image_size, rsd=(2, 4), learning_rate=1e-3, optimizer="adam" if args.adam else "sgd", dice=False,
+                 l2=False, seed=0, device=device, use_graph=not args.no_graph, max_shots=max(16, shots), spatial_pyramid_pooling=args.aspp,
+                 matmul_precision="fp32-native", skip_decoding=args.skip_decoding)
+    kw = dict(dist=SingleRank(), rng_mode="per_task", seed=0)
+    meta = FOMLIS(L2, train_shots=shots, tail_shots=5, **kw) if args.foml else Gecko(L2, **kw)
+
+    def step():
+        meta.train_step(tasks, num_shots=shots, inner_batch_size=args.inner_batch, inner_iters=args.inner_iters, replacement=False, meta_step_size=0.1,
+                        meta_batch_size=1)
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 5
+    for _ in range(n):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    L2.close()
+    return {"value": n * imgs_per_task / dt, "note": "same workload, every matrix product on v_mfma_f32_16x16x4_f32 (--precision fp32-native): 2 warm-up + %d timed tasks on "
+                                                    "rank 0 after the headline region" % n}
+
+
+def batchnorm_hbm(L, calls, dll, flush_bytes):
+    """The batch-norm launches of one inner step against the HBM roofline, measured like `depthwise_hbm`: every recorded C-ABI call of
+    the family is re-issued through ctypes over ROTATING copies of its activation tensors (> 320 MB between two touches of a tensor:
+    the Infinity Cache is flushed), with a device copy of the same number of bytes timed the same way beside it.  Algorithmic bytes:
+    every activation tensor of the call once (x read, y written, residual read; backward: x, dy read, dx written, the skip gradient
+    written or read + written) -- the backward launches that form their own sums first (no stage 1 from the producer) read x and dy
+    TWICE by design; that second pass is NOT counted as algorithmic, it shows as a lower fraction (fp32 tensors only)."""
+    import torch
+    # entry -> (family, rows index, C index, [(pointer index, ld index or None, role)], indices nulled, indices redirected to scratch of C floats)
+    BN = {
+        "mliis_bn_apply_fused": ("bn_apply_fused", 4, 5, [(0, 1, "r"), (2, 3, "w"), (21, 22, "r")], (14, 15), (12, 13)),
+        "mliis_bn_apply_fused_pair": ("bn_apply_fused", 22, 23, [(0, 20, "r"), (1, 21, "w"), (10, 20, "r"), (11, 21, "w")], (6, 7, 16, 17), (4, 5, 14, 15)),
+        "mliis_bn_bwd": ("bn_bwd", 6, 7, [(0, 1, "r"), (2, 3, "r"), (4, 5, "w"), (20, 21, "s")], (), ()),
+        "mliis_bn_bwd_pair": ("bn_bwd", 23, 24, [(0, 20, "r"), (1, 21, "r"), (2, 22, "w"), (10, 20, "r"), (11, 21, "r"), (12, 22, "w")], (), ()),
+        "mliis_bn_stats_partial": ("bn_stats", 2, 3, [(0, 1, "r")], (), ()),
+    }
+    fams, layers = {}, []
+    with torch.cuda.stream(L.stream):
+        for n, a in calls:
+            if n not in BN:
+                continue
+            fam, i_rows, i_c, tensors, nulled, scratch = BN[n]
+            if n in ("mliis_bn_apply_fused", "mliis_bn_bwd") and a[26 if n == "mliis_bn_apply_fused" else 29] != 0:
+                continue                                    # (bf16 tensors: not this table)
+            rows, c = int(a[i_rows]), int(a[i_c])
+            nbytes, live = 0.0, []
+            for ip, ild, role in tensors:
+                if a[ip] is None or a[ip] == 0:
+                    continue
+                ld = int(a[ild]) if ild is not None else c
+                acc = role == "s" and n == "mliis_bn_bwd" and int(a[22]) != 0     # skip gradient accumulated: read + written
+                nbytes += 4.0 * rows * c * (2 if acc else 1)
+                live.append((ip, rows * ld))
+            two_pass = (n == "mliis_bn_bwd" and (a[27] is None or a[27] == 0)) or n == "mliis_bn_bwd_pair"
+            copies = max(2, int(flush_bytes / nbytes) + 1)
+            bufs, variants = [], []
+            for r in range(copies):
+                args_r, same = list(a), {}
+                for ip, nel in live:
+                    if a[ip] in same:                       # (operands that alias in the recorded call alias in the re-issue)
+                        args_r[ip] = same[a[ip]]
+                        continue
+                    buf = torch.empty(int(nel), dtype=torch.float32, device=L.device).normal_()
+                    bufs.append(buf)
+                    args_r[ip] = same[a[ip]] = buf.data_ptr()
+                for ix in nulled:
+                    args_r[ix] = None
+                for ix in scratch:                          # mean / rstd outputs: not into the learner's own state
+                    scr = torch.empty(c, dtype=torch.float32, device=L.device)
+                    bufs.append(scr)
+                    args_r[ix] = scr.data_ptr()
+                variants.append(tuple(args_r))
+            fn = getattr(dll, n)
+            for v in variants:
+                fn(*v)
+            reps_k = max(20, 2 * copies)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(L.stream)
+            for r in range(reps_k):
+                fn(*variants[r % copies])
+            e1.record(L.stream)
+            e1.synchronize()
+            us = 1e3 * e0.elapsed_time(e1) / reps_k
+            del variants, bufs
+            half = int(nbytes // 8)
+            csrc = [torch.empty(half, dtype=torch.float32, device=L.device).normal_() for _ in range(copies)]
+            cdst = [torch.empty(half, dtype=torch.float32, device=L.device) for _ in range(copies)]
+            for a_, b_ in zip(csrc, cdst):
+                b_.copy_(a_)
+            cus_ = []
+            for _ in range(3):
+                e0.record(L.stream)
+                for r in range(reps_k):
+                    cdst[r % copies].copy_(csrc[r % copies])
+                e1.record(L.stream)
+                e1.synchronize()
+                cus_.append(1e3 * e0.elapsed_time(e1) / reps_k)
+            cus = sorted(cus_)[1]
+            del csrc, cdst
+            layers.append({"entry": n[6:], "rows,C": [rows, c], "reads_x_dy_twice": bool(two_pass), "us": round(us, 2), "algorithmic_MB": round(nbytes / 1e6, 2),
+                           "frac_of_8TBps": round(nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 3), "rotating_copies": copies,
+                           "copy_same_bytes_us": round(cus, 2), "frac_of_copy": round(cus / us, 3)})
+            d_ = fams.setdefault(fam, {"us_per_step": 0.0, "launches_per_step": 0, "algorithmic_MB_per_step": 0.0, "copy_same_bytes_us_per_step": 0.0})
+            d_["us_per_step"] += us
+            d_["launches_per_step"] += 1
+            d_["algorithmic_MB_per_step"] += nbytes / 1e6
+            d_["copy_same_bytes_us_per_step"] += cus
+    tot = {"us_per_step": 0.0, "launches_per_step": 0, "algorithmic_MB_per_step": 0.0, "copy_same_bytes_us_per_step": 0.0}
+    for d_ in fams.values():
+        for k_ in tot:
+            tot[k_] += d_[k_]
+    fams["all_batchnorm"] = tot
+    for d_ in fams.values():
+        d_["frac_of_8TBps"] = d_["algorithmic_MB_per_step"] * 1e6 / (d_["us_per_step"] * 1e-6) / 1e9 / HBM_PEAK_GBS if d_["us_per_step"] else None
+        d_["frac_of_copy"] = d_["copy_same_bytes_us_per_step"] / d_["us_per_step"] if d_["us_per_step"] else None
+    fams["all_batchnorm"]["method"] = ("C-ABI calls of one eager inner step re-issued cold (rotating copies, > 320 MB between two touches); launches = "
+                                       "API calls (a backward call without the producer's stage 1 is two kernels: reduce + apply)")
+    fams["per_launch"] = layers
+    return fams
 
 
 def main():
@@ -454,6 +586,7 @@ def _run(args):
 
     for _ in range(args.warmup):
         step()
+    D.timed = world > 1     # events around the ONE all-reduce of every timed meta-step (dist.allreduce_ms / dist.tasks_imbalance)
     D.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -462,18 +595,22 @@ def _run(args):
     D.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    ar_ms = adapt_max = adapt_min = None
     if world > 1:
         import torch.distributed as dist
-        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        D.timed = False
+        inside, between = D.timing()
+        tt = torch.tensor([dt, inside or 0.0, between or 0.0, -(between or 0.0)], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        dt, ar_ms, adapt_max, adapt_min = float(tt[0].item()), float(tt[1].item()), float(tt[2].item()), -float(tt[3].item())
     imgs_per_task = ((args.inner_iters - 1) * args.inner_batch + 5) if args.foml else args.inner_iters * args.inner_batch
     value = world * args.tasks_per_gpu * imgs_per_task * args.steps / dt
     loss = L.loss_value()
 
-    roof = dwr = fam = None
+    roof = dwr = fam = bnr = None
+    native = None
     if rank == 0 and not args.no_roofline:
-        roof, dwr, fam = roofline(L, args)
+        roof, dwr, fam, bnr = roofline(L, args)
         t_step = dt / args.steps / (args.tasks_per_gpu * args.inner_iters)          # seconds per inner step (HIP-graph replay, as timed)
         issued, hbm = roof.pop("_issued_flops_per_step"), roof.pop("_hbm_bytes_per_step")
         default_cfg = (args.backbone == "efficientnet-b0" and args.image_size == 224 and args.inner_batch == 8 and not (args.aspp or args.skip_decoding))
@@ -488,13 +625,15 @@ def _run(args):
             "step_note": "whole inner step: algorithmic 95.9 GFLOP of the reference graph (SURVEY.md Appendix A) and the conv flops this build "
                          "issues (pooled branch folded into a bias) / the measured step time, against the fp32 MFMA peak %.1f TFLOP/s; HBM bytes per "
                          "step from the committed rocprofv3 --pmc passes / step time / 8 TB/s" % MFMA_F32_PEAK_TFLOPS})
+    if rank == 0 and args.precision == "fp32" and L.x3 is not None and not args.no_native_retime:
+        native = retime_native(args, device, tasks, shots, imgs_per_task)
     if rank == 0:
         out = {
             "metric": "inner-loop images/sec (EfficientLab-6-3, 224x224, 5-shot)", "value": value, "unit": "images/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": ("f32 (the long-K decoder convs and their filter gradients with every operand split exactly into three bf16 terms on the "
                                           "matrix cores, 6 term products, f32 accumulate: fp32-equivalent products; everything else the fp32 instruction)"
-                                          if args.precision == "fp32" else "f32 (native fp32 matrix instruction everywhere)") if args.precision in ("fp32", "fp32-native") else ("bf16 matrix-core operands, f32 accumulate / tensors" if args.precision == "bf16" else
+                                          if L.x3 is not None else "f32 (native fp32 matrix instruction everywhere)") if args.precision in ("fp32", "fp32-native") else ("bf16 matrix-core operands, f32 accumulate / tensors" if args.precision == "bf16" else
                                                               "bf16 matrix-core operands and bf16 expanded MBConv tensors in HBM (z0, z1, a1 and their gradients), f32 accumulate / statistics / block tensors / weights" if args.precision == "bf16-storage" else
                                                               "fp8 e4m3 operands on the 1x1 forward convs (bf16 elsewhere), f32 accumulate / tensors"), "data": "synthetic",
             "config": {"workload": "%s + %sRSD(4)+RSD(2)), %dx%d, meta-batch=%d (1 task/GPU), "
@@ -515,11 +654,20 @@ def _run(args):
             # meta-step (flat task delta + BN moving-average contributions, fp32)
             "dist": {"world": world, "backend": ("nccl (RCCL)" if backend == "nccl" else backend + " (test hook, ranks share a GPU)") if world > 1 else None, "rccl_version": _rccl_version(),
                      "allreduce_bytes_per_meta_step": int(meta._comm.numel() * 4) if meta._comm is not None else None,
-                     "tasks_per_meta_step": world * args.tasks_per_gpu},
+                     "tasks_per_meta_step": world * args.tasks_per_gpu,
+                     # decomposition of a meta-step of an N > 1 run (HIP events on the learner's stream; max over ranks): time inside the
+                     # collective (it contains the wait for the slowest rank) and each rank's own work between two collectives
+                     "allreduce_ms": ar_ms, "adapt_ms_slowest_rank": adapt_max, "adapt_ms_fastest_rank": adapt_min,
+                     "tasks_imbalance": ((adapt_max - adapt_min) / adapt_max) if adapt_max else None},
         }
         if dwr is not None:
             out["depthwise_hbm"] = dwr
             out["kernel_families_eager_us"] = fam
+        if bnr is not None:
+            out["batchnorm_hbm"] = bnr
+        if native is not None:
+            out["fp32_native_images_per_s"] = native["value"]
+            out["fp32_native_note"] = native["note"]
         if cpu is not None:
             out["gpu_over_cpu"] = value / cpu["value"]
     else:

@@ -69,8 +69,8 @@ SIGNATURES = {
     "mliis_x3_pack_weights": (_i, [_p, _p, _p, _i, _i, _p]),
     "mliis_conv2d_x3_workspace_floats": (_sz, [_i, _i, _i, _i, _i, _i]),
     "mliis_conv2d_x3_plan": (_i, [_i, _i, _i, _i, _i, _i, _p]),
-    "mliis_conv2d_fwd_x3": (_i, [_p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _p, _sz, _p]),
-    "mliis_conv2d_bwd_data_x3": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _p]),
+    "mliis_conv2d_fwd_x3": (_i, [_p, _i, _p, _sz, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _p, _sz, _p]),
+    "mliis_conv2d_bwd_data_x3": (_i, [_p, _i, _p, _sz, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _p]),
     "mliis_conv2d_bwd_filter_workspace_floats": (_sz, [_i, _i, _i, _i, _i, _i]),
     "mliis_conv2d_bwd_filter": (_i, [_p, _i, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _i, _p]),
     "mliis_conv2d_bwd_filter_plan": (_i, [_i, _i, _i, _i, _i, _i, _p]),

@@ -671,8 +671,8 @@ struct Outer2Op {
   }
   __device__ __forceinline__ void eval(const Ctx&, const Raw& r, float4* o) const {
     const float4 v = f4mul(r.x, r.m);
-    o[0] = f4scale(v, r.d.x);
-    o[1] = f4scale(v, r.d.y);
+    o[0] = f4scale(v, lone(r.d.x));   // (the two halves of an 8-byte load, each broadcast over four channels: common.hpp, lone())
+    o[1] = f4scale(v, lone(r.d.y));
   }
 };
 

@@ -315,21 +315,26 @@ __device__ __forceinline__ void conv_x3_tile(const X3Params& q, char* __restrict
 // (tile, slot) slab [tiles][smax][256][BN]; one 512-thread workgroup per CU.  (A whole-tile form -- tiles beyond a multiple of the CU
 // count finished inside this kernel -- gave results that depended on what ran beside it on the chip in one of 3 x 16 trials with
 // two learners' graphs in flight, tests/test_step_gpu.py::test_concurrent_task_lanes_...; the all-parts form did not in 32, and it is
-// one code path less.  SkPlan.full stays 0.  What actually disturbed the other learner's kernels was co-residency with this kernel:
-// see the register-file claim below.)
+// one code path less.  SkPlan.full stays 0.  What actually disturbed the other learner's kernels was co-residency with this kernel's
+// matrix instruction: see the register-file claim below.)
 template <int NT>
 __global__ __launch_bounds__(512) void conv_x3_k(X3Params q, SkPlan k) {
   __shared__ __attribute__((aligned(16))) char sm[X3Sm<NT>::BYTES];
   constexpr int BN = 16 * NT;
   // This kernel claims the CU's WHOLE register file (eight waves x 256 VGPRs: touching v255 makes the descriptor say so), so that no
-  // wave of another kernel can be co-resident with it.  Measured, not understood (profiles/r05_notes.md, tools/x3_race_probe.py): with
-  // its natural 157-194 registers, small kernels of ANOTHER stream that ran beside it on a CU (resize_fwd_k, the final layer's
-  // filter-gradient reduction: no LDS, 30 VGPRs) returned wrong values in 150-350 of 1200 launches -- with its memory writes, its
-  // scalar-offset loads and its SGPR count ablated one by one to no effect, and never beside the native kernels; with the file
-  // claimed: 0 of 1200 for this kernel alone.  (Together with conv_filter_x3_batched_k on the same stream the victims are still
-  // disturbed now and then, so the meta-learner's concurrent lanes do not use the split-product kernels at all: reptile.py.)  One
-  // workgroup per CU is the plan anyway: the claim costs nothing.
+  // wave of another kernel can be co-resident with it on a CU.  Why (measured on MI355X, ROCm 7.2: tools/interfere_probe.py,
+  // profiles/r06_notes.md): while a wave that interleaves v_mfma_f32_16x16x32_bf16 with LDS or vector-memory instructions is resident
+  // on a CU, a packed fp32 instruction (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32) of ANY OTHER wave on that CU whose op_sel is [0,1]
+  // (low result from src0's low and src1's HIGH register) intermittently returns a wrong LOW result for a 16-lane pass.
+  // Every other select form, the high result, single fp32 instructions, loads, stores and integer work are never
+  // affected; neither is anything on a CU the aggressor does not occupy; the fp32 matrix instruction is not an aggressor.  (Round 5 saw
+  // it as "kernels of another stream return wrong values beside this kernel": the head's resize and the final layer's filter gradient
+  // are two of the six kernels of this library that contain that form.)  With its natural 157-194 registers: victims wrong in 240 of 360
+  // rounds; with the file claimed (this kernel and conv_filter_x3_batched_k below): 0 of 3600.  One workgroup per CU is the plan anyway:
+  // the claim costs nothing.  -DX3_NO_CLAIM: probe builds only (tools/build_variants.sh).
+#ifndef X3_NO_CLAIM
   asm volatile("v_mov_b32 v255, 0" ::: "v255");
+#endif
   const int part = blockIdx.x;
   int lo = part * k.ipp;
   const int total = k.rem * k.nchunks;
@@ -678,6 +683,11 @@ __device__ __forceinline__ void conv_filter_x3_body(const FilterGradParams& p, c
 template <int NT>
 __global__ __launch_bounds__(512) void conv_filter_x3_batched_k(const long long* __restrict__ desc, int nprob) {
   __shared__ __attribute__((aligned(16))) char sm[2 * kF3Stage];
+  // the CU's whole register file, as conv_x3_k and for the same reason (one 512-thread workgroup per CU already: 96 KB of LDS);
+  // -DF3_NO_CLAIM: probe builds only
+#ifndef F3_NO_CLAIM
+  asm volatile("v_mov_b32 v255, 0" ::: "v255");
+#endif
   // (The 18 (tap, channel-block) workgroups of one pixel range read the same dY rows and overlapping X rows and have consecutive block
   //  ids, which the hardware deals round-robin over the eight XCDs.  Remapped so that they share ONE L2 -- xcd_remap -- the launch
   //  took 183 us instead of 152: eight L2s serve the hot lines faster than one.  Plain order.)
@@ -842,12 +852,15 @@ int mliis_conv2d_x3_plan(int Nimg, int H, int W, int Cred, int Nout, int ksize, 
 // y[M, Cout] (ld = ldy) (+)= conv(x[M, Cin] (ld = ldx), w) + bias (+ border_bias), stride 1, TF-SAME, dilation dil, the weights as the
 // mode-0 image of mliis_x3_pack_weights over the same Cin window.  stats_part / stats_swish / stats_nblk as mliis_conv2d_fwd
 // (*stats_nblk = four blocks per 256-row tile).  ws: stream-K slabs (mliis_conv2d_x3_workspace_floats).
-int mliis_conv2d_fwd_x3(const float* x, int ldx, const void* image, const float* bias, const float* border_bias, float* y, int ldy, int Nimg,
+int mliis_conv2d_fwd_x3(const float* x, int ldx, const void* image, size_t image_bytes, const float* bias, const float* border_bias, float* y, int ldy, int Nimg,
                         int H, int W, int Cin, int Cout, int ksize, int dil, int accumulate, float* stats_part, int stats_swish,
                         int* stats_nblk, float* ws, size_t ws_floats, hipStream_t stream) {
   int rc = x3_shape_check("conv2d_fwd_x3", Nimg, H, W, Cin, Cout, ksize, dil);
   if (rc) return rc;
   MLIIS_REQUIRE(x && image && y, MLIIS_ERR_ARG, "conv2d_fwd_x3: null pointer");
+  MLIIS_REQUIRE(image_bytes == mliis_x3_image_bytes(Cin, Cout, ksize), MLIIS_ERR_ARG,
+                "conv2d_fwd_x3: the weight image has %zu bytes, a forward image over %d reduced channels x %d columns (k = %d) has %zu -- packed for another "
+                "window or direction?", image_bytes, Cin, Cout, ksize, mliis_x3_image_bytes(Cin, Cout, ksize));
   MLIIS_REQUIRE((ldx & 3) == 0 && ldx >= Cin && (ldy & 3) == 0 && ldy >= Cout, MLIIS_ERR_ARG, "conv2d_fwd_x3: bad leading dimensions");
   MLIIS_REQUIRE(aligned16(x) && aligned16(image) && aligned16(bias) && aligned16(y) && aligned16(border_bias) && aligned16(ws), MLIIS_ERR_ALIGN,
                 "conv2d_fwd_x3: pointers must be 16-byte aligned");
@@ -873,11 +886,14 @@ int mliis_conv2d_fwd_x3(const float* x, int ldx, const void* image, const float*
 }
 
 // dx[M, Cin_out] (ld = lddx) (+)= conv_transpose(dy[M, Cout] (ld = lddy), w) over the input-channel window the mode-1 image was packed for
-int mliis_conv2d_bwd_data_x3(const float* dy, int lddy, const void* image, float* dx, int lddx, int Nimg, int H, int W, int Cin_out, int Cout,
+int mliis_conv2d_bwd_data_x3(const float* dy, int lddy, const void* image, size_t image_bytes, float* dx, int lddx, int Nimg, int H, int W, int Cin_out, int Cout,
                              int ksize, int dil, int accumulate, float* ws, size_t ws_floats, hipStream_t stream) {
   int rc = x3_shape_check("conv2d_bwd_data_x3", Nimg, H, W, Cout, Cin_out, ksize, dil);
   if (rc) return rc;
   MLIIS_REQUIRE(dy && image && dx, MLIIS_ERR_ARG, "conv2d_bwd_data_x3: null pointer");
+  MLIIS_REQUIRE(image_bytes == mliis_x3_image_bytes(Cout, Cin_out, ksize), MLIIS_ERR_ARG,
+                "conv2d_bwd_data_x3: the weight image has %zu bytes, a backward-data image over %d reduced channels x %d columns (k = %d) has %zu -- packed "
+                "for another window or direction?", image_bytes, Cout, Cin_out, ksize, mliis_x3_image_bytes(Cout, Cin_out, ksize));
   MLIIS_REQUIRE((lddy & 3) == 0 && lddy >= Cout && (lddx & 3) == 0 && lddx >= Cin_out, MLIIS_ERR_ARG, "conv2d_bwd_data_x3: bad leading dimensions");
   MLIIS_REQUIRE(aligned16(dy) && aligned16(image) && aligned16(dx) && aligned16(ws), MLIIS_ERR_ALIGN,
                 "conv2d_bwd_data_x3: pointers must be 16-byte aligned");

@@ -52,10 +52,12 @@ __global__ __launch_bounds__(256) void resize_fwd_k(const float* __restrict__ x,
     const T br = *reinterpret_cast<const T*>(base + ((long long)y1 * Wi + x1) * ldx);
     // top = tl + (tr - tl) * lx ; bottom likewise ; out = top + (bottom - top) * ly   (TF ResizeBilinear form)
     T o = vzero<T>();
-    o = vfma((1.f - ly) * (1.f - lx), tl, o);
-    o = vfma((1.f - ly) * lx, tr, o);
-    o = vfma(ly * (1.f - lx), bl, o);
-    o = vfma(ly * lx, br, o);
+    float wtl, wtr, wbl, wbr;
+    bilinear_weights(ly, lx, wtl, wtr, wbl, wbr);
+    o = vfma(wtl, tl, o);
+    o = vfma(wtr, tr, o);
+    o = vfma(wbl, bl, o);
+    o = vfma(wbr, br, o);
     *reinterpret_cast<T*>(y + p * ldy + c) = o;
   }
 }
@@ -358,16 +360,18 @@ __global__ __launch_bounds__(256) void head_ce_fused_k(const float* __restrict__
     const float2 br = *reinterpret_cast<const float2*>(zb + ((long long)y1 * Wi + x1) * 2);
     const float2 tt = *reinterpret_cast<const float2*>(tb + ((long long)ho * Wo + wo) * 2);
     float2 zz = make_float2(0.f, 0.f);
-    zz = vfma((1.f - ly) * (1.f - lx), tl, zz);
-    zz = vfma((1.f - ly) * lx, tr, zz);
-    zz = vfma(ly * (1.f - lx), bl, zz);
-    zz = vfma(ly * lx, br, zz);
+    float wtl, wtr, wbl, wbr;
+    bilinear_weights(ly, lx, wtl, wtr, wbl, wbr);
+    zz = vfma(wtl, tl, zz);
+    zz = vfma(wtr, tr, zz);
+    zz = vfma(wbl, bl, zz);
+    zz = vfma(wbr, br, zz);
     const float m = fmaxf(zz.x, zz.y);
     const float e0 = expf(zz.x - m), e1 = expf(zz.y - m);
     const float inv = 1.f / (e0 + e1);
     const float p0 = e0 * inv, p1 = e1 * inv;
     const float t0 = tt.x * (1.f - ls) + 0.5f * ls, t1 = tt.y * (1.f - ls) + 0.5f * ls;
-    const float ts = t0 + t1;
+    const float ts = lone(t0) + lone(t1);   // (the sum of the two halves of a packed pair, broadcast back over the pair: common.hpp, lone())
     gl[fr * kHeadFoot + fc] = make_float2((p0 * ts - t0) * inv_rows, (p1 * ts - t1) * inv_rows);
     if (y0 >= hi0 && y0 <= hi1 && x0 >= wi0 && x0 <= wi1) {   // this tile owns the image pixel's loss terms
       const float lse = m + logf(e0 + e1);

@@ -65,10 +65,12 @@ __global__ __launch_bounds__(kCatThreads) void rsd_concat_pool_k(const float* __
 #pragma unroll
         for (int u = 0; u < 4; ++u) {   // (the weights and the order of mliis_resize_bilinear_fwd: bit-identical)
           float4 o = f4zero();
-          o = f4sfma((1.f - ly[u]) * (1.f - lx[u]), tl[u], o);
-          o = f4sfma((1.f - ly[u]) * lx[u], tr[u], o);
-          o = f4sfma(ly[u] * (1.f - lx[u]), bl[u], o);
-          o = f4sfma(ly[u] * lx[u], br[u], o);
+          float wtl, wtr, wbl, wbr;
+          bilinear_weights(ly[u], lx[u], wtl, wtr, wbl, wbr);
+          o = f4sfma(wtl, tl[u], o);
+          o = f4sfma(wtr, tr[u], o);
+          o = f4sfma(wbl, bl[u], o);
+          o = f4sfma(wbr, br[u], o);
           v[u] = o;
         }
       } else {

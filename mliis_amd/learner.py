@@ -352,8 +352,8 @@ class Learner(_Passes):
         return n
 
     def disable_split_products(self):
-        """Back to the native fp32 matrix instruction for the decoder convs (matmul_precision "fp32-native"): the concurrent-lanes
-        variant calls this (reptile.py).  Captured graphs hold the x3 launches: dropped, the next step of each plan is eager again."""
+        """Back to the native fp32 matrix instruction for the decoder convs (matmul_precision "fp32-native") on a live learner.
+        Captured graphs hold the x3 launches: dropped, the next step of each plan is eager again."""
         if self.x3 is None:
             return
         self.stream.synchronize()

@@ -517,7 +517,7 @@ def conv2d_fwd_x3(x, image, k, cout, bias=None, dil=1, out=None, accumulate=Fals
     meta = {}
     if PROFILE is not None:
         meta = dict(kernel=conv2d_x3_kernel_name(N, H, W, Cin, cout, k), flops=2.0 * N * H * W * k * k * Cin * cout, shape=(N, H, W, Cin, cout, k, dil))
-    _timed("conv2d_fwd_x3", meta, lambda: lib.call("mliis_conv2d_fwd_x3", _aptr(x), ldx, _ptr(image), _ptr(bias), _ptr(border_bias), _aptr(out), ldy,
+    _timed("conv2d_fwd_x3", meta, lambda: lib.call("mliis_conv2d_fwd_x3", _aptr(x), ldx, _ptr(image), image.numel() * image.element_size(), _ptr(bias), _ptr(border_bias), _aptr(out), ldy,
                                                    N, H, W, Cin, cout, k, dil, int(accumulate), _ptr(stats_part), int(stats_swish), C.byref(nblk),
                                                    _ptr(buf), buf.numel(), _stream()))
     if stats_part is not None:
@@ -536,7 +536,7 @@ def conv2d_bwd_data_x3(dy, image, k, cin_out, dil=1, out=None, accumulate=False,
     meta = {}
     if PROFILE is not None:
         meta = dict(kernel=conv2d_x3_kernel_name(N, H, W, Cout, cin_out, k), flops=2.0 * N * H * W * k * k * cin_out * Cout, shape=(N, H, W, Cout, cin_out, k, dil))
-    _timed("conv2d_bwd_data_x3", meta, lambda: lib.call("mliis_conv2d_bwd_data_x3", _aptr(dy), lddy, _ptr(image), _aptr(out), lddx, N, H, W, cin_out,
+    _timed("conv2d_bwd_data_x3", meta, lambda: lib.call("mliis_conv2d_bwd_data_x3", _aptr(dy), lddy, _ptr(image), image.numel() * image.element_size(), _aptr(out), lddx, N, H, W, cin_out,
                                                         Cout, k, dil, int(accumulate), _ptr(buf), buf.numel(), _stream()))
     return out
 

@@ -36,11 +36,32 @@ class Dist:
         self._d = dist if (dist.is_available() and dist.is_initialized()) else None
         self.rank = self._d.get_rank() if self._d else 0
         self.world = self._d.get_world_size() if self._d else 1
+        self.timed = False     # bench.py: events around every all_reduce_sum on the calling stream (see timing())
+        self._events = []
 
     def all_reduce_sum(self, t: torch.Tensor):
         if self._d is not None and self.world > 1:
-            self._d.all_reduce(t, op=self._d.ReduceOp.SUM)
+            if self.timed and t.is_cuda:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                self._d.all_reduce(t, op=self._d.ReduceOp.SUM)
+                e1.record()
+                self._events.append((e0, e1))
+            else:
+                self._d.all_reduce(t, op=self._d.ReduceOp.SUM)
         return t
+
+    def timing(self):
+        """(mean ms inside the collectives, mean ms of this rank's own work between two collectives) over the timed all_reduce_sum calls
+        since the last call; the events are dropped.  The collective's span on the calling stream contains the wait for the slowest
+        rank, the span between two collectives is this rank's adaptation work: the two decompose a meta-step of an N > 1 run."""
+        ev, self._events = self._events, []
+        if not ev:
+            return None, None
+        ev[-1][1].synchronize()
+        inside = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+        between = [ev[i][1].elapsed_time(ev[i + 1][0]) for i in range(len(ev) - 1)]
+        return inside, (sum(between) / len(between) if between else None)
 
     def barrier(self):
         if self._d is not None and self.world > 1:
@@ -118,14 +139,11 @@ class Gecko:
         for ln in self.lanes:
             if ln.n_trainable != learner.n_trainable or getattr(ln, "optimizer", "sgd") != getattr(learner, "optimizer", "sgd"):
                 raise ValueError("lanes must share the learner's architecture and inner optimizer")
-        if self.lanes:
-            # Several learners' HIP graphs in flight: every learner falls back to the native fp32 matrix instruction for the decoder
-            # convs.  Measured (profiles/r05_notes.md): while the split-product kernels of one stream run, small kernels of ANOTHER
-            # stream that execute beside them return wrong values now and then; one stream alone is unaffected.  Not understood, so
-            # not risked: the concurrent-lanes variant does not use those kernels.
-            for ln in [learner] + self.lanes:
-                if getattr(ln, "x3", None) is not None:
-                    ln.disable_split_products()
+        # (Lanes keep the split-product kernels of the default fp32 path.  Round 5 switched them to the native instruction because small
+        # kernels of one learner returned wrong values while the split-product kernels of another were on the chip; round 6 named the
+        # mechanism -- a packed fp32 instruction with op_sel:[0,1] on a CU that also holds a wave mixing bf16 matrix instructions with
+        # memory instructions, profiles/r06_notes.md -- and fenced it on both sides: conv_x3_k / conv_filter_x3_batched_k occupy their
+        # CUs alone, and the library is built without that instruction form, tests/test_build_cpu.py.)
         self._transductive = transductive
         # pre_step_op: the reference passes a TF op that multiplies all trainables by `weight_decay_rate`
         # (variables.py:48-55); here it is that rate (float) or None.

@@ -3,6 +3,7 @@ translation unit for gfx950 without a GPU and links a library that exports exact
 import os
 import re
 import subprocess
+import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "mliis_amd", "csrc")
@@ -11,6 +12,16 @@ CSRC = os.path.join(ROOT, "mliis_amd", "csrc")
 def _dynamic_symbols(path):
     out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
     return [ln.split()[-1] for ln in out.splitlines() if ln.strip()]
+
+
+def _affected_packed_forms(lib):
+    """Kernels of the built code objects that contain v_pk_{mul,add,fma}_f32 with op_sel:[0,1]: on MI355X that instruction form returns wrong
+    low results while a wave mixing bf16 / fp8 matrix instructions with memory instructions is resident on the same CU (measured:
+    tools/interfere_probe.py, profiles/r06_notes.md), which the library's own bf16 / fp8 / split-product kernels do on concurrent streams.
+    The sources avoid it (csrc/common.hpp: lone(); the Makefile's flags for optim.hip); this is the check that they still do."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from check_packed_forms import affected_kernels
+    return affected_kernels(lib)
 
 
 def _header_names():
@@ -33,6 +44,7 @@ def test_clean_make_cross_compiles_and_exports_only_the_c_abi(tmp_path):
     # a gfx950 code object is embedded (and no other architecture)
     blob = open(so, "rb").read()
     assert b"gfx950" in blob and b"gfx942" not in blob and b"gfx90a" not in blob
+    assert _affected_packed_forms(so) == {}
 
 
 def test_in_tree_library_exports_only_the_c_abi():
@@ -43,3 +55,4 @@ def test_in_tree_library_exports_only_the_c_abi():
     syms = _dynamic_symbols(LIB_PATH)
     assert syms and all(s.startswith("mliis_") for s in syms), [s for s in syms if not s.startswith("mliis_")][:5]
     assert set(syms) == _header_names()
+    assert _affected_packed_forms(LIB_PATH) == {}, "packed fp32 instructions with op_sel:[0,1] in the shipped library: see csrc/common.hpp, lone()"

@@ -499,9 +499,9 @@ def test_concurrent_task_lanes_equal_the_sequential_meta_step(fomaml, H, bs):
         tasks.append(DeviceTask("t%d" % i, torch.tensor(x).to(dev), torch.tensor(y).to(dev)))
 
     def run(n_lanes):
-        # (concurrent lanes run the native fp32 matrix instruction -- Learner.disable_split_products, profiles/r05_notes.md -- so the
-        #  task-by-task loop they must reproduce bit for bit is the one on that instruction too)
-        L = Learner(image_size=H, seed=1, use_graph=True, drop_connect=False, matmul_precision="fp32" if n_lanes else "fp32-native")
+        # (every learner on the default fp32 path, split-product decoder convs included: several learners' graphs in flight is the
+        #  arrangement in which round 5 saw the packed-fp32 select fault, profiles/r06_notes.md)
+        L = Learner(image_size=H, seed=1, use_graph=True, drop_connect=False, matmul_precision="fp32")
         lanes = [Learner(image_size=H, seed=50 + k, use_graph=True, drop_connect=False) for k in range(n_lanes)]
         kw = dict(rng_mode="per_task", seed=9, lanes=lanes)
         meta = FOMLIS(L, train_shots=10, tail_shots=5, **kw) if fomaml else Gecko(L, **kw)
