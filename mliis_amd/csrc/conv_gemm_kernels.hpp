@@ -794,8 +794,9 @@ __global__ __launch_bounds__(64 * kStreamWaves, 4) void conv1x1_stream_k(ConvGem
     const int fc = fq * 4;
     FoldAcc f;
     if (fl < FL && fc < p.C) {
-      // (a descriptor that ends with the last partial block: the surplus slots of a batch read zeros -- no clamps, no predicates,
-      //  and the batch's addresses are one lane offset + uniform strides)
+      // (a descriptor that ends with the last partial block: the surplus slots of a batch read zeros -- no clamps, no predicates.  The
+      //  slot displacement goes into the VECTOR offset: the range check of a raw buffer load covers voffset + the instruction offset, the
+      //  scalar offset is not promised to take part in it -- ADVICE r05)
       const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc((void*)p.ain.part, 0, p.ain.nblk * 2 * p.C * 4, 0x00020000);
       const int bstride = FL * 2 * p.C * 4;
       for (int k = fl; k < p.ain.nblk; k += FL * 8) {
@@ -803,8 +804,8 @@ __global__ __launch_bounds__(64 * kStreamWaves, 4) void conv1x1_stream_k(ConvGem
         u32x4 u[8], v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          u[j] = __builtin_amdgcn_raw_buffer_load_b128(rP, off, j * bstride, 0);
-          v[j] = __builtin_amdgcn_raw_buffer_load_b128(rP, off + p.C * 4, j * bstride, 0);
+          u[j] = __builtin_amdgcn_raw_buffer_load_b128(rP, off + j * bstride, 0, 0);
+          v[j] = __builtin_amdgcn_raw_buffer_load_b128(rP, off + j * bstride + p.C * 4, 0, 0);
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {

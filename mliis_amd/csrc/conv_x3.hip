@@ -61,7 +61,8 @@ template <int NT>
 struct X3Sm {
   static constexpr int BN = 16 * NT;
   static constexpr int B_BYTES = NT * kX3Block;
-  static constexpr int BYTES = 2 * B_BYTES + 64;   // two chunks of the B tile + a scratch slot for surplus store lanes
+  static constexpr int STAGES = 2;
+  static constexpr int BYTES = STAGES * B_BYTES + 64;   // the chunks of the B tile + a scratch slot for surplus store lanes
 };
 
 // One output tile (256-row tile bx, column tile by) over the K chunks [it0, it1): the raw partial tile to pdst[row * BN + column] (a
@@ -150,7 +151,7 @@ __device__ __forceinline__ void conv_x3_tile(const X3Params& q, char* __restrict
     s_c0 = adv ? (wrap ? 0 : c_next) : s_c0;
     s_tap += adv & wrap;
   };
-  auto load_b = [&]() {
+  auto load_b_into = [&](u32x4 (&rbv)[NB]) {
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       rbv[i] = __builtin_amdgcn_raw_buffer_load_b128(rB, (int)b_voff[i], (int)s_boff, 0);
@@ -159,14 +160,16 @@ __device__ __forceinline__ void conv_x3_tile(const X3Params& q, char* __restrict
     s_bleft -= adv;
     s_boff += adv ? b_step : 0u;
   };
-  auto store_b = [&](char* buf) {
+  auto store_b_from = [&](char* buf, const u32x4 (&rbv)[NB]) {
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const int idx = t + 512 * i;
-      char* d = (512 * (i + 1) <= NT * 192 || idx < NT * 192) ? buf + idx * 16 : sm + 2 * B_BYTES + (t & 3) * 16;   // surplus lanes: scratch
+      char* d = (512 * (i + 1) <= NT * 192 || idx < NT * 192) ? buf + idx * 16 : sm + X3Sm<NT>::STAGES * B_BYTES + (t & 3) * 16;   // surplus lanes: scratch
       *reinterpret_cast<u32x4*>(d) = rbv[i];
     }
   };
+  auto load_b = [&]() { load_b_into(rbv); };
+  auto store_b = [&](char* buf) { store_b_from(buf, rbv); };
   bf16x8 a3[3][2], a3n[3][2];
   auto split_into = [&](const float4 (&ra)[2][2], bf16x8 (&a3)[3][2]) {
 #pragma unroll
@@ -335,7 +338,14 @@ __global__ __launch_bounds__(512) void conv_x3_k(X3Params q, SkPlan k) {
 #ifndef X3_NO_CLAIM
   asm volatile("v_mov_b32 v255, 0" ::: "v255");
 #endif
+  // Consecutive parts -- the K ranges of one row tile and of its neighbours, i.e. the nine taps over the same A rows -- on ONE XCD, so that
+  // they share an L2: fabric reads of the 224 -> 112 conv at 56 x 56 199.2 -> 45.6 MB per launch (rocprofv3 --pmc FETCH_SIZE; algorithmic
+  // 31.5 MB), 78.1 -> 76.0 us with its fix-up, +0.3 % on the step (profiles/r06_notes.md).  -DX3_NO_XCD: the plain order.
+#ifndef X3_NO_XCD
+  const int part = (int)xcd_remap(blockIdx.x, gridDim.x);
+#else
   const int part = blockIdx.x;
+#endif
   int lo = part * k.ipp;
   const int total = k.rem * k.nchunks;
   int hi = lo + k.ipp;

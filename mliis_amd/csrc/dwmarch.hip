@@ -83,9 +83,14 @@ __device__ __forceinline__ void dwm_store(__amdgpu_buffer_rsrc_t r, int off, boo
 __device__ __forceinline__ float4 f4sel(bool ok, const float4 v) { return ok ? v : make_float4(0.f, 0.f, 0.f, 0.f); }
 template <typename T> __device__ __forceinline__ float4 dwm_stored(const float4 v) { return stored_value(static_cast<const T*>(nullptr), v); }
 
+// -DDWM_K5_TS2 (experiment of round 6): the 5x5 stride-1 layer with TWO outputs per thread along W instead of four --
+// bands of 14 columns (twice the workgroups), a 5 x 6 window per strip, fewer live registers in the window phase
+#ifndef DWM_K5_TS2
+#define DWM_K5_TS2 0
+#endif
 template <int K, int S>
 struct MarchCfg {
-  static constexpr int TS = S == 1 ? 4 : 2;            // outputs per thread along W (TS * S = 4 input pixels between strips)
+  static constexpr int TS = (S == 1 && !(K == 5 && DWM_K5_TS2)) ? 4 : 2;   // outputs per thread along W (TS * S input pixels between strips)
   static constexpr int BW = 7 * TS;                    // produced columns of a band: 7 strips (28 | 14), so that ...
   static constexpr int SPR = BW / TS;
   static constexpr int RS = 4;                         // output rows per step: 4 rows x 8 strip slots = the 32 pixel lanes
@@ -476,13 +481,22 @@ __global__ __launch_bounds__(256, BWD ? 1 : 2) void dwm_conv_k(const DwmArgs a) 
     auto read_row = [&](int ky, float4 (&in)[WW]) {
       int slot = s0 + ky;
       if (slot >= NR) slot -= NR;
-      const float4* rowp = ring + slot * (IBWP * 8) + colbase * 8 + q;
-      const float4* A0 = rowp + sxpar * 8;   // columns whose swizzled index is even: je ^ sxpar = je + sxpar
-      const float4* A1 = rowp - sxpar * 8;   // odd: je - sxpar
+      if constexpr ((TS * S) % 4 == 0) {
+        const float4* rowp = ring + slot * (IBWP * 8) + colbase * 8 + q;
+        const float4* A0 = rowp + sxpar * 8;   // columns whose swizzled index is even: je ^ sxpar = je + sxpar
+        const float4* A1 = rowp - sxpar * 8;   // odd: je - sxpar
 #pragma unroll
-      for (int j = 0; j < WW; ++j) {
-        const int je = j ^ ((j >> 2) & 1);
-        in[j] = ((je & 1) ? A1 : A0)[je * 8];
+        for (int j = 0; j < WW; ++j) {
+          const int je = j ^ ((j >> 2) & 1);
+          in[j] = ((je & 1) ? A1 : A0)[je * 8];
+        }
+      } else {   // strips that do not start on a multiple of four columns: the swizzled column of every window element, computed per thread
+        const float4* rowp = ring + slot * (IBWP * 8) + q;
+#pragma unroll
+        for (int j = 0; j < WW; ++j) {
+          const int col = colbase + j;
+          in[j] = rowp[(col ^ ((col >> 2) & 1)) * 8];
+        }
       }
     };
     auto fma_row = [&](int ky, const float4 (&in)[WW]) {
@@ -873,7 +887,7 @@ static inline MarchGeom march_geom_fwd(int N, int H, int W, int C, int K, int S)
   MarchGeom g;
   same_pad(H, K, S, &g.Ho, &g.pt);
   same_pad(W, K, S, &g.Wo, &g.pl);
-  if (S == 1) march_split(N, ceil_div(C, 32), g.Ho, g.Wo, 4, 28, 4, false, &g);
+  if (S == 1 && !(K == 5 && DWM_K5_TS2)) march_split(N, ceil_div(C, 32), g.Ho, g.Wo, 4, 28, 4, false, &g);
   else march_split(N, ceil_div(C, 32), g.Ho, g.Wo, 4, 14, 2, false, &g);
   return g;
 }
@@ -884,7 +898,8 @@ static inline MarchGeom march_geom_bwd(int N, int H, int W, int C, int K, int S)
   same_pad(H, K, S, &g.Ho, &g.pt);
   same_pad(W, K, S, &g.Wo, &g.pl);
   if (S == 1) {
-    march_split(N, ceil_div(C, 32), H, W, 4, 28, 4, true, &g);
+    if (K == 5 && DWM_K5_TS2) march_split(N, ceil_div(C, 32), H, W, 4, 14, 2, true, &g);
+    else march_split(N, ceil_div(C, 32), H, W, 4, 28, 4, true, &g);
   } else {
     const int py = ((H + g.pt - 1) >> 1) - (g.pt >> 1) + 1, pxn = ((W + g.pl - 1) >> 1) - (g.pl >> 1) + 1;
     march_split(N, ceil_div(C, 32), py, pxn, 2, 14, 1, true, &g);

@@ -259,10 +259,10 @@ class Learner(_Passes):
             self._out(v)
         return st
 
-    def import_all(self, st, external: bool = False):
-        """Restore every variable from an export_all() state.  external=True: the state comes from OUTSIDE this training run (a
-        checkpoint), so concurrent lanes must take over its Adam slots too (adam_epoch); the evaluation path's own save / restore
-        around a fine-tune (reptile.py: _evaluate) is not such an event -- it must not erase the lanes' second-moment history."""
+    def import_all(self, st):
+        """Restore every variable from an export_all() state of THIS run (the evaluation path's save / restore around a fine-tune,
+        reptile.py: _evaluate): the lanes' second-moment history stays.  State from outside the run (a checkpoint) arrives through
+        load_named, which advances adam_epoch so that concurrent lanes take over its Adam slots too."""
         self._in()
         with torch.cuda.stream(self.stream):
             self.arena.theta.copy_(st["theta"])
@@ -270,8 +270,6 @@ class Learner(_Passes):
             if self.adam_v is not None and "adam_v" in st:
                 self.adam_v.copy_(st["adam_v"])
                 self.adam_t.copy_(st["adam_t"])
-                if external:
-                    self.adam_epoch += 1
 
     def import_adam(self, adam_v: torch.Tensor, adam_t: torch.Tensor):
         """Replace only the Adam slots (second moments + step count): how a lane takes over the main learner's restored optimizer state."""

@@ -319,8 +319,13 @@ class Gecko:
         ep = getattr(L, "adam_epoch", None)
         if getattr(L, "adam_v", None) is None or ep is None or ep == self._lane_adam_epoch:
             return
+        # Called inside L.comm_context(): the current stream IS L.stream, so each lane's copy is ordered after L's pending writes of its
+        # slots (import_adam -> _in()).  The other direction needs an edge of its own: L's next Adam step rewrites adam_v IN PLACE and must
+        # not start before the lanes' copies (on their streams) have read it (write-after-read).
+        assert torch.cuda.current_stream(L.device) == L.stream, "_sync_lane_optimizer_state must run inside the main learner's comm_context()"
         for ln in self.lanes:
             ln.import_adam(L.adam_v, L.adam_t)
+            L.stream.wait_stream(ln.stream)
         self._lane_adam_epoch = ep
 
     def _task_batches(self, n_shots, inner_batch_size, inner_iters, replacement, rng):
