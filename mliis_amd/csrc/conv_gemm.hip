@@ -937,7 +937,11 @@ int mliis_conv2d_bwd_filter_batched(const long long* desc, int nprob, int blocks
   if (precision == MLIIS_PREC_F32X3) {
     precision = MLIIS_PREC_FP32;
     MLIIS_REQUIRE(desc && nprob >= 1 && nprob <= 64 && blocks >= 1 && aligned16(desc), MLIIS_ERR_ARG, "conv2d_bwd_filter_batched: bad table");
-    if (tmf == 2 && !has_scale) x3_done = launch_filter_batched_x3(nt, desc, nprob, blocks, stream);
+    // tmf == 4 (this precision only): the table was built for 256-channel tiles of the problems with more than 128 input channels
+    // (gx = taps x ceil(C / 256) for those, first blocks accordingly: ops.FilterBatch) -- conv_filter_x3_batched_k stages dY once per
+    // 256 input channels there
+    if ((tmf == 2 || tmf == 4) && !has_scale) x3_done = launch_filter_batched_x3(nt, desc, nprob, blocks, tmf == 4 ? 256 : 128, stream);
+    MLIIS_REQUIRE(tmf != 4 || x3_done, MLIIS_ERR_ARG, "conv2d_bwd_filter_batched: TMF = 4 exists for MLIIS_PREC_F32X3 with 4..8 column tiles and no x_scale only");
   }
   int rc = prec_check("conv2d_bwd_filter_batched", precision);
   if (rc) return rc;

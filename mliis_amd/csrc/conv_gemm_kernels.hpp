@@ -1762,6 +1762,6 @@ bool launch_stream_lowp(int precision, int kc, int nt, dim3 grid, const ConvGemm
 bool launch_ksplit_lowp(int precision, int kc, int nt, dim3 grid, const ConvGemmParams& p, int row_groups, hipStream_t stream);   // conv_gemm_fp8.hip
 void launch_filter_bf16(const FilterPlan& f, const FilterGradParams& p, hipStream_t stream);
 bool launch_filter_batched_bf16(int tmf, int nt, bool sc, const long long* desc, int nprob, int blocks, hipStream_t stream);
-bool launch_filter_batched_x3(int nt, const long long* desc, int nprob, int blocks, hipStream_t stream);   // conv_x3.hip: the (TMF = 2, NT >= 4, no x_scale) groups as split products
+bool launch_filter_batched_x3(int nt, const long long* desc, int nprob, int blocks, int tile_ci, hipStream_t stream);   // conv_x3.hip: the (TMF = 2, NT >= 4, no x_scale) groups as split products (tile_ci: 128 | 256 input channels per workgroup tile)
 
 }  // namespace mliis

@@ -455,15 +455,29 @@ constexpr int kF3Plane = kF3Rows * 256;              // bytes of one term plane 
 constexpr int kF3Stage = 6 * kF3Plane;               // X planes + dY planes
 __device__ __forceinline__ int f3_swz(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }   // chunk XOR of a pixel row
 
-template <int NT>
+// BCI = input channels of a workgroup tile.  128: eight waves = 4 channel blocks x 2 halves of the column tiles (round 5).  256 (round 6,
+// problems with more than 128 input channels): eight waves = 8 channel blocks, every wave all column tiles -- dY is staged (loaded, split,
+// stored) ONCE for up to 256 input channels instead of once per 128, twice the matrix instructions per staged chunk and barrier.
+template <int BCI>
+struct F3Sm {
+  static constexpr int XQ = BCI / 4;                      // channel quads of an X plane row
+  static constexpr int XP = BCI * 2;                      // bytes of an X plane row (bf16)
+  static constexpr int X_PLANE = kF3Rows * XP;
+  static constexpr int STAGE = 3 * X_PLANE + 3 * kF3Plane;   // X planes + dY planes
+};
+template <int NT, int BCI>
 __device__ __forceinline__ void conv_filter_x3_body(const FilterGradParams& p, char* __restrict__ sm, int bx, int by, int bz) {
-  constexpr int BCI = 128, BN = 16 * NT;
+  constexpr int BN = 16 * NT;
+  constexpr bool WIDE = BCI == 256;
+  constexpr int XQ = F3Sm<BCI>::XQ, XP = F3Sm<BCI>::XP, X_PLANE = F3Sm<BCI>::X_PLANE, STAGE = F3Sm<BCI>::STAGE;
+  constexpr int X_PER_THREAD = kF3Rows * XQ / 512;        // 2 | 4 quads of X per thread and chunk
+  constexpr int X_ROWS_PASS = 512 / XQ;                   // 16 | 8 pixel rows per pass of the 512 threads
   constexpr int D_TOTAL = kF3Rows * (BN / 4);
   constexpr int D_PER_THREAD = (D_TOTAL + 511) / 512;
-  constexpr int NT0 = (NT + 1) / 2, NT1 = NT / 2;   // column tiles of the two wave halves
+  constexpr int NT0 = WIDE ? NT : (NT + 1) / 2, NT1 = WIDE ? 0 : NT / 2;   // column tiles of the two wave halves (WIDE: no halves)
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int cib = wave & 3, half = wave >> 2;       // 32-channel block of the tile's 128; column half
+  const int cib = WIDE ? wave : (wave & 3), half = WIDE ? 0 : (wave >> 2);   // 32-channel block of the tile; column half
   const int l15 = lane & 15, g = lane >> 4;
   const int M = p.Nimg * p.H * p.W;
   const bool mt = p.multitap != 0;
@@ -483,8 +497,8 @@ __device__ __forceinline__ void conv_filter_x3_body(const FilterGradParams& p, c
   const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)p.X, 0, kBufRecords, 0x00020000);
   const __amdgpu_buffer_rsrc_t rD = __builtin_amdgcn_make_buffer_rsrc((void*)p.dY, 0, kBufRecords, 0x00020000);
 
-  // ---- X: thread t loads the channel quad x_cq of pixel rows x_r0 and x_r0 + 16 of every chunk
-  const int x_cq = t & 31, x_r0 = t >> 5;
+  // ---- X: thread t loads the channel quad x_cq of pixel rows x_r0, x_r0 + X_ROWS_PASS, ... of every chunk
+  const int x_cq = t % XQ, x_r0 = t / XQ;
   int l_tap = tap, l_c = ci0 + x_cq * 4;
   if (mt) {
     l_tap = (x_cq * 4) / p.C;
@@ -496,11 +510,11 @@ __device__ __forceinline__ void conv_filter_x3_body(const FilterGradParams& p, c
     dh = (l_tap / 3 - 1) * p.dil;
     dw = (l_tap % 3 - 1) * p.dil;
   }
-  int x_m[2], x_h[2], x_w[2];
-  unsigned x_off[2];
+  int x_m[X_PER_THREAD], x_h[X_PER_THREAD], x_w[X_PER_THREAD];
+  unsigned x_off[X_PER_THREAD];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int m = mbeg + x_r0 + 16 * i;
+  for (int i = 0; i < X_PER_THREAD; ++i) {
+    const int m = mbeg + x_r0 + X_ROWS_PASS * i;
     x_m[i] = m;
     const int n = m / HW;
     const int rem = m - n * HW;
@@ -520,21 +534,22 @@ __device__ __forceinline__ void conv_filter_x3_body(const FilterGradParams& p, c
     d_m[i] = mbeg + r;
     d_ok[i] = (idx < D_TOTAL) && (n0 + nq * 4 < p.Nout);
     d_off[i] = (unsigned)((((long long)mbeg + r) * p.lddy + n0 + nq * 4) * 4);
-    d_lds[i] = idx < D_TOTAL ? 3 * kF3Plane + r * 256 + (((nq >> 2) ^ f3_swz(r)) * 32) + (nq & 3) * 8 : -1;
+    d_lds[i] = idx < D_TOTAL ? 3 * X_PLANE + r * 256 + (((nq >> 2) ^ f3_swz(r)) * 32) + (nq & 3) * 8 : -1;
   }
   const unsigned d_step = (unsigned)(kF3Rows * p.lddy * 4);
-  int x_lds[2];
+  int x_lds[X_PER_THREAD];   // (the XOR swizzle acts on the low three bits of the 32-byte chunk index: rows of 256 or 512 bytes alike)
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int r = x_r0 + 16 * i;
-    x_lds[i] = r * 256 + (((x_cq >> 2) ^ f3_swz(r)) * 32) + (x_cq & 3) * 8;
+  for (int i = 0; i < X_PER_THREAD; ++i) {
+    const int r = x_r0 + X_ROWS_PASS * i;
+    const int ch = x_cq >> 2;
+    x_lds[i] = r * XP + (((ch & ~7) | ((ch & 7) ^ f3_swz(r))) * 32) + (x_cq & 3) * 8;
   }
 
-  float4 rxa[2], rda[D_PER_THREAD], rxb[2], rdb[D_PER_THREAD];   // two chunks in flight (requested a whole chunk before their split)
-  auto load_chunk = [&](float4 (&rx)[2], float4 (&rd)[D_PER_THREAD]) {   // next 32 pixel rows -> registers, then advance (rows beyond
-                                                                        // mend / halo pixels come back as zeros)
+  float4 rxa[X_PER_THREAD], rda[D_PER_THREAD], rxb[X_PER_THREAD], rdb[D_PER_THREAD];   // two chunks in flight (requested a whole chunk before their split)
+  auto load_chunk = [&](float4 (&rx)[X_PER_THREAD], float4 (&rd)[D_PER_THREAD]) {   // next 32 pixel rows -> registers, then advance (rows beyond
+                                                                                   // mend / halo pixels come back as zeros)
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < X_PER_THREAD; ++i) {
       const bool ok = x_cok & (x_m[i] < mend) & ((unsigned)(x_h[i] + dh) < (unsigned)p.H) & ((unsigned)(x_w[i] + dw) < (unsigned)p.W);
       rx[i] = buf_ld4(rX, ok ? x_off[i] : kOob);
       x_m[i] += kF3Rows;
@@ -556,28 +571,28 @@ __device__ __forceinline__ void conv_filter_x3_body(const FilterGradParams& p, c
   };
   // the split of the chunk in registers (this thread's 2 + D_PER_THREAD quads -> three terms each) is done in pieces BETWEEN the
   // matrix instructions of the chunk being multiplied (compute_split below), the terms are stored behind them
-  constexpr int NP = 2 + D_PER_THREAD;
+  constexpr int NP = X_PER_THREAD + D_PER_THREAD;
   uint2 th[NP], tm[NP], tl[NP];
-  auto split_piece = [&](int k, const float4 (&rx)[2], const float4 (&rd)[D_PER_THREAD]) {
-    split3(k < 2 ? rx[k < 2 ? k : 0] : rd[k >= 2 ? k - 2 : 0], th[k], tm[k], tl[k]);
+  auto split_piece = [&](int k, const float4 (&rx)[X_PER_THREAD], const float4 (&rd)[D_PER_THREAD]) {
+    split3(k < X_PER_THREAD ? rx[k < X_PER_THREAD ? k : 0] : rd[k >= X_PER_THREAD ? k - X_PER_THREAD : 0], th[k], tm[k], tl[k]);
     // (an empty statement that "uses" the piece here: without it the optimiser sinks the arithmetic to the stores behind the loop)
     asm volatile("" : "+v"(th[k].x), "+v"(th[k].y), "+v"(tm[k].x), "+v"(tm[k].y), "+v"(tl[k].x), "+v"(tl[k].y));
   };
   auto store_terms = [&](char* buf) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < X_PER_THREAD; ++i) {
       char* d = buf + x_lds[i];
       *reinterpret_cast<uint2*>(d) = th[i];
-      *reinterpret_cast<uint2*>(d + kF3Plane) = tm[i];
-      *reinterpret_cast<uint2*>(d + 2 * kF3Plane) = tl[i];
+      *reinterpret_cast<uint2*>(d + X_PLANE) = tm[i];
+      *reinterpret_cast<uint2*>(d + 2 * X_PLANE) = tl[i];
     }
 #pragma unroll
     for (int i = 0; i < D_PER_THREAD; ++i) {
       if (512 * (i + 1) <= D_TOTAL || d_lds[i] >= 0) {
         char* d = buf + d_lds[i];
-        *reinterpret_cast<uint2*>(d) = th[2 + i];
-        *reinterpret_cast<uint2*>(d + kF3Plane) = tm[2 + i];
-        *reinterpret_cast<uint2*>(d + 2 * kF3Plane) = tl[2 + i];
+        *reinterpret_cast<uint2*>(d) = th[X_PER_THREAD + i];
+        *reinterpret_cast<uint2*>(d + kF3Plane) = tm[X_PER_THREAD + i];
+        *reinterpret_cast<uint2*>(d + 2 * kF3Plane) = tl[X_PER_THREAD + i];
       }
     }
   };
@@ -589,39 +604,40 @@ __device__ __forceinline__ void conv_filter_x3_body(const FilterGradParams& p, c
     for (int j = 0; j < NTW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   // fragment addresses: lane (g, q = l15 >> 2, pq = l15 & 3) supplies pixel row 8 g + 4 hh + q, columns 4 pq .. 4 pq + 3 of a 16-channel chunk
   const int fq = l15 >> 2, fp = l15 & 3;
-  int a_row[2], a_sw[2];
+  int a_row[2], d_row[2], a_sw[2];   // byte offset of this lane's pixel row in an X plane / a dY plane, and the row's chunk XOR
 #pragma unroll
   for (int hh = 0; hh < 2; ++hh) {
     const int r = 8 * g + 4 * hh + fq;
-    a_row[hh] = r * 256 + fp * 8;
+    a_row[hh] = r * XP + fp * 8;
+    d_row[hh] = r * 256 + fp * 8;
     a_sw[hh] = f3_swz(r);
   }
   const bool wave_live = mt ? cib * 32 < p.ntaps * p.C : ci0 + cib * 32 < p.C;
   const int jn0 = half == 0 ? 0 : NT0;           // first column tile of this wave
   const int njn = half == 0 ? NT0 : NT1;
-  auto frag = [&](const char* plane, int chunk16) {   // the 8 k values of one 16-channel block: two transposed reads
-    const uint2 lo = ds_read_tr16(plane + a_row[0] + ((chunk16 ^ a_sw[0]) * 32));
-    const uint2 hi = ds_read_tr16(plane + a_row[1] + ((chunk16 ^ a_sw[1]) * 32));
+  auto frag = [&](const char* plane, const int (&row)[2], int chunk16) {   // the 8 k values of one 16-channel block: two transposed reads
+    const uint2 lo = ds_read_tr16(plane + row[0] + (((chunk16 & ~7) | ((chunk16 & 7) ^ a_sw[0])) * 32));
+    const uint2 hi = ds_read_tr16(plane + row[1] + (((chunk16 & ~7) | ((chunk16 & 7) ^ a_sw[1])) * 32));
     return __builtin_bit_cast(bf16x8, (u32x4){lo.x, lo.y, hi.x, hi.y});
   };
   // One chunk's products out of LDS stage `buf`; the fragments of column tile j + 1 are requested before the products of tile j, and
   // one piece of the NEXT chunk's split rides behind the matrix instructions of every column tile (fenced: conv_x3_tile)
-  auto compute_split = [&](const char* buf, const float4 (&rx)[2], const float4 (&rd)[D_PER_THREAD]) {
+  auto compute_split = [&](const char* buf, const float4 (&rx)[X_PER_THREAD], const float4 (&rd)[D_PER_THREAD]) {
     bf16x8 a3[3][2], b3[2][3];
     if (wave_live) {
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb) a3[pl][rb] = frag(buf + pl * kF3Plane, cib * 2 + rb);
+        for (int rb = 0; rb < 2; ++rb) a3[pl][rb] = frag(buf + pl * X_PLANE, a_row, cib * 2 + rb);
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) b3[0][pl] = frag(buf + (3 + pl) * kF3Plane, jn0);
+      for (int pl = 0; pl < 3; ++pl) b3[0][pl] = frag(buf + 3 * X_PLANE + pl * kF3Plane, d_row, jn0);
     }
 #pragma unroll
     for (int j = 0; j < NTW; ++j) {
       if (wave_live && j < njn) {   // (uniform)
         if (j + 1 < NTW && j + 1 < njn) {
 #pragma unroll
-          for (int pl = 0; pl < 3; ++pl) b3[(j + 1) & 1][pl] = frag(buf + (3 + pl) * kF3Plane, jn0 + j + 1);
+          for (int pl = 0; pl < 3; ++pl) b3[(j + 1) & 1][pl] = frag(buf + 3 * X_PLANE + pl * kF3Plane, d_row, jn0 + j + 1);
         }
 #define X3_MM(PA, PB)                                                                                            \
   acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3[PA][0], b3[j & 1][PB], acc[0][j], 0, 0, 0);           \
@@ -650,7 +666,7 @@ __device__ __forceinline__ void conv_filter_x3_body(const FilterGradParams& p, c
   load_chunk(rxa, rda);   // chunk 1
   load_chunk(rxb, rdb);   // chunk 2
   lds_barrier();
-  auto trip = [&](char* cur, char* nxt, float4 (&rx)[2], float4 (&rd)[D_PER_THREAD]) {   // (rx, rd): the chunk after the one in `cur`
+  auto trip = [&](char* cur, char* nxt, float4 (&rx)[X_PER_THREAD], float4 (&rd)[D_PER_THREAD]) {   // (rx, rd): the chunk after the one in `cur`
     compute_split(cur, rx, rd);   // + the split of the next chunk
 #ifndef F3_NOSTAGE                // (ablation: no split arithmetic, no LDS stores -- the products run on stale stages)
     store_terms(nxt);             // (zeros after the last chunk: nobody reads them)
@@ -660,10 +676,10 @@ __device__ __forceinline__ void conv_filter_x3_body(const FilterGradParams& p, c
   };
   int it = 0;
   for (; it + 2 <= nchunks; it += 2) {
-    trip(sm, sm + kF3Stage, rxa, rda);
-    trip(sm + kF3Stage, sm, rxb, rdb);
+    trip(sm, sm + STAGE, rxa, rda);
+    trip(sm + STAGE, sm, rxb, rdb);
   }
-  if (it < nchunks) trip(sm, sm + kF3Stage, rxa, rda);
+  if (it < nchunks) trip(sm, sm + STAGE, rxa, rda);
 #ifndef X3_NO_DRAIN
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (as in conv_x3_tile)
 #endif
@@ -691,8 +707,8 @@ __device__ __forceinline__ void conv_filter_x3_body(const FilterGradParams& p, c
 //  149 against 151 us inside the step, 3424 / 3416 against 3409 / 3418 images/s: no gain where it counts, 330 lines: not kept.)
 // the problems of one (TMF = 2, NT) group of a FilterBatch as one grid: descriptor table as conv_filter_grad2_batched_k
 template <int NT>
-__global__ __launch_bounds__(512) void conv_filter_x3_batched_k(const long long* __restrict__ desc, int nprob) {
-  __shared__ __attribute__((aligned(16))) char sm[2 * kF3Stage];
+__global__ __launch_bounds__(512) void conv_filter_x3_batched_k(const long long* __restrict__ desc, int nprob, int tile_ci) {
+  __shared__ __attribute__((aligned(16))) char sm[2 * F3Sm<256>::STAGE];
   // the CU's whole register file, as conv_x3_k and for the same reason (one 512-thread workgroup per CU already: 96 KB of LDS);
   // -DF3_NO_CLAIM: probe builds only
 #ifndef F3_NO_CLAIM
@@ -713,12 +729,15 @@ __global__ __launch_bounds__(512) void conv_filter_x3_batched_k(const long long*
   const int gx = (int)(d[14] & 0xfffff), gy = (int)((d[14] >> 20) & 0xfffff);
   const int local = b - (int)d[15];
   const int bx = local % gx, r = local / gx;
-  conv_filter_x3_body<NT>(p, sm, bx, r % gy, r / gy);
+  // problems with more than 128 input channels take 256-channel tiles (the table's gx of such a problem is taps x ceil(C / 256): the caller
+  // builds the table for THIS kernel -- mliis_conv2d_bwd_filter_batched, tile_ci == 256), everything else, the multitap form included, 128
+  if (tile_ci == 256 && p.multitap == 0 && p.C > 128) conv_filter_x3_body<NT, 256>(p, sm, bx, r % gy, r / gy);   // (uniform)
+  else conv_filter_x3_body<NT, 128>(p, sm, bx, r % gy, r / gy);
 }
 
-bool launch_filter_batched_x3(int nt, const long long* desc, int nprob, int blocks, hipStream_t stream) {
+bool launch_filter_batched_x3(int nt, const long long* desc, int nprob, int blocks, int tile_ci, hipStream_t stream) {
   dim3 grid(blocks), block(512);
-#define L(NT_) hipLaunchKernelGGL((conv_filter_x3_batched_k<NT_>), grid, block, 0, stream, desc, nprob); return true;
+#define L(NT_) hipLaunchKernelGGL((conv_filter_x3_batched_k<NT_>), grid, block, 0, stream, desc, nprob, tile_ci); return true;
   switch (nt) {
     case 4: L(4)
     case 5: L(5)

@@ -7,6 +7,7 @@ There is no eager/PyTorch fallback -- a missing library or a non-device tensor r
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -641,6 +642,9 @@ class FilterBatch:
         self._keep += [x, dy, partial, x_scale]
         self.tables = None
 
+    # fp32x3 launches: 256-channel workgroup tiles for the problems with more than 128 input channels (MLIIS_X3_NARROW=1: round 5's 128)
+    X3_WIDE = os.environ.get("MLIIS_X3_NARROW", "0") != "1"
+
     def _build(self):
         self.tables = []
         for (tmf, nt, sc), items in sorted(self.groups.items()):
@@ -649,7 +653,21 @@ class FilterBatch:
                 for row, blocks in items[i0:i0 + 64]:
                     rows.append(row[:15] + [first])
                     first += blocks
-                self.tables.append((torch.tensor(rows, dtype=torch.int64, device=self.device), len(rows), first, tmf, nt, int(sc)))
+                # the same problems tiled for conv_filter_x3_batched_k's 256-channel form (MLIIS_PREC_F32X3, TMF passed as 4): a problem with
+                # more than 128 input channels takes gx = taps * ceil(Cin / 256) workgroups along x; slabs, pixel splits and fold unchanged
+                wide = None
+                if tmf == 2 and not sc and 4 <= nt <= 8 and self.X3_WIDE:
+                    wrows, wfirst = [], 0
+                    for row, _ in items[i0:i0 + 64]:
+                        cin, kk, multitap = row[9], row[11] & 0xff, (row[13] >> 32) & 1
+                        gx, gy, gz = row[14] & 0xfffff, (row[14] >> 20) & 0xfffff, row[14] >> 40
+                        if not multitap and cin > 128:
+                            gx = kk * kk * ((cin + 255) // 256)
+                        wrows.append(row[:14] + [gx | (gy << 20) | (gz << 40), wfirst])
+                        wfirst += gx * gy * gz
+                    if wfirst != first:   # (at least one problem is tiled differently)
+                        wide = (torch.tensor(wrows, dtype=torch.int64, device=self.device), wfirst)
+                self.tables.append((torch.tensor(rows, dtype=torch.int64, device=self.device), len(rows), first, tmf, nt, int(sc), wide))
 
     def launch(self, precision="fp32"):
         """precision "fp32x3": the groups of 128-channel tiles as fp32-equivalent split products on the bf16 matrix cores
@@ -660,8 +678,11 @@ class FilterBatch:
         if prec in (0, 3) and any((row[11] >> 8) for items in self.groups.values() for row, _ in items):
             raise MliisError("FilterBatch: bf16 tensors need the bf16-operand instances (precision 'bf16')")
         def issue():
-            for table, nprob, blocks, tmf, nt, sc in self.tables:
-                lib.call("mliis_conv2d_bwd_filter_batched", _ptr(table), nprob, blocks, tmf, nt, sc, prec, _stream())
+            for table, nprob, blocks, tmf, nt, sc, wide in self.tables:
+                if prec == 3 and wide is not None:
+                    lib.call("mliis_conv2d_bwd_filter_batched", _ptr(wide[0]), nprob, wide[1], 4, nt, sc, prec, _stream())
+                else:
+                    lib.call("mliis_conv2d_bwd_filter_batched", _ptr(table), nprob, blocks, tmf, nt, sc, prec, _stream())
         _timed("conv2d_bwd_filter_batched", dict(flops=getattr(self, "flops", 0.0)) if PROFILE is not None else {}, issue)
 
     def __len__(self):

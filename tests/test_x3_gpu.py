@@ -230,6 +230,34 @@ def test_x3_filter_gradient_of_the_concat_sliver_takes_the_multitap_form():
     close(_fold(pa, 9 * 8 * Cout).view(3, 3, 8, Cout).cpu(), gw, 1e-4, "x3 multitap filter gradient")
 
 
+def test_x3_filter_gradient_wide_tiles_equal_the_128_channel_tiles_bit_for_bit():
+    """Round 6: problems with more than 128 input channels take 256-channel workgroup tiles (dY staged once per 256 input channels;
+    FilterBatch builds a second table, the slabs / pixel splits / fold do not change).  The decoder's launch -- fuse conv 224 -> 112, the
+    dilated branch's 128-channel part, its 8-channel multitap sliver -- and a ragged 200-channel problem: every slab element equal to the
+    128-channel form's (the reduction order over the pixels is the same)."""
+    from mliis_amd import ops
+    d = dev()
+    N, H = 8, 56
+    buf1, buf2, buf3 = f32(rnd(N, H, H, 224, seed=41), d), f32(rnd(N, H, H, 136, seed=42), d), f32(rnd(2, 19, 19, 200, seed=44), d)
+    dy, dy3 = f32(rnd(N, H, H, 112, seed=43), d), f32(rnd(2, 19, 19, 112, seed=45), d)
+    specs = [(buf1, dy, 3, 1), (buf2[..., :128], dy, 3, 2), (buf2[..., 128:], dy, 3, 2), (buf3, dy3, 3, 1)]
+    out = {}
+    for wide in (False, True):
+        fb = ops.FilterBatch(d)
+        fb.X3_WIDE = wide
+        slabs = []
+        for x, g, k, dil in specs:
+            n = ops.lib.size("mliis_conv2d_bwd_filter_workspace_floats", x.shape[0], x.shape[1], x.shape[2], x.shape[3], g.shape[3], k)
+            slabs.append(torch.full((n,), 7.0, device=d))
+            fb.add(x, g, k, dil, slabs[-1])
+        fb.launch("fp32x3")
+        torch.cuda.synchronize()
+        assert any(t[6] is not None for t in fb.tables) == wide
+        out[wide] = slabs
+    for a, b in zip(out[False], out[True]):
+        assert torch.equal(a, b)
+
+
 def test_concurrent_lanes_keep_the_split_product_kernels():
     """Several learners' graphs in flight (Gecko(lanes=...), --concurrent-tasks) run the default fp32 path, split-product decoder convs
     included.  (Round 5 dropped them there: kernels of one learner went wrong beside the split-product kernels of another.  Round 6:
