@@ -1,6 +1,6 @@
 #!/bin/bash
 # copies the summaries tools/final_profile.sh left under gpurun_out/<tag> into profiles/ (tracked), named per round
-TAG=${1:-r05_final}; R=${2:-r05}
+TAG=${1:-r06_final}; R=${2:-r06}
 S=gpurun_out/$TAG
 cp $S/trace/t_kernel_stats.csv profiles/${R}_final_kernel_stats.csv
 cp $S/profile.md profiles/${R}_final_profile.md
