@@ -1734,10 +1734,12 @@ __device__ __forceinline__ void x3_pack_block(const float* __restrict__ theta, c
   const int chunk = local / ncol16, c16 = local - chunk * ncol16;
   const int nl = t & 15, kq = t >> 4;   // column of the tile, k quad 0..7 of the chunk
   const int n = c16 * 16 + nl;
-  const int cpt = (kc + 31) / 32;                    // chunks per tap: a chunk never straddles a tap (the last one of a tap is zero-padded)
-  const int tap = chunk / cpt, c = (chunk - tap * cpt) * 32 + kq * 4;
+  // K = the flattened (tap, channel) index, tap-major, in chunks of 32 without padding between taps (kc % 4 == 0: a k quad belongs to one
+  // tap; only the last chunk of the image is zero-padded) -- conv_x3_tile advances the same index per lane
+  const int k = chunk * 32 + kq * 4;
+  const int tap = k / kc, c = k - tap * kc;
   float4 v = f4zero();
-  if (n < nn && c < kc) {
+  if (n < nn && tap < taps) {
     if (mode == 0) {
       const float* s = w + ((long long)tap * cin_total + ci_begin + c) * cout + n;
       v = make_float4(s[0], s[cout], s[2 * (long long)cout], s[3 * (long long)cout]);

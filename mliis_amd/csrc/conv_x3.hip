@@ -9,8 +9,8 @@
 // the split itself) became the bound (the split done inside that kernel: 120 -> 95 us, and 82 us with NO split arithmetic at all), so
 // this kernel is laid out for the split product (how each choice measured: profiles/r05_notes.md):
 //   * B (the weights) is split ONCE per inner step by x3_pack_k into an image that is already the LDS image of the kernel:
-//     [K chunk of 32][16-column tile][term 3][lane group g 4][column 16][8 bf16] = 3072 bytes per (chunk, column tile), every tap padded
-//     to whole chunks (a chunk belongs to one tap: tap offset and tap validity are scalars of the chunk).  A chunk of a workgroup's B
+//     [K chunk of 32][16-column tile][term 3][lane group g 4][column 16][8 bf16] = 3072 bytes per (chunk, column tile); K is the
+//     flattened (tap, channel) index without padding between taps (round 6).  A chunk of a workgroup's B
 //     tile is ONE contiguous run of NT x 3072 bytes: linear 16-byte loads, linear ds_write_b128, conflict-free ds_read_b128
 //     fragments, no arithmetic;
 //   * A (the activations) does not go through LDS at all: a wave owns 32 rows (two 16-row blocks) and loads its own A fragments from
@@ -84,19 +84,21 @@ __device__ __forceinline__ void conv_x3_tile(const X3Params& q, char* __restrict
   const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, kBufRecords, 0x00020000);
   const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)q.image, 0, kBufRecords, 0x00020000);
 
-  // ---- this lane's two rows (row blocks rb = 0, 1 of the wave's 32 rows): byte offset of the row's k quads and the 9-bit mask of the
-  // taps whose source pixel lies inside the image (a K chunk belongs to ONE tap -- the image pads every tap to whole chunks -- so the
-  // tap offset, the channel offset and the tap bit are scalars of the chunk)
+  // ---- this lane's two rows (row blocks rb = 0, 1 of the wave's 32 rows): byte offset of the row and the 9-bit mask of the taps whose
+  // source pixel lies inside the image.  K is the FLATTENED (tap, channel) index, tap-major, cut into chunks of 32 with no padding
+  // between taps (round 6: a tap of 112 or 136 channels used to be padded to 128 / 160 -- 12-18 % of the matrix instructions multiplied
+  // zeros); a lane's two k quads of a chunk (k = 32 chunk + 16 qd + 4 g ...) may therefore belong to different taps: tap, channel and
+  // source offset are per-lane values, advanced incrementally (Cred >= 32: at most one tap boundary per advance; Cred % 4 == 0: a quad
+  // never straddles one)
   const int wrow = wave * 32;   // first row of this wave inside the tile
-  unsigned a_off[2][2], a_taps[2];
+  unsigned a_row[2], a_taps[2];
 #pragma unroll
   for (int rb = 0; rb < 2; ++rb) {
     const long long m = m0 + wrow + rb * 16 + l15;
     a_taps[rb] = 0;
-    a_off[rb][0] = a_off[rb][1] = 0;
+    a_row[rb] = 0;
     if (m < M) {
-      a_off[rb][0] = (unsigned)((m * p.lda + g * 4) * 4);
-      a_off[rb][1] = a_off[rb][0] + 64u;
+      a_row[rb] = (unsigned)(m * p.lda * 4);
       if (p.ntaps > 1) {
         const int HWp = p.H * p.W;
         const int n = (int)(m / HWp);
@@ -112,11 +114,15 @@ __device__ __forceinline__ void conv_x3_tile(const X3Params& q, char* __restrict
       }
     }
   }
-  const int klane = g * 4;   // first channel of this lane's quad 0 inside a chunk (quad 1: + 16)
-  // ---- the next A chunk to LOAD: tap s_tap, first channel s_c0; the next B chunk to load: byte offset s_boff (uniform per wave; past
-  // the last chunk of the range the SAME chunk is requested again -- cache hits, never used -- so the hot path has no predicate)
-  const int cpt = (p.C + 31) / 32;
-  int s_tap = it0 / cpt, s_c0 = (it0 - s_tap * cpt) * 32;
+  // ---- the next A chunk to LOAD: per lane and k quad its tap l_tap and channel l_c; the next B chunk to load: byte offset s_boff
+  // (uniform per wave; past the last chunk the SAME chunk is requested again -- cache hits, never used -- so the hot path has no predicate)
+  int l_tap[2], l_c[2];
+#pragma unroll
+  for (int qd = 0; qd < 2; ++qd) {
+    const int k0 = it0 * 32 + qd * 16 + g * 4;
+    l_tap[qd] = k0 / p.C;
+    l_c[qd] = k0 - l_tap[qd] * p.C;
+  }
   int s_aleft = it1 - it0, s_bleft = it1 - it0;
   int ncol_here = q.ncol16 - by * NT;
   if (ncol_here > NT) ncol_here = NT;
@@ -130,26 +136,24 @@ __device__ __forceinline__ void conv_x3_tile(const X3Params& q, char* __restrict
   float4 ra[2][2];    // [row block][quad]: the next A chunk, fp32
   float4 ra2[2][2];   // the A chunk after that
   u32x4 rbv[NB];      // this thread's pieces of the next B chunk
+  const int tap_scale = p.dil * p.sign;
   auto load_a_into = [&](float4 (&ra)[2][2]) {
-    const int th = p.ntaps > 1 ? s_tap / 3 : 1, tw = p.ntaps > 1 ? s_tap - th * 3 : 1;
-    const int dh = (th - 1) * p.dil * p.sign, dw = (tw - 1) * p.dil * p.sign;
-    const unsigned s_aoff = (unsigned)(((dh * p.W + dw) * p.lda + s_c0) * 4);   // (two's complement: the sum with a row's offset is exact)
-    const unsigned tapbit = 1u << s_tap;
-    const int cleft = p.C - s_c0;
-#pragma unroll
-    for (int qd = 0; qd < 2; ++qd) {
-      const bool cok = klane + 16 * qd < cleft;
-#pragma unroll
-      for (int rb = 0; rb < 2; ++rb) {
-        ra[rb][qd] = buf_ld4(rA, (cok & ((a_taps[rb] & tapbit) != 0)) ? a_off[rb][qd] + s_aoff : kOob);
-      }
-    }
     const int adv = s_aleft > 1 ? 1 : 0;   // (branch-free advance)
     s_aleft -= adv;
-    const int c_next = s_c0 + 32;
-    const int wrap = c_next >= p.C ? 1 : 0;
-    s_c0 = adv ? (wrap ? 0 : c_next) : s_c0;
-    s_tap += adv & wrap;
+#pragma unroll
+    for (int qd = 0; qd < 2; ++qd) {
+      const int tap = l_tap[qd];
+      const int th = p.ntaps > 1 ? (tap * 11) >> 5 : 1, tw = p.ntaps > 1 ? tap - 3 * th : 1;   // (tap / 3 for tap <= 9)
+      const int dh = (th - 1) * tap_scale, dw = (tw - 1) * tap_scale;
+      const unsigned koff = (unsigned)(((dh * p.W + dw) * p.lda + l_c[qd]) * 4);   // (two's complement: the sum with a row's offset is exact)
+      const unsigned tapbit = tap < p.ntaps ? 1u << tap : 0u;                       // (k beyond the last tap: zeros)
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) ra[rb][qd] = buf_ld4(rA, (a_taps[rb] & tapbit) != 0 ? a_row[rb] + koff : kOob);
+      const int c_next = l_c[qd] + 32;
+      const int wrap = c_next >= p.C ? 1 : 0;
+      l_c[qd] = adv ? (wrap ? c_next - p.C : c_next) : l_c[qd];
+      l_tap[qd] += adv & wrap;
+    }
   };
   auto load_b_into = [&](u32x4 (&rbv)[NB]) {
 #pragma unroll
@@ -773,7 +777,7 @@ static int x3_pick_nt(int Nout) {   // the widest column tile that does not pad 
   return best;
 }
 
-static inline int x3_chunks(int ntaps, int Cred) { return ntaps * ((Cred + 31) / 32); }   // every tap padded to whole chunks of 32
+static inline int x3_chunks(int ntaps, int Cred) { return (ntaps * Cred + 31) / 32; }   // the flattened (tap, channel) index in chunks of 32
 static X3Plan x3_plan(long long M, int Nout, int ntaps, int Cred, int num_cus) {
   X3Plan g;
   g.nt = x3_pick_nt(Nout);
