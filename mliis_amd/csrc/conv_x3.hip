@@ -373,9 +373,12 @@ __global__ __launch_bounds__(512) void conv_x3_k(X3Params q, SkPlan k) {
 constexpr int kX3Fix = 4;
 template <int NT>
 __global__ __launch_bounds__(1024) void x3_fixup_k(ConvGemmParams p, SkPlan k) {
-  constexpr int BN = 16 * NT, QN = BN / 4, RPT = kX3BM / kX3Fix / 32;
-  __shared__ float4 red[2][32][32];
-  const int t = threadIdx.x, q = t & 31, rl = t >> 5;
+  constexpr int BN = 16 * NT, QN = BN / 4;
+  constexpr int QS = QN <= 32 ? 32 : 64;              // column-quad slots (NT = 9: 36 quads)
+  constexpr int RL = 1024 / QS;                       // row lanes
+  constexpr int RPT = kX3BM / kX3Fix / RL;            // rows per thread
+  __shared__ float4 red[2][RL][QS];
+  const int t = threadIdx.x, q = t % QS, rl = t / QS;
   const int rt = blockIdx.x, sub = blockIdx.y;
   const unsigned tau = k.full + rt;
   const int bx = tau / k.gy, by = tau % k.gy;
@@ -395,17 +398,17 @@ __global__ __launch_bounds__(1024) void x3_fixup_k(ConvGemmParams p, SkPlan k) {
     const long long HWp = (long long)p.H * p.W;
     float4 v[RPT];
 #pragma unroll
-    for (int i = 0; i < RPT; ++i) v[i] = (m0 + rl + 32 * i < M) ? ld4(base + (long long)(rl + 32 * i) * BN) : f4zero();
+    for (int i = 0; i < RPT; ++i) v[i] = (m0 + rl + RL * i < M) ? ld4(base + (long long)(rl + RL * i) * BN) : f4zero();
     for (int z = 1; z < nslots; ++z) {
       float4 u[RPT];
 #pragma unroll
-      for (int i = 0; i < RPT; ++i) u[i] = (m0 + rl + 32 * i < M) ? ld4(base + ((long long)z * kX3BM + rl + 32 * i) * BN) : f4zero();
+      for (int i = 0; i < RPT; ++i) u[i] = (m0 + rl + RL * i < M) ? ld4(base + ((long long)z * kX3BM + rl + RL * i) * BN) : f4zero();
 #pragma unroll
       for (int i = 0; i < RPT; ++i) v[i] = f4add(v[i], u[i]);
     }
 #pragma unroll
     for (int i = 0; i < RPT; ++i) {
-      const long long m = m0 + rl + 32 * i;
+      const long long m = m0 + rl + RL * i;
       if (m >= M) continue;
       float4 o = f4add(v[i], bv);
       if (p.border_bias != nullptr) {
@@ -427,13 +430,13 @@ __global__ __launch_bounds__(1024) void x3_fixup_k(ConvGemmParams p, SkPlan k) {
   red[0][rl][q] = s1;
   red[1][rl][q] = s2;
   __syncthreads();
-  if (t < 64) {
-    const int v = t >> 5, qq = t & 31;
+  if (t < 2 * QS) {
+    const int v = t / QS, qq = t % QS;
     const int nn = by * BN + qq * 4;
     if (qq < QN && nn < p.Nout) {
       float4 a = red[v][0][qq];
 #pragma unroll 8
-      for (int r = 1; r < 32; ++r) a = f4add(a, red[v][r][qq]);
+      for (int r = 1; r < RL; ++r) a = f4add(a, red[v][r][qq]);
       st4(p.stats_part + (((long long)bx * kX3Fix + sub) * 2 + v) * p.Nout + nn, a);
     }
   }
@@ -761,12 +764,16 @@ struct X3Plan {
 };
 constexpr int kX3MinPart = 4;   // K chunks per stream-K part, at least
 
+#ifndef X3_MAX_NT
+#define X3_MAX_NT 9   // (-DX3_MAX_NT=8: probe builds, round 5's tiling)
+#endif
 static int x3_pick_nt(int Nout) {   // the widest column tile that does not pad the output width by much (as conv_gemm.hip: pick_nt, with a
                                     // stronger pull towards few column tiles)
   int best = 1;
   double best_cost = 1e30;
   const int tiles = (Nout + 15) / 16;
-  for (int nt = 1; nt <= 8; ++nt) {
+  for (int nt = 1; nt <= X3_MAX_NT; ++nt) {   // (9: the 136-column backward-data conv of the dilated branch as ONE column tile of 144 -- A loaded and split
+                                      //  once instead of once per 80-column tile: round 6)
     const int blocks = (tiles + nt - 1) / nt;
     const double cost = (double)(blocks * nt * 16) / (double)Nout * (1.0 + 0.08 * (8 - nt));   // (A is loaded AND split once per column tile)
     if (cost < best_cost - 1e-9 || (cost < best_cost + 1e-9 && nt > best)) {
@@ -835,7 +842,8 @@ static void x3_launch(const X3Plan& g, const X3Params& q_, float* slab, hipStrea
     case 5: L(5)
     case 6: L(6)
     case 7: L(7)
-    default: L(8)
+    case 8: L(8)
+    default: L(9)
   }
 #undef L
 }
