@@ -499,6 +499,10 @@ int mliis_adam_b1zero_fused(float* w, const float* g, float* v, const uint8_t* l
                             float l2, float l1, float beta2, float eps, float* step_dev, unsigned* step_ticket, hipStream_t stream);
 int mliis_axpby(float a, const float* x, float b, float* y, long long n, hipStream_t stream);
 int mliis_lincomb(float a, const float* x, float b, const float* y, float* out, long long n, hipStream_t stream);
+/*      dst[0..n) = src[0..n) (32-bit words, n <= 1024) by ONE small kernel: the upload of a step's batch indices out of pinned host
+ *      memory (src may be a device-visible HOST pointer).  A hipMemcpyAsync in its place runs on a copy engine: 4 us + a ~5 us engine
+ *      switch between two steps of the compute queue (profiles/r06_notes.md). */
+int mliis_copy_words(const void* src, void* dst, int n, hipStream_t stream);
 
 /* ---- weight-gradient producers (conv2d / dwconv / stem *_bwd_filter) called with dw == NULL leave their per-split slabs in
  *      `ws`; one mliis_fold_batched launch then folds all of them into the gradient arena.  desc: device int64 [ndesc][8] =

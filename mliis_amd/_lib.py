@@ -107,6 +107,7 @@ SIGNATURES = {
     "mliis_adam_b1zero_fused": (_i, [_p, _p, _p, _p, _ll, _f, _p, _f, _f, _f, _f, _p, _p, _p]),
     "mliis_axpby": (_i, [_f, _p, _f, _p, _ll, _p]),
     "mliis_lincomb": (_i, [_f, _p, _f, _p, _p, _ll, _p]),
+    "mliis_copy_words": (_i, [_p, _p, _i, _p]),
     "mliis_fold_batched": (_i, [_p, _p, _p, _i, _ll, _p, _i, _ll, _p]),
     "mliis_fold_tile_outputs": (_i, []),
     "mliis_graph_begin_capture": (_i, [_p]),

@@ -85,6 +85,11 @@ __global__ __launch_bounds__(256) void adam_b1zero_k(float* __restrict__ w, cons
   }
 }
 
+__global__ void copy_words_k(const unsigned* __restrict__ src, unsigned* __restrict__ dst, int n) {
+  const int i = threadIdx.x;
+  if (i < n) dst[i] = src[i];
+}
+
 // y = a * x + b * y   (x nullable when a == 0)
 __global__ __launch_bounds__(256) void axpby_k(float a, const float* __restrict__ x, float b, float* __restrict__ y, long long nquads) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nquads; i += (long long)gridDim.x * blockDim.x) {
@@ -148,6 +153,13 @@ int mliis_axpby(float a, const float* x, float b, float* y, long long n, hipStre
   MLIIS_REQUIRE(aligned16(x) && aligned16(y), MLIIS_ERR_ALIGN, "axpby: pointers must be 16-byte aligned");
   hipLaunchKernelGGL(axpby_k, dim3(flat_blocks(n / 4)), dim3(256), 0, stream, a, a == 0.f ? nullptr : x, b, y, n / 4);
   MLIIS_CHECK_LAUNCH("axpby");
+  return MLIIS_OK;
+}
+
+int mliis_copy_words(const void* src, void* dst, int n, hipStream_t stream) {
+  MLIIS_REQUIRE(src && dst && n > 0 && n <= 1024, MLIIS_ERR_ARG, "copy_words: 1..1024 words");
+  hipLaunchKernelGGL(copy_words_k, dim3(1), dim3(((n + 63) / 64) * 64), 0, stream, reinterpret_cast<const unsigned*>(src), reinterpret_cast<unsigned*>(dst), n);
+  MLIIS_CHECK_LAUNCH("copy_words");
   return MLIIS_OK;
 }
 

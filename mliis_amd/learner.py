@@ -99,6 +99,7 @@ class Learner(_Passes):
         self._idx_pin = torch.empty((16, 64), dtype=torch.int32).pin_memory()
         self._idx_ev = [None] * 16
         self._idx_n = 0
+        self._idx_by_kernel = os.environ.get("MLIIS_IDX_MEMCPY", "0") != "1"
         self.arena = Arena(self.arch, self.device)
         self.arena.init_weights(seed)
         self.variables_initialized = True
@@ -507,7 +508,10 @@ class Learner(_Passes):
                     self._idx_ev[slot] = torch.cuda.Event()
                 src = self._idx_pin[slot, :N]
                 src.copy_(torch.tensor(list(batch_idx), dtype=torch.int32))
-                P.idx.copy_(src, non_blocking=True)
+                if self._idx_by_kernel:    # one small kernel reading the pinned slot: no copy engine between two steps
+                    ops.copy_words(src, P.idx)
+                else:
+                    P.idx.copy_(src, non_blocking=True)
                 self._idx_ev[slot].record(self.stream)
             else:
                 P.idx.copy_(torch.tensor(list(batch_idx), dtype=torch.int32), non_blocking=True)

@@ -1089,5 +1089,10 @@ def axpby(a, x, b, y):
     lib.call("mliis_axpby", float(a), _ptr(x), float(b), _ptr(y), y.numel(), _stream())
 
 
+def copy_words(src, dst):
+    """dst <- src (<= 1024 32-bit words) by one small kernel on the current stream; src may be a pinned HOST tensor."""
+    lib.call("mliis_copy_words", C.c_void_p(src.data_ptr()), _ptr(dst), src.numel(), _stream())
+
+
 def lincomb(a, x, b, y, out):
     lib.call("mliis_lincomb", float(a), _ptr(x), float(b), _ptr(y), _ptr(out), out.numel(), _stream())
