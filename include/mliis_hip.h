@@ -264,6 +264,12 @@ int mliis_transpose_weights(const float* src, float* dst, const int* desc, int n
  *      shadows of the weight arena; total_tiles > 0 required */
 int mliis_weight_shadows(const float* src, float* dst, const int* desc, int ndesc, long long total_tiles, float* amax, void* x3_images,
                          const long long* x3_desc, int x3_ndesc, int x3_blocks, hipStream_t stream);
+/*      ... and mliis_rng_masks (the masks of the training step: same rng_state / job arrays) in the SAME launch -- the three launches a
+ *      step used to start with are one (x3_blocks may be 0: no weight images). */
+int mliis_weight_shadows_rng(const float* src, float* dst, const int* desc, int ndesc, long long total_tiles, float* amax, void* x3_images,
+                             const long long* x3_desc, int x3_ndesc, int x3_blocks, unsigned* rng_state, int njobs, float* const* outs,
+                             const long long* numels, const float* keep, const float* const* keeps, const int* row_len, const int* floor_form,
+                             hipStream_t stream);
 /*      gradient w.r.t. input channels [ci_begin, ci_begin+Cin_out) of a conv whose weight has Cin_total input channels */
 int mliis_conv2d_bwd_data(const float* dy, int lddy, const float* w, float* dx, int lddx, int Nimg, int H, int W, int Cin_total,
                           int ci_begin, int Cin_out, int Cout, int ksize, int dil, int accumulate, float* ws, size_t ws_floats,

@@ -61,6 +61,7 @@ SIGNATURES = {
     "mliis_rsd_pool_bwd": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _p]),
     "mliis_transpose_weights": (_i, [_p, _p, _p, _i, _ll, _p, _p]),
     "mliis_weight_shadows": (_i, [_p, _p, _p, _i, _ll, _p, _p, _p, _i, _i, _p]),
+    "mliis_weight_shadows_rng": (_i, [_p, _p, _p, _i, _ll, _p, _p, _p, _i, _i, _p, _i, _p, _p, _p, _p, _p, _p, _p]),
     "mliis_conv2d_bwd_data": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _i, _i, _i, _p]),
     "mliis_conv2d_bwd_data_bn": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _i, _p, _i, _p, _p, _p, _p, _sz, _p, _i, _i, _p]),
     "mliis_conv2d_bwd_data_gate": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _i, _p, _i, _p, _sz, _p, _i, _i, _p]),

@@ -19,6 +19,7 @@
 // Global loads are raw 16-byte buffer loads along C (128-byte spans per 8 lanes) whose offset is pushed out of range for padding
 // (the hardware returns zeros: no branches), software-pipelined two chunks deep through registers into double-buffered LDS.
 #include "conv_gemm_kernels.hpp"
+#include "rng_masks.hpp"
 
 namespace mliis {
 
@@ -115,9 +116,20 @@ struct X3PackArgs {
   const long long* desc;
   int ndesc, blocks, first_block;   // first_block = the transposes' tile count; blocks == 0: no images
 };
+// rng (mliis_weight_shadows_rng; flat form only): the workgroups behind the pack blocks draw the masks of the training step (rng.hip's
+// job table) -- the third launch every step starts with rides in the same grid.  blocks == 0: none.
+struct RngArgs {
+  unsigned* state;
+  MaskJobs jobs;
+  int blocks, first_block;
+};
 __global__ __launch_bounds__(256) void transpose_weights_k(const float* __restrict__ src, float* __restrict__ dst,
                                                            const int* __restrict__ desc, unsigned* __restrict__ amax_bits, int ndesc_flat,
-                                                           X3PackArgs x3) {
+                                                           X3PackArgs x3, RngArgs rng) {
+  if (rng.blocks > 0 && (int)blockIdx.x >= rng.first_block) {   // (uniform)
+    rng_masks_body(rng.state, rng.jobs, (int)blockIdx.x - rng.first_block, rng.blocks);
+    return;
+  }
   if (x3.blocks > 0 && (int)blockIdx.x >= x3.first_block) {   // (uniform)
     const int pb = ((int)blockIdx.x - x3.first_block) * 2 + (int)(threadIdx.x >> 7);
     if (pb < x3.blocks) x3_pack_block(src, x3.images, x3.desc, x3.ndesc, pb, (int)(threadIdx.x & 127));
@@ -877,7 +889,8 @@ static int conv2d_bwd_data_impl(const float* dy, int lddy, const float* w, float
 // total_tiles > 0: the sum over the descriptors of taps * ceil(Cin / 32) * ceil(Cout / 32) (the caller built the table, it knows):
 // one workgroup per tile.  0: a 224 x ndesc grid whose workgroups stride over their descriptor's tiles.
 static int weight_shadows(const char* name, const float* src, float* dst, const int* desc, int ndesc, long long total_tiles, float* amax,
-                          void* x3_images, const long long* x3_desc, int x3_ndesc, int x3_blocks, hipStream_t stream) {
+                          void* x3_images, const long long* x3_desc, int x3_ndesc, int x3_blocks, hipStream_t stream,
+                          const RngArgs* rng_in = nullptr) {
   MLIIS_REQUIRE(src && dst && desc && ndesc > 0 && total_tiles >= 0 && total_tiles < (1LL << 30), MLIIS_ERR_ARG, "%s: bad arguments", name);
   MLIIS_REQUIRE(x3_blocks == 0 || (total_tiles > 0 && x3_images && x3_desc && x3_ndesc >= 1 && x3_ndesc <= 64 && x3_blocks > 0 &&
                                    aligned16(src) && aligned16(x3_images) && aligned16(x3_desc)),
@@ -887,12 +900,18 @@ static int weight_shadows(const char* name, const float* src, float* dst, const 
     MLIIS_REQUIRE(e == hipSuccess, MLIIS_ERR_LAUNCH, "%s: memset failed: %s", name, hipGetErrorString(e));
   }
   const X3PackArgs x3{reinterpret_cast<char*>(x3_images), x3_desc, x3_ndesc, x3_blocks, (int)total_tiles};
+  RngArgs rng{};
+  if (rng_in != nullptr) {
+    MLIIS_REQUIRE(total_tiles > 0, MLIIS_ERR_ARG, "%s: the mask jobs need the one-tile-per-workgroup form", name);
+    rng = *rng_in;
+    rng.first_block = (int)total_tiles + (x3_blocks + 1) / 2;
+  }
   if (total_tiles > 0)
-    hipLaunchKernelGGL(transpose_weights_k, dim3((unsigned)(total_tiles + (x3_blocks + 1) / 2)), dim3(256), 0, stream, src, dst, desc,
-                       reinterpret_cast<unsigned*>(amax), ndesc, x3);
+    hipLaunchKernelGGL(transpose_weights_k, dim3((unsigned)(total_tiles + (x3_blocks + 1) / 2 + rng.blocks)), dim3(256), 0, stream, src, dst, desc,
+                       reinterpret_cast<unsigned*>(amax), ndesc, x3, rng);
   else
     hipLaunchKernelGGL(transpose_weights_k, dim3(224, ndesc), dim3(256), 0, stream, src, dst, desc, reinterpret_cast<unsigned*>(amax),
-                       0, x3);   // (the largest tensor has ~2000 tiles)
+                       0, x3, rng);   // (the largest tensor has ~2000 tiles)
   MLIIS_CHECK_LAUNCH(name);
   return MLIIS_OK;
 }
@@ -907,6 +926,19 @@ int mliis_weight_shadows(const float* src, float* dst, const int* desc, int ndes
                          const long long* x3_desc, int x3_ndesc, int x3_blocks, hipStream_t stream) {
   MLIIS_REQUIRE(x3_blocks > 0, MLIIS_ERR_ARG, "weight_shadows: no image blocks (use mliis_transpose_weights)");
   return weight_shadows("weight_shadows", src, dst, desc, ndesc, total_tiles, amax, x3_images, x3_desc, x3_ndesc, x3_blocks, stream);
+}
+
+// ... and the masks of the step (mliis_rng_masks, same arguments) in the same launch: x3_blocks may be 0 (no weight images).
+int mliis_weight_shadows_rng(const float* src, float* dst, const int* desc, int ndesc, long long total_tiles, float* amax, void* x3_images,
+                             const long long* x3_desc, int x3_ndesc, int x3_blocks, unsigned* rng_state, int njobs, float* const* outs,
+                             const long long* numels, const float* keep, const float* const* keeps, const int* row_len, const int* floor_form,
+                             hipStream_t stream) {
+  MLIIS_REQUIRE(rng_state, MLIIS_ERR_ARG, "weight_shadows_rng: null generator state");
+  RngArgs rng{};
+  rng.state = rng_state;
+  rng.blocks = rng_make_jobs("weight_shadows_rng", njobs, outs, numels, keep, keeps, row_len, floor_form, &rng.jobs);
+  if (rng.blocks < 0) return rng.blocks;
+  return weight_shadows("weight_shadows_rng", src, dst, desc, ndesc, total_tiles, amax, x3_images, x3_desc, x3_ndesc, x3_blocks, stream, &rng);
 }
 
 size_t mliis_conv2d_bwd_filter_workspace_floats(int Nimg, int H, int W, int Cin, int Cout, int ksize) {

@@ -467,8 +467,8 @@ class Learner(_Passes):
                                   ticket=self.adam_ticket)
 
     def _train_sequence(self, P: _Plan, draw_masks: bool):
-        if draw_masks and P.mask_plan is not None:
-            ops.rng_masks(self.rng_state, P.mask_plan)
+        # (the masks of the step are drawn by the launch that builds the weight shadows at the head of the forward pass: passes.py)
+        self._rng_now = (self.rng_state, P.mask_plan) if (draw_masks and P.mask_plan is not None) else None
         # Without the dice term (and DARC1, which reads the full-resolution logits) the tail of the step -- resize to the image size,
         # softmax cross-entropy, its gradient, the resize's transpose -- is ONE launch on the decoder's map (ops.head_ce_fused)
         hd_, H_ = self.arch.h_dec, self.arch.image_size

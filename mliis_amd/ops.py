@@ -346,10 +346,20 @@ def transpose_tiles(desc_rows):
     return int(sum(int(t) * ((int(ci) + 31) // 32) * ((int(co) + 31) // 32) for _, t, ci, co in desc_rows))
 
 
-def transpose_weights(src, dst, desc, amax=None, tiles=0, x3=None):
+def transpose_weights(src, dst, desc, amax=None, tiles=0, x3=None, rng=None):
     """dst <- HWOI copies of the dense-conv weights listed in desc (device int32 [n,4] = offset, taps, Cin, Cout); amax (optional,
     float [n]): also max |w| per tensor -- the fp8 operand scale.  tiles = transpose_tiles(rows of desc): one workgroup per 32 x 32
-    tile; 0: a fixed grid that strides over the tiles.  x3 (an X3Images over the same arena): its images are rebuilt too."""
+    tile; 0: a fixed grid that strides over the tiles.  x3 (an X3Images over the same arena): its images are rebuilt too.
+    rng = (generator state, MaskPlan): the masks of the training step are drawn by the same launch (rng_masks)."""
+    if rng is not None and tiles > 0:
+        st, plan = rng
+        has = x3 is not None and x3.desc is not None
+        lib.call("mliis_weight_shadows_rng", _ptr(src), _ptr(dst), _ptr(desc), int(desc.shape[0]), int(tiles), _ptr(amax),
+                 _ptr(x3.images) if has else None, _ptr(x3.desc) if has else None, len(x3.rows) if has else 0, x3.blocks if has else 0,
+                 _ptr(st), plan.n, plan.outs, plan.numels, plan.keep, plan.keeps, plan.row_len, plan.floor_form, _stream())
+        return
+    if rng is not None:
+        rng_masks(*rng)
     if x3 is not None and x3.desc is not None and tiles > 0:   # the split-product weight images ride in the same launch
         lib.call("mliis_weight_shadows", _ptr(src), _ptr(dst), _ptr(desc), int(desc.shape[0]), int(tiles), _ptr(amax), _ptr(x3.images), _ptr(x3.desc),
                  len(x3.rows), x3.blocks, _stream())

@@ -43,7 +43,9 @@ class _Passes:
             torch.rsqrt(mv[prefix + "/moving_variance"] + spec.BN_EPS, out=st[1])
             return ops.bn_apply(xin, st[0], st[1], w[prefix + "/gamma"], w[prefix + "/beta"], pre, post, img_scale, res, out=y)
 
-        ops.transpose_weights(A.theta, self.theta_t, self.wt_desc, self.w_amax, tiles=self.wt_tiles, x3=self.x3)
+        # (the weight shadows of the step and -- in a training step that draws its masks on the device -- the masks: ONE launch)
+        ops.transpose_weights(A.theta, self.theta_t, self.wt_desc, self.w_amax, tiles=self.wt_tiles, x3=self.x3, rng=getattr(self, "_rng_now", None))
+        self._rng_now = None
 
         def conv(xin, wname, bname, dil, out, swish_stats, x_scale=None, border_bias=None, out_block=0, part=None, bnin=None):
             """dense conv; in training the epilogue also emits the following BN's statistics (returns their block count) into

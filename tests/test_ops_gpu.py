@@ -1196,6 +1196,42 @@ def test_rng_masks_are_philox_and_advance_per_launch():
     assert 0.6 < (big == big2).float().mean().item() < 0.75     # P(agree) = 0.8^2 + 0.2^2 = 0.68 for independent streams
 
 
+def test_masks_drawn_by_the_weight_shadow_launch_equal_the_mask_launch():
+    """mliis_weight_shadows_rng (round 6: the masks of a training step ride in the launch that builds the weight shadows -- one launch less
+    per step): same masks and same generator state as mliis_rng_masks, same K-contiguous weight copies and split-product images as
+    mliis_weight_shadows, over three steps; with and without weight images; a mask tensor large enough for several mask workgroups."""
+    from mliis_amd import ops
+    d = dev()
+    theta = f32(rnd(3 * 3 * 40 * 48 + 1 * 1 * 48 * 24, seed=5), d)
+    rows = [[0, 9, 40, 48], [9 * 40 * 48, 1, 48, 24]]
+    desc = torch.tensor(rows, dtype=torch.int32, device=d)
+    tiles = ops.transpose_tiles(rows)
+
+    def images():
+        im = ops.X3Images(d)
+        im.add("w", "fwd", 0, 3, 40, 48)
+        im.add("w", "bwd", 0, 3, 40, 48)
+        return im.finish()
+    for with_images in (True, False):
+        sa, sb = ops.rng_state(77, d), ops.rng_state(77, d)
+        keeps = torch.tensor([0.9, 0.8], device=d)
+        ma, mb = [torch.zeros(2, 8, device=d), torch.zeros(5000, device=d)], [torch.zeros(2, 8, device=d), torch.zeros(5000, device=d)]
+        pa = ops.MaskPlan([(ma[0], keeps, 8, True), (ma[1], 0.5, 1, False)])
+        pb = ops.MaskPlan([(mb[0], keeps, 8, True), (mb[1], 0.5, 1, False)])
+        ta, tb = torch.zeros_like(theta), torch.zeros_like(theta)
+        xa, xb = (images(), images()) if with_images else (None, None)
+        for step in range(3):
+            ops.rng_masks(sa, pa)
+            ops.transpose_weights(theta, ta, desc, tiles=tiles, x3=xa)
+            ops.transpose_weights(theta, tb, desc, tiles=tiles, x3=xb, rng=(sb, pb))
+            torch.cuda.synchronize()
+            assert sb.cpu().tolist() == sa.cpu().tolist() and sa.cpu().tolist()[2:] == [step + 1, 0]
+            assert all(torch.equal(u, v) for u, v in zip(ma, mb)) and torch.equal(ta, tb)
+            if with_images:
+                assert torch.equal(xa.images, xb.images)
+        assert 0.45 < (ma[1] == 0).float().mean().item() < 0.55
+
+
 # ------------------------------------------------------------------------------------------------ fp8 (OCP e4m3) operands, 1x1 forward
 @pytest.mark.parametrize("H,Cin,Cout,N,gated", [(32, 24, 144, 2, False), (28, 240, 40, 2, True), (14, 672, 112, 2, True), (48, 40, 240, 2, False),
                                                 (14, 112, 672, 8, False)])
