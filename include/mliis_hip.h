@@ -465,6 +465,10 @@ int mliis_final_conv_fwd(const float* x, int ldx, const float* mask, const float
                          hipStream_t stream);
 int mliis_final_conv_bwd_data(const float* dy, const float* w, const float* mask, float* dx, int lddx, long long rows, int C,
                               hipStream_t stream);
+/*      ... with the loss fold of a mliis_head_ce_fused call that was given out == NULL riding in workgroup 0 (fin_ws = that call's
+ *      workspace, untouched since; N .. extra_loss as given there): one launch less between the head and the backward pass. */
+int mliis_final_conv_bwd_data_fin(const float* dy, const float* w, const float* mask, float* dx, int lddx, long long rows, int C, float* fin_ws,
+                                  int N, int Hd, int Wd, int H, int W, float extra_loss, float* out, hipStream_t stream);
 /*      workspace: mliis_colreduce_workspace_floats(rows, C, 1, 2) */
 int mliis_final_conv_bwd_filter(const float* x, int ldx, const float* mask, const float* dy, long long rows, int C, float* dw, float* db,
                                 float* ws, size_t ws_floats, hipStream_t stream);
@@ -479,7 +483,8 @@ int mliis_softmax_ce(const float* logits, const float* labels, const int* img_id
  *      resize (align_corners, efficientlab.py:166-173) of small [N,Hd,Wd,2] to [H,W]; per-pixel softmax cross-entropy with label
  *      smoothing (efficientlab.py:294-303) against labels [S,H,W,2] (through img_idx, nullable); dsmall = the gradient w.r.t. small --
  *      what mliis_resize_bilinear_fwd -> mliis_softmax_ce -> mliis_resize_bilinear_bwd compute, without writing the full-resolution
- *      logits and their gradient; out[0..2] = {loss + extra_loss, ce, iou}. */
+ *      logits and their gradient; out[0..2] = {loss + extra_loss, ce, iou}.  out == NULL: the second launch (the fold of the per-workgroup
+ *      loss partials in ws) is left to mliis_final_conv_bwd_data_fin -- ws must stay untouched until then. */
 int mliis_head_ce_fused_supported(int Hd, int Wd, int H, int W);   /* 1: up-sampling factor within the kernel's tile footprint (<= ~4.5) */
 size_t mliis_head_ce_fused_workspace_floats(int N, int Hd, int Wd);
 int mliis_head_ce_fused(const float* small, const float* labels, const int* img_idx, int N, int Hd, int Wd, int H, int W,

@@ -100,6 +100,7 @@ SIGNATURES = {
     "mliis_resize_bilinear_bwd": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "mliis_final_conv_fwd": (_i, [_p, _i, _p, _p, _p, _p, _ll, _i, _p]),
     "mliis_final_conv_bwd_data": (_i, [_p, _p, _p, _p, _i, _ll, _i, _p]),
+    "mliis_final_conv_bwd_data_fin": (_i, [_p, _p, _p, _p, _i, _ll, _i, _p, _i, _i, _i, _i, _i, _f, _p, _p]),
     "mliis_final_conv_bwd_filter": (_i, [_p, _i, _p, _p, _ll, _i, _p, _p, _p, _sz, _p]),
     "mliis_softmax_ce_workspace_floats": (_sz, [_i, _i, _i]),
     "mliis_softmax_ce": (_i, [_p, _p, _p, _i, _i, _i, _f, _i, _f, _p, _p, _p, _p, _sz, _p]),

@@ -156,9 +156,22 @@ __global__ __launch_bounds__(256) void final_conv_fwd_k(const float* __restrict_
   if (row < rows && part == 0) *reinterpret_cast<float2*>(y + row * 2) = make_float2(a0 + b[0], a1 + b[1]);
 }
 
+// fin_part != nullptr (mliis_final_conv_bwd_data_fin): workgroup 0 first folds the loss partials the fused head launch left behind
+// (ce_finalize: out[0..2] = {loss, ce, iou}) -- the fold needs nothing of this kernel and nothing of the step waits for it, so it
+// rides here instead of in a launch of its own between the head and the backward pass.
+struct CeFin {
+  const float* part;
+  int nblk, N, HW;
+  float extra_loss;
+  float* out;
+  float* coef;
+};
+__device__ __forceinline__ void ce_finalize(const float* __restrict__ part, int nblk, int N, int HW, int dice, float extra_loss, float* __restrict__ out,
+                                            float* __restrict__ coef);
 __global__ __launch_bounds__(256) void final_conv_bwd_data_k(const float* __restrict__ dy, const float* __restrict__ w,
                                                              const float* __restrict__ mask, float* __restrict__ dx, int lddx,
-                                                             long long rows, int C) {
+                                                             long long rows, int C, CeFin fin) {
+  if (fin.part != nullptr && blockIdx.x == 0) ce_finalize(fin.part, fin.nblk, fin.N, fin.HW, 0, fin.extra_loss, fin.out, fin.coef);   // (uniform)
   const int Q = C >> 2;
   const long long total = rows * Q;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -615,8 +628,24 @@ int mliis_final_conv_bwd_data(const float* dy, const float* w, const float* mask
   MLIIS_REQUIRE(dy && w && dx, MLIIS_ERR_ARG, "final_conv_bwd_data: null pointer");
   MLIIS_REQUIRE(rows > 0 && C > 0 && (C & 3) == 0 && (lddx & 3) == 0 && lddx >= C, MLIIS_ERR_ARG, "final_conv_bwd_data: bad shape");
   MLIIS_REQUIRE(aligned16(dx) && aligned16(mask) && aligned16(w), MLIIS_ERR_ALIGN, "final_conv_bwd_data: pointers must be 16-byte aligned");
-  hipLaunchKernelGGL(final_conv_bwd_data_k, dim3(ew_blocks(rows * (C / 4))), dim3(256), 0, stream, dy, w, mask, dx, lddx, rows, C);
+  hipLaunchKernelGGL(final_conv_bwd_data_k, dim3(ew_blocks(rows * (C / 4))), dim3(256), 0, stream, dy, w, mask, dx, lddx, rows, C, CeFin{});
   MLIIS_CHECK_LAUNCH("final_conv_bwd_data");
+  return MLIIS_OK;
+}
+
+static inline int head_tiles(int n);
+// mliis_final_conv_bwd_data + the loss fold of a mliis_head_ce_fused call that was given out == NULL: fin_ws = that call's workspace
+// (untouched since), (N, Hd, Wd, H, W, extra_loss) as given there; out[0..2] = {loss + extra_loss, ce, iou}.
+int mliis_final_conv_bwd_data_fin(const float* dy, const float* w, const float* mask, float* dx, int lddx, long long rows, int C, float* fin_ws,
+                                  int N, int Hd, int Wd, int H, int W, float extra_loss, float* out, hipStream_t stream) {
+  MLIIS_REQUIRE(dy && w && dx && fin_ws && out, MLIIS_ERR_ARG, "final_conv_bwd_data_fin: null pointer");
+  MLIIS_REQUIRE(rows > 0 && C > 0 && (C & 3) == 0 && (lddx & 3) == 0 && lddx >= C && N > 0 && Hd > 1 && Wd > 1 && H > 1 && W > 1, MLIIS_ERR_ARG,
+                "final_conv_bwd_data_fin: bad shape");
+  MLIIS_REQUIRE(aligned16(dx) && aligned16(mask) && aligned16(w) && aligned16(fin_ws), MLIIS_ERR_ALIGN, "final_conv_bwd_data_fin: pointers must be 16-byte aligned");
+  const int nblk = head_tiles(Hd) * head_tiles(Wd);
+  const CeFin fin{fin_ws, nblk, N, H * W, extra_loss, out, fin_ws + (size_t)N * nblk * 4};
+  hipLaunchKernelGGL(final_conv_bwd_data_k, dim3(ew_blocks(rows * (C / 4))), dim3(256), 0, stream, dy, w, mask, dx, lddx, rows, C, fin);
+  MLIIS_CHECK_LAUNCH("final_conv_bwd_data_fin");
   return MLIIS_OK;
 }
 
@@ -680,7 +709,7 @@ size_t mliis_head_ce_fused_workspace_floats(int N, int Hd, int Wd) {
 int mliis_head_ce_fused(const float* small, const float* labels, const int* img_idx, int N, int Hd, int Wd, int H, int W,
                         float label_smoothing, float extra_loss, float* dsmall, float* out, float* ws, size_t ws_floats,
                         hipStream_t stream) {
-  MLIIS_REQUIRE(small && labels && dsmall && out && ws, MLIIS_ERR_ARG, "head_ce_fused: null pointer");
+  MLIIS_REQUIRE(small && labels && dsmall && ws, MLIIS_ERR_ARG, "head_ce_fused: null pointer");
   MLIIS_REQUIRE(N > 0 && Hd > 1 && Wd > 1 && H > 1 && W > 1 && N <= 65535, MLIIS_ERR_ARG, "head_ce_fused: bad shape (both maps must be larger than 1x1)");
   MLIIS_REQUIRE(mliis_head_ce_fused_supported(Hd, Wd, H, W), MLIIS_ERR_UNSUPPORTED,
                 "head_ce_fused: up-sampling factor too large for the tile footprint (mliis_head_ce_fused_supported)");
@@ -695,6 +724,7 @@ int mliis_head_ce_fused(const float* small, const float* labels, const int* img_
   hipLaunchKernelGGL(head_ce_fused_k, dim3(nblk, N), dim3(256), 0, stream, small, labels, img_idx, N, Hd, Wd, H, W, sh, sw, label_smoothing,
                      1.0f / ((float)N * (float)H * (float)W), dsmall, ws, tx);
   MLIIS_CHECK_LAUNCH("head_ce_fused");
+  if (out == nullptr) return MLIIS_OK;   // (the loss fold is left to mliis_final_conv_bwd_data_fin, with ws untouched until then)
   hipLaunchKernelGGL(ce_finalize_k, dim3(1), dim3(256), 0, stream, ws, nblk, N, H * W, 0, extra_loss, out, coef);
   MLIIS_CHECK_LAUNCH("head_ce_fused_finalize");
   return MLIIS_OK;

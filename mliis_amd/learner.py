@@ -100,6 +100,7 @@ class Learner(_Passes):
         self._idx_ev = [None] * 16
         self._idx_n = 0
         self._idx_by_kernel = os.environ.get("MLIIS_IDX_MEMCPY", "0") != "1"
+        self.defer_loss_fold = os.environ.get("MLIIS_NO_DEFER_LOSS_FOLD", "0") != "1"
         self.arena = Arena(self.arch, self.device)
         self.arena.init_weights(seed)
         self.variables_initialized = True
@@ -474,9 +475,17 @@ class Learner(_Passes):
         hd_, H_ = self.arch.h_dec, self.arch.image_size
         head_fused = bool(self.fuse_head and not self.dice and not self.darc1 and lib.size("mliis_head_ce_fused_supported", hd_, hd_, H_, H_))
         logits = self._forward(P, self.shots_x, P.idx, True, upsample=not head_fused)
+        P.head_fin = None
         if head_fused:
             H = self.arch.image_size
-            ops.head_ce_fused(P.small, self.shots_y, P.idx, (H, H), self.label_smoothing, P.dsmall, P.loss_out, ws=self.ws)
+            if self.defer_loss_fold:   # ONE launch: the fold of the loss partials rides in the final conv's backward-data launch (passes.py)
+                if getattr(P, "head_ws", None) is None:
+                    P.head_ws = ops.Workspace(self.device, lib.size("mliis_head_ce_fused_workspace_floats", P.N, hd_, hd_))
+                _, _, buf = ops.head_ce_fused(P.small, self.shots_y, P.idx, (H, H), self.label_smoothing, P.dsmall, P.loss_out, ws=P.head_ws,
+                                              finalize=False)
+                P.head_fin = (buf, (H, H), 0.0, P.loss_out)
+            else:
+                ops.head_ce_fused(P.small, self.shots_y, P.idx, (H, H), self.label_smoothing, P.dsmall, P.loss_out, ws=self.ws)
         else:
             ops.softmax_ce(logits, self.shots_y, P.idx, self.label_smoothing, self.dice, 0.0, want_grad=True, want_pred=False,
                            dlogits=P.dlogits, out=P.loss_out, ws=self.ws)

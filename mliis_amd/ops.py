@@ -994,10 +994,17 @@ def final_conv_fwd(x, w, b, mask=None, out=None):
     return out
 
 
-def final_conv_bwd_data(dy, w, C_, mask=None, out=None):
+def final_conv_bwd_data(dy, w, C_, mask=None, out=None, fin=None):
+    """fin = (partials buffer of head_ce_fused(finalize=False), image size (H, W), extra_loss, loss_out): the loss fold rides in this launch."""
     rows = dy.numel() // 2
     out = torch.empty(tuple(dy.shape[:-1]) + (C_,), dtype=torch.float32, device=dy.device) if out is None else out
     _, _, lddx = rows_ld(out)
+    if fin is not None:
+        buf, size, extra_loss, loss_out = fin
+        N, Hd, Wd = dy.shape[:3]
+        lib.call("mliis_final_conv_bwd_data_fin", _ptr(dy), _ptr(w), _ptr(mask), _ptr(out), lddx, rows, C_, _ptr(buf), N, Hd, Wd, int(size[0]), int(size[1]),
+                 float(extra_loss), _ptr(loss_out), _stream())
+        return out
     lib.call("mliis_final_conv_bwd_data", _ptr(dy), _ptr(w), _ptr(mask), _ptr(out), lddx, rows, C_, _stream())
     return out
 
@@ -1028,15 +1035,17 @@ def softmax_ce(logits, labels, idx=None, label_smoothing=0.0, dice=False, extra_
     return out, dlogits, pred
 
 
-def head_ce_fused(small, labels, idx, size, label_smoothing, dsmall, out, extra_loss=0.0, ws: Optional[Workspace] = None):
+def head_ce_fused(small, labels, idx, size, label_smoothing, dsmall, out, extra_loss=0.0, ws: Optional[Workspace] = None, finalize=True):
     """resize(small -> size) -> softmax cross-entropy (no dice term) -> gradient -> resize^T: dsmall and out[0..2] = {loss, ce, iou};
-    the full-resolution logits are never written (two launches instead of five)."""
+    the full-resolution logits are never written (two launches instead of five).  finalize=False: ONE launch -- the loss partials stay
+    in the workspace buffer (returned third; nothing else may use it meanwhile) for final_conv_bwd_data(fin=...) to fold."""
     N, Hd, Wd, _ = small.shape
     ws = ws or default_ws()
     buf = ws.get(lib.size("mliis_head_ce_fused_workspace_floats", N, Hd, Wd))
     _timed("head_ce_fused", {}, lambda: lib.call("mliis_head_ce_fused", _ptr(_chk(small)), _ptr(labels), _ptr(idx), N, Hd, Wd, int(size[0]), int(size[1]),
-                                                 float(label_smoothing), float(extra_loss), _ptr(dsmall), _ptr(out), _ptr(buf), buf.numel(), _stream()))
-    return out, dsmall
+                                                 float(label_smoothing), float(extra_loss), _ptr(dsmall), _ptr(out) if finalize else None, _ptr(buf),
+                                                 buf.numel(), _stream()))
+    return (out, dsmall) if finalize else (out, dsmall, buf)
 
 
 def darc1(logits, weight, dlogits=None, out=None, ws: Optional[Workspace] = None):

@@ -335,7 +335,7 @@ class _Passes:
         has_grad = [False] * len(P.blocks)
         dtop = P.rsd[-1]["dout"] if P.rsd else (P.skipdec["dout"] if a.skipdec is not None else
                                                  (P.aspp["dout"] if a.aspp else P.blocks[-1]["dout"]))
-        ops.final_conv_bwd_data(P.dsmall, w[self.n_final[0]], a.c_final, mask, out=dtop)
+        ops.final_conv_bwd_data(P.dsmall, w[self.n_final[0]], a.c_final, mask, out=dtop, fin=getattr(P, "head_fin", None) if head_fused else None)
         if not P.rsd and not a.aspp and a.skipdec is None:
             has_grad[-1] = True
 
