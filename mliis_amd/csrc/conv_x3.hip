@@ -211,14 +211,22 @@ __device__ __forceinline__ void conv_x3_tile(const X3Params& q, char* __restrict
       }
 #pragma unroll
     for (int jn = 0; jn < NT; ++jn) {
+#if defined(X3_ABL) && (X3_ABL & 2)   // ablation: every column tile multiplies the FIRST tile's fragments (no further LDS reads)
+      if (jn + PF < NT && jn + PF < 2) {
+#else
       if (jn + PF < NT) {
+#endif
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) b3[(jn + PF) % (PF + 1)][pl] = *reinterpret_cast<const bf16x8*>(pb + (jn + PF) * kX3Block + pl * 1024);
       }
 #define X3_MM(PA, PB)                                                                                                           \
   acc[0][jn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3[PA][0], b3[jn % (PF + 1)][PB], acc[0][jn], 0, 0, 0);                \
   acc[1][jn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3[PA][1], b3[jn % (PF + 1)][PB], acc[1][jn], 0, 0, 0);
+#if defined(X3_ABL) && (X3_ABL & 1)   // ablation: one matrix instruction per accumulator instead of six
+      X3_MM(0, 0)
+#else
       X3_MM(2, 0) X3_MM(0, 2) X3_MM(1, 1) X3_MM(1, 0) X3_MM(0, 1) X3_MM(0, 0)
+#endif
 #undef X3_MM
 #pragma unroll
       for (int k = 0; k < 4; ++k)
@@ -267,9 +275,13 @@ __device__ __forceinline__ void conv_x3_tile(const X3Params& q, char* __restrict
   auto chunk = [&](char* cur, char* nxt, float4 (&rs)[2][2]) {   // rs: the registers holding A of the chunk after this one
     compute_split(cur, rs);
     X3_TICK(c_comp);
+#if !(defined(X3_ABL) && (X3_ABL & 8))   // (ablation 8: the B tile of the first chunks forever -- no B loads, no LDS stores)
     store_b(nxt);        // B of the next chunk (requested one chunk ago)
     load_b();            // B of the chunk after next
+#endif
+#if !(defined(X3_ABL) && (X3_ABL & 4))   // (ablation 4: the A registers of the prologue forever -- no A loads)
     load_a_into(rs);     // A two chunks after the one just split
+#endif
     X3_TICK(c_skel);
     lds_barrier();
     X3_TICK(c_bar);
