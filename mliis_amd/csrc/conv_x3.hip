@@ -593,7 +593,16 @@ __device__ __forceinline__ void conv_filter_x3_body(const FilterGradParams& p, c
   constexpr int NP = X_PER_THREAD + D_PER_THREAD;
   uint2 th[NP], tm[NP], tl[NP];
   auto split_piece = [&](int k, const float4 (&rx)[X_PER_THREAD], const float4 (&rd)[D_PER_THREAD]) {
+#ifdef F3_NOSPLIT   // ablation: the loads and the LDS stores of the staging, none of its arithmetic (wrong numbers)
+    {
+      const float4 v_ = k < X_PER_THREAD ? rx[k < X_PER_THREAD ? k : 0] : rd[k >= X_PER_THREAD ? k - X_PER_THREAD : 0];
+      th[k] = make_uint2(__float_as_uint(v_.x), __float_as_uint(v_.y));
+      tm[k] = make_uint2(__float_as_uint(v_.z), __float_as_uint(v_.w));
+      tl[k] = th[k];
+    }
+#else
     split3(k < X_PER_THREAD ? rx[k < X_PER_THREAD ? k : 0] : rd[k >= X_PER_THREAD ? k - X_PER_THREAD : 0], th[k], tm[k], tl[k]);
+#endif
     // (an empty statement that "uses" the piece here: without it the optimiser sinks the arithmetic to the stores behind the loop)
     asm volatile("" : "+v"(th[k].x), "+v"(th[k].y), "+v"(tm[k].x), "+v"(tm[k].y), "+v"(tl[k].x), "+v"(tl[k].y));
   };
