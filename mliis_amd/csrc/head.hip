@@ -130,6 +130,69 @@ __global__ __launch_bounds__(256) void resize_bwd_k(const float* __restrict__ dy
   *dst = acc;
 }
 
+// Separable form of the same transpose for wide tensors (C a multiple of 4): dx = Wy^T (dy Wx^T) per (image, input row hi, group of
+// 32 channels).  Phase 1 folds the candidate output rows of hi into ONE row t [Wo][32 channels] in LDS -- a thread owns (column, channel
+// quad), its candidate rows are loaded RB at a time (128-byte lines, all in flight); phase 2 folds the candidate columns of every
+// input column out of LDS.  An output row feeds two input rows, so dy crosses L2 ~2x instead of the ~7.5x of the gather form (a 4x
+// upsample), and the chain is one round of loads + one barrier.  Deterministic (fixed loop orders, no atomics).
+#ifndef RESIZE_BWD_ROWS
+#define RESIZE_BWD_ROWS 1   // 0: the gather form for every shape (A/B: tools/build_variants.sh)
+#endif
+constexpr int kResizeRowsThreads = 512;
+template <int RB>
+__global__ __launch_bounds__(kResizeRowsThreads) void resize_bwd_rows_k(const float* __restrict__ dy, int lddy, float* __restrict__ dx,
+                                                                         int lddx, int Hi, int Wi, int Ho, int Wo, int C, float sh,
+                                                                         float sw, int accumulate) {
+  extern __shared__ float4 rsz_t[];   // [Wo][8 quads]
+  const int cg = blockIdx.x, hi = blockIdx.y, n = blockIdx.z;
+  const int q = threadIdx.x & 7, lane_px = threadIdx.x >> 3;
+  const int c = cg * 32 + q * 4;
+  const bool cok = c < C;
+  int ho_lo = (int)floorf((float)(hi - 1) / sh) - 1, ho_hi = (int)ceilf((float)(hi + 1) / sh) + 1;
+  if (ho_lo < 0) ho_lo = 0;
+  if (ho_hi > Ho - 1) ho_hi = Ho - 1;
+  const float* base = dy + (long long)n * Ho * Wo * lddy + (cok ? c : 0);
+  for (int wo = lane_px; wo < Wo; wo += kResizeRowsThreads / 8) {
+    float4 acc = vzero<float4>();
+    for (int h0 = ho_lo; h0 <= ho_hi; h0 += RB) {
+      float4 v[RB];
+      float wy[RB];
+#pragma unroll
+      for (int u = 0; u < RB; ++u) {
+        const int ho = h0 + u <= ho_hi ? h0 + u : ho_hi;
+        int y0, y1;
+        float ly;
+        src_coord(ho, sh, Hi, y0, y1, ly);
+        const float w_ = (y0 == hi ? 1.f - ly : 0.f) + (y1 == hi ? ly : 0.f);
+        wy[u] = h0 + u <= ho_hi ? w_ : 0.f;
+        v[u] = ld4(base + ((long long)ho * Wo + wo) * lddy);
+      }
+#pragma unroll
+      for (int u = 0; u < RB; ++u) acc = vfma(wy[u], v[u], acc);
+    }
+    rsz_t[wo * 8 + q] = acc;
+  }
+  __syncthreads();
+  for (int wi = lane_px; wi < Wi; wi += kResizeRowsThreads / 8) {
+    int wo_lo = (int)floorf((float)(wi - 1) / sw) - 1, wo_hi = (int)ceilf((float)(wi + 1) / sw) + 1;
+    if (wo_lo < 0) wo_lo = 0;
+    if (wo_hi > Wo - 1) wo_hi = Wo - 1;
+    float4 acc = vzero<float4>();
+    for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+      int x0, x1;
+      float lx;
+      src_coord(wo, sw, Wi, x0, x1, lx);
+      const float wx = (x0 == wi ? 1.f - lx : 0.f) + (x1 == wi ? lx : 0.f);
+      acc = vfma(wx, rsz_t[wo * 8 + q], acc);
+    }
+    if (cok) {
+      float* dst = dx + (((long long)n * Hi + hi) * Wi + wi) * lddx + c;
+      if (accumulate) acc = f4add(acc, ld4(dst));
+      st4(dst, acc);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ final 1x1 conv, Cout = 2
 // 4 lanes per pixel, lanes interleave the channel quads (64 contiguous bytes per pixel per step), xor-shuffle reduce.
 __global__ __launch_bounds__(256) void final_conv_fwd_k(const float* __restrict__ x, int ldx, const float* __restrict__ mask,
@@ -600,6 +663,16 @@ int mliis_resize_bilinear_bwd(const float* dy, int lddy, float* dx, int lddx, in
                 "resize_bilinear_bwd: bad shape (input side must be > 1)");
   const float sh = (float)(Hi - 1) / (float)(Ho - 1), sw = (float)(Wi - 1) / (float)(Wo - 1);
   if ((C & 3) == 0 && (lddx & 3) == 0 && (lddy & 3) == 0 && aligned16(dx) && aligned16(dy)) {
+    if (RESIZE_BWD_ROWS && C >= 16 && Wo <= 512 && Hi <= 65535 && N <= 65535) {   // separable form: one workgroup per (32-channel group, input row, image)
+      const dim3 grid((unsigned)((C + 31) / 32), (unsigned)Hi, (unsigned)N);
+      const size_t lds = (size_t)Wo * 8 * sizeof(float4);
+      if (2.f / sh + 3.f > 4.f)
+        hipLaunchKernelGGL((resize_bwd_rows_k<12>), grid, dim3(kResizeRowsThreads), lds, stream, dy, lddy, dx, lddx, Hi, Wi, Ho, Wo, C, sh, sw, accumulate);
+      else
+        hipLaunchKernelGGL((resize_bwd_rows_k<4>), grid, dim3(kResizeRowsThreads), lds, stream, dy, lddy, dx, lddx, Hi, Wi, Ho, Wo, C, sh, sw, accumulate);
+      MLIIS_CHECK_LAUNCH("resize_bilinear_bwd");
+      return MLIIS_OK;
+    }
     long long q = (long long)N * Hi * Wi * (C / 4);
     hipLaunchKernelGGL((resize_bwd_k<4>), dim3((unsigned)((q * 8 + 255) / 256)), dim3(256), 0, stream, dy, lddy, dx, lddx, N, Hi, Wi, Ho, Wo, C, sh,
                        sw, accumulate, q);

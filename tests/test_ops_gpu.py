@@ -459,6 +459,32 @@ def test_resize(Hi, Wi, Ho, Wo, C):
     close(ops.resize_bilinear_bwd(f32(nhwc(dy), d), (Hi, Wi)), gx, 1e-4, "resize bwd")
 
 
+@pytest.mark.parametrize("Hi,Wi,Ho,Wo,C,pad", [(14, 14, 56, 56, 112, 24), (7, 9, 28, 28, 40, 0), (14, 14, 14, 14, 48, 8), (28, 28, 14, 14, 16, 0),
+                                               (5, 70, 9, 130, 36, 4)])
+def test_resize_bwd_separable_form_strided_and_accumulating(Hi, Wi, Ho, Wo, C, pad):
+    """The wide-channel resize transpose (resize_bwd_rows_k: per input row, candidate output rows folded into LDS, then the columns)
+    against float64 autograd: channel counts that are not a multiple of its 32-channel groups, gradient and target as channel slices of
+    wider tensors (leading dimension > C, as the decoder's concat gradient is), accumulation into an existing gradient, up- and
+    down-sampling, more output columns than the 64 pixel lanes of a workgroup."""
+    from mliis_amd import ops
+    d = dev()
+    x = rnd(2, Hi, Wi, C, seed=35).requires_grad_(True)
+    y = F.interpolate(nchw(x), size=(Ho, Wo), mode="bilinear", align_corners=True)
+    dy = rnd(*y.shape, seed=36)
+    (gx,) = torch.autograd.grad(y, [x], dy)
+    wide = torch.full((2, Ho, Wo, C + pad), float("nan"), device=d)
+    wide[..., :C] = f32(nhwc(dy), d)
+    prev = rnd(2, Hi, Wi, C, seed=37)
+    tgt = torch.full((2, Hi, Wi, C + pad), 7.0, device=d)
+    tgt[..., pad:] = f32(prev, d)
+    ops.resize_bilinear_bwd(wide[..., :C], (Hi, Wi), out=tgt[..., pad:], accumulate=True)
+    close(tgt[..., pad:], gx + prev, 1e-4, "resize bwd, accumulate, strided")
+    if pad:
+        assert (tgt[..., :pad] == 7.0).all(), "channels outside the slice are untouched"
+    ops.resize_bilinear_bwd(wide[..., :C], (Hi, Wi), out=tgt[..., pad:])
+    close(tgt[..., pad:], gx, 1e-4, "resize bwd, overwrite, strided")
+
+
 # ------------------------------------------------------------------------------------------------ final conv + loss
 @pytest.mark.parametrize("C,rows,use_mask", [(112, 300, False), (136, 77, True), (8, 5, True)])
 def test_final_conv(C, rows, use_mask):
