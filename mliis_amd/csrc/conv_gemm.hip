@@ -244,8 +244,12 @@ static inline GemmPlan plan_gemm(long long M, int Nout, int C, int ntaps, int nu
   g.gx = (int)((M + 64 * g.tm - 1) / (64 * g.tm));
   // small grids (14x14 / 28x28 maps) are latency-bound: narrower column tiles (down to 32 columns) until the grid holds
   // kGemmFill blocks per CU -> a shorter MFMA chain per block and often no split-K pass at all (measured +3 % on the whole step)
+  // (3x3 convs -- the 14x14 decoder level, K = 1008 / 2016 -- stop at 64 columns and split K instead: a 64 x 32 tile re-reads its A
+  //  chunk from LDS per 32 columns.  Round 6, same box, three alternations: floor 2: 20.5 us per launch, 3484 images/s; 4: 16.3 us + a
+  //  split-K fold on the two backward-data convs, 3498; 7 (no narrowing): 15.5 us but 12 us folds of eight slabs, 3481.)
+  const int min_nt = ntaps == 9 ? 4 : 2;
   if (g.tm == 1 && g.gx < num_cus)
-    while (g.nt > 2 && (long long)g.gx * g.gy < (long long)kGemmFill * num_cus) {
+    while (g.nt > min_nt && (long long)g.gx * g.gy < (long long)kGemmFill * num_cus) {
       g.nt = (g.nt + 1) / 2;
       g.gy = (Nout + g.nt * 16 - 1) / (g.nt * 16);
     }
@@ -369,11 +373,12 @@ static inline bool stream_plan(long long M, int K, int Nout, int num_cus, Stream
   // 4 -> 2447, 2 -> 2439 images/s: more column blocks = more waves in flight beats fewer re-reads of A.)
   int nt = 8 / sp->kc;
   if (nt < 1) nt = 1;
-  // NT <= 4: the instances with 5-8 column tiles need 153-199 VGPRs, so only ONE 512-thread workgroup fits a CU and the grid of two per
-  // CU ran in two rounds (stamps build, round 3: the second half of the waves of the 16 -> 96 expand conv started 6-13 us after the
-  // first; 23 us per launch).  Two column blocks of NT = 3 (102 VGPRs) are all resident at once.
-  if (nt > 4) nt = 4;
-  if (sp->kc == 2 && nt > 3) nt = 3;   // (<2, 4> spills 11 registers at that budget)
+  // (Round 3 capped NT at 4: the instances with 5-8 column tiles need 153-199 VGPRs, so only ONE 512-thread workgroup fits a CU and the
+  // grid of two per CU ran in two rounds -- stamps build: the second half of the waves of the 16 -> 96 expand conv started 6-13 us after
+  // the first; 23 us per launch.)
+  // Round 6, re-measured on the present kernels (same box, two alternations each, whole step): cap 1: 3496, 2: 3505, 3: 3486, 4: 3487,
+  // 8: 3455 images/s -- two column tiles per wave: more column blocks in flight, and a workgroup holds half the B fragments.
+  if (nt > 2) nt = 2;
   const int tiles = (Nout + 15) / 16;
   if (nt > tiles) nt = tiles;
   const int gy = (tiles + nt - 1) / nt;   // balanced column tiles: Nout = 144 -> 9 tiles -> 2 x NT 5 rather than NT 8 + a sliver
@@ -488,9 +493,11 @@ static inline bool ksplit_plan(long long M, int K, int Nout, int num_cus, Stream
   sp->nt = (tiles + gy - 1) / gy;
   sp->gy = gy;
   sp->row_groups = (int)((M + 15) / 16);
-  // two 512-thread workgroups per CU, ONE round (rounding up spills a few workgroups into a second); the KC = 7 instances need 132
-  // VGPRs: one workgroup per CU
-  long long gx = ((sp->kc >= 7 ? 1LL : 2LL) * num_cus) / gy;
+  // Workgroups (ONE round: rounding up would spill a few workgroups into a second): every workgroup loads the B slice of its column block into registers once, and on the small maps that is most of the
+  // launch's traffic (K = 672, 112 columns: 300 KB per workgroup against 4 MB of A in all) -- ONE workgroup per CU on the 28x28 / 14x14
+  // maps, two on the 56x56 ones.  Round 6, same box, whole step: two everywhere 3491, one everywhere 3507-3520, one up to 8192 rows
+  // 3526-3530; 0.75 / 0.5 per CU 3462 / 3381 images/s.  (The KC = 7 instances need 132 VGPRs: one workgroup per CU anyway.)
+  long long gx = ((sp->kc >= 7 || M <= 8192 ? 1LL : 2LL) * num_cus) / gy;
   if (gx < 1) gx = 1;
   if (gx > sp->row_groups) gx = sp->row_groups;
   sp->gx = (int)gx;

@@ -902,7 +902,8 @@ def test_swish_mask_fwd_bwd(pre_mask):
 
 
 @pytest.mark.parametrize("k,dil,H,W,Cin,Cout,N", [(1, 1, 14, 14, 40, 240, 2), (3, 2, 14, 14, 136, 112, 2), (1, 1, 56, 56, 136, 144, 4), (3, 1, 8, 8, 20, 16, 2),
-                                                  (1, 1, 14, 14, 480, 80, 8), (1, 1, 14, 14, 672, 112, 5), (1, 1, 28, 28, 240, 40, 2)])   # (conv1x1_ksplit_k, bf16 instances)
+                                                  (1, 1, 14, 14, 480, 80, 8), (1, 1, 14, 14, 672, 112, 5), (1, 1, 28, 28, 240, 40, 2),   # (conv1x1_ksplit_k, bf16 instances)
+                                                  (3, 1, 14, 14, 224, 112, 8), (3, 2, 16, 16, 136, 112, 8)])   # (the decoder's small-map 3x3 convs: 64-column tiles, split K -- forward and backward-data)
 def test_conv2d_bf16_operands(k, dil, H, W, Cin, Cout, N):
     """precision = MLIIS_PREC_BF16 (per call): bf16 operands on the matrix cores (v_mfma_f32_16x16x32_bf16), fp32 accumulation.  Exactly the fp32
     result of the bf16-ROUNDED operands up to accumulation order (tolerance 2e-5), i.e. within bf16 rounding (2^-9 relative per operand)

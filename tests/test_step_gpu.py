@@ -1019,9 +1019,14 @@ def test_config5_fp8_pointwise_operands_match_the_quantised_oracle(H, N, steps):
     weight scale from the on-device amax), bf16 operands everywhere else on the matrix cores, at the 64x64 test size over three steps
     (eager, captured, replayed) and at 384x384.  e4m3 has 3 mantissa bits and the fp8 MFMA aligns the products of a K block before adding
     (~2^-14): measured loss rel 3e-2 / 7e-3, gradient cosine 0.915 / 0.94 against the quantised oracle (0.79 / 0.82 against the exact
-    one) at 64 / 224 px.  (384, 8, 2): BASELINE configs[4] as one rank sees it -- 384x384 inputs at the inner batch of 8, two steps."""
+    one) at 64 / 224 px.  (384, 8, 2): BASELINE configs[4] as one rank sees it -- 384x384 inputs at the inner batch of 8, two steps.
+    Later steps: once a step has moved the weights, which e4m3 values the operands round to depends on the last bits of fp32 sums, and
+    the 64 px loss follows: with nothing changed but the fp32 SUMMATION ORDER of the decoder's 3x3 convs (four tilings of the same
+    kernel, round 6: first-step loss and gradient cosine identical to four digits) the second step's loss is 13.0 / 14.1 / 14.2 / 17.6 %
+    from the quantised oracle's.  The bound for the later steps is therefore 25 % -- a divergence check, not a parity claim; the
+    operands of those convs are checked exactly at the operator level (test_ops_gpu.py::test_conv2d_bf16_operands)."""
     _need_gpu()
-    _lowp_step_check("efficientnet-b0", H, N, "fp8", steps=steps, loss_tol=4e-2, cos_min=0.90, l2_max=0.5, later_loss_tol=0.15)
+    _lowp_step_check("efficientnet-b0", H, N, "fp8", steps=steps, loss_tol=4e-2, cos_min=0.90, l2_max=0.5, later_loss_tol=0.25)
 
 
 def test_inner_batch_of_32_images():
