@@ -63,6 +63,15 @@ const char* mliis_last_error(void);
  *      int32[N]) selects the batch images out of the S resident shots.  mean3 / std3 are HOST float[3]. */
 int mliis_stem_conv_fwd(const float* x, const int* img_idx, const float* w, float* z, int N, int H, int W, int Co,
                         const float* mean3, const float* std3, hipStream_t stream);
+/*      mliis_stem_conv_fwd_stats: the same conv (z bit-identical) from a row-strip kernel that stages and normalises every input value
+ *      once, plus the stage-1 statistics of z for the batch norm that follows (efficientnet_model.py:411-413): stats_part (nullable)
+ *      [*nblk][2][Co] = {sum, sum of squares} per workgroup -- the layout of mliis_bn_stats_partial, at most ~256 blocks; capacity from
+ *      mliis_stem_conv_fwd_stats_floats.  MLIIS_ERR_UNSUPPORTED (nothing launched) when a row's staging window does not fit LDS
+ *      (W > ~400): take mliis_stem_conv_fwd + mliis_bn_stats_partial then. */
+size_t mliis_stem_conv_fwd_stats_floats(int N, int H, int W, int Co);
+int mliis_stem_conv_fwd_stats(const float* x, const int* img_idx, const float* w, float* z, int N, int H, int W, int Co,
+                              const float* mean3, const float* std3, float* stats_part, size_t stats_floats, int* nblk,
+                              hipStream_t stream);
 size_t mliis_stem_conv_bwd_filter_workspace_floats(int N, int H, int W, int Co);
 int mliis_stem_conv_bwd_filter(const float* x, const int* img_idx, const float* dz, float* dw, int N, int H, int W, int Co,
                                const float* mean3, const float* std3, float* ws, size_t ws_floats, hipStream_t stream);

@@ -24,6 +24,8 @@ SIGNATURES = {
     "mliis_version": (_i, []),
     "mliis_last_error": (C.c_char_p, []),
     "mliis_stem_conv_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p]),
+    "mliis_stem_conv_fwd_stats_floats": (_sz, [_i, _i, _i, _i]),
+    "mliis_stem_conv_fwd_stats": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _sz, _p, _p]),
     "mliis_stem_conv_bwd_filter_workspace_floats": (_sz, [_i, _i, _i, _i]),
     "mliis_stem_conv_bwd_filter": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _sz, _p]),
     "mliis_dwconv_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _sz, _p, _p]),

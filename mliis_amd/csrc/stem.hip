@@ -93,6 +93,97 @@ __global__ __launch_bounds__(256) void stem_fwd_k(const float* __restrict__ x, c
   st4(dst + 4, make_float4(acc[4], acc[5], acc[6], acc[7]));
 }
 
+// Row-strip form with the NEXT batch norm's stage-1 statistics (round 6).  stem_fwd_k gives every (pixel, channel octet) thread its own
+// 27 loads and 27 divisions -- each input value is fetched and normalised ~2.25 x Co / 8 times -- and the statistics of z were a launch
+// of their own over the 12.8 MB it had just written.  Here a workgroup owns (image, a run of output rows) and walks it four output rows
+// at a time: the nine input rows under them are fetched once (contiguous 4-byte lanes), normalised once and staged in LDS with the
+// zero padding in place; thread = (pixel lane, channel octet) as before, the window comes from LDS (same fma order: z is bit-identical
+// to stem_fwd_k's), and the thread keeps sum / sum of squares of its octet, folded through LDS in lane order at the end:
+// part [workgroup][2][Co], the layout of mliis_bn_stats_partial.  At most ~256 workgroups (= partial blocks the consumer folds).
+constexpr int kStemRows = 4;        // output rows per staging round
+constexpr int kStemRowsThreads = 512;
+__global__ __launch_bounds__(kStemRowsThreads) void stem_fwd_rows_k(const float* __restrict__ x, const int* __restrict__ idx,
+                                                                    const float* __restrict__ w, float* __restrict__ z, int H, int W,
+                                                                    int Ho, int Wo, int Co, int pt, int pl, Norm3 nm,
+                                                                    int rows_per_block, int blocks_per_img, float* __restrict__ part) {
+  extern __shared__ float sdyn[];
+  constexpr int NT = kStemRowsThreads;
+  const int IW = 2 * Wo + 1, IR = 2 * kStemRows + 1;
+  float* sx = sdyn;                        // [IR][IW][3] normalised, zero outside the image
+  float* red = sx + IR * IW * 3;           // [NT][8]
+  const int t = threadIdx.x;
+  const int n = blockIdx.x / blocks_per_img, chunk = blockIdx.x - n * blocks_per_img;
+  const int src = idx ? idx[n] : n;
+  const float* img = x + (long long)src * H * W * 3;
+  const int Q = Co >> 2, TPW = NT / Q;               // channel quads per pixel, pixel lanes
+  const bool live = t < TPW * Q;
+  const int quad = live ? t % Q : 0, lane_px = t / Q;
+  float4 wr[27];                                     // the thread's 27 x 4 weights stay in registers for the whole strip
+#pragma unroll
+  for (int k = 0; k < 27; ++k) wr[k] = ld4(w + k * Co + quad * 4);
+  const int ho_end = (chunk + 1) * rows_per_block < Ho ? (chunk + 1) * rows_per_block : Ho;
+  float4 s1 = f4zero(), s2 = f4zero();
+  for (int ho0 = chunk * rows_per_block; ho0 < ho_end; ho0 += kStemRows) {
+    if (ho0 != chunk * rows_per_block) __syncthreads();   // the previous round's window reads are done
+    const int hi0 = ho0 * 2 - pt;
+    constexpr int FB = 12;   // loads of a thread in flight per round trip (a plain loop waits for every value before it asks for the next)
+    for (int e0 = t; e0 < IR * IW * 3; e0 += NT * FB) {
+      float raw[FB];
+      int chs[FB];
+      bool oks[FB];
+#pragma unroll
+      for (int u = 0; u < FB; ++u) {
+        const int e = e0 + u * NT;
+        const int r = e / (IW * 3), rem = e - r * (IW * 3);
+        const int col = rem / 3, ch = rem - col * 3;
+        const int hi = hi0 + r, wi = col - pl;
+        oks[u] = e < IR * IW * 3 && hi >= 0 && hi < H && wi >= 0 && wi < W;
+        chs[u] = ch;
+        raw[u] = img[oks[u] ? ((long long)hi * W + wi) * 3 + ch : 0];
+      }
+#pragma unroll
+      for (int u = 0; u < FB; ++u) {
+        const int e = e0 + u * NT;
+        const float m = chs[u] == 0 ? nm.m0 : (chs[u] == 1 ? nm.m1 : nm.m2), sd = chs[u] == 0 ? nm.i0 : (chs[u] == 1 ? nm.i1 : nm.i2);
+        if (e < IR * IW * 3) sx[e] = oks[u] ? (raw[u] - m) / sd : 0.f;   // (a true division, as stem_fwd_k: within 1 ulp of TF's)
+      }
+    }
+    __syncthreads();
+    const int npix = (ho_end - ho0 < kStemRows ? ho_end - ho0 : kStemRows) * Wo;
+    if (live)
+      for (int p = lane_px; p < npix; p += TPW) {
+        const int ro = p / Wo, wo = p - ro * Wo;
+        float4 acc = f4zero();
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+          const float* row = sx + ((ro * 2 + ky) * IW + wo * 2) * 3;
+#pragma unroll
+          for (int q = 0; q < 9; ++q) {
+            const float v = row[q];
+            const float4 wk = wr[ky * 9 + q];
+            acc.x = fmaf(v, wk.x, acc.x);
+            acc.y = fmaf(v, wk.y, acc.y);
+            acc.z = fmaf(v, wk.z, acc.z);
+            acc.w = fmaf(v, wk.w, acc.w);
+          }
+        }
+        st4(z + (((long long)n * Ho + ho0 + ro) * Wo + wo) * Co + quad * 4, acc);
+        s1 = f4add(s1, acc);
+        s2 = f4fma(acc, acc, s2);
+      }
+  }
+  if (part == nullptr) return;   // (uniform)
+  st4(red + t * 8, s1);
+  st4(red + t * 8 + 4, s2);
+  __syncthreads();
+  if (t < Q * 8) {   // the pixel lanes in lane order (deterministic)
+    const int o = t >> 3, j = t & 7;
+    float a = 0.f;
+    for (int l = 0; l < TPW; ++l) a += red[(l * Q + o) * 8 + j];
+    part[((long long)blockIdx.x * 2 + (j >> 2)) * Co + o * 4 + (j & 3)] = a;
+  }
+}
+
 // thread = (pixel lane, channel quad): 27 x float4 accumulators.  The block walks its pixels PL at a time: the 27 normalised window
 // values of those PL pixels are fetched ONCE, cooperatively, into LDS (instead of once per channel-quad thread) and every thread
 // reads its pixel's window from there (8-way broadcast, conflict-free stride 27).  Block reduction: butterfly over the pixel lanes
@@ -292,6 +383,46 @@ int mliis_stem_conv_fwd(const float* x, const int* img_idx, const float* w, floa
   hipLaunchKernelGGL(stem_fwd_k, dim3(ceil_div(total, 256)), dim3(256), 27 * Co * sizeof(float), stream, x, img_idx, w, z, N, H, W,
                      g.Ho, g.Wo, Co, g.pt, g.pl, nm);
   MLIIS_CHECK_LAUNCH("stem_conv_fwd");
+  return MLIIS_OK;
+}
+
+// The same conv with the stage-1 statistics of z ({sum, sum of squares} per workgroup, [*nblk][2][Co]: what mliis_bn_stats_partial(z)
+// would produce in a second launch) for the batch norm that follows.  stats_part == NULL: no statistics (z only, *nblk = 0).
+// MLIIS_ERR_UNSUPPORTED (nothing launched) when the staging window of a row does not fit LDS (W > ~400): the caller then takes
+// mliis_stem_conv_fwd + mliis_bn_stats_partial.
+static void stem_rows_geom(int N, int Ho, int* rows_per_block, int* blocks_per_img) {
+  const int groups = (Ho + kStemRows - 1) / kStemRows;
+  long long g = ((long long)N * groups + 255) / 256;   // staging rounds per workgroup so that the grid stays near 256 workgroups
+  if (g < 1) g = 1;
+  *rows_per_block = (int)g * kStemRows;
+  *blocks_per_img = (Ho + *rows_per_block - 1) / *rows_per_block;
+}
+static size_t stem_rows_lds(int Wo, int Co) { return ((size_t)(2 * kStemRows + 1) * (2 * Wo + 1) * 3 + kStemRowsThreads * 8) * sizeof(float); }
+
+size_t mliis_stem_conv_fwd_stats_floats(int N, int H, int W, int Co) {
+  if (N <= 0 || H <= 1 || W <= 1 || Co <= 0) return 0;
+  int rpb, bpi;
+  stem_rows_geom(N, (H + 1) / 2, &rpb, &bpi);
+  return (size_t)N * bpi * 2 * Co;
+}
+
+int mliis_stem_conv_fwd_stats(const float* x, const int* img_idx, const float* w, float* z, int N, int H, int W, int Co, const float* mean3,
+                              const float* std3, float* stats_part, size_t stats_floats, int* nblk, hipStream_t stream) {
+  MLIIS_REQUIRE(x && w && z && mean3 && std3, MLIIS_ERR_ARG, "stem_conv_fwd_stats: null pointer");
+  MLIIS_REQUIRE(N > 0 && H > 1 && W > 1 && Co > 0 && (Co & 7) == 0 && Co <= 256, MLIIS_ERR_ARG, "stem_conv_fwd_stats: bad shape (Co %% 8 == 0 required)");
+  MLIIS_REQUIRE(aligned16(w), MLIIS_ERR_ALIGN, "stem_conv_fwd_stats: weights must be 16-byte aligned");
+  MLIIS_REQUIRE(aligned16(z), MLIIS_ERR_ALIGN, "stem_conv_fwd_stats: output must be 16-byte aligned");
+  StemGeom g = stem_geom(H, W);
+  const size_t lds = stem_rows_lds(g.Wo, Co);
+  MLIIS_REQUIRE(lds <= 64 * 1024, MLIIS_ERR_UNSUPPORTED, "stem_conv_fwd_stats: the staging window of a %d-pixel row does not fit LDS", W);
+  int rpb, bpi;
+  stem_rows_geom(N, g.Ho, &rpb, &bpi);
+  MLIIS_REQUIRE(stats_part == nullptr || (size_t)N * bpi * 2 * Co <= stats_floats, MLIIS_ERR_WORKSPACE, "stem_conv_fwd_stats: statistics buffer too small");
+  Norm3 nm{mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]};
+  hipLaunchKernelGGL(stem_fwd_rows_k, dim3((unsigned)(N * bpi)), dim3(kStemRowsThreads), lds, stream, x, img_idx, w, z, H, W, g.Ho, g.Wo, Co, g.pt, g.pl, nm, rpb,
+                     bpi, stats_part);
+  MLIIS_CHECK_LAUNCH("stem_conv_fwd_stats");
+  if (nblk) *nblk = stats_part != nullptr ? N * bpi : 0;
   return MLIIS_OK;
 }
 

@@ -100,6 +100,7 @@ class Learner(_Passes):
         self._idx_ev = [None] * 16
         self._idx_n = 0
         self._idx_by_kernel = os.environ.get("MLIIS_IDX_MEMCPY", "0") != "1"
+        self.stem_stats = os.environ.get("MLIIS_STEM_STATS", "1") != "0"   # the stem conv's launch also emits its batch norm's stage-1 sums
         self.defer_loss_fold = os.environ.get("MLIIS_NO_DEFER_LOSS_FOLD", "0") != "1"
         self.arena = Arena(self.arch, self.device)
         self.arena.init_weights(seed)

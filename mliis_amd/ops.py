@@ -151,14 +151,35 @@ def rows_ld(t: torch.Tensor) -> Tuple[int, int, int]:
 
 
 # ------------------------------------------------------------------------------------------------ stem
-def stem_conv_fwd(x, w, idx=None, out=None):
+def stem_conv_fwd(x, w, idx=None, out=None, stats_part=None, rows=None):
+    """With stats_part (a float buffer, or rows=True for the same kernel without statistics): the row-strip kernel, z bit-identical,
+    returns (out, nblk) -- nblk stage-1 partial blocks [nblk][2][Co] of z for the batch norm that follows; nblk == -1: the shape does
+    not fit that kernel (rows wider than ~400 pixels), z comes from the plain kernel and the caller takes bn_stats_partial."""
     S, H, W, _ = x.shape
     N = S if idx is None else idx.numel()
     Co = w.shape[-1]
     Ho, Wo = (H + 1) // 2, (W + 1) // 2
     out = torch.empty((N, Ho, Wo, Co), dtype=torch.float32, device=x.device) if out is None else out
+    if stats_part is not None or rows:
+        nblk = C.c_int(0)
+        if stem_conv_fwd_stats_fits(N, H, W, Co):
+            lib.call("mliis_stem_conv_fwd_stats", _ptr(_chk(x)), _ptr(idx), _ptr(w), _ptr(out), N, H, W, Co, _MEAN3, _STD3, _ptr(stats_part),
+                     stats_part.numel() if stats_part is not None else 0, C.byref(nblk), _stream())
+            return out, nblk.value
+        lib.call("mliis_stem_conv_fwd", _ptr(_chk(x)), _ptr(idx), _ptr(w), _ptr(out), N, H, W, Co, _MEAN3, _STD3, _stream())
+        return out, -1
     lib.call("mliis_stem_conv_fwd", _ptr(_chk(x)), _ptr(idx), _ptr(w), _ptr(out), N, H, W, Co, _MEAN3, _STD3, _stream())
     return out
+
+
+def stem_conv_fwd_stats_fits(N, H, W, Co):
+    """whether mliis_stem_conv_fwd_stats takes this shape (its staging window: 9 input rows of 2 * ceil(W / 2) + 1 pixels, in LDS)"""
+    Wo = (W + 1) // 2
+    return (9 * (2 * Wo + 1) * 3 + 512 * 8) * 4 <= 64 * 1024
+
+
+def stem_conv_fwd_stats_floats(N, H, W, Co):
+    return lib.size("mliis_stem_conv_fwd_stats_floats", N, H, W, Co)
 
 
 def stem_conv_bwd_filter(x, dz, idx=None, out=None, ws: Optional[Workspace] = None, partial=None):

@@ -74,13 +74,19 @@ class _Passes:
                            border_bias=border_bias, fp8_w_amax=am)
             return 0
 
-        ops.stem_conv_fwd(x, w[self.n_stem[0]], idx, out=P.z_stem)
+        # training: the stem conv's launch also leaves the stage-1 statistics of its batch norm (row-strip kernel; -1: the rows are too
+        # wide for it -- the plain kernel ran and the consumer takes the statistics launch); MLIIS_STEM_STATS=0: always the two launches
+        nb_stem = 0
+        if training and self.stem_stats:
+            nb_stem = max(0, ops.stem_conv_fwd(x, w[self.n_stem[0]], idx, out=P.z_stem, stats_part=P.stats_part)[1])
+        else:
+            ops.stem_conv_fwd(x, w[self.n_stem[0]], idx, out=P.z_stem)
         ex = [b for b in a.blocks if b.executed]
         fuse_stem = P.fuse_stem   # (block 0 takes the stem's BN + swish into its depthwise launch: _Plan)
         if fuse_stem:
             cur = None
         else:
-            cur = bn(P.z_stem, P.st_stem, self.n_stem[1], P.a_stem, post=True)
+            cur = bn(P.z_stem, P.st_stem, self.n_stem[1], P.a_stem, post=True, nblk=nb_stem)
 
         def bn_in(z, st, prefix, nblk):
             """The batch norm in front of a marching depthwise launch: (bn tuple, nblk) for ops.dwconv_bn_fwd.  Training: the launch
@@ -144,7 +150,7 @@ class _Passes:
                     bn0, nb = bn_in(B["z0"], B["st0"], nm["bn0"], nb)
                     zin = B["z0"]
                 elif bi_ == 0 and fuse_stem:
-                    bn0, nb = bn_in(P.z_stem, P.st_stem, self.n_stem[1], 0)
+                    bn0, nb = bn_in(P.z_stem, P.st_stem, self.n_stem[1], nb_stem)
                     zin = P.z_stem
                 else:
                     bn0, nb, zin = None, 0, t

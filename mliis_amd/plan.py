@@ -138,7 +138,7 @@ class _Plan:
             rows = N * a.skipdec.h ** 2
             for c in (a.skipdec.c_skip, a.skipdec.c_cat, a.skipdec.c_sep):
                 need = max(need, -(-rows // 16) * 2 * c, ops.bn_stats_partial_floats(rows, c))
-        need = max(need, ops.bn_stats_partial_floats(N * hs * hs, a.stem_out))
+        need = max(need, ops.bn_stats_partial_floats(N * hs * hs, a.stem_out), ops.stem_conv_fwd_stats_floats(N, H, H, a.stem_out))
         self.stats_part = buf(need + 64)
         # the row-marching depthwise kernels (ops.dwconv_bn_fwd / _bwd) READ the producer's partial sums from stats_part while other
         # workgroups of the same launch already WRITE theirs: a second buffer

@@ -168,8 +168,37 @@ def test_stem(H, W, Co):
     dz = rnd(*z.shape, seed=13)
     (gw,) = torch.autograd.grad(z, [w], dz)
     ig = torch.tensor(idx, dtype=torch.int32, device=d)
-    close(ops.stem_conv_fwd(f32(x, d), f32(w, d), ig), nhwc(z), 2e-5, "stem fwd")
+    zd = ops.stem_conv_fwd(f32(x, d), f32(w, d), ig)
+    close(zd, nhwc(z), 2e-5, "stem fwd")
     close(ops.stem_conv_bwd_filter(f32(x, d), f32(nhwc(dz), d), ig), gw, 1e-4, "stem bwd filter")
+    # the row-strip kernel (a training step's stem launch): z bit-identical to the plain kernel's, and the stage-1 statistics of z
+    # ([nblk][2][Co] partial sums / sums of squares) fold to the sums of that z
+    part = torch.full((ops.stem_conv_fwd_stats_floats(len(idx), H, W, Co) + 8,), float("nan"), device=d)
+    z2, nblk = ops.stem_conv_fwd(f32(x, d), f32(w, d), ig, stats_part=part)
+    assert nblk > 0 and nblk * 2 * Co <= part.numel() - 8 and torch.isnan(part[nblk * 2 * Co:]).all()
+    assert torch.equal(z2, zd), "row-strip stem kernel differs from the plain one"
+    folded = part[:nblk * 2 * Co].view(nblk, 2, Co).double().sum(0).cpu()
+    zz = zd.double().cpu().reshape(-1, Co)
+    close(folded[0], zz.sum(0), 1e-5, "stem statistics: sum")
+    close(folded[1], (zz * zz).sum(0), 1e-5, "stem statistics: sum of squares")
+    z3, nb3 = ops.stem_conv_fwd(f32(x, d), f32(w, d), ig, rows=True)
+    assert nb3 == 0 and torch.equal(z3, zd)
+
+
+def test_stem_rows_wider_than_the_staging_window_take_the_plain_kernel():
+    """mliis_stem_conv_fwd_stats stages nine input rows in LDS: rows wider than ~400 pixels do not fit -- the C entry refuses (nothing
+    launched), the wrapper runs the plain kernel and reports -1 so that the caller takes the statistics launch."""
+    import ctypes as C
+    from mliis_amd import ops
+    d = dev()
+    x = torch.randint(0, 256, (1, 6, 900, 3), generator=torch.Generator().manual_seed(3)).float().to(d)
+    w = f32(rnd(3, 3, 3, 32, seed=12), d)
+    part = torch.zeros(ops.stem_conv_fwd_stats_floats(1, 6, 900, 32) + 8, device=d)
+    z, nblk = ops.stem_conv_fwd(x, w, None, stats_part=part)
+    assert nblk == -1 and torch.equal(z, ops.stem_conv_fwd(x, w, None))
+    with pytest.raises(Exception):
+        ops.lib.call("mliis_stem_conv_fwd_stats", C.c_void_p(x.data_ptr()), None, C.c_void_p(w.data_ptr()), C.c_void_p(z.data_ptr()), 1, 6, 900, 32,
+                     ops._MEAN3, ops._STD3, C.c_void_p(part.data_ptr()), part.numel(), None, C.c_void_p(torch.cuda.current_stream().cuda_stream))
 
 
 # ------------------------------------------------------------------------------------------------ batch norm
