@@ -860,7 +860,10 @@ static inline int dwm_target(bool bwd) {
     g_dwm_target = e ? atoi(e) : 0;
     if (g_dwm_target < 0) g_dwm_target = 0;
   }
-  return g_dwm_target ? g_dwm_target : 256;   // (forward: 256 and 512 time the same; 256 leaves the next batch norm half the partial blocks)
+  // (forward, cold, op by op: 256 and 512 time the same.  In the step -- round 6, same box, three alternations, the consumer's fold of
+  //  the partial blocks included: 192: 3528, 256: 3537-3540, 320: 3534, 384: 3538, 448: 3545-3547, 512: 3532-3543, 640+: 3530-3535
+  //  images/s; backward 192 / 224 / 256 / 320 / 512: 3507 / 3511 / 3537 / 3497 / 3506.)
+  return g_dwm_target ? g_dwm_target : (bwd ? 256 : 448);
 }
 
 // produced extent P x Q (rows x columns); unit = produced rows per step; bmax = produced columns of a band (multiple of ts)
