@@ -453,7 +453,7 @@ int mliis_conv1x1_occupancy(int kind, int kc, int nt, int* blocks_per_cu) {
 #define KS(KC_, NT_) if (kind == 1 && kc == KC_ && nt == NT_) fn = reinterpret_cast<const void*>(&conv1x1_ksplit_k<KC_, NT_, 8, 0>);
   ST(1, 1) ST(1, 2) ST(1, 3) ST(1, 4) ST(2, 1) ST(2, 2) ST(2, 3) ST(3, 1) ST(3, 2) ST(4, 1) ST(4, 2) ST(5, 1) ST(6, 1) ST(7, 1)
   KS(1, 1) KS(1, 2) KS(1, 3) KS(1, 4) KS(1, 5) KS(1, 6) KS(1, 7) KS(2, 1) KS(2, 2) KS(2, 3) KS(2, 4) KS(3, 1) KS(3, 2) KS(4, 1) KS(4, 2)
-  KS(5, 1) KS(6, 1) KS(7, 1)
+  KS(5, 1) KS(6, 1) KS(7, 1) KS(4, 3) KS(5, 2) KS(6, 2)
 #undef ST
 #undef KS
   MLIIS_REQUIRE(fn != nullptr, MLIIS_ERR_ARG, "conv1x1_occupancy: no instance kind %d <%d, %d>", kind, kc, nt);
@@ -484,7 +484,11 @@ static const bool kKsplit = getenv("MLIIS_NO_KSPLIT") == nullptr;   // (A/B swit
 static inline bool ksplit_plan(long long M, int K, int Nout, int num_cus, StreamPlan* sp) {
   if (!kKsplit || K <= 112 || K > 7 * 128 || M > kKsplitMaxRows || M < 16) return false;
   sp->kc = (K + 127) / 128;                // 16-wide K groups per wave
-  int nt = 8 / sp->kc;                     // B fragments of the wave's K slice in registers: KC * NT <= 8 quads
+  // B fragments of the wave's K slice in registers: KC * NT <= 8 quads; on the small maps (one workgroup per CU below: 256 registers)
+  // the long-K instances take 12 -- K = 480 / 672: three / two column tiles per wave, fewer column blocks re-reading A and fewer row
+  // groups per workgroup (round 6, same box: <6,1> 11.9 -> <6,2> 10.9 us, <4,2> 8.7 -> <4,3> 8.1 us, +0.25 % on the step; wider tiles
+  // for K <= 384 measured slower: <2,4> 5.3 -> <2,7> 8.0 us)
+  int nt = ((M <= 8192 && sp->kc >= 4) ? 12 : 8) / sp->kc;
   if (nt < 1) nt = 1;
   if (nt > 7) nt = 7;                      // (the 8 x 16 x (16 NT + 4) staging tile must stay below 64 KB of static LDS)
   const int tiles = (Nout + 15) / 16;

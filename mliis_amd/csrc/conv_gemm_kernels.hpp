@@ -1090,7 +1090,7 @@ __global__ __launch_bounds__(64 * kStreamWaves, 4) void conv1x1_stream_k(ConvGem
 #define KS_STAMP(k) do { } while (0)
 #endif
 template <int KC, int NT, int WV, int PREC>
-__global__ __launch_bounds__(64 * WV, KC <= 6 ? 4 : 2) void conv1x1_ksplit_k(ConvGemmParams p, int row_groups) {   // (KC <= 6: two workgroups per CU)
+__global__ __launch_bounds__(64 * WV, (KC <= 6 && KC * NT <= 8) ? 4 : 2) void conv1x1_ksplit_k(ConvGemmParams p, int row_groups) {   // (KC <= 6, KC NT <= 8: two workgroups per CU)
 #ifdef KS_DBG
   unsigned long long ks_st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
@@ -1633,7 +1633,8 @@ static void launch_gemm_t(const GemmPlan& g, const ConvGemmParams& p, hipStream_
 #undef NK
 }
 
-// conv1x1_ksplit_k instances: KC 16-wide K groups per wave (8 waves: K <= 128 KC), NT column tiles, KC * NT <= 8, NT <= 7
+// conv1x1_ksplit_k instances: KC 16-wide K groups per wave (8 waves: K <= 128 KC), NT column tiles, KC * NT <= 8, NT <= 7; and the
+// three instances with KC * NT = 12 that the planner takes on the small maps (one workgroup per CU there: 256 registers)
 template <int PREC>
 static bool launch_ksplit_t(int kc, int nt, dim3 grid, const ConvGemmParams& p, int row_groups, hipStream_t stream) {
   dim3 block(512);
@@ -1642,9 +1643,9 @@ static bool launch_ksplit_t(int kc, int nt, dim3 grid, const ConvGemmParams& p, 
     case 1: switch (nt) { case 1: S(1, 1) case 2: S(1, 2) case 3: S(1, 3) case 4: S(1, 4) case 5: S(1, 5) case 6: S(1, 6) case 7: S(1, 7) default: return false; } break;
     case 2: switch (nt) { case 1: S(2, 1) case 2: S(2, 2) case 3: S(2, 3) case 4: S(2, 4) default: return false; } break;
     case 3: switch (nt) { case 1: S(3, 1) case 2: S(3, 2) default: return false; } break;
-    case 4: switch (nt) { case 1: S(4, 1) case 2: S(4, 2) default: return false; } break;
-    case 5: switch (nt) { case 1: S(5, 1) default: return false; } break;
-    case 6: switch (nt) { case 1: S(6, 1) default: return false; } break;
+    case 4: switch (nt) { case 1: S(4, 1) case 2: S(4, 2) case 3: S(4, 3) default: return false; } break;
+    case 5: switch (nt) { case 1: S(5, 1) case 2: S(5, 2) default: return false; } break;
+    case 6: switch (nt) { case 1: S(6, 1) case 2: S(6, 2) default: return false; } break;
     case 7: switch (nt) { case 1: S(7, 1) default: return false; } break;
     default: return false;
   }
