@@ -665,6 +665,10 @@ class FilterBatch:
         tmf, nt, multitap, gx, gy, gz, rps = [int(v) for v in plan[:7]]
         if partial.numel() < gz * k * k * Cin * Cout:
             raise MliisError("FilterBatch: slab region too small")
+        remap = self.NT_REMAP.get((tmf, nt)) if not multitap else None
+        if remap is not None:   # run this problem with the column tiling of a neighbouring group: one launch fewer (the kernels mask n >= Cout)
+            nt = remap
+            gy = -(-Cout // (16 * nt))
         # (ksize word: bits 8 / 9 = X / dY stored as bf16 -- an expanded MBConv tensor under `--precision bf16-storage`)
         row = [x.data_ptr(), dy.data_ptr(), x_scale.data_ptr() if x_scale is not None else 0, partial.data_ptr(), ldx, lddy, N, H, W, Cin,
                Cout, k | (_dt(x) << 8) | (_dt(dy) << 9), dil, rps | (multitap << 32), gx | (gy << 20) | (gz << 40), 0]
@@ -672,6 +676,16 @@ class FilterBatch:
         self.flops = getattr(self, "flops", 0.0) + 2.0 * N * H * W * k * k * Cin * Cout
         self._keep += [x, dy, partial, x_scale]
         self.tables = None
+
+    # (tmf, nt) of a problem's own plan -> column tiles per workgroup it runs with in the batched launch.  The planner narrows the tiles of
+    # a problem until ITS grid fills the chip; in a batched launch the other problems' workgroups do that, and what narrow tiles cost is
+    # re-reads of the big operand (a project conv's X is read once per column block: 112 columns = four blocks of 32, two of 64) and a
+    # launch per tile width.  Round 6, same box, two alternations, whole step: as planned (seven native launches) 3547-3551; widths 3 and 6
+    # -> 4: 3572-3577; 2, 3, 6 -> 4 (four launches): 3584-3593; 1 too: 3583-3588; everything -> 6 / 7 / 8: 3528 / 3530 / 3513 (one
+    # workgroup per CU at those widths).  MLIIS_FB_MERGE="1:3=4,1:6=4" overrides the table, "-" empties it.
+    _FB = os.environ.get("MLIIS_FB_MERGE")
+    NT_REMAP = ({(1, 1): 4, (1, 2): 4, (1, 3): 4, (1, 6): 4} if _FB is None else
+                {(int(a.split(":")[0]), int(a.split(":")[1].split("=")[0])): int(a.split("=")[1]) for a in _FB.split(",") if a and a != "-"})
 
     # fp32x3 launches: 256-channel workgroup tiles for the problems with more than 128 input channels (MLIIS_X3_NARROW=1: round 5's 128)
     X3_WIDE = os.environ.get("MLIIS_X3_NARROW", "0") != "1"
