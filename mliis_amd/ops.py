@@ -665,37 +665,50 @@ class FilterBatch:
         tmf, nt, multitap, gx, gy, gz, rps = [int(v) for v in plan[:7]]
         if partial.numel() < gz * k * k * Cin * Cout:
             raise MliisError("FilterBatch: slab region too small")
-        remap = self.NT_REMAP.get((tmf, nt)) if not multitap else None
-        if remap is not None:   # run this problem with the column tiling of a neighbouring group: one launch fewer (the kernels mask n >= Cout)
-            nt = remap
-            gy = -(-Cout // (16 * nt))
         # (ksize word: bits 8 / 9 = X / dY stored as bf16 -- an expanded MBConv tensor under `--precision bf16-storage`)
         row = [x.data_ptr(), dy.data_ptr(), x_scale.data_ptr() if x_scale is not None else 0, partial.data_ptr(), ldx, lddy, N, H, W, Cin,
                Cout, k | (_dt(x) << 8) | (_dt(dy) << 9), dil, rps | (multitap << 32), gx | (gy << 20) | (gz << 40), 0]
-        self.groups.setdefault((tmf, nt, x_scale is not None), []).append((row, gx * gy * gz))
+        self.groups.setdefault((tmf, nt, x_scale is not None), []).append((row, gx * gy * gz, bool(multitap)))
         self.flops = getattr(self, "flops", 0.0) + 2.0 * N * H * W * k * k * Cin * Cout
         self._keep += [x, dy, partial, x_scale]
         self.tables = None
 
-    # (tmf, nt) of a problem's own plan -> column tiles per workgroup it runs with in the batched launch.  The planner narrows the tiles of
-    # a problem until ITS grid fills the chip; in a batched launch the other problems' workgroups do that, and what narrow tiles cost is
-    # re-reads of the big operand (a project conv's X is read once per column block: 112 columns = four blocks of 32, two of 64) and a
-    # launch per tile width.  Round 6, same box, two alternations, whole step: as planned (seven native launches) 3547-3551; widths 3 and 6
-    # -> 4: 3572-3577; 2, 3, 6 -> 4 (four launches): 3584-3593; 1 too: 3583-3588; everything -> 6 / 7 / 8: 3528 / 3530 / 3513 (one
-    # workgroup per CU at those widths).  MLIIS_FB_MERGE="1:3=4,1:6=4" overrides the table, "-" empties it.
-    _FB = os.environ.get("MLIIS_FB_MERGE")
-    NT_REMAP = ({(1, 1): 4, (1, 2): 4, (1, 3): 4, (1, 6): 4} if _FB is None else
-                {(int(a.split(":")[0]), int(a.split(":")[1].split("=")[0])): int(a.split("=")[1]) for a in _FB.split(",") if a and a != "-"})
+    # Small groups join the 64-column group.  The planner narrows the column tiles of a problem until ITS grid fills the chip; in a batched
+    # launch the other problems' workgroups do that, and every tile width that occurs is a launch of its own: EfficientLab-6-3 at N = 8 has
+    # seven native launches per step, four of them under 20 us.  A (64-channel-block, nt, gated) group with fewer than MERGE_MAX_BLOCKS
+    # workgroups is re-tiled to four column tiles (the kernels mask the columns beyond Cout; slabs, pixel splits and the fold are
+    # unchanged, results bit-identical) and rides in that group's launch.  Round 6, same box (profiles/r06_notes.md section 8): config 2
+    # as planned 3547, widths 3 and 6 re-tiled 3574, 2 too (four launches instead of seven) 3588 images/s; EfficientNet-B3 (its width-3
+    # group is thousands of workgroups of 48-column problems: padding them to 64 costs 2 %) 2079 as planned -- hence the size bound.
+    # MLIIS_FB_MERGE_MAX overrides the bound (0: off).
+    MERGE_MAX_BLOCKS = int(os.environ.get("MLIIS_FB_MERGE_MAX", "2500"))
 
     # fp32x3 launches: 256-channel workgroup tiles for the problems with more than 128 input channels (MLIIS_X3_NARROW=1: round 5's 128)
     X3_WIDE = os.environ.get("MLIIS_X3_NARROW", "0") != "1"
 
+    def _merged_groups(self):
+        groups = {k: list(v) for k, v in self.groups.items()}
+        for (tmf, nt, sc) in sorted(groups):
+            items = groups[(tmf, nt, sc)]
+            if not (tmf == 1 and nt in (1, 2, 3, 6) and items and not any(mt for _, _, mt in items) and
+                    sum(b for _, b, _ in items) < self.MERGE_MAX_BLOCKS):
+                continue
+            moved = []
+            for row, _, mt in items:
+                cout = row[10]
+                gx, gz = row[14] & 0xfffff, row[14] >> 40
+                gy = -(-cout // 64)
+                moved.append((row[:14] + [gx | (gy << 20) | (gz << 40), 0], gx * gy * gz, mt))
+            groups.setdefault((1, 4, sc), []).extend(moved)
+            del groups[(tmf, nt, sc)]
+        return groups
+
     def _build(self):
         self.tables = []
-        for (tmf, nt, sc), items in sorted(self.groups.items()):
+        for (tmf, nt, sc), items in sorted(self._merged_groups().items()):
             for i0 in range(0, len(items), 64):          # (the kernel scans at most 64 rows)
                 rows, first = [], 0
-                for row, blocks in items[i0:i0 + 64]:
+                for row, blocks, _ in items[i0:i0 + 64]:
                     rows.append(row[:15] + [first])
                     first += blocks
                 # the same problems tiled for conv_filter_x3_batched_k's 256-channel form (MLIIS_PREC_F32X3, TMF passed as 4): a problem with
@@ -703,7 +716,7 @@ class FilterBatch:
                 wide = None
                 if tmf == 2 and not sc and 4 <= nt <= 8 and self.X3_WIDE:
                     wrows, wfirst = [], 0
-                    for row, _ in items[i0:i0 + 64]:
+                    for row, _, _ in items[i0:i0 + 64]:
                         cin, kk, multitap = row[9], row[11] & 0xff, (row[13] >> 32) & 1
                         gx, gy, gz = row[14] & 0xfffff, (row[14] >> 20) & 0xfffff, row[14] >> 40
                         if not multitap and cin > 128:
@@ -720,7 +733,7 @@ class FilterBatch:
         if self.tables is None:
             self._build()
         prec = 3 if precision == "fp32x3" else _prec(precision)
-        if prec in (0, 3) and any((row[11] >> 8) for items in self.groups.values() for row, _ in items):
+        if prec in (0, 3) and any((row[11] >> 8) for items in self.groups.values() for row, _, _ in items):
             raise MliisError("FilterBatch: bf16 tensors need the bf16-operand instances (precision 'bf16')")
         def issue():
             for table, nprob, blocks, tmf, nt, sc, wide in self.tables:

@@ -1360,6 +1360,46 @@ def test_conv2d_bwd_filter_batched_equals_the_single_calls():
         assert torch.equal(pa, pb), i
 
 
+def test_small_filter_gradient_groups_join_the_64_column_launch(monkeypatch):
+    """FilterBatch re-tiles a (64-channel-block, 1 / 2 / 3 / 6 column tiles) group of fewer than MERGE_MAX_BLOCKS workgroups to four
+    column tiles so that it rides in that group's launch (profiles/r06_notes.md section 8): fewer launches, and every slab bit-identical
+    to the launch-per-width form -- output widths of 16, 24, 40, 96 and 144 columns (tile widths 1, 2, 3, 6, 3 of their own plans; the
+    kernels mask the columns beyond Cout), gated and ungated; a group above the bound keeps its own launch."""
+    from mliis_amd import ops
+    d = dev()
+    shapes = [(8, 28, 32, 16, True), (8, 28, 96, 24, True), (8, 28, 144, 40, True), (8, 28, 16, 96, False), (8, 28, 24, 144, False),
+              (8, 14, 240, 80, True), (8, 14, 80, 480, False), (4, 28, 24, 144, False)]
+    probs = []
+    for i, (N, H, Cin, Cout, gated) in enumerate(shapes):
+        x = f32(rnd(N, H, H, Cin, seed=600 + i), d)
+        dy = f32(rnd(N, H, H, Cout, seed=700 + i), d)
+        gate = f32(torch.sigmoid(rnd(N, Cin, seed=800 + i)), d) if gated else None
+        n = ops.lib.size("mliis_conv2d_bwd_filter_workspace_floats", N, H, H, Cin, Cout, 1)
+        probs.append((x, dy, gate, n))
+
+    def run(bound):
+        monkeypatch.setattr(ops.FilterBatch, "MERGE_MAX_BLOCKS", bound)
+        fb = ops.FilterBatch(d)
+        outs = []
+        for x, dy, gate, n in probs:
+            outs.append(torch.full((n,), float("nan"), device=d))
+            fb.add(x, dy, 1, 1, outs[-1], x_scale=gate)
+        fb.launch()
+        torch.cuda.synchronize()
+        return outs, [(t[3], t[4], t[5]) for t in fb.tables]
+
+    plain, launches_plain = run(0)
+    merged, launches_merged = run(2500)
+    assert len(launches_merged) < len(launches_plain), (launches_plain, launches_merged)
+    assert all(nt >= 4 or tmf != 1 for tmf, nt, _ in launches_merged), launches_merged
+    for i, (a, b) in enumerate(zip(plain, merged)):
+        assert not torch.isnan(a).any() and torch.equal(a, b), i
+    some, launches_some = run(200)      # (only the groups below 200 workgroups move)
+    assert len(launches_merged) <= len(launches_some) <= len(launches_plain)
+    for i, (a, b) in enumerate(zip(plain, some)):
+        assert torch.equal(a, b), i
+
+
 def test_conv1x1_ksplit_random_shapes():
     """conv1x1_ksplit_k (long-K 1x1 convs on small maps) over 28 seeded random shapes: K 113..896 (every KC 1..7, K tails), 16..32768
     rows (row-group tails, maps from 2x2 up), 8..240 output channels (column tails), with / without bias, SE gate on load, fused
